@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- u64 range-proof batch verification throughput on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the exact per-proof verify pipeline over one batch of synthetic proofs that is already
+resident in HBM (BASELINE.json configs[1]: 2^16 independent proofs per GPU, one shared generator set).  With N > 1
+(launched by torch.distributed.run, one rank per GPU) every rank verifies its own shard of different proofs (weak
+scaling, no data-path collective) and the per-step reject count is all-reduced over RCCL -- the single accept-reduce of
+BASELINE.json configs[2].
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel: algorithmic bytes per launch (559 B/verify) / its average launch
+                  duration, measured with HIP events on the launch stream inside the timed region, against 8 TB/s.
+  cpu_baseline -- the reference-shaped C restatement (oracle/, kind "port": the Rust reference cannot be built here)
+                  timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+ALGO_BYTES_PER_VERIFY = 13 * 33 + 3 * 32 + 33 + 1   # 559 B: SEC1 proof + commitment + accept byte
+HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--proofs-per-gpu", type=int, default=1 << 16)
+    ap.add_argument("--fb-window-bits", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="proofs verified by the CPU baseline (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the bp_pp_amd product path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import workload                                   # synthetic inputs (setup, untimed)
+    from bp_pp_amd import U64RangeProofProtocol
+
+    n = args.proofs_per_gpu
+    host_threads = max(1, (os.cpu_count() or 1) // max(1, world))
+    t0 = time.time()
+    gens, V, P, _ = workload.make_batch(n, first=rank * n, nthreads=host_threads)
+    P, expect = workload.corrupt(P, V, every=1024)
+    t_gen = time.time() - t0
+    g, gv, hv = workload.split_generators(gens)
+    t0 = time.time()
+    proto = U64RangeProofProtocol(g, gv, hv, device=local_rank, fb_window_bits=args.fb_window_bits)
+    t_ctx = time.time() - t0
+
+    dV = torch.from_numpy(V).cuda()
+    dP = torch.from_numpy(P).cuda()
+    dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    dS = torch.zeros(n, dtype=torch.int32, device="cuda")
+    dR = torch.zeros(1, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream()
+    proto.set_stream(stream.cuda_stream)
+
+    def step():
+        proto.verify_batch_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, dR.data_ptr())
+        if world > 1:
+            dist.all_reduce(dR, op=dist.ReduceOp.SUM)   # the single accept-reduce (4 bytes over RCCL/xGMI)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    proto.enable_timing(True)
+    proto.timings(reset=True)
+    fence()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    kernel_times = proto.timings(reset=True)
+    proto.enable_timing(False)
+
+    # correctness of what was just timed (untimed): accept bits == expectation, reject count == corrupted proofs
+    acc = dA.cpu().numpy()
+    st = dS.cpu().numpy()
+    ok_local = bool((acc == expect).all() and not st.any())
+    rejects = int(dR.item())
+    expected_rejects = int((expect == 0).sum()) * world
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    ok_all = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+    elapsed = float(t_max.item())
+    ok = bool(ok_all.item()) and rejects == expected_rejects
+
+    if rank == 0:
+        total = n * world * args.steps
+        value = total / elapsed
+        dom = max(kernel_times.items(), key=lambda kv: kv[1]["total_ms"])
+        dom_name, dom_t = dom
+        avg_ms = dom_t["total_ms"] / max(1, dom_t["launches"])
+        achieved = ALGO_BYTES_PER_VERIFY * n / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tr_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from the committed rocprofv3 --pmc run
+        if os.path.exists(tr_path):
+            try:
+                traffic = json.load(open(tr_path)).get(dom_name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "u64 range-proof batch verifies/sec",
+            "value": value,
+            "unit": "verifies/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"batch verify {n} independent u64 range proofs per GPU (BASELINE configs[1]), exact per-proof mode, "
+                            "shared generators, inputs resident in HBM, 1/1024 proofs corrupted",
+                "proofs_per_gpu": n,
+                "total_proofs_per_step": n * world,
+                "fb_window_bits": args.fb_window_bits or 16,
+                "label": workload.LABEL.decode(),
+                "parallelism": f"shard{world}" if world > 1 else "single",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom_name,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "avg_launch_ms": avg_ms,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_VERIFY * n,
+                "note": "256-bit modular integer path: VALU integer-multiply bound, HBM fraction is small by construction "
+                        "(SURVEY.md 8d); see DESIGN.md for the integer-op ceiling",
+            },
+            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kernel_times.items()},
+            "accept_bits_ok": ok,
+            "setup_s": {"proof_generation": t_gen, "context_tables": t_ctx},
+            "device_bytes": proto.device_bytes(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import bppp_oracle_c as OC                 # the oracle, as the timed CPU baseline ONLY
+            m = min(args.cpu_sample, n)
+            cores = os.cpu_count() or 1
+            t0 = time.perf_counter()
+            oacc, ost = OC.u64_verify_batch(gens, workload.LABEL, V[:m].copy(), P[:m].copy(), nthreads=cores)
+            dt = time.perf_counter() - t0
+            result["cpu_baseline"] = {
+                "value": m / dt,
+                "unit": "verifies/s",
+                "cores": cores,
+                "kind": "port",
+                "sample": f"first {m} proofs of the same batch, reference-shaped C restatement (oracle/bppp_ref.c), "
+                          f"{cores} host threads, {dt:.2f} s wall",
+                "agrees_with_gpu": bool((oacc == acc[:m]).all()),
+            }
+        print(json.dumps(result), flush=True)
+    proto.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

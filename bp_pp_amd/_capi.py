@@ -1,0 +1,65 @@
+"""ctypes binding of include/bppp.h (libbppp_hip.so).  No CPU fallback: loading or context creation fails loudly
+when the HIP extension or a gfx950 device is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+OK = 0
+ERR_NO_DEVICE, ERR_INVALID_ARG, ERR_HIP, ERR_ENCODING, ERR_NOMEM = -1, -2, -3, -4, -5
+ST_BAD_ENCODING, ST_DEGENERATE = 1, 2
+POINT_BYTES, SCALAR_BYTES, U64_PROOF_BYTES, U64_TRACE_BYTES = 64, 32, 928, 704
+
+# every symbol include/bppp.h declares (tests/test_capi_symbols.py checks the header against this list and the .so)
+EXPORTS = [
+    "bppp_ctx_create", "bppp_ctx_destroy", "bppp_ctx_set_stream", "bppp_u64_verify_batch", "bppp_u64_verify_batch_device",
+    "bppp_u64_commit_value_batch", "bppp_ctx_enable_timing", "bppp_ctx_get_timings", "bppp_ctx_device_bytes",
+    "bppp_strerror", "bppp_last_error",
+]
+
+_lib = None
+
+
+class BpppError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        msg = lib().bppp_strerror(code).decode() if _lib is not None else str(code)
+        super().__init__(f"bppp error {code}: {msg}" + (f" ({detail})" if detail else ""))
+
+
+def lib():
+    """Load libbppp_hip.so.  Import torch first when it is going to be used in the same process: both HIP runtimes carry
+    the soname libamdhip64.so.7, so whichever is loaded first serves both and device pointers stay interchangeable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_build.SO):
+        raise ImportError(f"{_build.SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the bp_pp_amd product path)")
+    L = C.CDLL(_build.SO)
+    vp, sz, i32, u8p = C.c_void_p, C.c_size_t, C.c_int, C.c_char_p
+    L.bppp_ctx_create.argtypes = [C.POINTER(vp), u8p, u8p, u8p, i32, i32]
+    L.bppp_ctx_create.restype = i32
+    L.bppp_ctx_destroy.argtypes = [vp]
+    L.bppp_ctx_destroy.restype = None
+    L.bppp_ctx_set_stream.argtypes = [vp, vp]
+    L.bppp_u64_verify_batch.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp]
+    L.bppp_u64_verify_batch_device.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, vp, vp]
+    L.bppp_u64_commit_value_batch.argtypes = [vp, sz, vp, vp, vp]
+    L.bppp_ctx_enable_timing.argtypes = [vp, i32]
+    L.bppp_ctx_get_timings.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
+    L.bppp_ctx_device_bytes.argtypes = [vp]
+    L.bppp_ctx_device_bytes.restype = sz
+    L.bppp_strerror.argtypes = [i32]
+    L.bppp_strerror.restype = C.c_char_p
+    L.bppp_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc < 0:
+        raise BpppError(rc, lib().bppp_last_error().decode())
+    return rc

@@ -1,0 +1,466 @@
+// libbppp_hip.so: HIP kernels (gfx950) + the C ABI of include/bppp.h.
+//
+// Host side of the batch u64 range-proof verifier: context (generators -> fixed-base tables in HBM), workspace,
+// stream, and the launch sequence of the exact per-proof pipeline.  The per-lane work is in verify_core.h.
+// One lane per proof; 64-thread workgroups (one wavefront) so that a 2^16-proof batch yields 1024 workgroups
+// (4 per CU) and no lane ever waits on a workgroup barrier -- there is no inter-lane communication in this pipeline.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/bppp.h"
+#include "verify_core.h"
+
+using namespace bppp;
+
+// ---------------------------------------------------------------- kernels
+#define BPPP_BLOCK 64
+
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1(VerifyWs ws) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_phase1(ws, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_fixed(VerifyWs ws) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_c0_fixed(ws, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var(VerifyWs ws) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_c0_var(ws, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round(VerifyWs ws, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_round(ws, t, k);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(VerifyWs ws) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_final_scalars(ws, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_check(VerifyWs ws, int* reject_count) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) {
+        verify_final_check(ws, t);
+        if (reject_count && !ws.accept[t]) atomicAdd(reject_count, 1);
+    }
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass1(FbBuild fb, size_t nthreads) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < nthreads) fb_build_pass1(fb, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass2(FbBuild fb, size_t nthreads) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < nthreads) fb_build_pass2(fb, t);
+}
+// generator decoding + validation (context creation): 64-B big-endian -> device affine; flags[0] |= 1 on a bad point
+__global__ void k_decode_generators(const uint8_t* in, apt* out, int n, int* flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    apt a;
+    if (!apt_from_xy64(a, in + 64 * i)) atomicOr(flags, 1);
+    out[i] = a;
+}
+// U64RangeProofProtocol::commit_value (u64_proof.rs:37-39): x*g + s*h_vec[0] through the fixed-base tables
+__global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(VerifyWs ws, const uint64_t* x, const uint8_t* s, uint8_t* out,
+                                                             int* flags) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= ws.N) return;
+    sc xs, ss;
+    sc_set_u64(xs, x[t]);
+    if (!sc_from_be(ss, s + 32 * t)) {
+        atomicOr(flags, 1);
+        sc_set_u32(ss, 0);
+    }
+    // scalars for bases 0 (g) and 17 (h_vec[0]) staged in the fsc scratch area, slots 0 and 1
+    ws_st8(ws.fsc, ws.N, t, 0, xs.v);
+    ws_st8(ws.fsc, ws.N, t, 1, ss.v);
+    pt acc;
+    pt_set_identity(acc);
+    fixed_base_msm(acc, ws, t, ws.fsc, 0, 0, 1);
+    fixed_base_msm(acc, ws, t, ws.fsc, 1, 17, 1);
+    apt a;
+    pt_to_affine(a, acc);
+    apt_to_xy64(out + 64 * t, a);
+}
+
+// ---------------------------------------------------------------- host side
+static thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+            return BPPP_ERR_HIP;                                                                       \
+        }                                                                                              \
+    } while (0)
+
+enum KernelId { K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"k_verify_phase1",        "k_verify_c0_fixed",   "k_verify_c0_var", "k_verify_round",
+                                                  "k_verify_final_scalars", "k_verify_final_check"};
+
+struct TimedLaunch { int id; hipEvent_t a, b; };
+
+struct bppp_ctx {
+    int device = 0;
+    int fb_w = 16;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    apt* d_gens = nullptr;       // 49
+    apt* d_table = nullptr;
+    size_t table_bytes = 0;
+    // per-proof workspace
+    size_t cap = 0;
+    u32* d_ws = nullptr;
+    size_t ws_bytes = 0;
+    pt* d_straus = nullptr;
+    size_t straus_bytes = 0;
+    // staging for the host-pointer entry points
+    uint8_t* d_stage = nullptr;
+    size_t stage_bytes = 0;
+    int* d_flags = nullptr;
+    bool timing = false;
+    std::vector<TimedLaunch> pending;
+    std::vector<hipEvent_t> event_pool;
+    double total_ms[K_COUNT] = {0};
+    int64_t launches[K_COUNT] = {0};
+};
+
+static const size_t WS_WORDS_PER_PROOF = 52 + 80 + 176 + 200 + 208 + 24 + 24 + 24 + 392;
+
+static int ensure_capacity(bppp_ctx* c, size_t n) {
+    if (n <= c->cap) return BPPP_OK;
+    if (c->d_ws) { (void)hipFree(c->d_ws); c->d_ws = nullptr; }
+    if (c->d_straus) { (void)hipFree(c->d_straus); c->d_straus = nullptr; }
+    c->cap = 0;
+    size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    c->ws_bytes = cap * WS_WORDS_PER_PROOF * sizeof(u32);
+    c->straus_bytes = cap * 5 * BPPP_STRAUS_ENTRIES * sizeof(pt);
+    HIP_TRY(hipMalloc(&c->d_ws, c->ws_bytes));
+    HIP_TRY(hipMalloc(&c->d_straus, c->straus_bytes));
+    c->cap = cap;
+    return BPPP_OK;
+}
+static int ensure_stage(bppp_ctx* c, size_t bytes) {
+    if (bytes <= c->stage_bytes) return BPPP_OK;
+    if (c->d_stage) { (void)hipFree(c->d_stage); c->d_stage = nullptr; c->stage_bytes = 0; }
+    HIP_TRY(hipMalloc(&c->d_stage, bytes));
+    c->stage_bytes = bytes;
+    return BPPP_OK;
+}
+// workspace carve-up: the SoA stride is the batch size n of THIS call (so lanes stay coalesced for any n <= cap)
+static void carve(bppp_ctx* c, VerifyWs& ws, size_t n) {
+    u32* p = c->d_ws;
+    ws.N = n;
+    ws.tstate = p; p += 52 * n;
+    ws.chal = p; p += 80 * n;
+    ws.sc0 = p; p += 176 * n;
+    ws.cvec = p; p += 200 * n;
+    ws.pts = p; p += 208 * n;
+    ws.lns = p; p += 24 * n;
+    ws.acc = p; p += 24 * n;
+    ws.pfix = p; p += 24 * n;
+    ws.fsc = p; p += 392 * n;
+    ws.straus = c->d_straus;
+    ws.fb_table = c->d_table;
+    ws.fb_w = c->fb_w;
+}
+
+template <typename F>
+static int timed(bppp_ctx* c, int id, F&& launch) {
+    if (!c->timing) {
+        launch();
+        return BPPP_OK;
+    }
+    auto get_event = [&](hipEvent_t& ev) -> hipError_t {
+        if (!c->event_pool.empty()) { ev = c->event_pool.back(); c->event_pool.pop_back(); return hipSuccess; }
+        return hipEventCreate(&ev);
+    };
+    TimedLaunch tl;
+    tl.id = id;
+    HIP_TRY(get_event(tl.a));
+    HIP_TRY(get_event(tl.b));
+    HIP_TRY(hipEventRecord(tl.a, c->stream));
+    launch();
+    HIP_TRY(hipEventRecord(tl.b, c->stream));
+    c->pending.push_back(tl);
+    return BPPP_OK;
+}
+static int drain_timings(bppp_ctx* c) {
+    if (c->pending.empty()) return BPPP_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto& tl : c->pending) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, tl.a, tl.b));
+        c->total_ms[tl.id] += ms;
+        c->launches[tl.id] += 1;
+        c->event_pool.push_back(tl.a);
+        c->event_pool.push_back(tl.b);
+    }
+    c->pending.clear();
+    return BPPP_OK;
+}
+
+static int check_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_last_error = std::string("no HIP device: ") + hipGetErrorString(e);
+        return BPPP_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        g_last_error = "device index out of range";
+        return BPPP_ERR_INVALID_ARG;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BPPP_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_last_error = std::string("this library is built for gfx950 only, found ") + prop.gcnArchName;
+        return BPPP_ERR_NO_DEVICE;
+    }
+    return BPPP_OK;
+}
+
+extern "C" {
+
+const char* bppp_strerror(int code) {
+    switch (code) {
+        case BPPP_OK: return "ok";
+        case BPPP_ERR_NO_DEVICE: return "no usable gfx950 HIP device (this library has no CPU fallback)";
+        case BPPP_ERR_INVALID_ARG: return "invalid argument";
+        case BPPP_ERR_HIP: return "HIP runtime error";
+        case BPPP_ERR_ENCODING: return "generator is not a valid secp256k1 point";
+        case BPPP_ERR_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+const char* bppp_last_error(void) { return g_last_error.c_str(); }
+
+int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, const uint8_t* h_vec, int device, int fb_window_bits) {
+    if (!out || !g || !g_vec || !h_vec) return BPPP_ERR_INVALID_ARG;
+    *out = nullptr;
+    int W = fb_window_bits ? fb_window_bits : 16;
+    if (W != 4 && W != 8 && W != 16) return BPPP_ERR_INVALID_ARG;
+    int rc = check_device(device);
+    if (rc != BPPP_OK) return rc;
+    HIP_TRY(hipSetDevice(device));
+    bppp_ctx* c = new (std::nothrow) bppp_ctx();
+    if (!c) return BPPP_ERR_NOMEM;
+    c->device = device;
+    c->fb_w = W;
+    auto fail = [&](int code) { bppp_ctx_destroy(c); return code; };
+#define HIP_TRY_C(expr)                                                             \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);       \
+            return fail(BPPP_ERR_HIP);                                              \
+        }                                                                           \
+    } while (0)
+    HIP_TRY_C(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY_C(hipMalloc(&c->d_gens, BPPP_NG * sizeof(apt)));
+    HIP_TRY_C(hipMalloc(&c->d_flags, sizeof(int)));
+    HIP_TRY_C(hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
+    // upload + decode generators
+    uint8_t hg[BPPP_NG * 64];
+    std::memcpy(hg, g, 64);
+    std::memcpy(hg + 64, g_vec, 16 * 64);
+    std::memcpy(hg + 17 * 64, h_vec, 32 * 64);
+    uint8_t* d_raw = nullptr;
+    HIP_TRY_C(hipMalloc(&d_raw, sizeof hg));
+    HIP_TRY_C(hipMemcpyAsync(d_raw, hg, sizeof hg, hipMemcpyHostToDevice, c->stream));
+    k_decode_generators<<<1, 64, 0, c->stream>>>(d_raw, c->d_gens, BPPP_NG, c->d_flags);
+    int flags = 0;
+    HIP_TRY_C(hipMemcpyAsync(&flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY_C(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_raw);
+    if (flags) return fail(BPPP_ERR_ENCODING);
+    // fixed-base tables
+    const int nwin = 256 / W;
+    const size_t per_win = ((size_t)1 << W) - 1;
+    const size_t entries = (size_t)BPPP_NG * nwin * per_win;
+    c->table_bytes = entries * sizeof(apt);
+    HIP_TRY_C(hipMalloc(&c->d_table, c->table_bytes));
+    fe *d_z = nullptr, *d_p = nullptr;
+    HIP_TRY_C(hipMalloc(&d_z, entries * sizeof(fe)));
+    HIP_TRY_C(hipMalloc(&d_p, entries * sizeof(fe)));
+    FbBuild fb{c->d_gens, BPPP_NG, W, c->d_table, d_z, d_p};
+    size_t nthreads = (size_t)BPPP_NG * nwin * fb_chunks_per_window(W);
+    unsigned blocks = (unsigned)((nthreads + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    k_fb_build_pass1<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
+    k_fb_build_pass2<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
+    HIP_TRY_C(hipGetLastError());
+    HIP_TRY_C(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_z);
+    (void)hipFree(d_p);
+#undef HIP_TRY_C
+    *out = c;
+    return BPPP_OK;
+}
+
+void bppp_ctx_destroy(bppp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& tl : c->pending) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); }
+    for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
+    if (c->d_gens) (void)hipFree(c->d_gens);
+    if (c->d_table) (void)hipFree(c->d_table);
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_straus) (void)hipFree(c->d_straus);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_flags) (void)hipFree(c->d_flags);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int bppp_ctx_set_stream(bppp_ctx* c, void* hip_stream) {
+    if (!c) return BPPP_ERR_INVALID_ARG;
+    int rc = drain_timings(c);
+    if (rc != BPPP_OK) return rc;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return BPPP_OK;
+}
+
+size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
+    if (!c) return 0;
+    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->stage_bytes + BPPP_NG * sizeof(apt);
+}
+
+int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
+    if (!c) return BPPP_ERR_INVALID_ARG;
+    int rc = drain_timings(c);
+    c->timing = enable != 0;
+    return rc;
+}
+int bppp_ctx_get_timings(bppp_ctx* c, int max_entries, const char** names, double* total_ms, int64_t* launches, int reset) {
+    if (!c) return BPPP_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    int rc = drain_timings(c);
+    if (rc != BPPP_OK) return rc;
+    int n = max_entries < K_COUNT ? max_entries : K_COUNT;
+    for (int i = 0; i < n; i++) {
+        if (names) names[i] = kKernelNames[i];
+        if (total_ms) total_ms[i] = c->total_ms[i];
+        if (launches) launches[i] = c->launches[i];
+    }
+    if (reset)
+        for (int i = 0; i < K_COUNT; i++) { c->total_ms[i] = 0; c->launches[i] = 0; }
+    return n;
+}
+
+int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
+                                 const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count) {
+    if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    VerifyWs ws;
+    std::memset(&ws, 0, sizeof ws);
+    carve(c, ws, n);
+    ws.commitments = (const uint8_t*)d_commitments;
+    ws.proofs = (const uint8_t*)d_proofs;
+    ws.accept = (uint8_t*)d_accept;
+    ws.trace = (uint8_t*)d_trace;
+    // per-proof status lives in caller memory when given, else in a spare corner of the staging buffer
+    if (d_status) ws.status = (int32_t*)d_status;
+    else {
+        rc = ensure_stage(c, c->cap * sizeof(int32_t));
+        if (rc != BPPP_OK) return rc;
+        ws.status = (int32_t*)c->d_stage;
+    }
+    t_new(ws.base, label, (u32)label_len);   // Transcript::new(label), shared by every proof of the batch
+    if (d_reject_count) HIP_TRY(hipMemsetAsync(d_reject_count, 0, sizeof(int), c->stream));
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    hipStream_t s = c->stream;
+#define LAUNCH(id, ...)                                         \
+    do {                                                        \
+        rc = timed(c, id, [&]() { __VA_ARGS__; });              \
+        if (rc != BPPP_OK) return rc;                           \
+    } while (0)
+    LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    LAUNCH(K_C0_FIXED, k_verify_c0_fixed<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    for (int k = 1; k <= 4; k++) LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+    LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
+#undef LAUNCH
+    HIP_TRY(hipGetLastError());
+    return BPPP_OK;
+}
+
+int bppp_u64_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                          const uint8_t* proofs, uint8_t* accept, int32_t* status) {
+    if (!c || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    // separate device buffers (the staging buffer may be used for status inside the device call)
+    uint8_t *d_c = nullptr, *d_p = nullptr, *d_a = nullptr;
+    int32_t* d_s = nullptr;
+    int rc = BPPP_OK;
+    auto cleanup = [&]() {
+        if (d_c) (void)hipFree(d_c);
+        if (d_p) (void)hipFree(d_p);
+        if (d_a) (void)hipFree(d_a);
+        if (d_s) (void)hipFree(d_s);
+    };
+#define HIP_TRY_V(expr)                                                             \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);       \
+            cleanup();                                                              \
+            return BPPP_ERR_HIP;                                                    \
+        }                                                                           \
+    } while (0)
+    HIP_TRY_V(hipMalloc(&d_c, n * 64));
+    HIP_TRY_V(hipMalloc(&d_p, n * (size_t)BPPP_U64_PROOF_BYTES));
+    HIP_TRY_V(hipMalloc(&d_a, n));
+    HIP_TRY_V(hipMalloc(&d_s, n * sizeof(int32_t)));
+    HIP_TRY_V(hipMemcpyAsync(d_c, commitments, n * 64, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY_V(hipMemcpyAsync(d_p, proofs, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, c->stream));
+    rc = bppp_u64_verify_batch_device(c, label, label_len, n, d_c, d_p, d_a, d_s, nullptr, nullptr);
+    if (rc == BPPP_OK) {
+        HIP_TRY_V(hipMemcpyAsync(accept, d_a, n, hipMemcpyDeviceToHost, c->stream));
+        if (status) HIP_TRY_V(hipMemcpyAsync(status, d_s, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY_V(hipStreamSynchronize(c->stream));
+    }
+#undef HIP_TRY_V
+    cleanup();
+    return rc;
+}
+
+int bppp_u64_commit_value_batch(bppp_ctx* c, size_t n, const uint64_t* x, const uint8_t* s, uint8_t* out) {
+    if (!c || !x || !s || !out) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    size_t need = n * 8 + n * 32 + n * 64;
+    rc = ensure_stage(c, need);
+    if (rc != BPPP_OK) return rc;
+    uint64_t* d_x = (uint64_t*)c->d_stage;
+    uint8_t* d_s = c->d_stage + n * 8;
+    uint8_t* d_o = d_s + n * 32;
+    VerifyWs ws;
+    std::memset(&ws, 0, sizeof ws);
+    carve(c, ws, n);
+    HIP_TRY(hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
+    HIP_TRY(hipMemcpyAsync(d_x, x, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_s, s, n * 32, hipMemcpyHostToDevice, c->stream));
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    k_commit_value<<<blocks, BPPP_BLOCK, 0, c->stream>>>(ws, d_x, d_s, d_o, c->d_flags);
+    HIP_TRY(hipGetLastError());
+    int flags = 0;
+    HIP_TRY(hipMemcpyAsync(out, d_o, n * 64, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return flags ? BPPP_ERR_INVALID_ARG : BPPP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// secp256k1 group operations for gfx950: homogeneous projective coordinates with the COMPLETE a = 0
+// formulas of Renes-Costello-Batina 2016 (algorithms 7, 8, 9; b3 = 3*7 = 21).
+//
+// Replaces k256 0.13.3 `ProjectivePoint::{add, sub, double, eq, to_affine, to_bytes}` as used by the
+// reference (util.rs:46-85, wnla.rs:66-102, circuit.rs:182-235, transcript.rs:6-8).  Complete formulas are
+// used on purpose: a verifier sees adversarial inputs (identity operands, P + P, P + (-P)) and the reference's
+// library handles all of them; they are also branch-free, so the 64 lanes of a wavefront never diverge.
+#pragma once
+#include "field.h"
+
+namespace bppp {
+
+struct pt { fe X, Y, Z; };   // (X : Y : Z), identity = (0 : 1 : 0)
+struct apt { fe x, y; };     // affine; (0, 0) is the identity sentinel (not on the curve: 0 != 7)
+
+HD void pt_set_identity(pt& r) {
+    fe_set_u32(r.X, 0);
+    fe_set_u32(r.Y, 1);
+    fe_set_u32(r.Z, 0);
+}
+HD bool pt_is_identity(const pt& p) { return fe_is_zero(p.Z); }
+HD bool apt_is_identity(const apt& a) { return fe_is_zero(a.x) & fe_is_zero(a.y); }
+HD void pt_from_affine(pt& r, const apt& a) {
+    bool id = apt_is_identity(a);
+    r.X = a.x;
+    r.Y = a.y;
+    fe_set_u32(r.Z, id ? 0u : 1u);
+    if (id) fe_set_u32(r.Y, 1);
+}
+HD void pt_cmov(pt& r, bool take, const pt& b) {
+    fe_cmov(r.X, take, b.X);
+    fe_cmov(r.Y, take, b.Y);
+    fe_cmov(r.Z, take, b.Z);
+}
+HD void pt_neg(pt& r, const pt& p) {
+    r.X = p.X;
+    fe_neg(r.Y, p.Y);
+    r.Z = p.Z;
+}
+HD void apt_neg(apt& r, const apt& p) {
+    r.x = p.x;
+    fe_neg(r.y, p.y);  // identity sentinel (0,0) stays (0,0)
+}
+
+// RCB16 algorithm 7: complete addition, 12M + 2 m(b3)
+HD void pt_add(pt& r, const pt& p, const pt& q) {
+    fe t0, t1, t2, t3, t4, X3, Y3, Z3;
+    fe_mul(t0, p.X, q.X);
+    fe_mul(t1, p.Y, q.Y);
+    fe_mul(t2, p.Z, q.Z);
+    fe_add(t3, p.X, p.Y);
+    fe_add(t4, q.X, q.Y);
+    fe_mul(t3, t3, t4);
+    fe_add(t4, t0, t1);
+    fe_sub(t3, t3, t4);
+    fe_add(t4, p.Y, p.Z);
+    fe_add(X3, q.Y, q.Z);
+    fe_mul(t4, t4, X3);
+    fe_add(X3, t1, t2);
+    fe_sub(t4, t4, X3);
+    fe_add(X3, p.X, p.Z);
+    fe_add(Y3, q.X, q.Z);
+    fe_mul(X3, X3, Y3);
+    fe_add(Y3, t0, t2);
+    fe_sub(Y3, X3, Y3);
+    fe_add(X3, t0, t0);
+    fe_add(t0, X3, t0);
+    fe_mul_small(t2, t2, 21);
+    fe_add(Z3, t1, t2);
+    fe_sub(t1, t1, t2);
+    fe_mul_small(Y3, Y3, 21);
+    fe_mul(X3, t4, Y3);
+    fe_mul(t2, t3, t1);
+    fe_sub(X3, t2, X3);
+    fe_mul(Y3, Y3, t0);
+    fe_mul(t1, t1, Z3);
+    fe_add(Y3, t1, Y3);
+    fe_mul(t0, t0, t3);
+    fe_mul(Z3, Z3, t4);
+    fe_add(Z3, Z3, t0);
+    r.X = X3; r.Y = Y3; r.Z = Z3;
+}
+// RCB16 algorithm 8: complete mixed addition (q affine, q != identity), 11M + 2 m(b3)
+HD void pt_madd_nonid(pt& r, const pt& p, const apt& q) {
+    fe t0, t1, t2, t3, t4, X3, Y3, Z3;
+    fe_mul(t0, p.X, q.x);
+    fe_mul(t1, p.Y, q.y);
+    fe_add(t3, q.x, q.y);
+    fe_add(t4, p.X, p.Y);
+    fe_mul(t3, t3, t4);
+    fe_add(t4, t0, t1);
+    fe_sub(t3, t3, t4);
+    fe_mul(t4, q.y, p.Z);
+    fe_add(t4, t4, p.Y);
+    fe_mul(Y3, q.x, p.Z);
+    fe_add(Y3, Y3, p.X);
+    fe_add(X3, t0, t0);
+    fe_add(t0, X3, t0);
+    fe_mul_small(t2, p.Z, 21);
+    fe_add(Z3, t1, t2);
+    fe_sub(t1, t1, t2);
+    fe_mul_small(Y3, Y3, 21);
+    fe_mul(X3, t4, Y3);
+    fe_mul(t2, t3, t1);
+    fe_sub(X3, t2, X3);
+    fe_mul(Y3, Y3, t0);
+    fe_mul(t1, t1, Z3);
+    fe_add(Y3, t1, Y3);
+    fe_mul(t0, t0, t3);
+    fe_mul(Z3, Z3, t4);
+    fe_add(Z3, Z3, t0);
+    r.X = X3; r.Y = Y3; r.Z = Z3;
+}
+// mixed addition that also accepts the identity sentinel / a skip flag (result = p when skipped)
+HD void pt_madd(pt& r, const pt& p, const apt& q, bool skip) {
+    pt s;
+    pt_madd_nonid(s, p, q);
+    bool keep = skip | apt_is_identity(q);
+    r = p;
+    pt_cmov(r, !keep, s);
+}
+// RCB16 algorithm 9: complete doubling, 6M + 2S + 1 m(b3)
+HD void pt_dbl(pt& r, const pt& p) {
+    fe t0, t1, t2, X3, Y3, Z3;
+    fe_sqr(t0, p.Y);
+    fe_add(Z3, t0, t0);
+    fe_add(Z3, Z3, Z3);
+    fe_add(Z3, Z3, Z3);
+    fe_mul(t1, p.Y, p.Z);
+    fe_sqr(t2, p.Z);
+    fe_mul_small(t2, t2, 21);
+    fe_mul(X3, t2, Z3);
+    fe_add(Y3, t0, t2);
+    fe_mul(Z3, t1, Z3);
+    fe_add(t1, t2, t2);
+    fe_add(t2, t1, t2);
+    fe_sub(t0, t0, t2);
+    fe_mul(Y3, t0, Y3);
+    fe_add(Y3, X3, Y3);
+    fe_mul(t1, p.X, p.Y);
+    fe_mul(X3, t0, t1);
+    fe_add(X3, X3, X3);
+    r.X = X3; r.Y = Y3; r.Z = Z3;
+}
+// projective-class equality (k256 `ProjectivePoint::eq`, used at wnla.rs:81)
+HD bool pt_eq(const pt& a, const pt& b) {
+    fe l, r;
+    fe_mul(l, a.X, b.Z);
+    fe_mul(r, b.X, a.Z);
+    bool ok = fe_eq(l, r);
+    fe_mul(l, a.Y, b.Z);
+    fe_mul(r, b.Y, a.Z);
+    return ok & fe_eq(l, r);
+}
+// k256 `to_affine`: one field inversion; identity -> (0, 0)
+HD void pt_to_affine(apt& r, const pt& p) {
+    fe zi;
+    fe_inv(zi, p.Z);  // 0 -> 0
+    fe_mul(r.x, p.X, zi);
+    fe_mul(r.y, p.Y, zi);
+}
+// y^2 == x^3 + 7 (identity sentinel accepted)
+HD bool apt_on_curve(const apt& a) {
+    fe y2, x3, seven;
+    fe_sqr(y2, a.y);
+    fe_sqr(x3, a.x);
+    fe_mul(x3, x3, a.x);
+    fe_set_u32(seven, 7);
+    fe_add(x3, x3, seven);
+    return fe_eq(y2, x3) | apt_is_identity(a);
+}
+// k256 GroupEncoding::to_bytes: 33-byte SEC1 compressed; identity -> 33 zero bytes (transcript.rs:7)
+HD void apt_to_sec1(uint8_t out[33], const apt& a) {
+    bool id = apt_is_identity(a);
+    out[0] = id ? 0 : (uint8_t)(2 + (a.y.v[0] & 1));
+    fe_to_be(out + 1, a.x);
+}
+// C-ABI point: 64 B affine big-endian x||y, identity = 64 zero bytes.  false if a coordinate is >= p or the
+// point is off the curve (k256 would never have produced such an AffinePoint).
+HD bool apt_from_xy64(apt& r, const uint8_t* b) {
+    bool ok = fe_from_be(r.x, b);
+    ok &= fe_from_be(r.y, b + 32);
+    ok &= apt_on_curve(r);
+    return ok;
+}
+HD void apt_to_xy64(uint8_t* b, const apt& a) {
+    fe_to_be(b, a.x);
+    fe_to_be(b + 32, a.y);
+}
+
+}  // namespace bppp

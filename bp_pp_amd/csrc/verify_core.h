@@ -1,0 +1,608 @@
+// Batch u64 range-proof verification, exact per-proof mode: the per-proof work of
+// `U64RangeProofProtocol::verify` (u64_proof.rs:42-54) -> `ReciprocalRangeProofProtocol::verify`
+// (reciprocal.rs:98-107) -> `ArithmeticCircuit::verify` (circuit.rs:154-256) -> `WeightNormLinearArgument::verify`
+// (wnla.rs:75-121), restructured for one lane per proof over a batch that shares one generator set.
+//
+// What is restructured (same group elements, same transcript bytes, same accept bit -- SURVEY.md 8a closed forms,
+// checked numerically against the dense reference-shaped oracle in tests/):
+//  * make_circuit + collect_c's dense 16x48 / 17x48 matrices (reciprocal.rs:150-214, circuit.rs:584-653) collapse to
+//    closed forms for pn_tau / ps_tau / c; the 256 recomputed inversions become ONE Fn inversion (Montgomery trick).
+//  * circuit.rs:206,230-235 (22 scalar multiplications) -> one 17-term fixed-base MSM over batch-shared tables plus
+//    one 5-point shared-doubling (Straus) multi-scalar multiplication.
+//  * each WNLA round's generator folding (wnla.rs:96-97, 68 scalar multiplications over 4 rounds) is NOT executed:
+//    folded generators only matter in the base case (wnla.rs:80-82), where they unroll to a 49-term fixed-base MSM
+//    over the ORIGINAL generators.  Only com_ = com + y*X + (y^2-1)*R (wnla.rs:100-102) runs per round, because the
+//    next challenge hashes it (wnla.rs:88).
+//
+// Data layout in HBM (workspace): structure-of-arrays, limb-major -- word (slot*8 + limb) of proof t sits at
+// base[(slot*8 + limb) * N + t], so a wavefront's 64 lanes read 256 contiguous bytes per load.
+#pragma once
+#include "merlin.h"
+#include "point.h"
+
+namespace bppp {
+
+enum : int32_t {
+    ST_OK = 0,
+    ST_BAD_ENCODING = 1,     // coordinate >= p, point off curve, scalar >= n (k256 deserialisation would have failed)
+    ST_DEGENERATE = 2,       // challenge >= n or a zero inverse: the reference panics on unwrap() here
+};
+
+#define BPPP_U64_PROOF_BYTES 928
+#define BPPP_NG 49            // g, g_vec[16], h_vec[32]
+#define BPPP_STRAUS_ENTRIES 9 // 0..8 times the point (signed 4-bit windows)
+
+// C0 MSM scalar slots (sc0): 0 ps_tau(g) | 1..16 pn_tau(g_vec) | 17 tau^-1 (c_s) | 18 -delta (c_o) | 19 tau (c_l) |
+//                            20 -tau^2 (c_r) | 21 2 tau^3 (V+r)
+// proof point slots (pts): 0 c_l | 1 c_r | 2 c_o | 3 c_s | 4..7 r[0..3] | 8..11 x[0..3] | 12 V+r
+// challenge slots (chal): 0 e | 1 rho | 2 lambda | 3 beta | 4 delta | 5 tau | 6..9 y1..y4
+struct VerifyWs {
+    size_t N;
+    const uint8_t* commitments;  // N x 64 (C-ABI layout)
+    const uint8_t* proofs;       // N x 928
+    uint8_t* accept;             // N
+    int32_t* status;             // N
+    uint8_t* trace;              // N x 704 or null
+    u32* tstate;                 // [52][N] transcript (STROBE) state
+    u32* chal;                   // [10*8][N]
+    u32* sc0;                    // [22*8][N]
+    u32* cvec;                   // [25*8][N]
+    u32* pts;                    // [13*16][N]
+    u32* lns;                    // [3*8][N]
+    u32* acc;                    // [24][N]
+    u32* pfix;                   // [24][N]
+    u32* fsc;                    // [49*8][N]
+    pt* straus;                  // [N][5][9]
+    const apt* fb_table;         // [49][nwin][2^W - 1]
+    int fb_w;                    // window bits: 4, 8 or 16
+    strobe base;                 // Transcript::new(label)
+};
+
+// ---------------------------------------------------------------- SoA access
+HD void ws_ld8(u32 r[8], const u32* base, size_t N, size_t t, int slot) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = base[(size_t)(slot * 8 + i) * N + t];
+}
+HD void ws_st8(u32* base, size_t N, size_t t, int slot, const u32 r[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) base[(size_t)(slot * 8 + i) * N + t] = r[i];
+}
+HD void ws_ld_apt(apt& a, const u32* base, size_t N, size_t t, int slot) {
+    ws_ld8(a.x.v, base, N, t, 2 * slot);
+    ws_ld8(a.y.v, base, N, t, 2 * slot + 1);
+}
+HD void ws_st_apt(u32* base, size_t N, size_t t, int slot, const apt& a) {
+    ws_st8(base, N, t, 2 * slot, a.x.v);
+    ws_st8(base, N, t, 2 * slot + 1, a.y.v);
+}
+HD void ws_ld_pt(pt& p, const u32* base, size_t N, size_t t) {
+    ws_ld8(p.X.v, base, N, t, 0);
+    ws_ld8(p.Y.v, base, N, t, 1);
+    ws_ld8(p.Z.v, base, N, t, 2);
+}
+HD void ws_st_pt(u32* base, size_t N, size_t t, const pt& p) {
+    ws_st8(base, N, t, 0, p.X.v);
+    ws_st8(base, N, t, 1, p.Y.v);
+    ws_st8(base, N, t, 2, p.Z.v);
+}
+HD void ws_ld_strobe(strobe& s, const u32* base, size_t N, size_t t) {
+#pragma unroll
+    for (int i = 0; i < 25; i++) s.st[i] = (u64)base[(size_t)(2 * i) * N + t] | ((u64)base[(size_t)(2 * i + 1) * N + t] << 32);
+    s.pos = base[(size_t)50 * N + t];
+    s.pos_begin = base[(size_t)51 * N + t];
+}
+HD void ws_st_strobe(u32* base, size_t N, size_t t, const strobe& s) {
+#pragma unroll
+    for (int i = 0; i < 25; i++) {
+        base[(size_t)(2 * i) * N + t] = (u32)s.st[i];
+        base[(size_t)(2 * i + 1) * N + t] = (u32)(s.st[i] >> 32);
+    }
+    base[(size_t)50 * N + t] = s.pos;
+    base[(size_t)51 * N + t] = s.pos_begin;
+}
+
+template <int L>
+HD void app_point(strobe& t, const char (&label)[L], const apt& a) {  // transcript.rs:6-8
+    uint8_t b[33];
+    apt_to_sec1(b, a);
+    t_append(t, label, b, 33);
+}
+
+// ---------------------------------------------------------------- fixed-base MSM over the batch-shared tables
+// table[(b * nwin + w) * (2^W - 1) + (d - 1)] = d * 2^(W w) * generator_b, affine (64 B); (0,0) = identity.
+// This is `vector_mul(points, scalars)` (util.rs:46-60) for points that are batch constants.
+HD void fixed_base_msm(pt& accp, const VerifyWs& ws, size_t t, const u32* scal, int first_slot, int first_base, int count) {
+    const int W = ws.fb_w;
+    const int nwin = 256 / W;
+    const u32 mask = (W == 32) ? 0xFFFFFFFFu : ((1u << W) - 1u);
+    const size_t per_win = (size_t)mask;
+    pt acc = accp;
+#pragma nounroll
+    for (int j = 0; j < count; j++) {
+        u32 k[8];
+        ws_ld8(k, scal, ws.N, t, first_slot + j);
+        const apt* tb = ws.fb_table + (size_t)(first_base + j) * nwin * per_win;
+#pragma nounroll
+        for (int w = 0; w < nwin; w++) {
+            int bit = w * W;
+            u32 limb = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) limb = (i == (bit >> 5)) ? k[i] : limb;
+            u32 d = (limb >> (bit & 31)) & mask;
+            size_t idx = (size_t)w * per_win + (d ? d - 1 : 0);
+            apt e = tb[idx];
+            pt_madd(acc, acc, e, d == 0);
+        }
+    }
+    accp = acc;
+}
+
+// ---------------------------------------------------------------- variable-base shared-doubling MSM (Straus), signed 4-bit windows
+// k = sum_{i<64} (nib_i(k') - 8) 16^i + c 16^64 with k' = k + 0x88..8 (mod 2^256), c = carry out; digits in [-8, 7].
+struct straus_scalar { u32 kp[8]; u32 top; };
+HD void straus_recode(straus_scalar& r, const sc& k) {
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += (u64)k.v[i] + 0x88888888u; r.kp[i] = (u32)c; c >>= 32; }
+    r.top = (u32)c;
+}
+// tbl[e] = e * P, e = 0..8 (P affine, may be the identity sentinel)
+HD void straus_build_table(pt* tbl, const apt& P) {
+    pt cur;
+    pt_set_identity(cur);
+    tbl[0] = cur;
+    pt_from_affine(cur, P);
+    tbl[1] = cur;
+#pragma nounroll
+    for (int e = 2; e <= 8; e++) {
+        pt src = tbl[(e & 1) ? e - 1 : e / 2];
+        pt d;
+        if (e & 1) pt_madd(d, src, P, false);   // loop counter: wave-uniform branch
+        else pt_dbl(d, src);
+        tbl[e] = d;
+    }
+}
+// acc = sum_j k_j * P_j using tables tbl[j*9 + e]; scalars recoded in rs[0..m)
+HD void straus_msm(pt& out, const pt* tbl, const straus_scalar* rs, int m) {
+    pt acc;
+    pt_set_identity(acc);
+    // top digit (0 or 1) for each scalar
+#pragma nounroll
+    for (int j = 0; j < m; j++) {
+        pt q = tbl[j * BPPP_STRAUS_ENTRIES + (rs[j].top ? 1 : 0)];
+        pt_add(acc, acc, q);
+    }
+#pragma nounroll
+    for (int i = 63; i >= 0; i--) {
+#pragma nounroll
+        for (int d = 0; d < 4; d++) pt_dbl(acc, acc);
+#pragma nounroll
+        for (int j = 0; j < m; j++) {
+            u32 limb = 0;
+#pragma unroll
+            for (int l = 0; l < 8; l++) limb = (l == (i >> 3)) ? rs[j].kp[l] : limb;
+            int dg = (int)((limb >> ((i & 7) * 4)) & 15) - 8;
+            int mag = dg < 0 ? -dg : dg;
+            pt q = tbl[j * BPPP_STRAUS_ENTRIES + mag];
+            fe ny;
+            fe_neg(ny, q.Y);
+            fe_cmov(q.Y, dg < 0, ny);
+            pt_add(acc, acc, q);
+        }
+    }
+    out = acc;
+}
+
+// ---------------------------------------------------------------- phase 1: decode, transcript up to tau, scalar derivation
+// reciprocal.rs:98-104 + circuit.rs:155-228 (closed forms of SURVEY.md 8a)
+HD void verify_phase1(const VerifyWs& ws, size_t t) {
+    const size_t N = ws.N;
+    int32_t status = ST_OK;
+    const uint8_t* pv = ws.commitments + 64 * t;
+    const uint8_t* pp = ws.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
+    apt V, P[13];
+    bool ok = apt_from_xy64(V, pv);
+#pragma nounroll
+    for (int i = 0; i < 13; i++) ok &= apt_from_xy64(P[i], pp + 64 * i);
+    sc l0, l1, n0;
+    ok &= sc_from_be(l0, pp + 832);
+    ok &= sc_from_be(l1, pp + 864);
+    ok &= sc_from_be(n0, pp + 896);
+    if (!ok) {
+        // keep control flow uniform: run on harmless values, the status forces accept = 0 at the end
+        status |= ST_BAD_ENCODING;
+        apt zero;
+        fe_set_u32(zero.x, 0);
+        fe_set_u32(zero.y, 0);
+        V = zero;
+#pragma nounroll
+        for (int i = 0; i < 13; i++) P[i] = zero;
+        sc_set_u32(l0, 0); sc_set_u32(l1, 0); sc_set_u32(n0, 0);
+    }
+    strobe tr = ws.base;
+    sc e, rho, lambda, beta, delta, tau;
+    app_point(tr, "reciprocal_commitment", V);                          // reciprocal.rs:99
+    bool cok = t_get_challenge(tr, "reciprocal_challenge", e);          // reciprocal.rs:100
+    // circuit_commitment = commitment + proof.r                         (reciprocal.rs:104)
+    apt Vr;
+    {
+        pt s;
+        pt_from_affine(s, V);
+        pt_madd(s, s, P[12], false);
+        pt_to_affine(Vr, s);
+    }
+    app_point(tr, "commitment_cl", P[0]);                                // circuit.rs:155-159
+    app_point(tr, "commitment_cr", P[1]);
+    app_point(tr, "commitment_co", P[2]);
+    app_point(tr, "commitment_v", Vr);
+    cok &= t_get_challenge(tr, "circuit_rho", rho);                      // circuit.rs:161-164
+    cok &= t_get_challenge(tr, "circuit_lambda", lambda);
+    cok &= t_get_challenge(tr, "circuit_beta", beta);
+    cok &= t_get_challenge(tr, "circuit_delta", delta);
+    app_point(tr, "commitment_cs", P[3]);                                // circuit.rs:189
+    cok &= t_get_challenge(tr, "circuit_tau", tau);                      // circuit.rs:191
+    if (!cok) {
+        status |= ST_DEGENERATE;
+        sc_set_u32(e, 1); sc_set_u32(rho, 1); sc_set_u32(lambda, 1); sc_set_u32(beta, 1); sc_set_u32(delta, 1); sc_set_u32(tau, 1);
+    }
+    ws_st_strobe(ws.tstate, N, t, tr);
+    ws_st8(ws.chal, N, t, 0, e.v); ws_st8(ws.chal, N, t, 1, rho.v); ws_st8(ws.chal, N, t, 2, lambda.v);
+    ws_st8(ws.chal, N, t, 3, beta.v); ws_st8(ws.chal, N, t, 4, delta.v); ws_st8(ws.chal, N, t, 5, tau.v);
+#pragma nounroll
+    for (int i = 0; i < 12; i++) ws_st_apt(ws.pts, N, t, i, P[i]);
+    ws_st_apt(ws.pts, N, t, 12, Vr);
+    ws_st8(ws.lns, N, t, 0, l0.v); ws_st8(ws.lns, N, t, 1, l1.v); ws_st8(ws.lns, N, t, 2, n0.v);
+
+    // ---- scalars.  One Fn inversion for {mu, tau, e+0..e+15} (the reference: util.rs:119, circuit.rs:192, reciprocal.rs:181 x256)
+    sc mu;
+    sc_mul(mu, rho, rho);                                                // circuit.rs:166
+    sc a[18], pre[18];
+    a[0] = mu;
+    a[1] = tau;
+#pragma nounroll
+    for (int j = 0; j < 16; j++) {
+        sc js;
+        sc_set_u32(js, (u32)j);
+        sc_add(a[2 + j], e, js);
+    }
+    bool zero_inv = sc_is_zero(delta);                                   // circuit.rs:196 unwraps delta^-1 although u64 never uses it
+    sc one;
+    sc_set_u32(one, 1);
+#pragma nounroll
+    for (int i = 0; i < 18; i++) {
+        bool z = sc_is_zero(a[i]);
+        zero_inv |= z;
+        if (z) a[i] = one;
+        if (i == 0) pre[0] = a[0];
+        else sc_mul(pre[i], pre[i - 1], a[i]);
+    }
+    if (zero_inv) status |= ST_DEGENERATE;
+    sc inv;
+    sc_inv(inv, pre[17]);
+#pragma nounroll
+    for (int i = 17; i >= 1; i--) {
+        sc ai;
+        sc_mul(ai, inv, pre[i - 1]);
+        sc_mul(inv, inv, a[i]);
+        a[i] = ai;
+    }
+    a[0] = inv;  // a[] now holds the inverses: mu^-1, tau^-1, (e+j)^-1
+    sc mu_inv = a[0], tau_inv = a[1];
+    sc tau2, tau3, S, t1, t2;
+    sc_mul(tau2, tau, tau);
+    sc_mul(tau3, tau2, tau);
+    // S = sum_{i=1..16} lambda^i ; musum = sum_{i=1..16} mu^i
+    sc lp = lambda, mp = mu, musum;
+    S = lambda;
+    musum = mu;
+#pragma nounroll
+    for (int i = 1; i < 16; i++) {
+        sc_mul(lp, lp, lambda);
+        sc_add(S, S, lp);
+        sc_mul(mp, mp, mu);
+        sc_add(musum, musum, mp);
+    }
+    sc tau_e, two_tau2_S, ps;
+    sc_mul(tau_e, tau, e);
+    sc_mul(two_tau2_S, tau2, S);
+    sc_add(two_tau2_S, two_tau2_S, two_tau2_S);
+    sc_set_u32(ps, 0);
+    sc mip = mu_inv;   // mu^-(j+1)
+    lp = lambda;       // lambda^(j+1)
+    mp = mu;           // mu^(j+1)
+#pragma nounroll
+    for (int j = 0; j < 16; j++) {
+        // pn_tau[j] = mu^-(j+1) (tau^2 16^j + tau (S - lambda^(j+1))) + tau e          (circuit.rs:198-200)
+        sc p16, pn;
+        sc_set_u64(p16, (u64)1 << (4 * j));
+        sc_mul(t1, tau2, p16);
+        sc_sub(t2, S, lp);
+        sc_mul(t2, t2, tau);
+        sc_add(t1, t1, t2);
+        sc_mul(pn, t1, mip);
+        sc_add(pn, pn, tau_e);
+        ws_st8(ws.sc0, N, t, 1 + j, pn.v);
+        // ps_tau += mu^(j+1) pn^2                                                       (circuit.rs:202)
+        sc_mul(t1, pn, pn);
+        sc_mul(t1, t1, mp);
+        sc_add(ps, ps, t1);
+        // cl_tau[j] = 2 tau^2 S (e+j)^-1 - lambda^(j+1)                                 (circuit.rs:222-226)
+        sc_mul(t1, two_tau2_S, a[2 + j]);
+        sc_sub(t1, t1, lp);
+        ws_st8(ws.cvec, N, t, 9 + j, t1.v);
+        sc_mul(mip, mip, mu_inv);
+        sc_mul(lp, lp, lambda);
+        sc_mul(mp, mp, mu);
+    }
+    // ps_tau -= 2 tau^3 sum mu^i   (a_l = 0, a_m = 1s; circuit.rs:203-204)
+    sc two_tau3;
+    sc_add(two_tau3, tau3, tau3);
+    sc_mul(t1, two_tau3, musum);
+    sc_sub(ps, ps, t1);
+    ws_st8(ws.sc0, N, t, 0, ps.v);
+    ws_st8(ws.sc0, N, t, 17, tau_inv.v);
+    sc_neg(t1, delta);
+    ws_st8(ws.sc0, N, t, 18, t1.v);
+    ws_st8(ws.sc0, N, t, 19, tau.v);
+    sc_neg(t1, tau2);
+    ws_st8(ws.sc0, N, t, 20, t1.v);
+    ws_st8(ws.sc0, N, t, 21, two_tau3.v);   // v_ = 2 (V + r), times tau^3 (circuit.rs:182-187,235)
+    // cr_tau = [1, beta/tau, beta tau, ..., beta tau^7]                                  (circuit.rs:208-218)
+    ws_st8(ws.cvec, N, t, 0, one.v);
+    sc_mul(t1, beta, tau_inv);
+    ws_st8(ws.cvec, N, t, 1, t1.v);
+    sc bt = beta;
+#pragma nounroll
+    for (int i = 2; i < 9; i++) {
+        sc_mul(bt, bt, tau);
+        ws_st8(ws.cvec, N, t, i, bt.v);
+    }
+    ws.status[t] = status;
+    if (ws.trace) {
+        uint8_t* tb = ws.trace + 704 * t;
+        sc_to_be(tb, e); sc_to_be(tb + 32, rho); sc_to_be(tb + 64, lambda); sc_to_be(tb + 96, beta);
+        sc_to_be(tb + 128, delta); sc_to_be(tb + 160, tau);
+        apt_to_xy64(tb + 320, Vr);
+    }
+}
+
+// ---------------------------------------------------------------- phase 2a: C0 fixed-base part: ps_tau*g + <g_vec, pn_tau>  (circuit.rs:206)
+HD void verify_c0_fixed(const VerifyWs& ws, size_t t) {
+    pt acc;
+    pt_set_identity(acc);
+    fixed_base_msm(acc, ws, t, ws.sc0, 0, 0, 17);
+    ws_st_pt(ws.pfix, ws.N, t, acc);
+}
+// ---------------------------------------------------------------- phase 2b: C0 variable-base part (circuit.rs:230-235) + pfix
+HD void verify_c0_var(const VerifyWs& ws, size_t t) {
+    const size_t N = ws.N;
+    pt* tbl = ws.straus + t * (5 * BPPP_STRAUS_ENTRIES);
+    straus_scalar rs[5];
+    const int pslot[5] = {3, 2, 0, 1, 12};  // c_s, c_o, c_l, c_r, V+r  <->  sc0 slots 17..21
+#pragma nounroll
+    for (int j = 0; j < 5; j++) {
+        apt P;
+        ws_ld_apt(P, ws.pts, N, t, pslot[j]);
+        straus_build_table(tbl + j * BPPP_STRAUS_ENTRIES, P);
+        sc k;
+        ws_ld8(k.v, ws.sc0, N, t, 17 + j);
+        straus_recode(rs[j], k);
+    }
+    pt acc, pf;
+    straus_msm(acc, tbl, rs, 5);
+    ws_ld_pt(pf, ws.pfix, N, t);
+    pt_add(acc, acc, pf);
+    ws_st_pt(ws.acc, N, t, acc);
+}
+// ---------------------------------------------------------------- phase 3 (k = 1..4): one WNLA round (wnla.rs:84-102)
+HD void verify_round(const VerifyWs& ws, size_t t, int k) {
+    const size_t N = ws.N;
+    pt C;
+    ws_ld_pt(C, ws.acc, N, t);
+    apt Ca, X, R;
+    pt_to_affine(Ca, C);
+    ws_ld_apt(X, ws.pts, N, t, 8 + (4 - k));   // proof.x.last()
+    ws_ld_apt(R, ws.pts, N, t, 4 + (4 - k));   // proof.r.last()
+    strobe tr;
+    ws_ld_strobe(tr, ws.tstate, N, t);
+    app_point(tr, "wnla_com", Ca);                                       // wnla.rs:88-92
+    app_point(tr, "wnla_x", X);
+    app_point(tr, "wnla_r", R);
+    t_append_u64(tr, "l.sz", (u64)(32 >> (k - 1)));
+    t_append_u64(tr, "n.sz", (u64)(16 >> (k - 1)));
+    sc y;
+    bool cok = t_get_challenge(tr, "wnla_challenge", y);                 // wnla.rs:94
+    if (!cok) {
+        ws.status[t] |= ST_DEGENERATE;
+        sc_set_u32(y, 1);
+    }
+    ws_st_strobe(ws.tstate, N, t, tr);
+    ws_st8(ws.chal, N, t, 5 + k, y.v);
+    if (ws.trace) {
+        uint8_t* tb = ws.trace + 704 * t;
+        sc_to_be(tb + 32 * (5 + k), y);
+        apt_to_xy64(tb + 320 + 64 * k, Ca);
+    }
+    // com_ = com + y X + (y^2 - 1) R                                     (wnla.rs:100-102)
+    sc y2m1, one;
+    sc_set_u32(one, 1);
+    sc_mul(y2m1, y, y);
+    sc_sub(y2m1, y2m1, one);
+    pt* tbl = ws.straus + t * (5 * BPPP_STRAUS_ENTRIES);
+    straus_scalar rs[2];
+    straus_build_table(tbl, X);
+    straus_build_table(tbl + BPPP_STRAUS_ENTRIES, R);
+    straus_recode(rs[0], y);
+    straus_recode(rs[1], y2m1);
+    pt acc;
+    straus_msm(acc, tbl, rs, 2);
+    pt_madd(acc, acc, Ca, false);
+    ws_st_pt(ws.acc, N, t, acc);
+}
+// ---------------------------------------------------------------- phase 4: base case (wnla.rs:80-82 with :66-72), generators unrolled
+HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
+    const size_t N = ws.N;
+    sc rho, y[4], rk[4], l0, l1, n0;
+    ws_ld8(rho.v, ws.chal, N, t, 1);
+#pragma nounroll
+    for (int k = 0; k < 4; k++) ws_ld8(y[k].v, ws.chal, N, t, 6 + k);
+    ws_ld8(l0.v, ws.lns, N, t, 0);
+    ws_ld8(l1.v, ws.lns, N, t, 1);
+    ws_ld8(n0.v, ws.lns, N, t, 2);
+    // rho_1 = rho, rho_{k+1} = mu_k, mu_{k+1} = mu_k^2 (wnla.rs:109-110): rho_k = rho^(2^(k-1)); final mu = rho^32
+    rk[0] = rho;
+#pragma nounroll
+    for (int k = 1; k < 4; k++) sc_mul(rk[k], rk[k - 1], rk[k - 1]);
+    sc mu5;
+    sc_mul(mu5, rk[3], rk[3]);
+    sc_mul(mu5, mu5, mu5);
+    // ch[b] = prod_{k: bit k of b} y_{k+1}        (h_vec / c folding, wnla.rs:96,98 unrolled)
+    // cg[b] = prod_k (bit k of b ? y_{k+1} : rho_{k+1})   (g_vec folding, wnla.rs:97 unrolled)
+    sc ch[16], cg[16];
+    sc_set_u32(ch[0], 1);
+    sc_set_u32(cg[0], 1);
+#pragma nounroll
+    for (int k = 0; k < 4; k++) {
+        int half = 1 << k;
+#pragma nounroll
+        for (int b = 0; b < half; b++) {
+            sc_mul(ch[b + half], ch[b], y[k]);
+            sc_mul(cg[b + half], cg[b], y[k]);
+            sc_mul(cg[b], cg[b], rk[k]);
+        }
+    }
+    // c'_0, c'_1 = folded c (c[25..31] = 0)
+    sc c0f, c1f, tmp, cv;
+    sc_set_u32(c0f, 0);
+    sc_set_u32(c1f, 0);
+#pragma nounroll
+    for (int i = 0; i < 25; i++) {
+        ws_ld8(cv.v, ws.cvec, N, t, i);
+        sc_mul(tmp, cv, ch[i & 15]);
+        if (i < 16) sc_add(c0f, c0f, tmp);
+        else sc_add(c1f, c1f, tmp);
+    }
+    // v = <c', l> + n0^2 mu'   (wnla.rs:67 with weight_vector_mul exponent 1, util.rs:28-44)
+    sc v, w;
+    sc_mul(v, c0f, l0);
+    sc_mul(w, c1f, l1);
+    sc_add(v, v, w);
+    sc_mul(w, n0, n0);
+    sc_mul(w, w, mu5);
+    sc_add(v, v, w);
+    ws_st8(ws.fsc, N, t, 0, v.v);
+#pragma nounroll
+    for (int i = 0; i < 16; i++) {
+        sc_mul(tmp, n0, cg[i]);
+        ws_st8(ws.fsc, N, t, 1 + i, tmp.v);
+    }
+#pragma nounroll
+    for (int i = 0; i < 32; i++) {
+        sc_mul(tmp, (i < 16) ? l0 : l1, ch[i & 15]);
+        ws_st8(ws.fsc, N, t, 17 + i, tmp.v);
+    }
+}
+HD void verify_final_check(const VerifyWs& ws, size_t t) {
+    const size_t N = ws.N;
+    pt rhs, C;
+    pt_set_identity(rhs);
+    fixed_base_msm(rhs, ws, t, ws.fsc, 0, 0, BPPP_NG);
+    ws_ld_pt(C, ws.acc, N, t);
+    bool eq = pt_eq(C, rhs);                                             // wnla.rs:81
+    ws.accept[t] = (eq && ws.status[t] == ST_OK) ? 1 : 0;
+    if (ws.trace) {
+        apt Ca;
+        pt_to_affine(Ca, C);
+        apt_to_xy64(ws.trace + 704 * t + 320 + 64 * 5, Ca);
+    }
+}
+
+// ---------------------------------------------------------------- fixed-base table construction (context creation)
+// Pass 1: thread (b, w, chunk c) writes projective d * 2^(W w) * G_b for d in (c*CH, (c+1)*CH] into X/Y (table slots) and Z (ztmp).
+// Pass 2: same thread batch-inverts its Z's (Montgomery trick) and normalises the slots to affine.
+#define BPPP_FB_CHUNK 256
+struct FbBuild {
+    const apt* gens;   // [nbases]
+    int nbases, W;
+    apt* table;        // [nbases][nwin][2^W - 1]
+    fe* ztmp;          // same count
+    fe* ptmp;          // same count (prefix products)
+};
+HD size_t fb_chunks_per_window(int W) { return (((size_t)1 << W) - 1 + BPPP_FB_CHUNK - 1) / BPPP_FB_CHUNK; }
+HD void fb_build_pass1(const FbBuild& fb, size_t tid) {
+    const int nwin = 256 / fb.W;
+    const size_t per_win = ((size_t)1 << fb.W) - 1;
+    const size_t cpw = fb_chunks_per_window(fb.W);
+    size_t c = tid % cpw;
+    size_t w = (tid / cpw) % nwin;
+    size_t b = tid / (cpw * nwin);
+    if (b >= (size_t)fb.nbases) return;
+    apt G = fb.gens[b];
+    pt base;
+    pt_from_affine(base, G);
+#pragma nounroll
+    for (size_t i = 0; i < w * (size_t)fb.W; i++) pt_dbl(base, base);
+    // start = (c*CH + 1) * base by double-and-add over the (<= 17-bit) multiplier
+    u32 m = (u32)(c * BPPP_FB_CHUNK + 1);
+    pt cur;
+    pt_set_identity(cur);
+#pragma nounroll
+    for (int bit = 16; bit >= 0; bit--) {
+        pt_dbl(cur, cur);
+        pt s;
+        pt_add(s, cur, base);
+        pt_cmov(cur, (m >> bit) & 1, s);
+    }
+    size_t d0 = c * BPPP_FB_CHUNK;   // entries d0+1 .. min(d0+CH, per_win)
+    size_t off = (b * nwin + w) * per_win;
+#pragma nounroll
+    for (size_t i = 0; i < BPPP_FB_CHUNK && d0 + i < per_win; i++) {
+        apt xy;
+        xy.x = cur.X;
+        xy.y = cur.Y;
+        fb.table[off + d0 + i] = xy;
+        fb.ztmp[off + d0 + i] = cur.Z;
+        pt_add(cur, cur, base);
+    }
+}
+HD void fb_build_pass2(const FbBuild& fb, size_t tid) {
+    const int nwin = 256 / fb.W;
+    const size_t per_win = ((size_t)1 << fb.W) - 1;
+    const size_t cpw = fb_chunks_per_window(fb.W);
+    size_t c = tid % cpw;
+    size_t w = (tid / cpw) % nwin;
+    size_t b = tid / (cpw * nwin);
+    if (b >= (size_t)fb.nbases) return;
+    size_t d0 = c * BPPP_FB_CHUNK;
+    size_t off = (b * nwin + w) * per_win + d0;
+    size_t cnt = per_win - d0 < BPPP_FB_CHUNK ? per_win - d0 : BPPP_FB_CHUNK;
+    // identity entries (Z = 0; only when the generator itself is the identity) are skipped in the product
+    fe run;
+    fe_set_u32(run, 1);
+#pragma nounroll
+    for (size_t i = 0; i < cnt; i++) {
+        fe z = fb.ztmp[off + i];
+        fb.ptmp[off + i] = run;
+        fe m;
+        fe_mul(m, run, z);
+        fe_cmov(run, !fe_is_zero(z), m);
+    }
+    fe inv;
+    fe_inv(inv, run);
+#pragma nounroll
+    for (size_t i = cnt; i-- > 0;) {
+        fe z = fb.ztmp[off + i];
+        bool id = fe_is_zero(z);
+        fe zi, m;
+        fe_mul(zi, inv, fb.ptmp[off + i]);
+        fe_mul(m, inv, z);
+        fe_cmov(inv, !id, m);
+        apt xy = fb.table[off + i];
+        fe_mul(xy.x, xy.x, zi);
+        fe_mul(xy.y, xy.y, zi);
+        if (id) { fe_set_u32(xy.x, 0); fe_set_u32(xy.y, 0); }
+        fb.table[off + i] = xy;
+    }
+}
+
+}  // namespace bppp

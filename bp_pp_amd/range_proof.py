@@ -1,0 +1,107 @@
+"""Host-side mirror of the reference's `range_proof::u64_proof::U64RangeProofProtocol` (u64_proof.rs:19-82) over the
+C ABI of include/bppp.h, batch-first: one call verifies n independent proofs on one MI355X.
+
+Differences from the Rust signatures, forced by the C boundary (see INTEGRATION.md for the Rust facade that hides them):
+  * points are 64-byte affine big-endian x||y (identity = 64 zero bytes), scalars 32-byte big-endian;
+  * `t: &mut Transcript` becomes `label: bytes` -- every reference call site creates `Transcript::new(label)`
+    immediately before verify/prove (tests.rs:34,40; benches/range_proof.rs:32,47);
+  * verify returns the accept bits AND a per-proof status where the reference would have panicked.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _capi
+
+G_VEC_FULL_SZ = 16      # u64_proof.rs:12
+H_VEC_CIRCUIT_SZ = 26   # u64_proof.rs:13
+H_VEC_FULL_SZ = 32      # u64_proof.rs:14
+U64_PROOF_BYTES = _capi.U64_PROOF_BYTES
+
+
+def _as_u8(a, shape) -> np.ndarray:
+    arr = np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8) if isinstance(a, (bytes, bytearray)) else a, dtype=np.uint8)
+    return arr.reshape(shape)
+
+
+class U64RangeProofProtocol:
+    """Public parameters g, g_vec[16], h_vec[32] (u64_proof.rs:19-28) resident on one GPU."""
+
+    DIM_ND = 16
+    DIM_NP = 16
+
+    def __init__(self, g: bytes, g_vec: Sequence[bytes], h_vec: Sequence[bytes], device: int = 0, fb_window_bits: int = 0):
+        if len(g_vec) != G_VEC_FULL_SZ or len(h_vec) != H_VEC_FULL_SZ:
+            raise ValueError("g_vec must hold 16 points and h_vec 32 points")
+        self.g, self.g_vec, self.h_vec = bytes(g), [bytes(p) for p in g_vec], [bytes(p) for p in h_vec]
+        self.device = device
+        self._ctx = C.c_void_p()
+        _capi.check(_capi.lib().bppp_ctx_create(C.byref(self._ctx), self.g, b"".join(self.g_vec), b"".join(self.h_vec),
+                                                device, fb_window_bits))
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            _capi.lib().bppp_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- commit_value (u64_proof.rs:37-39)
+    def commit_value(self, x: int, s: bytes) -> bytes:
+        return bytes(self.commit_value_batch(np.array([x], dtype=np.uint64), _as_u8(s, (1, 32)))[0])
+
+    def commit_value_batch(self, x: np.ndarray, s: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        n = x.shape[0]
+        s = _as_u8(s, (n, 32))
+        out = np.zeros((n, 64), dtype=np.uint8)
+        _capi.check(_capi.lib().bppp_u64_commit_value_batch(self._ctx, n, x.ctypes.data, s.ctypes.data, out.ctypes.data))
+        return out
+
+    # ---- verify (u64_proof.rs:42-54)
+    def verify(self, v: bytes, proof: bytes, label: bytes) -> bool:
+        acc, _ = self.verify_batch(_as_u8(v, (1, 64)), _as_u8(proof, (1, U64_PROOF_BYTES)), label)
+        return bool(acc[0])
+
+    def verify_batch(self, commitments, proofs, label: bytes) -> Tuple[np.ndarray, np.ndarray]:
+        """Host buffers in, host buffers out.  Returns (accept[n] u8, status[n] i32)."""
+        commitments = _as_u8(commitments, (-1, 64))
+        n = commitments.shape[0]
+        proofs = _as_u8(proofs, (n, U64_PROOF_BYTES))
+        accept = np.zeros(n, dtype=np.uint8)
+        status = np.zeros(n, dtype=np.int32)
+        _capi.check(_capi.lib().bppp_u64_verify_batch(self._ctx, label, len(label), n, commitments.ctypes.data,
+                                                      proofs.ctypes.data, accept.ctypes.data, status.ctypes.data))
+        return accept, status
+
+    def verify_batch_device(self, label: bytes, n: int, d_commitments: int, d_proofs: int, d_accept: int,
+                            d_status: int = 0, d_trace: int = 0, d_reject_count: int = 0) -> None:
+        """Everything already resident in HBM (raw device addresses, e.g. torch tensor .data_ptr()); asynchronous on the
+        context's stream."""
+        _capi.check(_capi.lib().bppp_u64_verify_batch_device(self._ctx, label, len(label), n, d_commitments, d_proofs,
+                                                             d_accept, d_status or None, d_trace or None,
+                                                             d_reject_count or None))
+
+    # ---- plumbing
+    def set_stream(self, hip_stream: Optional[int]) -> None:
+        _capi.check(_capi.lib().bppp_ctx_set_stream(self._ctx, hip_stream or None))
+
+    def enable_timing(self, on: bool = True) -> None:
+        _capi.check(_capi.lib().bppp_ctx_enable_timing(self._ctx, 1 if on else 0))
+
+    def timings(self, reset: bool = True) -> dict:
+        names = (C.c_char_p * 16)()
+        ms = (C.c_double * 16)()
+        cnt = (C.c_int64 * 16)()
+        k = _capi.check(_capi.lib().bppp_ctx_get_timings(self._ctx, 16, names, ms, cnt, 1 if reset else 0))
+        return {names[i].decode(): {"total_ms": ms[i], "launches": cnt[i]} for i in range(k)}
+
+    def device_bytes(self) -> int:
+        return int(_capi.lib().bppp_ctx_device_bytes(self._ctx))

@@ -1,0 +1,107 @@
+/*
+ * bppp.h -- C ABI of the MI355X-native Bulletproofs++ u64 range-proof engine (libbppp_hip.so).
+ *
+ * This is the drop-in boundary for ONE hot path of distributed-lab/bp-pp 0.1.1: batch verification (and, next,
+ * batch proving) of independent u64 range proofs that share one generator set.  The reference has no FFI of its
+ * own (it is a pure-Rust crate); each entry point below names the reference interface it replaces
+ * (file:line under /root/reference/src) and INTEGRATION.md shows the Rust `extern "C"` facade a maintainer
+ * would add.  Plain pointers and sizes only; no torch / HIP types in the signatures.
+ *
+ * Encodings (identical to the byte strings k256 0.13.3 produces):
+ *   point   64 B  affine big-endian x || y; the identity is 64 zero bytes
+ *                 (ProjectivePoint::to_affine() + to_encoded_point(false) without the 0x04 tag)
+ *   scalar  32 B  big-endian canonical (Scalar::to_bytes / from_repr)
+ *   u64 proof 928 B = 13 points + 3 scalars, in this order (reciprocal.rs:30-33, circuit.rs:24-33):
+ *                 c_l, c_r, c_o, c_s, r[0..3], x[0..3], reciprocal.r, l[0], l[1], n[0]
+ *
+ * Threading: a context is bound to one GPU and one HIP stream; calls on one context must not overlap.  Different
+ * contexts (e.g. one per GPU, one process per GPU) are independent.  The library never retains caller pointers.
+ *
+ * There is NO CPU fallback: without a usable gfx950 device every compute entry point returns BPPP_ERR_NO_DEVICE.
+ */
+#ifndef BPPP_H
+#define BPPP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPPP_POINT_BYTES 64
+#define BPPP_SCALAR_BYTES 32
+#define BPPP_U64_PROOF_BYTES 928
+#define BPPP_U64_TRACE_BYTES 704
+#define BPPP_G_VEC_FULL_SZ 16 /* u64_proof.rs:12 */
+#define BPPP_H_VEC_FULL_SZ 32 /* u64_proof.rs:14 */
+
+/* return codes */
+#define BPPP_OK 0
+#define BPPP_ERR_NO_DEVICE (-1)   /* no HIP device / not gfx950 / HIP runtime failed to initialise */
+#define BPPP_ERR_INVALID_ARG (-2) /* null pointer, bad size, unsupported window width */
+#define BPPP_ERR_HIP (-3)         /* a HIP call failed; see bppp_last_error() */
+#define BPPP_ERR_ENCODING (-4)    /* a generator is not a valid curve point */
+#define BPPP_ERR_NOMEM (-5)
+
+/* per-proof status written by the verify kernels (0 = fine) */
+#define BPPP_ST_BAD_ENCODING 1 /* off-curve point / coordinate >= p / scalar >= n: k256 deserialisation would fail */
+#define BPPP_ST_DEGENERATE 2   /* the reference would panic here: challenge >= n (transcript.rs:13) or zero inverse
+                                  (circuit.rs:192,196, reciprocal.rs:181, util.rs:119) */
+
+#if defined(__GNUC__)
+#define BPPP_API __attribute__((visibility("default")))
+#else
+#define BPPP_API
+#endif
+
+typedef struct bppp_ctx bppp_ctx;
+
+/* U64RangeProofProtocol { g, g_vec[16], h_vec[32] } (u64_proof.rs:19-28) bound to GPU `device`.
+ * Builds the fixed-base tables for the 49 generators on the GPU (fb_window_bits in {4, 8, 16}; 0 = default 16:
+ * 49 x 16 x 65535 affine points = 3.3 GB of HBM). */
+BPPP_API int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec /* 16 x 64 */,
+                    const uint8_t* h_vec /* 32 x 64 */, int device, int fb_window_bits);
+BPPP_API void bppp_ctx_destroy(bppp_ctx* ctx);
+
+/* Run the context's kernels on a caller-owned hipStream_t (passed as void*); NULL restores the context's own stream. */
+BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
+
+/* U64RangeProofProtocol::verify (u64_proof.rs:42-54) for n independent proofs, fresh
+ * `merlin::Transcript::new(label)` per proof (benches/range_proof.rs:47).
+ * accept[i] = 1 iff the reference's verify returns true for (commitments[i], proofs[i]); status[i] (optional, may be
+ * NULL) holds BPPP_ST_* flags; a proof with a non-zero status is never accepted.  Host pointers; copies in and out. */
+BPPP_API int bppp_u64_verify_batch(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n,
+                          const uint8_t* commitments /* n x 64 */, const uint8_t* proofs /* n x 928 */,
+                          uint8_t* accept /* n */, int32_t* status /* n or NULL */);
+
+/* Same, but every buffer is DEVICE memory on the context's GPU (inputs already resident in HBM).  Asynchronous on
+ * the context's stream; d_trace (optional, n x 704) receives per-proof intermediates: 10 challenges
+ * (e, rho, lambda, beta, delta, tau, y1..y4; 32 B each) then 6 points (V+r, C0..C4; 64 B each).
+ * reject_count (optional, device int32[1]) receives the number of proofs with accept == 0 -- the value a multi-GPU
+ * caller all-reduces over RCCL. */
+BPPP_API int bppp_u64_verify_batch_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n,
+                                 const void* d_commitments, const void* d_proofs, void* d_accept, void* d_status,
+                                 void* d_trace, void* d_reject_count);
+
+/* U64RangeProofProtocol::commit_value (u64_proof.rs:37-39): out[i] = x[i]*g + s[i]*h_vec[0], host pointers. */
+BPPP_API int bppp_u64_commit_value_batch(bppp_ctx* ctx, size_t n, const uint64_t* x, const uint8_t* s /* n x 32 */,
+                                uint8_t* out /* n x 64 */);
+
+/* Profiling aid for bench.py: when enabled, every kernel launch of the verify pipeline is bracketed by HIP events on
+ * the context's stream; bppp_ctx_get_timings returns accumulated milliseconds and launch counts per kernel since the
+ * last reset.  names[i] points to a static string. */
+BPPP_API int bppp_ctx_enable_timing(bppp_ctx* ctx, int enable);
+BPPP_API int bppp_ctx_get_timings(bppp_ctx* ctx, int max_entries, const char** names, double* total_ms, int64_t* launches,
+                         int reset);
+
+/* Workspace the context currently holds on the GPU, in bytes (tables + per-proof workspace). */
+BPPP_API size_t bppp_ctx_device_bytes(const bppp_ctx* ctx);
+
+BPPP_API const char* bppp_strerror(int code);
+BPPP_API const char* bppp_last_error(void); /* thread-local detail of the last BPPP_ERR_HIP */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPPP_H */

@@ -1,0 +1,149 @@
+// TEST-ONLY host emulation of the device code: compiles bp_pp_amd/csrc/*.h (the exact __host__ __device__ functions
+// the HIP kernels call) with g++ and runs each "thread" in a CPU loop, so the kernel logic can be checked against the
+// oracle in the CPU-only test tier.  This is a development aid: the product library (libbppp_hip.so) never loads or
+// falls back to it, and fails loudly without a GPU.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../bp_pp_amd/csrc/verify_core.h"
+
+using namespace bppp;
+
+extern "C" {
+
+void emul_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {
+    fe x, y, r;
+    fe_from_be(x, a); fe_from_be(y, b);
+    fe_mul(r, x, y);
+    fe_to_be(out, r);
+}
+void emul_fe_addsub(const uint8_t a[32], const uint8_t b[32], uint8_t sum[32], uint8_t diff[32], uint8_t m21[32]) {
+    fe x, y, r;
+    fe_from_be(x, a); fe_from_be(y, b);
+    fe_add(r, x, y); fe_to_be(sum, r);
+    fe_sub(r, x, y); fe_to_be(diff, r);
+    fe_mul_small(r, x, 21); fe_to_be(m21, r);
+}
+void emul_fe_inv(const uint8_t a[32], uint8_t out[32], uint8_t sqrt_out[32]) {
+    fe x, r;
+    fe_from_be(x, a);
+    fe_inv(r, x); fe_to_be(out, r);
+    fe_sqrt_candidate(r, x); fe_to_be(sqrt_out, r);
+}
+int emul_fe_canonical(const uint8_t a[32]) { fe x; return fe_from_be(x, a) ? 1 : 0; }
+void emul_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {
+    sc x, y, r;
+    sc_from_be(x, a); sc_from_be(y, b);
+    sc_mul(r, x, y);
+    sc_to_be(out, r);
+}
+void emul_sc_addsub(const uint8_t a[32], const uint8_t b[32], uint8_t sum[32], uint8_t diff[32]) {
+    sc x, y, r;
+    sc_from_be(x, a); sc_from_be(y, b);
+    sc_add(r, x, y); sc_to_be(sum, r);
+    sc_sub(r, x, y); sc_to_be(diff, r);
+}
+void emul_sc_inv(const uint8_t a[32], uint8_t out[32]) {
+    sc x, r;
+    sc_from_be(x, a);
+    sc_inv(r, x);
+    sc_to_be(out, r);
+}
+int emul_sc_canonical(const uint8_t a[32]) { sc x; return sc_from_be(x, a) ? 1 : 0; }
+// op: 0 add (complete), 1 mixed add, 2 double(A)
+int emul_pt_op(int op, const uint8_t A[64], const uint8_t B[64], uint8_t out[64]) {
+    apt a, b, r;
+    if (!apt_from_xy64(a, A) || !apt_from_xy64(b, B)) return -1;
+    pt p, q, s;
+    pt_from_affine(p, a);
+    pt_from_affine(q, b);
+    if (op == 0) pt_add(s, p, q);
+    else if (op == 1) pt_madd(s, p, b, false);
+    else pt_dbl(s, p);
+    pt_to_affine(r, s);
+    apt_to_xy64(out, r);
+    return 0;
+}
+// sum_j k_j P_j via the Straus path (m <= 5)
+int emul_straus(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64]) {
+    std::vector<pt> tbl(m * BPPP_STRAUS_ENTRIES);
+    straus_scalar rs[5];
+    for (int j = 0; j < m; j++) {
+        apt a;
+        sc s;
+        if (!apt_from_xy64(a, P + 64 * j) || !sc_from_be(s, k + 32 * j)) return -1;
+        straus_build_table(tbl.data() + j * BPPP_STRAUS_ENTRIES, a);
+        straus_recode(rs[j], s);
+    }
+    pt acc;
+    straus_msm(acc, tbl.data(), rs, m);
+    apt r;
+    pt_to_affine(r, acc);
+    apt_to_xy64(out, r);
+    return 0;
+}
+void emul_merlin_kat(const uint8_t* label, size_t label_len, const uint8_t* m1, size_t m1_len, uint8_t* out, size_t out_len) {
+    strobe t;
+    t_new(t, label, (u32)label_len);
+    t_append(t, "some label", m1, (u32)m1_len);
+    t_challenge_bytes(t, "challenge", out, (u32)out_len);
+}
+size_t emul_fb_table_entries(int nbases, int W) { return (size_t)nbases * (256 / W) * (((size_t)1 << W) - 1); }
+int emul_fb_build(const uint8_t* gens, int nbases, int W, uint8_t* table_out /* entries x 64 B, LE limbs as device */) {
+    std::vector<apt> g(nbases);
+    for (int i = 0; i < nbases; i++) if (!apt_from_xy64(g[i], gens + 64 * i)) return -1;
+    size_t entries = emul_fb_table_entries(nbases, W);
+    std::vector<fe> z(entries), pz(entries);
+    FbBuild fb{g.data(), nbases, W, (apt*)table_out, z.data(), pz.data()};
+    size_t nthreads = (size_t)nbases * (256 / W) * fb_chunks_per_window(W);
+    for (size_t t = 0; t < nthreads; t++) fb_build_pass1(fb, t);
+    for (size_t t = 0; t < nthreads; t++) fb_build_pass2(fb, t);
+    return 0;
+}
+// fixed-base MSM sum_j k_j G_{first+j} through the table
+int emul_fb_msm(const uint8_t* table, int W, int first_base, int count, const uint8_t* k, uint8_t out[64]) {
+    VerifyWs ws;
+    memset(&ws, 0, sizeof ws);
+    ws.N = 1;
+    ws.fb_table = (const apt*)table;
+    ws.fb_w = W;
+    std::vector<u32> scal(count * 8);
+    for (int j = 0; j < count; j++) {
+        sc s;
+        if (!sc_from_be(s, k + 32 * j)) return -1;
+        for (int i = 0; i < 8; i++) scal[(j * 8 + i)] = s.v[i];
+    }
+    pt acc;
+    pt_set_identity(acc);
+    fixed_base_msm(acc, ws, 0, scal.data(), 0, first_base, count);
+    apt r;
+    pt_to_affine(r, acc);
+    apt_to_xy64(out, r);
+    return 0;
+}
+// full exact verify pipeline, every phase in thread order
+int emul_u64_verify_batch(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
+                          const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* trace) {
+    VerifyWs ws;
+    memset(&ws, 0, sizeof ws);
+    ws.N = n;
+    ws.commitments = V; ws.proofs = proofs; ws.accept = accept; ws.status = status; ws.trace = trace;
+    std::vector<u32> strobe_(52 * n), chal(80 * n), sc0(176 * n), cvec(200 * n), pts(208 * n), lns(24 * n), acc(24 * n), pfix(24 * n),
+        fsc(392 * n);
+    std::vector<pt> straus(n * 5 * BPPP_STRAUS_ENTRIES);
+    ws.tstate = strobe_.data(); ws.chal = chal.data(); ws.sc0 = sc0.data(); ws.cvec = cvec.data(); ws.pts = pts.data();
+    ws.lns = lns.data(); ws.acc = acc.data(); ws.pfix = pfix.data(); ws.fsc = fsc.data(); ws.straus = straus.data();
+    ws.fb_table = (const apt*)table;
+    ws.fb_w = W;
+    t_new(ws.base, label, (u32)label_len);
+    for (size_t t = 0; t < n; t++) verify_phase1(ws, t);
+    for (size_t t = 0; t < n; t++) verify_c0_fixed(ws, t);
+    for (size_t t = 0; t < n; t++) verify_c0_var(ws, t);
+    for (int k = 1; k <= 4; k++)
+        for (size_t t = 0; t < n; t++) verify_round(ws, t, k);
+    for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);
+    for (size_t t = 0; t < n; t++) verify_final_check(ws, t);
+    return 0;
+}
+}

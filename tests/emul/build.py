@@ -1,0 +1,27 @@
+"""Builds the TEST-ONLY host emulation of the device code (tests/emul/bppp_emul.cpp) with g++."""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SO = os.path.join(HERE, "libbppp_emul.so")
+
+
+def load():
+    src = os.path.join(HERE, "bppp_emul.cpp")
+    deps = [src] + glob.glob(os.path.join(ROOT, "bp_pp_amd", "csrc", "*.h"))
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-std=c++17", "-o", SO, src])
+    L = C.CDLL(SO)
+    vp, sz, i32, cp = C.c_void_p, C.c_size_t, C.c_int, C.c_char_p
+    L.emul_fb_table_entries.restype = sz
+    L.emul_fb_table_entries.argtypes = [i32, i32]
+    L.emul_fb_build.argtypes = [cp, i32, i32, vp]
+    L.emul_fb_msm.argtypes = [vp, i32, i32, i32, cp, vp]
+    L.emul_straus.argtypes = [i32, cp, cp, vp]
+    L.emul_pt_op.argtypes = [i32, cp, cp, vp]
+    L.emul_merlin_kat.argtypes = [cp, sz, cp, sz, vp, sz]
+    L.emul_u64_verify_batch.argtypes = [vp, i32, cp, sz, sz, vp, vp, vp, vp, vp]
+    return L

@@ -1,0 +1,129 @@
+"""CPU tier for the DEVICE code: bp_pp_amd/csrc/{field,point,merlin,verify_core}.h are `__host__ __device__`, so the exact
+functions the HIP kernels call are compiled here with g++ (tests/emul) and run thread by thread against the oracle.
+This catches logic errors before any GPU minute is spent; the -m gpu tests then check the same code as compiled for
+gfx950.  The emulation library is never loaded by the product."""
+import ctypes as C
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import bppp_oracle as O
+from emul.build import load
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+b32 = lambda v: int(v).to_bytes(32, "big")
+
+
+@pytest.fixture(scope="module")
+def L():
+    return load()
+
+
+def test_field_arithmetic(L):
+    rnd = random.Random(7)
+    edge = [0, 1, 2, O.P - 1, O.P - 2, 2**256 - 1 - O.P, 1 << 255, 2**32 + 977, O.N - 1, O.N, 2**128, 0xFFFFFFFF, 1 << 32,
+            2**256 - 1, O.P + 1, (1 << 224) - 1]
+    vals = edge + [rnd.getrandbits(256) for _ in range(400)]
+    o1, o2, o3 = (C.create_string_buffer(32) for _ in range(3))
+    for i, v in enumerate(vals):
+        a, b = v % O.P, vals[(i * 7 + 3) % len(vals)] % O.P
+        L.emul_fe_mul(b32(a), b32(b), o1)
+        assert int.from_bytes(o1.raw, "big") == a * b % O.P
+        L.emul_fe_addsub(b32(a), b32(b), o1, o2, o3)
+        assert int.from_bytes(o1.raw, "big") == (a + b) % O.P
+        assert int.from_bytes(o2.raw, "big") == (a - b) % O.P
+        assert int.from_bytes(o3.raw, "big") == a * 21 % O.P
+        a, b = v % O.N, vals[(i * 7 + 3) % len(vals)] % O.N
+        L.emul_sc_mul(b32(a), b32(b), o1)
+        assert int.from_bytes(o1.raw, "big") == a * b % O.N
+        L.emul_sc_addsub(b32(a), b32(b), o1, o2)
+        assert int.from_bytes(o1.raw, "big") == (a + b) % O.N and int.from_bytes(o2.raw, "big") == (a - b) % O.N
+    for v in vals[:48]:
+        a = v % O.P
+        L.emul_fe_inv(b32(a), o1, o2)
+        assert int.from_bytes(o1.raw, "big") == (pow(a, -1, O.P) if a else 0)
+        assert int.from_bytes(o2.raw, "big") == pow(a, (O.P + 1) // 4, O.P)
+        a = v % O.N
+        L.emul_sc_inv(b32(a), o1)
+        assert int.from_bytes(o1.raw, "big") == (pow(a, -1, O.N) if a else 0)
+    assert L.emul_fe_canonical(b32(O.P - 1)) == 1 and L.emul_fe_canonical(b32(O.P)) == 0 and L.emul_fe_canonical(b32(2**256 - 1)) == 0
+    assert L.emul_sc_canonical(b32(O.N - 1)) == 1 and L.emul_sc_canonical(b32(O.N)) == 0
+
+
+def test_complete_point_formulas_and_straus(L):
+    rnd = random.Random(11)
+    pts = [None, O.G, O.pt_mul(O.G, 2), O.pt_neg(O.G)] + [O.pt_mul(O.G, rnd.getrandbits(256)) for _ in range(5)]
+    out = C.create_string_buffer(64)
+    for A in pts:
+        for B in pts:       # includes identity operands, P + P and P + (-P): what complete formulas are for
+            assert L.emul_pt_op(0, O.pt_to_xy64(A), O.pt_to_xy64(B), out) == 0
+            assert out.raw == O.pt_to_xy64(O.pt_add(A, B))
+            L.emul_pt_op(1, O.pt_to_xy64(A), O.pt_to_xy64(B), out)
+            assert out.raw == O.pt_to_xy64(O.pt_add(A, B))
+        L.emul_pt_op(2, O.pt_to_xy64(A), O.pt_to_xy64(A), out)
+        assert out.raw == O.pt_to_xy64(O.pt_add(A, A))
+    bad = bytearray(O.pt_to_xy64(O.G)); bad[63] ^= 1
+    assert L.emul_pt_op(0, bytes(bad), O.pt_to_xy64(O.G), out) == -1
+    for m in (1, 2, 5):
+        for _ in range(3):
+            P = [pts[rnd.randrange(len(pts))] for _ in range(m)]
+            ks = [rnd.choice([0, 1, O.N - 1, 8, 2**255, 0x8888888888888888, rnd.getrandbits(256) % O.N]) for _ in range(m)]
+            assert L.emul_straus(m, b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out) == 0
+            exp = None
+            for p, k in zip(P, ks):
+                exp = O.pt_add(exp, O.pt_mul(p, k))
+            assert out.raw == O.pt_to_xy64(exp)
+
+
+def test_merlin_known_answer_on_device_code(L):
+    kat = C.create_string_buffer(32)
+    L.emul_merlin_kat(b"test protocol", 13, b"some data", 9, kat, 32)
+    assert kat.raw.hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(GOLD, "u64_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("W", [4, 8])
+def test_fixed_base_tables(L, gold, W):
+    gens = bytes.fromhex(gold["generators"])
+    g3 = gens[:128] + bytes(64)                  # two generators + the identity as a (degenerate but legal) generator
+    ent = L.emul_fb_table_entries(3, W)
+    tab = np.zeros(ent * 64, dtype=np.uint8)
+    assert L.emul_fb_build(g3, 3, W, tab.ctypes.data) == 0
+    out = C.create_string_buffer(64)
+    for ks in ([0x1234567890ABCDEF1234567890ABCDEF, O.N - 1, 12345], [0, 0, 0], [1, 0, 5]):
+        L.emul_fb_msm(tab.ctypes.data, W, 0, 3, b"".join(map(b32, ks)), out)
+        exp = O.pt_add(O.pt_mul(O.pt_from_xy64(gens[:64]), ks[0]), O.pt_mul(O.pt_from_xy64(gens[64:128]), ks[1]))
+        assert out.raw == O.pt_to_xy64(exp)
+
+
+def test_full_verify_pipeline_against_golden(L, gold, oracle_c):
+    gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
+    W = 4                                        # small tables: this is a logic test
+    ent = L.emul_fb_table_entries(49, W)
+    tab = np.zeros(ent * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0
+    items = [(c["commitment"], c["proof"], 1, 0) for c in gold["cases"]]
+    items += [(c["commitment"], c["proof"], 0, c["status"]) for c in gold["negative_cases"]]
+    n = len(items)
+    V = np.frombuffer(b"".join(bytes.fromhex(i[0]) for i in items), dtype=np.uint8).reshape(n, 64).copy()
+    P = np.frombuffer(b"".join(bytes.fromhex(i[1]) for i in items), dtype=np.uint8).reshape(n, 928).copy()
+    acc, st, tr = np.zeros(n, np.uint8), np.zeros(n, np.int32), np.zeros((n, 704), np.uint8)
+    L.emul_u64_verify_batch(tab.ctypes.data, W, label, len(label), n, V.ctypes.data, P.ctypes.data, acc.ctypes.data,
+                            st.ctypes.data, tr.ctypes.data)
+    assert acc.tolist() == [i[2] for i in items]
+    assert st.tolist() == [i[3] for i in items]
+    for k, c in enumerate(gold["cases"]):         # every challenge and every hashed commitment, byte for byte
+        exp = bytes.fromhex(c["trace_challenges_and_points"])
+        assert bytes(tr[k][:len(exp)]) == exp
+    for k in range(n):                            # and the C oracle's full trace (incl. C4) wherever it decodes
+        if items[k][3] == 0:
+            rc, otr = oracle_c.u64_verify(gens, label, bytes(V[k]), bytes(P[k]), trace=True)
+            assert rc == items[k][2] and bytes(tr[k]) == otr

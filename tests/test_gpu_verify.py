@@ -1,0 +1,135 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of include/bppp.h, against the
+oracle on the same seeded inputs.  Bit-exact bar: accept bits, per-proof status and every transcript challenge /
+hashed commitment (the trace) must equal the oracle's bytes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("these tests need a GPU (they are selected with -m gpu only on the GPU box)")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(GOLD, "u64_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module", params=[8, 16])
+def proto(request, torch_mod, gold):
+    from bp_pp_amd import U64RangeProofProtocol
+    import workload
+    g, gv, hv = workload.split_generators(bytes.fromhex(gold["generators"]))
+    p = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=request.param)
+    yield p
+    p.close()
+
+
+def _device_verify(torch, proto, label, V, P, want_trace=True):
+    n = V.shape[0]
+    dV = torch.from_numpy(V).cuda()
+    dP = torch.from_numpy(P).cuda()
+    dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    dS = torch.zeros(n, dtype=torch.int32, device="cuda")
+    dT = torch.zeros((n, 704), dtype=torch.uint8, device="cuda") if want_trace else None
+    dR = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    proto.set_stream(torch.cuda.current_stream().cuda_stream)
+    proto.verify_batch_device(label, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(),
+                              dT.data_ptr() if want_trace else 0, dR.data_ptr())
+    torch.cuda.synchronize()
+    return dA.cpu().numpy(), dS.cpu().numpy(), (dT.cpu().numpy() if want_trace else None), int(dR.item())
+
+
+def test_golden_vectors_bit_exact(torch_mod, proto, gold, oracle_c):
+    gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
+    items = [(c["commitment"], c["proof"], 1, 0) for c in gold["cases"]]
+    items += [(c["commitment"], c["proof"], 0, c["status"]) for c in gold["negative_cases"]]
+    n = len(items)
+    V = np.frombuffer(b"".join(bytes.fromhex(i[0]) for i in items), dtype=np.uint8).reshape(n, 64).copy()
+    P = np.frombuffer(b"".join(bytes.fromhex(i[1]) for i in items), dtype=np.uint8).reshape(n, 928).copy()
+    acc, st, tr, rej = _device_verify(torch_mod, proto, label, V, P)
+    assert acc.tolist() == [i[2] for i in items]
+    assert st.tolist() == [i[3] for i in items]
+    assert rej == sum(1 for i in items if not i[2])
+    for k, c in enumerate(gold["cases"]):
+        exp = bytes.fromhex(c["trace_challenges_and_points"])
+        assert bytes(tr[k][:len(exp)]) == exp
+    for k in range(n):
+        if items[k][3] == 0:
+            rc, otr = oracle_c.u64_verify(gens, label, bytes(V[k]), bytes(P[k]), trace=True)
+            assert rc == items[k][2] and bytes(tr[k]) == otr
+    # host-pointer entry point (copies in and out) agrees
+    acc2, st2 = proto.verify_batch(V, P, label)
+    assert (acc2 == acc).all() and (st2 == st).all()
+    assert proto.verify(bytes(V[2]), bytes(P[2]), label) is True
+
+
+def test_commit_value_matches_reference_formula(torch_mod, proto, gold, oracle_c):
+    gens = bytes.fromhex(gold["generators"])
+    for c in gold["cases"]:
+        assert proto.commit_value(c["x"], bytes.fromhex(c["s"])).hex() == c["commitment"]
+    x = np.array([0, 1, 2**64 - 1, 123456, 16**15], dtype=np.uint64)
+    s = np.frombuffer(b"".join(int(v).to_bytes(32, "big") for v in [0, 1, 5, 2**200, 7]), dtype=np.uint8).reshape(5, 32)
+    out = proto.commit_value_batch(x, s)
+    for i in range(5):
+        assert bytes(out[i]) == oracle_c.u64_commit_value(gens, int(x[i]), bytes(s[i]))
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
+def test_ragged_batches_vs_oracle(torch_mod, proto, oracle_c, n):
+    import workload
+    gens, V, P, _ = workload.make_batch(n, first=1000)
+    P, expect = workload.corrupt(P, V, every=7)
+    acc, st, tr, rej = _device_verify(torch_mod, proto, workload.LABEL, V, P)
+    oacc, ost = oracle_c.u64_verify_batch(gens, workload.LABEL, V, P, nthreads=os.cpu_count() or 1)
+    assert (acc == oacc).all() and (acc == expect).all()
+    assert (st == 0).all() and (ost == 0).all()
+    assert rej == int((expect == 0).sum())
+    for k in range(0, n, max(1, n // 16)):       # sampled intermediates, byte for byte
+        rc, otr = oracle_c.u64_verify(gens, workload.LABEL, bytes(V[k]), bytes(P[k]), trace=True)
+        assert bytes(tr[k]) == otr
+
+
+def test_empty_batch_is_a_no_op(torch_mod, proto):
+    acc, st = proto.verify_batch(np.zeros((0, 64), np.uint8), np.zeros((0, 928), np.uint8), b"u64 range proof")
+    assert acc.shape == (0,) and st.shape == (0,)
+
+
+def test_full_size_batch_properties(torch_mod, gold):
+    """BASELINE config 2: 2^16 independent proofs on one GPU.  Size-independent properties: every honest proof is accepted,
+    exactly the corrupted ones are rejected, the result is idempotent and permutation-equivariant, and a sampled subset
+    is bit-exact against the oracle."""
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    import bppp_oracle_c as OC
+    torch = torch_mod
+    n = 1 << 16
+    gens, V, P, _ = workload.make_batch(n)
+    P, expect = workload.corrupt(P, V, every=1024)
+    g, gv, hv = workload.split_generators(gens)
+    proto = U64RangeProofProtocol(g, gv, hv, device=0)
+    try:
+        acc, st, _, rej = _device_verify(torch, proto, workload.LABEL, V, P, want_trace=False)
+        assert (acc == expect).all() and (st == 0).all() and rej == n // 1024
+        acc2, _, _, _ = _device_verify(torch, proto, workload.LABEL, V, P, want_trace=False)
+        assert (acc2 == acc).all()
+        perm = np.random.default_rng(1).permutation(n)
+        acc3, _, _, _ = _device_verify(torch, proto, workload.LABEL, V[perm].copy(), P[perm].copy(), want_trace=False)
+        assert (acc3 == acc[perm]).all()
+        idx = np.concatenate([np.arange(0, n, 1024)[:16], np.arange(5, n, 257)[:240]])
+        oacc, _ = OC.u64_verify_batch(gens, workload.LABEL, V[idx].copy(), P[idx].copy(), nthreads=os.cpu_count() or 1)
+        assert (oacc == acc[idx]).all()
+    finally:
+        proto.close()
