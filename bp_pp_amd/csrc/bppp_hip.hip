@@ -24,9 +24,17 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1(VerifyWs ws) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N) verify_phase1(ws, t);
 }
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_fixed(VerifyWs ws) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < ws.N) verify_c0_fixed(ws, t);
+// fixed-base MSM kernels: BPPP_FB_LANES lanes per proof, 256-thread workgroups, registers capped for 4 wavefronts per SIMD
+#define BPPP_FB_BLOCK 256
+__global__ __launch_bounds__(BPPP_FB_BLOCK, 4) void k_verify_c0_fixed(VerifyWs ws) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= ws.N) return;   // whole lane groups leave together
+    pt part;
+    verify_c0_fixed_lane(part, ws, t, lane);
+    lane_group_sum(part);
+    if (lane == 0) verify_c0_fixed_store(ws, t, part);
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var(VerifyWs ws) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
@@ -40,10 +48,20 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(VerifyWs ws
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N) verify_final_scalars(ws, t);
 }
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_check(VerifyWs ws, int* reject_count) {
+__global__ __launch_bounds__(BPPP_FB_BLOCK, 4) void k_verify_final_check(VerifyWs ws) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= ws.N) return;
+    pt part;
+    verify_final_check_lane(part, ws, t, lane);
+    lane_group_sum(part);
+    if (lane == 0) verify_final_check_store(ws, t, part);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(VerifyWs ws, int* reject_count) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N) {
-        verify_final_check(ws, t);
+        verify_accept(ws, t);
         if (reject_count && !ws.accept[t]) atomicAdd(reject_count, 1);
     }
 }
@@ -98,9 +116,9 @@ static thread_local std::string g_last_error;
         }                                                                                              \
     } while (0)
 
-enum KernelId { K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_COUNT };
+enum KernelId { K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_ACCEPT, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"k_verify_phase1",        "k_verify_c0_fixed",   "k_verify_c0_var", "k_verify_round",
-                                                  "k_verify_final_scalars", "k_verify_final_check"};
+                                                  "k_verify_final_scalars", "k_verify_final_check", "k_verify_accept"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -384,11 +402,13 @@ int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label
         if (rc != BPPP_OK) return rc;                           \
     } while (0)
     LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
-    LAUNCH(K_C0_FIXED, k_verify_c0_fixed<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    LAUNCH(K_C0_FIXED, k_verify_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
     for (int k = 1; k <= 4; k++) LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
     LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
-    LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
+    LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+    LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
 #undef LAUNCH
     HIP_TRY(hipGetLastError());
     return BPPP_OK;

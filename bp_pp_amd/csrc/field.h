@@ -28,22 +28,60 @@ typedef uint64_t u64;
 struct fe { u32 v[8]; };  // mod p = 2^256 - 2^32 - 977
 struct sc { u32 v[8]; };  // mod n (group order)
 
+// ---------------------------------------------------------------- carry primitives
+// hipcc turns __builtin_addc / __builtin_subc chains into v_add_co_u32 / v_addc_co_u32 (32-bit, full rate); the same
+// arithmetic written with 64-bit temporaries compiles to half-rate v_lshl_add_u64 plus register shuffles.
+HD u32 addc(u32 a, u32 b, u32& carry) {
+#if defined(__clang__)
+    u32 co;
+    u32 r = __builtin_addc(a, b, carry, &co);
+    carry = co;
+    return r;
+#else
+    u64 s = (u64)a + b + carry;
+    carry = (u32)(s >> 32);
+    return (u32)s;
+#endif
+}
+HD u32 subb(u32 a, u32 b, u32& borrow) {
+#if defined(__clang__)
+    u32 bo;
+    u32 r = __builtin_subc(a, b, borrow, &bo);
+    borrow = bo;
+    return r;
+#else
+    u64 d = (u64)a - b - borrow;
+    borrow = (u32)(d >> 32) & 1u;
+    return (u32)d;
+#endif
+}
+// acc (64-bit) += a*b with the carry out of bit 64 delivered separately: on gfx950 exactly v_mad_u64_u32 (carry-out in an
+// SGPR pair) + v_addc_co_u32 (consumes it).  hipcc does not form this pair from C, hence the two one-instruction asm
+// statements; being separate statements, the scheduler is free to interleave several columns between them.
+#if defined(__HIP_DEVICE_COMPILE__)
+HD void mad_c(u64& acc, u64& carry, u32 a, u32 b) { asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry) : "v"(a), "v"(b)); }
+HD void add_c(u32& cnt, u64& carry) { asm("v_addc_co_u32_e64 %0, %1, 0, %0, %1" : "+v"(cnt), "+s"(carry)); }
+#else
+HD void mad_c(u64& acc, u64& carry, u32 a, u32 b) {
+    u64 p = (u64)a * b, o = acc;
+    acc = o + p;
+    carry = acc < o ? 1u : 0u;
+}
+HD void add_c(u32& cnt, u64& carry) { cnt += (u32)carry; }
+#endif
+
 // ---------------------------------------------------------------- generic 256-bit helpers
 HD u32 add256(u32 r[8], const u32 a[8], const u32 b[8]) {
-    u64 c = 0;
+    u32 c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { c += (u64)a[i] + b[i]; r[i] = (u32)c; c >>= 32; }
-    return (u32)c;
+    for (int i = 0; i < 8; i++) r[i] = addc(a[i], b[i], c);
+    return c;
 }
 HD u32 sub256(u32 r[8], const u32 a[8], const u32 b[8]) {
-    u32 borrow = 0;
+    u32 bw = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 d = (u64)a[i] - b[i] - borrow;
-        r[i] = (u32)d;
-        borrow = (u32)(d >> 32) & 1;
-    }
-    return borrow;
+    for (int i = 0; i < 8; i++) r[i] = subb(a[i], b[i], bw);
+    return bw;
 }
 HD void sel256(u32 r[8], u32 take_b, const u32 a[8], const u32 b[8]) {  // r = take_b ? b : a
 #pragma unroll
@@ -61,19 +99,55 @@ HD bool eq256(const u32 a[8], const u32 b[8]) {
     for (int i = 0; i < 8; i++) x |= a[i] ^ b[i];
     return x == 0;
 }
-// full 256x256 -> 512 product, operand scanning: 64 limb products, each one mad into a 64-bit carry word
-HD void mul256(u32 t[16], const u32 a[8], const u32 b[8]) {
-    u64 c = 0;
+// Columns K0..K0+G-1 of the 8x8 limb product, interleaved: each column is a 64-bit accumulator + carry counter.
+template <int K0, int G>
+HD void mul256_cols(u64* acc, u32* cnt, const u32* a, const u32* b) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) { c += (u64)a[0] * b[j]; t[j] = (u32)c; c >>= 32; }
-    t[8] = (u32)c;
-#pragma unroll
-    for (int i = 1; i < 8; i++) {
-        c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { c += (u64)a[i] * b[j] + t[i + j]; t[i + j] = (u32)c; c >>= 32; }
-        t[i + 8] = (u32)c;
+    for (int g = 0; g < G; g++) {
+        const int k = K0 + g;
+        if (k > 14) continue;
+        const int i0 = k < 8 ? 0 : k - 7;
+        acc[k] = (u64)a[i0] * b[k - i0];   // the first product of a column cannot carry
+        cnt[k] = 0;
     }
+#pragma unroll
+    for (int s = 1; s < 8; s++) {
+        u64 cr[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int k = K0 + g;
+            if (k > 14) continue;
+            const int i0 = k < 8 ? 0 : k - 7, i1 = k < 8 ? k : 7;
+            if (i0 + s <= i1) mad_c(acc[k], cr[g], a[i0 + s], b[k - i0 - s]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int k = K0 + g;
+            if (k > 14) continue;
+            const int i0 = k < 8 ? 0 : k - 7, i1 = k < 8 ? k : 7;
+            if (i0 + s <= i1) add_c(cnt[k], cr[g]);
+        }
+    }
+}
+// full 256x256 -> 512 product, product scanning: 64 v_mad_u64_u32 + 49 v_addc (all 15 column sums independent, which
+// is what lets a lone wavefront keep issuing), then one carry-propagation pass (3 full-rate adds per column).
+HD void mul256(u32 t[16], const u32 a[8], const u32 b[8]) {
+    u64 acc[16];
+    u32 cnt[16];
+    mul256_cols<0, 4>(acc, cnt, a, b);
+    mul256_cols<4, 4>(acc, cnt, a, b);
+    mul256_cols<8, 4>(acc, cnt, a, b);
+    mul256_cols<12, 4>(acc, cnt, a, b);
+    t[0] = (u32)acc[0];
+    u32 c_lo = (u32)(acc[0] >> 32), c_hi = 0;
+#pragma unroll
+    for (int k = 1; k < 15; k++) {
+        u32 cy = 0;
+        t[k] = addc((u32)acc[k], c_lo, cy);
+        c_lo = addc((u32)(acc[k] >> 32), c_hi, cy);
+        c_hi = cnt[k] + cy;
+    }
+    t[15] = c_lo;
 }
 // big-endian 32 bytes <-> limbs
 HD void be32_to_limbs(u32 r[8], const uint8_t* b) {
@@ -94,15 +168,15 @@ HD void limbs_to_be32(uint8_t* b, const u32 a[8]) {
 // ---------------------------------------------------------------- Fp: p = 2^256 - PC, PC = 2^32 + 977
 #define BPPP_PC0 0x000003D1u  // low limb of PC; limb 1 of PC is 1
 
-// r (8 limbs) + carry*2^256, value < 2^256 + small  ->  canonical.  x >= p  <=>  x + PC carries out of 2^256.
+// x (8 limbs) + carry*2^256, value < 2^256 + small  ->  canonical.  x >= p  <=>  x + PC carries out of 2^256.
 HD void fe_final(fe& r, const u32 x[8], u32 carry) {
     u32 t[8];
-    u64 c = (u64)x[0] + BPPP_PC0; t[0] = (u32)c; c >>= 32;
-    c += (u64)x[1] + 1; t[1] = (u32)c; c >>= 32;
+    u32 c = 0;
+    t[0] = addc(x[0], BPPP_PC0, c);
+    t[1] = addc(x[1], 1u, c);
 #pragma unroll
-    for (int i = 2; i < 8; i++) { c += x[i]; t[i] = (u32)c; c >>= 32; }
-    u32 take = carry | (u32)c;
-    sel256(r.v, take, x, t);
+    for (int i = 2; i < 8; i++) t[i] = addc(x[i], 0u, c);
+    sel256(r.v, carry | c, x, t);
 }
 HD void fe_add(fe& r, const fe& a, const fe& b) {
     u32 s[8];
@@ -113,10 +187,11 @@ HD void fe_sub(fe& r, const fe& a, const fe& b) {
     u32 d[8], e[8];
     u32 borrow = sub256(d, a.v, b.v);
     // d + p = d - PC (mod 2^256)
-    u64 c = (u64)d[0] - BPPP_PC0; e[0] = (u32)c; u32 bw = (u32)(c >> 32) & 1;
-    c = (u64)d[1] - 1 - bw; e[1] = (u32)c; bw = (u32)(c >> 32) & 1;
+    u32 bw = 0;
+    e[0] = subb(d[0], BPPP_PC0, bw);
+    e[1] = subb(d[1], 1u, bw);
 #pragma unroll
-    for (int i = 2; i < 8; i++) { c = (u64)d[i] - bw; e[i] = (u32)c; bw = (u32)(c >> 32) & 1; }
+    for (int i = 2; i < 8; i++) e[i] = subb(d[i], 0u, bw);
     sel256(r.v, borrow, d, e);
 }
 HD void fe_neg(fe& r, const fe& a) {
@@ -126,28 +201,44 @@ HD void fe_neg(fe& r, const fe& a) {
     fe_sub(r, z, a);
 }
 HD void fe_dbl(fe& r, const fe& a) { fe_add(r, a, a); }
-// reduce a 512-bit value: hi*2^256 + lo == hi*PC + lo
-HD void fe_reduce512(fe& r, const u32 t[16]) {
+// reduce a 512-bit value: hi*2^256 + lo == lo + (hi << 32) + hi*977, then fold the (< 2^35) overflow once more
+HD void fe_reduce512(fe& out, const u32 t[16]) {
+    u32 r[9];
+    u32 c = 0;
+    r[0] = t[0];
+#pragma unroll
+    for (int j = 1; j < 8; j++) r[j] = addc(t[j], t[8 + j - 1], c);
+    r[8] = addc(t[15], 0u, c);
+    u32 r9 = c;
+    u64 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (u64)t[8 + j] * BPPP_PC0;
+    c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = addc(r[j], (u32)v[j], c);
+    r[8] = addc(r[8], 0u, c);
+    r9 += c;
+    c = 0;
+#pragma unroll
+    for (int j = 1; j < 8; j++) r[j] = addc(r[j], (u32)(v[j - 1] >> 32), c);
+    r[8] = addc(r[8], (u32)(v[7] >> 32), c);
+    r9 += c;
+    // top = r[8] + r9 * 2^32 (< 2^35); top * PC = top*977 + (top << 32)
+    u64 m = (u64)r[8] * BPPP_PC0 + ((u64)(r9 * BPPP_PC0) << 32);
     u32 s[8];
-    u64 c = 0;
+    c = 0;
+    s[0] = addc(r[0], (u32)m, c);
+    s[1] = addc(r[1], (u32)(m >> 32), c);
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        c += (u64)t[8 + j] * BPPP_PC0 + t[j];
-        if (j > 0) c += t[8 + j - 1];
-        s[j] = (u32)c;
-        c >>= 32;
-    }
-    c += t[15];  // overflow word(s): < 2^34
-    u64 top = c;
-    // fold top * PC = top*977 + (top << 32)
-    c = (u64)s[0] + (top & 0xFFFFFFFFu) * BPPP_PC0 + (((top >> 32) * BPPP_PC0) << 32);
-    s[0] = (u32)c; c >>= 32;
-    c += (u64)s[1] + (top & 0xFFFFFFFFu); s[1] = (u32)c; c >>= 32;
-    c += (u64)s[2] + (top >> 32); s[2] = (u32)c; c >>= 32;
+    for (int i = 2; i < 8; i++) s[i] = addc(r[i], 0u, c);
+    u32 k1 = c;
+    c = 0;
+    s[1] = addc(s[1], r[8], c);
+    s[2] = addc(s[2], r9, c);
 #pragma unroll
-    for (int i = 3; i < 8; i++) { c += s[i]; s[i] = (u32)c; c >>= 32; }
-    // a carry here means value = 2^256 + s with s tiny; fe_final adds PC once for the wrap (cannot wrap again)
-    fe_final(r, s, (u32)c);
+    for (int i = 3; i < 8; i++) s[i] = addc(s[i], 0u, c);
+    // at most one of the two chains wraps 2^256 (the folded value is < 2^256 + 2^68); fe_final adds PC for the wrap
+    fe_final(out, s, k1 | c);
 }
 HD void fe_mul(fe& r, const fe& a, const fe& b) {
     u32 t[16];
@@ -156,16 +247,22 @@ HD void fe_mul(fe& r, const fe& a, const fe& b) {
 }
 HD void fe_sqr(fe& r, const fe& a) { fe_mul(r, a, a); }
 HD void fe_mul_small(fe& r, const fe& a, u32 k) {  // k < 2^16
+    u64 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (u64)a.v[i] * k;   // 8 independent mads; high words < 2^16
     u32 s[8];
-    u64 c = 0;
+    u32 c = 0;
+    s[0] = (u32)v[0];
 #pragma unroll
-    for (int i = 0; i < 8; i++) { c += (u64)a.v[i] * k; s[i] = (u32)c; c >>= 32; }
-    u64 top = c;  // < 2^16
-    c = (u64)s[0] + top * BPPP_PC0; s[0] = (u32)c; c >>= 32;
-    c += (u64)s[1] + top; s[1] = (u32)c; c >>= 32;
+    for (int i = 1; i < 8; i++) s[i] = addc((u32)v[i], (u32)(v[i - 1] >> 32), c);
+    u32 top = (u32)(v[7] >> 32) + c;   // < 2^17
+    // fold top * PC = top*977 (< 2^27) + (top << 32)
+    c = 0;
+    s[0] = addc(s[0], top * BPPP_PC0, c);
+    s[1] = addc(s[1], top, c);
 #pragma unroll
-    for (int i = 2; i < 8; i++) { c += s[i]; s[i] = (u32)c; c >>= 32; }
-    fe_final(r, s, (u32)c);
+    for (int i = 2; i < 8; i++) s[i] = addc(s[i], 0u, c);
+    fe_final(r, s, c);
 }
 HD bool fe_is_zero(const fe& a) { return is_zero256(a.v); }
 HD bool fe_eq(const fe& a, const fe& b) { return eq256(a.v, b.v); }
@@ -222,12 +319,11 @@ HD_NOINLINE void fe_sqrt_candidate(fe& r, const fe& a) {
 // big-endian bytes -> canonical element; false if >= p
 HD bool fe_from_be(fe& r, const uint8_t* b) {
     be32_to_limbs(r.v, b);
-    u32 t[8];
-    u64 c = (u64)r.v[0] + BPPP_PC0; t[0] = (u32)c; c >>= 32;
-    c += (u64)r.v[1] + 1; t[1] = (u32)c; c >>= 32;
+    u32 c = 0;
+    (void)addc(r.v[0], BPPP_PC0, c);
+    (void)addc(r.v[1], 1u, c);
 #pragma unroll
-    for (int i = 2; i < 8; i++) { c += r.v[i]; t[i] = (u32)c; c >>= 32; }
-    (void)t;
+    for (int i = 2; i < 8; i++) (void)addc(r.v[i], 0u, c);
     return c == 0;
 }
 HD void fe_to_be(uint8_t* b, const fe& a) { limbs_to_be32(b, a.v); }
@@ -242,11 +338,10 @@ HD void fe_to_be(uint8_t* b, const fe& a) { limbs_to_be32(b, a.v); }
 HD void sc_final(sc& r, const u32 x[8], u32 carry) {  // x + carry*2^256 < 2n  ->  canonical
     const u32 nd[5] = {BPPP_ND0, BPPP_ND1, BPPP_ND2, BPPP_ND3, BPPP_ND4};
     u32 t[8];
-    u64 c = 0;
+    u32 c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { c += (u64)x[i] + (i < 5 ? nd[i] : 0u); t[i] = (u32)c; c >>= 32; }
-    u32 take = carry | (u32)c;
-    sel256(r.v, take, x, t);
+    for (int i = 0; i < 8; i++) t[i] = addc(x[i], i < 5 ? nd[i] : 0u, c);
+    sel256(r.v, carry | c, x, t);
 }
 HD void sc_add(sc& r, const sc& a, const sc& b) {
     u32 s[8];
@@ -259,11 +354,7 @@ HD void sc_sub(sc& r, const sc& a, const sc& b) {
     u32 borrow = sub256(d, a.v, b.v);
     u32 bw = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 c = (u64)d[i] - (i < 5 ? nd[i] : 0u) - bw;
-        e[i] = (u32)c;
-        bw = (u32)(c >> 32) & 1;
-    }
+    for (int i = 0; i < 8; i++) e[i] = subb(d[i], i < 5 ? nd[i] : 0u, bw);
     sel256(r.v, borrow, d, e);
 }
 HD void sc_set_u32(sc& r, u32 x) {
@@ -332,9 +423,9 @@ HD_NOINLINE void sc_inv(sc& r, const sc& a) {
 HD bool sc_from_be(sc& r, const uint8_t* b) {
     const u32 nd[5] = {BPPP_ND0, BPPP_ND1, BPPP_ND2, BPPP_ND3, BPPP_ND4};
     be32_to_limbs(r.v, b);
-    u64 c = 0;
+    u32 c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { c += (u64)r.v[i] + (i < 5 ? nd[i] : 0u); c >>= 32; }
+    for (int i = 0; i < 8; i++) (void)addc(r.v[i], i < 5 ? nd[i] : 0u, c);
     return c == 0;
 }
 HD void sc_to_be(uint8_t* b, const sc& a) { limbs_to_be32(b, a.v); }

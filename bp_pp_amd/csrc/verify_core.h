@@ -137,6 +137,55 @@ HD void fixed_base_msm(pt& accp, const VerifyWs& ws, size_t t, const u32* scal, 
     accp = acc;
 }
 
+// ---- the same MSM split over BPPP_FB_LANES lanes per proof: lane `lane` takes every (base, window) pair whose window
+// index is congruent to it, accumulates a partial sum, and the partial sums are tree-added across the lane group
+// (wavefront shuffles on the device).  49 bases x 16 windows = 784 independent table additions per proof is where this
+// path has intra-proof parallelism; it lifts the kernel from 1 to 4 resident wavefronts per SIMD at 2^16 proofs.
+#define BPPP_FB_LANES 8
+HD void fixed_base_msm_partial(pt& accp, const VerifyWs& ws, size_t t, int lane, const u32* scal, int first_slot, int first_base,
+                               int count) {
+    const int W = ws.fb_w;
+    const int nwin = 256 / W;
+    const u32 mask = (1u << W) - 1u;
+    const size_t per_win = (size_t)mask;
+    pt acc;
+    pt_set_identity(acc);
+#pragma nounroll
+    for (int j = 0; j < count; j++) {
+        u32 k[8];
+        ws_ld8(k, scal, ws.N, t, first_slot + j);
+        const apt* tb = ws.fb_table + (size_t)(first_base + j) * nwin * per_win;
+#pragma nounroll
+        for (int w = lane; w < nwin; w += BPPP_FB_LANES) {
+            int bit = w * W;
+            u32 limb = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) limb = (i == (bit >> 5)) ? k[i] : limb;
+            u32 d = (limb >> (bit & 31)) & mask;
+            size_t idx = (size_t)w * per_win + (d ? d - 1 : 0);
+            apt e = tb[idx];
+            pt_madd(acc, acc, e, d == 0);
+        }
+    }
+    accp = acc;
+}
+#if defined(__HIPCC__)
+// tree-add the partial sums of the BPPP_FB_LANES consecutive lanes of a group; every lane ends with the total
+__device__ __forceinline__ void lane_group_sum(pt& acc) {
+#pragma unroll
+    for (int m = 1; m < BPPP_FB_LANES; m <<= 1) {
+        pt o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            o.X.v[i] = __shfl_xor(acc.X.v[i], m, 64);
+            o.Y.v[i] = __shfl_xor(acc.Y.v[i], m, 64);
+            o.Z.v[i] = __shfl_xor(acc.Z.v[i], m, 64);
+        }
+        pt_add(acc, acc, o);
+    }
+}
+#endif
+
 // ---------------------------------------------------------------- variable-base shared-doubling MSM (Straus), signed 4-bit windows
 // k = sum_{i<64} (nib_i(k') - 8) 16^i + c 16^64 with k' = k + 0x88..8 (mod 2^256), c = carry out; digits in [-8, 7].
 struct straus_scalar { u32 kp[8]; u32 top; };
@@ -366,14 +415,28 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
     }
 }
 
-// ---------------------------------------------------------------- phase 2a: C0 fixed-base part: ps_tau*g + <g_vec, pn_tau>  (circuit.rs:206)
-HD void verify_c0_fixed(const VerifyWs& ws, size_t t) {
-    pt acc;
-    pt_set_identity(acc);
-    fixed_base_msm(acc, ws, t, ws.sc0, 0, 0, 17);
-    ws_st_pt(ws.pfix, ws.N, t, acc);
+// ---------------------------------------------------------------- phase 2b: C0 fixed-base part: ps_tau*g + <g_vec, pn_tau>  (circuit.rs:206), added to acc
+// lane-group form: every lane of the proof's group computes a partial sum; the group total is stored by _store.
+HD void verify_c0_fixed_lane(pt& part, const VerifyWs& ws, size_t t, int lane) {
+    fixed_base_msm_partial(part, ws, t, lane, ws.sc0, 0, 0, 17);
 }
-// ---------------------------------------------------------------- phase 2b: C0 variable-base part (circuit.rs:230-235) + pfix
+HD void verify_c0_fixed_store(const VerifyWs& ws, size_t t, const pt& total) {   // C0 = (variable-base part, in acc) + total
+    pt a;
+    ws_ld_pt(a, ws.acc, ws.N, t);
+    pt_add(a, a, total);
+    ws_st_pt(ws.acc, ws.N, t, a);
+}
+// single-thread form (host emulation in tests/emul, thread order = lane order)
+HD void verify_c0_fixed(const VerifyWs& ws, size_t t) {
+    pt acc, part;
+    pt_set_identity(acc);
+    for (int lane = 0; lane < BPPP_FB_LANES; lane++) {
+        verify_c0_fixed_lane(part, ws, t, lane);
+        pt_add(acc, acc, part);
+    }
+    verify_c0_fixed_store(ws, t, acc);
+}
+// ---------------------------------------------------------------- phase 2a: C0 variable-base part (circuit.rs:230-235)
 HD void verify_c0_var(const VerifyWs& ws, size_t t) {
     const size_t N = ws.N;
     pt* tbl = ws.straus + t * (5 * BPPP_STRAUS_ENTRIES);
@@ -388,11 +451,9 @@ HD void verify_c0_var(const VerifyWs& ws, size_t t) {
         ws_ld8(k.v, ws.sc0, N, t, 17 + j);
         straus_recode(rs[j], k);
     }
-    pt acc, pf;
+    pt acc;
     straus_msm(acc, tbl, rs, 5);
-    ws_ld_pt(pf, ws.pfix, N, t);
-    pt_add(acc, acc, pf);
-    ws_st_pt(ws.acc, N, t, acc);
+    ws_st_pt(ws.acc, N, t, acc);   // the fixed-base part is added by verify_c0_fixed_store
 }
 // ---------------------------------------------------------------- phase 3 (k = 1..4): one WNLA round (wnla.rs:84-102)
 HD void verify_round(const VerifyWs& ws, size_t t, int k) {
@@ -502,12 +563,16 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
         ws_st8(ws.fsc, N, t, 17 + i, tmp.v);
     }
 }
-HD void verify_final_check(const VerifyWs& ws, size_t t) {
+HD void verify_final_check_lane(pt& part, const VerifyWs& ws, size_t t, int lane) {
+    fixed_base_msm_partial(part, ws, t, lane, ws.fsc, 0, 0, BPPP_NG);
+}
+HD void verify_final_check_store(const VerifyWs& ws, size_t t, const pt& rhs) { ws_st_pt(ws.pfix, ws.N, t, rhs); }
+// accept bit: C4 == rhs as projective classes (wnla.rs:81), and no status flag
+HD void verify_accept(const VerifyWs& ws, size_t t) {
     const size_t N = ws.N;
-    pt rhs, C;
-    pt_set_identity(rhs);
-    fixed_base_msm(rhs, ws, t, ws.fsc, 0, 0, BPPP_NG);
+    pt C, rhs;
     ws_ld_pt(C, ws.acc, N, t);
+    ws_ld_pt(rhs, ws.pfix, N, t);
     bool eq = pt_eq(C, rhs);                                             // wnla.rs:81
     ws.accept[t] = (eq && ws.status[t] == ST_OK) ? 1 : 0;
     if (ws.trace) {
@@ -515,6 +580,16 @@ HD void verify_final_check(const VerifyWs& ws, size_t t) {
         pt_to_affine(Ca, C);
         apt_to_xy64(ws.trace + 704 * t + 320 + 64 * 5, Ca);
     }
+}
+HD void verify_final_check(const VerifyWs& ws, size_t t) {
+    pt acc, part;
+    pt_set_identity(acc);
+    for (int lane = 0; lane < BPPP_FB_LANES; lane++) {
+        verify_final_check_lane(part, ws, t, lane);
+        pt_add(acc, acc, part);
+    }
+    verify_final_check_store(ws, t, acc);
+    verify_accept(ws, t);
 }
 
 // ---------------------------------------------------------------- fixed-base table construction (context creation)

@@ -138,8 +138,8 @@ int emul_u64_verify_batch(const uint8_t* table, int W, const uint8_t* label, siz
     ws.fb_w = W;
     t_new(ws.base, label, (u32)label_len);
     for (size_t t = 0; t < n; t++) verify_phase1(ws, t);
-    for (size_t t = 0; t < n; t++) verify_c0_fixed(ws, t);
     for (size_t t = 0; t < n; t++) verify_c0_var(ws, t);
+    for (size_t t = 0; t < n; t++) verify_c0_fixed(ws, t);
     for (int k = 1; k <= 4; k++)
         for (size_t t = 0; t < n; t++) verify_round(ws, t, k);
     for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);

@@ -154,7 +154,7 @@ int main() {
     u32* out;
     CHECK(hipMalloc(&out, (size_t)CU * 32 * 64 * 4 * 4));
     const int iters = 4096;
-    for (int wps : {1, 2, 4, 8}) {   // waves per SIMD -> blocks of 256 threads per CU = wps
+    for (int wps : {1, 8}) {   // waves per SIMD -> blocks of 256 threads per CU = wps
         int blocks = CU * wps;
         size_t lanes = (size_t)blocks * 256;
         double ms;
@@ -171,7 +171,7 @@ int main() {
         ms = time_ms([&] { k_add32<8><<<blocks, 256>>>(out, 12345, 6789, iters); });
         printf("add/xor/shift ilp8 wps %d : %8.1f Gop/s (3 ops per iter counted)\n", wps, lanes * (double)iters * 8 * 3 / ms / 1e6);
     }
-    for (int wps : {1, 2}) {
+    for (int wps : {1, 2, 3, 4, 6, 8}) {
         int blocks = CU * 4 * wps;   // 64-thread blocks: 4 per CU = 1 wave/SIMD
         size_t lanes = (size_t)blocks * 64;
         const int it = 2048;
@@ -179,7 +179,7 @@ int main() {
         printf("fe_mul chain       wps %d : %8.2f G fe_mul/s\n", wps, lanes * (double)it * 2 / ms / 1e6);
         ms = time_ms([&] { k_femul2<<<blocks, 64>>>(out, it); });
         printf("fe_mul 2 chains    wps %d : %8.2f G fe_mul/s\n", wps, lanes * (double)it * 4 / ms / 1e6);
-        for (int mode = 0; mode < 3; mode++) {
+        for (int mode = 0; mode < 3 && wps <= 4; mode++) {
             const int itp = 512;
             ms = time_ms([&] { k_ptops<<<blocks, 64>>>(out, itp, mode); });
             printf("%-18s wps %d : %8.3f G op/s  (%.2f us per op per wave)\n", mode == 0 ? "pt_dbl" : mode == 1 ? "pt_add" : "pt_madd", wps,
