@@ -60,6 +60,7 @@ def main():
 
     import workload                                   # synthetic inputs (setup, untimed)
     from bp_pp_amd import U64RangeProofProtocol
+    from bp_pp_amd.distributed import all_reduce_reject_count
 
     n = args.proofs_per_gpu
     host_threads = max(1, (os.cpu_count() or 1) // max(1, world))
@@ -82,8 +83,7 @@ def main():
 
     def step():
         proto.verify_batch_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, dR.data_ptr())
-        if world > 1:
-            dist.all_reduce(dR, op=dist.ReduceOp.SUM)   # the single accept-reduce (4 bytes over RCCL/xGMI)
+        all_reduce_reject_count(dR)                     # the single accept-reduce (4 bytes over RCCL/xGMI); no-op at N=1
 
     def fence():
         if world > 1:

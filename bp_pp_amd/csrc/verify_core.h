@@ -111,8 +111,10 @@ HD void app_point(strobe& t, const char (&label)[L], const apt& a) {  // transcr
 // ---------------------------------------------------------------- fixed-base MSM over the batch-shared tables
 // table[(b * nwin + w) * (2^W - 1) + (d - 1)] = d * 2^(W w) * generator_b, affine (64 B); (0,0) = identity.
 // This is `vector_mul(points, scalars)` (util.rs:46-60) for points that are batch constants.
-HD void fixed_base_msm(pt& accp, const VerifyWs& ws, size_t t, const u32* scal, int first_slot, int first_base, int count) {
-    const int W = ws.fb_w;
+struct FbTable { const apt* table; int W; size_t N; };
+HD FbTable fb_of(const VerifyWs& ws) { FbTable f = {ws.fb_table, ws.fb_w, ws.N}; return f; }
+HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, int first_slot, int first_base, int count) {
+    const int W = fbt.W;
     const int nwin = 256 / W;
     const u32 mask = (W == 32) ? 0xFFFFFFFFu : ((1u << W) - 1u);
     const size_t per_win = (size_t)mask;
@@ -120,8 +122,8 @@ HD void fixed_base_msm(pt& accp, const VerifyWs& ws, size_t t, const u32* scal, 
 #pragma nounroll
     for (int j = 0; j < count; j++) {
         u32 k[8];
-        ws_ld8(k, scal, ws.N, t, first_slot + j);
-        const apt* tb = ws.fb_table + (size_t)(first_base + j) * nwin * per_win;
+        ws_ld8(k, scal, fbt.N, t, first_slot + j);
+        const apt* tb = fbt.table + (size_t)(first_base + j) * nwin * per_win;
 #pragma nounroll
         for (int w = 0; w < nwin; w++) {
             int bit = w * W;
@@ -142,9 +144,9 @@ HD void fixed_base_msm(pt& accp, const VerifyWs& ws, size_t t, const u32* scal, 
 // (wavefront shuffles on the device).  49 bases x 16 windows = 784 independent table additions per proof is where this
 // path has intra-proof parallelism; it lifts the kernel from 1 to 4 resident wavefronts per SIMD at 2^16 proofs.
 #define BPPP_FB_LANES 8
-HD void fixed_base_msm_partial(pt& accp, const VerifyWs& ws, size_t t, int lane, const u32* scal, int first_slot, int first_base,
+HD void fixed_base_msm_partial(pt& accp, const FbTable& fbt, size_t t, int lane, const u32* scal, int first_slot, int first_base,
                                int count) {
-    const int W = ws.fb_w;
+    const int W = fbt.W;
     const int nwin = 256 / W;
     const u32 mask = (1u << W) - 1u;
     const size_t per_win = (size_t)mask;
@@ -153,8 +155,8 @@ HD void fixed_base_msm_partial(pt& accp, const VerifyWs& ws, size_t t, int lane,
 #pragma nounroll
     for (int j = 0; j < count; j++) {
         u32 k[8];
-        ws_ld8(k, scal, ws.N, t, first_slot + j);
-        const apt* tb = ws.fb_table + (size_t)(first_base + j) * nwin * per_win;
+        ws_ld8(k, scal, fbt.N, t, first_slot + j);
+        const apt* tb = fbt.table + (size_t)(first_base + j) * nwin * per_win;
 #pragma nounroll
         for (int w = lane; w < nwin; w += BPPP_FB_LANES) {
             int bit = w * W;
@@ -237,6 +239,91 @@ HD void straus_msm(pt& out, const pt* tbl, const straus_scalar* rs, int m) {
             fe_neg(ny, q.Y);
             fe_cmov(q.Y, dg < 0, ny);
             pt_add(acc, acc, q);
+        }
+    }
+    out = acc;
+}
+
+// ---------------------------------------------------------------- GLV endomorphism split (secp256k1: lambda*(x, y) = (beta*x, y))
+// k = k1 + k2*lambda (mod n) with |k1|, |k2| < 2^128: halves the doublings of every variable-base multiplication.
+// Constants: lattice basis of (n, lambda); g1, g2 = round(2^384 * b2 / n), round(2^384 * (-b1) / n)  (derived and checked in
+// tests/test_core_emul.py against big-integer arithmetic).
+struct glv_split { u32 k1[5], k2[5]; bool neg1, neg2; };
+HD void glv_round_shift384(sc& c, const sc& k, const u32 g[8]) {   // c = (k*g + 2^383) >> 384
+    u32 t[16];
+    mul256(t, k.v, g);
+    u32 cy = (t[11] >> 31) & 1u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) c.v[i] = addc(t[12 + i], 0u, cy);
+#pragma unroll
+    for (int i = 4; i < 8; i++) c.v[i] = 0;
+}
+HD bool glv_abs(u32 out[5], const sc& r) {   // r is either small (< 2^129) or n - small; returns true when negated
+    bool neg = ((r.v[5] | r.v[6] | r.v[7]) != 0) | (r.v[4] > 1u);
+    sc m;
+    sc_neg(m, r);
+#pragma unroll
+    for (int i = 0; i < 5; i++) out[i] = neg ? m.v[i] : r.v[i];
+    return neg;
+}
+HD void glv_decompose(glv_split& out, const sc& k) {
+    const u32 G1[8] = {0x45DBB031u, 0xE893209Au, 0x71E8CA7Fu, 0x3DAA8A14u, 0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u};
+    const u32 G2[8] = {0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu, 0x0ABFE4C4u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u};
+    const sc MB1 = {{0x0ABFE4C3u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u}};
+    const sc MB2 = {{0x3DB1562Cu, 0xD765CDA8u, 0x0774346Du, 0x8A280AC5u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}};
+    const sc LAM = {{0x1B23BD72u, 0xDF02967Cu, 0x20816678u, 0x122E22EAu, 0x8812645Au, 0xA5261C02u, 0xC05C30E0u, 0x5363AD4Cu}};
+    sc c1, c2, r1, r2, t;
+    glv_round_shift384(c1, k, G1);
+    glv_round_shift384(c2, k, G2);
+    sc_mul(c1, c1, MB1);
+    sc_mul(c2, c2, MB2);
+    sc_add(r2, c1, c2);
+    sc_mul(t, r2, LAM);
+    sc_sub(r1, k, t);
+    out.neg1 = glv_abs(out.k1, r1);
+    out.neg2 = glv_abs(out.k2, r2);
+    // signed 4-bit recoding offset (33 nibbles): k' = |k| + 0x8...8; digit_i = nib_i(k') - 8 in [-8, 7]
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) out.k1[i] = addc(out.k1[i], i < 4 ? 0x88888888u : 0x8u, c);
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) out.k2[i] = addc(out.k2[i], i < 4 ? 0x88888888u : 0x8u, c);
+}
+HD u32 limb5_at(const u32 v[5], int idx) {
+    u32 r = 0;
+#pragma unroll
+    for (int l = 0; l < 5; l++) r = (l == idx) ? v[l] : r;
+    return r;
+}
+// acc = sum_j k_j * P_j with tables tbl[j*9 + e] = e*P_j: 33 windows x (4 doublings + 2m additions); the lambda stream reuses
+// P_j's table with X scaled by beta.
+HD void straus_msm_glv(pt& out, const pt* tbl, const glv_split* sp, int m) {
+    const fe BETA = {{0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu}};
+    pt acc;
+    pt_set_identity(acc);
+#pragma nounroll
+    for (int i = 32; i >= 0; i--) {
+        if (i != 32) {
+#pragma nounroll
+            for (int d = 0; d < 4; d++) pt_dbl(acc, acc);
+        }
+#pragma nounroll
+        for (int j = 0; j < m; j++) {
+#pragma nounroll
+            for (int h = 0; h < 2; h++) {
+                const u32* kp = h ? sp[j].k2 : sp[j].k1;
+                bool sneg = h ? sp[j].neg2 : sp[j].neg1;
+                int dg = (int)((limb5_at(kp, i >> 3) >> ((i & 7) * 4)) & 15) - 8;
+                int mag = dg < 0 ? -dg : dg;
+                pt q = tbl[j * BPPP_STRAUS_ENTRIES + mag];
+                fe bx, ny;
+                fe_mul(bx, q.X, BETA);
+                fe_cmov(q.X, h != 0, bx);
+                fe_neg(ny, q.Y);
+                fe_cmov(q.Y, (dg < 0) != sneg, ny);
+                pt_add(acc, acc, q);
+            }
         }
     }
     out = acc;
@@ -418,7 +505,7 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
 // ---------------------------------------------------------------- phase 2b: C0 fixed-base part: ps_tau*g + <g_vec, pn_tau>  (circuit.rs:206), added to acc
 // lane-group form: every lane of the proof's group computes a partial sum; the group total is stored by _store.
 HD void verify_c0_fixed_lane(pt& part, const VerifyWs& ws, size_t t, int lane) {
-    fixed_base_msm_partial(part, ws, t, lane, ws.sc0, 0, 0, 17);
+    fixed_base_msm_partial(part, fb_of(ws), t, lane, ws.sc0, 0, 0, 17);
 }
 HD void verify_c0_fixed_store(const VerifyWs& ws, size_t t, const pt& total) {   // C0 = (variable-base part, in acc) + total
     pt a;
@@ -440,7 +527,7 @@ HD void verify_c0_fixed(const VerifyWs& ws, size_t t) {
 HD void verify_c0_var(const VerifyWs& ws, size_t t) {
     const size_t N = ws.N;
     pt* tbl = ws.straus + t * (5 * BPPP_STRAUS_ENTRIES);
-    straus_scalar rs[5];
+    glv_split rs[5];
     const int pslot[5] = {3, 2, 0, 1, 12};  // c_s, c_o, c_l, c_r, V+r  <->  sc0 slots 17..21
 #pragma nounroll
     for (int j = 0; j < 5; j++) {
@@ -449,10 +536,10 @@ HD void verify_c0_var(const VerifyWs& ws, size_t t) {
         straus_build_table(tbl + j * BPPP_STRAUS_ENTRIES, P);
         sc k;
         ws_ld8(k.v, ws.sc0, N, t, 17 + j);
-        straus_recode(rs[j], k);
+        glv_decompose(rs[j], k);
     }
     pt acc;
-    straus_msm(acc, tbl, rs, 5);
+    straus_msm_glv(acc, tbl, rs, 5);
     ws_st_pt(ws.acc, N, t, acc);   // the fixed-base part is added by verify_c0_fixed_store
 }
 // ---------------------------------------------------------------- phase 3 (k = 1..4): one WNLA round (wnla.rs:84-102)
@@ -490,13 +577,13 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k) {
     sc_mul(y2m1, y, y);
     sc_sub(y2m1, y2m1, one);
     pt* tbl = ws.straus + t * (5 * BPPP_STRAUS_ENTRIES);
-    straus_scalar rs[2];
+    glv_split rs[2];
     straus_build_table(tbl, X);
     straus_build_table(tbl + BPPP_STRAUS_ENTRIES, R);
-    straus_recode(rs[0], y);
-    straus_recode(rs[1], y2m1);
+    glv_decompose(rs[0], y);
+    glv_decompose(rs[1], y2m1);
     pt acc;
-    straus_msm(acc, tbl, rs, 2);
+    straus_msm_glv(acc, tbl, rs, 2);
     pt_madd(acc, acc, Ca, false);
     ws_st_pt(ws.acc, N, t, acc);
 }
@@ -564,7 +651,7 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
     }
 }
 HD void verify_final_check_lane(pt& part, const VerifyWs& ws, size_t t, int lane) {
-    fixed_base_msm_partial(part, ws, t, lane, ws.fsc, 0, 0, BPPP_NG);
+    fixed_base_msm_partial(part, fb_of(ws), t, lane, ws.fsc, 0, 0, BPPP_NG);
 }
 HD void verify_final_check_store(const VerifyWs& ws, size_t t, const pt& rhs) { ws_st_pt(ws.pfix, ws.N, t, rhs); }
 // accept bit: C4 == rhs as projective classes (wnla.rs:81), and no status flag

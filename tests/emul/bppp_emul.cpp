@@ -83,6 +83,32 @@ int emul_straus(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64]) {
     apt_to_xy64(out, r);
     return 0;
 }
+// sum_j k_j P_j via the GLV Straus path (m <= 5); also returns the split of k_0 (|k1|, |k2| as 20-byte LE + signs)
+int emul_straus_glv(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64]) {
+    std::vector<pt> tbl(m * BPPP_STRAUS_ENTRIES);
+    glv_split rs[5];
+    for (int j = 0; j < m; j++) {
+        apt a;
+        sc s;
+        if (!apt_from_xy64(a, P + 64 * j) || !sc_from_be(s, k + 32 * j)) return -1;
+        straus_build_table(tbl.data() + j * BPPP_STRAUS_ENTRIES, a);
+        glv_decompose(rs[j], s);
+    }
+    pt acc;
+    straus_msm_glv(acc, tbl.data(), rs, m);
+    apt r;
+    pt_to_affine(r, acc);
+    apt_to_xy64(out, r);
+    return 0;
+}
+void emul_glv_split(const uint8_t k[32], uint32_t k1p[5], uint32_t k2p[5], int* neg1, int* neg2) {
+    sc s;
+    sc_from_be(s, k);
+    glv_split sp;
+    glv_decompose(sp, s);
+    for (int i = 0; i < 5; i++) { k1p[i] = sp.k1[i]; k2p[i] = sp.k2[i]; }
+    *neg1 = sp.neg1; *neg2 = sp.neg2;
+}
 void emul_merlin_kat(const uint8_t* label, size_t label_len, const uint8_t* m1, size_t m1_len, uint8_t* out, size_t out_len) {
     strobe t;
     t_new(t, label, (u32)label_len);
@@ -116,7 +142,7 @@ int emul_fb_msm(const uint8_t* table, int W, int first_base, int count, const ui
     }
     pt acc;
     pt_set_identity(acc);
-    fixed_base_msm(acc, ws, 0, scal.data(), 0, first_base, count);
+    fixed_base_msm(acc, fb_of(ws), 0, scal.data(), 0, first_base, count);
     apt r;
     pt_to_affine(r, acc);
     apt_to_xy64(out, r);

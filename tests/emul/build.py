@@ -21,6 +21,8 @@ def load():
     L.emul_fb_build.argtypes = [cp, i32, i32, vp]
     L.emul_fb_msm.argtypes = [vp, i32, i32, i32, cp, vp]
     L.emul_straus.argtypes = [i32, cp, cp, vp]
+    L.emul_straus_glv.argtypes = [i32, cp, cp, vp]
+    L.emul_glv_split.argtypes = [cp, vp, vp, vp, vp]
     L.emul_pt_op.argtypes = [i32, cp, cp, vp]
     L.emul_merlin_kat.argtypes = [cp, sz, cp, sz, vp, sz]
     L.emul_u64_verify_batch.argtypes = [vp, i32, cp, sz, sz, vp, vp, vp, vp, vp]

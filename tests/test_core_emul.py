@@ -78,6 +78,32 @@ def test_complete_point_formulas_and_straus(L):
             assert out.raw == O.pt_to_xy64(exp)
 
 
+def test_glv_split_and_straus(L):
+    """k = k1 + k2*lambda (mod n) with both halves below 2^129, then the full GLV shared-doubling MSM."""
+    rnd = random.Random(13)
+    OFF = int("8" * 33, 16)
+    k1p, k2p = (C.c_uint32 * 5)(), (C.c_uint32 * 5)()
+    n1, n2 = C.c_int(), C.c_int()
+    for k in [0, 1, 2, O.N - 1, O.N // 2, O.LAMBDA, O.N - O.LAMBDA, 2**128, 2**255] + [rnd.getrandbits(256) % O.N for _ in range(300)]:
+        L.emul_glv_split(b32(k), k1p, k2p, C.byref(n1), C.byref(n2))
+        a = sum(int(k1p[i]) << (32 * i) for i in range(5)) - OFF
+        b = sum(int(k2p[i]) << (32 * i) for i in range(5)) - OFF
+        assert 0 <= a < 2**129 and 0 <= b < 2**129
+        a, b = (-a if n1.value else a), (-b if n2.value else b)
+        assert (a + b * O.LAMBDA) % O.N == k
+    pts = [None, O.G, O.pt_neg(O.G)] + [O.pt_mul(O.G, rnd.getrandbits(256)) for _ in range(5)]
+    out = C.create_string_buffer(64)
+    for m in (1, 2, 5):
+        for _ in range(4):
+            P = [pts[rnd.randrange(len(pts))] for _ in range(m)]
+            ks = [rnd.choice([0, 1, O.N - 1, O.LAMBDA, 2**255, rnd.getrandbits(256) % O.N, rnd.getrandbits(256) % O.N]) for _ in range(m)]
+            assert L.emul_straus_glv(m, b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out) == 0
+            exp = None
+            for p, k in zip(P, ks):
+                exp = O.pt_add(exp, O.pt_mul(p, k))
+            assert out.raw == O.pt_to_xy64(exp)
+
+
 def test_merlin_known_answer_on_device_code(L):
     kat = C.create_string_buffer(32)
     L.emul_merlin_kat(b"test protocol", 13, b"some data", 9, kat, 32)
