@@ -13,7 +13,7 @@
 #include <vector>
 
 #include "../../include/bppp.h"
-#include "verify_core.h"
+#include "prove_core.h"
 
 using namespace bppp;
 
@@ -104,6 +104,42 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(VerifyWs ws, const 
     apt_to_xy64(out + 64 * t, a);
 }
 
+// ---- prover kernels (prove_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_a(ProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_stage_a(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_b(ProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_stage_b(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d(ProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_stage_d(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f(ProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_stage_f(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(ProveWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_round_scalars(w, t, k);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(ProveWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_round_fold(w, t, k);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, 4) void k_prove_msm(ProveWs w, MsmJob job) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt part;
+    prove_msm_lane(part, w, job, t, lane);
+    lane_group_sum(part);
+    if (lane == 0) prove_msm_store(w, job, t, part);
+}
+
 // ---------------------------------------------------------------- host side
 static thread_local std::string g_last_error;
 
@@ -136,6 +172,10 @@ struct bppp_ctx {
     size_t ws_bytes = 0;
     pt* d_straus = nullptr;
     size_t straus_bytes = 0;
+    // prover workspace
+    size_t pcap = 0;
+    u32* d_pws = nullptr;
+    size_t pws_bytes = 0;
     // staging for the host-pointer entry points
     uint8_t* d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -160,6 +200,19 @@ static int ensure_capacity(bppp_ctx* c, size_t n) {
     HIP_TRY(hipMalloc(&c->d_ws, c->ws_bytes));
     HIP_TRY(hipMalloc(&c->d_straus, c->straus_bytes));
     c->cap = cap;
+    return BPPP_OK;
+}
+static const size_t PWS_WORDS_PER_PROOF = 52 + (size_t)SV_COUNT * 8 + (size_t)BPPP_MSC_SETS * BPPP_NG * 8 + (size_t)PB_COUNT * 24;
+static int ensure_prove_capacity(bppp_ctx* c, size_t n) {
+    int rc = ensure_capacity(c, n);   // Straus tables are shared with the verifier workspace
+    if (rc != BPPP_OK) return rc;
+    if (n <= c->pcap) return BPPP_OK;
+    if (c->d_pws) { (void)hipFree(c->d_pws); c->d_pws = nullptr; }
+    c->pcap = 0;
+    size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    c->pws_bytes = cap * PWS_WORDS_PER_PROOF * sizeof(u32);
+    HIP_TRY(hipMalloc(&c->d_pws, c->pws_bytes));
+    c->pcap = cap;
     return BPPP_OK;
 }
 static int ensure_stage(bppp_ctx* c, size_t bytes) {
@@ -330,6 +383,7 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->d_table) (void)hipFree(c->d_table);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_straus) (void)hipFree(c->d_straus);
+    if (c->d_pws) (void)hipFree(c->d_pws);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -346,7 +400,7 @@ int bppp_ctx_set_stream(bppp_ctx* c, void* hip_stream) {
 
 size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
     if (!c) return 0;
-    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->stage_bytes + BPPP_NG * sizeof(apt);
+    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->pws_bytes + c->stage_bytes + BPPP_NG * sizeof(apt);
 }
 
 int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
@@ -481,6 +535,80 @@ int bppp_u64_commit_value_batch(bppp_ctx* c, size_t n, const uint64_t* x, const 
     HIP_TRY(hipMemcpyAsync(&flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return flags ? BPPP_ERR_INVALID_ARG : BPPP_OK;
+}
+
+int bppp_u64_prove_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
+                                const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status) {
+    if (!c || (!label && label_len) || !d_x || !d_s || !d_rnd || !d_proofs || !d_commitments) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_prove_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    ProveWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n;
+    w.x = (const uint64_t*)d_x; w.s = (const uint8_t*)d_s; w.rnd = (const uint8_t*)d_rnd;
+    w.proofs = (uint8_t*)d_proofs; w.commitments = (uint8_t*)d_commitments;
+    if (d_status) w.status = (int32_t*)d_status;
+    else {
+        rc = ensure_stage(c, c->cap * sizeof(int32_t));
+        if (rc != BPPP_OK) return rc;
+        w.status = (int32_t*)c->d_stage;
+    }
+    u32* p = c->d_pws;
+    w.tstate = p; p += 52 * n;
+    w.sv = p; p += (size_t)SV_COUNT * 8 * n;
+    w.msc = p; p += (size_t)BPPP_MSC_SETS * BPPP_NG * 8 * n;
+    w.pbuf = p;
+    w.straus = c->d_straus;
+    w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    t_new(w.base, label, (u32)label_len);
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    hipStream_t s = c->stream;
+    auto msm = [&](MsmJob job) { k_prove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job); };
+    k_prove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    msm(job_v());
+    k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    msm(job_rcom()); msm(job_co()); msm(job_cl()); msm(job_cr());
+    k_prove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    msm(job_cs());
+    k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    msm(job_c0());
+    for (int k = 1; k <= 4; k++) {
+        k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+        msm(job_x()); msm(job_r());
+        k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+    }
+    HIP_TRY(hipGetLastError());
+    return BPPP_OK;
+}
+
+int bppp_u64_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x, const uint8_t* s,
+                         const uint8_t* rnd, uint8_t* proofs, uint8_t* commitments, int32_t* status) {
+    if (!c || !x || !s || !rnd || !proofs || !commitments) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    uint8_t* d = nullptr;
+    const size_t o_x = 0, o_s = o_x + n * 8, o_r = o_s + n * 32, o_p = o_r + n * 52 * 32, o_c = o_p + n * (size_t)BPPP_U64_PROOF_BYTES,
+                 o_st = o_c + n * 64, total = o_st + n * sizeof(int32_t);
+    HIP_TRY(hipMalloc(&d, total));
+    int rc = BPPP_OK;
+    hipError_t e = hipMemcpyAsync(d + o_x, x, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_s, s, n * 32, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_r, rnd, n * 52 * 32, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rc = bppp_u64_prove_batch_device(c, label, label_len, n, d + o_x, d + o_s, d + o_r, d + o_p, d + o_c, d + o_st);
+        if (rc == BPPP_OK) {
+            e = hipMemcpyAsync(proofs, d + o_p, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(commitments, d + o_c, n * 64, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess && status) e = hipMemcpyAsync(status, d + o_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) { g_last_error = std::string("prove_batch: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
+    return rc;
 }
 
 }  // extern "C"

@@ -1,0 +1,654 @@
+// Batch u64 range-proof PROVER, one lane per proof (+ 8-lane fixed-base MSM kernels): the per-proof work of
+// `U64RangeProofProtocol::prove` (u64_proof.rs:57-82) -> `ReciprocalRangeProofProtocol::prove` (reciprocal.rs:110-146)
+// -> `ArithmeticCircuit::prove` (circuit.rs:260-556) -> `WeightNormLinearArgument::prove` (wnla.rs:125-190).
+//
+// Byte-identical output to the reference prover for the same 52 `Scalar::generate_biased` draws (an input here, in the
+// reference's draw order: reciprocal.rs:121 | circuit.rs:264-298 ro(7) rl(6) rr(5) | circuit.rs:371 ls(17) | :372 ns(16)).
+//
+// Restructuring (same group / field elements, hence same transcript bytes):
+//  * the dense circuit coefficients collapse to the u64 closed forms (as in verify_core.h); with c_nO = c_lR = c_lO = 0,
+//    no = lo = lr = 0 the polynomial coefficients f_[0..7] (circuit.rs:403-453) reduce to 7 short sums;
+//  * every prover point is a fixed-base MSM over the 49 ORIGINAL generators through the batch-shared tables: the folded
+//    generators of WNLA round k (wnla.rs:170-171) are linear combinations of the originals with coefficients
+//    ch[i] = prod_{t<k-1, bit t of i} y_{t+1} (h) and cg[i] = prod_{t<k-1} (bit t of i ? y_{t+1} : rho_{t+1}) (g), so
+//    X (wnla.rs:152-156) and R (wnla.rs:158-160) become 49-term MSMs with computed scalars;
+//  * the next round's commitment `wnla.commit(l_, n_)` (wnla.rs:186) equals com + y X + (y^2 - 1) R (the verifier's
+//    relation, wnla.rs:100-102) and is computed that way with one GLV Straus multiplication.
+#pragma once
+#include "verify_core.h"
+
+namespace bppp {
+
+// scalar slots (sv): [slot*8 + limb][N]
+enum : int {
+    SV_E = 0, SV_RHO, SV_MU, SV_RHOINV, SV_LAMBDA, SV_BETA, SV_DELTA, SV_MUINV, SV_SV /* s + r_blind */, SV_Y,
+    SV_R0 = 10,      // 16 reciprocals r_j = (d_j + e)^-1
+    SV_EINV0 = 26,   // 16 inverses (e + j)^-1
+    SV_L0 = 42,      // l vector, 32
+    SV_N0 = 74,      // n vector, 16
+    SV_C0 = 90,      // c vector, 32
+    SV_CH0 = 122,    // h-generator unrolling coefficients, 32
+    SV_CG0 = 154,    // g-generator unrolling coefficients, 16
+    SV_COUNT = 170
+};
+// point buffer slots (pbuf): [slot*24 + word][N], projective
+enum : int { PB_V = 0, PB_RCOM, PB_CO, PB_CL, PB_CR, PB_CS, PB_C, PB_X, PB_R, PB_COUNT };
+// MSM scalar sets (msc): set s, base b -> slot s*49 + b
+#define BPPP_MSC_SETS 4
+
+struct ProveWs {
+    size_t N;
+    const uint64_t* x;      // N
+    const uint8_t* s;       // N x 32
+    const uint8_t* rnd;     // N x 52 x 32
+    uint8_t* proofs;        // N x 928
+    uint8_t* commitments;   // N x 64
+    int32_t* status;        // N
+    u32* tstate;            // [52][N]
+    u32* sv;                // [SV_COUNT*8][N]
+    u32* msc;               // [4*49*8][N]
+    u32* pbuf;              // [PB_COUNT*24][N]
+    pt* straus;             // [N][2][9]
+    FbTable fb;
+    strobe base;
+};
+struct MsmJob {             // one fixed-base MSM per proof: sum over up to 3 contiguous base ranges of scalar set `set`
+    int set, out_slot, nranges;
+    int first[3], count[3];
+};
+
+HD void pw_ld_sc(sc& r, const ProveWs& w, size_t t, int slot) { ws_ld8(r.v, w.sv, w.N, t, slot); }
+HD void pw_st_sc(const ProveWs& w, size_t t, int slot, const sc& r) { ws_st8(w.sv, w.N, t, slot, r.v); }
+HD void pw_st_msc(const ProveWs& w, size_t t, int set, int base, const sc& r) { ws_st8(w.msc, w.N, t, set * BPPP_NG + base, r.v); }
+HD void pw_ld_msc(sc& r, const ProveWs& w, size_t t, int set, int base) { ws_ld8(r.v, w.msc, w.N, t, set * BPPP_NG + base); }
+HD void pw_ld_pt(pt& p, const ProveWs& w, size_t t, int slot) { ws_ld_pt(p, w.pbuf + (size_t)slot * 24 * w.N, w.N, t); }
+HD void pw_st_pt(const ProveWs& w, size_t t, int slot, const pt& p) { ws_st_pt(w.pbuf + (size_t)slot * 24 * w.N, w.N, t, p); }
+HD bool pw_rnd(sc& r, const ProveWs& w, size_t t, int i) { return sc_from_be(r, w.rnd + ((size_t)t * 52 + i) * 32); }
+
+// MSM lane work (8 lanes per proof on the device; the caller tree-adds the partial sums)
+HD void prove_msm_lane(pt& part, const ProveWs& w, const MsmJob& job, size_t t, int lane) {
+    pt acc;
+    pt_set_identity(acc);
+#pragma nounroll
+    for (int r = 0; r < job.nranges; r++) {
+        pt p;
+        fixed_base_msm_partial(p, w.fb, t, lane, w.msc, job.set * BPPP_NG + job.first[r], job.first[r], job.count[r]);
+        pt_add(acc, acc, p);
+    }
+    part = acc;
+}
+HD void prove_msm_store(const ProveWs& w, const MsmJob& job, size_t t, const pt& total) { pw_st_pt(w, t, job.out_slot, total); }
+HD void prove_msm(const ProveWs& w, const MsmJob& job, size_t t) {   // single-thread form (host emulation)
+    pt acc, part;
+    pt_set_identity(acc);
+    for (int lane = 0; lane < BPPP_FB_LANES; lane++) {
+        prove_msm_lane(part, w, job, t, lane);
+        pt_add(acc, acc, part);
+    }
+    prove_msm_store(w, job, t, acc);
+}
+
+// K points -> affine with one field inversion (Montgomery trick); identity (Z = 0) -> (0, 0)
+template <int K>
+HD void batch_to_affine(apt* out, const pt* in) {
+    fe pre[K], run;
+    fe_set_u32(run, 1);
+#pragma nounroll
+    for (int i = 0; i < K; i++) {
+        pre[i] = run;
+        fe m;
+        fe_mul(m, run, in[i].Z);
+        fe_cmov(run, !fe_is_zero(in[i].Z), m);
+    }
+    fe inv;
+    fe_inv(inv, run);
+#pragma nounroll
+    for (int i = K - 1; i >= 0; i--) {
+        bool id = fe_is_zero(in[i].Z);
+        fe zi, m;
+        fe_mul(zi, inv, pre[i]);
+        fe_mul(m, inv, in[i].Z);
+        fe_cmov(inv, !id, m);
+        fe_mul(out[i].x, in[i].X, zi);
+        fe_mul(out[i].y, in[i].Y, zi);
+        if (id) { fe_set_u32(out[i].x, 0); fe_set_u32(out[i].y, 0); }
+    }
+}
+// hex digits and their multiplicities (u64_proof.rs:84-102)
+HD u32 u64_digit(uint64_t x, int j) { return (u32)(x >> (4 * j)) & 15u; }
+HD u32 u64_multiplicity(uint64_t x, int d) {
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) c += (((u32)(x >> (4 * j)) & 15u) == (u32)d) ? 1u : 0u;
+    return c;
+}
+
+// ---------------------------------------------------------------- stage A: scalars of V = x*g + s*h_vec[0]   (reciprocal.rs:88-90)
+HD void prove_stage_a(const ProveWs& w, size_t t) {
+    sc xs, ss;
+    int32_t status = ST_OK;
+    sc_set_u64(xs, w.x[t]);
+    if (!sc_from_be(ss, w.s + 32 * t)) { status |= ST_BAD_ENCODING; sc_set_u32(ss, 0); }
+    pw_st_msc(w, t, 0, 0, xs);
+    pw_st_msc(w, t, 0, 17, ss);
+    w.status[t] = status;
+}
+// ---------------------------------------------------------------- stage B: V -> transcript -> e, reciprocals, scalars of r_com, c_o, c_l, c_r
+HD void prove_stage_b(const ProveWs& w, size_t t) {
+    const uint64_t x = w.x[t];
+    int32_t status = w.status[t];
+    pt V;
+    pw_ld_pt(V, w, t, PB_V);
+    apt Va;
+    pt_to_affine(Va, V);
+    apt_to_xy64(w.commitments + 64 * t, Va);
+    strobe tr = w.base;
+    app_point(tr, "reciprocal_commitment", Va);                          // reciprocal.rs:114
+    sc e;
+    if (!t_get_challenge(tr, "reciprocal_challenge", e)) { status |= ST_DEGENERATE; sc_set_u32(e, 1); }
+    ws_st_strobe(w.tstate, w.N, t, tr);
+    pw_st_sc(w, t, SV_E, e);
+    // (e + j)^-1 for j = 0..15 with one inversion; r_i = (digit_i + e)^-1 = inv[digit_i]   (reciprocal.rs:117-119)
+    sc a[16], pre[16], one;
+    sc_set_u32(one, 1);
+    bool zero_inv = false;
+#pragma nounroll
+    for (int j = 0; j < 16; j++) {
+        sc js;
+        sc_set_u32(js, (u32)j);
+        sc_add(a[j], e, js);
+        bool z = sc_is_zero(a[j]);
+        zero_inv |= z;
+        if (z) a[j] = one;
+        if (j == 0) pre[0] = a[0];
+        else sc_mul(pre[j], pre[j - 1], a[j]);
+    }
+    if (zero_inv) status |= ST_DEGENERATE;
+    sc inv;
+    sc_inv(inv, pre[15]);
+#pragma nounroll
+    for (int j = 15; j >= 1; j--) {
+        sc aj;
+        sc_mul(aj, inv, pre[j - 1]);
+        sc_mul(inv, inv, a[j]);
+        a[j] = aj;
+    }
+    a[0] = inv;
+#pragma nounroll
+    for (int j = 0; j < 16; j++) pw_st_sc(w, t, SV_EINV0 + j, a[j]);
+    sc rnd[19];
+    bool rok = true;
+#pragma nounroll
+    for (int i = 0; i < 19; i++) rok &= pw_rnd(rnd[i], w, t, i);
+    if (!rok) {
+        status |= ST_BAD_ENCODING;
+#pragma nounroll
+        for (int i = 0; i < 19; i++) sc_set_u32(rnd[i], 0);
+    }
+    sc zero;
+    sc_set_u32(zero, 0);
+    // r_com = r_blind*h[0] + <h[9..], r>          (set 0: bases 17, 26..41)   reciprocal.rs:93-95,121-122
+    pw_st_msc(w, t, 0, 17, rnd[0]);
+    // c_o: ro over h[0..9)                         (set 1: bases 17..25)       circuit.rs:264-274,335-337
+    // c_l: d over g_vec, rl ‖ m over h[0..25)      (set 2: bases 1..16, 17..41)  circuit.rs:276-286,339-341
+    // c_r: r over g_vec, rr over h[0..9)           (set 3: bases 1..16, 17..25)  circuit.rs:288-298,343-345
+    const int ro_idx[9] = {1, 2, 3, 4, -1, 5, 6, 7, -1};
+    const int rl_idx[9] = {8, 9, 10, -1, 11, 12, 13, -1, -1};
+    const int rr_idx[9] = {14, 15, -1, 16, 17, 18, -1, -1, -1};
+#pragma nounroll
+    for (int i = 0; i < 9; i++) {
+        pw_st_msc(w, t, 1, 17 + i, ro_idx[i] >= 0 ? rnd[ro_idx[i]] : zero);
+        pw_st_msc(w, t, 2, 17 + i, rl_idx[i] >= 0 ? rnd[rl_idx[i]] : zero);
+        pw_st_msc(w, t, 3, 17 + i, rr_idx[i] >= 0 ? rnd[rr_idx[i]] : zero);
+    }
+#pragma nounroll
+    for (int j = 0; j < 16; j++) {
+        sc r = a[0];
+        u32 d = u64_digit(x, j);
+#pragma nounroll
+        for (int q = 0; q < 16; q++)
+            if ((u32)q == d) r = a[q];
+        pw_st_sc(w, t, SV_R0 + j, r);
+        pw_st_msc(w, t, 0, 26 + j, r);
+        pw_st_msc(w, t, 3, 1 + j, r);
+        sc ds, ms;
+        sc_set_u32(ds, d);
+        sc_set_u32(ms, u64_multiplicity(x, j));
+        pw_st_msc(w, t, 2, 1 + j, ds);
+        pw_st_msc(w, t, 2, 26 + j, ms);
+    }
+    sc ssc, svv;
+    if (!sc_from_be(ssc, w.s + 32 * t)) sc_set_u32(ssc, 0);
+    sc_add(svv, ssc, rnd[0]);                                            // s_v = s + r_blind  (reciprocal.rs:135)
+    pw_st_sc(w, t, SV_SV, svv);
+    w.status[t] = status;
+}
+// ---------------------------------------------------------------- stage D: transcript to delta; f_, rs; scalars of c_s
+HD void prove_stage_d(const ProveWs& w, size_t t) {
+    const size_t N = w.N;
+    const uint64_t x = w.x[t];
+    int32_t status = w.status[t];
+    pt P[5];   // cl, cr, co, Vc = V + r_com, r_com
+    pt V;
+    pw_ld_pt(P[0], w, t, PB_CL);
+    pw_ld_pt(P[1], w, t, PB_CR);
+    pw_ld_pt(P[2], w, t, PB_CO);
+    pw_ld_pt(P[4], w, t, PB_RCOM);
+    pw_ld_pt(V, w, t, PB_V);
+    pt_add(P[3], V, P[4]);                                               // circuit.commit(v, s + r_blind) (reciprocal.rs:142) = V + r_com
+    apt A[5];
+    batch_to_affine<5>(A, P);
+    uint8_t* pb = w.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
+    apt_to_xy64(pb + 0, A[0]);          // c_l
+    apt_to_xy64(pb + 64, A[1]);         // c_r
+    apt_to_xy64(pb + 128, A[2]);        // c_o
+    apt_to_xy64(pb + 64 * 12, A[4]);    // reciprocal proof.r
+    strobe tr;
+    ws_ld_strobe(tr, w.tstate, N, t);
+    app_point(tr, "commitment_cl", A[0]);                                // circuit.rs:347-350
+    app_point(tr, "commitment_cr", A[1]);
+    app_point(tr, "commitment_co", A[2]);
+    app_point(tr, "commitment_v", A[3]);
+    sc rho, lambda, beta, delta;
+    bool cok = t_get_challenge(tr, "circuit_rho", rho);                  // circuit.rs:352-355
+    cok &= t_get_challenge(tr, "circuit_lambda", lambda);
+    cok &= t_get_challenge(tr, "circuit_beta", beta);
+    cok &= t_get_challenge(tr, "circuit_delta", delta);
+    if (!cok) { status |= ST_DEGENERATE; sc_set_u32(rho, 1); sc_set_u32(lambda, 1); sc_set_u32(beta, 1); sc_set_u32(delta, 1); }
+    ws_st_strobe(w.tstate, N, t, tr);
+    sc e, mu;
+    pw_ld_sc(e, w, t, SV_E);
+    sc_mul(mu, rho, rho);
+    // inverses of mu, beta, rho (delta^-1 is unwrapped by the reference, circuit.rs:401, but multiplies only zeros here)
+    sc iv[3] = {mu, beta, rho}, pre[3], one;
+    sc_set_u32(one, 1);
+    bool zero_inv = sc_is_zero(delta);
+#pragma nounroll
+    for (int i = 0; i < 3; i++) {
+        bool z = sc_is_zero(iv[i]);
+        zero_inv |= z;
+        if (z) iv[i] = one;
+        if (i == 0) pre[0] = iv[0];
+        else sc_mul(pre[i], pre[i - 1], iv[i]);
+    }
+    if (zero_inv) status |= ST_DEGENERATE;
+    sc inv;
+    sc_inv(inv, pre[2]);
+#pragma nounroll
+    for (int i = 2; i >= 1; i--) {
+        sc ai;
+        sc_mul(ai, inv, pre[i - 1]);
+        sc_mul(inv, inv, iv[i]);
+        iv[i] = ai;
+    }
+    iv[0] = inv;
+    const sc mu_inv = iv[0], beta_inv = iv[1], rho_inv = iv[2];
+    pw_st_sc(w, t, SV_RHO, rho); pw_st_sc(w, t, SV_MU, mu); pw_st_sc(w, t, SV_RHOINV, rho_inv);
+    pw_st_sc(w, t, SV_LAMBDA, lambda); pw_st_sc(w, t, SV_BETA, beta); pw_st_sc(w, t, SV_DELTA, delta);
+    pw_st_sc(w, t, SV_MUINV, mu_inv);
+    // S = sum_{i=1..16} lambda^i
+    sc S = lambda, lp = lambda;
+#pragma nounroll
+    for (int i = 1; i < 16; i++) { sc_mul(lp, lp, lambda); sc_add(S, S, lp); }
+    // prover randomness ls (17), ns (16): draws 19..35, 36..51   (circuit.rs:371-372)
+    bool rok = true;
+    sc f0, f1, f2, f3, f4, f5, f6, t1, t2;
+    sc_set_u32(f0, 0); sc_set_u32(f1, 0); sc_set_u32(f2, 0); sc_set_u32(f3, 0); sc_set_u32(f4, 0); sc_set_u32(f5, 0); sc_set_u32(f6, 0);
+    sc mip = mu_inv, mp = mu;
+    lp = lambda;
+#pragma nounroll
+    for (int j = 0; j < 16; j++) {
+        sc ls_j, ns_j, r_j, einv_j, d_j, m_j, p16;
+        rok &= pw_rnd(ls_j, w, t, 19 + j);
+        rok &= pw_rnd(ns_j, w, t, 36 + j);
+        pw_ld_sc(r_j, w, t, SV_R0 + j);
+        pw_ld_sc(einv_j, w, t, SV_EINV0 + j);
+        sc_set_u32(d_j, u64_digit(x, j));
+        sc_set_u32(m_j, u64_multiplicity(x, j));
+        pw_st_msc(w, t, 0, 26 + j, ls_j);          // c_s: ls over h[9..]
+        pw_st_msc(w, t, 0, 1 + j, ns_j);           // c_s: ns over g_vec
+        // c_nL[j] = -16^j mu^-(j+1); c_nR[j] = (S - lambda^(j+1)) mu^-(j+1) + e; c_lL[j] = -S (e+j)^-1
+        sc cnl, cnr, cll;
+        sc_set_u64(p16, (u64)1 << (4 * j));
+        sc_mul(cnl, p16, mip);
+        sc_neg(cnl, cnl);
+        sc_sub(cnr, S, lp);
+        sc_mul(cnr, cnr, mip);
+        sc_add(cnr, cnr, e);
+        sc_mul(cll, S, einv_j);
+        sc_neg(cll, cll);
+        sc A_, B_;
+        sc_add(A_, d_j, cnr);                      // nl + c_nR
+        sc_add(B_, r_j, cnl);                      // nr + c_nL
+        // f0 -= ns^2 mu^(j+1)                                              (circuit.rs:406)
+        sc_mul(t1, ns_j, ns_j); sc_mul(t1, t1, mp); sc_sub(f0, f0, t1);
+        // f1 += lambda^(j+1) ls_j                                          (circuit.rs:409)
+        sc_mul(t1, lp, ls_j); sc_add(f1, f1, t1);
+        // f2 -= 2 ns A mu^(j+1)                                            (circuit.rs:415)
+        sc_mul(t1, ns_j, A_); sc_mul(t1, t1, mp); sc_add(t1, t1, t1); sc_sub(f2, f2, t1);
+        // f3 += 2 c_lL ls + lambda^(j+1) m + 2 ns B mu^(j+1)               (circuit.rs:419-422)
+        sc_mul(t1, cll, ls_j); sc_add(t1, t1, t1); sc_add(f3, f3, t1);
+        sc_mul(t1, lp, m_j); sc_add(f3, f3, t1);
+        sc_mul(t1, ns_j, B_); sc_mul(t1, t1, mp); sc_add(t1, t1, t1); sc_add(f3, f3, t1);
+        // f4 += (c_nR^2 - A^2) mu^(j+1)                                    (circuit.rs:426,433)
+        sc_mul(t1, cnr, cnr); sc_mul(t2, A_, A_); sc_sub(t1, t1, t2); sc_mul(t1, t1, mp); sc_add(f4, f4, t1);
+        // f5 += (c_nL^2 - B^2) mu^(j+1)                                    (circuit.rs:439,444)
+        sc_mul(t1, cnl, cnl); sc_mul(t2, B_, B_); sc_sub(t1, t1, t2); sc_mul(t1, t1, mp); sc_add(f5, f5, t1);
+        // f6 += 2 c_lL v_1[j], v_1 = 2 r                                   (circuit.rs:449, 392-395)
+        sc_mul(t1, cll, r_j); sc_add(t1, t1, t1); sc_add(t1, t1, t1); sc_add(f6, f6, t1);
+        sc_mul(mip, mip, mu_inv);
+        sc_mul(lp, lp, lambda);
+        sc_mul(mp, mp, mu);
+    }
+    sc ls16;
+    rok &= pw_rnd(ls16, w, t, 19 + 16);
+    pw_st_msc(w, t, 0, 26 + 16, ls16);
+    sc ro[9], rl[9], rr[9];
+#pragma nounroll
+    for (int i = 0; i < 9; i++) { pw_ld_msc(ro[i], w, t, 1, 17 + i); pw_ld_msc(rl[i], w, t, 2, 17 + i); pw_ld_msc(rr[i], w, t, 3, 17 + i); }
+    if (!rok) status |= ST_BAD_ENCODING;
+    // rs (circuit.rs:457-467), f7 = 0, rv[0] = 2 (s + r_blind)
+    sc rs[9], svv, rv0;
+    pw_ld_sc(svv, w, t, SV_SV);
+    sc_add(rv0, svv, svv);
+    sc_mul(t1, ro[1], delta); sc_mul(t1, t1, beta); sc_add(rs[0], f1, t1);
+    sc_mul(rs[1], f0, beta_inv);
+    sc_mul(t1, ro[0], delta); sc_add(t1, t1, f2); sc_mul(t1, t1, beta_inv); sc_sub(rs[2], t1, rl[1]);
+    sc_sub(t1, f3, rl[0]); sc_mul(t1, t1, beta_inv); sc_mul(t2, ro[2], delta); sc_add(t2, t2, rr[1]); sc_add(rs[3], t1, t2);
+    sc_add(t1, f4, rr[0]); sc_mul(t1, t1, beta_inv); sc_mul(t2, ro[3], delta); sc_sub(t2, t2, rl[2]); sc_add(rs[4], t1, t2);
+    sc_mul(t1, rv0, beta_inv); sc_neg(rs[5], t1);
+    sc_mul(t1, f5, beta_inv); sc_mul(t2, ro[5], delta); sc_add(t1, t1, t2); sc_add(t1, t1, rr[3]); sc_sub(rs[6], t1, rl[4]);
+    sc_mul(t1, f6, beta_inv); sc_add(t1, t1, rr[4]); sc_mul(t2, ro[6], delta); sc_add(t1, t1, t2); sc_sub(rs[7], t1, rl[5]);
+    sc_mul(t1, ro[7], delta); sc_sub(t1, t1, rl[6]); sc_add(rs[8], t1, rr[5]);
+#pragma nounroll
+    for (int i = 0; i < 9; i++) pw_st_msc(w, t, 0, 17 + i, rs[i]);       // c_s: rs over h[0..9)   (circuit.rs:469-470)
+    w.status[t] = status;
+}
+// ---------------------------------------------------------------- stage F: c_s -> tau; l, n, c, v; scalars of C0; WNLA state
+HD void prove_stage_f(const ProveWs& w, size_t t) {
+    const size_t N = w.N;
+    const uint64_t x = w.x[t];
+    int32_t status = w.status[t];
+    pt CS;
+    pw_ld_pt(CS, w, t, PB_CS);
+    apt csa;
+    pt_to_affine(csa, CS);
+    apt_to_xy64(w.proofs + (size_t)BPPP_U64_PROOF_BYTES * t + 192, csa);
+    strobe tr;
+    ws_ld_strobe(tr, w.tstate, N, t);
+    app_point(tr, "commitment_cs", csa);                                 // circuit.rs:472
+    sc tau;
+    if (!t_get_challenge(tr, "circuit_tau", tau)) { status |= ST_DEGENERATE; sc_set_u32(tau, 1); }
+    ws_st_strobe(w.tstate, N, t, tr);
+    if (sc_is_zero(tau)) { status |= ST_DEGENERATE; sc_set_u32(tau, 1); }
+    sc tau_inv, tau2, tau3, e, mu, mu_inv, lambda, beta, delta, svv;
+    sc_inv(tau_inv, tau);
+    sc_mul(tau2, tau, tau);
+    sc_mul(tau3, tau2, tau);
+    pw_ld_sc(e, w, t, SV_E); pw_ld_sc(mu, w, t, SV_MU); pw_ld_sc(mu_inv, w, t, SV_MUINV); pw_ld_sc(lambda, w, t, SV_LAMBDA);
+    pw_ld_sc(beta, w, t, SV_BETA); pw_ld_sc(delta, w, t, SV_DELTA); pw_ld_sc(svv, w, t, SV_SV);
+    sc zero, one, t1, t2;
+    sc_set_u32(zero, 0);
+    sc_set_u32(one, 1);
+    // l[0..9) = tau^-1 rs - delta ro + tau rl - tau^2 rr + tau^3 rv                      (circuit.rs:479-483)
+#pragma nounroll
+    for (int i = 0; i < 9; i++) {
+        sc rs_i, ro_i, rl_i, rr_i, li;
+        pw_ld_msc(rs_i, w, t, 0, 17 + i); pw_ld_msc(ro_i, w, t, 1, 17 + i); pw_ld_msc(rl_i, w, t, 2, 17 + i); pw_ld_msc(rr_i, w, t, 3, 17 + i);
+        sc_mul(li, tau_inv, rs_i);
+        sc_mul(t1, delta, ro_i); sc_sub(li, li, t1);
+        sc_mul(t1, tau, rl_i); sc_add(li, li, t1);
+        sc_mul(t1, tau2, rr_i); sc_sub(li, li, t1);
+        if (i == 0) { sc_add(t1, svv, svv); sc_mul(t1, t1, tau3); sc_add(li, li, t1); }   // rv[0] = 2 (s + r_blind)
+        pw_st_sc(w, t, SV_L0 + i, li);
+    }
+    // S, closed forms as in the verifier
+    sc S = lambda, lp = lambda, mp = mu, musum = mu;
+#pragma nounroll
+    for (int i = 1; i < 16; i++) { sc_mul(lp, lp, lambda); sc_add(S, S, lp); sc_mul(mp, mp, mu); sc_add(musum, musum, mp); }
+    sc tau_e, two_tau2_S, two_tau3, ps;
+    sc_mul(tau_e, tau, e);
+    sc_mul(two_tau2_S, tau2, S);
+    sc_add(two_tau2_S, two_tau2_S, two_tau2_S);
+    sc_add(two_tau3, tau3, tau3);
+    sc_set_u32(ps, 0);
+    sc mip = mu_inv;
+    lp = lambda;
+    mp = mu;
+#pragma nounroll
+    for (int j = 0; j < 16; j++) {
+        sc ls_j, ns_j, r_j, einv_j, d_j, m_j, p16, pn, lj, nj, cj;
+        pw_ld_msc(ls_j, w, t, 0, 26 + j);
+        pw_ld_msc(ns_j, w, t, 0, 1 + j);
+        pw_ld_sc(r_j, w, t, SV_R0 + j);
+        pw_ld_sc(einv_j, w, t, SV_EINV0 + j);
+        sc_set_u32(d_j, u64_digit(x, j));
+        sc_set_u32(m_j, u64_multiplicity(x, j));
+        // l[9+j] = tau^-1 ls + tau ll + tau^3 v_1,  ll = m, v_1 = 2 r
+        sc_mul(lj, tau_inv, ls_j);
+        sc_mul(t1, tau, m_j); sc_add(lj, lj, t1);
+        sc_mul(t1, two_tau3, r_j); sc_add(lj, lj, t1);
+        pw_st_sc(w, t, SV_L0 + 9 + j, lj);
+        // pn_tau[j] (circuit.rs:485-487)
+        sc_set_u64(p16, (u64)1 << (4 * j));
+        sc_mul(t1, tau2, p16);
+        sc_sub(t2, S, lp);
+        sc_mul(t2, t2, tau);
+        sc_add(t1, t1, t2);
+        sc_mul(pn, t1, mip);
+        sc_add(pn, pn, tau_e);
+        sc_mul(t1, pn, pn); sc_mul(t1, t1, mp); sc_add(ps, ps, t1);
+        // n[j] = pn_tau + tau^-1 ns - delta no + tau nl - tau^2 nr   (circuit.rs:493-498), no = 0, nl = d, nr = r
+        sc_mul(nj, tau_inv, ns_j);
+        sc_mul(t1, tau, d_j); sc_add(nj, nj, t1);
+        sc_mul(t1, tau2, r_j); sc_sub(nj, nj, t1);
+        sc_add(nj, nj, pn);
+        pw_st_sc(w, t, SV_N0 + j, nj);
+        // c[9+j] = cl_tau[j] = 2 tau^2 S (e+j)^-1 - lambda^(j+1)
+        sc_mul(cj, two_tau2_S, einv_j);
+        sc_sub(cj, cj, lp);
+        pw_st_sc(w, t, SV_C0 + 9 + j, cj);
+        sc_mul(mip, mip, mu_inv);
+        sc_mul(lp, lp, lambda);
+        sc_mul(mp, mp, mu);
+    }
+    {   // l[25] = tau^-1 ls[16]; l[26..32) = 0; c[25..32) = 0     (circuit.rs:526-529)
+        sc ls16, l25;
+        pw_ld_msc(ls16, w, t, 0, 26 + 16);
+        sc_mul(l25, tau_inv, ls16);
+        pw_st_sc(w, t, SV_L0 + 25, l25);
+        pw_st_sc(w, t, SV_C0 + 25, zero);
+#pragma nounroll
+        for (int i = 26; i < 32; i++) { pw_st_sc(w, t, SV_L0 + i, zero); pw_st_sc(w, t, SV_C0 + i, zero); }
+    }
+    // cr_tau
+    pw_st_sc(w, t, SV_C0, one);
+    sc_mul(t1, beta, tau_inv);
+    pw_st_sc(w, t, SV_C0 + 1, t1);
+    sc bt = beta;
+#pragma nounroll
+    for (int i = 2; i < 9; i++) { sc_mul(bt, bt, tau); pw_st_sc(w, t, SV_C0 + i, bt); }
+    // v = ps_tau + tau^3 v_0, v_0 = 2 x        (circuit.rs:518, 376-381)
+    sc_mul(t1, two_tau3, musum);
+    sc_sub(ps, ps, t1);
+    sc xs;
+    sc_set_u64(xs, x);
+    sc_mul(t1, two_tau3, xs);
+    sc_add(ps, ps, t1);
+    // scalars of C0 = v g + <h, l> + <g_vec, n>  (set 0: bases 0..42)   circuit.rs:520-524
+    pw_st_msc(w, t, 0, 0, ps);
+#pragma nounroll
+    for (int j = 0; j < 16; j++) { sc nj; pw_ld_sc(nj, w, t, SV_N0 + j); pw_st_msc(w, t, 0, 1 + j, nj); }
+#pragma nounroll
+    for (int i = 0; i < 26; i++) { sc li; pw_ld_sc(li, w, t, SV_L0 + i); pw_st_msc(w, t, 0, 17 + i, li); }
+    // generator unrolling coefficients start at 1
+#pragma nounroll
+    for (int i = 0; i < 32; i++) pw_st_sc(w, t, SV_CH0 + i, one);
+#pragma nounroll
+    for (int i = 0; i < 16; i++) pw_st_sc(w, t, SV_CG0 + i, one);
+    w.status[t] = status;
+}
+// ---------------------------------------------------------------- WNLA round k: scalars of X (set 1) and R (set 2)   (wnla.rs:135-160)
+HD void prove_round_scalars(const ProveWs& w, size_t t, int k) {
+    const int sh = k - 1, nl = 32 >> sh, nn = 16 >> sh;
+    sc rho, rho_inv, mu, mu2, t1, t2, vx, vr, zero;
+    sc_set_u32(zero, 0);
+    pw_ld_sc(rho, w, t, SV_RHO); pw_ld_sc(rho_inv, w, t, SV_RHOINV); pw_ld_sc(mu, w, t, SV_MU);
+    sc_mul(mu2, mu, mu);
+    // vx = wvm(n0, n1, mu2) * 2 rho^-1 + <c0, l1> + <c1, l0>;  vr = wvm(n1, n1, mu2) + <c1, l1>
+    sc wx, wr, wpow = mu2;
+    sc_set_u32(wx, 0);
+    sc_set_u32(wr, 0);
+#pragma nounroll
+    for (int m = 0; m < nn / 2; m++) {
+        sc n0, n1;
+        pw_ld_sc(n0, w, t, SV_N0 + 2 * m);
+        pw_ld_sc(n1, w, t, SV_N0 + 2 * m + 1);
+        sc_mul(t1, n0, n1); sc_mul(t1, t1, wpow); sc_add(wx, wx, t1);
+        sc_mul(t1, n1, n1); sc_mul(t1, t1, wpow); sc_add(wr, wr, t1);
+        sc_mul(wpow, wpow, mu2);
+    }
+    sc_add(t1, rho_inv, rho_inv);
+    sc_mul(vx, wx, t1);
+    vr = wr;
+#pragma nounroll
+    for (int m = 0; m < nl / 2; m++) {
+        sc c0, c1, l0, l1;
+        pw_ld_sc(c0, w, t, SV_C0 + 2 * m); pw_ld_sc(c1, w, t, SV_C0 + 2 * m + 1);
+        pw_ld_sc(l0, w, t, SV_L0 + 2 * m); pw_ld_sc(l1, w, t, SV_L0 + 2 * m + 1);
+        sc_mul(t1, c0, l1); sc_add(vx, vx, t1);
+        sc_mul(t1, c1, l0); sc_add(vx, vx, t1);
+        sc_mul(t1, c1, l1); sc_add(vr, vr, t1);
+    }
+    pw_st_msc(w, t, 1, 0, vx);
+    pw_st_msc(w, t, 2, 0, vr);
+    // original h_i sits in folded slot j = i >> (k-1) with coefficient ch[i]:  X gets ch[i] l[j^1], R gets (j odd) ch[i] l[j]
+#pragma nounroll
+    for (int i = 0; i < 32; i++) {
+        int j = i >> sh;
+        sc ch, lx, lr;
+        pw_ld_sc(ch, w, t, SV_CH0 + i);
+        pw_ld_sc(lx, w, t, SV_L0 + (j ^ 1));
+        sc_mul(t1, ch, lx);
+        pw_st_msc(w, t, 1, 17 + i, t1);
+        pw_ld_sc(lr, w, t, SV_L0 + j);
+        sc_mul(t2, ch, lr);
+        pw_st_msc(w, t, 2, 17 + i, (j & 1) ? t2 : zero);
+    }
+    // g_i: X gets cg[i] * (j even ? rho n[j+1] : rho^-1 n[j-1]);  R gets (j odd) cg[i] n[j]
+#pragma nounroll
+    for (int i = 0; i < 16; i++) {
+        int j = i >> sh;
+        sc cg, nx, nr;
+        pw_ld_sc(cg, w, t, SV_CG0 + i);
+        pw_ld_sc(nx, w, t, SV_N0 + (j ^ 1));
+        sc_mul(t1, nx, (j & 1) ? rho_inv : rho);
+        sc_mul(t1, t1, cg);
+        pw_st_msc(w, t, 1, 1 + i, t1);
+        pw_ld_sc(nr, w, t, SV_N0 + j);
+        sc_mul(t2, cg, nr);
+        pw_st_msc(w, t, 2, 1 + i, (j & 1) ? t2 : zero);
+    }
+}
+// ---------------------------------------------------------------- WNLA round k: transcript, challenge, folds, next commitment (wnla.rs:162-188)
+HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
+    const size_t N = w.N;
+    const int sh = k - 1, nl = 32 >> sh, nn = 16 >> sh;
+    int32_t status = w.status[t];
+    pt P[3];   // C_{k-1}, X, R
+    pw_ld_pt(P[0], w, t, PB_C);
+    pw_ld_pt(P[1], w, t, PB_X);
+    pw_ld_pt(P[2], w, t, PB_R);
+    apt A[3];
+    batch_to_affine<3>(A, P);
+    uint8_t* pb = w.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
+    apt_to_xy64(pb + 64 * (8 + (4 - k)), A[1]);     // proof.x is pushed innermost-first (wnla.rs:188): x[4-k] = X of round k
+    apt_to_xy64(pb + 64 * (4 + (4 - k)), A[2]);
+    strobe tr;
+    ws_ld_strobe(tr, w.tstate, N, t);
+    app_point(tr, "wnla_com", A[0]);
+    app_point(tr, "wnla_x", A[1]);
+    app_point(tr, "wnla_r", A[2]);
+    t_append_u64(tr, "l.sz", (u64)nl);
+    t_append_u64(tr, "n.sz", (u64)nn);
+    sc y;
+    if (!t_get_challenge(tr, "wnla_challenge", y)) { status |= ST_DEGENERATE; sc_set_u32(y, 1); }
+    ws_st_strobe(w.tstate, N, t, tr);
+    sc rho, rho_inv, mu, t1;
+    pw_ld_sc(rho, w, t, SV_RHO); pw_ld_sc(rho_inv, w, t, SV_RHOINV); pw_ld_sc(mu, w, t, SV_MU);
+    // l_ = l0 + y l1; c_ = c0 + y c1; n_ = rho^-1 n0 + y n1   (in place: slot m is written after slots 2m, 2m+1 are read)
+#pragma nounroll
+    for (int m = 0; m < nl / 2; m++) {
+        sc a0, a1;
+        pw_ld_sc(a0, w, t, SV_L0 + 2 * m); pw_ld_sc(a1, w, t, SV_L0 + 2 * m + 1);
+        sc_mul(t1, a1, y); sc_add(a0, a0, t1);
+        pw_st_sc(w, t, SV_L0 + m, a0);
+        pw_ld_sc(a0, w, t, SV_C0 + 2 * m); pw_ld_sc(a1, w, t, SV_C0 + 2 * m + 1);
+        sc_mul(t1, a1, y); sc_add(a0, a0, t1);
+        pw_st_sc(w, t, SV_C0 + m, a0);
+    }
+#pragma nounroll
+    for (int m = 0; m < nn / 2; m++) {
+        sc a0, a1;
+        pw_ld_sc(a0, w, t, SV_N0 + 2 * m); pw_ld_sc(a1, w, t, SV_N0 + 2 * m + 1);
+        sc_mul(a0, a0, rho_inv);
+        sc_mul(t1, a1, y); sc_add(a0, a0, t1);
+        pw_st_sc(w, t, SV_N0 + m, a0);
+    }
+    if (k < 4) {
+        // generator coefficients pick up this round's factor
+#pragma nounroll
+        for (int i = 0; i < 32; i++) {
+            if ((i >> sh) & 1) { sc c; pw_ld_sc(c, w, t, SV_CH0 + i); sc_mul(c, c, y); pw_st_sc(w, t, SV_CH0 + i, c); }
+        }
+#pragma nounroll
+        for (int i = 0; i < 16; i++) {
+            sc c;
+            pw_ld_sc(c, w, t, SV_CG0 + i);
+            sc_mul(c, c, ((i >> sh) & 1) ? y : rho);
+            pw_st_sc(w, t, SV_CG0 + i, c);
+        }
+        // rho <- mu, mu <- mu^2, rho^-1 <- (rho^-1)^2           (wnla.rs:180-181; mu = rho^2 at every level)
+        pw_st_sc(w, t, SV_RHO, mu);
+        sc_mul(t1, mu, mu);
+        pw_st_sc(w, t, SV_MU, t1);
+        sc_mul(t1, rho_inv, rho_inv);
+        pw_st_sc(w, t, SV_RHOINV, t1);
+        // next commitment = com + y X + (y^2 - 1) R             (= wnla.commit(l_, n_), wnla.rs:186)
+        sc y2m1, one;
+        sc_set_u32(one, 1);
+        sc_mul(y2m1, y, y);
+        sc_sub(y2m1, y2m1, one);
+        pt* tbl = w.straus + t * (2 * BPPP_STRAUS_ENTRIES);
+        glv_split rs[2];
+        straus_build_table(tbl, A[1]);
+        straus_build_table(tbl + BPPP_STRAUS_ENTRIES, A[2]);
+        glv_decompose(rs[0], y);
+        glv_decompose(rs[1], y2m1);
+        pt acc;
+        straus_msm_glv(acc, tbl, rs, 2);
+        pt_madd(acc, acc, A[0], false);
+        pw_st_pt(w, t, PB_C, acc);
+    } else {
+        // proof.l = [l0, l1], proof.n = [n0]   (wnla.rs:126-133)
+        sc l0, l1, n0;
+        pw_ld_sc(l0, w, t, SV_L0); pw_ld_sc(l1, w, t, SV_L0 + 1); pw_ld_sc(n0, w, t, SV_N0);
+        sc_to_be(pb + 832, l0);
+        sc_to_be(pb + 864, l1);
+        sc_to_be(pb + 896, n0);
+    }
+    w.status[t] = status;
+}
+
+// the MSM jobs of the pipeline, in launch order
+HD MsmJob job_v() { MsmJob j = {0, PB_V, 2, {0, 17, 0}, {1, 1, 0}}; return j; }
+HD MsmJob job_rcom() { MsmJob j = {0, PB_RCOM, 2, {17, 26, 0}, {1, 16, 0}}; return j; }
+HD MsmJob job_co() { MsmJob j = {1, PB_CO, 1, {17, 0, 0}, {9, 0, 0}}; return j; }
+HD MsmJob job_cl() { MsmJob j = {2, PB_CL, 1, {1, 0, 0}, {41, 0, 0}}; return j; }
+HD MsmJob job_cr() { MsmJob j = {3, PB_CR, 1, {1, 0, 0}, {25, 0, 0}}; return j; }
+HD MsmJob job_cs() { MsmJob j = {0, PB_CS, 1, {1, 0, 0}, {42, 0, 0}}; return j; }
+HD MsmJob job_c0() { MsmJob j = {0, PB_C, 1, {0, 0, 0}, {43, 0, 0}}; return j; }
+HD MsmJob job_x() { MsmJob j = {1, PB_X, 1, {0, 0, 0}, {49, 0, 0}}; return j; }
+HD MsmJob job_r() { MsmJob j = {2, PB_R, 1, {0, 0, 0}, {49, 0, 0}}; return j; }
+
+}  // namespace bppp

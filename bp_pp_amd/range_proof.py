@@ -89,6 +89,32 @@ class U64RangeProofProtocol:
                                                              d_accept, d_status or None, d_trace or None,
                                                              d_reject_count or None))
 
+    # ---- prove (u64_proof.rs:57-82)
+    def prove(self, x: int, s: bytes, label: bytes, rnd: bytes) -> bytes:
+        """One proof; `rnd` = the 52 x 32 bytes the reference would draw with Scalar::generate_biased, in draw order."""
+        proofs, _, st = self.prove_batch(np.array([x], dtype=np.uint64), _as_u8(s, (1, 32)), _as_u8(rnd, (1, 52 * 32)), label)
+        if st[0]:
+            raise ValueError(f"prove: status {int(st[0])}")
+        return bytes(proofs[0])
+
+    def prove_batch(self, x: np.ndarray, s, rnd, label: bytes):
+        """Host buffers.  Returns (proofs[n,928], commitments[n,64], status[n])."""
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        n = x.shape[0]
+        s = _as_u8(s, (n, 32))
+        rnd = _as_u8(rnd, (n, 52 * 32))
+        proofs = np.zeros((n, U64_PROOF_BYTES), dtype=np.uint8)
+        com = np.zeros((n, 64), dtype=np.uint8)
+        status = np.zeros(n, dtype=np.int32)
+        _capi.check(_capi.lib().bppp_u64_prove_batch(self._ctx, label, len(label), n, x.ctypes.data, s.ctypes.data,
+                                                     rnd.ctypes.data, proofs.ctypes.data, com.ctypes.data, status.ctypes.data))
+        return proofs, com, status
+
+    def prove_batch_device(self, label: bytes, n: int, d_x: int, d_s: int, d_rnd: int, d_proofs: int, d_commitments: int,
+                           d_status: int = 0) -> None:
+        _capi.check(_capi.lib().bppp_u64_prove_batch_device(self._ctx, label, len(label), n, d_x, d_s, d_rnd, d_proofs,
+                                                            d_commitments, d_status or None))
+
     # ---- plumbing
     def set_stream(self, hip_stream: Optional[int]) -> None:
         _capi.check(_capi.lib().bppp_ctx_set_stream(self._ctx, hip_stream or None))

@@ -84,6 +84,19 @@ BPPP_API int bppp_u64_verify_batch_device(bppp_ctx* ctx, const uint8_t* label, s
                                  const void* d_commitments, const void* d_proofs, void* d_accept, void* d_status,
                                  void* d_trace, void* d_reject_count);
 
+/* U64RangeProofProtocol::prove (u64_proof.rs:57-82) for n independent values, fresh `Transcript::new(label)` per proof.
+ * rnd holds, per proof, the 52 scalars the reference draws with `Scalar::generate_biased(rng)` in its draw order
+ * (reciprocal.rs:121 r_blind | circuit.rs:264-298 ro x7, rl x6, rr x5 | circuit.rs:371 ls x17 | circuit.rs:372 ns x16), so
+ * the output is byte-identical to the reference prover driven by the same RNG stream.  Also returns the commitments
+ * x*g + s*h_vec[0].  status (optional): BPPP_ST_BAD_ENCODING for a non-canonical input scalar, BPPP_ST_DEGENERATE where the
+ * reference would panic.  Host pointers. */
+BPPP_API int bppp_u64_prove_batch(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x,
+                                  const uint8_t* s /* n x 32 */, const uint8_t* rnd /* n x 52 x 32 */,
+                                  uint8_t* proofs /* n x 928 */, uint8_t* commitments /* n x 64 */, int32_t* status /* n or NULL */);
+/* Same with DEVICE buffers, asynchronous on the context's stream. */
+BPPP_API int bppp_u64_prove_batch_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, const void* d_x,
+                                         const void* d_s, const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status);
+
 /* U64RangeProofProtocol::commit_value (u64_proof.rs:37-39): out[i] = x[i]*g + s[i]*h_vec[0], host pointers. */
 BPPP_API int bppp_u64_commit_value_batch(bppp_ctx* ctx, size_t n, const uint64_t* x, const uint8_t* s /* n x 32 */,
                                 uint8_t* out /* n x 64 */);

@@ -6,7 +6,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../../bp_pp_amd/csrc/verify_core.h"
+#include "../../bp_pp_amd/csrc/prove_core.h"
 
 using namespace bppp;
 
@@ -170,6 +170,34 @@ int emul_u64_verify_batch(const uint8_t* table, int W, const uint8_t* label, siz
         for (size_t t = 0; t < n; t++) verify_round(ws, t, k);
     for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);
     for (size_t t = 0; t < n; t++) verify_final_check(ws, t);
+    return 0;
+}
+// full prover pipeline, every stage in thread order
+int emul_u64_prove_batch(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x,
+                         const uint8_t* s, const uint8_t* rnd, uint8_t* proofs, uint8_t* V, int32_t* status) {
+    ProveWs w;
+    memset(&w, 0, sizeof w);
+    w.N = n;
+    w.x = x; w.s = s; w.rnd = rnd; w.proofs = proofs; w.commitments = V; w.status = status;
+    std::vector<u32> tstate(52 * n), sv((size_t)SV_COUNT * 8 * n), msc((size_t)BPPP_MSC_SETS * BPPP_NG * 8 * n), pbuf((size_t)PB_COUNT * 24 * n);
+    std::vector<pt> straus(n * 2 * BPPP_STRAUS_ENTRIES);
+    w.tstate = tstate.data(); w.sv = sv.data(); w.msc = msc.data(); w.pbuf = pbuf.data(); w.straus = straus.data();
+    w.fb.table = (const apt*)table; w.fb.W = W; w.fb.N = n;
+    t_new(w.base, label, (u32)label_len);
+    auto msm = [&](MsmJob job) { for (size_t t = 0; t < n; t++) prove_msm(w, job, t); };
+    for (size_t t = 0; t < n; t++) prove_stage_a(w, t);
+    msm(job_v());
+    for (size_t t = 0; t < n; t++) prove_stage_b(w, t);
+    msm(job_rcom()); msm(job_co()); msm(job_cl()); msm(job_cr());
+    for (size_t t = 0; t < n; t++) prove_stage_d(w, t);
+    msm(job_cs());
+    for (size_t t = 0; t < n; t++) prove_stage_f(w, t);
+    msm(job_c0());
+    for (int k = 1; k <= 4; k++) {
+        for (size_t t = 0; t < n; t++) prove_round_scalars(w, t, k);
+        msm(job_x()); msm(job_r());
+        for (size_t t = 0; t < n; t++) prove_round_fold(w, t, k);
+    }
     return 0;
 }
 }

@@ -153,3 +153,31 @@ def test_full_verify_pipeline_against_golden(L, gold, oracle_c):
         if items[k][3] == 0:
             rc, otr = oracle_c.u64_verify(gens, label, bytes(V[k]), bytes(P[k]), trace=True)
             assert rc == items[k][2] and bytes(tr[k]) == otr
+
+
+def test_full_prove_pipeline_is_byte_identical_to_the_oracle(L, gold, oracle_c):
+    """The device prover code (prove_core.h) on CPU: proofs must equal the reference-shaped prover's bytes for the same
+    (x, s, 52 random scalars), on the golden cases and on fresh seeded cases incl. x = 0 and x = 2^64 - 1."""
+    import workload
+    gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
+    W = 4
+    ent = L.emul_fb_table_entries(49, W)
+    tab = np.zeros(ent * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0
+    cases = gold["cases"]
+    n = len(cases) + 3
+    x = np.array([c["x"] for c in cases] + [int(v) for v in workload.values(3, first=77)], dtype=np.uint64)
+    s = np.concatenate([np.frombuffer(b"".join(bytes.fromhex(c["s"]) for c in cases), dtype=np.uint8).reshape(-1, 32),
+                        workload.blindings(3, first=77)])
+    rnd = np.concatenate([np.frombuffer(b"".join(bytes.fromhex(c["rnd"]) for c in cases), dtype=np.uint8).reshape(-1, 52 * 32),
+                          workload.prover_randomness(3, first=77)])
+    x, s, rnd = np.ascontiguousarray(x), np.ascontiguousarray(s), np.ascontiguousarray(rnd)
+    proofs, V, st = np.zeros((n, 928), np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.int32)
+    L.emul_u64_prove_batch(tab.ctypes.data, W, label, len(label), n, x.ctypes.data, s.ctypes.data, rnd.ctypes.data,
+                           proofs.ctypes.data, V.ctypes.data, st.ctypes.data)
+    assert not st.any()
+    for i, c in enumerate(cases):
+        assert bytes(V[i]).hex() == c["commitment"]
+        assert bytes(proofs[i]).hex() == c["proof"], f"case {i}"
+    op, ov = oracle_c.u64_prove_batch(gens, label, x, s, rnd, nthreads=2)
+    assert (ov == V).all() and (op == proofs).all()

@@ -1,0 +1,76 @@
+"""GPU parity tests of the batch PROVER: proofs produced by the HIP path through the C ABI must be
+byte-identical to the oracle prover's for the same (x, s, 52 prover scalars), and must verify (HIP verifier and oracle)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(GOLD, "u64_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def proto(gold):
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    from bp_pp_amd import U64RangeProofProtocol
+    import workload
+    g, gv, hv = workload.split_generators(bytes.fromhex(gold["generators"]))
+    p = U64RangeProofProtocol(g, gv, hv, device=0)
+    yield p
+    p.close()
+
+
+def test_golden_proofs_byte_exact(proto, gold):
+    label = bytes.fromhex(gold["label"])
+    cases = gold["cases"]
+    x = np.array([c["x"] for c in cases], dtype=np.uint64)
+    s = np.frombuffer(b"".join(bytes.fromhex(c["s"]) for c in cases), dtype=np.uint8).reshape(-1, 32)
+    rnd = np.frombuffer(b"".join(bytes.fromhex(c["rnd"]) for c in cases), dtype=np.uint8).reshape(-1, 52 * 32)
+    proofs, com, st = proto.prove_batch(x, s, rnd, label)
+    assert not st.any()
+    for i, c in enumerate(cases):
+        assert bytes(com[i]).hex() == c["commitment"]
+        assert bytes(proofs[i]).hex() == c["proof"]
+    c = cases[2]
+    assert proto.prove(c["x"], bytes.fromhex(c["s"]), label, bytes.fromhex(c["rnd"])).hex() == c["proof"]   # tests.rs:13-42 shape
+    assert proto.verify(bytes.fromhex(c["commitment"]), bytes.fromhex(c["proof"]), label)
+
+
+@pytest.mark.parametrize("n", [1, 65, 1 << 14])
+def test_batch_prove_vs_oracle(proto, oracle_c, n):
+    """n = 2^14 is BASELINE config 4.  Every proof equals the oracle's trapdoor prover byte for byte (itself equal to the
+    honest reference-shaped prover, tests/test_oracle_c.py); a sample is also proved by the honest prover directly."""
+    import workload
+    first = 5000
+    x, s, rnd = workload.values(n, first), workload.blindings(n, first), workload.prover_randomness(n, first)
+    proofs, com, st = proto.prove_batch(x, s, rnd, workload.LABEL)
+    assert not st.any()
+    op, ov = oracle_c.u64_prove_trapdoor_batch(workload.generator_dlogs(), workload.LABEL, x, s, rnd, nthreads=os.cpu_count() or 1)
+    assert (ov == com).all()
+    assert (op == proofs).all()
+    k = min(n, 8)
+    hp, hv = oracle_c.u64_prove_batch(workload.generators(), workload.LABEL, x[:k], s[:k], rnd[:k], nthreads=k)
+    assert (hp == proofs[:k]).all() and (hv == com[:k]).all()
+    acc, vst = proto.verify_batch(com, proofs, workload.LABEL)          # prove -> verify round trip on the GPU
+    assert acc.all() and not vst.any()
+    m = min(n, 256)
+    oacc, ost = oracle_c.u64_verify_batch(workload.generators(), workload.LABEL, com[:m].copy(), proofs[:m].copy(), nthreads=os.cpu_count() or 1)
+    assert oacc.all() and not ost.any()
+
+
+def test_non_canonical_prover_input_is_flagged(proto):
+    import workload
+    x, s, rnd = workload.values(2, 9), workload.blindings(2, 9).copy(), workload.prover_randomness(2, 9).copy()
+    s[0] = np.frombuffer(workload.N_ORDER.to_bytes(32, "big"), dtype=np.uint8)        # s = n: not a canonical Scalar
+    rnd[1, 32 * 20:32 * 21] = 0xFF                                                      # one prover draw >= n
+    _, _, st = proto.prove_batch(x, s, rnd, workload.LABEL)
+    assert (st & 1).all()
