@@ -35,10 +35,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_build.SO):
+    so = os.environ.get("BPPP_LIB", _build.SO)      # A/B builds of the same ABI (tools/), default: the in-tree build
+    if not os.path.exists(so):
         raise ImportError(f"{_build.SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the bp_pp_amd product path)")
-    L = C.CDLL(_build.SO)
+    L = C.CDLL(so)
     vp, sz, i32, u8p = C.c_void_p, C.c_size_t, C.c_int, C.c_char_p
     L.bppp_ctx_create.argtypes = [C.POINTER(vp), u8p, u8p, u8p, i32, i32]
     L.bppp_ctx_create.restype = i32

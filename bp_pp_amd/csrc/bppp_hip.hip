@@ -26,7 +26,10 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1(VerifyWs ws) {
 }
 // fixed-base MSM kernels: BPPP_FB_LANES lanes per proof, 256-thread workgroups, registers capped for 4 wavefronts per SIMD
 #define BPPP_FB_BLOCK 256
-__global__ __launch_bounds__(BPPP_FB_BLOCK, 4) void k_verify_c0_fixed(VerifyWs ws) {
+#ifndef BPPP_FB_MIN_WAVES
+#define BPPP_FB_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed(VerifyWs ws) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
     size_t t = g / BPPP_FB_LANES;
     int lane = (int)(g % BPPP_FB_LANES);
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(VerifyWs ws
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N) verify_final_scalars(ws, t);
 }
-__global__ __launch_bounds__(BPPP_FB_BLOCK, 4) void k_verify_final_check(VerifyWs ws) {
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(VerifyWs ws) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
     size_t t = g / BPPP_FB_LANES;
     int lane = (int)(g % BPPP_FB_LANES);
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(ProveWs w, int 
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) prove_round_fold(w, t, k);
 }
-__global__ __launch_bounds__(BPPP_FB_BLOCK, 4) void k_prove_msm(ProveWs w, MsmJob job) {
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(ProveWs w, MsmJob job) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
     size_t t = g / BPPP_FB_LANES;
     int lane = (int)(g % BPPP_FB_LANES);
