@@ -166,14 +166,16 @@ struct bppp_ctx {
     int fb_w = 16;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;   // runs the fixed-base half of C0 concurrently with the variable-base half
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     apt* d_gens = nullptr;       // 49
-    apt* d_table = nullptr;
+    apt_packed* d_table = nullptr;
     size_t table_bytes = 0;
     // per-proof workspace
     size_t cap = 0;
     u32* d_ws = nullptr;
     size_t ws_bytes = 0;
-    pt* d_straus = nullptr;
+    pt_slot* d_straus = nullptr;
     size_t straus_bytes = 0;
     // prover workspace
     size_t pcap = 0;
@@ -190,7 +192,7 @@ struct bppp_ctx {
     int64_t launches[K_COUNT] = {0};
 };
 
-static const size_t WS_WORDS_PER_PROOF = 52 + 80 + 176 + 200 + 208 + 24 + 24 + 24 + 392;
+static const size_t WS_WORDS_PER_PROOF = 52 + 80 + 176 + 200 + 208 + 24 + 30 + 30 + 392;
 
 static int ensure_capacity(bppp_ctx* c, size_t n) {
     if (n <= c->cap) return BPPP_OK;
@@ -199,13 +201,13 @@ static int ensure_capacity(bppp_ctx* c, size_t n) {
     c->cap = 0;
     size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
     c->ws_bytes = cap * WS_WORDS_PER_PROOF * sizeof(u32);
-    c->straus_bytes = cap * 5 * BPPP_STRAUS_ENTRIES * sizeof(pt);
+    c->straus_bytes = cap * 5 * BPPP_STRAUS_ENTRIES * sizeof(pt_slot);
     HIP_TRY(hipMalloc(&c->d_ws, c->ws_bytes));
     HIP_TRY(hipMalloc(&c->d_straus, c->straus_bytes));
     c->cap = cap;
     return BPPP_OK;
 }
-static const size_t PWS_WORDS_PER_PROOF = 52 + (size_t)SV_COUNT * 8 + (size_t)BPPP_MSC_SETS * BPPP_NG * 8 + (size_t)PB_COUNT * 24;
+static const size_t PWS_WORDS_PER_PROOF = 52 + (size_t)SV_COUNT * 8 + (size_t)BPPP_MSC_SETS * BPPP_NG * 8 + (size_t)PB_COUNT * 30;
 static int ensure_prove_capacity(bppp_ctx* c, size_t n) {
     int rc = ensure_capacity(c, n);   // Straus tables are shared with the verifier workspace
     if (rc != BPPP_OK) return rc;
@@ -235,8 +237,8 @@ static void carve(bppp_ctx* c, VerifyWs& ws, size_t n) {
     ws.cvec = p; p += 200 * n;
     ws.pts = p; p += 208 * n;
     ws.lns = p; p += 24 * n;
-    ws.acc = p; p += 24 * n;
-    ws.pfix = p; p += 24 * n;
+    ws.acc = p; p += 30 * n;
+    ws.pfix = p; p += 30 * n;
     ws.fsc = p; p += 392 * n;
     ws.straus = c->d_straus;
     ws.fb_table = c->d_table;
@@ -244,7 +246,7 @@ static void carve(bppp_ctx* c, VerifyWs& ws, size_t n) {
 }
 
 template <typename F>
-static int timed(bppp_ctx* c, int id, F&& launch) {
+static int timed(bppp_ctx* c, int id, hipStream_t st, F&& launch) {
     if (!c->timing) {
         launch();
         return BPPP_OK;
@@ -257,15 +259,16 @@ static int timed(bppp_ctx* c, int id, F&& launch) {
     tl.id = id;
     HIP_TRY(get_event(tl.a));
     HIP_TRY(get_event(tl.b));
-    HIP_TRY(hipEventRecord(tl.a, c->stream));
+    HIP_TRY(hipEventRecord(tl.a, st));
     launch();
-    HIP_TRY(hipEventRecord(tl.b, c->stream));
+    HIP_TRY(hipEventRecord(tl.b, st));
     c->pending.push_back(tl);
     return BPPP_OK;
 }
 static int drain_timings(bppp_ctx* c) {
     if (c->pending.empty()) return BPPP_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->aux_stream));
     for (auto& tl : c->pending) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, tl.a, tl.b));
@@ -336,6 +339,9 @@ int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, c
     } while (0)
     HIP_TRY_C(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
+    HIP_TRY_C(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIP_TRY_C(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY_C(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRY_C(hipMalloc(&c->d_gens, BPPP_NG * sizeof(apt)));
     HIP_TRY_C(hipMalloc(&c->d_flags, sizeof(int)));
     HIP_TRY_C(hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
@@ -357,20 +363,18 @@ int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, c
     const int nwin = 256 / W;
     const size_t per_win = ((size_t)1 << W) - 1;
     const size_t entries = (size_t)BPPP_NG * nwin * per_win;
-    c->table_bytes = entries * sizeof(apt);
+    c->table_bytes = entries * sizeof(apt_packed);
     HIP_TRY_C(hipMalloc(&c->d_table, c->table_bytes));
-    fe *d_z = nullptr, *d_p = nullptr;
-    HIP_TRY_C(hipMalloc(&d_z, entries * sizeof(fe)));
-    HIP_TRY_C(hipMalloc(&d_p, entries * sizeof(fe)));
-    FbBuild fb{c->d_gens, BPPP_NG, W, c->d_table, d_z, d_p};
+    fe* d_tmp = nullptr;   // x, y, z, prefix products of every entry (freed after the build)
+    HIP_TRY_C(hipMalloc(&d_tmp, entries * 4 * sizeof(fe)));
+    FbBuild fb{c->d_gens, BPPP_NG, W, c->d_table, d_tmp, d_tmp + entries, d_tmp + 2 * entries, d_tmp + 3 * entries};
     size_t nthreads = (size_t)BPPP_NG * nwin * fb_chunks_per_window(W);
     unsigned blocks = (unsigned)((nthreads + BPPP_BLOCK - 1) / BPPP_BLOCK);
     k_fb_build_pass1<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
     k_fb_build_pass2<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
     HIP_TRY_C(hipGetLastError());
     HIP_TRY_C(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_z);
-    (void)hipFree(d_p);
+    (void)hipFree(d_tmp);
 #undef HIP_TRY_C
     *out = c;
     return BPPP_OK;
@@ -389,6 +393,9 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->d_pws) (void)hipFree(c->d_pws);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_flags) (void)hipFree(c->d_flags);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -453,20 +460,29 @@ int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label
     if (d_reject_count) HIP_TRY(hipMemsetAsync(d_reject_count, 0, sizeof(int), c->stream));
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     hipStream_t s = c->stream;
-#define LAUNCH(id, ...)                                         \
+#define LAUNCH_ON(st, id, ...)                                  \
     do {                                                        \
-        rc = timed(c, id, [&]() { __VA_ARGS__; });              \
+        rc = timed(c, id, st, [&]() { __VA_ARGS__; });          \
         if (rc != BPPP_OK) return rc;                           \
     } while (0)
+#define LAUNCH(id, ...) LAUNCH_ON(s, id, __VA_ARGS__)
     LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    // C0 = variable-base half (one lane per proof, 1 wave/SIMD) + fixed-base half (8 lanes per proof): independent, so they
+    // run concurrently on two streams and share the SIMDs; round 1 adds the halves.
+    hipStream_t a = c->aux_stream;
+    HIP_TRY(hipEventRecord(c->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
+    LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
+    HIP_TRY(hipEventRecord(c->ev_join, a));
     LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
-    LAUNCH(K_C0_FIXED, k_verify_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+    HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     for (int k = 1; k <= 4; k++) LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
     LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
     LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
 #undef LAUNCH
+#undef LAUNCH_ON
     HIP_TRY(hipGetLastError());
     return BPPP_OK;
 }

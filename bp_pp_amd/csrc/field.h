@@ -4,10 +4,10 @@
 // `FieldElement`; every `.mul/.add/.sub/.invert*` call site in /root/reference/src, e.g.
 // util.rs:28-60, wnla.rs:96-102, circuit.rs:166-235).
 //
-// Representation: 8 x 32-bit little-endian limbs, always canonical (< modulus).  32-bit limbs because
-// the CDNA4 integer multiplier is v_mad_u64_u32 (32x32+64 -> 64): one instruction per limb product, the
-// 64-bit accumulator carries the running column sum.  No MFMA: this is carry-chained integer work.
-// Everything is branch-free (selects), so a 64-lane wavefront never diverges on data.
+// The CDNA4 integer multiplier is v_mad_u64_u32 (32x32+64 -> 64, half rate): one instruction per limb product with the
+// running column sum in the 64-bit accumulator.  Fp (the hot field: ~2.5e4 multiplications per verify) uses 10 x 26-bit
+// unsaturated limbs; Fn (scalars: ~1.5e3 multiplications per verify) uses 8 x 32-bit canonical limbs.  No MFMA: this is
+// carry-chained integer work.  Everything is branch-free (selects), so a 64-lane wavefront never diverges on data.
 #pragma once
 #include <stdint.h>
 
@@ -25,8 +25,7 @@ namespace bppp {
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-struct fe { u32 v[8]; };  // mod p = 2^256 - 2^32 - 977
-struct sc { u32 v[8]; };  // mod n (group order)
+struct sc { u32 v[8]; };  // mod n (group order), 8 x 32-bit limbs, canonical
 
 // ---------------------------------------------------------------- carry primitives
 // hipcc turns __builtin_addc / __builtin_subc chains into v_add_co_u32 / v_addc_co_u32 (32-bit, full rate); the same
@@ -99,56 +98,61 @@ HD bool eq256(const u32 a[8], const u32 b[8]) {
     for (int i = 0; i < 8; i++) x |= a[i] ^ b[i];
     return x == 0;
 }
-// Columns K0..K0+G-1 of the 8x8 limb product, interleaved: each column is a 64-bit accumulator + carry counter.
-template <int K0, int G>
-HD void mul256_cols(u64* acc, u32* cnt, const u32* a, const u32* b) {
+// Columns K0..K0+G-1 of the NA x NB limb product a*b, interleaved: each column is a 64-bit accumulator + carry counter.
+template <int NA, int NB, int K0, int G>
+HD void mul_cols_group(u64* acc, u32* cnt, const u32* a, const u32* b) {
+    constexpr int NC = NA + NB - 1;
 #pragma unroll
     for (int g = 0; g < G; g++) {
         const int k = K0 + g;
-        if (k > 14) continue;
-        const int i0 = k < 8 ? 0 : k - 7;
+        if (k >= NC) continue;
+        const int i0 = k < NB ? 0 : k - (NB - 1);
         acc[k] = (u64)a[i0] * b[k - i0];   // the first product of a column cannot carry
         cnt[k] = 0;
     }
 #pragma unroll
-    for (int s = 1; s < 8; s++) {
+    for (int s = 1; s < (NA < NB ? NA : NB); s++) {
         u64 cr[G];
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int k = K0 + g;
-            if (k > 14) continue;
-            const int i0 = k < 8 ? 0 : k - 7, i1 = k < 8 ? k : 7;
+            if (k >= NC) continue;
+            const int i0 = k < NB ? 0 : k - (NB - 1), i1 = k < NA ? k : NA - 1;
             if (i0 + s <= i1) mad_c(acc[k], cr[g], a[i0 + s], b[k - i0 - s]);
         }
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int k = K0 + g;
-            if (k > 14) continue;
-            const int i0 = k < 8 ? 0 : k - 7, i1 = k < 8 ? k : 7;
+            if (k >= NC) continue;
+            const int i0 = k < NB ? 0 : k - (NB - 1), i1 = k < NA ? k : NA - 1;
             if (i0 + s <= i1) add_c(cnt[k], cr[g]);
         }
     }
 }
-// full 256x256 -> 512 product, product scanning: 64 v_mad_u64_u32 + 49 v_addc (all 15 column sums independent, which
-// is what lets a lone wavefront keep issuing), then one carry-propagation pass (3 full-rate adds per column).
-HD void mul256(u32 t[16], const u32 a[8], const u32 b[8]) {
-    u64 acc[16];
-    u32 cnt[16];
-    mul256_cols<0, 4>(acc, cnt, a, b);
-    mul256_cols<4, 4>(acc, cnt, a, b);
-    mul256_cols<8, 4>(acc, cnt, a, b);
-    mul256_cols<12, 4>(acc, cnt, a, b);
+// t (NA + NB limbs) = a (NA limbs) * b (NB limbs), product scanning: all column sums are accumulated independently
+// (v_mad_u64_u32 + v_addc per limb product, independent columns -> ILP for a lone wavefront), then one carry-propagation
+// pass (3 full-rate adds per column).
+template <int NA, int NB>
+HD void mul_limbs(u32* t, const u32* a, const u32* b) {
+    constexpr int NC = NA + NB - 1;
+    u64 acc[NC + 3];
+    u32 cnt[NC + 3];
+    mul_cols_group<NA, NB, 0, 4>(acc, cnt, a, b);
+    if (NC > 4) mul_cols_group<NA, NB, 4, 4>(acc, cnt, a, b);
+    if (NC > 8) mul_cols_group<NA, NB, 8, 4>(acc, cnt, a, b);
+    if (NC > 12) mul_cols_group<NA, NB, 12, 4>(acc, cnt, a, b);
     t[0] = (u32)acc[0];
     u32 c_lo = (u32)(acc[0] >> 32), c_hi = 0;
 #pragma unroll
-    for (int k = 1; k < 15; k++) {
+    for (int k = 1; k < NC; k++) {
         u32 cy = 0;
         t[k] = addc((u32)acc[k], c_lo, cy);
         c_lo = addc((u32)(acc[k] >> 32), c_hi, cy);
         c_hi = cnt[k] + cy;
     }
-    t[15] = c_lo;
+    t[NC] = c_lo;
 }
+HD void mul256(u32 t[16], const u32 a[8], const u32 b[8]) { mul_limbs<8, 8>(t, a, b); }
 // big-endian 32 bytes <-> limbs
 HD void be32_to_limbs(u32 r[8], const uint8_t* b) {
 #pragma unroll
@@ -165,113 +169,231 @@ HD void limbs_to_be32(uint8_t* b, const u32 a[8]) {
     }
 }
 
-// ---------------------------------------------------------------- Fp: p = 2^256 - PC, PC = 2^32 + 977
-#define BPPP_PC0 0x000003D1u  // low limb of PC; limb 1 of PC is 1
+// ---------------------------------------------------------------- Fp: p = 2^256 - 2^32 - 977, 10 x 26-bit limbs (unsaturated)
+// Why not the saturated 8 x 32 form used for Fn below: measured on MI355X (tools/intbench.hip), a lone wavefront per SIMD --
+// the regime of the shared-doubling kernels at 2^16 proofs -- pays per INSTRUCTION, and the saturated product needs a carry
+// counter per limb product plus canonical selects after every add/sub.  With 26-bit limbs the 100 limb products accumulate
+// into 64-bit columns with no carries at all (v_mad_u64_u32 chains), add is 10 plain adds, sub is 10 add-sub pairs against a
+// multiple of p, and reduction happens once per multiplication: 1.5x the point-addition rate at 1 wave/SIMD, 1.1x at 4.
+//
+// Value = sum v[i] 2^(26 i).  Limbs may exceed 26 bits: "magnitude m" means v[i] <= 2 m (2^26 - 1) for i < 9 and
+// v[9] <= 2 m (2^22 - 1) (the convention of libsecp256k1's 10x26 field).  mul/sqr/mul_small accept magnitudes <= 8 and
+// return magnitude 1; add sums magnitudes; sub/neg add a multiple of p.  The host build (tests/emul) carries the magnitude
+// in the struct and asserts every bound; the device build carries nothing.
+#define BPPP_M26 0x3FFFFFFu
+#define BPPP_M22 0x03FFFFFu
+#define BPPP_R0 0x3D10u        // 2^260 mod p = 2^36 + 0x3D10  ->  R0 at limb 0, 2^10 at limb 1
+#define BPPP_PC0 0x000003D1u   // 2^256 mod p = 2^32 + 0x3D1   ->  0x3D1 at limb 0, 2^6 at limb 1
 
-// x (8 limbs) + carry*2^256, value < 2^256 + small  ->  canonical.  x >= p  <=>  x + PC carries out of 2^256.
-HD void fe_final(fe& r, const u32 x[8], u32 carry) {
-    u32 t[8];
-    u32 c = 0;
-    t[0] = addc(x[0], BPPP_PC0, c);
-    t[1] = addc(x[1], 1u, c);
-#pragma unroll
-    for (int i = 2; i < 8; i++) t[i] = addc(x[i], 0u, c);
-    sel256(r.v, carry | c, x, t);
+#if !defined(__HIPCC__) && !defined(BPPP_NO_FE_DEBUG)
+#define BPPP_FE_DEBUG 1
+#include <assert.h>
+#include <execinfo.h>
+#include <stdio.h>
+#endif
+
+struct fe {
+    u32 v[10];
+#ifdef BPPP_FE_DEBUG
+    int mag;
+#endif
+};
+#ifdef BPPP_FE_DEBUG
+#define FE_SETMAG(x, m) ((x).mag = (m))
+#define FE_MAG(x) ((x).mag)
+inline void fe_check(const fe& a, int max_mag) {
+    if (!(a.mag >= 0 && a.mag <= max_mag)) {
+        fprintf(stderr, "fe_check: magnitude %d exceeds %d\n", a.mag, max_mag);
+        void* bt[24];
+        int n = backtrace(bt, 24);
+        backtrace_symbols_fd(bt, n, 2);
+    }
+    assert(a.mag >= 0 && a.mag <= max_mag);
+    for (int i = 0; i < 9; i++) assert((u64)a.v[i] <= 2ull * (u64)a.mag * BPPP_M26 || (a.mag == 0 && a.v[i] == 0));
+    assert((u64)a.v[9] <= 2ull * (u64)a.mag * BPPP_M22 || (a.mag == 0 && a.v[9] == 0));
 }
-HD void fe_add(fe& r, const fe& a, const fe& b) {
-    u32 s[8];
-    u32 k = add256(s, a.v, b.v);
-    fe_final(r, s, k);
-}
-HD void fe_sub(fe& r, const fe& a, const fe& b) {
-    u32 d[8], e[8];
-    u32 borrow = sub256(d, a.v, b.v);
-    // d + p = d - PC (mod 2^256)
-    u32 bw = 0;
-    e[0] = subb(d[0], BPPP_PC0, bw);
-    e[1] = subb(d[1], 1u, bw);
-#pragma unroll
-    for (int i = 2; i < 8; i++) e[i] = subb(d[i], 0u, bw);
-    sel256(r.v, borrow, d, e);
-}
-HD void fe_neg(fe& r, const fe& a) {
-    fe z;
-#pragma unroll
-    for (int i = 0; i < 8; i++) z.v[i] = 0;
-    fe_sub(r, z, a);
-}
-HD void fe_dbl(fe& r, const fe& a) { fe_add(r, a, a); }
-// reduce a 512-bit value: hi*2^256 + lo == lo + (hi << 32) + hi*977, then fold the (< 2^35) overflow once more
-HD void fe_reduce512(fe& out, const u32 t[16]) {
-    u32 r[9];
-    u32 c = 0;
-    r[0] = t[0];
-#pragma unroll
-    for (int j = 1; j < 8; j++) r[j] = addc(t[j], t[8 + j - 1], c);
-    r[8] = addc(t[15], 0u, c);
-    u32 r9 = c;
-    u64 v[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = (u64)t[8 + j] * BPPP_PC0;
-    c = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) r[j] = addc(r[j], (u32)v[j], c);
-    r[8] = addc(r[8], 0u, c);
-    r9 += c;
-    c = 0;
-#pragma unroll
-    for (int j = 1; j < 8; j++) r[j] = addc(r[j], (u32)(v[j - 1] >> 32), c);
-    r[8] = addc(r[8], (u32)(v[7] >> 32), c);
-    r9 += c;
-    // top = r[8] + r9 * 2^32 (< 2^35); top * PC = top*977 + (top << 32)
-    u64 m = (u64)r[8] * BPPP_PC0 + ((u64)(r9 * BPPP_PC0) << 32);
-    u32 s[8];
-    c = 0;
-    s[0] = addc(r[0], (u32)m, c);
-    s[1] = addc(r[1], (u32)(m >> 32), c);
-#pragma unroll
-    for (int i = 2; i < 8; i++) s[i] = addc(r[i], 0u, c);
-    u32 k1 = c;
-    c = 0;
-    s[1] = addc(s[1], r[8], c);
-    s[2] = addc(s[2], r9, c);
-#pragma unroll
-    for (int i = 3; i < 8; i++) s[i] = addc(s[i], 0u, c);
-    // at most one of the two chains wraps 2^256 (the folded value is < 2^256 + 2^68); fe_final adds PC for the wrap
-    fe_final(out, s, k1 | c);
-}
-HD void fe_mul(fe& r, const fe& a, const fe& b) {
-    u32 t[16];
-    mul256(t, a.v, b.v);
-    fe_reduce512(r, t);
-}
-HD void fe_sqr(fe& r, const fe& a) { fe_mul(r, a, a); }
-HD void fe_mul_small(fe& r, const fe& a, u32 k) {  // k < 2^16
-    u64 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = (u64)a.v[i] * k;   // 8 independent mads; high words < 2^16
-    u32 s[8];
-    u32 c = 0;
-    s[0] = (u32)v[0];
-#pragma unroll
-    for (int i = 1; i < 8; i++) s[i] = addc((u32)v[i], (u32)(v[i - 1] >> 32), c);
-    u32 top = (u32)(v[7] >> 32) + c;   // < 2^17
-    // fold top * PC = top*977 (< 2^27) + (top << 32)
-    c = 0;
-    s[0] = addc(s[0], top * BPPP_PC0, c);
-    s[1] = addc(s[1], top, c);
-#pragma unroll
-    for (int i = 2; i < 8; i++) s[i] = addc(s[i], 0u, c);
-    fe_final(r, s, c);
-}
-HD bool fe_is_zero(const fe& a) { return is_zero256(a.v); }
-HD bool fe_eq(const fe& a, const fe& b) { return eq256(a.v, b.v); }
-HD void fe_set_u32(fe& r, u32 x) {
+#define FE_CHECK(x, m) fe_check((x), (m))
+#else
+#define FE_SETMAG(x, m) ((void)0)
+#define FE_MAG(x) 0
+#define FE_CHECK(x, m) ((void)0)
+#endif
+
+HD void fe_set_u32(fe& r, u32 x) {   // x < 2^26
     r.v[0] = x;
 #pragma unroll
-    for (int i = 1; i < 8; i++) r.v[i] = 0;
+    for (int i = 1; i < 10; i++) r.v[i] = 0;
+    FE_SETMAG(r, x ? 1 : 0);
 }
-HD void fe_cmov(fe& r, bool take, const fe& b) { sel256(r.v, take ? 1u : 0u, r.v, b.v); }
+HD void fe_add(fe& r, const fe& a, const fe& b) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + b.v[i];
+    FE_SETMAG(r, FE_MAG(a) + FE_MAG(b));
+    FE_CHECK(r, 16);
+}
+HD void fe_dbl(fe& r, const fe& a) { fe_add(r, a, a); }
+// r = a - b for mag(b) <= M: r = a + 2(M+1) p - b, magnitude mag(a) + M + 1
+template <int M>
+HD void fe_sub_m(fe& r, const fe& a, const fe& b) {
+    FE_CHECK(b, M);
+    const u32 k = 2u * (M + 1);
+    r.v[0] = a.v[0] + k * 0x3FFFC2Fu - b.v[0];
+    r.v[1] = a.v[1] + k * 0x3FFFFBFu - b.v[1];
+#pragma unroll
+    for (int i = 2; i < 9; i++) r.v[i] = a.v[i] + k * BPPP_M26 - b.v[i];
+    r.v[9] = a.v[9] + k * BPPP_M22 - b.v[9];
+    FE_SETMAG(r, FE_MAG(a) + M + 1);
+    FE_CHECK(r, 16);
+}
+HD void fe_sub(fe& r, const fe& a, const fe& b) { fe_sub_m<3>(r, a, b); }   // default: subtrahend magnitude <= 3
+template <int M>
+HD void fe_neg_m(fe& r, const fe& a) {
+    fe z;
+    fe_set_u32(z, 0);
+    fe_sub_m<M>(r, z, a);
+}
+HD void fe_neg(fe& r, const fe& a) { fe_neg_m<3>(r, a); }
+HD void fe_cmov(fe& r, bool take, const fe& b) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) r.v[i] = take ? b.v[i] : r.v[i];
+#ifdef BPPP_FE_DEBUG
+    r.mag = r.mag > b.mag ? r.mag : b.mag;
+#endif
+}
+// 19 column sums -> magnitude-1 limbs.  c[k] < 2^64 are the exact column sums of a product (or any value sum c[k] 2^(26k)).
+HD void fe_reduce_cols(fe& r, const u64 c[19]) {
+    // carry chain over all columns: 26-bit digits t[0..18], top carry t19
+    u32 t[19];
+    u64 d = c[0];
+#pragma unroll
+    for (int k = 0; k < 18; k++) { t[k] = (u32)d & BPPP_M26; d = (d >> 26) + c[k + 1]; }
+    t[18] = (u32)d & BPPP_M26;
+    const u64 t19 = d >> 26;                       // < 2^38
+    // fold digits 10..19 through 2^260 = R0 + 2^10 * 2^26 (mod p):  u[k] = t[k] + t[k+10] R0 + t[k+9] 2^10
+    u64 e = (u64)t[0] + (u64)t[10] * BPPP_R0;
+    u32 q[10];
+    q[0] = (u32)e & BPPP_M26; e >>= 26;
+#pragma unroll
+    for (int k = 1; k < 9; k++) {
+        e += (u64)t[k] + (u64)t[k + 10] * BPPP_R0 + ((u64)t[k + 9] << 10);
+        q[k] = (u32)e & BPPP_M26; e >>= 26;
+    }
+    e += (u64)t[9] + t19 * BPPP_R0 + ((u64)t[18] << 10);    // t19 R0 < 2^52
+    q[9] = (u32)e & BPPP_M22;                                // keep 22 bits: value now counted from 2^256
+    // what is left above 2^256: (e >> 22) from this column, plus t19 * 2^10 at column 10 (= 2^260 = 2^4 * 2^256)
+    u64 top = (e >> 22) + (t19 << 14);                       // < 2^53
+    // top * 2^256 = top * (0x3D1 + 2^6 * 2^26)  (mod p); split top into 26-bit digits so every product is 32 x 32
+    const u32 top0 = (u32)top & BPPP_M26, top1 = (u32)(top >> 26);   // top1 < 2^27
+    u64 f = (u64)q[0] + (u64)top0 * BPPP_PC0;
+    r.v[0] = (u32)f & BPPP_M26; f >>= 26;
+    f += (u64)q[1] + ((u64)top0 << 6) + (u64)top1 * BPPP_PC0;
+    r.v[1] = (u32)f & BPPP_M26; f >>= 26;
+    f += (u64)q[2] + ((u64)top1 << 6);
+    r.v[2] = (u32)f & BPPP_M26; f >>= 26;
+    r.v[3] = q[3] + (u32)f;                                  // f < 2^8: limb 3 stays within magnitude 1
+#pragma unroll
+    for (int k = 4; k < 10; k++) r.v[k] = q[k];
+    FE_SETMAG(r, 1);
+    FE_CHECK(r, 1);
+}
+HD void fe_mul(fe& r, const fe& a, const fe& b) {
+    FE_CHECK(a, 8);
+    FE_CHECK(b, 8);
+    u64 c[19];
+#pragma unroll
+    for (int k = 0; k < 19; k++) {
+        const int i0 = k < 10 ? 0 : k - 9, i1 = k < 10 ? k : 9;
+        u64 acc = (u64)a.v[i0] * b.v[k - i0];
+#pragma unroll
+        for (int i = i0 + 1; i <= i1; i++) acc += (u64)a.v[i] * b.v[k - i];
+        c[k] = acc;
+    }
+    fe_reduce_cols(r, c);
+}
+HD void fe_sqr(fe& r, const fe& a) {   // 55 limb products: cross terms use the doubled limb
+    FE_CHECK(a, 8);
+    u32 a2[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) a2[i] = a.v[i] << 1;   // <= 2^31
+    u64 c[19];
+#pragma unroll
+    for (int k = 0; k < 19; k++) {
+        const int i0 = k < 10 ? 0 : k - 9;
+        u64 acc = 0;
+#pragma unroll
+        for (int i = i0; 2 * i < k; i++) acc += (u64)a2[i] * a.v[k - i];
+        if ((k & 1) == 0) acc += (u64)a.v[k / 2] * a.v[k / 2];
+        c[k] = acc;
+    }
+    fe_reduce_cols(r, c);
+}
+HD void fe_mul_small(fe& r, const fe& a, u32 k) {   // k <= 32, mag(a) <= 8
+    FE_CHECK(a, 8);
+    u64 c[19];
+#pragma unroll
+    for (int i = 0; i < 10; i++) c[i] = (u64)a.v[i] * k;
+#pragma unroll
+    for (int i = 10; i < 19; i++) c[i] = 0;
+    // same tail as a product, specialised: only 10 columns are non-zero
+    u64 d = c[0];
+    u32 q[10];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { q[i] = (u32)d & BPPP_M26; d = (d >> 26) + c[i + 1]; }
+    q[9] = (u32)d & BPPP_M22;
+    const u32 top = (u32)(d >> 22);                          // < 2^20
+    u64 f = (u64)q[0] + (u64)top * BPPP_PC0;
+    r.v[0] = (u32)f & BPPP_M26; f >>= 26;
+    f += (u64)q[1] + ((u64)top << 6);
+    r.v[1] = (u32)f & BPPP_M26; f >>= 26;
+    r.v[2] = q[2] + (u32)f;
+#pragma unroll
+    for (int i = 3; i < 10; i++) r.v[i] = q[i];
+    FE_SETMAG(r, 1);
+    FE_CHECK(r, 1);
+}
+// full reduction to the canonical representative in [0, p)
+HD void fe_normalize(fe& r) {
+    FE_CHECK(r, 16);
+    // weak pass: fold the part above 2^256 once, carry through
+    u32 x = r.v[9] >> 22;
+    r.v[9] &= BPPP_M22;
+    u32 t0 = r.v[0] + x * BPPP_PC0, t1 = r.v[1] + (x << 6), t[10];
+    t1 += t0 >> 26; t[0] = t0 & BPPP_M26;
+    u32 cur = r.v[2] + (t1 >> 26); t[1] = t1 & BPPP_M26;
+#pragma unroll
+    for (int i = 2; i < 9; i++) { t[i] = cur & BPPP_M26; cur = r.v[i + 1] + (cur >> 26); }
+    t[9] = cur;                                               // may again exceed 22 bits by one unit at most
+    // now value < 2^256 + 2^232-ish; decide whether to subtract p: x2 = bit 256 or (value >= p)
+    u32 m = t[2];
+#pragma unroll
+    for (int i = 3; i < 9; i++) m &= t[i];
+    u32 ge = (t[9] >> 22) | ((t[9] == BPPP_M22) & (m == BPPP_M26) & ((t[1] + 0x40u + ((t[0] + BPPP_PC0) >> 26)) > BPPP_M26));
+    // add 2^256 - p = 0x1000003D1 when ge, then drop bit 256
+    u32 u0 = t[0] + (ge ? BPPP_PC0 : 0u), u1 = t[1] + (ge ? 0x40u : 0u);
+    u1 += u0 >> 26; r.v[0] = u0 & BPPP_M26;
+    cur = t[2] + (u1 >> 26); r.v[1] = u1 & BPPP_M26;
+#pragma unroll
+    for (int i = 2; i < 9; i++) { r.v[i] = cur & BPPP_M26; cur = t[i + 1] + (cur >> 26); }
+    r.v[9] = cur & BPPP_M22;
+    FE_SETMAG(r, 1);
+}
+HD bool fe_is_zero(const fe& a) {
+    fe t = a;
+    fe_normalize(t);
+    u32 x = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) x |= t.v[i];
+    return x == 0;
+}
+HD bool fe_eq(const fe& a, const fe& b) {   // magnitudes <= 8
+    fe ta = a, tb = b;
+    fe_normalize(ta);
+    fe_normalize(tb);
+    u32 x = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) x |= ta.v[i] ^ tb.v[i];
+    return x == 0;
+}
 HD void fe_sqr_n(fe& r, const fe& a, int n) {
     r = a;
 #pragma nounroll
@@ -316,17 +438,54 @@ HD_NOINLINE void fe_sqrt_candidate(fe& r, const fe& a) {
     fe_sqr_n(t, t, 6); fe_mul(t, t, x2);
     fe_sqr_n(r, t, 2);
 }
+// packed canonical form (8 x 32-bit little-endian words: HBM tables, decoded inputs) <-> limbs
+HD void fe_from_w8(fe& r, const u32 w[8]) {
+    r.v[0] = w[0] & BPPP_M26;
+    r.v[1] = ((w[0] >> 26) | (w[1] << 6)) & BPPP_M26;
+    r.v[2] = ((w[1] >> 20) | (w[2] << 12)) & BPPP_M26;
+    r.v[3] = ((w[2] >> 14) | (w[3] << 18)) & BPPP_M26;
+    r.v[4] = ((w[3] >> 8) | (w[4] << 24)) & BPPP_M26;
+    r.v[5] = (w[4] >> 2) & BPPP_M26;
+    r.v[6] = ((w[4] >> 28) | (w[5] << 4)) & BPPP_M26;
+    r.v[7] = ((w[5] >> 22) | (w[6] << 10)) & BPPP_M26;
+    r.v[8] = ((w[6] >> 16) | (w[7] << 16)) & BPPP_M26;
+    r.v[9] = w[7] >> 10;
+    FE_SETMAG(r, 1);
+}
+HD void fe_to_w8(u32 w[8], const fe& a) {   // normalises
+    fe t = a;
+    fe_normalize(t);
+    w[0] = t.v[0] | (t.v[1] << 26);
+    w[1] = (t.v[1] >> 6) | (t.v[2] << 20);
+    w[2] = (t.v[2] >> 12) | (t.v[3] << 14);
+    w[3] = (t.v[3] >> 18) | (t.v[4] << 8);
+    w[4] = (t.v[4] >> 24) | (t.v[5] << 2) | (t.v[6] << 28);
+    w[5] = (t.v[6] >> 4) | (t.v[7] << 22);
+    w[6] = (t.v[7] >> 10) | (t.v[8] << 16);
+    w[7] = (t.v[8] >> 16) | (t.v[9] << 10);
+}
 // big-endian bytes -> canonical element; false if >= p
 HD bool fe_from_be(fe& r, const uint8_t* b) {
-    be32_to_limbs(r.v, b);
+    u32 w[8];
+    be32_to_limbs(w, b);
+    fe_from_w8(r, w);
     u32 c = 0;
-    (void)addc(r.v[0], BPPP_PC0, c);
-    (void)addc(r.v[1], 1u, c);
+    (void)addc(w[0], BPPP_PC0, c);
+    (void)addc(w[1], 1u, c);
 #pragma unroll
-    for (int i = 2; i < 8; i++) (void)addc(r.v[i], 0u, c);
+    for (int i = 2; i < 8; i++) (void)addc(w[i], 0u, c);
     return c == 0;
 }
-HD void fe_to_be(uint8_t* b, const fe& a) { limbs_to_be32(b, a.v); }
+HD void fe_to_be(uint8_t* b, const fe& a) {
+    u32 w[8];
+    fe_to_w8(w, a);
+    limbs_to_be32(b, w);
+}
+HD bool fe_is_odd(const fe& a) {
+    fe t = a;
+    fe_normalize(t);
+    return t.v[0] & 1u;
+}
 
 // ---------------------------------------------------------------- Fn: n = 2^256 - ND, ND = 0x1_45512319_50B75FC4_402DA173_2FC9BEBF
 #define BPPP_ND0 0x2FC9BEBFu
@@ -372,31 +531,43 @@ HD void sc_neg(sc& r, const sc& a) {
     sc_set_u32(z, 0);
     sc_sub(r, z, a);
 }
-// acc[0..] += hi[0..nh) * ND   (schoolbook, 5-limb ND), acc has room for nh+5 limbs (+ carry handled by caller sizes)
-template <int NH, int NT>
-HD void sc_fold(u32 out[NT], const u32 lo[8], const u32 hi[NH]) {
-    // out = lo + hi * ND, NT >= max(9, NH + 5 + 1) limbs
-    const u32 nd[5] = {BPPP_ND0, BPPP_ND1, BPPP_ND2, BPPP_ND3, BPPP_ND4};
+// out (NH + 5 limbs) = lo (8 limbs) + hi (NH limbs) * ND, with ND = nd4 (4 limbs) + 2^128: the NH x 4 product by independent
+// columns (mul_limbs), then two carry chains.
+template <int NH>
+HD void sc_fold(u32* out /* NH + 5 */, const u32* lo /* 8 */, const u32* hi /* NH */) {
+    const u32 nd[4] = {BPPP_ND0, BPPP_ND1, BPPP_ND2, BPPP_ND3};
+    constexpr int NT = NH + 5;
+    u32 m[NH + 4];
+    mul_limbs<NH, 4>(m, hi, nd);
+    u32 c = 0;
 #pragma unroll
-    for (int i = 0; i < NT; i++) out[i] = i < 8 ? lo[i] : 0u;
+    for (int i = 0; i < NT; i++) out[i] = addc(i < 8 ? lo[i] : 0u, i < NH + 4 ? m[i] : 0u, c);
+    c = 0;
 #pragma unroll
-    for (int i = 0; i < NH; i++) {
-        u64 c = 0;
-#pragma unroll
-        for (int j = 0; j < 5; j++) { c += (u64)hi[i] * nd[j] + out[i + j]; out[i + j] = (u32)c; c >>= 32; }
-#pragma unroll
-        for (int k = i + 5; k < NT; k++) { c += out[k]; out[k] = (u32)c; c >>= 32; }
-    }
+    for (int i = 4; i < NT; i++) out[i] = addc(out[i], (i - 4) < NH ? hi[i - 4] : 0u, c);
 }
 HD void sc_reduce512(sc& r, const u32 t[16]) {
-    u32 a[14];   // lo + hi*ND < 2^256 + 2^385: 13 limbs (+1 spare)
-    sc_fold<8, 14>(a, t, t + 8);
-    u32 b[11];   // lo + hi(6 limbs, < 2^130 in fact)*ND < 2^260: 9 limbs (+ spare)
-    sc_fold<6, 11>(b, a, a + 8);
-    u32 c[10];   // lo + hi(b[8..10], < 2^5)*ND < 2^256 + 2^134
-    sc_fold<3, 10>(c, b, b + 8);
-    // c[8] in {0,1}: one more wrap adds ND; value then < 2n
-    sc_final(r, c, c[8]);
+    u32 a[13];   // lo + hi*ND < 2^256 + 2^385: 13 limbs
+    sc_fold<8>(a, t, t + 8);
+    u32 b[10];   // lo + a[8..13) (< 2^130) * ND < 2^260: 9 limbs (+1 spare)
+    sc_fold<5>(b, a, a + 8);
+    // lo + b[8] (< 2^5; b[9] = 0 by the bound above) * ND < 2^256 + 2^134: 8 limbs + carry limb
+    u32 d[9];
+    {
+        const u32 nd5[5] = {BPPP_ND0, BPPP_ND1, BPPP_ND2, BPPP_ND3, BPPP_ND4};
+        const u32 h = b[8];
+        u64 p[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) p[j] = (u64)h * nd5[j];
+        u32 cy = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) d[k] = addc(k < 8 ? b[k] : 0u, k < 5 ? (u32)p[k] : 0u, cy);
+        cy = 0;
+#pragma unroll
+        for (int k = 1; k < 9; k++) d[k] = addc(d[k], (k - 1) < 5 ? (u32)(p[k - 1] >> 32) : 0u, cy);
+    }
+    // d[8] in {0,1}: one more wrap adds ND; value then < 2n
+    sc_final(r, d, d[8]);
 }
 HD void sc_mul(sc& r, const sc& a, const sc& b) {
     u32 t[16];

@@ -10,8 +10,11 @@
 
 namespace bppp {
 
-struct pt { fe X, Y, Z; };   // (X : Y : Z), identity = (0 : 1 : 0)
-struct apt { fe x, y; };     // affine; (0, 0) is the identity sentinel (not on the curve: 0 != 7)
+struct pt { fe X, Y, Z; };   // (X : Y : Z), identity = (0 : 1 : 0); coordinate magnitudes <= (5, 2, 2) between operations
+struct apt { fe x, y; };     // affine, magnitude 1; (0, 0) is the identity sentinel (not on the curve: 0 != 7)
+// HBM formats: packed canonical words (8 x u32 per coordinate) for affine points; 128-byte slots for projective table entries
+struct apt_packed { u32 x[8], y[8]; };                                   // 64 B
+struct __attribute__((aligned(16))) pt_slot { pt p; u32 pad[2]; };        // 30 limbs + pad = 128 B (device build)
 
 HD void pt_set_identity(pt& r) {
     fe_set_u32(r.X, 0);
@@ -32,14 +35,23 @@ HD void pt_cmov(pt& r, bool take, const pt& b) {
     fe_cmov(r.Y, take, b.Y);
     fe_cmov(r.Z, take, b.Z);
 }
-HD void pt_neg(pt& r, const pt& p) {
-    r.X = p.X;
-    fe_neg(r.Y, p.Y);
-    r.Z = p.Z;
+HD void apt_unpack(apt& a, bool& is_identity, const apt_packed& k) {
+    u32 z = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z |= k.x[i] | k.y[i];
+    is_identity = z == 0;
+    fe_from_w8(a.x, k.x);
+    fe_from_w8(a.y, k.y);
 }
-HD void apt_neg(apt& r, const apt& p) {
-    r.x = p.x;
-    fe_neg(r.y, p.y);  // identity sentinel (0,0) stays (0,0)
+HD void apt_pack(apt_packed& k, const apt& a) {
+    fe_to_w8(k.x, a.x);
+    fe_to_w8(k.y, a.y);
+}
+// canonical coordinates (magnitude 1): what table entries are stored as, so look-ups can negate / scale lazily
+HD void pt_normalize(pt& p) {
+    fe_normalize(p.X);
+    fe_normalize(p.Y);
+    fe_normalize(p.Z);
 }
 
 // RCB16 algorithm 7: complete addition, 12M + 2 m(b3)
@@ -111,13 +123,12 @@ HD void pt_madd_nonid(pt& r, const pt& p, const apt& q) {
     fe_add(Z3, Z3, t0);
     r.X = X3; r.Y = Y3; r.Z = Z3;
 }
-// mixed addition that also accepts the identity sentinel / a skip flag (result = p when skipped)
+// mixed addition with a skip flag (result = p when skipped); the caller passes skip = true for the identity sentinel
 HD void pt_madd(pt& r, const pt& p, const apt& q, bool skip) {
     pt s;
     pt_madd_nonid(s, p, q);
-    bool keep = skip | apt_is_identity(q);
     r = p;
-    pt_cmov(r, !keep, s);
+    pt_cmov(r, !skip, s);
 }
 // RCB16 algorithm 9: complete doubling, 6M + 2S + 1 m(b3)
 HD void pt_dbl(pt& r, const pt& p) {
@@ -172,7 +183,7 @@ HD bool apt_on_curve(const apt& a) {
 // k256 GroupEncoding::to_bytes: 33-byte SEC1 compressed; identity -> 33 zero bytes (transcript.rs:7)
 HD void apt_to_sec1(uint8_t out[33], const apt& a) {
     bool id = apt_is_identity(a);
-    out[0] = id ? 0 : (uint8_t)(2 + (a.y.v[0] & 1));
+    out[0] = id ? 0 : (uint8_t)(2 + (fe_is_odd(a.y) ? 1 : 0));
     fe_to_be(out + 1, a.x);
 }
 // C-ABI point: 64 B affine big-endian x||y, identity = 64 zero bytes.  false if a coordinate is >= p or the

@@ -31,7 +31,7 @@ enum : int {
     SV_CG0 = 154,    // g-generator unrolling coefficients, 16
     SV_COUNT = 170
 };
-// point buffer slots (pbuf): [slot*24 + word][N], projective
+// point buffer slots (pbuf): [slot*30 + word][N], projective limbs
 enum : int { PB_V = 0, PB_RCOM, PB_CO, PB_CL, PB_CR, PB_CS, PB_C, PB_X, PB_R, PB_COUNT };
 // MSM scalar sets (msc): set s, base b -> slot s*49 + b
 #define BPPP_MSC_SETS 4
@@ -47,8 +47,8 @@ struct ProveWs {
     u32* tstate;            // [52][N]
     u32* sv;                // [SV_COUNT*8][N]
     u32* msc;               // [4*49*8][N]
-    u32* pbuf;              // [PB_COUNT*24][N]
-    pt* straus;             // [N][2][9]
+    u32* pbuf;              // [PB_COUNT*30][N]
+    pt_slot* straus;        // [N][2][9]
     FbTable fb;
     strobe base;
 };
@@ -61,8 +61,8 @@ HD void pw_ld_sc(sc& r, const ProveWs& w, size_t t, int slot) { ws_ld8(r.v, w.sv
 HD void pw_st_sc(const ProveWs& w, size_t t, int slot, const sc& r) { ws_st8(w.sv, w.N, t, slot, r.v); }
 HD void pw_st_msc(const ProveWs& w, size_t t, int set, int base, const sc& r) { ws_st8(w.msc, w.N, t, set * BPPP_NG + base, r.v); }
 HD void pw_ld_msc(sc& r, const ProveWs& w, size_t t, int set, int base) { ws_ld8(r.v, w.msc, w.N, t, set * BPPP_NG + base); }
-HD void pw_ld_pt(pt& p, const ProveWs& w, size_t t, int slot) { ws_ld_pt(p, w.pbuf + (size_t)slot * 24 * w.N, w.N, t); }
-HD void pw_st_pt(const ProveWs& w, size_t t, int slot, const pt& p) { ws_st_pt(w.pbuf + (size_t)slot * 24 * w.N, w.N, t, p); }
+HD void pw_ld_pt(pt& p, const ProveWs& w, size_t t, int slot) { ws_ld_pt(p, w.pbuf + (size_t)slot * 30 * w.N, w.N, t); }
+HD void pw_st_pt(const ProveWs& w, size_t t, int slot, const pt& p) { ws_st_pt(w.pbuf + (size_t)slot * 30 * w.N, w.N, t, p); }
 HD bool pw_rnd(sc& r, const ProveWs& w, size_t t, int i) { return sc_from_be(r, w.rnd + ((size_t)t * 52 + i) * 32); }
 
 // MSM lane work (8 lanes per proof on the device; the caller tree-adds the partial sums)
@@ -619,7 +619,7 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
         sc_set_u32(one, 1);
         sc_mul(y2m1, y, y);
         sc_sub(y2m1, y2m1, one);
-        pt* tbl = w.straus + t * (2 * BPPP_STRAUS_ENTRIES);
+        pt_slot* tbl = w.straus + t * (2 * BPPP_STRAUS_ENTRIES);
         glv_split rs[2];
         straus_build_table(tbl, A[1]);
         straus_build_table(tbl + BPPP_STRAUS_ENTRIES, A[2]);
@@ -627,7 +627,7 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
         glv_decompose(rs[1], y2m1);
         pt acc;
         straus_msm_glv(acc, tbl, rs, 2);
-        pt_madd(acc, acc, A[0], false);
+        pt_madd(acc, acc, A[0], apt_is_identity(A[0]));
         pw_st_pt(w, t, PB_C, acc);
     } else {
         // proof.l = [l0, l1], proof.n = [n0]   (wnla.rs:126-133)

@@ -49,11 +49,11 @@ struct VerifyWs {
     u32* cvec;                   // [25*8][N]
     u32* pts;                    // [13*16][N]
     u32* lns;                    // [3*8][N]
-    u32* acc;                    // [24][N]
-    u32* pfix;                   // [24][N]
+    u32* acc;                    // [30][N] running commitment, projective limbs
+    u32* pfix;                   // [30][N]
     u32* fsc;                    // [49*8][N]
-    pt* straus;                  // [N][5][9]
-    const apt* fb_table;         // [49][nwin][2^W - 1]
+    pt_slot* straus;             // [N][5][9]
+    const apt_packed* fb_table;  // [49][nwin][2^W - 1]
     int fb_w;                    // window bits: 4, 8 or 16
     strobe base;                 // Transcript::new(label)
 };
@@ -67,23 +67,38 @@ HD void ws_st8(u32* base, size_t N, size_t t, int slot, const u32 r[8]) {
 #pragma unroll
     for (int i = 0; i < 8; i++) base[(size_t)(slot * 8 + i) * N + t] = r[i];
 }
-HD void ws_ld_apt(apt& a, const u32* base, size_t N, size_t t, int slot) {
-    ws_ld8(a.x.v, base, N, t, 2 * slot);
-    ws_ld8(a.y.v, base, N, t, 2 * slot + 1);
+HD void ws_ld_apt(apt& a, const u32* base, size_t N, size_t t, int slot) {   // packed canonical words
+    u32 w[8];
+    ws_ld8(w, base, N, t, 2 * slot);
+    fe_from_w8(a.x, w);
+    ws_ld8(w, base, N, t, 2 * slot + 1);
+    fe_from_w8(a.y, w);
 }
 HD void ws_st_apt(u32* base, size_t N, size_t t, int slot, const apt& a) {
-    ws_st8(base, N, t, 2 * slot, a.x.v);
-    ws_st8(base, N, t, 2 * slot + 1, a.y.v);
+    u32 w[8];
+    fe_to_w8(w, a.x);
+    ws_st8(base, N, t, 2 * slot, w);
+    fe_to_w8(w, a.y);
+    ws_st8(base, N, t, 2 * slot + 1, w);
 }
+// projective points travel between kernels as raw limbs (30 words); their magnitudes are the (5, 2, 2) the group law leaves
 HD void ws_ld_pt(pt& p, const u32* base, size_t N, size_t t) {
-    ws_ld8(p.X.v, base, N, t, 0);
-    ws_ld8(p.Y.v, base, N, t, 1);
-    ws_ld8(p.Z.v, base, N, t, 2);
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        p.X.v[i] = base[(size_t)i * N + t];
+        p.Y.v[i] = base[(size_t)(10 + i) * N + t];
+        p.Z.v[i] = base[(size_t)(20 + i) * N + t];
+    }
+    FE_SETMAG(p.X, 5); FE_SETMAG(p.Y, 2); FE_SETMAG(p.Z, 2);
 }
 HD void ws_st_pt(u32* base, size_t N, size_t t, const pt& p) {
-    ws_st8(base, N, t, 0, p.X.v);
-    ws_st8(base, N, t, 1, p.Y.v);
-    ws_st8(base, N, t, 2, p.Z.v);
+    FE_CHECK(p.X, 5); FE_CHECK(p.Y, 2); FE_CHECK(p.Z, 2);
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        base[(size_t)i * N + t] = p.X.v[i];
+        base[(size_t)(10 + i) * N + t] = p.Y.v[i];
+        base[(size_t)(20 + i) * N + t] = p.Z.v[i];
+    }
 }
 HD void ws_ld_strobe(strobe& s, const u32* base, size_t N, size_t t) {
 #pragma unroll
@@ -111,7 +126,7 @@ HD void app_point(strobe& t, const char (&label)[L], const apt& a) {  // transcr
 // ---------------------------------------------------------------- fixed-base MSM over the batch-shared tables
 // table[(b * nwin + w) * (2^W - 1) + (d - 1)] = d * 2^(W w) * generator_b, affine (64 B); (0,0) = identity.
 // This is `vector_mul(points, scalars)` (util.rs:46-60) for points that are batch constants.
-struct FbTable { const apt* table; int W; size_t N; };
+struct FbTable { const apt_packed* table; int W; size_t N; };
 HD FbTable fb_of(const VerifyWs& ws) { FbTable f = {ws.fb_table, ws.fb_w, ws.N}; return f; }
 HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, int first_slot, int first_base, int count) {
     const int W = fbt.W;
@@ -123,7 +138,7 @@ HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, 
     for (int j = 0; j < count; j++) {
         u32 k[8];
         ws_ld8(k, scal, fbt.N, t, first_slot + j);
-        const apt* tb = fbt.table + (size_t)(first_base + j) * nwin * per_win;
+        const apt_packed* tb = fbt.table + (size_t)(first_base + j) * nwin * per_win;
 #pragma nounroll
         for (int w = 0; w < nwin; w++) {
             int bit = w * W;
@@ -132,8 +147,10 @@ HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, 
             for (int i = 0; i < 8; i++) limb = (i == (bit >> 5)) ? k[i] : limb;
             u32 d = (limb >> (bit & 31)) & mask;
             size_t idx = (size_t)w * per_win + (d ? d - 1 : 0);
-            apt e = tb[idx];
-            pt_madd(acc, acc, e, d == 0);
+            apt e;
+            bool id;
+            apt_unpack(e, id, tb[idx]);
+            pt_madd(acc, acc, e, (d == 0) | id);
         }
     }
     accp = acc;
@@ -156,7 +173,7 @@ HD void fixed_base_msm_partial(pt& accp, const FbTable& fbt, size_t t, int lane,
     for (int j = 0; j < count; j++) {
         u32 k[8];
         ws_ld8(k, scal, fbt.N, t, first_slot + j);
-        const apt* tb = fbt.table + (size_t)(first_base + j) * nwin * per_win;
+        const apt_packed* tb = fbt.table + (size_t)(first_base + j) * nwin * per_win;
 #pragma nounroll
         for (int w = lane; w < nwin; w += BPPP_FB_LANES) {
             int bit = w * W;
@@ -165,8 +182,10 @@ HD void fixed_base_msm_partial(pt& accp, const FbTable& fbt, size_t t, int lane,
             for (int i = 0; i < 8; i++) limb = (i == (bit >> 5)) ? k[i] : limb;
             u32 d = (limb >> (bit & 31)) & mask;
             size_t idx = (size_t)w * per_win + (d ? d - 1 : 0);
-            apt e = tb[idx];
-            pt_madd(acc, acc, e, d == 0);
+            apt e;
+            bool id;
+            apt_unpack(e, id, tb[idx]);
+            pt_madd(acc, acc, e, (d == 0) | id);
         }
     }
     accp = acc;
@@ -178,7 +197,7 @@ __device__ __forceinline__ void lane_group_sum(pt& acc) {
     for (int m = 1; m < BPPP_FB_LANES; m <<= 1) {
         pt o;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 10; i++) {
             o.X.v[i] = __shfl_xor(acc.X.v[i], m, 64);
             o.Y.v[i] = __shfl_xor(acc.Y.v[i], m, 64);
             o.Z.v[i] = __shfl_xor(acc.Z.v[i], m, 64);
@@ -197,30 +216,32 @@ HD void straus_recode(straus_scalar& r, const sc& k) {
     for (int i = 0; i < 8; i++) { c += (u64)k.v[i] + 0x88888888u; r.kp[i] = (u32)c; c >>= 32; }
     r.top = (u32)c;
 }
-// tbl[e] = e * P, e = 0..8 (P affine, may be the identity sentinel)
-HD void straus_build_table(pt* tbl, const apt& P) {
+// tbl[e] = e * P, e = 0..8 (P affine, may be the identity sentinel); entries are stored with canonical coordinates
+HD void straus_build_table(pt_slot* tbl, const apt& P) {
     pt cur;
     pt_set_identity(cur);
-    tbl[0] = cur;
+    tbl[0].p = cur;
     pt_from_affine(cur, P);
-    tbl[1] = cur;
+    tbl[1].p = cur;
+    const bool pid = apt_is_identity(P);
 #pragma nounroll
     for (int e = 2; e <= 8; e++) {
-        pt src = tbl[(e & 1) ? e - 1 : e / 2];
+        pt src = tbl[(e & 1) ? e - 1 : e / 2].p;
         pt d;
-        if (e & 1) pt_madd(d, src, P, false);   // loop counter: wave-uniform branch
+        if (e & 1) pt_madd(d, src, P, pid);     // loop counter: wave-uniform branch
         else pt_dbl(d, src);
-        tbl[e] = d;
+        pt_normalize(d);
+        tbl[e].p = d;
     }
 }
 // acc = sum_j k_j * P_j using tables tbl[j*9 + e]; scalars recoded in rs[0..m)
-HD void straus_msm(pt& out, const pt* tbl, const straus_scalar* rs, int m) {
+HD void straus_msm(pt& out, const pt_slot* tbl, const straus_scalar* rs, int m) {
     pt acc;
     pt_set_identity(acc);
     // top digit (0 or 1) for each scalar
 #pragma nounroll
     for (int j = 0; j < m; j++) {
-        pt q = tbl[j * BPPP_STRAUS_ENTRIES + (rs[j].top ? 1 : 0)];
+        pt q = tbl[j * BPPP_STRAUS_ENTRIES + (rs[j].top ? 1 : 0)].p;
         pt_add(acc, acc, q);
     }
 #pragma nounroll
@@ -234,9 +255,9 @@ HD void straus_msm(pt& out, const pt* tbl, const straus_scalar* rs, int m) {
             for (int l = 0; l < 8; l++) limb = (l == (i >> 3)) ? rs[j].kp[l] : limb;
             int dg = (int)((limb >> ((i & 7) * 4)) & 15) - 8;
             int mag = dg < 0 ? -dg : dg;
-            pt q = tbl[j * BPPP_STRAUS_ENTRIES + mag];
+            pt q = tbl[j * BPPP_STRAUS_ENTRIES + mag].p;
             fe ny;
-            fe_neg(ny, q.Y);
+            fe_neg_m<1>(ny, q.Y);
             fe_cmov(q.Y, dg < 0, ny);
             pt_add(acc, acc, q);
         }
@@ -298,8 +319,10 @@ HD u32 limb5_at(const u32 v[5], int idx) {
 }
 // acc = sum_j k_j * P_j with tables tbl[j*9 + e] = e*P_j: 33 windows x (4 doublings + 2m additions); the lambda stream reuses
 // P_j's table with X scaled by beta.
-HD void straus_msm_glv(pt& out, const pt* tbl, const glv_split* sp, int m) {
-    const fe BETA = {{0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu}};
+HD void straus_msm_glv(pt& out, const pt_slot* tbl, const glv_split* sp, int m) {
+    const u32 BETA_W[8] = {0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu};
+    fe BETA;
+    fe_from_w8(BETA, BETA_W);
     pt acc;
     pt_set_identity(acc);
 #pragma nounroll
@@ -316,11 +339,11 @@ HD void straus_msm_glv(pt& out, const pt* tbl, const glv_split* sp, int m) {
                 bool sneg = h ? sp[j].neg2 : sp[j].neg1;
                 int dg = (int)((limb5_at(kp, i >> 3) >> ((i & 7) * 4)) & 15) - 8;
                 int mag = dg < 0 ? -dg : dg;
-                pt q = tbl[j * BPPP_STRAUS_ENTRIES + mag];
+                pt q = tbl[j * BPPP_STRAUS_ENTRIES + mag].p;
                 fe bx, ny;
                 fe_mul(bx, q.X, BETA);
                 fe_cmov(q.X, h != 0, bx);
-                fe_neg(ny, q.Y);
+                fe_neg_m<1>(ny, q.Y);
                 fe_cmov(q.Y, (dg < 0) != sneg, ny);
                 pt_add(acc, acc, q);
             }
@@ -364,7 +387,7 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
     {
         pt s;
         pt_from_affine(s, V);
-        pt_madd(s, s, P[12], false);
+        pt_madd(s, s, P[12], apt_is_identity(P[12]));
         pt_to_affine(Vr, s);
     }
     app_point(tr, "commitment_cl", P[0]);                                // circuit.rs:155-159
@@ -502,17 +525,12 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
     }
 }
 
-// ---------------------------------------------------------------- phase 2b: C0 fixed-base part: ps_tau*g + <g_vec, pn_tau>  (circuit.rs:206), added to acc
+// ---------------------------------------------------------------- phase 2b: C0 fixed-base part: ps_tau*g + <g_vec, pn_tau>  (circuit.rs:206) -> pfix
 // lane-group form: every lane of the proof's group computes a partial sum; the group total is stored by _store.
 HD void verify_c0_fixed_lane(pt& part, const VerifyWs& ws, size_t t, int lane) {
     fixed_base_msm_partial(part, fb_of(ws), t, lane, ws.sc0, 0, 0, 17);
 }
-HD void verify_c0_fixed_store(const VerifyWs& ws, size_t t, const pt& total) {   // C0 = (variable-base part, in acc) + total
-    pt a;
-    ws_ld_pt(a, ws.acc, ws.N, t);
-    pt_add(a, a, total);
-    ws_st_pt(ws.acc, ws.N, t, a);
-}
+HD void verify_c0_fixed_store(const VerifyWs& ws, size_t t, const pt& total) { ws_st_pt(ws.pfix, ws.N, t, total); }   // added in round 1
 // single-thread form (host emulation in tests/emul, thread order = lane order)
 HD void verify_c0_fixed(const VerifyWs& ws, size_t t) {
     pt acc, part;
@@ -526,7 +544,7 @@ HD void verify_c0_fixed(const VerifyWs& ws, size_t t) {
 // ---------------------------------------------------------------- phase 2a: C0 variable-base part (circuit.rs:230-235)
 HD void verify_c0_var(const VerifyWs& ws, size_t t) {
     const size_t N = ws.N;
-    pt* tbl = ws.straus + t * (5 * BPPP_STRAUS_ENTRIES);
+    pt_slot* tbl = ws.straus + t * (5 * BPPP_STRAUS_ENTRIES);
     glv_split rs[5];
     const int pslot[5] = {3, 2, 0, 1, 12};  // c_s, c_o, c_l, c_r, V+r  <->  sc0 slots 17..21
 #pragma nounroll
@@ -540,13 +558,18 @@ HD void verify_c0_var(const VerifyWs& ws, size_t t) {
     }
     pt acc;
     straus_msm_glv(acc, tbl, rs, 5);
-    ws_st_pt(ws.acc, N, t, acc);   // the fixed-base part is added by verify_c0_fixed_store
+    ws_st_pt(ws.acc, N, t, acc);   // the fixed-base part (pfix) is added at the top of round 1
 }
 // ---------------------------------------------------------------- phase 3 (k = 1..4): one WNLA round (wnla.rs:84-102)
 HD void verify_round(const VerifyWs& ws, size_t t, int k) {
     const size_t N = ws.N;
     pt C;
     ws_ld_pt(C, ws.acc, N, t);
+    if (k == 1) {   // C0 = variable-base part (acc) + fixed-base part (pfix); the two kernels run concurrently on two streams
+        pt F;
+        ws_ld_pt(F, ws.pfix, N, t);
+        pt_add(C, C, F);
+    }
     apt Ca, X, R;
     pt_to_affine(Ca, C);
     ws_ld_apt(X, ws.pts, N, t, 8 + (4 - k));   // proof.x.last()
@@ -576,7 +599,7 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k) {
     sc_set_u32(one, 1);
     sc_mul(y2m1, y, y);
     sc_sub(y2m1, y2m1, one);
-    pt* tbl = ws.straus + t * (5 * BPPP_STRAUS_ENTRIES);
+    pt_slot* tbl = ws.straus + t * (5 * BPPP_STRAUS_ENTRIES);
     glv_split rs[2];
     straus_build_table(tbl, X);
     straus_build_table(tbl + BPPP_STRAUS_ENTRIES, R);
@@ -584,7 +607,7 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k) {
     glv_decompose(rs[1], y2m1);
     pt acc;
     straus_msm_glv(acc, tbl, rs, 2);
-    pt_madd(acc, acc, Ca, false);
+    pt_madd(acc, acc, Ca, apt_is_identity(Ca));
     ws_st_pt(ws.acc, N, t, acc);
 }
 // ---------------------------------------------------------------- phase 4: base case (wnla.rs:80-82 with :66-72), generators unrolled
@@ -684,11 +707,11 @@ HD void verify_final_check(const VerifyWs& ws, size_t t) {
 // Pass 2: same thread batch-inverts its Z's (Montgomery trick) and normalises the slots to affine.
 #define BPPP_FB_CHUNK 256
 struct FbBuild {
-    const apt* gens;   // [nbases]
+    const apt* gens;        // [nbases]
     int nbases, W;
-    apt* table;        // [nbases][nwin][2^W - 1]
-    fe* ztmp;          // same count
-    fe* ptmp;          // same count (prefix products)
+    apt_packed* table;      // [nbases][nwin][2^W - 1], packed canonical affine
+    fe *xtmp, *ytmp, *ztmp; // projective coordinates of every entry (pass 1 -> pass 2)
+    fe* ptmp;               // prefix products of Z
 };
 HD size_t fb_chunks_per_window(int W) { return (((size_t)1 << W) - 1 + BPPP_FB_CHUNK - 1) / BPPP_FB_CHUNK; }
 HD void fb_build_pass1(const FbBuild& fb, size_t tid) {
@@ -719,10 +742,8 @@ HD void fb_build_pass1(const FbBuild& fb, size_t tid) {
     size_t off = (b * nwin + w) * per_win;
 #pragma nounroll
     for (size_t i = 0; i < BPPP_FB_CHUNK && d0 + i < per_win; i++) {
-        apt xy;
-        xy.x = cur.X;
-        xy.y = cur.Y;
-        fb.table[off + d0 + i] = xy;
+        fb.xtmp[off + d0 + i] = cur.X;
+        fb.ytmp[off + d0 + i] = cur.Y;
         fb.ztmp[off + d0 + i] = cur.Z;
         pt_add(cur, cur, base);
     }
@@ -759,11 +780,13 @@ HD void fb_build_pass2(const FbBuild& fb, size_t tid) {
         fe_mul(zi, inv, fb.ptmp[off + i]);
         fe_mul(m, inv, z);
         fe_cmov(inv, !id, m);
-        apt xy = fb.table[off + i];
-        fe_mul(xy.x, xy.x, zi);
-        fe_mul(xy.y, xy.y, zi);
+        apt xy;
+        fe_mul(xy.x, fb.xtmp[off + i], zi);
+        fe_mul(xy.y, fb.ytmp[off + i], zi);
         if (id) { fe_set_u32(xy.x, 0); fe_set_u32(xy.y, 0); }
-        fb.table[off + i] = xy;
+        apt_packed k;
+        apt_pack(k, xy);
+        fb.table[off + i] = k;
     }
 }
 

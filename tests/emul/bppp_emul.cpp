@@ -59,7 +59,7 @@ int emul_pt_op(int op, const uint8_t A[64], const uint8_t B[64], uint8_t out[64]
     pt_from_affine(p, a);
     pt_from_affine(q, b);
     if (op == 0) pt_add(s, p, q);
-    else if (op == 1) pt_madd(s, p, b, false);
+    else if (op == 1) pt_madd(s, p, b, apt_is_identity(b));
     else pt_dbl(s, p);
     pt_to_affine(r, s);
     apt_to_xy64(out, r);
@@ -67,7 +67,7 @@ int emul_pt_op(int op, const uint8_t A[64], const uint8_t B[64], uint8_t out[64]
 }
 // sum_j k_j P_j via the Straus path (m <= 5)
 int emul_straus(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64]) {
-    std::vector<pt> tbl(m * BPPP_STRAUS_ENTRIES);
+    std::vector<pt_slot> tbl(m * BPPP_STRAUS_ENTRIES);
     straus_scalar rs[5];
     for (int j = 0; j < m; j++) {
         apt a;
@@ -85,7 +85,7 @@ int emul_straus(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64]) {
 }
 // sum_j k_j P_j via the GLV Straus path (m <= 5); also returns the split of k_0 (|k1|, |k2| as 20-byte LE + signs)
 int emul_straus_glv(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64]) {
-    std::vector<pt> tbl(m * BPPP_STRAUS_ENTRIES);
+    std::vector<pt_slot> tbl(m * BPPP_STRAUS_ENTRIES);
     glv_split rs[5];
     for (int j = 0; j < m; j++) {
         apt a;
@@ -120,8 +120,8 @@ int emul_fb_build(const uint8_t* gens, int nbases, int W, uint8_t* table_out /* 
     std::vector<apt> g(nbases);
     for (int i = 0; i < nbases; i++) if (!apt_from_xy64(g[i], gens + 64 * i)) return -1;
     size_t entries = emul_fb_table_entries(nbases, W);
-    std::vector<fe> z(entries), pz(entries);
-    FbBuild fb{g.data(), nbases, W, (apt*)table_out, z.data(), pz.data()};
+    std::vector<fe> tmp(entries * 4);
+    FbBuild fb{g.data(), nbases, W, (apt_packed*)table_out, tmp.data(), tmp.data() + entries, tmp.data() + 2 * entries, tmp.data() + 3 * entries};
     size_t nthreads = (size_t)nbases * (256 / W) * fb_chunks_per_window(W);
     for (size_t t = 0; t < nthreads; t++) fb_build_pass1(fb, t);
     for (size_t t = 0; t < nthreads; t++) fb_build_pass2(fb, t);
@@ -132,7 +132,7 @@ int emul_fb_msm(const uint8_t* table, int W, int first_base, int count, const ui
     VerifyWs ws;
     memset(&ws, 0, sizeof ws);
     ws.N = 1;
-    ws.fb_table = (const apt*)table;
+    ws.fb_table = (const apt_packed*)table;
     ws.fb_w = W;
     std::vector<u32> scal(count * 8);
     for (int j = 0; j < count; j++) {
@@ -155,12 +155,12 @@ int emul_u64_verify_batch(const uint8_t* table, int W, const uint8_t* label, siz
     memset(&ws, 0, sizeof ws);
     ws.N = n;
     ws.commitments = V; ws.proofs = proofs; ws.accept = accept; ws.status = status; ws.trace = trace;
-    std::vector<u32> strobe_(52 * n), chal(80 * n), sc0(176 * n), cvec(200 * n), pts(208 * n), lns(24 * n), acc(24 * n), pfix(24 * n),
+    std::vector<u32> strobe_(52 * n), chal(80 * n), sc0(176 * n), cvec(200 * n), pts(208 * n), lns(24 * n), acc(30 * n), pfix(30 * n),
         fsc(392 * n);
-    std::vector<pt> straus(n * 5 * BPPP_STRAUS_ENTRIES);
+    std::vector<pt_slot> straus(n * 5 * BPPP_STRAUS_ENTRIES);
     ws.tstate = strobe_.data(); ws.chal = chal.data(); ws.sc0 = sc0.data(); ws.cvec = cvec.data(); ws.pts = pts.data();
     ws.lns = lns.data(); ws.acc = acc.data(); ws.pfix = pfix.data(); ws.fsc = fsc.data(); ws.straus = straus.data();
-    ws.fb_table = (const apt*)table;
+    ws.fb_table = (const apt_packed*)table;
     ws.fb_w = W;
     t_new(ws.base, label, (u32)label_len);
     for (size_t t = 0; t < n; t++) verify_phase1(ws, t);
@@ -179,10 +179,10 @@ int emul_u64_prove_batch(const uint8_t* table, int W, const uint8_t* label, size
     memset(&w, 0, sizeof w);
     w.N = n;
     w.x = x; w.s = s; w.rnd = rnd; w.proofs = proofs; w.commitments = V; w.status = status;
-    std::vector<u32> tstate(52 * n), sv((size_t)SV_COUNT * 8 * n), msc((size_t)BPPP_MSC_SETS * BPPP_NG * 8 * n), pbuf((size_t)PB_COUNT * 24 * n);
-    std::vector<pt> straus(n * 2 * BPPP_STRAUS_ENTRIES);
+    std::vector<u32> tstate(52 * n), sv((size_t)SV_COUNT * 8 * n), msc((size_t)BPPP_MSC_SETS * BPPP_NG * 8 * n), pbuf((size_t)PB_COUNT * 30 * n);
+    std::vector<pt_slot> straus(n * 2 * BPPP_STRAUS_ENTRIES);
     w.tstate = tstate.data(); w.sv = sv.data(); w.msc = msc.data(); w.pbuf = pbuf.data(); w.straus = straus.data();
-    w.fb.table = (const apt*)table; w.fb.W = W; w.fb.N = n;
+    w.fb.table = (const apt_packed*)table; w.fb.W = W; w.fb.N = n;
     t_new(w.base, label, (u32)label_len);
     auto msm = [&](MsmJob job) { for (size_t t = 0; t < n; t++) prove_msm(w, job, t); };
     for (size_t t = 0; t < n; t++) prove_stage_a(w, t);

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <vector>
 #include "../bp_pp_amd/csrc/point.h"
+#include "fe26.h"
 using namespace bppp;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
@@ -87,24 +88,30 @@ __global__ void k_add32(u32* out, u32 a0, u32 b0, int iters) {
 }
 __global__ void k_femul(u32* out, int iters) {
     fe a, b;
+    u32 wa[8], wb[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) { a.v[i] = 0x9E3779B9u * (threadIdx.x + i + 1); b.v[i] = 0x85EBCA6Bu * (blockIdx.x + i + 7); }
-    a.v[7] &= 0x7FFFFFFF; b.v[7] &= 0x7FFFFFFF;
+    for (int i = 0; i < 8; i++) { wa[i] = 0x9E3779B9u * (threadIdx.x + i + 1); wb[i] = 0x85EBCA6Bu * (blockIdx.x + i + 7); }
+    wa[7] &= 0x7FFFFFFF; wb[7] &= 0x7FFFFFFF;
+    fe_from_w8(a, wa); fe_from_w8(b, wb);
     for (int i = 0; i < iters; i++) { fe_mul(a, a, b); fe_mul(b, b, a); }
     u32 s = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) s ^= a.v[i] ^ b.v[i];
+    for (int i = 0; i < 10; i++) s ^= a.v[i] ^ b.v[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 __global__ void k_femul2(u32* out, int iters) {   // two independent chains per lane
     fe a, b, c, d;
+    u32 wa[8], wb[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) { a.v[i] = 0x9E3779B9u * (threadIdx.x + i + 1); b.v[i] = 0x85EBCA6Bu * (blockIdx.x + i + 7); c.v[i] = a.v[i] ^ 0x55; d.v[i] = b.v[i] ^ 0x33; }
-    a.v[7] &= 0x7FFFFFFF; b.v[7] &= 0x7FFFFFFF; c.v[7] &= 0x7FFFFFFF; d.v[7] &= 0x7FFFFFFF;
-    for (int i = 0; i < iters; i++) { fe_mul(a, a, b); fe_mul(c, c, d); fe_mul(b, b, a); fe_mul(d, d, c); }
+    for (int i = 0; i < 8; i++) { wa[i] = 0x9E3779B9u * (threadIdx.x + i + 1); wb[i] = 0x85EBCA6Bu * (blockIdx.x + i + 7); }
+    wa[7] &= 0x7FFFFFFF; wb[7] &= 0x7FFFFFFF;
+    fe_from_w8(a, wa); fe_from_w8(b, wb);
+    wa[0] ^= 0x55; wb[0] ^= 0x33;
+    fe_from_w8(c, wa); fe_from_w8(d, wb);
+    for (int i = 0; i < iters; i++) { fe_sqr(a, a); fe_sqr(c, c); fe_sqr(b, b); fe_sqr(d, d); }
     u32 s = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) s ^= a.v[i] ^ b.v[i] ^ c.v[i] ^ d.v[i];
+    for (int i = 0; i < 10; i++) s ^= a.v[i] ^ b.v[i] ^ c.v[i] ^ d.v[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 __global__ void k_ptops(u32* out, int iters, int mode) {
@@ -113,8 +120,7 @@ __global__ void k_ptops(u32* out, int iters, int mode) {
     fe gx, gy;
     const u32 GX[8] = {0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu, 0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu};
     const u32 GY[8] = {0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u, 0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u};
-#pragma unroll
-    for (int i = 0; i < 8; i++) { gx.v[i] = GX[i]; gy.v[i] = GY[i]; }
+    fe_from_w8(gx, GX); fe_from_w8(gy, GY);
     q.X = gx; q.Y = gy; fe_set_u32(q.Z, 1);
     apt qa; qa.x = gx; qa.y = gy;
     p = q;
@@ -126,10 +132,45 @@ __global__ void k_ptops(u32* out, int iters, int mode) {
     }
     u32 s = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) s ^= p.X.v[i] ^ p.Y.v[i] ^ p.Z.v[i];
+    for (int i = 0; i < 10; i++) s ^= p.X.v[i] ^ p.Y.v[i] ^ p.Z.v[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// synthetic "point addition" op mix on the 10x26 prototype: 12 mul + 22 add/sub (values are garbage; throughput only)
+__global__ void k_pt26(u32* out, int iters) {
+    using namespace fe26ns;
+    fe26 X, Y, Z, x2, y2, z2;
+#pragma unroll
+    for (int i = 0; i < 10; i++) { X.n[i] = (0x9E3779B9u * (threadIdx.x + i + 1)) & M26; Y.n[i] = (0x85EBCA6Bu * (blockIdx.x + i + 7)) & M26; Z.n[i] = (X.n[i] ^ 0x155555) & M26; x2.n[i] = (Y.n[i] ^ 0x2AAAAA) & M26; y2.n[i] = (X.n[i] + 12345) & M26; z2.n[i] = (Y.n[i] + 777) & M26; }
+    for (int it = 0; it < iters; it++) {
+        fe26 t0, t1, t2, t3, t4, X3, Y3, Z3;
+        fe26_mul(t0, X, x2); fe26_mul(t1, Y, y2); fe26_mul(t2, Z, z2);
+        fe26_add(t3, X, Y); fe26_add(t4, x2, y2); fe26_mul(t3, t3, t4);
+        fe26_add(t4, t0, t1); fe26_sub(t3, t3, t4); fe26_add(t4, Y, Z); fe26_add(X3, y2, z2); fe26_mul(t4, t4, X3);
+        fe26_add(X3, t1, t2); fe26_sub(t4, t4, X3); fe26_add(X3, X, Z); fe26_add(Y3, x2, z2); fe26_mul(X3, X3, Y3);
+        fe26_add(Y3, t0, t2); fe26_sub(Y3, X3, Y3); fe26_add(X3, t0, t0); fe26_add(t0, X3, t0);
+        fe26_add(Z3, t1, t2); fe26_sub(t1, t1, t2);
+        fe26_mul(X3, t4, Y3); fe26_mul(t2, t3, t1); fe26_sub(X3, t2, X3); fe26_mul(Y3, Y3, t0); fe26_mul(t1, t1, Z3);
+        fe26_add(Y3, t1, Y3); fe26_mul(t0, t0, t3); fe26_mul(Z3, Z3, t4); fe26_add(Z3, Z3, t0);
+#pragma unroll
+        for (int i = 0; i < 10; i++) { X.n[i] = X3.n[i] & M26; Y.n[i] = Y3.n[i] & M26; Z.n[i] = Z3.n[i] & M26; }
+    }
+    u32 s = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) s ^= X.n[i] ^ Y.n[i] ^ Z.n[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_femul26(u32* out, int iters) {
+    using namespace fe26ns;
+    fe26 a, b;
+#pragma unroll
+    for (int i = 0; i < 10; i++) { a.n[i] = (0x9E3779B9u * (threadIdx.x + i + 1)) & M26; b.n[i] = (0x85EBCA6Bu * (blockIdx.x + i + 7)) & M26; }
+    for (int i = 0; i < iters; i++) { fe26_mul(a, a, b); fe26_mul(b, b, a); }
+    u32 s = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) s ^= a.n[i] ^ b.n[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 template <typename F>
 static double time_ms(F&& f) {
     hipEvent_t a, b;
@@ -178,7 +219,13 @@ int main() {
         double ms = time_ms([&] { k_femul<<<blocks, 64>>>(out, it); });
         printf("fe_mul chain       wps %d : %8.2f G fe_mul/s\n", wps, lanes * (double)it * 2 / ms / 1e6);
         ms = time_ms([&] { k_femul2<<<blocks, 64>>>(out, it); });
-        printf("fe_mul 2 chains    wps %d : %8.2f G fe_mul/s\n", wps, lanes * (double)it * 4 / ms / 1e6);
+        printf("fe_sqr 4 chains    wps %d : %8.2f G fe_mul/s\n", wps, lanes * (double)it * 4 / ms / 1e6);
+        ms = time_ms([&] { k_femul26<<<blocks, 64>>>(out, it); });
+        printf("fe26_mul chain     wps %d : %8.2f G fe_mul/s\n", wps, lanes * (double)it * 2 / ms / 1e6);
+        if (wps <= 4) {
+            ms = time_ms([&] { k_pt26<<<blocks, 64>>>(out, 512); });
+            printf("pt26 add-mix       wps %d : %8.3f G op/s  (%.2f us per op per wave)\n", wps, lanes * 512.0 / ms / 1e6, ms * 1e3 / 512);
+        }
         for (int mode = 0; mode < 3 && wps <= 4; mode++) {
             const int itp = 512;
             ms = time_ms([&] { k_ptops<<<blocks, 64>>>(out, itp, mode); });
