@@ -141,7 +141,7 @@ def main():
         tr_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from the committed rocprofv3 --pmc run
         if os.path.exists(tr_path):
             try:
-                traffic = json.load(open(tr_path)).get(dom_name, {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tr_path)).get("kernels", {}).get(dom_name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         result = {
@@ -189,18 +189,29 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import bppp_oracle_c as OC                 # the oracle, as the timed CPU baseline ONLY
             m = min(args.cpu_sample, n)
-            cores = os.cpu_count() or 1
+            hw = os.cpu_count() or 1
+            # one thread first (64 proofs), then every thread count in a short ladder: containers often expose more hardware
+            # threads than their CPU quota, so the best rate and the thread count that gave it are what is reported
             t0 = time.perf_counter()
-            oacc, ost = OC.u64_verify_batch(gens, workload.LABEL, V[:m].copy(), P[:m].copy(), nthreads=cores)
-            dt = time.perf_counter() - t0
+            OC.u64_verify_batch(gens, workload.LABEL, V[:64].copy(), P[:64].copy(), nthreads=1)
+            single = 64 / (time.perf_counter() - t0)
+            best = None
+            ladder = sorted({hw, max(1, hw // 2), max(1, hw // 4), max(1, hw // 8), min(hw, 16)}, reverse=True)
+            for th in ladder:
+                t0 = time.perf_counter()
+                oacc, ost = OC.u64_verify_batch(gens, workload.LABEL, V[:m].copy(), P[:m].copy(), nthreads=th)
+                dt = time.perf_counter() - t0
+                if best is None or m / dt > best[0]:
+                    best = (m / dt, th, dt, bool((oacc == acc[:m]).all()))
             result["cpu_baseline"] = {
-                "value": m / dt,
+                "value": best[0],
                 "unit": "verifies/s",
-                "cores": cores,
+                "cores": best[1],
                 "kind": "port",
-                "sample": f"first {m} proofs of the same batch, reference-shaped C restatement (oracle/bppp_ref.c), "
-                          f"{cores} host threads, {dt:.2f} s wall",
-                "agrees_with_gpu": bool((oacc == acc[:m]).all()),
+                "sample": f"first {m} proofs of the same batch, reference-shaped C restatement (oracle/bppp_ref.c); best of thread "
+                          f"counts {ladder} = {best[1]} threads, {best[2]:.2f} s wall; box reports {hw} hardware threads",
+                "single_thread_value": single,
+                "agrees_with_gpu": best[3],
             }
         print(json.dumps(result), flush=True)
     proto.close()
