@@ -107,6 +107,14 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(VerifyWs ws, const 
     apt_to_xy64(out + 64 * t, a);
 }
 
+// wire format: 16 lanes per proof (14 points + scalar copy), SEC1 compressed -> the 64-byte form
+__global__ __launch_bounds__(256) void k_sec1_expand(uint8_t* commitments64, uint8_t* proofs928, const uint8_t* commitments33,
+                                                     const uint8_t* proofs525, size_t n) {
+    size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t t = g / 16;
+    int j = (int)(g % 16);
+    if (t < n && j < 15) sec1_expand_lane(commitments64, proofs928, commitments33, proofs525, t, j);
+}
 // ---- prover kernels (prove_core.h)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_a(ProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
@@ -184,6 +192,9 @@ struct bppp_ctx {
     // staging for the host-pointer entry points
     uint8_t* d_stage = nullptr;
     size_t stage_bytes = 0;
+    // expanded (64-byte) form of SEC1-compressed inputs
+    uint8_t* d_expand = nullptr;
+    size_t expand_bytes = 0;
     int* d_flags = nullptr;
     bool timing = false;
     std::vector<TimedLaunch> pending;
@@ -392,6 +403,7 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->d_straus) (void)hipFree(c->d_straus);
     if (c->d_pws) (void)hipFree(c->d_pws);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_expand) (void)hipFree(c->d_expand);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -627,6 +639,50 @@ int bppp_u64_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, si
     }
     (void)hipFree(d);
     if (e != hipSuccess) { g_last_error = std::string("prove_batch: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
+    return rc;
+}
+
+int bppp_u64_verify_batch_sec1_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments33,
+                                      const void* d_proofs525, void* d_accept, void* d_status, void* d_trace, void* d_reject_count) {
+    if (!c || !d_commitments33 || !d_proofs525 || !d_accept) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t need = n * (64 + (size_t)BPPP_U64_PROOF_BYTES);
+    if (need > c->expand_bytes) {
+        if (c->d_expand) { (void)hipFree(c->d_expand); c->d_expand = nullptr; c->expand_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->d_expand, need));
+        c->expand_bytes = need;
+    }
+    uint8_t* d_c64 = c->d_expand;
+    uint8_t* d_p928 = c->d_expand + n * 64;
+    const unsigned blocks = (unsigned)((n * 16 + 255) / 256);
+    k_sec1_expand<<<blocks, 256, 0, c->stream>>>(d_c64, d_p928, (const uint8_t*)d_commitments33, (const uint8_t*)d_proofs525, n);
+    HIP_TRY(hipGetLastError());
+    return bppp_u64_verify_batch_device(c, label, label_len, n, d_c64, d_p928, d_accept, d_status, d_trace, d_reject_count);
+}
+
+int bppp_u64_verify_batch_sec1(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments33,
+                               const uint8_t* proofs525, uint8_t* accept, int32_t* status) {
+    if (!c || !commitments33 || !proofs525 || !accept) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    uint8_t* d = nullptr;
+    const size_t o_c = 0, o_p = o_c + n * 33, o_a = o_p + n * (size_t)BPPP_U64_PROOF_SEC1_BYTES, o_s = (o_a + n + 3) / 4 * 4,
+                 total = o_s + n * sizeof(int32_t);
+    HIP_TRY(hipMalloc(&d, total));
+    int rc = BPPP_OK;
+    hipError_t e = hipMemcpyAsync(d + o_c, commitments33, n * 33, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_p, proofs525, n * (size_t)BPPP_U64_PROOF_SEC1_BYTES, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rc = bppp_u64_verify_batch_sec1_device(c, label, label_len, n, d + o_c, d + o_p, d + o_a, d + o_s, nullptr, nullptr);
+        if (rc == BPPP_OK) {
+            e = hipMemcpyAsync(accept, d + o_a, n, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess && status) e = hipMemcpyAsync(status, d + o_s, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) { g_last_error = std::string("verify_batch_sec1: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
     return rc;
 }
 

@@ -702,6 +702,54 @@ HD void verify_final_check(const VerifyWs& ws, size_t t) {
     verify_accept(ws, t);
 }
 
+// ---------------------------------------------------------------- wire format: SEC1 compressed points
+// The reference's SerializableProof (reciprocal.rs:37-41, circuit.rs:37-46, wnla.rs:33-38) holds k256 `AffinePoint`s, whose
+// byte form is 33-byte SEC1 compressed (02|03 || x; the identity is 33 zero bytes), and 32-byte big-endian scalars: a u64
+// proof is 13*33 + 3*32 = 525 bytes, its commitment 33.  One lane per point recovers y = sqrt(x^3 + 7) (p = 3 mod 4: one
+// exponentiation) and writes the 64-byte x||y form the verify pipeline reads.  An undecodable point (bad tag, x >= p,
+// x^3 + 7 a non-residue -- k256's from_bytes fails) becomes (x, 0), which is never on the curve, so verify_phase1 flags
+// BPPP_ST_BAD_ENCODING for that proof.
+#define BPPP_U64_PROOF_SEC1_BYTES 525
+HD void sec1_decompress_to_xy64(uint8_t* out64, const uint8_t* in33) {
+    u32 nz = 0;
+#pragma nounroll
+    for (int i = 0; i < 33; i++) nz |= in33[i];
+    fe x, rhs, y, y2, seven;
+    bool ok = fe_from_be(x, in33 + 1);
+    const uint8_t tag = in33[0];
+    ok &= (tag == 2) | (tag == 3);
+    fe_sqr(rhs, x);
+    fe_mul(rhs, rhs, x);
+    fe_set_u32(seven, 7);
+    fe_add(rhs, rhs, seven);
+    fe_sqrt_candidate(y, rhs);
+    fe_sqr(y2, y);
+    ok &= fe_eq(y2, rhs);
+    fe ny;
+    fe_neg_m<1>(ny, y);
+    fe_cmov(y, fe_is_odd(y) != ((tag & 1) != 0), ny);
+    fe zero;
+    fe_set_u32(zero, 0);
+    fe_cmov(y, !ok, zero);
+    const bool identity = nz == 0;
+    fe_cmov(x, identity, zero);
+    fe_cmov(y, identity, zero);
+    fe_to_be(out64, x);
+    fe_to_be(out64 + 32, y);
+}
+// lane j of proof t: j = 0 commitment, 1..13 proof points, 14 copies the three scalars
+HD void sec1_expand_lane(uint8_t* commitments64, uint8_t* proofs928, const uint8_t* commitments33, const uint8_t* proofs525,
+                         size_t t, int j) {
+    if (j == 0) sec1_decompress_to_xy64(commitments64 + 64 * t, commitments33 + 33 * t);
+    else if (j <= 13) sec1_decompress_to_xy64(proofs928 + (size_t)BPPP_U64_PROOF_BYTES * t + 64 * (j - 1),
+                                              proofs525 + (size_t)BPPP_U64_PROOF_SEC1_BYTES * t + 33 * (j - 1));
+    else if (j == 14) {
+#pragma nounroll
+        for (int i = 0; i < 96; i++)
+            proofs928[(size_t)BPPP_U64_PROOF_BYTES * t + 832 + i] = proofs525[(size_t)BPPP_U64_PROOF_SEC1_BYTES * t + 429 + i];
+    }
+}
+
 // ---------------------------------------------------------------- fixed-base table construction (context creation)
 // Pass 1: thread (b, w, chunk c) writes projective d * 2^(W w) * G_b for d in (c*CH, (c+1)*CH] into X/Y (table slots) and Z (ztmp).
 // Pass 2: same thread batch-inverts its Z's (Montgomery trick) and normalises the slots to affine.

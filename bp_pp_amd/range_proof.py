@@ -89,6 +89,17 @@ class U64RangeProofProtocol:
                                                              d_accept, d_status or None, d_trace or None,
                                                              d_reject_count or None))
 
+    def verify_batch_sec1(self, commitments33, proofs525, label: bytes) -> Tuple[np.ndarray, np.ndarray]:
+        """verify over the wire content of SerializableProof: 33-byte SEC1 points, 525-byte proofs (bp_pp_amd/wire.py)."""
+        commitments33 = _as_u8(commitments33, (-1, 33))
+        n = commitments33.shape[0]
+        proofs525 = _as_u8(proofs525, (n, 525))
+        accept = np.zeros(n, dtype=np.uint8)
+        status = np.zeros(n, dtype=np.int32)
+        _capi.check(_capi.lib().bppp_u64_verify_batch_sec1(self._ctx, label, len(label), n, commitments33.ctypes.data,
+                                                           proofs525.ctypes.data, accept.ctypes.data, status.ctypes.data))
+        return accept, status
+
     # ---- prove (u64_proof.rs:57-82)
     def prove(self, x: int, s: bytes, label: bytes, rnd: bytes) -> bytes:
         """One proof; `rnd` = the 52 x 32 bytes the reference would draw with Scalar::generate_biased, in draw order."""

@@ -1,0 +1,74 @@
+"""Wire formats of a u64 range proof, host side.
+
+Three byte-level forms of the same content:
+  * ABI form (include/bppp.h): 928 B = 13 x (x||y, 64 B) + 3 x 32 B
+  * SEC1 form: 525 B = 13 x 33 B compressed points + 3 x 32 B -- the bytes k256 puts into the reference's
+    `SerializableProof` (reciprocal.rs:37-41, circuit.rs:37-46, wnla.rs:33-38)
+  * JSON: the `serde_json` shape of `reciprocal::SerializableProof`:
+        {"circuit_proof": {"c_l", "c_r", "c_o", "c_s", "r": [...], "x": [...], "l": [...], "n": [...]}, "r"}
+    with every point / scalar as a hex string.  k256's serde goes through `serdect` (hex for human-readable formats);
+    whether it emits upper- or lower-case hex cannot be checked here (no Rust toolchain) -- this module WRITES upper case
+    and READS either.
+Only integer arithmetic on the curve equation is needed (square root for decompression), no group law.
+"""
+from __future__ import annotations
+
+import json
+from typing import Dict, List
+
+P = 2**256 - 2**32 - 977
+POINT_FIELDS = ["c_l", "c_r", "c_o", "c_s"]
+
+
+def compress_point(xy64: bytes) -> bytes:
+    if xy64 == bytes(64):
+        return bytes(33)
+    y = int.from_bytes(xy64[32:], "big")
+    return bytes([2 + (y & 1)]) + xy64[:32]
+
+
+def decompress_point(sec1: bytes) -> bytes:
+    if sec1 == bytes(33):
+        return bytes(64)
+    if len(sec1) != 33 or sec1[0] not in (2, 3):
+        raise ValueError("bad SEC1 compressed point")
+    x = int.from_bytes(sec1[1:], "big")
+    if x >= P:
+        raise ValueError("x out of range")
+    rhs = (x * x * x + 7) % P
+    y = pow(rhs, (P + 1) // 4, P)
+    if y * y % P != rhs:
+        raise ValueError("not on the curve")
+    if (y & 1) != (sec1[0] & 1):
+        y = P - y
+    return sec1[1:] + y.to_bytes(32, "big")
+
+
+def abi_to_sec1(proof928: bytes) -> bytes:
+    assert len(proof928) == 928
+    return b"".join(compress_point(proof928[64 * i:64 * i + 64]) for i in range(13)) + proof928[832:]
+
+
+def sec1_to_abi(proof525: bytes) -> bytes:
+    assert len(proof525) == 525
+    return b"".join(decompress_point(proof525[33 * i:33 * i + 33]) for i in range(13)) + proof525[429:]
+
+
+def sec1_to_json(proof525: bytes) -> str:
+    pts = [proof525[33 * i:33 * i + 33].hex().upper() for i in range(13)]
+    sc = [proof525[429 + 32 * i:429 + 32 * i + 32].hex().upper() for i in range(3)]
+    doc = {"circuit_proof": {"c_l": pts[0], "c_r": pts[1], "c_o": pts[2], "c_s": pts[3], "r": pts[4:8], "x": pts[8:12],
+                             "l": sc[0:2], "n": sc[2:3]}, "r": pts[12]}
+    return json.dumps(doc, indent=2)
+
+
+def json_to_sec1(text: str) -> bytes:
+    doc = json.loads(text)
+    cp = doc["circuit_proof"]
+    if len(cp["r"]) != 4 or len(cp["x"]) != 4 or len(cp["l"]) != 2 or len(cp["n"]) != 1:
+        raise ValueError("not a u64 range proof shape (r, x: 4 points; l: 2 scalars; n: 1 scalar)")
+    pts: List[str] = [cp[k] for k in POINT_FIELDS] + list(cp["r"]) + list(cp["x"]) + [doc["r"]]
+    out = b"".join(bytes.fromhex(h) for h in pts) + b"".join(bytes.fromhex(h) for h in list(cp["l"]) + list(cp["n"]))
+    if len(out) != 525:
+        raise ValueError("bad field length")
+    return out

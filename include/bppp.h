@@ -84,6 +84,21 @@ BPPP_API int bppp_u64_verify_batch_device(bppp_ctx* ctx, const uint8_t* label, s
                                  const void* d_commitments, const void* d_proofs, void* d_accept, void* d_status,
                                  void* d_trace, void* d_reject_count);
 
+/* The same verify over the reference's WIRE content: what `reciprocal::SerializableProof` / `circuit::SerializableProof`
+ * (reciprocal.rs:37-41, circuit.rs:37-46) carry -- k256 `AffinePoint`s, whose byte form is 33-byte SEC1 compressed
+ * (02|03 || x, identity = 33 zero bytes), and 32-byte big-endian scalars.  proofs: n x 525 bytes (13 x 33 in the order
+ * c_l, c_r, c_o, c_s, r[0..3], x[0..3], reciprocal.r, then l[0], l[1], n[0]); commitments: n x 33 bytes.  Points are
+ * decompressed on the device (one square root in Fp per point); a point k256's from_bytes would reject (bad tag, x >= p,
+ * not on the curve) yields BPPP_ST_BAD_ENCODING for that proof.  Host pointers / device pointers as above. */
+#define BPPP_U64_PROOF_SEC1_BYTES 525
+#define BPPP_POINT_SEC1_BYTES 33
+BPPP_API int bppp_u64_verify_batch_sec1(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n,
+                                        const uint8_t* commitments /* n x 33 */, const uint8_t* proofs /* n x 525 */,
+                                        uint8_t* accept /* n */, int32_t* status /* n or NULL */);
+BPPP_API int bppp_u64_verify_batch_sec1_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n,
+                                               const void* d_commitments, const void* d_proofs, void* d_accept, void* d_status,
+                                               void* d_trace, void* d_reject_count);
+
 /* U64RangeProofProtocol::prove (u64_proof.rs:57-82) for n independent values, fresh `Transcript::new(label)` per proof.
  * rnd holds, per proof, the 52 scalars the reference draws with `Scalar::generate_biased(rng)` in its draw order
  * (reciprocal.rs:121 r_blind | circuit.rs:264-298 ro x7, rl x6, rr x5 | circuit.rs:371 ls x17 | circuit.rs:372 ns x16), so

@@ -200,4 +200,9 @@ int emul_u64_prove_batch(const uint8_t* table, int W, const uint8_t* label, size
     }
     return 0;
 }
+// wire format: SEC1 compressed inputs -> 64-byte form, lane by lane
+void emul_sec1_expand(size_t n, const uint8_t* c33, const uint8_t* p525, uint8_t* c64, uint8_t* p928) {
+    for (size_t t = 0; t < n; t++)
+        for (int j = 0; j < 15; j++) sec1_expand_lane(c64, p928, c33, p525, t, j);
+}
 }

@@ -27,4 +27,5 @@ def load():
     L.emul_merlin_kat.argtypes = [cp, sz, cp, sz, vp, sz]
     L.emul_u64_verify_batch.argtypes = [vp, i32, cp, sz, sz, vp, vp, vp, vp, vp]
     L.emul_u64_prove_batch.argtypes = [vp, i32, cp, sz, sz, vp, vp, vp, vp, vp, vp]
+    L.emul_sec1_expand.argtypes = [sz, vp, vp, vp, vp]
     return L

@@ -133,3 +133,23 @@ def test_full_size_batch_properties(torch_mod, gold):
         assert (oacc == acc[idx]).all()
     finally:
         proto.close()
+
+
+def test_sec1_wire_inputs(torch_mod, proto, gold, oracle_c):
+    """the same verify fed with the reference's wire content (33-byte SEC1 points, 525-byte proofs)."""
+    import workload
+    from bp_pp_amd import wire
+    n = 300
+    gens, V, P, _ = workload.make_batch(n, first=2000)
+    P, expect = workload.corrupt(P, V, every=11)
+    C33 = np.frombuffer(b"".join(wire.compress_point(bytes(V[i])) for i in range(n)), dtype=np.uint8).reshape(n, 33).copy()
+    P525 = np.frombuffer(b"".join(wire.abi_to_sec1(bytes(P[i])) for i in range(n)), dtype=np.uint8).reshape(n, 525).copy()
+    P525[5, 0] = 4                      # bad SEC1 tag
+    P525[6, 33:66] = np.frombuffer(b"\x02" + (5).to_bytes(32, "big"), dtype=np.uint8)     # x without a square root
+    P525[7, 0] ^= 1                     # the other root of c_l: decodes, must be rejected by the protocol
+    acc, st = proto.verify_batch_sec1(C33, P525, workload.LABEL)
+    acc_ref, st_ref = proto.verify_batch(V, P, workload.LABEL)
+    keep = np.ones(n, bool); keep[[5, 6, 7]] = False
+    assert (acc[keep] == acc_ref[keep]).all() and (acc[keep] == expect[keep]).all() and not st[keep].any()
+    assert st[5] == 1 and st[6] == 1 and acc[5] == 0 and acc[6] == 0
+    assert st[7] == 0 and acc[7] == 0

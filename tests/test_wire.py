@@ -1,0 +1,81 @@
+"""Wire format, CPU tier: bp_pp_amd/wire.py against the oracle's SEC1 encoding, the JSON mirror of
+`SerializableProof`, and the device decompression code (compiled for the host) against both."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import bppp_oracle as O
+from bp_pp_amd import wire
+from emul.build import load
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(GOLD, "u64_golden.json")) as f:
+        return json.load(f)
+
+
+def test_point_compression_matches_k256_semantics():
+    for k in [1, 2, 3, 0xDEADBEEF, O.N - 1]:
+        p = O.pt_mul(O.G, k)
+        assert wire.compress_point(O.pt_to_xy64(p)) == O.pt_to_bytes(p)
+        assert wire.decompress_point(O.pt_to_bytes(p)) == O.pt_to_xy64(p)
+    assert wire.compress_point(bytes(64)) == bytes(33) and wire.decompress_point(bytes(33)) == bytes(64)
+    with pytest.raises(ValueError):
+        wire.decompress_point(b"\x04" + bytes(32))
+    with pytest.raises(ValueError):
+        wire.decompress_point(b"\x02" + (5).to_bytes(32, "big"))      # x = 5: x^3 + 7 = 132 is a non-residue mod p
+    with pytest.raises(ValueError):
+        wire.decompress_point(b"\x02" + O.P.to_bytes(32, "big"))
+
+
+def test_proof_forms_round_trip(gold):
+    for c in gold["cases"]:
+        abi = bytes.fromhex(c["proof"])
+        sec1 = wire.abi_to_sec1(abi)
+        assert len(sec1) == 525 and wire.sec1_to_abi(sec1) == abi
+        text = wire.sec1_to_json(sec1)
+        doc = json.loads(text)
+        assert set(doc) == {"circuit_proof", "r"} and set(doc["circuit_proof"]) == {"c_l", "c_r", "c_o", "c_s", "r", "x", "l", "n"}
+        assert wire.json_to_sec1(text) == sec1 and wire.json_to_sec1(text.lower()) == sec1
+        proof = O.u64_proof_from_bytes(abi)                              # field order = the reference's struct order
+        assert bytes.fromhex(doc["circuit_proof"]["c_s"]) == O.pt_to_bytes(proof.circuit_proof.c_s)
+        assert bytes.fromhex(doc["circuit_proof"]["x"][3]) == O.pt_to_bytes(proof.circuit_proof.x[3])
+        assert bytes.fromhex(doc["r"]) == O.pt_to_bytes(proof.r)
+        assert bytes.fromhex(doc["circuit_proof"]["n"][0]) == O.sc_to_bytes(proof.circuit_proof.n[0])
+
+
+def test_device_decompression_code(gold):
+    L = load()
+    cases = gold["cases"]
+    n = len(cases) + 4
+    c33 = [wire.compress_point(bytes.fromhex(c["commitment"])) for c in cases]
+    p525 = [wire.abi_to_sec1(bytes.fromhex(c["proof"])) for c in cases]
+    exp_c = [bytes.fromhex(c["commitment"]) for c in cases]
+    exp_p = [bytes.fromhex(c["proof"]) for c in cases]
+    bad = bytearray(p525[0]); bad[0] = 4                                 # bad tag on c_l
+    c33.append(c33[0]); p525.append(bytes(bad)); exp_c.append(exp_c[0]); exp_p.append(None)
+    bad = bytearray(p525[0]); bad[33:66] = b"\x02" + (5).to_bytes(32, "big")   # c_r: x with no square root
+    c33.append(c33[0]); p525.append(bytes(bad)); exp_c.append(exp_c[0]); exp_p.append(None)
+    idp = bytearray(p525[0]); idp[132:165] = bytes(33)                    # r[0] = identity
+    c33.append(bytes(33)); p525.append(bytes(idp)); exp_c.append(bytes(64)); exp_p.append(wire.sec1_to_abi(bytes(idp)))
+    flip = bytearray(p525[1]); flip[0] ^= 1                               # the other square root of c_l
+    c33.append(c33[1]); p525.append(bytes(flip)); exp_c.append(exp_c[1]); exp_p.append(wire.sec1_to_abi(bytes(flip)))
+    C33 = np.frombuffer(b"".join(c33), dtype=np.uint8).copy()
+    P525 = np.frombuffer(b"".join(p525), dtype=np.uint8).copy()
+    C64, P928 = np.zeros(n * 64, np.uint8), np.zeros(n * 928, np.uint8)
+    L.emul_sec1_expand(n, C33.ctypes.data, P525.ctypes.data, C64.ctypes.data, P928.ctypes.data)
+    for i in range(n):
+        assert bytes(C64[64 * i:64 * i + 64]) == exp_c[i]
+        got = bytes(P928[928 * i:928 * i + 928])
+        if exp_p[i] is not None:
+            assert got == exp_p[i]
+    # undecodable points come out as (x, 0): off the curve, so the verifier flags them
+    g = bytes(P928[928 * len(cases):928 * len(cases) + 64])
+    assert g[32:] == bytes(32) and not O.on_curve((int.from_bytes(g[:32], "big"), 0))
+    g = bytes(P928[928 * (len(cases) + 1) + 64:928 * (len(cases) + 1) + 128])
+    assert g[:32] == (5).to_bytes(32, "big") and g[32:] == bytes(32)
