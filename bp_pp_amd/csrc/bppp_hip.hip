@@ -14,6 +14,7 @@
 
 #include "../../include/bppp.h"
 #include "prove_core.h"
+#include "wnla_core.h"
 
 using namespace bppp;
 
@@ -151,6 +152,47 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(
     if (lane == 0) prove_msm_store(w, job, t, part);
 }
 
+// ---- generic WNLA kernels (wnla_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_scalars(WnlaWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_commit_scalars(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(WnlaWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_verify_begin(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round(WnlaWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_verify_round(w, t, k);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars(WnlaWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_verify_final_scalars(w, t);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(WnlaWs w, int commit_mode) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt part;
+    wnla_msm_lane(part, w, t, lane);
+    lane_group_sum(part);
+    if (lane == 0) wnla_verify_store(w, t, part);
+    (void)commit_mode;
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(WnlaWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) {
+        pt total;
+        ws_ld_pt(total, w.pfix, w.N, t);
+        wnla_commit_store(w, t, total);
+    }
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(WnlaWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_verify_accept(w, t);
+}
+
 // ---------------------------------------------------------------- host side
 static thread_local std::string g_last_error;
 
@@ -172,6 +214,7 @@ struct TimedLaunch { int id; hipEvent_t a, b; };
 struct bppp_ctx {
     int device = 0;
     int fb_w = 16;
+    int ng = 16, nh = 32, nbases = BPPP_NG;   // generator set: g, g_vec[ng], h_vec[nh]
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;   // runs the fixed-base half of C0 concurrently with the variable-base half
@@ -328,8 +371,14 @@ const char* bppp_strerror(int code) {
 const char* bppp_last_error(void) { return g_last_error.c_str(); }
 
 int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, const uint8_t* h_vec, int device, int fb_window_bits) {
-    if (!out || !g || !g_vec || !h_vec) return BPPP_ERR_INVALID_ARG;
+    return bppp_wnla_ctx_create(out, g, g_vec, 16, h_vec, 32, device, fb_window_bits);
+}
+
+int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, size_t ng, const uint8_t* h_vec, size_t nh, int device,
+                         int fb_window_bits) {
+    if (!out || !g || (!g_vec && ng) || (!h_vec && nh) || ng > 4096 || nh > 4096) return BPPP_ERR_INVALID_ARG;
     *out = nullptr;
+    const int NB = 1 + (int)ng + (int)nh;
     int W = fb_window_bits ? fb_window_bits : 16;
     if (W != 4 && W != 8 && W != 16) return BPPP_ERR_INVALID_ARG;
     int rc = check_device(device);
@@ -339,6 +388,7 @@ int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, c
     if (!c) return BPPP_ERR_NOMEM;
     c->device = device;
     c->fb_w = W;
+    c->ng = (int)ng; c->nh = (int)nh; c->nbases = NB;
     auto fail = [&](int code) { bppp_ctx_destroy(c); return code; };
 #define HIP_TRY_C(expr)                                                             \
     do {                                                                            \
@@ -353,18 +403,18 @@ int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, c
     HIP_TRY_C(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIP_TRY_C(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY_C(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    HIP_TRY_C(hipMalloc(&c->d_gens, BPPP_NG * sizeof(apt)));
+    HIP_TRY_C(hipMalloc(&c->d_gens, NB * sizeof(apt)));
     HIP_TRY_C(hipMalloc(&c->d_flags, sizeof(int)));
     HIP_TRY_C(hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
     // upload + decode generators
-    uint8_t hg[BPPP_NG * 64];
-    std::memcpy(hg, g, 64);
-    std::memcpy(hg + 64, g_vec, 16 * 64);
-    std::memcpy(hg + 17 * 64, h_vec, 32 * 64);
+    std::vector<uint8_t> hg((size_t)NB * 64);
+    std::memcpy(hg.data(), g, 64);
+    if (ng) std::memcpy(hg.data() + 64, g_vec, ng * 64);
+    if (nh) std::memcpy(hg.data() + (1 + ng) * 64, h_vec, nh * 64);
     uint8_t* d_raw = nullptr;
-    HIP_TRY_C(hipMalloc(&d_raw, sizeof hg));
-    HIP_TRY_C(hipMemcpyAsync(d_raw, hg, sizeof hg, hipMemcpyHostToDevice, c->stream));
-    k_decode_generators<<<1, 64, 0, c->stream>>>(d_raw, c->d_gens, BPPP_NG, c->d_flags);
+    HIP_TRY_C(hipMalloc(&d_raw, hg.size()));
+    HIP_TRY_C(hipMemcpyAsync(d_raw, hg.data(), hg.size(), hipMemcpyHostToDevice, c->stream));
+    k_decode_generators<<<(NB + 63) / 64, 64, 0, c->stream>>>(d_raw, c->d_gens, NB, c->d_flags);
     int flags = 0;
     HIP_TRY_C(hipMemcpyAsync(&flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY_C(hipStreamSynchronize(c->stream));
@@ -373,13 +423,13 @@ int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, c
     // fixed-base tables
     const int nwin = 256 / W;
     const size_t per_win = ((size_t)1 << W) - 1;
-    const size_t entries = (size_t)BPPP_NG * nwin * per_win;
+    const size_t entries = (size_t)NB * nwin * per_win;
     c->table_bytes = entries * sizeof(apt_packed);
     HIP_TRY_C(hipMalloc(&c->d_table, c->table_bytes));
     fe* d_tmp = nullptr;   // x, y, z, prefix products of every entry (freed after the build)
     HIP_TRY_C(hipMalloc(&d_tmp, entries * 4 * sizeof(fe)));
-    FbBuild fb{c->d_gens, BPPP_NG, W, c->d_table, d_tmp, d_tmp + entries, d_tmp + 2 * entries, d_tmp + 3 * entries};
-    size_t nthreads = (size_t)BPPP_NG * nwin * fb_chunks_per_window(W);
+    FbBuild fb{c->d_gens, NB, W, c->d_table, d_tmp, d_tmp + entries, d_tmp + 2 * entries, d_tmp + 3 * entries};
+    size_t nthreads = (size_t)NB * nwin * fb_chunks_per_window(W);
     unsigned blocks = (unsigned)((nthreads + BPPP_BLOCK - 1) / BPPP_BLOCK);
     k_fb_build_pass1<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
     k_fb_build_pass2<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
@@ -422,7 +472,7 @@ int bppp_ctx_set_stream(bppp_ctx* c, void* hip_stream) {
 
 size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
     if (!c) return 0;
-    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->pws_bytes + c->stage_bytes + BPPP_NG * sizeof(apt);
+    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->pws_bytes + c->stage_bytes + (size_t)c->nbases * sizeof(apt);
 }
 
 int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
@@ -450,6 +500,7 @@ int bppp_ctx_get_timings(bppp_ctx* c, int max_entries, const char** names, doubl
 int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
                                  const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count) {
     if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept) return BPPP_ERR_INVALID_ARG;
+    if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;   // u64 entry points need the u64 generator shape
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_capacity(c, n);
@@ -542,6 +593,7 @@ int bppp_u64_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, s
 
 int bppp_u64_commit_value_batch(bppp_ctx* c, size_t n, const uint64_t* x, const uint8_t* s, uint8_t* out) {
     if (!c || !x || !s || !out) return BPPP_ERR_INVALID_ARG;
+    if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_capacity(c, n);
@@ -571,6 +623,7 @@ int bppp_u64_commit_value_batch(bppp_ctx* c, size_t n, const uint64_t* x, const 
 int bppp_u64_prove_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
                                 const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status) {
     if (!c || (!label && label_len) || !d_x || !d_s || !d_rnd || !d_proofs || !d_commitments) return BPPP_ERR_INVALID_ARG;
+    if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_prove_capacity(c, n);
@@ -684,6 +737,96 @@ int bppp_u64_verify_batch_sec1(bppp_ctx* c, const uint8_t* label, size_t label_l
     (void)hipFree(d);
     if (e != hipSuccess) { g_last_error = std::string("verify_batch_sec1: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
     return rc;
+}
+
+// ---- generic WeightNormLinearArgument entry points (host pointers; one device blob per call)
+struct WnlaBlob {
+    uint8_t* d = nullptr;
+    ~WnlaBlob() { if (d) (void)hipFree(d); }
+};
+static size_t align16(size_t x) { return (x + 15) / 16 * 16; }
+
+static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                    const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, size_t rounds, const uint8_t* proof_r,
+                    const uint8_t* proof_x, const uint8_t* proof_l, size_t nl, const uint8_t* proof_n, size_t nn, uint8_t* out_points,
+                    uint8_t* accept, int32_t* status) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (rounds > 12 || nl > 4096 || nn > 4096) return BPPP_ERR_INVALID_ARG;
+    int rc = ensure_capacity(c, n);   // Straus tables
+    if (rc != BPPP_OK) return rc;
+    const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds;
+    // layout of the blob: inputs | outputs | workspace
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    const size_t o_com = take(n * 64), o_c = take(n * (size_t)c->nh * 32), o_rho = take(n * 32), o_mu = take(n * 32),
+                 o_r = take(n * rounds * 64), o_x = take(n * rounds * 64), o_l = take(n * nl * 32), o_n = take(n * nn * 32),
+                 o_out = take(n * 64), o_acc = take(n), o_st = take(n * 4), o_ts = take(52 * n * 4), o_a = take(30 * n * 4),
+                 o_pf = take(30 * n * 4), o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4),
+                 o_msc = take(NB * 8 * n * 4);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    auto up = [&](size_t o, const uint8_t* src, size_t bytes) -> hipError_t {
+        return (src && bytes) ? hipMemcpyAsync(d + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+    };
+    HIP_TRY(up(o_com, commitments, n * 64));
+    HIP_TRY(up(o_c, cvec, n * (size_t)c->nh * 32));
+    HIP_TRY(up(o_rho, rho, n * 32));
+    HIP_TRY(up(o_mu, mu, n * 32));
+    HIP_TRY(up(o_r, proof_r, n * rounds * 64));
+    HIP_TRY(up(o_x, proof_x, n * rounds * 64));
+    HIP_TRY(up(o_l, proof_l, n * nl * 32));
+    HIP_TRY(up(o_n, proof_n, n * nn * 32));
+    WnlaWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.ng = c->ng; w.nh = c->nh; w.rounds = (int)rounds; w.nl = (int)nl; w.nn = (int)nn;
+    w.commitments = d + o_com; w.c = d + o_c; w.rho = d + o_rho; w.mu = d + o_mu; w.proof_r = d + o_r; w.proof_x = d + o_x;
+    w.proof_l = d + o_l; w.proof_n = d + o_n; w.out_points = d + o_out; w.accept = d + o_acc; w.status = (int32_t*)(d + o_st);
+    w.tstate = (u32*)(d + o_ts); w.acc = (u32*)(d + o_a); w.pfix = (u32*)(d + o_pf); w.ys = (u32*)(d + o_ys);
+    w.tab = (u32*)(d + o_tab); w.msc = (u32*)(d + o_msc);
+    w.straus = c->d_straus;
+    w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    if (!commit) t_new(w.base, label, (u32)label_len);
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    if (commit) {
+        k_wnla_commit_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1);
+        k_wnla_commit_store<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out_points, d + o_out, n * 64, hipMemcpyDeviceToHost, s));
+    } else {
+        k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        for (int k = 1; k <= (int)rounds; k++) k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+        k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
+        k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
+    }
+    if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return BPPP_OK;
+}
+
+int bppp_wnla_commit_batch(bppp_ctx* c, size_t n, const uint8_t* cvec, const uint8_t* mu, const uint8_t* l, size_t nl,
+                           const uint8_t* nvec, size_t nn, uint8_t* out, int32_t* status) {
+    if (!c || !cvec || !mu || (!l && nl) || (!nvec && nn) || !out) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    return wnla_run(c, true, nullptr, 0, n, nullptr, cvec, nullptr, mu, 0, nullptr, nullptr, l, nl, nvec, nn, out, nullptr, status);
+}
+
+int bppp_wnla_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                           const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, size_t rounds, const uint8_t* proof_r,
+                           const uint8_t* proof_x, const uint8_t* proof_l, size_t nl, const uint8_t* proof_n, size_t nn,
+                           uint8_t* accept, int32_t* status) {
+    if (!c || (!label && label_len) || !commitments || !cvec || !rho || !mu || (rounds && (!proof_r || !proof_x)) || (!proof_l && nl) ||
+        (!proof_n && nn) || !accept)
+        return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    return wnla_run(c, false, label, label_len, n, commitments, cvec, rho, mu, rounds, proof_r, proof_x, proof_l, nl, proof_n, nn, nullptr,
+                    accept, status);
 }
 
 }  // extern "C"

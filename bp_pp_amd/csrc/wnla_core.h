@@ -1,0 +1,224 @@
+// Generic batched `WeightNormLinearArgument::{commit, verify}` (wnla.rs:66-121) for arbitrary generator-vector sizes:
+// the crate's `wnla` API surface (tests.rs:139-171 uses N = 4; an "aggregated" reciprocal proof with dim_nd = 256 uses
+// |h_vec| = 512, |g_vec| = 256, 8 rounds).  n independent instances share one generator set (g, g_vec[ng], h_vec[nh]) and
+// one shape (rounds = proof.x.len() = proof.r.len(), nl = proof.l.len(), nn = proof.n.len()); c, rho, mu, the commitment and
+// the proof are per instance.
+//
+// Same restructuring as the u64 path: the per-round generator folds (wnla.rs:96-97) are never executed -- after k rounds,
+// original generator i sits in folded slot i >> k with coefficient  ch(i) = prod_{t<k, bit t of i} y_{t+1}  (h_vec, c) or
+// cg(i) = prod_{t<k} (bit t of i ? y_{t+1} : rho_{t+1})  (g_vec), for ANY lengths (reduce() = even/odd split, util.rs:7-22,
+// and the zero-extension of vector_add, util.rs:69-76, make the odd-length cases fall out of the same bit rule).  Only
+// com_ = com + y X + (y^2 - 1) R runs per round (the next challenge hashes it); the base case (wnla.rs:80-82) is one
+// (1 + ng + nh)-term fixed-base MSM.  Length quirks are reproduced: extra entries of proof.l / proof.n beyond the folded
+// generator vectors multiply identities (util.rs:24-26) but extra n entries still enter |n|^2_mu (wnla.rs:67).
+#pragma once
+#include "verify_core.h"
+
+namespace bppp {
+
+struct WnlaWs {
+    size_t N;
+    int ng, nh, rounds, nl, nn;
+    const uint8_t *commitments, *c, *rho, *mu, *proof_r, *proof_x, *proof_l, *proof_n;   // C-ABI layouts (device memory)
+    uint8_t* accept;
+    uint8_t* out_points;   // commit: n x 64
+    int32_t* status;
+    u32* tstate;           // [52][N]
+    u32* acc;              // [30][N]
+    u32* pfix;             // [30][N]
+    u32* ys;               // [rounds*8][N]
+    u32* tab;              // [2 * 2^rounds * 8][N]: ch table then cg table
+    u32* msc;              // [(1+ng+nh)*8][N]
+    pt_slot* straus;       // [N][2][9]
+    FbTable fb;
+    strobe base;
+};
+HD size_t wnla_ceil_shift(size_t n, int k) { return (n + (((size_t)1 << k) - 1)) >> k; }
+
+// ---- WeightNormLinearArgument::commit: scalars of  v g + <h_vec, l> + <g_vec, n>,  v = <c, l> + sum n_j^2 mu^(j+1)   (wnla.rs:66-72)
+HD void wnla_commit_scalars(const WnlaWs& w, size_t t) {
+    const size_t N = w.N;
+    int32_t status = ST_OK;
+    sc mu, v, mp, t1, zero;
+    sc_set_u32(zero, 0);
+    sc_set_u32(v, 0);
+    bool ok = sc_from_be(mu, w.mu + 32 * t);
+    mp = mu;
+#pragma nounroll
+    for (int j = 0; j < w.nn; j++) {
+        sc nj;
+        ok &= sc_from_be(nj, w.proof_n + ((size_t)t * w.nn + j) * 32);
+        sc_mul(t1, nj, nj); sc_mul(t1, t1, mp); sc_add(v, v, t1);
+        sc_mul(mp, mp, mu);
+        if (j < w.ng) ws_st8(w.msc, N, t, 1 + j, nj.v);
+    }
+#pragma nounroll
+    for (int j = w.nn; j < w.ng; j++) ws_st8(w.msc, N, t, 1 + j, zero.v);
+#pragma nounroll
+    for (int i = 0; i < w.nl; i++) {
+        sc li;
+        ok &= sc_from_be(li, w.proof_l + ((size_t)t * w.nl + i) * 32);
+        if (i < w.nh) {
+            sc ci;
+            ok &= sc_from_be(ci, w.c + ((size_t)t * w.nh + i) * 32);
+            sc_mul(t1, ci, li); sc_add(v, v, t1);
+            ws_st8(w.msc, N, t, 1 + w.ng + i, li.v);
+        }
+    }
+#pragma nounroll
+    for (int i = w.nl; i < w.nh; i++) ws_st8(w.msc, N, t, 1 + w.ng + i, zero.v);
+    if (!ok) { status |= ST_BAD_ENCODING; sc_set_u32(v, 0); }
+    ws_st8(w.msc, N, t, 0, v.v);
+    w.status[t] = status;
+}
+HD void wnla_commit_store(const WnlaWs& w, size_t t, const pt& total) {
+    apt a;
+    pt_to_affine(a, total);
+    if (w.status[t] != ST_OK) { fe_set_u32(a.x, 0); fe_set_u32(a.y, 0); }
+    apt_to_xy64(w.out_points + 64 * t, a);
+}
+
+// ---- verify: decode the commitment, start the transcript
+HD void wnla_verify_begin(const WnlaWs& w, size_t t) {
+    int32_t status = ST_OK;
+    apt C;
+    bool ok = apt_from_xy64(C, w.commitments + 64 * t);
+    sc s;
+    ok &= sc_from_be(s, w.rho + 32 * t);
+    ok &= sc_from_be(s, w.mu + 32 * t);
+    if (!ok) { status |= ST_BAD_ENCODING; fe_set_u32(C.x, 0); fe_set_u32(C.y, 0); }
+    pt P;
+    pt_from_affine(P, C);
+    ws_st_pt(w.acc, w.N, t, P);
+    ws_st_strobe(w.tstate, w.N, t, w.base);
+    w.status[t] = status;
+}
+// ---- verify: round k = 1..rounds (wnla.rs:84-102), X = proof.x[rounds - k], R = proof.r[rounds - k]
+HD void wnla_verify_round(const WnlaWs& w, size_t t, int k) {
+    const size_t N = w.N;
+    int32_t status = w.status[t];
+    pt C;
+    ws_ld_pt(C, w.acc, N, t);
+    apt Ca, X, R;
+    pt_to_affine(Ca, C);
+    bool ok = apt_from_xy64(X, w.proof_x + ((size_t)t * w.rounds + (w.rounds - k)) * 64);
+    ok &= apt_from_xy64(R, w.proof_r + ((size_t)t * w.rounds + (w.rounds - k)) * 64);
+    if (!ok) { status |= ST_BAD_ENCODING; fe_set_u32(X.x, 0); fe_set_u32(X.y, 0); R = X; }
+    strobe tr;
+    ws_ld_strobe(tr, w.tstate, N, t);
+    app_point(tr, "wnla_com", Ca);
+    app_point(tr, "wnla_x", X);
+    app_point(tr, "wnla_r", R);
+    t_append_u64(tr, "l.sz", (u64)wnla_ceil_shift((size_t)w.nh, k - 1));     // self.h_vec.len() of this level
+    t_append_u64(tr, "n.sz", (u64)wnla_ceil_shift((size_t)w.ng, k - 1));
+    sc y;
+    if (!t_get_challenge(tr, "wnla_challenge", y)) { status |= ST_DEGENERATE; sc_set_u32(y, 1); }
+    ws_st_strobe(w.tstate, N, t, tr);
+    ws_st8(w.ys, N, t, k - 1, y.v);
+    sc y2m1, one;
+    sc_set_u32(one, 1);
+    sc_mul(y2m1, y, y);
+    sc_sub(y2m1, y2m1, one);
+    pt_slot* tbl = w.straus + t * (2 * BPPP_STRAUS_ENTRIES);
+    glv_split rs[2];
+    straus_build_table(tbl, X);
+    straus_build_table(tbl + BPPP_STRAUS_ENTRIES, R);
+    glv_decompose(rs[0], y);
+    glv_decompose(rs[1], y2m1);
+    pt acc;
+    straus_msm_glv(acc, tbl, rs, 2);
+    pt_madd(acc, acc, Ca, apt_is_identity(Ca));
+    ws_st_pt(w.acc, N, t, acc);
+    w.status[t] = status;
+}
+// ---- verify: base case scalars (wnla.rs:80-82 with :66-72), generators unrolled
+HD void wnla_verify_final_scalars(const WnlaWs& w, size_t t) {
+    const size_t N = w.N;
+    const int k = w.rounds;
+    const int T = 1 << k;
+    int32_t status = w.status[t];
+    sc rho, mu, one, zero, t1;
+    sc_set_u32(one, 1);
+    sc_set_u32(zero, 0);
+    bool ok = sc_from_be(rho, w.rho + 32 * t);
+    ok &= sc_from_be(mu, w.mu + 32 * t);
+    // coefficient tables over the low k index bits: ch[b] = prod_{bit t of b} y_{t+1}; cg[b] = prod_t (bit ? y_{t+1} : rho_{t+1})
+    ws_st8(w.tab, N, t, 0, one.v);
+    ws_st8(w.tab, N, t, T, one.v);
+    sc rt = rho, mt = mu;    // rho_{t+1}, mu_{t+1}
+#pragma nounroll
+    for (int r = 0; r < k; r++) {
+        sc y;
+        ws_ld8(y.v, w.ys, N, t, r);
+        const int half = 1 << r;
+#pragma nounroll
+        for (int b = 0; b < half; b++) {
+            sc ch, cg;
+            ws_ld8(ch.v, w.tab, N, t, b);
+            ws_ld8(cg.v, w.tab, N, t, T + b);
+            sc_mul(t1, ch, y);
+            ws_st8(w.tab, N, t, b + half, t1.v);
+            sc_mul(t1, cg, y);
+            ws_st8(w.tab, N, t, T + b + half, t1.v);
+            sc_mul(t1, cg, rt);
+            ws_st8(w.tab, N, t, T + b, t1.v);
+        }
+        rt = mt;                     // wnla.rs:109-110: rho <- mu, mu <- mu^2
+        sc_mul(mt, mt, mt);
+    }
+    const sc mu_fin = mt;
+    // v = <c', l> + sum_j n_j^2 mu_fin^(j+1);  c'_j = sum_{i >> k == j} c_i ch(i)
+    sc v, mp = mu_fin;
+    sc_set_u32(v, 0);
+#pragma nounroll
+    for (int j = 0; j < w.nn; j++) {
+        sc nj;
+        ok &= sc_from_be(nj, w.proof_n + ((size_t)t * w.nn + j) * 32);
+        sc_mul(t1, nj, nj); sc_mul(t1, t1, mp); sc_add(v, v, t1);
+        sc_mul(mp, mp, mu_fin);
+    }
+    const int nlf = (int)wnla_ceil_shift((size_t)w.nh, k), nnf = (int)wnla_ceil_shift((size_t)w.ng, k);
+#pragma nounroll
+    for (int i = 0; i < w.nh; i++) {
+        const int j = i >> k;
+        sc ci, ch, lj, coef;
+        ok &= sc_from_be(ci, w.c + ((size_t)t * w.nh + i) * 32);
+        ws_ld8(ch.v, w.tab, N, t, i & (T - 1));
+        lj = zero;
+        if (j < w.nl) ok &= sc_from_be(lj, w.proof_l + ((size_t)t * w.nl + j) * 32);
+        sc_mul(coef, lj, ch);                       // scalar of h_i
+        ws_st8(w.msc, N, t, 1 + w.ng + i, coef.v);
+        sc_mul(t1, ci, coef);                       // c_i ch(i) l_j
+        sc_add(v, v, t1);
+    }
+    (void)nlf;
+#pragma nounroll
+    for (int i = 0; i < w.ng; i++) {
+        const int j = i >> k;
+        sc cg, nj, coef;
+        ws_ld8(cg.v, w.tab, N, t, T + (i & (T - 1)));
+        nj = zero;
+        if (j < w.nn && j < nnf) ok &= sc_from_be(nj, w.proof_n + ((size_t)t * w.nn + j) * 32);
+        sc_mul(coef, nj, cg);
+        ws_st8(w.msc, N, t, 1 + i, coef.v);
+    }
+    // proof.l entries are validated even when they multiply nothing
+#pragma nounroll
+    for (int j = 0; j < w.nl; j++) { sc lj; ok &= sc_from_be(lj, w.proof_l + ((size_t)t * w.nl + j) * 32); }
+    if (!ok) status |= ST_BAD_ENCODING;
+    ws_st8(w.msc, N, t, 0, v.v);
+    w.status[t] = status;
+}
+HD void wnla_msm_lane(pt& part, const WnlaWs& w, size_t t, int lane) {
+    fixed_base_msm_partial(part, w.fb, t, lane, w.msc, 0, 0, 1 + w.ng + w.nh);
+}
+HD void wnla_verify_store(const WnlaWs& w, size_t t, const pt& rhs) { ws_st_pt(w.pfix, w.N, t, rhs); }
+HD void wnla_verify_accept(const WnlaWs& w, size_t t) {
+    pt C, rhs;
+    ws_ld_pt(C, w.acc, w.N, t);
+    ws_ld_pt(rhs, w.pfix, w.N, t);
+    bool eq = pt_eq(C, rhs);
+    w.accept[t] = (eq && w.status[t] == ST_OK) ? 1 : 0;
+}
+
+}  // namespace bppp

@@ -1,0 +1,65 @@
+"""Host-side mirror of the reference's `wnla::WeightNormLinearArgument` (wnla.rs:12-19, 66-121), batch-first over the C ABI.
+The generators (g, g_vec, h_vec) live in the context and are shared by the batch; c, rho, mu are per instance."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence, Tuple
+
+import numpy as np
+
+from . import _capi
+
+
+def _u8(a, shape):
+    arr = np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8) if isinstance(a, (bytes, bytearray)) else a, dtype=np.uint8)
+    return arr.reshape(shape)
+
+
+class WeightNormLinearArgument:
+    def __init__(self, g: bytes, g_vec: Sequence[bytes], h_vec: Sequence[bytes], device: int = 0, fb_window_bits: int = 0):
+        self.ng, self.nh = len(g_vec), len(h_vec)
+        self._ctx = C.c_void_p()
+        _capi.check(_capi.lib().bppp_wnla_ctx_create(C.byref(self._ctx), bytes(g), b"".join(g_vec), self.ng, b"".join(h_vec),
+                                                     self.nh, device, fb_window_bits))
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            _capi.lib().bppp_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def commit_batch(self, c, mu, l, n) -> Tuple[np.ndarray, np.ndarray]:
+        """wnla.rs:66-72 for a batch: c [B, nh, 32], mu [B, 32], l [B, nl, 32], n [B, nn, 32] -> (points [B, 64], status [B])."""
+        mu = _u8(mu, (-1, 32))
+        B = mu.shape[0]
+        c = _u8(c, (B, self.nh, 32))
+        l = _u8(l, (B, -1, 32))
+        n = _u8(n, (B, -1, 32))
+        out = np.zeros((B, 64), np.uint8)
+        st = np.zeros(B, np.int32)
+        _capi.check(_capi.lib().bppp_wnla_commit_batch(self._ctx, B, c.ctypes.data, mu.ctypes.data, l.ctypes.data, l.shape[1],
+                                                       n.ctypes.data, n.shape[1], out.ctypes.data, st.ctypes.data))
+        return out, st
+
+    def verify_batch(self, label: bytes, commitments, c, rho, mu, proof_r, proof_x, proof_l, proof_n) -> Tuple[np.ndarray, np.ndarray]:
+        """wnla.rs:75-121 for a batch; proof_r / proof_x: [B, rounds, 64] in the reference's vector order."""
+        commitments = _u8(commitments, (-1, 64))
+        B = commitments.shape[0]
+        c = _u8(c, (B, self.nh, 32))
+        rho, mu = _u8(rho, (B, 32)), _u8(mu, (B, 32))
+        proof_r, proof_x = _u8(proof_r, (B, -1, 64)), _u8(proof_x, (B, -1, 64))
+        if proof_r.shape[1] != proof_x.shape[1]:
+            return np.zeros(B, np.uint8), np.zeros(B, np.int32)          # wnla.rs:76-78
+        proof_l, proof_n = _u8(proof_l, (B, -1, 32)), _u8(proof_n, (B, -1, 32))
+        acc = np.zeros(B, np.uint8)
+        st = np.zeros(B, np.int32)
+        _capi.check(_capi.lib().bppp_wnla_verify_batch(self._ctx, label, len(label), B, commitments.ctypes.data, c.ctypes.data,
+                                                       rho.ctypes.data, mu.ctypes.data, proof_r.shape[1], proof_r.ctypes.data,
+                                                       proof_x.ctypes.data, proof_l.ctypes.data, proof_l.shape[1], proof_n.ctypes.data,
+                                                       proof_n.shape[1], acc.ctypes.data, st.ctypes.data))
+        return acc, st

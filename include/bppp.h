@@ -116,6 +116,26 @@ BPPP_API int bppp_u64_prove_batch_device(bppp_ctx* ctx, const uint8_t* label, si
 BPPP_API int bppp_u64_commit_value_batch(bppp_ctx* ctx, size_t n, const uint64_t* x, const uint8_t* s /* n x 32 */,
                                 uint8_t* out /* n x 64 */);
 
+/* ---- the crate's `wnla` API surface (wnla.rs:12-19, 66-121), generic sizes ----
+ * WeightNormLinearArgument { g, g_vec[ng], h_vec[nh], c, rho, mu }: the generators are the context (shared by the batch),
+ * c (nh scalars, zero-padded as circuit.rs:237-239 does), rho, mu are per instance.  A context created here serves the wnla
+ * entry points only (the u64 entry points require ng = 16, nh = 32, which bppp_ctx_create builds). */
+BPPP_API int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec /* ng x 64 */, size_t ng,
+                                  const uint8_t* h_vec /* nh x 64 */, size_t nh, int device, int fb_window_bits);
+/* WeightNormLinearArgument::commit (wnla.rs:66-72): out[i] = v*g + <h_vec, l_i> + <g_vec, n_i>, v = <c_i, l_i> + |n_i|^2_mu. */
+BPPP_API int bppp_wnla_commit_batch(bppp_ctx* ctx, size_t n, const uint8_t* c /* n x nh x 32 */, const uint8_t* mu /* n x 32 */,
+                                    const uint8_t* l /* n x nl x 32 */, size_t nl, const uint8_t* nvec /* n x nn x 32 */, size_t nn,
+                                    uint8_t* out /* n x 64 */, int32_t* status /* n or NULL */);
+/* WeightNormLinearArgument::verify (wnla.rs:75-121), fresh Transcript::new(label) per instance.  rounds = proof.x.len() =
+ * proof.r.len() (a proof with different lengths is rejected by the reference at wnla.rs:76-78 before anything else);
+ * proof_r / proof_x hold each instance's vectors in the reference's order (index rounds-1 is consumed first). */
+BPPP_API int bppp_wnla_verify_batch(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n,
+                                    const uint8_t* commitments /* n x 64 */, const uint8_t* c /* n x nh x 32 */,
+                                    const uint8_t* rho /* n x 32 */, const uint8_t* mu /* n x 32 */, size_t rounds,
+                                    const uint8_t* proof_r /* n x rounds x 64 */, const uint8_t* proof_x /* n x rounds x 64 */,
+                                    const uint8_t* proof_l /* n x nl x 32 */, size_t nl, const uint8_t* proof_n /* n x nn x 32 */,
+                                    size_t nn, uint8_t* accept /* n */, int32_t* status /* n or NULL */);
+
 /* Profiling aid for bench.py: when enabled, every kernel launch of the verify pipeline is bracketed by HIP events on
  * the context's stream; bppp_ctx_get_timings returns accumulated milliseconds and launch counts per kernel since the
  * last reset.  names[i] points to a static string. */

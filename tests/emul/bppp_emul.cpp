@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../bp_pp_amd/csrc/prove_core.h"
+#include "../../bp_pp_amd/csrc/wnla_core.h"
 
 using namespace bppp;
 
@@ -204,5 +205,44 @@ int emul_u64_prove_batch(const uint8_t* table, int W, const uint8_t* label, size
 void emul_sec1_expand(size_t n, const uint8_t* c33, const uint8_t* p525, uint8_t* c64, uint8_t* p928) {
     for (size_t t = 0; t < n; t++)
         for (int j = 0; j < 15; j++) sec1_expand_lane(c64, p928, c33, p525, t, j);
+}
+// generic WNLA commit / verify, every stage in thread order (commit: out_points; verify: accept)
+int emul_wnla_run(int commit, const uint8_t* table, int W, int ng, int nh, const uint8_t* label, size_t label_len, size_t n,
+                  const uint8_t* commitments, const uint8_t* c, const uint8_t* rho, const uint8_t* mu, int rounds, const uint8_t* proof_r,
+                  const uint8_t* proof_x, const uint8_t* proof_l, int nl, const uint8_t* proof_n, int nn, uint8_t* out_points,
+                  uint8_t* accept, int32_t* status) {
+    WnlaWs w;
+    memset(&w, 0, sizeof w);
+    w.N = n; w.ng = ng; w.nh = nh; w.rounds = rounds; w.nl = nl; w.nn = nn;
+    w.commitments = commitments; w.c = c; w.rho = rho; w.mu = mu; w.proof_r = proof_r; w.proof_x = proof_x; w.proof_l = proof_l;
+    w.proof_n = proof_n; w.out_points = out_points; w.accept = accept; w.status = status;
+    const size_t T = (size_t)1 << rounds, NB = 1 + ng + nh;
+    std::vector<u32> ts(52 * n), acc(30 * n), pf(30 * n), ys((rounds ? rounds : 1) * 8 * n), tab(2 * T * 8 * n), msc(NB * 8 * n);
+    std::vector<pt_slot> straus(n * 2 * BPPP_STRAUS_ENTRIES);
+    w.tstate = ts.data(); w.acc = acc.data(); w.pfix = pf.data(); w.ys = ys.data(); w.tab = tab.data(); w.msc = msc.data();
+    w.straus = straus.data();
+    w.fb.table = (const apt_packed*)table; w.fb.W = W; w.fb.N = n;
+    auto msm = [&]() {
+        for (size_t t = 0; t < n; t++) {
+            pt a, part;
+            pt_set_identity(a);
+            for (int lane = 0; lane < BPPP_FB_LANES; lane++) { wnla_msm_lane(part, w, t, lane); pt_add(a, a, part); }
+            wnla_verify_store(w, t, a);
+        }
+    };
+    if (commit) {
+        for (size_t t = 0; t < n; t++) wnla_commit_scalars(w, t);
+        msm();
+        for (size_t t = 0; t < n; t++) { pt total; ws_ld_pt(total, w.pfix, n, t); wnla_commit_store(w, t, total); }
+    } else {
+        t_new(w.base, label, (u32)label_len);
+        for (size_t t = 0; t < n; t++) wnla_verify_begin(w, t);
+        for (int k = 1; k <= rounds; k++)
+            for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, k);
+        for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);
+        msm();
+        for (size_t t = 0; t < n; t++) wnla_verify_accept(w, t);
+    }
+    return 0;
 }
 }

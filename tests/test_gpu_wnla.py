@@ -1,0 +1,47 @@
+"""GPU parity tests of the generic batched WeightNormLinearArgument::{commit, verify} (the crate's `wnla` API surface) through
+the C ABI, against the oracle: the reference's own shape (tests.rs:139-171), odd lengths, the u64 shape, and the
+"aggregated" shape of BASELINE configs[4] (|h_vec| = 512, |g_vec| = 256, 8 rounds)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("ng,nh,B", [(4, 4, 5), (16, 32, 70), (3, 5, 4), (1, 2, 3), (256, 512, 3)])
+def test_wnla_commit_verify_vs_oracle(ng, nh, B):
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import wnla_cases
+    from bp_pp_amd.wnla import WeightNormLinearArgument
+    case = wnla_cases.make(ng, nh, B)
+    w = WeightNormLinearArgument(case["g"], case["gv"], case["hv"], device=0, fb_window_bits=8 if nh > 64 else 16)
+    try:
+        out, st = w.commit_batch(case["c"], case["mu"], case["l"], case["n"])
+        assert not st.any() and (out == case["commitments"]).all()
+        args = dict(commitments=case["commitments"], c=case["c"], rho=case["rho"], mu=case["mu"], proof_r=case["proof_r"],
+                    proof_x=case["proof_x"], proof_l=case["proof_l"], proof_n=case["proof_n"])
+        acc, st = w.verify_batch(case["label"], **args)
+        assert acc.all() and not st.any()
+        # tampered instances: accept bits must equal the oracle's, instance by instance
+        pl = case["proof_l"].copy(); pl[0, 0, 31] ^= 1
+        pn = case["proof_n"].copy(); pn[B - 1, 0, 5] ^= 0x10
+        com = case["commitments"].copy()
+        if B > 2:
+            com[1] = case["commitments"][2]
+        t = dict(args, proof_l=pl, proof_n=pn, commitments=com)
+        acc, st = w.verify_batch(case["label"], **t)
+        exp = [wnla_cases.oracle_verify(case, b, proof_l=pl, proof_n=pn, commitments=com) for b in range(B)]
+        assert acc.tolist() == exp and not st.any()
+        assert acc[0] == 0 and acc[B - 1] == 0
+        # malformed: off-curve round point -> status flag, never accepted
+        px = case["proof_x"].copy()
+        if px.shape[1]:
+            px[0, 0, 63] ^= 1
+            acc, st = w.verify_batch(case["label"], **dict(args, proof_x=px))
+            assert st[0] == 1 and acc[0] == 0 and acc[1:].all()
+        # proof.x.len() != proof.r.len() -> false (wnla.rs:76-78)
+        acc, _ = w.verify_batch(case["label"], **dict(args, proof_r=case["proof_r"][:, :-1] if case["proof_r"].shape[1] else np.zeros((B, 1, 64), np.uint8)))
+        assert not acc.any()
+    finally:
+        w.close()
