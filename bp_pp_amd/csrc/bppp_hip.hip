@@ -379,8 +379,8 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     if (!out || !g || (!g_vec && ng) || (!h_vec && nh) || ng > 4096 || nh > 4096) return BPPP_ERR_INVALID_ARG;
     *out = nullptr;
     const int NB = 1 + (int)ng + (int)nh;
-    int W = fb_window_bits ? fb_window_bits : 16;
-    if (W != 4 && W != 8 && W != 16) return BPPP_ERR_INVALID_ARG;
+    int W = fb_window_bits ? fb_window_bits : 20;
+    if (W != 4 && W != 8 && W != 16 && W != 10 && W != 20) return BPPP_ERR_INVALID_ARG;
     int rc = check_device(device);
     if (rc != BPPP_OK) return rc;
     HIP_TRY(hipSetDevice(device));
@@ -421,8 +421,8 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     (void)hipFree(d_raw);
     if (flags) return fail(BPPP_ERR_ENCODING);
     // fixed-base tables
-    const int nwin = 256 / W;
-    const size_t per_win = ((size_t)1 << W) - 1;
+    const int nwin = fb_nwin(W);
+    const size_t per_win = fb_per_win(W);
     const size_t entries = (size_t)NB * nwin * per_win;
     c->table_bytes = entries * sizeof(apt_packed);
     HIP_TRY_C(hipMalloc(&c->d_table, c->table_bytes));

@@ -126,32 +126,75 @@ HD void app_point(strobe& t, const char (&label)[L], const apt& a) {  // transcr
 // ---------------------------------------------------------------- fixed-base MSM over the batch-shared tables
 // table[(b * nwin + w) * (2^W - 1) + (d - 1)] = d * 2^(W w) * generator_b, affine (64 B); (0,0) = identity.
 // This is `vector_mul(points, scalars)` (util.rs:46-60) for points that are batch constants.
+// Window geometry.  W in {4, 8, 16}: unsigned digits, 256/W windows, 2^W - 1 entries per window.
+// W = 20: SIGNED digits in [-2^19, 2^19) (k + sum_i 2^(19+20i) has the digit + 2^19 in every 20-bit field), 13 windows,
+// 2^19 entries per window (|d| = 1..2^19) and a conditional negation of y -- 13 instead of 16 additions per scalar for
+// a 21 GB table; random 64-byte reads from a table of that size still run at ~19 G/s on MI355X (tools/gatherbench.hip),
+// above the ~12 G/s the arithmetic can consume.
+// (W = 10 is the same signed scheme with a table small enough for the CPU emulation tests: 26 windows of 512 entries.)
 struct FbTable { const apt_packed* table; int W; size_t N; };
+HD bool fb_signed(int W) { return W == 20 || W == 10; }
+HD int fb_nwin(int W) { return fb_signed(W) ? 260 / W : 256 / W; }
+HD size_t fb_per_win(int W) { return fb_signed(W) ? ((size_t)1 << (W - 1)) : (((size_t)1 << W) - 1); }
 HD FbTable fb_of(const VerifyWs& ws) { FbTable f = {ws.fb_table, ws.fb_w, ws.N}; return f; }
+// digit of window w: returns the table index (|d| - 1), whether to skip (d == 0) and whether to negate
+HD void fb_digit(const u32 k[8], int W, int w, size_t& idx, bool& skip, bool& neg) {
+    if (!fb_signed(W)) {
+        const u32 mask = (1u << W) - 1u;
+        const int bit = w * W;
+        u32 limb = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) limb = (i == (bit >> 5)) ? k[i] : limb;
+        const u32 d = (limb >> (bit & 31)) & mask;
+        idx = d ? d - 1 : 0;
+        skip = d == 0;
+        neg = false;
+        return;
+    }
+    // k' = k + sum_i 2^(W-1 + W i)  (9 limbs; < 2^260)
+    const u32 off20[9] = {0x00080000u, 0x08000080u, 0x00008000u, 0x00800008u, 0x80000800u, 0x00080000u, 0x08000080u, 0x00008000u, 0x00000008u};
+    const u32 off10[9] = {0x20080200u, 0x08020080u, 0x02008020u, 0x00802008u, 0x80200802u, 0x20080200u, 0x08020080u, 0x02008020u, 0x00000008u};
+    u32 off[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) off[i] = (W == 20) ? off20[i] : off10[i];
+    u32 kp[10];
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) kp[i] = addc(k[i], off[i], c);
+    kp[8] = off[8] + c;
+    kp[9] = 0;
+    const int bit = W * w, li = bit >> 5, sh = bit & 31;
+    u32 lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { lo = (i == li) ? kp[i] : lo; hi = (i == li) ? kp[i + 1] : hi; }
+    const u64 both = ((u64)hi << 32) | lo;
+    const int d = (int)((u32)(both >> sh) & ((1u << W) - 1u)) - (1 << (W - 1));
+    const int mag = d < 0 ? -d : d;
+    idx = mag ? (size_t)(mag - 1) : 0;
+    skip = mag == 0;
+    neg = d < 0;
+}
+HD void fb_lookup_add(pt& acc, const FbTable& fbt, int base, int w, const u32 k[8]) {
+    size_t idx;
+    bool skip, neg, id;
+    fb_digit(k, fbt.W, w, idx, skip, neg);
+    const apt_packed* tb = fbt.table + ((size_t)base * fb_nwin(fbt.W) + w) * fb_per_win(fbt.W);
+    apt e;
+    apt_unpack(e, id, tb[idx]);
+    fe ny;
+    fe_neg_m<1>(ny, e.y);
+    fe_cmov(e.y, neg, ny);
+    pt_madd(acc, acc, e, skip | id);
+}
 HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, int first_slot, int first_base, int count) {
-    const int W = fbt.W;
-    const int nwin = 256 / W;
-    const u32 mask = (W == 32) ? 0xFFFFFFFFu : ((1u << W) - 1u);
-    const size_t per_win = (size_t)mask;
+    const int nwin = fb_nwin(fbt.W);
     pt acc = accp;
 #pragma nounroll
     for (int j = 0; j < count; j++) {
         u32 k[8];
         ws_ld8(k, scal, fbt.N, t, first_slot + j);
-        const apt_packed* tb = fbt.table + (size_t)(first_base + j) * nwin * per_win;
 #pragma nounroll
-        for (int w = 0; w < nwin; w++) {
-            int bit = w * W;
-            u32 limb = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) limb = (i == (bit >> 5)) ? k[i] : limb;
-            u32 d = (limb >> (bit & 31)) & mask;
-            size_t idx = (size_t)w * per_win + (d ? d - 1 : 0);
-            apt e;
-            bool id;
-            apt_unpack(e, id, tb[idx]);
-            pt_madd(acc, acc, e, (d == 0) | id);
-        }
+        for (int w = 0; w < nwin; w++) fb_lookup_add(acc, fbt, first_base + j, w, k);
     }
     accp = acc;
 }
@@ -163,29 +206,27 @@ HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, 
 #define BPPP_FB_LANES 8
 HD void fixed_base_msm_partial(pt& accp, const FbTable& fbt, size_t t, int lane, const u32* scal, int first_slot, int first_base,
                                int count) {
-    const int W = fbt.W;
-    const int nwin = 256 / W;
-    const u32 mask = (1u << W) - 1u;
-    const size_t per_win = (size_t)mask;
+    const int nwin = fb_nwin(fbt.W);
     pt acc;
     pt_set_identity(acc);
+    if (nwin % BPPP_FB_LANES == 0) {
+        // every lane takes the windows congruent to it: the scalar is loaded once per base and shared by the group
 #pragma nounroll
-    for (int j = 0; j < count; j++) {
-        u32 k[8];
-        ws_ld8(k, scal, fbt.N, t, first_slot + j);
-        const apt_packed* tb = fbt.table + (size_t)(first_base + j) * nwin * per_win;
+        for (int j = 0; j < count; j++) {
+            u32 k[8];
+            ws_ld8(k, scal, fbt.N, t, first_slot + j);
 #pragma nounroll
-        for (int w = lane; w < nwin; w += BPPP_FB_LANES) {
-            int bit = w * W;
-            u32 limb = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) limb = (i == (bit >> 5)) ? k[i] : limb;
-            u32 d = (limb >> (bit & 31)) & mask;
-            size_t idx = (size_t)w * per_win + (d ? d - 1 : 0);
-            apt e;
-            bool id;
-            apt_unpack(e, id, tb[idx]);
-            pt_madd(acc, acc, e, (d == 0) | id);
+            for (int w = lane; w < nwin; w += BPPP_FB_LANES) fb_lookup_add(acc, fbt, first_base + j, w, k);
+        }
+    } else {
+        // 13 windows do not divide over 8 lanes: deal the (base, window) pairs round-robin instead
+        const int pairs = count * nwin;
+#pragma nounroll
+        for (int q = lane; q < pairs; q += BPPP_FB_LANES) {
+            const int j = q / nwin, w = q - j * nwin;
+            u32 k[8];
+            ws_ld8(k, scal, fbt.N, t, first_slot + j);
+            fb_lookup_add(acc, fbt, first_base + j, w, k);
         }
     }
     accp = acc;
@@ -761,10 +802,10 @@ struct FbBuild {
     fe *xtmp, *ytmp, *ztmp; // projective coordinates of every entry (pass 1 -> pass 2)
     fe* ptmp;               // prefix products of Z
 };
-HD size_t fb_chunks_per_window(int W) { return (((size_t)1 << W) - 1 + BPPP_FB_CHUNK - 1) / BPPP_FB_CHUNK; }
+HD size_t fb_chunks_per_window(int W) { return (fb_per_win(W) + BPPP_FB_CHUNK - 1) / BPPP_FB_CHUNK; }
 HD void fb_build_pass1(const FbBuild& fb, size_t tid) {
-    const int nwin = 256 / fb.W;
-    const size_t per_win = ((size_t)1 << fb.W) - 1;
+    const int nwin = fb_nwin(fb.W);
+    const size_t per_win = fb_per_win(fb.W);
     const size_t cpw = fb_chunks_per_window(fb.W);
     size_t c = tid % cpw;
     size_t w = (tid / cpw) % nwin;
@@ -775,12 +816,12 @@ HD void fb_build_pass1(const FbBuild& fb, size_t tid) {
     pt_from_affine(base, G);
 #pragma nounroll
     for (size_t i = 0; i < w * (size_t)fb.W; i++) pt_dbl(base, base);
-    // start = (c*CH + 1) * base by double-and-add over the (<= 17-bit) multiplier
+    // start = (c*CH + 1) * base by double-and-add over the (<= 20-bit) multiplier
     u32 m = (u32)(c * BPPP_FB_CHUNK + 1);
     pt cur;
     pt_set_identity(cur);
 #pragma nounroll
-    for (int bit = 16; bit >= 0; bit--) {
+    for (int bit = 20; bit >= 0; bit--) {
         pt_dbl(cur, cur);
         pt s;
         pt_add(s, cur, base);
@@ -797,8 +838,8 @@ HD void fb_build_pass1(const FbBuild& fb, size_t tid) {
     }
 }
 HD void fb_build_pass2(const FbBuild& fb, size_t tid) {
-    const int nwin = 256 / fb.W;
-    const size_t per_win = ((size_t)1 << fb.W) - 1;
+    const int nwin = fb_nwin(fb.W);
+    const size_t per_win = fb_per_win(fb.W);
     const size_t cpw = fb_chunks_per_window(fb.W);
     size_t c = tid % cpw;
     size_t w = (tid / cpw) % nwin;

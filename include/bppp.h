@@ -58,8 +58,9 @@ extern "C" {
 typedef struct bppp_ctx bppp_ctx;
 
 /* U64RangeProofProtocol { g, g_vec[16], h_vec[32] } (u64_proof.rs:19-28) bound to GPU `device`.
- * Builds the fixed-base tables for the 49 generators on the GPU (fb_window_bits in {4, 8, 16}; 0 = default 16:
- * 49 x 16 x 65535 affine points = 3.3 GB of HBM). */
+ * Builds the fixed-base tables for the 49 generators on the GPU.  fb_window_bits: 0 = default 20 (signed 20-bit digits:
+ * 49 x 13 x 2^19 affine points = 21 GB of HBM, 13 table additions per scalar; ~53 GB of temporaries during the build);
+ * 16 (unsigned, 3.3 GB, 16 additions per scalar); 4, 8, 10 (small tables for tests). */
 BPPP_API int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec /* 16 x 64 */,
                     const uint8_t* h_vec /* 32 x 64 */, int device, int fb_window_bits);
 BPPP_API void bppp_ctx_destroy(bppp_ctx* ctx);

@@ -116,14 +116,14 @@ void emul_merlin_kat(const uint8_t* label, size_t label_len, const uint8_t* m1, 
     t_append(t, "some label", m1, (u32)m1_len);
     t_challenge_bytes(t, "challenge", out, (u32)out_len);
 }
-size_t emul_fb_table_entries(int nbases, int W) { return (size_t)nbases * (256 / W) * (((size_t)1 << W) - 1); }
+size_t emul_fb_table_entries(int nbases, int W) { return (size_t)nbases * fb_nwin(W) * fb_per_win(W); }
 int emul_fb_build(const uint8_t* gens, int nbases, int W, uint8_t* table_out /* entries x 64 B, LE limbs as device */) {
     std::vector<apt> g(nbases);
     for (int i = 0; i < nbases; i++) if (!apt_from_xy64(g[i], gens + 64 * i)) return -1;
     size_t entries = emul_fb_table_entries(nbases, W);
     std::vector<fe> tmp(entries * 4);
     FbBuild fb{g.data(), nbases, W, (apt_packed*)table_out, tmp.data(), tmp.data() + entries, tmp.data() + 2 * entries, tmp.data() + 3 * entries};
-    size_t nthreads = (size_t)nbases * (256 / W) * fb_chunks_per_window(W);
+    size_t nthreads = (size_t)nbases * fb_nwin(W) * fb_chunks_per_window(W);
     for (size_t t = 0; t < nthreads; t++) fb_build_pass1(fb, t);
     for (size_t t = 0; t < nthreads; t++) fb_build_pass2(fb, t);
     return 0;

@@ -116,7 +116,7 @@ def gold():
         return json.load(f)
 
 
-@pytest.mark.parametrize("W", [4, 8])
+@pytest.mark.parametrize("W", [4, 8, 10])
 def test_fixed_base_tables(L, gold, W):
     gens = bytes.fromhex(gold["generators"])
     g3 = gens[:128] + bytes(64)                  # two generators + the identity as a (degenerate but legal) generator
@@ -124,15 +124,16 @@ def test_fixed_base_tables(L, gold, W):
     tab = np.zeros(ent * 64, dtype=np.uint8)
     assert L.emul_fb_build(g3, 3, W, tab.ctypes.data) == 0
     out = C.create_string_buffer(64)
-    for ks in ([0x1234567890ABCDEF1234567890ABCDEF, O.N - 1, 12345], [0, 0, 0], [1, 0, 5]):
+    for ks in ([0x1234567890ABCDEF1234567890ABCDEF, O.N - 1, 12345], [0, 0, 0], [1, 0, 5], [2**255 + 2**9, O.N - 2, 1 << 19],
+               [int("7" * 64, 16) % O.N, int("8" * 63, 16), 511]):
         L.emul_fb_msm(tab.ctypes.data, W, 0, 3, b"".join(map(b32, ks)), out)
         exp = O.pt_add(O.pt_mul(O.pt_from_xy64(gens[:64]), ks[0]), O.pt_mul(O.pt_from_xy64(gens[64:128]), ks[1]))
         assert out.raw == O.pt_to_xy64(exp)
 
 
-def test_full_verify_pipeline_against_golden(L, gold, oracle_c):
+@pytest.mark.parametrize("W", [4, 10])            # 10 = the signed-window scheme (26 windows: pairs dealt round-robin over the lanes)
+def test_full_verify_pipeline_against_golden(L, gold, oracle_c, W):
     gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
-    W = 4                                        # small tables: this is a logic test
     ent = L.emul_fb_table_entries(49, W)
     tab = np.zeros(ent * 64, dtype=np.uint8)
     assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0
