@@ -260,39 +260,51 @@ HD void fe_cmov(fe& r, bool take, const fe& b) {
     r.mag = r.mag > b.mag ? r.mag : b.mag;
 #endif
 }
-// 19 column sums -> magnitude-1 limbs.  c[k] < 2^64 are the exact column sums of a product (or any value sum c[k] 2^(26k)).
+// A value the compiler must treat as unknown (keeps `x * 1024` a v_mad_u64_u32 instead of a 64-bit shift plus a 64-bit add).
+HD u32 opaque_u32(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(x));
+#endif
+    return x;
+}
+// 19 column sums -> magnitude-1 limbs, one interleaved pass: a "high" accumulator d walks columns 9, 10..18 emitting 26-bit
+// digits u, each of which is folded straight into the "low" accumulator e walking columns 0..8 through
+// 2^260 = R0 + 2^10 * 2^26 (mod p); the part above 2^256 is folded once more through 2^256 = 0x3D1 + 2^6 * 2^26.
+// (Same dataflow as the 10x26 field of libsecp256k1; bounds for column sums < 2^64, i.e. input magnitudes <= 8.)
 HD void fe_reduce_cols(fe& r, const u64 c[19]) {
-    // carry chain over all columns: 26-bit digits t[0..18], top carry t19
-    u32 t[19];
-    u64 d = c[0];
+    const u32 k1024 = opaque_u32(1024u), k64 = opaque_u32(64u);
+    u64 d = c[9];
+    const u32 t9 = (u32)d & BPPP_M26;
+    d >>= 26;                                             // < 2^38
+    u64 e = 0;
+    u32 t[9];
 #pragma unroll
-    for (int k = 0; k < 18; k++) { t[k] = (u32)d & BPPP_M26; d = (d >> 26) + c[k + 1]; }
-    t[18] = (u32)d & BPPP_M26;
-    const u64 t19 = d >> 26;                       // < 2^38
-    // fold digits 10..19 through 2^260 = R0 + 2^10 * 2^26 (mod p):  u[k] = t[k] + t[k+10] R0 + t[k+9] 2^10
-    u64 e = (u64)t[0] + (u64)t[10] * BPPP_R0;
-    u32 q[10];
-    q[0] = (u32)e & BPPP_M26; e >>= 26;
-#pragma unroll
-    for (int k = 1; k < 9; k++) {
-        e += (u64)t[k] + (u64)t[k + 10] * BPPP_R0 + ((u64)t[k + 9] << 10);
-        q[k] = (u32)e & BPPP_M26; e >>= 26;
+    for (int k = 0; k < 9; k++) {
+        d += c[k + 10];                                   // < 2^64: c <= 9 * 2^60 for the high columns
+        const u32 u = (u32)d & BPPP_M26;
+        d >>= 26;
+        e += c[k] + (u64)u * BPPP_R0;                     // < 2^64
+        t[k] = (u32)e & BPPP_M26;
+        e >>= 26;
+        e += (u64)u * k1024;                              // u * 2^10 as a mad: one instruction instead of shift + add
     }
-    e += (u64)t[9] + t19 * BPPP_R0 + ((u64)t[18] << 10);    // t19 R0 < 2^52
-    q[9] = (u32)e & BPPP_M22;                                // keep 22 bits: value now counted from 2^256
-    // what is left above 2^256: (e >> 22) from this column, plus t19 * 2^10 at column 10 (= 2^260 = 2^4 * 2^256)
-    u64 top = (e >> 22) + (t19 << 14);                       // < 2^53
-    // top * 2^256 = top * (0x3D1 + 2^6 * 2^26)  (mod p); split top into 26-bit digits so every product is 32 x 32
-    const u32 top0 = (u32)top & BPPP_M26, top1 = (u32)(top >> 26);   // top1 < 2^27
-    u64 f = (u64)q[0] + (u64)top0 * BPPP_PC0;
+    // d < 2^38 is the digit of column 19; e the carry into column 9
+    const u32 d_lo = (u32)d, d_hi = (u32)(d >> 32);      // d * R0 as two 32 x 32 products
+    e += (u64)t9 + (u64)d_lo * BPPP_R0 + (((u64)d_hi * BPPP_R0) << 32);
+    r.v[9] = (u32)e & BPPP_M22;
+    e >>= 22;                                             // counts units of 2^256 now
+    e += d << 14;                                         // d * 2^10 at column 10 = 2^260 = 2^4 * 2^256; < 2^53
+    // e * 2^256 = e * (0x3D1 + 2^6 * 2^26); split e into 26-bit digits so every product is 32 x 32
+    const u32 e0 = (u32)e & BPPP_M26, e1 = (u32)(e >> 26);   // e1 < 2^27
+    u64 f = (u64)t[0] + (u64)e0 * BPPP_PC0;
     r.v[0] = (u32)f & BPPP_M26; f >>= 26;
-    f += (u64)q[1] + ((u64)top0 << 6) + (u64)top1 * BPPP_PC0;
+    f += (u64)t[1] + (u64)e0 * k64 + (u64)e1 * BPPP_PC0;
     r.v[1] = (u32)f & BPPP_M26; f >>= 26;
-    f += (u64)q[2] + ((u64)top1 << 6);
+    f += (u64)t[2] + (u64)e1 * k64;
     r.v[2] = (u32)f & BPPP_M26; f >>= 26;
-    r.v[3] = q[3] + (u32)f;                                  // f < 2^8: limb 3 stays within magnitude 1
+    r.v[3] = t[3] + (u32)f;                               // f < 2^8: limb 3 stays within magnitude 1
 #pragma unroll
-    for (int k = 4; k < 10; k++) r.v[k] = q[k];
+    for (int k = 4; k < 9; k++) r.v[k] = t[k];
     FE_SETMAG(r, 1);
     FE_CHECK(r, 1);
 }
