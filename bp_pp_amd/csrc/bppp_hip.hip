@@ -14,7 +14,7 @@
 
 #include "../../include/bppp.h"
 #include "prove_core.h"
-#include "wnla_core.h"
+#include "recip_core.h"
 
 using namespace bppp;
 
@@ -191,6 +191,30 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(WnlaWs w) {
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) wnla_verify_accept(w, t);
+}
+
+// ---- generic reciprocal range proof kernels (recip_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1(RecipWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) recip_phase1(w, t);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed(RecipWs w) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt part;
+    recip_c0_fixed_lane(part, w, t, lane);
+    lane_group_sum(part);
+    if (lane == 0) recip_c0_fixed_store(w, t, part);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var(RecipWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) recip_c0_var(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_finish(RecipWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) recip_c0_finish(w, t);
 }
 
 // ---------------------------------------------------------------- host side
@@ -785,6 +809,7 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
     w.proof_l = d + o_l; w.proof_n = d + o_n; w.out_points = d + o_out; w.accept = d + o_acc; w.status = (int32_t*)(d + o_st);
     w.tstate = (u32*)(d + o_ts); w.acc = (u32*)(d + o_a); w.pfix = (u32*)(d + o_pf); w.ys = (u32*)(d + o_ys);
     w.tab = (u32*)(d + o_tab); w.msc = (u32*)(d + o_msc);
+    w.stride_r = rounds * 64; w.stride_x = rounds * 64; w.stride_l = nl * 32; w.stride_n = nn * 32;
     w.straus = c->d_straus;
     w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
     if (!commit) t_new(w.base, label, (u32)label_len);
@@ -827,6 +852,73 @@ int bppp_wnla_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, 
     if (n == 0) return BPPP_OK;
     return wnla_run(c, false, label, label_len, n, commitments, cvec, rho, mu, rounds, proof_r, proof_x, proof_l, nl, proof_n, nn, nullptr,
                     accept, status);
+}
+
+// ---- generic ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) on a context built by bppp_wnla_ctx_create over
+//      g, g_vec || g_vec_, h_vec || h_vec_
+int bppp_reciprocal_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                 const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                 int32_t* status) {
+    if (!c || (!label && label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
+    if (dim_nd == 0 || dim_np == 0 || dim_nd > (size_t)c->ng || dim_nd + 10 > (size_t)c->nh || dim_np > dim_nd + 1 || rounds > 12 ||
+        nl > 4096 || nn > 4096)
+        return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh;
+    const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    const size_t o_com = take(n * 64), o_pr = take(n * proof_bytes), o_acc = take(n), o_st = take(n * 4), o_ts = take(52 * n * 4),
+                 o_sc0 = take((dim_nd + 6) * 8 * n * 4), o_pts = take(5 * 16 * n * 4), o_a = take(30 * n * 4), o_pf = take(30 * n * 4),
+                 o_inv = take(dim_np * 8 * n * 4), o_wc = take(n * 64), o_wcv = take(n * NH * 32), o_rho = take(n * 32), o_mu = take(n * 32),
+                 o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4), o_msc = take(NB * 8 * n * 4);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * 64, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_pr, proofs, n * proof_bytes, hipMemcpyHostToDevice, s));
+    RecipWs r;
+    std::memset(&r, 0, sizeof r);
+    r.N = n; r.nd = (int)dim_nd; r.np = (int)dim_np; r.rounds = (int)rounds; r.nl = (int)nl; r.nn = (int)nn;
+    r.NG = c->ng; r.NH = c->nh; r.proof_bytes = proof_bytes;
+    r.commitments = d + o_com; r.proofs = d + o_pr; r.status = (int32_t*)(d + o_st); r.tstate = (u32*)(d + o_ts);
+    r.sc0 = (u32*)(d + o_sc0); r.pts = (u32*)(d + o_pts); r.acc = (u32*)(d + o_a); r.pfix = (u32*)(d + o_pf); r.inv = (u32*)(d + o_inv);
+    r.straus = c->d_straus;
+    r.wn_commit = d + o_wc; r.wn_c = d + o_wcv; r.wn_rho = d + o_rho; r.wn_mu = d + o_mu;
+    r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
+    t_new(r.base, label, (u32)label_len);
+    WnlaWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.ng = c->ng; w.nh = c->nh; w.rounds = (int)rounds; w.nl = (int)nl; w.nn = (int)nn;
+    w.commitments = r.wn_commit; w.c = r.wn_c; w.rho = r.wn_rho; w.mu = r.wn_mu;
+    w.proof_r = r.proofs + 256; w.proof_x = r.proofs + 256 + 64 * rounds; w.proof_l = r.proofs + 320 + 128 * rounds;
+    w.proof_n = w.proof_l + 32 * nl;
+    w.stride_r = w.stride_x = w.stride_l = w.stride_n = proof_bytes;
+    w.transcript_preloaded = 1;
+    w.accept = d + o_acc; w.status = r.status; w.tstate = r.tstate; w.acc = r.acc; w.pfix = r.pfix;
+    w.ys = (u32*)(d + o_ys); w.tab = (u32*)(d + o_tab); w.msc = (u32*)(d + o_msc);
+    w.straus = c->d_straus;
+    w.fb = r.fb;
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    k_recip_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    k_recip_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r);
+    k_recip_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    k_recip_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    for (int k = 1; k <= (int)rounds; k++) k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+    k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
+    k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return BPPP_OK;
 }
 
 }  // extern "C"

@@ -20,6 +20,8 @@ struct WnlaWs {
     size_t N;
     int ng, nh, rounds, nl, nn;
     const uint8_t *commitments, *c, *rho, *mu, *proof_r, *proof_x, *proof_l, *proof_n;   // C-ABI layouts (device memory)
+    size_t stride_r, stride_x, stride_l, stride_n;   // bytes between instances (dense arrays: rounds*64, rounds*64, nl*32, nn*32)
+    int transcript_preloaded;                        // 1: tstate already holds each instance's transcript (circuit stage ran before)
     uint8_t* accept;
     uint8_t* out_points;   // commit: n x 64
     int32_t* status;
@@ -47,7 +49,7 @@ HD void wnla_commit_scalars(const WnlaWs& w, size_t t) {
 #pragma nounroll
     for (int j = 0; j < w.nn; j++) {
         sc nj;
-        ok &= sc_from_be(nj, w.proof_n + ((size_t)t * w.nn + j) * 32);
+        ok &= sc_from_be(nj, w.proof_n + (size_t)t * w.stride_n + (size_t)j * 32);
         sc_mul(t1, nj, nj); sc_mul(t1, t1, mp); sc_add(v, v, t1);
         sc_mul(mp, mp, mu);
         if (j < w.ng) ws_st8(w.msc, N, t, 1 + j, nj.v);
@@ -57,7 +59,7 @@ HD void wnla_commit_scalars(const WnlaWs& w, size_t t) {
 #pragma nounroll
     for (int i = 0; i < w.nl; i++) {
         sc li;
-        ok &= sc_from_be(li, w.proof_l + ((size_t)t * w.nl + i) * 32);
+        ok &= sc_from_be(li, w.proof_l + (size_t)t * w.stride_l + (size_t)i * 32);
         if (i < w.nh) {
             sc ci;
             ok &= sc_from_be(ci, w.c + ((size_t)t * w.nh + i) * 32);
@@ -90,8 +92,8 @@ HD void wnla_verify_begin(const WnlaWs& w, size_t t) {
     pt P;
     pt_from_affine(P, C);
     ws_st_pt(w.acc, w.N, t, P);
-    ws_st_strobe(w.tstate, w.N, t, w.base);
-    w.status[t] = status;
+    if (!w.transcript_preloaded) ws_st_strobe(w.tstate, w.N, t, w.base);
+    w.status[t] = w.transcript_preloaded ? (w.status[t] | status) : status;
 }
 // ---- verify: round k = 1..rounds (wnla.rs:84-102), X = proof.x[rounds - k], R = proof.r[rounds - k]
 HD void wnla_verify_round(const WnlaWs& w, size_t t, int k) {
@@ -101,8 +103,8 @@ HD void wnla_verify_round(const WnlaWs& w, size_t t, int k) {
     ws_ld_pt(C, w.acc, N, t);
     apt Ca, X, R;
     pt_to_affine(Ca, C);
-    bool ok = apt_from_xy64(X, w.proof_x + ((size_t)t * w.rounds + (w.rounds - k)) * 64);
-    ok &= apt_from_xy64(R, w.proof_r + ((size_t)t * w.rounds + (w.rounds - k)) * 64);
+    bool ok = apt_from_xy64(X, w.proof_x + (size_t)t * w.stride_x + (size_t)(w.rounds - k) * 64);
+    ok &= apt_from_xy64(R, w.proof_r + (size_t)t * w.stride_r + (size_t)(w.rounds - k) * 64);
     if (!ok) { status |= ST_BAD_ENCODING; fe_set_u32(X.x, 0); fe_set_u32(X.y, 0); R = X; }
     strobe tr;
     ws_ld_strobe(tr, w.tstate, N, t);
@@ -173,7 +175,7 @@ HD void wnla_verify_final_scalars(const WnlaWs& w, size_t t) {
 #pragma nounroll
     for (int j = 0; j < w.nn; j++) {
         sc nj;
-        ok &= sc_from_be(nj, w.proof_n + ((size_t)t * w.nn + j) * 32);
+        ok &= sc_from_be(nj, w.proof_n + (size_t)t * w.stride_n + (size_t)j * 32);
         sc_mul(t1, nj, nj); sc_mul(t1, t1, mp); sc_add(v, v, t1);
         sc_mul(mp, mp, mu_fin);
     }
@@ -185,7 +187,7 @@ HD void wnla_verify_final_scalars(const WnlaWs& w, size_t t) {
         ok &= sc_from_be(ci, w.c + ((size_t)t * w.nh + i) * 32);
         ws_ld8(ch.v, w.tab, N, t, i & (T - 1));
         lj = zero;
-        if (j < w.nl) ok &= sc_from_be(lj, w.proof_l + ((size_t)t * w.nl + j) * 32);
+        if (j < w.nl) ok &= sc_from_be(lj, w.proof_l + (size_t)t * w.stride_l + (size_t)j * 32);
         sc_mul(coef, lj, ch);                       // scalar of h_i
         ws_st8(w.msc, N, t, 1 + w.ng + i, coef.v);
         sc_mul(t1, ci, coef);                       // c_i ch(i) l_j
@@ -198,13 +200,13 @@ HD void wnla_verify_final_scalars(const WnlaWs& w, size_t t) {
         sc cg, nj, coef;
         ws_ld8(cg.v, w.tab, N, t, T + (i & (T - 1)));
         nj = zero;
-        if (j < w.nn && j < nnf) ok &= sc_from_be(nj, w.proof_n + ((size_t)t * w.nn + j) * 32);
+        if (j < w.nn && j < nnf) ok &= sc_from_be(nj, w.proof_n + (size_t)t * w.stride_n + (size_t)j * 32);
         sc_mul(coef, nj, cg);
         ws_st8(w.msc, N, t, 1 + i, coef.v);
     }
     // proof.l entries are validated even when they multiply nothing
 #pragma nounroll
-    for (int j = 0; j < w.nl; j++) { sc lj; ok &= sc_from_be(lj, w.proof_l + ((size_t)t * w.nl + j) * 32); }
+    for (int j = 0; j < w.nl; j++) { sc lj; ok &= sc_from_be(lj, w.proof_l + (size_t)t * w.stride_l + (size_t)j * 32); }
     if (!ok) status |= ST_BAD_ENCODING;
     ws_st8(w.msc, N, t, 0, v.v);
     w.status[t] = status;

@@ -63,3 +63,27 @@ class WeightNormLinearArgument:
                                                        proof_x.ctypes.data, proof_l.ctypes.data, proof_l.shape[1], proof_n.ctypes.data,
                                                        proof_n.shape[1], acc.ctypes.data, st.ctypes.data))
         return acc, st
+
+
+class ReciprocalRangeProofProtocol:
+    """Mirror of `range_proof::reciprocal::ReciprocalRangeProofProtocol` (reciprocal.rs:64-107) for runtime dim_nd / dim_np,
+    verify only.  dim_nd = dim_np = 16 is what U64RangeProofProtocol specialises."""
+
+    def __init__(self, dim_nd: int, dim_np: int, g: bytes, g_vec, h_vec, g_vec_, h_vec_, device: int = 0, fb_window_bits: int = 0):
+        if len(g_vec) != dim_nd or len(h_vec) != dim_nd + 10:
+            raise ValueError("g_vec must hold dim_nd points and h_vec dim_nd + 10 (dim_nv + 9)")
+        self.dim_nd, self.dim_np = dim_nd, dim_np
+        self._w = WeightNormLinearArgument(g, list(g_vec) + list(g_vec_), list(h_vec) + list(h_vec_), device, fb_window_bits)
+
+    def close(self):
+        self._w.close()
+
+    def verify_batch(self, label: bytes, commitments, proofs, rounds: int, nl: int, nn: int):
+        commitments = _u8(commitments, (-1, 64))
+        B = commitments.shape[0]
+        proofs = _u8(proofs, (B, 64 * (5 + 2 * rounds) + 32 * (nl + nn)))
+        acc, st = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        _capi.check(_capi.lib().bppp_reciprocal_verify_batch(self._w._ctx, label, len(label), B, self.dim_nd, self.dim_np,
+                                                             commitments.ctypes.data, proofs.ctypes.data, rounds, nl, nn,
+                                                             acc.ctypes.data, st.ctypes.data))
+        return acc, st

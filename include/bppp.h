@@ -137,6 +137,15 @@ BPPP_API int bppp_wnla_verify_batch(bppp_ctx* ctx, const uint8_t* label, size_t 
                                     const uint8_t* proof_l /* n x nl x 32 */, size_t nl, const uint8_t* proof_n /* n x nn x 32 */,
                                     size_t nn, uint8_t* accept /* n */, int32_t* status /* n or NULL */);
 
+/* ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) for runtime dim_nd / dim_np (dim_np <= dim_nd + 1): e.g.
+ * dim_nd = 256, dim_np = 16 -> |g_vec| = 256, |h_vec| + |h_vec_| = 512, 8 WNLA rounds (BASELINE configs[4]).  The context
+ * comes from bppp_wnla_ctx_create(g, g_vec || g_vec_, NG, h_vec || h_vec_, NH) with NG >= dim_nd, NH >= dim_nd + 10.
+ * Proof layout per instance, 64 (5 + 2 rounds) + 32 (nl + nn) bytes:
+ *   c_l, c_r, c_o, c_s | r[rounds] | x[rounds] | reciprocal r | l[nl] | n[nn]       (for dim_nd = 16 this is the 928-byte u64 form) */
+BPPP_API int bppp_reciprocal_verify_batch(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                          const uint8_t* commitments /* n x 64 */, const uint8_t* proofs, size_t rounds, size_t nl,
+                                          size_t nn, uint8_t* accept /* n */, int32_t* status /* n or NULL */);
+
 /* Profiling aid for bench.py: when enabled, every kernel launch of the verify pipeline is bracketed by HIP events on
  * the context's stream; bppp_ctx_get_timings returns accumulated milliseconds and launch counts per kernel since the
  * last reset.  names[i] points to a static string. */

@@ -1648,6 +1648,98 @@ API int bppp_oracle_scalar_inv(const uint8_t a[32], uint8_t out_fermat[32], uint
     return 0;
 }
 
+/* Generic ReciprocalRangeProofProtocol (reciprocal.rs:64-146) over byte buffers: any dim_nd / dim_np.
+ * h_vec has dim_nd + 10 points, g_vec dim_nd points; g_vec_ / h_vec_ are the WNLA padding generators.
+ * Proof wire layout (generic): c_l, c_r, c_o, c_s | r[rounds] | x[rounds] | reciprocal r   (64 B each)   then l[nl] | n[nn] (32 B each). */
+static int recip_load(reciprocal_t* r, pt** store, const uint8_t* g, const uint8_t* g_vec, size_t dim_nd, size_t dim_np, const uint8_t* h_vec,
+                      const uint8_t* g_vec_, size_t ng_, const uint8_t* h_vec_, size_t nh_) {
+    size_t nh = dim_nd + 10;
+    pt* a = (pt*)malloc(sizeof(pt) * (dim_nd + nh + ng_ + nh_ + 1));
+    *store = a;
+    int ok = pt_from_xy64(&r->g, g);
+    for (size_t i = 0; i < dim_nd; i++) ok &= pt_from_xy64(&a[i], g_vec + 64 * i);
+    for (size_t i = 0; i < nh; i++) ok &= pt_from_xy64(&a[dim_nd + i], h_vec + 64 * i);
+    for (size_t i = 0; i < ng_; i++) ok &= pt_from_xy64(&a[dim_nd + nh + i], g_vec_ + 64 * i);
+    for (size_t i = 0; i < nh_; i++) ok &= pt_from_xy64(&a[dim_nd + nh + ng_ + i], h_vec_ + 64 * i);
+    r->dim_nd = dim_nd; r->dim_np = dim_np;
+    r->g_vec = a; r->n_g_vec = dim_nd;
+    r->h_vec = a + dim_nd; r->n_h_vec = nh;
+    r->g_vec_ = a + dim_nd + nh; r->n_g_vec_ = ng_;
+    r->h_vec_ = a + dim_nd + nh + ng_; r->n_h_vec_ = nh_;
+    return ok;
+}
+/* x: value as a 32-byte scalar; digits: dim_nd scalars (base dim_np digits of x); m: dim_np multiplicities; rnd: 20 + 2*dim_nd draws.
+ * Outputs: commitment (64 B), proof buffer, and the proof shape. */
+API int bppp_oracle_reciprocal_prove(const uint8_t* g, const uint8_t* g_vec, size_t dim_nd, size_t dim_np, const uint8_t* h_vec,
+                                     const uint8_t* g_vec_, size_t ng_, const uint8_t* h_vec_, size_t nh_, const uint8_t* label,
+                                     size_t label_len, const uint8_t x[32], const uint8_t s[32], const uint8_t* digits, const uint8_t* m,
+                                     const uint8_t* rnd, size_t n_rnd, uint8_t commitment_out[64], uint8_t* proof_out, size_t* rounds,
+                                     size_t* nl, size_t* nn) {
+    reciprocal_t r;
+    pt* store;
+    int ok = recip_load(&r, &store, g, g_vec, dim_nd, dim_np, h_vec, g_vec_, ng_, h_vec_, nh_);
+    sc xs, ss;
+    sc *dg = malloc(sizeof(sc) * dim_nd), *ms = malloc(sizeof(sc) * dim_np), *draws = malloc(sizeof(sc) * (n_rnd + 1));
+    ok &= sc_from_be(&xs, x) & sc_from_be(&ss, s);
+    for (size_t i = 0; i < dim_nd; i++) ok &= sc_from_be(&dg[i], digits + 32 * i);
+    for (size_t i = 0; i < dim_np; i++) ok &= sc_from_be(&ms[i], m + 32 * i);
+    for (size_t i = 0; i < n_rnd; i++) ok &= sc_from_be(&draws[i], rnd + 32 * i);
+    int rc = ORACLE_ERR_ENCODING;
+    if (ok) {
+        pt com = reciprocal_commit_value(&r, &xs, &ss);
+        transcript t;
+        t_new(&t, label, label_len);
+        rng_t rng = {draws, n_rnd};
+        circuit_proof_t cp;
+        pt proof_r;
+        rc = reciprocal_prove(&r, &com, &xs, &ss, ms, dg, &t, &rng, &cp, &proof_r);
+        if (rc == 1) {
+            uint8_t* o = proof_out;
+            pt_to_xy64(o, &cp.c_l); pt_to_xy64(o + 64, &cp.c_r); pt_to_xy64(o + 128, &cp.c_o); pt_to_xy64(o + 192, &cp.c_s);
+            o += 256;
+            for (size_t i = 0; i < cp.nr; i++, o += 64) pt_to_xy64(o, &cp.r[i]);
+            for (size_t i = 0; i < cp.nx; i++, o += 64) pt_to_xy64(o, &cp.x[i]);
+            pt_to_xy64(o, &proof_r); o += 64;
+            for (size_t i = 0; i < cp.nl; i++, o += 32) sc_to_be(o, &cp.l[i]);
+            for (size_t i = 0; i < cp.nn; i++, o += 32) sc_to_be(o, &cp.n[i]);
+            *rounds = cp.nr; *nl = cp.nl; *nn = cp.nn;
+            pt_to_xy64(commitment_out, &com);
+            rc = 0;
+        }
+    }
+    free(store); free(dg); free(ms); free(draws);
+    return rc;
+}
+API int bppp_oracle_reciprocal_verify(const uint8_t* g, const uint8_t* g_vec, size_t dim_nd, size_t dim_np, const uint8_t* h_vec,
+                                      const uint8_t* g_vec_, size_t ng_, const uint8_t* h_vec_, size_t nh_, const uint8_t* label,
+                                      size_t label_len, const uint8_t commitment[64], const uint8_t* proof, size_t rounds, size_t nl,
+                                      size_t nn) {
+    if (rounds > 64 || nl > 8 || nn > 8) return ORACLE_ERR_ENCODING;
+    reciprocal_t r;
+    pt* store;
+    int ok = recip_load(&r, &store, g, g_vec, dim_nd, dim_np, h_vec, g_vec_, ng_, h_vec_, nh_);
+    circuit_proof_t cp;
+    pt proof_r, com;
+    ok &= pt_from_xy64(&com, commitment);
+    const uint8_t* o = proof;
+    ok &= pt_from_xy64(&cp.c_l, o) & pt_from_xy64(&cp.c_r, o + 64) & pt_from_xy64(&cp.c_o, o + 128) & pt_from_xy64(&cp.c_s, o + 192);
+    o += 256;
+    for (size_t i = 0; i < rounds; i++, o += 64) ok &= pt_from_xy64(&cp.r[i], o);
+    for (size_t i = 0; i < rounds; i++, o += 64) ok &= pt_from_xy64(&cp.x[i], o);
+    ok &= pt_from_xy64(&proof_r, o); o += 64;
+    for (size_t i = 0; i < nl; i++, o += 32) ok &= sc_from_be(&cp.l[i], o);
+    for (size_t i = 0; i < nn; i++, o += 32) ok &= sc_from_be(&cp.n[i], o);
+    cp.nr = cp.nx = rounds; cp.nl = nl; cp.nn = nn;
+    int rc = ORACLE_ERR_ENCODING;
+    if (ok) {
+        transcript t;
+        t_new(&t, label, label_len);
+        rc = reciprocal_verify(&r, &com, &cp, &proof_r, &t, NULL);
+    }
+    free(store);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ threaded batch drivers (CPU baseline + checker) */
 typedef struct {
     const uint8_t *gens, *label; size_t label_len, n, stride_v, lo, hi;

@@ -7,7 +7,7 @@
 #include <vector>
 
 #include "../../bp_pp_amd/csrc/prove_core.h"
-#include "../../bp_pp_amd/csrc/wnla_core.h"
+#include "../../bp_pp_amd/csrc/recip_core.h"
 
 using namespace bppp;
 
@@ -216,6 +216,7 @@ int emul_wnla_run(int commit, const uint8_t* table, int W, int ng, int nh, const
     w.N = n; w.ng = ng; w.nh = nh; w.rounds = rounds; w.nl = nl; w.nn = nn;
     w.commitments = commitments; w.c = c; w.rho = rho; w.mu = mu; w.proof_r = proof_r; w.proof_x = proof_x; w.proof_l = proof_l;
     w.proof_n = proof_n; w.out_points = out_points; w.accept = accept; w.status = status;
+    w.stride_r = (size_t)rounds * 64; w.stride_x = (size_t)rounds * 64; w.stride_l = (size_t)nl * 32; w.stride_n = (size_t)nn * 32;
     const size_t T = (size_t)1 << rounds, NB = 1 + ng + nh;
     std::vector<u32> ts(52 * n), acc(30 * n), pf(30 * n), ys((rounds ? rounds : 1) * 8 * n), tab(2 * T * 8 * n), msc(NB * 8 * n);
     std::vector<pt_slot> straus(n * 2 * BPPP_STRAUS_ENTRIES);
@@ -243,6 +244,54 @@ int emul_wnla_run(int commit, const uint8_t* table, int W, int ng, int nh, const
         msm();
         for (size_t t = 0; t < n; t++) wnla_verify_accept(w, t);
     }
+    return 0;
+}
+// generic reciprocal verify: circuit stage then the generic WNLA stage, thread order
+int emul_recip_verify(const uint8_t* table, int W, int NG, int NH, int nd, int np, const uint8_t* label, size_t label_len, size_t n,
+                      const uint8_t* commitments, const uint8_t* proofs, int rounds, int nl, int nn, uint8_t* accept, int32_t* status) {
+    const size_t T = (size_t)1 << rounds, NB = 1 + NG + NH, proof_bytes = 64 * (5 + 2 * (size_t)rounds) + 32 * ((size_t)nl + nn);
+    RecipWs r;
+    memset(&r, 0, sizeof r);
+    r.N = n; r.nd = nd; r.np = np; r.rounds = rounds; r.nl = nl; r.nn = nn; r.NG = NG; r.NH = NH; r.proof_bytes = proof_bytes;
+    r.commitments = commitments; r.proofs = proofs; r.status = status;
+    std::vector<u32> ts(52 * n), sc0((size_t)(nd + 6) * 8 * n), pts(80 * n), acc(30 * n), pf(30 * n), inv((size_t)np * 8 * n),
+        ys((rounds ? rounds : 1) * 8 * n), tab(2 * T * 8 * n), msc(NB * 8 * n);
+    std::vector<uint8_t> wc(n * 64), wcv(n * (size_t)NH * 32), wrho(n * 32), wmu(n * 32);
+    std::vector<pt_slot> straus(n * 5 * BPPP_STRAUS_ENTRIES);
+    r.tstate = ts.data(); r.sc0 = sc0.data(); r.pts = pts.data(); r.acc = acc.data(); r.pfix = pf.data(); r.inv = inv.data();
+    r.straus = straus.data(); r.wn_commit = wc.data(); r.wn_c = wcv.data(); r.wn_rho = wrho.data(); r.wn_mu = wmu.data();
+    r.fb.table = (const apt_packed*)table; r.fb.W = W; r.fb.N = n;
+    t_new(r.base, label, (u32)label_len);
+    WnlaWs w;
+    memset(&w, 0, sizeof w);
+    w.N = n; w.ng = NG; w.nh = NH; w.rounds = rounds; w.nl = nl; w.nn = nn;
+    w.commitments = r.wn_commit; w.c = r.wn_c; w.rho = r.wn_rho; w.mu = r.wn_mu;
+    w.proof_r = proofs + 256; w.proof_x = proofs + 256 + 64 * (size_t)rounds; w.proof_l = proofs + 320 + 128 * (size_t)rounds;
+    w.proof_n = w.proof_l + 32 * (size_t)nl;
+    w.stride_r = w.stride_x = w.stride_l = w.stride_n = proof_bytes;
+    w.transcript_preloaded = 1;
+    w.accept = accept; w.status = status; w.tstate = r.tstate; w.acc = r.acc; w.pfix = r.pfix; w.ys = ys.data(); w.tab = tab.data();
+    w.msc = msc.data(); w.straus = straus.data(); w.fb = r.fb;
+    for (size_t t = 0; t < n; t++) recip_phase1(r, t);
+    for (size_t t = 0; t < n; t++) {
+        pt a, part;
+        pt_set_identity(a);
+        for (int lane = 0; lane < BPPP_FB_LANES; lane++) { recip_c0_fixed_lane(part, r, t, lane); pt_add(a, a, part); }
+        recip_c0_fixed_store(r, t, a);
+    }
+    for (size_t t = 0; t < n; t++) recip_c0_var(r, t);
+    for (size_t t = 0; t < n; t++) recip_c0_finish(r, t);
+    for (size_t t = 0; t < n; t++) wnla_verify_begin(w, t);
+    for (int k = 1; k <= rounds; k++)
+        for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, k);
+    for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);
+    for (size_t t = 0; t < n; t++) {
+        pt a, part;
+        pt_set_identity(a);
+        for (int lane = 0; lane < BPPP_FB_LANES; lane++) { wnla_msm_lane(part, w, t, lane); pt_add(a, a, part); }
+        wnla_verify_store(w, t, a);
+    }
+    for (size_t t = 0; t < n; t++) wnla_verify_accept(w, t);
     return 0;
 }
 }

@@ -1,0 +1,75 @@
+"""Seeded generic reciprocal range-proof instances (reciprocal.rs, any dim_nd / dim_np) built with the oracle.
+dim_nd = 16, dim_np = 16 is the u64 protocol; dim_nd = 256, dim_np = 16 is the "aggregated 16-value" shape of BASELINE configs[4]
+(|g_vec| = 256, |h_vec| = 266 + 246 padding = 512, 8 WNLA rounds)."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+
+import bppp_oracle as O
+import bppp_oracle_c as OC
+
+
+def _sc(tag: bytes, *idx) -> int:
+    return O.wide_reduce(hashlib.shake_256(b"bppp-recip-cases" + tag + b"".join(int(i).to_bytes(4, "little") for i in idx)).digest(64))
+
+
+def _pow2_at_least(n):
+    p = 1
+    while p < n:
+        p *= 2
+    return p
+
+
+def make(dim_nd: int, dim_np: int, B: int, label: bytes = b"reciprocal test"):
+    L = OC.lib()
+    sz = C.c_size_t
+    nh = dim_nd + 10
+    NH, NG = _pow2_at_least(nh), _pow2_at_least(dim_nd)
+    pt = lambda tag, i: OC.point_mul(None, O.sc_to_bytes(_sc(tag, i)))
+    g = pt(b"g", 0)
+    gv = [pt(b"gv", i) for i in range(dim_nd)]
+    hv = [pt(b"hv", i) for i in range(nh)]
+    gv_ = [pt(b"gv_", i) for i in range(NG - dim_nd)]
+    hv_ = [pt(b"hv_", i) for i in range(NH - nh)]
+    case = dict(g=g, gv=gv, hv=hv, gv_=gv_, hv_=hv_, nd=dim_nd, np=dim_np, label=label, NG=NG, NH=NH)
+    coms, proofs, shape = [], [], None
+    n_rnd = 20 + 2 * dim_nd
+    for b in range(B):
+        digits = [int.from_bytes(hashlib.shake_256(b"dig" + bytes([b]) + i.to_bytes(4, "little")).digest(2), "little") % dim_np
+                  for i in range(dim_nd)]
+        if b == 0:
+            digits = [0] * dim_nd
+        if b == 1:
+            digits = [dim_np - 1] * dim_nd
+        x = sum(d * pow(dim_np, i, O.N) for i, d in enumerate(digits)) % O.N
+        m = [digits.count(v) for v in range(dim_np)]
+        s = _sc(b"s", b)
+        rnd = b"".join(O.sc_to_bytes(_sc(b"rnd", b, i)) for i in range(n_rnd))
+        com = C.create_string_buffer(64)
+        pbuf = C.create_string_buffer(64 * (5 + 2 * 16) + 32 * 16)
+        rounds, nl, nn = sz(0), sz(0), sz(0)
+        rc = L.bppp_oracle_reciprocal_prove(g, b"".join(gv), sz(dim_nd), sz(dim_np), b"".join(hv), b"".join(gv_), sz(len(gv_)), b"".join(hv_),
+                                            sz(len(hv_)), label, sz(len(label)), O.sc_to_bytes(x), O.sc_to_bytes(s),
+                                            b"".join(O.sc_to_bytes(d) for d in digits), b"".join(O.sc_to_bytes(v) for v in m), rnd, sz(n_rnd),
+                                            com, pbuf, C.byref(rounds), C.byref(nl), C.byref(nn))
+        assert rc == 0, rc
+        sh = (rounds.value, nl.value, nn.value)
+        shape = shape or sh
+        assert sh == shape
+        nbytes = 64 * (5 + 2 * sh[0]) + 32 * (sh[1] + sh[2])
+        coms.append(com.raw)
+        proofs.append(pbuf.raw[:nbytes])
+    case.update(rounds=shape[0], nl=shape[1], nn=shape[2], proof_bytes=len(proofs[0]),
+                commitments=np.frombuffer(b"".join(coms), dtype=np.uint8).reshape(B, 64).copy(),
+                proofs=np.frombuffer(b"".join(proofs), dtype=np.uint8).reshape(B, -1).copy())
+    return case
+
+
+def oracle_verify(case, commitment: bytes, proof: bytes) -> int:
+    L = OC.lib()
+    sz = C.c_size_t
+    return L.bppp_oracle_reciprocal_verify(case["g"], b"".join(case["gv"]), sz(case["nd"]), sz(case["np"]), b"".join(case["hv"]),
+                                           b"".join(case["gv_"]), sz(len(case["gv_"])), b"".join(case["hv_"]), sz(len(case["hv_"])),
+                                           case["label"], sz(len(case["label"])), commitment, proof, sz(case["rounds"]), sz(case["nl"]),
+                                           sz(case["nn"]))
