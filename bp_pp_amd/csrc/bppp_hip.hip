@@ -36,8 +36,9 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_
     int lane = (int)(g % BPPP_FB_LANES);
     if (t >= ws.N) return;   // whole lane groups leave together
     pt part;
-    verify_c0_fixed_lane(part, ws, t, lane);
-    lane_group_sum(part);
+    FbRanges rg;
+    verify_c0_fixed_ranges(rg);
+    fb_group_sum(part, fb_of(ws), t, lane, ws.sc0, rg);
     if (lane == 0) verify_c0_fixed_store(ws, t, part);
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var(VerifyWs ws) {
@@ -58,8 +59,9 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_fin
     int lane = (int)(g % BPPP_FB_LANES);
     if (t >= ws.N) return;
     pt part;
-    verify_final_check_lane(part, ws, t, lane);
-    lane_group_sum(part);
+    FbRanges rg;
+    verify_final_check_ranges(rg);
+    fb_group_sum(part, fb_of(ws), t, lane, ws.fsc, rg);
     if (lane == 0) verify_final_check_store(ws, t, part);
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(VerifyWs ws, int* reject_count) {
@@ -147,8 +149,9 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(
     int lane = (int)(g % BPPP_FB_LANES);
     if (t >= w.N) return;
     pt part;
-    prove_msm_lane(part, w, job, t, lane);
-    lane_group_sum(part);
+    FbRanges rg;
+    prove_msm_ranges(rg, job);
+    fb_group_sum(part, w.fb, t, lane, w.msc, rg);
     if (lane == 0) prove_msm_store(w, job, t, part);
 }
 
@@ -175,8 +178,9 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(W
     int lane = (int)(g % BPPP_FB_LANES);
     if (t >= w.N) return;
     pt part;
-    wnla_msm_lane(part, w, t, lane);
-    lane_group_sum(part);
+    FbRanges rg;
+    wnla_msm_ranges(rg, w);
+    fb_group_sum(part, w.fb, t, lane, w.msc, rg);
     if (lane == 0) wnla_verify_store(w, t, part);
     (void)commit_mode;
 }
@@ -204,8 +208,9 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_f
     int lane = (int)(g % BPPP_FB_LANES);
     if (t >= w.N) return;
     pt part;
-    recip_c0_fixed_lane(part, w, t, lane);
-    lane_group_sum(part);
+    FbRanges rg;
+    recip_c0_fixed_ranges(rg, w);
+    fb_group_sum(part, w.fb, t, lane, w.sc0, rg);
     if (lane == 0) recip_c0_fixed_store(w, t, part);
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var(RecipWs w) {

@@ -153,6 +153,51 @@ HD void pt_dbl(pt& r, const pt& p) {
     fe_add(X3, X3, X3);
     r.X = X3; r.Y = Y3; r.Z = Z3;
 }
+// ---- XYZZ accumulator for sums of MANY affine table points (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2): mixed addition 8M + 2S.
+// The formulas are INCOMPLETE (acc = +-q is not handled), so they are used with deferred detection: an exceptional addition
+// has P = x2 ZZ1 - X1 = 0, which makes ZZ3 = ZZ1 P^2 = 0, and ZZ then stays 0 through every later addition.  A lane therefore
+// tests ZZ once, after its whole sum; if it is 0 although points were added, the proof is re-done with the complete formulas
+// (verify_core.h: fixed_base_msm_partial_fast / the *_slow kernels).  For independent generators this never happens; it does
+// for degenerate generator sets (repeated or related generators), which stay correct through the fallback.
+struct ptz { fe X, Y, ZZ, ZZZ; };
+HD void ptz_madd(ptz& a, bool& empty, const apt& q, bool skip) {
+    fe U2, S2, P, R, PP, PPP, Q, X3, Y3, ZZ3, ZZZ3, t;
+    fe_mul(U2, q.x, a.ZZ);
+    fe_mul(S2, q.y, a.ZZZ);
+    fe_sub_m<6>(P, U2, a.X);
+    fe_sub_m<3>(R, S2, a.Y);
+    fe_sqr(PP, P);
+    fe_mul(PPP, P, PP);
+    fe_mul(Q, a.X, PP);
+    fe_sqr(X3, R);
+    fe_sub_m<1>(X3, X3, PPP);
+    fe_add(t, Q, Q);
+    fe_sub_m<2>(X3, X3, t);            // magnitude 6
+    fe_sub_m<6>(t, Q, X3);             // magnitude 8
+    fe_mul(Y3, R, t);
+    fe_mul(t, a.Y, PPP);
+    fe_sub_m<1>(Y3, Y3, t);            // magnitude 3
+    fe_mul(ZZ3, a.ZZ, PP);
+    fe_mul(ZZZ3, a.ZZZ, PPP);
+    // first real point: the sum IS q
+    fe one;
+    fe_set_u32(one, 1);
+    fe_cmov(X3, empty, q.x); fe_cmov(Y3, empty, q.y); fe_cmov(ZZ3, empty, one); fe_cmov(ZZZ3, empty, one);
+    fe_cmov(a.X, !skip, X3); fe_cmov(a.Y, !skip, Y3); fe_cmov(a.ZZ, !skip, ZZ3); fe_cmov(a.ZZZ, !skip, ZZZ3);
+    empty = empty & skip;
+}
+HD void ptz_init(ptz& a) {
+    fe_set_u32(a.X, 0); fe_set_u32(a.Y, 0); fe_set_u32(a.ZZ, 1); fe_set_u32(a.ZZZ, 1);
+}
+// -> homogeneous projective (X ZZZ : Y ZZ : ZZ ZZZ); `empty` -> identity
+HD void ptz_to_pt(pt& r, const ptz& a, bool empty) {
+    fe_mul(r.X, a.X, a.ZZZ);
+    fe_mul(r.Y, a.Y, a.ZZ);
+    fe_mul(r.Z, a.ZZ, a.ZZZ);
+    pt id;
+    pt_set_identity(id);
+    pt_cmov(r, empty, id);
+}
 // projective-class equality (k256 `ProjectivePoint::eq`, used at wnla.rs:81)
 HD bool pt_eq(const pt& a, const pt& b) {
     fe l, r;

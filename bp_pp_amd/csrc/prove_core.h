@@ -65,26 +65,17 @@ HD void pw_ld_pt(pt& p, const ProveWs& w, size_t t, int slot) { ws_ld_pt(p, w.pb
 HD void pw_st_pt(const ProveWs& w, size_t t, int slot, const pt& p) { ws_st_pt(w.pbuf + (size_t)slot * 30 * w.N, w.N, t, p); }
 HD bool pw_rnd(sc& r, const ProveWs& w, size_t t, int i) { return sc_from_be(r, w.rnd + ((size_t)t * 52 + i) * 32); }
 
-// MSM lane work (8 lanes per proof on the device; the caller tree-adds the partial sums)
-HD void prove_msm_lane(pt& part, const ProveWs& w, const MsmJob& job, size_t t, int lane) {
-    pt acc;
-    pt_set_identity(acc);
-#pragma nounroll
-    for (int r = 0; r < job.nranges; r++) {
-        pt p;
-        fixed_base_msm_partial(p, w.fb, t, lane, w.msc, job.set * BPPP_NG + job.first[r], job.first[r], job.count[r]);
-        pt_add(acc, acc, p);
-    }
-    part = acc;
+// MSM lane work (8 lanes per proof on the device; fb_group_sum tree-adds the partial sums)
+HD void prove_msm_ranges(FbRanges& rg, const MsmJob& job) {
+    rg.n = job.nranges;
+    for (int r = 0; r < job.nranges; r++) { rg.slot[r] = job.set * BPPP_NG + job.first[r]; rg.base[r] = job.first[r]; rg.count[r] = job.count[r]; }
 }
 HD void prove_msm_store(const ProveWs& w, const MsmJob& job, size_t t, const pt& total) { pw_st_pt(w, t, job.out_slot, total); }
 HD void prove_msm(const ProveWs& w, const MsmJob& job, size_t t) {   // single-thread form (host emulation)
-    pt acc, part;
-    pt_set_identity(acc);
-    for (int lane = 0; lane < BPPP_FB_LANES; lane++) {
-        prove_msm_lane(part, w, job, t, lane);
-        pt_add(acc, acc, part);
-    }
+    FbRanges rg;
+    prove_msm_ranges(rg, job);
+    pt acc;
+    fb_sum_serial(acc, w.fb, t, w.msc, rg);
     prove_msm_store(w, job, t, acc);
 }
 

@@ -183,7 +183,7 @@ HD void recip_phase1(const RecipWs& w, size_t t) {
     w.status[t] = status;
 }
 // C0 fixed-base half: ps_tau g + <g_vec, pn_tau>  (bases 0..nd of the table)
-HD void recip_c0_fixed_lane(pt& part, const RecipWs& w, size_t t, int lane) { fixed_base_msm_partial(part, w.fb, t, lane, w.sc0, 0, 0, 1 + w.nd); }
+HD void recip_c0_fixed_ranges(FbRanges& rg, const RecipWs& w) { fb_ranges_one(rg, 0, 0, 1 + w.nd); }
 HD void recip_c0_fixed_store(const RecipWs& w, size_t t, const pt& total) { ws_st_pt(w.pfix, w.N, t, total); }
 // C0 variable-base half + sum -> affine C0 for the WNLA stage (which hashes it first thing, wnla.rs:88)
 HD void recip_c0_var(const RecipWs& w, size_t t) {

@@ -231,6 +231,138 @@ HD void fixed_base_msm_partial(pt& accp, const FbTable& fbt, size_t t, int lane,
     }
     accp = acc;
 }
+// ---- fast form of the lane partial sums: XYZZ accumulator (point.h), 8M + 2S per table addition instead of 11M + 2m.  The
+// law is incomplete; a lane that hit an exceptional addition reports it (fb_lane_finish_fast returns false) and the whole
+// lane group re-does its sums with fixed_base_msm_partial.
+// Table reads are random 64-byte gathers from a multi-GB table (HBM + TLB latency of microseconds), so the loop is software
+// pipelined two deep: at the top of step i the table entry of step i+1 (address known) and the scalar words of step i+2 are
+// requested, then the ~2000-instruction addition of step i runs, then the digit/address of step i+2 is derived.  The vector
+// memory counter retires in order, so any load that is WAITED for before the addition would also wait for the table entry;
+// fb_order_after() gives the scalar words a (fake) data dependency on the addition's result so that the compiler cannot
+// place their use -- and with it the wait -- ahead of the addition.
+HD void fb_sched_fence() {      // keeps the requests above the addition in the instruction stream
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+HD void fb_order_after(u32 k[8], const ptz& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(k[0]), "+v"(k[1]), "+v"(k[2]), "+v"(k[3]), "+v"(k[4]), "+v"(k[5]), "+v"(k[6]), "+v"(k[7])
+                 : "v"(a.X.v[9]), "v"(a.Y.v[9]), "v"(a.ZZ.v[9]), "v"(a.ZZZ.v[9]));
+#else
+    (void)k;
+    (void)a;
+#endif
+}
+struct FbStep {          // where step i's table entry lives, and how to use it
+    size_t addr;
+    bool skip, neg;
+};
+HD void fb_step_from_scalar(FbStep& st, const FbTable& fbt, const u32 k[8], int base, int w) {
+    size_t idx;
+    fb_digit(k, fbt.W, w, idx, st.skip, st.neg);
+    st.addr = ((size_t)base * fb_nwin(fbt.W) + w) * fb_per_win(fbt.W) + idx;
+}
+HD void fb_consume_fast(ptz& acc, bool& empty, const apt_packed& pe, bool skip, bool neg) {
+    apt e;
+    bool id;
+    apt_unpack(e, id, pe);
+    fe ny;
+    fe_neg_m<1>(ny, e.y);
+    fe_cmov(e.y, neg, ny);
+    ptz_madd(acc, empty, e, skip | id);
+}
+HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, size_t t, int lane, const u32* scal, int first_slot,
+                                int first_base, int count) {
+    const int nwin = fb_nwin(fbt.W);
+    // step i of this lane -> (base j, window w): windows congruent to the lane when they divide evenly, else the
+    // (base, window) pairs dealt round-robin (13 windows do not divide over 8 lanes)
+    const bool by_window = (nwin % BPPP_FB_LANES) == 0;
+    const int per_base = nwin / BPPP_FB_LANES;
+    const int steps = by_window ? count * per_base : (count * nwin - lane + BPPP_FB_LANES - 1) / BPPP_FB_LANES;
+    if (steps <= 0) return;
+    auto locate = [&](int i, int& j, int& w) {      // steps past the end re-use the last one (requested, never consumed)
+        if (i > steps - 1) i = steps - 1;
+        if (by_window) {
+            j = i / per_base;
+            w = lane + BPPP_FB_LANES * (i - j * per_base);
+        } else {
+            const int q = lane + BPPP_FB_LANES * i;
+            j = q / nwin;
+            w = q - j * nwin;
+        }
+    };
+    int j, w, j2, w2;
+    u32 k[8];
+    FbStep cur_st, nxt_st;
+    apt_packed cur_e, nxt_e;
+    // prologue: entry of step 0, address of step 1
+    locate(0, j, w);
+    ws_ld8(k, scal, fbt.N, t, first_slot + j);
+    fb_step_from_scalar(cur_st, fbt, k, first_base + j, w);
+    cur_e = fbt.table[cur_st.addr];
+    locate(1, j, w);
+    ws_ld8(k, scal, fbt.N, t, first_slot + j);
+    fb_step_from_scalar(nxt_st, fbt, k, first_base + j, w);
+#pragma nounroll
+    for (int i = 0; i < steps; i++) {
+        nxt_e = fbt.table[nxt_st.addr];                         // step i+1's entry
+        locate(i + 2, j2, w2);
+        ws_ld8(k, scal, fbt.N, t, first_slot + j2);             // step i+2's scalar
+        fb_sched_fence();
+        fb_consume_fast(acc, empty, cur_e, cur_st.skip, cur_st.neg);
+        fb_order_after(k, acc);
+        cur_e = nxt_e;
+        cur_st = nxt_st;
+        fb_step_from_scalar(nxt_st, fbt, k, first_base + j2, w2);
+    }
+}
+HD bool fb_lane_finish_fast(pt& part, const ptz& acc, bool empty) {
+    const bool exceptional = !empty && fe_is_zero(acc.ZZ);
+    ptz_to_pt(part, acc, empty);
+    return !exceptional;
+}
+// The sums every fixed-base kernel computes are described as up to 3 runs of consecutive (scalar slot, base) pairs.
+struct FbRanges {
+    int n;
+    int slot[3], base[3], count[3];
+};
+HD void fb_ranges_one(FbRanges& r, int slot, int base, int count) { r.n = 1; r.slot[0] = slot; r.base[0] = base; r.count[0] = count; }
+HD void fb_lane_sum_complete(pt& part, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg) {
+    pt acc;
+    pt_set_identity(acc);
+#pragma nounroll
+    for (int r = 0; r < rg.n; r++) {
+        pt p;
+        fixed_base_msm_partial(p, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r]);
+        pt_add(acc, acc, p);
+    }
+    part = acc;
+}
+HD bool fb_lane_sum_fast(pt& part, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg) {
+    ptz acc;
+    ptz_init(acc);
+    bool empty = true;
+#pragma nounroll
+    for (int r = 0; r < rg.n; r++) fb_lane_accumulate_fast(acc, empty, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r]);
+    return fb_lane_finish_fast(part, acc, empty);
+}
+// single-thread form of the group sum (host emulation, and device code that runs one thread per proof)
+HD void fb_sum_serial(pt& total, const FbTable& fbt, size_t t, const u32* scal, const FbRanges& rg) {
+    pt part;
+    bool ok = true;
+    pt_set_identity(total);
+    for (int lane = 0; lane < BPPP_FB_LANES; lane++) {
+        ok &= fb_lane_sum_fast(part, fbt, t, lane, scal, rg);
+        pt_add(total, total, part);
+    }
+    if (ok) return;
+    pt_set_identity(total);
+    for (int lane = 0; lane < BPPP_FB_LANES; lane++) {
+        fb_lane_sum_complete(part, fbt, t, lane, scal, rg);
+        pt_add(total, total, part);
+    }
+}
 #if defined(__HIPCC__)
 // tree-add the partial sums of the BPPP_FB_LANES consecutive lanes of a group; every lane ends with the total
 __device__ __forceinline__ void lane_group_sum(pt& acc) {
@@ -245,6 +377,14 @@ __device__ __forceinline__ void lane_group_sum(pt& acc) {
         }
         pt_add(acc, acc, o);
     }
+}
+// the 8-lane group sum the fixed-base kernels run: fast lane sums, group-wide vote, complete-formula re-do if any lane asks
+__device__ __forceinline__ void fb_group_sum(pt& total, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg) {
+    int bad = fb_lane_sum_fast(total, fbt, t, lane, scal, rg) ? 0 : 1;
+#pragma unroll
+    for (int m = 1; m < BPPP_FB_LANES; m <<= 1) bad |= __shfl_xor(bad, m, 64);
+    if (bad) fb_lane_sum_complete(total, fbt, t, lane, scal, rg);
+    lane_group_sum(total);
 }
 #endif
 
@@ -568,18 +708,14 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
 
 // ---------------------------------------------------------------- phase 2b: C0 fixed-base part: ps_tau*g + <g_vec, pn_tau>  (circuit.rs:206) -> pfix
 // lane-group form: every lane of the proof's group computes a partial sum; the group total is stored by _store.
-HD void verify_c0_fixed_lane(pt& part, const VerifyWs& ws, size_t t, int lane) {
-    fixed_base_msm_partial(part, fb_of(ws), t, lane, ws.sc0, 0, 0, 17);
-}
+HD void verify_c0_fixed_ranges(FbRanges& rg) { fb_ranges_one(rg, 0, 0, 17); }
 HD void verify_c0_fixed_store(const VerifyWs& ws, size_t t, const pt& total) { ws_st_pt(ws.pfix, ws.N, t, total); }   // added in round 1
 // single-thread form (host emulation in tests/emul, thread order = lane order)
 HD void verify_c0_fixed(const VerifyWs& ws, size_t t) {
-    pt acc, part;
-    pt_set_identity(acc);
-    for (int lane = 0; lane < BPPP_FB_LANES; lane++) {
-        verify_c0_fixed_lane(part, ws, t, lane);
-        pt_add(acc, acc, part);
-    }
+    FbRanges rg;
+    verify_c0_fixed_ranges(rg);
+    pt acc;
+    fb_sum_serial(acc, fb_of(ws), t, ws.sc0, rg);
     verify_c0_fixed_store(ws, t, acc);
 }
 // ---------------------------------------------------------------- phase 2a: C0 variable-base part (circuit.rs:230-235)
@@ -714,9 +850,7 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
         ws_st8(ws.fsc, N, t, 17 + i, tmp.v);
     }
 }
-HD void verify_final_check_lane(pt& part, const VerifyWs& ws, size_t t, int lane) {
-    fixed_base_msm_partial(part, fb_of(ws), t, lane, ws.fsc, 0, 0, BPPP_NG);
-}
+HD void verify_final_check_ranges(FbRanges& rg) { fb_ranges_one(rg, 0, 0, BPPP_NG); }
 HD void verify_final_check_store(const VerifyWs& ws, size_t t, const pt& rhs) { ws_st_pt(ws.pfix, ws.N, t, rhs); }
 // accept bit: C4 == rhs as projective classes (wnla.rs:81), and no status flag
 HD void verify_accept(const VerifyWs& ws, size_t t) {
@@ -733,12 +867,10 @@ HD void verify_accept(const VerifyWs& ws, size_t t) {
     }
 }
 HD void verify_final_check(const VerifyWs& ws, size_t t) {
-    pt acc, part;
-    pt_set_identity(acc);
-    for (int lane = 0; lane < BPPP_FB_LANES; lane++) {
-        verify_final_check_lane(part, ws, t, lane);
-        pt_add(acc, acc, part);
-    }
+    FbRanges rg;
+    verify_final_check_ranges(rg);
+    pt acc;
+    fb_sum_serial(acc, fb_of(ws), t, ws.fsc, rg);
     verify_final_check_store(ws, t, acc);
     verify_accept(ws, t);
 }

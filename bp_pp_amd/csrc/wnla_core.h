@@ -211,9 +211,7 @@ HD void wnla_verify_final_scalars(const WnlaWs& w, size_t t) {
     ws_st8(w.msc, N, t, 0, v.v);
     w.status[t] = status;
 }
-HD void wnla_msm_lane(pt& part, const WnlaWs& w, size_t t, int lane) {
-    fixed_base_msm_partial(part, w.fb, t, lane, w.msc, 0, 0, 1 + w.ng + w.nh);
-}
+HD void wnla_msm_ranges(FbRanges& rg, const WnlaWs& w) { fb_ranges_one(rg, 0, 0, 1 + w.ng + w.nh); }
 HD void wnla_verify_store(const WnlaWs& w, size_t t, const pt& rhs) { ws_st_pt(w.pfix, w.N, t, rhs); }
 HD void wnla_verify_accept(const WnlaWs& w, size_t t) {
     pt C, rhs;

@@ -149,6 +149,38 @@ int emul_fb_msm(const uint8_t* table, int W, int first_base, int count, const ui
     apt_to_xy64(out, r);
     return 0;
 }
+// the 8-lane form the device kernels use: XYZZ fast partial sums, complete-formula re-do when a lane reports an exceptional
+// addition.  *fell_back tells the test which path produced the result.
+int emul_fb_msm_lanes(const uint8_t* table, int W, int first_base, int count, const uint8_t* k, uint8_t out[64], int* fell_back) {
+    FbTable fbt;
+    fbt.table = (const apt_packed*)table;
+    fbt.W = W;
+    fbt.N = 1;
+    std::vector<u32> scal(count * 8);
+    for (int j = 0; j < count; j++) {
+        sc s;
+        if (!sc_from_be(s, k + 32 * j)) return -1;
+        for (int i = 0; i < 8; i++) scal[(j * 8 + i)] = s.v[i];
+    }
+    FbRanges rg;
+    fb_ranges_one(rg, 0, first_base, count);
+    pt acc, part;
+    pt_set_identity(acc);
+    bool ok = true;
+    for (int lane = 0; lane < BPPP_FB_LANES; lane++) {
+        ok &= fb_lane_sum_fast(part, fbt, 0, lane, scal.data(), rg);
+        pt_add(acc, acc, part);
+    }
+    *fell_back = !ok;
+    pt viaserial;
+    fb_sum_serial(viaserial, fbt, 0, scal.data(), rg);      // fast + fallback, as the kernels do
+    if (ok && !pt_eq(acc, viaserial)) return -2;
+    acc = viaserial;
+    apt r;
+    pt_to_affine(r, acc);
+    apt_to_xy64(out, r);
+    return 0;
+}
 // full exact verify pipeline, every phase in thread order
 int emul_u64_verify_batch(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
                           const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* trace) {
@@ -225,9 +257,10 @@ int emul_wnla_run(int commit, const uint8_t* table, int W, int ng, int nh, const
     w.fb.table = (const apt_packed*)table; w.fb.W = W; w.fb.N = n;
     auto msm = [&]() {
         for (size_t t = 0; t < n; t++) {
-            pt a, part;
-            pt_set_identity(a);
-            for (int lane = 0; lane < BPPP_FB_LANES; lane++) { wnla_msm_lane(part, w, t, lane); pt_add(a, a, part); }
+            pt a;
+            FbRanges rg;
+            wnla_msm_ranges(rg, w);
+            fb_sum_serial(a, w.fb, t, w.msc, rg);
             wnla_verify_store(w, t, a);
         }
     };
@@ -274,9 +307,10 @@ int emul_recip_verify(const uint8_t* table, int W, int NG, int NH, int nd, int n
     w.msc = msc.data(); w.straus = straus.data(); w.fb = r.fb;
     for (size_t t = 0; t < n; t++) recip_phase1(r, t);
     for (size_t t = 0; t < n; t++) {
-        pt a, part;
-        pt_set_identity(a);
-        for (int lane = 0; lane < BPPP_FB_LANES; lane++) { recip_c0_fixed_lane(part, r, t, lane); pt_add(a, a, part); }
+        pt a;
+        FbRanges rg;
+        recip_c0_fixed_ranges(rg, r);
+        fb_sum_serial(a, r.fb, t, r.sc0, rg);
         recip_c0_fixed_store(r, t, a);
     }
     for (size_t t = 0; t < n; t++) recip_c0_var(r, t);
@@ -286,9 +320,10 @@ int emul_recip_verify(const uint8_t* table, int W, int NG, int NH, int nd, int n
         for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, k);
     for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);
     for (size_t t = 0; t < n; t++) {
-        pt a, part;
-        pt_set_identity(a);
-        for (int lane = 0; lane < BPPP_FB_LANES; lane++) { wnla_msm_lane(part, w, t, lane); pt_add(a, a, part); }
+        pt a;
+        FbRanges rg;
+        wnla_msm_ranges(rg, w);
+        fb_sum_serial(a, w.fb, t, w.msc, rg);
         wnla_verify_store(w, t, a);
     }
     for (size_t t = 0; t < n; t++) wnla_verify_accept(w, t);

@@ -20,6 +20,7 @@ def load():
     L.emul_fb_table_entries.argtypes = [i32, i32]
     L.emul_fb_build.argtypes = [cp, i32, i32, vp]
     L.emul_fb_msm.argtypes = [vp, i32, i32, i32, cp, vp]
+    L.emul_fb_msm_lanes.argtypes = [vp, i32, i32, i32, cp, vp, vp]
     L.emul_straus.argtypes = [i32, cp, cp, vp]
     L.emul_straus_glv.argtypes = [i32, cp, cp, vp]
     L.emul_glv_split.argtypes = [cp, vp, vp, vp, vp]
