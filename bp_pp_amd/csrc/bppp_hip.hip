@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -40,6 +41,10 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_
     verify_c0_fixed_ranges(rg);
     fb_group_sum(part, fb_of(ws), t, lane, ws.sc0, rg);
     if (lane == 0) verify_c0_fixed_store(ws, t, part);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables(VerifyWs ws) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_tables(ws, t);
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var(VerifyWs ws) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
@@ -234,9 +239,9 @@ static thread_local std::string g_last_error;
         }                                                                                              \
     } while (0)
 
-enum KernelId { K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_ACCEPT, K_COUNT };
-static const char* const kKernelNames[K_COUNT] = {"k_verify_phase1",        "k_verify_c0_fixed",   "k_verify_c0_var", "k_verify_round",
-                                                  "k_verify_final_scalars", "k_verify_final_check", "k_verify_accept"};
+enum KernelId { K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_ACCEPT, K_TABLES, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"k_verify_phase1",        "k_verify_c0_fixed",    "k_verify_c0_var", "k_verify_round",
+                                                  "k_verify_final_scalars", "k_verify_final_check", "k_verify_accept", "k_verify_tables"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -257,6 +262,11 @@ struct bppp_ctx {
     size_t ws_bytes = 0;
     pt_slot* d_straus = nullptr;
     size_t straus_bytes = 0;
+    // u64 verifier: affine window tables of the 13 proof points + the scratch of the kernel that builds them
+    size_t vcap = 0;
+    apt_packed* d_atab = nullptr;
+    u32* d_tscr = nullptr;
+    size_t vtab_bytes = 0;
     // prover workspace
     size_t pcap = 0;
     u32* d_pws = nullptr;
@@ -288,6 +298,21 @@ static int ensure_capacity(bppp_ctx* c, size_t n) {
     HIP_TRY(hipMalloc(&c->d_ws, c->ws_bytes));
     HIP_TRY(hipMalloc(&c->d_straus, c->straus_bytes));
     c->cap = cap;
+    return BPPP_OK;
+}
+static int ensure_vtab_capacity(bppp_ctx* c, size_t n) {
+    if (n <= c->vcap) return BPPP_OK;
+    if (c->d_atab) { (void)hipFree(c->d_atab); c->d_atab = nullptr; }
+    if (c->d_tscr) { (void)hipFree(c->d_tscr); c->d_tscr = nullptr; }
+    c->vcap = 0;
+    c->vtab_bytes = 0;
+    size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    const size_t atab_bytes = cap * BPPP_ATAB_PER_PROOF * sizeof(apt_packed);
+    const size_t tscr_bytes = cap * (size_t)(BPPP_VPOINTS * 7 * 4 * 10) * sizeof(u32);
+    HIP_TRY(hipMalloc(&c->d_atab, atab_bytes));
+    HIP_TRY(hipMalloc(&c->d_tscr, tscr_bytes));
+    c->vtab_bytes = atab_bytes + tscr_bytes;
+    c->vcap = cap;
     return BPPP_OK;
 }
 static const size_t PWS_WORDS_PER_PROOF = 52 + (size_t)SV_COUNT * 8 + (size_t)BPPP_MSC_SETS * BPPP_NG * 8 + (size_t)PB_COUNT * 30;
@@ -480,6 +505,8 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->d_table) (void)hipFree(c->d_table);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_straus) (void)hipFree(c->d_straus);
+    if (c->d_atab) (void)hipFree(c->d_atab);
+    if (c->d_tscr) (void)hipFree(c->d_tscr);
     if (c->d_pws) (void)hipFree(c->d_pws);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_expand) (void)hipFree(c->d_expand);
@@ -501,7 +528,7 @@ int bppp_ctx_set_stream(bppp_ctx* c, void* hip_stream) {
 
 size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
     if (!c) return 0;
-    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->pws_bytes + c->stage_bytes + (size_t)c->nbases * sizeof(apt);
+    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->pws_bytes + c->stage_bytes + (size_t)c->nbases * sizeof(apt);
 }
 
 int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
@@ -534,9 +561,13 @@ int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_capacity(c, n);
     if (rc != BPPP_OK) return rc;
+    rc = ensure_vtab_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
     VerifyWs ws;
     std::memset(&ws, 0, sizeof ws);
     carve(c, ws, n);
+    ws.atab = c->d_atab;
+    ws.tscr = c->d_tscr;
     ws.commitments = (const uint8_t*)d_commitments;
     ws.proofs = (const uint8_t*)d_proofs;
     ws.accept = (uint8_t*)d_accept;
@@ -560,9 +591,11 @@ int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label
 #define LAUNCH(id, ...) LAUNCH_ON(s, id, __VA_ARGS__)
     LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
-    // C0 = variable-base half (one lane per proof, 1 wave/SIMD) + fixed-base half (8 lanes per proof): independent, so they
-    // run concurrently on two streams and share the SIMDs; round 1 adds the halves.
-    hipStream_t a = c->aux_stream;
+    // C0 = variable-base half (window tables of the proof points, then the shared-doubling sum: one lane per proof, 1 wave
+    // per SIMD) + fixed-base half (8 lanes per proof): independent, so they run concurrently on two streams and share the
+    // SIMDs; round 1 adds the halves.
+    hipStream_t a = std::getenv("BPPP_SERIAL_C0") ? s : c->aux_stream;   // diagnostic: un-overlapped kernel times
+    LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
     LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));

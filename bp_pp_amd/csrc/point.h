@@ -198,6 +198,71 @@ HD void ptz_to_pt(pt& r, const ptz& a, bool empty) {
     pt_set_identity(id);
     pt_cmov(r, empty, id);
 }
+// ---- Jacobian accumulator (x = X/Z^2, y = Y/Z^3) for the shared-doubling (Straus) loops over AFFINE per-proof tables:
+// doubling 2M + 5S, mixed addition 8M + 3S (the complete projective law costs 6M + 2S + m and 12M).  Incomplete in the same
+// way as the XYZZ law above and used with the same deferred detection: an exceptional addition has H = 0, so Z3 = Z1 H = 0,
+// and Z stays 0 through every later doubling (Z3 = 2 Y1 Z1) and addition.  Coordinate magnitudes stay <= (6, 3, 2).
+struct ptj { fe X, Y, Z; };
+HD void ptj_init(ptj& a) { fe_set_u32(a.X, 0); fe_set_u32(a.Y, 0); fe_set_u32(a.Z, 0); }
+HD void ptj_dbl(ptj& a) {   // dbl-2009-l (a = 0)
+    fe A, B, C, D, E, F, t;
+    fe_sqr(A, a.X);
+    fe_sqr(B, a.Y);
+    fe_sqr(C, B);
+    fe_add(t, a.X, B);                 // <= 7
+    fe_sqr(t, t);
+    fe_sub_m<1>(t, t, A);              // 3
+    fe_sub_m<1>(t, t, C);              // 5
+    fe_mul_small(D, t, 2);             // 1
+    fe_add(E, A, A);
+    fe_add(E, E, A);                   // 3
+    fe_sqr(F, E);
+    fe_mul(t, a.Y, a.Z);
+    fe_add(a.Z, t, t);                 // Z3 = 2 Y1 Z1, magnitude 2
+    fe_add(t, D, D);                   // 2
+    fe_sub_m<2>(a.X, F, t);            // X3 = F - 2D, magnitude 4
+    fe_sub_m<4>(t, D, a.X);            // 6
+    fe_mul(t, E, t);
+    fe_mul_small(C, C, 8);
+    fe_sub_m<1>(a.Y, t, C);            // Y3 = E (D - X3) - 8C, magnitude 3
+}
+HD void ptj_madd(ptj& a, bool& empty, const apt& q, bool skip) {
+    fe Z2, U2, S2, H, R, HH, HHH, V, X3, Y3, Z3, t;
+    fe_sqr(Z2, a.Z);
+    fe_mul(U2, q.x, Z2);
+    fe_mul(t, a.Z, Z2);
+    fe_mul(S2, q.y, t);
+    fe_sub_m<6>(H, U2, a.X);           // 8
+    fe_sub_m<3>(R, S2, a.Y);           // 5
+    fe_sqr(HH, H);
+    fe_mul(HHH, H, HH);
+    fe_mul(V, a.X, HH);
+    fe_sqr(X3, R);
+    fe_sub_m<1>(X3, X3, HHH);          // 3
+    fe_add(t, V, V);
+    fe_sub_m<2>(X3, X3, t);            // 6
+    fe_sub_m<6>(t, V, X3);             // 8
+    fe_mul(Y3, R, t);
+    fe_mul(t, a.Y, HHH);
+    fe_sub_m<1>(Y3, Y3, t);            // 3
+    fe_mul(Z3, a.Z, H);
+    fe one;
+    fe_set_u32(one, 1);
+    fe_cmov(X3, empty, q.x); fe_cmov(Y3, empty, q.y); fe_cmov(Z3, empty, one);
+    fe_cmov(a.X, !skip, X3); fe_cmov(a.Y, !skip, Y3); fe_cmov(a.Z, !skip, Z3);
+    empty = empty & skip;
+}
+// -> homogeneous projective (X Z : Y : Z^3); `empty` -> identity
+HD void ptj_to_pt(pt& r, const ptj& a, bool empty) {
+    fe z2;
+    fe_sqr(z2, a.Z);
+    fe_mul(r.X, a.X, a.Z);
+    fe_mul(r.Z, z2, a.Z);
+    fe_mul_small(r.Y, a.Y, 1);         // magnitude 3 -> 1 (what the projective law expects of its inputs)
+    pt id;
+    pt_set_identity(id);
+    pt_cmov(r, empty, id);
+}
 // projective-class equality (k256 `ProjectivePoint::eq`, used at wnla.rs:81)
 HD bool pt_eq(const pt& a, const pt& b) {
     fe l, r;

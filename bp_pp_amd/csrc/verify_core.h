@@ -52,7 +52,9 @@ struct VerifyWs {
     u32* acc;                    // [30][N] running commitment, projective limbs
     u32* pfix;                   // [30][N]
     u32* fsc;                    // [49*8][N]
-    pt_slot* straus;             // [N][5][9]
+    pt_slot* straus;             // [N][5][9]  (generic WNLA / reciprocal paths)
+    apt_packed* atab;            // [N][13][2][8] affine multiples 1..8 of the 13 proof points, and of their GLV images (beta x, y)
+    u32* tscr;                   // [91*4*10][N] scratch of verify_tables: projective multiples + prefix products
     const apt_packed* fb_table;  // [49][nwin][2^W - 1]
     int fb_w;                    // window bits: 4, 8 or 16
     strobe base;                 // Transcript::new(label)
@@ -533,6 +535,226 @@ HD void straus_msm_glv(pt& out, const pt_slot* tbl, const glv_split* sp, int m) 
     out = acc;
 }
 
+// ---------------------------------------------------------------- the u64 verifier's variable-base path: affine per-proof tables
+// All 13 variable-base points of a proof (c_l, c_r, c_o, c_s, r[4], x[4], V + r) are inputs, known before any challenge, so
+// their window tables are built once, up front, and brought to AFFINE form with a single field inversion per proof
+// (Montgomery's trick over the 91 non-trivial multiples).  The five shared-doubling sums that follow (C0 and the four WNLA
+// rounds) then run on a Jacobian accumulator with mixed additions (point.h), and the GLV image tables (beta x, y) are stored
+// too, so the inner loop has no beta multiplication.
+#define BPPP_VPOINTS 13
+#define BPPP_ATAB_PER_PROOF (BPPP_VPOINTS * 16)
+HD void ws_st_fe(u32* base, size_t N, size_t t, int slot, const fe& a) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) base[(size_t)(slot * 10 + i) * N + t] = a.v[i];
+}
+HD void ws_ld_fe(fe& a, const u32* base, size_t N, size_t t, int slot, int mag) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) a.v[i] = base[(size_t)(slot * 10 + i) * N + t];
+    FE_SETMAG(a, mag);
+    (void)mag;
+}
+HD void glv_beta(fe& b) {
+    const u32 BETA_W[8] = {0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu};
+    fe_from_w8(b, BETA_W);
+}
+HD void atab_store(apt_packed* tb, int e, const apt& a, const fe& beta, bool identity) {   // e = 1..8
+    apt_packed k, kb;
+    fe bx;
+    fe_mul(bx, a.x, beta);
+    fe_to_w8(k.x, a.x);
+    fe_to_w8(k.y, a.y);
+    fe_to_w8(kb.x, bx);
+#pragma unroll
+    for (int i = 0; i < 8; i++) kb.y[i] = k.y[i];
+    if (identity) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) k.x[i] = k.y[i] = kb.x[i] = kb.y[i] = 0;
+    }
+    tb[e - 1] = k;
+    tb[8 + e - 1] = kb;
+}
+struct TabScratch { fe X, Y, Z, pre; };
+HD void tscr_load(TabScratch& r, const VerifyWs& ws, size_t t, int idx) {
+    const int slot = idx * 4;
+    ws_ld_fe(r.X, ws.tscr, ws.N, t, slot, 5);
+    ws_ld_fe(r.Y, ws.tscr, ws.N, t, slot + 1, 2);
+    ws_ld_fe(r.Z, ws.tscr, ws.N, t, slot + 2, 2);
+    ws_ld_fe(r.pre, ws.tscr, ws.N, t, slot + 3, 1);
+}
+HD void verify_tables(const VerifyWs& ws, size_t t) {
+    const size_t N = ws.N;
+    fe run, beta, one;
+    fe_set_u32(run, 1);
+    fe_set_u32(one, 1);
+    glv_beta(beta);
+    // forward: multiples 2P..8P (projective, complete formulas), running product of their Z
+#pragma nounroll
+    for (int p = 0; p < BPPP_VPOINTS; p++) {
+        apt P;
+        ws_ld_apt(P, ws.pts, N, t, p);
+        const bool pid = apt_is_identity(P);
+        pt cur;
+        pt_from_affine(cur, P);
+#pragma nounroll
+        for (int e = 2; e <= 8; e++) {
+            pt d;
+            if (e == 2) pt_dbl(d, cur);          // loop counter: wave-uniform branch
+            else pt_madd(d, cur, P, pid);
+            cur = d;
+            const int slot = (p * 7 + (e - 2)) * 4;
+            ws_st_fe(ws.tscr, N, t, slot, cur.X);
+            ws_st_fe(ws.tscr, N, t, slot + 1, cur.Y);
+            ws_st_fe(ws.tscr, N, t, slot + 2, cur.Z);
+            ws_st_fe(ws.tscr, N, t, slot + 3, run);
+            fe z = cur.Z;
+            fe_cmov(z, pid, one);               // the identity's multiples have Z = 0: keep the product invertible
+            fe_mul(run, run, z);
+        }
+    }
+    fe inv;
+    fe_inv(inv, run);
+    // backward: 1/Z_e = inv * prefix_e; the next entry's scratch words are requested before this entry's arithmetic
+    TabScratch cur, nxt;
+    tscr_load(cur, ws, t, BPPP_VPOINTS * 7 - 1);
+#pragma nounroll
+    for (int p = BPPP_VPOINTS - 1; p >= 0; p--) {
+        apt P;
+        ws_ld_apt(P, ws.pts, N, t, p);
+        const bool pid = apt_is_identity(P);
+        apt_packed* tb = ws.atab + (t * BPPP_VPOINTS + p) * 16;
+#pragma nounroll
+        for (int e = 8; e >= 2; e--) {
+            const int idx = p * 7 + (e - 2);
+            tscr_load(nxt, ws, t, idx > 0 ? idx - 1 : 0);
+            fe zinv;
+            fe_cmov(cur.Z, pid, one);
+            fe_mul(zinv, inv, cur.pre);
+            fe_mul(inv, inv, cur.Z);
+            apt a;
+            fe_mul(a.x, cur.X, zinv);
+            fe_mul(a.y, cur.Y, zinv);
+            atab_store(tb, e, a, beta, pid);
+            cur = nxt;
+        }
+        atab_store(tb, 1, P, beta, pid);
+    }
+}
+// The 2M GLV half-scalars of an M-point sum, kept in registers; digits are picked with select chains (no dynamic indexing).
+template <int M>
+struct glv_words {
+    u32 w[2 * M][5];
+    bool neg[2 * M];
+};
+template <int M>
+HD void glv_words_set(glv_words<M>& g, int j, const glv_split& sp) {
+#pragma unroll
+    for (int l = 0; l < 5; l++) { g.w[2 * j][l] = sp.k1[l]; g.w[2 * j + 1][l] = sp.k2[l]; }
+    g.neg[2 * j] = sp.neg1;
+    g.neg[2 * j + 1] = sp.neg2;
+}
+// signed digit of stream r at window i: magnitude 0..8 and whether the table entry is negated
+template <int M>
+HD void glv_digit(const glv_words<M>& g, int r, int i, int& mag, bool& neg) {
+    u32 word = 0;
+    bool sneg = false;
+#pragma unroll
+    for (int st = 0; st < 2 * M; st++) {
+#pragma unroll
+        for (int l = 0; l < 5; l++) word = (st == r && l == (i >> 3)) ? g.w[st][l] : word;
+        sneg = (st == r) ? g.neg[st] : sneg;
+    }
+    const int dg = (int)((word >> ((i & 7) * 4)) & 15) - 8;
+    mag = dg < 0 ? -dg : dg;
+    neg = (dg < 0) != sneg;
+}
+// sum_j k_j P_j over the affine tables; pidx[j] = table (proof point slot) of P_j.  33 windows x (4 doublings + 2M mixed
+// additions); the table entry of the next addition is requested before the current one starts.  Returns false when an
+// exceptional addition was met (re-do with straus_affine_complete).
+template <int M>
+HD bool straus_affine_fast(pt& out, const apt_packed* tab, const int* pidx, const glv_words<M>& g) {
+    const int total = 33 * 2 * M;
+    ptj acc;
+    ptj_init(acc);
+    bool empty = true;
+    apt_packed cur_e, nxt_e;
+    int cur_mag, nxt_mag;
+    bool cur_neg, nxt_neg;
+    glv_digit<M>(g, 0, 32, cur_mag, cur_neg);
+    cur_e = tab[pidx[0] * 16 + (cur_mag ? cur_mag - 1 : 0)];
+    int r = 0, i = 32;
+#pragma nounroll
+    for (int s = 0; s < total; s++) {
+        // successor step (clamped at the end: requested, never consumed)
+        int rn = r + 1, in = i;
+        if (rn == 2 * M) { rn = 0; in = i - 1; }
+        if (in < 0) { rn = r; in = i; }
+        glv_digit<M>(g, rn, in, nxt_mag, nxt_neg);
+        int pn = 0;
+#pragma unroll
+        for (int j = 0; j < M; j++) pn = (j == (rn >> 1)) ? pidx[j] : pn;
+        nxt_e = tab[pn * 16 + (rn & 1) * 8 + (nxt_mag ? nxt_mag - 1 : 0)];
+        if (r == 0 && s != 0) {
+#pragma nounroll
+            for (int d = 0; d < 4; d++) ptj_dbl(acc);
+        }
+        apt e;
+        bool id;
+        apt_unpack(e, id, cur_e);
+        fe ny;
+        fe_neg_m<1>(ny, e.y);
+        fe_cmov(e.y, cur_neg, ny);
+        ptj_madd(acc, empty, e, (cur_mag == 0) | id);
+        cur_e = nxt_e;
+        cur_mag = nxt_mag;
+        cur_neg = nxt_neg;
+        r = rn;
+        i = in;
+    }
+    const bool exceptional = !empty && fe_is_zero(acc.Z);
+    ptj_to_pt(out, acc, empty);
+    return !exceptional;
+}
+template <int M>
+HD_NOINLINE void straus_affine_complete(pt& out, const apt_packed* tab, const int* pidx, const glv_words<M>& g) {
+    pt acc;
+    pt_set_identity(acc);
+#pragma nounroll
+    for (int i = 32; i >= 0; i--) {
+        if (i != 32) {
+#pragma nounroll
+            for (int d = 0; d < 4; d++) pt_dbl(acc, acc);
+        }
+#pragma nounroll
+        for (int r = 0; r < 2 * M; r++) {
+            int mag, pn = 0;
+            bool neg, id;
+            glv_digit<M>(g, r, i, mag, neg);
+#pragma unroll
+            for (int j = 0; j < M; j++) pn = (j == (r >> 1)) ? pidx[j] : pn;
+            apt e;
+            apt_unpack(e, id, tab[pn * 16 + (r & 1) * 8 + (mag ? mag - 1 : 0)]);
+            fe ny;
+            fe_neg_m<1>(ny, e.y);
+            fe_cmov(e.y, neg, ny);
+            pt_madd(acc, acc, e, (mag == 0) | id);
+        }
+    }
+    out = acc;
+}
+template <int M>
+HD void straus_affine(pt& out, const apt_packed* tab, const int* pidx, const glv_words<M>& g) {
+    if (!straus_affine_fast<M>(out, tab, pidx, g)) {
+        // the out-of-line call takes addresses: hand it copies, so the hot loop's scalars and accumulator stay in registers
+        glv_words<M> gc = g;
+        int pc[M];
+#pragma unroll
+        for (int j = 0; j < M; j++) pc[j] = pidx[j];
+        pt o;
+        straus_affine_complete<M>(o, tab, pc, gc);
+        out = o;
+    }
+}
+
 // ---------------------------------------------------------------- phase 1: decode, transcript up to tau, scalar derivation
 // reciprocal.rs:98-104 + circuit.rs:155-228 (closed forms of SURVEY.md 8a)
 HD void verify_phase1(const VerifyWs& ws, size_t t) {
@@ -721,20 +943,18 @@ HD void verify_c0_fixed(const VerifyWs& ws, size_t t) {
 // ---------------------------------------------------------------- phase 2a: C0 variable-base part (circuit.rs:230-235)
 HD void verify_c0_var(const VerifyWs& ws, size_t t) {
     const size_t N = ws.N;
-    pt_slot* tbl = ws.straus + t * (5 * BPPP_STRAUS_ENTRIES);
-    glv_split rs[5];
     const int pslot[5] = {3, 2, 0, 1, 12};  // c_s, c_o, c_l, c_r, V+r  <->  sc0 slots 17..21
-#pragma nounroll
+    glv_words<5> g;
+#pragma unroll
     for (int j = 0; j < 5; j++) {
-        apt P;
-        ws_ld_apt(P, ws.pts, N, t, pslot[j]);
-        straus_build_table(tbl + j * BPPP_STRAUS_ENTRIES, P);
         sc k;
         ws_ld8(k.v, ws.sc0, N, t, 17 + j);
-        glv_decompose(rs[j], k);
+        glv_split sp;
+        glv_decompose(sp, k);
+        glv_words_set<5>(g, j, sp);
     }
     pt acc;
-    straus_msm_glv(acc, tbl, rs, 5);
+    straus_affine<5>(acc, ws.atab + t * BPPP_ATAB_PER_PROOF, pslot, g);
     ws_st_pt(ws.acc, N, t, acc);   // the fixed-base part (pfix) is added at the top of round 1
 }
 // ---------------------------------------------------------------- phase 3 (k = 1..4): one WNLA round (wnla.rs:84-102)
@@ -776,14 +996,15 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k) {
     sc_set_u32(one, 1);
     sc_mul(y2m1, y, y);
     sc_sub(y2m1, y2m1, one);
-    pt_slot* tbl = ws.straus + t * (5 * BPPP_STRAUS_ENTRIES);
-    glv_split rs[2];
-    straus_build_table(tbl, X);
-    straus_build_table(tbl + BPPP_STRAUS_ENTRIES, R);
-    glv_decompose(rs[0], y);
-    glv_decompose(rs[1], y2m1);
+    const int pslot[2] = {8 + (4 - k), 4 + (4 - k)};
+    glv_words<2> g;
+    glv_split sp;
+    glv_decompose(sp, y);
+    glv_words_set<2>(g, 0, sp);
+    glv_decompose(sp, y2m1);
+    glv_words_set<2>(g, 1, sp);
     pt acc;
-    straus_msm_glv(acc, tbl, rs, 2);
+    straus_affine<2>(acc, ws.atab + t * BPPP_ATAB_PER_PROOF, pslot, g);
     pt_madd(acc, acc, Ca, apt_is_identity(Ca));
     ws_st_pt(ws.acc, N, t, acc);
 }

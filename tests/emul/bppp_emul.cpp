@@ -181,6 +181,43 @@ int emul_fb_msm_lanes(const uint8_t* table, int W, int first_base, int count, co
     apt_to_xy64(out, r);
     return 0;
 }
+// the u64 verifier's variable-base path in isolation: affine tables of up to 13 points (verify_tables), then the Jacobian
+// shared-doubling sum over the first m of them (m <= 5) with its complete-formula fallback.  Points beyond m are identities.
+int emul_straus_affine(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64], int* fell_back) {
+    VerifyWs ws;
+    memset(&ws, 0, sizeof ws);
+    ws.N = 1;
+    std::vector<u32> pts(208, 0);
+    std::vector<apt_packed> atab(BPPP_ATAB_PER_PROOF);
+    std::vector<u32> tscr((size_t)91 * 40);
+    ws.pts = pts.data(); ws.atab = atab.data(); ws.tscr = tscr.data();
+    glv_words<5> g5;
+    glv_words<2> g2;
+    for (int j = 0; j < 5; j++) {
+        sc s;
+        sc_set_u32(s, 0);
+        if (j < m) {
+            apt a;
+            if (!apt_from_xy64(a, P + 64 * j) || !sc_from_be(s, k + 32 * j)) return -1;
+            ws_st_apt(ws.pts, 1, 0, j, a);
+        }
+        glv_split sp;
+        glv_decompose(sp, s);
+        glv_words_set<5>(g5, j, sp);
+        if (j < 2) glv_words_set<2>(g2, j, sp);
+    }
+    verify_tables(ws, 0);
+    const int pidx[5] = {0, 1, 2, 3, 4};
+    pt acc, viafb;
+    bool ok = (m <= 2) ? straus_affine_fast<2>(acc, atab.data(), pidx, g2) : straus_affine_fast<5>(acc, atab.data(), pidx, g5);
+    *fell_back = !ok;
+    if (m <= 2) straus_affine_complete<2>(viafb, atab.data(), pidx, g2); else straus_affine_complete<5>(viafb, atab.data(), pidx, g5);
+    if (ok && !pt_eq(acc, viafb)) return -2;      // both laws must agree whenever the fast one claims success
+    apt r;
+    pt_to_affine(r, viafb);
+    apt_to_xy64(out, r);
+    return 0;
+}
 // full exact verify pipeline, every phase in thread order
 int emul_u64_verify_batch(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
                           const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* trace) {
@@ -193,10 +230,14 @@ int emul_u64_verify_batch(const uint8_t* table, int W, const uint8_t* label, siz
     std::vector<pt_slot> straus(n * 5 * BPPP_STRAUS_ENTRIES);
     ws.tstate = strobe_.data(); ws.chal = chal.data(); ws.sc0 = sc0.data(); ws.cvec = cvec.data(); ws.pts = pts.data();
     ws.lns = lns.data(); ws.acc = acc.data(); ws.pfix = pfix.data(); ws.fsc = fsc.data(); ws.straus = straus.data();
+    std::vector<apt_packed> atab(n * BPPP_ATAB_PER_PROOF);
+    std::vector<u32> tscr((size_t)91 * 40 * n);
+    ws.atab = atab.data(); ws.tscr = tscr.data();
     ws.fb_table = (const apt_packed*)table;
     ws.fb_w = W;
     t_new(ws.base, label, (u32)label_len);
     for (size_t t = 0; t < n; t++) verify_phase1(ws, t);
+    for (size_t t = 0; t < n; t++) verify_tables(ws, t);
     for (size_t t = 0; t < n; t++) verify_c0_var(ws, t);
     for (size_t t = 0; t < n; t++) verify_c0_fixed(ws, t);
     for (int k = 1; k <= 4; k++)

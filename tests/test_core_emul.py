@@ -104,6 +104,44 @@ def test_glv_split_and_straus(L):
             assert out.raw == O.pt_to_xy64(exp)
 
 
+def test_affine_tables_and_jacobian_straus(L):
+    """The u64 verifier's variable-base path: per-proof affine tables from one batched inversion (identity points included),
+    Jacobian shared-doubling sum with deferred exception detection, complete-formula fallback."""
+    rnd = random.Random(29)
+    pts = [None, O.G, O.pt_neg(O.G)] + [O.pt_mul(O.G, rnd.getrandbits(256)) for _ in range(6)]
+    out, fb = C.create_string_buffer(64), C.c_int(0)
+    special = [0, 1, O.N - 1, O.LAMBDA, 2**255, 8, O.N - 8, int("8" * 64, 16) % O.N]
+    n_fast = 0
+    for m in (1, 2, 5):
+        for _ in range(8):
+            P = [pts[rnd.randrange(len(pts))] for _ in range(m)]
+            ks = [rnd.choice(special + [rnd.getrandbits(256) % O.N] * 8) for _ in range(m)]
+            assert L.emul_straus_affine(m, b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out, C.byref(fb)) == 0
+            exp = None
+            for p, k in zip(P, ks):
+                exp = O.pt_add(exp, O.pt_mul(p, k))
+            assert out.raw == O.pt_to_xy64(exp)
+            n_fast += 1 - fb.value
+    assert n_fast >= 12
+    # distinct random points and scalars: the fast law alone must do (no fallback)
+    for m in (2, 5):
+        P = [O.pt_mul(O.G, rnd.getrandbits(256)) for _ in range(m)]
+        ks = [rnd.getrandbits(256) % O.N for _ in range(m)]
+        assert L.emul_straus_affine(m, b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out, C.byref(fb)) == 0
+        assert fb.value == 0
+    # exceptional additions: the same point twice with the same scalar (second stream adds an entry to itself); P and -P
+    # (sum passes through the identity); both must be flagged and still come out right
+    A = O.pt_mul(O.G, 0xABCDEF)
+    for P, ks in (([A, A], [5, 5]), ([A, A], [rnd.getrandbits(120)] * 2), ([A, O.pt_neg(A)], [77, 77]),
+                  ([A, O.pt_neg(A), A, A, A], [9, 9, 0, 0, 0])):
+        assert L.emul_straus_affine(len(P), b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out, C.byref(fb)) == 0
+        exp = None
+        for p, k in zip(P, ks):
+            exp = O.pt_add(exp, O.pt_mul(p, k))
+        assert out.raw == O.pt_to_xy64(exp)
+        assert fb.value == 1
+
+
 def test_merlin_known_answer_on_device_code(L):
     kat = C.create_string_buffer(32)
     L.emul_merlin_kat(b"test protocol", 13, b"some data", 9, kat, 32)
