@@ -45,3 +45,40 @@ def test_wnla_commit_verify_vs_oracle(ng, nh, B):
         assert not acc.any()
     finally:
         w.close()
+
+
+def test_fixed_base_fast_accumulator_fallback_on_device():
+    """Repeated generators + a scalar pattern that makes one lane add a table entry to itself: the incomplete (XYZZ) fixed-base
+    accumulator must notice and the lane group must re-do the sum with the complete law (verify_core.h: fb_group_sum)."""
+    import ctypes as C
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import bppp_oracle as O
+    import bppp_oracle_c as OC
+    import wnla_cases
+    from bp_pp_amd.wnla import WeightNormLinearArgument
+    g, gv, hv = wnla_cases.generators(2, 4)
+    gv = [gv[0], gv[1], gv[0], gv[1]]                       # g_vec[2] == g_vec[0], g_vec[3] == g_vec[1]
+    B = 3
+    n_rows = [[7, 0, 7, 0], [0, 5 << 32, 0, 5 << 32], [3, 9, 4, 1]]    # rows 0, 1: single equal window on both copies; row 2: ordinary
+    mu = [1 << 16, 1 << 16, 12345]                          # v = sum n_i^2 mu^(i+1) stays out of the colliding lane's windows
+    c = np.zeros((B, 4, 32), np.uint8)
+    l = np.zeros((B, 4, 32), np.uint8)
+    n = np.frombuffer(b"".join(O.sc_to_bytes(v) for row in n_rows for v in row), np.uint8).reshape(B, 4, 32).copy()
+    mub = np.frombuffer(b"".join(O.sc_to_bytes(v) for v in mu), np.uint8).reshape(B, 32).copy()
+    L = OC.lib()
+    sz = C.c_size_t
+    exp = []
+    for b in range(B):
+        com = C.create_string_buffer(64)
+        assert L.bppp_oracle_wnla_commit(g, b"".join(gv), sz(4), b"".join(hv), sz(4), c[b].tobytes(), sz(4), O.sc_to_bytes(1),
+                                         mub[b].tobytes(), l[b].tobytes(), sz(4), n[b].tobytes(), sz(4), com) == 0
+        exp.append(com.raw)
+    w = WeightNormLinearArgument(g, gv, hv, device=0, fb_window_bits=16)
+    try:
+        out, st = w.commit_batch(c, mub, l, n)
+        assert not st.any()
+        assert [bytes(o) for o in out] == exp
+    finally:
+        w.close()
