@@ -19,6 +19,7 @@
 #define HD inline
 #define HD_NOINLINE inline
 #endif
+#include "modinv.h"
 
 namespace bppp {
 
@@ -411,8 +412,9 @@ HD void fe_sqr_n(fe& r, const fe& a, int n) {
 #pragma nounroll
     for (int i = 0; i < n; i++) fe_sqr(r, r);
 }
-// a^(p-2) (0 -> 0).  Addition chain on the run structure of p-2: 255 squarings + 15 multiplications.
-HD_NOINLINE void fe_inv(fe& r, const fe& a) {
+// a^(p-2) (0 -> 0).  Addition chain on the run structure of p-2: 255 squarings + 15 multiplications.  Kept as the cross-check
+// of fe_inv (tests/emul); the product path inverts with division steps (modinv.h).
+HD_NOINLINE void fe_inv_fermat(fe& r, const fe& a) {
     fe x2, x3, x6, x9, x11, x22, x44, x88, x176, x220, x223, t;
     fe_sqr(x2, a); fe_mul(x2, x2, a);
     fe_sqr(x3, x2); fe_mul(x3, x3, a);
@@ -477,6 +479,18 @@ HD void fe_to_w8(u32 w[8], const fe& a) {   // normalises
     w[7] = (t.v[8] >> 16) | (t.v[9] << 10);
 }
 // big-endian bytes -> canonical element; false if >= p
+// a^-1 mod p (0 -> 0) by division steps (modinv.h)
+HD_NOINLINE void fe_inv(fe& r, const fe& a) {
+    u32 w[8];
+    fe_to_w8(w, a);
+    mi_modulus m;
+    mi_modulus_p(m);
+    mi_s30 x;
+    mi_from_w8(x, w);
+    mi_modinv(x, m);
+    mi_to_w8(w, x);
+    fe_from_w8(r, w);
+}
 HD bool fe_from_be(fe& r, const uint8_t* b) {
     u32 w[8];
     be32_to_limbs(w, b);
@@ -589,8 +603,8 @@ HD void sc_mul(sc& r, const sc& a, const sc& b) {
 HD void sc_sqr(sc& r, const sc& a) { sc_mul(r, a, a); }
 HD bool sc_is_zero(const sc& a) { return is_zero256(a.v); }
 HD bool sc_eq(const sc& a, const sc& b) { return eq256(a.v, b.v); }
-// a^(n-2) (0 -> 0): left-to-right square-and-multiply over the public exponent
-HD_NOINLINE void sc_inv(sc& r, const sc& a) {
+// a^(n-2) (0 -> 0): left-to-right square-and-multiply over the public exponent (cross-check of sc_inv)
+HD_NOINLINE void sc_inv_fermat(sc& r, const sc& a) {
     // n - 2 little-endian limbs
     const u32 e[8] = {0xD036413Fu, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     sc acc;
@@ -601,6 +615,15 @@ HD_NOINLINE void sc_inv(sc& r, const sc& a) {
         if ((e[i >> 5] >> (i & 31)) & 1) sc_mul(acc, acc, a);  // exponent is public: wave-uniform branch
     }
     r = acc;
+}
+// a^-1 mod n (0 -> 0) by division steps (modinv.h)
+HD_NOINLINE void sc_inv(sc& r, const sc& a) {
+    mi_modulus m;
+    mi_modulus_n(m);
+    mi_s30 x;
+    mi_from_w8(x, a.v);
+    mi_modinv(x, m);
+    mi_to_w8(r.v, x);
 }
 // big-endian bytes -> canonical scalar; false if >= n (k256 Scalar::from_repr returns None)
 HD bool sc_from_be(sc& r, const uint8_t* b) {

@@ -128,6 +128,25 @@ int emul_fb_build(const uint8_t* gens, int nbases, int W, uint8_t* table_out /* 
     for (size_t t = 0; t < nthreads; t++) fb_build_pass2(fb, t);
     return 0;
 }
+// inversions: division-step form (product) and exponentiation form (cross-check); which = 0 field, 1 scalar
+int emul_inv(int which, const uint8_t a[32], uint8_t out_divsteps[32], uint8_t out_fermat[32]) {
+    if (which == 0) {
+        fe x, r1, r2;
+        if (!fe_from_be(x, a)) return -1;
+        fe_inv(r1, x);
+        fe_inv_fermat(r2, x);
+        fe_to_be(out_divsteps, r1);
+        fe_to_be(out_fermat, r2);
+    } else {
+        sc x, r1, r2;
+        if (!sc_from_be(x, a)) return -1;
+        sc_inv(r1, x);
+        sc_inv_fermat(r2, x);
+        sc_to_be(out_divsteps, r1);
+        sc_to_be(out_fermat, r2);
+    }
+    return 0;
+}
 // fixed-base MSM sum_j k_j G_{first+j} through the table
 int emul_fb_msm(const uint8_t* table, int W, int first_base, int count, const uint8_t* k, uint8_t out[64]) {
     VerifyWs ws;

@@ -22,6 +22,7 @@ def load():
     L.emul_fb_msm.argtypes = [vp, i32, i32, i32, cp, vp]
     L.emul_fb_msm_lanes.argtypes = [vp, i32, i32, i32, cp, vp, vp]
     L.emul_straus.argtypes = [i32, cp, cp, vp]
+    L.emul_inv.argtypes = [i32, cp, vp, vp]
     L.emul_straus_affine.argtypes = [i32, cp, cp, vp, vp]
     L.emul_straus_glv.argtypes = [i32, cp, cp, vp]
     L.emul_glv_split.argtypes = [cp, vp, vp, vp, vp]

@@ -104,6 +104,21 @@ def test_glv_split_and_straus(L):
             assert out.raw == O.pt_to_xy64(exp)
 
 
+def test_division_step_inversion(L):
+    """fe_inv / sc_inv (Bernstein-Yang division steps, modinv.h) against big-integer inverses and the exponentiation forms."""
+    rnd = random.Random(41)
+    a, b = C.create_string_buffer(32), C.create_string_buffer(32)
+    for which, m in ((0, O.P), (1, O.N)):
+        vals = [0, 1, 2, m - 1, m - 2, (m + 1) // 2, 2**255 % m, 2**30, 2**30 - 1, 2**60 + 1, 0x3FFFFFFF << 30, (1 << 256) % m]
+        vals += [rnd.getrandbits(256) % m for _ in range(40)] + [rnd.getrandbits(k) for k in (8, 31, 64, 129, 200)]
+        for v in vals:
+            assert L.emul_inv(which, b32(v), a, b) == 0
+            exp = pow(v, -1, m) if v else 0
+            assert int.from_bytes(a.raw, "big") == exp, (which, hex(v))
+            assert b.raw == a.raw
+    assert L.emul_inv(0, b32(O.P), a, b) == -1          # non-canonical encodings are still refused upstream
+
+
 def test_affine_tables_and_jacobian_straus(L):
     """The u64 verifier's variable-base path: per-proof affine tables from one batched inversion (identity points included),
     Jacobian shared-doubling sum with deferred exception detection, complete-formula fallback."""
