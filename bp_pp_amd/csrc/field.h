@@ -155,7 +155,18 @@ HD void mul_limbs(u32* t, const u32* a, const u32* b) {
 }
 HD void mul256(u32 t[16], const u32 a[8], const u32 b[8]) { mul_limbs<8, 8>(t, a, b); }
 // big-endian 32 bytes <-> limbs
+// 32 big-endian bytes <-> 8 little-endian words.  16-byte aligned addresses (every 64-byte point and 32-byte scalar slot of
+// the C-ABI layouts, when the buffer itself is aligned) move as two 128-bit accesses + byte swaps; anything else goes byte by
+// byte.  The alignment test is the same for every lane of a wavefront in practice (strides are multiples of 16).
+struct alignas(16) u32x4 { u32 x, y, z, w; };
+HD u32 bswap32(u32 v) { return __builtin_bswap32(v); }
 HD void be32_to_limbs(u32 r[8], const uint8_t* b) {
+    if ((((uintptr_t)b) & 15u) == 0) {
+        const u32x4 hi = ((const u32x4*)b)[0], lo = ((const u32x4*)b)[1];
+        r[7] = bswap32(hi.x); r[6] = bswap32(hi.y); r[5] = bswap32(hi.z); r[4] = bswap32(hi.w);
+        r[3] = bswap32(lo.x); r[2] = bswap32(lo.y); r[1] = bswap32(lo.z); r[0] = bswap32(lo.w);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         const uint8_t* q = b + 4 * (7 - i);
@@ -163,6 +174,14 @@ HD void be32_to_limbs(u32 r[8], const uint8_t* b) {
     }
 }
 HD void limbs_to_be32(uint8_t* b, const u32 a[8]) {
+    if ((((uintptr_t)b) & 15u) == 0) {
+        u32x4 hi, lo;
+        hi.x = bswap32(a[7]); hi.y = bswap32(a[6]); hi.z = bswap32(a[5]); hi.w = bswap32(a[4]);
+        lo.x = bswap32(a[3]); lo.y = bswap32(a[2]); lo.z = bswap32(a[1]); lo.w = bswap32(a[0]);
+        ((u32x4*)b)[0] = hi;
+        ((u32x4*)b)[1] = lo;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         uint8_t* q = b + 4 * (7 - i);
