@@ -144,6 +144,29 @@ def main():
                 traffic = json.load(open(tr_path)).get("kernels", {}).get(dom_name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # compute-side ceiling of the same kernel: VALU wave-instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU pass,
+        # profiles/pmc_valu.json, scaled to this batch size) over the live-measured launch time, against the issue rate the
+        # chip sustains for this kernel's instruction mix (tools/intbench.hip: 64-bit multiply-add 29 T lane-ops/s, add/logic
+        # 67 T lane-ops/s; the field arithmetic is ~49 % multiply-adds)
+        valu = None
+        vp_path = os.path.join(ROOT, "profiles", "pmc_valu.json")
+        if os.path.exists(vp_path):
+            try:
+                kv = json.load(open(vp_path)).get(dom_name, {})
+                per_wave = kv.get("valu_insts_per_wave")
+                lanes_per_proof = 8 if dom_name in ("k_verify_c0_fixed", "k_verify_final_check") else 1
+                if per_wave:
+                    waves = (n * lanes_per_proof + 63) // 64
+                    insts = per_wave * waves
+                    mad_frac = 0.49
+                    peak = 1.0 / (mad_frac / (29e12 / 64) + (1 - mad_frac) / (67e12 / 64)) / 1e9
+                    ach = insts / (avg_ms * 1e-3) / 1e9
+                    valu = {"kernel": dom_name, "wave_insts_per_launch": insts, "achieved": ach, "peak": peak,
+                            "unit": "G wave-instructions/s", "frac": ach / peak,
+                            "valu_active_frac_of_wave_cycles": kv.get("SQ_ACTIVE_INST_VALU_frac_of_wave_cycles"),
+                            "wait_frac_of_wave_cycles": kv.get("SQ_WAIT_ANY_frac_of_wave_cycles")}
+            except Exception:
+                valu = None
         result = {
             "metric": "u64 range-proof batch verifies/sec",
             "value": value,
@@ -176,9 +199,10 @@ def main():
                 "traffic": traffic,
                 "avg_launch_ms": avg_ms,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_VERIFY * n,
-                "note": "256-bit modular integer path: VALU integer-multiply bound, HBM fraction is small by construction "
-                        "(SURVEY.md 8d); see DESIGN.md for the integer-op ceiling",
+                "note": "256-bit modular integer path: VALU issue bound, HBM fraction is small by construction "
+                        "(SURVEY.md 8d); roofline_valu is the ceiling that binds",
             },
+            "roofline_valu": valu,
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kernel_times.items()},
             "accept_bits_ok": ok,
             "setup_s": {"seeded_inputs_host": t_inputs, "gpu_batch_prove_incl_pcie": t_gen, "context_tables": t_ctx},
