@@ -15,6 +15,7 @@
 
 #include "../../include/bppp.h"
 #include "prove_core.h"
+#include "circuit_core.h"
 #include "recip_core.h"
 
 using namespace bppp;
@@ -200,6 +201,31 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(WnlaWs w) {
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) wnla_verify_accept(w, t);
+}
+
+// ---- generic arithmetic circuit kernels (circuit_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_phase1(CircuitWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) circuit_phase1(w, t);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_circuit_c0_fixed(CircuitWs w) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt part;
+    FbRanges rg;
+    circuit_c0_fixed_ranges(rg, w);
+    fb_group_sum(part, w.fb, t, lane, w.sc0, rg);
+    if (lane == 0) circuit_c0_fixed_store(w, t, part);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_var(CircuitWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) circuit_c0_var(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_finish(CircuitWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) circuit_c0_finish(w, t);
 }
 
 // ---- generic reciprocal range proof kernels (recip_core.h)
@@ -949,6 +975,124 @@ int bppp_reciprocal_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label
     k_recip_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r);
     k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     for (int k = 1; k <= (int)rounds; k++) k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+    k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
+    k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return BPPP_OK;
+}
+
+// ---------------------------------------------------------------- generic ArithmeticCircuit (circuit.rs:95-256)
+struct bppp_circuit {
+    CircuitDev cd;
+    uint8_t* d_blob = nullptr;
+    size_t blob_bytes = 0;
+};
+int bppp_circuit_create(bppp_ctx* c, bppp_circuit** out, const size_t dims[6], int f_l, int f_m, const uint8_t* W_m, const uint8_t* W_l,
+                        const uint8_t* a_m, const uint8_t* a_l, const int32_t* part_lo, const int32_t* part_ll, const int32_t* part_lr,
+                        const int32_t* part_no) {
+    if (!c || !out || !dims || !W_m || !W_l || !a_m || !a_l || !part_lo || !part_ll || !part_lr || !part_no) return BPPP_ERR_INVALID_ARG;
+    const size_t nm = dims[0], no = dims[1], k = dims[2], nl = dims[3], nv = dims[4], nw = dims[5];
+    // the reference's own definitions (circuit.rs:100-106) and what the context's generators can serve
+    if (nm == 0 || nv == 0 || k == 0 || nl != nv * k || nw != 2 * nm + no || nm > (size_t)c->ng || nv + 9 > (size_t)c->nh || k > 1024 ||
+        nm > 65536 || nv > 65536 || no > 65536)
+        return BPPP_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    CircuitHostData hd;
+    if (!circuit_host_build(hd, dims, W_m, W_l, a_m, a_l, part_lo, part_ll, part_lr, part_no)) return BPPP_ERR_INVALID_ARG;
+    std::vector<int>&cpl = hd.cpl, &rl = hd.rl, &cpm = hd.cpm, &rm = hd.rm, &colmap = hd.colmap;
+    std::vector<u32>&vl = hd.vl, &vm = hd.vm, &al = hd.al, &am = hd.am;
+    bppp_circuit* q = new (std::nothrow) bppp_circuit();
+    if (!q) return BPPP_ERR_INVALID_ARG;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes + 16); return o; };
+    const size_t o_cpl = take(cpl.size() * 4), o_rl = take(rl.size() * 4), o_vl = take(vl.size() * 4), o_cpm = take(cpm.size() * 4),
+                 o_rm = take(rm.size() * 4), o_vm = take(vm.size() * 4), o_cm = take(colmap.size() * 4), o_al = take(al.size() * 4),
+                 o_am = take(am.size() * 4);
+    hipError_t e = hipMalloc(&q->d_blob, off);
+    if (e != hipSuccess) { delete q; g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
+    q->blob_bytes = off;
+    auto up = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpy(q->d_blob + o, src, bytes, hipMemcpyHostToDevice) : hipSuccess; };
+    if (up(o_cpl, cpl.data(), cpl.size() * 4) != hipSuccess || up(o_rl, rl.data(), rl.size() * 4) != hipSuccess ||
+        up(o_vl, vl.data(), vl.size() * 4) != hipSuccess || up(o_cpm, cpm.data(), cpm.size() * 4) != hipSuccess ||
+        up(o_rm, rm.data(), rm.size() * 4) != hipSuccess || up(o_vm, vm.data(), vm.size() * 4) != hipSuccess ||
+        up(o_cm, colmap.data(), colmap.size() * 4) != hipSuccess || up(o_al, al.data(), al.size() * 4) != hipSuccess ||
+        up(o_am, am.data(), am.size() * 4) != hipSuccess) {
+        (void)hipFree(q->d_blob);
+        delete q;
+        g_last_error = "circuit upload failed";
+        return BPPP_ERR_HIP;
+    }
+    CircuitDev& cd = q->cd;
+    cd.nm = (int)nm; cd.no = (int)no; cd.k = (int)k; cd.nl = (int)nl; cd.nv = (int)nv; cd.nw = (int)nw; cd.f_l = f_l ? 1 : 0; cd.f_m = f_m ? 1 : 0;
+    cd.colptr_l = (const int*)(q->d_blob + o_cpl); cd.rows_l = (const int*)(q->d_blob + o_rl); cd.vals_l = (const u32*)(q->d_blob + o_vl);
+    cd.colptr_m = (const int*)(q->d_blob + o_cpm); cd.rows_m = (const int*)(q->d_blob + o_rm); cd.vals_m = (const u32*)(q->d_blob + o_vm);
+    cd.colmap = (const int*)(q->d_blob + o_cm); cd.a_l = (const u32*)(q->d_blob + o_al); cd.a_m = (const u32*)(q->d_blob + o_am);
+    *out = q;
+    return BPPP_OK;
+}
+void bppp_circuit_destroy(bppp_circuit* q) {
+    if (!q) return;
+    if (q->d_blob) (void)hipFree(q->d_blob);
+    delete q;
+}
+int bppp_circuit_verify_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                              const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept, int32_t* status) {
+    if (!c || !q || (!label && label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
+    const CircuitDev& cd = q->cd;
+    if (cd.nm > c->ng || cd.nv + 9 > c->nh || rounds > 12 || nl > 4096 || nn > 4096) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh, k = (size_t)cd.k, nm = (size_t)cd.nm, nv = (size_t)cd.nv;
+    const size_t proof_bytes = 64 * (4 + 2 * rounds) + 32 * (nl + nn);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    const size_t o_com = take(n * k * 64), o_pr = take(n * proof_bytes), o_acc = take(n), o_st = take(n * 4), o_ts = take(52 * n * 4),
+                 o_lam = take((size_t)cd.nl * 8 * n * 4), o_muv = take(nm * 8 * n * 4), o_coef = take((3 * nm + 3 * nv) * 8 * n * 4),
+                 o_sc0 = take((nm + 5 + k) * 8 * n * 4), o_pts = take((4 + k) * 16 * n * 4), o_a = take(30 * n * 4), o_pf = take(30 * n * 4),
+                 o_wc = take(n * 64), o_wcv = take(n * NH * 32), o_rho = take(n * 32), o_mu = take(n * 32),
+                 o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4), o_msc = take(NB * 8 * n * 4);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * k * 64, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_pr, proofs, n * proof_bytes, hipMemcpyHostToDevice, s));
+    CircuitWs r;
+    std::memset(&r, 0, sizeof r);
+    r.N = n; r.cd = cd; r.rounds = (int)rounds; r.NG = c->ng; r.NH = c->nh; r.proof_bytes = proof_bytes;
+    r.commitments = d + o_com; r.proofs = d + o_pr; r.status = (int32_t*)(d + o_st); r.tstate = (u32*)(d + o_ts);
+    r.lamv = (u32*)(d + o_lam); r.muv = (u32*)(d + o_muv); r.coef = (u32*)(d + o_coef); r.sc0 = (u32*)(d + o_sc0); r.pts = (u32*)(d + o_pts);
+    r.acc = (u32*)(d + o_a); r.pfix = (u32*)(d + o_pf);
+    r.straus = c->d_straus;
+    r.wn_commit = d + o_wc; r.wn_c = d + o_wcv; r.wn_rho = d + o_rho; r.wn_mu = d + o_mu;
+    r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
+    t_new(r.base, label, (u32)label_len);
+    WnlaWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.ng = c->ng; w.nh = c->nh; w.rounds = (int)rounds; w.nl = (int)nl; w.nn = (int)nn;
+    w.commitments = r.wn_commit; w.c = r.wn_c; w.rho = r.wn_rho; w.mu = r.wn_mu;
+    w.proof_r = r.proofs + 256; w.proof_x = r.proofs + 256 + 64 * rounds; w.proof_l = r.proofs + 256 + 128 * rounds;
+    w.proof_n = w.proof_l + 32 * nl;
+    w.stride_r = w.stride_x = w.stride_l = w.stride_n = proof_bytes;
+    w.transcript_preloaded = 1;
+    w.accept = d + o_acc; w.status = r.status; w.tstate = r.tstate; w.acc = r.acc; w.pfix = r.pfix;
+    w.ys = (u32*)(d + o_ys); w.tab = (u32*)(d + o_tab); w.msc = (u32*)(d + o_msc);
+    w.straus = c->d_straus;
+    w.fb = r.fb;
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    k_circuit_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    k_circuit_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r);
+    k_circuit_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    k_circuit_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    for (int kk = 1; kk <= (int)rounds; kk++) k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
     k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
     k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);

@@ -87,3 +87,51 @@ class ReciprocalRangeProofProtocol:
                                                              commitments.ctypes.data, proofs.ctypes.data, rounds, nl, nn,
                                                              acc.ctypes.data, st.ctypes.data))
         return acc, st
+
+
+class ArithmeticCircuit:
+    """Mirror of `circuit::ArithmeticCircuit` (circuit.rs:95-139), verify only, for a circuit shared by a batch of instances.
+
+    W_m / W_l: row-major lists (or arrays) of 32-byte big-endian scalars, a_m / a_l likewise; `partition(typ, index)` is the
+    reference's closure with typ in {"LO", "LL", "LR", "NO"}, returning an index into w_o or None -- it is sampled once here
+    into the four index tables the C ABI takes."""
+
+    def __init__(self, dim_nm: int, dim_no: int, k: int, dim_nv: int, g: bytes, g_vec, h_vec, W_m, W_l, a_m, a_l, f_l: bool, f_m: bool,
+                 g_vec_, h_vec_, partition, device: int = 0, fb_window_bits: int = 0):
+        import ctypes as C
+        if len(g_vec) != dim_nm or len(h_vec) != dim_nv + 9:
+            raise ValueError("g_vec must hold dim_nm points and h_vec dim_nv + 9")
+        self.dim_nm, self.dim_no, self.k, self.dim_nv = dim_nm, dim_no, k, dim_nv
+        self.dim_nl, self.dim_nw = dim_nv * k, 2 * dim_nm + dim_no
+        self._w = WeightNormLinearArgument(g, list(g_vec) + list(g_vec_), list(h_vec) + list(h_vec_), device, fb_window_bits)
+        Wm = _u8(W_m, (dim_nm * self.dim_nw, 32))
+        Wl = _u8(W_l, (self.dim_nl * self.dim_nw, 32))
+        am, al = _u8(a_m, (dim_nm, 32)), _u8(a_l, (self.dim_nl, 32))
+        tab = lambda typ, size: np.array([-1 if partition(typ, j) is None else int(partition(typ, j)) for j in range(size)], np.int32)
+        lo, ll, lr, no = tab("LO", dim_nv), tab("LL", dim_nv), tab("LR", dim_nv), tab("NO", dim_nm)
+        dims = (C.c_size_t * 6)(dim_nm, dim_no, k, self.dim_nl, dim_nv, self.dim_nw)
+        h = C.c_void_p()
+        try:
+            _capi.check(_capi.lib().bppp_circuit_create(self._w._ctx, C.byref(h), dims, 1 if f_l else 0, 1 if f_m else 0, Wm.ctypes.data,
+                                                        Wl.ctypes.data, am.ctypes.data, al.ctypes.data, lo.ctypes.data, ll.ctypes.data,
+                                                        lr.ctypes.data, no.ctypes.data))
+        except Exception:
+            self._w.close()
+            raise
+        self._circuit = h
+
+    def close(self):
+        if getattr(self, "_circuit", None):
+            _capi.lib().bppp_circuit_destroy(self._circuit)
+            self._circuit = None
+        self._w.close()
+
+    def verify_batch(self, label: bytes, commitments, proofs, rounds: int, nl: int, nn: int):
+        """circuit.rs:154-256 for a batch: commitments [B, k, 64], proofs [B, 64 (4 + 2 rounds) + 32 (nl + nn)] -> (accept, status)."""
+        commitments = _u8(commitments, (-1, self.k, 64))
+        B = commitments.shape[0]
+        proofs = _u8(proofs, (B, 64 * (4 + 2 * rounds) + 32 * (nl + nn)))
+        acc, st = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        _capi.check(_capi.lib().bppp_circuit_verify_batch(self._w._ctx, self._circuit, label, len(label), B, commitments.ctypes.data,
+                                                          proofs.ctypes.data, rounds, nl, nn, acc.ctypes.data, st.ctypes.data))
+        return acc, st

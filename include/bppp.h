@@ -137,6 +137,24 @@ BPPP_API int bppp_wnla_verify_batch(bppp_ctx* ctx, const uint8_t* label, size_t 
                                     const uint8_t* proof_l /* n x nl x 32 */, size_t nl, const uint8_t* proof_n /* n x nn x 32 */,
                                     size_t nn, uint8_t* accept /* n */, int32_t* status /* n or NULL */);
 
+/* ArithmeticCircuit (circuit.rs:95-139) shared by a batch, and ArithmeticCircuit::verify (circuit.rs:154-256) for n
+ * independent (commitments, proof) instances of it.  dims = {dim_nm, dim_no, k, dim_nl, dim_nv, dim_nw} with the reference's
+ * own relations dim_nl = dim_nv k, dim_nw = 2 dim_nm + dim_no; W_m (dim_nm x dim_nw), W_l (dim_nl x dim_nw), a_m, a_l are
+ * row-major 32-byte big-endian scalars; the `partition` closure is given as four index tables (value = index into w_o, or -1
+ * for None): part_lo / part_ll / part_lr (dim_nv entries each, PartitionType::{LO, LL, LR}) and part_no (dim_nm entries,
+ * PartitionType::NO).  The context comes from bppp_wnla_ctx_create(g, g_vec || g_vec_, NG, h_vec || h_vec_, NH) with
+ * NG >= dim_nm and NH >= dim_nv + 9 (both powers of two, as the WNLA stage needs).
+ * Instance inputs: commitments n x k x 64 (the `v` slice of verify), proofs n x (64 (4 + 2 rounds) + 32 (nl + nn)) laid out
+ *   c_l, c_r, c_o, c_s | r[rounds] | x[rounds] | l[nl] | n[nn];   the transcript starts as Transcript::new(label). */
+typedef struct bppp_circuit bppp_circuit;
+BPPP_API int bppp_circuit_create(bppp_ctx* ctx, bppp_circuit** out, const size_t dims[6], int f_l, int f_m, const uint8_t* W_m,
+                                 const uint8_t* W_l, const uint8_t* a_m, const uint8_t* a_l, const int32_t* part_lo,
+                                 const int32_t* part_ll, const int32_t* part_lr, const int32_t* part_no);
+BPPP_API void bppp_circuit_destroy(bppp_circuit* circuit);
+BPPP_API int bppp_circuit_verify_batch(bppp_ctx* ctx, const bppp_circuit* circuit, const uint8_t* label, size_t label_len, size_t n,
+                                       const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn,
+                                       uint8_t* accept /* n */, int32_t* status /* n or NULL */);
+
 /* ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) for runtime dim_nd / dim_np (dim_np <= dim_nd + 1): e.g.
  * dim_nd = 256, dim_np = 16 -> |g_vec| = 256, |h_vec| + |h_vec_| = 512, 8 WNLA rounds (BASELINE configs[4]).  The context
  * comes from bppp_wnla_ctx_create(g, g_vec || g_vec_, NG, h_vec || h_vec_, NH) with NG >= dim_nd, NH >= dim_nd + 10.

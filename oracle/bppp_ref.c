@@ -1740,6 +1740,123 @@ API int bppp_oracle_reciprocal_verify(const uint8_t* g, const uint8_t* g_vec, si
     return rc;
 }
 
+/* ------------------------------------------------------------------ generic ArithmeticCircuit exports (circuit.rs:95-556)
+ * Circuit description as flat arrays: dims = {dim_nm, dim_no, k, dim_nl, dim_nv, dim_nw}; W_m (nm x nw), W_l (nl x nw), a_m, a_l
+ * as 32-byte big-endian scalars, row-major; the partition closure as four index tables (-1 = None): LO, LL, LR (dim_nv
+ * entries each) and NO (dim_nm entries).  Generators: g, g_vec (dim_nm), h_vec (9 + dim_nv), padding g_vec_ / h_vec_.
+ * Proof layout: c_l, c_r, c_o, c_s | r[rounds] | x[rounds] | l[nl] | n[nn]. */
+typedef struct { circuit_t c; pt* pts; sc* scs; } circ_loaded;
+static int circ_load(circ_loaded* L, const uint8_t* g, const uint8_t* g_vec, const uint8_t* h_vec, const uint8_t* g_vec_, size_t ng_,
+                     const uint8_t* h_vec_, size_t nh_, const size_t dims[6], int f_l, int f_m, const uint8_t* W_m, const uint8_t* W_l,
+                     const uint8_t* a_m, const uint8_t* a_l, const int32_t* part_lo, const int32_t* part_ll, const int32_t* part_lr,
+                     const int32_t* part_no) {
+    size_t nm = dims[0], no = dims[1], k = dims[2], nl = dims[3], nv = dims[4], nw = dims[5], nh = nv + 9;
+    circuit_t* c = &L->c;
+    L->pts = (pt*)malloc(sizeof(pt) * (nm + nh + ng_ + nh_ + 1));
+    L->scs = (sc*)malloc(sizeof(sc) * (nm * nw + nl * nw + nm + nl + 1));
+    int ok = pt_from_xy64(&c->g, g);
+    pt* a = L->pts;
+    for (size_t i = 0; i < nm; i++) ok &= pt_from_xy64(&a[i], g_vec + 64 * i);
+    for (size_t i = 0; i < nh; i++) ok &= pt_from_xy64(&a[nm + i], h_vec + 64 * i);
+    for (size_t i = 0; i < ng_; i++) ok &= pt_from_xy64(&a[nm + nh + i], g_vec_ + 64 * i);
+    for (size_t i = 0; i < nh_; i++) ok &= pt_from_xy64(&a[nm + nh + ng_ + i], h_vec_ + 64 * i);
+    sc* q = L->scs;
+    sc *Wm = q, *Wl = q + nm * nw, *am = Wl + nl * nw, *al = am + nm;
+    for (size_t i = 0; i < nm * nw; i++) ok &= sc_from_be(&Wm[i], W_m + 32 * i);
+    for (size_t i = 0; i < nl * nw; i++) ok &= sc_from_be(&Wl[i], W_l + 32 * i);
+    for (size_t i = 0; i < nm; i++) ok &= sc_from_be(&am[i], a_m + 32 * i);
+    for (size_t i = 0; i < nl; i++) ok &= sc_from_be(&al[i], a_l + 32 * i);
+    for (size_t j = 0; j < nv; j++) ok &= part_lo[j] < (int32_t)no && part_ll[j] < (int32_t)no && part_lr[j] < (int32_t)no;
+    for (size_t j = 0; j < nm; j++) ok &= part_no[j] < (int32_t)no;
+    c->dim_nm = nm; c->dim_no = no; c->k = k; c->dim_nl = nl; c->dim_nv = nv; c->dim_nw = nw;
+    c->g_vec = a; c->n_g_vec = nm;
+    c->h_vec = a + nm; c->n_h_vec = nh;
+    c->g_vec_ = a + nm + nh; c->n_g_vec_ = ng_;
+    c->h_vec_ = a + nm + nh + ng_; c->n_h_vec_ = nh_;
+    c->W_m = Wm; c->W_l = Wl; c->a_m = am; c->a_l = al;
+    c->f_l = f_l; c->f_m = f_m;
+    c->part[PART_LO] = part_lo; c->part[PART_LL] = part_ll; c->part[PART_LR] = part_lr; c->part[PART_NO] = part_no;
+    return ok && nw == 2 * nm + no;
+}
+static void circ_free(circ_loaded* L) { free(L->pts); free(L->scs); }
+/* witness: v = k vectors of dim_nv scalars, s_v = k blinding scalars, w_l / w_r (dim_nm), w_o (dim_no); rnd = the prover's
+ * Scalar::generate_biased draws in order.  Outputs the k commitments (circuit.rs:146-151) and the proof. */
+API int bppp_oracle_circuit_prove(const uint8_t* g, const uint8_t* g_vec, const uint8_t* h_vec, const uint8_t* g_vec_, size_t ng_,
+                                  const uint8_t* h_vec_, size_t nh_, const size_t dims[6], int f_l, int f_m, const uint8_t* W_m,
+                                  const uint8_t* W_l, const uint8_t* a_m, const uint8_t* a_l, const int32_t* part_lo,
+                                  const int32_t* part_ll, const int32_t* part_lr, const int32_t* part_no, const uint8_t* label,
+                                  size_t label_len, const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l, const uint8_t* w_r,
+                                  const uint8_t* w_o, const uint8_t* rnd, size_t n_rnd, uint8_t* commitments_out, uint8_t* proof_out,
+                                  size_t* rounds, size_t* nl_out, size_t* nn_out) {
+    circ_loaded L;
+    int ok = circ_load(&L, g, g_vec, h_vec, g_vec_, ng_, h_vec_, nh_, dims, f_l, f_m, W_m, W_l, a_m, a_l, part_lo, part_ll, part_lr, part_no);
+    size_t nm = dims[0], no = dims[1], k = dims[2], nv = dims[4];
+    sc* ws = (sc*)malloc(sizeof(sc) * (k * nv + k + 2 * nm + no + n_rnd + 1));
+    sc *vv = ws, *sv = vv + k * nv, *wl = sv + k, *wr = wl + nm, *wo = wr + nm, *draws = wo + no;
+    for (size_t i = 0; i < k * nv; i++) ok &= sc_from_be(&vv[i], v + 32 * i);
+    for (size_t i = 0; i < k; i++) ok &= sc_from_be(&sv[i], s_v + 32 * i);
+    for (size_t i = 0; i < nm; i++) ok &= sc_from_be(&wl[i], w_l + 32 * i) & sc_from_be(&wr[i], w_r + 32 * i);
+    for (size_t i = 0; i < no; i++) ok &= sc_from_be(&wo[i], w_o + 32 * i);
+    for (size_t i = 0; i < n_rnd; i++) ok &= sc_from_be(&draws[i], rnd + 32 * i);
+    int rc = ORACLE_ERR_ENCODING;
+    if (ok && k <= 64) {
+        pt coms[64];
+        for (size_t i = 0; i < k; i++) coms[i] = circuit_commit(&L.c, vv + i * nv, nv, &sv[i]);
+        cwitness w = {vv, nv, sv, wl, wr, wo};
+        transcript t;
+        t_new(&t, label, label_len);
+        rng_t rng = {draws, n_rnd};
+        circuit_proof_t cp;
+        rc = circuit_prove(&L.c, coms, k, &w, &t, &rng, &cp);
+        if (rc == 1) {
+            uint8_t* o = proof_out;
+            pt_to_xy64(o, &cp.c_l); pt_to_xy64(o + 64, &cp.c_r); pt_to_xy64(o + 128, &cp.c_o); pt_to_xy64(o + 192, &cp.c_s);
+            o += 256;
+            for (size_t i = 0; i < cp.nr; i++, o += 64) pt_to_xy64(o, &cp.r[i]);
+            for (size_t i = 0; i < cp.nx; i++, o += 64) pt_to_xy64(o, &cp.x[i]);
+            for (size_t i = 0; i < cp.nl; i++, o += 32) sc_to_be(o, &cp.l[i]);
+            for (size_t i = 0; i < cp.nn; i++, o += 32) sc_to_be(o, &cp.n[i]);
+            *rounds = cp.nr; *nl_out = cp.nl; *nn_out = cp.nn;
+            for (size_t i = 0; i < k; i++) pt_to_xy64(commitments_out + 64 * i, &coms[i]);
+            rc = 0;
+        }
+    }
+    free(ws);
+    circ_free(&L);
+    return rc;
+}
+/* -> 1 accept, 0 reject, < 0 error */
+API int bppp_oracle_circuit_verify(const uint8_t* g, const uint8_t* g_vec, const uint8_t* h_vec, const uint8_t* g_vec_, size_t ng_,
+                                   const uint8_t* h_vec_, size_t nh_, const size_t dims[6], int f_l, int f_m, const uint8_t* W_m,
+                                   const uint8_t* W_l, const uint8_t* a_m, const uint8_t* a_l, const int32_t* part_lo,
+                                   const int32_t* part_ll, const int32_t* part_lr, const int32_t* part_no, const uint8_t* label,
+                                   size_t label_len, const uint8_t* commitments, const uint8_t* proof, size_t rounds, size_t nl,
+                                   size_t nn) {
+    if (rounds > 64 || nl > 8 || nn > 8 || dims[2] > 64) return ORACLE_ERR_ENCODING;
+    circ_loaded L;
+    int ok = circ_load(&L, g, g_vec, h_vec, g_vec_, ng_, h_vec_, nh_, dims, f_l, f_m, W_m, W_l, a_m, a_l, part_lo, part_ll, part_lr, part_no);
+    size_t k = dims[2];
+    pt coms[64];
+    for (size_t i = 0; i < k; i++) ok &= pt_from_xy64(&coms[i], commitments + 64 * i);
+    circuit_proof_t cp;
+    const uint8_t* o = proof;
+    ok &= pt_from_xy64(&cp.c_l, o) & pt_from_xy64(&cp.c_r, o + 64) & pt_from_xy64(&cp.c_o, o + 128) & pt_from_xy64(&cp.c_s, o + 192);
+    o += 256;
+    for (size_t i = 0; i < rounds; i++, o += 64) ok &= pt_from_xy64(&cp.r[i], o);
+    for (size_t i = 0; i < rounds; i++, o += 64) ok &= pt_from_xy64(&cp.x[i], o);
+    for (size_t i = 0; i < nl; i++, o += 32) ok &= sc_from_be(&cp.l[i], o);
+    for (size_t i = 0; i < nn; i++, o += 32) ok &= sc_from_be(&cp.n[i], o);
+    cp.nr = cp.nx = rounds; cp.nl = nl; cp.nn = nn;
+    int rc = ORACLE_ERR_ENCODING;
+    if (ok) {
+        transcript t;
+        t_new(&t, label, label_len);
+        rc = circuit_verify(&L.c, coms, k, &t, &cp, NULL);
+    }
+    circ_free(&L);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ threaded batch drivers (CPU baseline + checker) */
 typedef struct {
     const uint8_t *gens, *label; size_t label_len, n, stride_v, lo, hi;

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../bp_pp_amd/csrc/prove_core.h"
+#include "../../bp_pp_amd/csrc/circuit_core.h"
 #include "../../bp_pp_amd/csrc/recip_core.h"
 
 using namespace bppp;
@@ -378,6 +379,72 @@ int emul_recip_verify(const uint8_t* table, int W, int NG, int NH, int nd, int n
     for (size_t t = 0; t < n; t++) wnla_verify_begin(w, t);
     for (int k = 1; k <= rounds; k++)
         for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, k);
+    for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);
+    for (size_t t = 0; t < n; t++) {
+        pt a;
+        FbRanges rg;
+        wnla_msm_ranges(rg, w);
+        fb_sum_serial(a, w.fb, t, w.msc, rg);
+        wnla_verify_store(w, t, a);
+    }
+    for (size_t t = 0; t < n; t++) wnla_verify_accept(w, t);
+    return 0;
+}
+// generic ArithmeticCircuit::verify (circuit_core.h) + the WNLA stage, every phase in thread order
+int emul_circuit_verify(const uint8_t* table, int W, int NG, int NH, const size_t dims[6], int f_l, int f_m, const uint8_t* W_m,
+                        const uint8_t* W_l, const uint8_t* a_m, const uint8_t* a_l, const int32_t* part_lo, const int32_t* part_ll,
+                        const int32_t* part_lr, const int32_t* part_no, const uint8_t* label, size_t label_len, size_t n,
+                        const uint8_t* commitments, const uint8_t* proofs, int rounds, int nl, int nn, uint8_t* accept, int32_t* status,
+                        uint8_t* c0_out /* n x 64 or null */, uint8_t* c_out /* n x NH x 32 or null */) {
+    CircuitHostData hd;
+    if (!circuit_host_build(hd, dims, W_m, W_l, a_m, a_l, part_lo, part_ll, part_lr, part_no)) return -2;
+    const size_t nm = dims[0], k = dims[2], nv = dims[4];
+    if ((int)nm > NG || (int)nv + 9 > NH) return -2;
+    const size_t T = (size_t)1 << rounds, NB = 1 + NG + NH, proof_bytes = 64 * (4 + 2 * (size_t)rounds) + 32 * ((size_t)nl + nn);
+    CircuitWs r;
+    memset(&r, 0, sizeof r);
+    CircuitDev& cd = r.cd;
+    cd.nm = (int)nm; cd.no = (int)dims[1]; cd.k = (int)k; cd.nl = (int)dims[3]; cd.nv = (int)nv; cd.nw = (int)dims[5]; cd.f_l = f_l; cd.f_m = f_m;
+    hd.rl.push_back(0); hd.rm.push_back(0); hd.vl.resize(hd.vl.size() + 8); hd.vm.resize(hd.vm.size() + 8);   // never empty
+    cd.colptr_l = hd.cpl.data(); cd.rows_l = hd.rl.data(); cd.vals_l = hd.vl.data();
+    cd.colptr_m = hd.cpm.data(); cd.rows_m = hd.rm.data(); cd.vals_m = hd.vm.data();
+    cd.colmap = hd.colmap.data(); cd.a_l = hd.al.data(); cd.a_m = hd.am.data();
+    r.N = n; r.rounds = rounds; r.NG = NG; r.NH = NH; r.proof_bytes = proof_bytes;
+    r.commitments = commitments; r.proofs = proofs; r.status = status;
+    std::vector<u32> ts(52 * n), lam((size_t)cd.nl * 8 * n), muv(nm * 8 * n), coef((3 * nm + 3 * nv) * 8 * n), sc0((nm + 5 + k) * 8 * n),
+        pts((4 + k) * 16 * n), acc(30 * n), pf(30 * n), ys((rounds ? rounds : 1) * 8 * n), tab(2 * T * 8 * n), msc(NB * 8 * n);
+    std::vector<uint8_t> wc(n * 64), wcv(n * (size_t)NH * 32), wrho(n * 32), wmu(n * 32);
+    std::vector<pt_slot> straus(n * 5 * BPPP_STRAUS_ENTRIES);
+    r.tstate = ts.data(); r.lamv = lam.data(); r.muv = muv.data(); r.coef = coef.data(); r.sc0 = sc0.data(); r.pts = pts.data();
+    r.acc = acc.data(); r.pfix = pf.data(); r.straus = straus.data();
+    r.wn_commit = wc.data(); r.wn_c = wcv.data(); r.wn_rho = wrho.data(); r.wn_mu = wmu.data();
+    r.fb.table = (const apt_packed*)table; r.fb.W = W; r.fb.N = n;
+    t_new(r.base, label, (u32)label_len);
+    WnlaWs w;
+    memset(&w, 0, sizeof w);
+    w.N = n; w.ng = NG; w.nh = NH; w.rounds = rounds; w.nl = nl; w.nn = nn;
+    w.commitments = r.wn_commit; w.c = r.wn_c; w.rho = r.wn_rho; w.mu = r.wn_mu;
+    w.proof_r = proofs + 256; w.proof_x = proofs + 256 + 64 * (size_t)rounds; w.proof_l = proofs + 256 + 128 * (size_t)rounds;
+    w.proof_n = w.proof_l + 32 * (size_t)nl;
+    w.stride_r = w.stride_x = w.stride_l = w.stride_n = proof_bytes;
+    w.transcript_preloaded = 1;
+    w.accept = accept; w.status = status; w.tstate = r.tstate; w.acc = r.acc; w.pfix = r.pfix; w.ys = ys.data(); w.tab = tab.data();
+    w.msc = msc.data(); w.straus = straus.data(); w.fb = r.fb;
+    for (size_t t = 0; t < n; t++) circuit_phase1(r, t);
+    for (size_t t = 0; t < n; t++) {
+        pt a;
+        FbRanges rg;
+        circuit_c0_fixed_ranges(rg, r);
+        fb_sum_serial(a, r.fb, t, r.sc0, rg);
+        circuit_c0_fixed_store(r, t, a);
+    }
+    for (size_t t = 0; t < n; t++) circuit_c0_var(r, t);
+    for (size_t t = 0; t < n; t++) circuit_c0_finish(r, t);
+    if (c0_out) memcpy(c0_out, wc.data(), wc.size());
+    if (c_out) memcpy(c_out, wcv.data(), wcv.size());
+    for (size_t t = 0; t < n; t++) wnla_verify_begin(w, t);
+    for (int kk = 1; kk <= rounds; kk++)
+        for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, kk);
     for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);
     for (size_t t = 0; t < n; t++) {
         pt a;

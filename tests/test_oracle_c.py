@@ -85,3 +85,25 @@ def test_c_wnla_golden(oracle_c):
                                    sz(len(b("label"))), b("commitment"), b("proof_r"), b("proof_x"), sz(nr.value), b("proof_l"),
                                    sz(nl.value), b("proof_n"), sz(nn.value))
     assert rc == 1
+
+
+def test_c_generic_circuit_matches_bigint_oracle(oracle_c):
+    """The C restatement's generic ArithmeticCircuit::{prove, verify} (circuit.rs:154-556) against the Python big-integer one: the
+    reference's `ac_works` statement (tests.rs:45-136) must verify; so must k = 2 with all partition types and the f_m path at
+    dim_nv = 1; f_l + f_m is rejected by BOTH restatements (the shape the reference's coefficient helpers do not complete)."""
+    import circuit_cases
+    from test_circuit_emul import _oracle_circuit
+    import bppp_oracle as O
+    for name, want in (("ac_works", 1), ("mixed_k2", 1), ("fm_nv1", 1), ("fl_fm", 0)):
+        case = circuit_cases.make(name, B=1)
+        pr = case["proofs"][0].tobytes()
+        assert circuit_cases.oracle_verify(case, case["commitments"][0].tobytes(), pr) == want
+        R = case["rounds"]
+        P = lambda i: O.pt_from_xy64(pr[64 * i:64 * i + 64])
+        off = 64 * (4 + 2 * R)
+        sc_at = lambda o: int.from_bytes(pr[o:o + 32], "big")
+        proof = O.CircuitProof(c_l=P(0), c_r=P(1), c_o=P(2), c_s=P(3), r=[P(4 + i) for i in range(R)], x=[P(4 + R + i) for i in range(R)],
+                               l=[sc_at(off + 32 * i) for i in range(case["pl"])],
+                               n=[sc_at(off + 32 * case["pl"] + 32 * i) for i in range(case["pn"])])
+        v = [O.pt_from_xy64(case["commitments"][0, i].tobytes()) for i in range(case["k"])]
+        assert int(_oracle_circuit(case).verify(v, O.Transcript(case["label"]), proof)) == want
