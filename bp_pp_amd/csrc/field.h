@@ -645,13 +645,16 @@ HD_NOINLINE void sc_inv(sc& r, const sc& a) {
     mi_to_w8(r.v, x);
 }
 // big-endian bytes -> canonical scalar; false if >= n (k256 Scalar::from_repr returns None)
-HD bool sc_from_be(sc& r, const uint8_t* b) {
+HD bool sc_is_canonical(const sc& r) {   // r < n  <=>  r + (2^256 - n) does not carry out
     const u32 nd[5] = {BPPP_ND0, BPPP_ND1, BPPP_ND2, BPPP_ND3, BPPP_ND4};
-    be32_to_limbs(r.v, b);
     u32 c = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) (void)addc(r.v[i], i < 5 ? nd[i] : 0u, c);
     return c == 0;
+}
+HD bool sc_from_be(sc& r, const uint8_t* b) {
+    be32_to_limbs(r.v, b);
+    return sc_is_canonical(r);
 }
 HD void sc_to_be(uint8_t* b, const sc& a) { limbs_to_be32(b, a.v); }
 
