@@ -715,7 +715,7 @@ HD bool straus_affine_fast(pt& out, const apt_packed* tab, const int* pidx, cons
     return !exceptional;
 }
 template <int M>
-HD_NOINLINE void straus_affine_complete(pt& out, const apt_packed* tab, const int* pidx, const glv_words<M>& g) {
+HD void straus_affine_complete(pt& out, const apt_packed* tab, const int* pidx, const glv_words<M>& g) {
     pt acc;
     pt_set_identity(acc);
 #pragma nounroll
