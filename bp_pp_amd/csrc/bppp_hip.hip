@@ -17,6 +17,7 @@
 #include "prove_core.h"
 #include "circuit_core.h"
 #include "recip_core.h"
+#include "rlc_core.h"
 
 using namespace bppp;
 
@@ -76,6 +77,95 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(VerifyWs ws, int* 
         verify_accept(ws, t);
         if (reject_count && !ws.accept[t]) atomicAdd(reject_count, 1);
     }
+}
+// ---- random-linear-combination batch mode (rlc_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(VerifyWs ws, RlcWs r) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) rlc_lhs(ws, r, t);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(VerifyWs ws, RlcWs r) {
+    const size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    const size_t chunk = g / BPPP_RLC_CHUNK;
+    const int lane = (int)(g % BPPP_RLC_CHUNK);
+    const size_t N = ws.N, nchunks = (N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    if (chunk >= nchunks) return;            // whole lane groups leave together
+    const size_t t = chunk * BPPP_RLC_CHUNK + lane;
+    // a chunk with a missing or flagged proof goes to the exact kernels
+    int bad = (t < N) ? (ws.status[t] != ST_OK) : 1;
+#pragma unroll
+    for (int m = 1; m < BPPP_RLC_CHUNK; m <<= 1) bad |= __shfl_xor(bad, m, 64);
+    if (bad) {
+        if (lane == 0) { r.flag[chunk] = 1; r.list[atomicAdd(r.count, 1)] = (u32)chunk; }
+        return;
+    }
+    u64 a, b;
+    rlc_weight(a, b, r, t);
+    sc w;
+    rlc_weight_scalar(w, a, b);
+#pragma nounroll
+    for (int i = 0; i < BPPP_NG; i++) {
+        sc p;
+        rlc_product(p, ws, w, t, i);
+#pragma unroll
+        for (int m = 1; m < BPPP_RLC_CHUNK; m <<= 1) {
+            sc o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = __shfl_xor(p.v[k], m, 64);
+            sc_add(p, p, o);
+        }
+        ws_st8(r.sc, N, t, i, p.v);          // every lane keeps its own (identical) copy: no cross-lane memory traffic
+    }
+    FbRanges rg;
+    rlc_ranges(rg);
+    pt rhs, lhs;
+    fb_group_sum(rhs, fb_of(ws), t, lane, r.sc, rg);
+    ws_ld_pt(lhs, r.lhs, N, t);
+    lane_group_sum(lhs);
+    const bool ok = pt_eq(lhs, rhs);
+    if (ok) ws.accept[t] = 1;
+    if (lane == 0) {
+        r.flag[chunk] = ok ? 0 : 1;
+        if (!ok) r.list[atomicAdd(r.count, 1)] = (u32)chunk;
+    }
+}
+// exact final check of the proofs of the flagged chunks: a whole wavefront per proof (637 table additions over 64 lanes, 6-step
+// tree), because only a few proofs are expected here and an 8-lane group would take the full 80-addition latency for each
+__global__ __launch_bounds__(64) void k_verify_final_check_flagged(VerifyWs ws, RlcWs r) {
+    const int lane = (int)threadIdx.x;
+    const size_t nchunks = (ws.N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    if ((size_t)(*r.count) * 8 > nchunks) return;   // many flagged chunks: k_verify_final_check_flagged_dense does them
+    const size_t items = (size_t)(*r.count) * BPPP_RLC_CHUNK;
+#pragma nounroll
+    for (size_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const size_t t = (size_t)r.list[item / BPPP_RLC_CHUNK] * BPPP_RLC_CHUNK + item % BPPP_RLC_CHUNK;
+        if (t >= ws.N) continue;
+        pt part;
+        FbRanges rg;
+        verify_final_check_ranges(rg);
+        fb_group_sum<64>(part, fb_of(ws), t, lane, ws.fsc, rg);
+        if (lane == 0) verify_final_check_store(ws, t, part);
+    }
+}
+// the same for a batch where more than 1/8 of the chunks failed (an adversarial or broken input stream): the regular 8-lane
+// kernel over the whole batch, skipping the chunks that passed
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_flagged_dense(VerifyWs ws, RlcWs r) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    const size_t nchunks = (ws.N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    if ((size_t)(*r.count) * 8 <= nchunks) return;
+    if (t >= ws.N || !r.flag[t / BPPP_RLC_CHUNK]) return;
+    pt part;
+    FbRanges rg;
+    verify_final_check_ranges(rg);
+    fb_group_sum(part, fb_of(ws), t, lane, ws.fsc, rg);
+    if (lane == 0) verify_final_check_store(ws, t, part);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept_flagged(VerifyWs ws, RlcWs r, int* reject_count) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= ws.N) return;
+    if (r.flag[t / BPPP_RLC_CHUNK]) verify_accept(ws, t);
+    if (reject_count && !ws.accept[t]) atomicAdd(reject_count, 1);
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass1(FbBuild fb, size_t nthreads) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
@@ -265,9 +355,10 @@ static thread_local std::string g_last_error;
         }                                                                                              \
     } while (0)
 
-enum KernelId { K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_ACCEPT, K_TABLES, K_COUNT };
+enum KernelId { K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_ACCEPT, K_TABLES, K_RLC_LHS, K_RLC_CHUNK, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"k_verify_phase1",        "k_verify_c0_fixed",    "k_verify_c0_var", "k_verify_round",
-                                                  "k_verify_final_scalars", "k_verify_final_check", "k_verify_accept", "k_verify_tables"};
+                                                  "k_verify_final_scalars", "k_verify_final_check", "k_verify_accept", "k_verify_tables",
+                                                  "k_rlc_lhs",              "k_rlc_chunk"};
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -293,6 +384,10 @@ struct bppp_ctx {
     apt_packed* d_atab = nullptr;
     u32* d_tscr = nullptr;
     size_t vtab_bytes = 0;
+    // random-linear-combination mode: per-proof weighted commitments, chunk scalars, chunk flags
+    size_t rcap = 0;
+    u32* d_rlc = nullptr;
+    size_t rlc_bytes = 0;
     // prover workspace
     size_t pcap = 0;
     u32* d_pws = nullptr;
@@ -339,6 +434,16 @@ static int ensure_vtab_capacity(bppp_ctx* c, size_t n) {
     HIP_TRY(hipMalloc(&c->d_tscr, tscr_bytes));
     c->vtab_bytes = atab_bytes + tscr_bytes;
     c->vcap = cap;
+    return BPPP_OK;
+}
+static int ensure_rlc_capacity(bppp_ctx* c, size_t n) {
+    if (n <= c->rcap) return BPPP_OK;
+    if (c->d_rlc) { (void)hipFree(c->d_rlc); c->d_rlc = nullptr; }
+    c->rcap = 0;
+    size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    c->rlc_bytes = cap * (30 + (size_t)BPPP_NG * 8) * sizeof(u32) + cap + (cap / BPPP_RLC_CHUNK + 4) * sizeof(u32);   // lhs, sc | flags (cap bytes) | list, count
+    HIP_TRY(hipMalloc(&c->d_rlc, c->rlc_bytes));
+    c->rcap = cap;
     return BPPP_OK;
 }
 static const size_t PWS_WORDS_PER_PROOF = 52 + (size_t)SV_COUNT * 8 + (size_t)BPPP_MSC_SETS * BPPP_NG * 8 + (size_t)PB_COUNT * 30;
@@ -531,6 +636,7 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->d_table) (void)hipFree(c->d_table);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_straus) (void)hipFree(c->d_straus);
+    if (c->d_rlc) (void)hipFree(c->d_rlc);
     if (c->d_atab) (void)hipFree(c->d_atab);
     if (c->d_tscr) (void)hipFree(c->d_tscr);
     if (c->d_pws) (void)hipFree(c->d_pws);
@@ -554,7 +660,7 @@ int bppp_ctx_set_stream(bppp_ctx* c, void* hip_stream) {
 
 size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
     if (!c) return 0;
-    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->pws_bytes + c->stage_bytes + (size_t)c->nbases * sizeof(apt);
+    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->pws_bytes + c->stage_bytes + (size_t)c->nbases * sizeof(apt);
 }
 
 int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
@@ -579,8 +685,9 @@ int bppp_ctx_get_timings(bppp_ctx* c, int max_entries, const char** names, doubl
     return n;
 }
 
-int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
-                                 const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count) {
+static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
+                              const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count,
+                              const uint8_t* rlc_seed) {
     if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept) return BPPP_ERR_INVALID_ARG;
     if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;   // u64 entry points need the u64 generator shape
     if (n == 0) return BPPP_OK;
@@ -594,6 +701,22 @@ int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label
     carve(c, ws, n);
     ws.atab = c->d_atab;
     ws.tscr = c->d_tscr;
+    RlcWs rl;
+    std::memset(&rl, 0, sizeof rl);
+    if (rlc_seed) {
+        rc = ensure_rlc_capacity(c, n);
+        if (rc != BPPP_OK) return rc;
+        for (int i = 0; i < 4; i++) {
+            u64 v = 0;
+            for (int k = 0; k < 8; k++) v |= (u64)rlc_seed[8 * i + k] << (8 * k);
+            rl.seed[i] = v;
+        }
+        rl.lhs = c->d_rlc;
+        rl.sc = c->d_rlc + 30 * n;
+        rl.flag = (uint8_t*)(c->d_rlc + (30 + (size_t)BPPP_NG * 8) * n);
+        rl.list = c->d_rlc + (30 + (size_t)BPPP_NG * 8) * c->rcap + c->rcap / 4;
+        rl.count = (int*)(rl.list + c->rcap / BPPP_RLC_CHUNK + 1);
+    }
     ws.commitments = (const uint8_t*)d_commitments;
     ws.proofs = (const uint8_t*)d_proofs;
     ws.accept = (uint8_t*)d_accept;
@@ -630,12 +753,42 @@ int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label
     HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     for (int k = 1; k <= 4; k++) LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
     LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
-    LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
-    LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
+    if (!rlc_seed) {
+        LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+        LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
+    } else {
+        // combined check per chunk of 8 proofs; chunks that fail it (or hold a flagged proof) fall through to the exact kernels
+        const size_t nchunks = (n + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+        const unsigned chunk_blocks = (unsigned)((nchunks * BPPP_RLC_CHUNK + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+        HIP_TRY(hipMemsetAsync(d_accept, 0, n, s));
+        HIP_TRY(hipMemsetAsync(rl.count, 0, sizeof(int), s));
+        LAUNCH(K_RLC_LHS, k_rlc_lhs<<<blocks, BPPP_BLOCK, 0, s>>>(ws, rl));
+        LAUNCH(K_RLC_CHUNK, k_rlc_chunk<<<chunk_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
+        LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged<<<1024, 64, 0, s>>>(ws, rl));
+        LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged_dense<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
+        LAUNCH(K_ACCEPT, k_verify_accept_flagged<<<blocks, BPPP_BLOCK, 0, s>>>(ws, rl, (int*)d_reject_count));
+        if (std::getenv("BPPP_RLC_DEBUG")) {   // diagnostic: how many chunks went to the exact kernels
+            std::vector<uint8_t> hf(nchunks);
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpy(hf.data(), rl.flag, nchunks, hipMemcpyDeviceToHost));
+            size_t cnt = 0;
+            for (uint8_t f : hf) cnt += f ? 1 : 0;
+            std::fprintf(stderr, "bppp rlc: %zu of %zu chunks re-checked exactly\n", cnt, nchunks);
+        }
+    }
 #undef LAUNCH
 #undef LAUNCH_ON
     HIP_TRY(hipGetLastError());
     return BPPP_OK;
+}
+int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
+                                 const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count) {
+    return verify_device_impl(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, d_trace, d_reject_count, nullptr);
+}
+int bppp_u64_verify_batch_rlc_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
+                                     const void* d_proofs, void* d_accept, void* d_status, void* d_reject_count, const uint8_t seed[32]) {
+    if (!seed) return BPPP_ERR_INVALID_ARG;
+    return verify_device_impl(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, nullptr, d_reject_count, seed);
 }
 
 int bppp_u64_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,

@@ -207,24 +207,24 @@ HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, 
 // path has intra-proof parallelism; it lifts the kernel from 1 to 4 resident wavefronts per SIMD at 2^16 proofs.
 #define BPPP_FB_LANES 8
 HD void fixed_base_msm_partial(pt& accp, const FbTable& fbt, size_t t, int lane, const u32* scal, int first_slot, int first_base,
-                               int count) {
+                               int count, int nl = BPPP_FB_LANES) {
     const int nwin = fb_nwin(fbt.W);
     pt acc;
     pt_set_identity(acc);
-    if (nwin % BPPP_FB_LANES == 0) {
+    if (nwin % nl == 0) {
         // every lane takes the windows congruent to it: the scalar is loaded once per base and shared by the group
 #pragma nounroll
         for (int j = 0; j < count; j++) {
             u32 k[8];
             ws_ld8(k, scal, fbt.N, t, first_slot + j);
 #pragma nounroll
-            for (int w = lane; w < nwin; w += BPPP_FB_LANES) fb_lookup_add(acc, fbt, first_base + j, w, k);
+            for (int w = lane; w < nwin; w += nl) fb_lookup_add(acc, fbt, first_base + j, w, k);
         }
     } else {
         // 13 windows do not divide over 8 lanes: deal the (base, window) pairs round-robin instead
         const int pairs = count * nwin;
 #pragma nounroll
-        for (int q = lane; q < pairs; q += BPPP_FB_LANES) {
+        for (int q = lane; q < pairs; q += nl) {
             const int j = q / nwin, w = q - j * nwin;
             u32 k[8];
             ws_ld8(k, scal, fbt.N, t, first_slot + j);
@@ -275,21 +275,21 @@ HD void fb_consume_fast(ptz& acc, bool& empty, const apt_packed& pe, bool skip, 
     ptz_madd(acc, empty, e, skip | id);
 }
 HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, size_t t, int lane, const u32* scal, int first_slot,
-                                int first_base, int count) {
+                                int first_base, int count, int nl = BPPP_FB_LANES) {
     const int nwin = fb_nwin(fbt.W);
     // step i of this lane -> (base j, window w): windows congruent to the lane when they divide evenly, else the
     // (base, window) pairs dealt round-robin (13 windows do not divide over 8 lanes)
-    const bool by_window = (nwin % BPPP_FB_LANES) == 0;
-    const int per_base = nwin / BPPP_FB_LANES;
-    const int steps = by_window ? count * per_base : (count * nwin - lane + BPPP_FB_LANES - 1) / BPPP_FB_LANES;
+    const bool by_window = (nwin % nl) == 0;
+    const int per_base = nwin / nl;
+    const int steps = by_window ? count * per_base : (count * nwin - lane + nl - 1) / nl;
     if (steps <= 0) return;
     auto locate = [&](int i, int& j, int& w) {      // steps past the end re-use the last one (requested, never consumed)
         if (i > steps - 1) i = steps - 1;
         if (by_window) {
             j = i / per_base;
-            w = lane + BPPP_FB_LANES * (i - j * per_base);
+            w = lane + nl * (i - j * per_base);
         } else {
-            const int q = lane + BPPP_FB_LANES * i;
+            const int q = lane + nl * i;
             j = q / nwin;
             w = q - j * nwin;
         }
@@ -330,46 +330,47 @@ struct FbRanges {
     int slot[3], base[3], count[3];
 };
 HD void fb_ranges_one(FbRanges& r, int slot, int base, int count) { r.n = 1; r.slot[0] = slot; r.base[0] = base; r.count[0] = count; }
-HD void fb_lane_sum_complete(pt& part, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg) {
+HD void fb_lane_sum_complete(pt& part, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg, int nl = BPPP_FB_LANES) {
     pt acc;
     pt_set_identity(acc);
 #pragma nounroll
     for (int r = 0; r < rg.n; r++) {
         pt p;
-        fixed_base_msm_partial(p, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r]);
+        fixed_base_msm_partial(p, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r], nl);
         pt_add(acc, acc, p);
     }
     part = acc;
 }
-HD bool fb_lane_sum_fast(pt& part, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg) {
+HD bool fb_lane_sum_fast(pt& part, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg, int nl = BPPP_FB_LANES) {
     ptz acc;
     ptz_init(acc);
     bool empty = true;
 #pragma nounroll
-    for (int r = 0; r < rg.n; r++) fb_lane_accumulate_fast(acc, empty, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r]);
+    for (int r = 0; r < rg.n; r++) fb_lane_accumulate_fast(acc, empty, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r], nl);
     return fb_lane_finish_fast(part, acc, empty);
 }
 // single-thread form of the group sum (host emulation, and device code that runs one thread per proof)
-HD void fb_sum_serial(pt& total, const FbTable& fbt, size_t t, const u32* scal, const FbRanges& rg) {
+HD void fb_sum_serial(pt& total, const FbTable& fbt, size_t t, const u32* scal, const FbRanges& rg, int nl = BPPP_FB_LANES) {
     pt part;
     bool ok = true;
     pt_set_identity(total);
-    for (int lane = 0; lane < BPPP_FB_LANES; lane++) {
-        ok &= fb_lane_sum_fast(part, fbt, t, lane, scal, rg);
+    for (int lane = 0; lane < nl; lane++) {
+        ok &= fb_lane_sum_fast(part, fbt, t, lane, scal, rg, nl);
         pt_add(total, total, part);
     }
     if (ok) return;
     pt_set_identity(total);
-    for (int lane = 0; lane < BPPP_FB_LANES; lane++) {
-        fb_lane_sum_complete(part, fbt, t, lane, scal, rg);
+    for (int lane = 0; lane < nl; lane++) {
+        fb_lane_sum_complete(part, fbt, t, lane, scal, rg, nl);
         pt_add(total, total, part);
     }
 }
 #if defined(__HIPCC__)
 // tree-add the partial sums of the BPPP_FB_LANES consecutive lanes of a group; every lane ends with the total
+template <int NL = BPPP_FB_LANES>
 __device__ __forceinline__ void lane_group_sum(pt& acc) {
 #pragma unroll
-    for (int m = 1; m < BPPP_FB_LANES; m <<= 1) {
+    for (int m = 1; m < NL; m <<= 1) {
         pt o;
 #pragma unroll
         for (int i = 0; i < 10; i++) {
@@ -381,12 +382,13 @@ __device__ __forceinline__ void lane_group_sum(pt& acc) {
     }
 }
 // the 8-lane group sum the fixed-base kernels run: fast lane sums, group-wide vote, complete-formula re-do if any lane asks
+template <int NL = BPPP_FB_LANES>
 __device__ __forceinline__ void fb_group_sum(pt& total, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg) {
-    int bad = fb_lane_sum_fast(total, fbt, t, lane, scal, rg) ? 0 : 1;
+    int bad = fb_lane_sum_fast(total, fbt, t, lane, scal, rg, NL) ? 0 : 1;
 #pragma unroll
-    for (int m = 1; m < BPPP_FB_LANES; m <<= 1) bad |= __shfl_xor(bad, m, 64);
-    if (bad) fb_lane_sum_complete(total, fbt, t, lane, scal, rg);
-    lane_group_sum(total);
+    for (int m = 1; m < NL; m <<= 1) bad |= __shfl_xor(bad, m, 64);
+    if (bad) fb_lane_sum_complete(total, fbt, t, lane, scal, rg, NL);
+    lane_group_sum<NL>(total);
 }
 #endif
 

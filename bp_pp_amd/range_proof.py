@@ -89,6 +89,16 @@ class U64RangeProofProtocol:
                                                              d_accept, d_status or None, d_trace or None,
                                                              d_reject_count or None))
 
+    def verify_batch_rlc_device(self, label: bytes, n: int, d_commitments: int, d_proofs: int, d_accept: int, seed: bytes,
+                                d_status: int = 0, d_reject_count: int = 0) -> None:
+        """Optional batch mode (include/bppp.h: bppp_u64_verify_batch_rlc_device): the final per-proof MSM is replaced by one
+        combined check per chunk of 8 proofs with secret weights derived from `seed` (32 unpredictable bytes, chosen after the
+        proofs are fixed); failing chunks are re-checked exactly, so accept bits stay per proof."""
+        if len(seed) != 32:
+            raise ValueError("seed must be 32 bytes")
+        _capi.check(_capi.lib().bppp_u64_verify_batch_rlc_device(self._ctx, label, len(label), n, d_commitments, d_proofs, d_accept,
+                                                                 d_status or None, d_reject_count or None, seed))
+
     def verify_batch_sec1(self, commitments33, proofs525, label: bytes) -> Tuple[np.ndarray, np.ndarray]:
         """verify over the wire content of SerializableProof: 33-byte SEC1 points, 525-byte proofs (bp_pp_amd/wire.py)."""
         commitments33 = _as_u8(commitments33, (-1, 33))

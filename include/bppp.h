@@ -85,6 +85,17 @@ BPPP_API int bppp_u64_verify_batch_device(bppp_ctx* ctx, const uint8_t* label, s
                                  const void* d_commitments, const void* d_proofs, void* d_accept, void* d_status,
                                  void* d_trace, void* d_reject_count);
 
+/* Optional batch mode: the same pipeline, but the per-proof final check (the 49-base MSM of wnla.rs:80-82, ~26 % of the work)
+ * is replaced by ONE such MSM per chunk of 8 proofs over a random linear combination with secret 128-bit weights derived
+ * from `seed` (Keccak PRF of seed || proof index).  The seed must be unpredictable to whoever produced the proofs and chosen
+ * after they are fixed (e.g. 32 bytes of OS randomness per call).  Chunks whose combined check fails, or that contain a
+ * malformed proof, are re-checked exactly, so accept[] is still per proof; it equals exact mode's except that a chunk holding
+ * an invalid proof passes with probability <= 2^-128.  Everything up to and including the four WNLA rounds -- every
+ * transcript challenge and hashed commitment -- is computed exactly as in exact mode. */
+BPPP_API int bppp_u64_verify_batch_rlc_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n,
+                                              const void* d_commitments, const void* d_proofs, void* d_accept, void* d_status,
+                                              void* d_reject_count, const uint8_t seed[32]);
+
 /* The same verify over the reference's WIRE content: what `reciprocal::SerializableProof` / `circuit::SerializableProof`
  * (reciprocal.rs:37-41, circuit.rs:37-46) carry -- k256 `AffinePoint`s, whose byte form is 33-byte SEC1 compressed
  * (02|03 || x, identity = 33 zero bytes), and 32-byte big-endian scalars.  proofs: n x 525 bytes (13 x 33 in the order

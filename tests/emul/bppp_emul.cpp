@@ -9,6 +9,7 @@
 #include "../../bp_pp_amd/csrc/prove_core.h"
 #include "../../bp_pp_amd/csrc/circuit_core.h"
 #include "../../bp_pp_amd/csrc/recip_core.h"
+#include "../../bp_pp_amd/csrc/rlc_core.h"
 
 using namespace bppp;
 
@@ -264,6 +265,67 @@ int emul_u64_verify_batch(const uint8_t* table, int W, const uint8_t* label, siz
         for (size_t t = 0; t < n; t++) verify_round(ws, t, k);
     for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);
     for (size_t t = 0; t < n; t++) verify_final_check(ws, t);
+    return 0;
+}
+// the random-linear-combination batch mode (rlc_core.h): exact pipeline through the final scalars, weighted commitments, one
+// combined check per chunk of 8 proofs, exact re-check of the chunks that fail it.  Also returns the number of re-checked
+// chunks and, for tests, each proof's weight halves and weighted commitment.
+int emul_u64_verify_batch_rlc(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
+                              const uint8_t* proofs, const uint8_t seed[32], uint8_t* accept, int32_t* status, int* rechecked_chunks,
+                              uint64_t* weights_ab /* n x 2 or null */, uint8_t* lhs_out /* n x 64 or null */) {
+    VerifyWs ws;
+    memset(&ws, 0, sizeof ws);
+    ws.N = n;
+    ws.commitments = V; ws.proofs = proofs; ws.accept = accept; ws.status = status; ws.trace = nullptr;
+    std::vector<u32> strobe_(52 * n), chal(80 * n), sc0(176 * n), cvec(200 * n), pts(208 * n), lns(24 * n), acc(30 * n), pfix(30 * n),
+        fsc(392 * n), lhs(30 * n), rsc(392 * n);
+    std::vector<pt_slot> straus(n * 5 * BPPP_STRAUS_ENTRIES);
+    std::vector<apt_packed> atab(n * BPPP_ATAB_PER_PROOF);
+    std::vector<u32> tscr((size_t)91 * 40 * n);
+    std::vector<uint8_t> flag(n / 8 + 1);
+    ws.tstate = strobe_.data(); ws.chal = chal.data(); ws.sc0 = sc0.data(); ws.cvec = cvec.data(); ws.pts = pts.data();
+    ws.lns = lns.data(); ws.acc = acc.data(); ws.pfix = pfix.data(); ws.fsc = fsc.data(); ws.straus = straus.data();
+    ws.atab = atab.data(); ws.tscr = tscr.data();
+    ws.fb_table = (const apt_packed*)table;
+    ws.fb_w = W;
+    t_new(ws.base, label, (u32)label_len);
+    RlcWs r;
+    memset(&r, 0, sizeof r);
+    for (int i = 0; i < 4; i++) {
+        u64 v = 0;
+        for (int k = 0; k < 8; k++) v |= (u64)seed[8 * i + k] << (8 * k);
+        r.seed[i] = v;
+    }
+    r.lhs = lhs.data(); r.sc = rsc.data(); r.flag = flag.data();
+    for (size_t t = 0; t < n; t++) verify_phase1(ws, t);
+    for (size_t t = 0; t < n; t++) verify_tables(ws, t);
+    for (size_t t = 0; t < n; t++) verify_c0_var(ws, t);
+    for (size_t t = 0; t < n; t++) verify_c0_fixed(ws, t);
+    for (int k = 1; k <= 4; k++)
+        for (size_t t = 0; t < n; t++) verify_round(ws, t, k);
+    for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);
+    for (size_t t = 0; t < n; t++) {
+        rlc_lhs(ws, r, t);
+        if (weights_ab) rlc_weight(*(u64*)&weights_ab[2 * t], *(u64*)&weights_ab[2 * t + 1], r, t);
+        if (lhs_out) {
+            pt L;
+            ws_ld_pt(L, r.lhs, n, t);
+            apt a;
+            pt_to_affine(a, L);
+            apt_to_xy64(lhs_out + 64 * t, a);
+        }
+    }
+    int re = 0;
+    const size_t nchunks = (n + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    for (size_t c = 0; c < nchunks; c++) {
+        const bool ok = rlc_chunk_serial(ws, r, c);
+        for (size_t t = c * BPPP_RLC_CHUNK; t < n && t < (c + 1) * BPPP_RLC_CHUNK; t++) {
+            if (ok) accept[t] = 1;
+            else verify_final_check(ws, t);        // exact: fixed-base MSM + accept
+        }
+        re += ok ? 0 : 1;
+    }
+    *rechecked_chunks = re;
     return 0;
 }
 // full prover pipeline, every stage in thread order

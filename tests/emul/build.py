@@ -29,6 +29,7 @@ def load():
     L.emul_pt_op.argtypes = [i32, cp, cp, vp]
     L.emul_merlin_kat.argtypes = [cp, sz, cp, sz, vp, sz]
     L.emul_u64_verify_batch.argtypes = [vp, i32, cp, sz, sz, vp, vp, vp, vp, vp]
+    L.emul_u64_verify_batch_rlc.argtypes = [vp, i32, cp, sz, sz, vp, vp, cp, vp, vp, vp, vp, vp]
     L.emul_u64_prove_batch.argtypes = [vp, i32, cp, sz, sz, vp, vp, vp, vp, vp, vp]
     L.emul_sec1_expand.argtypes = [sz, vp, vp, vp, vp]
     L.emul_wnla_run.argtypes = [i32, vp, i32, i32, i32, cp, sz, sz, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp]

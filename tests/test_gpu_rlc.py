@@ -1,0 +1,79 @@
+"""GPU tests of the optional random-linear-combination batch mode (bppp_u64_verify_batch_rlc_device): accept bits, statuses and the
+reject count must equal exact mode's and the oracle's on valid, corrupted and malformed proofs, for full and partial chunks."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    from bp_pp_amd import U64RangeProofProtocol
+    import workload
+    n = 1000 + 5                                     # 125 full chunks + a partial one
+    gens, V, P, _ = workload.make_batch(n, first=9000)
+    g, gv, hv = workload.split_generators(gens)
+    p = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=16)
+    yield torch, p, gens, V, P, n
+    p.close()
+
+
+def _run(torch, proto, V, P, seed):
+    import workload
+    n = V.shape[0]
+    dV, dP = torch.from_numpy(np.ascontiguousarray(V)).cuda(), torch.from_numpy(np.ascontiguousarray(P)).cuda()
+    dA = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+    dS = torch.zeros(n, dtype=torch.int32, device="cuda")
+    dR = torch.zeros(1, dtype=torch.int32, device="cuda")
+    proto.set_stream(torch.cuda.current_stream().cuda_stream)
+    if seed is None:
+        proto.verify_batch_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, dR.data_ptr())
+    else:
+        proto.verify_batch_rlc_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), seed, dS.data_ptr(), dR.data_ptr())
+    torch.cuda.synchronize()
+    return dA.cpu().numpy(), dS.cpu().numpy(), int(dR.item())
+
+
+def test_rlc_all_valid(env):
+    torch, proto, gens, V, P, n = env
+    acc, st, rej = _run(torch, proto, V, P, os.urandom(32))
+    assert acc.tolist() == [1] * n and not st.any() and rej == 0
+
+
+def test_rlc_matches_exact_mode_and_oracle_on_bad_proofs(env, oracle_c):
+    import workload
+    torch, proto, gens, V, P, n = env
+    Pc, Vc = P.copy(), V.copy()
+    rng = np.random.default_rng(3)
+    bad = sorted(set(int(i) for i in rng.integers(0, n, 40)) | {0, 7, 8, n - 1})
+    for k, i in enumerate(bad):
+        kind = k % 4
+        if kind == 0:
+            Pc[i, 896 + int(rng.integers(0, 32))] ^= 1            # scalar n0
+        elif kind == 1:
+            Pc[i, 64 * int(rng.integers(4, 12)) + 31] ^= 1         # a round point's x: leaves the curve -> status flag
+        elif kind == 2:
+            Vc[i] = V[(i + 1) % n]                                # commitment of another proof
+        else:
+            Pc[i, 832 + int(rng.integers(0, 32))] ^= 0x10          # scalar l0
+    e_acc, e_st, e_rej = _run(torch, proto, Vc, Pc, None)         # exact mode
+    for seed in (bytes(32), os.urandom(32)):
+        acc, st, rej = _run(torch, proto, Vc, Pc, seed)
+        assert acc.tolist() == e_acc.tolist() and st.tolist() == e_st.tolist() and rej == e_rej
+    assert e_rej == len(bad) and not e_acc[bad].any()
+    # and against the oracle on the touched chunks
+    for i in bad[:12]:
+        rc = oracle_c.u64_verify(gens, workload.LABEL, bytes(Vc[i]), bytes(Pc[i]))
+        assert int(e_acc[i]) == (1 if rc == 1 else 0)
+
+
+def test_rlc_small_batches(env):
+    torch, proto, gens, V, P, n = env
+    for m in (1, 7, 8, 9, 16):
+        acc, st, rej = _run(torch, proto, V[:m], P[:m], os.urandom(32))
+        assert acc.tolist() == [1] * m and rej == 0

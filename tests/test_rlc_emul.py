@@ -1,0 +1,85 @@
+"""CPU tier for the optional random-linear-combination batch mode (rlc_core.h compiled for the host): weights, weighted
+commitments, the combined chunk check and its exact re-check.  Accept bits must equal exact mode's (the oracle's)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import bppp_oracle as O
+import workload
+from emul.build import load
+
+SEED = bytes(range(7, 39))
+
+
+def _weight_halves(seed: bytes, t: int):
+    st = [int.from_bytes(seed[8 * i:8 * i + 8], "little") for i in range(4)] + [t, int.from_bytes(b"BPPP_RLC", "little")] + [0] * 19
+    out = O.keccak_f1600(st)
+    return out[0], out[1]
+
+
+@pytest.fixture(scope="module")
+def setup():
+    L = load()
+    n = 27                                          # 3 full chunks of 8 + a partial one
+    gens, V, P, _ = workload.make_batch(n, first=500)
+    W = 4
+    tab = np.zeros(L.emul_fb_table_entries(49, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0
+    return L, gens, V, P, tab, W, n
+
+
+def _run(L, tab, W, V, P, seed=SEED, want_mid=False):
+    n = V.shape[0]
+    acc, st = np.zeros(n, np.uint8), np.zeros(n, np.int32)
+    re = C.c_int(0)
+    ab = np.zeros((n, 2), np.uint64)
+    lhs = np.zeros((n, 64), np.uint8)
+    V, P = np.ascontiguousarray(V), np.ascontiguousarray(P)
+    rc = L.emul_u64_verify_batch_rlc(tab.ctypes.data, W, workload.LABEL, len(workload.LABEL), n, V.ctypes.data, P.ctypes.data, seed,
+                                     acc.ctypes.data, st.ctypes.data, C.byref(re), ab.ctypes.data if want_mid else None,
+                                     lhs.ctypes.data if want_mid else None)
+    assert rc == 0
+    return (acc, st, re.value, ab, lhs) if want_mid else (acc, st, re.value)
+
+
+def test_rlc_weights_and_weighted_commitments(setup, oracle_c):
+    L, gens, V, P, tab, W, n = setup
+    acc, st, re, ab, lhs = _run(L, tab, W, V[:9], P[:9], want_mid=True)
+    for t in range(9):
+        a, b = _weight_halves(SEED, t)
+        assert (int(ab[t, 0]), int(ab[t, 1])) == (a, b)            # keyed PRF: one Keccak-f[1600] of seed | index | tag
+        w = (a + b * O.LAMBDA) % O.N
+        rc, tr = oracle_c.u64_verify(gens, workload.LABEL, bytes(V[t]), bytes(P[t]), trace=True)
+        C4 = O.pt_from_xy64(tr[320 + 64 * 5:320 + 64 * 6])         # the oracle's final commitment
+        assert lhs[t].tobytes() == O.pt_to_xy64(O.pt_mul(C4, w))
+
+
+def test_rlc_mode_accept_bits_equal_exact_mode(setup, oracle_c):
+    L, gens, V, P, tab, W, n = setup
+    # all valid: three full chunks pass combined, the partial chunk (3 proofs) is re-checked exactly
+    acc, st, re = _run(L, tab, W, V, P)
+    assert acc.all() and not st.any() and re == 1
+    # corruptions in chunks 0 and 2 (two in the same chunk), a malformed proof in chunk 1, the last proof of the partial chunk
+    Pc = P.copy()
+    Pc[3, 900] ^= 1          # final scalar n
+    Pc[17, 5] ^= 0x40        # c_l: still decodes? (x change usually leaves the curve -> status) either way oracle decides
+    Pc[18, 840] ^= 2         # l0
+    Pc[9, 70] ^= 1           # malformed point
+    Pc[26, 927] ^= 1
+    Vc = V.copy()
+    Vc[20] = V[21]           # wrong commitment
+    acc, st, re = _run(L, tab, W, Vc, Pc)
+    exp_acc, exp_st = [], []
+    for t in range(n):
+        rc = oracle_c.u64_verify(gens, workload.LABEL, bytes(Vc[t]), bytes(Pc[t]))
+        exp_acc.append(1 if rc == 1 else 0)
+        exp_st.append(1 if rc < 0 else 0)
+    assert acc.tolist() == exp_acc
+    assert [int(x != 0) for x in st] == exp_st
+    assert re == 4           # every chunk holds a bad proof here (the partial one is always re-checked)
+    # a different seed changes the weights, not the verdicts
+    acc2, _, _ = _run(L, tab, W, Vc, Pc, seed=bytes(32))
+    assert acc2.tolist() == exp_acc
