@@ -153,3 +153,38 @@ def test_sec1_wire_inputs(torch_mod, proto, gold, oracle_c):
     assert (acc[keep] == acc_ref[keep]).all() and (acc[keep] == expect[keep]).all() and not st[keep].any()
     assert st[5] == 1 and st[6] == 1 and acc[5] == 0 and acc[6] == 0
     assert st[7] == 0 and acc[7] == 0
+
+
+def test_random_byte_corruptions_vs_oracle(torch_mod, proto, oracle_c):
+    """Fuzz: one random byte of every proof (or its commitment) is XOR-ed with a random value.  Accept bit and the
+    malformed-input status (non-canonical coordinate / scalar, point off the curve: the inputs k256 deserialisation refuses)
+    must equal the oracle's verdict for each proof; the oracle's negative return codes are its decoding failures."""
+    import workload
+    n = 768
+    gens, V, P, _ = workload.make_batch(n, first=31000)
+    rng = np.random.default_rng(11)
+    V, P = V.copy(), P.copy()
+    for i in range(n):
+        if i % 16 == 0:
+            continue                                         # keep some untouched
+        x = int(rng.integers(1, 256))
+        if i % 7 == 0:
+            V[i, int(rng.integers(0, 64))] ^= x
+        else:
+            P[i, int(rng.integers(0, 928))] ^= x
+    # force the rare encodings too: coordinate = p (non-canonical), scalar = n (non-canonical), y negated (valid other point)
+    pbytes = (2**256 - 2**32 - 977).to_bytes(32, "big")
+    nbytes = int("FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141", 16).to_bytes(32, "big")
+    P[16, 0:32] = np.frombuffer(pbytes, np.uint8)             # (these three proofs were left untouched above)
+    P[32, 832:864] = np.frombuffer(nbytes, np.uint8)
+    y = int.from_bytes(P[48, 96:128].tobytes(), "big")
+    P[48, 96:128] = np.frombuffer(((2**256 - 2**32 - 977) - y).to_bytes(32, "big"), np.uint8)
+    acc, st, _, rej = _device_verify(torch_mod, proto, workload.LABEL, V, P, want_trace=False)
+    n_flag = 0
+    for i in range(n):
+        rc = oracle_c.u64_verify(gens, workload.LABEL, bytes(V[i]), bytes(P[i]))
+        assert int(acc[i]) == (1 if rc == 1 else 0), i
+        assert (int(st[i]) != 0) == (rc < 0), (i, rc, int(st[i]))
+        n_flag += rc < 0
+    assert rej == int((acc == 0).sum()) and n_flag > 50 and acc[64::16].all()
+    assert st[16] != 0 and st[32] != 0 and st[48] == 0 and acc[48] == 0
