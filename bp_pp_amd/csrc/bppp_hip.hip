@@ -360,6 +360,8 @@ static const char* const kKernelNames[K_COUNT] = {"k_verify_phase1",        "k_v
                                                   "k_verify_final_scalars", "k_verify_final_check", "k_verify_accept", "k_verify_tables",
                                                   "k_rlc_lhs",              "k_rlc_chunk"};
 
+static size_t align16(size_t x) { return (x + 15) / 16 * 16; }
+
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
 struct bppp_ctx {
@@ -395,6 +397,8 @@ struct bppp_ctx {
     // staging for the host-pointer entry points
     uint8_t* d_stage = nullptr;
     size_t stage_bytes = 0;
+    uint8_t* d_io = nullptr;     // inputs / outputs of bppp_u64_verify_batch (host buffers)
+    size_t io_bytes = 0;
     // expanded (64-byte) form of SEC1-compressed inputs
     uint8_t* d_expand = nullptr;
     size_t expand_bytes = 0;
@@ -641,6 +645,7 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->d_tscr) (void)hipFree(c->d_tscr);
     if (c->d_pws) (void)hipFree(c->d_pws);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_io) (void)hipFree(c->d_io);
     if (c->d_expand) (void)hipFree(c->d_expand);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -660,7 +665,7 @@ int bppp_ctx_set_stream(bppp_ctx* c, void* hip_stream) {
 
 size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
     if (!c) return 0;
-    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->pws_bytes + c->stage_bytes + (size_t)c->nbases * sizeof(apt);
+    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + (size_t)c->nbases * sizeof(apt);
 }
 
 int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
@@ -796,40 +801,24 @@ int bppp_u64_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, s
     if (!c || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    // separate device buffers (the staging buffer may be used for status inside the device call)
-    uint8_t *d_c = nullptr, *d_p = nullptr, *d_a = nullptr;
-    int32_t* d_s = nullptr;
-    int rc = BPPP_OK;
-    auto cleanup = [&]() {
-        if (d_c) (void)hipFree(d_c);
-        if (d_p) (void)hipFree(d_p);
-        if (d_a) (void)hipFree(d_a);
-        if (d_s) (void)hipFree(d_s);
-    };
-#define HIP_TRY_V(expr)                                                             \
-    do {                                                                            \
-        hipError_t e_ = (expr);                                                     \
-        if (e_ != hipSuccess) {                                                     \
-            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);       \
-            cleanup();                                                              \
-            return BPPP_ERR_HIP;                                                    \
-        }                                                                           \
-    } while (0)
-    HIP_TRY_V(hipMalloc(&d_c, n * 64));
-    HIP_TRY_V(hipMalloc(&d_p, n * (size_t)BPPP_U64_PROOF_BYTES));
-    HIP_TRY_V(hipMalloc(&d_a, n));
-    HIP_TRY_V(hipMalloc(&d_s, n * sizeof(int32_t)));
-    HIP_TRY_V(hipMemcpyAsync(d_c, commitments, n * 64, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY_V(hipMemcpyAsync(d_p, proofs, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, c->stream));
-    rc = bppp_u64_verify_batch_device(c, label, label_len, n, d_c, d_p, d_a, d_s, nullptr, nullptr);
-    if (rc == BPPP_OK) {
-        HIP_TRY_V(hipMemcpyAsync(accept, d_a, n, hipMemcpyDeviceToHost, c->stream));
-        if (status) HIP_TRY_V(hipMemcpyAsync(status, d_s, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY_V(hipStreamSynchronize(c->stream));
+    // persistent I/O staging of the host-buffer entry points (grow-only; separate from d_stage, which the device call may use)
+    const size_t o_c = 0, o_p = align16(o_c + n * 64), o_a = align16(o_p + n * (size_t)BPPP_U64_PROOF_BYTES), o_s = align16(o_a + n),
+                 need = align16(o_s + n * sizeof(int32_t));
+    if (need > c->io_bytes) {
+        if (c->d_io) { (void)hipFree(c->d_io); c->d_io = nullptr; c->io_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->d_io, need));
+        c->io_bytes = need;
     }
-#undef HIP_TRY_V
-    cleanup();
-    return rc;
+    uint8_t *d_c = c->d_io + o_c, *d_p = c->d_io + o_p, *d_a = c->d_io + o_a;
+    int32_t* d_s = (int32_t*)(c->d_io + o_s);
+    HIP_TRY(hipMemcpyAsync(d_c, commitments, n * 64, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_p, proofs, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, c->stream));
+    int rc = bppp_u64_verify_batch_device(c, label, label_len, n, d_c, d_p, d_a, d_s, nullptr, nullptr);
+    if (rc != BPPP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(accept, d_a, n, hipMemcpyDeviceToHost, c->stream));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d_s, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BPPP_OK;
 }
 
 int bppp_u64_commit_value_batch(bppp_ctx* c, size_t n, const uint64_t* x, const uint8_t* s, uint8_t* out) {
@@ -985,7 +974,6 @@ struct WnlaBlob {
     uint8_t* d = nullptr;
     ~WnlaBlob() { if (d) (void)hipFree(d); }
 };
-static size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 
 static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
                     const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, size_t rounds, const uint8_t* proof_r,
