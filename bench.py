@@ -224,7 +224,7 @@ def main():
                             "shared generators, inputs resident in HBM, 1/1024 proofs corrupted",
                 "proofs_per_gpu": n,
                 "total_proofs_per_step": n * world,
-                "fb_window_bits": args.fb_window_bits or 20,
+                "fb_window_bits": args.fb_window_bits or 22,
                 "label": workload.LABEL.decode(),
                 "parallelism": f"shard{world}" if world > 1 else "single",
             },

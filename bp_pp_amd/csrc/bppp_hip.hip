@@ -568,8 +568,8 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     if (!out || !g || (!g_vec && ng) || (!h_vec && nh) || ng > 4096 || nh > 4096) return BPPP_ERR_INVALID_ARG;
     *out = nullptr;
     const int NB = 1 + (int)ng + (int)nh;
-    int W = fb_window_bits ? fb_window_bits : 20;
-    if (W != 4 && W != 8 && W != 16 && W != 10 && W != 20) return BPPP_ERR_INVALID_ARG;
+    int W = fb_window_bits ? fb_window_bits : 22;
+    if (W != 4 && W != 8 && W != 16 && W != 10 && W != 20 && W != 22) return BPPP_ERR_INVALID_ARG;
     int rc = check_device(device);
     if (rc != BPPP_OK) return rc;
     HIP_TRY(hipSetDevice(device));
@@ -615,13 +615,22 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     const size_t entries = (size_t)NB * nwin * per_win;
     c->table_bytes = entries * sizeof(apt_packed);
     HIP_TRY_C(hipMalloc(&c->d_table, c->table_bytes));
-    fe* d_tmp = nullptr;   // x, y, z, prefix products of every entry (freed after the build)
-    HIP_TRY_C(hipMalloc(&d_tmp, entries * 4 * sizeof(fe)));
-    FbBuild fb{c->d_gens, NB, W, c->d_table, d_tmp, d_tmp + entries, d_tmp + 2 * entries, d_tmp + 3 * entries};
-    size_t nthreads = (size_t)NB * nwin * fb_chunks_per_window(W);
-    unsigned blocks = (unsigned)((nthreads + BPPP_BLOCK - 1) / BPPP_BLOCK);
-    k_fb_build_pass1<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
-    k_fb_build_pass2<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
+    // built in passes over groups of bases so that the scratch (x, y, z, prefix product: 160 B per entry) stays below ~32 GB
+    const size_t per_base = (size_t)nwin * per_win;
+    size_t group = ((size_t)32 << 30) / (per_base * 4 * sizeof(fe));
+    if (group < 1) group = 1;
+    if (group > (size_t)NB) group = (size_t)NB;
+    fe* d_tmp = nullptr;
+    const size_t gentries = group * per_base;
+    HIP_TRY_C(hipMalloc(&d_tmp, gentries * 4 * sizeof(fe)));
+    for (size_t b0 = 0; b0 < (size_t)NB; b0 += group) {
+        const size_t nb = (size_t)NB - b0 < group ? (size_t)NB - b0 : group;
+        FbBuild fb{c->d_gens, NB, W, c->d_table, d_tmp, d_tmp + gentries, d_tmp + 2 * gentries, d_tmp + 3 * gentries, (int)b0, (int)nb};
+        size_t nthreads = nb * nwin * fb_chunks_per_window(W);
+        unsigned blocks = (unsigned)((nthreads + BPPP_BLOCK - 1) / BPPP_BLOCK);
+        k_fb_build_pass1<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
+        k_fb_build_pass2<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
+    }
     HIP_TRY_C(hipGetLastError());
     HIP_TRY_C(hipStreamSynchronize(c->stream));
     (void)hipFree(d_tmp);

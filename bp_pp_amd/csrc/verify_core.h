@@ -135,8 +135,8 @@ HD void app_point(strobe& t, const char (&label)[L], const apt& a) {  // transcr
 // above the ~12 G/s the arithmetic can consume.
 // (W = 10 is the same signed scheme with a table small enough for the CPU emulation tests: 26 windows of 512 entries.)
 struct FbTable { const apt_packed* table; int W; size_t N; };
-HD bool fb_signed(int W) { return W == 20 || W == 10; }
-HD int fb_nwin(int W) { return fb_signed(W) ? 260 / W : 256 / W; }
+HD bool fb_signed(int W) { return W == 20 || W == 10 || W == 22; }
+HD int fb_nwin(int W) { return fb_signed(W) ? (W == 22 ? 12 : 260 / W) : 256 / W; }   // signed: ceil(257 / W) windows
 HD size_t fb_per_win(int W) { return fb_signed(W) ? ((size_t)1 << (W - 1)) : (((size_t)1 << W) - 1); }
 HD FbTable fb_of(const VerifyWs& ws) { FbTable f = {ws.fb_table, ws.fb_w, ws.N}; return f; }
 // digit of window w: returns the table index (|d| - 1), whether to skip (d == 0) and whether to negate
@@ -156,9 +156,10 @@ HD void fb_digit(const u32 k[8], int W, int w, size_t& idx, bool& skip, bool& ne
     // k' = k + sum_i 2^(W-1 + W i)  (9 limbs; < 2^260)
     const u32 off20[9] = {0x00080000u, 0x08000080u, 0x00008000u, 0x00800008u, 0x80000800u, 0x00080000u, 0x08000080u, 0x00008000u, 0x00000008u};
     const u32 off10[9] = {0x20080200u, 0x08020080u, 0x02008020u, 0x00802008u, 0x80200802u, 0x20080200u, 0x08020080u, 0x02008020u, 0x00000008u};
+    const u32 off22[9] = {0x00200000u, 0x00000800u, 0x00800002u, 0x00002000u, 0x02000008u, 0x00008000u, 0x08000020u, 0x00020000u, 0x00000080u};
     u32 off[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) off[i] = (W == 20) ? off20[i] : off10[i];
+    for (int i = 0; i < 9; i++) off[i] = (W == 20) ? off20[i] : (W == 22) ? off22[i] : off10[i];
     u32 kp[10];
     u32 c = 0;
 #pragma unroll
@@ -1154,8 +1155,9 @@ struct FbBuild {
     const apt* gens;        // [nbases]
     int nbases, W;
     apt_packed* table;      // [nbases][nwin][2^W - 1], packed canonical affine
-    fe *xtmp, *ytmp, *ztmp; // projective coordinates of every entry (pass 1 -> pass 2)
+    fe *xtmp, *ytmp, *ztmp; // projective coordinates of the entries of THIS pass (pass 1 -> pass 2)
     fe* ptmp;               // prefix products of Z
+    int base0, nb;          // the bases built by this pass: base0 .. base0 + nb - 1 (the scratch holds nb bases' worth of entries)
 };
 HD size_t fb_chunks_per_window(int W) { return (fb_per_win(W) + BPPP_FB_CHUNK - 1) / BPPP_FB_CHUNK; }
 HD void fb_build_pass1(const FbBuild& fb, size_t tid) {
@@ -1165,18 +1167,18 @@ HD void fb_build_pass1(const FbBuild& fb, size_t tid) {
     size_t c = tid % cpw;
     size_t w = (tid / cpw) % nwin;
     size_t b = tid / (cpw * nwin);
-    if (b >= (size_t)fb.nbases) return;
-    apt G = fb.gens[b];
+    if (b >= (size_t)fb.nb) return;
+    apt G = fb.gens[fb.base0 + b];
     pt base;
     pt_from_affine(base, G);
 #pragma nounroll
     for (size_t i = 0; i < w * (size_t)fb.W; i++) pt_dbl(base, base);
-    // start = (c*CH + 1) * base by double-and-add over the (<= 20-bit) multiplier
+    // start = (c*CH + 1) * base by double-and-add over the (<= 22-bit) multiplier
     u32 m = (u32)(c * BPPP_FB_CHUNK + 1);
     pt cur;
     pt_set_identity(cur);
 #pragma nounroll
-    for (int bit = 20; bit >= 0; bit--) {
+    for (int bit = 22; bit >= 0; bit--) {
         pt_dbl(cur, cur);
         pt s;
         pt_add(s, cur, base);
@@ -1199,9 +1201,10 @@ HD void fb_build_pass2(const FbBuild& fb, size_t tid) {
     size_t c = tid % cpw;
     size_t w = (tid / cpw) % nwin;
     size_t b = tid / (cpw * nwin);
-    if (b >= (size_t)fb.nbases) return;
+    if (b >= (size_t)fb.nb) return;
     size_t d0 = c * BPPP_FB_CHUNK;
-    size_t off = (b * nwin + w) * per_win + d0;
+    size_t off = (b * nwin + w) * per_win + d0;                            // within this pass's scratch
+    const size_t toff = ((size_t)fb.base0 * nwin) * per_win;               // this pass's first table entry
     size_t cnt = per_win - d0 < BPPP_FB_CHUNK ? per_win - d0 : BPPP_FB_CHUNK;
     // identity entries (Z = 0; only when the generator itself is the identity) are skipped in the product
     fe run;
@@ -1230,7 +1233,7 @@ HD void fb_build_pass2(const FbBuild& fb, size_t tid) {
         if (id) { fe_set_u32(xy.x, 0); fe_set_u32(xy.y, 0); }
         apt_packed k;
         apt_pack(k, xy);
-        fb.table[off + i] = k;
+        fb.table[toff + off + i] = k;
     }
 }
 

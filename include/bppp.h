@@ -58,9 +58,10 @@ extern "C" {
 typedef struct bppp_ctx bppp_ctx;
 
 /* U64RangeProofProtocol { g, g_vec[16], h_vec[32] } (u64_proof.rs:19-28) bound to GPU `device`.
- * Builds the fixed-base tables for the 49 generators on the GPU.  fb_window_bits: 0 = default 20 (signed 20-bit digits:
- * 49 x 13 x 2^19 affine points = 21 GB of HBM, 13 table additions per scalar; ~53 GB of temporaries during the build);
- * 16 (unsigned, 3.3 GB, 16 additions per scalar); 4, 8, 10 (small tables for tests). */
+ * Builds the fixed-base tables for the 49 generators on the GPU.  fb_window_bits: 0 = default 22 (signed 22-bit digits:
+ * 49 x 12 x 2^21 affine points = 79 GB of HBM, 12 table additions per scalar; built in passes with <= 32 GB of temporaries);
+ * 20 (signed, 21 GB, 13 additions per scalar: ~3 % slower); 16 (unsigned, 3.3 GB, 16 additions); 4, 8, 10 (small tables
+ * for tests). */
 BPPP_API int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec /* 16 x 64 */,
                     const uint8_t* h_vec /* 32 x 64 */, int device, int fb_window_bits);
 BPPP_API void bppp_ctx_destroy(bppp_ctx* ctx);

@@ -123,12 +123,29 @@ int emul_fb_build(const uint8_t* gens, int nbases, int W, uint8_t* table_out /* 
     std::vector<apt> g(nbases);
     for (int i = 0; i < nbases; i++) if (!apt_from_xy64(g[i], gens + 64 * i)) return -1;
     size_t entries = emul_fb_table_entries(nbases, W);
-    std::vector<fe> tmp(entries * 4);
-    FbBuild fb{g.data(), nbases, W, (apt_packed*)table_out, tmp.data(), tmp.data() + entries, tmp.data() + 2 * entries, tmp.data() + 3 * entries};
-    size_t nthreads = (size_t)nbases * fb_nwin(W) * fb_chunks_per_window(W);
-    for (size_t t = 0; t < nthreads; t++) fb_build_pass1(fb, t);
-    for (size_t t = 0; t < nthreads; t++) fb_build_pass2(fb, t);
+    // in passes of two bases, as the library does for tables too large to build at once
+    const size_t per_base = (size_t)fb_nwin(W) * fb_per_win(W), group = 2, gentries = group * per_base;
+    (void)entries;
+    std::vector<fe> tmp(gentries * 4);
+    for (int b0 = 0; b0 < nbases; b0 += (int)group) {
+        const int nb = nbases - b0 < (int)group ? nbases - b0 : (int)group;
+        FbBuild fb{g.data(), nbases, W, (apt_packed*)table_out, tmp.data(), tmp.data() + gentries, tmp.data() + 2 * gentries,
+                   tmp.data() + 3 * gentries, b0, nb};
+        size_t nthreads = (size_t)nb * fb_nwin(W) * fb_chunks_per_window(W);
+        for (size_t t = 0; t < nthreads; t++) fb_build_pass1(fb, t);
+        for (size_t t = 0; t < nthreads; t++) fb_build_pass2(fb, t);
+    }
     return 0;
+}
+// signed / unsigned window digit of scalar k (fb_digit): magnitude index, skip and negate flags
+int emul_fb_digit(int W, const uint8_t k[32], int w, uint64_t* idx, int* skip, int* neg) {
+    sc s;
+    if (!sc_from_be(s, k)) return -1;
+    size_t i;
+    bool sk, ng;
+    fb_digit(s.v, W, w, i, sk, ng);
+    *idx = i; *skip = sk; *neg = ng;
+    return fb_nwin(W);
 }
 // inversions: division-step form (product) and exponentiation form (cross-check); which = 0 field, 1 scalar
 int emul_inv(int which, const uint8_t a[32], uint8_t out_divsteps[32], uint8_t out_fermat[32]) {

@@ -19,6 +19,7 @@ def load():
     L.emul_fb_table_entries.restype = sz
     L.emul_fb_table_entries.argtypes = [i32, i32]
     L.emul_fb_build.argtypes = [cp, i32, i32, vp]
+    L.emul_fb_digit.argtypes = [i32, cp, i32, vp, vp, vp]
     L.emul_fb_msm.argtypes = [vp, i32, i32, i32, cp, vp]
     L.emul_fb_msm_lanes.argtypes = [vp, i32, i32, i32, cp, vp, vp]
     L.emul_straus.argtypes = [i32, cp, cp, vp]
