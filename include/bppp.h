@@ -57,6 +57,10 @@ extern "C" {
 
 typedef struct bppp_ctx bppp_ctx;
 
+/* Concurrency: a context owns its workspace and streams and is NOT re-entrant -- one call at a time per context (use one
+ * context per host thread, or an external lock).  Calls are asynchronous on the context's stream only where the entry point
+ * says so (*_device variants); the host-buffer variants return after the results have been copied back. */
+
 /* U64RangeProofProtocol { g, g_vec[16], h_vec[32] } (u64_proof.rs:19-28) bound to GPU `device`.
  * Builds the fixed-base tables for the 49 generators on the GPU.  fb_window_bits: 0 = default 22 (signed 22-bit digits:
  * 49 x 12 x 2^21 affine points = 79 GB of HBM, 12 table additions per scalar; built in passes with <= 32 GB of temporaries);
