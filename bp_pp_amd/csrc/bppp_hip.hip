@@ -293,6 +293,62 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(WnlaWs w) {
     if (t < w.N) wnla_verify_accept(w, t);
 }
 
+// ---- generic fixed-base linear combination over the context's generators (the crate's commit functions)
+struct MsmWs {
+    size_t N;
+    int nterms, nruns;
+    const uint8_t* scalars;     // N x nterms x 32
+    const int* runs;            // [nruns][3]: first scalar slot, first base, count
+    u32* msc;                   // [nterms * 8][N]
+    u32* pfix;                  // [30][N]
+    int32_t* status;
+    uint8_t* out;               // N x 64
+    FbTable fb;
+};
+__global__ __launch_bounds__(BPPP_BLOCK) void k_msm_scalars(MsmWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= w.N) return;
+    bool ok = true;
+    sc zero;
+    sc_set_u32(zero, 0);
+#pragma nounroll
+    for (int j = 0; j < w.nterms; j++) {
+        sc k;
+        const bool kok = sc_from_be(k, w.scalars + ((size_t)t * w.nterms + j) * 32);
+        ok &= kok;
+        ws_st8(w.msc, w.N, t, j, kok ? k.v : zero.v);
+    }
+    w.status[t] = ok ? ST_OK : ST_BAD_ENCODING;
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_msm(MsmWs w) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt total;
+    pt_set_identity(total);
+#pragma nounroll
+    for (int r = 0; r < w.nruns; r += 3) {      // up to three runs per pass of the 8-lane group sum
+        FbRanges rg;
+        rg.n = w.nruns - r < 3 ? w.nruns - r : 3;
+        for (int q = 0; q < rg.n; q++) { rg.slot[q] = w.runs[3 * (r + q)]; rg.base[q] = w.runs[3 * (r + q) + 1]; rg.count[q] = w.runs[3 * (r + q) + 2]; }
+        pt part;
+        fb_group_sum(part, w.fb, t, lane, w.msc, rg);
+        pt_add(total, total, part);
+    }
+    if (lane == 0) ws_st_pt(w.pfix, w.N, t, total);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_msm_store(MsmWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= w.N) return;
+    pt total;
+    ws_ld_pt(total, w.pfix, w.N, t);
+    apt a;
+    pt_to_affine(a, total);
+    if (w.status[t] != ST_OK) { fe_set_u32(a.x, 0); fe_set_u32(a.y, 0); }
+    apt_to_xy64(w.out + 64 * t, a);
+}
+
 // ---- generic arithmetic circuit kernels (circuit_core.h)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_phase1(CircuitWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
@@ -1248,6 +1304,51 @@ int bppp_circuit_verify_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t*
     k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return BPPP_OK;
+}
+
+// sum_j scalars[i][j] * generator[base_index[j]] for n independent rows, through the context's fixed-base tables: the crate's
+// commit functions (circuit.rs:146-151, reciprocal.rs:88-95, u64_proof.rs:37-39) are instances of this with fixed index lists.
+int bppp_msm_batch(bppp_ctx* c, size_t n, size_t nterms, const int32_t* base_index, const uint8_t* scalars, uint8_t* out, int32_t* status) {
+    if (!c || !base_index || !scalars || !out || nterms == 0 || nterms > 65536) return BPPP_ERR_INVALID_ARG;
+    for (size_t j = 0; j < nterms; j++) {
+        if (base_index[j] < 0 || base_index[j] >= c->nbases) return BPPP_ERR_INVALID_ARG;
+        if (j && base_index[j] <= base_index[j - 1]) return BPPP_ERR_INVALID_ARG;      // strictly increasing
+    }
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<int> runs;
+    for (size_t j = 0; j < nterms;) {
+        size_t e = j + 1;
+        while (e < nterms && base_index[e] == base_index[e - 1] + 1) e++;
+        runs.push_back((int)j); runs.push_back(base_index[j]); runs.push_back((int)(e - j));
+        j = e;
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    const size_t o_sc = take(n * nterms * 32), o_runs = take(runs.size() * 4), o_msc = take(nterms * 8 * n * 4), o_pf = take(30 * n * 4),
+                 o_st = take(n * 4), o_out = take(n * 64);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(d + o_sc, scalars, n * nterms * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_runs, runs.data(), runs.size() * 4, hipMemcpyHostToDevice, s));
+    MsmWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.nterms = (int)nterms; w.nruns = (int)(runs.size() / 3);
+    w.scalars = d + o_sc; w.runs = (const int*)(d + o_runs); w.msc = (u32*)(d + o_msc); w.pfix = (u32*)(d + o_pf);
+    w.status = (int32_t*)(d + o_st); w.out = d + o_out;
+    w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    k_msm_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    k_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w);
+    k_msm_store<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d + o_out, n * 64, hipMemcpyDeviceToHost, s));
     if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return BPPP_OK;

@@ -46,6 +46,17 @@ class WeightNormLinearArgument:
                                                        n.ctypes.data, n.shape[1], out.ctypes.data, st.ctypes.data))
         return out, st
 
+    def msm_batch(self, base_index, scalars) -> Tuple[np.ndarray, np.ndarray]:
+        """sum_j scalars[i][j] * B[base_index[j]] per row over the context's generators (0 = g, 1.. = g_vec, 1 + ng.. = h_vec):
+        the crate's commit functions (include/bppp.h: bppp_msm_batch).  -> (points [B, 64], status [B])."""
+        idx = np.ascontiguousarray(np.asarray(base_index, dtype=np.int32))
+        scalars = _u8(scalars, (-1, idx.shape[0], 32))
+        B = scalars.shape[0]
+        out, st = np.zeros((B, 64), np.uint8), np.zeros(B, np.int32)
+        _capi.check(_capi.lib().bppp_msm_batch(self._ctx, B, idx.shape[0], idx.ctypes.data, scalars.ctypes.data, out.ctypes.data,
+                                               st.ctypes.data))
+        return out, st
+
     def verify_batch(self, label: bytes, commitments, c, rho, mu, proof_r, proof_x, proof_l, proof_n) -> Tuple[np.ndarray, np.ndarray]:
         """wnla.rs:75-121 for a batch; proof_r / proof_x: [B, rounds, 64] in the reference's vector order."""
         commitments = _u8(commitments, (-1, 64))
@@ -77,6 +88,17 @@ class ReciprocalRangeProofProtocol:
 
     def close(self):
         self._w.close()
+
+    def commit_value_batch(self, x, s):
+        """reciprocal.rs:88-90 for a batch: x [B, 32], s [B, 32] (big-endian scalars) -> (points, status)."""
+        x, s = _u8(x, (-1, 32)), _u8(s, (-1, 32))
+        return self._w.msm_batch([0, 1 + self._w.ng], np.stack([x, s], axis=1))
+
+    def commit_poles_batch(self, r, s):
+        """reciprocal.rs:93-95 for a batch: r [B, dim_nd, 32], s [B, 32] -> (points, status)."""
+        r, s = _u8(r, (-1, self.dim_nd, 32)), _u8(s, (-1, 32))
+        idx = [1 + self._w.ng] + [1 + self._w.ng + 9 + i for i in range(self.dim_nd)]
+        return self._w.msm_batch(idx, np.concatenate([s[:, None, :], r], axis=1))
 
     def verify_batch(self, label: bytes, commitments, proofs, rounds: int, nl: int, nn: int):
         commitments = _u8(commitments, (-1, 64))
@@ -125,6 +147,13 @@ class ArithmeticCircuit:
             _capi.lib().bppp_circuit_destroy(self._circuit)
             self._circuit = None
         self._w.close()
+
+    def commit_batch(self, v, s):
+        """circuit.rs:146-151 for a batch: v [B, dim_nv, 32], s [B, 32] -> (points, status)."""
+        v, s = _u8(v, (-1, self.dim_nv, 32)), _u8(s, (-1, 32))
+        ng = self._w.ng
+        idx = [0, 1 + ng] + [1 + ng + 9 + i for i in range(self.dim_nv - 1)]
+        return self._w.msm_batch(idx, np.concatenate([v[:, :1, :], s[:, None, :], v[:, 1:, :]], axis=1))
 
     def verify_batch(self, label: bytes, commitments, proofs, rounds: int, nl: int, nn: int):
         """circuit.rs:154-256 for a batch: commitments [B, k, 64], proofs [B, 64 (4 + 2 rounds) + 32 (nl + nn)] -> (accept, status)."""

@@ -153,6 +153,14 @@ BPPP_API int bppp_wnla_verify_batch(bppp_ctx* ctx, const uint8_t* label, size_t 
                                     const uint8_t* proof_l /* n x nl x 32 */, size_t nl, const uint8_t* proof_n /* n x nn x 32 */,
                                     size_t nn, uint8_t* accept /* n */, int32_t* status /* n or NULL */);
 
+/* out[i] = sum_j scalars[i][j] * B[base_index[j]] for n independent rows, B = the context's generators in table order
+ * (0 = g, 1 .. NG = g_vec || g_vec_, NG + 1 .. NG + NH = h_vec || h_vec_), base_index strictly increasing.  The crate's commit
+ * functions are instances: ArithmeticCircuit::commit(v, s) (circuit.rs:146-151) = {0: v[0], NG+1: s, NG+10 ..: v[1..]},
+ * ReciprocalRangeProofProtocol::commit_value (reciprocal.rs:88-90) = {0: x, NG+1: s}, ::commit_poles (reciprocal.rs:93-95)
+ * = {NG+1: s, NG+10 ..: r}.  A non-canonical scalar flags its row (status BPPP_ST_BAD_ENCODING, output = identity). */
+BPPP_API int bppp_msm_batch(bppp_ctx* ctx, size_t n, size_t nterms, const int32_t* base_index /* nterms */,
+                            const uint8_t* scalars /* n x nterms x 32 */, uint8_t* out /* n x 64 */, int32_t* status /* n or NULL */);
+
 /* ArithmeticCircuit (circuit.rs:95-139) shared by a batch, and ArithmeticCircuit::verify (circuit.rs:154-256) for n
  * independent (commitments, proof) instances of it.  dims = {dim_nm, dim_no, k, dim_nl, dim_nv, dim_nw} with the reference's
  * own relations dim_nl = dim_nv k, dim_nw = 2 dim_nm + dim_no; W_m (dim_nm x dim_nw), W_l (dim_nl x dim_nw), a_m, a_l are

@@ -69,3 +69,53 @@ def test_circuit_create_rejects_inconsistent_dimensions():
         _capi.lib().bppp_circuit_destroy(h)
     finally:
         w.close()
+
+
+def test_commit_functions_vs_oracle():
+    """ArithmeticCircuit::commit (circuit.rs:146-151) and ReciprocalRangeProofProtocol::{commit_value, commit_poles}
+    (reciprocal.rs:88-95) through bppp_msm_batch against the oracle's commitments / big-integer arithmetic."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import bppp_oracle as O
+    import circuit_cases
+    import recip_cases
+    from bp_pp_amd.wnla import ArithmeticCircuit, ReciprocalRangeProofProtocol
+    B = 5
+    case = circuit_cases.make("mixed_k2", B)
+    part = lambda typ, j: (None if case["part"][typ][j] < 0 else int(case["part"][typ][j]))
+    arr = lambda b: np.frombuffer(b, np.uint8).reshape(-1, 32)
+    circ = ArithmeticCircuit(case["nm"], case["no"], case["k"], case["nv"], case["g"], case["gv"], case["hv"], arr(case["Wm_bytes"]),
+                             arr(case["Wl_bytes"]), arr(case["am_bytes"]), arr(case["al_bytes"]), case["f_l"], case["f_m"], case["gv_"],
+                             case["hv_"], part, device=0, fb_window_bits=16)
+    try:
+        sc = lambda v: np.frombuffer(O.sc_to_bytes(v % O.N), np.uint8)
+        v = np.stack([np.stack([sc(x) for x in case["v"][j]]) for b in range(B) for j in range(case["k"])])
+        s = np.stack([sc(circuit_cases._sc(b"sv", b, j)) for b in range(B) for j in range(case["k"])])
+        out, st = circ.commit_batch(v, s)
+        assert not st.any() and (out.reshape(B, case["k"], 64) == case["commitments"]).all()
+        bad = s.copy()
+        bad[1] = 0xFF                                   # >= n: flagged, identity output
+        out, st = circ.commit_batch(v, bad)
+        assert st.tolist() == [0, 1] + [0] * (B * case["k"] - 2) and not out[1].any()
+    finally:
+        circ.close()
+    rc = recip_cases.make(8, 4, 3)
+    proto = ReciprocalRangeProofProtocol(8, 4, rc["g"], rc["gv"], rc["hv"], rc["gv_"], rc["hv_"], device=0, fb_window_bits=16)
+    try:
+        xs = [7, 0, O.N - 1]
+        ss = [recip_cases._sc(b"cs", i) for i in range(3)]
+        out, st = proto.commit_value_batch(np.stack([sc(x) for x in xs]), np.stack([sc(x) for x in ss]))
+        G, H0 = O.pt_from_xy64(rc["g"]), O.pt_from_xy64(rc["hv"][0])
+        for i in range(3):
+            assert out[i].tobytes() == O.pt_to_xy64(O.pt_add(O.pt_mul(G, xs[i]), O.pt_mul(H0, ss[i])))
+        r = [[recip_cases._sc(b"pole", i, j) for j in range(8)] for i in range(3)]
+        out, st = proto.commit_poles_batch(np.stack([np.stack([sc(x) for x in row]) for row in r]), np.stack([sc(x) for x in ss]))
+        for i in range(3):
+            exp = O.pt_mul(H0, ss[i])
+            for j in range(8):
+                exp = O.pt_add(exp, O.pt_mul(O.pt_from_xy64(rc["hv"][9 + j]), r[i][j]))
+            assert out[i].tobytes() == O.pt_to_xy64(exp)
+        assert not st.any()
+    finally:
+        proto.close()
