@@ -18,6 +18,7 @@
 #include "circuit_core.h"
 #include "recip_core.h"
 #include "rlc_core.h"
+#include "wnla_prove_core.h"
 
 using namespace bppp;
 
@@ -291,6 +292,35 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(WnlaWs w) {
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) wnla_verify_accept(w, t);
+}
+
+// ---- generic WNLA prover kernels (wnla_prove_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_init(WnlaProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_prove_init(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_scalars(WnlaProveWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_prove_round_scalars(w, t, k);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wprove_msm(WnlaProveWs w, int set) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt part;
+    FbRanges rg;
+    wnla_prove_msm_ranges(rg, w);
+    fb_group_sum(part, w.fb, t, lane, w.msc + (size_t)set * wp_set_words(w), rg);
+    if (lane == 0) ws_st_pt(w.pbuf + (size_t)set * 30 * w.N, w.N, t, part);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_fold(WnlaProveWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_prove_round_fold(w, t, k);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_finish(WnlaProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_prove_finish(w, t);
 }
 
 // ---- generic fixed-base linear combination over the context's generators (the crate's commit functions)
@@ -1349,6 +1379,76 @@ int bppp_msm_batch(bppp_ctx* c, size_t n, size_t nterms, const int32_t* base_ind
     k_msm_store<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, d + o_out, n * 64, hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return BPPP_OK;
+}
+
+// WeightNormLinearArgument::prove (wnla.rs:125-190) for n instances sharing the context's generators.
+void bppp_wnla_proof_shape(size_t nl, size_t nn, size_t* rounds, size_t* nl_out, size_t* nn_out) {
+    size_t r, a, b;
+    wnla_proof_shape(nl, nn, r, a, b);
+    if (rounds) *rounds = r;
+    if (nl_out) *nl_out = a;
+    if (nn_out) *nn_out = b;
+}
+int bppp_wnla_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments, const uint8_t* cvec,
+                          const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl, const uint8_t* nvec, size_t nn,
+                          uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l, uint8_t* proof_n, int32_t* status) {
+    if (!c || (!label && label_len) || !commitments || !cvec || !rho || !mu || (!l && nl) || (!nvec && nn) || nl > 65536 || nn > 65536)
+        return BPPP_ERR_INVALID_ARG;
+    size_t rounds, nl_f, nn_f;
+    wnla_proof_shape(nl, nn, rounds, nl_f, nn_f);
+    if ((rounds && (!proof_r || !proof_x)) || (nl_f && !proof_l) || (nn_f && !proof_n)) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t NB = (size_t)c->nbases, ng = (size_t)c->ng, nh = (size_t)c->nh;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    const size_t o_com = take(n * 64), o_c = take(n * nh * 32), o_rho = take(n * 32), o_mu = take(n * 32), o_l = take(n * nl * 32 + 16),
+                 o_n = take(n * nn * 32 + 16), o_pr = take(n * rounds * 64 + 16), o_px = take(n * rounds * 64 + 16),
+                 o_pl = take(n * nl_f * 32 + 16), o_pn = take(n * nn_f * 32 + 16), o_st = take(n * 4), o_ts = take(52 * n * 4),
+                 o_vl = take((nl + 1) * 8 * n * 4), o_vn = take((nn + 1) * 8 * n * 4), o_vc = take(nh * 8 * n * 4), o_ch = take(nh * 8 * n * 4),
+                 o_cg = take((ng + 1) * 8 * n * 4), o_prm = take(3 * 8 * n * 4), o_cm = take(16 * n * 4), o_msc = take(3 * NB * 8 * n * 4),
+                 o_pb = take(3 * 30 * n * 4);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * 64, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_c, cvec, n * nh * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_rho, rho, n * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_mu, mu, n * 32, hipMemcpyHostToDevice, s));
+    if (nl) HIP_TRY(hipMemcpyAsync(d + o_l, l, n * nl * 32, hipMemcpyHostToDevice, s));
+    if (nn) HIP_TRY(hipMemcpyAsync(d + o_n, nvec, n * nn * 32, hipMemcpyHostToDevice, s));
+    WnlaProveWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.ng = c->ng; w.nh = c->nh; w.nl = (int)nl; w.nn = (int)nn; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
+    w.commitments = d + o_com; w.c = d + o_c; w.rho = d + o_rho; w.mu = d + o_mu; w.l_in = d + o_l; w.n_in = d + o_n;
+    w.proof_r = d + o_pr; w.proof_x = d + o_px; w.proof_l = d + o_pl; w.proof_n = d + o_pn;
+    w.status = (int32_t*)(d + o_st); w.tstate = (u32*)(d + o_ts); w.vl = (u32*)(d + o_vl); w.vn = (u32*)(d + o_vn); w.vc = (u32*)(d + o_vc);
+    w.ch = (u32*)(d + o_ch); w.cg = (u32*)(d + o_cg); w.prm = (u32*)(d + o_prm); w.com = (u32*)(d + o_cm); w.msc = (u32*)(d + o_msc);
+    w.pbuf = (u32*)(d + o_pb);
+    w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    t_new(w.base, label, (u32)label_len);
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    k_wprove_init<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    for (int k = 0; k < (int)rounds; k++) {
+        k_wprove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1);
+        k_wprove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+        if (k + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2);
+    }
+    k_wprove_finish<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    HIP_TRY(hipGetLastError());
+    if (rounds) {
+        HIP_TRY(hipMemcpyAsync(proof_r, d + o_pr, n * rounds * 64, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(proof_x, d + o_px, n * rounds * 64, hipMemcpyDeviceToHost, s));
+    }
+    if (nl_f) HIP_TRY(hipMemcpyAsync(proof_l, d + o_pl, n * nl_f * 32, hipMemcpyDeviceToHost, s));
+    if (nn_f) HIP_TRY(hipMemcpyAsync(proof_n, d + o_pn, n * nn_f * 32, hipMemcpyDeviceToHost, s));
     if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return BPPP_OK;

@@ -46,6 +46,25 @@ class WeightNormLinearArgument:
                                                        n.ctypes.data, n.shape[1], out.ctypes.data, st.ctypes.data))
         return out, st
 
+    def prove_batch(self, label: bytes, commitments, c, rho, mu, l, n):
+        """wnla.rs:125-190 for a batch: commitments [B, 64], c [B, nh, 32], rho / mu [B, 32], l [B, nl, 32], n [B, nn, 32]
+        -> (proof_r [B, rounds, 64], proof_x, proof_l [B, nl', 32], proof_n [B, nn', 32], status [B])."""
+        import ctypes as C
+        commitments = _u8(commitments, (-1, 64))
+        B = commitments.shape[0]
+        c = _u8(c, (B, self.nh, 32))
+        rho, mu = _u8(rho, (B, 32)), _u8(mu, (B, 32))
+        l, n = _u8(l, (B, -1, 32)), _u8(n, (B, -1, 32))
+        rounds, nl_f, nn_f = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _capi.lib().bppp_wnla_proof_shape(l.shape[1], n.shape[1], C.byref(rounds), C.byref(nl_f), C.byref(nn_f))
+        pr, px = np.zeros((B, rounds.value, 64), np.uint8), np.zeros((B, rounds.value, 64), np.uint8)
+        pl, pn = np.zeros((B, nl_f.value, 32), np.uint8), np.zeros((B, nn_f.value, 32), np.uint8)
+        st = np.zeros(B, np.int32)
+        _capi.check(_capi.lib().bppp_wnla_prove_batch(self._ctx, label, len(label), B, commitments.ctypes.data, c.ctypes.data, rho.ctypes.data,
+                                                      mu.ctypes.data, l.ctypes.data, l.shape[1], n.ctypes.data, n.shape[1], pr.ctypes.data,
+                                                      px.ctypes.data, pl.ctypes.data, pn.ctypes.data, st.ctypes.data))
+        return pr, px, pl, pn, st
+
     def msm_batch(self, base_index, scalars) -> Tuple[np.ndarray, np.ndarray]:
         """sum_j scalars[i][j] * B[base_index[j]] per row over the context's generators (0 = g, 1.. = g_vec, 1 + ng.. = h_vec):
         the crate's commit functions (include/bppp.h: bppp_msm_batch).  -> (points [B, 64], status [B])."""

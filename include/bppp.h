@@ -179,6 +179,19 @@ BPPP_API int bppp_circuit_verify_batch(bppp_ctx* ctx, const bppp_circuit* circui
                                        const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn,
                                        uint8_t* accept /* n */, int32_t* status /* n or NULL */);
 
+/* WeightNormLinearArgument::prove(commitment, t, l, n) (wnla.rs:125-190) for n instances sharing the context's generators
+ * (bppp_wnla_ctx_create); c (|c| = nh), rho, mu, the commitment and the witness vectors l (nl entries) and n (nn entries) are
+ * per instance, the transcript is Transcript::new(label).  The proof shape follows from nl and nn alone
+ * (bppp_wnla_proof_shape: the recursion stops when |l| + |n| < 6): proof_r / proof_x are n x rounds x 64 in the reference's
+ * vector order (last round first), proof_l n x nl_out x 32, proof_n n x nn_out x 32.  A non-canonical input scalar or an
+ * undecodable commitment flags the instance (status BPPP_ST_BAD_ENCODING, zeroed proof); rho = 0 at some level, where the
+ * reference unwrap()s, gives BPPP_ST_DEGENERATE. */
+BPPP_API void bppp_wnla_proof_shape(size_t nl, size_t nn, size_t* rounds, size_t* nl_out, size_t* nn_out);
+BPPP_API int bppp_wnla_prove_batch(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                                   const uint8_t* c, const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl,
+                                   const uint8_t* n_vec, size_t nn, uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l,
+                                   uint8_t* proof_n, int32_t* status /* n or NULL */);
+
 /* ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) for runtime dim_nd / dim_np (dim_np <= dim_nd + 1): e.g.
  * dim_nd = 256, dim_np = 16 -> |g_vec| = 256, |h_vec| + |h_vec_| = 512, 8 WNLA rounds (BASELINE configs[4]).  The context
  * comes from bppp_wnla_ctx_create(g, g_vec || g_vec_, NG, h_vec || h_vec_, NH) with NG >= dim_nd, NH >= dim_nd + 10.

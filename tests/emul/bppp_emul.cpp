@@ -10,6 +10,7 @@
 #include "../../bp_pp_amd/csrc/circuit_core.h"
 #include "../../bp_pp_amd/csrc/recip_core.h"
 #include "../../bp_pp_amd/csrc/rlc_core.h"
+#include "../../bp_pp_amd/csrc/wnla_prove_core.h"
 
 using namespace bppp;
 
@@ -533,6 +534,47 @@ int emul_circuit_verify(const uint8_t* table, int W, int NG, int NH, const size_
         wnla_verify_store(w, t, a);
     }
     for (size_t t = 0; t < n; t++) wnla_verify_accept(w, t);
+    return 0;
+}
+// generic WeightNormLinearArgument::prove (wnla_prove_core.h), every stage in thread order; returns the proof shape through
+// rounds_out / nl_out / nn_out (buffers must be large enough: rounds <= 16, final vectors <= 8 entries)
+int emul_wnla_prove(const uint8_t* table, int W, int ng, int nh, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                    const uint8_t* c, const uint8_t* rho, const uint8_t* mu, const uint8_t* l, int nl, const uint8_t* nv, int nn,
+                    uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l, uint8_t* proof_n, int32_t* status, int* rounds_out, int* nl_out,
+                    int* nn_out) {
+    size_t rounds, nl_f, nn_f;
+    wnla_proof_shape((size_t)nl, (size_t)nn, rounds, nl_f, nn_f);
+    *rounds_out = (int)rounds; *nl_out = (int)nl_f; *nn_out = (int)nn_f;
+    const size_t NB = 1 + ng + nh;
+    WnlaProveWs w;
+    memset(&w, 0, sizeof w);
+    w.N = n; w.ng = ng; w.nh = nh; w.nl = nl; w.nn = nn; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
+    w.commitments = commitments; w.c = c; w.rho = rho; w.mu = mu; w.l_in = l; w.n_in = nv;
+    w.proof_r = proof_r; w.proof_x = proof_x; w.proof_l = proof_l; w.proof_n = proof_n; w.status = status;
+    std::vector<u32> ts(52 * n), vl((size_t)(nl + 1) * 8 * n), vn((size_t)(nn + 1) * 8 * n), vc((size_t)nh * 8 * n), ch((size_t)nh * 8 * n),
+        cg((size_t)(ng + 1) * 8 * n), prm(24 * n), com(16 * n), msc(3 * NB * 8 * n), pb(90 * n);
+    w.tstate = ts.data(); w.vl = vl.data(); w.vn = vn.data(); w.vc = vc.data(); w.ch = ch.data(); w.cg = cg.data(); w.prm = prm.data();
+    w.com = com.data(); w.msc = msc.data(); w.pbuf = pb.data();
+    w.fb.table = (const apt_packed*)table; w.fb.W = W; w.fb.N = n;
+    t_new(w.base, label, (u32)label_len);
+    auto msm = [&](int set) {
+        for (size_t t = 0; t < n; t++) {
+            pt a;
+            FbRanges rg;
+            wnla_prove_msm_ranges(rg, w);
+            fb_sum_serial(a, w.fb, t, w.msc + (size_t)set * wp_set_words(w), rg);
+            ws_st_pt(w.pbuf + (size_t)set * 30 * n, n, t, a);
+        }
+    };
+    for (size_t t = 0; t < n; t++) wnla_prove_init(w, t);
+    for (int k = 0; k < (int)rounds; k++) {
+        for (size_t t = 0; t < n; t++) wnla_prove_round_scalars(w, t, k);
+        msm(0);
+        msm(1);
+        for (size_t t = 0; t < n; t++) wnla_prove_round_fold(w, t, k);
+        if (k + 1 < (int)rounds) msm(2);
+    }
+    for (size_t t = 0; t < n; t++) wnla_prove_finish(w, t);
     return 0;
 }
 }

@@ -82,3 +82,30 @@ def test_fixed_base_fast_accumulator_fallback_on_device():
         assert [bytes(o) for o in out] == exp
     finally:
         w.close()
+
+
+@pytest.mark.parametrize("ng,nh,B", [(4, 4, 5), (16, 32, 70), (3, 5, 4), (7, 9, 3), (256, 512, 2)])
+def test_wnla_prove_byte_identical_and_verifies(ng, nh, B):
+    """Generic WeightNormLinearArgument::prove on the GPU (bppp_wnla_prove_batch): proof bytes equal the reference-shaped
+    prover's, and the GPU verifier accepts them (tests.rs:139-171 round trip)."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import wnla_cases
+    from bp_pp_amd.wnla import WeightNormLinearArgument
+    case = wnla_cases.make(ng, nh, B)
+    w = WeightNormLinearArgument(case["g"], case["gv"], case["hv"], device=0, fb_window_bits=8 if nh > 64 else 16)
+    try:
+        pr, px, pl, pn, st = w.prove_batch(case["label"], case["commitments"], case["c"], case["rho"], case["mu"], case["l"], case["n"])
+        assert not st.any()
+        assert (pr == case["proof_r"]).all() and (px == case["proof_x"]).all()
+        assert (pl == case["proof_l"]).all() and (pn == case["proof_n"]).all()
+        acc, st = w.verify_batch(case["label"], case["commitments"], case["c"], case["rho"], case["mu"], pr, px, pl, pn)
+        assert acc.all() and not st.any()
+        # a non-canonical witness scalar flags its instance only
+        l_bad = case["l"].copy()
+        l_bad[0, 0] = 0xFF
+        pr2, px2, pl2, pn2, st2 = w.prove_batch(case["label"], case["commitments"], case["c"], case["rho"], case["mu"], l_bad, case["n"])
+        assert st2[0] == 1 and not st2[1:].any() and not pr2[0].any() and (pr2[1:] == pr[1:]).all() and (pl2[1:] == pl[1:]).all()
+    finally:
+        w.close()

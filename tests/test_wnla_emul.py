@@ -68,3 +68,32 @@ def test_length_quirks_match_reference():
         exp = [wnla_cases.oracle_verify(case, b, proof_l=pl, proof_n=pn) for b in range(2)]
         assert acc.tolist() == exp and not st.any()
     assert exp == [0, 0]
+
+
+@pytest.mark.parametrize("ng,nh,musq", [(4, 4, True), (16, 32, True), (3, 5, True), (4, 8, False), (1, 2, True), (7, 9, True), (8, 8, True)])
+def test_generic_prove_is_byte_identical_to_the_oracle(ng, nh, musq):
+    """wnla.rs:125-190 on the device code: the proof (r, x in the reference's vector order, final l and n) must equal the
+    reference-shaped prover's bytes for the same inputs -- power-of-two and odd sizes, mu != rho^2, and the sizes that stop
+    after one round or none."""
+    L = load()
+    B = 3
+    case = wnla_cases.make(ng, nh, B=B, mu_is_rho_sq=musq)
+    tab, W = _table(L, case)
+    d = {k: np.ascontiguousarray(case[k]) for k in ("commitments", "c", "rho", "mu", "l", "n")}
+    pr, px = np.zeros((B, 16, 64), np.uint8), np.zeros((B, 16, 64), np.uint8)
+    pl, pn = np.zeros((B, 8, 32), np.uint8), np.zeros((B, 8, 32), np.uint8)
+    st = np.zeros(B, np.int32)
+    import ctypes as C
+    r, a, b = C.c_int(), C.c_int(), C.c_int()
+    # the emulation writes with the TRUE strides (rounds, nl', nn'), so size the buffers after asking for the shape
+    L.emul_wnla_prove(tab.ctypes.data, W, ng, nh, case["label"], len(case["label"]), 0, None, None, None, None, None, d["l"].shape[1], None,
+                      d["n"].shape[1], None, None, None, None, None, C.byref(r), C.byref(a), C.byref(b))
+    assert (r.value, a.value, b.value) == (case["rounds"], case["nl"], case["nn"])
+    pr, px = np.zeros((B, r.value, 64), np.uint8), np.zeros((B, r.value, 64), np.uint8)
+    pl, pn = np.zeros((B, a.value, 32), np.uint8), np.zeros((B, b.value, 32), np.uint8)
+    L.emul_wnla_prove(tab.ctypes.data, W, ng, nh, case["label"], len(case["label"]), B, d["commitments"].ctypes.data, d["c"].ctypes.data,
+                      d["rho"].ctypes.data, d["mu"].ctypes.data, d["l"].ctypes.data, d["l"].shape[1], d["n"].ctypes.data, d["n"].shape[1],
+                      pr.ctypes.data, px.ctypes.data, pl.ctypes.data, pn.ctypes.data, st.ctypes.data, C.byref(r), C.byref(a), C.byref(b))
+    assert not st.any()
+    assert (pr == case["proof_r"]).all() and (px == case["proof_x"]).all()
+    assert (pl == case["proof_l"]).all() and (pn == case["proof_n"]).all()
