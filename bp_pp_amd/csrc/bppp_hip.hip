@@ -18,6 +18,7 @@
 #include "circuit_core.h"
 #include "recip_core.h"
 #include "rlc_core.h"
+#include "circuit_prove_core.h"
 #include "wnla_prove_core.h"
 
 using namespace bppp;
@@ -321,6 +322,35 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_fold(WnlaProveWs w,
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_finish(WnlaProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) wnla_prove_finish(w, t);
+}
+
+// ---- generic circuit prover kernels (circuit_prove_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_a(CircuitProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) circuit_prove_stage_a(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_b(CircuitProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) circuit_prove_stage_b(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_c(CircuitProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) circuit_prove_stage_c(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_d(CircuitProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) circuit_prove_stage_d(w, t);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_cprove_msm(CircuitProveWs w, int set, int with_g) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt part;
+    FbRanges rg;
+    cp_ranges(rg, w, with_g != 0);
+    fb_group_sum(part, w.fb, t, lane, w.msc + (size_t)set * cp_set_words(w), rg);
+    if (lane == 0) ws_st_pt(w.pbuf + (size_t)set * 30 * w.N, w.N, t, part);
 }
 
 // ---- generic fixed-base linear combination over the context's generators (the crate's commit functions)
@@ -1224,6 +1254,7 @@ int bppp_reciprocal_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label
 // ---------------------------------------------------------------- generic ArithmeticCircuit (circuit.rs:95-256)
 struct bppp_circuit {
     CircuitDev cd;
+    const int* d_part = nullptr;     // [3 nv + nm]: LO | LL | LR | NO (the prover places w_o with it)
     uint8_t* d_blob = nullptr;
     size_t blob_bytes = 0;
 };
@@ -1248,6 +1279,10 @@ int bppp_circuit_create(bppp_ctx* c, bppp_circuit** out, const size_t dims[6], i
     const size_t o_cpl = take(cpl.size() * 4), o_rl = take(rl.size() * 4), o_vl = take(vl.size() * 4), o_cpm = take(cpm.size() * 4),
                  o_rm = take(rm.size() * 4), o_vm = take(vm.size() * 4), o_cm = take(colmap.size() * 4), o_al = take(al.size() * 4),
                  o_am = take(am.size() * 4);
+    std::vector<int> parts(3 * nv + nm);
+    for (size_t j = 0; j < nv; j++) { parts[j] = part_lo[j]; parts[nv + j] = part_ll[j]; parts[2 * nv + j] = part_lr[j]; }
+    for (size_t j = 0; j < nm; j++) parts[3 * nv + j] = part_no[j];
+    const size_t o_part = take(parts.size() * 4);
     hipError_t e = hipMalloc(&q->d_blob, off);
     if (e != hipSuccess) { delete q; g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
     q->blob_bytes = off;
@@ -1256,7 +1291,7 @@ int bppp_circuit_create(bppp_ctx* c, bppp_circuit** out, const size_t dims[6], i
         up(o_vl, vl.data(), vl.size() * 4) != hipSuccess || up(o_cpm, cpm.data(), cpm.size() * 4) != hipSuccess ||
         up(o_rm, rm.data(), rm.size() * 4) != hipSuccess || up(o_vm, vm.data(), vm.size() * 4) != hipSuccess ||
         up(o_cm, colmap.data(), colmap.size() * 4) != hipSuccess || up(o_al, al.data(), al.size() * 4) != hipSuccess ||
-        up(o_am, am.data(), am.size() * 4) != hipSuccess) {
+        up(o_am, am.data(), am.size() * 4) != hipSuccess || up(o_part, parts.data(), parts.size() * 4) != hipSuccess) {
         (void)hipFree(q->d_blob);
         delete q;
         g_last_error = "circuit upload failed";
@@ -1267,6 +1302,7 @@ int bppp_circuit_create(bppp_ctx* c, bppp_circuit** out, const size_t dims[6], i
     cd.colptr_l = (const int*)(q->d_blob + o_cpl); cd.rows_l = (const int*)(q->d_blob + o_rl); cd.vals_l = (const u32*)(q->d_blob + o_vl);
     cd.colptr_m = (const int*)(q->d_blob + o_cpm); cd.rows_m = (const int*)(q->d_blob + o_rm); cd.vals_m = (const u32*)(q->d_blob + o_vm);
     cd.colmap = (const int*)(q->d_blob + o_cm); cd.a_l = (const u32*)(q->d_blob + o_al); cd.a_m = (const u32*)(q->d_blob + o_am);
+    q->d_part = (const int*)(q->d_blob + o_part);
     *out = q;
     return BPPP_OK;
 }
@@ -1451,6 +1487,115 @@ int bppp_wnla_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, s
     if (nn_f) HIP_TRY(hipMemcpyAsync(proof_n, d + o_pn, n * nn_f * 32, hipMemcpyDeviceToHost, s));
     if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return BPPP_OK;
+}
+
+// ArithmeticCircuit::prove (circuit.rs:260-556) for n instances of a shared circuit.
+int bppp_circuit_prove_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n, const uint8_t* v_commitments,
+                             const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l, const uint8_t* w_r, const uint8_t* w_o,
+                             const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
+    if (!c || !q || (!label && label_len) || !v_commitments || !v || !s_v || !w_l || !w_r || !rnd || !proofs) return BPPP_ERR_INVALID_ARG;
+    const CircuitDev& cd = q->cd;
+    if ((cd.no && !w_o) || cd.nm > c->ng || cd.nv + 9 > c->nh) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t NB = (size_t)c->nbases, NG = (size_t)c->ng, NH = (size_t)c->nh, k = (size_t)cd.k, nm = (size_t)cd.nm, nv = (size_t)cd.nv,
+                 no = (size_t)cd.no, nl = (size_t)cd.nl, n_rnd = 18 + nv + nm;
+    size_t rounds, nl_f, nn_f;
+    wnla_proof_shape(NH, NG, rounds, nl_f, nn_f);
+    const size_t proof_bytes = 64 * (4 + 2 * rounds) + 32 * (nl_f + nn_f);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes + 16); return o; };
+    const size_t o_vp = take(n * k * 64), o_v = take(n * k * nv * 32), o_sv = take(n * k * 32), o_wl = take(n * nm * 32), o_wr = take(n * nm * 32),
+                 o_wo = take(n * no * 32), o_rnd = take(n * n_rnd * 32), o_head = take(n * 256), o_st = take(n * 4), o_ts = take(52 * n * 4),
+                 o_r9 = take(4 * 9 * 8 * n * 4), o_lv = take(6 * nv * 8 * n * 4), o_nv = take(4 * nm * 8 * n * 4), o_lam = take(nl * 8 * n * 4),
+                 o_muv = take(nm * 8 * n * 4), o_coef = take((3 * nm + 3 * nv) * 8 * n * 4), o_misc = take(8 * 8 * n * 4),
+                 o_msc = take(3 * NB * 8 * n * 4), o_pb = take(3 * 30 * n * 4), o_wc = take(n * 64), o_wcv = take(n * NH * 32),
+                 o_rho = take(n * 32), o_mu = take(n * 32), o_wlv = take(n * NH * 32), o_wnv = take(n * NG * 32),
+                 // WNLA prover state
+                 o_pr = take(n * rounds * 64), o_px = take(n * rounds * 64), o_pl = take(n * nl_f * 32), o_pn = take(n * nn_f * 32),
+                 o_vl = take((NH + 1) * 8 * n * 4), o_vn = take((NG + 1) * 8 * n * 4), o_vc = take(NH * 8 * n * 4), o_ch = take(NH * 8 * n * 4),
+                 o_cg = take((NG + 1) * 8 * n * 4), o_prm = take(3 * 8 * n * 4), o_cm = take(16 * n * 4), o_proofs = take(n * proof_bytes);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(d + o_vp, v_commitments, n * k * 64, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_v, v, n * k * nv * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_sv, s_v, n * k * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_wl, w_l, n * nm * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_wr, w_r, n * nm * 32, hipMemcpyHostToDevice, s));
+    if (no) HIP_TRY(hipMemcpyAsync(d + o_wo, w_o, n * no * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_rnd, rnd, n * n_rnd * 32, hipMemcpyHostToDevice, s));
+    CircuitProveWs p;
+    std::memset(&p, 0, sizeof p);
+    p.N = n; p.cd = cd; p.NG = c->ng; p.NH = c->nh; p.n_rnd = (int)n_rnd; p.part = q->d_part;
+    p.v_pts = d + o_vp; p.v = d + o_v; p.s_v = d + o_sv; p.w_l = d + o_wl; p.w_r = d + o_wr; p.w_o = d + o_wo; p.rnd = d + o_rnd;
+    p.proof_head = d + o_head; p.status = (int32_t*)(d + o_st); p.tstate = (u32*)(d + o_ts);
+    u32* r9 = (u32*)(d + o_r9);
+    p.ro = r9; p.rl = r9 + 72 * n; p.rr = r9 + 144 * n; p.rs = r9 + 216 * n;
+    u32* lv = (u32*)(d + o_lv);
+    p.lo = lv; p.ll = lv + nv * 8 * n; p.lr = lv + 2 * nv * 8 * n; p.ls = lv + 3 * nv * 8 * n; p.v1 = lv + 4 * nv * 8 * n; p.cl0 = lv + 5 * nv * 8 * n;
+    u32* nvv = (u32*)(d + o_nv);
+    p.no = nvv; p.nl = nvv + nm * 8 * n; p.nr = nvv + 2 * nm * 8 * n; p.ns = nvv + 3 * nm * 8 * n;
+    p.lamv = (u32*)(d + o_lam); p.muv = (u32*)(d + o_muv); p.coef = (u32*)(d + o_coef); p.misc = (u32*)(d + o_misc);
+    p.msc = (u32*)(d + o_msc); p.pbuf = (u32*)(d + o_pb);
+    p.wn_commit = d + o_wc; p.wn_c = d + o_wcv; p.wn_rho = d + o_rho; p.wn_mu = d + o_mu; p.wn_l = d + o_wlv; p.wn_n = d + o_wnv;
+    p.fb.table = c->d_table; p.fb.W = c->fb_w; p.fb.N = n;
+    t_new(p.base, label, (u32)label_len);
+    WnlaProveWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.ng = c->ng; w.nh = c->nh; w.nl = (int)NH; w.nn = (int)NG; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
+    w.transcript_preloaded = 1;
+    w.commitments = p.wn_commit; w.c = p.wn_c; w.rho = p.wn_rho; w.mu = p.wn_mu; w.l_in = p.wn_l; w.n_in = p.wn_n;
+    w.proof_r = d + o_pr; w.proof_x = d + o_px; w.proof_l = d + o_pl; w.proof_n = d + o_pn;
+    w.status = p.status; w.tstate = p.tstate; w.vl = (u32*)(d + o_vl); w.vn = (u32*)(d + o_vn); w.vc = (u32*)(d + o_vc);
+    w.ch = (u32*)(d + o_ch); w.cg = (u32*)(d + o_cg); w.prm = (u32*)(d + o_prm); w.com = (u32*)(d + o_cm); w.msc = p.msc; w.pbuf = p.pbuf;
+    w.fb = p.fb;
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    HIP_TRY(hipMemsetAsync(p.msc, 0, 3 * NB * 8 * n * 4, s));     // the sets are written sparsely (slot = base index)
+    k_cprove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    for (int set = 0; set < 3; set++) k_cprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(p, set, 0);
+    k_cprove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    k_cprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(p, 0, 0);
+    k_cprove_stage_c<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    k_cprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(p, 0, 1);
+    k_cprove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    k_wprove_init<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    for (int kk = 0; kk < (int)rounds; kk++) {
+        k_wprove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1);
+        k_wprove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
+        if (kk + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2);
+    }
+    k_wprove_finish<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    HIP_TRY(hipGetLastError());
+    // assemble the proofs on the host side of the copy: head | r | x | l | n per instance
+    std::vector<uint8_t> head(n * 256), pr(n * rounds * 64), px(n * rounds * 64), pl(n * nl_f * 32), pn(n * nn_f * 32);
+    std::vector<int32_t> st(n);
+    HIP_TRY(hipMemcpyAsync(head.data(), d + o_head, head.size(), hipMemcpyDeviceToHost, s));
+    if (rounds) {
+        HIP_TRY(hipMemcpyAsync(pr.data(), d + o_pr, pr.size(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(px.data(), d + o_px, px.size(), hipMemcpyDeviceToHost, s));
+    }
+    if (nl_f) HIP_TRY(hipMemcpyAsync(pl.data(), d + o_pl, pl.size(), hipMemcpyDeviceToHost, s));
+    if (nn_f) HIP_TRY(hipMemcpyAsync(pn.data(), d + o_pn, pn.size(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(st.data(), d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; i++) {
+        uint8_t* o = proofs + i * proof_bytes;
+        if (st[i] != 0) { std::memset(o, 0, proof_bytes); continue; }
+        std::memcpy(o, &head[i * 256], 256);
+        o += 256;
+        std::memcpy(o, &pr[i * rounds * 64], rounds * 64); o += rounds * 64;
+        std::memcpy(o, &px[i * rounds * 64], rounds * 64); o += rounds * 64;
+        std::memcpy(o, &pl[i * nl_f * 32], nl_f * 32); o += nl_f * 32;
+        std::memcpy(o, &pn[i * nn_f * 32], nn_f * 32);
+    }
+    if (status) std::memcpy(status, st.data(), n * 4);
+    (void)o_proofs;
     return BPPP_OK;
 }
 

@@ -121,75 +121,22 @@ HD void cd_ld_sc(sc& r, const u32* base, int idx) {
     for (int i = 0; i < 8; i++) r.v[i] = base[(size_t)idx * 8 + i];
 }
 
-HD void circuit_phase1(const CircuitWs& w, size_t t) {
-    const size_t N = w.N;
-    const CircuitDev& cd = w.cd;
+// lambda_vec, mu_vec and the six coefficient vectors c_nL, c_nR, c_nO, c_lL, c_lR, c_lO (collect_lambda, collect_c:
+// circuit.rs:584-614) for one instance, into limb-major arrays of stride N.  Shared by the verifier and the prover.
+HD void circuit_collect(const CircuitDev& cd, u32* lamv_, u32* muv_, u32* coef_, size_t N, size_t t, const sc& lambda, const sc& mu,
+                        const sc& mu_inv, sc& lam_nv, sc& mu_nv) {
     const int nm = cd.nm, nv = cd.nv, nl = cd.nl, k = cd.k;
-    int32_t status = ST_OK;
-    const uint8_t* pp = w.proofs + w.proof_bytes * t;
-    const uint8_t* pv = w.commitments + (size_t)64 * k * t;
-    apt CL, CR, CO, CS;
-    bool ok = apt_from_xy64(CL, pp) & apt_from_xy64(CR, pp + 64) & apt_from_xy64(CO, pp + 128) & apt_from_xy64(CS, pp + 192);
-    strobe tr = w.base;
-    // a malformed instance runs on harmless values (identity points); its status forces accept = 0
-#pragma nounroll
-    for (int i = 0; i < k; i++) { apt V; ok &= apt_from_xy64(V, pv + 64 * i); }
-    apt zero_pt;
-    fe_set_u32(zero_pt.x, 0); fe_set_u32(zero_pt.y, 0);
-    if (!ok) { status |= ST_BAD_ENCODING; CL = zero_pt; CR = zero_pt; CO = zero_pt; CS = zero_pt; }
-    app_point(tr, "commitment_cl", CL);                                   // circuit.rs:155-159
-    app_point(tr, "commitment_cr", CR);
-    app_point(tr, "commitment_co", CO);
-#pragma nounroll
-    for (int i = 0; i < k; i++) {
-        apt V;
-        (void)apt_from_xy64(V, pv + 64 * i);
-        if (!ok) V = zero_pt;
-        app_point(tr, "commitment_v", V);
-        ws_st_apt(w.pts, N, t, 4 + i, V);
-    }
-    sc rho, lambda, beta, delta, tau;
-    bool cok = t_get_challenge(tr, "circuit_rho", rho);                   // circuit.rs:161-164
-    cok &= t_get_challenge(tr, "circuit_lambda", lambda);
-    cok &= t_get_challenge(tr, "circuit_beta", beta);
-    cok &= t_get_challenge(tr, "circuit_delta", delta);
-    app_point(tr, "commitment_cs", CS);                                   // circuit.rs:189
-    cok &= t_get_challenge(tr, "circuit_tau", tau);                       // circuit.rs:191
-    if (!cok) {
-        status |= ST_DEGENERATE;
-        sc_set_u32(rho, 1); sc_set_u32(lambda, 1); sc_set_u32(beta, 1); sc_set_u32(delta, 1); sc_set_u32(tau, 1);
-    }
-    ws_st_strobe(w.tstate, N, t, tr);
-    ws_st_apt(w.pts, N, t, 0, CS); ws_st_apt(w.pts, N, t, 1, CO); ws_st_apt(w.pts, N, t, 2, CL); ws_st_apt(w.pts, N, t, 3, CR);
-    sc mu, one, zero, t1, t2;
+    struct { u32 *lamv, *muv, *coef; } w = {lamv_, muv_, coef_};
+    sc one, zero, t1, t2;
     sc_set_u32(one, 1);
     sc_set_u32(zero, 0);
-    sc_mul(mu, rho, rho);                                                 // circuit.rs:166
-    sc_to_be(w.wn_rho + 32 * t, rho);
-    sc_to_be(w.wn_mu + 32 * t, mu);
-    // mu^-1, tau^-1, delta^-1 from one inversion (the reference unwrap()s these: zero -> DEGENERATE)
-    const bool zero_inv = sc_is_zero(mu) | sc_is_zero(tau) | sc_is_zero(delta);
-    if (zero_inv) status |= ST_DEGENERATE;
-    sc m_ = sc_is_zero(mu) ? one : mu, t_ = sc_is_zero(tau) ? one : tau, d_ = sc_is_zero(delta) ? one : delta;
-    sc mt, mtd, inv, mu_inv, tau_inv, delta_inv;
-    sc_mul(mt, m_, t_);
-    sc_mul(mtd, mt, d_);
-    sc_inv(inv, mtd);
-    sc_mul(delta_inv, inv, mt);
-    sc_mul(inv, inv, d_);              // (mu tau)^-1
-    sc_mul(mu_inv, inv, t_);
-    sc_mul(tau_inv, inv, m_);
-    sc tau2, tau3, two_tau3, t3di;
-    sc_mul(tau2, tau, tau);
-    sc_mul(tau3, tau2, tau);
-    sc_add(two_tau3, tau3, tau3);
-    sc_mul(t3di, tau3, delta_inv);
     // lambda_vec = e(lambda, nl) [- tensor terms when f_l && f_m]   (collect_lambda, circuit.rs:584-599)
     sc lp = one;
 #pragma nounroll
     for (int i = 0; i < nl; i++) { ws_st8(w.lamv, N, t, i, lp.v); sc_mul(lp, lp, lambda); }
     // lambda^nv, mu^nv
-    sc lam_nv = one, mu_nv = one;
+    lam_nv = one;
+    mu_nv = one;
 #pragma nounroll
     for (int i = 0; i < nv; i++) { sc_mul(lam_nv, lam_nv, lambda); sc_mul(mu_nv, mu_nv, mu); }
     if (cd.f_l && cd.f_m) {
@@ -254,6 +201,74 @@ HD void circuit_phase1(const CircuitWs& w, size_t t) {
         }
         ws_st8(w.coef, N, t, o, a.v);
     }
+}
+
+HD void circuit_phase1(const CircuitWs& w, size_t t) {
+    const size_t N = w.N;
+    const CircuitDev& cd = w.cd;
+    const int nm = cd.nm, nv = cd.nv, nl = cd.nl, k = cd.k;
+    int32_t status = ST_OK;
+    const uint8_t* pp = w.proofs + w.proof_bytes * t;
+    const uint8_t* pv = w.commitments + (size_t)64 * k * t;
+    apt CL, CR, CO, CS;
+    bool ok = apt_from_xy64(CL, pp) & apt_from_xy64(CR, pp + 64) & apt_from_xy64(CO, pp + 128) & apt_from_xy64(CS, pp + 192);
+    strobe tr = w.base;
+    // a malformed instance runs on harmless values (identity points); its status forces accept = 0
+#pragma nounroll
+    for (int i = 0; i < k; i++) { apt V; ok &= apt_from_xy64(V, pv + 64 * i); }
+    apt zero_pt;
+    fe_set_u32(zero_pt.x, 0); fe_set_u32(zero_pt.y, 0);
+    if (!ok) { status |= ST_BAD_ENCODING; CL = zero_pt; CR = zero_pt; CO = zero_pt; CS = zero_pt; }
+    app_point(tr, "commitment_cl", CL);                                   // circuit.rs:155-159
+    app_point(tr, "commitment_cr", CR);
+    app_point(tr, "commitment_co", CO);
+#pragma nounroll
+    for (int i = 0; i < k; i++) {
+        apt V;
+        (void)apt_from_xy64(V, pv + 64 * i);
+        if (!ok) V = zero_pt;
+        app_point(tr, "commitment_v", V);
+        ws_st_apt(w.pts, N, t, 4 + i, V);
+    }
+    sc rho, lambda, beta, delta, tau;
+    bool cok = t_get_challenge(tr, "circuit_rho", rho);                   // circuit.rs:161-164
+    cok &= t_get_challenge(tr, "circuit_lambda", lambda);
+    cok &= t_get_challenge(tr, "circuit_beta", beta);
+    cok &= t_get_challenge(tr, "circuit_delta", delta);
+    app_point(tr, "commitment_cs", CS);                                   // circuit.rs:189
+    cok &= t_get_challenge(tr, "circuit_tau", tau);                       // circuit.rs:191
+    if (!cok) {
+        status |= ST_DEGENERATE;
+        sc_set_u32(rho, 1); sc_set_u32(lambda, 1); sc_set_u32(beta, 1); sc_set_u32(delta, 1); sc_set_u32(tau, 1);
+    }
+    ws_st_strobe(w.tstate, N, t, tr);
+    ws_st_apt(w.pts, N, t, 0, CS); ws_st_apt(w.pts, N, t, 1, CO); ws_st_apt(w.pts, N, t, 2, CL); ws_st_apt(w.pts, N, t, 3, CR);
+    sc mu, one, zero, t1, t2;
+    sc_set_u32(one, 1);
+    sc_set_u32(zero, 0);
+    sc_mul(mu, rho, rho);                                                 // circuit.rs:166
+    sc_to_be(w.wn_rho + 32 * t, rho);
+    sc_to_be(w.wn_mu + 32 * t, mu);
+    // mu^-1, tau^-1, delta^-1 from one inversion (the reference unwrap()s these: zero -> DEGENERATE)
+    const bool zero_inv = sc_is_zero(mu) | sc_is_zero(tau) | sc_is_zero(delta);
+    if (zero_inv) status |= ST_DEGENERATE;
+    sc m_ = sc_is_zero(mu) ? one : mu, t_ = sc_is_zero(tau) ? one : tau, d_ = sc_is_zero(delta) ? one : delta;
+    sc mt, mtd, inv, mu_inv, tau_inv, delta_inv;
+    sc_mul(mt, m_, t_);
+    sc_mul(mtd, mt, d_);
+    sc_inv(inv, mtd);
+    sc_mul(delta_inv, inv, mt);
+    sc_mul(inv, inv, d_);              // (mu tau)^-1
+    sc_mul(mu_inv, inv, t_);
+    sc_mul(tau_inv, inv, m_);
+    sc tau2, tau3, two_tau3, t3di;
+    sc_mul(tau2, tau, tau);
+    sc_mul(tau3, tau2, tau);
+    sc_add(two_tau3, tau3, tau3);
+    sc_mul(t3di, tau3, delta_inv);
+    sc lam_nv, mu_nv;
+    circuit_collect(cd, w.lamv, w.muv, w.coef, N, t, lambda, mu, mu_inv, lam_nv, mu_nv);
+    sc mp;
     // pn_tau, ps_tau                                                     (circuit.rs:196-206)
     sc ps = zero;
     mp = mu;
@@ -311,7 +326,7 @@ HD void circuit_phase1(const CircuitWs& w, size_t t) {
     sc bt = beta;
 #pragma nounroll
     for (int i = 2; i < 9; i++) { sc_mul(bt, bt, tau); sc_to_be(cw + (size_t)i * 32, bt); }
-    lp = lambda;                 // lambda^(j+1)
+    sc lp = lambda;              // lambda^(j+1)
     sc mq;
     sc_mul(mq, mu, mu);          // mu^(j+2)
 #pragma nounroll

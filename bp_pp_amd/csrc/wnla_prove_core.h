@@ -20,6 +20,7 @@ struct WnlaProveWs {
     const uint8_t *commitments, *c, *rho, *mu, *l_in, *n_in;     // C-ABI layouts (device memory): n x 64, n x nh x 32, n x 32, ...
     uint8_t *proof_r, *proof_x, *proof_l, *proof_n;              // outputs: n x rounds x 64 (x2), n x nl_f x 32, n x nn_f x 32
     int nl_f, nn_f;
+    int transcript_preloaded;                                    // 1: tstate / status already hold each instance's transcript and flags (circuit prover)
     int32_t* status;
     u32* tstate;      // [52][N]
     u32* vl;          // [nl * 8][N]   current l (prefix of length ceil(nl / 2^k))
@@ -76,8 +77,8 @@ HD void wnla_prove_init(const WnlaProveWs& w, size_t t) {
     if (!ok) { status |= ST_BAD_ENCODING; rho = one; mu = one; }
     ws_st8(w.prm, N, t, 0, rho.v);
     ws_st8(w.prm, N, t, 1, mu.v);
-    ws_st_strobe(w.tstate, N, t, w.base);
-    w.status[t] = status;
+    if (!w.transcript_preloaded) ws_st_strobe(w.tstate, N, t, w.base);
+    w.status[t] = w.transcript_preloaded ? (w.status[t] | status) : status;
 }
 // round k (0-based): vx, vr and the scalar sets of X and R (wnla.rs:136-157)
 HD void wnla_prove_round_scalars(const WnlaProveWs& w, size_t t, int k) {

@@ -167,6 +167,26 @@ class ArithmeticCircuit:
             self._circuit = None
         self._w.close()
 
+    def prove_batch(self, label: bytes, v_commitments, v, s_v, w_l, w_r, w_o, rnd):
+        """circuit.rs:260-556 for a batch: v_commitments [B, k, 64], v [B, k, dim_nv, 32], s_v [B, k, 32], w_l / w_r [B, dim_nm, 32],
+        w_o [B, dim_no, 32], rnd [B, 18 + dim_nv + dim_nm, 32] (the prover's random scalars in the reference's draw order)
+        -> (proofs [B, proof_bytes], status [B], (rounds, nl, nn))."""
+        import ctypes as C
+        v_commitments = _u8(v_commitments, (-1, self.k, 64))
+        B = v_commitments.shape[0]
+        v, s_v = _u8(v, (B, self.k, self.dim_nv, 32)), _u8(s_v, (B, self.k, 32))
+        w_l, w_r = _u8(w_l, (B, self.dim_nm, 32)), _u8(w_r, (B, self.dim_nm, 32))
+        w_o = _u8(w_o, (B, self.dim_no, 32))
+        rnd = _u8(rnd, (B, 18 + self.dim_nv + self.dim_nm, 32))
+        rounds, nl, nn = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _capi.lib().bppp_wnla_proof_shape(self._w.nh, self._w.ng, C.byref(rounds), C.byref(nl), C.byref(nn))
+        proofs = np.zeros((B, 64 * (4 + 2 * rounds.value) + 32 * (nl.value + nn.value)), np.uint8)
+        st = np.zeros(B, np.int32)
+        _capi.check(_capi.lib().bppp_circuit_prove_batch(self._w._ctx, self._circuit, label, len(label), B, v_commitments.ctypes.data,
+                                                         v.ctypes.data, s_v.ctypes.data, w_l.ctypes.data, w_r.ctypes.data, w_o.ctypes.data,
+                                                         rnd.ctypes.data, proofs.ctypes.data, st.ctypes.data))
+        return proofs, st, (rounds.value, nl.value, nn.value)
+
     def commit_batch(self, v, s):
         """circuit.rs:146-151 for a batch: v [B, dim_nv, 32], s [B, 32] -> (points, status)."""
         v, s = _u8(v, (-1, self.dim_nv, 32)), _u8(s, (-1, 32))

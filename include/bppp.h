@@ -179,6 +179,18 @@ BPPP_API int bppp_circuit_verify_batch(bppp_ctx* ctx, const bppp_circuit* circui
                                        const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn,
                                        uint8_t* accept /* n */, int32_t* status /* n or NULL */);
 
+/* ArithmeticCircuit::prove(v, witness, t, rng) (circuit.rs:260-556) for n instances of a shared circuit (bppp_circuit_create).
+ * Per instance: v_commitments k x 64 (the reference's `v` argument: circuit.commit of each witness.v[i], e.g. from
+ * bppp_msm_batch), witness v (k x dim_nv scalars), s_v (k), w_l, w_r (dim_nm), w_o (dim_no), and the prover's random scalars
+ * rnd in the reference's draw order -- 18 + dim_nv + dim_nm of them: r_o (7), r_l (6), r_r (5) (circuit.rs:264-298), then
+ * l_s (dim_nv), n_s (dim_nm) (circuit.rs:371-372) -- so that the proof equals the CPU prover's for the same RNG stream.
+ * proofs: n x (64 (4 + 2 rounds) + 32 (nl + nn)) with (rounds, nl, nn) = bppp_wnla_proof_shape(NH, NG), laid out as the
+ * verifier takes them.  Non-canonical inputs flag the instance (status, zeroed proof). */
+BPPP_API int bppp_circuit_prove_batch(bppp_ctx* ctx, const bppp_circuit* circuit, const uint8_t* label, size_t label_len, size_t n,
+                                      const uint8_t* v_commitments, const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l,
+                                      const uint8_t* w_r, const uint8_t* w_o, const uint8_t* rnd, uint8_t* proofs,
+                                      int32_t* status /* n or NULL */);
+
 /* WeightNormLinearArgument::prove(commitment, t, l, n) (wnla.rs:125-190) for n instances sharing the context's generators
  * (bppp_wnla_ctx_create); c (|c| = nh), rho, mu, the commitment and the witness vectors l (nl entries) and n (nn entries) are
  * per instance, the transcript is Transcript::new(label).  The proof shape follows from nl and nn alone

@@ -104,9 +104,13 @@ def make(name: str, B: int, label: bytes = b"circuit test"):
     case["dims"] = dims
     coms, proofs, shape = [], [], None
     n_rnd = 64
+    used = 18 + nv + nm                                  # draws the prover consumes: r_o 7, r_l 6, r_r 5, l_s nv, n_s nm
+    sv_all, rnd_all = [], []
     for b in range(B):
         s_v = [_sc(b"sv", b, j) for j in range(k)]
         rnd = _b(_sc(b"rnd", b, i) for i in range(n_rnd))
+        sv_all.append(_b(s_v))
+        rnd_all.append(rnd[:32 * used])
         com = C.create_string_buffer(64 * k)
         pbuf = C.create_string_buffer(64 * (4 + 2 * 16) + 32 * 16)
         rounds, pl, pn = sz(0), sz(0), sz(0)
@@ -123,6 +127,10 @@ def make(name: str, B: int, label: bytes = b"circuit test"):
         nbytes = 64 * (4 + 2 * sh[0]) + 32 * (sh[1] + sh[2])
         coms.append(com.raw)
         proofs.append(pbuf.raw[:nbytes])
+    u8 = lambda blobs, *shape_: np.frombuffer(b"".join(blobs), dtype=np.uint8).reshape(B, *shape_).copy()
+    case.update(s_v=u8(sv_all, k, 32), rnd=u8(rnd_all, used, 32),
+                v_bytes=u8([_b(x for row in st["v"] for x in row)] * B, k, nv, 32), wl_bytes=u8([_b(st["w_l"])] * B, nm, 32),
+                wr_bytes=u8([_b(st["w_r"])] * B, nm, 32), wo_bytes=u8([_b(st["w_o"])] * B, no, 32))
     case.update(rounds=shape[0], pl=shape[1], pn=shape[2], proof_bytes=len(proofs[0]),
                 commitments=np.frombuffer(b"".join(coms), dtype=np.uint8).reshape(B, k, 64).copy(),
                 proofs=np.frombuffer(b"".join(proofs), dtype=np.uint8).reshape(B, -1).copy())

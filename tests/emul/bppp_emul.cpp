@@ -11,6 +11,7 @@
 #include "../../bp_pp_amd/csrc/recip_core.h"
 #include "../../bp_pp_amd/csrc/rlc_core.h"
 #include "../../bp_pp_amd/csrc/wnla_prove_core.h"
+#include "../../bp_pp_amd/csrc/circuit_prove_core.h"
 
 using namespace bppp;
 
@@ -576,5 +577,99 @@ int emul_wnla_prove(const uint8_t* table, int W, int ng, int nh, const uint8_t* 
     }
     for (size_t t = 0; t < n; t++) wnla_prove_finish(w, t);
     return 0;
+}
+// generic ArithmeticCircuit::prove (circuit_prove_core.h + wnla_prove_core.h), every stage in thread order
+int emul_circuit_prove(const uint8_t* table, int W, int NG, int NH, const size_t dims[6], int f_l, int f_m, const uint8_t* W_m,
+                       const uint8_t* W_l, const uint8_t* a_m, const uint8_t* a_l, const int32_t* part_lo, const int32_t* part_ll,
+                       const int32_t* part_lr, const int32_t* part_no, const uint8_t* label, size_t label_len, size_t n,
+                       const uint8_t* v_pts, const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l, const uint8_t* w_r, const uint8_t* w_o,
+                       const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
+    CircuitHostData hd;
+    if (!circuit_host_build(hd, dims, W_m, W_l, a_m, a_l, part_lo, part_ll, part_lr, part_no)) return -2;
+    const size_t nm = dims[0], no = dims[1], k = dims[2], nl = dims[3], nv = dims[4], NB = 1 + NG + NH, n_rnd = 18 + nv + nm;
+    (void)no; (void)k;
+    size_t rounds, nl_f, nn_f;
+    wnla_proof_shape((size_t)NH, (size_t)NG, rounds, nl_f, nn_f);
+    const size_t proof_bytes = 64 * (4 + 2 * rounds) + 32 * (nl_f + nn_f);
+    CircuitProveWs p;
+    memset(&p, 0, sizeof p);
+    CircuitDev& cd = p.cd;
+    cd.nm = (int)nm; cd.no = (int)dims[1]; cd.k = (int)dims[2]; cd.nl = (int)nl; cd.nv = (int)nv; cd.nw = (int)dims[5]; cd.f_l = f_l; cd.f_m = f_m;
+    hd.rl.push_back(0); hd.rm.push_back(0); hd.vl.resize(hd.vl.size() + 8); hd.vm.resize(hd.vm.size() + 8);
+    cd.colptr_l = hd.cpl.data(); cd.rows_l = hd.rl.data(); cd.vals_l = hd.vl.data();
+    cd.colptr_m = hd.cpm.data(); cd.rows_m = hd.rm.data(); cd.vals_m = hd.vm.data();
+    cd.colmap = hd.colmap.data(); cd.a_l = hd.al.data(); cd.a_m = hd.am.data();
+    std::vector<int> parts(3 * nv + nm);
+    for (size_t j = 0; j < nv; j++) { parts[j] = part_lo[j]; parts[nv + j] = part_ll[j]; parts[2 * nv + j] = part_lr[j]; }
+    for (size_t j = 0; j < nm; j++) parts[3 * nv + j] = part_no[j];
+    p.N = n; p.NG = NG; p.NH = NH; p.n_rnd = (int)n_rnd; p.part = parts.data();
+    p.v_pts = v_pts; p.v = v; p.s_v = s_v; p.w_l = w_l; p.w_r = w_r; p.w_o = w_o; p.rnd = rnd; p.status = status;
+    std::vector<uint8_t> head(n * 256), wc(n * 64), wcv(n * (size_t)NH * 32), wrho(n * 32), wmu(n * 32), wlv(n * (size_t)NH * 32), wnv(n * (size_t)NG * 32);
+    std::vector<u32> ts(52 * n), r9(4 * 72 * n), lv(6 * nv * 8 * n), nvv(4 * nm * 8 * n), lam(nl * 8 * n), muv(nm * 8 * n),
+        coef((3 * nm + 3 * nv) * 8 * n), misc(64 * n), msc(3 * NB * 8 * n, 0), pb(90 * n);
+    p.proof_head = head.data(); p.tstate = ts.data();
+    p.ro = r9.data(); p.rl = p.ro + 72 * n; p.rr = p.ro + 144 * n; p.rs = p.ro + 216 * n;
+    p.lo = lv.data(); p.ll = p.lo + nv * 8 * n; p.lr = p.lo + 2 * nv * 8 * n; p.ls = p.lo + 3 * nv * 8 * n; p.v1 = p.lo + 4 * nv * 8 * n;
+    p.cl0 = p.lo + 5 * nv * 8 * n;
+    p.no = nvv.data(); p.nl = p.no + nm * 8 * n; p.nr = p.no + 2 * nm * 8 * n; p.ns = p.no + 3 * nm * 8 * n;
+    p.lamv = lam.data(); p.muv = muv.data(); p.coef = coef.data(); p.misc = misc.data(); p.msc = msc.data(); p.pbuf = pb.data();
+    p.wn_commit = wc.data(); p.wn_c = wcv.data(); p.wn_rho = wrho.data(); p.wn_mu = wmu.data(); p.wn_l = wlv.data(); p.wn_n = wnv.data();
+    p.fb.table = (const apt_packed*)table; p.fb.W = W; p.fb.N = n;
+    t_new(p.base, label, (u32)label_len);
+    std::vector<uint8_t> pr(n * rounds * 64 + 1), px(n * rounds * 64 + 1), pl(n * nl_f * 32 + 1), pn(n * nn_f * 32 + 1);
+    WnlaProveWs w;
+    memset(&w, 0, sizeof w);
+    w.N = n; w.ng = NG; w.nh = NH; w.nl = NH; w.nn = NG; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
+    w.transcript_preloaded = 1;
+    w.commitments = p.wn_commit; w.c = p.wn_c; w.rho = p.wn_rho; w.mu = p.wn_mu; w.l_in = p.wn_l; w.n_in = p.wn_n;
+    w.proof_r = pr.data(); w.proof_x = px.data(); w.proof_l = pl.data(); w.proof_n = pn.data(); w.status = status;
+    std::vector<u32> vl((size_t)(NH + 1) * 8 * n), vn((size_t)(NG + 1) * 8 * n), vc((size_t)NH * 8 * n), ch((size_t)NH * 8 * n),
+        cg((size_t)(NG + 1) * 8 * n), prm(24 * n), com(16 * n);
+    w.tstate = p.tstate; w.vl = vl.data(); w.vn = vn.data(); w.vc = vc.data(); w.ch = ch.data(); w.cg = cg.data(); w.prm = prm.data();
+    w.com = com.data(); w.msc = p.msc; w.pbuf = p.pbuf; w.fb = p.fb;
+    auto cmsm = [&](int set, bool with_g) {
+        for (size_t t = 0; t < n; t++) {
+            pt a;
+            FbRanges rg;
+            cp_ranges(rg, p, with_g);
+            fb_sum_serial(a, p.fb, t, p.msc + (size_t)set * cp_set_words(p), rg);
+            ws_st_pt(p.pbuf + (size_t)set * 30 * n, n, t, a);
+        }
+    };
+    auto wmsm = [&](int set) {
+        for (size_t t = 0; t < n; t++) {
+            pt a;
+            FbRanges rg;
+            wnla_prove_msm_ranges(rg, w);
+            fb_sum_serial(a, w.fb, t, w.msc + (size_t)set * wp_set_words(w), rg);
+            ws_st_pt(w.pbuf + (size_t)set * 30 * n, n, t, a);
+        }
+    };
+    for (size_t t = 0; t < n; t++) circuit_prove_stage_a(p, t);
+    for (int set = 0; set < 3; set++) cmsm(set, false);
+    for (size_t t = 0; t < n; t++) circuit_prove_stage_b(p, t);
+    cmsm(0, false);
+    for (size_t t = 0; t < n; t++) circuit_prove_stage_c(p, t);
+    cmsm(0, true);
+    for (size_t t = 0; t < n; t++) circuit_prove_stage_d(p, t);
+    for (size_t t = 0; t < n; t++) wnla_prove_init(w, t);
+    for (int kk = 0; kk < (int)rounds; kk++) {
+        for (size_t t = 0; t < n; t++) wnla_prove_round_scalars(w, t, kk);
+        wmsm(0);
+        wmsm(1);
+        for (size_t t = 0; t < n; t++) wnla_prove_round_fold(w, t, kk);
+        if (kk + 1 < (int)rounds) wmsm(2);
+    }
+    for (size_t t = 0; t < n; t++) wnla_prove_finish(w, t);
+    for (size_t i = 0; i < n; i++) {
+        uint8_t* o = proofs + i * proof_bytes;
+        if (status[i] != 0) { memset(o, 0, proof_bytes); continue; }
+        memcpy(o, &head[i * 256], 256); o += 256;
+        memcpy(o, &pr[i * rounds * 64], rounds * 64); o += rounds * 64;
+        memcpy(o, &px[i * rounds * 64], rounds * 64); o += rounds * 64;
+        memcpy(o, &pl[i * nl_f * 32], nl_f * 32); o += nl_f * 32;
+        memcpy(o, &pn[i * nn_f * 32], nn_f * 32);
+    }
+    return (int)proof_bytes;
 }
 }

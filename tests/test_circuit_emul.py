@@ -91,3 +91,27 @@ def test_circuit_intermediates_vs_bigint_oracle(name):
         assert [int.from_bytes(cv[b, i].tobytes(), "big") for i in range(case["NH"])] == exp_c
         assert int(acc[b]) == int(ok) == circuit_cases.oracle_verify(case, case["commitments"][b].tobytes(), pr)
     assert not st.any()
+
+
+@pytest.mark.parametrize("name", ["ac_works", "mixed_k2", "fm_nv1", "fl_fm"])
+def test_generic_circuit_prove_is_byte_identical_to_the_oracle(name):
+    """circuit.rs:260-556 + wnla.rs:125-190 on the device code: for the same witness and the same sequence of prover scalars the
+    proof bytes must equal the reference-shaped prover's (incl. the f_l + f_m shape, whose proofs neither side's verifier accepts)."""
+    L = load()
+    B = 2
+    case = circuit_cases.make(name, B=B)
+    tab, W = _table(L, case)
+    p = case["parts"]
+    proofs = np.zeros((B, case["proof_bytes"]), np.uint8)
+    st = np.zeros(B, np.int32)
+    c = {k_: np.ascontiguousarray(case[k_]) for k_ in ("commitments", "v_bytes", "s_v", "wl_bytes", "wr_bytes", "wo_bytes", "rnd")}
+    rc = L.emul_circuit_prove(tab.ctypes.data, W, case["NG"], case["NH"], case["dims"], int(case["f_l"]), int(case["f_m"]), case["Wm_bytes"],
+                              case["Wl_bytes"], case["am_bytes"], case["al_bytes"], p["LO"].ctypes.data, p["LL"].ctypes.data,
+                              p["LR"].ctypes.data, p["NO"].ctypes.data, case["label"], len(case["label"]), B, c["commitments"].ctypes.data,
+                              c["v_bytes"].ctypes.data, c["s_v"].ctypes.data, c["wl_bytes"].ctypes.data, c["wr_bytes"].ctypes.data,
+                              c["wo_bytes"].ctypes.data, c["rnd"].ctypes.data, proofs.ctypes.data, st.ctypes.data)
+    assert rc == case["proof_bytes"] and not st.any()
+    for b in range(B):
+        got, exp = proofs[b].tobytes(), case["proofs"][b].tobytes()
+        assert got[:256] == exp[:256], "c_l, c_r, c_o, c_s"
+        assert got == exp

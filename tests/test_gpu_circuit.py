@@ -119,3 +119,38 @@ def test_commit_functions_vs_oracle():
         assert not st.any()
     finally:
         proto.close()
+
+
+@pytest.mark.parametrize("name,B", [("ac_works", 33), ("mixed_k2", 6), ("fm_nv1", 4), ("fl_fm", 3)])
+def test_circuit_prove_byte_identical_and_verifies(name, B):
+    """Generic ArithmeticCircuit::prove on the GPU (bppp_circuit_prove_batch): commitments via commit_batch, proof bytes equal to
+    the reference-shaped prover's for the same witness and prover scalars, and the GPU verifier's verdict on them equals the
+    oracle's (accept wherever the protocol is complete)."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import circuit_cases
+    from bp_pp_amd.wnla import ArithmeticCircuit
+    case = circuit_cases.make(name, B)
+    part = lambda typ, j: (None if case["part"][typ][j] < 0 else int(case["part"][typ][j]))
+    arr = lambda b: np.frombuffer(b, np.uint8).reshape(-1, 32)
+    circ = ArithmeticCircuit(case["nm"], case["no"], case["k"], case["nv"], case["g"], case["gv"], case["hv"], arr(case["Wm_bytes"]),
+                             arr(case["Wl_bytes"]), arr(case["am_bytes"]), arr(case["al_bytes"]), case["f_l"], case["f_m"], case["gv_"],
+                             case["hv_"], part, device=0, fb_window_bits=16)
+    try:
+        k, nv = case["k"], case["nv"]
+        com, st = circ.commit_batch(case["v_bytes"].reshape(B * k, nv, 32), case["s_v"].reshape(B * k, 32))
+        assert not st.any() and (com.reshape(B, k, 64) == case["commitments"]).all()
+        proofs, st, shape = circ.prove_batch(case["label"], com.reshape(B, k, 64), case["v_bytes"], case["s_v"], case["wl_bytes"],
+                                             case["wr_bytes"], case["wo_bytes"], case["rnd"])
+        assert not st.any() and shape == (case["rounds"], case["pl"], case["pn"])
+        assert (proofs == case["proofs"]).all()
+        acc, st = circ.verify_batch(case["label"], com.reshape(B, k, 64), proofs, *shape)
+        assert acc.tolist() == [0 if name == "fl_fm" else 1] * B and not st.any()
+        bad = case["wl_bytes"].copy()
+        bad[0, 0] = 0xFF                                  # non-canonical witness scalar: that instance is flagged, its proof zeroed
+        proofs2, st2, _ = circ.prove_batch(case["label"], com.reshape(B, k, 64), case["v_bytes"], case["s_v"], bad, case["wr_bytes"],
+                                           case["wo_bytes"], case["rnd"])
+        assert st2[0] == 1 and not st2[1:].any() and not proofs2[0].any() and (proofs2[1:] == proofs[1:]).all()
+    finally:
+        circ.close()
