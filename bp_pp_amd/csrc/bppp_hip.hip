@@ -19,6 +19,7 @@
 #include "recip_core.h"
 #include "rlc_core.h"
 #include "circuit_prove_core.h"
+#include "recip_prove_core.h"
 #include "wnla_prove_core.h"
 
 using namespace bppp;
@@ -351,6 +352,27 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_cprove_msm
     cp_ranges(rg, w, with_g != 0);
     fb_group_sum(part, w.fb, t, lane, w.msc + (size_t)set * cp_set_words(w), rg);
     if (lane == 0) ws_st_pt(w.pbuf + (size_t)set * 30 * w.N, w.N, t, part);
+}
+
+// ---- generic reciprocal prover kernels (recip_prove_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_rprove_stage_r1(RecipProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) recip_prove_stage_r1(w, t);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rprove_msm(RecipProveWs w) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt part;
+    FbRanges rg;
+    recip_prove_ranges(rg, w);
+    fb_group_sum(part, w.fb, t, lane, w.msc, rg);
+    if (lane == 0) ws_st_pt(w.pbuf, w.N, t, part);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_rprove_stage_r2(RecipProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) recip_prove_stage_r2(w, t);
 }
 
 // ---- generic fixed-base linear combination over the context's generators (the crate's commit functions)
@@ -1529,7 +1551,7 @@ int bppp_circuit_prove_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* 
     HIP_TRY(hipMemcpyAsync(d + o_rnd, rnd, n * n_rnd * 32, hipMemcpyHostToDevice, s));
     CircuitProveWs p;
     std::memset(&p, 0, sizeof p);
-    p.N = n; p.cd = cd; p.NG = c->ng; p.NH = c->nh; p.n_rnd = (int)n_rnd; p.part = q->d_part;
+    p.N = n; p.cd = cd; p.NG = c->ng; p.NH = c->nh; p.n_rnd = (int)n_rnd; p.rnd_stride = n_rnd * 32; p.part = q->d_part;
     p.v_pts = d + o_vp; p.v = d + o_v; p.s_v = d + o_sv; p.w_l = d + o_wl; p.w_r = d + o_wr; p.w_o = d + o_wo; p.rnd = d + o_rnd;
     p.proof_head = d + o_head; p.status = (int32_t*)(d + o_st); p.tstate = (u32*)(d + o_ts);
     u32* r9 = (u32*)(d + o_r9);
@@ -1596,6 +1618,147 @@ int bppp_circuit_prove_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* 
     }
     if (status) std::memcpy(status, st.data(), n * 4);
     (void)o_proofs;
+    return BPPP_OK;
+}
+
+// ReciprocalRangeProofProtocol::prove (reciprocal.rs:110-146) for runtime dim_nd / dim_np.
+int bppp_reciprocal_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                const uint8_t* commitments, const uint8_t* x, const uint8_t* sblind, const uint8_t* digits, const uint8_t* m,
+                                const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
+    if (!c || (!label && label_len) || !commitments || !x || !sblind || !digits || !m || !rnd || !proofs) return BPPP_ERR_INVALID_ARG;
+    if (dim_nd == 0 || dim_np == 0 || dim_nd > (size_t)c->ng || dim_nd + 10 > (size_t)c->nh || dim_np > dim_nd + 1 || dim_nd > 4096)
+        return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    RecipPattern P;
+    recip_pattern_build(P, dim_nd, dim_np);
+    const size_t NB = (size_t)c->nbases, NG = (size_t)c->ng, NH = (size_t)c->nh, nd = dim_nd, np = dim_np, nm = nd, nv = nd + 1, nl = nv,
+                 n_rnd = 20 + 2 * nd;
+    size_t rounds, nl_f, nn_f;
+    wnla_proof_shape(NH, NG, rounds, nl_f, nn_f);
+    const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl_f + nn_f);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes + 16); return o; };
+    const CircuitHostData& hd = P.hd;
+    // circuit pattern
+    const size_t o_cpl = take(hd.cpl.size() * 4), o_rl = take(hd.rl.size() * 4), o_vl = take(hd.vl.size() * 4), o_cpm = take(hd.cpm.size() * 4),
+                 o_rm = take(hd.rm.size() * 4), o_vm = take(hd.vm.size() * 4), o_cmp = take(hd.colmap.size() * 4), o_al = take(hd.al.size() * 4),
+                 o_am = take(hd.am.size() * 4), o_il = take(P.inst_l.size() * 4), o_im = take(P.inst_m.size() * 4), o_part = take(P.parts.size() * 4);
+    // inputs
+    const size_t o_com = take(n * 64), o_x = take(n * 32), o_s = take(n * 32), o_dig = take(n * nd * 32), o_m = take(n * np * 32),
+                 o_rnd = take(n * n_rnd * 32);
+    // reciprocal stage
+    const size_t o_st = take(n * 4), o_ts = take(52 * n * 4), o_inst = take((1 + np) * 8 * n * 4), o_scr = take((nd + np) * 8 * n * 4),
+                 o_cpv = take(n * nv * 32), o_cpsv = take(n * 32), o_cpwr = take(n * nm * 32), o_cpvp = take(n * 64), o_prr = take(n * 64);
+    // circuit prover
+    const size_t o_head = take(n * 256), o_r9 = take(4 * 9 * 8 * n * 4), o_lv = take(6 * nv * 8 * n * 4), o_nv = take(4 * nm * 8 * n * 4),
+                 o_lam = take(nl * 8 * n * 4), o_muv = take(nm * 8 * n * 4), o_coef = take((3 * nm + 3 * nv) * 8 * n * 4), o_misc = take(8 * 8 * n * 4),
+                 o_msc = take(3 * NB * 8 * n * 4), o_pb = take(3 * 30 * n * 4), o_wc = take(n * 64), o_wcv = take(n * NH * 32),
+                 o_rho = take(n * 32), o_mu = take(n * 32), o_wlv = take(n * NH * 32), o_wnv = take(n * NG * 32);
+    // WNLA prover
+    const size_t o_pr = take(n * rounds * 64), o_px = take(n * rounds * 64), o_pl = take(n * nl_f * 32), o_pn = take(n * nn_f * 32),
+                 o_vl2 = take((NH + 1) * 8 * n * 4), o_vn2 = take((NG + 1) * 8 * n * 4), o_vc = take(NH * 8 * n * 4), o_ch = take(NH * 8 * n * 4),
+                 o_cg = take((NG + 1) * 8 * n * 4), o_prm = take(3 * 8 * n * 4), o_cm = take(16 * n * 4);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    auto up = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(d + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess; };
+    HIP_TRY(up(o_cpl, hd.cpl.data(), hd.cpl.size() * 4)); HIP_TRY(up(o_rl, hd.rl.data(), hd.rl.size() * 4)); HIP_TRY(up(o_vl, hd.vl.data(), hd.vl.size() * 4));
+    HIP_TRY(up(o_cpm, hd.cpm.data(), hd.cpm.size() * 4)); HIP_TRY(up(o_rm, hd.rm.data(), hd.rm.size() * 4)); HIP_TRY(up(o_vm, hd.vm.data(), hd.vm.size() * 4));
+    HIP_TRY(up(o_cmp, hd.colmap.data(), hd.colmap.size() * 4)); HIP_TRY(up(o_al, hd.al.data(), hd.al.size() * 4)); HIP_TRY(up(o_am, hd.am.data(), hd.am.size() * 4));
+    HIP_TRY(up(o_il, P.inst_l.data(), P.inst_l.size() * 4)); HIP_TRY(up(o_im, P.inst_m.data(), P.inst_m.size() * 4));
+    HIP_TRY(up(o_part, P.parts.data(), P.parts.size() * 4));
+    HIP_TRY(up(o_com, commitments, n * 64)); HIP_TRY(up(o_x, x, n * 32)); HIP_TRY(up(o_s, sblind, n * 32));
+    HIP_TRY(up(o_dig, digits, n * nd * 32)); HIP_TRY(up(o_m, m, n * np * 32)); HIP_TRY(up(o_rnd, rnd, n * n_rnd * 32));
+    HIP_TRY(hipStreamSynchronize(s));                      // the pattern vectors live on this stack frame
+    RecipProveWs r;
+    std::memset(&r, 0, sizeof r);
+    r.N = n; r.nd = (int)nd; r.np = (int)np; r.NG = c->ng; r.NH = c->nh; r.n_rnd = (int)n_rnd;
+    r.commitments = d + o_com; r.x = d + o_x; r.s = d + o_s; r.digits = d + o_dig; r.m = d + o_m; r.rnd = d + o_rnd;
+    r.status = (int32_t*)(d + o_st); r.tstate = (u32*)(d + o_ts); r.inst_vals = (u32*)(d + o_inst); r.scr = (u32*)(d + o_scr);
+    r.msc = (u32*)(d + o_msc); r.pbuf = (u32*)(d + o_pb);
+    r.cp_v = d + o_cpv; r.cp_sv = d + o_cpsv; r.cp_wr = d + o_cpwr; r.cp_vpts = d + o_cpvp; r.proof_r = d + o_prr;
+    r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
+    t_new(r.base, label, (u32)label_len);
+    CircuitProveWs p;
+    std::memset(&p, 0, sizeof p);
+    CircuitDev& cd = p.cd;
+    cd.nm = (int)nm; cd.no = (int)np; cd.k = 1; cd.nl = (int)nl; cd.nv = (int)nv; cd.nw = (int)P.dims[5]; cd.f_l = 1; cd.f_m = 0;
+    cd.colptr_l = (const int*)(d + o_cpl); cd.rows_l = (const int*)(d + o_rl); cd.vals_l = (const u32*)(d + o_vl);
+    cd.colptr_m = (const int*)(d + o_cpm); cd.rows_m = (const int*)(d + o_rm); cd.vals_m = (const u32*)(d + o_vm);
+    cd.colmap = (const int*)(d + o_cmp); cd.a_l = (const u32*)(d + o_al); cd.a_m = (const u32*)(d + o_am);
+    cd.inst_l = (const int*)(d + o_il); cd.inst_m = (const int*)(d + o_im); cd.inst_vals = r.inst_vals;
+    p.N = n; p.NG = c->ng; p.NH = c->nh; p.n_rnd = (int)(18 + nv + nm); p.rnd_stride = n_rnd * 32; p.part = (const int*)(d + o_part);
+    p.transcript_preloaded = 1;
+    p.v_pts = r.cp_vpts; p.v = r.cp_v; p.s_v = r.cp_sv; p.w_l = r.digits; p.w_r = r.cp_wr; p.w_o = r.m; p.rnd = r.rnd + 32;
+    p.proof_head = d + o_head; p.status = r.status; p.tstate = r.tstate;
+    u32* r9 = (u32*)(d + o_r9);
+    p.ro = r9; p.rl = r9 + 72 * n; p.rr = r9 + 144 * n; p.rs = r9 + 216 * n;
+    u32* lv = (u32*)(d + o_lv);
+    p.lo = lv; p.ll = lv + nv * 8 * n; p.lr = lv + 2 * nv * 8 * n; p.ls = lv + 3 * nv * 8 * n; p.v1 = lv + 4 * nv * 8 * n; p.cl0 = lv + 5 * nv * 8 * n;
+    u32* nvv = (u32*)(d + o_nv);
+    p.no = nvv; p.nl = nvv + nm * 8 * n; p.nr = nvv + 2 * nm * 8 * n; p.ns = nvv + 3 * nm * 8 * n;
+    p.lamv = (u32*)(d + o_lam); p.muv = (u32*)(d + o_muv); p.coef = (u32*)(d + o_coef); p.misc = (u32*)(d + o_misc);
+    p.msc = r.msc; p.pbuf = r.pbuf;
+    p.wn_commit = d + o_wc; p.wn_c = d + o_wcv; p.wn_rho = d + o_rho; p.wn_mu = d + o_mu; p.wn_l = d + o_wlv; p.wn_n = d + o_wnv;
+    p.fb = r.fb;
+    WnlaProveWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.ng = c->ng; w.nh = c->nh; w.nl = (int)NH; w.nn = (int)NG; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
+    w.transcript_preloaded = 1;
+    w.commitments = p.wn_commit; w.c = p.wn_c; w.rho = p.wn_rho; w.mu = p.wn_mu; w.l_in = p.wn_l; w.n_in = p.wn_n;
+    w.proof_r = d + o_pr; w.proof_x = d + o_px; w.proof_l = d + o_pl; w.proof_n = d + o_pn;
+    w.status = r.status; w.tstate = r.tstate; w.vl = (u32*)(d + o_vl2); w.vn = (u32*)(d + o_vn2); w.vc = (u32*)(d + o_vc);
+    w.ch = (u32*)(d + o_ch); w.cg = (u32*)(d + o_cg); w.prm = (u32*)(d + o_prm); w.com = (u32*)(d + o_cm); w.msc = p.msc; w.pbuf = p.pbuf;
+    w.fb = p.fb;
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    HIP_TRY(hipMemsetAsync(p.msc, 0, 3 * NB * 8 * n * 4, s));
+    k_rprove_stage_r1<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    k_rprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r);
+    k_rprove_stage_r2<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    HIP_TRY(hipMemsetAsync(p.msc, 0, 3 * NB * 8 * n * 4, s));
+    k_cprove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    for (int set = 0; set < 3; set++) k_cprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(p, set, 0);
+    k_cprove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    k_cprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(p, 0, 0);
+    k_cprove_stage_c<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    k_cprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(p, 0, 1);
+    k_cprove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    k_wprove_init<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    for (int kk = 0; kk < (int)rounds; kk++) {
+        k_wprove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1);
+        k_wprove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
+        if (kk + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2);
+    }
+    k_wprove_finish<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint8_t> head(n * 256), prr(n * 64), pr(n * rounds * 64 + 1), px(n * rounds * 64 + 1), pl(n * nl_f * 32 + 1), pn(n * nn_f * 32 + 1);
+    std::vector<int32_t> st(n);
+    HIP_TRY(hipMemcpyAsync(head.data(), d + o_head, n * 256, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(prr.data(), d + o_prr, n * 64, hipMemcpyDeviceToHost, s));
+    if (rounds) {
+        HIP_TRY(hipMemcpyAsync(pr.data(), d + o_pr, n * rounds * 64, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(px.data(), d + o_px, n * rounds * 64, hipMemcpyDeviceToHost, s));
+    }
+    if (nl_f) HIP_TRY(hipMemcpyAsync(pl.data(), d + o_pl, n * nl_f * 32, hipMemcpyDeviceToHost, s));
+    if (nn_f) HIP_TRY(hipMemcpyAsync(pn.data(), d + o_pn, n * nn_f * 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(st.data(), d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; i++) {
+        uint8_t* o = proofs + i * proof_bytes;
+        if (st[i] != 0) { std::memset(o, 0, proof_bytes); continue; }
+        std::memcpy(o, &head[i * 256], 256); o += 256;
+        std::memcpy(o, &pr[i * rounds * 64], rounds * 64); o += rounds * 64;
+        std::memcpy(o, &px[i * rounds * 64], rounds * 64); o += rounds * 64;
+        std::memcpy(o, &prr[i * 64], 64); o += 64;
+        std::memcpy(o, &pl[i * nl_f * 32], nl_f * 32); o += nl_f * 32;
+        std::memcpy(o, &pn[i * nn_f * 32], nn_f * 32);
+    }
+    if (status) std::memcpy(status, st.data(), n * 4);
     return BPPP_OK;
 }
 

@@ -29,6 +29,12 @@ struct CircuitDev {
     const int* colmap;      // [3 nm + 3 nv]: W column behind c_nL[j], c_nR[j], c_nO[j] (j < nm), c_lL[j], c_lR[j], c_lO[j] (j < nv); -1 = zero
     const u32* a_l;         // [nl][8]
     const u32* a_m;         // [nm][8]
+    // optional per-instance matrix entries (a circuit whose VALUES depend on a per-proof challenge but whose sparsity pattern
+    // does not -- the reciprocal range proof's, reciprocal.rs:150-214): inst_l[p] / inst_m[p] >= 0 selects scalar slot
+    // inst_vals[slot] of the instance instead of the shared vals_l[p] / vals_m[p]
+    const int* inst_l;
+    const int* inst_m;
+    const u32* inst_vals;   // [n_inst * 8][N]
 };
 struct CircuitWs {
     size_t N;
@@ -180,7 +186,8 @@ HD void circuit_collect(const CircuitDev& cd, u32* lamv_, u32* muv_, u32* coef_,
             for (int p = cd.colptr_l[col]; p < cd.colptr_l[col + 1]; p++) {
                 sc x, val;
                 ws_ld8(x.v, w.lamv, N, t, cd.rows_l[p]);
-                cd_ld_sc(val, cd.vals_l, p);
+                if (cd.inst_l && cd.inst_l[p] >= 0) ws_ld8(val.v, cd.inst_vals, N, t, cd.inst_l[p]);
+                else cd_ld_sc(val, cd.vals_l, p);
                 sc_mul(x, x, val);
                 sc_add(a, a, x);
             }
@@ -188,7 +195,8 @@ HD void circuit_collect(const CircuitDev& cd, u32* lamv_, u32* muv_, u32* coef_,
             for (int p = cd.colptr_m[col]; p < cd.colptr_m[col + 1]; p++) {
                 sc x, val;
                 ws_ld8(x.v, w.muv, N, t, cd.rows_m[p]);
-                cd_ld_sc(val, cd.vals_m, p);
+                if (cd.inst_m && cd.inst_m[p] >= 0) ws_ld8(val.v, cd.inst_vals, N, t, cd.inst_m[p]);
+                else cd_ld_sc(val, cd.vals_m, p);
                 sc_mul(x, x, val);
                 sc_sub(a, a, x);
             }

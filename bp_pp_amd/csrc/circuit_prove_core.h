@@ -18,6 +18,8 @@ struct CircuitProveWs {
     size_t N;
     CircuitDev cd;
     int NG, NH, n_rnd;
+    int transcript_preloaded;        // 1: tstate / status were prepared by an outer protocol stage (reciprocal prover)
+    size_t rnd_stride;               // bytes between instances' draws (n_rnd * 32 when dense)
     const int* part;                 // [3 nv + nm]: LO | LL | LR | NO  (index into w_o or -1)
     const uint8_t *v_pts, *v, *s_v, *w_l, *w_r, *w_o, *rnd;   // C-ABI layouts (device): n x k x 64, n x k x nv x 32, n x k x 32, ...
     uint8_t* proof_head;             // n x 256: c_l, c_r, c_o, c_s
@@ -66,7 +68,7 @@ HD void circuit_prove_stage_a(const CircuitProveWs& w, size_t t) {
     bool ok = true;
     sc zero, x;
     sc_set_u32(zero, 0);
-    const uint8_t* rnd = w.rnd + (size_t)t * w.n_rnd * 32;
+    const uint8_t* rnd = w.rnd + (size_t)t * w.rnd_stride;
     int d = 0;
     auto draw = [&](sc& out) { ok &= sc_from_be(out, rnd + 32 * (size_t)d); d++; };
     const int ro_slots[7] = {0, 1, 2, 3, 5, 6, 7}, rl_slots[6] = {0, 1, 2, 4, 5, 6}, rr_slots[5] = {0, 1, 3, 4, 5};
@@ -108,7 +110,8 @@ HD void circuit_prove_stage_a(const CircuitProveWs& w, size_t t) {
     cp_fill_hg(w, t, 0, w.ro, w.lo, w.no);
     cp_fill_hg(w, t, 1, w.rl, w.ll, w.nl);
     cp_fill_hg(w, t, 2, w.rr, w.lr, w.nr);
-    w.status[t] = ok ? ST_OK : ST_BAD_ENCODING;
+    const int32_t st = ok ? ST_OK : ST_BAD_ENCODING;
+    w.status[t] = w.transcript_preloaded ? (w.status[t] | st) : st;
 }
 // ---- stage B: c_o, c_l, c_r -> affine + transcript, challenges, coefficient vectors, f polynomial, r_s, scalar set of c_s (set 0)
 HD void circuit_prove_stage_b(const CircuitProveWs& w, size_t t) {
@@ -124,6 +127,7 @@ HD void circuit_prove_stage_b(const CircuitProveWs& w, size_t t) {
     apt_to_xy64(ph + 64, A[2]);
     apt_to_xy64(ph + 128, A[0]);
     strobe tr = w.base;
+    if (w.transcript_preloaded) ws_ld_strobe(tr, w.tstate, N, t);
     app_point(tr, "commitment_cl", A[1]);          // circuit.rs:347-350
     app_point(tr, "commitment_cr", A[2]);
     app_point(tr, "commitment_co", A[0]);

@@ -108,6 +108,24 @@ class ReciprocalRangeProofProtocol:
     def close(self):
         self._w.close()
 
+    def prove_batch(self, label: bytes, commitments, x, s, digits, m, rnd):
+        """reciprocal.rs:110-146 for a batch: commitments [B, 64], x / s [B, 32], digits [B, dim_nd, 32], m [B, dim_np, 32],
+        rnd [B, 20 + 2 dim_nd, 32] -> (proofs, status, (rounds, nl, nn))."""
+        import ctypes as C
+        commitments = _u8(commitments, (-1, 64))
+        B = commitments.shape[0]
+        x, s = _u8(x, (B, 32)), _u8(s, (B, 32))
+        digits, m = _u8(digits, (B, self.dim_nd, 32)), _u8(m, (B, self.dim_np, 32))
+        rnd = _u8(rnd, (B, 20 + 2 * self.dim_nd, 32))
+        rounds, nl, nn = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _capi.lib().bppp_wnla_proof_shape(self._w.nh, self._w.ng, C.byref(rounds), C.byref(nl), C.byref(nn))
+        proofs = np.zeros((B, 64 * (5 + 2 * rounds.value) + 32 * (nl.value + nn.value)), np.uint8)
+        st = np.zeros(B, np.int32)
+        _capi.check(_capi.lib().bppp_reciprocal_prove_batch(self._w._ctx, label, len(label), B, self.dim_nd, self.dim_np,
+                                                            commitments.ctypes.data, x.ctypes.data, s.ctypes.data, digits.ctypes.data,
+                                                            m.ctypes.data, rnd.ctypes.data, proofs.ctypes.data, st.ctypes.data))
+        return proofs, st, (rounds.value, nl.value, nn.value)
+
     def commit_value_batch(self, x, s):
         """reciprocal.rs:88-90 for a batch: x [B, 32], s [B, 32] (big-endian scalars) -> (points, status)."""
         x, s = _u8(x, (-1, 32)), _u8(s, (-1, 32))

@@ -161,6 +161,16 @@ BPPP_API int bppp_wnla_verify_batch(bppp_ctx* ctx, const uint8_t* label, size_t 
 BPPP_API int bppp_msm_batch(bppp_ctx* ctx, size_t n, size_t nterms, const int32_t* base_index /* nterms */,
                             const uint8_t* scalars /* n x nterms x 32 */, uint8_t* out /* n x 64 */, int32_t* status /* n or NULL */);
 
+/* ReciprocalRangeProofProtocol::prove(commitment, witness, t, rng) (reciprocal.rs:110-146) for runtime dim_nd / dim_np, context
+ * as for bppp_reciprocal_verify_batch.  Per instance: the value commitment (commit_value(x, s), e.g. from bppp_msm_batch), the
+ * witness x, s (32-byte scalars), digits (dim_nd scalars: the base-dim_np digits of x), m (dim_np multiplicities), and the
+ * prover's random scalars rnd in the reference's draw order: r_blind, then the circuit prover's 18 + (dim_nd + 1) + dim_nd
+ * (20 + 2 dim_nd in all).  proofs: n x (64 (5 + 2 rounds) + 32 (nl + nn)), (rounds, nl, nn) = bppp_wnla_proof_shape(NH, NG),
+ * in the layout bppp_reciprocal_verify_batch takes (for dim_nd = dim_np = 16 the 928-byte u64 proof). */
+BPPP_API int bppp_reciprocal_prove_batch(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                         const uint8_t* commitments, const uint8_t* x, const uint8_t* s, const uint8_t* digits,
+                                         const uint8_t* m, const uint8_t* rnd, uint8_t* proofs, int32_t* status /* n or NULL */);
+
 /* ArithmeticCircuit (circuit.rs:95-139) shared by a batch, and ArithmeticCircuit::verify (circuit.rs:154-256) for n
  * independent (commitments, proof) instances of it.  dims = {dim_nm, dim_no, k, dim_nl, dim_nv, dim_nw} with the reference's
  * own relations dim_nl = dim_nv k, dim_nw = 2 dim_nm + dim_no; W_m (dim_nm x dim_nw), W_l (dim_nl x dim_nw), a_m, a_l are

@@ -12,6 +12,7 @@
 #include "../../bp_pp_amd/csrc/rlc_core.h"
 #include "../../bp_pp_amd/csrc/wnla_prove_core.h"
 #include "../../bp_pp_amd/csrc/circuit_prove_core.h"
+#include "../../bp_pp_amd/csrc/recip_prove_core.h"
 
 using namespace bppp;
 
@@ -602,7 +603,7 @@ int emul_circuit_prove(const uint8_t* table, int W, int NG, int NH, const size_t
     std::vector<int> parts(3 * nv + nm);
     for (size_t j = 0; j < nv; j++) { parts[j] = part_lo[j]; parts[nv + j] = part_ll[j]; parts[2 * nv + j] = part_lr[j]; }
     for (size_t j = 0; j < nm; j++) parts[3 * nv + j] = part_no[j];
-    p.N = n; p.NG = NG; p.NH = NH; p.n_rnd = (int)n_rnd; p.part = parts.data();
+    p.N = n; p.NG = NG; p.NH = NH; p.n_rnd = (int)n_rnd; p.rnd_stride = n_rnd * 32; p.part = parts.data();
     p.v_pts = v_pts; p.v = v; p.s_v = s_v; p.w_l = w_l; p.w_r = w_r; p.w_o = w_o; p.rnd = rnd; p.status = status;
     std::vector<uint8_t> head(n * 256), wc(n * 64), wcv(n * (size_t)NH * 32), wrho(n * 32), wmu(n * 32), wlv(n * (size_t)NH * 32), wnv(n * (size_t)NG * 32);
     std::vector<u32> ts(52 * n), r9(4 * 72 * n), lv(6 * nv * 8 * n), nvv(4 * nm * 8 * n), lam(nl * 8 * n), muv(nm * 8 * n),
@@ -667,6 +668,97 @@ int emul_circuit_prove(const uint8_t* table, int W, int NG, int NH, const size_t
         memcpy(o, &head[i * 256], 256); o += 256;
         memcpy(o, &pr[i * rounds * 64], rounds * 64); o += rounds * 64;
         memcpy(o, &px[i * rounds * 64], rounds * 64); o += rounds * 64;
+        memcpy(o, &pl[i * nl_f * 32], nl_f * 32); o += nl_f * 32;
+        memcpy(o, &pn[i * nn_f * 32], nn_f * 32);
+    }
+    return (int)proof_bytes;
+}
+// generic ReciprocalRangeProofProtocol::prove (recip_prove_core.h -> circuit_prove_core.h -> wnla_prove_core.h), thread order
+int emul_recip_prove(const uint8_t* table, int W, int NG, int NH, int nd, int np, const uint8_t* label, size_t label_len, size_t n,
+                     const uint8_t* commitments, const uint8_t* x, const uint8_t* sblind, const uint8_t* digits, const uint8_t* m,
+                     const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
+    RecipPattern P;
+    recip_pattern_build(P, (size_t)nd, (size_t)np);
+    const size_t nm = nd, nv = nd + 1, nl = nv, NB = 1 + NG + NH, n_rnd = 20 + 2 * (size_t)nd;
+    size_t rounds, nl_f, nn_f;
+    wnla_proof_shape((size_t)NH, (size_t)NG, rounds, nl_f, nn_f);
+    const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl_f + nn_f);
+    std::vector<u32> ts(52 * n), inst((1 + (size_t)np) * 8 * n), scr(((size_t)nd + np) * 8 * n), msc(3 * NB * 8 * n, 0), pb(90 * n);
+    std::vector<uint8_t> cpv(n * nv * 32), cpsv(n * 32), cpwr(n * nm * 32), cpvp(n * 64), prr(n * 64);
+    RecipProveWs r;
+    memset(&r, 0, sizeof r);
+    r.N = n; r.nd = nd; r.np = np; r.NG = NG; r.NH = NH; r.n_rnd = (int)n_rnd;
+    r.commitments = commitments; r.x = x; r.s = sblind; r.digits = digits; r.m = m; r.rnd = rnd; r.status = status; r.tstate = ts.data();
+    r.inst_vals = inst.data(); r.scr = scr.data(); r.msc = msc.data(); r.pbuf = pb.data();
+    r.cp_v = cpv.data(); r.cp_sv = cpsv.data(); r.cp_wr = cpwr.data(); r.cp_vpts = cpvp.data(); r.proof_r = prr.data();
+    r.fb.table = (const apt_packed*)table; r.fb.W = W; r.fb.N = n;
+    t_new(r.base, label, (u32)label_len);
+    CircuitProveWs p;
+    memset(&p, 0, sizeof p);
+    CircuitDev& cd = p.cd;
+    cd.nm = (int)nm; cd.no = np; cd.k = 1; cd.nl = (int)nl; cd.nv = (int)nv; cd.nw = (int)P.dims[5]; cd.f_l = 1; cd.f_m = 0;
+    cd.colptr_l = P.hd.cpl.data(); cd.rows_l = P.hd.rl.data(); cd.vals_l = P.hd.vl.data();
+    cd.colptr_m = P.hd.cpm.data(); cd.rows_m = P.hd.rm.data(); cd.vals_m = P.hd.vm.data();
+    cd.colmap = P.hd.colmap.data(); cd.a_l = P.hd.al.data(); cd.a_m = P.hd.am.data();
+    cd.inst_l = P.inst_l.data(); cd.inst_m = P.inst_m.data(); cd.inst_vals = r.inst_vals;
+    p.N = n; p.NG = NG; p.NH = NH; p.n_rnd = (int)(18 + nv + nm); p.rnd_stride = n_rnd * 32; p.part = P.parts.data(); p.transcript_preloaded = 1;
+    p.v_pts = r.cp_vpts; p.v = r.cp_v; p.s_v = r.cp_sv; p.w_l = digits; p.w_r = r.cp_wr; p.w_o = m; p.rnd = rnd + 32; p.status = status;
+    std::vector<uint8_t> head(n * 256), wc(n * 64), wcv(n * (size_t)NH * 32), wrho(n * 32), wmu(n * 32), wlv(n * (size_t)NH * 32), wnv(n * (size_t)NG * 32);
+    std::vector<u32> r9(4 * 72 * n), lv(6 * nv * 8 * n), nvv(4 * nm * 8 * n), lam(nl * 8 * n), muv(nm * 8 * n), coef((3 * nm + 3 * nv) * 8 * n), misc(64 * n);
+    p.proof_head = head.data(); p.tstate = ts.data();
+    p.ro = r9.data(); p.rl = p.ro + 72 * n; p.rr = p.ro + 144 * n; p.rs = p.ro + 216 * n;
+    p.lo = lv.data(); p.ll = p.lo + nv * 8 * n; p.lr = p.lo + 2 * nv * 8 * n; p.ls = p.lo + 3 * nv * 8 * n; p.v1 = p.lo + 4 * nv * 8 * n;
+    p.cl0 = p.lo + 5 * nv * 8 * n;
+    p.no = nvv.data(); p.nl = p.no + nm * 8 * n; p.nr = p.no + 2 * nm * 8 * n; p.ns = p.no + 3 * nm * 8 * n;
+    p.lamv = lam.data(); p.muv = muv.data(); p.coef = coef.data(); p.misc = misc.data(); p.msc = msc.data(); p.pbuf = pb.data();
+    p.wn_commit = wc.data(); p.wn_c = wcv.data(); p.wn_rho = wrho.data(); p.wn_mu = wmu.data(); p.wn_l = wlv.data(); p.wn_n = wnv.data();
+    p.fb = r.fb;
+    std::vector<uint8_t> pr(n * rounds * 64 + 1), px(n * rounds * 64 + 1), pl(n * nl_f * 32 + 1), pn(n * nn_f * 32 + 1);
+    WnlaProveWs w;
+    memset(&w, 0, sizeof w);
+    w.N = n; w.ng = NG; w.nh = NH; w.nl = NH; w.nn = NG; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
+    w.transcript_preloaded = 1;
+    w.commitments = p.wn_commit; w.c = p.wn_c; w.rho = p.wn_rho; w.mu = p.wn_mu; w.l_in = p.wn_l; w.n_in = p.wn_n;
+    w.proof_r = pr.data(); w.proof_x = px.data(); w.proof_l = pl.data(); w.proof_n = pn.data(); w.status = status;
+    std::vector<u32> vl((size_t)(NH + 1) * 8 * n), vn((size_t)(NG + 1) * 8 * n), vc((size_t)NH * 8 * n), ch((size_t)NH * 8 * n),
+        cg((size_t)(NG + 1) * 8 * n), prm(24 * n), com(16 * n);
+    w.tstate = p.tstate; w.vl = vl.data(); w.vn = vn.data(); w.vc = vc.data(); w.ch = ch.data(); w.cg = cg.data(); w.prm = prm.data();
+    w.com = com.data(); w.msc = p.msc; w.pbuf = p.pbuf; w.fb = p.fb;
+    auto sum = [&](const FbRanges& rg, const u32* scal, u32* out) {
+        for (size_t t = 0; t < n; t++) { pt a; fb_sum_serial(a, r.fb, t, scal, rg); ws_st_pt(out, n, t, a); }
+    };
+    FbRanges rg;
+    for (size_t t = 0; t < n; t++) recip_prove_stage_r1(r, t);
+    recip_prove_ranges(rg, r);
+    sum(rg, r.msc, r.pbuf);
+    for (size_t t = 0; t < n; t++) recip_prove_stage_r2(r, t);
+    std::fill(msc.begin(), msc.end(), 0u);
+    for (size_t t = 0; t < n; t++) circuit_prove_stage_a(p, t);
+    cp_ranges(rg, p, false);
+    for (int set = 0; set < 3; set++) sum(rg, p.msc + (size_t)set * cp_set_words(p), p.pbuf + (size_t)set * 30 * n);
+    for (size_t t = 0; t < n; t++) circuit_prove_stage_b(p, t);
+    sum(rg, p.msc, p.pbuf);
+    for (size_t t = 0; t < n; t++) circuit_prove_stage_c(p, t);
+    cp_ranges(rg, p, true);
+    sum(rg, p.msc, p.pbuf);
+    for (size_t t = 0; t < n; t++) circuit_prove_stage_d(p, t);
+    for (size_t t = 0; t < n; t++) wnla_prove_init(w, t);
+    wnla_prove_msm_ranges(rg, w);
+    for (int kk = 0; kk < (int)rounds; kk++) {
+        for (size_t t = 0; t < n; t++) wnla_prove_round_scalars(w, t, kk);
+        sum(rg, w.msc, w.pbuf);
+        sum(rg, w.msc + wp_set_words(w), w.pbuf + 30 * n);
+        for (size_t t = 0; t < n; t++) wnla_prove_round_fold(w, t, kk);
+        if (kk + 1 < (int)rounds) sum(rg, w.msc + 2 * wp_set_words(w), w.pbuf + 60 * n);
+    }
+    for (size_t t = 0; t < n; t++) wnla_prove_finish(w, t);
+    for (size_t i = 0; i < n; i++) {
+        uint8_t* o = proofs + i * proof_bytes;
+        if (status[i] != 0) { memset(o, 0, proof_bytes); continue; }
+        memcpy(o, &head[i * 256], 256); o += 256;
+        memcpy(o, &pr[i * rounds * 64], rounds * 64); o += rounds * 64;
+        memcpy(o, &px[i * rounds * 64], rounds * 64); o += rounds * 64;
+        memcpy(o, &prr[i * 64], 64); o += 64;
         memcpy(o, &pl[i * nl_f * 32], nl_f * 32); o += nl_f * 32;
         memcpy(o, &pn[i * nn_f * 32], nn_f * 32);
     }

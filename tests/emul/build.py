@@ -38,4 +38,5 @@ def load():
     L.emul_circuit_verify.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, cp, sz, sz, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.emul_wnla_prove.argtypes = [vp, i32, i32, i32, cp, sz, sz, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.emul_circuit_prove.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, cp, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.emul_recip_prove.argtypes = [vp, i32, i32, i32, i32, i32, cp, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp]
     return L

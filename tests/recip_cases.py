@@ -35,6 +35,7 @@ def make(dim_nd: int, dim_np: int, B: int, label: bytes = b"reciprocal test"):
     case = dict(g=g, gv=gv, hv=hv, gv_=gv_, hv_=hv_, nd=dim_nd, np=dim_np, label=label, NG=NG, NH=NH)
     coms, proofs, shape = [], [], None
     n_rnd = 20 + 2 * dim_nd
+    wx, ws, wd, wm, wr = [], [], [], [], []
     for b in range(B):
         digits = [int.from_bytes(hashlib.shake_256(b"dig" + bytes([b]) + i.to_bytes(4, "little")).digest(2), "little") % dim_np
                   for i in range(dim_nd)]
@@ -46,6 +47,8 @@ def make(dim_nd: int, dim_np: int, B: int, label: bytes = b"reciprocal test"):
         m = [digits.count(v) for v in range(dim_np)]
         s = _sc(b"s", b)
         rnd = b"".join(O.sc_to_bytes(_sc(b"rnd", b, i)) for i in range(n_rnd))
+        wx.append(O.sc_to_bytes(x)); ws.append(O.sc_to_bytes(s)); wd.append(b"".join(O.sc_to_bytes(d) for d in digits))
+        wm.append(b"".join(O.sc_to_bytes(v) for v in m)); wr.append(rnd)
         com = C.create_string_buffer(64)
         pbuf = C.create_string_buffer(64 * (5 + 2 * 16) + 32 * 16)
         rounds, nl, nn = sz(0), sz(0), sz(0)
@@ -60,6 +63,8 @@ def make(dim_nd: int, dim_np: int, B: int, label: bytes = b"reciprocal test"):
         nbytes = 64 * (5 + 2 * sh[0]) + 32 * (sh[1] + sh[2])
         coms.append(com.raw)
         proofs.append(pbuf.raw[:nbytes])
+    u8 = lambda blobs, *sh: np.frombuffer(b"".join(blobs), dtype=np.uint8).reshape(B, *sh).copy()
+    case.update(x=u8(wx, 32), s=u8(ws, 32), digits=u8(wd, dim_nd, 32), m=u8(wm, dim_np, 32), rnd=u8(wr, n_rnd, 32))
     case.update(rounds=shape[0], nl=shape[1], nn=shape[2], proof_bytes=len(proofs[0]),
                 commitments=np.frombuffer(b"".join(coms), dtype=np.uint8).reshape(B, 64).copy(),
                 proofs=np.frombuffer(b"".join(proofs), dtype=np.uint8).reshape(B, -1).copy())

@@ -55,3 +55,27 @@ def test_u64_dimensions_agree_with_the_specialised_path():
         assert (a1 == a2).all() and (a1 == expect).all() and not s1.any() and not s2.any()
     finally:
         u.close(); r.close()
+
+
+@pytest.mark.parametrize("nd,npp,B", [(16, 16, 40), (8, 4, 5), (12, 10, 3), (256, 16, 2)])
+def test_generic_reciprocal_prove_byte_identical_and_verifies(nd, npp, B):
+    """Generic ReciprocalRangeProofProtocol::prove on the GPU: commitments via commit_value_batch, proof bytes equal to the
+    reference-shaped prover's, and the GPU verifier accepts them.  (256, 16) is the "aggregated" shape of BASELINE configs[4]."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import recip_cases
+    from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
+    case = recip_cases.make(nd, npp, B)
+    proto = ReciprocalRangeProofProtocol(nd, npp, case["g"], case["gv"], case["hv"], case["gv_"], case["hv_"], device=0,
+                                         fb_window_bits=8 if nd > 64 else 16)
+    try:
+        com, st = proto.commit_value_batch(case["x"], case["s"])
+        assert not st.any() and (com == case["commitments"]).all()
+        proofs, st, shape = proto.prove_batch(case["label"], com, case["x"], case["s"], case["digits"], case["m"], case["rnd"])
+        assert not st.any() and shape == (case["rounds"], case["nl"], case["nn"])
+        assert (proofs == case["proofs"]).all()
+        acc, st = proto.verify_batch(case["label"], com, proofs, *shape)
+        assert acc.all() and not st.any()
+    finally:
+        proto.close()

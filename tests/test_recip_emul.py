@@ -40,3 +40,26 @@ def test_generic_reciprocal_verify_vs_oracle(nd, npp):
     P[1, 70] ^= 1                                  # c_r off the curve
     acc, st = run(case["commitments"], P)
     assert st.tolist() == [0, 1, 0] and acc.tolist() == [1, 0, 1]
+
+
+@pytest.mark.parametrize("nd,npp", [(16, 16), (8, 4), (12, 10), (32, 16)])
+def test_generic_reciprocal_prove_is_byte_identical_to_the_oracle(nd, npp):
+    """reciprocal.rs:110-146 on the device code (per-instance matrix values over the shared sparsity pattern, then the generic
+    circuit and WNLA provers): proof bytes equal the reference-shaped prover's for the same witness and prover scalars.
+    dim_nd = dim_np = 16 is the u64 protocol through the generic path."""
+    L = load()
+    B = 3
+    case = recip_cases.make(nd, npp, B=B)
+    W = 4
+    gens = case["g"] + b"".join(case["gv"]) + b"".join(case["gv_"]) + b"".join(case["hv"]) + b"".join(case["hv_"])
+    NB = 1 + case["NG"] + case["NH"]
+    tab = np.zeros(L.emul_fb_table_entries(NB, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, NB, W, tab.ctypes.data) == 0
+    proofs = np.zeros((B, case["proof_bytes"]), np.uint8)
+    st = np.zeros(B, np.int32)
+    c = {k: np.ascontiguousarray(case[k]) for k in ("commitments", "x", "s", "digits", "m", "rnd")}
+    rc = L.emul_recip_prove(tab.ctypes.data, W, case["NG"], case["NH"], nd, npp, case["label"], len(case["label"]), B, c["commitments"].ctypes.data,
+                            c["x"].ctypes.data, c["s"].ctypes.data, c["digits"].ctypes.data, c["m"].ctypes.data, c["rnd"].ctypes.data,
+                            proofs.ctypes.data, st.ctypes.data)
+    assert rc == case["proof_bytes"] and not st.any()
+    assert (proofs == case["proofs"]).all()
