@@ -72,3 +72,57 @@ def json_to_sec1(text: str) -> bytes:
     if len(out) != 525:
         raise ValueError("bad field length")
     return out
+
+
+# ---------------------------------------------------------------- generic proofs (any shape)
+# The generic C-ABI proof layouts (include/bppp.h) <-> the `serde_json` shapes of the reference's serializable mirrors:
+#   wnla::SerializableProof      {"r": [...], "x": [...], "l": [...], "n": [...]}                      (wnla.rs:33-38)
+#   circuit::SerializableProof   {"c_l", "c_r", "c_o", "c_s", "r": [...], "x": [...], "l": [...], "n": [...]}   (circuit.rs:37-46)
+#   reciprocal::SerializableProof {"circuit_proof": {...}, "r"}                                       (reciprocal.rs:37-41)
+# with points as SEC1-compressed hex and scalars as 32-byte big-endian hex (same caveat on hex case as above).
+def _pts(buf: bytes, off: int, count: int):
+    return [compress_point(buf[off + 64 * i:off + 64 * i + 64]).hex().upper() for i in range(count)], off + 64 * count
+
+
+def _scs(buf: bytes, off: int, count: int):
+    return [buf[off + 32 * i:off + 32 * i + 32].hex().upper() for i in range(count)], off + 32 * count
+
+
+def wnla_proof_to_doc(proof_r: bytes, proof_x: bytes, proof_l: bytes, proof_n: bytes) -> Dict:
+    """The four arrays of bppp_wnla_{prove,verify}_batch for ONE instance -> wnla::SerializableProof document."""
+    r, _ = _pts(proof_r, 0, len(proof_r) // 64)
+    x, _ = _pts(proof_x, 0, len(proof_x) // 64)
+    l, _ = _scs(proof_l, 0, len(proof_l) // 32)
+    n, _ = _scs(proof_n, 0, len(proof_n) // 32)
+    return {"r": r, "x": x, "l": l, "n": n}
+
+
+def circuit_proof_to_doc(proof: bytes, rounds: int, nl: int, nn: int, reciprocal: bool = False) -> Dict:
+    """One proof in the layout of bppp_circuit_* (or, with reciprocal=True, bppp_reciprocal_*) -> serializable document."""
+    want = 64 * ((5 if reciprocal else 4) + 2 * rounds) + 32 * (nl + nn)
+    if len(proof) != want:
+        raise ValueError(f"proof has {len(proof)} bytes, the shape needs {want}")
+    head, off = _pts(proof, 0, 4)
+    r, off = _pts(proof, off, rounds)
+    x, off = _pts(proof, off, rounds)
+    rr = None
+    if reciprocal:
+        (rr,), off = _pts(proof, off, 1)
+    l, off = _scs(proof, off, nl)
+    n, off = _scs(proof, off, nn)
+    cp = dict(zip(POINT_FIELDS, head), r=r, x=x, l=l, n=n)
+    return {"circuit_proof": cp, "r": rr} if reciprocal else cp
+
+
+def doc_to_circuit_proof(doc: Dict) -> bytes:
+    """Inverse of circuit_proof_to_doc (either shape); points are decompressed (ValueError on a malformed point)."""
+    reciprocal = "circuit_proof" in doc
+    cp = doc["circuit_proof"] if reciprocal else doc
+    if len(cp["r"]) != len(cp["x"]):
+        raise ValueError("r and x must have the same length")
+    pt = lambda h: decompress_point(bytes.fromhex(h))
+    sc = lambda h: bytes.fromhex(h).rjust(32, b"\0")
+    out = b"".join(pt(cp[k]) for k in POINT_FIELDS) + b"".join(pt(h) for h in cp["r"]) + b"".join(pt(h) for h in cp["x"])
+    if reciprocal:
+        out += pt(doc["r"])
+    return out + b"".join(sc(h) for h in cp["l"]) + b"".join(sc(h) for h in cp["n"])

@@ -79,3 +79,28 @@ def test_device_decompression_code(gold):
     assert g[32:] == bytes(32) and not O.on_curve((int.from_bytes(g[:32], "big"), 0))
     g = bytes(P928[928 * (len(cases) + 1) + 64:928 * (len(cases) + 1) + 128])
     assert g[:32] == (5).to_bytes(32, "big") and g[32:] == bytes(32)
+
+
+def test_generic_proof_documents_round_trip():
+    """circuit / reciprocal / wnla proofs of any shape <-> the serde-shaped documents, on oracle-made proofs."""
+    import circuit_cases
+    import recip_cases
+    import wnla_cases
+    from bp_pp_amd import wire
+    c = circuit_cases.make("mixed_k2", 1)
+    doc = wire.circuit_proof_to_doc(c["proofs"][0].tobytes(), c["rounds"], c["pl"], c["pn"])
+    assert set(doc) == {"c_l", "c_r", "c_o", "c_s", "r", "x", "l", "n"} and len(doc["r"]) == len(doc["x"]) == c["rounds"]
+    assert all(len(h) == 66 for h in doc["r"] + doc["x"] + [doc["c_l"]]) and all(len(h) == 64 for h in doc["l"] + doc["n"])
+    assert wire.doc_to_circuit_proof(json.loads(json.dumps(doc))) == c["proofs"][0].tobytes()
+    r = recip_cases.make(8, 4, 1)
+    doc = wire.circuit_proof_to_doc(r["proofs"][0].tobytes(), r["rounds"], r["nl"], r["nn"], reciprocal=True)
+    assert set(doc) == {"circuit_proof", "r"} and wire.doc_to_circuit_proof(doc) == r["proofs"][0].tobytes()
+    # the u64 shape agrees with the dedicated 928-byte converters
+    u = recip_cases.make(16, 16, 1)
+    assert json.loads(wire.sec1_to_json(wire.abi_to_sec1(u["proofs"][0].tobytes()))) == \
+        wire.circuit_proof_to_doc(u["proofs"][0].tobytes(), u["rounds"], u["nl"], u["nn"], reciprocal=True)
+    w = wnla_cases.make(4, 4, 1)
+    d = wire.wnla_proof_to_doc(w["proof_r"][0].tobytes(), w["proof_x"][0].tobytes(), w["proof_l"][0].tobytes(), w["proof_n"][0].tobytes())
+    assert len(d["r"]) == w["rounds"] and len(d["l"]) == w["nl"] and len(d["n"]) == w["nn"]
+    with pytest.raises(ValueError):
+        wire.circuit_proof_to_doc(c["proofs"][0].tobytes()[:-1], c["rounds"], c["pl"], c["pn"])
