@@ -943,8 +943,8 @@ int bppp_u64_verify_batch_rlc_device(bppp_ctx* c, const uint8_t* label, size_t l
     return verify_device_impl(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, nullptr, d_reject_count, seed);
 }
 
-int bppp_u64_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
-                          const uint8_t* proofs, uint8_t* accept, int32_t* status) {
+static int verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                            const uint8_t* proofs, uint8_t* accept, int32_t* status, const uint8_t* rlc_seed) {
     if (!c || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -960,12 +960,21 @@ int bppp_u64_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, s
     int32_t* d_s = (int32_t*)(c->d_io + o_s);
     HIP_TRY(hipMemcpyAsync(d_c, commitments, n * 64, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_p, proofs, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, c->stream));
-    int rc = bppp_u64_verify_batch_device(c, label, label_len, n, d_c, d_p, d_a, d_s, nullptr, nullptr);
+    int rc = verify_device_impl(c, label, label_len, n, d_c, d_p, d_a, d_s, nullptr, nullptr, rlc_seed);
     if (rc != BPPP_OK) return rc;
     HIP_TRY(hipMemcpyAsync(accept, d_a, n, hipMemcpyDeviceToHost, c->stream));
     if (status) HIP_TRY(hipMemcpyAsync(status, d_s, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BPPP_OK;
+}
+int bppp_u64_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                          const uint8_t* proofs, uint8_t* accept, int32_t* status) {
+    return verify_host_impl(c, label, label_len, n, commitments, proofs, accept, status, nullptr);
+}
+int bppp_u64_verify_batch_rlc(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                              const uint8_t* proofs, uint8_t* accept, int32_t* status, const uint8_t seed[32]) {
+    if (!seed) return BPPP_ERR_INVALID_ARG;
+    return verify_host_impl(c, label, label_len, n, commitments, proofs, accept, status, seed);
 }
 
 int bppp_u64_commit_value_batch(bppp_ctx* c, size_t n, const uint64_t* x, const uint8_t* s, uint8_t* out) {

@@ -89,6 +89,18 @@ class U64RangeProofProtocol:
                                                              d_accept, d_status or None, d_trace or None,
                                                              d_reject_count or None))
 
+    def verify_batch_rlc(self, commitments, proofs, label: bytes, seed: bytes) -> Tuple[np.ndarray, np.ndarray]:
+        """verify_batch in the optional RLC mode (host buffers); see verify_batch_rlc_device."""
+        if len(seed) != 32:
+            raise ValueError("seed must be 32 bytes")
+        commitments = _as_u8(commitments, (-1, 64))
+        n = commitments.shape[0]
+        proofs = _as_u8(proofs, (n, U64_PROOF_BYTES))
+        accept, status = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.int32)
+        _capi.check(_capi.lib().bppp_u64_verify_batch_rlc(self._ctx, label, len(label), n, commitments.ctypes.data, proofs.ctypes.data,
+                                                          accept.ctypes.data, status.ctypes.data, seed))
+        return accept, status
+
     def verify_batch_rlc_device(self, label: bytes, n: int, d_commitments: int, d_proofs: int, d_accept: int, seed: bytes,
                                 d_status: int = 0, d_reject_count: int = 0) -> None:
         """Optional batch mode (include/bppp.h: bppp_u64_verify_batch_rlc_device): the final per-proof MSM is replaced by one

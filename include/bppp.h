@@ -100,6 +100,9 @@ BPPP_API int bppp_u64_verify_batch_device(bppp_ctx* ctx, const uint8_t* label, s
 BPPP_API int bppp_u64_verify_batch_rlc_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n,
                                               const void* d_commitments, const void* d_proofs, void* d_accept, void* d_status,
                                               void* d_reject_count, const uint8_t seed[32]);
+/* the same with host buffers (as bppp_u64_verify_batch) */
+BPPP_API int bppp_u64_verify_batch_rlc(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                                       const uint8_t* proofs, uint8_t* accept, int32_t* status, const uint8_t seed[32]);
 
 /* The same verify over the reference's WIRE content: what `reciprocal::SerializableProof` / `circuit::SerializableProof`
  * (reciprocal.rs:37-41, circuit.rs:37-46) carry -- k256 `AffinePoint`s, whose byte form is 33-byte SEC1 compressed

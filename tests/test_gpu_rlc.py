@@ -72,6 +72,16 @@ def test_rlc_matches_exact_mode_and_oracle_on_bad_proofs(env, oracle_c):
         assert int(e_acc[i]) == (1 if rc == 1 else 0)
 
 
+def test_rlc_host_buffer_entry_point(env):
+    import workload
+    torch, proto, gens, V, P, n = env
+    Pc = P.copy()
+    Pc[5, 900] ^= 1
+    acc, st = proto.verify_batch_rlc(V, Pc, workload.LABEL, os.urandom(32))
+    exp, _ = proto.verify_batch(V, Pc, workload.LABEL)
+    assert (acc == exp).all() and not st.any() and acc[5] == 0 and acc.sum() == n - 1
+
+
 def test_rlc_small_batches(env):
     torch, proto, gens, V, P, n = env
     for m in (1, 7, 8, 9, 16):
