@@ -43,3 +43,42 @@ def test_no_device_means_error_not_fallback():
     rc = L.bppp_ctx_create(C.byref(ctx), bytes(64), bytes(16 * 64), bytes(32 * 64), 0, 8)
     assert rc == _capi.ERR_NO_DEVICE and not ctx.value
     assert L.bppp_u64_verify_batch(None, b"x", 1, 1, None, None, None, None) == _capi.ERR_INVALID_ARG
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """The boundary is a C ABI: include/bppp.h must compile as C99 (no C++-isms, no torch / HIP types), and a C program must link
+    against libbppp_hip.so and get BPPP_ERR_NO_DEVICE -- not a crash, not a fallback -- on a machine without a gfx950 device."""
+    import shutil
+    import subprocess
+    import torch
+    from bp_pp_amd import _build
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not available")
+    src = tmp_path / "capi_smoke.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "bppp.h"
+int main(void) {
+    unsigned char g[64], gv[16 * 64], hv[32 * 64];
+    bppp_ctx* ctx = NULL;
+    size_t rounds = 0, nl = 0, nn = 0;
+    memset(g, 0, sizeof g); memset(gv, 0, sizeof gv); memset(hv, 0, sizeof hv);
+    bppp_wnla_proof_shape(32, 16, &rounds, &nl, &nn);
+    if (rounds != 4 || nl != 2 || nn != 1) return 10;                 /* the u64 proof's shape (wnla.rs:126) */
+    printf("%d %s\n", bppp_ctx_create(&ctx, g, gv, hv, 0, 8), bppp_strerror(BPPP_ERR_NO_DEVICE));
+    return ctx != NULL;
+}
+''')
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)])
+    if not os.path.exists(_build.SO):
+        pytest.skip("libbppp_hip.so not built yet")
+    exe = tmp_path / "capi_smoke"
+    subprocess.check_call([gcc, "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), _build.SO,
+                           "-Wl,-rpath," + os.path.dirname(_build.SO), "-Wl,-rpath,/opt/rocm/lib"])
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present; the no-device path is a CPU-tier check")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[0] == "-1" and "no CPU fallback" in out.stdout
