@@ -22,6 +22,15 @@
 
 namespace bppp {
 
+// Optional phase stamps (diagnostic builds only: -DBPPP_PHASE_TIMING): lane 0 of every wavefront records the shader clock at
+// marked points of verify_phase1 / verify_round into g_bppp_stamps; tools/phase_probe.py reads them back.
+#if defined(BPPP_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long g_bppp_stamps[1024 * 16];
+#define BPPP_STAMP(t, i) do { if (((t) & 63) == 0 && ((t) >> 6) < 1024) g_bppp_stamps[((t) >> 6) * 16 + (i)] = (unsigned long long)clock64(); } while (0)
+#else
+#define BPPP_STAMP(t, i) ((void)0)
+#endif
+
 enum : int32_t {
     ST_OK = 0,
     ST_BAD_ENCODING = 1,     // coordinate >= p, point off curve, scalar >= n (k256 deserialisation would have failed)
@@ -120,9 +129,18 @@ HD void ws_st_strobe(u32* base, size_t N, size_t t, const strobe& s) {
 
 template <int L>
 HD void app_point(strobe& t, const char (&label)[L], const apt& a) {  // transcript.rs:6-8
-    uint8_t b[33];
-    apt_to_sec1(b, a);
-    t_append(t, label, b, 33);
+    // SEC1 compressed bytes (tag, then x big-endian) packed little-endian into 9 message words, all in registers
+    const bool id = apt_is_identity(a);
+    const u32 tag = id ? 0u : (2u + (fe_is_odd(a.y) ? 1u : 0u));
+    u32 xw[8], be[8], mw[9];
+    fe_to_w8(xw, a.x);
+#pragma unroll
+    for (int k = 0; k < 8; k++) be[k] = bswap32(xw[7 - k]);      // be[k] = message bytes 1 + 4k .. 4 + 4k, first byte lowest
+    mw[0] = tag | (be[0] << 8);
+#pragma unroll
+    for (int k = 1; k < 8; k++) mw[k] = (be[k - 1] >> 24) | (be[k] << 8);
+    mw[8] = be[7] >> 24;
+    t_append_words(t, label, mw, 33);
 }
 
 // ---------------------------------------------------------------- fixed-base MSM over the batch-shared tables
@@ -763,6 +781,7 @@ HD void straus_affine(pt& out, const apt_packed* tab, const int* pidx, const glv
 HD void verify_phase1(const VerifyWs& ws, size_t t) {
     const size_t N = ws.N;
     int32_t status = ST_OK;
+    BPPP_STAMP(t, 0);
     const uint8_t* pv = ws.commitments + 64 * t;
     const uint8_t* pp = ws.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
     apt V, P[13];
@@ -786,6 +805,7 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
     }
     strobe tr = ws.base;
     sc e, rho, lambda, beta, delta, tau;
+    BPPP_STAMP(t, 1);
     app_point(tr, "reciprocal_commitment", V);                          // reciprocal.rs:99
     bool cok = t_get_challenge(tr, "reciprocal_challenge", e);          // reciprocal.rs:100
     // circuit_commitment = commitment + proof.r                         (reciprocal.rs:104)
@@ -796,14 +816,17 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
         pt_madd(s, s, P[12], apt_is_identity(P[12]));
         pt_to_affine(Vr, s);
     }
+    BPPP_STAMP(t, 2);
     app_point(tr, "commitment_cl", P[0]);                                // circuit.rs:155-159
     app_point(tr, "commitment_cr", P[1]);
     app_point(tr, "commitment_co", P[2]);
     app_point(tr, "commitment_v", Vr);
+    BPPP_STAMP(t, 3);
     cok &= t_get_challenge(tr, "circuit_rho", rho);                      // circuit.rs:161-164
     cok &= t_get_challenge(tr, "circuit_lambda", lambda);
     cok &= t_get_challenge(tr, "circuit_beta", beta);
     cok &= t_get_challenge(tr, "circuit_delta", delta);
+    BPPP_STAMP(t, 4);
     app_point(tr, "commitment_cs", P[3]);                                // circuit.rs:189
     cok &= t_get_challenge(tr, "circuit_tau", tau);                      // circuit.rs:191
     if (!cok) {
@@ -820,6 +843,7 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
 
     // ---- scalars.  One Fn inversion for {mu, tau, e+0..e+15} (the reference: util.rs:119, circuit.rs:192, reciprocal.rs:181 x256)
     sc mu;
+    BPPP_STAMP(t, 5);
     sc_mul(mu, rho, rho);                                                // circuit.rs:166
     sc a[18], pre[18];
     a[0] = mu;
@@ -856,6 +880,7 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
     sc tau2, tau3, S, t1, t2;
     sc_mul(tau2, tau, tau);
     sc_mul(tau3, tau2, tau);
+    BPPP_STAMP(t, 6);
     // S = sum_{i=1..16} lambda^i ; musum = sum_{i=1..16} mu^i
     sc lp = lambda, mp = mu, musum;
     S = lambda;
@@ -912,6 +937,7 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
     sc_neg(t1, tau2);
     ws_st8(ws.sc0, N, t, 20, t1.v);
     ws_st8(ws.sc0, N, t, 21, two_tau3.v);   // v_ = 2 (V + r), times tau^3 (circuit.rs:182-187,235)
+    BPPP_STAMP(t, 7);
     // cr_tau = [1, beta/tau, beta tau, ..., beta tau^7]                                  (circuit.rs:208-218)
     ws_st8(ws.cvec, N, t, 0, one.v);
     sc_mul(t1, beta, tau_inv);
@@ -922,6 +948,7 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
         sc_mul(bt, bt, tau);
         ws_st8(ws.cvec, N, t, i, bt.v);
     }
+    BPPP_STAMP(t, 8);
     ws.status[t] = status;
     if (ws.trace) {
         uint8_t* tb = ws.trace + 704 * t;
@@ -970,8 +997,10 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k) {
         ws_ld_pt(F, ws.pfix, N, t);
         pt_add(C, C, F);
     }
+    BPPP_STAMP(t, 9);
     apt Ca, X, R;
     pt_to_affine(Ca, C);
+    BPPP_STAMP(t, 10);
     ws_ld_apt(X, ws.pts, N, t, 8 + (4 - k));   // proof.x.last()
     ws_ld_apt(R, ws.pts, N, t, 4 + (4 - k));   // proof.r.last()
     strobe tr;
@@ -987,6 +1016,7 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k) {
         ws.status[t] |= ST_DEGENERATE;
         sc_set_u32(y, 1);
     }
+    BPPP_STAMP(t, 11);
     ws_st_strobe(ws.tstate, N, t, tr);
     ws_st8(ws.chal, N, t, 5 + k, y.v);
     if (ws.trace) {
@@ -1006,8 +1036,10 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k) {
     glv_words_set<2>(g, 0, sp);
     glv_decompose(sp, y2m1);
     glv_words_set<2>(g, 1, sp);
+    BPPP_STAMP(t, 12);
     pt acc;
     straus_affine<2>(acc, ws.atab + t * BPPP_ATAB_PER_PROOF, pslot, g);
+    BPPP_STAMP(t, 13);
     pt_madd(acc, acc, Ca, apt_is_identity(Ca));
     ws_st_pt(ws.acc, N, t, acc);
 }
