@@ -15,7 +15,7 @@
 
 #include "../../include/bppp.h"
 #if defined(BPPP_PHASE_TIMING)
-namespace bppp { __device__ unsigned long long g_bppp_stamps[1024 * 16]; }
+namespace bppp { __device__ unsigned long long g_bppp_stamps[1024 * 32]; }
 #endif
 #include "prove_core.h"
 #include "circuit_core.h"
@@ -1777,7 +1777,7 @@ int bppp_reciprocal_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_
 #if defined(BPPP_PHASE_TIMING)
 // diagnostic builds only (not declared in include/bppp.h): copy the phase stamps out
 BPPP_API int bppp_debug_read_stamps(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bppp::g_bppp_stamps), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bppp::g_bppp_stamps), sizeof(unsigned long long) * 1024 * 32) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -25,8 +25,8 @@ namespace bppp {
 // Optional phase stamps (diagnostic builds only: -DBPPP_PHASE_TIMING): lane 0 of every wavefront records the shader clock at
 // marked points of verify_phase1 / verify_round into g_bppp_stamps; tools/phase_probe.py reads them back.
 #if defined(BPPP_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-extern __device__ unsigned long long g_bppp_stamps[1024 * 16];
-#define BPPP_STAMP(t, i) do { if (((t) & 63) == 0 && ((t) >> 6) < 1024) g_bppp_stamps[((t) >> 6) * 16 + (i)] = (unsigned long long)clock64(); } while (0)
+extern __device__ unsigned long long g_bppp_stamps[1024 * 32];
+#define BPPP_STAMP(t, i) do { if (((t) & 63) == 0 && ((t) >> 6) < 1024) g_bppp_stamps[((t) >> 6) * 32 + (i)] = (unsigned long long)clock64(); } while (0)
 #else
 #define BPPP_STAMP(t, i) ((void)0)
 #endif
@@ -604,6 +604,7 @@ HD void tscr_load(TabScratch& r, const VerifyWs& ws, size_t t, int idx) {
 }
 HD void verify_tables(const VerifyWs& ws, size_t t) {
     const size_t N = ws.N;
+    BPPP_STAMP(t, 16);
     fe run, beta, one;
     fe_set_u32(run, 1);
     fe_set_u32(one, 1);
@@ -632,8 +633,10 @@ HD void verify_tables(const VerifyWs& ws, size_t t) {
             fe_mul(run, run, z);
         }
     }
+    BPPP_STAMP(t, 17);
     fe inv;
     fe_inv(inv, run);
+    BPPP_STAMP(t, 18);
     // backward: 1/Z_e = inv * prefix_e; the next entry's scratch words are requested before this entry's arithmetic
     TabScratch cur, nxt;
     tscr_load(cur, ws, t, BPPP_VPOINTS * 7 - 1);
@@ -659,6 +662,7 @@ HD void verify_tables(const VerifyWs& ws, size_t t) {
         }
         atab_store(tb, 1, P, beta, pid);
     }
+    BPPP_STAMP(t, 19);
 }
 // The 2M GLV half-scalars of an M-point sum, kept in registers; digits are picked with select chains (no dynamic indexing).
 template <int M>
@@ -983,8 +987,10 @@ HD void verify_c0_var(const VerifyWs& ws, size_t t) {
         glv_decompose(sp, k);
         glv_words_set<5>(g, j, sp);
     }
+    BPPP_STAMP(t, 20);
     pt acc;
     straus_affine<5>(acc, ws.atab + t * BPPP_ATAB_PER_PROOF, pslot, g);
+    BPPP_STAMP(t, 21);
     ws_st_pt(ws.acc, N, t, acc);   // the fixed-base part (pfix) is added at the top of round 1
 }
 // ---------------------------------------------------------------- phase 3 (k = 1..4): one WNLA round (wnla.rs:84-102)
@@ -1046,6 +1052,7 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k) {
 // ---------------------------------------------------------------- phase 4: base case (wnla.rs:80-82 with :66-72), generators unrolled
 HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
     const size_t N = ws.N;
+    BPPP_STAMP(t, 22);
     sc rho, y[4], rk[4], l0, l1, n0;
     ws_ld8(rho.v, ws.chal, N, t, 1);
 #pragma nounroll

@@ -16,7 +16,7 @@ proto.set_stream(torch.cuda.current_stream().cuda_stream)
 for _ in range(2):
     proto.verify_batch_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, 0)
 torch.cuda.synchronize()
-buf = np.zeros((1024, 16), np.uint64)
+buf = np.zeros((1024, 32), np.uint64)
 L = _capi.lib()
 L.bppp_debug_read_stamps.argtypes = [C.c_void_p]
 assert L.bppp_debug_read_stamps(buf.ctypes.data) == 0
@@ -28,4 +28,8 @@ for i, nm in enumerate(names):
         continue
     delta = (d[:, i + 1] - d[:, i])
     print(f"{nm:36s} {delta.mean():12.0f} cycles  ({delta.mean() / 100e6 * 1e3:7.3f} ms at 100 MHz s_memtime; min {delta.min()}, max {delta.max()})")
+for a, b, nm in ((16, 17, "tables: forward (multiples + prefix products)"), (17, 18, "tables: inversion"), (18, 19, "tables: backward (affine, pack, store)"),
+                 (20, 21, "c0_var: straus (5 points)")):
+    delta = d[:, b] - d[:, a]
+    print(f"{nm:48s} {delta.mean():12.0f} cycles")
 print("phase1 total", (d[:, 8] - d[:, 0]).mean(), " round total (9..13)", (d[:, 13] - d[:, 9]).mean())
