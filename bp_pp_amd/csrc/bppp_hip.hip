@@ -17,472 +17,9 @@
 #if defined(BPPP_PHASE_TIMING)
 namespace bppp { __device__ unsigned long long g_bppp_stamps[1024 * 32]; }
 #endif
-#include "prove_core.h"
-#include "circuit_core.h"
-#include "recip_core.h"
-#include "rlc_core.h"
-#include "circuit_prove_core.h"
-#include "recip_prove_core.h"
-#include "wnla_prove_core.h"
+#include "kernels.h"
 
 using namespace bppp;
-
-// ---------------------------------------------------------------- kernels
-#define BPPP_BLOCK 64
-
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1(VerifyWs ws) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < ws.N) verify_phase1(ws, t);
-}
-// fixed-base MSM kernels: BPPP_FB_LANES lanes per proof, 256-thread workgroups, registers capped for 4 wavefronts per SIMD
-#define BPPP_FB_BLOCK 256
-#ifndef BPPP_FB_MIN_WAVES
-#define BPPP_FB_MIN_WAVES 2
-#endif
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed(VerifyWs ws) {
-    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
-    if (t >= ws.N) return;   // whole lane groups leave together
-    pt part;
-    FbRanges rg;
-    verify_c0_fixed_ranges(rg);
-    fb_group_sum(part, fb_of(ws), t, lane, ws.sc0, rg);
-    if (lane == 0) verify_c0_fixed_store(ws, t, part);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables(VerifyWs ws) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < ws.N) verify_tables(ws, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var(VerifyWs ws) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < ws.N) verify_c0_var(ws, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round(VerifyWs ws, int k) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < ws.N) verify_round(ws, t, k);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(VerifyWs ws) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < ws.N) verify_final_scalars(ws, t);
-}
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(VerifyWs ws) {
-    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
-    if (t >= ws.N) return;
-    pt part;
-    FbRanges rg;
-    verify_final_check_ranges(rg);
-    fb_group_sum(part, fb_of(ws), t, lane, ws.fsc, rg);
-    if (lane == 0) verify_final_check_store(ws, t, part);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(VerifyWs ws, int* reject_count) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < ws.N) {
-        verify_accept(ws, t);
-        if (reject_count && !ws.accept[t]) atomicAdd(reject_count, 1);
-    }
-}
-// ---- random-linear-combination batch mode (rlc_core.h)
-__global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(VerifyWs ws, RlcWs r) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < ws.N) rlc_lhs(ws, r, t);
-}
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(VerifyWs ws, RlcWs r) {
-    const size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    const size_t chunk = g / BPPP_RLC_CHUNK;
-    const int lane = (int)(g % BPPP_RLC_CHUNK);
-    const size_t N = ws.N, nchunks = (N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
-    if (chunk >= nchunks) return;            // whole lane groups leave together
-    const size_t t = chunk * BPPP_RLC_CHUNK + lane;
-    // a chunk with a missing or flagged proof goes to the exact kernels
-    int bad = (t < N) ? (ws.status[t] != ST_OK) : 1;
-#pragma unroll
-    for (int m = 1; m < BPPP_RLC_CHUNK; m <<= 1) bad |= __shfl_xor(bad, m, 64);
-    if (bad) {
-        if (lane == 0) { r.flag[chunk] = 1; r.list[atomicAdd(r.count, 1)] = (u32)chunk; }
-        return;
-    }
-    u64 a, b;
-    rlc_weight(a, b, r, t);
-    sc w;
-    rlc_weight_scalar(w, a, b);
-#pragma nounroll
-    for (int i = 0; i < BPPP_NG; i++) {
-        sc p;
-        rlc_product(p, ws, w, t, i);
-#pragma unroll
-        for (int m = 1; m < BPPP_RLC_CHUNK; m <<= 1) {
-            sc o;
-#pragma unroll
-            for (int k = 0; k < 8; k++) o.v[k] = __shfl_xor(p.v[k], m, 64);
-            sc_add(p, p, o);
-        }
-        ws_st8(r.sc, N, t, i, p.v);          // every lane keeps its own (identical) copy: no cross-lane memory traffic
-    }
-    FbRanges rg;
-    rlc_ranges(rg);
-    pt rhs, lhs;
-    fb_group_sum(rhs, fb_of(ws), t, lane, r.sc, rg);
-    ws_ld_pt(lhs, r.lhs, N, t);
-    lane_group_sum(lhs);
-    const bool ok = pt_eq(lhs, rhs);
-    if (ok) ws.accept[t] = 1;
-    if (lane == 0) {
-        r.flag[chunk] = ok ? 0 : 1;
-        if (!ok) r.list[atomicAdd(r.count, 1)] = (u32)chunk;
-    }
-}
-// exact final check of the proofs of the flagged chunks: a whole wavefront per proof (637 table additions over 64 lanes, 6-step
-// tree), because only a few proofs are expected here and an 8-lane group would take the full 80-addition latency for each
-__global__ __launch_bounds__(64) void k_verify_final_check_flagged(VerifyWs ws, RlcWs r) {
-    const int lane = (int)threadIdx.x;
-    const size_t nchunks = (ws.N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
-    if ((size_t)(*r.count) * 8 > nchunks) return;   // many flagged chunks: k_verify_final_check_flagged_dense does them
-    const size_t items = (size_t)(*r.count) * BPPP_RLC_CHUNK;
-#pragma nounroll
-    for (size_t item = blockIdx.x; item < items; item += gridDim.x) {
-        const size_t t = (size_t)r.list[item / BPPP_RLC_CHUNK] * BPPP_RLC_CHUNK + item % BPPP_RLC_CHUNK;
-        if (t >= ws.N) continue;
-        pt part;
-        FbRanges rg;
-        verify_final_check_ranges(rg);
-        fb_group_sum<64>(part, fb_of(ws), t, lane, ws.fsc, rg);
-        if (lane == 0) verify_final_check_store(ws, t, part);
-    }
-}
-// the same for a batch where more than 1/8 of the chunks failed (an adversarial or broken input stream): the regular 8-lane
-// kernel over the whole batch, skipping the chunks that passed
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_flagged_dense(VerifyWs ws, RlcWs r) {
-    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
-    const size_t nchunks = (ws.N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
-    if ((size_t)(*r.count) * 8 <= nchunks) return;
-    if (t >= ws.N || !r.flag[t / BPPP_RLC_CHUNK]) return;
-    pt part;
-    FbRanges rg;
-    verify_final_check_ranges(rg);
-    fb_group_sum(part, fb_of(ws), t, lane, ws.fsc, rg);
-    if (lane == 0) verify_final_check_store(ws, t, part);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept_flagged(VerifyWs ws, RlcWs r, int* reject_count) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t >= ws.N) return;
-    if (r.flag[t / BPPP_RLC_CHUNK]) verify_accept(ws, t);
-    if (reject_count && !ws.accept[t]) atomicAdd(reject_count, 1);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass1(FbBuild fb, size_t nthreads) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < nthreads) fb_build_pass1(fb, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass2(FbBuild fb, size_t nthreads) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < nthreads) fb_build_pass2(fb, t);
-}
-// generator decoding + validation (context creation): 64-B big-endian -> device affine; flags[0] |= 1 on a bad point
-__global__ void k_decode_generators(const uint8_t* in, apt* out, int n, int* flags) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    apt a;
-    if (!apt_from_xy64(a, in + 64 * i)) atomicOr(flags, 1);
-    out[i] = a;
-}
-// U64RangeProofProtocol::commit_value (u64_proof.rs:37-39): x*g + s*h_vec[0] through the fixed-base tables
-__global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(VerifyWs ws, const uint64_t* x, const uint8_t* s, uint8_t* out,
-                                                             int* flags) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t >= ws.N) return;
-    sc xs, ss;
-    sc_set_u64(xs, x[t]);
-    if (!sc_from_be(ss, s + 32 * t)) {
-        atomicOr(flags, 1);
-        sc_set_u32(ss, 0);
-    }
-    // scalars for bases 0 (g) and 17 (h_vec[0]) staged in the fsc scratch area, slots 0 and 1
-    ws_st8(ws.fsc, ws.N, t, 0, xs.v);
-    ws_st8(ws.fsc, ws.N, t, 1, ss.v);
-    pt acc;
-    pt_set_identity(acc);
-    fixed_base_msm(acc, fb_of(ws), t, ws.fsc, 0, 0, 1);
-    fixed_base_msm(acc, fb_of(ws), t, ws.fsc, 1, 17, 1);
-    apt a;
-    pt_to_affine(a, acc);
-    apt_to_xy64(out + 64 * t, a);
-}
-
-// wire format: 16 lanes per proof (14 points + scalar copy), SEC1 compressed -> the 64-byte form
-__global__ __launch_bounds__(256) void k_sec1_expand(uint8_t* commitments64, uint8_t* proofs928, const uint8_t* commitments33,
-                                                     const uint8_t* proofs525, size_t n) {
-    size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-    size_t t = g / 16;
-    int j = (int)(g % 16);
-    if (t < n && j < 15) sec1_expand_lane(commitments64, proofs928, commitments33, proofs525, t, j);
-}
-// ---- prover kernels (prove_core.h)
-__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_a(ProveWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) prove_stage_a(w, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_b(ProveWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) prove_stage_b(w, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d(ProveWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) prove_stage_d(w, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f(ProveWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) prove_stage_f(w, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(ProveWs w, int k) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) prove_round_scalars(w, t, k);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(ProveWs w, int k) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) prove_round_fold(w, t, k);
-}
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(ProveWs w, MsmJob job) {
-    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
-    if (t >= w.N) return;
-    pt part;
-    FbRanges rg;
-    prove_msm_ranges(rg, job);
-    fb_group_sum(part, w.fb, t, lane, w.msc, rg);
-    if (lane == 0) prove_msm_store(w, job, t, part);
-}
-
-// ---- generic WNLA kernels (wnla_core.h)
-__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_scalars(WnlaWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) wnla_commit_scalars(w, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(WnlaWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) wnla_verify_begin(w, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round(WnlaWs w, int k) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) wnla_verify_round(w, t, k);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars(WnlaWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) wnla_verify_final_scalars(w, t);
-}
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(WnlaWs w, int commit_mode) {
-    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
-    if (t >= w.N) return;
-    pt part;
-    FbRanges rg;
-    wnla_msm_ranges(rg, w);
-    fb_group_sum(part, w.fb, t, lane, w.msc, rg);
-    if (lane == 0) wnla_verify_store(w, t, part);
-    (void)commit_mode;
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(WnlaWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) {
-        pt total;
-        ws_ld_pt(total, w.pfix, w.N, t);
-        wnla_commit_store(w, t, total);
-    }
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(WnlaWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) wnla_verify_accept(w, t);
-}
-
-// ---- generic WNLA prover kernels (wnla_prove_core.h)
-__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_init(WnlaProveWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) wnla_prove_init(w, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_scalars(WnlaProveWs w, int k) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) wnla_prove_round_scalars(w, t, k);
-}
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wprove_msm(WnlaProveWs w, int set) {
-    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
-    if (t >= w.N) return;
-    pt part;
-    FbRanges rg;
-    wnla_prove_msm_ranges(rg, w);
-    fb_group_sum(part, w.fb, t, lane, w.msc + (size_t)set * wp_set_words(w), rg);
-    if (lane == 0) ws_st_pt(w.pbuf + (size_t)set * 30 * w.N, w.N, t, part);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_fold(WnlaProveWs w, int k) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) wnla_prove_round_fold(w, t, k);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_finish(WnlaProveWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) wnla_prove_finish(w, t);
-}
-
-// ---- generic circuit prover kernels (circuit_prove_core.h)
-__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_a(CircuitProveWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) circuit_prove_stage_a(w, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_b(CircuitProveWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) circuit_prove_stage_b(w, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_c(CircuitProveWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) circuit_prove_stage_c(w, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_d(CircuitProveWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) circuit_prove_stage_d(w, t);
-}
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_cprove_msm(CircuitProveWs w, int set, int with_g) {
-    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
-    if (t >= w.N) return;
-    pt part;
-    FbRanges rg;
-    cp_ranges(rg, w, with_g != 0);
-    fb_group_sum(part, w.fb, t, lane, w.msc + (size_t)set * cp_set_words(w), rg);
-    if (lane == 0) ws_st_pt(w.pbuf + (size_t)set * 30 * w.N, w.N, t, part);
-}
-
-// ---- generic reciprocal prover kernels (recip_prove_core.h)
-__global__ __launch_bounds__(BPPP_BLOCK) void k_rprove_stage_r1(RecipProveWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) recip_prove_stage_r1(w, t);
-}
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rprove_msm(RecipProveWs w) {
-    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
-    if (t >= w.N) return;
-    pt part;
-    FbRanges rg;
-    recip_prove_ranges(rg, w);
-    fb_group_sum(part, w.fb, t, lane, w.msc, rg);
-    if (lane == 0) ws_st_pt(w.pbuf, w.N, t, part);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_rprove_stage_r2(RecipProveWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) recip_prove_stage_r2(w, t);
-}
-
-// ---- generic fixed-base linear combination over the context's generators (the crate's commit functions)
-struct MsmWs {
-    size_t N;
-    int nterms, nruns;
-    const uint8_t* scalars;     // N x nterms x 32
-    const int* runs;            // [nruns][3]: first scalar slot, first base, count
-    u32* msc;                   // [nterms * 8][N]
-    u32* pfix;                  // [30][N]
-    int32_t* status;
-    uint8_t* out;               // N x 64
-    FbTable fb;
-};
-__global__ __launch_bounds__(BPPP_BLOCK) void k_msm_scalars(MsmWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t >= w.N) return;
-    bool ok = true;
-    sc zero;
-    sc_set_u32(zero, 0);
-#pragma nounroll
-    for (int j = 0; j < w.nterms; j++) {
-        sc k;
-        const bool kok = sc_from_be(k, w.scalars + ((size_t)t * w.nterms + j) * 32);
-        ok &= kok;
-        ws_st8(w.msc, w.N, t, j, kok ? k.v : zero.v);
-    }
-    w.status[t] = ok ? ST_OK : ST_BAD_ENCODING;
-}
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_msm(MsmWs w) {
-    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
-    if (t >= w.N) return;
-    pt total;
-    pt_set_identity(total);
-#pragma nounroll
-    for (int r = 0; r < w.nruns; r += 3) {      // up to three runs per pass of the 8-lane group sum
-        FbRanges rg;
-        rg.n = w.nruns - r < 3 ? w.nruns - r : 3;
-        for (int q = 0; q < rg.n; q++) { rg.slot[q] = w.runs[3 * (r + q)]; rg.base[q] = w.runs[3 * (r + q) + 1]; rg.count[q] = w.runs[3 * (r + q) + 2]; }
-        pt part;
-        fb_group_sum(part, w.fb, t, lane, w.msc, rg);
-        pt_add(total, total, part);
-    }
-    if (lane == 0) ws_st_pt(w.pfix, w.N, t, total);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_msm_store(MsmWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t >= w.N) return;
-    pt total;
-    ws_ld_pt(total, w.pfix, w.N, t);
-    apt a;
-    pt_to_affine(a, total);
-    if (w.status[t] != ST_OK) { fe_set_u32(a.x, 0); fe_set_u32(a.y, 0); }
-    apt_to_xy64(w.out + 64 * t, a);
-}
-
-// ---- generic arithmetic circuit kernels (circuit_core.h)
-__global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_phase1(CircuitWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) circuit_phase1(w, t);
-}
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_circuit_c0_fixed(CircuitWs w) {
-    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
-    if (t >= w.N) return;
-    pt part;
-    FbRanges rg;
-    circuit_c0_fixed_ranges(rg, w);
-    fb_group_sum(part, w.fb, t, lane, w.sc0, rg);
-    if (lane == 0) circuit_c0_fixed_store(w, t, part);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_var(CircuitWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) circuit_c0_var(w, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_finish(CircuitWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) circuit_c0_finish(w, t);
-}
-
-// ---- generic reciprocal range proof kernels (recip_core.h)
-__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1(RecipWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) recip_phase1(w, t);
-}
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed(RecipWs w) {
-    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
-    if (t >= w.N) return;
-    pt part;
-    FbRanges rg;
-    recip_c0_fixed_ranges(rg, w);
-    fb_group_sum(part, w.fb, t, lane, w.sc0, rg);
-    if (lane == 0) recip_c0_fixed_store(w, t, part);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var(RecipWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) recip_c0_var(w, t);
-}
-__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_finish(RecipWs w) {
-    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) recip_c0_finish(w, t);
-}
 
 // ---------------------------------------------------------------- host side
 static thread_local std::string g_last_error;

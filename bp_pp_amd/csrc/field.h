@@ -14,7 +14,7 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define HD __host__ __device__ __forceinline__
-#define HD_NOINLINE __host__ __device__ __noinline__
+#define HD_NOINLINE __host__ __device__ __noinline__ inline
 #else
 #define HD inline
 #define HD_NOINLINE inline

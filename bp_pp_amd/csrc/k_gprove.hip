@@ -1,0 +1,82 @@
+// generic WNLA / arithmetic circuit / reciprocal prover kernels.
+// Part of libbppp_hip.so; per-lane work lives in the *_core.h headers, declarations in kernels.h.
+#include "kernels.h"
+
+using namespace bppp;
+
+// ---- generic WNLA prover kernels (wnla_prove_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_init(WnlaProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_prove_init(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_scalars(WnlaProveWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_prove_round_scalars(w, t, k);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wprove_msm(WnlaProveWs w, int set) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt part;
+    FbRanges rg;
+    wnla_prove_msm_ranges(rg, w);
+    fb_group_sum(part, w.fb, t, lane, w.msc + (size_t)set * wp_set_words(w), rg);
+    if (lane == 0) ws_st_pt(w.pbuf + (size_t)set * 30 * w.N, w.N, t, part);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_fold(WnlaProveWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_prove_round_fold(w, t, k);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_finish(WnlaProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_prove_finish(w, t);
+}
+// ---- generic circuit prover kernels (circuit_prove_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_a(CircuitProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) circuit_prove_stage_a(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_b(CircuitProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) circuit_prove_stage_b(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_c(CircuitProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) circuit_prove_stage_c(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_d(CircuitProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) circuit_prove_stage_d(w, t);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_cprove_msm(CircuitProveWs w, int set, int with_g) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt part;
+    FbRanges rg;
+    cp_ranges(rg, w, with_g != 0);
+    fb_group_sum(part, w.fb, t, lane, w.msc + (size_t)set * cp_set_words(w), rg);
+    if (lane == 0) ws_st_pt(w.pbuf + (size_t)set * 30 * w.N, w.N, t, part);
+}
+// ---- generic reciprocal prover kernels (recip_prove_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_rprove_stage_r1(RecipProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) recip_prove_stage_r1(w, t);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rprove_msm(RecipProveWs w) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt part;
+    FbRanges rg;
+    recip_prove_ranges(rg, w);
+    fb_group_sum(part, w.fb, t, lane, w.msc, rg);
+    if (lane == 0) ws_st_pt(w.pbuf, w.N, t, part);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_rprove_stage_r2(RecipProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) recip_prove_stage_r2(w, t);
+}

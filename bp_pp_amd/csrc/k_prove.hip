@@ -1,0 +1,42 @@
+// u64 batch prover kernels (prove_core.h).
+// Part of libbppp_hip.so; per-lane work lives in the *_core.h headers, declarations in kernels.h.
+#include "kernels.h"
+
+using namespace bppp;
+
+// ---- prover kernels (prove_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_a(ProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_stage_a(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_b(ProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_stage_b(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d(ProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_stage_d(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f(ProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_stage_f(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(ProveWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_round_scalars(w, t, k);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(ProveWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_round_fold(w, t, k);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(ProveWs w, MsmJob job) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt part;
+    FbRanges rg;
+    prove_msm_ranges(rg, job);
+    fb_group_sum(part, w.fb, t, lane, w.msc, rg);
+    if (lane == 0) prove_msm_store(w, job, t, part);
+}

@@ -1,0 +1,137 @@
+// u64 verifier: the 8-lanes-per-proof fixed-base kernels (C0 fixed half, final check, RLC chunks), table construction, commit_value.
+// Part of libbppp_hip.so; per-lane work lives in the *_core.h headers, declarations in kernels.h.
+#include "kernels.h"
+
+using namespace bppp;
+
+// fixed-base MSM kernels: BPPP_FB_LANES lanes per proof, 256-thread workgroups, registers capped for 4 wavefronts per SIMD
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed(VerifyWs ws) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= ws.N) return;   // whole lane groups leave together
+    pt part;
+    FbRanges rg;
+    verify_c0_fixed_ranges(rg);
+    fb_group_sum(part, fb_of(ws), t, lane, ws.sc0, rg);
+    if (lane == 0) verify_c0_fixed_store(ws, t, part);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(VerifyWs ws) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= ws.N) return;
+    pt part;
+    FbRanges rg;
+    verify_final_check_ranges(rg);
+    fb_group_sum(part, fb_of(ws), t, lane, ws.fsc, rg);
+    if (lane == 0) verify_final_check_store(ws, t, part);
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(VerifyWs ws, RlcWs r) {
+    const size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    const size_t chunk = g / BPPP_RLC_CHUNK;
+    const int lane = (int)(g % BPPP_RLC_CHUNK);
+    const size_t N = ws.N, nchunks = (N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    if (chunk >= nchunks) return;            // whole lane groups leave together
+    const size_t t = chunk * BPPP_RLC_CHUNK + lane;
+    // a chunk with a missing or flagged proof goes to the exact kernels
+    int bad = (t < N) ? (ws.status[t] != ST_OK) : 1;
+#pragma unroll
+    for (int m = 1; m < BPPP_RLC_CHUNK; m <<= 1) bad |= __shfl_xor(bad, m, 64);
+    if (bad) {
+        if (lane == 0) { r.flag[chunk] = 1; r.list[atomicAdd(r.count, 1)] = (u32)chunk; }
+        return;
+    }
+    u64 a, b;
+    rlc_weight(a, b, r, t);
+    sc w;
+    rlc_weight_scalar(w, a, b);
+#pragma nounroll
+    for (int i = 0; i < BPPP_NG; i++) {
+        sc p;
+        rlc_product(p, ws, w, t, i);
+#pragma unroll
+        for (int m = 1; m < BPPP_RLC_CHUNK; m <<= 1) {
+            sc o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = __shfl_xor(p.v[k], m, 64);
+            sc_add(p, p, o);
+        }
+        ws_st8(r.sc, N, t, i, p.v);          // every lane keeps its own (identical) copy: no cross-lane memory traffic
+    }
+    FbRanges rg;
+    rlc_ranges(rg);
+    pt rhs, lhs;
+    fb_group_sum(rhs, fb_of(ws), t, lane, r.sc, rg);
+    ws_ld_pt(lhs, r.lhs, N, t);
+    lane_group_sum(lhs);
+    const bool ok = pt_eq(lhs, rhs);
+    if (ok) ws.accept[t] = 1;
+    if (lane == 0) {
+        r.flag[chunk] = ok ? 0 : 1;
+        if (!ok) r.list[atomicAdd(r.count, 1)] = (u32)chunk;
+    }
+}
+// exact final check of the proofs of the flagged chunks: a whole wavefront per proof (637 table additions over 64 lanes, 6-step
+// tree), because only a few proofs are expected here and an 8-lane group would take the full 80-addition latency for each
+__global__ __launch_bounds__(64) void k_verify_final_check_flagged(VerifyWs ws, RlcWs r) {
+    const int lane = (int)threadIdx.x;
+    const size_t nchunks = (ws.N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    if ((size_t)(*r.count) * 8 > nchunks) return;   // many flagged chunks: k_verify_final_check_flagged_dense does them
+    const size_t items = (size_t)(*r.count) * BPPP_RLC_CHUNK;
+#pragma nounroll
+    for (size_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const size_t t = (size_t)r.list[item / BPPP_RLC_CHUNK] * BPPP_RLC_CHUNK + item % BPPP_RLC_CHUNK;
+        if (t >= ws.N) continue;
+        pt part;
+        FbRanges rg;
+        verify_final_check_ranges(rg);
+        fb_group_sum<64>(part, fb_of(ws), t, lane, ws.fsc, rg);
+        if (lane == 0) verify_final_check_store(ws, t, part);
+    }
+}
+// the same for a batch where more than 1/8 of the chunks failed (an adversarial or broken input stream): the regular 8-lane
+// kernel over the whole batch, skipping the chunks that passed
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_flagged_dense(VerifyWs ws, RlcWs r) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    const size_t nchunks = (ws.N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    if ((size_t)(*r.count) * 8 <= nchunks) return;
+    if (t >= ws.N || !r.flag[t / BPPP_RLC_CHUNK]) return;
+    pt part;
+    FbRanges rg;
+    verify_final_check_ranges(rg);
+    fb_group_sum(part, fb_of(ws), t, lane, ws.fsc, rg);
+    if (lane == 0) verify_final_check_store(ws, t, part);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass1(FbBuild fb, size_t nthreads) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < nthreads) fb_build_pass1(fb, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass2(FbBuild fb, size_t nthreads) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < nthreads) fb_build_pass2(fb, t);
+}
+// U64RangeProofProtocol::commit_value (u64_proof.rs:37-39): x*g + s*h_vec[0] through the fixed-base tables
+__global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(VerifyWs ws, const uint64_t* x, const uint8_t* s, uint8_t* out,
+                                                             int* flags) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= ws.N) return;
+    sc xs, ss;
+    sc_set_u64(xs, x[t]);
+    if (!sc_from_be(ss, s + 32 * t)) {
+        atomicOr(flags, 1);
+        sc_set_u32(ss, 0);
+    }
+    // scalars for bases 0 (g) and 17 (h_vec[0]) staged in the fsc scratch area, slots 0 and 1
+    ws_st8(ws.fsc, ws.N, t, 0, xs.v);
+    ws_st8(ws.fsc, ws.N, t, 1, ss.v);
+    pt acc;
+    pt_set_identity(acc);
+    fixed_base_msm(acc, fb_of(ws), t, ws.fsc, 0, 0, 1);
+    fixed_base_msm(acc, fb_of(ws), t, ws.fsc, 1, 17, 1);
+    apt a;
+    pt_to_affine(a, acc);
+    apt_to_xy64(out + 64 * t, a);
+}

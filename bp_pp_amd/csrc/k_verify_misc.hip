@@ -1,0 +1,46 @@
+// u64 verifier: phase 1 (decode + transcript + scalars), final scalars, accept, generator decoding, SEC1 expansion.
+// Part of libbppp_hip.so; per-lane work lives in the *_core.h headers, declarations in kernels.h.
+#include "kernels.h"
+
+using namespace bppp;
+
+// One-lane-per-proof kernels of the u64 verifier: minimum waves per SIMD the register allocator must leave room for
+// (2 => at most 256 VGPR + AGPR per lane, so two wavefronts share a SIMD and cover each other's table-gather latency).
+
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_phase1(VerifyWs ws) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_phase1(ws, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(VerifyWs ws) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_final_scalars(ws, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(VerifyWs ws, int* reject_count) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) {
+        verify_accept(ws, t);
+        if (reject_count && !ws.accept[t]) atomicAdd(reject_count, 1);
+    }
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept_flagged(VerifyWs ws, RlcWs r, int* reject_count) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= ws.N) return;
+    if (r.flag[t / BPPP_RLC_CHUNK]) verify_accept(ws, t);
+    if (reject_count && !ws.accept[t]) atomicAdd(reject_count, 1);
+}
+// generator decoding + validation (context creation): 64-B big-endian -> device affine; flags[0] |= 1 on a bad point
+__global__ void k_decode_generators(const uint8_t* in, apt* out, int n, int* flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    apt a;
+    if (!apt_from_xy64(a, in + 64 * i)) atomicOr(flags, 1);
+    out[i] = a;
+}
+// wire format: 16 lanes per proof (14 points + scalar copy), SEC1 compressed -> the 64-byte form
+__global__ __launch_bounds__(256) void k_sec1_expand(uint8_t* commitments64, uint8_t* proofs928, const uint8_t* commitments33,
+                                                     const uint8_t* proofs525, size_t n) {
+    size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t t = g / 16;
+    int j = (int)(g % 16);
+    if (t < n && j < 15) sec1_expand_lane(commitments64, proofs928, commitments33, proofs525, t, j);
+}

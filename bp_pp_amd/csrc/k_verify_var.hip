@@ -1,0 +1,23 @@
+// u64 verifier: the one-lane-per-proof shared-doubling kernels (window tables, C0 variable-base half, WNLA rounds, RLC left-hand side).
+// Part of libbppp_hip.so; per-lane work lives in the *_core.h headers, declarations in kernels.h.
+#include "kernels.h"
+
+using namespace bppp;
+
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables(VerifyWs ws) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_tables(ws, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_c0_var(VerifyWs ws) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_c0_var(ws, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_round(VerifyWs ws, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_round(ws, t, k);
+}
+// ---- random-linear-combination batch mode (rlc_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(VerifyWs ws, RlcWs r) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) rlc_lhs(ws, r, t);
+}

@@ -1,0 +1,97 @@
+// Kernel declarations shared by the kernel translation units (k_*.hip) and the host side (bppp_hip.hip).
+// The kernels are split over several translation units so that hipcc compiles them in parallel (the u64 verifier's
+// shared-doubling kernels alone take minutes); a kernel is launched from the host TU through its declaration here.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "circuit_prove_core.h"
+#include "prove_core.h"
+#include "recip_core.h"
+#include "recip_prove_core.h"
+#include "rlc_core.h"
+#include "wnla_prove_core.h"
+
+#define BPPP_BLOCK 64
+// One-lane-per-proof kernels of the u64 verifier: minimum waves per SIMD the register allocator must leave room for
+// (2 => at most 256 VGPR + AGPR per lane, so two wavefronts share a SIMD and cover each other's table-gather latency).
+#ifndef BPPP_LANE_MIN_WAVES
+#define BPPP_LANE_MIN_WAVES 1
+#endif
+// fixed-base MSM kernels: BPPP_FB_LANES lanes per proof, 256-thread workgroups
+#define BPPP_FB_BLOCK 256
+#ifndef BPPP_FB_MIN_WAVES
+#define BPPP_FB_MIN_WAVES 2
+#endif
+
+namespace bppp {
+// ---- generic fixed-base linear combination over the context's generators (the crate's commit functions)
+struct MsmWs {
+    size_t N;
+    int nterms, nruns;
+    const uint8_t* scalars;     // N x nterms x 32
+    const int* runs;            // [nruns][3]: first scalar slot, first base, count
+    u32* msc;                   // [nterms * 8][N]
+    u32* pfix;                  // [30][N]
+    int32_t* status;
+    uint8_t* out;               // N x 64
+    FbTable fb;
+};
+}  // namespace bppp
+using bppp::MsmWs;
+
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_phase1(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_c0_var(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_round(bppp::VerifyWs ws, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(bppp::VerifyWs ws, int* reject_count);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(bppp::VerifyWs ws, bppp::RlcWs r);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(bppp::VerifyWs ws, bppp::RlcWs r);
+__global__ __launch_bounds__(64) void k_verify_final_check_flagged(bppp::VerifyWs ws, bppp::RlcWs r);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_flagged_dense(bppp::VerifyWs ws, bppp::RlcWs r);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept_flagged(bppp::VerifyWs ws, bppp::RlcWs r, int* reject_count);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass1(bppp::FbBuild fb, size_t nthreads);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass2(bppp::FbBuild fb, size_t nthreads);
+__global__ void k_decode_generators(const uint8_t* in, bppp::apt* out, int n, int* flags);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(bppp::VerifyWs ws, const uint64_t* x, const uint8_t* s, uint8_t* out, int* flags);
+__global__ __launch_bounds__(256) void k_sec1_expand(uint8_t* commitments64, uint8_t* proofs928, const uint8_t* commitments33, const uint8_t* proofs525, size_t n);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_a(bppp::ProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_b(bppp::ProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d(bppp::ProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f(bppp::ProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(bppp::ProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(bppp::ProveWs w, int k);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(bppp::ProveWs w, bppp::MsmJob job);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_scalars(bppp::WnlaWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(bppp::WnlaWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round(bppp::WnlaWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars(bppp::WnlaWs w);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(bppp::WnlaWs w, int commit_mode);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(bppp::WnlaWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(bppp::WnlaWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_init(bppp::WnlaProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_scalars(bppp::WnlaProveWs w, int k);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wprove_msm(bppp::WnlaProveWs w, int set);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_fold(bppp::WnlaProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_finish(bppp::WnlaProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_a(bppp::CircuitProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_b(bppp::CircuitProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_c(bppp::CircuitProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_d(bppp::CircuitProveWs w);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_cprove_msm(bppp::CircuitProveWs w, int set, int with_g);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_rprove_stage_r1(bppp::RecipProveWs w);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rprove_msm(bppp::RecipProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_rprove_stage_r2(bppp::RecipProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_msm_scalars(bppp::MsmWs w);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_msm(bppp::MsmWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_msm_store(bppp::MsmWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_phase1(bppp::CircuitWs w);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_circuit_c0_fixed(bppp::CircuitWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_var(bppp::CircuitWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_finish(bppp::CircuitWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1(bppp::RecipWs w);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed(bppp::RecipWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var(bppp::RecipWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_finish(bppp::RecipWs w);
