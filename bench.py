@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- u64 range-proof batch verification throughput on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the exact per-proof verify pipeline over one batch of synthetic proofs that is already
-resident in HBM (BASELINE.json configs[1]: 2^16 independent proofs per GPU, one shared generator set).  With N > 1
-(launched by torch.distributed.run, one rank per GPU) every rank verifies its own shard of different proofs (weak
-scaling, no data-path collective) and the per-step reject count is all-reduced over RCCL -- the single accept-reduce of
-BASELINE.json configs[2].
+Default workload (BASELINE.json configs[2], the configuration `north_star` quotes the metric on): ONE fixed batch of 2^20
+independent u64 range proofs that share one generator set, split contiguously by proof index over the N GPUs
+(`shard_range`: 2^20 / N proofs per GPU; N = 1 keeps all 2^20 resident on one GPU) -- strong scaling.  One "step" = one pass
+of the exact per-proof verify pipeline over the whole batch, inputs already resident in HBM, followed by the single
+accept-reduce: one 4-byte all-reduce of the reject count over RCCL (a no-op at N = 1).  There is no data-path collective.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel: algorithmic bytes per launch (559 B/verify) / its average launch
-                  duration, measured with HIP events on the launch stream inside the timed region, against 8 TB/s.
+  roofline     -- dominant kernel: algorithmic bytes per launch (559 B/verify, SURVEY.md 8d, x the proofs one launch
+                  processes) / its average launch duration, measured with HIP events on the launch stream inside the timed
+                  region, against 8 TB/s; `traffic` = measured HBM bytes per launch from the committed PMC passes.
   cpu_baseline -- the reference-shaped C restatement (oracle/, kind "port": the Rust reference cannot be built here)
-                  timed on this box's host cores on a bounded sample of the same workload.
+                  timed on this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+Secondary objects (never `value`): configs[1] (2^16 proofs on one GPU), the optional RLC batch mode, the host-buffer
+(PCIe-inclusive) entry point.
+
+Other workloads, each printing its own JSON line with `roofline` and `cpu_baseline`:
+  --workload prove     BASELINE configs[3]: batch-prove 2^14 u64 values on one GPU (2262 algorithmic B/prove)
+  --workload recip256  BASELINE configs[4]'s shape: ReciprocalRangeProofProtocol (dim_nd 256, dim_np 16) batch verify
+                       (823 algorithmic B/verify)
 """
 import argparse
 import json
@@ -24,32 +32,74 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_VERIFY = 13 * 33 + 3 * 32 + 33 + 1   # 559 B: SEC1 proof + commitment + accept byte
+ALGO_BYTES_PER_PROVE = 8 + 32 + 52 * 32 + 13 * 33 + 96 + 33   # 2262 B
+ALGO_BYTES_PER_RECIP256 = 21 * 33 + 96 + 33 + 1     # 823 B
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8.0 TB/s spec
+# VALU issue ceilings for the 256-bit integer mix (G wave-instructions/s per chip):
+#   datasheet: 1024 SIMDs x 2.4 GHz; a wave64 full-rate op issues in 2 cycles, v_mad_u64_u32 / 64-bit shifts in 4
+#   measured : tools/intbench.hip on this chip (profiles/r01_a_intbench.txt): 29 T lane-ops/s for v_mad_u64_u32, 67 T for add/logic
+DATASHEET_SIMD_HZ = 1024 * 2.4e9
+MEASURED_MAD_LANE_OPS = 29e12
+MEASURED_ADD_LANE_OPS = 67e12
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--proofs-per-gpu", type=int, default=1 << 16)
-    ap.add_argument("--fb-window-bits", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="proofs verified by the CPU baseline (rank 0, N=1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-rlc", action="store_true", help="skip the secondary measurement of the optional RLC batch mode")
-    args = ap.parse_args()
+def _load_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
-    import numpy as np
+
+def valu_roofline(kernel, avg_ms, n_proofs, lanes_per_proof):
+    """Compute-side ceiling of one kernel: VALU wave-instructions per launch (SQ_INSTS_VALU per wave from the committed
+    rocprofv3 --pmc pass, times the waves this launch ran) over the live-measured launch time, against the issue rate of the
+    kernel's own instruction mix.  The mix (fraction of half-rate 64-bit multiply-add / shift instructions) comes from the
+    kernel's disassembly (tools/isa_mix.py -> profiles/isa_mix.json), not from a constant."""
+    pv = _load_json(os.path.join(ROOT, "profiles", "pmc_valu.json")) or {}
+    mix = _load_json(os.path.join(ROOT, "profiles", "isa_mix.json")) or {}
+    kv = pv.get(kernel, {})
+    per_wave = kv.get("valu_insts_per_wave")
+    half = (mix.get(kernel) or {}).get("half_rate_frac")
+    if not per_wave or half is None:
+        return None
+    waves = (n_proofs * lanes_per_proof + 63) // 64
+    insts = per_wave * waves
+    ach = insts / (avg_ms * 1e-3) / 1e9
+    peak_ds = DATASHEET_SIMD_HZ / (half * 4 + (1 - half) * 2) / 1e9
+    peak_ms = 1.0 / (half / (MEASURED_MAD_LANE_OPS / 64) + (1 - half) / (MEASURED_ADD_LANE_OPS / 64)) / 1e9
+    return {"kernel": kernel, "wave_insts_per_launch": insts, "achieved": ach, "unit": "G wave-instructions/s",
+            "half_rate_inst_frac": half, "mix_source": "static ISA count of the shipped code object (tools/isa_mix.py)",
+            "peak_datasheet": peak_ds, "frac_of_datasheet": ach / peak_ds,
+            "peak_microbench": peak_ms, "frac_of_microbench": ach / peak_ms,
+            "valu_active_frac_of_wave_cycles": kv.get("SQ_ACTIVE_INST_VALU_frac_of_wave_cycles"),
+            "wait_frac_of_wave_cycles": kv.get("SQ_WAIT_ANY_frac_of_wave_cycles")}
+
+
+def pmc_traffic(kernel, n_proofs):
+    """Measured HBM bytes per launch of `kernel` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, corrected
+    as tools/pmc_summarize.py documents), scaled linearly if the committed pass ran a different batch size."""
+    tr = _load_json(os.path.join(ROOT, "profiles", "pmc_traffic.json")) or {}
+    k = (tr.get("kernels") or {}).get(kernel) or {}
+    b = k.get("hbm_bytes_per_launch")
+    if b is None:
+        return None
+    n_ref = k.get("proofs_per_launch") or tr.get("proofs_per_launch") or 65536
+    return b * (n_proofs / n_ref)
+
+
+FB_KERNELS = ("k_verify_c0_fixed", "k_verify_final_check", "k_prove_msm", "k_wnla_msm", "k_recip_c0_fixed")
+
+
+def setup_dist(args):
     import torch
     import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
-            sys.exit(2)
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the bp_pp_amd product path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
@@ -57,45 +107,108 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    return world, rank, local_rank
 
-    from bp_pp_amd import U64RangeProofProtocol, synth as workload
-    from bp_pp_amd.distributed import all_reduce_reject_count
 
-    # Setup (untimed).  Generators: the 49 seeded points of the committed fixture (data, tests/golden/u64_golden.json).
-    # Proofs: produced by the product's own batch prover on this GPU from seeded (x, s, 52 prover scalars); the
-    # cpu_baseline leg below re-verifies a sample of them with the independent CPU oracle.
+def load_generators():
     with open(os.path.join(ROOT, "tests", "golden", "u64_golden.json")) as f:
         gens = bytes.fromhex(json.load(f)["generators"])
-    g, gv, hv = gens[:64], [gens[64 * i:64 * i + 64] for i in range(1, 17)], [gens[64 * i:64 * i + 64] for i in range(17, 49)]
-    n = args.proofs_per_gpu
-    t0 = time.time()
-    proto = U64RangeProofProtocol(g, gv, hv, device=local_rank, fb_window_bits=args.fb_window_bits)
-    torch.cuda.synchronize()
-    t_ctx = time.time() - t0
-    t0 = time.time()
-    x = workload.values(n, first=rank * n)
-    s_bl = workload.blindings(n, first=rank * n)
-    rnd = workload.prover_randomness(n, first=rank * n)
-    t_inputs = time.time() - t0
-    t0 = time.time()
-    P, V, pst = proto.prove_batch(x, s_bl, rnd, workload.LABEL)
-    t_gen = time.time() - t0
-    if pst.any():
+    return gens, gens[:64], [gens[64 * i:64 * i + 64] for i in range(1, 17)], [gens[64 * i:64 * i + 64] for i in range(17, 49)]
+
+
+def make_resident_batch(torch, proto, workload, lo, hi, corrupt_every=1024, slice_proofs=1 << 16):
+    """Proofs lo..hi of the global synthetic batch, made by the product's batch prover on this GPU in slices and left resident:
+    returns (dV [n,64], dP [n,928], expect [n] u8 numpy, seconds spent proving).  One proof in `corrupt_every` (by GLOBAL
+    index) gets one bit of l0/l1/n0 flipped and must be rejected."""
+    import numpy as np
+    n = hi - lo
+    dV = torch.empty((n, 64), dtype=torch.uint8, device="cuda")
+    dP = torch.empty((n, 928), dtype=torch.uint8, device="cuda")
+    dSt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    t_prove = 0.0
+    for a in range(0, n, slice_proofs):
+        b = min(n, a + slice_proofs)
+        x = torch.from_numpy(workload.bulk_values(b - a, first=lo + a).view(np.int64)).cuda()
+        s = torch.from_numpy(workload.bulk_blindings(b - a, first=lo + a)).cuda()
+        r = torch.from_numpy(workload.bulk_prover_randomness(b - a, first=lo + a)).cuda()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        proto.prove_batch_device(workload.LABEL, b - a, x.data_ptr(), s.data_ptr(), r.data_ptr(), dP[a:b].data_ptr(), dV[a:b].data_ptr(),
+                                 dSt[a:b].data_ptr())
+        proto.synchronize()
+        t_prove += time.perf_counter() - t0
+        del x, s, r
+    if bool(dSt.any().item()):
         print("bench.py: prover reported a status flag", file=sys.stderr)
         sys.exit(4)
-    P, expect = workload.corrupt(P, every=1024)
+    expect = np.ones(n, dtype=np.uint8)
+    first_bad = (-lo) % corrupt_every
+    idx = np.arange(first_bad, n, corrupt_every, dtype=np.int64)
+    if len(idx):
+        offs = np.array([workload.corrupt_offset(lo + int(j)) for j in idx], dtype=np.int64)
+        ti, to = torch.from_numpy(idx).cuda(), torch.from_numpy(offs).cuda()
+        dP[ti, to] = dP[ti, to] ^ 1
+        expect[idx] = 0
+    torch.cuda.synchronize()
+    return dV, dP, expect, t_prove
 
-    dV = torch.from_numpy(V).cuda()
-    dP = torch.from_numpy(P).cuda()
+
+def cpu_baseline_verify(gens, label, V, P, acc_gpu, sample_note):
+    """The oracle, as the timed CPU baseline ONLY: reference-shaped C restatement on the host cores, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bppp_oracle_c as OC
+    m = V.shape[0]
+    hw = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    OC.u64_verify_batch(gens, label, V[:64].copy(), P[:64].copy(), nthreads=1)
+    single = 64 / (time.perf_counter() - t0)
+    best = None
+    ladder = sorted({hw, max(1, hw // 4), min(hw, 16)}, reverse=True)
+    for th in ladder:
+        t0 = time.perf_counter()
+        oacc, _ = OC.u64_verify_batch(gens, label, V.copy(), P.copy(), nthreads=th)
+        dt = time.perf_counter() - t0
+        if best is None or m / dt > best[0]:
+            best = (m / dt, th, dt, bool((oacc == acc_gpu[:m]).all()))
+    return {"value": best[0], "unit": "verifies/s", "cores": best[1], "kind": "port",
+            "sample": f"{sample_note}, reference-shaped C restatement (oracle/bppp_ref.c); best of thread counts {ladder} = "
+                      f"{best[1]} threads, {best[2]:.2f} s wall; box reports {hw} hardware threads",
+            "single_thread_value": single, "agrees_with_gpu": best[3]}
+
+
+def run_verify(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    world, rank, local_rank = setup_dist(args)
+    from bp_pp_amd import U64RangeProofProtocol, synth as workload
+    from bp_pp_amd.distributed import all_reduce_reject_count, shard_range
+
+    gens, g, gv, hv = load_generators()
+    total = args.total_proofs
+    lo, hi = shard_range(total, rank, world)
+    n = hi - lo
+    t0 = time.time()
+    proto = U64RangeProofProtocol(g, gv, hv, device=local_rank, fb_window_bits=args.fb_window_bits)
+    proto.synchronize()
+    t_ctx = time.time() - t0
+    t0 = time.time()
+    dV, dP, expect, t_prove = make_resident_batch(torch, proto, workload, lo, hi)
+    t_setup = time.time() - t0
+
     dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
     dS = torch.zeros(n, dtype=torch.int32, device="cuda")
     dR = torch.zeros(1, dtype=torch.int32, device="cuda")
-    stream = torch.cuda.current_stream()
+    # one explicit stream for the verify kernels AND the accept-reduce, so that NCCL's stream dependency covers the kernels that
+    # write the reject count (the context's own streams are non-blocking: not ordered against torch's default stream)
+    stream = torch.cuda.Stream()
     proto.set_stream(stream.cuda_stream)
 
-    def step():
-        proto.verify_batch_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, dR.data_ptr())
-        all_reduce_reject_count(dR)                     # the single accept-reduce (4 bytes over RCCL/xGMI); no-op at N=1
+    def step(nn=n, acc=dA, rej=dR):
+        with torch.cuda.stream(stream):
+            proto.verify_batch_device(workload.LABEL, nn, dV.data_ptr(), dP.data_ptr(), acc.data_ptr(), dS.data_ptr(), 0, rej.data_ptr())
+            if nn == n:
+                all_reduce_reject_count(rej)            # the single accept-reduce (4 bytes over RCCL/xGMI); no-op at N=1
 
     def fence():
         if world > 1:
@@ -116,17 +229,51 @@ def main():
     kernel_times = proto.timings(reset=True)
     proto.enable_timing(False)
 
-    # secondary, reported separately and never as `value`: the optional random-linear-combination batch mode on the same
-    # resident inputs (per-proof accept bits, identical unless a forged chunk passes with probability <= 2^-128)
-    rlc = None
-    if not args.no_rlc:
+    # correctness of what was just timed (untimed): accept bits == expectation, global reject count == corrupted proofs
+    acc = dA.cpu().numpy()
+    st = dS.cpu().numpy()
+    ok_local = bool((acc == expect).all() and not st.any())
+    rejects = int(dR.item())
+    expected_rejects = len(range(0, total, 1024))
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- secondary measurements, reported separately and never as `value`
+    cfg1 = rlc = host_path = None
+    if world == 1 and not args.no_secondary:
+        m = min(n, 1 << 16)
+        dA1 = torch.zeros(m, dtype=torch.uint8, device="cuda")
+        dR1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+        step(m, dA1, dR1)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(max(args.steps, 10)):
+            step(m, dA1, dR1)
+        fence()
+        t1 = (time.perf_counter() - t1) / max(args.steps, 10)
+        cfg1 = {"workload": f"BASELINE configs[1]: the first {m} proofs of the same resident batch on one GPU", "value": m / t1,
+                "unit": "verifies/s", "ms_per_step": t1 * 1e3, "accept_bits_ok": bool((dA1.cpu().numpy() == expect[:m]).all())}
+        V16, P16 = dV[:m].cpu().numpy(), dP[:m].cpu().numpy()
+        proto.verify_batch(V16, P16, workload.LABEL)
+        t_h = time.perf_counter()
+        hacc, _ = proto.verify_batch(V16, P16, workload.LABEL)
+        t_h = time.perf_counter() - t_h
+        host_path = {"value": m / t_h, "unit": "verifies/s", "ms_per_batch": t_h * 1e3, "proofs": m,
+                     "accept_bits_ok": bool((hacc == expect[:m]).all()),
+                     "note": "bppp_u64_verify_batch with pageable host buffers: 65 MB host-to-device per batch included"}
+    if not args.no_secondary:
         dA2 = torch.zeros(n, dtype=torch.uint8, device="cuda")
         dR2 = torch.zeros(1, dtype=torch.int32, device="cuda")
         seed = os.urandom(32)
 
         def rlc_step():
-            proto.verify_batch_rlc_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA2.data_ptr(), seed, dS.data_ptr(), dR2.data_ptr())
-            all_reduce_reject_count(dR2)
+            with torch.cuda.stream(stream):
+                proto.verify_batch_rlc_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA2.data_ptr(), seed, dS.data_ptr(), dR2.data_ptr())
+                all_reduce_reject_count(dR2)
 
         rlc_step()
         fence()
@@ -134,78 +281,23 @@ def main():
         for _ in range(args.steps):
             rlc_step()
         fence()
-        rlc_elapsed = time.perf_counter() - t_r
-        rt = torch.tensor([rlc_elapsed], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(rt, op=dist.ReduceOp.MAX)
-        rlc = {"value": n * world * args.steps / float(rt.item()), "unit": "verifies/s", "ms_per_step": float(rt.item()) / args.steps * 1e3,
-               "accept_bits_equal_exact_mode": bool((dA2 == dA).all().item()) and int(dR2.item()) == int(dR.item()),
-               "note": "optional mode (bppp_u64_verify_batch_rlc_device): one 49-base MSM per chunk of 8 proofs instead of one per "
-                       "proof, failing chunks re-checked exactly; NOT the headline metric"}
+        t_r = max_over_ranks(time.perf_counter() - t_r)
+        rlc = {"value": total * args.steps / t_r, "unit": "verifies/s", "ms_per_step": t_r / args.steps * 1e3,
+               "accept_bits_equal_exact_mode": bool((dA2 == dA).all().item()) and int(dR2.item()) == rejects,
+               "note": "optional mode (bppp_u64_verify_batch_rlc_device): random linear combination of the final checks, failing "
+                       "chunks re-checked exactly; NOT the headline metric"}
 
-    # informative only: the host-buffer entry point (bppp_u64_verify_batch: pageable host arrays in, accept bits out), i.e. the
-    # PCIe-inclusive rate.  Never `value`.
-    host_path = None
-    if world == 1:
-        proto.verify_batch(V, P, workload.LABEL)
-        t_h = time.perf_counter()
-        hacc, _ = proto.verify_batch(V, P, workload.LABEL)
-        t_h = time.perf_counter() - t_h
-        host_path = {"value": n / t_h, "unit": "verifies/s", "ms_per_batch": t_h * 1e3,
-                     "note": "bppp_u64_verify_batch with pageable host buffers: 65 MB host-to-device per batch included"}
-
-    # correctness of what was just timed (untimed): accept bits == expectation, reject count == corrupted proofs
-    acc = dA.cpu().numpy()
-    st = dS.cpu().numpy()
-    ok_local = bool((acc == expect).all() and not st.any())
-    rejects = int(dR.item())
-    expected_rejects = int((expect == 0).sum()) * world
-
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    elapsed = max_over_ranks(elapsed)
     ok_all = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device="cuda")
     if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
-    elapsed = float(t_max.item())
     ok = bool(ok_all.item()) and rejects == expected_rejects
 
     if rank == 0:
-        total = n * world * args.steps
-        value = total / elapsed
-        dom = max(kernel_times.items(), key=lambda kv: kv[1]["total_ms"])
-        dom_name, dom_t = dom
+        value = total * args.steps / elapsed
+        dom_name, dom_t = max(kernel_times.items(), key=lambda kv: kv[1]["total_ms"])
         avg_ms = dom_t["total_ms"] / max(1, dom_t["launches"])
         achieved = ALGO_BYTES_PER_VERIFY * n / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tr_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # per-launch HBM bytes from the committed rocprofv3 --pmc run
-        if os.path.exists(tr_path):
-            try:
-                traffic = json.load(open(tr_path)).get("kernels", {}).get(dom_name, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # compute-side ceiling of the same kernel: VALU wave-instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU pass,
-        # profiles/pmc_valu.json, scaled to this batch size) over the live-measured launch time, against the issue rate the
-        # chip sustains for this kernel's instruction mix (tools/intbench.hip: 64-bit multiply-add 29 T lane-ops/s, add/logic
-        # 67 T lane-ops/s; the field arithmetic is ~49 % multiply-adds)
-        valu = None
-        vp_path = os.path.join(ROOT, "profiles", "pmc_valu.json")
-        if os.path.exists(vp_path):
-            try:
-                kv = json.load(open(vp_path)).get(dom_name, {})
-                per_wave = kv.get("valu_insts_per_wave")
-                lanes_per_proof = 8 if dom_name in ("k_verify_c0_fixed", "k_verify_final_check") else 1
-                if per_wave:
-                    waves = (n * lanes_per_proof + 63) // 64
-                    insts = per_wave * waves
-                    mad_frac = 0.49
-                    peak = 1.0 / (mad_frac / (29e12 / 64) + (1 - mad_frac) / (67e12 / 64)) / 1e9
-                    ach = insts / (avg_ms * 1e-3) / 1e9
-                    valu = {"kernel": dom_name, "wave_insts_per_launch": insts, "achieved": ach, "peak": peak,
-                            "unit": "G wave-instructions/s", "frac": ach / peak,
-                            "valu_active_frac_of_wave_cycles": kv.get("SQ_ACTIVE_INST_VALU_frac_of_wave_cycles"),
-                            "wait_frac_of_wave_cycles": kv.get("SQ_WAIT_ANY_frac_of_wave_cycles")}
-            except Exception:
-                valu = None
         result = {
             "metric": "u64 range-proof batch verifies/sec",
             "value": value,
@@ -215,15 +307,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"batch verify {n} independent u64 range proofs per GPU (BASELINE configs[1]), exact per-proof mode, "
-                            "shared generators, inputs resident in HBM, 1/1024 proofs corrupted",
+                "workload": f"batch verify ONE fixed batch of {total} independent u64 range proofs (BASELINE configs[2]; "
+                            f"{'all resident on one GPU' if world == 1 else f'sharded contiguously over {world} GPUs, {n} proofs per GPU'}), "
+                            "exact per-proof mode, shared generators, inputs resident in HBM, 1/1024 proofs corrupted, one 4-byte "
+                            "reject-count all-reduce per step",
+                "total_proofs_per_step": total,
                 "proofs_per_gpu": n,
-                "total_proofs_per_step": n * world,
                 "fb_window_bits": args.fb_window_bits or 22,
                 "label": workload.LABEL.decode(),
                 "parallelism": f"shard{world}" if world > 1 else "single",
@@ -235,55 +329,55 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": pmc_traffic(dom_name, n),
                 "avg_launch_ms": avg_ms,
+                "launches_per_step": dom_t["launches"] / args.steps,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_VERIFY * n,
                 "note": "256-bit modular integer path: VALU issue bound, HBM fraction is small by construction "
                         "(SURVEY.md 8d); roofline_valu is the ceiling that binds",
             },
-            "roofline_valu": valu,
-            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kernel_times.items()},
+            "roofline_valu": valu_roofline(dom_name, avg_ms, n, 8 if dom_name in FB_KERNELS else 1),
+            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kernel_times.items() if v["launches"]},
             "accept_bits_ok": ok,
+            "reject_count_all_reduced": rejects,
+            "configs1_2pow16": cfg1,
             "rlc_mode": rlc,
             "host_buffer_path": host_path,
-            "setup_s": {"seeded_inputs_host": t_inputs, "gpu_batch_prove_incl_pcie": t_gen, "context_tables": t_ctx},
-            "prover": {"proofs_per_s_incl_pcie": n / t_gen, "note": "setup only (BASELINE configs[3] path), not the headline metric"},
+            "setup_s": {"context_tables": t_ctx, "inputs_and_gpu_batch_prove": t_setup, "gpu_batch_prove_only": t_prove},
+            "prover": {"proofs_per_s_device_buffers": n / t_prove, "note": "setup only; see --workload prove for BASELINE configs[3]"},
             "device_bytes": proto.device_bytes(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import bppp_oracle_c as OC                 # the oracle, as the timed CPU baseline ONLY
             m = min(args.cpu_sample, n)
-            hw = os.cpu_count() or 1
-            # one thread first (64 proofs), then every thread count in a short ladder: containers often expose more hardware
-            # threads than their CPU quota, so the best rate and the thread count that gave it are what is reported
-            t0 = time.perf_counter()
-            OC.u64_verify_batch(gens, workload.LABEL, V[:64].copy(), P[:64].copy(), nthreads=1)
-            single = 64 / (time.perf_counter() - t0)
-            best = None
-            ladder = sorted({hw, max(1, hw // 2), max(1, hw // 4), max(1, hw // 8), min(hw, 16)}, reverse=True)
-            for th in ladder:
-                t0 = time.perf_counter()
-                oacc, ost = OC.u64_verify_batch(gens, workload.LABEL, V[:m].copy(), P[:m].copy(), nthreads=th)
-                dt = time.perf_counter() - t0
-                if best is None or m / dt > best[0]:
-                    best = (m / dt, th, dt, bool((oacc == acc[:m]).all()))
-            result["cpu_baseline"] = {
-                "value": best[0],
-                "unit": "verifies/s",
-                "cores": best[1],
-                "kind": "port",
-                "sample": f"first {m} proofs of the same batch, reference-shaped C restatement (oracle/bppp_ref.c); best of thread "
-                          f"counts {ladder} = {best[1]} threads, {best[2]:.2f} s wall; box reports {hw} hardware threads",
-                "single_thread_value": single,
-                "agrees_with_gpu": best[3],
-            }
+            result["cpu_baseline"] = cpu_baseline_verify(gens, workload.LABEL, dV[:m].cpu().numpy(), dP[:m].cpu().numpy(), acc,
+                                                         f"first {m} proofs of the same batch")
         print(json.dumps(result), flush=True)
     proto.close()
     if world > 1:
         dist.destroy_process_group()
     if not ok:
         sys.exit(1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["verify", "prove", "recip256"], default="verify")
+    ap.add_argument("--total-proofs", type=int, default=0, help="size of the fixed global batch (default: 2^20 verify, 2^14 prove, 2^12 recip256)")
+    ap.add_argument("--fb-window-bits", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="proofs verified by the CPU baseline (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs[1], RLC mode, host-buffer path)")
+    args = ap.parse_args()
+    if args.workload == "verify":
+        args.total_proofs = args.total_proofs or (1 << 20)
+        run_verify(args)
+    else:
+        import bench_other
+        args.total_proofs = args.total_proofs or ((1 << 14) if args.workload == "prove" else (1 << 12))
+        (bench_other.run_prove if args.workload == "prove" else bench_other.run_recip256)(args)
 
 
 if __name__ == "__main__":

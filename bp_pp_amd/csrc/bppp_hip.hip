@@ -57,6 +57,7 @@ struct bppp_ctx {
     size_t cap = 0;
     u32* d_ws = nullptr;
     size_t ws_bytes = 0;
+    size_t scap = 0;
     pt_slot* d_straus = nullptr;
     size_t straus_bytes = 0;
     // u64 verifier: affine window tables of the 13 proof points + the scratch of the kernel that builds them
@@ -82,6 +83,7 @@ struct bppp_ctx {
     size_t expand_bytes = 0;
     int* d_flags = nullptr;
     bool timing = false;
+    bool serial_c0 = false, rlc_debug = false;   // diagnostics, read from the environment once at context creation
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> event_pool;
     double total_ms[K_COUNT] = {0};
@@ -93,14 +95,23 @@ static const size_t WS_WORDS_PER_PROOF = 52 + 80 + 176 + 200 + 208 + 24 + 30 + 3
 static int ensure_capacity(bppp_ctx* c, size_t n) {
     if (n <= c->cap) return BPPP_OK;
     if (c->d_ws) { (void)hipFree(c->d_ws); c->d_ws = nullptr; }
-    if (c->d_straus) { (void)hipFree(c->d_straus); c->d_straus = nullptr; }
     c->cap = 0;
     size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
     c->ws_bytes = cap * WS_WORDS_PER_PROOF * sizeof(u32);
-    c->straus_bytes = cap * 5 * BPPP_STRAUS_ENTRIES * sizeof(pt_slot);
     HIP_TRY(hipMalloc(&c->d_ws, c->ws_bytes));
-    HIP_TRY(hipMalloc(&c->d_straus, c->straus_bytes));
     c->cap = cap;
+    return BPPP_OK;
+}
+// projective window tables of the generic WNLA / circuit / reciprocal paths and of the provers (5.6 KB per instance); the u64
+// verifier keeps its own affine tables (ensure_vtab_capacity) and never touches these
+static int ensure_straus_capacity(bppp_ctx* c, size_t n) {
+    if (n <= c->scap) return BPPP_OK;
+    if (c->d_straus) { (void)hipFree(c->d_straus); c->d_straus = nullptr; }
+    c->scap = 0;
+    size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    c->straus_bytes = cap * 5 * BPPP_STRAUS_ENTRIES * sizeof(pt_slot);
+    HIP_TRY(hipMalloc(&c->d_straus, c->straus_bytes));
+    c->scap = cap;
     return BPPP_OK;
 }
 static int ensure_vtab_capacity(bppp_ctx* c, size_t n) {
@@ -130,7 +141,9 @@ static int ensure_rlc_capacity(bppp_ctx* c, size_t n) {
 }
 static const size_t PWS_WORDS_PER_PROOF = 52 + (size_t)SV_COUNT * 8 + (size_t)BPPP_MSC_SETS * BPPP_NG * 8 + (size_t)PB_COUNT * 30;
 static int ensure_prove_capacity(bppp_ctx* c, size_t n) {
-    int rc = ensure_capacity(c, n);   // Straus tables are shared with the verifier workspace
+    int rc = ensure_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    rc = ensure_straus_capacity(c, n);
     if (rc != BPPP_OK) return rc;
     if (n <= c->pcap) return BPPP_OK;
     if (c->d_pws) { (void)hipFree(c->d_pws); c->d_pws = nullptr; }
@@ -255,6 +268,8 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     if (!c) return BPPP_ERR_NOMEM;
     c->device = device;
     c->fb_w = W;
+    c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;
+    c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
     c->ng = (int)ng; c->nh = (int)nh; c->nbases = NB;
     auto fail = [&](int code) { bppp_ctx_destroy(c); return code; };
 #define HIP_TRY_C(expr)                                                             \
@@ -350,6 +365,14 @@ int bppp_ctx_set_stream(bppp_ctx* c, void* hip_stream) {
     return BPPP_OK;
 }
 
+int bppp_ctx_synchronize(bppp_ctx* c) {
+    if (!c) return BPPP_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->aux_stream));
+    return BPPP_OK;
+}
+
 size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
     if (!c) return 0;
     return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + (size_t)c->nbases * sizeof(apt);
@@ -398,6 +421,9 @@ static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_le
     if (rlc_seed) {
         rc = ensure_rlc_capacity(c, n);
         if (rc != BPPP_OK) return rc;
+        rc = ensure_straus_capacity(c, n);   // k_rlc_lhs keeps the window table of C4 there
+        if (rc != BPPP_OK) return rc;
+        ws.straus = c->d_straus;
         for (int i = 0; i < 4; i++) {
             u64 v = 0;
             for (int k = 0; k < 8; k++) v |= (u64)rlc_seed[8 * i + k] << (8 * k);
@@ -435,7 +461,7 @@ static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_le
     // C0 = variable-base half (window tables of the proof points, then the shared-doubling sum: one lane per proof, 1 wave
     // per SIMD) + fixed-base half (8 lanes per proof): independent, so they run concurrently on two streams and share the
     // SIMDs; round 1 adds the halves.
-    hipStream_t a = std::getenv("BPPP_SERIAL_C0") ? s : c->aux_stream;   // diagnostic: un-overlapped kernel times
+    hipStream_t a = c->serial_c0 ? s : c->aux_stream;   // diagnostic: un-overlapped kernel times
     LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
@@ -459,7 +485,7 @@ static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_le
         LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged<<<1024, 64, 0, s>>>(ws, rl));
         LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged_dense<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
         LAUNCH(K_ACCEPT, k_verify_accept_flagged<<<blocks, BPPP_BLOCK, 0, s>>>(ws, rl, (int*)d_reject_count));
-        if (std::getenv("BPPP_RLC_DEBUG")) {   // diagnostic: how many chunks went to the exact kernels
+        if (c->rlc_debug) {   // diagnostic: how many chunks went to the exact kernels
             std::vector<uint8_t> hf(nchunks);
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipMemcpy(hf.data(), rl.flag, nchunks, hipMemcpyDeviceToHost));
@@ -677,7 +703,7 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
                     uint8_t* accept, int32_t* status) {
     HIP_TRY(hipSetDevice(c->device));
     if (rounds > 12 || nl > 4096 || nn > 4096) return BPPP_ERR_INVALID_ARG;
-    int rc = ensure_capacity(c, n);   // Straus tables
+    int rc = ensure_straus_capacity(c, n);
     if (rc != BPPP_OK) return rc;
     const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds;
     // layout of the blob: inputs | outputs | workspace
@@ -766,7 +792,7 @@ int bppp_reciprocal_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label
         return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = ensure_capacity(c, n);
+    int rc = ensure_straus_capacity(c, n);
     if (rc != BPPP_OK) return rc;
     const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh;
     const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
@@ -889,7 +915,7 @@ int bppp_circuit_verify_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t*
     if (cd.nm > c->ng || cd.nv + 9 > c->nh || rounds > 12 || nl > 4096 || nn > 4096) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = ensure_capacity(c, n);
+    int rc = ensure_straus_capacity(c, n);
     if (rc != BPPP_OK) return rc;
     const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh, k = (size_t)cd.k, nm = (size_t)cd.nm, nv = (size_t)cd.nv;
     const size_t proof_bytes = 64 * (4 + 2 * rounds) + 32 * (nl + nn);

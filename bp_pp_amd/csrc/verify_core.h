@@ -1143,7 +1143,7 @@ HD void verify_final_check(const VerifyWs& ws, size_t t) {
 // byte form is 33-byte SEC1 compressed (02|03 || x; the identity is 33 zero bytes), and 32-byte big-endian scalars: a u64
 // proof is 13*33 + 3*32 = 525 bytes, its commitment 33.  One lane per point recovers y = sqrt(x^3 + 7) (p = 3 mod 4: one
 // exponentiation) and writes the 64-byte x||y form the verify pipeline reads.  An undecodable point (bad tag, x >= p,
-// x^3 + 7 a non-residue -- k256's from_bytes fails) becomes (x, 0), which is never on the curve, so verify_phase1 flags
+// x^3 + 7 a non-residue -- k256's from_bytes fails) becomes (1, 0), which is never on the curve, so verify_phase1 flags
 // BPPP_ST_BAD_ENCODING for that proof.
 #define BPPP_U64_PROOF_SEC1_BYTES 525
 HD void sec1_decompress_to_xy64(uint8_t* out64, const uint8_t* in33) {
@@ -1164,8 +1164,13 @@ HD void sec1_decompress_to_xy64(uint8_t* out64, const uint8_t* in33) {
     fe ny;
     fe_neg_m<1>(ny, y);
     fe_cmov(y, fe_is_odd(y) != ((tag & 1) != 0), ny);
-    fe zero;
+    // an undecodable point must never alias the identity (0, 0): it becomes (1, 0), which is off the curve for every tag and x
+    // (0 != 1 + 7), so verify_phase1 / apt_from_xy64 flag the proof.  (x, 0) would not do: x = 0 mod p -- 02||00..00, a bad tag
+    // over x = 0, 02||p -- would come out as 64 zero bytes, the identity's encoding.
+    fe zero, one;
     fe_set_u32(zero, 0);
+    fe_set_u32(one, 1);
+    fe_cmov(x, !ok, one);
     fe_cmov(y, !ok, zero);
     const bool identity = nz == 0;
     fe_cmov(x, identity, zero);

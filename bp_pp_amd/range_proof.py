@@ -150,7 +150,18 @@ class U64RangeProofProtocol:
 
     # ---- plumbing
     def set_stream(self, hip_stream: Optional[int]) -> None:
-        _capi.check(_capi.lib().bppp_ctx_set_stream(self._ctx, hip_stream or None))
+        """Run the context's kernels on a caller-owned hipStream_t (its raw handle); None restores the context's own stream.
+        The NULL (legacy default) stream cannot be selected -- its handle is 0, which the C ABI reads as "restore", and the
+        context's own streams are non-blocking, i.e. NOT ordered against the null stream.  Callers that want ordering with
+        their own work (torch ops, an RCCL all-reduce of the reject count) create a stream and run both on it:
+            s = torch.cuda.Stream(); proto.set_stream(s.cuda_stream); with torch.cuda.stream(s): ..."""
+        if hip_stream is not None and int(hip_stream) == 0:
+            raise ValueError("the null stream (handle 0) cannot be selected; pass a non-default stream, or None for the context's own")
+        _capi.check(_capi.lib().bppp_ctx_set_stream(self._ctx, hip_stream))
+
+    def synchronize(self) -> None:
+        """Block until everything queued on the context's current stream (and its helper stream) has finished."""
+        _capi.check(_capi.lib().bppp_ctx_synchronize(self._ctx))
 
     def enable_timing(self, on: bool = True) -> None:
         _capi.check(_capi.lib().bppp_ctx_enable_timing(self._ctx, 1 if on else 0))

@@ -45,6 +45,14 @@ def prover_randomness(n: int, first: int = 0, seed: bytes = SEED) -> np.ndarray:
     return _wide_scalars(b"rng", first, n, N_RNG_DRAWS_U64, seed)
 
 
+def corrupt_offset(j: int, seed: bytes = SEED) -> int:
+    """Byte of proof j whose low bit the negative set flips: inside l0 / l1 / n0, never one of their top bytes."""
+    off = 832 + 1 + (xof(b"neg", j, 1, seed)[0] % 95)
+    if off in (832, 864, 896):
+        off += 1
+    return off
+
+
 def corrupt(proofs: np.ndarray, every: int = 1024, seed: bytes = SEED):
     """Negative set: in one proof out of `every`, flip the low bit of one byte inside l0/l1/n0 (never a top byte, so the
     scalar stays canonical) -> the proof must be rejected.  Returns (proofs', expected_accept)."""
@@ -52,9 +60,53 @@ def corrupt(proofs: np.ndarray, every: int = 1024, seed: bytes = SEED):
     n = p.shape[0]
     expect = np.ones(n, dtype=np.uint8)
     for j in range(0, n, every):
-        off = 832 + 1 + (xof(b"neg", j, 1, seed)[0] % 95)
-        if off in (832, 864, 896):
-            off += 1
-        p[j, off] ^= 0x01
+        p[j, corrupt_offset(j, seed)] ^= 0x01
         expect[j] = 0
     return p, expect
+
+
+# ---------------------------------------------------------------- bulk inputs for the full-size batches (2^17 .. 2^20 proofs)
+# The per-proof XOF calls above cost ~25 us each in Python; a 2^20-proof batch needs 5.6e7 scalars (1.7 GB).  The bulk
+# generators draw every chunk of BULK_CHUNK proofs from a counter-based generator (numpy's Philox: raw 64-bit output, stable
+# across numpy versions) keyed by SHAKE256(seed, tag, chunk index) -- so any rank can produce exactly its own shard of a fixed
+# global batch -- and make scalars canonical by clearing the top four bits (uniform below 2^252 < n) instead of a wide
+# reduction: the prover takes any canonical scalars, and the bench only needs reproducible ones.  Forced edge-case values
+# are kept.
+BULK_CHUNK = 1 << 14
+
+
+def _bulk_bytes(tag: bytes, first: int, n: int, per_proof_bytes: int, seed: bytes) -> np.ndarray:
+    assert per_proof_bytes % 8 == 0
+    out = np.empty((n, per_proof_bytes), dtype=np.uint8)
+    j = 0
+    while j < n:
+        g = first + j
+        chunk, off = divmod(g, BULK_CHUNK)
+        take = min(n - j, BULK_CHUNK - off)
+        key = int.from_bytes(hashlib.shake_256(seed + b"bulk" + tag + struct.pack("<Q", chunk)).digest(16), "little")
+        raw = np.random.Philox(key=key).random_raw(BULK_CHUNK * per_proof_bytes // 8).astype("<u8", copy=False)
+        out[j:j + take] = raw.view(np.uint8).reshape(BULK_CHUNK, per_proof_bytes)[off:off + take]
+        j += take
+    return out
+
+
+def bulk_values(n: int, first: int = 0, seed: bytes = SEED) -> np.ndarray:
+    v = _bulk_bytes(b"val", first, n, 8, seed).view("<u8").reshape(n).copy()
+    for g, forced in ((0, 0), (1, 2**64 - 1), (2, 123456)):
+        if first <= g < first + n:
+            v[g - first] = forced
+    return v
+
+
+def _bulk_scalars(tag: bytes, first: int, n: int, per: int, seed: bytes) -> np.ndarray:
+    raw = _bulk_bytes(tag, first, n, 32 * per, seed)
+    raw.reshape(n, per, 32)[:, :, 0] &= 0x0F          # big-endian top byte: value < 2^252 < n, hence canonical
+    return raw
+
+
+def bulk_blindings(n: int, first: int = 0, seed: bytes = SEED) -> np.ndarray:
+    return _bulk_scalars(b"bld", first, n, 1, seed)
+
+
+def bulk_prover_randomness(n: int, first: int = 0, seed: bytes = SEED) -> np.ndarray:
+    return _bulk_scalars(b"rng", first, n, N_RNG_DRAWS_U64, seed)

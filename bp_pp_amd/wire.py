@@ -9,6 +9,12 @@ Three byte-level forms of the same content:
     with every point / scalar as a hex string.  k256's serde goes through `serdect` (hex for human-readable formats);
     whether it emits upper- or lower-case hex cannot be checked here (no Rust toolchain) -- this module WRITES upper case
     and READS either.
+The identity point has two byte forms in k256 0.13.3 and they must not be confused:
+  * `GroupEncoding::to_bytes` (what `transcript::app_point` hashes, transcript.rs:7, and this ABI's 33-byte SEC1 form) is a
+    fixed 33-byte array: the identity is 33 zero bytes, and `from_bytes` accepts exactly that;
+  * serde of an `AffinePoint` goes through `to_encoded_point(true)`, whose identity is the ONE byte 0x00: the JSON string is
+    "00", and a 66-character all-zero string would be refused by the Rust side.
+The JSON helpers below therefore write "00" for the identity and read "00" (and, leniently, 66 zeros) back to it.
 Only integer arithmetic on the curve equation is needed (square root for decompression), no group law.
 """
 from __future__ import annotations
@@ -44,6 +50,21 @@ def decompress_point(sec1: bytes) -> bytes:
     return sec1[1:] + y.to_bytes(32, "big")
 
 
+def point_to_hex(sec1: bytes) -> str:
+    """33-byte form -> the hex string serde emits for an `AffinePoint` (identity: "00")."""
+    return "00" if sec1 == bytes(33) else sec1.hex().upper()
+
+
+def hex_to_point(h: str) -> bytes:
+    """Inverse of point_to_hex: "00" (the SEC1 identity) -> 33 zero bytes, else the 33 compressed bytes."""
+    b = bytes.fromhex(h)
+    if b == b"\x00":
+        return bytes(33)
+    if len(b) != 33:
+        raise ValueError("a serialized point is 33 bytes (66 hex characters) or \"00\" for the identity")
+    return b
+
+
 def abi_to_sec1(proof928: bytes) -> bytes:
     assert len(proof928) == 928
     return b"".join(compress_point(proof928[64 * i:64 * i + 64]) for i in range(13)) + proof928[832:]
@@ -55,7 +76,7 @@ def sec1_to_abi(proof525: bytes) -> bytes:
 
 
 def sec1_to_json(proof525: bytes) -> str:
-    pts = [proof525[33 * i:33 * i + 33].hex().upper() for i in range(13)]
+    pts = [point_to_hex(proof525[33 * i:33 * i + 33]) for i in range(13)]
     sc = [proof525[429 + 32 * i:429 + 32 * i + 32].hex().upper() for i in range(3)]
     doc = {"circuit_proof": {"c_l": pts[0], "c_r": pts[1], "c_o": pts[2], "c_s": pts[3], "r": pts[4:8], "x": pts[8:12],
                              "l": sc[0:2], "n": sc[2:3]}, "r": pts[12]}
@@ -68,7 +89,7 @@ def json_to_sec1(text: str) -> bytes:
     if len(cp["r"]) != 4 or len(cp["x"]) != 4 or len(cp["l"]) != 2 or len(cp["n"]) != 1:
         raise ValueError("not a u64 range proof shape (r, x: 4 points; l: 2 scalars; n: 1 scalar)")
     pts: List[str] = [cp[k] for k in POINT_FIELDS] + list(cp["r"]) + list(cp["x"]) + [doc["r"]]
-    out = b"".join(bytes.fromhex(h) for h in pts) + b"".join(bytes.fromhex(h) for h in list(cp["l"]) + list(cp["n"]))
+    out = b"".join(hex_to_point(h) for h in pts) + b"".join(bytes.fromhex(h) for h in list(cp["l"]) + list(cp["n"]))
     if len(out) != 525:
         raise ValueError("bad field length")
     return out
@@ -81,7 +102,7 @@ def json_to_sec1(text: str) -> bytes:
 #   reciprocal::SerializableProof {"circuit_proof": {...}, "r"}                                       (reciprocal.rs:37-41)
 # with points as SEC1-compressed hex and scalars as 32-byte big-endian hex (same caveat on hex case as above).
 def _pts(buf: bytes, off: int, count: int):
-    return [compress_point(buf[off + 64 * i:off + 64 * i + 64]).hex().upper() for i in range(count)], off + 64 * count
+    return [point_to_hex(compress_point(buf[off + 64 * i:off + 64 * i + 64])) for i in range(count)], off + 64 * count
 
 
 def _scs(buf: bytes, off: int, count: int):
@@ -120,7 +141,7 @@ def doc_to_circuit_proof(doc: Dict) -> bytes:
     cp = doc["circuit_proof"] if reciprocal else doc
     if len(cp["r"]) != len(cp["x"]):
         raise ValueError("r and x must have the same length")
-    pt = lambda h: decompress_point(bytes.fromhex(h))
+    pt = lambda h: decompress_point(hex_to_point(h))
     sc = lambda h: bytes.fromhex(h).rjust(32, b"\0")
     out = b"".join(pt(cp[k]) for k in POINT_FIELDS) + b"".join(pt(h) for h in cp["r"]) + b"".join(pt(h) for h in cp["x"])
     if reciprocal:

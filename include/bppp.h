@@ -70,8 +70,13 @@ BPPP_API int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t*
                     const uint8_t* h_vec /* 32 x 64 */, int device, int fb_window_bits);
 BPPP_API void bppp_ctx_destroy(bppp_ctx* ctx);
 
-/* Run the context's kernels on a caller-owned hipStream_t (passed as void*); NULL restores the context's own stream. */
+/* Run the context's kernels on a caller-owned hipStream_t (passed as void*); NULL restores the context's own stream.  The
+ * context's own streams are created non-blocking: they are NOT ordered against the NULL (legacy default) stream, and the NULL
+ * stream itself cannot be selected here (its handle is the NULL pointer).  A caller that needs its own work ordered with the
+ * *_device entry points -- e.g. the RCCL all-reduce of reject_count -- passes the stream that work runs on. */
 BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
+/* Block the calling host thread until everything queued by this context (current stream + its helper stream) has finished. */
+BPPP_API int bppp_ctx_synchronize(bppp_ctx* ctx);
 
 /* U64RangeProofProtocol::verify (u64_proof.rs:42-54) for n independent proofs, fresh
  * `merlin::Transcript::new(label)` per proof (benches/range_proof.rs:47).
@@ -105,11 +110,13 @@ BPPP_API int bppp_u64_verify_batch_rlc(bppp_ctx* ctx, const uint8_t* label, size
                                        const uint8_t* proofs, uint8_t* accept, int32_t* status, const uint8_t seed[32]);
 
 /* The same verify over the reference's WIRE content: what `reciprocal::SerializableProof` / `circuit::SerializableProof`
- * (reciprocal.rs:37-41, circuit.rs:37-46) carry -- k256 `AffinePoint`s, whose byte form is 33-byte SEC1 compressed
- * (02|03 || x, identity = 33 zero bytes), and 32-byte big-endian scalars.  proofs: n x 525 bytes (13 x 33 in the order
+ * (reciprocal.rs:37-41, circuit.rs:37-46) carry -- k256 `AffinePoint`s, as the 33 bytes of `GroupEncoding::to_bytes`
+ * (SEC1 compressed 02|03 || x; the identity is 33 zero bytes -- the same bytes transcript.rs:7 hashes), and 32-byte
+ * big-endian scalars.  (serde writes the identity as the ONE byte 0x00 instead -- JSON "00"; a caller holding serde output
+ * widens that to 33 zero bytes, as bp_pp_amd/wire.py and the Rust facade do.)  proofs: n x 525 bytes (13 x 33 in the order
  * c_l, c_r, c_o, c_s, r[0..3], x[0..3], reciprocal.r, then l[0], l[1], n[0]); commitments: n x 33 bytes.  Points are
  * decompressed on the device (one square root in Fp per point); a point k256's from_bytes would reject (bad tag, x >= p,
- * not on the curve) yields BPPP_ST_BAD_ENCODING for that proof.  Host pointers / device pointers as above. */
+ * not on the curve -- including 02 || 0, whose x^3 + 7 = 7 is a non-residue) yields BPPP_ST_BAD_ENCODING for that proof.  Host pointers / device pointers as above. */
 #define BPPP_U64_PROOF_SEC1_BYTES 525
 #define BPPP_POINT_SEC1_BYTES 33
 BPPP_API int bppp_u64_verify_batch_sec1(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n,

@@ -21,7 +21,11 @@ def _pow2_at_least(n):
     return p
 
 
-def make(dim_nd: int, dim_np: int, B: int, label: bytes = b"reciprocal test"):
+def make(dim_nd: int, dim_np: int, B: int, label: bytes = b"reciprocal test", n_oracle: int = None):
+    """B seeded instances (witnesses + prover randomness).  The oracle proves the first `n_oracle` of them (default: all B);
+    case["commitments"] / case["proofs"] then hold only those rows -- large batches get their proofs from the product prover and
+    use the oracle rows as the cross-check sample."""
+    n_oracle = B if n_oracle is None else min(B, n_oracle)
     L = OC.lib()
     sz = C.c_size_t
     nh = dim_nd + 10
@@ -37,7 +41,9 @@ def make(dim_nd: int, dim_np: int, B: int, label: bytes = b"reciprocal test"):
     n_rnd = 20 + 2 * dim_nd
     wx, ws, wd, wm, wr = [], [], [], [], []
     for b in range(B):
-        digits = [int.from_bytes(hashlib.shake_256(b"dig" + bytes([b]) + i.to_bytes(4, "little")).digest(2), "little") % dim_np
+        dg = hashlib.shake_256(b"dig" + (bytes([b]) if b < 256 else b.to_bytes(4, "little"))).digest(2 * dim_nd) if b >= 256 else None
+        digits = [int.from_bytes(dg[2 * i:2 * i + 2] if dg else
+                                 hashlib.shake_256(b"dig" + bytes([b]) + i.to_bytes(4, "little")).digest(2), "little") % dim_np
                   for i in range(dim_nd)]
         if b == 0:
             digits = [0] * dim_nd
@@ -46,9 +52,16 @@ def make(dim_nd: int, dim_np: int, B: int, label: bytes = b"reciprocal test"):
         x = sum(d * pow(dim_np, i, O.N) for i, d in enumerate(digits)) % O.N
         m = [digits.count(v) for v in range(dim_np)]
         s = _sc(b"s", b)
-        rnd = b"".join(O.sc_to_bytes(_sc(b"rnd", b, i)) for i in range(n_rnd))
+        if b < 256:
+            rnd = b"".join(O.sc_to_bytes(_sc(b"rnd", b, i)) for i in range(n_rnd))
+        else:       # large batches: one XOF call per instance, top four bits cleared (canonical without a wide reduction)
+            raw = bytearray(hashlib.shake_256(b"bppp-recip-cases-rnd" + b.to_bytes(4, "little")).digest(32 * n_rnd))
+            raw[0::32] = bytes(v & 0x0F for v in raw[0::32])
+            rnd = bytes(raw)
         wx.append(O.sc_to_bytes(x)); ws.append(O.sc_to_bytes(s)); wd.append(b"".join(O.sc_to_bytes(d) for d in digits))
         wm.append(b"".join(O.sc_to_bytes(v) for v in m)); wr.append(rnd)
+        if b >= n_oracle:
+            continue
         com = C.create_string_buffer(64)
         pbuf = C.create_string_buffer(64 * (5 + 2 * 16) + 32 * 16)
         rounds, nl, nn = sz(0), sz(0), sz(0)
@@ -64,10 +77,16 @@ def make(dim_nd: int, dim_np: int, B: int, label: bytes = b"reciprocal test"):
         coms.append(com.raw)
         proofs.append(pbuf.raw[:nbytes])
     u8 = lambda blobs, *sh: np.frombuffer(b"".join(blobs), dtype=np.uint8).reshape(B, *sh).copy()
+    if not proofs:      # n_oracle == 0: shape from the sizes alone
+        rounds, nl, nn = 0, NH, NG
+        while nl + nn >= 6:
+            nl, nn, rounds = (nl + 1) // 2, (nn + 1) // 2, rounds + 1
+        shape = (rounds, nl, nn)
+        proofs, coms = [bytes(64 * (5 + 2 * rounds) + 32 * (nl + nn))], [bytes(64)]
     case.update(x=u8(wx, 32), s=u8(ws, 32), digits=u8(wd, dim_nd, 32), m=u8(wm, dim_np, 32), rnd=u8(wr, n_rnd, 32))
     case.update(rounds=shape[0], nl=shape[1], nn=shape[2], proof_bytes=len(proofs[0]),
-                commitments=np.frombuffer(b"".join(coms), dtype=np.uint8).reshape(B, 64).copy(),
-                proofs=np.frombuffer(b"".join(proofs), dtype=np.uint8).reshape(B, -1).copy())
+                commitments=np.frombuffer(b"".join(coms), dtype=np.uint8).reshape(len(coms), 64).copy(),
+                proofs=np.frombuffer(b"".join(proofs), dtype=np.uint8).reshape(len(proofs), -1).copy(), n_oracle=n_oracle)
     return case
 
 

@@ -30,7 +30,7 @@ def _run(torch, proto, V, P, seed):
     dA = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
     dS = torch.zeros(n, dtype=torch.int32, device="cuda")
     dR = torch.zeros(1, dtype=torch.int32, device="cuda")
-    proto.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()   # inputs ready; the context runs on its own (non-blocking) stream, joined by proto.synchronize()
     if seed is None:
         proto.verify_batch_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, dR.data_ptr())
     else:

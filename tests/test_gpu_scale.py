@@ -1,0 +1,115 @@
+"""GPU parity tests at the sizes BASELINE.json quotes the metric on (run with -m gpu on an MI355X):
+
+  * configs[2]: u64 verify at 2^17 proofs (one GPU's shard of the 8-GPU split) and at 2^20 proofs (the whole batch resident on one
+    GPU, the N = 1 workload of bench.py) -- size-independent properties over the full batch (every honest proof accepted, every
+    corrupted one rejected, reject count, invariance under a permutation of the batch) plus a >= 512-proof sample checked bit
+    for bit against the CPU oracle; the proofs come from the product's batch prover and a sample of THEM is compared byte for
+    byte with the oracle prover's output for the same inputs;
+  * configs[4]: ReciprocalRangeProofProtocol (dim_nd 256, dim_np 16: |g_vec| 256, |h_vec| 512, 8 WNLA rounds) prove + verify at
+    B = 2^12 instances, with an oracle-proved / oracle-verified sample.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("these tests need a GPU (they are selected with -m gpu only on the GPU box)")
+    return torch
+
+
+@pytest.mark.parametrize("log_n,wbits", [(17, 20), (20, 0)])
+def test_u64_verify_at_baseline_sizes(torch_mod, oracle_c, log_n, wbits):
+    torch = torch_mod
+    import bench
+    import workload                        # oracle-side helpers (trapdoor prover, generators)
+    from bp_pp_amd import U64RangeProofProtocol, synth
+    n = 1 << log_n
+    gens, g, gv, hv = bench.load_generators()
+    assert gens == workload.generators()
+    proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=wbits)     # 0 = the library default bench.py runs with
+    try:
+        lo = 3 << 20                        # a shard that does not start at proof 0 of the synthetic stream
+        dV, dP, expect, _ = bench.make_resident_batch(torch, proto, synth, lo, lo + n)
+        assert int((expect == 0).sum()) == n // 1024
+        dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dS = torch.zeros(n, dtype=torch.int32, device="cuda")
+        dR = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        proto.verify_batch_device(synth.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, dR.data_ptr())
+        proto.synchronize()
+        acc, st = dA.cpu().numpy(), dS.cpu().numpy()
+        # properties over the whole batch
+        assert (acc == expect).all() and not st.any()
+        assert int(dR.item()) == n // 1024
+        # the batch order carries no state: a permuted copy gives the permuted accept bits
+        perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+        dV2, dP2 = dV[perm].contiguous(), dP[perm].contiguous()
+        dA2 = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        proto.verify_batch_device(synth.LABEL, n, dV2.data_ptr(), dP2.data_ptr(), dA2.data_ptr(), dS.data_ptr(), 0, dR.data_ptr())
+        proto.synchronize()
+        assert bool((dA2 == dA[perm]).all().item()) and int(dR.item()) == n // 1024
+        del dV2, dP2
+        # oracle sample: 512 spread proofs + 64 of the corrupted ones + both ends, verified by the CPU oracle
+        idx = np.unique(np.concatenate([np.arange(0, n, n // 512), np.nonzero(expect == 0)[0][:64], [1, n - 1]])).astype(np.int64)
+        assert len(idx) >= 512
+        ti = torch.from_numpy(idx).cuda()
+        Vs, Ps = dV[ti].cpu().numpy(), dP[ti].cpu().numpy()
+        oacc, ost = oracle_c.u64_verify_batch(gens, synth.LABEL, Vs, Ps, nthreads=os.cpu_count() or 1)
+        assert (oacc == acc[idx]).all() and not ost.any()
+        # the prover that made the batch, cross-checked: the oracle prover on the same (x, s, rnd) gives the same bytes
+        p0 = n // 2 + 1000                      # 96 consecutive proofs, none of them a corrupted one
+        pidx = np.arange(p0, p0 + 96, dtype=np.int64)
+        assert expect[pidx].all()
+        x, s, rnd = synth.bulk_values(96, first=lo + p0), synth.bulk_blindings(96, first=lo + p0), synth.bulk_prover_randomness(96, first=lo + p0)
+        Pref, Vref = oracle_c.u64_prove_trapdoor_batch(workload.generator_dlogs(), synth.LABEL, x, s, rnd, nthreads=os.cpu_count() or 1)
+        tp = torch.from_numpy(pidx).cuda()
+        assert (Pref == dP[tp].cpu().numpy()).all() and (Vref == dV[tp].cpu().numpy()).all()
+    finally:
+        proto.close()
+
+
+def test_recip256_prove_and_verify_at_batch_scale(torch_mod):
+    """BASELINE configs[4]'s shape at B = 2^12: multi-wavefront indexing, workspace growth and the fixed-base path of the
+    generic kernels at batch scale (they were only exercised at B <= 4 before)."""
+    import recip_cases
+    from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
+    nd, npp, B, n_or = 256, 16, 1 << 12, 6
+    case = recip_cases.make(nd, npp, B, n_oracle=n_or)
+    proto = ReciprocalRangeProofProtocol(nd, npp, case["g"], case["gv"], case["hv"], case["gv_"], case["hv_"], device=0, fb_window_bits=10)
+    try:
+        com, st = proto.commit_value_batch(case["x"], case["s"])
+        assert not st.any() and (com[:n_or] == case["commitments"]).all()
+        proofs, st, shape = proto.prove_batch(case["label"], com, case["x"], case["s"], case["digits"], case["m"], case["rnd"])
+        assert not st.any() and shape == (case["rounds"], case["nl"], case["nn"]) == (8, 2, 1)
+        assert (proofs[:n_or] == case["proofs"]).all()                     # byte-identical to the reference-shaped prover
+        acc, st = proto.verify_batch(case["label"], com, proofs, *shape)
+        assert acc.all() and not st.any()
+        # negatives spread over the batch (different wavefronts), each judged by the oracle too for a sample
+        P, V = proofs.copy(), com.copy()
+        bad = list(range(7, B, 97))
+        for k, i in enumerate(bad):
+            kind = k % 4
+            if kind == 0:
+                P[i, -1] ^= 1                                               # n0
+            elif kind == 1:
+                P[i, 64 * (4 + (k % 16)) + 9] ^= 0x20                       # a round point's x
+            elif kind == 2:
+                V[i] = com[(i + 1) % B]                                     # someone else's commitment
+            else:
+                P[i, 192:256] = P[i, 0:64]                                  # c_s := c_l
+        acc, st = proto.verify_batch(case["label"], V, P, *shape)
+        good = np.ones(B, bool); good[bad] = False
+        assert acc[good].all() and not st[good].any() and not acc[bad].any()
+        for i in bad[:6] + [0, 1, B - 1]:
+            rc = recip_cases.oracle_verify(case, bytes(V[i]), bytes(P[i]))
+            assert int(acc[i]) == (1 if rc == 1 else 0) and (int(st[i]) != 0) == (rc < 0), (i, rc)
+    finally:
+        proto.close()

@@ -45,7 +45,7 @@ def _device_verify(torch, proto, label, V, P, want_trace=True):
     dT = torch.zeros((n, 704), dtype=torch.uint8, device="cuda") if want_trace else None
     dR = torch.zeros(1, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    proto.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()   # inputs ready; the context runs on its own (non-blocking) stream, joined by proto.synchronize()
     proto.verify_batch_device(label, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(),
                               dT.data_ptr() if want_trace else 0, dR.data_ptr())
     torch.cuda.synchronize()
@@ -147,11 +147,19 @@ def test_sec1_wire_inputs(torch_mod, proto, gold, oracle_c):
     P525[5, 0] = 4                      # bad SEC1 tag
     P525[6, 33:66] = np.frombuffer(b"\x02" + (5).to_bytes(32, "big"), dtype=np.uint8)     # x without a square root
     P525[7, 0] ^= 1                     # the other root of c_l: decodes, must be rejected by the protocol
+    # encodings with x = 0 mod p that k256's from_bytes refuses: they must be flagged, never read as the identity
+    pbytes = (2**256 - 2**32 - 977).to_bytes(32, "big")
+    P525[8, 66:99] = np.frombuffer(b"\x02" + bytes(32), dtype=np.uint8)       # 02 || 0: 7 is a non-residue
+    P525[9, 99:132] = np.frombuffer(b"\x05" + bytes(32), dtype=np.uint8)      # bad tag over x = 0
+    P525[10, 132:165] = np.frombuffer(b"\x02" + pbytes, dtype=np.uint8)       # x = p
+    C33[12] = np.frombuffer(b"\x03" + pbytes, dtype=np.uint8)                 # the commitment itself
     acc, st = proto.verify_batch_sec1(C33, P525, workload.LABEL)
     acc_ref, st_ref = proto.verify_batch(V, P, workload.LABEL)
-    keep = np.ones(n, bool); keep[[5, 6, 7]] = False
+    touched = [5, 6, 7, 8, 9, 10, 12]
+    keep = np.ones(n, bool); keep[touched] = False
     assert (acc[keep] == acc_ref[keep]).all() and (acc[keep] == expect[keep]).all() and not st[keep].any()
-    assert st[5] == 1 and st[6] == 1 and acc[5] == 0 and acc[6] == 0
+    for i in (5, 6, 8, 9, 10, 12):
+        assert st[i] == 1 and acc[i] == 0, i
     assert st[7] == 0 and acc[7] == 0
 
 

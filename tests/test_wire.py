@@ -52,33 +52,59 @@ def test_proof_forms_round_trip(gold):
 def test_device_decompression_code(gold):
     L = load()
     cases = gold["cases"]
-    n = len(cases) + 4
+    PRIME = 2**256 - 2**32 - 977
     c33 = [wire.compress_point(bytes.fromhex(c["commitment"])) for c in cases]
     p525 = [wire.abi_to_sec1(bytes.fromhex(c["proof"])) for c in cases]
     exp_c = [bytes.fromhex(c["commitment"]) for c in cases]
     exp_p = [bytes.fromhex(c["proof"]) for c in cases]
-    bad = bytearray(p525[0]); bad[0] = 4                                 # bad tag on c_l
-    c33.append(c33[0]); p525.append(bytes(bad)); exp_c.append(exp_c[0]); exp_p.append(None)
-    bad = bytearray(p525[0]); bad[33:66] = b"\x02" + (5).to_bytes(32, "big")   # c_r: x with no square root
-    c33.append(c33[0]); p525.append(bytes(bad)); exp_c.append(exp_c[0]); exp_p.append(None)
+    # encodings k256's from_bytes rejects; the last three have x = 0 mod p and must NOT come out as the identity (0, 0)
+    rejects = [b"\x04" + p525[0][1:33],                        # bad tag on c_l
+               b"\x02" + (5).to_bytes(32, "big"),              # x with no square root
+               b"\x02" + bytes(32),                            # x = 0: 7 is a non-residue, so 02||0 is off the curve
+               b"\x05" + bytes(32),                            # bad tag over x = 0
+               b"\x02" + PRIME.to_bytes(32, "big"),            # x = p: out of range
+               b"\x03" + PRIME.to_bytes(32, "big")]
+    first_bad = len(c33)
+    for j, enc in enumerate(rejects):
+        bad = bytearray(p525[0]); bad[33 * (j % 13):33 * (j % 13) + 33] = enc
+        c33.append(c33[0]); p525.append(bytes(bad)); exp_c.append(exp_c[0]); exp_p.append(None)
     idp = bytearray(p525[0]); idp[132:165] = bytes(33)                    # r[0] = identity
     c33.append(bytes(33)); p525.append(bytes(idp)); exp_c.append(bytes(64)); exp_p.append(wire.sec1_to_abi(bytes(idp)))
     flip = bytearray(p525[1]); flip[0] ^= 1                               # the other square root of c_l
     c33.append(c33[1]); p525.append(bytes(flip)); exp_c.append(exp_c[1]); exp_p.append(wire.sec1_to_abi(bytes(flip)))
+    c33.append(rejects[2]); p525.append(p525[0]); exp_c.append(None); exp_p.append(exp_p[0])   # an undecodable COMMITMENT
+    n = len(c33)
     C33 = np.frombuffer(b"".join(c33), dtype=np.uint8).copy()
     P525 = np.frombuffer(b"".join(p525), dtype=np.uint8).copy()
     C64, P928 = np.zeros(n * 64, np.uint8), np.zeros(n * 928, np.uint8)
     L.emul_sec1_expand(n, C33.ctypes.data, P525.ctypes.data, C64.ctypes.data, P928.ctypes.data)
     for i in range(n):
-        assert bytes(C64[64 * i:64 * i + 64]) == exp_c[i]
+        if exp_c[i] is not None:
+            assert bytes(C64[64 * i:64 * i + 64]) == exp_c[i]
         got = bytes(P928[928 * i:928 * i + 928])
         if exp_p[i] is not None:
             assert got == exp_p[i]
-    # undecodable points come out as (x, 0): off the curve, so the verifier flags them
-    g = bytes(P928[928 * len(cases):928 * len(cases) + 64])
-    assert g[32:] == bytes(32) and not O.on_curve((int.from_bytes(g[:32], "big"), 0))
-    g = bytes(P928[928 * (len(cases) + 1) + 64:928 * (len(cases) + 1) + 128])
-    assert g[:32] == (5).to_bytes(32, "big") and g[32:] == bytes(32)
+    # undecodable points come out as (1, 0): off the curve and never the identity, so the verifier flags them
+    sentinel = (1).to_bytes(32, "big") + bytes(32)
+    assert not O.on_curve((1, 0))
+    for j in range(len(rejects)):
+        i = first_bad + j
+        assert bytes(P928[928 * i + 64 * (j % 13):928 * i + 64 * (j % 13) + 64]) == sentinel, j
+    assert bytes(C64[64 * (n - 1):64 * n]) == sentinel
+
+
+def test_identity_in_json_is_00(gold):
+    """serde writes the identity AffinePoint as the one SEC1 byte 0x00 ("00"), not as 33 zero bytes."""
+    abi = bytearray(bytes.fromhex(gold["cases"][0]["proof"]))
+    abi[64 * 5:64 * 6] = bytes(64)                                        # r[1] = identity
+    sec1 = wire.abi_to_sec1(bytes(abi))
+    doc = json.loads(wire.sec1_to_json(sec1))
+    assert doc["circuit_proof"]["r"][1] == "00" and len(doc["circuit_proof"]["r"][0]) == 66
+    assert wire.json_to_sec1(json.dumps(doc)) == sec1
+    d2 = wire.circuit_proof_to_doc(bytes(abi), 4, 2, 1, reciprocal=True)
+    assert d2["circuit_proof"]["r"][1] == "00" and wire.doc_to_circuit_proof(d2) == bytes(abi)
+    with pytest.raises(ValueError):
+        wire.hex_to_point("0000")
 
 
 def test_generic_proof_documents_round_trip():

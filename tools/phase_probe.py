@@ -12,7 +12,7 @@ proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=16)
 P, V, pst = proto.prove_batch(workload.values(n), workload.blindings(n), workload.prover_randomness(n), workload.LABEL)
 dV, dP = torch.from_numpy(V).cuda(), torch.from_numpy(P).cuda()
 dA = torch.zeros(n, dtype=torch.uint8, device="cuda"); dS = torch.zeros(n, dtype=torch.int32, device="cuda")
-proto.set_stream(torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()   # inputs ready; the context runs on its own (non-blocking) stream, joined by proto.synchronize()
 for _ in range(2):
     proto.verify_batch_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, 0)
 torch.cuda.synchronize()

@@ -13,7 +13,7 @@ every = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 P, expect = workload.corrupt(P, every=every)
 dV, dP = torch.from_numpy(V).cuda(), torch.from_numpy(P).cuda()
 dA = torch.zeros(n, dtype=torch.uint8, device="cuda"); dS = torch.zeros(n, dtype=torch.int32, device="cuda"); dR = torch.zeros(1, dtype=torch.int32, device="cuda")
-proto.set_stream(torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()   # inputs ready; the context runs on its own (non-blocking) stream, joined by proto.synchronize()
 seed = os.urandom(32)
 for _ in range(2):
     proto.verify_batch_rlc_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), seed, dS.data_ptr(), dR.data_ptr())

@@ -1,4 +1,24 @@
-import sys, json
-for l in sys.stdin:
-    if '"value"' in l:
-        d=json.loads(l); print(d['config']['proofs_per_gpu'], round(d['value']), round(d['ms_per_step'],3), {k:round(v,3) for k,v in d['kernels_ms_per_step'].items()})
+"""Print the essentials of bench.py JSON lines: python tools/show_bench.py file.json [...]  (or stdin)."""
+import json, sys
+def show(l):
+    if '"value"' not in l:
+        return
+    d = json.loads(l)
+    print(d["config"].get("total_proofs_per_step"), "proofs  n_gpus", d["n_gpus"], " value", round(d["value"]), d["unit"], " ms/step", round(d["ms_per_step"], 3),
+          " ok", d.get("accept_bits_ok"))
+    print("  kernels ms/step:", {k: round(v, 3) for k, v in (d.get("kernels_ms_per_step") or {}).items()})
+    r = d.get("roofline") or {}
+    print("  roofline:", r.get("kernel"), "avg launch ms", round(r.get("avg_launch_ms", 0), 4), "frac", round(r.get("frac", 0), 5), "traffic", r.get("traffic"))
+    for k in ("configs1_2pow16", "rlc_mode", "host_buffer_path", "cpu_baseline"):
+        v = d.get(k)
+        if v:
+            print(f"  {k}:", round(v["value"]), v.get("unit"), {a: b for a, b in v.items() if a in ("ms_per_step", "ms_per_batch", "cores", "accept_bits_ok", "accept_bits_equal_exact_mode", "agrees_with_gpu")})
+    print("  setup:", d.get("setup_s"), " device GB", round((d.get("device_bytes") or 0) / 1e9, 1))
+files = sys.argv[1:]
+if files:
+    for f in files:
+        for l in open(f):
+            show(l)
+else:
+    for l in sys.stdin:
+        show(l)

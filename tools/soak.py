@@ -12,7 +12,7 @@ g, gv, hv = gens[:64], [gens[64 * i:64 * i + 64] for i in range(1, 17)], [gens[6
 n = 1 << 16
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 proto = U64RangeProofProtocol(g, gv, hv, device=0)
-proto.set_stream(torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()   # inputs ready; the context runs on its own (non-blocking) stream, joined by proto.synchronize()
 rng = np.random.default_rng(2026)
 bad_total = 0
 t0 = time.time()
