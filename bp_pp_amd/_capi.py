@@ -8,7 +8,7 @@ import os
 from . import _build
 
 OK = 0
-ERR_NO_DEVICE, ERR_INVALID_ARG, ERR_HIP, ERR_ENCODING, ERR_NOMEM = -1, -2, -3, -4, -5
+ERR_NO_DEVICE, ERR_INVALID_ARG, ERR_HIP, ERR_ENCODING, ERR_NOMEM, ERR_RCCL = -1, -2, -3, -4, -5, -6
 ST_BAD_ENCODING, ST_DEGENERATE = 1, 2
 POINT_BYTES, SCALAR_BYTES, U64_PROOF_BYTES, U64_TRACE_BYTES = 64, 32, 928, 704
 
@@ -17,6 +17,10 @@ EXPORTS = [
     "bppp_ctx_create", "bppp_wnla_ctx_create", "bppp_wnla_commit_batch", "bppp_wnla_verify_batch", "bppp_reciprocal_verify_batch", "bppp_reciprocal_prove_batch", "bppp_msm_batch", "bppp_wnla_proof_shape", "bppp_wnla_prove_batch", "bppp_circuit_create", "bppp_circuit_destroy", "bppp_circuit_verify_batch", "bppp_circuit_prove_batch", "bppp_ctx_destroy", "bppp_ctx_set_stream", "bppp_ctx_synchronize", "bppp_u64_verify_batch", "bppp_u64_verify_batch_device", "bppp_u64_verify_batch_rlc_device", "bppp_u64_verify_batch_rlc", "bppp_u64_verify_batch_sec1", "bppp_u64_verify_batch_sec1_device",
     "bppp_u64_commit_value_batch", "bppp_u64_prove_batch", "bppp_u64_prove_batch_device", "bppp_ctx_enable_timing", "bppp_ctx_get_timings", "bppp_ctx_device_bytes",
     "bppp_strerror", "bppp_last_error",
+    "bppp_u64_verify_batch_transcript", "bppp_u64_verify_batch_transcript_device", "bppp_transcript_new",
+    "bppp_transcript_append_message", "bppp_transcript_challenge_bytes",
+    "bppp_shard_range", "bppp_group_create", "bppp_group_destroy", "bppp_group_size", "bppp_group_ctx", "bppp_u64_verify_batch_sharded",
+    "bppp_u64_verify_batch_sharded_device",
 ]
 
 _lib = None
@@ -74,6 +78,21 @@ def lib():
     L.bppp_ctx_get_timings.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     L.bppp_ctx_device_bytes.argtypes = [vp]
     L.bppp_ctx_device_bytes.restype = sz
+    L.bppp_u64_verify_batch_transcript.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, vp]
+    L.bppp_u64_verify_batch_transcript_device.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, vp, vp]
+    L.bppp_transcript_new.argtypes = [u8p, sz, vp]
+    L.bppp_transcript_append_message.argtypes = [vp, u8p, sz, u8p, sz]
+    L.bppp_transcript_challenge_bytes.argtypes = [vp, u8p, sz, vp, sz]
+    L.bppp_shard_range.argtypes = [sz, i32, i32, C.POINTER(sz), C.POINTER(sz)]
+    L.bppp_shard_range.restype = None
+    L.bppp_group_create.argtypes = [C.POINTER(vp), u8p, u8p, u8p, C.POINTER(i32), i32, i32]
+    L.bppp_group_destroy.argtypes = [vp]
+    L.bppp_group_destroy.restype = None
+    L.bppp_group_size.argtypes = [vp]
+    L.bppp_group_ctx.argtypes = [vp, i32]
+    L.bppp_group_ctx.restype = vp
+    L.bppp_u64_verify_batch_sharded.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, C.POINTER(C.c_int32)]
+    L.bppp_u64_verify_batch_sharded_device.argtypes = [vp, u8p, sz, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.bppp_strerror.argtypes = [i32]
     L.bppp_strerror.restype = C.c_char_p
     L.bppp_last_error.restype = C.c_char_p

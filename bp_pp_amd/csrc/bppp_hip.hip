@@ -6,11 +6,14 @@
 // (4 per CU) and no lane ever waits on a workgroup barrier -- there is no inter-lane communication in this pipeline.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bppp.h"
@@ -122,7 +125,7 @@ static int ensure_vtab_capacity(bppp_ctx* c, size_t n) {
     c->vtab_bytes = 0;
     size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
     const size_t atab_bytes = cap * BPPP_ATAB_PER_PROOF * sizeof(apt_packed);
-    const size_t tscr_bytes = cap * (size_t)(BPPP_VPOINTS * 7 * 4 * 10) * sizeof(u32);
+    const size_t tscr_bytes = cap * (size_t)(BPPP_TSCR_FE * 10) * sizeof(u32);
     HIP_TRY(hipMalloc(&c->d_atab, atab_bytes));
     HIP_TRY(hipMalloc(&c->d_tscr, tscr_bytes));
     c->vtab_bytes = atab_bytes + tscr_bytes;
@@ -245,6 +248,7 @@ const char* bppp_strerror(int code) {
         case BPPP_ERR_HIP: return "HIP runtime error";
         case BPPP_ERR_ENCODING: return "generator is not a valid secp256k1 point";
         case BPPP_ERR_NOMEM: return "out of memory";
+        case BPPP_ERR_RCCL: return "RCCL unavailable or an RCCL call failed";
         default: return "unknown error";
     }
 }
@@ -400,9 +404,11 @@ int bppp_ctx_get_timings(bppp_ctx* c, int max_entries, const char** names, doubl
     return n;
 }
 
+// optional pre-loaded transcripts of a verify call (device pointers): see VerifyWs::states
+struct VerifyTranscripts { const void* d_states; size_t n_states; void* d_states_out; };
 static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
                               const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count,
-                              const uint8_t* rlc_seed) {
+                              const uint8_t* rlc_seed, const VerifyTranscripts* tx = nullptr) {
     if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept) return BPPP_ERR_INVALID_ARG;
     if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;   // u64 entry points need the u64 generator shape
     if (n == 0) return BPPP_OK;
@@ -447,6 +453,12 @@ static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_le
         ws.status = (int32_t*)c->d_stage;
     }
     t_new(ws.base, label, (u32)label_len);   // Transcript::new(label), shared by every proof of the batch
+    if (tx) {
+        if (tx->d_states && tx->n_states != 1 && tx->n_states != n) return BPPP_ERR_INVALID_ARG;
+        ws.states = (const uint8_t*)tx->d_states;
+        ws.n_states = tx->n_states;
+        ws.states_out = (uint8_t*)tx->d_states_out;
+    }
     if (d_reject_count) HIP_TRY(hipMemsetAsync(d_reject_count, 0, sizeof(int), c->stream));
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     hipStream_t s = c->stream;
@@ -494,9 +506,78 @@ static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_le
             std::fprintf(stderr, "bppp rlc: %zu of %zu chunks re-checked exactly\n", cnt, nchunks);
         }
     }
+    if (ws.states_out) k_verify_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
 #undef LAUNCH
 #undef LAUNCH_ON
     HIP_TRY(hipGetLastError());
+    return BPPP_OK;
+}
+int bppp_u64_verify_batch_transcript_device(bppp_ctx* c, size_t n, const void* d_states, size_t n_states, const void* d_commitments,
+                                            const void* d_proofs, void* d_accept, void* d_status, void* d_reject_count, void* d_states_out) {
+    if (!d_states) return BPPP_ERR_INVALID_ARG;
+    VerifyTranscripts tx = {d_states, n_states, d_states_out};
+    return verify_device_impl(c, nullptr, 0, n, d_commitments, d_proofs, d_accept, d_status, nullptr, d_reject_count, nullptr, &tx);
+}
+int bppp_u64_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, const uint8_t* commitments,
+                                     const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    if (!c || !states || !commitments || !proofs || !accept || (n_states != 1 && n_states != n)) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    for (size_t i = 0; i < n_states; i++)
+        if (states[203 * i + 200] >= BPPP_STROBE_R || states[203 * i + 201] > BPPP_STROBE_R) return BPPP_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    uint8_t* d = nullptr;
+    const size_t SB = BPPP_TRANSCRIPT_STATE_BYTES;
+    const size_t o_c = 0, o_p = align16(o_c + n * 64), o_a = align16(o_p + n * (size_t)BPPP_U64_PROOF_BYTES), o_s = align16(o_a + n),
+                 o_ti = align16(o_s + n * sizeof(int32_t)), o_to = align16(o_ti + n_states * SB), total = align16(o_to + n * SB);
+    HIP_TRY(hipMalloc(&d, total));
+    int rc = BPPP_OK;
+    hipStream_t st = c->stream;
+    hipError_t e = hipMemcpyAsync(d + o_c, commitments, n * 64, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_p, proofs, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_ti, states, n_states * SB, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        rc = bppp_u64_verify_batch_transcript_device(c, n, d + o_ti, n_states, d + o_c, d + o_p, d + o_a, d + o_s, nullptr,
+                                                     states_out ? d + o_to : nullptr);
+        if (rc == BPPP_OK) {
+            e = hipMemcpyAsync(accept, d + o_a, n, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && status) e = hipMemcpyAsync(status, d + o_s, n * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && states_out) e = hipMemcpyAsync(states_out, d + o_to, n * SB, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) { g_last_error = std::string("verify_batch_transcript: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
+    return rc;
+}
+// merlin::Transcript as 203 serialized bytes, on the host: lets a C caller build the pre-loaded states without merlin and lets
+// the tests follow the reference's `t: &mut Transcript` contract end to end (no GPU involved)
+int bppp_transcript_new(const uint8_t* label, size_t label_len, uint8_t state_out[203]) {
+    if ((!label && label_len) || !state_out) return BPPP_ERR_INVALID_ARG;
+    strobe t;
+    t_new(t, label, (u32)label_len);
+    strobe_to_bytes(state_out, t, 2);       // the last operation of Transcript::new is the AD of the dom-sep message
+    return BPPP_OK;
+}
+int bppp_transcript_append_message(uint8_t state[203], const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len) {
+    if (!state || (!label && label_len) || (!msg && msg_len) || msg_len > 0xFFFFFFFFu) return BPPP_ERR_INVALID_ARG;
+    strobe t;
+    if (!strobe_from_bytes(t, state)) return BPPP_ERR_INVALID_ARG;
+    uint8_t len4[4] = {(uint8_t)msg_len, (uint8_t)(msg_len >> 8), (uint8_t)(msg_len >> 16), (uint8_t)(msg_len >> 24)};
+    strobe_meta_ad(t, label, (u32)label_len, false);
+    strobe_meta_ad(t, len4, 4, true);
+    strobe_ad(t, msg, (u32)msg_len, false);
+    strobe_to_bytes(state, t, 2);
+    return BPPP_OK;
+}
+int bppp_transcript_challenge_bytes(uint8_t state[203], const uint8_t* label, size_t label_len, uint8_t* out, size_t n) {
+    if (!state || (!label && label_len) || (!out && n) || n > 0xFFFFFFFFu) return BPPP_ERR_INVALID_ARG;
+    strobe t;
+    if (!strobe_from_bytes(t, state)) return BPPP_ERR_INVALID_ARG;
+    uint8_t len4[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
+    strobe_meta_ad(t, label, (u32)label_len, false);
+    strobe_meta_ad(t, len4, 4, true);
+    strobe_prf(t, out, (u32)n);
+    strobe_to_bytes(state, t, 7);
     return BPPP_OK;
 }
 int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
@@ -1343,5 +1424,220 @@ BPPP_API int bppp_debug_read_stamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(bppp::g_bppp_stamps), sizeof(unsigned long long) * 1024 * 32) == hipSuccess ? 0 : -1;
 }
 #endif
+
+
+// ---------------------------------------------------------------- one batch over the GPUs of a node
+// RCCL through dlopen: no link-time dependency, and whichever librccl the process already holds (e.g. torch's) serves.
+namespace {
+typedef void* rcclComm;
+struct RcclApi {
+    void* handle = nullptr;
+    int (*CommInitAll)(rcclComm*, int, const int*) = nullptr;
+    int (*CommDestroy)(rcclComm) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+const int kRcclInt32 = 2, kRcclSum = 0;   // ncclInt32, ncclSum (rccl.h)
+bool rccl_load(RcclApi& a) {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (a.handle) break;
+    }
+    if (!a.handle) { g_last_error = std::string("dlopen(librccl): ") + (dlerror() ? dlerror() : "not found"); return false; }
+    a.CommInitAll = (int (*)(rcclComm*, int, const int*))dlsym(a.handle, "ncclCommInitAll");
+    a.CommDestroy = (int (*)(rcclComm))dlsym(a.handle, "ncclCommDestroy");
+    a.AllReduce = (int (*)(const void*, void*, size_t, int, int, rcclComm, hipStream_t))dlsym(a.handle, "ncclAllReduce");
+    a.GroupStart = (int (*)())dlsym(a.handle, "ncclGroupStart");
+    a.GroupEnd = (int (*)())dlsym(a.handle, "ncclGroupEnd");
+    a.GetErrorString = (const char* (*)(int))dlsym(a.handle, "ncclGetErrorString");
+    if (!a.CommInitAll || !a.CommDestroy || !a.AllReduce || !a.GroupStart || !a.GroupEnd) {
+        g_last_error = "librccl lacks a required symbol";
+        return false;
+    }
+    return true;
+}
+}  // namespace
+
+struct bppp_group {
+    std::vector<int> devices;
+    std::vector<bppp_ctx*> ctx;
+    std::vector<rcclComm> comm;          // empty when the accept-reduce needs no collective (one device)
+    std::vector<int*> d_rej;             // per device: int32 reject counter of the host-buffer entry point
+    RcclApi rccl;
+};
+
+void bppp_shard_range(size_t n_total, int rank, int world, size_t* lo, size_t* hi) {
+    if (world <= 0 || rank < 0 || rank >= world) { if (lo) *lo = 0; if (hi) *hi = 0; return; }
+    // n_total * rank may exceed 64 bits only for absurd sizes; use the quotient / remainder form
+    const size_t q = n_total / (size_t)world, r = n_total % (size_t)world;
+    auto at = [&](size_t k) { return q * k + (r * k) / (size_t)world; };   // floor(n_total * k / world)
+    if (lo) *lo = at((size_t)rank);
+    if (hi) *hi = at((size_t)rank + 1);
+}
+
+int bppp_group_size(const bppp_group* grp) { return grp ? (int)grp->devices.size() : 0; }
+bppp_ctx* bppp_group_ctx(bppp_group* grp, int rank) { return (grp && rank >= 0 && rank < (int)grp->ctx.size()) ? grp->ctx[rank] : nullptr; }
+
+void bppp_group_destroy(bppp_group* grp) {
+    if (!grp) return;
+    for (size_t r = 0; r < grp->comm.size(); r++)
+        if (grp->comm[r]) { (void)hipSetDevice(grp->devices[r]); (void)grp->rccl.CommDestroy(grp->comm[r]); }
+    for (size_t r = 0; r < grp->ctx.size(); r++) {
+        if (r < grp->d_rej.size() && grp->d_rej[r]) { (void)hipSetDevice(grp->devices[r]); (void)hipFree(grp->d_rej[r]); }
+        bppp_ctx_destroy(grp->ctx[r]);
+    }
+    delete grp;
+}
+
+int bppp_group_create(bppp_group** out, const uint8_t g[64], const uint8_t* g_vec, const uint8_t* h_vec, const int* devices, int n_devices,
+                      int fb_window_bits) {
+    if (!out || !g || !g_vec || !h_vec || !devices || n_devices <= 0 || n_devices > 64) return BPPP_ERR_INVALID_ARG;
+    *out = nullptr;
+    for (int i = 0; i < n_devices; i++)
+        for (int j = 0; j < i; j++)
+            if (devices[i] == devices[j]) return BPPP_ERR_INVALID_ARG;
+    bppp_group* grp = new (std::nothrow) bppp_group();
+    if (!grp) return BPPP_ERR_NOMEM;
+    grp->devices.assign(devices, devices + n_devices);
+    grp->ctx.assign(n_devices, nullptr);
+    grp->d_rej.assign(n_devices, nullptr);
+    // contexts (fixed-base tables) are built concurrently, one host thread per device
+    std::vector<int> rcs(n_devices, BPPP_OK);
+    std::vector<std::string> errs(n_devices);
+    {
+        std::vector<std::thread> th;
+        for (int r = 0; r < n_devices; r++)
+            th.emplace_back([&, r]() {
+                rcs[r] = bppp_ctx_create(&grp->ctx[r], g, g_vec, h_vec, devices[r], fb_window_bits);
+                if (rcs[r] == BPPP_OK && hipMalloc(&grp->d_rej[r], sizeof(int)) != hipSuccess) rcs[r] = BPPP_ERR_NOMEM;
+                if (rcs[r] != BPPP_OK) errs[r] = g_last_error;
+            });
+        for (auto& t : th) t.join();
+    }
+    for (int r = 0; r < n_devices; r++)
+        if (rcs[r] != BPPP_OK) { g_last_error = errs[r]; int rc = rcs[r]; bppp_group_destroy(grp); return rc; }
+    if (n_devices > 1 || std::getenv("BPPP_FORCE_RCCL")) {
+        if (!rccl_load(grp->rccl)) { bppp_group_destroy(grp); return BPPP_ERR_RCCL; }
+        grp->comm.assign(n_devices, nullptr);
+        const int e = grp->rccl.CommInitAll(grp->comm.data(), n_devices, grp->devices.data());
+        if (e != 0) {
+            g_last_error = std::string("ncclCommInitAll: ") + (grp->rccl.GetErrorString ? grp->rccl.GetErrorString(e) : "failed");
+            grp->comm.clear();
+            bppp_group_destroy(grp);
+            return BPPP_ERR_RCCL;
+        }
+    }
+    *out = grp;
+    return BPPP_OK;
+}
+
+// one device's part of a sharded call: verify the shard, then take part in the accept-reduce; everything on the context's stream
+static int group_rank_verify(bppp_group* grp, int r, const uint8_t* label, size_t label_len, size_t n_r, const void* d_c, const void* d_p,
+                             void* d_a, void* d_s, void* d_rej) {
+    bppp_ctx* c = grp->ctx[r];
+    HIP_TRY(hipSetDevice(grp->devices[r]));
+    if (n_r) {
+        int rc = verify_device_impl(c, label, label_len, n_r, d_c, d_p, d_a, d_s, nullptr, d_rej, nullptr);
+        if (rc != BPPP_OK) return rc;
+    } else {
+        HIP_TRY(hipMemsetAsync(d_rej, 0, sizeof(int), c->stream));
+    }
+    if (!grp->comm.empty()) {
+        const int e = grp->rccl.AllReduce(d_rej, d_rej, 1, kRcclInt32, kRcclSum, grp->comm[r], c->stream);
+        if (e != 0) {
+            g_last_error = std::string("ncclAllReduce: ") + (grp->rccl.GetErrorString ? grp->rccl.GetErrorString(e) : "failed");
+            return BPPP_ERR_RCCL;
+        }
+    }
+    return BPPP_OK;
+}
+
+int bppp_u64_verify_batch_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const void* const* d_commitments,
+                                         const void* const* d_proofs, void* const* d_accept, void* const* d_status,
+                                         void* const* d_reject_count) {
+    if (!grp || (!label && label_len) || !d_commitments || !d_proofs || !d_accept || !d_reject_count) return BPPP_ERR_INVALID_ARG;
+    const int G = (int)grp->devices.size();
+    for (int r = 0; r < G; r++) {
+        size_t lo, hi;
+        bppp_shard_range(n, r, G, &lo, &hi);
+        if (!d_reject_count[r] || (hi > lo && (!d_commitments[r] || !d_proofs[r] || !d_accept[r]))) return BPPP_ERR_INVALID_ARG;
+    }
+    std::vector<int> rcs(G, BPPP_OK);
+    std::vector<std::string> errs(G);
+    std::vector<std::thread> th;
+    for (int r = 0; r < G; r++)
+        th.emplace_back([&, r]() {
+            size_t lo, hi;
+            bppp_shard_range(n, r, G, &lo, &hi);
+            rcs[r] = group_rank_verify(grp, r, label, label_len, hi - lo, d_commitments[r], d_proofs[r], d_accept[r],
+                                       d_status ? d_status[r] : nullptr, d_reject_count[r]);
+            if (rcs[r] == BPPP_OK) rcs[r] = bppp_ctx_synchronize(grp->ctx[r]);
+            if (rcs[r] != BPPP_OK) errs[r] = g_last_error;
+        });
+    for (auto& t : th) t.join();
+    for (int r = 0; r < G; r++)
+        if (rcs[r] != BPPP_OK) { g_last_error = errs[r]; return rcs[r]; }
+    return BPPP_OK;
+}
+
+int bppp_u64_verify_batch_sharded(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                                  const uint8_t* proofs, uint8_t* accept, int32_t* status, int32_t* reject_count) {
+    if (!grp || (!label && label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
+    if (reject_count) *reject_count = 0;
+    if (n == 0) return BPPP_OK;
+    const int G = (int)grp->devices.size();
+    std::vector<int> rcs(G, BPPP_OK), counts(G, 0);
+    std::vector<std::string> errs(G);
+    std::vector<std::thread> th;
+    for (int r = 0; r < G; r++)
+        th.emplace_back([&, r]() {
+            auto run = [&]() -> int {
+                size_t lo, hi;
+                bppp_shard_range(n, r, G, &lo, &hi);
+                const size_t m = hi - lo;
+                bppp_ctx* c = grp->ctx[r];
+                HIP_TRY(hipSetDevice(grp->devices[r]));
+                // the shard goes through the context's persistent I/O staging, exactly as bppp_u64_verify_batch does
+                const size_t o_c = 0, o_p = align16(o_c + m * 64), o_a = align16(o_p + m * (size_t)BPPP_U64_PROOF_BYTES), o_s = align16(o_a + m),
+                             need = align16(o_s + m * sizeof(int32_t)) + 16;
+                if (need > c->io_bytes) {
+                    if (c->d_io) { (void)hipFree(c->d_io); c->d_io = nullptr; c->io_bytes = 0; }
+                    HIP_TRY(hipMalloc(&c->d_io, need));
+                    c->io_bytes = need;
+                }
+                uint8_t *d_c = c->d_io + o_c, *d_p = c->d_io + o_p, *d_a = c->d_io + o_a;
+                int32_t* d_s = (int32_t*)(c->d_io + o_s);
+                if (m) {
+                    HIP_TRY(hipMemcpyAsync(d_c, commitments + lo * 64, m * 64, hipMemcpyHostToDevice, c->stream));
+                    HIP_TRY(hipMemcpyAsync(d_p, proofs + lo * (size_t)BPPP_U64_PROOF_BYTES, m * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice,
+                                           c->stream));
+                }
+                int rc = group_rank_verify(grp, r, label, label_len, m, d_c, d_p, d_a, d_s, grp->d_rej[r]);
+                if (rc != BPPP_OK) return rc;
+                if (m) {
+                    HIP_TRY(hipMemcpyAsync(accept + lo, d_a, m, hipMemcpyDeviceToHost, c->stream));
+                    if (status) HIP_TRY(hipMemcpyAsync(status + lo, d_s, m * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+                }
+                HIP_TRY(hipMemcpyAsync(&counts[r], grp->d_rej[r], sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                return bppp_ctx_synchronize(c);
+            };
+            rcs[r] = run();
+            if (rcs[r] != BPPP_OK) errs[r] = g_last_error;
+        });
+    for (auto& t : th) t.join();
+    for (int r = 0; r < G; r++)
+        if (rcs[r] != BPPP_OK) { g_last_error = errs[r]; return rcs[r]; }
+    if (reject_count) {
+        // with a communicator every device already holds the global count; without one (a single device) it is the local one
+        int total = 0;
+        if (!grp->comm.empty()) total = counts[0];
+        else for (int r = 0; r < G; r++) total += counts[r];
+        *reject_count = total;
+    }
+    return BPPP_OK;
+}
 
 }  // extern "C"

@@ -44,3 +44,8 @@ __global__ __launch_bounds__(256) void k_sec1_expand(uint8_t* commitments64, uin
     int j = (int)(g % 16);
     if (t < n && j < 15) sec1_expand_lane(commitments64, proofs928, commitments33, proofs525, t, j);
 }
+// pre-loaded transcript variant: each proof's advanced STROBE state back to the caller (203 bytes per proof)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_export_states(VerifyWs ws) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_export_state(ws, t);
+}

@@ -63,11 +63,40 @@ struct VerifyWs {
     u32* fsc;                    // [49*8][N]
     pt_slot* straus;             // [N][5][9]  (generic WNLA / reciprocal paths)
     apt_packed* atab;            // [N][13][2][8] affine multiples 1..8 of the 13 proof points, and of their GLV images (beta x, y)
-    u32* tscr;                   // [91*4*10][N] scratch of verify_tables: projective multiples + prefix products
+    u32* tscr;                   // [78*10][N] scratch of verify_tables: running products of the slope denominators
     const apt_packed* fb_table;  // [49][nwin][2^W - 1]
     int fb_w;                    // window bits: 4, 8 or 16
     strobe base;                 // Transcript::new(label)
+    // pre-loaded transcripts (the reference's `t: &mut Transcript`, u64_proof.rs:42): serialized STROBE states, 203 bytes each
+    // (200 state bytes, pos, pos_begin, cur_flags); n_states = 1 (one state shared by the batch) or N (one per proof); null =
+    // every proof starts from `base`.  states_out (optional, N x 203): each proof's transcript as verify leaves it.
+    const uint8_t* states;
+    size_t n_states;
+    uint8_t* states_out;
 };
+#define BPPP_TRANSCRIPT_STATE_BYTES 203
+HD bool strobe_from_bytes(strobe& s, const uint8_t* b) {
+#pragma nounroll
+    for (int i = 0; i < 25; i++) {
+        u64 v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v |= (u64)b[8 * i + k] << (8 * k);
+        s.st[i] = v;
+    }
+    s.pos = b[200];
+    s.pos_begin = b[201];
+    return s.pos < BPPP_STROBE_R && s.pos_begin <= BPPP_STROBE_R;      // merlin keeps pos in [0, R) between operations
+}
+HD void strobe_to_bytes(uint8_t* b, const strobe& s, u32 cur_flags) {
+#pragma nounroll
+    for (int i = 0; i < 25; i++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) b[8 * i + k] = (uint8_t)(s.st[i] >> (8 * k));
+    }
+    b[200] = (uint8_t)s.pos;
+    b[201] = (uint8_t)s.pos_begin;
+    b[202] = (uint8_t)cur_flags;
+}
 
 // ---------------------------------------------------------------- SoA access
 HD void ws_ld8(u32 r[8], const u32* base, size_t N, size_t t, int slot) {
@@ -594,73 +623,169 @@ HD void atab_store(apt_packed* tb, int e, const apt& a, const fe& beta, bool ide
     tb[e - 1] = k;
     tb[8 + e - 1] = kb;
 }
-struct TabScratch { fe X, Y, Z, pre; };
-HD void tscr_load(TabScratch& r, const VerifyWs& ws, size_t t, int idx) {
-    const int slot = idx * 4;
-    ws_ld_fe(r.X, ws.tscr, ws.N, t, slot, 5);
-    ws_ld_fe(r.Y, ws.tscr, ws.N, t, slot + 1, 2);
-    ws_ld_fe(r.Z, ws.tscr, ws.N, t, slot + 2, 2);
-    ws_ld_fe(r.pre, ws.tscr, ws.N, t, slot + 3, 1);
+// Window tables by AFFINE arithmetic, three batched inversions per proof.  The multiples of one point form three levels whose
+// slopes only need earlier levels:   2P = 2.P  |  3P = 2P + P, 4P = 2.2P  |  5P = 4P + P, 6P = 2.3P, 7P = 4P + 3P, 8P = 2.4P,
+// so all 13 points' level-l slope denominators (13, 26, 52 of them) are inverted together with Montgomery's trick.  An affine
+// step costs 1M (prefix) + 2M (unwinding) + 1M + 2S (slope, x, y) against 12M for a complete projective step plus 6M of
+// normalisation afterwards, and the only scratch is the running products (91 field elements per proof instead of 364).  The
+// unwinding of level l (which produces that level's points) is fused with the forward pass of level l + 1 on the same point,
+// so the passes alternate direction over the 13 points: A up, B down, C up, D down.
+// No exceptional cases arise: the group has prime order n > 8, so for a point P != O none of P .. 8P is O, 2y != 0, and the
+// additions jP + P (j = 2, 4) and 4P + 3P never meet equal x.  P = O (the (0, 0) sentinel, also what a malformed proof's
+// points are replaced by) gives zero denominators: they are replaced by 1 and every multiple is stored as O.
+#define BPPP_TSCR_FE 78   // running products: levels 1 and 3 share slots 0..51 (13, then 52), level 2 lives in 52..77 (26)
+#define BPPP_TSCR_L2 52
+struct aff_src { fe x, y; };
+HD void aff_ld(aff_src& r, const apt_packed* tb, int e) {   // multiple e (1..8) of the point whose table is tb
+    const apt_packed k = tb[e - 1];
+    fe_from_w8(r.x, k.x);
+    fe_from_w8(r.y, k.y);
+}
+HD void aff_den_dbl(fe& d, const aff_src& a, bool pid, const fe& one) { fe_add(d, a.y, a.y); fe_cmov(d, pid, one); }
+HD void aff_den_add(fe& d, const aff_src& a, const aff_src& b, bool pid, const fe& one) { fe_sub_m<1>(d, a.x, b.x); fe_cmov(d, pid, one); }   // a + b
+// 2a given 1 / (2 y_a)
+HD void aff_dbl(apt& r, const aff_src& a, const fe& dinv) {
+    fe num, lam, t;
+    fe_sqr(num, a.x);
+    fe_mul_small(num, num, 3);
+    fe_mul(lam, num, dinv);
+    fe_sqr(r.x, lam);
+    fe_add(t, a.x, a.x);
+    fe_sub_m<2>(r.x, r.x, t);            // magnitude 4
+    fe_sub_m<4>(t, a.x, r.x);            // 6
+    fe_mul(t, lam, t);
+    fe_sub_m<1>(r.y, t, a.y);            // 3
+}
+// a + b given 1 / (x_a - x_b)
+HD void aff_add(apt& r, const aff_src& a, const aff_src& b, const fe& dinv) {
+    fe num, lam, t;
+    fe_sub_m<1>(num, a.y, b.y);
+    fe_mul(lam, num, dinv);
+    fe_sqr(r.x, lam);
+    fe_sub_m<1>(r.x, r.x, a.x);          // 3
+    fe_sub_m<1>(r.x, r.x, b.x);          // 5
+    fe_sub_m<5>(t, a.x, r.x);            // 7
+    fe_mul(t, lam, t);
+    fe_sub_m<1>(r.y, t, a.y);            // 3
+}
+HD void aff_take(aff_src& r, const apt& a) {   // a freshly computed point as the operand of the next level (magnitudes -> 1)
+    fe_mul_small(r.x, a.x, 1);
+    fe_mul_small(r.y, a.y, 1);
+}
+// one Montgomery-trick step forward: store the running product, multiply the denominator in
+HD void aff_push(const VerifyWs& ws, size_t t, int slot, fe& run, const fe& den) {
+    ws_st_fe(ws.tscr, ws.N, t, slot, run);
+    fe_mul(run, run, den);
+}
+// ... and backward: dinv = 1 / den, inv loses den
+HD void aff_pop(fe& dinv, const VerifyWs& ws, size_t t, int slot, fe& inv, const fe& den) {
+    fe pre;
+    ws_ld_fe(pre, ws.tscr, ws.N, t, slot, 1);
+    fe_mul(dinv, inv, pre);
+    fe_mul(inv, inv, den);
 }
 HD void verify_tables(const VerifyWs& ws, size_t t) {
     const size_t N = ws.N;
     BPPP_STAMP(t, 16);
-    fe run, beta, one;
-    fe_set_u32(run, 1);
+    fe run, inv, beta, one, d, dinv;
     fe_set_u32(one, 1);
     glv_beta(beta);
-    // forward: multiples 2P..8P (projective, complete formulas), running product of their Z
+    apt_packed* const tab = ws.atab + t * BPPP_ATAB_PER_PROOF;
+    // ---- pass A (up): entry 1 of every table; level-1 denominators 2 y_P
+    fe_set_u32(run, 1);
 #pragma nounroll
     for (int p = 0; p < BPPP_VPOINTS; p++) {
         apt P;
         ws_ld_apt(P, ws.pts, N, t, p);
         const bool pid = apt_is_identity(P);
-        pt cur;
-        pt_from_affine(cur, P);
-#pragma nounroll
-        for (int e = 2; e <= 8; e++) {
-            pt d;
-            if (e == 2) pt_dbl(d, cur);          // loop counter: wave-uniform branch
-            else pt_madd(d, cur, P, pid);
-            cur = d;
-            const int slot = (p * 7 + (e - 2)) * 4;
-            ws_st_fe(ws.tscr, N, t, slot, cur.X);
-            ws_st_fe(ws.tscr, N, t, slot + 1, cur.Y);
-            ws_st_fe(ws.tscr, N, t, slot + 2, cur.Z);
-            ws_st_fe(ws.tscr, N, t, slot + 3, run);
-            fe z = cur.Z;
-            fe_cmov(z, pid, one);               // the identity's multiples have Z = 0: keep the product invertible
-            fe_mul(run, run, z);
-        }
+        atab_store(tab + p * 16, 1, P, beta, pid);
+        aff_src a = {P.x, P.y};
+        aff_den_dbl(d, a, pid, one);
+        aff_push(ws, t, p, run, d);
     }
-    BPPP_STAMP(t, 17);
-    fe inv;
     fe_inv(inv, run);
-    BPPP_STAMP(t, 18);
-    // backward: 1/Z_e = inv * prefix_e; the next entry's scratch words are requested before this entry's arithmetic
-    TabScratch cur, nxt;
-    tscr_load(cur, ws, t, BPPP_VPOINTS * 7 - 1);
+    BPPP_STAMP(t, 17);
+    // ---- pass B (down): 2P; level-2 denominators x_2P - x_P (3P = 2P + P), 2 y_2P (4P)
+    fe_set_u32(run, 1);
 #pragma nounroll
     for (int p = BPPP_VPOINTS - 1; p >= 0; p--) {
         apt P;
         ws_ld_apt(P, ws.pts, N, t, p);
         const bool pid = apt_is_identity(P);
-        apt_packed* tb = ws.atab + (t * BPPP_VPOINTS + p) * 16;
+        aff_src a = {P.x, P.y};
+        aff_den_dbl(d, a, pid, one);
+        aff_pop(dinv, ws, t, p, inv, d);
+        apt P2;
+        aff_dbl(P2, a, dinv);
+        atab_store(tab + p * 16, 2, P2, beta, pid);
+        aff_src a2;
+        aff_take(a2, P2);
+        const int q = BPPP_TSCR_L2 + (BPPP_VPOINTS - 1 - p) * 2;
+        aff_den_add(d, a2, a, pid, one);
+        aff_push(ws, t, q, run, d);
+        aff_den_dbl(d, a2, pid, one);
+        aff_push(ws, t, q + 1, run, d);
+    }
+    fe_inv(inv, run);
+    BPPP_STAMP(t, 18);
+    // ---- pass C (up): 4P, 3P; level-3 denominators x_4P - x_P (5P), 2 y_3P (6P), x_4P - x_3P (7P), 2 y_4P (8P)
+    fe_set_u32(run, 1);
 #pragma nounroll
-        for (int e = 8; e >= 2; e--) {
-            const int idx = p * 7 + (e - 2);
-            tscr_load(nxt, ws, t, idx > 0 ? idx - 1 : 0);
-            fe zinv;
-            fe_cmov(cur.Z, pid, one);
-            fe_mul(zinv, inv, cur.pre);
-            fe_mul(inv, inv, cur.Z);
-            apt a;
-            fe_mul(a.x, cur.X, zinv);
-            fe_mul(a.y, cur.Y, zinv);
-            atab_store(tb, e, a, beta, pid);
-            cur = nxt;
-        }
-        atab_store(tb, 1, P, beta, pid);
+    for (int p = 0; p < BPPP_VPOINTS; p++) {
+        apt_packed* tb = tab + p * 16;
+        aff_src a, a2;
+        aff_ld(a, tb, 1);
+        aff_ld(a2, tb, 2);
+        const bool pid = fe_is_zero(a.x) & fe_is_zero(a.y);
+        const int q = BPPP_TSCR_L2 + (BPPP_VPOINTS - 1 - p) * 2;
+        apt P3, P4;
+        aff_den_dbl(d, a2, pid, one);
+        aff_pop(dinv, ws, t, q + 1, inv, d);
+        aff_dbl(P4, a2, dinv);
+        aff_den_add(d, a2, a, pid, one);
+        aff_pop(dinv, ws, t, q, inv, d);
+        aff_add(P3, a2, a, dinv);
+        atab_store(tb, 3, P3, beta, pid);
+        atab_store(tb, 4, P4, beta, pid);
+        aff_src a3, a4;
+        aff_take(a3, P3);
+        aff_take(a4, P4);
+        aff_den_add(d, a4, a, pid, one);
+        aff_push(ws, t, 4 * p, run, d);
+        aff_den_dbl(d, a3, pid, one);
+        aff_push(ws, t, 4 * p + 1, run, d);
+        aff_den_add(d, a4, a3, pid, one);
+        aff_push(ws, t, 4 * p + 2, run, d);
+        aff_den_dbl(d, a4, pid, one);
+        aff_push(ws, t, 4 * p + 3, run, d);
+    }
+    fe_inv(inv, run);
+    // ---- pass D (down): 8P, 7P, 6P, 5P
+#pragma nounroll
+    for (int p = BPPP_VPOINTS - 1; p >= 0; p--) {
+        apt_packed* tb = tab + p * 16;
+        aff_src a, a3, a4;
+        aff_ld(a, tb, 1);
+        aff_ld(a3, tb, 3);
+        aff_ld(a4, tb, 4);
+        const bool pid = fe_is_zero(a.x) & fe_is_zero(a.y);
+        apt R;
+        aff_den_dbl(d, a4, pid, one);
+        aff_pop(dinv, ws, t, 4 * p + 3, inv, d);
+        aff_dbl(R, a4, dinv);
+        atab_store(tb, 8, R, beta, pid);
+        aff_den_add(d, a4, a3, pid, one);
+        aff_pop(dinv, ws, t, 4 * p + 2, inv, d);
+        aff_add(R, a4, a3, dinv);
+        atab_store(tb, 7, R, beta, pid);
+        aff_den_dbl(d, a3, pid, one);
+        aff_pop(dinv, ws, t, 4 * p + 1, inv, d);
+        aff_dbl(R, a3, dinv);
+        atab_store(tb, 6, R, beta, pid);
+        aff_den_add(d, a4, a, pid, one);
+        aff_pop(dinv, ws, t, 4 * p, inv, d);
+        aff_add(R, a4, a, dinv);
+        atab_store(tb, 5, R, beta, pid);
     }
     BPPP_STAMP(t, 19);
 }
@@ -808,6 +933,12 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
         sc_set_u32(l0, 0); sc_set_u32(l1, 0); sc_set_u32(n0, 0);
     }
     strobe tr = ws.base;
+    if (ws.states) {
+        strobe pre;
+        const bool sok = strobe_from_bytes(pre, ws.states + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * (ws.n_states == 1 ? 0 : t));
+        if (sok) tr = pre;
+        else status |= ST_BAD_ENCODING;      // not a state merlin could be in: flag the proof, run on the shared base
+    }
     sc e, rho, lambda, beta, delta, tau;
     BPPP_STAMP(t, 1);
     app_point(tr, "reciprocal_commitment", V);                          // reciprocal.rs:99
@@ -1004,16 +1135,20 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k) {
         pt_add(C, C, F);
     }
     BPPP_STAMP(t, 9);
-    apt Ca, X, R;
+    apt Ca;
     pt_to_affine(Ca, C);
     BPPP_STAMP(t, 10);
-    ws_ld_apt(X, ws.pts, N, t, 8 + (4 - k));   // proof.x.last()
-    ws_ld_apt(R, ws.pts, N, t, 4 + (4 - k));   // proof.r.last()
     strobe tr;
     ws_ld_strobe(tr, ws.tstate, N, t);
     app_point(tr, "wnla_com", Ca);                                       // wnla.rs:88-92
-    app_point(tr, "wnla_x", X);
-    app_point(tr, "wnla_r", R);
+    {   // the round's proof points are only hashed here (the sum below reads their window tables): loaded one at a time, right
+        // before their append, so that nothing but the sponge state and C is live across the permutations
+        apt Q;
+        ws_ld_apt(Q, ws.pts, N, t, 8 + (4 - k));   // proof.x.last()
+        app_point(tr, "wnla_x", Q);
+        ws_ld_apt(Q, ws.pts, N, t, 4 + (4 - k));   // proof.r.last()
+        app_point(tr, "wnla_r", Q);
+    }
     t_append_u64(tr, "l.sz", (u64)(32 >> (k - 1)));
     t_append_u64(tr, "n.sz", (u64)(16 >> (k - 1)));
     sc y;
@@ -1128,6 +1263,26 @@ HD void verify_accept(const VerifyWs& ws, size_t t) {
         pt_to_affine(Ca, C);
         apt_to_xy64(ws.trace + 704 * t + 320 + 64 * 5, Ca);
     }
+}
+// The caller's `&mut Transcript` after verify (Ownership): the state after the last challenge (wnla.rs:94 in round 4,
+// a PRF operation: cur_flags = I|A|C = 7).  A proof whose inputs k256 would have refused to deserialize never reaches the
+// reference's verify, so its transcript comes back untouched.
+HD void verify_export_state(const VerifyWs& ws, size_t t) {
+    if (!ws.states_out) return;
+    uint8_t* out = ws.states_out + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * t;
+    if (ws.status[t] & ST_BAD_ENCODING) {
+        if (ws.states) {
+            const uint8_t* in = ws.states + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * (ws.n_states == 1 ? 0 : t);
+#pragma nounroll
+            for (int i = 0; i < BPPP_TRANSCRIPT_STATE_BYTES; i++) out[i] = in[i];
+        } else {
+            strobe_to_bytes(out, ws.base, 2);      // Transcript::new ends with an AD operation (the dom-sep message)
+        }
+        return;
+    }
+    strobe tr;
+    ws_ld_strobe(tr, ws.tstate, ws.N, t);
+    strobe_to_bytes(out, tr, 7);
 }
 HD void verify_final_check(const VerifyWs& ws, size_t t) {
     FbRanges rg;

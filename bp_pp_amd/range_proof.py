@@ -89,6 +89,24 @@ class U64RangeProofProtocol:
                                                              d_accept, d_status or None, d_trace or None,
                                                              d_reject_count or None))
 
+    def verify_batch_transcript(self, commitments, proofs, transcripts, want_states: bool = True):
+        """verify with the caller's transcripts (the reference's `t: &mut Transcript`): `transcripts` is ONE serialized state
+        (203 bytes or a bp_pp_amd.transcript.Transcript) shared by the batch, or a sequence of n of them.  Returns (accept,
+        status, states_out [n, 203] or None): states_out[i] is proof i's transcript as the reference's verify leaves it."""
+        commitments = _as_u8(commitments, (-1, 64))
+        n = commitments.shape[0]
+        proofs = _as_u8(proofs, (n, U64_PROOF_BYTES))
+        as_bytes = lambda t: t.state if hasattr(t, "state") else bytes(t)
+        blob = as_bytes(transcripts) if hasattr(transcripts, "state") or isinstance(transcripts, (bytes, bytearray)) else \
+            b"".join(as_bytes(t) for t in transcripts)
+        states = _as_u8(blob, (-1, 203))
+        accept, status = np.zeros(n, dtype=np.uint8), np.zeros(n, dtype=np.int32)
+        out = np.zeros((n, 203), dtype=np.uint8) if want_states else None
+        _capi.check(_capi.lib().bppp_u64_verify_batch_transcript(self._ctx, n, states.ctypes.data, states.shape[0], commitments.ctypes.data,
+                                                                 proofs.ctypes.data, accept.ctypes.data, status.ctypes.data,
+                                                                 out.ctypes.data if want_states else None))
+        return accept, status, out
+
     def verify_batch_rlc(self, commitments, proofs, label: bytes, seed: bytes) -> Tuple[np.ndarray, np.ndarray]:
         """verify_batch in the optional RLC mode (host buffers); see verify_batch_rlc_device."""
         if len(seed) != 32:

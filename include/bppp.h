@@ -233,6 +233,62 @@ BPPP_API int bppp_reciprocal_verify_batch(bppp_ctx* ctx, const uint8_t* label, s
                                           const uint8_t* commitments /* n x 64 */, const uint8_t* proofs, size_t rounds, size_t nl,
                                           size_t nn, uint8_t* accept /* n */, int32_t* status /* n or NULL */);
 
+/* ---- the reference's `t: &mut Transcript` (u64_proof.rs:42, wnla.rs:75, circuit.rs:154; SURVEY 8b "Ownership") ----
+ * Every entry point above takes a label and starts each proof from `Transcript::new(label)`, which is what all of the reference's
+ * own call sites do.  A caller that has already appended to its transcript (binding a context, a transaction id, ...) passes the
+ * transcript itself instead, as merlin's STROBE-128 state serialized to 203 bytes:
+ *     bytes 0..199  the Keccak-f[1600] state (strobe.rs `state`), byte order as in memory
+ *     byte  200     pos          byte 201  pos_begin          byte 202  cur_flags
+ * states holds n_states = 1 transcript (shared by every proof of the batch) or n_states = n (one per proof).  states_out
+ * (optional, n x 203) receives each proof's transcript as the reference's verify leaves it for the caller -- advanced through the
+ * last `wnla_challenge` -- so the caller can keep using it; a proof flagged BPPP_ST_BAD_ENCODING (inputs k256 would not have
+ * deserialized, so the reference's verify is never entered) gets its input state back unchanged.  A state merlin cannot be in
+ * (pos >= 166) is refused: BPPP_ERR_INVALID_ARG from the host entry point, BPPP_ST_BAD_ENCODING per proof from the device one. */
+#define BPPP_TRANSCRIPT_STATE_BYTES 203
+BPPP_API int bppp_u64_verify_batch_transcript(bppp_ctx* ctx, size_t n, const uint8_t* states /* n_states x 203 */, size_t n_states,
+                                              const uint8_t* commitments /* n x 64 */, const uint8_t* proofs /* n x 928 */,
+                                              uint8_t* accept /* n */, int32_t* status /* n or NULL */,
+                                              uint8_t* states_out /* n x 203 or NULL */);
+/* the same with DEVICE buffers, asynchronous on the context's stream */
+BPPP_API int bppp_u64_verify_batch_transcript_device(bppp_ctx* ctx, size_t n, const void* d_states, size_t n_states,
+                                                     const void* d_commitments, const void* d_proofs, void* d_accept, void* d_status,
+                                                     void* d_reject_count, void* d_states_out);
+/* merlin::Transcript on serialized states, host only (no GPU needed): Transcript::new(label), append_message(label, msg)
+ * (transcript.rs:7 uses it for points, wnla.rs:91-92 for u64s) and challenge_bytes(label, out) (transcript.rs:12).  A Rust caller
+ * holding a real merlin::Transcript does not need these; a C caller builds its pre-loaded states with them. */
+BPPP_API int bppp_transcript_new(const uint8_t* label, size_t label_len, uint8_t state_out[203]);
+BPPP_API int bppp_transcript_append_message(uint8_t state[203], const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len);
+BPPP_API int bppp_transcript_challenge_bytes(uint8_t state[203], const uint8_t* label, size_t label_len, uint8_t* out, size_t n);
+
+/* ---- one batch over the GPUs of a node (BASELINE configs[2]; SURVEY 8b `device_mask`, 8e) ----
+ * Proofs are independent (fresh transcript per proof, benches/range_proof.rs:47), so a batch shards by proof index with no
+ * data-path collective: device r of a group of G verifies proofs [n r / G, n (r + 1) / G) (bppp_shard_range) against its own
+ * replica of the fixed-base tables, and the single exchange is the number of rejected proofs: one 4-byte ncclAllReduce(sum,
+ * int32) over RCCL/xGMI, after which every device holds the batch's global reject count (0 <=> the batch is accepted).
+ * A group owns one context, one stream and (for G > 1) one RCCL communicator per device, all inside this process; a call runs
+ * one host thread per device.  RCCL is loaded at group creation with dlopen("librccl.so.1") -- the library has no link-time
+ * dependency on it, and a group of ONE device never needs it (set BPPP_FORCE_RCCL=1 to route a one-device group through a
+ * one-rank communicator anyway, which is how the single-GPU test tier exercises this path). */
+typedef struct bppp_group bppp_group;
+#define BPPP_ERR_RCCL (-6) /* librccl could not be loaded, or an RCCL call failed; see bppp_last_error() */
+BPPP_API void bppp_shard_range(size_t n_total, int rank, int world, size_t* lo, size_t* hi);
+/* devices: n_devices distinct HIP device ordinals.  Every device gets the same generators / window width (see bppp_ctx_create). */
+BPPP_API int bppp_group_create(bppp_group** out, const uint8_t g[64], const uint8_t* g_vec, const uint8_t* h_vec, const int* devices,
+                               int n_devices, int fb_window_bits);
+BPPP_API void bppp_group_destroy(bppp_group* grp);
+BPPP_API int bppp_group_size(const bppp_group* grp);
+BPPP_API bppp_ctx* bppp_group_ctx(bppp_group* grp, int rank); /* the rank-th device's context (owned by the group) */
+/* U64RangeProofProtocol::verify for ONE batch of n proofs in HOST memory, sharded over the group.  accept / status as in
+ * bppp_u64_verify_batch; *reject_count (optional) receives the all-reduced number of rejected proofs. */
+BPPP_API int bppp_u64_verify_batch_sharded(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                                           const uint8_t* proofs, uint8_t* accept, int32_t* status, int32_t* reject_count);
+/* The same with every shard already resident on its device: rank r's arrays hold its n_r = hi - lo proofs of bppp_shard_range(n,
+ * r, G) in DEVICE memory of device r; d_reject_count[r] (device int32[1], required) receives the GLOBAL reject count on every
+ * device.  Returns when all devices have finished. */
+BPPP_API int bppp_u64_verify_batch_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n,
+                                                  const void* const* d_commitments, const void* const* d_proofs, void* const* d_accept,
+                                                  void* const* d_status /* entries may be NULL */, void* const* d_reject_count);
+
 /* Profiling aid for bench.py: when enabled, every kernel launch of the verify pipeline is bracketed by HIP events on
  * the context's stream; bppp_ctx_get_timings returns accumulated milliseconds and launch counts per kernel since the
  * last reset.  names[i] points to a static string. */

@@ -230,7 +230,7 @@ int emul_straus_affine(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64
     ws.N = 1;
     std::vector<u32> pts(208, 0);
     std::vector<apt_packed> atab(BPPP_ATAB_PER_PROOF);
-    std::vector<u32> tscr((size_t)91 * 40);
+    std::vector<u32> tscr((size_t)BPPP_TSCR_FE * 10);
     ws.pts = pts.data(); ws.atab = atab.data(); ws.tscr = tscr.data();
     glv_words<5> g5;
     glv_words<2> g2;
@@ -260,11 +260,25 @@ int emul_straus_affine(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64
     return 0;
 }
 // full exact verify pipeline, every phase in thread order
+static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
+                                const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* trace, const uint8_t* states,
+                                size_t n_states, uint8_t* states_out);
 int emul_u64_verify_batch(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
                           const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* trace) {
+    return emul_u64_verify_impl(table, W, label, label_len, n, V, proofs, accept, status, trace, nullptr, 0, nullptr);
+}
+// the same with pre-loaded transcripts (include/bppp.h: bppp_u64_verify_batch_transcript): n_states = 1 or n serialized states
+int emul_u64_verify_batch_transcript(const uint8_t* table, int W, size_t n, const uint8_t* states, size_t n_states, const uint8_t* V,
+                                     const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    return emul_u64_verify_impl(table, W, nullptr, 0, n, V, proofs, accept, status, nullptr, states, n_states, states_out);
+}
+static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
+                                const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* trace, const uint8_t* states,
+                                size_t n_states, uint8_t* states_out) {
     VerifyWs ws;
     memset(&ws, 0, sizeof ws);
     ws.N = n;
+    ws.states = states; ws.n_states = n_states; ws.states_out = states_out;
     ws.commitments = V; ws.proofs = proofs; ws.accept = accept; ws.status = status; ws.trace = trace;
     std::vector<u32> strobe_(52 * n), chal(80 * n), sc0(176 * n), cvec(200 * n), pts(208 * n), lns(24 * n), acc(30 * n), pfix(30 * n),
         fsc(392 * n);
@@ -272,7 +286,7 @@ int emul_u64_verify_batch(const uint8_t* table, int W, const uint8_t* label, siz
     ws.tstate = strobe_.data(); ws.chal = chal.data(); ws.sc0 = sc0.data(); ws.cvec = cvec.data(); ws.pts = pts.data();
     ws.lns = lns.data(); ws.acc = acc.data(); ws.pfix = pfix.data(); ws.fsc = fsc.data(); ws.straus = straus.data();
     std::vector<apt_packed> atab(n * BPPP_ATAB_PER_PROOF);
-    std::vector<u32> tscr((size_t)91 * 40 * n);
+    std::vector<u32> tscr((size_t)BPPP_TSCR_FE * 10 * n);
     ws.atab = atab.data(); ws.tscr = tscr.data();
     ws.fb_table = (const apt_packed*)table;
     ws.fb_w = W;
@@ -285,6 +299,7 @@ int emul_u64_verify_batch(const uint8_t* table, int W, const uint8_t* label, siz
         for (size_t t = 0; t < n; t++) verify_round(ws, t, k);
     for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);
     for (size_t t = 0; t < n; t++) verify_final_check(ws, t);
+    for (size_t t = 0; t < n; t++) verify_export_state(ws, t);
     return 0;
 }
 // the random-linear-combination batch mode (rlc_core.h): exact pipeline through the final scalars, weighted commitments, one
@@ -301,7 +316,7 @@ int emul_u64_verify_batch_rlc(const uint8_t* table, int W, const uint8_t* label,
         fsc(392 * n), lhs(30 * n), rsc(392 * n);
     std::vector<pt_slot> straus(n * 5 * BPPP_STRAUS_ENTRIES);
     std::vector<apt_packed> atab(n * BPPP_ATAB_PER_PROOF);
-    std::vector<u32> tscr((size_t)91 * 40 * n);
+    std::vector<u32> tscr((size_t)BPPP_TSCR_FE * 10 * n);
     std::vector<uint8_t> flag(n / 8 + 1);
     ws.tstate = strobe_.data(); ws.chal = chal.data(); ws.sc0 = sc0.data(); ws.cvec = cvec.data(); ws.pts = pts.data();
     ws.lns = lns.data(); ws.acc = acc.data(); ws.pfix = pfix.data(); ws.fsc = fsc.data(); ws.straus = straus.data();

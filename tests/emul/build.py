@@ -30,6 +30,7 @@ def load():
     L.emul_pt_op.argtypes = [i32, cp, cp, vp]
     L.emul_merlin_kat.argtypes = [cp, sz, cp, sz, vp, sz]
     L.emul_u64_verify_batch.argtypes = [vp, i32, cp, sz, sz, vp, vp, vp, vp, vp]
+    L.emul_u64_verify_batch_transcript.argtypes = [vp, i32, sz, vp, sz, vp, vp, vp, vp, vp]
     L.emul_u64_verify_batch_rlc.argtypes = [vp, i32, cp, sz, sz, vp, vp, cp, vp, vp, vp, vp, vp]
     L.emul_u64_prove_batch.argtypes = [vp, i32, cp, sz, sz, vp, vp, vp, vp, vp, vp]
     L.emul_sec1_expand.argtypes = [sz, vp, vp, vp, vp]

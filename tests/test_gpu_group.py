@@ -1,0 +1,75 @@
+"""GPU tests of the node-level sharded entry points (include/bppp.h: bppp_group_*, bppp_u64_verify_batch_sharded[_device]).
+The GPU tier has ONE device, so the group has one rank: its results must equal the single-context entry point's, with and
+without the RCCL accept-reduce (BPPP_FORCE_RCCL=1 routes a one-device group through a one-rank communicator, so that
+dlopen(librccl), ncclCommInitAll and ncclAllReduce on the verify stream really run)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def batch():
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import workload
+    n = 333
+    gens, V, P, _ = workload.make_batch(n, first=77000)
+    P, expect = workload.corrupt(P, V, every=10)
+    P = P.copy()
+    P[5, 3] ^= 0x80                       # c_l leaves the curve: status flag, counted as a reject
+    expect = expect.copy(); expect[5] = 0
+    return gens, V, P, expect
+
+
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_one_device_group_equals_single_context(batch, force_rccl, monkeypatch):
+    import torch
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    from bp_pp_amd.distributed import U64RangeProofGroup
+    gens, V, P, expect = batch
+    g, gv, hv = workload.split_generators(gens)
+    if force_rccl:
+        monkeypatch.setenv("BPPP_FORCE_RCCL", "1")
+    else:
+        monkeypatch.delenv("BPPP_FORCE_RCCL", raising=False)
+    grp = U64RangeProofGroup(g, gv, hv, [0], fb_window_bits=8)
+    single = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
+    try:
+        assert len(grp) == 1
+        acc, st, rej = grp.verify_batch(V, P, workload.LABEL)
+        acc1, st1 = single.verify_batch(V, P, workload.LABEL)
+        assert (acc == acc1).all() and (st == st1).all() and (acc == expect).all()
+        assert rej == int((expect == 0).sum()) and st[5] == 1
+        # ragged and empty batches
+        for m in (0, 1, 65):
+            a, s, r = grp.verify_batch(V[:m], P[:m], workload.LABEL)
+            assert a.tolist() == expect[:m].tolist() and r == int((expect[:m] == 0).sum())
+        # shards already resident on their device
+        n = V.shape[0]
+        dV, dP = torch.from_numpy(V).cuda(), torch.from_numpy(P).cuda()
+        dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dS = torch.zeros(n, dtype=torch.int32, device="cuda")
+        dR = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        grp.verify_batch_device(workload.LABEL, n, [dV.data_ptr()], [dP.data_ptr()], [dA.data_ptr()], [dS.data_ptr()], [dR.data_ptr()])
+        assert (dA.cpu().numpy() == expect).all() and int(dR.item()) == rej and (dS.cpu().numpy() == st).all()
+    finally:
+        grp.close()
+        single.close()
+
+
+def test_group_rejects_bad_arguments():
+    import ctypes as C
+    import workload
+    from bp_pp_amd import BpppError
+    from bp_pp_amd.distributed import U64RangeProofGroup
+    g, gv, hv = workload.split_generators(workload.generators())
+    with pytest.raises(BpppError):
+        U64RangeProofGroup(g, gv, hv, [0, 0], fb_window_bits=8)           # the same device twice
+    with pytest.raises(BpppError):
+        U64RangeProofGroup(g, gv, hv, [99], fb_window_bits=8)             # no such device

@@ -65,7 +65,7 @@ def test_u64_verify_at_baseline_sizes(torch_mod, oracle_c, log_n, wbits):
         oacc, ost = oracle_c.u64_verify_batch(gens, synth.LABEL, Vs, Ps, nthreads=os.cpu_count() or 1)
         assert (oacc == acc[idx]).all() and not ost.any()
         # the prover that made the batch, cross-checked: the oracle prover on the same (x, s, rnd) gives the same bytes
-        p0 = n // 2 + 1000                      # 96 consecutive proofs, none of them a corrupted one
+        p0 = n // 2 + 100                       # 96 consecutive proofs between two corrupted ones (global index = 0 mod 1024)
         pidx = np.arange(p0, p0 + 96, dtype=np.int64)
         assert expect[pidx].all()
         x, s, rnd = synth.bulk_values(96, first=lo + p0), synth.bulk_blindings(96, first=lo + p0), synth.bulk_prover_randomness(96, first=lo + p0)

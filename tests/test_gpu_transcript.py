@@ -1,0 +1,64 @@
+"""GPU twin of tests/test_transcript_state.py: bppp_u64_verify_batch_transcript[_device] on an MI355X -- proofs made over
+pre-loaded transcripts by the oracle, accept bits and the per-proof advanced merlin states equal to the oracle's."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_preloaded_transcripts_on_the_gpu(shared):
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import transcript_cases as TC
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    from bp_pp_amd.transcript import Transcript
+    case = TC.make(5, shared=shared)
+    g, gv, hv = workload.split_generators(case["gens"])
+    proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
+    try:
+        V, P, S = case["V"], case["P"], case["states_in"]
+        n = V.shape[0]
+        acc, st, out = proto.verify_batch_transcript(V, P, S[0].tobytes() if shared else [s.tobytes() for s in S])
+        assert acc.tolist() == [1] * n and not st.any() and (out == case["states_after"]).all()
+        # label-only entry point on the same proofs: the bound context is missing from the transcript, so they must fail
+        acc0, st0 = proto.verify_batch(V, P, workload.LABEL)
+        assert not acc0.any() and not st0.any()
+        # ... and the transcript entry point fed Transcript::new(label) equals the label entry point on label-made proofs
+        gens2, V2, P2, _ = workload.make_batch(70, first=5)
+        assert gens2 == case["gens"]
+        a1, s1 = proto.verify_batch(V2, P2, workload.LABEL)
+        a2, s2, o2 = proto.verify_batch_transcript(V2, P2, Transcript(workload.LABEL))
+        assert a1.all() and (a1 == a2).all() and (s1 == s2).all()
+        # negatives, judged by the oracle: wrong proof (state advances), malformed proof (state untouched), wrong commitment
+        Pn, Vn = P.copy(), V.copy()
+        Pn[0, 900] ^= 1
+        Pn[1, 5] ^= 0x10
+        Vn[2] = V[3]
+        acc, st, out = proto.verify_batch_transcript(Vn, Pn, S[0].tobytes() if shared else [s.tobytes() for s in S])
+        s_in = lambda j: bytes(S[0 if shared else j])
+        assert acc.tolist() == [0, 0, 0, 1, 1] and st.tolist() == [0, 1, 0, 0, 0]
+        for j in (0, 2):
+            ok, after = TC.oracle_verify(case, j, bytes(Vn[j]), bytes(Pn[j]), s_in(j))
+            assert not ok and bytes(out[j]) == after
+        assert bytes(out[1]) == s_in(1) and (out[3:] == case["states_after"][3:]).all()
+        # device-buffer variant, asynchronous on the context's stream
+        dV, dP, dS = torch.from_numpy(V).cuda(), torch.from_numpy(P).cuda(), torch.from_numpy(S).cuda()
+        dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dSt = torch.zeros(n, dtype=torch.int32, device="cuda")
+        dR = torch.zeros(1, dtype=torch.int32, device="cuda")
+        dO = torch.zeros((n, 203), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        from bp_pp_amd import _capi
+        _capi.check(_capi.lib().bppp_u64_verify_batch_transcript_device(proto._ctx, n, dS.data_ptr(), S.shape[0], dV.data_ptr(), dP.data_ptr(),
+                                                                        dA.data_ptr(), dSt.data_ptr(), dR.data_ptr(), dO.data_ptr()))
+        proto.synchronize()
+        assert dA.cpu().numpy().all() and int(dR.item()) == 0 and (dO.cpu().numpy() == case["states_after"]).all()
+        # a state merlin cannot be in is refused
+        bad = bytearray(S[0].tobytes()); bad[200] = 166
+        with pytest.raises(Exception):
+            proto.verify_batch_transcript(V, P, bytes(bad))
+    finally:
+        proto.close()

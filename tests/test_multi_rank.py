@@ -68,3 +68,21 @@ def test_two_ranks_gloo_reject_count():
         merged[lo:hi] = acc
         assert total == sum(1 for e in expect if e == 0)      # every rank sees the global reject count
     assert merged == expect
+
+
+def test_c_abi_shard_range_equals_the_python_split():
+    """bppp_shard_range (what a Rust / C caller of the sharded entry points uses) == bp_pp_amd.distributed.shard_range, covers
+    [0, n) exactly, for ragged sizes too.  No GPU needed: the function is pure host code of libbppp_hip.so."""
+    import ctypes as C
+    from bp_pp_amd import _capi
+    from bp_pp_amd.distributed import shard_range
+    L = _capi.lib()
+    for n in (0, 1, 7, 8, 9, 1000, 65536, (1 << 20), (1 << 20) + 5, (1 << 62) + 3):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = C.c_size_t(), C.c_size_t()
+                L.bppp_shard_range(n, r, world, C.byref(lo), C.byref(hi))
+                assert (lo.value, hi.value) == shard_range(n, r, world) and lo.value == prev
+                prev = hi.value
+            assert prev == n

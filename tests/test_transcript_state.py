@@ -1,0 +1,66 @@
+"""The `t: &mut Transcript` boundary: serialized merlin states through the C ABI's host helpers and through the
+device code of the verifier (compiled for the host, tests/emul).  CPU tier; the -m gpu twin is in tests/test_gpu_transcript.py."""
+import os
+
+import numpy as np
+import pytest
+
+import bppp_oracle as O
+import transcript_cases as TC
+from bp_pp_amd.transcript import Transcript
+from emul.build import load
+
+
+def test_host_transcript_ops_equal_merlin():
+    """bppp_transcript_{new, append_message, challenge_bytes}: merlin's published known answer, and state-for-state equality with
+    the oracle's Strobe128 through operations that cross the sponge rate."""
+    t = Transcript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    o, t = O.Transcript(b"u64 range proof"), Transcript(b"u64 range proof")
+    assert TC.ser(o) == t.state
+    rng = np.random.default_rng(9)
+    for k in range(40):
+        label = bytes(rng.integers(0, 256, int(rng.integers(0, 50)), dtype=np.uint8))
+        if k % 3 == 2:
+            n = int(rng.integers(0, 400))
+            assert o.challenge_bytes(label, n) == t.challenge_bytes(label, n)
+        elif k % 3 == 1:
+            x = int(rng.integers(0, 2**63))
+            o.append_u64(label, x); t.append_u64(label, x)
+        else:
+            m = bytes(rng.integers(0, 256, int(rng.integers(0, 700)), dtype=np.uint8))
+            o.append_message(label, m); t.append_message(label, m)
+        assert TC.ser(o) == t.state, k
+    assert Transcript(state=t.state).state == t.state and t.clone().state == t.state
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_preloaded_transcripts_through_the_device_code(shared):
+    L = load()
+    case = TC.make(4, shared=shared)
+    W = 4
+    tab = np.zeros(L.emul_fb_table_entries(49, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(case["gens"], 49, W, tab.ctypes.data) == 0
+    V, P, S = case["V"].copy(), case["P"].copy(), case["states_in"]
+    n = V.shape[0]
+    acc, st, out = np.zeros(n, np.uint8), np.zeros(n, np.int32), np.zeros((n, 203), np.uint8)
+    L.emul_u64_verify_batch_transcript(tab.ctypes.data, W, n, S.ctypes.data, S.shape[0], V.ctypes.data, P.ctypes.data, acc.ctypes.data,
+                                       st.ctypes.data, out.ctypes.data)
+    assert acc.tolist() == [1] * n and not st.any()
+    assert (out == case["states_after"]).all()                      # the caller's transcript, advanced exactly as merlin's
+    # the transcript content matters: the same proofs against Transcript::new(label) alone must fail
+    plain = np.frombuffer(Transcript(b"u64 range proof").state, dtype=np.uint8).copy()
+    L.emul_u64_verify_batch_transcript(tab.ctypes.data, W, n, plain.ctypes.data, 1, V.ctypes.data, P.ctypes.data, acc.ctypes.data,
+                                       st.ctypes.data, out.ctypes.data)
+    assert not acc.any() and not st.any()
+    # negatives: a wrong proof (state still advances, as the reference's verify runs to the end), a malformed one (state untouched)
+    P2 = P.copy()
+    P2[0, 900] ^= 1
+    P2[1, 5] ^= 0x10
+    L.emul_u64_verify_batch_transcript(tab.ctypes.data, W, n, S.ctypes.data, S.shape[0], V.ctypes.data, P2.ctypes.data, acc.ctypes.data,
+                                       st.ctypes.data, out.ctypes.data)
+    s_in = lambda j: bytes(S[0 if shared else j])
+    ok0, after0 = TC.oracle_verify(case, 0, bytes(V[0]), bytes(P2[0]), s_in(0))
+    assert acc.tolist() == [0, 0, 1, 1] and not ok0 and st.tolist() == [0, 1, 0, 0]
+    assert bytes(out[0]) == after0 and bytes(out[1]) == s_in(1) and (out[2:] == case["states_after"][2:]).all()
