@@ -36,10 +36,20 @@ static thread_local std::string g_last_error;
         }                                                                                              \
     } while (0)
 
-enum KernelId { K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_ACCEPT, K_TABLES, K_RLC_LHS, K_RLC_CHUNK, K_COUNT };
-static const char* const kKernelNames[K_COUNT] = {"k_verify_phase1",        "k_verify_c0_fixed",    "k_verify_c0_var", "k_verify_round",
-                                                  "k_verify_final_scalars", "k_verify_final_check", "k_verify_accept", "k_verify_tables",
-                                                  "k_rlc_lhs",              "k_rlc_chunk"};
+enum KernelId {
+    K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_ACCEPT, K_TABLES, K_RLC_LHS, K_RLC_CHUNK,
+    // u64 batch prover
+    K_PROVE_STAGES, K_PROVE_MSM, K_PROVE_ROUND_SCALARS, K_PROVE_ROUND_FOLD,
+    // generic reciprocal / WNLA verifier
+    K_RECIP_PHASE1, K_RECIP_C0_FIXED, K_RECIP_C0_VAR, K_RECIP_C0_FINISH, K_WNLA_BEGIN, K_WNLA_ROUND, K_WNLA_FINAL_SCALARS, K_WNLA_MSM, K_WNLA_ACCEPT,
+    K_COUNT
+};
+static const char* const kKernelNames[K_COUNT] = {
+    "k_verify_phase1", "k_verify_c0_fixed", "k_verify_c0_var", "k_verify_round", "k_verify_final_scalars", "k_verify_final_check",
+    "k_verify_accept", "k_verify_tables", "k_rlc_lhs", "k_rlc_chunk",
+    "k_prove_stage_*", "k_prove_msm", "k_prove_round_scalars", "k_prove_round_fold",
+    "k_recip_phase1", "k_recip_c0_fixed", "k_recip_c0_var", "k_recip_c0_finish", "k_wnla_begin", "k_wnla_round", "k_wnla_final_scalars",
+    "k_wnla_msm", "k_wnla_accept"};
 
 static size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 
@@ -81,6 +91,8 @@ struct bppp_ctx {
     size_t stage_bytes = 0;
     uint8_t* d_io = nullptr;     // inputs / outputs of bppp_u64_verify_batch (host buffers)
     size_t io_bytes = 0;
+    uint8_t* d_gws = nullptr;    // workspace of bppp_reciprocal_verify_batch_device
+    size_t gws_bytes = 0;
     // expanded (64-byte) form of SEC1-compressed inputs
     uint8_t* d_expand = nullptr;
     size_t expand_bytes = 0;
@@ -352,6 +364,7 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->d_pws) (void)hipFree(c->d_pws);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_io) (void)hipFree(c->d_io);
+    if (c->d_gws) (void)hipFree(c->d_gws);
     if (c->d_expand) (void)hipFree(c->d_expand);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -379,7 +392,7 @@ int bppp_ctx_synchronize(bppp_ctx* c) {
 
 size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
     if (!c) return 0;
-    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + (size_t)c->nbases * sizeof(apt);
+    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + c->gws_bytes + (size_t)c->nbases * sizeof(apt);
 }
 
 int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
@@ -683,20 +696,27 @@ int bppp_u64_prove_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     hipStream_t s = c->stream;
-    auto msm = [&](MsmJob job) { k_prove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job); };
-    k_prove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(w);
-    msm(job_v());
-    k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w);
-    msm(job_rcom()); msm(job_co()); msm(job_cl()); msm(job_cr());
-    k_prove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(w);
-    msm(job_cs());
-    k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w);
-    msm(job_c0());
+#define PLAUNCH(id, ...)                                       \
+    do {                                                       \
+        rc = timed(c, id, s, [&]() { __VA_ARGS__; });          \
+        if (rc != BPPP_OK) return rc;                          \
+    } while (0)
+#define PMSM(job) PLAUNCH(K_PROVE_MSM, k_prove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job))
+    PLAUNCH(K_PROVE_STAGES, k_prove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    PMSM(job_v());
+    PLAUNCH(K_PROVE_STAGES, k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    PMSM(job_rcom()); PMSM(job_co()); PMSM(job_cl()); PMSM(job_cr());
+    PLAUNCH(K_PROVE_STAGES, k_prove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    PMSM(job_cs());
+    PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    PMSM(job_c0());
     for (int k = 1; k <= 4; k++) {
-        k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
-        msm(job_x()); msm(job_r());
-        k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+        PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        PMSM(job_x()); PMSM(job_r());
+        PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
     }
+#undef PMSM
+#undef PLAUNCH
     HIP_TRY(hipGetLastError());
     return BPPP_OK;
 }
@@ -864,36 +884,34 @@ int bppp_wnla_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, 
 
 // ---- generic ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) on a context built by bppp_wnla_ctx_create over
 //      g, g_vec || g_vec_, h_vec || h_vec_
-int bppp_reciprocal_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
-                                 const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
-                                 int32_t* status) {
-    if (!c || (!label && label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
-    if (dim_nd == 0 || dim_np == 0 || dim_nd > (size_t)c->ng || dim_nd + 10 > (size_t)c->nh || dim_np > dim_nd + 1 || rounds > 12 ||
-        nl > 4096 || nn > 4096)
-        return BPPP_ERR_INVALID_ARG;
-    if (n == 0) return BPPP_OK;
-    HIP_TRY(hipSetDevice(c->device));
-    int rc = ensure_straus_capacity(c, n);
-    if (rc != BPPP_OK) return rc;
+// workspace bytes (beyond the caller's commitments / proofs / accept / status) of one reciprocal verify call
+static size_t recip_verify_ws_bytes(const bppp_ctx* c, size_t n, size_t dim_nd, size_t dim_np, size_t rounds) {
+    const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = align16(off + bytes); };
+    take(52 * n * 4); take((dim_nd + 6) * 8 * n * 4); take(5 * 16 * n * 4); take(30 * n * 4); take(30 * n * 4); take(dim_np * 8 * n * 4);
+    take(n * 64); take(n * NH * 32); take(n * 32); take(n * 32); take((rounds ? rounds : 1) * 8 * n * 4); take(2 * T * 8 * n * 4);
+    take(NB * 8 * n * 4);
+    return off;
+}
+// the launch sequence, every buffer in device memory; d_ws holds recip_verify_ws_bytes()
+static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                    const uint8_t* d_com, const uint8_t* d_proofs, size_t rounds, size_t nl, size_t nn, uint8_t* d_acc,
+                                    int32_t* d_st, uint8_t* d_ws) {
     const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh;
     const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
-    const size_t o_com = take(n * 64), o_pr = take(n * proof_bytes), o_acc = take(n), o_st = take(n * 4), o_ts = take(52 * n * 4),
-                 o_sc0 = take((dim_nd + 6) * 8 * n * 4), o_pts = take(5 * 16 * n * 4), o_a = take(30 * n * 4), o_pf = take(30 * n * 4),
-                 o_inv = take(dim_np * 8 * n * 4), o_wc = take(n * 64), o_wcv = take(n * NH * 32), o_rho = take(n * 32), o_mu = take(n * 32),
-                 o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4), o_msc = take(NB * 8 * n * 4);
-    WnlaBlob blob;
-    HIP_TRY(hipMalloc(&blob.d, off));
-    uint8_t* d = blob.d;
+    const size_t o_ts = take(52 * n * 4), o_sc0 = take((dim_nd + 6) * 8 * n * 4), o_pts = take(5 * 16 * n * 4), o_a = take(30 * n * 4),
+                 o_pf = take(30 * n * 4), o_inv = take(dim_np * 8 * n * 4), o_wc = take(n * 64), o_wcv = take(n * NH * 32), o_rho = take(n * 32),
+                 o_mu = take(n * 32), o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4), o_msc = take(NB * 8 * n * 4);
+    uint8_t* d = d_ws;
     hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * 64, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d + o_pr, proofs, n * proof_bytes, hipMemcpyHostToDevice, s));
     RecipWs r;
     std::memset(&r, 0, sizeof r);
     r.N = n; r.nd = (int)dim_nd; r.np = (int)dim_np; r.rounds = (int)rounds; r.nl = (int)nl; r.nn = (int)nn;
     r.NG = c->ng; r.NH = c->nh; r.proof_bytes = proof_bytes;
-    r.commitments = d + o_com; r.proofs = d + o_pr; r.status = (int32_t*)(d + o_st); r.tstate = (u32*)(d + o_ts);
+    r.commitments = d_com; r.proofs = d_proofs; r.status = d_st; r.tstate = (u32*)(d + o_ts);
     r.sc0 = (u32*)(d + o_sc0); r.pts = (u32*)(d + o_pts); r.acc = (u32*)(d + o_a); r.pfix = (u32*)(d + o_pf); r.inv = (u32*)(d + o_inv);
     r.straus = c->d_straus;
     r.wn_commit = d + o_wc; r.wn_c = d + o_wcv; r.wn_rho = d + o_rho; r.wn_mu = d + o_mu;
@@ -907,22 +925,79 @@ int bppp_reciprocal_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label
     w.proof_n = w.proof_l + 32 * nl;
     w.stride_r = w.stride_x = w.stride_l = w.stride_n = proof_bytes;
     w.transcript_preloaded = 1;
-    w.accept = d + o_acc; w.status = r.status; w.tstate = r.tstate; w.acc = r.acc; w.pfix = r.pfix;
+    w.accept = d_acc; w.status = r.status; w.tstate = r.tstate; w.acc = r.acc; w.pfix = r.pfix;
     w.ys = (u32*)(d + o_ys); w.tab = (u32*)(d + o_tab); w.msc = (u32*)(d + o_msc);
     w.straus = c->d_straus;
     w.fb = r.fb;
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
-    k_recip_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r);
-    k_recip_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r);
-    k_recip_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r);
-    k_recip_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r);
-    k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
-    for (int k = 1; k <= (int)rounds; k++) k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
-    k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
-    k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
-    k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    int rc;
+#define GLAUNCH(id, ...)                                       \
+    do {                                                       \
+        rc = timed(c, id, s, [&]() { __VA_ARGS__; });          \
+        if (rc != BPPP_OK) return rc;                          \
+    } while (0)
+    GLAUNCH(K_RECIP_PHASE1, k_recip_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
+    GLAUNCH(K_RECIP_C0_VAR, k_recip_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    GLAUNCH(K_RECIP_C0_FINISH, k_recip_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    GLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    for (int k = 1; k <= (int)rounds; k++) GLAUNCH(K_WNLA_ROUND, k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+    GLAUNCH(K_WNLA_FINAL_SCALARS, k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    GLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
+    GLAUNCH(K_WNLA_ACCEPT, k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+#undef GLAUNCH
     HIP_TRY(hipGetLastError());
+    return BPPP_OK;
+}
+static int recip_verify_check_args(const bppp_ctx* c, size_t dim_nd, size_t dim_np, size_t rounds, size_t nl, size_t nn) {
+    if (dim_nd == 0 || dim_np == 0 || dim_nd > (size_t)c->ng || dim_nd + 10 > (size_t)c->nh || dim_np > dim_nd + 1 || rounds > 12 ||
+        nl > 4096 || nn > 4096)
+        return BPPP_ERR_INVALID_ARG;
+    return BPPP_OK;
+}
+int bppp_reciprocal_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                        const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn,
+                                        void* d_accept, void* d_status) {
+    if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept || !d_status) return BPPP_ERR_INVALID_ARG;
+    int rc = recip_verify_check_args(c, dim_nd, dim_np, rounds, nl, nn);
+    if (rc != BPPP_OK) return rc;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    rc = ensure_straus_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    // persistent, grow-only workspace (the host-pointer entry point allocates per call instead)
+    const size_t need = recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds);
+    if (need > c->gws_bytes) {
+        if (c->d_gws) { (void)hipFree(c->d_gws); c->d_gws = nullptr; c->gws_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->d_gws, need));
+        c->gws_bytes = need;
+    }
+    return recip_verify_device_impl(c, label, label_len, n, dim_nd, dim_np, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, rounds, nl,
+                                    nn, (uint8_t*)d_accept, (int32_t*)d_status, c->d_gws);
+}
+int bppp_reciprocal_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                 const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                 int32_t* status) {
+    if (!c || (!label && label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
+    int rc = recip_verify_check_args(c, dim_nd, dim_np, rounds, nl, nn);
+    if (rc != BPPP_OK) return rc;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    rc = ensure_straus_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
+    const size_t o_com = 0, o_pr = align16(n * 64), o_acc = align16(o_pr + n * proof_bytes), o_st = align16(o_acc + n),
+                 o_ws = align16(o_st + n * 4), total = o_ws + recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, total));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * 64, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_pr, proofs, n * proof_bytes, hipMemcpyHostToDevice, s));
+    rc = recip_verify_device_impl(c, label, label_len, n, dim_nd, dim_np, d + o_com, d + o_pr, rounds, nl, nn, d + o_acc, (int32_t*)(d + o_st),
+                                  d + o_ws);
+    if (rc != BPPP_OK) return rc;
     HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
     if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -27,6 +27,16 @@ def _as_u8(a, shape) -> np.ndarray:
     return arr.reshape(shape)
 
 
+def ctx_timings(ctx, reset: bool = True) -> dict:
+    """Per-kernel HIP-event times accumulated by a context since the last reset (bppp_ctx_enable_timing / _get_timings)."""
+    cap = 48
+    names = (C.c_char_p * cap)()
+    ms = (C.c_double * cap)()
+    cnt = (C.c_int64 * cap)()
+    k = _capi.check(_capi.lib().bppp_ctx_get_timings(ctx, cap, names, ms, cnt, 1 if reset else 0))
+    return {names[i].decode(): {"total_ms": ms[i], "launches": cnt[i]} for i in range(k)}
+
+
 class U64RangeProofProtocol:
     """Public parameters g, g_vec[16], h_vec[32] (u64_proof.rs:19-28) resident on one GPU."""
 
@@ -185,11 +195,7 @@ class U64RangeProofProtocol:
         _capi.check(_capi.lib().bppp_ctx_enable_timing(self._ctx, 1 if on else 0))
 
     def timings(self, reset: bool = True) -> dict:
-        names = (C.c_char_p * 16)()
-        ms = (C.c_double * 16)()
-        cnt = (C.c_int64 * 16)()
-        k = _capi.check(_capi.lib().bppp_ctx_get_timings(self._ctx, 16, names, ms, cnt, 1 if reset else 0))
-        return {names[i].decode(): {"total_ms": ms[i], "launches": cnt[i]} for i in range(k)}
+        return ctx_timings(self._ctx, reset)
 
     def device_bytes(self) -> int:
         return int(_capi.lib().bppp_ctx_device_bytes(self._ctx))

@@ -148,6 +148,26 @@ class ReciprocalRangeProofProtocol:
         return acc, st
 
 
+    def verify_batch_device(self, label: bytes, n: int, d_commitments: int, d_proofs: int, rounds: int, nl: int, nn: int, d_accept: int,
+                            d_status: int) -> None:
+        """Everything resident in HBM (raw device addresses); asynchronous on the context's stream."""
+        _capi.check(_capi.lib().bppp_reciprocal_verify_batch_device(self._w._ctx, label, len(label), n, self.dim_nd, self.dim_np,
+                                                                    d_commitments, d_proofs, rounds, nl, nn, d_accept, d_status))
+
+    def synchronize(self) -> None:
+        _capi.check(_capi.lib().bppp_ctx_synchronize(self._w._ctx))
+
+    def enable_timing(self, on: bool = True) -> None:
+        _capi.check(_capi.lib().bppp_ctx_enable_timing(self._w._ctx, 1 if on else 0))
+
+    def timings(self, reset: bool = True) -> dict:
+        from .range_proof import ctx_timings
+        return ctx_timings(self._w._ctx, reset)
+
+    def device_bytes(self) -> int:
+        return int(_capi.lib().bppp_ctx_device_bytes(self._w._ctx))
+
+
 class ArithmeticCircuit:
     """Mirror of `circuit::ArithmeticCircuit` (circuit.rs:95-139), verify only, for a circuit shared by a batch of instances.
 

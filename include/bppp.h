@@ -289,6 +289,11 @@ BPPP_API int bppp_u64_verify_batch_sharded_device(bppp_group* grp, const uint8_t
                                                   const void* const* d_commitments, const void* const* d_proofs, void* const* d_accept,
                                                   void* const* d_status /* entries may be NULL */, void* const* d_reject_count);
 
+/* the same with DEVICE buffers (d_status required), asynchronous on the context's stream; the workspace lives in the context */
+BPPP_API int bppp_reciprocal_verify_batch_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd,
+                                                 size_t dim_np, const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl,
+                                                 size_t nn, void* d_accept, void* d_status);
+
 /* Profiling aid for bench.py: when enabled, every kernel launch of the verify pipeline is bracketed by HIP events on
  * the context's stream; bppp_ctx_get_timings returns accumulated milliseconds and launch counts per kernel since the
  * last reset.  names[i] points to a static string. */
