@@ -19,6 +19,7 @@ EXPORTS = [
     "bppp_strerror", "bppp_last_error",
     "bppp_u64_verify_batch_transcript", "bppp_u64_verify_batch_transcript_device", "bppp_transcript_new",
     "bppp_transcript_append_message", "bppp_transcript_challenge_bytes",
+    "bppp_derive_generators", "bppp_ctx_save_tables", "bppp_ctx_create_from_tables", "bppp_ctx_create_shared",
     "bppp_shard_range", "bppp_group_create", "bppp_group_destroy", "bppp_group_size", "bppp_group_ctx", "bppp_u64_verify_batch_sharded",
     "bppp_u64_verify_batch_sharded_device",
 ]
@@ -84,6 +85,10 @@ def lib():
     L.bppp_transcript_new.argtypes = [u8p, sz, vp]
     L.bppp_transcript_append_message.argtypes = [vp, u8p, sz, u8p, sz]
     L.bppp_transcript_challenge_bytes.argtypes = [vp, u8p, sz, vp, sz]
+    L.bppp_derive_generators.argtypes = [u8p, sz, sz, sz, vp]
+    L.bppp_ctx_save_tables.argtypes = [vp, u8p]
+    L.bppp_ctx_create_from_tables.argtypes = [C.POINTER(vp), u8p, i32]
+    L.bppp_ctx_create_shared.argtypes = [C.POINTER(vp), vp]
     L.bppp_shard_range.argtypes = [sz, i32, i32, C.POINTER(sz), C.POINTER(sz)]
     L.bppp_shard_range.restype = None
     L.bppp_group_create.argtypes = [C.POINTER(vp), u8p, u8p, u8p, C.POINTER(i32), i32, i32]

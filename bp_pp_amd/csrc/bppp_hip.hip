@@ -97,6 +97,7 @@ struct bppp_ctx {
     uint8_t* d_expand = nullptr;
     size_t expand_bytes = 0;
     int* d_flags = nullptr;
+    bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
     bool serial_c0 = false, rlc_debug = false;   // diagnostics, read from the environment once at context creation
     std::vector<TimedLaunch> pending;
@@ -275,7 +276,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     if (!out || !g || (!g_vec && ng) || (!h_vec && nh) || ng > 4096 || nh > 4096) return BPPP_ERR_INVALID_ARG;
     *out = nullptr;
     const int NB = 1 + (int)ng + (int)nh;
-    int W = fb_window_bits ? fb_window_bits : 22;
+    int W = fb_window_bits ? fb_window_bits : 20;
     if (W != 4 && W != 8 && W != 16 && W != 10 && W != 20 && W != 22) return BPPP_ERR_INVALID_ARG;
     int rc = check_device(device);
     if (rc != BPPP_OK) return rc;
@@ -354,8 +355,8 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& tl : c->pending) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); }
     for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
-    if (c->d_gens) (void)hipFree(c->d_gens);
-    if (c->d_table) (void)hipFree(c->d_table);
+    if (c->d_gens && !c->borrows_tables) (void)hipFree(c->d_gens);
+    if (c->d_table && !c->borrows_tables) (void)hipFree(c->d_table);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_straus) (void)hipFree(c->d_straus);
     if (c->d_rlc) (void)hipFree(c->d_rlc);
@@ -1500,6 +1501,156 @@ BPPP_API int bppp_debug_read_stamps(unsigned long long* out) {
 }
 #endif
 
+
+// ---------------------------------------------------------------- setup: generator derivation, table artefact, shared tables
+// SHAKE256 (FIPS 202) on the host, over the same Keccak-f[1600] the device transcripts use
+static void shake256(const uint8_t* msg, size_t len, uint8_t* out, size_t outlen) {
+    u64 st[25];
+    for (int i = 0; i < 25; i++) st[i] = 0;
+    const size_t R = 136;
+    auto xor_byte = [&](size_t pos, uint8_t b) { st[pos >> 3] ^= (u64)b << (8 * (pos & 7)); };
+    size_t pos = 0;
+    for (size_t i = 0; i < len; i++) {
+        xor_byte(pos++, msg[i]);
+        if (pos == R) { keccak_f1600(st); pos = 0; }
+    }
+    xor_byte(pos, 0x1F);
+    xor_byte(R - 1, 0x80);
+    keccak_f1600(st);
+    pos = 0;
+    for (size_t i = 0; i < outlen; i++) {
+        if (pos == R) { keccak_f1600(st); pos = 0; }
+        out[i] = (uint8_t)(st[pos >> 3] >> (8 * (pos & 7)));
+        pos++;
+    }
+}
+
+// Nothing-up-my-sleeve generators (the step before the path: benches/range_proof.rs:18-20 draws random points; a deployment
+// needs reproducible ones whose discrete logarithms nobody knows).  Try-and-increment: candidate x = SHAKE256(seed || "bppp-gen"
+// || u32le(index) || u32le(counter)) read big-endian; accepted when x < p and x^3 + 7 is a square; y = the EVEN root.  Host only.
+int bppp_derive_generators(const uint8_t* seed, size_t seed_len, size_t first_index, size_t n, uint8_t* out /* n x 64 */) {
+    if ((!seed && seed_len) || !out || seed_len > 4096) return BPPP_ERR_INVALID_ARG;
+    std::vector<uint8_t> msg(seed_len + 8 + 8);
+    if (seed_len) std::memcpy(msg.data(), seed, seed_len);
+    std::memcpy(msg.data() + seed_len, "bppp-gen", 8);
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t idx = (uint32_t)(first_index + i);
+        for (uint32_t ctr = 0;; ctr++) {
+            for (int k = 0; k < 4; k++) { msg[seed_len + 8 + k] = (uint8_t)(idx >> (8 * k)); msg[seed_len + 12 + k] = (uint8_t)(ctr >> (8 * k)); }
+            uint8_t xb[32];
+            shake256(msg.data(), msg.size(), xb, 32);
+            fe x, rhs, y, y2, seven;
+            if (!fe_from_be(x, xb)) continue;
+            fe_sqr(rhs, x);
+            fe_mul(rhs, rhs, x);
+            fe_set_u32(seven, 7);
+            fe_add(rhs, rhs, seven);
+            fe_sqrt_candidate(y, rhs);
+            fe_sqr(y2, y);
+            if (!fe_eq(y2, rhs)) continue;
+            if (fe_is_odd(y)) { fe ny; fe_neg_m<1>(ny, y); y = ny; }
+            fe_to_be(out + 64 * i, x);
+            fe_to_be(out + 64 * i + 32, y);
+            break;
+        }
+    }
+    return BPPP_OK;
+}
+
+// ---- fixed-base tables as an artefact.  File = header | generators (nbases x 64 B, the device's decoded form re-encoded) | table.
+struct TableFileHeader {
+    char magic[8];             // "BPPPTAB1"
+    uint32_t nbases, ng, nh, window_bits, nwin, reserved;
+    uint64_t per_win, table_bytes;
+};
+int bppp_ctx_save_tables(bppp_ctx* c, const char* path) {
+    if (!c || !path) return BPPP_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { g_last_error = std::string("cannot open ") + path; return BPPP_ERR_INVALID_ARG; }
+    TableFileHeader h;
+    std::memset(&h, 0, sizeof h);
+    std::memcpy(h.magic, "BPPPTAB1", 8);
+    h.nbases = (uint32_t)c->nbases; h.ng = (uint32_t)c->ng; h.nh = (uint32_t)c->nh; h.window_bits = (uint32_t)c->fb_w;
+    h.nwin = (uint32_t)fb_nwin(c->fb_w); h.per_win = fb_per_win(c->fb_w); h.table_bytes = c->table_bytes;
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+    std::vector<apt> gens(c->nbases);
+    if (hipMemcpy(gens.data(), c->d_gens, gens.size() * sizeof(apt), hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+    ok = ok && std::fwrite(gens.data(), sizeof(apt), gens.size(), f) == gens.size();
+    const size_t CH = (size_t)256 << 20;
+    std::vector<uint8_t> buf(c->table_bytes < CH ? c->table_bytes : CH);
+    for (size_t off = 0; ok && off < c->table_bytes; off += CH) {
+        const size_t m = c->table_bytes - off < CH ? c->table_bytes - off : CH;
+        if (hipMemcpy(buf.data(), (const uint8_t*)c->d_table + off, m, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+        ok = ok && std::fwrite(buf.data(), 1, m, f) == m;
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) { g_last_error = std::string("writing ") + path + " failed"; return BPPP_ERR_HIP; }
+    return BPPP_OK;
+}
+static int ctx_alloc_common(bppp_ctx* c) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipMalloc(&c->d_flags, sizeof(int)));
+    c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;
+    c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
+    return BPPP_OK;
+}
+int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device) {
+    if (!out || !path) return BPPP_ERR_INVALID_ARG;
+    *out = nullptr;
+    int rc = check_device(device);
+    if (rc != BPPP_OK) return rc;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { g_last_error = std::string("cannot open ") + path; return BPPP_ERR_INVALID_ARG; }
+    TableFileHeader h;
+    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "BPPPTAB1", 8) == 0;
+    const int W = (int)h.window_bits;
+    ok = ok && (W == 4 || W == 8 || W == 10 || W == 16 || W == 20 || W == 22) && h.nbases == 1 + h.ng + h.nh && h.nbases <= 8193 &&
+         h.nwin == (uint32_t)fb_nwin(W) && h.per_win == fb_per_win(W) && h.table_bytes == (uint64_t)h.nbases * h.nwin * h.per_win * sizeof(apt_packed);
+    if (!ok) { std::fclose(f); g_last_error = std::string(path) + " is not a table file of this library"; return BPPP_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    bppp_ctx* c = new (std::nothrow) bppp_ctx();
+    if (!c) { std::fclose(f); return BPPP_ERR_NOMEM; }
+    c->device = device; c->fb_w = W; c->ng = (int)h.ng; c->nh = (int)h.nh; c->nbases = (int)h.nbases; c->table_bytes = h.table_bytes;
+    auto fail = [&](int code) { std::fclose(f); bppp_ctx_destroy(c); return code; };
+    rc = ctx_alloc_common(c);
+    if (rc != BPPP_OK) return fail(rc);
+    std::vector<apt> gens(h.nbases);
+    if (std::fread(gens.data(), sizeof(apt), gens.size(), f) != gens.size()) return fail(BPPP_ERR_INVALID_ARG);
+    if (hipMalloc(&c->d_gens, gens.size() * sizeof(apt)) != hipSuccess || hipMalloc(&c->d_table, c->table_bytes) != hipSuccess) return fail(BPPP_ERR_NOMEM);
+    if (hipMemcpy(c->d_gens, gens.data(), gens.size() * sizeof(apt), hipMemcpyHostToDevice) != hipSuccess) return fail(BPPP_ERR_HIP);
+    const size_t CH = (size_t)256 << 20;
+    std::vector<uint8_t> buf(c->table_bytes < CH ? c->table_bytes : CH);
+    for (size_t off = 0; off < c->table_bytes; off += CH) {
+        const size_t m = c->table_bytes - off < CH ? c->table_bytes - off : CH;
+        if (std::fread(buf.data(), 1, m, f) != m) return fail(BPPP_ERR_INVALID_ARG);
+        if (hipMemcpy((uint8_t*)c->d_table + off, buf.data(), m, hipMemcpyHostToDevice) != hipSuccess) return fail(BPPP_ERR_HIP);
+    }
+    std::fclose(f);
+    *out = c;
+    return BPPP_OK;
+}
+// A second context on the SAME device that shares `parent`'s generators and fixed-base tables (read-only data) and owns its
+// streams and workspaces: several host threads can then verify concurrently on one GPU without a second 21 GB table.  The
+// parent must outlive its children.
+int bppp_ctx_create_shared(bppp_ctx** out, bppp_ctx* parent) {
+    if (!out || !parent) return BPPP_ERR_INVALID_ARG;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(parent->device));
+    bppp_ctx* c = new (std::nothrow) bppp_ctx();
+    if (!c) return BPPP_ERR_NOMEM;
+    c->device = parent->device; c->fb_w = parent->fb_w; c->ng = parent->ng; c->nh = parent->nh; c->nbases = parent->nbases;
+    c->d_gens = parent->d_gens; c->d_table = parent->d_table; c->table_bytes = 0; c->borrows_tables = true;
+    int rc = ctx_alloc_common(c);
+    if (rc != BPPP_OK) { bppp_ctx_destroy(c); return rc; }
+    *out = c;
+    return BPPP_OK;
+}
 
 // ---------------------------------------------------------------- one batch over the GPUs of a node
 // RCCL through dlopen: no link-time dependency, and whichever librccl the process already holds (e.g. torch's) serves.

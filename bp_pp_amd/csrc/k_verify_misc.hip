@@ -9,7 +9,10 @@ using namespace bppp;
 
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_phase1(VerifyWs ws) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < ws.N) verify_phase1(ws, t);
+    if (t >= ws.N) return;
+    // per-proof pre-loaded transcripts may sit at different byte positions (byte 200 of the serialized state)
+    const u32 key = (ws.states && ws.n_states != 1) ? ws.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
+    for_each_position_group(key, [&]() { verify_phase1(ws, t); });
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(VerifyWs ws) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;

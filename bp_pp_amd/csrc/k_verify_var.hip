@@ -14,7 +14,9 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_c0_v
 }
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_round(VerifyWs ws, int k) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < ws.N) verify_round(ws, t, k);
+    if (t >= ws.N) return;
+    const u32 key = (ws.states && ws.n_states != 1) ? ws.tstate[(size_t)50 * ws.N + t] : 0u;   // the stored sponge position
+    for_each_position_group(key, [&]() { verify_round(ws, t, k); });
 }
 // ---- random-linear-combination batch mode (rlc_core.h)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(VerifyWs ws, RlcWs r) {

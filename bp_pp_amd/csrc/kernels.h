@@ -14,16 +14,40 @@
 #define BPPP_BLOCK 64
 // One-lane-per-proof kernels of the u64 verifier: minimum waves per SIMD the register allocator must leave room for
 // (2 => at most 256 VGPR + AGPR per lane, so two wavefronts share a SIMD and cover each other's table-gather latency).
+// Measured on MI355X at 2^20 proofs (profiles/r02_occupancy_ab.txt): 1 wave/SIMD (374 / 272 / 312 VGPRs) 182.8 ms per batch, 2 waves
+// (256, the round kernel spilling 109 VGPRs into transcript-only code) 164.6 ms, 3 waves (168, spills inside the hot loops) 173.4 ms.
 #ifndef BPPP_LANE_MIN_WAVES
-#define BPPP_LANE_MIN_WAVES 1
+#define BPPP_LANE_MIN_WAVES 2
 #endif
-// fixed-base MSM kernels: BPPP_FB_LANES lanes per proof, 256-thread workgroups
+// fixed-base MSM kernels: BPPP_FB_LANES lanes per proof, 256-thread workgroups; 2 waves/SIMD (212 VGPRs, no spills) -- forcing 3
+// (168 VGPRs, 52 spilled) slows k_verify_final_check from 42.8 to 61.6 ms per 2^20 proofs (same measurement)
 #define BPPP_FB_BLOCK 256
 #ifndef BPPP_FB_MIN_WAVES
 #define BPPP_FB_MIN_WAVES 2
 #endif
 
 namespace bppp {
+// The transcript code keeps the sponge's byte position in a scalar register (merlin.h: st_uniform), which is right whenever
+// every lane of a wavefront runs the same transcript schedule from the same position -- always, except when the caller passed
+// PER-PROOF pre-loaded transcripts whose lengths differ (bppp_u64_verify_batch_transcript with n_states = n).  The kernels that
+// touch the transcript therefore run their body once per distinct position present in the wavefront (one trip in every other
+// case): lanes at the first active lane's position execute, the rest wait their turn.
+template <typename F>
+__device__ __forceinline__ void for_each_position_group(u32 key, F&& body) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    bool pending = true;
+    while (pending) {
+        const u32 k = (u32)__builtin_amdgcn_readfirstlane((int)key);
+        if (key == k) {
+            body();
+            pending = false;
+        }
+    }
+#else
+    (void)key;
+    body();
+#endif
+}
 // ---- generic fixed-base linear combination over the context's generators (the crate's commit functions)
 struct MsmWs {
     size_t N;

@@ -27,6 +27,14 @@ def _as_u8(a, shape) -> np.ndarray:
     return arr.reshape(shape)
 
 
+def derive_generators(seed: bytes, n: int = 49, first_index: int = 0) -> bytes:
+    """n x 64 bytes of nothing-up-my-sleeve generators (include/bppp.h: bppp_derive_generators; host code, no GPU needed):
+    g, g_vec[16], h_vec[32] for the u64 protocol when n = 49."""
+    out = C.create_string_buffer(64 * n)
+    _capi.check(_capi.lib().bppp_derive_generators(seed, len(seed), first_index, n, out))
+    return out.raw
+
+
 def ctx_timings(ctx, reset: bool = True) -> dict:
     """Per-kernel HIP-event times accumulated by a context since the last reset (bppp_ctx_enable_timing / _get_timings)."""
     cap = 48
@@ -51,6 +59,28 @@ class U64RangeProofProtocol:
         self._ctx = C.c_void_p()
         _capi.check(_capi.lib().bppp_ctx_create(C.byref(self._ctx), self.g, b"".join(self.g_vec), b"".join(self.h_vec),
                                                 device, fb_window_bits))
+
+    @classmethod
+    def _wrap(cls, ctx, g=b"", g_vec=(), h_vec=(), device=0, parent=None):
+        self = cls.__new__(cls)
+        self.g, self.g_vec, self.h_vec, self.device, self._ctx, self._parent = g, list(g_vec), list(h_vec), device, ctx, parent
+        return self
+
+    @classmethod
+    def from_tables(cls, path: str, device: int = 0) -> "U64RangeProofProtocol":
+        """A context from a table file written by save_tables (bppp_ctx_create_from_tables)."""
+        ctx = C.c_void_p()
+        _capi.check(_capi.lib().bppp_ctx_create_from_tables(C.byref(ctx), path.encode(), device))
+        return cls._wrap(ctx, device=device)
+
+    def save_tables(self, path: str) -> None:
+        _capi.check(_capi.lib().bppp_ctx_save_tables(self._ctx, path.encode()))
+
+    def clone_shared(self) -> "U64RangeProofProtocol":
+        """Another context on the same GPU sharing this one's tables (bppp_ctx_create_shared); close it before this one."""
+        ctx = C.c_void_p()
+        _capi.check(_capi.lib().bppp_ctx_create_shared(C.byref(ctx), self._ctx))
+        return type(self)._wrap(ctx, self.g, self.g_vec, self.h_vec, self.device, parent=self)
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:

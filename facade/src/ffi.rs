@@ -49,6 +49,10 @@ extern "C" {
     pub fn bppp_wnla_proof_shape(nl: usize, nn: usize, rounds: *mut usize, nl_out: *mut usize, nn_out: *mut usize);
     pub fn bppp_wnla_prove_batch(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, commitments: *const u8, c: *const u8, rho: *const u8, mu: *const u8, l: *const u8, nl: usize, n_vec: *const u8, nn: usize, proof_r: *mut u8, proof_x: *mut u8, proof_l: *mut u8, proof_n: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_reciprocal_verify_batch(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, commitments: *const u8, proofs: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32) -> c_int;
+    pub fn bppp_derive_generators(seed: *const u8, seed_len: usize, first_index: usize, n: usize, out: *mut u8) -> c_int;
+    pub fn bppp_ctx_save_tables(ctx: *mut BpppCtx, path: *const c_char) -> c_int;
+    pub fn bppp_ctx_create_from_tables(out: *mut *mut BpppCtx, path: *const c_char, device: c_int) -> c_int;
+    pub fn bppp_ctx_create_shared(out: *mut *mut BpppCtx, parent: *mut BpppCtx) -> c_int;
     pub fn bppp_u64_verify_batch_transcript(ctx: *mut BpppCtx, n: usize, states: *const u8, n_states: usize, commitments: *const u8, proofs: *const u8, accept: *mut u8, status: *mut i32, states_out: *mut u8) -> c_int;
     pub fn bppp_u64_verify_batch_transcript_device(ctx: *mut BpppCtx, n: usize, d_states: *const c_void, n_states: usize, d_commitments: *const c_void, d_proofs: *const c_void, d_accept: *mut c_void, d_status: *mut c_void, d_reject_count: *mut c_void, d_states_out: *mut c_void) -> c_int;
     pub fn bppp_transcript_new(label: *const u8, label_len: usize, state_out: *mut u8) -> c_int;

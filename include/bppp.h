@@ -62,10 +62,11 @@ typedef struct bppp_ctx bppp_ctx;
  * says so (*_device variants); the host-buffer variants return after the results have been copied back. */
 
 /* U64RangeProofProtocol { g, g_vec[16], h_vec[32] } (u64_proof.rs:19-28) bound to GPU `device`.
- * Builds the fixed-base tables for the 49 generators on the GPU.  fb_window_bits: 0 = default 22 (signed 22-bit digits:
- * 49 x 12 x 2^21 affine points = 79 GB of HBM, 12 table additions per scalar; built in passes with <= 32 GB of temporaries);
- * 20 (signed, 21 GB, 13 additions per scalar: ~3 % slower); 16 (unsigned, 3.3 GB, 16 additions); 4, 8, 10 (small tables
- * for tests). */
+ * Builds the fixed-base tables for the 49 generators on the GPU.  fb_window_bits: 0 = default 20 (signed 20-bit digits: 49 x 13 x
+ * 2^19 affine points = 21 GB of HBM, 13 table additions per scalar); 22 (signed, 49 x 12 x 2^21 points = 79 GB, 12 additions per
+ * scalar: 2.7 % faster end to end on a 2^20-proof batch, built in passes with <= 32 GB of temporaries); 16 (unsigned, 3.3 GB, 16
+ * additions); 4, 8, 10 (small tables for tests).  bppp_ctx_save_tables / bppp_ctx_create_from_tables keep a built table set as a
+ * file. */
 BPPP_API int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec /* 16 x 64 */,
                     const uint8_t* h_vec /* 32 x 64 */, int device, int fb_window_bits);
 BPPP_API void bppp_ctx_destroy(bppp_ctx* ctx);
@@ -232,6 +233,22 @@ BPPP_API int bppp_wnla_prove_batch(bppp_ctx* ctx, const uint8_t* label, size_t l
 BPPP_API int bppp_reciprocal_verify_batch(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                           const uint8_t* commitments /* n x 64 */, const uint8_t* proofs, size_t rounds, size_t nl,
                                           size_t nn, uint8_t* accept /* n */, int32_t* status /* n or NULL */);
+
+/* ---- setup: the step before the path (benches/range_proof.rs:18-20, u64_proof.rs:37) ----
+ * bppp_derive_generators: n reproducible generators with unknown discrete logarithms, indices first_index .. first_index + n - 1 of
+ * the stream defined by `seed` (try-and-increment: x = SHAKE256(seed || "bppp-gen" || u32le(index) || u32le(counter)) as a
+ * big-endian integer, first counter with x < p and x^3 + 7 a square; y = the even root).  64 bytes each, host only (no GPU needed).
+ * The reference draws random points instead (`ProjectivePoint::random`); any 49 valid points work with every entry point here. */
+BPPP_API int bppp_derive_generators(const uint8_t* seed, size_t seed_len, size_t first_index, size_t n, uint8_t* out /* n x 64 */);
+/* The fixed-base tables of a context as a file, and a context created from such a file instead of from the generators (any of the
+ * bppp_ctx_create / bppp_wnla_ctx_create shapes).  NOTE: the tables are BUILT on the GPU in 0.5 s (79 GB, 22-bit) to 3 s -- faster than any
+ * disk or PCIe can deliver them -- so the file is for reproducibility and inspection, not for start-up time; what saves memory and
+ * time is bppp_ctx_create_shared. */
+BPPP_API int bppp_ctx_save_tables(bppp_ctx* ctx, const char* path);
+BPPP_API int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device);
+/* A further context on the same GPU that shares `parent`'s generators and tables (read-only) and owns its streams and workspaces:
+ * concurrent callers on one GPU, one copy of the tables.  `parent` must be destroyed after every context created from it. */
+BPPP_API int bppp_ctx_create_shared(bppp_ctx** out, bppp_ctx* parent);
 
 /* ---- the reference's `t: &mut Transcript` (u64_proof.rs:42, wnla.rs:75, circuit.rs:154; SURVEY 8b "Ownership") ----
  * Every entry point above takes a label and starts each proof from `Transcript::new(label)`, which is what all of the reference's

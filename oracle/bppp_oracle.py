@@ -1207,3 +1207,23 @@ def synth_blinding(j: int, seed: bytes = SEED) -> int:
 def synth_rng_scalars(j: int, seed: bytes = SEED) -> List[int]:
     raw = xof(b"rng", j, 64 * N_RNG_DRAWS_U64, seed)
     return [wide_reduce(raw[64 * i:64 * i + 64]) for i in range(N_RNG_DRAWS_U64)]
+
+
+# --------------------------------------------------------------------------
+# Setup step: reproducible generators with unknown discrete logarithms -- restatement of
+# bppp_derive_generators (include/bppp.h) for the parity test; the reference itself draws random points
+# (benches/range_proof.rs:18-20), so this has no reference counterpart to follow.
+# --------------------------------------------------------------------------
+def derive_generator(seed: bytes, index: int) -> Point:
+    ctr = 0
+    while True:
+        xb = hashlib.shake_256(seed + b"bppp-gen" + struct.pack("<II", index, ctr)).digest(32)
+        x = int.from_bytes(xb, "big")
+        ctr += 1
+        if x >= P:
+            continue
+        rhs = (x * x * x + 7) % P
+        y = pow(rhs, (P + 1) // 4, P)
+        if y * y % P != rhs:
+            continue
+        return (x, y if y % 2 == 0 else P - y)

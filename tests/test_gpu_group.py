@@ -73,3 +73,47 @@ def test_group_rejects_bad_arguments():
         U64RangeProofGroup(g, gv, hv, [0, 0], fb_window_bits=8)           # the same device twice
     with pytest.raises(BpppError):
         U64RangeProofGroup(g, gv, hv, [99], fb_window_bits=8)             # no such device
+
+
+def test_table_file_round_trip_and_shared_tables(batch, tmp_path):
+    """the fixed-base tables as an artefact (save -> context from the file) and one table set shared by several
+    contexts on the same GPU (two host threads verifying concurrently)."""
+    import threading
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    gens, V, P, expect = batch
+    g, gv, hv = workload.split_generators(gens)
+    a = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=10)
+    path = str(tmp_path / "tables.bin")
+    b = c = None
+    try:
+        ref_acc, ref_st = a.verify_batch(V, P, workload.LABEL)
+        assert (ref_acc == expect).all()
+        a.save_tables(path)
+        b = U64RangeProofProtocol.from_tables(path, device=0)
+        acc, st = b.verify_batch(V, P, workload.LABEL)
+        assert (acc == ref_acc).all() and (st == ref_st).all()
+        x = np.array([0, 5, 2**64 - 1], dtype=np.uint64)
+        s = np.frombuffer(bytes(range(96)), dtype=np.uint8).reshape(3, 32) & 0x7F
+        assert (a.commit_value_batch(x, s) == b.commit_value_batch(x, s)).all()
+        with open(path, "r+b") as f:                       # a damaged header is refused
+            f.write(b"NOTATABLE")
+        with pytest.raises(Exception):
+            U64RangeProofProtocol.from_tables(path, device=0)
+        c = a.clone_shared()
+        before = a.device_bytes()
+        out = {}
+
+        def run(name, proto):
+            for _ in range(3):
+                out[name] = proto.verify_batch(V, P, workload.LABEL)
+
+        ts = [threading.Thread(target=run, args=("a", a)), threading.Thread(target=run, args=("c", c))]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert (out["a"][0] == ref_acc).all() and (out["c"][0] == ref_acc).all() and (out["c"][1] == ref_st).all()
+        assert c.device_bytes() < before                    # the clone holds workspaces only, not a second table set
+    finally:
+        for p in (c, b, a):
+            if p is not None:
+                p.close()

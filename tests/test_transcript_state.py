@@ -64,3 +64,15 @@ def test_preloaded_transcripts_through_the_device_code(shared):
     ok0, after0 = TC.oracle_verify(case, 0, bytes(V[0]), bytes(P2[0]), s_in(0))
     assert acc.tolist() == [0, 0, 1, 1] and not ok0 and st.tolist() == [0, 1, 0, 0]
     assert bytes(out[0]) == after0 and bytes(out[1]) == s_in(1) and (out[2:] == case["states_after"][2:]).all()
+
+
+def test_derived_generators_equal_the_oracle_and_are_valid_points():
+    """bppp_derive_generators (host code of the library: SHAKE256 try-and-increment, even y) against the oracle's restatement."""
+    from bp_pp_amd import derive_generators
+    for seed in (b"", b"bppp-bench-v1", b"x" * 200):
+        gens = derive_generators(seed, 49)
+        assert len(gens) == 49 * 64 and len({gens[64 * i:64 * i + 64] for i in range(49)}) == 49
+        for i in (0, 1, 16, 17, 48):
+            pt = O.derive_generator(seed, i)
+            assert gens[64 * i:64 * i + 64] == O.pt_to_xy64(pt) and O.on_curve(pt) and pt[1] % 2 == 0
+    assert derive_generators(b"s", 3, first_index=5) == derive_generators(b"s", 8)[5 * 64:]
