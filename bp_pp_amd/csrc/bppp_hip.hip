@@ -37,7 +37,7 @@ static thread_local std::string g_last_error;
     } while (0)
 
 enum KernelId {
-    K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_ACCEPT, K_TABLES, K_RLC_LHS, K_RLC_CHUNK,
+    K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_ACCEPT, K_TABLES, K_RLC_LHS, K_RLC_CHUNK, K_BKT_PREPARE, K_BKT_ACCUMULATE, K_BKT_SCALARS, K_BKT_CHECK,
     // u64 batch prover
     K_PROVE_STAGES, K_PROVE_MSM, K_PROVE_ROUND_SCALARS, K_PROVE_ROUND_FOLD,
     // generic reciprocal / WNLA verifier
@@ -46,7 +46,7 @@ enum KernelId {
 };
 static const char* const kKernelNames[K_COUNT] = {
     "k_verify_phase1", "k_verify_c0_fixed", "k_verify_c0_var", "k_verify_round", "k_verify_final_scalars", "k_verify_final_check",
-    "k_verify_accept", "k_verify_tables", "k_rlc_lhs", "k_rlc_chunk",
+    "k_verify_accept", "k_verify_tables", "k_rlc_lhs", "k_rlc_chunk", "k_bkt_prepare", "k_bkt_accumulate", "k_bkt_scalars", "k_bkt_check",
     "k_prove_stage_*", "k_prove_msm", "k_prove_round_scalars", "k_prove_round_fold",
     "k_recip_phase1", "k_recip_c0_fixed", "k_recip_c0_var", "k_recip_c0_finish", "k_wnla_begin", "k_wnla_round", "k_wnla_final_scalars",
     "k_wnla_msm", "k_wnla_accept"};
@@ -82,6 +82,11 @@ struct bppp_ctx {
     size_t rcap = 0;
     u32* d_rlc = nullptr;
     size_t rlc_bytes = 0;
+    // bucket stage of the RLC mode (bucket_core.h): superchunk size (0 = stage off) and its workspace
+    unsigned rlc_super_m = 4096;
+    size_t bcap = 0;
+    uint8_t* d_bkt = nullptr;
+    size_t bkt_bytes = 0;
     // prover workspace
     size_t pcap = 0;
     u32* d_pws = nullptr;
@@ -153,6 +158,19 @@ static int ensure_rlc_capacity(bppp_ctx* c, size_t n) {
     c->rlc_bytes = cap * (30 + (size_t)BPPP_NG * 8) * sizeof(u32) + cap + (cap / BPPP_RLC_CHUNK + 4) * sizeof(u32);   // lhs, sc | flags (cap bytes) | list, count
     HIP_TRY(hipMalloc(&c->d_rlc, c->rlc_bytes));
     c->rcap = cap;
+    return BPPP_OK;
+}
+// workspace of the bucket stage: half-weights, packed commitments | per superchunk: lhs, combined scalars, flag
+static size_t bkt_bytes_for(size_t cap, size_t nsuper) {
+    return align16(cap * 16) + align16(cap * sizeof(c4_packed)) + align16(nsuper * 30 * 4) + align16(nsuper * (size_t)BPPP_NG * 32) + align16(nsuper + 16);
+}
+static int ensure_bucket_capacity(bppp_ctx* c, size_t n) {
+    const size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    const size_t need = bkt_bytes_for(cap, cap / 64 + 1);      // enough for any superchunk size >= 64
+    if (need <= c->bkt_bytes) return BPPP_OK;
+    if (c->d_bkt) { (void)hipFree(c->d_bkt); c->d_bkt = nullptr; c->bkt_bytes = 0; }
+    HIP_TRY(hipMalloc(&c->d_bkt, need));
+    c->bkt_bytes = need;
     return BPPP_OK;
 }
 static const size_t PWS_WORDS_PER_PROOF = 52 + (size_t)SV_COUNT * 8 + (size_t)BPPP_MSC_SETS * BPPP_NG * 8 + (size_t)PB_COUNT * 30;
@@ -360,6 +378,7 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_straus) (void)hipFree(c->d_straus);
     if (c->d_rlc) (void)hipFree(c->d_rlc);
+    if (c->d_bkt) (void)hipFree(c->d_bkt);
     if (c->d_atab) (void)hipFree(c->d_atab);
     if (c->d_tscr) (void)hipFree(c->d_tscr);
     if (c->d_pws) (void)hipFree(c->d_pws);
@@ -383,6 +402,15 @@ int bppp_ctx_set_stream(bppp_ctx* c, void* hip_stream) {
     return BPPP_OK;
 }
 
+int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
+    if (!c || !name) return BPPP_ERR_INVALID_ARG;
+    if (std::strcmp(name, "rlc_superchunk") == 0) {
+        if (value != 0 && (value < 64 || value > BPPP_BKT_MAX_M || (value & 7))) return BPPP_ERR_INVALID_ARG;
+        c->rlc_super_m = (unsigned)value;
+        return BPPP_OK;
+    }
+    return BPPP_ERR_INVALID_ARG;
+}
 int bppp_ctx_synchronize(bppp_ctx* c) {
     if (!c) return BPPP_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
@@ -393,7 +421,7 @@ int bppp_ctx_synchronize(bppp_ctx* c) {
 
 size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
     if (!c) return 0;
-    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + c->gws_bytes + (size_t)c->nbases * sizeof(apt);
+    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->bkt_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + c->gws_bytes + (size_t)c->nbases * sizeof(apt);
 }
 
 int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
@@ -506,6 +534,34 @@ static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_le
         const unsigned chunk_blocks = (unsigned)((nchunks * BPPP_RLC_CHUNK + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
         HIP_TRY(hipMemsetAsync(d_accept, 0, n, s));
         HIP_TRY(hipMemsetAsync(rl.count, 0, sizeof(int), s));
+        if (c->rlc_super_m) {
+            // bucket stage first: superchunks of rlc_super_m proofs, one combined check each; the chunk-of-8 kernels below only see
+            // the proofs of superchunks that failed it
+            const size_t SM = c->rlc_super_m, nsuper = (n + SM - 1) / SM;
+            rc = ensure_bucket_capacity(c, n);
+            if (rc != BPPP_OK) return rc;
+            BucketWs bw;
+            std::memset(&bw, 0, sizeof bw);
+            bw.N = n; bw.M = (u32)SM;
+            for (int i = 0; i < 4; i++) bw.seed[i] = rl.seed[i];
+            bw.status = ws.status; bw.acc = ws.acc; bw.fsc = ws.fsc; bw.accept = ws.accept;
+            uint8_t* p = c->d_bkt;
+            const size_t capn = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+            bw.wab = (u64*)p; p += align16(capn * 16);
+            bw.c4 = (c4_packed*)p; p += align16(capn * sizeof(c4_packed));
+            bw.lhs = (u32*)p; p += align16(nsuper * 30 * 4);
+            bw.asc = (u32*)p; p += align16(nsuper * (size_t)BPPP_NG * 32);
+            bw.sflag = p;
+            bw.fb.table = c->d_table; bw.fb.W = c->fb_w; bw.fb.N = nsuper;
+            const size_t lds_bytes = ((size_t)4 * (512 + SM) + 8 * 30) * sizeof(u32);
+            (void)hipFuncSetAttribute((const void*)k_bkt_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            LAUNCH(K_BKT_PREPARE, k_bkt_prepare<<<blocks, BPPP_BLOCK, 0, s>>>(bw));
+            LAUNCH(K_BKT_ACCUMULATE, k_bkt_accumulate<<<(unsigned)nsuper, 256, lds_bytes, s>>>(bw));
+            LAUNCH(K_BKT_SCALARS, k_bkt_scalars<<<(unsigned)nsuper, 256, 0, s>>>(bw));
+            LAUNCH(K_BKT_CHECK, k_bkt_check<<<(unsigned)nsuper, 64, 0, s>>>(bw));
+            rl.sflag = bw.sflag;
+            rl.super_m = (u32)SM;
+        }
         LAUNCH(K_RLC_LHS, k_rlc_lhs<<<blocks, BPPP_BLOCK, 0, s>>>(ws, rl));
         LAUNCH(K_RLC_CHUNK, k_rlc_chunk<<<chunk_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
         LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged<<<1024, 64, 0, s>>>(ws, rl));

@@ -34,6 +34,10 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(
     const size_t N = ws.N, nchunks = (N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
     if (chunk >= nchunks) return;            // whole lane groups leave together
     const size_t t = chunk * BPPP_RLC_CHUNK + lane;
+    if (rlc_done_by_bucket_stage(r, chunk * BPPP_RLC_CHUNK)) {     // whole lane groups leave together (super_m is a multiple of 8)
+        if (lane == 0) r.flag[chunk] = 0;
+        return;
+    }
     // a chunk with a missing or flagged proof goes to the exact kernels
     int bad = (t < N) ? (ws.status[t] != ST_OK) : 1;
 #pragma unroll

@@ -21,5 +21,5 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_roun
 // ---- random-linear-combination batch mode (rlc_core.h)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(VerifyWs ws, RlcWs r) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < ws.N) rlc_lhs(ws, r, t);
+    if (t < ws.N && !rlc_done_by_bucket_stage(r, t)) rlc_lhs(ws, r, t);
 }

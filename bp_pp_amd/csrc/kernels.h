@@ -8,6 +8,7 @@
 #include "prove_core.h"
 #include "recip_core.h"
 #include "recip_prove_core.h"
+#include "bucket_core.h"
 #include "rlc_core.h"
 #include "wnla_prove_core.h"
 
@@ -35,10 +36,15 @@ namespace bppp {
 template <typename F>
 __device__ __forceinline__ void for_each_position_group(u32 key, F&& body) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // the leader is taken from a ballot of the lanes still pending, so the choice depends on the loop state: a bare
+    // readfirstlane(key) is loop-invariant to the optimiser, which then (forward-progress rule) drops the loop altogether
     bool pending = true;
-    while (pending) {
-        const u32 k = (u32)__builtin_amdgcn_readfirstlane((int)key);
-        if (key == k) {
+    while (true) {
+        const unsigned long long todo = __ballot(pending);
+        if (!todo) break;
+        const int leader = __ffsll((long long)todo) - 1;
+        const u32 k = (u32)__builtin_amdgcn_readlane((int)key, leader);
+        if (pending && key == k) {
             body();
             pending = false;
         }
@@ -120,3 +126,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1(bppp::RecipWs w);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed(bppp::RecipWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var(bppp::RecipWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_finish(bppp::RecipWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_bkt_prepare(bppp::BucketWs w);
+__global__ __launch_bounds__(256) void k_bkt_accumulate(bppp::BucketWs w);
+__global__ __launch_bounds__(256) void k_bkt_scalars(bppp::BucketWs w);
+__global__ __launch_bounds__(64) void k_bkt_check(bppp::BucketWs w);

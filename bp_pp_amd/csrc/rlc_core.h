@@ -26,7 +26,12 @@ struct RlcWs {
     uint8_t* flag;     // [ceil(N / 8)]  1 = chunk must be re-checked exactly
     u32* list;         // [ceil(N / 8)]  the flagged chunks, compacted (device: appended with an atomic counter)
     int* count;        // number of entries in `list`
+    // bucket stage in front (bucket_core.h): superchunks of `super_m` proofs whose combined check PASSED (sflag = 0) are done --
+    // their proofs are skipped here; null = no bucket stage, every chunk of 8 is checked
+    const uint8_t* sflag;
+    u32 super_m;
 };
+HD bool rlc_done_by_bucket_stage(const RlcWs& r, size_t t) { return r.sflag && !r.sflag[t / r.super_m]; }
 
 // weight halves (a, b): one permutation of  seed[0..3] | index | domain tag | 0...
 HD void rlc_weight(u64& a, u64& b, const RlcWs& r, size_t t) {

@@ -217,6 +217,10 @@ class U64RangeProofProtocol:
             raise ValueError("the null stream (handle 0) cannot be selected; pass a non-default stream, or None for the context's own")
         _capi.check(_capi.lib().bppp_ctx_set_stream(self._ctx, hip_stream))
 
+    def set_option(self, name: str, value: int) -> None:
+        """include/bppp.h: bppp_ctx_set_option (e.g. "rlc_superchunk": 0 = bucket stage off, else 64..8192)."""
+        _capi.check(_capi.lib().bppp_ctx_set_option(self._ctx, name.encode(), int(value)))
+
     def synchronize(self) -> None:
         """Block until everything queued on the context's current stream (and its helper stream) has finished."""
         _capi.check(_capi.lib().bppp_ctx_synchronize(self._ctx))

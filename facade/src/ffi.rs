@@ -2,7 +2,7 @@
 //! tools/gen_facade_ffi.py and checked against it by tests/test_facade_tree.py.  UNCOMPILED (no Rust toolchain in the build
 //! image); the identical prototypes are exercised through ctypes in bp_pp_amd/_capi.py.
 #![allow(dead_code)]
-use std::os::raw::{c_char, c_int, c_void};
+use std::os::raw::{c_char, c_int, c_long, c_void};
 
 #[repr(C)] pub struct BpppCtx { _private: [u8; 0] }
 #[repr(C)] pub struct BpppCircuit { _private: [u8; 0] }
@@ -27,6 +27,7 @@ extern "C" {
     pub fn bppp_ctx_create(out: *mut *mut BpppCtx, g: *const u8, g_vec: *const u8, h_vec: *const u8, device: c_int, fb_window_bits: c_int) -> c_int;
     pub fn bppp_ctx_destroy(ctx: *mut BpppCtx);
     pub fn bppp_ctx_set_stream(ctx: *mut BpppCtx, hip_stream: *mut c_void) -> c_int;
+    pub fn bppp_ctx_set_option(ctx: *mut BpppCtx, name: *const c_char, value: c_long) -> c_int;
     pub fn bppp_ctx_synchronize(ctx: *mut BpppCtx) -> c_int;
     pub fn bppp_u64_verify_batch(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, commitments: *const u8, proofs: *const u8, accept: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_u64_verify_batch_device(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, d_commitments: *const c_void, d_proofs: *const c_void, d_accept: *mut c_void, d_status: *mut c_void, d_trace: *mut c_void, d_reject_count: *mut c_void) -> c_int;

@@ -76,6 +76,9 @@ BPPP_API void bppp_ctx_destroy(bppp_ctx* ctx);
  * stream itself cannot be selected here (its handle is the NULL pointer).  A caller that needs its own work ordered with the
  * *_device entry points -- e.g. the RCCL all-reduce of reject_count -- passes the stream that work runs on. */
 BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
+/* Tunables.  "rlc_superchunk": proofs per superchunk of the bucket (Pippenger) stage of the RLC mode below -- 0 switches the stage
+ * off (chunks of 8 only), otherwise a multiple of 8 in [64, 8192]; default 4096. */
+BPPP_API int bppp_ctx_set_option(bppp_ctx* ctx, const char* name, long value);
 /* Block the calling host thread until everything queued by this context (current stream + its helper stream) has finished. */
 BPPP_API int bppp_ctx_synchronize(bppp_ctx* ctx);
 
@@ -96,13 +99,16 @@ BPPP_API int bppp_u64_verify_batch_device(bppp_ctx* ctx, const uint8_t* label, s
                                  const void* d_commitments, const void* d_proofs, void* d_accept, void* d_status,
                                  void* d_trace, void* d_reject_count);
 
-/* Optional batch mode: the same pipeline, but the per-proof final check (the 49-base MSM of wnla.rs:80-82, ~26 % of the work)
- * is replaced by ONE such MSM per chunk of 8 proofs over a random linear combination with secret 128-bit weights derived
- * from `seed` (Keccak PRF of seed || proof index).  The seed must be unpredictable to whoever produced the proofs and chosen
- * after they are fixed (e.g. 32 bytes of OS randomness per call).  Chunks whose combined check fails, or that contain a
- * malformed proof, are re-checked exactly, so accept[] is still per proof; it equals exact mode's except that a chunk holding
- * an invalid proof passes with probability <= 2^-128.  Everything up to and including the four WNLA rounds -- every
- * transcript challenge and hashed commitment -- is computed exactly as in exact mode. */
+/* Optional batch mode: the same pipeline, but the per-proof final check (the 49-base MSM of wnla.rs:80-82, ~26 % of the work) is
+ * replaced by checks of random linear combinations with secret 128-bit weights derived from `seed` (Keccak PRF of seed || proof
+ * index), in two stages: (1) superchunks of 4096 proofs (bppp_ctx_set_option "rlc_superchunk"): sum_j w_j C4_j by bucket
+ * accumulation -- `util::vector_mul` over ProjectivePoint (util.rs:46-60) as a Pippenger MSM with LDS-staged buckets -- against ONE
+ * 49-base MSM of the combined scalars; (2) the proofs of a superchunk that fails are re-checked in chunks of 8 (one short scalar
+ * multiplication per proof, one 49-base MSM per chunk), and the chunks that fail THAT are checked exactly, proof by proof.  So
+ * accept[] is still per proof; it equals exact mode's except that a chunk holding an invalid proof passes with probability <=
+ * 2^-128.  The seed must be unpredictable to whoever produced the proofs and chosen after they are fixed (e.g. 32 bytes of OS
+ * randomness per call).  Everything up to and including the four WNLA rounds -- every transcript challenge and hashed commitment
+ * -- is computed exactly as in exact mode. */
 BPPP_API int bppp_u64_verify_batch_rlc_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n,
                                               const void* d_commitments, const void* d_proofs, void* d_accept, void* d_status,
                                               void* d_reject_count, const uint8_t seed[32]);

@@ -9,6 +9,7 @@
 #include "../../bp_pp_amd/csrc/prove_core.h"
 #include "../../bp_pp_amd/csrc/circuit_core.h"
 #include "../../bp_pp_amd/csrc/recip_core.h"
+#include "../../bp_pp_amd/csrc/bucket_core.h"
 #include "../../bp_pp_amd/csrc/rlc_core.h"
 #include "../../bp_pp_amd/csrc/wnla_prove_core.h"
 #include "../../bp_pp_amd/csrc/circuit_prove_core.h"
@@ -361,6 +362,51 @@ int emul_u64_verify_batch_rlc(const uint8_t* table, int W, const uint8_t* label,
         re += ok ? 0 : 1;
     }
     *rechecked_chunks = re;
+    return 0;
+}
+// bucket stage of the RLC mode (bucket_core.h), single-thread form: exact pipeline through the final scalars, then per superchunk
+// of M proofs the combined check; returns per-superchunk verdicts (1 = passed).  The proofs of failing superchunks would go on to
+// the chunk-of-8 stage (emul_u64_verify_batch_rlc covers that one).
+int emul_u64_bucket_stage(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
+                          const uint8_t* proofs, const uint8_t seed[32], uint32_t M, uint8_t* passed /* ceil(n / M) */, int32_t* status) {
+    VerifyWs ws;
+    memset(&ws, 0, sizeof ws);
+    ws.N = n;
+    std::vector<uint8_t> accept(n);
+    ws.commitments = V; ws.proofs = proofs; ws.accept = accept.data(); ws.status = status; ws.trace = nullptr;
+    std::vector<u32> strobe_(52 * n), chal(80 * n), sc0(176 * n), cvec(200 * n), pts(208 * n), lns(24 * n), acc(30 * n), pfix(30 * n), fsc(392 * n);
+    std::vector<apt_packed> atab(n * BPPP_ATAB_PER_PROOF);
+    std::vector<u32> tscr((size_t)BPPP_TSCR_FE * 10 * n);
+    ws.tstate = strobe_.data(); ws.chal = chal.data(); ws.sc0 = sc0.data(); ws.cvec = cvec.data(); ws.pts = pts.data();
+    ws.lns = lns.data(); ws.acc = acc.data(); ws.pfix = pfix.data(); ws.fsc = fsc.data();
+    ws.atab = atab.data(); ws.tscr = tscr.data();
+    ws.fb_table = (const apt_packed*)table;
+    ws.fb_w = W;
+    t_new(ws.base, label, (u32)label_len);
+    for (size_t t = 0; t < n; t++) verify_phase1(ws, t);
+    for (size_t t = 0; t < n; t++) verify_tables(ws, t);
+    for (size_t t = 0; t < n; t++) verify_c0_var(ws, t);
+    for (size_t t = 0; t < n; t++) verify_c0_fixed(ws, t);
+    for (int k = 1; k <= 4; k++)
+        for (size_t t = 0; t < n; t++) verify_round(ws, t, k);
+    for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);
+    const size_t nsuper = (n + M - 1) / M;
+    BucketWs bw;
+    memset(&bw, 0, sizeof bw);
+    bw.N = n; bw.M = M;
+    for (int i = 0; i < 4; i++) {
+        u64 v = 0;
+        for (int k = 0; k < 8; k++) v |= (u64)seed[8 * i + k] << (8 * k);
+        bw.seed[i] = v;
+    }
+    std::vector<u64> wab(2 * n);
+    std::vector<c4_packed> c4(n);
+    std::vector<u32> lhs(30 * nsuper), asc((size_t)BPPP_NG * 8 * nsuper);
+    bw.status = status; bw.acc = acc.data(); bw.fsc = fsc.data(); bw.wab = wab.data(); bw.c4 = c4.data(); bw.lhs = lhs.data();
+    bw.asc = asc.data(); bw.accept = accept.data();
+    bw.fb.table = (const apt_packed*)table; bw.fb.W = W; bw.fb.N = nsuper;
+    for (size_t t = 0; t < n; t++) bkt_prepare(bw, t);
+    for (size_t c = 0; c < nsuper; c++) passed[c] = bkt_superchunk_serial(bw, c) ? 1 : 0;
     return 0;
 }
 // full prover pipeline, every stage in thread order

@@ -31,6 +31,7 @@ def load():
     L.emul_merlin_kat.argtypes = [cp, sz, cp, sz, vp, sz]
     L.emul_u64_verify_batch.argtypes = [vp, i32, cp, sz, sz, vp, vp, vp, vp, vp]
     L.emul_u64_verify_batch_transcript.argtypes = [vp, i32, sz, vp, sz, vp, vp, vp, vp, vp]
+    L.emul_u64_bucket_stage.argtypes = [vp, i32, cp, sz, sz, vp, vp, cp, C.c_uint32, vp, vp]
     L.emul_u64_verify_batch_rlc.argtypes = [vp, i32, cp, sz, sz, vp, vp, cp, vp, vp, vp, vp, vp]
     L.emul_u64_prove_batch.argtypes = [vp, i32, cp, sz, sz, vp, vp, vp, vp, vp, vp]
     L.emul_sec1_expand.argtypes = [sz, vp, vp, vp, vp]

@@ -87,3 +87,37 @@ def test_rlc_small_batches(env):
     for m in (1, 7, 8, 9, 16):
         acc, st, rej = _run(torch, proto, V[:m], P[:m], os.urandom(32))
         assert acc.tolist() == [1] * m and rej == 0
+
+
+@pytest.mark.parametrize("super_m", [0, 64, 256, 4096])
+def test_bucket_stage_agrees_with_exact_mode(env, super_m):
+    """The bucket (Pippenger) stage in front of the chunk-of-8 stage (bucket_core.h), for several superchunk sizes (0 = stage off):
+    accept bits, statuses and reject count equal exact mode's; with every proof valid nothing falls through; with bad proofs only
+    their superchunks fall through (k_rlc_* timings show which stage did the work)."""
+    torch, proto, gens, V, P, n = env
+    proto.set_option("rlc_superchunk", super_m)
+    try:
+        proto.enable_timing(True)
+        proto.timings(reset=True)
+        acc, st, rej = _run(torch, proto, V, P, os.urandom(32))
+        t = proto.timings(reset=True)
+        assert acc.tolist() == [1] * n and not st.any() and rej == 0
+        if super_m:
+            assert t["k_bkt_accumulate"]["launches"] == 1 and t["k_bkt_check"]["launches"] == 1
+        else:
+            assert t["k_bkt_accumulate"]["launches"] == 0
+        Pc, Vc = P.copy(), V.copy()
+        Pc[3, 900] ^= 1                       # wrong n0
+        Pc[70, 64 * 5 + 31] ^= 1              # r[1] off the curve: status flag
+        Vc[200] = V[201]                      # someone else's commitment
+        Pc[n - 1, 840] ^= 4                   # l0 of the last proof (partial superchunk / partial chunk of 8)
+        e_acc, e_st, e_rej = _run(torch, proto, Vc, Pc, None)
+        assert e_rej == 4 and e_st[70] == 1
+        for seed in (bytes(32), os.urandom(32)):
+            acc, st, rej = _run(torch, proto, Vc, Pc, seed)
+            assert acc.tolist() == e_acc.tolist() and st.tolist() == e_st.tolist() and rej == e_rej
+    finally:
+        proto.enable_timing(False)
+        proto.set_option("rlc_superchunk", 4096)
+    with pytest.raises(Exception):
+        proto.set_option("rlc_superchunk", 100)        # not a multiple of 8 / out of range values are refused

@@ -83,3 +83,30 @@ def test_rlc_mode_accept_bits_equal_exact_mode(setup, oracle_c):
     # a different seed changes the weights, not the verdicts
     acc2, _, _ = _run(L, tab, W, Vc, Pc, seed=bytes(32))
     assert acc2.tolist() == exp_acc
+
+
+def test_bucket_stage_superchunk_verdicts(setup):
+    """bucket_core.h (single-thread form): a superchunk passes iff every unflagged proof in it is valid; a flagged (malformed)
+    proof gets weight zero and does not fail its superchunk; the last superchunk may be partial."""
+    L, gens, V, P, tab, W, n = setup
+    M = 8
+
+    def run(Vx, Px):
+        nx = Vx.shape[0]
+        ns = (nx + M - 1) // M
+        passed, st = np.zeros(ns, np.uint8), np.zeros(nx, np.int32)
+        Vx, Px = np.ascontiguousarray(Vx), np.ascontiguousarray(Px)
+        assert L.emul_u64_bucket_stage(tab.ctypes.data, W, workload.LABEL, len(workload.LABEL), nx, Vx.ctypes.data, Px.ctypes.data, SEED,
+                                       M, passed.ctypes.data, st.ctypes.data) == 0
+        return passed.tolist(), st
+    passed, st = run(V, P)
+    assert passed == [1, 1, 1, 1] and not st.any()                 # 27 proofs: three full superchunks and one of 3
+    P2 = P.copy()
+    P2[9, 900] ^= 1          # wrong n0 in superchunk 1
+    P2[17, 3] ^= 0x40        # c_l off the curve in superchunk 2: flagged, weight 0, the rest of the superchunk still passes
+    passed, st = run(V, P2)
+    assert passed == [1, 0, 1, 1] and st[17] == 1 and st[9] == 0
+    V3 = V.copy()
+    V3[26] = V[0]            # someone else's commitment in the partial superchunk
+    passed, st = run(V3, P)
+    assert passed == [1, 1, 1, 0]

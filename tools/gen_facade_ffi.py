@@ -12,14 +12,14 @@ TMAP = [(r'const uint8_t\s*\*\s*const\s*\*', '*const *const u8'), (r'const void\
         (r'bppp_ctx\s*\*\s*\*', '*mut *mut BpppCtx'), (r'const bppp_ctx\s*\*', '*const BpppCtx'), (r'bppp_ctx\s*\*', '*mut BpppCtx'),
         (r'bppp_circuit\s*\*\s*\*', '*mut *mut BpppCircuit'), (r'const bppp_circuit\s*\*', '*const BpppCircuit'), (r'bppp_circuit\s*\*', '*mut BpppCircuit'),
         (r'bppp_group\s*\*\s*\*', '*mut *mut BpppGroup'), (r'const bppp_group\s*\*', '*const BpppGroup'), (r'bppp_group\s*\*', '*mut BpppGroup'),
-        (r'size_t', 'usize'), (r'uint64_t', 'u64'), (r'int32_t', 'i32'), (r'int', 'c_int')]
+        (r'size_t', 'usize'), (r'uint64_t', 'u64'), (r'int32_t', 'i32'), (r'int', 'c_int'), (r'long', 'c_long')]
 RET = {'int': ' -> c_int', 'void': '', 'size_t': ' -> usize', 'const char*': ' -> *const c_char', 'const char *': ' -> *const c_char',
        'bppp_ctx*': ' -> *mut BpppCtx', 'bppp_ctx *': ' -> *mut BpppCtx'}
 HEAD = '''//! `extern "C"` declarations of EVERY entry point of include/bppp.h (libbppp_hip.so).  Generated from the header by
 //! tools/gen_facade_ffi.py and checked against it by tests/test_facade_tree.py.  UNCOMPILED (no Rust toolchain in the build
 //! image); the identical prototypes are exercised through ctypes in bp_pp_amd/_capi.py.
 #![allow(dead_code)]
-use std::os::raw::{c_char, c_int, c_void};
+use std::os::raw::{c_char, c_int, c_long, c_void};
 
 #[repr(C)] pub struct BpppCtx { _private: [u8; 0] }
 #[repr(C)] pub struct BpppCircuit { _private: [u8; 0] }

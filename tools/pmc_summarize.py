@@ -25,7 +25,8 @@ def load(prefix, counter):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
-res = {"units": "bytes per launch; raw = counter * 1024", "calibration": {}, "kernels": {}}
+res = {"units": "bytes per launch; raw = counter * 1024", "calibration": {}, "kernels": {},
+       "proofs_per_launch": int(sys.argv[2]) if len(sys.argv) > 2 else 65536}
 GIB = float(1 << 30)
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     cal = load("cal", counter)
@@ -45,7 +46,8 @@ def factor(kernel, counter):
 f_stream = factor("k_copy_dword", "FETCH_SIZE") or 2.0
 f_gather = factor("k_gather64", "FETCH_SIZE") or 1.0
 wf = factor("k_copy_dword", "WRITE_SIZE") or 1.0
-GATHER_DOMINATED = ("k_verify_c0_fixed", "k_verify_final_check", "k_verify_c0_var", "k_verify_round", "k_prove_msm", "k_prove_round_fold")
+GATHER_DOMINATED = ("k_verify_c0_fixed", "k_verify_final_check", "k_verify_c0_var", "k_verify_round", "k_prove_msm", "k_prove_round_fold",
+                    "k_wnla_msm", "k_recip_c0_fixed", "k_rlc_chunk")
 for k, v in res["kernels"].items():
     fr, wr = v.get("FETCH_SIZE_raw_bytes", 0.0), v.get("WRITE_SIZE_raw_bytes", 0.0)
     ff = f_gather if k in GATHER_DOMINATED else f_stream
