@@ -54,13 +54,17 @@ def _load_json(path):
 def valu_roofline(kernel, avg_ms, n_proofs, lanes_per_proof):
     """Compute-side ceiling of one kernel: VALU wave-instructions per launch (SQ_INSTS_VALU per wave from the committed
     rocprofv3 --pmc pass, times the waves this launch ran) over the live-measured launch time, against the issue rate of the
-    kernel's own instruction mix.  The mix (fraction of half-rate 64-bit multiply-add / shift instructions) comes from the
-    kernel's disassembly (tools/isa_mix.py -> profiles/isa_mix.json), not from a constant."""
+    kernel's own instruction mix.  The mix -- the fraction of half-rate instructions (v_mad_u64_u32, 64-bit shifts / adds) -- is
+    MEASURED per kernel: SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU from the same PMC passes (profiles/pmc_valu.json), with the static
+    count of the shipped code object (tools/isa_mix.py -> profiles/isa_mix.json) printed beside it as a cross-check.  Two peaks:
+    datasheet (1024 SIMDs x 2.4 GHz, 2 cycles per full-rate and 4 per half-rate wave64 instruction) and this chip's
+    micro-benchmark (tools/intbench.hip, which includes the clock the chip actually holds under load)."""
     pv = _load_json(os.path.join(ROOT, "profiles", "pmc_valu.json")) or {}
     mix = _load_json(os.path.join(ROOT, "profiles", "isa_mix.json")) or {}
     kv = pv.get(kernel, {})
     per_wave = kv.get("valu_insts_per_wave")
-    half = (mix.get(kernel) or {}).get("half_rate_frac")
+    half_static = (mix.get(kernel) or {}).get("half_rate_frac")
+    half = kv.get("int64_frac_of_valu", half_static)
     if not per_wave or half is None:
         return None
     waves = (n_proofs * lanes_per_proof + 63) // 64
@@ -69,10 +73,12 @@ def valu_roofline(kernel, avg_ms, n_proofs, lanes_per_proof):
     peak_ds = DATASHEET_SIMD_HZ / (half * 4 + (1 - half) * 2) / 1e9
     peak_ms = 1.0 / (half / (MEASURED_MAD_LANE_OPS / 64) + (1 - half) / (MEASURED_ADD_LANE_OPS / 64)) / 1e9
     return {"kernel": kernel, "wave_insts_per_launch": insts, "achieved": ach, "unit": "G wave-instructions/s",
-            "half_rate_inst_frac": half, "mix_source": "static ISA count of the shipped code object (tools/isa_mix.py)",
+            "half_rate_inst_frac": half, "half_rate_inst_frac_source": "SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU (rocprofv3 --pmc)" if "int64_frac_of_valu" in kv else "static ISA count",
+            "half_rate_inst_frac_static_isa": half_static,
             "peak_datasheet": peak_ds, "frac_of_datasheet": ach / peak_ds,
             "peak_microbench": peak_ms, "frac_of_microbench": ach / peak_ms,
             "valu_active_frac_of_wave_cycles": kv.get("SQ_ACTIVE_INST_VALU_frac_of_wave_cycles"),
+            "issue_stall_frac_of_wave_cycles": kv.get("SQ_WAIT_INST_ANY_frac_of_wave_cycles"),
             "wait_frac_of_wave_cycles": kv.get("SQ_WAIT_ANY_frac_of_wave_cycles")}
 
 
@@ -362,12 +368,12 @@ def run_verify(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["verify", "prove", "recip256"], default="verify")
     ap.add_argument("--total-proofs", type=int, default=0, help="size of the fixed global batch (default: 2^20 verify, 2^14 prove, 2^12 recip256)")
     ap.add_argument("--fb-window-bits", type=int, default=0)
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="proofs verified by the CPU baseline (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=8192, help="proofs verified by the CPU baseline (rank 0, N=1): ~10-20 s of host work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs[1], RLC mode, host-buffer path)")
     args = ap.parse_args()

@@ -76,7 +76,7 @@ def run_prove(args):
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import bppp_oracle_c as OC                                   # the oracle, as the timed CPU baseline ONLY
-        m = min(256, n)
+        m = min(4096, n)                                             # ~10 s of host work on 64 threads
         hw = os.cpu_count() or 1
         th = min(hw, 64)
         t0 = time.perf_counter()
@@ -109,7 +109,7 @@ def run_recip256(args):
     import recip_cases                                                # seeded instances; the oracle proves / verifies the sample only
     from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
     nd, npp, n = 256, 16, args.total_proofs
-    n_or = 0 if args.no_cpu_baseline else 4
+    n_or = 0 if args.no_cpu_baseline else 48                      # ~10 s of single-thread oracle work (prove + verify)
     t0 = time.time()
     case = recip_cases.make(nd, npp, n, n_oracle=n_or)
     t_inputs = time.time() - t0

@@ -1,6 +1,7 @@
-"""N > 1 path on CPU: world_size 2 over gloo.  Each rank takes its shard of one batch (shard_range), verifies it (here with
-the oracle standing in for the GPU, which the CPU tier does not have) and the reject counts are all-reduced exactly as
-bench.py does over RCCL; the union of the shards must reproduce the single-process result."""
+"""N > 1 path on CPU: world_size 2 over gloo.  Each rank takes its shard of one batch (shard_range) and verifies it with the
+PRODUCT's device code compiled for the host (tests/emul: the same verify_core.h functions the HIP kernels run, thread by thread --
+the CPU tier has no GPU), the reject counts are all-reduced exactly as bench.py does over RCCL, and the union of the shards must
+reproduce the oracle's single-process verdicts."""
 import os
 import socket
 
@@ -39,7 +40,19 @@ def _worker(rank, world, port, n, q):
     gens, V, P, _ = workload.make_batch(n, first=300, nthreads=1)
     P, expect = workload.corrupt(P, V, every=5)
     lo, hi = shard_range(n, rank, world)
-    acc, st = OC.u64_verify_batch(gens, workload.LABEL, V[lo:hi].copy(), P[lo:hi].copy(), nthreads=1)
+    from emul.build import load
+    L = load()
+    W = 4
+    tab = np.zeros(L.emul_fb_table_entries(49, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0
+    m = hi - lo
+    Vs, Ps = V[lo:hi].copy(), P[lo:hi].copy()
+    acc, st = np.zeros(m, np.uint8), np.zeros(m, np.int32)
+    if m:
+        L.emul_u64_verify_batch(tab.ctypes.data, W, workload.LABEL, len(workload.LABEL), m, Vs.ctypes.data, Ps.ctypes.data, acc.ctypes.data,
+                                st.ctypes.data, None)
+    oacc, _ = OC.u64_verify_batch(gens, workload.LABEL, Vs, Ps, nthreads=1)     # the checker
+    assert (acc == oacc).all()
     cnt = torch.tensor([int((acc == 0).sum())], dtype=torch.int32)
     all_reduce_reject_count(cnt)
     q.put((rank, lo, hi, acc.tolist(), int(cnt.item()), expect.tolist()))
