@@ -342,6 +342,27 @@ HD void fe_mul(fe& r, const fe& a, const fe& b) {
     }
     fe_reduce_cols(r, c);
 }
+// r = a b + c d with ONE reduction: both products accumulate into the same 19 column sums (the reduction is 44 % of a
+// multiplication's issue cycles, so a sum of two products costs ~1.55 multiplications instead of 2).  Bound: the column sums
+// must stay below 2^64, i.e. mag(a) mag(b) + mag(c) mag(d) <= 64 in the magnitude convention above (a single product of
+// magnitude-8 inputs is 64).  Used for y3 = r (q - x3) + (-y1) ppp in the mixed additions (point.h).
+HD void fe_mul2_add(fe& r, const fe& a, const fe& b, const fe& c, const fe& d) {
+#ifdef BPPP_FE_DEBUG
+    assert(a.mag * b.mag + c.mag * d.mag <= 64);
+#endif
+    u64 col[19];
+#pragma unroll
+    for (int k = 0; k < 19; k++) {
+        const int i0 = k < 10 ? 0 : k - 9, i1 = k < 10 ? k : 9;
+        u64 acc = (u64)a.v[i0] * b.v[k - i0];
+#pragma unroll
+        for (int i = i0 + 1; i <= i1; i++) acc += (u64)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = i0; i <= i1; i++) acc += (u64)c.v[i] * d.v[k - i];
+        col[k] = acc;
+    }
+    fe_reduce_cols(r, col);
+}
 HD void fe_sqr(fe& r, const fe& a) {   // 55 limb products: cross terms use the doubled limb
     FE_CHECK(a, 8);
     u32 a2[10];

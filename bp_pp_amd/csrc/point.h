@@ -174,9 +174,9 @@ HD void ptz_madd(ptz& a, bool& empty, const apt& q, bool skip) {
     fe_add(t, Q, Q);
     fe_sub_m<2>(X3, X3, t);            // magnitude 6
     fe_sub_m<6>(t, Q, X3);             // magnitude 8
-    fe_mul(Y3, R, t);
-    fe_mul(t, a.Y, PPP);
-    fe_sub_m<1>(Y3, Y3, t);            // magnitude 3
+    fe nY;
+    fe_neg_m<3>(nY, a.Y);              // magnitude 4
+    fe_mul2_add(Y3, R, t, nY, PPP);    // Y3 = R (Q - X3) - Y1 PPP, one reduction (5 * 8 + 4 * 1 <= 64); magnitude 1
     fe_mul(ZZ3, a.ZZ, PP);
     fe_mul(ZZZ3, a.ZZZ, PPP);
     // first real point: the sum IS q
@@ -242,9 +242,9 @@ HD void ptj_madd(ptj& a, bool& empty, const apt& q, bool skip) {
     fe_add(t, V, V);
     fe_sub_m<2>(X3, X3, t);            // 6
     fe_sub_m<6>(t, V, X3);             // 8
-    fe_mul(Y3, R, t);
-    fe_mul(t, a.Y, HHH);
-    fe_sub_m<1>(Y3, Y3, t);            // 3
+    fe nY;
+    fe_neg_m<3>(nY, a.Y);              // 4
+    fe_mul2_add(Y3, R, t, nY, HHH);    // Y3 = R (V - X3) - Y1 HHH, one reduction; magnitude 1
     fe_mul(Z3, a.Z, H);
     fe one;
     fe_set_u32(one, 1);

@@ -57,6 +57,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_re
 find $OUT -name "*kernel_trace*" -size +4M -delete
 find $OUT -name "*counter_collection.csv" -size +8M -delete
 cd "$REPO"
+timeout 900 python tools/rlc_sweep.py 20 2> $OUT/rlc_sweep.err | grep '^{' > $OUT/rlc_sweep.jsonl; echo "sweep rc=$?" >> $OUT/log.txt
 tail -8 $OUT/pytest_gpu.txt 2>/dev/null
 cat $OUT/log.txt
 python tools/show_bench.py $OUT/bench.json; tail -3 $OUT/bench.err
