@@ -110,9 +110,12 @@ def setup_dist(args):
         print("bench.py: no GPU visible; the bp_pp_amd product path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1: initialise RCCL even for one rank, so that the N > 1 code path (process group, barrier, the reject-count
+    # all-reduce on the verify stream) can be exercised on a one-GPU box
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
     return world, rank, local_rank
 
 
@@ -216,8 +219,10 @@ def run_verify(args):
             if nn == n:
                 all_reduce_reject_count(rej)            # the single accept-reduce (4 bytes over RCCL/xGMI); no-op at N=1
 
+    dist_on = dist.is_initialized()
+
     def fence():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -244,7 +249,7 @@ def run_verify(args):
 
     def max_over_ranks(x):
         t = torch.tensor([x], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if dist_on:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -295,7 +300,7 @@ def run_verify(args):
 
     elapsed = max_over_ranks(elapsed)
     ok_all = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device="cuda")
-    if world > 1:
+    if dist_on:
         dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
     ok = bool(ok_all.item()) and rejects == expected_rejects
 
@@ -359,7 +364,7 @@ def run_verify(args):
                                                          f"first {m} proofs of the same batch")
         print(json.dumps(result), flush=True)
     proto.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
     if not ok:
         sys.exit(1)

@@ -17,7 +17,8 @@ EXPORTS = [
     "bppp_ctx_create", "bppp_wnla_ctx_create", "bppp_wnla_commit_batch", "bppp_wnla_verify_batch", "bppp_reciprocal_verify_batch", "bppp_reciprocal_verify_batch_device", "bppp_reciprocal_prove_batch", "bppp_msm_batch", "bppp_wnla_proof_shape", "bppp_wnla_prove_batch", "bppp_circuit_create", "bppp_circuit_destroy", "bppp_circuit_verify_batch", "bppp_circuit_prove_batch", "bppp_ctx_destroy", "bppp_ctx_set_stream", "bppp_ctx_synchronize", "bppp_ctx_set_option", "bppp_u64_verify_batch", "bppp_u64_verify_batch_device", "bppp_u64_verify_batch_rlc_device", "bppp_u64_verify_batch_rlc", "bppp_u64_verify_batch_sec1", "bppp_u64_verify_batch_sec1_device",
     "bppp_u64_commit_value_batch", "bppp_u64_prove_batch", "bppp_u64_prove_batch_device", "bppp_ctx_enable_timing", "bppp_ctx_get_timings", "bppp_ctx_device_bytes",
     "bppp_strerror", "bppp_last_error",
-    "bppp_u64_verify_batch_transcript", "bppp_u64_verify_batch_transcript_device", "bppp_transcript_new",
+    "bppp_u64_verify_batch_transcript", "bppp_u64_verify_batch_transcript_device", "bppp_u64_prove_batch_transcript",
+    "bppp_u64_prove_batch_transcript_device", "bppp_transcript_new",
     "bppp_transcript_append_message", "bppp_transcript_challenge_bytes",
     "bppp_derive_generators", "bppp_ctx_save_tables", "bppp_ctx_create_from_tables", "bppp_ctx_create_shared",
     "bppp_shard_range", "bppp_group_create", "bppp_group_destroy", "bppp_group_size", "bppp_group_ctx", "bppp_u64_verify_batch_sharded",
@@ -83,6 +84,8 @@ def lib():
     L.bppp_ctx_device_bytes.restype = sz
     L.bppp_u64_verify_batch_transcript.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, vp]
     L.bppp_u64_verify_batch_transcript_device.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, vp, vp]
+    L.bppp_u64_prove_batch_transcript.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, vp, vp, vp]
+    L.bppp_u64_prove_batch_transcript_device.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.bppp_transcript_new.argtypes = [u8p, sz, vp]
     L.bppp_transcript_append_message.argtypes = [vp, u8p, sz, u8p, sz]
     L.bppp_transcript_challenge_bytes.argtypes = [vp, u8p, sz, vp, sz]

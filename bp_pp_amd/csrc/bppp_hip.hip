@@ -723,8 +723,20 @@ int bppp_u64_commit_value_batch(bppp_ctx* c, size_t n, const uint64_t* x, const 
     return flags ? BPPP_ERR_INVALID_ARG : BPPP_OK;
 }
 
+static int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
+                             const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status, const VerifyTranscripts* tx);
 int bppp_u64_prove_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
                                 const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status) {
+    return prove_device_impl(c, label, label_len, n, d_x, d_s, d_rnd, d_proofs, d_commitments, d_status, nullptr);
+}
+int bppp_u64_prove_batch_transcript_device(bppp_ctx* c, size_t n, const void* d_states, size_t n_states, const void* d_x, const void* d_s,
+                                           const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status, void* d_states_out) {
+    if (!d_states || (n_states != 1 && n_states != n)) return BPPP_ERR_INVALID_ARG;
+    VerifyTranscripts tx = {d_states, n_states, d_states_out};
+    return prove_device_impl(c, nullptr, 0, n, d_x, d_s, d_rnd, d_proofs, d_commitments, d_status, &tx);
+}
+static int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
+                             const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status, const VerifyTranscripts* tx) {
     if (!c || (!label && label_len) || !d_x || !d_s || !d_rnd || !d_proofs || !d_commitments) return BPPP_ERR_INVALID_ARG;
     if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
@@ -750,6 +762,7 @@ int bppp_u64_prove_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_
     w.straus = c->d_straus;
     w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
     t_new(w.base, label, (u32)label_len);
+    if (tx) { w.states = (const uint8_t*)tx->d_states; w.n_states = tx->n_states; w.states_out = (uint8_t*)tx->d_states_out; }
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     hipStream_t s = c->stream;
@@ -772,10 +785,46 @@ int bppp_u64_prove_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_
         PMSM(job_x()); PMSM(job_r());
         PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
     }
+    if (w.states_out) k_prove_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
 #undef PMSM
 #undef PLAUNCH
     HIP_TRY(hipGetLastError());
     return BPPP_OK;
+}
+// U64RangeProofProtocol::prove with the caller's transcripts (u64_proof.rs:57: `t: &mut Transcript`), host buffers
+int bppp_u64_prove_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, const uint64_t* x, const uint8_t* s,
+                                    const uint8_t* rnd, uint8_t* proofs, uint8_t* commitments, int32_t* status, uint8_t* states_out) {
+    if (!c || !states || !x || !s || !rnd || !proofs || !commitments || (n_states != 1 && n_states != n)) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    for (size_t i = 0; i < n_states; i++)
+        if (states[203 * i + 200] >= BPPP_STROBE_R || states[203 * i + 201] > BPPP_STROBE_R) return BPPP_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t SB = BPPP_TRANSCRIPT_STATE_BYTES;
+    uint8_t* d = nullptr;
+    const size_t o_x = 0, o_s = align16(o_x + n * 8), o_r = align16(o_s + n * 32), o_p = align16(o_r + n * 52 * 32),
+                 o_c = align16(o_p + n * (size_t)BPPP_U64_PROOF_BYTES), o_st = align16(o_c + n * 64), o_ti = align16(o_st + n * sizeof(int32_t)),
+                 o_to = align16(o_ti + n_states * SB), total = align16(o_to + n * SB);
+    HIP_TRY(hipMalloc(&d, total));
+    int rc = BPPP_OK;
+    hipStream_t st = c->stream;
+    hipError_t e = hipMemcpyAsync(d + o_x, x, n * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_s, s, n * 32, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_r, rnd, n * 52 * 32, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_ti, states, n_states * SB, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        rc = bppp_u64_prove_batch_transcript_device(c, n, d + o_ti, n_states, d + o_x, d + o_s, d + o_r, d + o_p, d + o_c, d + o_st,
+                                                    states_out ? d + o_to : nullptr);
+        if (rc == BPPP_OK) {
+            e = hipMemcpyAsync(proofs, d + o_p, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(commitments, d + o_c, n * 64, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && status) e = hipMemcpyAsync(status, d + o_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && states_out) e = hipMemcpyAsync(states_out, d + o_to, n * SB, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) { g_last_error = std::string("prove_batch_transcript: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
+    return rc;
 }
 
 int bppp_u64_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x, const uint8_t* s,

@@ -9,17 +9,30 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_a(ProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) prove_stage_a(w, t);
 }
+// stages that touch the transcript run once per distinct sponge position in the wavefront (kernels.h: for_each_position_group;
+// one trip unless the caller passed per-proof pre-loaded transcripts of different lengths)
+__device__ __forceinline__ u32 prove_position_key(const ProveWs& w, size_t t) {
+    return (w.states && w.n_states != 1) ? w.tstate[(size_t)50 * w.N + t] : 0u;
+}
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_b(ProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) prove_stage_b(w, t);
+    if (t >= w.N) return;
+    const u32 key = (w.states && w.n_states != 1) ? w.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
+    for_each_position_group(key, [&]() { prove_stage_b(w, t); });
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d(ProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) prove_stage_d(w, t);
+    if (t >= w.N) return;
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_stage_d(w, t); });
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f(ProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) prove_stage_f(w, t);
+    if (t >= w.N) return;
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_stage_f(w, t); });
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_export_states(ProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_export_state(w, t);
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(ProveWs w, int k) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
@@ -27,7 +40,8 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(ProveWs w, i
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(ProveWs w, int k) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) prove_round_fold(w, t, k);
+    if (t >= w.N) return;
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_round_fold(w, t, k); });
 }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(ProveWs w, MsmJob job) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;

@@ -51,6 +51,10 @@ struct ProveWs {
     pt_slot* straus;        // [N][2][9]
     FbTable fb;
     strobe base;
+    // pre-loaded transcripts (the reference's `t: &mut Transcript`, u64_proof.rs:57): as VerifyWs::states
+    const uint8_t* states;
+    size_t n_states;
+    uint8_t* states_out;
 };
 struct MsmJob {             // one fixed-base MSM per proof: sum over up to 3 contiguous base ranges of scalar set `set`
     int set, out_slot, nranges;
@@ -134,6 +138,11 @@ HD void prove_stage_b(const ProveWs& w, size_t t) {
     pt_to_affine(Va, V);
     apt_to_xy64(w.commitments + 64 * t, Va);
     strobe tr = w.base;
+    if (w.states) {
+        strobe pre;
+        if (strobe_from_bytes(pre, w.states + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * (w.n_states == 1 ? 0 : t))) tr = pre;
+        else status |= ST_BAD_ENCODING;      // not a state merlin could be in
+    }
     app_point(tr, "reciprocal_commitment", Va);                          // reciprocal.rs:114
     sc e;
     if (!t_get_challenge(tr, "reciprocal_challenge", e)) { status |= ST_DEGENERATE; sc_set_u32(e, 1); }
@@ -641,5 +650,25 @@ HD MsmJob job_cs() { MsmJob j = {0, PB_CS, 1, {1, 0, 0}, {42, 0, 0}}; return j; 
 HD MsmJob job_c0() { MsmJob j = {0, PB_C, 1, {0, 0, 0}, {43, 0, 0}}; return j; }
 HD MsmJob job_x() { MsmJob j = {1, PB_X, 1, {0, 0, 0}, {49, 0, 0}}; return j; }
 HD MsmJob job_r() { MsmJob j = {2, PB_R, 1, {0, 0, 0}, {49, 0, 0}}; return j; }
+
+// the caller's `&mut Transcript` after prove: the state after the last wnla_challenge (a PRF operation: cur_flags = 7); a flagged
+// instance (malformed input scalar or state) gets its input state back
+HD void prove_export_state(const ProveWs& w, size_t t) {
+    if (!w.states_out) return;
+    uint8_t* out = w.states_out + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * t;
+    if (w.status[t] & ST_BAD_ENCODING) {
+        if (w.states) {
+            const uint8_t* in = w.states + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * (w.n_states == 1 ? 0 : t);
+#pragma nounroll
+            for (int i = 0; i < BPPP_TRANSCRIPT_STATE_BYTES; i++) out[i] = in[i];
+        } else {
+            strobe_to_bytes(out, w.base, 2);
+        }
+        return;
+    }
+    strobe tr;
+    ws_ld_strobe(tr, w.tstate, w.N, t);
+    strobe_to_bytes(out, tr, 7);
+}
 
 }  // namespace bppp

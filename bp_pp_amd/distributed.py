@@ -19,7 +19,8 @@ def all_reduce_reject_count(count_tensor):
     """Sum the per-rank reject counts in place; returns the global number of rejected proofs (0 => batch accepted).
     `count_tensor` is a 1-element int32 tensor on this rank's device (the `d_reject_count` of bppp_u64_verify_batch_device)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    import os
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("BENCH_FORCE_DIST")):
         dist.all_reduce(count_tensor, op=dist.ReduceOp.SUM)
     return count_tensor
 

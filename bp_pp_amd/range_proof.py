@@ -201,6 +201,24 @@ class U64RangeProofProtocol:
                                                      rnd.ctypes.data, proofs.ctypes.data, com.ctypes.data, status.ctypes.data))
         return proofs, com, status
 
+    def prove_batch_transcript(self, x: np.ndarray, s, rnd, transcripts, want_states: bool = True):
+        """prove with the caller's transcripts (u64_proof.rs:57: `t: &mut Transcript`): ONE serialized state shared by the batch
+        or a sequence of n.  Returns (proofs, commitments, status, states_out [n, 203] or None)."""
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        n = x.shape[0]
+        s, rnd = _as_u8(s, (n, 32)), _as_u8(rnd, (n, 52 * 32))
+        as_bytes = lambda t: t.state if hasattr(t, "state") else bytes(t)
+        blob = as_bytes(transcripts) if hasattr(transcripts, "state") or isinstance(transcripts, (bytes, bytearray)) else \
+            b"".join(as_bytes(t) for t in transcripts)
+        states = _as_u8(blob, (-1, 203))
+        proofs, com = np.zeros((n, U64_PROOF_BYTES), dtype=np.uint8), np.zeros((n, 64), dtype=np.uint8)
+        status = np.zeros(n, dtype=np.int32)
+        out = np.zeros((n, 203), dtype=np.uint8) if want_states else None
+        _capi.check(_capi.lib().bppp_u64_prove_batch_transcript(self._ctx, n, states.ctypes.data, states.shape[0], x.ctypes.data, s.ctypes.data,
+                                                                rnd.ctypes.data, proofs.ctypes.data, com.ctypes.data, status.ctypes.data,
+                                                                out.ctypes.data if want_states else None))
+        return proofs, com, status, out
+
     def prove_batch_device(self, label: bytes, n: int, d_x: int, d_s: int, d_rnd: int, d_proofs: int, d_commitments: int,
                            d_status: int = 0) -> None:
         _capi.check(_capi.lib().bppp_u64_prove_batch_device(self._ctx, label, len(label), n, d_x, d_s, d_rnd, d_proofs,

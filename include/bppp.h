@@ -276,6 +276,15 @@ BPPP_API int bppp_u64_verify_batch_transcript(bppp_ctx* ctx, size_t n, const uin
 BPPP_API int bppp_u64_verify_batch_transcript_device(bppp_ctx* ctx, size_t n, const void* d_states, size_t n_states,
                                                      const void* d_commitments, const void* d_proofs, void* d_accept, void* d_status,
                                                      void* d_reject_count, void* d_states_out);
+/* U64RangeProofProtocol::prove(x, s, t, rng) (u64_proof.rs:57-82) with the caller's transcripts, as for verify: states in (1 or n),
+ * each proof's advanced state out (optional); rnd, proofs, commitments, status as in bppp_u64_prove_batch. */
+BPPP_API int bppp_u64_prove_batch_transcript(bppp_ctx* ctx, size_t n, const uint8_t* states /* n_states x 203 */, size_t n_states,
+                                             const uint64_t* x, const uint8_t* s /* n x 32 */, const uint8_t* rnd /* n x 52 x 32 */,
+                                             uint8_t* proofs /* n x 928 */, uint8_t* commitments /* n x 64 */,
+                                             int32_t* status /* n or NULL */, uint8_t* states_out /* n x 203 or NULL */);
+BPPP_API int bppp_u64_prove_batch_transcript_device(bppp_ctx* ctx, size_t n, const void* d_states, size_t n_states, const void* d_x,
+                                                    const void* d_s, const void* d_rnd, void* d_proofs, void* d_commitments,
+                                                    void* d_status, void* d_states_out);
 /* merlin::Transcript on serialized states, host only (no GPU needed): Transcript::new(label), append_message(label, msg)
  * (transcript.rs:7 uses it for points, wnla.rs:91-92 for u64s) and challenge_bytes(label, out) (transcript.rs:12).  A Rust caller
  * holding a real merlin::Transcript does not need these; a C caller builds its pre-loaded states with them. */

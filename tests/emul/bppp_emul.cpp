@@ -410,11 +410,25 @@ int emul_u64_bucket_stage(const uint8_t* table, int W, const uint8_t* label, siz
     return 0;
 }
 // full prover pipeline, every stage in thread order
+static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x,
+                               const uint8_t* s, const uint8_t* rnd, uint8_t* proofs, uint8_t* V, int32_t* status, const uint8_t* states,
+                               size_t n_states, uint8_t* states_out);
 int emul_u64_prove_batch(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x,
                          const uint8_t* s, const uint8_t* rnd, uint8_t* proofs, uint8_t* V, int32_t* status) {
+    return emul_u64_prove_impl(table, W, label, label_len, n, x, s, rnd, proofs, V, status, nullptr, 0, nullptr);
+}
+// the same over pre-loaded transcripts (bppp_u64_prove_batch_transcript)
+int emul_u64_prove_batch_transcript(const uint8_t* table, int W, size_t n, const uint8_t* states, size_t n_states, const uint64_t* x,
+                                    const uint8_t* s, const uint8_t* rnd, uint8_t* proofs, uint8_t* V, int32_t* status, uint8_t* states_out) {
+    return emul_u64_prove_impl(table, W, nullptr, 0, n, x, s, rnd, proofs, V, status, states, n_states, states_out);
+}
+static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x,
+                               const uint8_t* s, const uint8_t* rnd, uint8_t* proofs, uint8_t* V, int32_t* status, const uint8_t* states,
+                               size_t n_states, uint8_t* states_out) {
     ProveWs w;
     memset(&w, 0, sizeof w);
     w.N = n;
+    w.states = states; w.n_states = n_states; w.states_out = states_out;
     w.x = x; w.s = s; w.rnd = rnd; w.proofs = proofs; w.commitments = V; w.status = status;
     std::vector<u32> tstate(52 * n), sv((size_t)SV_COUNT * 8 * n), msc((size_t)BPPP_MSC_SETS * BPPP_NG * 8 * n), pbuf((size_t)PB_COUNT * 30 * n);
     std::vector<pt_slot> straus(n * 2 * BPPP_STRAUS_ENTRIES);
@@ -435,6 +449,7 @@ int emul_u64_prove_batch(const uint8_t* table, int W, const uint8_t* label, size
         msm(job_x()); msm(job_r());
         for (size_t t = 0; t < n; t++) prove_round_fold(w, t, k);
     }
+    for (size_t t = 0; t < n; t++) prove_export_state(w, t);
     return 0;
 }
 // wire format: SEC1 compressed inputs -> 64-byte form, lane by lane

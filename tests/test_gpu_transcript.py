@@ -62,3 +62,35 @@ def test_preloaded_transcripts_on_the_gpu(shared):
             proto.verify_batch_transcript(V, P, bytes(bad))
     finally:
         proto.close()
+
+
+def test_prover_over_preloaded_transcripts_on_the_gpu():
+    """bppp_u64_prove_batch_transcript: per-proof transcripts at two different sponge positions in one wavefront; proofs byte-identical
+    to the oracle prover's, transcripts advanced as merlin's, and the GPU verifier accepts them over the same transcripts."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import ref_fixture_check as RC
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    doc = RC.oracle_made_document(4)
+    cs = doc["cases"]
+    n = len(cs)
+    g, gv, hv = workload.split_generators(bytes.fromhex(doc["generators"]))
+    proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
+    try:
+        u8 = lambda key, w: np.frombuffer(b"".join(bytes.fromhex(c[key]) for c in cs), dtype=np.uint8).reshape(n, w).copy()
+        x = np.array([int(c["x"]) for c in cs], dtype=np.uint64)
+        S = u8("state_before", 203)
+        proofs, com, st, out = proto.prove_batch_transcript(x, u8("s", 32), u8("rnd", 52 * 32), [s.tobytes() for s in S])
+        assert not st.any() and (proofs == u8("proof", 928)).all() and (com == u8("commitment", 64)).all()
+        assert (out == u8("state_after_prove", 203)).all()
+        acc, vst, vout = proto.verify_batch_transcript(com, proofs, [s.tobytes() for s in S])
+        assert acc.all() and not vst.any() and (vout == u8("state_after_verify", 203)).all()
+        # one shared state: Transcript::new(label) for everybody == the label entry point
+        from bp_pp_amd.transcript import Transcript
+        p2, c2, st2, _ = proto.prove_batch_transcript(x, u8("s", 32), u8("rnd", 52 * 32), Transcript(bytes.fromhex(doc["label"])))
+        p3, c3, st3 = proto.prove_batch(x, u8("s", 32), u8("rnd", 52 * 32), bytes.fromhex(doc["label"]))
+        assert (p2 == p3).all() and (c2 == c3).all() and not st2.any()
+    finally:
+        proto.close()

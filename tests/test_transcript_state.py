@@ -76,3 +76,24 @@ def test_derived_generators_equal_the_oracle_and_are_valid_points():
             pt = O.derive_generator(seed, i)
             assert gens[64 * i:64 * i + 64] == O.pt_to_xy64(pt) and O.on_curve(pt) and pt[1] % 2 == 0
     assert derive_generators(b"s", 3, first_index=5) == derive_generators(b"s", 8)[5 * 64:]
+
+
+def test_prover_over_preloaded_transcripts_through_the_device_code():
+    """`prove(x, s, t: &mut Transcript, rng)` (u64_proof.rs:57): proofs made on transcripts that already hold context are
+    byte-identical to the oracle prover's and the transcripts come back advanced exactly as merlin's."""
+    import ref_fixture_check as RC
+    L = load()
+    doc = RC.oracle_made_document(4)          # cases 1 and 3 carry context, so the four states sit at two different positions
+    cs = doc["cases"]
+    W = 4
+    tab = np.zeros(L.emul_fb_table_entries(49, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(bytes.fromhex(doc["generators"]), 49, W, tab.ctypes.data) == 0
+    n = len(cs)
+    u8 = lambda key, w: np.frombuffer(b"".join(bytes.fromhex(c[key]) for c in cs), dtype=np.uint8).reshape(n, w).copy()
+    x = np.array([int(c["x"]) for c in cs], dtype=np.uint64)
+    s, rnd, S = u8("s", 32), u8("rnd", 52 * 32), u8("state_before", 203)
+    proofs, V, st, out = np.zeros((n, 928), np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.int32), np.zeros((n, 203), np.uint8)
+    assert L.emul_u64_prove_batch_transcript(tab.ctypes.data, W, n, S.ctypes.data, n, x.ctypes.data, s.ctypes.data, rnd.ctypes.data,
+                                             proofs.ctypes.data, V.ctypes.data, st.ctypes.data, out.ctypes.data) == 0
+    assert not st.any() and (proofs == u8("proof", 928)).all() and (V == u8("commitment", 64)).all()
+    assert (out == u8("state_after_prove", 203)).all()
