@@ -43,6 +43,13 @@ def test_no_device_means_error_not_fallback():
     rc = L.bppp_ctx_create(C.byref(ctx), bytes(64), bytes(16 * 64), bytes(32 * 64), 0, 8)
     assert rc == _capi.ERR_NO_DEVICE and not ctx.value
     assert L.bppp_u64_verify_batch(None, b"x", 1, 1, None, None, None, None) == _capi.ERR_INVALID_ARG
+    # the other ways to obtain a context or a device group fail the same way: loudly, with no fallback
+    grp, dev = C.c_void_p(), (C.c_int * 1)(0)
+    assert L.bppp_group_create(C.byref(grp), bytes(64), bytes(16 * 64), bytes(32 * 64), dev, 1, 8) == _capi.ERR_NO_DEVICE and not grp.value
+    assert L.bppp_wnla_ctx_create(C.byref(ctx), bytes(64), bytes(64), 1, bytes(64), 1, 0, 8) == _capi.ERR_NO_DEVICE and not ctx.value
+    assert L.bppp_ctx_create_from_tables(C.byref(ctx), b"/nonexistent", 0) in (_capi.ERR_NO_DEVICE, _capi.ERR_INVALID_ARG) and not ctx.value
+    assert L.bppp_ctx_create_shared(C.byref(ctx), None) == _capi.ERR_INVALID_ARG
+    assert L.bppp_group_size(None) == 0
 
 
 def test_header_is_plain_c_and_a_c_program_links(tmp_path):
