@@ -91,7 +91,7 @@ def pmc_traffic(kernel, n_proofs):
     if b is None:
         return None
     n_ref = k.get("proofs_per_launch") or tr.get("proofs_per_launch") or 65536
-    return b * (n_proofs / n_ref)
+    return b * (n_proofs / n_ref)      # the PMC pass of this kernel ran n_ref proofs per launch
 
 
 FB_KERNELS = ("k_verify_c0_fixed", "k_verify_final_check", "k_prove_msm", "k_wnla_msm", "k_recip_c0_fixed")

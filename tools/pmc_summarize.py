@@ -25,16 +25,19 @@ def load(prefix, counter):
     return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
 
 
-res = {"units": "bytes per launch; raw = counter * 1024", "calibration": {}, "kernels": {},
-       "proofs_per_launch": int(sys.argv[2]) if len(sys.argv) > 2 else 65536}
+# usage: pmc_summarize.py <dir> [proofs per launch of the bench passes] [kernel-name prefixes to keep, comma separated] [bench prefix]
+N_PER_LAUNCH = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+KEEP = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 and sys.argv[3] else ("k_",)
+BENCH_PREFIX = sys.argv[4] if len(sys.argv) > 4 else "bench"
+res = {"units": "bytes per launch; raw = counter * 1024", "calibration": {}, "kernels": {}, "proofs_per_launch": N_PER_LAUNCH}
 GIB = float(1 << 30)
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     cal = load("cal", counter)
     for k, (avg, cnt) in cal.items():
         if k.startswith("k_copy") or k.startswith("k_gather64"):
             res["calibration"].setdefault(k, {})[counter] = {"raw_bytes": avg * 1024, "true_bytes": GIB, "factor_true_over_raw": GIB / (avg * 1024) if avg else None}
-    for k, (avg, cnt) in load("bench", counter).items():
-        if k.startswith("k_"):
+    for k, (avg, cnt) in load(BENCH_PREFIX, counter).items():
+        if k.startswith(KEEP):
             res["kernels"].setdefault(k, {})[counter + "_raw_bytes"] = avg * 1024
             res["kernels"][k]["launches_seen"] = cnt
 # corrected traffic.  Calibration on this chip (tools/membench): coalesced streams (4 or 16 B/lane) -> FETCH_SIZE reads exactly
@@ -54,5 +57,6 @@ for k, v in res["kernels"].items():
     v["hbm_bytes_per_launch"] = fr * ff + wr * wf
     v["hbm_bytes_per_launch_bounds"] = [fr * min(f_gather, f_stream) + wr * wf, fr * max(f_gather, f_stream) + wr * wf]
     v["correction"] = {"fetch_factor": ff, "write_factor": wf, "class": "gather" if k in GATHER_DOMINATED else "stream"}
-json.dump(res, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
+    v["proofs_per_launch"] = N_PER_LAUNCH
+json.dump(res, open(os.path.join(out_dir, f"pmc_traffic_{BENCH_PREFIX}.json" if BENCH_PREFIX != "bench" else "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
