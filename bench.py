@@ -376,7 +376,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["verify", "prove", "recip256"], default="verify")
-    ap.add_argument("--total-proofs", type=int, default=0, help="size of the fixed global batch (default: 2^20 verify, 2^14 prove, 2^12 recip256)")
+    ap.add_argument("--total-proofs", type=int, default=0, help="size of the fixed global batch (default: 2^20 verify, 2^14 prove, 2^15 recip256)")
     ap.add_argument("--fb-window-bits", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="proofs verified by the CPU baseline (rank 0, N=1): ~10-20 s of host work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -387,7 +387,7 @@ def main():
         run_verify(args)
     else:
         import bench_other
-        args.total_proofs = args.total_proofs or ((1 << 14) if args.workload == "prove" else (1 << 12))
+        args.total_proofs = args.total_proofs or ((1 << 14) if args.workload == "prove" else (1 << 15))
         (bench_other.run_prove if args.workload == "prove" else bench_other.run_recip256)(args)
 
 

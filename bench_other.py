@@ -111,7 +111,7 @@ def run_recip256(args):
     nd, npp, n = 256, 16, args.total_proofs
     n_or = 0 if args.no_cpu_baseline else 48                      # ~10 s of single-thread oracle work (prove + verify)
     t0 = time.time()
-    case = recip_cases.make(nd, npp, n, n_oracle=n_or)
+    case = recip_cases.make_bulk(nd, npp, n, n_oracle=n_or)
     t_inputs = time.time() - t0
     W = args.fb_window_bits or 16
     t0 = time.time()
