@@ -141,6 +141,13 @@ fn main() {
             "state_after_verify": hex::encode(tstate::to_bytes(&bt)), "accept": bad_ok,
         }));
     }
+    let merlin_kat = {
+        let mut t = Transcript::new(b"test protocol");
+        t.append_message(b"some label", b"some data");
+        let mut c = [0u8; 32];
+        t.challenge_bytes(b"challenge", &mut c);
+        hex::encode(c)
+    };
     let doc = json!({
         "source": "distributed-lab/bp-pp 0.1.1 (k256 0.13.3, merlin 3.0.0), facade/src/bin/gen_fixtures.rs",
         "seed": hex::encode(seed), "label": hex::encode(label), "generators": gens, "generator_rng_bytes": hex::encode(&gen_bytes),
@@ -149,10 +156,7 @@ fn main() {
         "identity_to_bytes": hex::encode(ProjectivePoint::IDENTITY.to_bytes()),
         "identity_json": serde_json::to_value(&AffinePoint::IDENTITY).unwrap(),
         "scalar_json_example": serde_json::to_value(&Scalar::from(0xABCDEFu32)).unwrap(),
-        "merlin_kat": {
-            "challenge": { let mut t = Transcript::new(b"test protocol"); t.append_message(b"some label", b"some data");
-                           let mut c = [0u8; 32]; t.challenge_bytes(b"challenge", &mut c); hex::encode(c) },
-        },
+        "merlin_kat": { "challenge": merlin_kat },
     });
     println!("{}", serde_json::to_string_pretty(&doc).unwrap());
 }

@@ -25,10 +25,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc/prove_$C -- python3 $REPO/bench.py --workload prove --no-cpu-baseline > /dev/null 2> $OUT/pmc_prove_$C.err
   timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc/recip_$C -- python3 $REPO/bench.py --workload recip256 --no-cpu-baseline > /dev/null 2> $OUT/pmc_recip_$C.err
 done
-# the verify bench's kernels at 2^20 proofs per launch; the prover's at 2^14; the generic reciprocal verifier's at 2^12
+# the verify bench's kernels at 2^20 proofs per launch; the prover's at 2^14; the generic reciprocal verifier's at 2^15
 python3 $REPO/tools/pmc_summarize.py $OUT/pmc $N k_verify,k_rlc,k_bkt,k_fb,k_decode > $OUT/pmc_summary.txt 2>&1
 python3 $REPO/tools/pmc_summarize.py $OUT/pmc 16384 k_prove prove >> $OUT/pmc_summary.txt 2>&1
-python3 $REPO/tools/pmc_summarize.py $OUT/pmc 4096 k_recip,k_wnla,k_msm recip >> $OUT/pmc_summary.txt 2>&1
+python3 $REPO/tools/pmc_summarize.py $OUT/pmc 32768 k_recip,k_wnla,k_msm recip >> $OUT/pmc_summary.txt 2>&1
 python3 - $OUT/pmc <<'PY'
 import json, os, sys
 d = sys.argv[1]
@@ -37,7 +37,7 @@ for extra in ("pmc_traffic_prove.json", "pmc_traffic_recip.json"):
     p = os.path.join(d, extra)
     if os.path.exists(p):
         base["kernels"].update(json.load(open(p))["kernels"])
-base["note"] = "proofs_per_launch is per kernel: 2^20 for the verify bench, 2^14 for --workload prove, 2^12 for --workload recip256"
+base["note"] = "proofs_per_launch is per kernel: 2^20 for the verify bench, 2^14 for --workload prove, 2^15 for --workload recip256"
 json.dump(base, open(os.path.join(d, "pmc_traffic.json"), "w"), indent=1)
 PY
 timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/sq/p1 -- $B > $OUT/sq_p1.json 2> $OUT/sq_p1.err; echo "sq1 rc=$?" >> $OUT/log.txt
