@@ -1,4 +1,5 @@
-"""Soak test on one GPU: fresh 2^16-proof batches (product prover), random byte corruptions, exact mode vs RLC mode vs expectation,
+"""Soak test on one GPU: fresh 2^16-proof batches (product prover), random byte corruptions, exact mode vs RLC mode (bucket stage at
+several superchunk sizes, chunks of 8, exact re-check) vs expectation,
 and a random sample of every batch re-verified by the CPU oracle.   python tools/soak.py [batches]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,10 +19,12 @@ bad_total = 0
 t0 = time.time()
 for it in range(K):
     first = (it + 1) * n
-    P, V, pst = proto.prove_batch(workload.values(n, first=first), workload.blindings(n, first=first), workload.prover_randomness(n, first=first), workload.LABEL)
+    P, V, pst = proto.prove_batch(workload.bulk_values(n, first=first), workload.bulk_blindings(n, first=first), workload.bulk_prover_randomness(n, first=first), workload.LABEL)
+    sm = (4096, 256, 1024, 8192, 0)[it % 5]                     # superchunk size of the RLC mode's bucket stage (0 = chunks of 8 only)
+    proto.set_option("rlc_superchunk", sm)
     assert not pst.any()
     P, V = P.copy(), V.copy()
-    idx = rng.choice(n, size=int(rng.integers(1, 400)), replace=False)
+    idx = rng.choice(n, size=int(rng.integers(0, 400)) if it % 3 else int(rng.integers(0, 4)), replace=False)   # every third batch nearly clean
     P0, V0 = P.copy(), V.copy()
     for i in idx:
         kind = int(rng.integers(0, 6))
@@ -60,5 +63,5 @@ for it in range(K):
     oacc, ost = OC.u64_verify_batch(gens, workload.LABEL, V[sample].copy(), P[sample].copy(), nthreads=min(64, os.cpu_count() or 1))
     assert (oacc == a0[sample]).all() and ((ost != 0) == (s0[sample] != 0)).all(), "GPU and CPU oracle disagree"
     bad_total += len(idx)
-    print(f"batch {it}: {len(idx)} corrupted, {int((s0 != 0).sum())} malformed, rejects {r0}; exact == rlc == oracle sample  [{time.time() - t0:.0f} s]", flush=True)
+    print(f"batch {it} (superchunk {sm}): {len(idx)} corrupted, {int((s0 != 0).sum())} malformed, rejects {r0}; exact == rlc == oracle sample  [{time.time() - t0:.0f} s]", flush=True)
 print(f"soak ok: {K} batches, {K * n} proofs, {bad_total} corrupted")
