@@ -102,6 +102,7 @@ struct bppp_ctx {
     uint8_t* d_expand = nullptr;
     size_t expand_bytes = 0;
     int* d_flags = nullptr;
+    int n_simds = 1024;            // CUs x 4 (device property), decides between the small-batch and the 2-waves/SIMD lane kernels
     bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
     bool serial_c0 = false, rlc_debug = false;   // diagnostics, read from the environment once at context creation
@@ -249,6 +250,11 @@ static int drain_timings(bppp_ctx* c) {
     return BPPP_OK;
 }
 
+static int device_simds(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount <= 0) return 1024;
+    return prop.multiProcessorCount * 4;
+}
 static int check_device(int device) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -303,6 +309,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     if (!c) return BPPP_ERR_NOMEM;
     c->device = device;
     c->fb_w = W;
+    c->n_simds = device_simds(device);
     c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
     c->ng = (int)ng; c->nh = (int)nh; c->nbases = NB;
@@ -510,7 +517,10 @@ static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_le
         if (rc != BPPP_OK) return rc;                           \
     } while (0)
 #define LAUNCH(id, ...) LAUNCH_ON(s, id, __VA_ARGS__)
-    LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    // a grid that does not even fill one wavefront per SIMD gains nothing from the 256-VGPR cap: use the uncapped builds
+    const bool small = blocks <= (unsigned)c->n_simds;
+    if (small) LAUNCH(K_PHASE1, k_verify_phase1_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    else LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     // C0 = variable-base half (window tables of the proof points, then the shared-doubling sum: one lane per proof, 1 wave
     // per SIMD) + fixed-base half (8 lanes per proof): independent, so they run concurrently on two streams and share the
@@ -521,9 +531,13 @@ static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_le
     HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
     LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_join, a));
-    LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    if (small) LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    else LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
-    for (int k = 1; k <= 4; k++) LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+    for (int k = 1; k <= 4; k++) {
+        if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+        else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+    }
     LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     if (!rlc_seed) {
         LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
@@ -1703,6 +1717,7 @@ static int ctx_alloc_common(bppp_ctx* c) {
     HIP_TRY(hipMalloc(&c->d_flags, sizeof(int)));
     c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
+    c->n_simds = device_simds(c->device);
     return BPPP_OK;
 }
 int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device) {

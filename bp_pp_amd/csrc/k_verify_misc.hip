@@ -14,6 +14,12 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_phas
     const u32 key = (ws.states && ws.n_states != 1) ? ws.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
     for_each_position_group(key, [&]() { verify_phase1(ws, t); });
 }
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_small(VerifyWs ws) {     // see k_verify_round_small
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= ws.N) return;
+    const u32 key = (ws.states && ws.n_states != 1) ? ws.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
+    for_each_position_group(key, [&]() { verify_phase1(ws, t); });
+}
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(VerifyWs ws) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N) verify_final_scalars(ws, t);

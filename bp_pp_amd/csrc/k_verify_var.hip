@@ -18,6 +18,19 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_roun
     const u32 key = (ws.states && ws.n_states != 1) ? ws.tstate[(size_t)50 * ws.N + t] : 0u;   // the stored sponge position
     for_each_position_group(key, [&]() { verify_round(ws, t, k); });
 }
+// Small-batch variants (at most one wavefront per SIMD anyway: 2^16 proofs = 1024 workgroups on 1024 SIMDs): no register cap, so
+// nothing spills -- the latency of the lone wavefront is what the batch takes.  The host picks them when the lane-kernel grid does
+// not exceed the number of SIMDs.
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_small(VerifyWs ws) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_c0_var(ws, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_small(VerifyWs ws, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= ws.N) return;
+    const u32 key = (ws.states && ws.n_states != 1) ? ws.tstate[(size_t)50 * ws.N + t] : 0u;
+    for_each_position_group(key, [&]() { verify_round(ws, t, k); });
+}
 // ---- random-linear-combination batch mode (rlc_core.h)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(VerifyWs ws, RlcWs r) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
