@@ -913,10 +913,18 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
     BPPP_STAMP(t, 0);
     const uint8_t* pv = ws.commitments + 64 * t;
     const uint8_t* pp = ws.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
-    apt V, P[13];
+    // The 13 proof points are decoded one at a time and go straight to the workspace (a 13-point array would live in scratch
+    // memory); the transcript below reloads each one right before it is hashed.  Only V and proof.r (needed for V + r) stay in
+    // registers.
+    apt V, Pr;
     bool ok = apt_from_xy64(V, pv);
 #pragma nounroll
-    for (int i = 0; i < 13; i++) ok &= apt_from_xy64(P[i], pp + 64 * i);
+    for (int i = 0; i < 12; i++) {
+        apt Q;
+        ok &= apt_from_xy64(Q, pp + 64 * i);
+        ws_st_apt(ws.pts, N, t, i, Q);
+    }
+    ok &= apt_from_xy64(Pr, pp + 64 * 12);
     sc l0, l1, n0;
     ok &= sc_from_be(l0, pp + 832);
     ok &= sc_from_be(l1, pp + 864);
@@ -928,8 +936,9 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
         fe_set_u32(zero.x, 0);
         fe_set_u32(zero.y, 0);
         V = zero;
+        Pr = zero;
 #pragma nounroll
-        for (int i = 0; i < 13; i++) P[i] = zero;
+        for (int i = 0; i < 12; i++) ws_st_apt(ws.pts, N, t, i, zero);
         sc_set_u32(l0, 0); sc_set_u32(l1, 0); sc_set_u32(n0, 0);
     }
     strobe tr = ws.base;
@@ -948,13 +957,20 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
     {
         pt s;
         pt_from_affine(s, V);
-        pt_madd(s, s, P[12], apt_is_identity(P[12]));
+        pt_madd(s, s, Pr, apt_is_identity(Pr));
         pt_to_affine(Vr, s);
     }
+    ws_st_apt(ws.pts, N, t, 12, Vr);
     BPPP_STAMP(t, 2);
-    app_point(tr, "commitment_cl", P[0]);                                // circuit.rs:155-159
-    app_point(tr, "commitment_cr", P[1]);
-    app_point(tr, "commitment_co", P[2]);
+    {
+        apt Q;
+        ws_ld_apt(Q, ws.pts, N, t, 0);
+        app_point(tr, "commitment_cl", Q);                               // circuit.rs:155-159
+        ws_ld_apt(Q, ws.pts, N, t, 1);
+        app_point(tr, "commitment_cr", Q);
+        ws_ld_apt(Q, ws.pts, N, t, 2);
+        app_point(tr, "commitment_co", Q);
+    }
     app_point(tr, "commitment_v", Vr);
     BPPP_STAMP(t, 3);
     cok &= t_get_challenge(tr, "circuit_rho", rho);                      // circuit.rs:161-164
@@ -962,7 +978,11 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
     cok &= t_get_challenge(tr, "circuit_beta", beta);
     cok &= t_get_challenge(tr, "circuit_delta", delta);
     BPPP_STAMP(t, 4);
-    app_point(tr, "commitment_cs", P[3]);                                // circuit.rs:189
+    {
+        apt Q;
+        ws_ld_apt(Q, ws.pts, N, t, 3);
+        app_point(tr, "commitment_cs", Q);                               // circuit.rs:189
+    }
     cok &= t_get_challenge(tr, "circuit_tau", tau);                      // circuit.rs:191
     if (!cok) {
         status |= ST_DEGENERATE;
@@ -971,47 +991,54 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
     ws_st_strobe(ws.tstate, N, t, tr);
     ws_st8(ws.chal, N, t, 0, e.v); ws_st8(ws.chal, N, t, 1, rho.v); ws_st8(ws.chal, N, t, 2, lambda.v);
     ws_st8(ws.chal, N, t, 3, beta.v); ws_st8(ws.chal, N, t, 4, delta.v); ws_st8(ws.chal, N, t, 5, tau.v);
-#pragma nounroll
-    for (int i = 0; i < 12; i++) ws_st_apt(ws.pts, N, t, i, P[i]);
-    ws_st_apt(ws.pts, N, t, 12, Vr);
     ws_st8(ws.lns, N, t, 0, l0.v); ws_st8(ws.lns, N, t, 1, l1.v); ws_st8(ws.lns, N, t, 2, n0.v);
 
     // ---- scalars.  One Fn inversion for {mu, tau, e+0..e+15} (the reference: util.rs:119, circuit.rs:192, reciprocal.rs:181 x256)
     sc mu;
     BPPP_STAMP(t, 5);
     sc_mul(mu, rho, rho);                                                // circuit.rs:166
-    sc a[18], pre[18];
-    a[0] = mu;
-    a[1] = tau;
-#pragma nounroll
-    for (int j = 0; j < 16; j++) {
-        sc js;
-        sc_set_u32(js, (u32)j);
-        sc_add(a[2 + j], e, js);
-    }
+    // Montgomery's trick over the 18 values a_0 = mu, a_1 = tau, a_{2+j} = e + j.  The values are recomputed where needed and the
+    // running products / the inverses travel through workspace slots that are free at this point (cvec: products, fsc:
+    // inverses) instead of two 18-element arrays in scratch memory.
+    auto batch_value = [&](int i, sc& v) {
+        if (i == 0) v = mu;
+        else if (i == 1) v = tau;
+        else {
+            sc js;
+            sc_set_u32(js, (u32)(i - 2));
+            sc_add(v, e, js);
+        }
+    };
     bool zero_inv = sc_is_zero(delta);                                   // circuit.rs:196 unwraps delta^-1 although u64 never uses it
     sc one;
     sc_set_u32(one, 1);
+    sc run = one;
 #pragma nounroll
     for (int i = 0; i < 18; i++) {
-        bool z = sc_is_zero(a[i]);
+        sc v;
+        batch_value(i, v);
+        const bool z = sc_is_zero(v);
         zero_inv |= z;
-        if (z) a[i] = one;
-        if (i == 0) pre[0] = a[0];
-        else sc_mul(pre[i], pre[i - 1], a[i]);
+        if (z) v = one;
+        ws_st8(ws.cvec, N, t, i, run.v);      // product of a_0 .. a_{i-1}
+        sc_mul(run, run, v);
     }
     if (zero_inv) status |= ST_DEGENERATE;
     sc inv;
-    sc_inv(inv, pre[17]);
+    sc_inv(inv, run);
+    sc mu_inv, tau_inv;
 #pragma nounroll
-    for (int i = 17; i >= 1; i--) {
-        sc ai;
-        sc_mul(ai, inv, pre[i - 1]);
-        sc_mul(inv, inv, a[i]);
-        a[i] = ai;
+    for (int i = 17; i >= 0; i--) {
+        sc v, pre, ai;
+        batch_value(i, v);
+        if (sc_is_zero(v)) v = one;
+        ws_ld8(pre.v, ws.cvec, N, t, i);
+        sc_mul(ai, inv, pre);                 // a_i^-1
+        sc_mul(inv, inv, v);
+        if (i >= 2) ws_st8(ws.fsc, N, t, i - 2, ai.v);      // (e + j)^-1 at fsc slot j
+        else if (i == 1) tau_inv = ai;
+        else mu_inv = ai;
     }
-    a[0] = inv;  // a[] now holds the inverses: mu^-1, tau^-1, (e+j)^-1
-    sc mu_inv = a[0], tau_inv = a[1];
     sc tau2, tau3, S, t1, t2;
     sc_mul(tau2, tau, tau);
     sc_mul(tau3, tau2, tau);
@@ -1052,7 +1079,9 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
         sc_mul(t1, t1, mp);
         sc_add(ps, ps, t1);
         // cl_tau[j] = 2 tau^2 S (e+j)^-1 - lambda^(j+1)                                 (circuit.rs:222-226)
-        sc_mul(t1, two_tau2_S, a[2 + j]);
+        sc einv;
+        ws_ld8(einv.v, ws.fsc, N, t, j);
+        sc_mul(t1, two_tau2_S, einv);
         sc_sub(t1, t1, lp);
         ws_st8(ws.cvec, N, t, 9 + j, t1.v);
         sc_mul(mip, mip, mu_inv);
@@ -1204,27 +1233,37 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
     sc_mul(mu5, mu5, mu5);
     // ch[b] = prod_{k: bit k of b} y_{k+1}        (h_vec / c folding, wnla.rs:96,98 unrolled)
     // cg[b] = prod_k (bit k of b ? y_{k+1} : rho_{k+1})   (g_vec folding, wnla.rs:97 unrolled)
-    sc ch[16], cg[16];
-    sc_set_u32(ch[0], 1);
-    sc_set_u32(cg[0], 1);
+    // Built in place in the output slots (cg[b] at fsc slot 1 + b, ch[b] at slot 17 + b) instead of two 16-element arrays in
+    // scratch memory; the final products overwrite them.
+    sc one;
+    sc_set_u32(one, 1);
+    ws_st8(ws.fsc, N, t, 17, one.v);
+    ws_st8(ws.fsc, N, t, 1, one.v);
 #pragma nounroll
     for (int k = 0; k < 4; k++) {
-        int half = 1 << k;
+        const int half = 1 << k;
 #pragma nounroll
         for (int b = 0; b < half; b++) {
-            sc_mul(ch[b + half], ch[b], y[k]);
-            sc_mul(cg[b + half], cg[b], y[k]);
-            sc_mul(cg[b], cg[b], rk[k]);
+            sc chb, cgb, tmp;
+            ws_ld8(chb.v, ws.fsc, N, t, 17 + b);
+            ws_ld8(cgb.v, ws.fsc, N, t, 1 + b);
+            sc_mul(tmp, chb, y[k]);
+            ws_st8(ws.fsc, N, t, 17 + b + half, tmp.v);
+            sc_mul(tmp, cgb, y[k]);
+            ws_st8(ws.fsc, N, t, 1 + b + half, tmp.v);
+            sc_mul(tmp, cgb, rk[k]);
+            ws_st8(ws.fsc, N, t, 1 + b, tmp.v);
         }
     }
     // c'_0, c'_1 = folded c (c[25..31] = 0)
-    sc c0f, c1f, tmp, cv;
+    sc c0f, c1f, tmp, cv, chv;
     sc_set_u32(c0f, 0);
     sc_set_u32(c1f, 0);
 #pragma nounroll
     for (int i = 0; i < 25; i++) {
         ws_ld8(cv.v, ws.cvec, N, t, i);
-        sc_mul(tmp, cv, ch[i & 15]);
+        ws_ld8(chv.v, ws.fsc, N, t, 17 + (i & 15));
+        sc_mul(tmp, cv, chv);
         if (i < 16) sc_add(c0f, c0f, tmp);
         else sc_add(c1f, c1f, tmp);
     }
@@ -1239,13 +1278,15 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
     ws_st8(ws.fsc, N, t, 0, v.v);
 #pragma nounroll
     for (int i = 0; i < 16; i++) {
-        sc_mul(tmp, n0, cg[i]);
+        sc cgv;
+        ws_ld8(cgv.v, ws.fsc, N, t, 1 + i);
+        sc_mul(tmp, n0, cgv);
         ws_st8(ws.fsc, N, t, 1 + i, tmp.v);
-    }
-#pragma nounroll
-    for (int i = 0; i < 32; i++) {
-        sc_mul(tmp, (i < 16) ? l0 : l1, ch[i & 15]);
+        ws_ld8(chv.v, ws.fsc, N, t, 17 + i);
+        sc_mul(tmp, l0, chv);
         ws_st8(ws.fsc, N, t, 17 + i, tmp.v);
+        sc_mul(tmp, l1, chv);
+        ws_st8(ws.fsc, N, t, 33 + i, tmp.v);
     }
 }
 HD void verify_final_check_ranges(FbRanges& rg) { fb_ranges_one(rg, 0, 0, BPPP_NG); }
