@@ -300,10 +300,11 @@ def run_verify(args):
                        "failing chunks re-checked exactly; NOT the headline metric"}
         # the regime the bucket stage is for: every proof valid.  The corrupted bytes are flipped back for this measurement only.
         bad_idx = np.nonzero(expect == 0)[0]
-        if len(bad_idx):
+        if expected_rejects:        # a GLOBAL condition: every rank takes part in the collectives below, with or without local repairs
             ti = torch.from_numpy(bad_idx).cuda()
             to = torch.from_numpy(np.array([workload.corrupt_offset(lo + int(j)) for j in bad_idx], dtype=np.int64)).cuda()
-            dP[ti, to] = dP[ti, to] ^ 1
+            if len(bad_idx):
+                dP[ti, to] = dP[ti, to] ^ 1
             torch.cuda.synchronize()
             rlc_step()
             fence()
@@ -315,7 +316,8 @@ def run_verify(args):
             rlc["all_valid"] = {"value": total * args.steps / t_v, "unit": "verifies/s", "ms_per_step": t_v / args.steps * 1e3,
                                 "all_accepted": bool(dA2.all().item()) and int(dR2.item()) == 0,
                                 "note": "same batch with the corrupted bytes restored: the bucket (Pippenger) stage passes every superchunk"}
-            dP[ti, to] = dP[ti, to] ^ 1
+            if len(bad_idx):
+                dP[ti, to] = dP[ti, to] ^ 1
             torch.cuda.synchronize()
 
     elapsed = max_over_ranks(elapsed)
