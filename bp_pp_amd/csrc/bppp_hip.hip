@@ -912,6 +912,15 @@ int bppp_u64_verify_batch_sec1(bppp_ctx* c, const uint8_t* label, size_t label_l
     return rc;
 }
 
+// caller transcripts of the generic verifiers (host pointers): n_states x 203 in, n x 203 out (optional)
+struct HostTranscripts { const uint8_t* states; size_t n_states; uint8_t* states_out; };
+static int check_host_transcripts(const HostTranscripts* tx, size_t n) {
+    if (!tx) return BPPP_OK;
+    if (!tx->states || (tx->n_states != 1 && tx->n_states != n)) return BPPP_ERR_INVALID_ARG;
+    for (size_t i = 0; i < tx->n_states; i++)
+        if (tx->states[203 * i + 200] >= BPPP_STROBE_R || tx->states[203 * i + 201] > BPPP_STROBE_R) return BPPP_ERR_INVALID_ARG;
+    return BPPP_OK;
+}
 // ---- generic WeightNormLinearArgument entry points (host pointers; one device blob per call)
 struct WnlaBlob {
     uint8_t* d = nullptr;
@@ -921,10 +930,12 @@ struct WnlaBlob {
 static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
                     const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, size_t rounds, const uint8_t* proof_r,
                     const uint8_t* proof_x, const uint8_t* proof_l, size_t nl, const uint8_t* proof_n, size_t nn, uint8_t* out_points,
-                    uint8_t* accept, int32_t* status) {
+                    uint8_t* accept, int32_t* status, const HostTranscripts* tx = nullptr) {
     HIP_TRY(hipSetDevice(c->device));
     if (rounds > 12 || nl > 4096 || nn > 4096) return BPPP_ERR_INVALID_ARG;
-    int rc = ensure_straus_capacity(c, n);
+    int rc = check_host_transcripts(tx, n);
+    if (rc != BPPP_OK) return rc;
+    rc = ensure_straus_capacity(c, n);
     if (rc != BPPP_OK) return rc;
     const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds;
     // layout of the blob: inputs | outputs | workspace
@@ -934,14 +945,15 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
                  o_r = take(n * rounds * 64), o_x = take(n * rounds * 64), o_l = take(n * nl * 32), o_n = take(n * nn * 32),
                  o_out = take(n * 64), o_acc = take(n), o_st = take(n * 4), o_ts = take(52 * n * 4), o_a = take(30 * n * 4),
                  o_pf = take(30 * n * 4), o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4),
-                 o_msc = take(NB * 8 * n * 4);
+                 o_msc = take(NB * 8 * n * 4), o_ti = take(tx ? tx->n_states * 203 : 0), o_to = take(tx && tx->states_out ? n * 203 : 0);
     WnlaBlob blob;
-    HIP_TRY(hipMalloc(&blob.d, off));
+    HIP_TRY(hipMalloc(&blob.d, off + 16));
     uint8_t* d = blob.d;
     hipStream_t s = c->stream;
     auto up = [&](size_t o, const uint8_t* src, size_t bytes) -> hipError_t {
         return (src && bytes) ? hipMemcpyAsync(d + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
     };
+    if (tx) HIP_TRY(up(o_ti, tx->states, tx->n_states * 203));
     HIP_TRY(up(o_com, commitments, n * 64));
     HIP_TRY(up(o_c, cvec, n * (size_t)c->nh * 32));
     HIP_TRY(up(o_rho, rho, n * 32));
@@ -961,6 +973,10 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
     w.straus = c->d_straus;
     w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
     if (!commit) t_new(w.base, label, (u32)label_len);
+    if (tx) {
+        w.tio.states = d + o_ti; w.tio.n_states = tx->n_states; w.tio.states_out = tx->states_out ? d + o_to : nullptr;
+        w.divergent_positions = tx->n_states != 1;
+    }
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     if (commit) {
@@ -975,8 +991,10 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
         k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
         k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
         k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
+        if (w.tio.states_out) HIP_TRY(hipMemcpyAsync(tx->states_out, d + o_to, n * 203, hipMemcpyDeviceToHost, s));
     }
     if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1002,6 +1020,19 @@ int bppp_wnla_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, 
                     accept, status);
 }
 
+int bppp_wnla_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, const uint8_t* commitments,
+                                      const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, size_t rounds, const uint8_t* proof_r,
+                                      const uint8_t* proof_x, const uint8_t* proof_l, size_t nl, const uint8_t* proof_n, size_t nn,
+                                      uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    if (!c || !states || !commitments || !cvec || !rho || !mu || (rounds && (!proof_r || !proof_x)) || (!proof_l && nl) || (!proof_n && nn) ||
+        !accept)
+        return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HostTranscripts tx = {states, n_states, states_out};
+    return wnla_run(c, false, nullptr, 0, n, commitments, cvec, rho, mu, rounds, proof_r, proof_x, proof_l, nl, proof_n, nn, nullptr, accept,
+                    status, &tx);
+}
+
 // ---- generic ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) on a context built by bppp_wnla_ctx_create over
 //      g, g_vec || g_vec_, h_vec || h_vec_
 // workspace bytes (beyond the caller's commitments / proofs / accept / status) of one reciprocal verify call
@@ -1017,7 +1048,7 @@ static size_t recip_verify_ws_bytes(const bppp_ctx* c, size_t n, size_t dim_nd, 
 // the launch sequence, every buffer in device memory; d_ws holds recip_verify_ws_bytes()
 static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                     const uint8_t* d_com, const uint8_t* d_proofs, size_t rounds, size_t nl, size_t nn, uint8_t* d_acc,
-                                    int32_t* d_st, uint8_t* d_ws) {
+                                    int32_t* d_st, uint8_t* d_ws, const TranscriptIo* dtio = nullptr) {
     const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh;
     const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
     size_t off = 0;
@@ -1037,9 +1068,12 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     r.wn_commit = d + o_wc; r.wn_c = d + o_wcv; r.wn_rho = d + o_rho; r.wn_mu = d + o_mu;
     r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
     t_new(r.base, label, (u32)label_len);
+    if (dtio) r.tio = *dtio;
     WnlaWs w;
     std::memset(&w, 0, sizeof w);
     w.N = n; w.ng = c->ng; w.nh = c->nh; w.rounds = (int)rounds; w.nl = (int)nl; w.nn = (int)nn;
+    w.base = r.base;
+    if (dtio) { w.tio = *dtio; w.divergent_positions = dtio->n_states != 1; }
     w.commitments = r.wn_commit; w.c = r.wn_c; w.rho = r.wn_rho; w.mu = r.wn_mu;
     w.proof_r = r.proofs + 256; w.proof_x = r.proofs + 256 + 64 * rounds; w.proof_l = r.proofs + 320 + 128 * rounds;
     w.proof_n = w.proof_l + 32 * nl;
@@ -1066,6 +1100,7 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     GLAUNCH(K_WNLA_FINAL_SCALARS, k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     GLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
     GLAUNCH(K_WNLA_ACCEPT, k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
 #undef GLAUNCH
     HIP_TRY(hipGetLastError());
     return BPPP_OK;
@@ -1096,28 +1131,52 @@ int bppp_reciprocal_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_
     return recip_verify_device_impl(c, label, label_len, n, dim_nd, dim_np, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, rounds, nl,
                                     nn, (uint8_t*)d_accept, (int32_t*)d_status, c->d_gws);
 }
+static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                  const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                  int32_t* status, const HostTranscripts* tx);
 int bppp_reciprocal_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                  const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
                                  int32_t* status) {
+    return recip_verify_host_impl(c, label, label_len, n, dim_nd, dim_np, commitments, proofs, rounds, nl, nn, accept, status, nullptr);
+}
+int bppp_reciprocal_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, size_t dim_nd, size_t dim_np,
+                                            const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn,
+                                            uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    if (!states) return BPPP_ERR_INVALID_ARG;
+    HostTranscripts tx = {states, n_states, states_out};
+    return recip_verify_host_impl(c, nullptr, 0, n, dim_nd, dim_np, commitments, proofs, rounds, nl, nn, accept, status, &tx);
+}
+static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                  const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                  int32_t* status, const HostTranscripts* tx) {
     if (!c || (!label && label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
     int rc = recip_verify_check_args(c, dim_nd, dim_np, rounds, nl, nn);
     if (rc != BPPP_OK) return rc;
     if (n == 0) return BPPP_OK;
+    rc = check_host_transcripts(tx, n);
+    if (rc != BPPP_OK) return rc;
     HIP_TRY(hipSetDevice(c->device));
     rc = ensure_straus_capacity(c, n);
     if (rc != BPPP_OK) return rc;
     const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
     const size_t o_com = 0, o_pr = align16(n * 64), o_acc = align16(o_pr + n * proof_bytes), o_st = align16(o_acc + n),
-                 o_ws = align16(o_st + n * 4), total = o_ws + recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds);
+                 o_ti = align16(o_st + n * 4), o_to = align16(o_ti + (tx ? tx->n_states * 203 : 0)),
+                 o_ws = align16(o_to + (tx && tx->states_out ? n * 203 : 0)), total = o_ws + recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds);
     WnlaBlob blob;
     HIP_TRY(hipMalloc(&blob.d, total));
     uint8_t* d = blob.d;
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * 64, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d + o_pr, proofs, n * proof_bytes, hipMemcpyHostToDevice, s));
+    TranscriptIo dtio = {nullptr, 0, nullptr};
+    if (tx) {
+        HIP_TRY(hipMemcpyAsync(d + o_ti, tx->states, tx->n_states * 203, hipMemcpyHostToDevice, s));
+        dtio.states = d + o_ti; dtio.n_states = tx->n_states; dtio.states_out = tx->states_out ? d + o_to : nullptr;
+    }
     rc = recip_verify_device_impl(c, label, label_len, n, dim_nd, dim_np, d + o_com, d + o_pr, rounds, nl, nn, d + o_acc, (int32_t*)(d + o_st),
-                                  d + o_ws);
+                                  d + o_ws, tx ? &dtio : nullptr);
     if (rc != BPPP_OK) return rc;
+    if (dtio.states_out) HIP_TRY(hipMemcpyAsync(tx->states_out, d + o_to, n * 203, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
     if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1184,14 +1243,31 @@ void bppp_circuit_destroy(bppp_circuit* q) {
     if (q->d_blob) (void)hipFree(q->d_blob);
     delete q;
 }
+static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n,
+                                    const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                    int32_t* status, const HostTranscripts* tx);
 int bppp_circuit_verify_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
                               const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept, int32_t* status) {
+    return circuit_verify_host_impl(c, q, label, label_len, n, commitments, proofs, rounds, nl, nn, accept, status, nullptr);
+}
+int bppp_circuit_verify_batch_transcript(bppp_ctx* c, const bppp_circuit* q, size_t n, const uint8_t* states, size_t n_states,
+                                         const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn,
+                                         uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    if (!states) return BPPP_ERR_INVALID_ARG;
+    HostTranscripts tx = {states, n_states, states_out};
+    return circuit_verify_host_impl(c, q, nullptr, 0, n, commitments, proofs, rounds, nl, nn, accept, status, &tx);
+}
+static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n,
+                                    const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                    int32_t* status, const HostTranscripts* tx) {
     if (!c || !q || (!label && label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
     const CircuitDev& cd = q->cd;
     if (cd.nm > c->ng || cd.nv + 9 > c->nh || rounds > 12 || nl > 4096 || nn > 4096) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
+    int rc = check_host_transcripts(tx, n);
+    if (rc != BPPP_OK) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    int rc = ensure_straus_capacity(c, n);
+    rc = ensure_straus_capacity(c, n);
     if (rc != BPPP_OK) return rc;
     const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh, k = (size_t)cd.k, nm = (size_t)cd.nm, nv = (size_t)cd.nv;
     const size_t proof_bytes = 64 * (4 + 2 * rounds) + 32 * (nl + nn);
@@ -1201,11 +1277,13 @@ int bppp_circuit_verify_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t*
                  o_lam = take((size_t)cd.nl * 8 * n * 4), o_muv = take(nm * 8 * n * 4), o_coef = take((3 * nm + 3 * nv) * 8 * n * 4),
                  o_sc0 = take((nm + 5 + k) * 8 * n * 4), o_pts = take((4 + k) * 16 * n * 4), o_a = take(30 * n * 4), o_pf = take(30 * n * 4),
                  o_wc = take(n * 64), o_wcv = take(n * NH * 32), o_rho = take(n * 32), o_mu = take(n * 32),
-                 o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4), o_msc = take(NB * 8 * n * 4);
+                 o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4), o_msc = take(NB * 8 * n * 4),
+                 o_ti = take(tx ? tx->n_states * 203 : 0), o_to = take(tx && tx->states_out ? n * 203 : 0);
     WnlaBlob blob;
-    HIP_TRY(hipMalloc(&blob.d, off));
+    HIP_TRY(hipMalloc(&blob.d, off + 16));
     uint8_t* d = blob.d;
     hipStream_t s = c->stream;
+    if (tx) HIP_TRY(hipMemcpyAsync(d + o_ti, tx->states, tx->n_states * 203, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * k * 64, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d + o_pr, proofs, n * proof_bytes, hipMemcpyHostToDevice, s));
     CircuitWs r;
@@ -1218,9 +1296,11 @@ int bppp_circuit_verify_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t*
     r.wn_commit = d + o_wc; r.wn_c = d + o_wcv; r.wn_rho = d + o_rho; r.wn_mu = d + o_mu;
     r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
     t_new(r.base, label, (u32)label_len);
+    if (tx) { r.tio.states = d + o_ti; r.tio.n_states = tx->n_states; r.tio.states_out = tx->states_out ? d + o_to : nullptr; }
     WnlaWs w;
     std::memset(&w, 0, sizeof w);
     w.N = n; w.ng = c->ng; w.nh = c->nh; w.rounds = (int)rounds; w.nl = (int)nl; w.nn = (int)nn;
+    w.base = r.base; w.tio = r.tio; w.divergent_positions = tx && tx->n_states != 1;
     w.commitments = r.wn_commit; w.c = r.wn_c; w.rho = r.wn_rho; w.mu = r.wn_mu;
     w.proof_r = r.proofs + 256; w.proof_x = r.proofs + 256 + 64 * rounds; w.proof_l = r.proofs + 256 + 128 * rounds;
     w.proof_n = w.proof_l + 32 * nl;
@@ -1241,8 +1321,10 @@ int bppp_circuit_verify_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t*
     k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
     k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
+    if (w.tio.states_out) HIP_TRY(hipMemcpyAsync(tx->states_out, d + o_to, n * 203, hipMemcpyDeviceToHost, s));
     if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return BPPP_OK;

@@ -59,6 +59,7 @@ struct CircuitWs {
     uint8_t* wn_mu;                  // N x 32
     FbTable fb;                      // bases: 0 g | 1..NG g_vec||g_vec_ | NG+1.. h_vec||h_vec_
     strobe base;
+    TranscriptIo tio;                // caller's transcripts (circuit.rs:154 `t: &mut Transcript`)
 };
 
 }  // namespace bppp
@@ -220,7 +221,8 @@ HD void circuit_phase1(const CircuitWs& w, size_t t) {
     const uint8_t* pv = w.commitments + (size_t)64 * k * t;
     apt CL, CR, CO, CS;
     bool ok = apt_from_xy64(CL, pp) & apt_from_xy64(CR, pp + 64) & apt_from_xy64(CO, pp + 128) & apt_from_xy64(CS, pp + 192);
-    strobe tr = w.base;
+    strobe tr;
+    tio_begin(tr, status, w.tio, w.base, t);
     // a malformed instance runs on harmless values (identity points); its status forces accept = 0
 #pragma nounroll
     for (int i = 0; i < k; i++) { apt V; ok &= apt_from_xy64(V, pv + 64 * i); }

@@ -13,9 +13,18 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) wnla_verify_begin(w, t);
 }
+// kernels that run transcript operations go through for_each_position_group (kernels.h) when per-instance pre-loaded transcripts
+// may sit at different sponge positions; one trip otherwise
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round(WnlaWs w, int k) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) wnla_verify_round(w, t, k);
+    if (t >= w.N) return;
+    const u32 key = w.divergent_positions ? w.tstate[(size_t)50 * w.N + t] : 0u;
+    for_each_position_group(key, [&]() { wnla_verify_round(w, t, k); });
+}
+// per-instance advanced transcripts back to the caller (any of the generic verifiers: they all end in the WNLA stage)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_generic_export_states(WnlaWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) tio_export(w.tio, w.base, w.tstate, w.N, w.status, t);
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
@@ -91,7 +100,9 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_msm_store(MsmWs w) {
 // ---- generic arithmetic circuit kernels (circuit_core.h)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_phase1(CircuitWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) circuit_phase1(w, t);
+    if (t >= w.N) return;
+    const u32 key = (w.tio.states && w.tio.n_states != 1) ? w.tio.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
+    for_each_position_group(key, [&]() { circuit_phase1(w, t); });
 }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_circuit_c0_fixed(CircuitWs w) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
@@ -115,7 +126,9 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_finish(CircuitWs w) {
 // ---- generic reciprocal range proof kernels (recip_core.h)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1(RecipWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) recip_phase1(w, t);
+    if (t >= w.N) return;
+    const u32 key = (w.tio.states && w.tio.n_states != 1) ? w.tio.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
+    for_each_position_group(key, [&]() { recip_phase1(w, t); });
 }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed(RecipWs w) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;

@@ -102,6 +102,7 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_scalars(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round(bppp::WnlaWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_generic_export_states(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(bppp::WnlaWs w, int commit_mode);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(bppp::WnlaWs w);

@@ -36,6 +36,7 @@ struct RecipWs {
     uint8_t* wn_mu;                  // N x 32
     FbTable fb;                      // bases: 0 g | 1..NG g_vec||g_vec_ | NG+1.. h_vec||h_vec_
     strobe base;
+    TranscriptIo tio;                // caller's transcripts (reciprocal.rs:98 `t: &mut Transcript`)
 };
 
 HD void recip_phase1(const RecipWs& w, size_t t) {
@@ -54,7 +55,8 @@ HD void recip_phase1(const RecipWs& w, size_t t) {
         fe_set_u32(z.x, 0); fe_set_u32(z.y, 0);
         V = z; CL = z; CR = z; CO = z; CS = z; RR = z;
     }
-    strobe tr = w.base;
+    strobe tr;
+    tio_begin(tr, status, w.tio, w.base, t);
     sc e, rho, lambda, beta, delta, tau;
     app_point(tr, "reciprocal_commitment", V);
     bool cok = t_get_challenge(tr, "reciprocal_challenge", e);

@@ -98,6 +98,20 @@ HD void strobe_to_bytes(uint8_t* b, const strobe& s, u32 cur_flags) {
     b[202] = (uint8_t)cur_flags;
 }
 
+// The same pre-loaded transcript plumbing for the generic verifiers (wnla_core.h, recip_core.h, circuit_core.h): where a
+// transcript starts (tio_begin) and how it goes back to the caller (tio_export).
+struct TranscriptIo {
+    const uint8_t* states;   // n_states x 203 or null (= start from the context's Transcript::new(label))
+    size_t n_states;         // 1 or N
+    uint8_t* states_out;     // N x 203 or null
+};
+HD void tio_begin(strobe& tr, int32_t& status, const TranscriptIo& io, const strobe& base, size_t t) {
+    tr = base;
+    if (!io.states) return;
+    strobe pre;
+    if (strobe_from_bytes(pre, io.states + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * (io.n_states == 1 ? 0 : t))) tr = pre;
+    else status |= ST_BAD_ENCODING;
+}
 // ---------------------------------------------------------------- SoA access
 HD void ws_ld8(u32 r[8], const u32* base, size_t N, size_t t, int slot) {
 #pragma unroll
@@ -156,6 +170,25 @@ HD void ws_st_strobe(u32* base, size_t N, size_t t, const strobe& s) {
     base[(size_t)51 * N + t] = s.pos_begin;
 }
 
+// the caller's `&mut Transcript` after a verify: the stored state of instance t (its last operation was a challenge: cur_flags 7);
+// an instance flagged BPPP_ST_BAD_ENCODING gets its input state back
+HD void tio_export(const TranscriptIo& io, const strobe& base, const u32* tstate, size_t N, const int32_t* status, size_t t) {
+    if (!io.states_out) return;
+    uint8_t* out = io.states_out + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * t;
+    if (status[t] & ST_BAD_ENCODING) {
+        if (io.states) {
+            const uint8_t* in = io.states + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * (io.n_states == 1 ? 0 : t);
+#pragma nounroll
+            for (int i = 0; i < BPPP_TRANSCRIPT_STATE_BYTES; i++) out[i] = in[i];
+        } else {
+            strobe_to_bytes(out, base, 2);
+        }
+        return;
+    }
+    strobe tr;
+    ws_ld_strobe(tr, tstate, N, t);
+    strobe_to_bytes(out, tr, 7);
+}
 template <int L>
 HD void app_point(strobe& t, const char (&label)[L], const apt& a) {  // transcript.rs:6-8
     // SEC1 compressed bytes (tag, then x big-endian) packed little-endian into 9 message words, all in registers

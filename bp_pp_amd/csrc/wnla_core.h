@@ -34,6 +34,8 @@ struct WnlaWs {
     pt_slot* straus;       // [N][2][9]
     FbTable fb;
     strobe base;
+    TranscriptIo tio;      // caller's transcripts (wnla.rs:75 `t: &mut Transcript`); the input side is ignored when transcript_preloaded
+    int divergent_positions;   // 1: instances of one wavefront may sit at different sponge positions (per-instance input states)
 };
 HD size_t wnla_ceil_shift(size_t n, int k) { return (n + (((size_t)1 << k) - 1)) >> k; }
 
@@ -92,7 +94,11 @@ HD void wnla_verify_begin(const WnlaWs& w, size_t t) {
     pt P;
     pt_from_affine(P, C);
     ws_st_pt(w.acc, w.N, t, P);
-    if (!w.transcript_preloaded) ws_st_strobe(w.tstate, w.N, t, w.base);
+    if (!w.transcript_preloaded) {
+        strobe tr;
+        tio_begin(tr, status, w.tio, w.base, t);
+        ws_st_strobe(w.tstate, w.N, t, tr);
+    }
     w.status[t] = w.transcript_preloaded ? (w.status[t] | status) : status;
 }
 // ---- verify: round k = 1..rounds (wnla.rs:84-102), X = proof.x[rounds - k], R = proof.r[rounds - k]

@@ -58,6 +58,9 @@ extern "C" {
     pub fn bppp_u64_verify_batch_transcript_device(ctx: *mut BpppCtx, n: usize, d_states: *const c_void, n_states: usize, d_commitments: *const c_void, d_proofs: *const c_void, d_accept: *mut c_void, d_status: *mut c_void, d_reject_count: *mut c_void, d_states_out: *mut c_void) -> c_int;
     pub fn bppp_u64_prove_batch_transcript(ctx: *mut BpppCtx, n: usize, states: *const u8, n_states: usize, x: *const u64, s: *const u8, rnd: *const u8, proofs: *mut u8, commitments: *mut u8, status: *mut i32, states_out: *mut u8) -> c_int;
     pub fn bppp_u64_prove_batch_transcript_device(ctx: *mut BpppCtx, n: usize, d_states: *const c_void, n_states: usize, d_x: *const c_void, d_s: *const c_void, d_rnd: *const c_void, d_proofs: *mut c_void, d_commitments: *mut c_void, d_status: *mut c_void, d_states_out: *mut c_void) -> c_int;
+    pub fn bppp_wnla_verify_batch_transcript(ctx: *mut BpppCtx, n: usize, states: *const u8, n_states: usize, commitments: *const u8, c: *const u8, rho: *const u8, mu: *const u8, rounds: usize, proof_r: *const u8, proof_x: *const u8, proof_l: *const u8, nl: usize, proof_n: *const u8, nn: usize, accept: *mut u8, status: *mut i32, states_out: *mut u8) -> c_int;
+    pub fn bppp_reciprocal_verify_batch_transcript(ctx: *mut BpppCtx, n: usize, states: *const u8, n_states: usize, dim_nd: usize, dim_np: usize, commitments: *const u8, proofs: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32, states_out: *mut u8) -> c_int;
+    pub fn bppp_circuit_verify_batch_transcript(ctx: *mut BpppCtx, circuit: *const BpppCircuit, n: usize, states: *const u8, n_states: usize, commitments: *const u8, proofs: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32, states_out: *mut u8) -> c_int;
     pub fn bppp_transcript_new(label: *const u8, label_len: usize, state_out: *mut u8) -> c_int;
     pub fn bppp_transcript_append_message(state: *mut u8, label: *const u8, label_len: usize, msg: *const u8, msg_len: usize) -> c_int;
     pub fn bppp_transcript_challenge_bytes(state: *mut u8, label: *const u8, label_len: usize, out: *mut u8, n: usize) -> c_int;

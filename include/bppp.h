@@ -285,6 +285,19 @@ BPPP_API int bppp_u64_prove_batch_transcript(bppp_ctx* ctx, size_t n, const uint
 BPPP_API int bppp_u64_prove_batch_transcript_device(bppp_ctx* ctx, size_t n, const void* d_states, size_t n_states, const void* d_x,
                                                     const void* d_s, const void* d_rnd, void* d_proofs, void* d_commitments,
                                                     void* d_status, void* d_states_out);
+/* The generic verifiers with the caller's transcripts -- `t: &mut Transcript` of WeightNormLinearArgument::verify (wnla.rs:75),
+ * ReciprocalRangeProofProtocol::verify (reciprocal.rs:98) and ArithmeticCircuit::verify (circuit.rs:154): states in (1 or n), each
+ * instance's advanced state out (optional); every other argument as in the label forms above. */
+BPPP_API int bppp_wnla_verify_batch_transcript(bppp_ctx* ctx, size_t n, const uint8_t* states, size_t n_states, const uint8_t* commitments,
+                                               const uint8_t* c, const uint8_t* rho, const uint8_t* mu, size_t rounds, const uint8_t* proof_r,
+                                               const uint8_t* proof_x, const uint8_t* proof_l, size_t nl, const uint8_t* proof_n, size_t nn,
+                                               uint8_t* accept, int32_t* status, uint8_t* states_out);
+BPPP_API int bppp_reciprocal_verify_batch_transcript(bppp_ctx* ctx, size_t n, const uint8_t* states, size_t n_states, size_t dim_nd,
+                                                     size_t dim_np, const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl,
+                                                     size_t nn, uint8_t* accept, int32_t* status, uint8_t* states_out);
+BPPP_API int bppp_circuit_verify_batch_transcript(bppp_ctx* ctx, const bppp_circuit* circuit, size_t n, const uint8_t* states,
+                                                  size_t n_states, const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl,
+                                                  size_t nn, uint8_t* accept, int32_t* status, uint8_t* states_out);
 /* merlin::Transcript on serialized states, host only (no GPU needed): Transcript::new(label), append_message(label, msg)
  * (transcript.rs:7 uses it for points, wnla.rs:91-92 for u64s) and challenge_bytes(label, out) (transcript.rs:12).  A Rust caller
  * holding a real merlin::Transcript does not need these; a C caller builds its pre-loaded states with them. */

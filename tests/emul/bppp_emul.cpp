@@ -458,6 +458,13 @@ void emul_sec1_expand(size_t n, const uint8_t* c33, const uint8_t* p525, uint8_t
         for (int j = 0; j < 15; j++) sec1_expand_lane(c64, p928, c33, p525, t, j);
 }
 // generic WNLA commit / verify, every stage in thread order (commit: out_points; verify: accept)
+// Pre-loaded transcripts for the NEXT generic verify call (emul_wnla_run / emul_recip_verify / emul_circuit_verify): states in
+// (n_states = 1 or n), per-instance advanced states out; consumed by that call.
+static TranscriptIo g_tio = {nullptr, 0, nullptr};
+void emul_set_transcripts(const uint8_t* states, size_t n_states, uint8_t* states_out) {
+    g_tio.states = states; g_tio.n_states = n_states; g_tio.states_out = states_out;
+}
+static TranscriptIo take_tio() { TranscriptIo t = g_tio; g_tio.states = nullptr; g_tio.n_states = 0; g_tio.states_out = nullptr; return t; }
 int emul_wnla_run(int commit, const uint8_t* table, int W, int ng, int nh, const uint8_t* label, size_t label_len, size_t n,
                   const uint8_t* commitments, const uint8_t* c, const uint8_t* rho, const uint8_t* mu, int rounds, const uint8_t* proof_r,
                   const uint8_t* proof_x, const uint8_t* proof_l, int nl, const uint8_t* proof_n, int nn, uint8_t* out_points,
@@ -489,12 +496,14 @@ int emul_wnla_run(int commit, const uint8_t* table, int W, int ng, int nh, const
         for (size_t t = 0; t < n; t++) { pt total; ws_ld_pt(total, w.pfix, n, t); wnla_commit_store(w, t, total); }
     } else {
         t_new(w.base, label, (u32)label_len);
+        w.tio = take_tio();
         for (size_t t = 0; t < n; t++) wnla_verify_begin(w, t);
         for (int k = 1; k <= rounds; k++)
             for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, k);
         for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);
         msm();
         for (size_t t = 0; t < n; t++) wnla_verify_accept(w, t);
+        for (size_t t = 0; t < n; t++) tio_export(w.tio, w.base, w.tstate, n, w.status, t);
     }
     return 0;
 }
@@ -514,9 +523,11 @@ int emul_recip_verify(const uint8_t* table, int W, int NG, int NH, int nd, int n
     r.straus = straus.data(); r.wn_commit = wc.data(); r.wn_c = wcv.data(); r.wn_rho = wrho.data(); r.wn_mu = wmu.data();
     r.fb.table = (const apt_packed*)table; r.fb.W = W; r.fb.N = n;
     t_new(r.base, label, (u32)label_len);
+    r.tio = take_tio();
     WnlaWs w;
     memset(&w, 0, sizeof w);
     w.N = n; w.ng = NG; w.nh = NH; w.rounds = rounds; w.nl = nl; w.nn = nn;
+    w.base = r.base; w.tio = r.tio;
     w.commitments = r.wn_commit; w.c = r.wn_c; w.rho = r.wn_rho; w.mu = r.wn_mu;
     w.proof_r = proofs + 256; w.proof_x = proofs + 256 + 64 * (size_t)rounds; w.proof_l = proofs + 320 + 128 * (size_t)rounds;
     w.proof_n = w.proof_l + 32 * (size_t)nl;
@@ -546,6 +557,7 @@ int emul_recip_verify(const uint8_t* table, int W, int NG, int NH, int nd, int n
         wnla_verify_store(w, t, a);
     }
     for (size_t t = 0; t < n; t++) wnla_verify_accept(w, t);
+    for (size_t t = 0; t < n; t++) tio_export(w.tio, w.base, w.tstate, n, w.status, t);
     return 0;
 }
 // generic ArithmeticCircuit::verify (circuit_core.h) + the WNLA stage, every phase in thread order

@@ -94,3 +94,51 @@ def test_prover_over_preloaded_transcripts_on_the_gpu():
         assert (p2 == p3).all() and (c2 == c3).all() and not st2.any()
     finally:
         proto.close()
+
+
+def test_generic_verifiers_over_preloaded_transcripts_on_the_gpu():
+    """bppp_wnla_verify_batch_transcript and bppp_reciprocal_verify_batch_transcript (instances at different sponge positions in one
+    wavefront), against the Python oracle's verdicts and advanced states."""
+    import ctypes as C
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import generic_transcript_cases as GC
+    import ref_fixture_check as RC
+    import workload
+    from bp_pp_amd import _capi
+    from bp_pp_amd.wnla import ReciprocalRangeProofProtocol, WeightNormLinearArgument
+    L = _capi.lib()
+    case = GC.wnla_case()
+    w = WeightNormLinearArgument(case["g"], case["gv"], case["hv"], device=0, fb_window_bits=8)
+    try:
+        B = case["commitments"].shape[0]
+        acc, st, out = np.zeros(B, np.uint8), np.zeros(B, np.int32), np.zeros((B, 203), np.uint8)
+        _capi.check(L.bppp_wnla_verify_batch_transcript(w._ctx, B, case["states_in"].ctypes.data, B, case["commitments"].ctypes.data,
+                                                        case["c"].ctypes.data, case["rho"].ctypes.data, case["mu"].ctypes.data, case["rounds"],
+                                                        case["proof_r"].ctypes.data, case["proof_x"].ctypes.data, case["proof_l"].ctypes.data,
+                                                        case["nl"], case["proof_n"].ctypes.data, case["nn"], acc.ctypes.data, st.ctypes.data,
+                                                        out.ctypes.data))
+        assert acc.tolist() == [1] * B and not st.any() and (out == case["states_after"]).all()
+        # the same proofs against the wrong transcripts (instance 0's state for everybody) fail for all but instance 0
+        _capi.check(L.bppp_wnla_verify_batch_transcript(w._ctx, B, case["states_in"].ctypes.data, 1, case["commitments"].ctypes.data,
+                                                        case["c"].ctypes.data, case["rho"].ctypes.data, case["mu"].ctypes.data, case["rounds"],
+                                                        case["proof_r"].ctypes.data, case["proof_x"].ctypes.data, case["proof_l"].ctypes.data,
+                                                        case["nl"], case["proof_n"].ctypes.data, case["nn"], acc.ctypes.data, st.ctypes.data, None))
+        assert acc.tolist() == [1] + [0] * (B - 1)
+    finally:
+        w.close()
+    doc = RC.oracle_made_document(4)
+    cs = doc["cases"]
+    n = len(cs)
+    g, gv, hv = workload.split_generators(bytes.fromhex(doc["generators"]))
+    r = ReciprocalRangeProofProtocol(16, 16, g, gv, hv[:26], [], hv[26:], device=0, fb_window_bits=8)
+    try:
+        u8 = lambda key, wd: np.frombuffer(b"".join(bytes.fromhex(c[key]) for c in cs), dtype=np.uint8).reshape(n, wd).copy()
+        V, P, S = u8("commitment", 64), u8("proof", 928), u8("state_before", 203)
+        acc, st, out = np.zeros(n, np.uint8), np.zeros(n, np.int32), np.zeros((n, 203), np.uint8)
+        _capi.check(L.bppp_reciprocal_verify_batch_transcript(r._w._ctx, n, S.ctypes.data, n, 16, 16, V.ctypes.data, P.ctypes.data, 4, 2, 1,
+                                                              acc.ctypes.data, st.ctypes.data, out.ctypes.data))
+        assert acc.tolist() == [1] * n and not st.any() and (out == u8("state_after_verify", 203)).all()
+    finally:
+        r.close()

@@ -97,3 +97,38 @@ def test_prover_over_preloaded_transcripts_through_the_device_code():
                                              proofs.ctypes.data, V.ctypes.data, st.ctypes.data, out.ctypes.data) == 0
     assert not st.any() and (proofs == u8("proof", 928)).all() and (V == u8("commitment", 64)).all()
     assert (out == u8("state_after_prove", 203)).all()
+
+
+def test_generic_verifiers_over_preloaded_transcripts_through_the_device_code():
+    """`t: &mut Transcript` of WeightNormLinearArgument::verify (wnla.rs:75) and ReciprocalRangeProofProtocol::verify
+    (reciprocal.rs:98) in the generic device code: accept bits and advanced states equal the Python oracle's."""
+    import generic_transcript_cases as GC
+    import ref_fixture_check as RC
+    L = load()
+    W = 4
+    # ---- wnla
+    case = GC.wnla_case()
+    gens = case["g"] + b"".join(case["gv"]) + b"".join(case["hv"])
+    NB = 1 + case["ng"] + case["nh"]
+    tab = np.zeros(L.emul_fb_table_entries(NB, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, NB, W, tab.ctypes.data) == 0
+    B = case["commitments"].shape[0]
+    acc, st, out = np.zeros(B, np.uint8), np.zeros(B, np.int32), np.zeros((B, 203), np.uint8)
+    L.emul_set_transcripts(case["states_in"].ctypes.data, B, out.ctypes.data)
+    L.emul_wnla_run(0, tab.ctypes.data, W, case["ng"], case["nh"], b"", 0, B, case["commitments"].ctypes.data, case["c"].ctypes.data,
+                    case["rho"].ctypes.data, case["mu"].ctypes.data, case["rounds"], case["proof_r"].ctypes.data, case["proof_x"].ctypes.data,
+                    case["proof_l"].ctypes.data, case["nl"], case["proof_n"].ctypes.data, case["nn"], None, acc.ctypes.data, st.ctypes.data)
+    assert acc.tolist() == [1] * B and not st.any() and (out == case["states_after"]).all()
+    # ---- reciprocal at the u64 dimensions, on the u64 proofs of the oracle-made document (two of them carry context)
+    doc = RC.oracle_made_document(4)
+    cs = doc["cases"]
+    gens = bytes.fromhex(doc["generators"])
+    tab = np.zeros(L.emul_fb_table_entries(49, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0
+    n = len(cs)
+    u8 = lambda key, w: np.frombuffer(b"".join(bytes.fromhex(c[key]) for c in cs), dtype=np.uint8).reshape(n, w).copy()
+    V, P, S = u8("commitment", 64), u8("proof", 928), u8("state_before", 203)
+    acc, st, out = np.zeros(n, np.uint8), np.zeros(n, np.int32), np.zeros((n, 203), np.uint8)
+    L.emul_set_transcripts(S.ctypes.data, n, out.ctypes.data)
+    L.emul_recip_verify(tab.ctypes.data, W, 16, 32, 16, 16, b"", 0, n, V.ctypes.data, P.ctypes.data, 4, 2, 1, acc.ctypes.data, st.ctypes.data)
+    assert acc.tolist() == [1] * n and not st.any() and (out == u8("state_after_verify", 203)).all()
