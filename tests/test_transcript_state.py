@@ -132,3 +132,28 @@ def test_generic_verifiers_over_preloaded_transcripts_through_the_device_code():
     L.emul_set_transcripts(S.ctypes.data, n, out.ctypes.data)
     L.emul_recip_verify(tab.ctypes.data, W, 16, 32, 16, 16, b"", 0, n, V.ctypes.data, P.ctypes.data, 4, 2, 1, acc.ctypes.data, st.ctypes.data)
     assert acc.tolist() == [1] * n and not st.any() and (out == u8("state_after_verify", 203)).all()
+
+
+def test_committed_round2_golden_vectors(oracle_c):
+    """tests/golden/r02_golden.json (made by make_golden_r02.py): the host transcript operations replay the scripted states byte
+    for byte, the oracle reproduces the document (proofs over pre-loaded transcripts, states before / after), and the generator
+    derivation reproduces the committed points."""
+    import json
+    import ref_fixture_check as RC
+    from bp_pp_amd import derive_generators
+    with open(os.path.join(os.path.dirname(__file__), "golden", "r02_golden.json")) as f:
+        doc = json.load(f)
+    ts = doc["transcript_script"]
+    t = Transcript(bytes.fromhex(ts["label"]))
+    assert t.state.hex() == ts["states"][0]
+    for op, st in zip(ts["ops"], ts["states"][1:]):
+        if op["op"] == "append_message":
+            t.append_message(bytes.fromhex(op["label"]), bytes.fromhex(op["message"]))
+        elif op["op"] == "append_u64":
+            t.append_u64(bytes.fromhex(op["label"]), int(op["value"]))
+        else:
+            assert t.challenge_bytes(bytes.fromhex(op["label"]), op["n"]).hex() == op["output"]
+        assert t.state.hex() == st
+    assert RC.check_document(doc, oracle_c) == len(doc["cases"])
+    dg = doc["derived_generators"]
+    assert derive_generators(bytes.fromhex(dg["seed"]), 5, dg["first_index"]).hex() == dg["points"]
