@@ -63,6 +63,9 @@ struct bppp_ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;   // runs the fixed-base half of C0 concurrently with the variable-base half
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t copy_stream = nullptr;  // host-buffer entry points: uploads chunk k + 1 while chunk k is being verified (created on first use)
+    hipEvent_t ev_copy = nullptr;
+    size_t host_chunk = (size_t)1 << 17;   // proofs per pipelined chunk (one full grid at 2 waves/SIMD); 0 = upload the whole batch first
     apt* d_gens = nullptr;       // 49
     apt_packed* d_table = nullptr;
     size_t table_bytes = 0;
@@ -395,6 +398,8 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->d_expand) (void)hipFree(c->d_expand);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -414,6 +419,11 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
     if (std::strcmp(name, "rlc_superchunk") == 0) {
         if (value != 0 && (value < 64 || value > BPPP_BKT_MAX_M || (value & 7))) return BPPP_ERR_INVALID_ARG;
         c->rlc_super_m = (unsigned)value;
+        return BPPP_OK;
+    }
+    if (std::strcmp(name, "host_chunk") == 0) {
+        if (value != 0 && (value < 1024 || (value & 63))) return BPPP_ERR_INVALID_ARG;
+        c->host_chunk = (size_t)value;
         return BPPP_OK;
     }
     return BPPP_ERR_INVALID_ARG;
@@ -689,10 +699,36 @@ static int verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
     }
     uint8_t *d_c = c->d_io + o_c, *d_p = c->d_io + o_p, *d_a = c->d_io + o_a;
     int32_t* d_s = (int32_t*)(c->d_io + o_s);
-    HIP_TRY(hipMemcpyAsync(d_c, commitments, n * 64, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_p, proofs, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, c->stream));
-    int rc = verify_device_impl(c, label, label_len, n, d_c, d_p, d_a, d_s, nullptr, nullptr, rlc_seed);
-    if (rc != BPPP_OK) return rc;
+    const size_t CH = c->host_chunk;
+    if (CH == 0 || n <= CH + CH / 2) {
+        HIP_TRY(hipMemcpyAsync(d_c, commitments, n * 64, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_p, proofs, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, c->stream));
+        int rc = verify_device_impl(c, label, label_len, n, d_c, d_p, d_a, d_s, nullptr, nullptr, rlc_seed);
+        if (rc != BPPP_OK) return rc;
+    } else {
+        // Large batch: proofs are independent, so the batch is verified chunk by chunk while the next chunk crosses PCIe on a second
+        // stream (from pageable memory the runtime stages the copy and this thread blocks in it; the GPU keeps verifying meanwhile).
+        // A chunk is one full grid of the lane kernels, so the kernels run exactly as they do for a resident batch.
+        if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        if (!c->ev_copy) HIP_TRY(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+        // the staging buffer may still be read by kernels of an earlier call on c->stream only if that call returned early on an
+        // error; order the first upload after whatever is queued there
+        HIP_TRY(hipEventRecord(c->ev_copy, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
+        for (size_t lo = 0; lo < n; lo += CH) {
+            size_t m = n - lo;
+            if (m > CH + CH / 2) m = CH;          // the tail joins the last chunk rather than running as a sliver
+            HIP_TRY(hipMemcpyAsync(d_c + lo * 64, commitments + lo * 64, m * 64, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(hipMemcpyAsync(d_p + lo * (size_t)BPPP_U64_PROOF_BYTES, proofs + lo * (size_t)BPPP_U64_PROOF_BYTES,
+                                   m * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(hipEventRecord(c->ev_copy, c->copy_stream));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+            int rc = verify_device_impl(c, label, label_len, m, d_c + lo * 64, d_p + lo * (size_t)BPPP_U64_PROOF_BYTES, d_a + lo, d_s + lo,
+                                        nullptr, nullptr, rlc_seed);
+            if (rc != BPPP_OK) return rc;
+            if (m != CH) break;
+        }
+    }
     HIP_TRY(hipMemcpyAsync(accept, d_a, n, hipMemcpyDeviceToHost, c->stream));
     if (status) HIP_TRY(hipMemcpyAsync(status, d_s, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -236,7 +236,8 @@ class U64RangeProofProtocol:
         _capi.check(_capi.lib().bppp_ctx_set_stream(self._ctx, hip_stream))
 
     def set_option(self, name: str, value: int) -> None:
-        """include/bppp.h: bppp_ctx_set_option (e.g. "rlc_superchunk": 0 = bucket stage off, else 64..8192)."""
+        """include/bppp.h: bppp_ctx_set_option ("rlc_superchunk": 0 = bucket stage off, else 64..8192; "host_chunk": proofs per
+        pipelined upload chunk of the host-buffer verify calls, 0 = upload first)."""
         _capi.check(_capi.lib().bppp_ctx_set_option(self._ctx, name.encode(), int(value)))
 
     def synchronize(self) -> None:

@@ -77,7 +77,10 @@ BPPP_API void bppp_ctx_destroy(bppp_ctx* ctx);
  * *_device entry points -- e.g. the RCCL all-reduce of reject_count -- passes the stream that work runs on. */
 BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
 /* Tunables.  "rlc_superchunk": proofs per superchunk of the bucket (Pippenger) stage of the RLC mode below -- 0 switches the stage
- * off (chunks of 8 only), otherwise a multiple of 8 in [64, 8192]; default 4096. */
+ * off (chunks of 8 only), otherwise a multiple of 8 in [64, 8192]; default 4096.  "host_chunk": the host-buffer verify entry points
+ * (bppp_u64_verify_batch, bppp_u64_verify_batch_rlc) cut a batch of more than 1.5 x host_chunk proofs into chunks of host_chunk proofs and upload
+ * chunk k + 1 on a second stream while chunk k is being verified (proofs are independent: the results are those of one call) --
+ * a multiple of 64, >= 1024; default 131072 (one full grid of the per-proof kernels); 0 = upload the whole batch first. */
 BPPP_API int bppp_ctx_set_option(bppp_ctx* ctx, const char* name, long value);
 /* Block the calling host thread until everything queued by this context (current stream + its helper stream) has finished. */
 BPPP_API int bppp_ctx_synchronize(bppp_ctx* ctx);

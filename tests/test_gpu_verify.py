@@ -196,3 +196,33 @@ def test_random_byte_corruptions_vs_oracle(torch_mod, proto, oracle_c):
         n_flag += rc < 0
     assert rej == int((acc == 0).sum()) and n_flag > 50 and acc[64::16].all()
     assert st[16] != 0 and st[32] != 0 and st[48] == 0 and acc[48] == 0
+
+
+@pytest.mark.parametrize("n,chunk", [(5000, 1024), (1537, 1024), (3072, 1024), (4097, 2048)])
+def test_host_buffer_path_pipelined_in_chunks(torch_mod, proto, oracle_c, n, chunk):
+    """bppp_u64_verify_batch over host buffers uploads a large batch chunk by chunk while the previous chunk is verified
+    (include/bppp.h, "host_chunk").  With a small chunk size so that a test batch spans several chunks -- tail merged into the
+    last chunk, exact multiples, one proof over -- the results are those of the unchunked call and of the oracle, in exact and
+    in RLC mode, including flagged (bad-encoding) proofs that sit on chunk boundaries."""
+    import workload
+    gens, V, P, _ = workload.make_batch(n, first=77)
+    P, expect = workload.corrupt(P, V, every=13)
+    st_expect = np.zeros(n, np.int32)
+    for j in (chunk - 1, chunk, n - 1):
+        P[j, 0:32] = 0xFF                                   # x coordinate >= p: k256 would refuse to deserialize it
+        expect[j], st_expect[j] = 0, 1
+    try:
+        proto.set_option("host_chunk", 0)
+        acc0, st0 = proto.verify_batch(V, P, workload.LABEL)
+        proto.set_option("host_chunk", chunk)
+        acc1, st1 = proto.verify_batch(V, P, workload.LABEL)
+        acc2, st2 = proto.verify_batch_rlc(V, P, workload.LABEL, seed=bytes(range(32)))
+    finally:
+        proto.set_option("host_chunk", 1 << 17)
+    assert (acc0 == expect).all() and (st0 == st_expect).all()
+    assert (acc1 == acc0).all() and (st1 == st0).all() and (acc2 == acc0).all() and (st2 == st0).all()
+    idx = np.unique(np.concatenate([np.arange(0, n, 41), [chunk - 1, chunk, chunk + 1, n - 1]]))
+    oacc, ost = oracle_c.u64_verify_batch(gens, workload.LABEL, V[idx].copy(), P[idx].copy(), nthreads=os.cpu_count() or 1)
+    assert (oacc == acc1[idx]).all() and ((ost != 0) == (st1[idx] != 0)).all()   # the oracle's own code for a bad encoding is -1
+    with pytest.raises(Exception):
+        proto.set_option("host_chunk", 1000)                # not a multiple of 64
