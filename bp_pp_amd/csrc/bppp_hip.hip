@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -56,6 +57,7 @@ static size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
 struct bppp_ctx {
+    std::recursive_mutex mu;   // every exported call on a context holds it: overlapping calls from several host threads are serialized
     int device = 0;
     int fb_w = 16;
     int ng = 16, nh = 32, nbases = BPPP_NG;   // generator set: g, g_vec[ng], h_vec[nh]
@@ -65,6 +67,7 @@ struct bppp_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t copy_stream = nullptr;  // host-buffer entry points: uploads chunk k + 1 while chunk k is being verified (created on first use)
     hipEvent_t ev_copy = nullptr;
+    size_t max_batch = (size_t)1 << 21;    // proofs verified per internal part of one call: bounds the workspace (~63 GB at 2^21)
     size_t host_chunk = (size_t)1 << 17;   // proofs per pipelined chunk (one full grid at 2 waves/SIMD); 0 = upload the whole batch first
     apt* d_gens = nullptr;       // 49
     apt_packed* d_table = nullptr;
@@ -113,6 +116,14 @@ struct bppp_ctx {
     std::vector<hipEvent_t> event_pool;
     double total_ms[K_COUNT] = {0};
     int64_t launches[K_COUNT] = {0};
+};
+
+struct CtxLock {
+    bppp_ctx* c;
+    explicit CtxLock(bppp_ctx* ctx) : c(ctx) { if (c) c->mu.lock(); }
+    ~CtxLock() { if (c) c->mu.unlock(); }
+    CtxLock(const CtxLock&) = delete;
+    CtxLock& operator=(const CtxLock&) = delete;
 };
 
 static const size_t WS_WORDS_PER_PROOF = 52 + 80 + 176 + 200 + 208 + 24 + 30 + 30 + 392;
@@ -407,6 +418,7 @@ void bppp_ctx_destroy(bppp_ctx* c) {
 }
 
 int bppp_ctx_set_stream(bppp_ctx* c, void* hip_stream) {
+    CtxLock lock_(c);
     if (!c) return BPPP_ERR_INVALID_ARG;
     int rc = drain_timings(c);
     if (rc != BPPP_OK) return rc;
@@ -415,10 +427,16 @@ int bppp_ctx_set_stream(bppp_ctx* c, void* hip_stream) {
 }
 
 int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
+    CtxLock lock_(c);
     if (!c || !name) return BPPP_ERR_INVALID_ARG;
     if (std::strcmp(name, "rlc_superchunk") == 0) {
         if (value != 0 && (value < 64 || value > BPPP_BKT_MAX_M || (value & 7))) return BPPP_ERR_INVALID_ARG;
         c->rlc_super_m = (unsigned)value;
+        return BPPP_OK;
+    }
+    if (std::strcmp(name, "max_batch") == 0) {
+        if (value < 1024 || (value & 63)) return BPPP_ERR_INVALID_ARG;
+        c->max_batch = (size_t)value;
         return BPPP_OK;
     }
     if (std::strcmp(name, "host_chunk") == 0) {
@@ -429,6 +447,7 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
     return BPPP_ERR_INVALID_ARG;
 }
 int bppp_ctx_synchronize(bppp_ctx* c) {
+    CtxLock lock_(c);
     if (!c) return BPPP_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -442,12 +461,14 @@ size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
 }
 
 int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
+    CtxLock lock_(c);
     if (!c) return BPPP_ERR_INVALID_ARG;
     int rc = drain_timings(c);
     c->timing = enable != 0;
     return rc;
 }
 int bppp_ctx_get_timings(bppp_ctx* c, int max_entries, const char** names, double* total_ms, int64_t* launches, int reset) {
+    CtxLock lock_(c);
     if (!c) return BPPP_ERR_INVALID_ARG;
     (void)hipSetDevice(c->device);
     int rc = drain_timings(c);
@@ -465,9 +486,40 @@ int bppp_ctx_get_timings(bppp_ctx* c, int max_entries, const char** names, doubl
 
 // optional pre-loaded transcripts of a verify call (device pointers): see VerifyWs::states
 struct VerifyTranscripts { const void* d_states; size_t n_states; void* d_states_out; };
+static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
+                              const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count,
+                              const uint8_t* rlc_seed, const VerifyTranscripts* tx, bool reset_reject_count);
+// One call = one batch for the caller; internally a batch larger than max_batch proofs runs as consecutive parts on the same
+// stream, so the per-proof workspace (~30 KB per proof) is bounded by max_batch whatever n is.  Proofs are independent, the reject
+// counter accumulates across parts, and every per-proof array is simply offset.
 static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
                               const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count,
                               const uint8_t* rlc_seed, const VerifyTranscripts* tx = nullptr) {
+    if (!c) return BPPP_ERR_INVALID_ARG;
+    const size_t cap = c->max_batch;
+    if (n <= cap || !d_commitments || !d_proofs || !d_accept)
+        return verify_device_part(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, d_trace, d_reject_count, rlc_seed, tx, true);
+    if (tx && tx->d_states && tx->n_states != 1 && tx->n_states != n) return BPPP_ERR_INVALID_ARG;
+    const size_t SB = BPPP_TRANSCRIPT_STATE_BYTES;
+    for (size_t lo = 0; lo < n; lo += cap) {
+        const size_t m = n - lo < cap ? n - lo : cap;
+        VerifyTranscripts part;
+        if (tx) {
+            part.d_states = tx->d_states && tx->n_states != 1 ? (const uint8_t*)tx->d_states + lo * SB : tx->d_states;
+            part.n_states = tx->n_states == 1 ? 1 : m;
+            part.d_states_out = tx->d_states_out ? (uint8_t*)tx->d_states_out + lo * SB : nullptr;
+        }
+        int rc = verify_device_part(c, label, label_len, m, (const uint8_t*)d_commitments + lo * 64,
+                                    (const uint8_t*)d_proofs + lo * (size_t)BPPP_U64_PROOF_BYTES, (uint8_t*)d_accept + lo,
+                                    d_status ? (int32_t*)d_status + lo : nullptr, d_trace ? (uint8_t*)d_trace + lo * (size_t)BPPP_U64_TRACE_BYTES : nullptr,
+                                    d_reject_count, rlc_seed, tx ? &part : nullptr, lo == 0);
+        if (rc != BPPP_OK) return rc;
+    }
+    return BPPP_OK;
+}
+static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
+                              const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count,
+                              const uint8_t* rlc_seed, const VerifyTranscripts* tx, bool reset_reject_count) {
     if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept) return BPPP_ERR_INVALID_ARG;
     if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;   // u64 entry points need the u64 generator shape
     if (n == 0) return BPPP_OK;
@@ -518,7 +570,7 @@ static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_le
         ws.n_states = tx->n_states;
         ws.states_out = (uint8_t*)tx->d_states_out;
     }
-    if (d_reject_count) HIP_TRY(hipMemsetAsync(d_reject_count, 0, sizeof(int), c->stream));
+    if (d_reject_count && reset_reject_count) HIP_TRY(hipMemsetAsync(d_reject_count, 0, sizeof(int), c->stream));
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     hipStream_t s = c->stream;
 #define LAUNCH_ON(st, id, ...)                                  \
@@ -608,12 +660,14 @@ static int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_le
 }
 int bppp_u64_verify_batch_transcript_device(bppp_ctx* c, size_t n, const void* d_states, size_t n_states, const void* d_commitments,
                                             const void* d_proofs, void* d_accept, void* d_status, void* d_reject_count, void* d_states_out) {
+    CtxLock lock_(c);
     if (!d_states) return BPPP_ERR_INVALID_ARG;
     VerifyTranscripts tx = {d_states, n_states, d_states_out};
     return verify_device_impl(c, nullptr, 0, n, d_commitments, d_proofs, d_accept, d_status, nullptr, d_reject_count, nullptr, &tx);
 }
 int bppp_u64_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, const uint8_t* commitments,
                                      const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
     if (!c || !states || !commitments || !proofs || !accept || (n_states != 1 && n_states != n)) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     for (size_t i = 0; i < n_states; i++)
@@ -676,10 +730,12 @@ int bppp_transcript_challenge_bytes(uint8_t state[203], const uint8_t* label, si
 }
 int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
                                  const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count) {
+    CtxLock lock_(c);
     return verify_device_impl(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, d_trace, d_reject_count, nullptr);
 }
 int bppp_u64_verify_batch_rlc_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
                                      const void* d_proofs, void* d_accept, void* d_status, void* d_reject_count, const uint8_t seed[32]) {
+    CtxLock lock_(c);
     if (!seed) return BPPP_ERR_INVALID_ARG;
     return verify_device_impl(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, nullptr, d_reject_count, seed);
 }
@@ -736,15 +792,18 @@ static int verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
 }
 int bppp_u64_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
                           const uint8_t* proofs, uint8_t* accept, int32_t* status) {
+    CtxLock lock_(c);
     return verify_host_impl(c, label, label_len, n, commitments, proofs, accept, status, nullptr);
 }
 int bppp_u64_verify_batch_rlc(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
                               const uint8_t* proofs, uint8_t* accept, int32_t* status, const uint8_t seed[32]) {
+    CtxLock lock_(c);
     if (!seed) return BPPP_ERR_INVALID_ARG;
     return verify_host_impl(c, label, label_len, n, commitments, proofs, accept, status, seed);
 }
 
 int bppp_u64_commit_value_batch(bppp_ctx* c, size_t n, const uint64_t* x, const uint8_t* s, uint8_t* out) {
+    CtxLock lock_(c);
     if (!c || !x || !s || !out) return BPPP_ERR_INVALID_ARG;
     if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
@@ -777,10 +836,12 @@ static int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len
                              const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status, const VerifyTranscripts* tx);
 int bppp_u64_prove_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
                                 const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status) {
+    CtxLock lock_(c);
     return prove_device_impl(c, label, label_len, n, d_x, d_s, d_rnd, d_proofs, d_commitments, d_status, nullptr);
 }
 int bppp_u64_prove_batch_transcript_device(bppp_ctx* c, size_t n, const void* d_states, size_t n_states, const void* d_x, const void* d_s,
                                            const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status, void* d_states_out) {
+    CtxLock lock_(c);
     if (!d_states || (n_states != 1 && n_states != n)) return BPPP_ERR_INVALID_ARG;
     VerifyTranscripts tx = {d_states, n_states, d_states_out};
     return prove_device_impl(c, nullptr, 0, n, d_x, d_s, d_rnd, d_proofs, d_commitments, d_status, &tx);
@@ -844,6 +905,7 @@ static int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len
 // U64RangeProofProtocol::prove with the caller's transcripts (u64_proof.rs:57: `t: &mut Transcript`), host buffers
 int bppp_u64_prove_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, const uint64_t* x, const uint8_t* s,
                                     const uint8_t* rnd, uint8_t* proofs, uint8_t* commitments, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
     if (!c || !states || !x || !s || !rnd || !proofs || !commitments || (n_states != 1 && n_states != n)) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     for (size_t i = 0; i < n_states; i++)
@@ -879,6 +941,7 @@ int bppp_u64_prove_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states
 
 int bppp_u64_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x, const uint8_t* s,
                          const uint8_t* rnd, uint8_t* proofs, uint8_t* commitments, int32_t* status) {
+    CtxLock lock_(c);
     if (!c || !x || !s || !rnd || !proofs || !commitments) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -906,6 +969,7 @@ int bppp_u64_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, si
 
 int bppp_u64_verify_batch_sec1_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments33,
                                       const void* d_proofs525, void* d_accept, void* d_status, void* d_trace, void* d_reject_count) {
+    CtxLock lock_(c);
     if (!c || !d_commitments33 || !d_proofs525 || !d_accept) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -925,6 +989,7 @@ int bppp_u64_verify_batch_sec1_device(bppp_ctx* c, const uint8_t* label, size_t 
 
 int bppp_u64_verify_batch_sec1(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments33,
                                const uint8_t* proofs525, uint8_t* accept, int32_t* status) {
+    CtxLock lock_(c);
     if (!c || !commitments33 || !proofs525 || !accept) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -1039,6 +1104,7 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
 
 int bppp_wnla_commit_batch(bppp_ctx* c, size_t n, const uint8_t* cvec, const uint8_t* mu, const uint8_t* l, size_t nl,
                            const uint8_t* nvec, size_t nn, uint8_t* out, int32_t* status) {
+    CtxLock lock_(c);
     if (!c || !cvec || !mu || (!l && nl) || (!nvec && nn) || !out) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     return wnla_run(c, true, nullptr, 0, n, nullptr, cvec, nullptr, mu, 0, nullptr, nullptr, l, nl, nvec, nn, out, nullptr, status);
@@ -1048,6 +1114,7 @@ int bppp_wnla_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, 
                            const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, size_t rounds, const uint8_t* proof_r,
                            const uint8_t* proof_x, const uint8_t* proof_l, size_t nl, const uint8_t* proof_n, size_t nn,
                            uint8_t* accept, int32_t* status) {
+    CtxLock lock_(c);
     if (!c || (!label && label_len) || !commitments || !cvec || !rho || !mu || (rounds && (!proof_r || !proof_x)) || (!proof_l && nl) ||
         (!proof_n && nn) || !accept)
         return BPPP_ERR_INVALID_ARG;
@@ -1060,6 +1127,7 @@ int bppp_wnla_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* stat
                                       const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, size_t rounds, const uint8_t* proof_r,
                                       const uint8_t* proof_x, const uint8_t* proof_l, size_t nl, const uint8_t* proof_n, size_t nn,
                                       uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
     if (!c || !states || !commitments || !cvec || !rho || !mu || (rounds && (!proof_r || !proof_x)) || (!proof_l && nl) || (!proof_n && nn) ||
         !accept)
         return BPPP_ERR_INVALID_ARG;
@@ -1150,6 +1218,7 @@ static int recip_verify_check_args(const bppp_ctx* c, size_t dim_nd, size_t dim_
 int bppp_reciprocal_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                         const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn,
                                         void* d_accept, void* d_status) {
+    CtxLock lock_(c);
     if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept || !d_status) return BPPP_ERR_INVALID_ARG;
     int rc = recip_verify_check_args(c, dim_nd, dim_np, rounds, nl, nn);
     if (rc != BPPP_OK) return rc;
@@ -1173,11 +1242,13 @@ static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t labe
 int bppp_reciprocal_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                  const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
                                  int32_t* status) {
+    CtxLock lock_(c);
     return recip_verify_host_impl(c, label, label_len, n, dim_nd, dim_np, commitments, proofs, rounds, nl, nn, accept, status, nullptr);
 }
 int bppp_reciprocal_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, size_t dim_nd, size_t dim_np,
                                             const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn,
                                             uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
     if (!states) return BPPP_ERR_INVALID_ARG;
     HostTranscripts tx = {states, n_states, states_out};
     return recip_verify_host_impl(c, nullptr, 0, n, dim_nd, dim_np, commitments, proofs, rounds, nl, nn, accept, status, &tx);
@@ -1229,6 +1300,7 @@ struct bppp_circuit {
 int bppp_circuit_create(bppp_ctx* c, bppp_circuit** out, const size_t dims[6], int f_l, int f_m, const uint8_t* W_m, const uint8_t* W_l,
                         const uint8_t* a_m, const uint8_t* a_l, const int32_t* part_lo, const int32_t* part_ll, const int32_t* part_lr,
                         const int32_t* part_no) {
+    CtxLock lock_(c);
     if (!c || !out || !dims || !W_m || !W_l || !a_m || !a_l || !part_lo || !part_ll || !part_lr || !part_no) return BPPP_ERR_INVALID_ARG;
     const size_t nm = dims[0], no = dims[1], k = dims[2], nl = dims[3], nv = dims[4], nw = dims[5];
     // the reference's own definitions (circuit.rs:100-106) and what the context's generators can serve
@@ -1284,11 +1356,13 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
                                     int32_t* status, const HostTranscripts* tx);
 int bppp_circuit_verify_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
                               const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept, int32_t* status) {
+    CtxLock lock_(c);
     return circuit_verify_host_impl(c, q, label, label_len, n, commitments, proofs, rounds, nl, nn, accept, status, nullptr);
 }
 int bppp_circuit_verify_batch_transcript(bppp_ctx* c, const bppp_circuit* q, size_t n, const uint8_t* states, size_t n_states,
                                          const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn,
                                          uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
     if (!states) return BPPP_ERR_INVALID_ARG;
     HostTranscripts tx = {states, n_states, states_out};
     return circuit_verify_host_impl(c, q, nullptr, 0, n, commitments, proofs, rounds, nl, nn, accept, status, &tx);
@@ -1369,6 +1443,7 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
 // sum_j scalars[i][j] * generator[base_index[j]] for n independent rows, through the context's fixed-base tables: the crate's
 // commit functions (circuit.rs:146-151, reciprocal.rs:88-95, u64_proof.rs:37-39) are instances of this with fixed index lists.
 int bppp_msm_batch(bppp_ctx* c, size_t n, size_t nterms, const int32_t* base_index, const uint8_t* scalars, uint8_t* out, int32_t* status) {
+    CtxLock lock_(c);
     if (!c || !base_index || !scalars || !out || nterms == 0 || nterms > 65536) return BPPP_ERR_INVALID_ARG;
     for (size_t j = 0; j < nterms; j++) {
         if (base_index[j] < 0 || base_index[j] >= c->nbases) return BPPP_ERR_INVALID_ARG;
@@ -1422,6 +1497,7 @@ void bppp_wnla_proof_shape(size_t nl, size_t nn, size_t* rounds, size_t* nl_out,
 int bppp_wnla_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments, const uint8_t* cvec,
                           const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl, const uint8_t* nvec, size_t nn,
                           uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l, uint8_t* proof_n, int32_t* status) {
+    CtxLock lock_(c);
     if (!c || (!label && label_len) || !commitments || !cvec || !rho || !mu || (!l && nl) || (!nvec && nn) || nl > 65536 || nn > 65536)
         return BPPP_ERR_INVALID_ARG;
     size_t rounds, nl_f, nn_f;
@@ -1485,6 +1561,7 @@ int bppp_wnla_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, s
 int bppp_circuit_prove_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n, const uint8_t* v_commitments,
                              const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l, const uint8_t* w_r, const uint8_t* w_o,
                              const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
+    CtxLock lock_(c);
     if (!c || !q || (!label && label_len) || !v_commitments || !v || !s_v || !w_l || !w_r || !rnd || !proofs) return BPPP_ERR_INVALID_ARG;
     const CircuitDev& cd = q->cd;
     if ((cd.no && !w_o) || cd.nm > c->ng || cd.nv + 9 > c->nh) return BPPP_ERR_INVALID_ARG;
@@ -1594,6 +1671,7 @@ int bppp_circuit_prove_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* 
 int bppp_reciprocal_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                 const uint8_t* commitments, const uint8_t* x, const uint8_t* sblind, const uint8_t* digits, const uint8_t* m,
                                 const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
+    CtxLock lock_(c);
     if (!c || (!label && label_len) || !commitments || !x || !sblind || !digits || !m || !rnd || !proofs) return BPPP_ERR_INVALID_ARG;
     if (dim_nd == 0 || dim_np == 0 || dim_nd > (size_t)c->ng || dim_nd + 10 > (size_t)c->nh || dim_np > dim_nd + 1 || dim_nd > 4096)
         return BPPP_ERR_INVALID_ARG;
@@ -1801,6 +1879,7 @@ struct TableFileHeader {
     uint64_t per_win, table_bytes;
 };
 int bppp_ctx_save_tables(bppp_ctx* c, const char* path) {
+    CtxLock lock_(c);
     if (!c || !path) return BPPP_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2036,6 +2115,7 @@ int bppp_u64_verify_batch_sharded_device(bppp_group* grp, const uint8_t* label, 
         th.emplace_back([&, r]() {
             size_t lo, hi;
             bppp_shard_range(n, r, G, &lo, &hi);
+            CtxLock lock_(grp->ctx[r]);
             rcs[r] = group_rank_verify(grp, r, label, label_len, hi - lo, d_commitments[r], d_proofs[r], d_accept[r],
                                        d_status ? d_status[r] : nullptr, d_reject_count[r]);
             if (rcs[r] == BPPP_OK) rcs[r] = bppp_ctx_synchronize(grp->ctx[r]);
@@ -2063,6 +2143,7 @@ int bppp_u64_verify_batch_sharded(bppp_group* grp, const uint8_t* label, size_t 
                 bppp_shard_range(n, r, G, &lo, &hi);
                 const size_t m = hi - lo;
                 bppp_ctx* c = grp->ctx[r];
+                CtxLock lock_(c);
                 HIP_TRY(hipSetDevice(grp->devices[r]));
                 // the shard goes through the context's persistent I/O staging, exactly as bppp_u64_verify_batch does
                 const size_t o_c = 0, o_p = align16(o_c + m * 64), o_a = align16(o_p + m * (size_t)BPPP_U64_PROOF_BYTES), o_s = align16(o_a + m),

@@ -14,7 +14,9 @@
  *   u64 proof 928 B = 13 points + 3 scalars, in this order (reciprocal.rs:30-33, circuit.rs:24-33):
  *                 c_l, c_r, c_o, c_s, r[0..3], x[0..3], reciprocal.r, l[0], l[1], n[0]
  *
- * Threading: a context is bound to one GPU and one HIP stream; calls on one context must not overlap.  Different
+ * Threading: a context is bound to one GPU and one HIP stream.  Every call on a context holds the context's lock, so calls from
+ * several host threads are safe and run one after the other (the reference's types are Send + Sync; SURVEY 8b "Threading"); for
+ * concurrency use one context per thread -- bppp_ctx_create_shared gives each its own workspace over one table set.  Different
  * contexts (e.g. one per GPU, one process per GPU) are independent.  The library never retains caller pointers.
  *
  * There is NO CPU fallback: without a usable gfx950 device every compute entry point returns BPPP_ERR_NO_DEVICE.
@@ -57,9 +59,10 @@ extern "C" {
 
 typedef struct bppp_ctx bppp_ctx;
 
-/* Concurrency: a context owns its workspace and streams and is NOT re-entrant -- one call at a time per context (use one
- * context per host thread, or an external lock).  Calls are asynchronous on the context's stream only where the entry point
- * says so (*_device variants); the host-buffer variants return after the results have been copied back. */
+/* Concurrency: a context owns its workspace and streams; calls on it are serialized by its lock (the *_device variants hold it while
+ * they enqueue: their kernels are ordered on the context's stream, and the workspace they share is reused in that order).  Calls
+ * are asynchronous on the context's stream only where the entry point says so (*_device variants); the host-buffer variants return
+ * after the results have been copied back. */
 
 /* U64RangeProofProtocol { g, g_vec[16], h_vec[32] } (u64_proof.rs:19-28) bound to GPU `device`.
  * Builds the fixed-base tables for the 49 generators on the GPU.  fb_window_bits: 0 = default 20 (signed 20-bit digits: 49 x 13 x
@@ -80,7 +83,9 @@ BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
  * off (chunks of 8 only), otherwise a multiple of 8 in [64, 8192]; default 4096.  "host_chunk": the host-buffer verify entry points
  * (bppp_u64_verify_batch, bppp_u64_verify_batch_rlc) cut a batch of more than 1.5 x host_chunk proofs into chunks of host_chunk proofs and upload
  * chunk k + 1 on a second stream while chunk k is being verified (proofs are independent: the results are those of one call) --
- * a multiple of 64, >= 1024; default 131072 (one full grid of the per-proof kernels); 0 = upload the whole batch first. */
+ * a multiple of 64, >= 1024; default 131072 (one full grid of the per-proof kernels); 0 = upload the whole batch first.  "max_batch": the u64 verify entry
+ * points run a batch of more than max_batch proofs as consecutive parts of max_batch on the same stream, which bounds the per-proof
+ * workspace (about 30 KB per proof) whatever n is -- a multiple of 64, >= 1024; default 2097152 (63 GB of workspace). */
 BPPP_API int bppp_ctx_set_option(bppp_ctx* ctx, const char* name, long value);
 /* Block the calling host thread until everything queued by this context (current stream + its helper stream) has finished. */
 BPPP_API int bppp_ctx_synchronize(bppp_ctx* ctx);

@@ -226,3 +226,66 @@ def test_host_buffer_path_pipelined_in_chunks(torch_mod, proto, oracle_c, n, chu
     assert (oacc == acc1[idx]).all() and ((ost != 0) == (st1[idx] != 0)).all()   # the oracle's own code for a bad encoding is -1
     with pytest.raises(Exception):
         proto.set_option("host_chunk", 1000)                # not a multiple of 64
+
+
+def test_internal_parts_bound_the_workspace(torch_mod, proto, oracle_c):
+    """A device-buffer batch larger than "max_batch" runs as consecutive parts (include/bppp.h): accept bits, status, the trace, the
+    reject count and the RLC mode are those of the one-part call; the per-proof workspace stops growing with n."""
+    import workload
+    torch = torch_mod
+    n = 3000
+    gens, V, P, _ = workload.make_batch(n, first=4000)
+    P, expect = workload.corrupt(P, V, every=11)
+    P[1024, 64:96] = 0xFF                                    # a flagged proof right at a part boundary
+    expect[1024] = 0
+    ref = _device_verify(torch, proto, workload.LABEL, V, P)
+    try:
+        proto.set_option("max_batch", 1024)
+        got = _device_verify(torch, proto, workload.LABEL, V, P)
+        dV, dP = torch.from_numpy(V).cuda(), torch.from_numpy(P).cuda()
+        dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dS = torch.zeros(n, dtype=torch.int32, device="cuda")
+        dR = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        proto.verify_batch_rlc_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), bytes(range(32)), dS.data_ptr(), dR.data_ptr())
+        proto.synchronize()
+    finally:
+        proto.set_option("max_batch", 1 << 21)
+    for a, b in zip(ref[:3], got[:3]):
+        assert (a == b).all()
+    assert ref[3] == got[3] == int((expect == 0).sum()) == int(dR.item())
+    assert (got[0] == expect).all() and got[1][1024] == 1
+    assert (dA.cpu().numpy() == expect).all() and (dS.cpu().numpy() == got[1]).all()
+    with pytest.raises(Exception):
+        proto.set_option("max_batch", 100)
+
+
+def test_calls_from_several_threads_on_one_context(torch_mod, proto):
+    """SURVEY 8b "Threading": the reference's types are Send + Sync.  Calls on ONE context from several host threads are serialized
+    by the context's lock; each gets its own batch's results."""
+    import threading
+    import workload
+    gens, V, P, _ = workload.make_batch(700, first=9000)
+    batches = []
+    for k in range(6):
+        lo, hi = 100 * k, 100 * k + 150 + 10 * k
+        Pk, ek = workload.corrupt(P[lo:hi].copy(), V[lo:hi], every=5 + k)
+        batches.append((V[lo:hi].copy(), Pk, ek))
+    results, errors = [None] * len(batches), []
+
+    def work(k):
+        try:
+            for _ in range(4):
+                Vk, Pk, ek = batches[k]
+                acc, st = (proto.verify_batch if k % 2 else lambda v, p, l: proto.verify_batch_rlc(v, p, l, seed=bytes([k]) * 32))(Vk, Pk, workload.LABEL)
+                assert (acc == ek).all() and not st.any()
+            results[k] = True
+        except Exception as e:          # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(batches))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors and all(results)
