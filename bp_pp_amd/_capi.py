@@ -19,7 +19,8 @@ EXPORTS = [
     "bppp_strerror", "bppp_last_error",
     "bppp_u64_verify_batch_transcript", "bppp_u64_verify_batch_transcript_device", "bppp_u64_prove_batch_transcript",
     "bppp_u64_prove_batch_transcript_device", "bppp_wnla_verify_batch_transcript", "bppp_reciprocal_verify_batch_transcript",
-    "bppp_circuit_verify_batch_transcript", "bppp_transcript_new",
+    "bppp_circuit_verify_batch_transcript", "bppp_wnla_prove_batch_transcript", "bppp_reciprocal_prove_batch_transcript",
+    "bppp_circuit_prove_batch_transcript", "bppp_transcript_new",
     "bppp_transcript_append_message", "bppp_transcript_challenge_bytes",
     "bppp_derive_generators", "bppp_ctx_save_tables", "bppp_ctx_create_from_tables", "bppp_ctx_create_shared",
     "bppp_shard_range", "bppp_group_create", "bppp_group_destroy", "bppp_group_size", "bppp_group_ctx", "bppp_u64_verify_batch_sharded",
@@ -90,6 +91,9 @@ def lib():
     L.bppp_wnla_verify_batch_transcript.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, vp, vp]
     L.bppp_reciprocal_verify_batch_transcript.argtypes = [vp, sz, vp, sz, sz, sz, vp, vp, sz, sz, sz, vp, vp, vp]
     L.bppp_circuit_verify_batch_transcript.argtypes = [vp, vp, sz, vp, sz, vp, vp, sz, sz, sz, vp, vp, vp]
+    L.bppp_wnla_prove_batch_transcript.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp]
+    L.bppp_reciprocal_prove_batch_transcript.argtypes = [vp, sz, vp, sz, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.bppp_circuit_prove_batch_transcript.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.bppp_transcript_new.argtypes = [u8p, sz, vp]
     L.bppp_transcript_append_message.argtypes = [vp, u8p, sz, u8p, sz]
     L.bppp_transcript_challenge_bytes.argtypes = [vp, u8p, sz, vp, sz]

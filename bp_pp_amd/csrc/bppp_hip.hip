@@ -1022,6 +1022,32 @@ static int check_host_transcripts(const HostTranscripts* tx, size_t n) {
         if (tx->states[203 * i + 200] >= BPPP_STROBE_R || tx->states[203 * i + 201] > BPPP_STROBE_R) return BPPP_ERR_INVALID_ARG;
     return BPPP_OK;
 }
+// device copies of a prover call's transcripts (host-buffer entry points): states in, advanced states out
+struct TxDev {
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    ~TxDev() { if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); }
+    int begin(const HostTranscripts* tx, size_t n, hipStream_t s, TranscriptIo& io, int& divergent) {
+        io.states = nullptr; io.n_states = 0; io.states_out = nullptr; io.no_ops = 0;
+        divergent = 0;
+        if (!tx) return BPPP_OK;
+        int rc = check_host_transcripts(tx, n);
+        if (rc != BPPP_OK) return rc;
+        HIP_TRY(hipMalloc(&d_in, tx->n_states * 203));
+        HIP_TRY(hipMemcpyAsync(d_in, tx->states, tx->n_states * 203, hipMemcpyHostToDevice, s));
+        if (tx->states_out) HIP_TRY(hipMalloc(&d_out, n * 203));
+        io.states = d_in; io.n_states = tx->n_states; io.states_out = d_out;
+        divergent = tx->n_states != 1;
+        return BPPP_OK;
+    }
+    // after the last prover kernel: serialize every instance's transcript and queue the copy back
+    int finish(const HostTranscripts* tx, const TranscriptIo& io, const strobe& base, const u32* tstate, size_t n, const int32_t* status, hipStream_t s) {
+        if (!tx || !tx->states_out) return BPPP_OK;
+        k_gprove_export_states<<<(unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(io, base, tstate, n, status);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(tx->states_out, d_out, n * 203, hipMemcpyDeviceToHost, s));
+        return BPPP_OK;
+    }
+};
 // ---- generic WeightNormLinearArgument entry points (host pointers; one device blob per call)
 struct WnlaBlob {
     uint8_t* d = nullptr;
@@ -1076,6 +1102,7 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
     if (!commit) t_new(w.base, label, (u32)label_len);
     if (tx) {
         w.tio.states = d + o_ti; w.tio.n_states = tx->n_states; w.tio.states_out = tx->states_out ? d + o_to : nullptr;
+        w.tio.no_ops = rounds == 0;
         w.divergent_positions = tx->n_states != 1;
     }
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
@@ -1275,7 +1302,7 @@ static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t labe
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * 64, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d + o_pr, proofs, n * proof_bytes, hipMemcpyHostToDevice, s));
-    TranscriptIo dtio = {nullptr, 0, nullptr};
+    TranscriptIo dtio = {nullptr, 0, nullptr, 0};
     if (tx) {
         HIP_TRY(hipMemcpyAsync(d + o_ti, tx->states, tx->n_states * 203, hipMemcpyHostToDevice, s));
         dtio.states = d + o_ti; dtio.n_states = tx->n_states; dtio.states_out = tx->states_out ? d + o_to : nullptr;
@@ -1494,10 +1521,9 @@ void bppp_wnla_proof_shape(size_t nl, size_t nn, size_t* rounds, size_t* nl_out,
     if (nl_out) *nl_out = a;
     if (nn_out) *nn_out = b;
 }
-int bppp_wnla_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments, const uint8_t* cvec,
-                          const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl, const uint8_t* nvec, size_t nn,
-                          uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l, uint8_t* proof_n, int32_t* status) {
-    CtxLock lock_(c);
+static int wnla_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, const HostTranscripts* tx, size_t n, const uint8_t* commitments,
+                           const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl, const uint8_t* nvec, size_t nn,
+                           uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l, uint8_t* proof_n, int32_t* status) {
     if (!c || (!label && label_len) || !commitments || !cvec || !rho || !mu || (!l && nl) || (!nvec && nn) || nl > 65536 || nn > 65536)
         return BPPP_ERR_INVALID_ARG;
     size_t rounds, nl_f, nn_f;
@@ -1534,6 +1560,10 @@ int bppp_wnla_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, s
     w.pbuf = (u32*)(d + o_pb);
     w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
     t_new(w.base, label, (u32)label_len);
+    TxDev txd;
+    int rc = txd.begin(tx, n, s, w.tio, w.divergent_positions);
+    if (rc != BPPP_OK) return rc;
+    w.tio.no_ops = rounds == 0;
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     k_wprove_init<<<blocks, BPPP_BLOCK, 0, s>>>(w);
@@ -1553,15 +1583,31 @@ int bppp_wnla_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, s
     if (nl_f) HIP_TRY(hipMemcpyAsync(proof_l, d + o_pl, n * nl_f * 32, hipMemcpyDeviceToHost, s));
     if (nn_f) HIP_TRY(hipMemcpyAsync(proof_n, d + o_pn, n * nn_f * 32, hipMemcpyDeviceToHost, s));
     if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    rc = txd.finish(tx, w.tio, w.base, w.tstate, n, w.status, s);
+    if (rc != BPPP_OK) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     return BPPP_OK;
 }
+int bppp_wnla_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments, const uint8_t* cvec,
+                          const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl, const uint8_t* nvec, size_t nn,
+                          uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l, uint8_t* proof_n, int32_t* status) {
+    CtxLock lock_(c);
+    return wnla_prove_impl(c, label, label_len, nullptr, n, commitments, cvec, rho, mu, l, nl, nvec, nn, proof_r, proof_x, proof_l, proof_n, status);
+}
+int bppp_wnla_prove_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, const uint8_t* commitments,
+                                     const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl, const uint8_t* nvec,
+                                     size_t nn, uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l, uint8_t* proof_n, int32_t* status,
+                                     uint8_t* states_out) {
+    CtxLock lock_(c);
+    if (!states) return BPPP_ERR_INVALID_ARG;
+    HostTranscripts tx = {states, n_states, states_out};
+    return wnla_prove_impl(c, nullptr, 0, &tx, n, commitments, cvec, rho, mu, l, nl, nvec, nn, proof_r, proof_x, proof_l, proof_n, status);
+}
 
 // ArithmeticCircuit::prove (circuit.rs:260-556) for n instances of a shared circuit.
-int bppp_circuit_prove_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n, const uint8_t* v_commitments,
-                             const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l, const uint8_t* w_r, const uint8_t* w_o,
-                             const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
-    CtxLock lock_(c);
+static int circuit_prove_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, const HostTranscripts* tx, size_t n,
+                              const uint8_t* v_commitments, const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l, const uint8_t* w_r,
+                              const uint8_t* w_o, const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
     if (!c || !q || (!label && label_len) || !v_commitments || !v || !s_v || !w_l || !w_r || !rnd || !proofs) return BPPP_ERR_INVALID_ARG;
     const CircuitDev& cd = q->cd;
     if ((cd.no && !w_o) || cd.nm > c->ng || cd.nv + 9 > c->nh) return BPPP_ERR_INVALID_ARG;
@@ -1611,10 +1657,14 @@ int bppp_circuit_prove_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* 
     p.wn_commit = d + o_wc; p.wn_c = d + o_wcv; p.wn_rho = d + o_rho; p.wn_mu = d + o_mu; p.wn_l = d + o_wlv; p.wn_n = d + o_wnv;
     p.fb.table = c->d_table; p.fb.W = c->fb_w; p.fb.N = n;
     t_new(p.base, label, (u32)label_len);
+    TxDev txd;
+    int rc = txd.begin(tx, n, s, p.tio, p.divergent_positions);
+    if (rc != BPPP_OK) return rc;
     WnlaProveWs w;
     std::memset(&w, 0, sizeof w);
     w.N = n; w.ng = c->ng; w.nh = c->nh; w.nl = (int)NH; w.nn = (int)NG; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
     w.transcript_preloaded = 1;
+    w.base = p.base; w.tio = p.tio; w.divergent_positions = p.divergent_positions;
     w.commitments = p.wn_commit; w.c = p.wn_c; w.rho = p.wn_rho; w.mu = p.wn_mu; w.l_in = p.wn_l; w.n_in = p.wn_n;
     w.proof_r = d + o_pr; w.proof_x = d + o_px; w.proof_l = d + o_pl; w.proof_n = d + o_pn;
     w.status = p.status; w.tstate = p.tstate; w.vl = (u32*)(d + o_vl); w.vn = (u32*)(d + o_vn); w.vc = (u32*)(d + o_vc);
@@ -1651,6 +1701,8 @@ int bppp_circuit_prove_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* 
     if (nl_f) HIP_TRY(hipMemcpyAsync(pl.data(), d + o_pl, pl.size(), hipMemcpyDeviceToHost, s));
     if (nn_f) HIP_TRY(hipMemcpyAsync(pn.data(), d + o_pn, pn.size(), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(st.data(), d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    rc = txd.finish(tx, p.tio, p.base, p.tstate, n, p.status, s);
+    if (rc != BPPP_OK) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     for (size_t i = 0; i < n; i++) {
         uint8_t* o = proofs + i * proof_bytes;
@@ -1666,12 +1718,25 @@ int bppp_circuit_prove_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* 
     (void)o_proofs;
     return BPPP_OK;
 }
+int bppp_circuit_prove_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n, const uint8_t* v_commitments,
+                             const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l, const uint8_t* w_r, const uint8_t* w_o,
+                             const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
+    CtxLock lock_(c);
+    return circuit_prove_impl(c, q, label, label_len, nullptr, n, v_commitments, v, s_v, w_l, w_r, w_o, rnd, proofs, status);
+}
+int bppp_circuit_prove_batch_transcript(bppp_ctx* c, const bppp_circuit* q, size_t n, const uint8_t* states, size_t n_states,
+                                        const uint8_t* v_commitments, const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l, const uint8_t* w_r,
+                                        const uint8_t* w_o, const uint8_t* rnd, uint8_t* proofs, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
+    if (!states) return BPPP_ERR_INVALID_ARG;
+    HostTranscripts tx = {states, n_states, states_out};
+    return circuit_prove_impl(c, q, nullptr, 0, &tx, n, v_commitments, v, s_v, w_l, w_r, w_o, rnd, proofs, status);
+}
 
 // ReciprocalRangeProofProtocol::prove (reciprocal.rs:110-146) for runtime dim_nd / dim_np.
-int bppp_reciprocal_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
-                                const uint8_t* commitments, const uint8_t* x, const uint8_t* sblind, const uint8_t* digits, const uint8_t* m,
-                                const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
-    CtxLock lock_(c);
+static int recip_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, const HostTranscripts* tx, size_t n, size_t dim_nd, size_t dim_np,
+                            const uint8_t* commitments, const uint8_t* x, const uint8_t* sblind, const uint8_t* digits, const uint8_t* m,
+                            const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
     if (!c || (!label && label_len) || !commitments || !x || !sblind || !digits || !m || !rnd || !proofs) return BPPP_ERR_INVALID_ARG;
     if (dim_nd == 0 || dim_np == 0 || dim_nd > (size_t)c->ng || dim_nd + 10 > (size_t)c->nh || dim_np > dim_nd + 1 || dim_nd > 4096)
         return BPPP_ERR_INVALID_ARG;
@@ -1728,8 +1793,12 @@ int bppp_reciprocal_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_
     r.cp_v = d + o_cpv; r.cp_sv = d + o_cpsv; r.cp_wr = d + o_cpwr; r.cp_vpts = d + o_cpvp; r.proof_r = d + o_prr;
     r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
     t_new(r.base, label, (u32)label_len);
+    TxDev txd;
+    int rc = txd.begin(tx, n, s, r.tio, r.divergent_positions);
+    if (rc != BPPP_OK) return rc;
     CircuitProveWs p;
     std::memset(&p, 0, sizeof p);
+    p.base = r.base; p.tio = r.tio; p.divergent_positions = r.divergent_positions;
     CircuitDev& cd = p.cd;
     cd.nm = (int)nm; cd.no = (int)np; cd.k = 1; cd.nl = (int)nl; cd.nv = (int)nv; cd.nw = (int)P.dims[5]; cd.f_l = 1; cd.f_m = 0;
     cd.colptr_l = (const int*)(d + o_cpl); cd.rows_l = (const int*)(d + o_rl); cd.vals_l = (const u32*)(d + o_vl);
@@ -1754,6 +1823,7 @@ int bppp_reciprocal_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_
     std::memset(&w, 0, sizeof w);
     w.N = n; w.ng = c->ng; w.nh = c->nh; w.nl = (int)NH; w.nn = (int)NG; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
     w.transcript_preloaded = 1;
+    w.base = r.base; w.tio = r.tio; w.divergent_positions = r.divergent_positions;
     w.commitments = p.wn_commit; w.c = p.wn_c; w.rho = p.wn_rho; w.mu = p.wn_mu; w.l_in = p.wn_l; w.n_in = p.wn_n;
     w.proof_r = d + o_pr; w.proof_x = d + o_px; w.proof_l = d + o_pl; w.proof_n = d + o_pn;
     w.status = r.status; w.tstate = r.tstate; w.vl = (u32*)(d + o_vl2); w.vn = (u32*)(d + o_vn2); w.vc = (u32*)(d + o_vc);
@@ -1794,6 +1864,8 @@ int bppp_reciprocal_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_
     if (nl_f) HIP_TRY(hipMemcpyAsync(pl.data(), d + o_pl, n * nl_f * 32, hipMemcpyDeviceToHost, s));
     if (nn_f) HIP_TRY(hipMemcpyAsync(pn.data(), d + o_pn, n * nn_f * 32, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(st.data(), d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    rc = txd.finish(tx, r.tio, r.base, r.tstate, n, r.status, s);
+    if (rc != BPPP_OK) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     for (size_t i = 0; i < n; i++) {
         uint8_t* o = proofs + i * proof_bytes;
@@ -1807,6 +1879,20 @@ int bppp_reciprocal_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_
     }
     if (status) std::memcpy(status, st.data(), n * 4);
     return BPPP_OK;
+}
+int bppp_reciprocal_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                const uint8_t* commitments, const uint8_t* x, const uint8_t* sblind, const uint8_t* digits, const uint8_t* m,
+                                const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
+    CtxLock lock_(c);
+    return recip_prove_impl(c, label, label_len, nullptr, n, dim_nd, dim_np, commitments, x, sblind, digits, m, rnd, proofs, status);
+}
+int bppp_reciprocal_prove_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, size_t dim_nd, size_t dim_np,
+                                           const uint8_t* commitments, const uint8_t* x, const uint8_t* sblind, const uint8_t* digits,
+                                           const uint8_t* m, const uint8_t* rnd, uint8_t* proofs, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
+    if (!states) return BPPP_ERR_INVALID_ARG;
+    HostTranscripts tx = {states, n_states, states_out};
+    return recip_prove_impl(c, nullptr, 0, &tx, n, dim_nd, dim_np, commitments, x, sblind, digits, m, rnd, proofs, status);
 }
 
 #if defined(BPPP_PHASE_TIMING)

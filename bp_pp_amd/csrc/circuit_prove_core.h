@@ -37,6 +37,8 @@ struct CircuitProveWs {
     uint8_t *wn_commit, *wn_c, *wn_rho, *wn_mu, *wn_l, *wn_n;
     FbTable fb;
     strobe base;
+    TranscriptIo tio;                // caller's transcripts (circuit.rs:260 `t: &mut Transcript`); input side ignored when transcript_preloaded
+    int divergent_positions;
 };
 enum { CM_RHO = 0, CM_LAMBDA, CM_BETA, CM_DELTA, CM_MU, CM_V0, CM_RV0, CM_DINV };
 
@@ -126,8 +128,13 @@ HD void circuit_prove_stage_b(const CircuitProveWs& w, size_t t) {
     apt_to_xy64(ph, A[1]);
     apt_to_xy64(ph + 64, A[2]);
     apt_to_xy64(ph + 128, A[0]);
-    strobe tr = w.base;
+    strobe tr;
     if (w.transcript_preloaded) ws_ld_strobe(tr, w.tstate, N, t);
+    else {
+        int32_t tst = ST_OK;
+        tio_begin(tr, tst, w.tio, w.base, t);
+        if (tst) w.status[t] |= tst;
+    }
     app_point(tr, "commitment_cl", A[1]);          // circuit.rs:347-350
     app_point(tr, "commitment_cr", A[2]);
     app_point(tr, "commitment_co", A[0]);

@@ -5,6 +5,18 @@
 using namespace bppp;
 
 // ---- generic WNLA prover kernels (wnla_prove_core.h)
+// Pre-loaded per-instance transcripts may sit at different sponge positions; the transcript code branches on the (wave-uniform)
+// position, so the hashing kernels run once per distinct position present in the wavefront (kernels.h).  All instances absorb the
+// same byte counts, so instances that start at one position stay together: the key is the position the caller handed in.
+template <typename Ws>
+__device__ __forceinline__ u32 gprove_position_key(const Ws& w, size_t t) {
+    return w.divergent_positions ? (u32)w.tio.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
+}
+// the caller's `&mut Transcript` after a prove (any generic prover: they all end in the WNLA prover's state array)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_gprove_export_states(TranscriptIo io, strobe base, const u32* tstate, size_t N, const int32_t* status) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < N) tio_export(io, base, tstate, N, status, t);
+}
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_init(WnlaProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) wnla_prove_init(w, t);
@@ -26,7 +38,8 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wprove_msm
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_fold(WnlaProveWs w, int k) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) wnla_prove_round_fold(w, t, k);
+    if (t >= w.N) return;
+    for_each_position_group(gprove_position_key(w, t), [&]() { wnla_prove_round_fold(w, t, k); });
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_finish(WnlaProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
@@ -39,11 +52,13 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_a(CircuitProveWs w)
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_b(CircuitProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) circuit_prove_stage_b(w, t);
+    if (t >= w.N) return;
+    for_each_position_group(gprove_position_key(w, t), [&]() { circuit_prove_stage_b(w, t); });
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_c(CircuitProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) circuit_prove_stage_c(w, t);
+    if (t >= w.N) return;
+    for_each_position_group(gprove_position_key(w, t), [&]() { circuit_prove_stage_c(w, t); });
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_d(CircuitProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
@@ -63,7 +78,8 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_cprove_msm
 // ---- generic reciprocal prover kernels (recip_prove_core.h)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_rprove_stage_r1(RecipProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N) recip_prove_stage_r1(w, t);
+    if (t >= w.N) return;
+    for_each_position_group(gprove_position_key(w, t), [&]() { recip_prove_stage_r1(w, t); });
 }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rprove_msm(RecipProveWs w) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_init(bppp::WnlaProveWs w)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_scalars(bppp::WnlaProveWs w, int k);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wprove_msm(bppp::WnlaProveWs w, int set);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_fold(bppp::WnlaProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_gprove_export_states(bppp::TranscriptIo io, bppp::strobe base, const bppp::u32* tstate, size_t N, const int32_t* status);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_finish(bppp::WnlaProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_a(bppp::CircuitProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_cprove_stage_b(bppp::CircuitProveWs w);

@@ -26,6 +26,8 @@ struct RecipProveWs {
     uint8_t* proof_r;    // n x 64
     FbTable fb;
     strobe base;
+    TranscriptIo tio;    // caller's transcripts (reciprocal.rs:109 `t: &mut Transcript`)
+    int divergent_positions;
 };
 HD void recip_prove_ranges(FbRanges& rg, const RecipProveWs& w) { fb_ranges_one(rg, 1 + w.NG, 1 + w.NG, 10 + w.nd); }   // h_vec[0 .. 9 + nv)
 
@@ -45,7 +47,8 @@ HD void recip_prove_stage_r1(const RecipProveWs& w, size_t t) {
     ok &= sc_from_be(rb, w.rnd + (size_t)t * w.n_rnd * 32);
 #pragma nounroll
     for (int j = 0; j < np; j++) { sc mj; ok &= sc_from_be(mj, w.m + ((size_t)t * np + j) * 32); }
-    strobe tr = w.base;
+    strobe tr;
+    tio_begin(tr, status, w.tio, w.base, t);
     app_point(tr, "reciprocal_commitment", V);                            // reciprocal.rs:111
     if (!t_get_challenge(tr, "reciprocal_challenge", e)) { status |= ST_DEGENERATE; e = one; }
     ws_st_strobe(w.tstate, N, t, tr);

@@ -104,6 +104,8 @@ struct TranscriptIo {
     const uint8_t* states;   // n_states x 203 or null (= start from the context's Transcript::new(label))
     size_t n_states;         // 1 or N
     uint8_t* states_out;     // N x 203 or null
+    int no_ops;              // 1: the protocol performs no transcript operation for this shape (WNLA base case, wnla.rs:80-82):
+                             // the caller's transcript comes back exactly as it went in, cur_flags included
 };
 HD void tio_begin(strobe& tr, int32_t& status, const TranscriptIo& io, const strobe& base, size_t t) {
     tr = base;
@@ -175,7 +177,7 @@ HD void ws_st_strobe(u32* base, size_t N, size_t t, const strobe& s) {
 HD void tio_export(const TranscriptIo& io, const strobe& base, const u32* tstate, size_t N, const int32_t* status, size_t t) {
     if (!io.states_out) return;
     uint8_t* out = io.states_out + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * t;
-    if (status[t] & ST_BAD_ENCODING) {
+    if ((status[t] & ST_BAD_ENCODING) || io.no_ops) {
         if (io.states) {
             const uint8_t* in = io.states + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * (io.n_states == 1 ? 0 : t);
 #pragma nounroll

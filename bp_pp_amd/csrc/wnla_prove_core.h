@@ -34,6 +34,8 @@ struct WnlaProveWs {
     u32* pbuf;        // [3][30][N]    X, R, next commitment (projective)
     FbTable fb;
     strobe base;
+    TranscriptIo tio;                                            // caller's transcripts (wnla.rs:125 `t: &mut Transcript`); input side ignored when transcript_preloaded
+    int divergent_positions;                                     // 1: the instances of one wavefront may sit at different sponge positions
 };
 HD size_t wp_set_words(const WnlaProveWs& w) { return (size_t)(1 + w.ng + w.nh) * 8 * w.N; }
 HD void wp_ld(sc& r, const u32* base, const WnlaProveWs& w, size_t t, int idx, int len) {   // zero-extended vector read
@@ -77,7 +79,11 @@ HD void wnla_prove_init(const WnlaProveWs& w, size_t t) {
     if (!ok) { status |= ST_BAD_ENCODING; rho = one; mu = one; }
     ws_st8(w.prm, N, t, 0, rho.v);
     ws_st8(w.prm, N, t, 1, mu.v);
-    if (!w.transcript_preloaded) ws_st_strobe(w.tstate, N, t, w.base);
+    if (!w.transcript_preloaded) {
+        strobe tr;
+        tio_begin(tr, status, w.tio, w.base, t);
+        ws_st_strobe(w.tstate, N, t, tr);
+    }
     w.status[t] = w.transcript_preloaded ? (w.status[t] | status) : status;
 }
 // round k (0-based): vx, vr and the scalar sets of X and R (wnla.rs:136-157)

@@ -15,6 +15,17 @@ def _u8(a, shape):
     return arr.reshape(shape)
 
 
+def _states(transcripts) -> np.ndarray:
+    """ONE serialized merlin state (203 bytes or a bp_pp_amd.transcript.Transcript) shared by the batch, a sequence of them, or an
+    [n, 203] array -> [n_states, 203] uint8."""
+    if isinstance(transcripts, np.ndarray):
+        return _u8(transcripts, (-1, 203))
+    as_bytes = lambda t: t.state if hasattr(t, "state") else bytes(t)
+    blob = as_bytes(transcripts) if hasattr(transcripts, "state") or isinstance(transcripts, (bytes, bytearray)) else \
+        b"".join(as_bytes(t) for t in transcripts)
+    return _u8(blob, (-1, 203))
+
+
 class WeightNormLinearArgument:
     def __init__(self, g: bytes, g_vec: Sequence[bytes], h_vec: Sequence[bytes], device: int = 0, fb_window_bits: int = 0):
         self.ng, self.nh = len(g_vec), len(h_vec)
@@ -46,9 +57,11 @@ class WeightNormLinearArgument:
                                                        n.ctypes.data, n.shape[1], out.ctypes.data, st.ctypes.data))
         return out, st
 
-    def prove_batch(self, label: bytes, commitments, c, rho, mu, l, n):
+    def prove_batch(self, label: bytes, commitments, c, rho, mu, l, n, transcripts=None):
         """wnla.rs:125-190 for a batch: commitments [B, 64], c [B, nh, 32], rho / mu [B, 32], l [B, nl, 32], n [B, nn, 32]
-        -> (proof_r [B, rounds, 64], proof_x, proof_l [B, nl', 32], proof_n [B, nn', 32], status [B])."""
+        -> (proof_r [B, rounds, 64], proof_x, proof_l [B, nl', 32], proof_n [B, nn', 32], status [B]).  With `transcripts` (the
+        reference's `t: &mut Transcript`: one serialized state or B of them; `label` is ignored) the advanced states [B, 203] are
+        appended to the result."""
         import ctypes as C
         commitments = _u8(commitments, (-1, 64))
         B = commitments.shape[0]
@@ -60,6 +73,13 @@ class WeightNormLinearArgument:
         pr, px = np.zeros((B, rounds.value, 64), np.uint8), np.zeros((B, rounds.value, 64), np.uint8)
         pl, pn = np.zeros((B, nl_f.value, 32), np.uint8), np.zeros((B, nn_f.value, 32), np.uint8)
         st = np.zeros(B, np.int32)
+        if transcripts is not None:
+            S, out = _states(transcripts), np.zeros((B, 203), np.uint8)
+            _capi.check(_capi.lib().bppp_wnla_prove_batch_transcript(self._ctx, B, S.ctypes.data, S.shape[0], commitments.ctypes.data,
+                                                                     c.ctypes.data, rho.ctypes.data, mu.ctypes.data, l.ctypes.data, l.shape[1],
+                                                                     n.ctypes.data, n.shape[1], pr.ctypes.data, px.ctypes.data, pl.ctypes.data,
+                                                                     pn.ctypes.data, st.ctypes.data, out.ctypes.data))
+            return pr, px, pl, pn, st, out
         _capi.check(_capi.lib().bppp_wnla_prove_batch(self._ctx, label, len(label), B, commitments.ctypes.data, c.ctypes.data, rho.ctypes.data,
                                                       mu.ctypes.data, l.ctypes.data, l.shape[1], n.ctypes.data, n.shape[1], pr.ctypes.data,
                                                       px.ctypes.data, pl.ctypes.data, pn.ctypes.data, st.ctypes.data))
@@ -76,8 +96,9 @@ class WeightNormLinearArgument:
                                                st.ctypes.data))
         return out, st
 
-    def verify_batch(self, label: bytes, commitments, c, rho, mu, proof_r, proof_x, proof_l, proof_n) -> Tuple[np.ndarray, np.ndarray]:
-        """wnla.rs:75-121 for a batch; proof_r / proof_x: [B, rounds, 64] in the reference's vector order."""
+    def verify_batch(self, label: bytes, commitments, c, rho, mu, proof_r, proof_x, proof_l, proof_n, transcripts=None):
+        """wnla.rs:75-121 for a batch; proof_r / proof_x: [B, rounds, 64] in the reference's vector order.  -> (accept, status), or
+        with `transcripts` (one serialized state or B; `label` ignored) -> (accept, status, advanced states [B, 203])."""
         commitments = _u8(commitments, (-1, 64))
         B = commitments.shape[0]
         c = _u8(c, (B, self.nh, 32))
@@ -88,6 +109,14 @@ class WeightNormLinearArgument:
         proof_l, proof_n = _u8(proof_l, (B, -1, 32)), _u8(proof_n, (B, -1, 32))
         acc = np.zeros(B, np.uint8)
         st = np.zeros(B, np.int32)
+        if transcripts is not None:
+            S, out = _states(transcripts), np.zeros((B, 203), np.uint8)
+            _capi.check(_capi.lib().bppp_wnla_verify_batch_transcript(self._ctx, B, S.ctypes.data, S.shape[0], commitments.ctypes.data,
+                                                                      c.ctypes.data, rho.ctypes.data, mu.ctypes.data, proof_r.shape[1],
+                                                                      proof_r.ctypes.data, proof_x.ctypes.data, proof_l.ctypes.data,
+                                                                      proof_l.shape[1], proof_n.ctypes.data, proof_n.shape[1], acc.ctypes.data,
+                                                                      st.ctypes.data, out.ctypes.data))
+            return acc, st, out
         _capi.check(_capi.lib().bppp_wnla_verify_batch(self._ctx, label, len(label), B, commitments.ctypes.data, c.ctypes.data,
                                                        rho.ctypes.data, mu.ctypes.data, proof_r.shape[1], proof_r.ctypes.data,
                                                        proof_x.ctypes.data, proof_l.ctypes.data, proof_l.shape[1], proof_n.ctypes.data,
@@ -108,9 +137,10 @@ class ReciprocalRangeProofProtocol:
     def close(self):
         self._w.close()
 
-    def prove_batch(self, label: bytes, commitments, x, s, digits, m, rnd):
+    def prove_batch(self, label: bytes, commitments, x, s, digits, m, rnd, transcripts=None):
         """reciprocal.rs:110-146 for a batch: commitments [B, 64], x / s [B, 32], digits [B, dim_nd, 32], m [B, dim_np, 32],
-        rnd [B, 20 + 2 dim_nd, 32] -> (proofs, status, (rounds, nl, nn))."""
+        rnd [B, 20 + 2 dim_nd, 32] -> (proofs, status, (rounds, nl, nn)); with `transcripts` (`label` ignored) the advanced states
+        [B, 203] are appended."""
         import ctypes as C
         commitments = _u8(commitments, (-1, 64))
         B = commitments.shape[0]
@@ -121,6 +151,13 @@ class ReciprocalRangeProofProtocol:
         _capi.lib().bppp_wnla_proof_shape(self._w.nh, self._w.ng, C.byref(rounds), C.byref(nl), C.byref(nn))
         proofs = np.zeros((B, 64 * (5 + 2 * rounds.value) + 32 * (nl.value + nn.value)), np.uint8)
         st = np.zeros(B, np.int32)
+        if transcripts is not None:
+            S, out = _states(transcripts), np.zeros((B, 203), np.uint8)
+            _capi.check(_capi.lib().bppp_reciprocal_prove_batch_transcript(self._w._ctx, B, S.ctypes.data, S.shape[0], self.dim_nd, self.dim_np,
+                                                                           commitments.ctypes.data, x.ctypes.data, s.ctypes.data,
+                                                                           digits.ctypes.data, m.ctypes.data, rnd.ctypes.data, proofs.ctypes.data,
+                                                                           st.ctypes.data, out.ctypes.data))
+            return proofs, st, (rounds.value, nl.value, nn.value), out
         _capi.check(_capi.lib().bppp_reciprocal_prove_batch(self._w._ctx, label, len(label), B, self.dim_nd, self.dim_np,
                                                             commitments.ctypes.data, x.ctypes.data, s.ctypes.data, digits.ctypes.data,
                                                             m.ctypes.data, rnd.ctypes.data, proofs.ctypes.data, st.ctypes.data))
@@ -137,11 +174,18 @@ class ReciprocalRangeProofProtocol:
         idx = [1 + self._w.ng] + [1 + self._w.ng + 9 + i for i in range(self.dim_nd)]
         return self._w.msm_batch(idx, np.concatenate([s[:, None, :], r], axis=1))
 
-    def verify_batch(self, label: bytes, commitments, proofs, rounds: int, nl: int, nn: int):
+    def verify_batch(self, label: bytes, commitments, proofs, rounds: int, nl: int, nn: int, transcripts=None):
+        """reciprocal.rs:98-107 for a batch -> (accept, status), or with `transcripts` (`label` ignored) (accept, status, states)."""
         commitments = _u8(commitments, (-1, 64))
         B = commitments.shape[0]
         proofs = _u8(proofs, (B, 64 * (5 + 2 * rounds) + 32 * (nl + nn)))
         acc, st = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        if transcripts is not None:
+            S, out = _states(transcripts), np.zeros((B, 203), np.uint8)
+            _capi.check(_capi.lib().bppp_reciprocal_verify_batch_transcript(self._w._ctx, B, S.ctypes.data, S.shape[0], self.dim_nd, self.dim_np,
+                                                                            commitments.ctypes.data, proofs.ctypes.data, rounds, nl, nn,
+                                                                            acc.ctypes.data, st.ctypes.data, out.ctypes.data))
+            return acc, st, out
         _capi.check(_capi.lib().bppp_reciprocal_verify_batch(self._w._ctx, label, len(label), B, self.dim_nd, self.dim_np,
                                                              commitments.ctypes.data, proofs.ctypes.data, rounds, nl, nn,
                                                              acc.ctypes.data, st.ctypes.data))
@@ -205,10 +249,11 @@ class ArithmeticCircuit:
             self._circuit = None
         self._w.close()
 
-    def prove_batch(self, label: bytes, v_commitments, v, s_v, w_l, w_r, w_o, rnd):
+    def prove_batch(self, label: bytes, v_commitments, v, s_v, w_l, w_r, w_o, rnd, transcripts=None):
         """circuit.rs:260-556 for a batch: v_commitments [B, k, 64], v [B, k, dim_nv, 32], s_v [B, k, 32], w_l / w_r [B, dim_nm, 32],
         w_o [B, dim_no, 32], rnd [B, 18 + dim_nv + dim_nm, 32] (the prover's random scalars in the reference's draw order)
-        -> (proofs [B, proof_bytes], status [B], (rounds, nl, nn))."""
+        -> (proofs [B, proof_bytes], status [B], (rounds, nl, nn)); with `transcripts` (circuit.rs:260 `t: &mut Transcript`; `label`
+        ignored) the advanced states [B, 203] are appended."""
         import ctypes as C
         v_commitments = _u8(v_commitments, (-1, self.k, 64))
         B = v_commitments.shape[0]
@@ -220,6 +265,13 @@ class ArithmeticCircuit:
         _capi.lib().bppp_wnla_proof_shape(self._w.nh, self._w.ng, C.byref(rounds), C.byref(nl), C.byref(nn))
         proofs = np.zeros((B, 64 * (4 + 2 * rounds.value) + 32 * (nl.value + nn.value)), np.uint8)
         st = np.zeros(B, np.int32)
+        if transcripts is not None:
+            S, out = _states(transcripts), np.zeros((B, 203), np.uint8)
+            _capi.check(_capi.lib().bppp_circuit_prove_batch_transcript(self._w._ctx, self._circuit, B, S.ctypes.data, S.shape[0],
+                                                                        v_commitments.ctypes.data, v.ctypes.data, s_v.ctypes.data, w_l.ctypes.data,
+                                                                        w_r.ctypes.data, w_o.ctypes.data, rnd.ctypes.data, proofs.ctypes.data,
+                                                                        st.ctypes.data, out.ctypes.data))
+            return proofs, st, (rounds.value, nl.value, nn.value), out
         _capi.check(_capi.lib().bppp_circuit_prove_batch(self._w._ctx, self._circuit, label, len(label), B, v_commitments.ctypes.data,
                                                          v.ctypes.data, s_v.ctypes.data, w_l.ctypes.data, w_r.ctypes.data, w_o.ctypes.data,
                                                          rnd.ctypes.data, proofs.ctypes.data, st.ctypes.data))
@@ -232,12 +284,19 @@ class ArithmeticCircuit:
         idx = [0, 1 + ng] + [1 + ng + 9 + i for i in range(self.dim_nv - 1)]
         return self._w.msm_batch(idx, np.concatenate([v[:, :1, :], s[:, None, :], v[:, 1:, :]], axis=1))
 
-    def verify_batch(self, label: bytes, commitments, proofs, rounds: int, nl: int, nn: int):
-        """circuit.rs:154-256 for a batch: commitments [B, k, 64], proofs [B, 64 (4 + 2 rounds) + 32 (nl + nn)] -> (accept, status)."""
+    def verify_batch(self, label: bytes, commitments, proofs, rounds: int, nl: int, nn: int, transcripts=None):
+        """circuit.rs:154-256 for a batch: commitments [B, k, 64], proofs [B, 64 (4 + 2 rounds) + 32 (nl + nn)] -> (accept, status),
+        or with `transcripts` (`label` ignored) (accept, status, advanced states [B, 203])."""
         commitments = _u8(commitments, (-1, self.k, 64))
         B = commitments.shape[0]
         proofs = _u8(proofs, (B, 64 * (4 + 2 * rounds) + 32 * (nl + nn)))
         acc, st = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        if transcripts is not None:
+            S, out = _states(transcripts), np.zeros((B, 203), np.uint8)
+            _capi.check(_capi.lib().bppp_circuit_verify_batch_transcript(self._w._ctx, self._circuit, B, S.ctypes.data, S.shape[0],
+                                                                         commitments.ctypes.data, proofs.ctypes.data, rounds, nl, nn,
+                                                                         acc.ctypes.data, st.ctypes.data, out.ctypes.data))
+            return acc, st, out
         _capi.check(_capi.lib().bppp_circuit_verify_batch(self._w._ctx, self._circuit, label, len(label), B, commitments.ctypes.data,
                                                           proofs.ctypes.data, rounds, nl, nn, acc.ctypes.data, st.ctypes.data))
         return acc, st

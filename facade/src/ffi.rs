@@ -61,6 +61,9 @@ extern "C" {
     pub fn bppp_wnla_verify_batch_transcript(ctx: *mut BpppCtx, n: usize, states: *const u8, n_states: usize, commitments: *const u8, c: *const u8, rho: *const u8, mu: *const u8, rounds: usize, proof_r: *const u8, proof_x: *const u8, proof_l: *const u8, nl: usize, proof_n: *const u8, nn: usize, accept: *mut u8, status: *mut i32, states_out: *mut u8) -> c_int;
     pub fn bppp_reciprocal_verify_batch_transcript(ctx: *mut BpppCtx, n: usize, states: *const u8, n_states: usize, dim_nd: usize, dim_np: usize, commitments: *const u8, proofs: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32, states_out: *mut u8) -> c_int;
     pub fn bppp_circuit_verify_batch_transcript(ctx: *mut BpppCtx, circuit: *const BpppCircuit, n: usize, states: *const u8, n_states: usize, commitments: *const u8, proofs: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32, states_out: *mut u8) -> c_int;
+    pub fn bppp_wnla_prove_batch_transcript(ctx: *mut BpppCtx, n: usize, states: *const u8, n_states: usize, commitments: *const u8, c: *const u8, rho: *const u8, mu: *const u8, l: *const u8, nl: usize, nvec: *const u8, nn: usize, proof_r: *mut u8, proof_x: *mut u8, proof_l: *mut u8, proof_n: *mut u8, status: *mut i32, states_out: *mut u8) -> c_int;
+    pub fn bppp_reciprocal_prove_batch_transcript(ctx: *mut BpppCtx, n: usize, states: *const u8, n_states: usize, dim_nd: usize, dim_np: usize, commitments: *const u8, x: *const u8, s: *const u8, digits: *const u8, m: *const u8, rnd: *const u8, proofs: *mut u8, status: *mut i32, states_out: *mut u8) -> c_int;
+    pub fn bppp_circuit_prove_batch_transcript(ctx: *mut BpppCtx, circuit: *const BpppCircuit, n: usize, states: *const u8, n_states: usize, v_commitments: *const u8, v: *const u8, s_v: *const u8, w_l: *const u8, w_r: *const u8, w_o: *const u8, rnd: *const u8, proofs: *mut u8, status: *mut i32, states_out: *mut u8) -> c_int;
     pub fn bppp_transcript_new(label: *const u8, label_len: usize, state_out: *mut u8) -> c_int;
     pub fn bppp_transcript_append_message(state: *mut u8, label: *const u8, label_len: usize, msg: *const u8, msg_len: usize) -> c_int;
     pub fn bppp_transcript_challenge_bytes(state: *mut u8, label: *const u8, label_len: usize, out: *mut u8, n: usize) -> c_int;

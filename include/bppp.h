@@ -306,6 +306,23 @@ BPPP_API int bppp_reciprocal_verify_batch_transcript(bppp_ctx* ctx, size_t n, co
 BPPP_API int bppp_circuit_verify_batch_transcript(bppp_ctx* ctx, const bppp_circuit* circuit, size_t n, const uint8_t* states,
                                                   size_t n_states, const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl,
                                                   size_t nn, uint8_t* accept, int32_t* status, uint8_t* states_out);
+/* The generic provers with the caller's transcripts -- `t: &mut Transcript` of WeightNormLinearArgument::prove (wnla.rs:125),
+ * ReciprocalRangeProofProtocol::prove (reciprocal.rs:109) and ArithmeticCircuit::prove (circuit.rs:260): states in (1 or n), each
+ * instance's transcript as the reference's prove leaves it out (optional; for a WNLA shape with no rounds, |l| + |n| < 6, that is
+ * the input state untouched); every other argument as in the label forms above, the proofs byte-identical to the reference
+ * prover's on the same transcript and draws. */
+BPPP_API int bppp_wnla_prove_batch_transcript(bppp_ctx* ctx, size_t n, const uint8_t* states, size_t n_states, const uint8_t* commitments,
+                                              const uint8_t* c, const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl,
+                                              const uint8_t* nvec, size_t nn, uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l,
+                                              uint8_t* proof_n, int32_t* status, uint8_t* states_out);
+BPPP_API int bppp_reciprocal_prove_batch_transcript(bppp_ctx* ctx, size_t n, const uint8_t* states, size_t n_states, size_t dim_nd,
+                                                    size_t dim_np, const uint8_t* commitments, const uint8_t* x, const uint8_t* s,
+                                                    const uint8_t* digits, const uint8_t* m, const uint8_t* rnd, uint8_t* proofs,
+                                                    int32_t* status, uint8_t* states_out);
+BPPP_API int bppp_circuit_prove_batch_transcript(bppp_ctx* ctx, const bppp_circuit* circuit, size_t n, const uint8_t* states,
+                                                 size_t n_states, const uint8_t* v_commitments, const uint8_t* v, const uint8_t* s_v,
+                                                 const uint8_t* w_l, const uint8_t* w_r, const uint8_t* w_o, const uint8_t* rnd,
+                                                 uint8_t* proofs, int32_t* status, uint8_t* states_out);
 /* merlin::Transcript on serialized states, host only (no GPU needed): Transcript::new(label), append_message(label, msg)
  * (transcript.rs:7 uses it for points, wnla.rs:91-92 for u64s) and challenge_bytes(label, out) (transcript.rs:12).  A Rust caller
  * holding a real merlin::Transcript does not need these; a C caller builds its pre-loaded states with them. */

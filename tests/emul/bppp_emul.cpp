@@ -460,7 +460,7 @@ void emul_sec1_expand(size_t n, const uint8_t* c33, const uint8_t* p525, uint8_t
 // generic WNLA commit / verify, every stage in thread order (commit: out_points; verify: accept)
 // Pre-loaded transcripts for the NEXT generic verify call (emul_wnla_run / emul_recip_verify / emul_circuit_verify): states in
 // (n_states = 1 or n), per-instance advanced states out; consumed by that call.
-static TranscriptIo g_tio = {nullptr, 0, nullptr};
+static TranscriptIo g_tio = {nullptr, 0, nullptr, 0};
 void emul_set_transcripts(const uint8_t* states, size_t n_states, uint8_t* states_out) {
     g_tio.states = states; g_tio.n_states = n_states; g_tio.states_out = states_out;
 }
@@ -497,6 +497,7 @@ int emul_wnla_run(int commit, const uint8_t* table, int W, int ng, int nh, const
     } else {
         t_new(w.base, label, (u32)label_len);
         w.tio = take_tio();
+        w.tio.no_ops = rounds == 0;
         for (size_t t = 0; t < n; t++) wnla_verify_begin(w, t);
         for (int k = 1; k <= rounds; k++)
             for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, k);
@@ -590,8 +591,10 @@ int emul_circuit_verify(const uint8_t* table, int W, int NG, int NH, const size_
     r.wn_commit = wc.data(); r.wn_c = wcv.data(); r.wn_rho = wrho.data(); r.wn_mu = wmu.data();
     r.fb.table = (const apt_packed*)table; r.fb.W = W; r.fb.N = n;
     t_new(r.base, label, (u32)label_len);
+    r.tio = take_tio();
     WnlaWs w;
     memset(&w, 0, sizeof w);
+    w.base = r.base; w.tio = r.tio;
     w.N = n; w.ng = NG; w.nh = NH; w.rounds = rounds; w.nl = nl; w.nn = nn;
     w.commitments = r.wn_commit; w.c = r.wn_c; w.rho = r.wn_rho; w.mu = r.wn_mu;
     w.proof_r = proofs + 256; w.proof_x = proofs + 256 + 64 * (size_t)rounds; w.proof_l = proofs + 256 + 128 * (size_t)rounds;
@@ -624,6 +627,7 @@ int emul_circuit_verify(const uint8_t* table, int W, int NG, int NH, const size_
         wnla_verify_store(w, t, a);
     }
     for (size_t t = 0; t < n; t++) wnla_verify_accept(w, t);
+    for (size_t t = 0; t < n; t++) tio_export(w.tio, w.base, w.tstate, n, w.status, t);
     return 0;
 }
 // generic WeightNormLinearArgument::prove (wnla_prove_core.h), every stage in thread order; returns the proof shape through
@@ -647,6 +651,8 @@ int emul_wnla_prove(const uint8_t* table, int W, int ng, int nh, const uint8_t* 
     w.com = com.data(); w.msc = msc.data(); w.pbuf = pb.data();
     w.fb.table = (const apt_packed*)table; w.fb.W = W; w.fb.N = n;
     t_new(w.base, label, (u32)label_len);
+    w.tio = take_tio();
+    w.tio.no_ops = rounds == 0;
     auto msm = [&](int set) {
         for (size_t t = 0; t < n; t++) {
             pt a;
@@ -665,6 +671,7 @@ int emul_wnla_prove(const uint8_t* table, int W, int ng, int nh, const uint8_t* 
         if (k + 1 < (int)rounds) msm(2);
     }
     for (size_t t = 0; t < n; t++) wnla_prove_finish(w, t);
+    for (size_t t = 0; t < n; t++) tio_export(w.tio, w.base, w.tstate, n, w.status, t);
     return 0;
 }
 // generic ArithmeticCircuit::prove (circuit_prove_core.h + wnla_prove_core.h), every stage in thread order
@@ -705,6 +712,7 @@ int emul_circuit_prove(const uint8_t* table, int W, int NG, int NH, const size_t
     p.wn_commit = wc.data(); p.wn_c = wcv.data(); p.wn_rho = wrho.data(); p.wn_mu = wmu.data(); p.wn_l = wlv.data(); p.wn_n = wnv.data();
     p.fb.table = (const apt_packed*)table; p.fb.W = W; p.fb.N = n;
     t_new(p.base, label, (u32)label_len);
+    p.tio = take_tio();
     std::vector<uint8_t> pr(n * rounds * 64 + 1), px(n * rounds * 64 + 1), pl(n * nl_f * 32 + 1), pn(n * nn_f * 32 + 1);
     WnlaProveWs w;
     memset(&w, 0, sizeof w);
@@ -750,6 +758,7 @@ int emul_circuit_prove(const uint8_t* table, int W, int NG, int NH, const size_t
         if (kk + 1 < (int)rounds) wmsm(2);
     }
     for (size_t t = 0; t < n; t++) wnla_prove_finish(w, t);
+    for (size_t t = 0; t < n; t++) tio_export(p.tio, p.base, p.tstate, n, status, t);
     for (size_t i = 0; i < n; i++) {
         uint8_t* o = proofs + i * proof_bytes;
         if (status[i] != 0) { memset(o, 0, proof_bytes); continue; }
@@ -781,6 +790,7 @@ int emul_recip_prove(const uint8_t* table, int W, int NG, int NH, int nd, int np
     r.cp_v = cpv.data(); r.cp_sv = cpsv.data(); r.cp_wr = cpwr.data(); r.cp_vpts = cpvp.data(); r.proof_r = prr.data();
     r.fb.table = (const apt_packed*)table; r.fb.W = W; r.fb.N = n;
     t_new(r.base, label, (u32)label_len);
+    r.tio = take_tio();
     CircuitProveWs p;
     memset(&p, 0, sizeof p);
     CircuitDev& cd = p.cd;
@@ -840,6 +850,7 @@ int emul_recip_prove(const uint8_t* table, int W, int NG, int NH, int nd, int np
         if (kk + 1 < (int)rounds) sum(rg, w.msc + 2 * wp_set_words(w), w.pbuf + 60 * n);
     }
     for (size_t t = 0; t < n; t++) wnla_prove_finish(w, t);
+    for (size_t t = 0; t < n; t++) tio_export(r.tio, r.base, r.tstate, n, status, t);
     for (size_t i = 0; i < n; i++) {
         uint8_t* o = proofs + i * proof_bytes;
         if (status[i] != 0) { memset(o, 0, proof_bytes); continue; }

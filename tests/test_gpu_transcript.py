@@ -142,3 +142,68 @@ def test_generic_verifiers_over_preloaded_transcripts_on_the_gpu():
         assert acc.tolist() == [1] * n and not st.any() and (out == u8("state_after_verify", 203)).all()
     finally:
         r.close()
+
+
+def test_generic_provers_over_preloaded_transcripts_on_the_gpu():
+    """bppp_{wnla,reciprocal,circuit}_prove_batch_transcript + bppp_circuit_verify_batch_transcript through the Python mirror:
+    instances of one wavefront at different sponge positions; proofs byte-identical to the Python oracle's, states advanced as
+    merlin's; the WNLA base case hands the transcript back untouched."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import generic_transcript_cases as GC
+    import ref_fixture_check as RC
+    import workload
+    from bp_pp_amd.wnla import ArithmeticCircuit, ReciprocalRangeProofProtocol, WeightNormLinearArgument
+    for kw in (dict(), dict(ng=2, nh=2, B=2)):
+        case = GC.wnla_case(**kw)
+        B = case["commitments"].shape[0]
+        w = WeightNormLinearArgument(case["g"], case["gv"], case["hv"], device=0, fb_window_bits=8)
+        try:
+            l, n = case["l"].reshape(B, -1, 32), case["n"].reshape(B, -1, 32)
+            pr, px, pl, pn, st, out = w.prove_batch(b"", case["commitments"], case["c"], case["rho"], case["mu"], l, n, transcripts=case["states_in"])
+            assert not st.any() and pr.shape[1] == case["rounds"]
+            assert pr.tobytes() == case["proof_r"].tobytes() and px.tobytes() == case["proof_x"].tobytes()
+            assert pl.tobytes() == case["proof_l"].tobytes() and pn.tobytes() == case["proof_n"].tobytes()
+            assert (out == case["states_after_prove"]).all()
+            acc, st, out = w.verify_batch(b"", case["commitments"], case["c"], case["rho"], case["mu"], pr, px, pl, pn, transcripts=case["states_in"])
+            assert acc.all() and not st.any() and (out == case["states_after"]).all()
+            # one shared transcript (instance 0's): instance 0's proof is reproduced, the states all start from it
+            pr1, px1, pl1, pn1, st1, out1 = w.prove_batch(b"", case["commitments"], case["c"], case["rho"], case["mu"], l, n,
+                                                          transcripts=case["states_in"][0].tobytes())
+            assert not st1.any() and pl1[0].tobytes() == pl[0].tobytes() and (out1[0] == case["states_after_prove"][0]).all()
+        finally:
+            w.close()
+    doc = RC.oracle_made_document(4)
+    cs = doc["cases"]
+    n = len(cs)
+    u8 = lambda key, *sh: np.frombuffer(b"".join(bytes.fromhex(c[key]) for c in cs), dtype=np.uint8).reshape(n, *sh).copy()
+    g, gv, hv = workload.split_generators(bytes.fromhex(doc["generators"]))
+    r = ReciprocalRangeProofProtocol(16, 16, g, gv, hv[:26], [], hv[26:], device=0, fb_window_bits=8)
+    try:
+        x, digits, m = GC.recip_prover_inputs(doc)
+        proofs, st, shape, out = r.prove_batch(b"", u8("commitment", 64), x, u8("s", 32), digits, m, u8("rnd", 52, 32), transcripts=u8("state_before", 203))
+        assert shape == (4, 2, 1) and not st.any() and (proofs == u8("proof", 928)).all() and (out == u8("state_after_prove", 203)).all()
+        acc, st, out = r.verify_batch(b"", u8("commitment", 64), proofs, *shape, transcripts=u8("state_before", 203))
+        assert acc.all() and not st.any() and (out == u8("state_after_verify", 203)).all()
+    finally:
+        r.close()
+    case = GC.circuit_case()
+    part = case["part"]
+    partition = lambda typ, j: part[typ][j] if j < len(part[typ]) and part[typ][j] >= 0 else None
+    sc = lambda blob: np.frombuffer(blob, np.uint8).reshape(-1, 32)
+    ckt = ArithmeticCircuit(case["nm"], case["no"], case["k"], case["nv"], case["g"], case["gv"], case["hv"], sc(case["Wm_bytes"]), sc(case["Wl_bytes"]),
+                            sc(case["am_bytes"]), sc(case["al_bytes"]), case["f_l"], case["f_m"], case["gv_"], case["hv_"], partition, device=0,
+                            fb_window_bits=8)
+    try:
+        proofs, st, shape, out = ckt.prove_batch(b"", case["commitments"], case["v_bytes"], case["s_v"], case["wl_bytes"], case["wr_bytes"],
+                                                 case["wo_bytes"], case["rnd"], transcripts=case["states_in"])
+        assert shape == (case["rounds"], case["pl"], case["pn"]) and not st.any()
+        assert (proofs == case["proofs"]).all() and (out == case["states_after_prove"]).all()
+        acc, st, out = ckt.verify_batch(b"", case["commitments"], proofs, *shape, transcripts=case["states_in"])
+        assert acc.all() and not st.any() and (out == case["states_after_verify"]).all()
+        # a proof verified on somebody else's transcript fails
+        acc, st, _ = ckt.verify_batch(b"", case["commitments"], proofs, *shape, transcripts=case["states_in"][0].tobytes())
+        assert acc.tolist() == [1] + [0] * (len(acc) - 1)
+    finally:
+        ckt.close()

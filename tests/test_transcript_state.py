@@ -119,6 +119,19 @@ def test_generic_verifiers_over_preloaded_transcripts_through_the_device_code():
                     case["rho"].ctypes.data, case["mu"].ctypes.data, case["rounds"], case["proof_r"].ctypes.data, case["proof_x"].ctypes.data,
                     case["proof_l"].ctypes.data, case["nl"], case["proof_n"].ctypes.data, case["nn"], None, acc.ctypes.data, st.ctypes.data)
     assert acc.tolist() == [1] * B and not st.any() and (out == case["states_after"]).all()
+    # the base case (|l| + |n| < 6, wnla.rs:80-82) performs no transcript operation: the state comes back untouched, its
+    # cur_flags byte (2 after append_message) included
+    case = GC.wnla_case(ng=2, nh=2, B=2)
+    assert case["rounds"] == 0 and (case["states_after"] == case["states_in"]).all() and case["states_in"][0, 202] == 2
+    gens = case["g"] + b"".join(case["gv"]) + b"".join(case["hv"])
+    tab = np.zeros(L.emul_fb_table_entries(5, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, 5, W, tab.ctypes.data) == 0
+    acc, st, out = np.zeros(2, np.uint8), np.zeros(2, np.int32), np.zeros((2, 203), np.uint8)
+    L.emul_set_transcripts(case["states_in"].ctypes.data, 2, out.ctypes.data)
+    L.emul_wnla_run(0, tab.ctypes.data, W, 2, 2, b"", 0, 2, case["commitments"].ctypes.data, case["c"].ctypes.data, case["rho"].ctypes.data,
+                    case["mu"].ctypes.data, 0, case["proof_r"].ctypes.data, case["proof_x"].ctypes.data, case["proof_l"].ctypes.data, case["nl"],
+                    case["proof_n"].ctypes.data, case["nn"], None, acc.ctypes.data, st.ctypes.data)
+    assert acc.tolist() == [1, 1] and not st.any() and (out == case["states_in"]).all()
     # ---- reciprocal at the u64 dimensions, on the u64 proofs of the oracle-made document (two of them carry context)
     doc = RC.oracle_made_document(4)
     cs = doc["cases"]
@@ -157,3 +170,73 @@ def test_committed_round2_golden_vectors(oracle_c):
     assert RC.check_document(doc, oracle_c) == len(doc["cases"])
     dg = doc["derived_generators"]
     assert derive_generators(bytes.fromhex(dg["seed"]), 5, dg["first_index"]).hex() == dg["points"]
+
+
+def _table(L, gens: bytes, nb: int, W: int = 4):
+    tab = np.zeros(L.emul_fb_table_entries(nb, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, nb, W, tab.ctypes.data) == 0
+    return tab
+
+
+def test_generic_provers_over_preloaded_transcripts_through_the_device_code():
+    """`t: &mut Transcript` of WeightNormLinearArgument::prove (wnla.rs:125), ReciprocalRangeProofProtocol::prove (reciprocal.rs:109)
+    and ArithmeticCircuit::prove / verify (circuit.rs:260,154) in the generic device code: proofs byte-identical to the Python
+    oracle's on transcripts that already hold per-instance context (different sponge positions), advanced states equal."""
+    import ctypes as C
+    import generic_transcript_cases as GC
+    import ref_fixture_check as RC
+    L = load()
+    W = 4
+    # ---- wnla prover (3 rounds) and its base case (no rounds: the transcript is not touched)
+    for kw in (dict(), dict(ng=2, nh=2, B=2)):
+        case = GC.wnla_case(**kw)
+        B, ng, nh = case["commitments"].shape[0], case["ng"], case["nh"]
+        tab = _table(L, case["g"] + b"".join(case["gv"]) + b"".join(case["hv"]), 1 + ng + nh)
+        pr, px = np.zeros((B, max(case["rounds"], 1), 64), np.uint8), np.zeros((B, max(case["rounds"], 1), 64), np.uint8)
+        pl, pn = np.zeros((B, case["nl"], 32), np.uint8), np.zeros((B, case["nn"], 32), np.uint8)
+        st, out = np.zeros(B, np.int32), np.zeros((B, 203), np.uint8)
+        r, a, b = C.c_int(), C.c_int(), C.c_int()
+        l, n = case["l"].reshape(B, -1, 32), case["n"].reshape(B, -1, 32)
+        L.emul_set_transcripts(case["states_in"].ctypes.data, B, out.ctypes.data)
+        L.emul_wnla_prove(tab.ctypes.data, W, ng, nh, b"", 0, B, case["commitments"].ctypes.data, case["c"].ctypes.data, case["rho"].ctypes.data,
+                          case["mu"].ctypes.data, l.ctypes.data, l.shape[1], n.ctypes.data, n.shape[1], pr.ctypes.data, px.ctypes.data,
+                          pl.ctypes.data, pn.ctypes.data, st.ctypes.data, C.byref(r), C.byref(a), C.byref(b))
+        assert (r.value, a.value, b.value) == (case["rounds"], case["nl"], case["nn"]) and not st.any()
+        if case["rounds"]:
+            assert pr.tobytes() == case["proof_r"].tobytes() and px.tobytes() == case["proof_x"].tobytes()
+        assert pl.tobytes() == case["proof_l"].tobytes() and pn.tobytes() == case["proof_n"].tobytes()
+        assert (out == case["states_after_prove"]).all()
+    # ---- reciprocal prover at the u64 dimensions on the oracle-made document (two of its cases carry context)
+    doc = RC.oracle_made_document(4)
+    cs = doc["cases"]
+    n = len(cs)
+    u8 = lambda key, *sh: np.frombuffer(b"".join(bytes.fromhex(c[key]) for c in cs), dtype=np.uint8).reshape(n, *sh).copy()
+    tab = _table(L, bytes.fromhex(doc["generators"]), 49)
+    x, digits, m = GC.recip_prover_inputs(doc)
+    V, s, rnd, S = u8("commitment", 64), u8("s", 32), u8("rnd", 52, 32), u8("state_before", 203)
+    proofs, st, out = np.zeros((n, 928), np.uint8), np.zeros(n, np.int32), np.zeros((n, 203), np.uint8)
+    L.emul_set_transcripts(S.ctypes.data, n, out.ctypes.data)
+    rc = L.emul_recip_prove(tab.ctypes.data, W, 16, 32, 16, 16, b"", 0, n, V.ctypes.data, x.ctypes.data, s.ctypes.data, digits.ctypes.data,
+                            m.ctypes.data, rnd.ctypes.data, proofs.ctypes.data, st.ctypes.data)
+    assert rc == 928 and not st.any() and (proofs == u8("proof", 928)).all() and (out == u8("state_after_prove", 203)).all()
+    # ---- generic circuit: prove, then verify the proofs, both over the pre-loaded transcripts
+    case = GC.circuit_case()
+    B, p = case["commitments"].shape[0], case["parts"]
+    gens = case["g"] + b"".join(case["gv"] + case["gv_"] + case["hv"] + case["hv_"])
+    tab = _table(L, gens, 1 + case["NG"] + case["NH"])
+    dims = (C.c_size_t * 6)(case["nm"], case["no"], case["k"], case["nl"], case["nv"], case["nw"])
+    proofs, st, out = np.zeros_like(case["proofs"]), np.zeros(B, np.int32), np.zeros((B, 203), np.uint8)
+    L.emul_set_transcripts(case["states_in"].ctypes.data, B, out.ctypes.data)
+    rc = L.emul_circuit_prove(tab.ctypes.data, W, case["NG"], case["NH"], dims, int(case["f_l"]), int(case["f_m"]), case["Wm_bytes"],
+                              case["Wl_bytes"], case["am_bytes"], case["al_bytes"], p["LO"].ctypes.data, p["LL"].ctypes.data, p["LR"].ctypes.data,
+                              p["NO"].ctypes.data, b"", 0, B, case["commitments"].ctypes.data, case["v_bytes"].ctypes.data, case["s_v"].ctypes.data,
+                              case["wl_bytes"].ctypes.data, case["wr_bytes"].ctypes.data, case["wo_bytes"].ctypes.data, case["rnd"].ctypes.data,
+                              proofs.ctypes.data, st.ctypes.data)
+    assert rc == proofs.shape[1] and not st.any() and (proofs == case["proofs"]).all() and (out == case["states_after_prove"]).all()
+    acc, st, out = np.zeros(B, np.uint8), np.zeros(B, np.int32), np.zeros((B, 203), np.uint8)
+    L.emul_set_transcripts(case["states_in"].ctypes.data, B, out.ctypes.data)
+    rc = L.emul_circuit_verify(tab.ctypes.data, W, case["NG"], case["NH"], dims, int(case["f_l"]), int(case["f_m"]), case["Wm_bytes"],
+                               case["Wl_bytes"], case["am_bytes"], case["al_bytes"], p["LO"].ctypes.data, p["LL"].ctypes.data, p["LR"].ctypes.data,
+                               p["NO"].ctypes.data, b"", 0, B, case["commitments"].ctypes.data, proofs.ctypes.data, case["rounds"], case["pl"],
+                               case["pn"], acc.ctypes.data, st.ctypes.data, None, None)
+    assert rc == 0 and acc.tolist() == [1] * B and not st.any() and (out == case["states_after_verify"]).all()
