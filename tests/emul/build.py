@@ -6,14 +6,18 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SO = os.path.join(HERE, "libbppp_emul.so")
+# BPPP_EMUL_SANITIZE=1: AddressSanitizer + UBSan build of the same translation unit (tools/sanitize_emul.sh preloads libasan and
+# runs the emulation tests on it) -- the device code's indexing and integer arithmetic checked on the CPU, where sanitizers exist
+SANITIZE = os.environ.get("BPPP_EMUL_SANITIZE") == "1"
+SO = os.path.join(HERE, "libbppp_emul_san.so" if SANITIZE else "libbppp_emul.so")
 
 
 def load():
     src = os.path.join(HERE, "bppp_emul.cpp")
     deps = [src] + glob.glob(os.path.join(ROOT, "bp_pp_amd", "csrc", "*.h"))
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-std=c++17", "-o", SO, src])
+        flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"] if SANITIZE else ["-O2"]
+        subprocess.check_call(["g++", *flags, "-shared", "-fPIC", "-std=c++17", "-o", SO, src])
     L = C.CDLL(SO)
     vp, sz, i32, cp = C.c_void_p, C.c_size_t, C.c_int, C.c_char_p
     L.emul_fb_table_entries.restype = sz
