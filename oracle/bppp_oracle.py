@@ -26,8 +26,13 @@ and cannot be built here (no cargo/rustc, k256/merlin not vendored).  What IS
 pinned: secp256k1 public known answers (G, 2G, n*G = identity, lambda*G = (beta*x, y)),
 Keccak-f via hashlib.sha3_256, the upstream Merlin known-answer test
 ("test protocol"/"some label"/"some data"/"challenge" ->
-d5a21972...cf0615), and the reference's completeness property (honest prove =>
-verify true) on the three shapes of src/tests.rs.  See tests/test_oracle.py.
+d5a21972...cf0615), the curve layer against an implementation that shares nothing
+with this repository -- OpenSSL's secp256k1: k*G (affine and 33-byte SEC1) and x(k*P)
+for 65 seeded and edge-case scalars, tests/golden/openssl_secp256k1.json,
+tests/test_openssl_vectors.py -- and the reference's completeness property (honest
+prove => verify true) on the three shapes of src/tests.rs.  See tests/test_oracle.py.
+What stays unpinned is the PROTOCOL layer above k256 / merlin (the reference's own
+Rust): facade/src/bin/gen_fixtures.rs is the hook that closes it on a machine with cargo.
 """
 from __future__ import annotations
 

@@ -18,7 +18,8 @@
  * SEC1, Keccak-f[1600], STROBE-128, Merlin.
  *
  * PARITY STATUS: parity unpinned against the reference itself (it has no golden vectors
- * and cannot be built here).  Pinned to: secp256k1 + Merlin public known answers and,
+ * and cannot be built here).  Pinned to: secp256k1 + Merlin public known answers, OpenSSL's
+ * secp256k1 for the curve layer (tests/golden/openssl_secp256k1.json, tests/test_openssl_vectors.py) and,
  * byte for byte, to the independent Python big-int oracle (oracle/bppp_oracle.py) on the
  * committed fixtures under tests/golden/ (tests/test_oracle_c.py).
  *
