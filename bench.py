@@ -283,10 +283,13 @@ def run_verify(args):
             full = {}
             for name, chunk in (("pipelined", 1 << 17), ("upload_first", 0)):
                 proto.set_option("host_chunk", chunk)
-                proto.verify_batch(Vh[: 1 << 18], Ph[: 1 << 18], workload.LABEL)
-                t_h = time.perf_counter()
-                hacc, _ = proto.verify_batch(Vh, Ph, workload.LABEL)
-                t_h = time.perf_counter() - t_h
+                proto.verify_batch(Vh, Ph, workload.LABEL)          # untimed: grows the context's staging buffers to this size
+                t_h = None
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    hacc, _ = proto.verify_batch(Vh, Ph, workload.LABEL)
+                    t0 = time.perf_counter() - t0
+                    t_h = t0 if t_h is None else min(t_h, t0)
                 full[name] = {"value": n / t_h, "ms_per_batch": t_h * 1e3, "accept_bits_ok": bool((hacc == expect).all())}
             proto.set_option("host_chunk", 1 << 17)
             host_path["full_batch"] = dict(full, proofs=n, unit="verifies/s")
