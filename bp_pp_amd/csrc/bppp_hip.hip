@@ -43,6 +43,7 @@ enum KernelId {
     K_PROVE_STAGES, K_PROVE_MSM, K_PROVE_ROUND_SCALARS, K_PROVE_ROUND_FOLD,
     // generic reciprocal / WNLA verifier
     K_RECIP_PHASE1, K_RECIP_C0_FIXED, K_RECIP_C0_VAR, K_RECIP_C0_FINISH, K_WNLA_BEGIN, K_WNLA_ROUND, K_WNLA_FINAL_SCALARS, K_WNLA_MSM, K_WNLA_ACCEPT,
+    K_WNLA_RLC_LHS, K_WNLA_RLC_CHUNK, K_WNLA_RLC_CHECK,
     K_COUNT
 };
 static const char* const kKernelNames[K_COUNT] = {
@@ -50,7 +51,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "k_verify_accept", "k_verify_tables", "k_rlc_lhs", "k_rlc_chunk", "k_bkt_prepare", "k_bkt_accumulate", "k_bkt_scalars", "k_bkt_check",
     "k_prove_stage_*", "k_prove_msm", "k_prove_round_scalars", "k_prove_round_fold",
     "k_recip_phase1", "k_recip_c0_fixed", "k_recip_c0_var", "k_recip_c0_finish", "k_wnla_begin", "k_wnla_round", "k_wnla_final_scalars",
-    "k_wnla_msm", "k_wnla_accept"};
+    "k_wnla_msm", "k_wnla_accept", "k_wnla_rlc_lhs", "k_wnla_rlc_chunk", "k_wnla_rlc_check"};
 
 static size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 
@@ -1167,19 +1168,20 @@ int bppp_wnla_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* stat
 // ---- generic ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) on a context built by bppp_wnla_ctx_create over
 //      g, g_vec || g_vec_, h_vec || h_vec_
 // workspace bytes (beyond the caller's commitments / proofs / accept / status) of one reciprocal verify call
-static size_t recip_verify_ws_bytes(const bppp_ctx* c, size_t n, size_t dim_nd, size_t dim_np, size_t rounds) {
+static size_t recip_verify_ws_bytes(const bppp_ctx* c, size_t n, size_t dim_nd, size_t dim_np, size_t rounds, bool rlc = false) {
     const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh;
     size_t off = 0;
     auto take = [&](size_t bytes) { off = align16(off + bytes); };
     take(52 * n * 4); take((dim_nd + 6) * 8 * n * 4); take(5 * 16 * n * 4); take(30 * n * 4); take(30 * n * 4); take(dim_np * 8 * n * 4);
     take(n * 64); take(n * NH * 32); take(n * 32); take(n * 32); take((rounds ? rounds : 1) * 8 * n * 4); take(2 * T * 8 * n * 4);
     take(NB * 8 * n * 4);
+    if (rlc) { take(30 * n * 4); take(NB * 8 * n * 4); take((n + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK); take(((n + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK + 4) * 4); }
     return off;
 }
 // the launch sequence, every buffer in device memory; d_ws holds recip_verify_ws_bytes()
 static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                     const uint8_t* d_com, const uint8_t* d_proofs, size_t rounds, size_t nl, size_t nn, uint8_t* d_acc,
-                                    int32_t* d_st, uint8_t* d_ws, const TranscriptIo* dtio = nullptr) {
+                                    int32_t* d_st, uint8_t* d_ws, const TranscriptIo* dtio = nullptr, const uint8_t* rlc_seed = nullptr) {
     const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh;
     const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
     size_t off = 0;
@@ -1187,6 +1189,9 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     const size_t o_ts = take(52 * n * 4), o_sc0 = take((dim_nd + 6) * 8 * n * 4), o_pts = take(5 * 16 * n * 4), o_a = take(30 * n * 4),
                  o_pf = take(30 * n * 4), o_inv = take(dim_np * 8 * n * 4), o_wc = take(n * 64), o_wcv = take(n * NH * 32), o_rho = take(n * 32),
                  o_mu = take(n * 32), o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4), o_msc = take(NB * 8 * n * 4);
+    const size_t nchunks = (n + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    const size_t o_rl = rlc_seed ? take(30 * n * 4) : 0, o_rs = rlc_seed ? take(NB * 8 * n * 4) : 0, o_rf = rlc_seed ? take(nchunks) : 0,
+                 o_rli = rlc_seed ? take((nchunks + 4) * 4) : 0;
     uint8_t* d = d_ws;
     hipStream_t s = c->stream;
     RecipWs r;
@@ -1229,8 +1234,31 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     GLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     for (int k = 1; k <= (int)rounds; k++) GLAUNCH(K_WNLA_ROUND, k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
     GLAUNCH(K_WNLA_FINAL_SCALARS, k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-    GLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
-    GLAUNCH(K_WNLA_ACCEPT, k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (!rlc_seed) {
+        GLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
+        GLAUNCH(K_WNLA_ACCEPT, k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    } else {
+        // one MSM per chunk of 8 instances instead of one per instance; what does not pass is re-checked exactly (wnla_rlc_core.h)
+        RlcWs rl;
+        std::memset(&rl, 0, sizeof rl);
+        for (int i = 0; i < 4; i++) {
+            u64 v = 0;
+            for (int k = 0; k < 8; k++) v |= (u64)rlc_seed[8 * i + k] << (8 * k);
+            rl.seed[i] = v;
+        }
+        rl.lhs = (u32*)(d + o_rl); rl.sc = (u32*)(d + o_rs); rl.flag = d + o_rf;
+        rl.list = (u32*)(d + o_rli); rl.count = (int*)(rl.list + nchunks + 1);
+        const unsigned chunk_blocks = (unsigned)((nchunks * BPPP_RLC_CHUNK + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+        const unsigned check_blocks = (unsigned)(nchunks < 16384 ? nchunks : 16384);
+        HIP_TRY(hipMemsetAsync(d_acc, 0, n, s));
+        HIP_TRY(hipMemsetAsync(rl.count, 0, sizeof(int), s));
+        GLAUNCH(K_WNLA_RLC_LHS, k_wnla_rlc_lhs<<<blocks, BPPP_BLOCK, 0, s>>>(w, rl));
+        GLAUNCH(K_WNLA_RLC_CHUNK, k_wnla_rlc_chunk<<<chunk_blocks, BPPP_FB_BLOCK, 0, s>>>(w, rl));
+        GLAUNCH(K_WNLA_RLC_CHECK, k_wnla_rlc_check<<<check_blocks, 64, 0, s>>>(w, rl));
+        GLAUNCH(K_WNLA_MSM, k_wnla_msm_flagged<<<1024, 64, 0, s>>>(w, rl));
+        GLAUNCH(K_WNLA_MSM, k_wnla_msm_flagged_dense<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, rl));
+        GLAUNCH(K_WNLA_ACCEPT, k_wnla_accept_flagged<<<blocks, BPPP_BLOCK, 0, s>>>(w, rl));
+    }
     if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
 #undef GLAUNCH
     HIP_TRY(hipGetLastError());
@@ -1242,10 +1270,9 @@ static int recip_verify_check_args(const bppp_ctx* c, size_t dim_nd, size_t dim_
         return BPPP_ERR_INVALID_ARG;
     return BPPP_OK;
 }
-int bppp_reciprocal_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
-                                        const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn,
-                                        void* d_accept, void* d_status) {
-    CtxLock lock_(c);
+static int recip_verify_device_entry(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                     const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn, void* d_accept,
+                                     void* d_status, const uint8_t* rlc_seed) {
     if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept || !d_status) return BPPP_ERR_INVALID_ARG;
     int rc = recip_verify_check_args(c, dim_nd, dim_np, rounds, nl, nn);
     if (rc != BPPP_OK) return rc;
@@ -1254,18 +1281,38 @@ int bppp_reciprocal_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_
     rc = ensure_straus_capacity(c, n);
     if (rc != BPPP_OK) return rc;
     // persistent, grow-only workspace (the host-pointer entry point allocates per call instead)
-    const size_t need = recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds);
+    const size_t need = recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds, rlc_seed != nullptr);
     if (need > c->gws_bytes) {
         if (c->d_gws) { (void)hipFree(c->d_gws); c->d_gws = nullptr; c->gws_bytes = 0; }
         HIP_TRY(hipMalloc(&c->d_gws, need));
         c->gws_bytes = need;
     }
     return recip_verify_device_impl(c, label, label_len, n, dim_nd, dim_np, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, rounds, nl,
-                                    nn, (uint8_t*)d_accept, (int32_t*)d_status, c->d_gws);
+                                    nn, (uint8_t*)d_accept, (int32_t*)d_status, c->d_gws, nullptr, rlc_seed);
+}
+int bppp_reciprocal_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                        const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn,
+                                        void* d_accept, void* d_status) {
+    CtxLock lock_(c);
+    return recip_verify_device_entry(c, label, label_len, n, dim_nd, dim_np, d_commitments, d_proofs, rounds, nl, nn, d_accept, d_status, nullptr);
+}
+int bppp_reciprocal_verify_batch_rlc_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                            const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn,
+                                            void* d_accept, void* d_status, const uint8_t seed[32]) {
+    CtxLock lock_(c);
+    if (!seed) return BPPP_ERR_INVALID_ARG;
+    return recip_verify_device_entry(c, label, label_len, n, dim_nd, dim_np, d_commitments, d_proofs, rounds, nl, nn, d_accept, d_status, seed);
 }
 static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                   const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
-                                  int32_t* status, const HostTranscripts* tx);
+                                  int32_t* status, const HostTranscripts* tx, const uint8_t* rlc_seed = nullptr);
+int bppp_reciprocal_verify_batch_rlc(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                     const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                     int32_t* status, const uint8_t seed[32]) {
+    CtxLock lock_(c);
+    if (!seed) return BPPP_ERR_INVALID_ARG;
+    return recip_verify_host_impl(c, label, label_len, n, dim_nd, dim_np, commitments, proofs, rounds, nl, nn, accept, status, nullptr, seed);
+}
 int bppp_reciprocal_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                  const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
                                  int32_t* status) {
@@ -1282,7 +1329,7 @@ int bppp_reciprocal_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t
 }
 static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                   const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
-                                  int32_t* status, const HostTranscripts* tx) {
+                                  int32_t* status, const HostTranscripts* tx, const uint8_t* rlc_seed) {
     if (!c || (!label && label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
     int rc = recip_verify_check_args(c, dim_nd, dim_np, rounds, nl, nn);
     if (rc != BPPP_OK) return rc;
@@ -1295,7 +1342,8 @@ static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t labe
     const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
     const size_t o_com = 0, o_pr = align16(n * 64), o_acc = align16(o_pr + n * proof_bytes), o_st = align16(o_acc + n),
                  o_ti = align16(o_st + n * 4), o_to = align16(o_ti + (tx ? tx->n_states * 203 : 0)),
-                 o_ws = align16(o_to + (tx && tx->states_out ? n * 203 : 0)), total = o_ws + recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds);
+                 o_ws = align16(o_to + (tx && tx->states_out ? n * 203 : 0)),
+                 total = o_ws + recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds, rlc_seed != nullptr);
     WnlaBlob blob;
     HIP_TRY(hipMalloc(&blob.d, total));
     uint8_t* d = blob.d;
@@ -1308,7 +1356,7 @@ static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t labe
         dtio.states = d + o_ti; dtio.n_states = tx->n_states; dtio.states_out = tx->states_out ? d + o_to : nullptr;
     }
     rc = recip_verify_device_impl(c, label, label_len, n, dim_nd, dim_np, d + o_com, d + o_pr, rounds, nl, nn, d + o_acc, (int32_t*)(d + o_st),
-                                  d + o_ws, tx ? &dtio : nullptr);
+                                  d + o_ws, tx ? &dtio : nullptr, rlc_seed);
     if (rc != BPPP_OK) return rc;
     if (dtio.states_out) HIP_TRY(hipMemcpyAsync(tx->states_out, d + o_to, n * 203, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));

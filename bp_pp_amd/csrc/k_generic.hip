@@ -54,6 +54,108 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) wnla_verify_accept(w, t);
 }
+// ---- random-linear-combination mode of the final MSM (wnla_rlc_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_rlc_lhs(WnlaWs w, RlcWs r) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N && w.status[t] == ST_OK) wnla_rlc_lhs(w, r, t);
+}
+// combined scalars: one lane group (8 lanes) per chunk of 8 instances, lane j owns instance j's weight; A_i = sum_j w_j s_ji is
+// summed across the group with shuffles and stored once per chunk (at the chunk's first instance)
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_rlc_chunk(WnlaWs w, RlcWs r) {
+    const size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    const size_t chunk = g / BPPP_RLC_CHUNK;
+    const int lane = (int)(g % BPPP_RLC_CHUNK);
+    const size_t N = w.N, nchunks = (N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    if (chunk >= nchunks) return;            // whole lane groups leave together
+    const size_t first = chunk * BPPP_RLC_CHUNK, t = first + lane;
+    int bad = (t < N) ? (w.status[t] != ST_OK) : 1;
+#pragma unroll
+    for (int m = 1; m < BPPP_RLC_CHUNK; m <<= 1) bad |= __shfl_xor(bad, m, 64);
+    if (bad) {                               // incomplete chunk or a flagged instance: the exact kernels take it
+        if (lane == 0) { r.flag[chunk] = 1; r.list[atomicAdd(r.count, 1)] = (u32)chunk; }
+        return;
+    }
+    if (lane == 0) r.flag[chunk] = 2;        // pending: k_wnla_rlc_check decides
+    u64 a, b;
+    rlc_weight(a, b, r, t);
+    sc wt;
+    rlc_weight_scalar(wt, a, b);
+    const int NB = 1 + w.ng + w.nh;
+#pragma nounroll
+    for (int i = 0; i < NB; i++) {
+        sc s, p;
+        ws_ld8(s.v, w.msc, N, t, i);
+        sc_mul(p, s, wt);
+#pragma unroll
+        for (int m = 1; m < BPPP_RLC_CHUNK; m <<= 1) {
+            sc o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) o.v[k] = __shfl_xor(p.v[k], m, 64);
+            sc_add(p, p, o);
+        }
+        if (lane == 0) ws_st8(r.sc, N, first, i, p.v);
+    }
+}
+// the chunk's MSM and verdict: a whole wavefront per chunk (the 1 + ng + nh bases x windows dealt over 64 lanes, 6-step tree) --
+// there are only N / 8 chunks, and an 8-lane group per chunk would leave most SIMDs without a wavefront
+__global__ __launch_bounds__(64) void k_wnla_rlc_check(WnlaWs w, RlcWs r) {
+    const int lane = (int)threadIdx.x;
+    const size_t N = w.N, nchunks = (N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+#pragma nounroll
+    for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (r.flag[chunk] != 2) continue;
+        const size_t first = chunk * BPPP_RLC_CHUNK;
+        FbRanges rg;
+        wnla_msm_ranges(rg, w);
+        pt rhs, lhs, L;
+        fb_group_sum<64>(rhs, w.fb, first, lane, r.sc, rg);
+        pt_set_identity(lhs);
+#pragma nounroll
+        for (int l = 0; l < BPPP_RLC_CHUNK; l++) { ws_ld_pt(L, r.lhs, N, first + l); pt_add(lhs, lhs, L); }
+        const bool ok = pt_eq(lhs, rhs);
+        if (ok && lane < BPPP_RLC_CHUNK) w.accept[first + lane] = 1;
+        if (lane == 0) {
+            r.flag[chunk] = ok ? 0 : 1;
+            if (!ok) r.list[atomicAdd(r.count, 1)] = (u32)chunk;
+        }
+    }
+}
+// the exact final MSM for the instances of the chunks that did not pass: a whole wavefront per instance from the compacted list
+// (only a few are expected) ...
+__global__ __launch_bounds__(64) void k_wnla_msm_flagged(WnlaWs w, RlcWs r) {
+    const int lane = (int)threadIdx.x;
+    const size_t nchunks = (w.N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    if ((size_t)(*r.count) * 8 > nchunks) return;   // many flagged chunks: k_wnla_msm_flagged_dense does them
+    const size_t items = (size_t)(*r.count) * BPPP_RLC_CHUNK;
+#pragma nounroll
+    for (size_t item = blockIdx.x; item < items; item += gridDim.x) {
+        const size_t t = (size_t)r.list[item / BPPP_RLC_CHUNK] * BPPP_RLC_CHUNK + item % BPPP_RLC_CHUNK;
+        if (t >= w.N) continue;
+        pt part;
+        FbRanges rg;
+        wnla_msm_ranges(rg, w);
+        fb_group_sum<64>(part, w.fb, t, lane, w.msc, rg);
+        if (lane == 0) wnla_verify_store(w, t, part);
+    }
+}
+// ... and the regular 8-lane kernel, skipping the chunks that passed, when more than 1/8 of the chunks failed (a broken input stream)
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm_flagged_dense(WnlaWs w, RlcWs r) {
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    const size_t nchunks = (w.N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    if ((size_t)(*r.count) * 8 <= nchunks) return;
+    if (t >= w.N || !r.flag[t / BPPP_RLC_CHUNK]) return;
+    pt part;
+    FbRanges rg;
+    wnla_msm_ranges(rg, w);
+    fb_group_sum(part, w.fb, t, lane, w.msc, rg);
+    if (lane == 0) wnla_verify_store(w, t, part);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept_flagged(WnlaWs w, RlcWs r) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N && r.flag[t / BPPP_RLC_CHUNK]) wnla_verify_accept(w, t);
+}
 __global__ __launch_bounds__(BPPP_BLOCK) void k_msm_scalars(MsmWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= w.N) return;

@@ -10,6 +10,7 @@
 #include "recip_prove_core.h"
 #include "bucket_core.h"
 #include "rlc_core.h"
+#include "wnla_rlc_core.h"
 #include "wnla_prove_core.h"
 
 #define BPPP_BLOCK 64
@@ -103,6 +104,12 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_scalars(bppp::WnlaWs
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round(bppp::WnlaWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_generic_export_states(bppp::WnlaWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_rlc_lhs(bppp::WnlaWs w, bppp::RlcWs r);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_rlc_chunk(bppp::WnlaWs w, bppp::RlcWs r);
+__global__ __launch_bounds__(64) void k_wnla_rlc_check(bppp::WnlaWs w, bppp::RlcWs r);
+__global__ __launch_bounds__(64) void k_wnla_msm_flagged(bppp::WnlaWs w, bppp::RlcWs r);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm_flagged_dense(bppp::WnlaWs w, bppp::RlcWs r);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept_flagged(bppp::WnlaWs w, bppp::RlcWs r);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(bppp::WnlaWs w, int commit_mode);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(bppp::WnlaWs w);

@@ -56,15 +56,9 @@ HD void rlc_weight_scalar(sc& w, u64 a, u64 b) {
     sc_mul(w, bs, lam);
     sc_add(w, w, as);
 }
-// L_j = a C4 + b phi(C4): projective window table of C4 (complete formulas), 17 signed 4-bit windows, 64 doublings
-HD void rlc_lhs(const VerifyWs& ws, const RlcWs& r, size_t t) {
-    const size_t N = ws.N;
-    u64 a, b;
-    rlc_weight(a, b, r, t);
-    pt C;
-    ws_ld_pt(C, ws.acc, N, t);
-    pt_slot* tbl = ws.straus + t * (5 * BPPP_STRAUS_ENTRIES);
-    {   // tbl[e] = e C4, e = 0..8
+// out = a C + b phi(C): projective window table of C in tbl[0..8] (complete formulas), 17 signed 4-bit windows, 64 doublings
+HD void rlc_weighted_point(pt& out, pt C, pt_slot* tbl, u64 a, u64 b) {
+    {   // tbl[e] = e C, e = 0..8
         pt cur;
         pt_set_identity(cur);
         tbl[0].p = cur;
@@ -115,7 +109,17 @@ HD void rlc_lhs(const VerifyWs& ws, const RlcWs& r, size_t t) {
             pt_add(acc, acc, q);
         }
     }
-    ws_st_pt(r.lhs, N, t, acc);
+    out = acc;
+}
+// L_j = a_j C4_j + b_j phi(C4_j)
+HD void rlc_lhs(const VerifyWs& ws, const RlcWs& r, size_t t) {
+    const size_t N = ws.N;
+    u64 a, b;
+    rlc_weight(a, b, r, t);
+    pt C, L;
+    ws_ld_pt(C, ws.acc, N, t);
+    rlc_weighted_point(L, C, ws.straus + t * (5 * BPPP_STRAUS_ENTRIES), a, b);
+    ws_st_pt(r.lhs, N, t, L);
 }
 // scalar side, lane work: P_i = w_j s_ji for proof j (i = 0..48)
 HD void rlc_product(sc& out, const VerifyWs& ws, const sc& w, size_t t, int i) {

@@ -198,6 +198,27 @@ class ReciprocalRangeProofProtocol:
         _capi.check(_capi.lib().bppp_reciprocal_verify_batch_device(self._w._ctx, label, len(label), n, self.dim_nd, self.dim_np,
                                                                     d_commitments, d_proofs, rounds, nl, nn, d_accept, d_status))
 
+    def verify_batch_rlc(self, label: bytes, commitments, proofs, rounds: int, nl: int, nn: int, seed: bytes):
+        """verify_batch in the optional random-linear-combination mode (include/bppp.h: bppp_reciprocal_verify_batch_rlc): one final MSM
+        per chunk of 8 instances; accept / status stay per instance."""
+        if len(seed) != 32:
+            raise ValueError("seed must be 32 bytes")
+        commitments = _u8(commitments, (-1, 64))
+        B = commitments.shape[0]
+        proofs = _u8(proofs, (B, 64 * (5 + 2 * rounds) + 32 * (nl + nn)))
+        acc, st = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        _capi.check(_capi.lib().bppp_reciprocal_verify_batch_rlc(self._w._ctx, label, len(label), B, self.dim_nd, self.dim_np,
+                                                                 commitments.ctypes.data, proofs.ctypes.data, rounds, nl, nn,
+                                                                 acc.ctypes.data, st.ctypes.data, seed))
+        return acc, st
+
+    def verify_batch_rlc_device(self, label: bytes, n: int, d_commitments: int, d_proofs: int, rounds: int, nl: int, nn: int, d_accept: int,
+                                d_status: int, seed: bytes) -> None:
+        if len(seed) != 32:
+            raise ValueError("seed must be 32 bytes")
+        _capi.check(_capi.lib().bppp_reciprocal_verify_batch_rlc_device(self._w._ctx, label, len(label), n, self.dim_nd, self.dim_np,
+                                                                        d_commitments, d_proofs, rounds, nl, nn, d_accept, d_status, seed))
+
     def synchronize(self) -> None:
         _capi.check(_capi.lib().bppp_ctx_synchronize(self._w._ctx))
 

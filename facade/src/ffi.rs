@@ -75,6 +75,8 @@ extern "C" {
     pub fn bppp_u64_verify_batch_sharded(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, commitments: *const u8, proofs: *const u8, accept: *mut u8, status: *mut i32, reject_count: *mut i32) -> c_int;
     pub fn bppp_u64_verify_batch_sharded_device(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, d_commitments: *const *const c_void, d_proofs: *const *const c_void, d_accept: *const *mut c_void, d_status: *const *mut c_void, d_reject_count: *const *mut c_void) -> c_int;
     pub fn bppp_reciprocal_verify_batch_device(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, d_commitments: *const c_void, d_proofs: *const c_void, rounds: usize, nl: usize, nn: usize, d_accept: *mut c_void, d_status: *mut c_void) -> c_int;
+    pub fn bppp_reciprocal_verify_batch_rlc(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, commitments: *const u8, proofs: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32, seed: *const u8) -> c_int;
+    pub fn bppp_reciprocal_verify_batch_rlc_device(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, d_commitments: *const c_void, d_proofs: *const c_void, rounds: usize, nl: usize, nn: usize, d_accept: *mut c_void, d_status: *mut c_void, seed: *const u8) -> c_int;
     pub fn bppp_ctx_enable_timing(ctx: *mut BpppCtx, enable: c_int) -> c_int;
     pub fn bppp_ctx_get_timings(ctx: *mut BpppCtx, max_entries: c_int, names: *mut *const c_char, total_ms: *mut f64, launches: *mut i64, reset: c_int) -> c_int;
     pub fn bppp_ctx_device_bytes(ctx: *const BpppCtx) -> usize;

@@ -363,6 +363,16 @@ BPPP_API int bppp_u64_verify_batch_sharded_device(bppp_group* grp, const uint8_t
 BPPP_API int bppp_reciprocal_verify_batch_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd,
                                                  size_t dim_np, const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl,
                                                  size_t nn, void* d_accept, void* d_status);
+/* The optional random-linear-combination mode (as bppp_u64_verify_batch_rlc above) for the reciprocal verifier at any dimensions:
+ * the final MSM over all 1 + |g_vec| + |h_vec| generators -- 769 bases for BASELINE configs[4]'s shape, about half of that
+ * verifier's time -- is done once per chunk of 8 instances on secretly weighted sums; chunks that do not pass are re-checked
+ * exactly, so accept / status stay per instance.  seed: 32 unpredictable bytes chosen after the proofs are fixed. */
+BPPP_API int bppp_reciprocal_verify_batch_rlc(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                              const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn,
+                                              uint8_t* accept, int32_t* status, const uint8_t seed[32]);
+BPPP_API int bppp_reciprocal_verify_batch_rlc_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd,
+                                                     size_t dim_np, const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl,
+                                                     size_t nn, void* d_accept, void* d_status, const uint8_t seed[32]);
 
 /* Profiling aid for bench.py: when enabled, every kernel launch of the verify pipeline is bracketed by HIP events on
  * the context's stream; bppp_ctx_get_timings returns accumulated milliseconds and launch counts per kernel since the

@@ -11,6 +11,7 @@
 #include "../../bp_pp_amd/csrc/recip_core.h"
 #include "../../bp_pp_amd/csrc/bucket_core.h"
 #include "../../bp_pp_amd/csrc/rlc_core.h"
+#include "../../bp_pp_amd/csrc/wnla_rlc_core.h"
 #include "../../bp_pp_amd/csrc/wnla_prove_core.h"
 #include "../../bp_pp_amd/csrc/circuit_prove_core.h"
 #include "../../bp_pp_amd/csrc/recip_prove_core.h"
@@ -461,6 +462,10 @@ void emul_sec1_expand(size_t n, const uint8_t* c33, const uint8_t* p525, uint8_t
 // Pre-loaded transcripts for the NEXT generic verify call (emul_wnla_run / emul_recip_verify / emul_circuit_verify): states in
 // (n_states = 1 or n), per-instance advanced states out; consumed by that call.
 static TranscriptIo g_tio = {nullptr, 0, nullptr, 0};
+// random-linear-combination mode for the NEXT emul_recip_verify call (consumed by it); flags_out: 1 per chunk of 8 re-checked exactly
+static const uint8_t* g_rlc_seed = nullptr;
+static uint8_t* g_rlc_flags = nullptr;
+void emul_set_rlc(const uint8_t* seed32, uint8_t* flags_out) { g_rlc_seed = seed32; g_rlc_flags = flags_out; }
 void emul_set_transcripts(const uint8_t* states, size_t n_states, uint8_t* states_out) {
     g_tio.states = states; g_tio.n_states = n_states; g_tio.states_out = states_out;
 }
@@ -550,14 +555,35 @@ int emul_recip_verify(const uint8_t* table, int W, int NG, int NH, int nd, int n
     for (int k = 1; k <= rounds; k++)
         for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, k);
     for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);
+    const uint8_t* seed = g_rlc_seed;
+    uint8_t* flags_out = g_rlc_flags;
+    g_rlc_seed = nullptr; g_rlc_flags = nullptr;
+    const size_t nchunks = (n + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    std::vector<uint8_t> flag(nchunks, 1);
+    std::vector<u32> rl_lhs(30 * n), rl_sc((size_t)NB * 8 * n);
+    if (seed) {     // the kernels' order: weighted commitments, one combined check per chunk, exact re-check of what did not pass
+        RlcWs rl;
+        memset(&rl, 0, sizeof rl);
+        for (int i = 0; i < 4; i++) { u64 v = 0; for (int k = 0; k < 8; k++) v |= (u64)seed[8 * i + k] << (8 * k); rl.seed[i] = v; }
+        rl.lhs = rl_lhs.data(); rl.sc = rl_sc.data(); rl.flag = flag.data();
+        memset(accept, 0, n);
+        for (size_t t = 0; t < n; t++) if (status[t] == ST_OK) wnla_rlc_lhs(w, rl, t);
+        for (size_t ch = 0; ch < nchunks; ch++) {
+            const bool ok = wnla_rlc_chunk_serial(w, rl, ch);
+            flag[ch] = ok ? 0 : 1;
+            if (ok) for (size_t t = ch * BPPP_RLC_CHUNK; t < (ch + 1) * BPPP_RLC_CHUNK; t++) accept[t] = 1;
+        }
+        if (flags_out) memcpy(flags_out, flag.data(), nchunks);
+    }
     for (size_t t = 0; t < n; t++) {
+        if (!flag[t / BPPP_RLC_CHUNK]) continue;
         pt a;
         FbRanges rg;
         wnla_msm_ranges(rg, w);
         fb_sum_serial(a, w.fb, t, w.msc, rg);
         wnla_verify_store(w, t, a);
+        wnla_verify_accept(w, t);
     }
-    for (size_t t = 0; t < n; t++) wnla_verify_accept(w, t);
     for (size_t t = 0; t < n; t++) tio_export(w.tio, w.base, w.tstate, n, w.status, t);
     return 0;
 }

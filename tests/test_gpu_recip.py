@@ -79,3 +79,42 @@ def test_generic_reciprocal_prove_byte_identical_and_verifies(nd, npp, B):
         assert acc.all() and not st.any()
     finally:
         proto.close()
+
+
+@pytest.mark.parametrize("nd,npp,B", [(16, 16, 100), (256, 16, 300)])
+def test_reciprocal_verify_rlc_mode_on_the_gpu(nd, npp, B):
+    """bppp_reciprocal_verify_batch_rlc[_device]: the final MSM once per chunk of 8 instances.  Accept bits and statuses equal exact
+    mode's for clean batches and for tampered / flagged instances spread over several chunks (and a partial last chunk)."""
+    import recip_cases
+    from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    case = recip_cases.make_bulk(nd, npp, B, n_oracle=0) if nd == 256 else recip_cases.make(nd, npp, B, n_oracle=2)
+    proto = ReciprocalRangeProofProtocol(nd, npp, case["g"], case["gv"], case["hv"], case["gv_"], case["hv_"], device=0, fb_window_bits=8)
+    try:
+        com, st = proto.commit_value_batch(case["x"], case["s"])
+        proofs, st, shape = proto.prove_batch(case["label"], com, case["x"], case["s"], case["digits"], case["m"], case["rnd"])
+        assert not st.any()
+        seed = bytes(range(7, 39))
+        acc, st = proto.verify_batch_rlc(case["label"], com, proofs, *shape, seed=seed)
+        assert acc.all() and not st.any()
+        P, V = proofs.copy(), com.copy()
+        bad = [3, 40, 41, B - 1]
+        P[3, -1] ^= 1
+        P[40, 70] ^= 1                                   # off-curve c_r: flagged
+        V[41] = com[42]
+        P[B - 1, 192:256] = P[B - 1, 0:64]
+        acc0, st0 = proto.verify_batch(case["label"], V, P, *shape)
+        acc1, st1 = proto.verify_batch_rlc(case["label"], V, P, *shape, seed=seed)
+        assert (acc1 == acc0).all() and (st1 == st0).all()
+        assert [i for i in range(B) if not acc1[i]] == bad and st1[40] == 1 and int((st1 != 0).sum()) == 1
+        # device-buffer form, another seed
+        dV, dP = torch.from_numpy(V).cuda(), torch.from_numpy(P).cuda()
+        dA, dS = torch.zeros(B, dtype=torch.uint8, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        proto.verify_batch_rlc_device(case["label"], B, dV.data_ptr(), dP.data_ptr(), *shape, dA.data_ptr(), dS.data_ptr(), bytes(32))
+        proto.synchronize()
+        assert (dA.cpu().numpy() == acc0).all() and (dS.cpu().numpy() == st0).all()
+    finally:
+        proto.close()

@@ -63,3 +63,41 @@ def test_generic_reciprocal_prove_is_byte_identical_to_the_oracle(nd, npp):
                             proofs.ctypes.data, st.ctypes.data)
     assert rc == case["proof_bytes"] and not st.any()
     assert (proofs == case["proofs"]).all()
+
+
+def test_generic_reciprocal_verify_rlc_mode_equals_exact_mode():
+    """The random-linear-combination mode of the generic final MSM (wnla_rlc_core.h) on the device code: 19 instances = two full
+    chunks of 8 and a partial one.  A clean chunk passes its combined check; a chunk with a tampered / flagged instance and the
+    partial chunk are re-checked exactly; accept bits and statuses equal exact mode's and the oracle's."""
+    L = load()
+    nd, npp, B = 8, 4, 19
+    case = recip_cases.make(nd, npp, B=B, n_oracle=B)
+    W = 4
+    gens = case["g"] + b"".join(case["gv"]) + b"".join(case["gv_"]) + b"".join(case["hv"]) + b"".join(case["hv_"])
+    NB = 1 + case["NG"] + case["NH"]
+    tab = np.zeros(L.emul_fb_table_entries(NB, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, NB, W, tab.ctypes.data) == 0
+    seed = bytes(range(100, 132))
+
+    def run(com, proofs, rlc):
+        acc, st, flags = np.zeros(B, np.uint8), np.zeros(B, np.int32), np.full(3, 9, np.uint8)
+        com, proofs = np.ascontiguousarray(com), np.ascontiguousarray(proofs)
+        if rlc:
+            L.emul_set_rlc(seed, flags.ctypes.data)
+        L.emul_recip_verify(tab.ctypes.data, W, case["NG"], case["NH"], nd, npp, case["label"], len(case["label"]), B, com.ctypes.data,
+                            proofs.ctypes.data, case["rounds"], case["nl"], case["nn"], acc.ctypes.data, st.ctypes.data)
+        return acc, st, flags
+
+    acc, st, flags = run(case["commitments"], case["proofs"], True)
+    assert acc.all() and not st.any() and flags.tolist() == [0, 0, 1]        # the partial chunk always goes to the exact check
+    P, com = case["proofs"].copy(), case["commitments"].copy()
+    P[9, -1] ^= 1                                   # n0 of instance 9 (chunk 1)
+    P[12, 70] ^= 1                                  # c_r of instance 12 off the curve (chunk 1): flagged
+    com[17] = case["commitments"][16]               # partial chunk
+    acc0, st0, _ = run(com, P, False)
+    acc1, st1, flags = run(com, P, True)
+    assert (acc1 == acc0).all() and (st1 == st0).all() and flags.tolist() == [0, 1, 1]
+    assert acc1.tolist() == [0 if b in (9, 12, 17) else 1 for b in range(B)] and st1[12] == 1
+    for b in (8, 9, 12, 17, 18):
+        rc = recip_cases.oracle_verify(case, bytes(com[b]), bytes(P[b]))
+        assert int(acc1[b]) == (1 if rc == 1 else 0)
