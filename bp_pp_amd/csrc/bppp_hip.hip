@@ -33,7 +33,8 @@ static thread_local std::string g_last_error;
         hipError_t e_ = (expr);                                                                        \
         if (e_ != hipSuccess) {                                                                        \
             g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
-            return BPPP_ERR_HIP;                                                                       \
+            (void)hipGetLastError(); /* a failed allocation must not poison the next call */          \
+            return e_ == hipErrorOutOfMemory ? BPPP_ERR_NOMEM : BPPP_ERR_HIP;                          \
         }                                                                                              \
     } while (0)
 
@@ -133,9 +134,11 @@ static int ensure_capacity(bppp_ctx* c, size_t n) {
     if (n <= c->cap) return BPPP_OK;
     if (c->d_ws) { (void)hipFree(c->d_ws); c->d_ws = nullptr; }
     c->cap = 0;
+    c->ws_bytes = 0;
     size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
-    c->ws_bytes = cap * WS_WORDS_PER_PROOF * sizeof(u32);
-    HIP_TRY(hipMalloc(&c->d_ws, c->ws_bytes));
+    const size_t bytes = cap * WS_WORDS_PER_PROOF * sizeof(u32);
+    HIP_TRY(hipMalloc(&c->d_ws, bytes));
+    c->ws_bytes = bytes;
     c->cap = cap;
     return BPPP_OK;
 }
@@ -145,9 +148,11 @@ static int ensure_straus_capacity(bppp_ctx* c, size_t n) {
     if (n <= c->scap) return BPPP_OK;
     if (c->d_straus) { (void)hipFree(c->d_straus); c->d_straus = nullptr; }
     c->scap = 0;
+    c->straus_bytes = 0;
     size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
-    c->straus_bytes = cap * 5 * BPPP_STRAUS_ENTRIES * sizeof(pt_slot);
-    HIP_TRY(hipMalloc(&c->d_straus, c->straus_bytes));
+    const size_t bytes = cap * 5 * BPPP_STRAUS_ENTRIES * sizeof(pt_slot);
+    HIP_TRY(hipMalloc(&c->d_straus, bytes));
+    c->straus_bytes = bytes;
     c->scap = cap;
     return BPPP_OK;
 }
@@ -170,9 +175,11 @@ static int ensure_rlc_capacity(bppp_ctx* c, size_t n) {
     if (n <= c->rcap) return BPPP_OK;
     if (c->d_rlc) { (void)hipFree(c->d_rlc); c->d_rlc = nullptr; }
     c->rcap = 0;
+    c->rlc_bytes = 0;
     size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
-    c->rlc_bytes = cap * (30 + (size_t)BPPP_NG * 8) * sizeof(u32) + cap + (cap / BPPP_RLC_CHUNK + 4) * sizeof(u32);   // lhs, sc | flags (cap bytes) | list, count
-    HIP_TRY(hipMalloc(&c->d_rlc, c->rlc_bytes));
+    const size_t rbytes = cap * (30 + (size_t)BPPP_NG * 8) * sizeof(u32) + cap + (cap / BPPP_RLC_CHUNK + 4) * sizeof(u32);   // lhs, sc | flags (cap bytes) | list, count
+    HIP_TRY(hipMalloc(&c->d_rlc, rbytes));
+    c->rlc_bytes = rbytes;
     c->rcap = cap;
     return BPPP_OK;
 }
@@ -198,9 +205,11 @@ static int ensure_prove_capacity(bppp_ctx* c, size_t n) {
     if (n <= c->pcap) return BPPP_OK;
     if (c->d_pws) { (void)hipFree(c->d_pws); c->d_pws = nullptr; }
     c->pcap = 0;
+    c->pws_bytes = 0;
     size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
-    c->pws_bytes = cap * PWS_WORDS_PER_PROOF * sizeof(u32);
-    HIP_TRY(hipMalloc(&c->d_pws, c->pws_bytes));
+    const size_t pbytes = cap * PWS_WORDS_PER_PROOF * sizeof(u32);
+    HIP_TRY(hipMalloc(&c->d_pws, pbytes));
+    c->pws_bytes = pbytes;
     c->pcap = cap;
     return BPPP_OK;
 }

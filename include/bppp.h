@@ -385,7 +385,7 @@ BPPP_API int bppp_ctx_get_timings(bppp_ctx* ctx, int max_entries, const char** n
 BPPP_API size_t bppp_ctx_device_bytes(const bppp_ctx* ctx);
 
 BPPP_API const char* bppp_strerror(int code);
-BPPP_API const char* bppp_last_error(void); /* thread-local detail of the last BPPP_ERR_HIP */
+BPPP_API const char* bppp_last_error(void); /* thread-local detail of the last BPPP_ERR_HIP / BPPP_ERR_NOMEM */
 
 #ifdef __cplusplus
 }

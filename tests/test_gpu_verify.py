@@ -289,3 +289,22 @@ def test_calls_from_several_threads_on_one_context(torch_mod, proto):
     for t in th:
         t.join()
     assert not errors and all(results)
+
+
+def test_a_batch_that_cannot_fit_is_refused_cleanly(torch_mod, proto):
+    """BPPP_ERR_NOMEM (include/bppp.h): with the internal partitioning switched off, 2^27 proofs would need ~0.6 TB of workspace.
+    The call fails before anything is launched, names the error, and the context keeps working."""
+    import workload
+    from bp_pp_amd import _capi
+    torch = torch_mod
+    small = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    try:
+        proto.set_option("max_batch", 1 << 27)
+        with pytest.raises(_capi.BpppError) as ei:
+            proto.verify_batch_device(workload.LABEL, 1 << 27, small.data_ptr(), small.data_ptr(), small.data_ptr(), 0, 0, 0)
+        assert ei.value.code == -5 and "memory" in str(ei.value).lower()
+    finally:
+        proto.set_option("max_batch", 1 << 21)
+    gens, V, P, _ = workload.make_batch(70, first=123)
+    acc, st = proto.verify_batch(V, P, workload.LABEL)
+    assert acc.all() and not st.any()
