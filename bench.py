@@ -103,6 +103,12 @@ def setup_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # diagnostics for a one-GPU box: BENCH_ONE_DEVICE=1 maps every rank to device 0 and BENCH_DIST_BACKEND=gloo replaces RCCL (which
+    # refuses two ranks on one device), so that `torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` dry-runs the N > 1
+    # logic (shards, barrier, reject-count reduce, max-over-ranks timing) on real kernels; never a measurement
+    if os.environ.get("BENCH_ONE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if args.gpus != world and world == 1 and args.gpus > 1:
         print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
@@ -115,7 +121,10 @@ def setup_dist(args):
     if world > 1 or os.environ.get("BENCH_FORCE_DIST"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return world, rank, local_rank
 
 
