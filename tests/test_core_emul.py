@@ -295,3 +295,40 @@ def test_full_prove_pipeline_is_byte_identical_to_the_oracle(L, gold, oracle_c):
         assert bytes(proofs[i]).hex() == c["proof"], f"case {i}"
     op, ov = oracle_c.u64_prove_batch(gens, label, x, s, rnd, nthreads=2)
     assert (ov == V).all() and (op == proofs).all()
+
+
+def test_identity_and_repeated_points_in_a_proof(L, gold, oracle_c):
+    """CPU twin of tests/test_gpu_verify.py::test_identity_points_in_proofs_vs_oracle on the device code: each of the 14 points of
+    a golden proof replaced by the identity (64 zero bytes: well-formed, hashed as 33 zero bytes, the neutral element of every
+    table and sum), all of them at once, and repeated points (P + P inside the window tables): accept, status and the full
+    trace equal the C oracle's."""
+    gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
+    W = 4
+    tab = np.zeros(L.emul_fb_table_entries(49, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0
+    V0 = np.frombuffer(bytes.fromhex(gold["cases"][1]["commitment"]), np.uint8)
+    P0 = np.frombuffer(bytes.fromhex(gold["cases"][1]["proof"]), np.uint8)
+    rows = []
+    for j in range(14):
+        V, P = V0.copy(), P0.copy()
+        if j == 13:
+            V[:] = 0
+        else:
+            P[64 * j:64 * j + 64] = 0
+        rows.append((V, P))
+    V, P = V0.copy(), P0.copy()
+    V[:] = 0; P[:832] = 0
+    rows.append((V, P))
+    for a, b in ((8, 4), (0, 1), (12, 3)):
+        V, P = V0.copy(), P0.copy()
+        P[64 * a:64 * a + 64] = P[64 * b:64 * b + 64]
+        rows.append((V, P))
+    rows.append((V0.copy(), P0.copy()))
+    n = len(rows)
+    V, P = np.stack([r[0] for r in rows]), np.stack([r[1] for r in rows])
+    acc, st, tr = np.zeros(n, np.uint8), np.zeros(n, np.int32), np.zeros((n, 704), np.uint8)
+    L.emul_u64_verify_batch(tab.ctypes.data, W, label, len(label), n, V.ctypes.data, P.ctypes.data, acc.ctypes.data, st.ctypes.data, tr.ctypes.data)
+    assert acc.tolist() == [0] * (n - 1) + [1] and not st.any()
+    for k in range(n):
+        rc, otr = oracle_c.u64_verify(gens, label, bytes(V[k]), bytes(P[k]), trace=True)
+        assert rc == int(acc[k]) and bytes(tr[k]) == otr, k

@@ -308,3 +308,39 @@ def test_a_batch_that_cannot_fit_is_refused_cleanly(torch_mod, proto):
     gens, V, P, _ = workload.make_batch(70, first=123)
     acc, st = proto.verify_batch(V, P, workload.LABEL)
     assert acc.all() and not st.any()
+
+
+def test_identity_points_in_proofs_vs_oracle(torch_mod, proto, oracle_c):
+    """The identity is a point k256 deserializes (serde "00"; 64 zero bytes at this ABI): a proof or commitment carrying it is
+    well-formed, gets hashed as 33 zero bytes (GroupEncoding) and runs through every window table and sum as the neutral element.
+    Each of the 14 points set to the identity in turn, and all 14 at once: accept bit, status and the whole trace (challenges and
+    hashed commitments) equal the oracle's; a duplicated point (X_1 := R_1, c_l := c_r) exercises the P + P cases of the tables."""
+    import workload
+    gens, V0, P0, _ = workload.make_batch(2, first=555)
+    rows_v, rows_p = [], []
+    for j in range(14):
+        V, P = V0[0].copy(), P0[0].copy()
+        if j == 13:
+            V[:] = 0
+        else:
+            P[64 * j:64 * j + 64] = 0
+        rows_v.append(V); rows_p.append(P)
+    V, P = V0[1].copy(), P0[1].copy()
+    V[:] = 0; P[:832] = 0
+    rows_v.append(V); rows_p.append(P)
+    for a, b in ((8, 4), (0, 1), (12, 3)):                   # X_1 := R_1, c_l := c_r, reciprocal r := c_s
+        V, P = V0[1].copy(), P0[1].copy()
+        P[64 * a:64 * a + 64] = P[64 * b:64 * b + 64]
+        rows_v.append(V); rows_p.append(P)
+    rows_v.append(V0[0].copy()); rows_p.append(P0[0].copy())  # untouched control
+    V, P = np.stack(rows_v), np.stack(rows_p)
+    acc, st, tr, rej = _device_verify(torch_mod, proto, workload.LABEL, V, P)
+    assert acc[-1] == 1 and not acc[:-1].any() and not st.any() and rej == len(acc) - 1
+    for i in range(len(acc)):
+        rc, otr = oracle_c.u64_verify(gens, workload.LABEL, bytes(V[i]), bytes(P[i]), trace=True)
+        assert int(acc[i]) == (1 if rc == 1 else 0) and rc >= 0, (i, rc)
+        assert bytes(tr[i]) == otr, i
+    # the same rows through the RLC mode and the host-buffer path
+    acc2, st2 = proto.verify_batch_rlc(V, P, workload.LABEL, seed=bytes(range(32)))
+    acc3, st3 = proto.verify_batch(V, P, workload.LABEL)
+    assert (acc2 == acc).all() and (acc3 == acc).all() and not st2.any() and not st3.any()
