@@ -323,6 +323,11 @@ def test_identity_and_repeated_points_in_a_proof(L, gold, oracle_c):
         V, P = V0.copy(), P0.copy()
         P[64 * a:64 * a + 64] = P[64 * b:64 * b + 64]
         rows.append((V, P))
+        V, P = V0.copy(), P0.copy()                           # ... and the negated copy: P + (-P) inside the sums
+        P[64 * a:64 * a + 32] = P[64 * b:64 * b + 32]
+        y = int.from_bytes(P[64 * b + 32:64 * b + 64].tobytes(), "big")
+        P[64 * a + 32:64 * a + 64] = np.frombuffer(((2**256 - 2**32 - 977) - y).to_bytes(32, "big"), np.uint8)
+        rows.append((V, P))
     rows.append((V0.copy(), P0.copy()))
     n = len(rows)
     V, P = np.stack([r[0] for r in rows]), np.stack([r[1] for r in rows])

@@ -332,6 +332,11 @@ def test_identity_points_in_proofs_vs_oracle(torch_mod, proto, oracle_c):
         V, P = V0[1].copy(), P0[1].copy()
         P[64 * a:64 * a + 64] = P[64 * b:64 * b + 64]
         rows_v.append(V); rows_p.append(P)
+        V, P = V0[1].copy(), P0[1].copy()                     # ... and the negated copy: P + (-P) inside the sums
+        P[64 * a:64 * a + 32] = P[64 * b:64 * b + 32]
+        y = int.from_bytes(P[64 * b + 32:64 * b + 64].tobytes(), "big")
+        P[64 * a + 32:64 * a + 64] = np.frombuffer(((2**256 - 2**32 - 977) - y).to_bytes(32, "big"), np.uint8)
+        rows_v.append(V); rows_p.append(P)
     rows_v.append(V0[0].copy()); rows_p.append(P0[0].copy())  # untouched control
     V, P = np.stack(rows_v), np.stack(rows_p)
     acc, st, tr, rej = _device_verify(torch_mod, proto, workload.LABEL, V, P)
