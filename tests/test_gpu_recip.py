@@ -118,3 +118,43 @@ def test_reciprocal_verify_rlc_mode_on_the_gpu(nd, npp, B):
         assert (dA.cpu().numpy() == acc0).all() and (dS.cpu().numpy() == st0).all()
     finally:
         proto.close()
+
+
+@pytest.mark.parametrize("nd,npp", [(16, 16), (12, 10)])
+def test_generic_reciprocal_fuzz_vs_oracle(nd, npp):
+    """Fuzz of the generic path: one random byte of every proof (or commitment) of a 240-instance batch is XOR-ed with a random
+    value; accept bit and malformed-input status equal the C oracle's verdict instance by instance, in exact and in RLC mode."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import recip_cases
+    from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
+    B = 240
+    case = recip_cases.make(nd, npp, B, n_oracle=1)
+    proto = ReciprocalRangeProofProtocol(nd, npp, case["g"], case["gv"], case["hv"], case["gv_"], case["hv_"], device=0, fb_window_bits=10)
+    try:
+        com, st = proto.commit_value_batch(case["x"], case["s"])
+        proofs, st, shape = proto.prove_batch(case["label"], com, case["x"], case["s"], case["digits"], case["m"], case["rnd"])
+        assert not st.any() and (proofs[0] == case["proofs"][0]).all()
+        rng = np.random.default_rng(nd * 100 + npp)
+        P, V = proofs.copy(), com.copy()
+        for i in range(B):
+            if i % 12 == 0:
+                continue
+            x = int(rng.integers(1, 256))
+            if i % 5 == 0:
+                V[i, int(rng.integers(0, 64))] ^= x
+            else:
+                P[i, int(rng.integers(0, P.shape[1]))] ^= x
+        acc, st = proto.verify_batch(case["label"], V, P, *shape)
+        acc2, st2 = proto.verify_batch_rlc(case["label"], V, P, *shape, seed=bytes(range(50, 82)))
+        assert (acc2 == acc).all() and (st2 == st).all()
+        n_flag = 0
+        for i in range(B):
+            rc = recip_cases.oracle_verify(case, bytes(V[i]), bytes(P[i]))
+            assert int(acc[i]) == (1 if rc == 1 else 0), (i, rc)
+            assert (int(st[i]) != 0) == (rc < 0), (i, rc, int(st[i]))
+            n_flag += rc < 0
+        assert acc[::12].all() and n_flag > 20 and int(acc.sum()) == B // 12
+    finally:
+        proto.close()
