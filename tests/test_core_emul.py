@@ -337,3 +337,25 @@ def test_identity_and_repeated_points_in_a_proof(L, gold, oracle_c):
     for k in range(n):
         rc, otr = oracle_c.u64_verify(gens, label, bytes(V[k]), bytes(P[k]), trace=True)
         assert rc == int(acc[k]) and bytes(tr[k]) == otr, k
+
+
+def test_prover_at_the_edges_of_its_inputs(L, gold, oracle_c):
+    """x = 0 and 2^64 - 1, blinding 0 and n - 1, prover draws all zero / all n - 1 / all one (workload.edge_prover_inputs): the
+    device code's proofs equal the reference-shaped oracle prover's byte for byte and both verifiers accept them."""
+    import workload
+    gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
+    W = 4
+    tab = np.zeros(L.emul_fb_table_entries(49, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0
+    x, s, rnd = workload.edge_prover_inputs()
+    n = len(x)
+    proofs, V, st = np.zeros((n, 928), np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.int32)
+    L.emul_u64_prove_batch(tab.ctypes.data, W, label, len(label), n, x.ctypes.data, s.ctypes.data, rnd.ctypes.data, proofs.ctypes.data,
+                           V.ctypes.data, st.ctypes.data)
+    op, ov = oracle_c.u64_prove_batch(gens, label, x, s, rnd, nthreads=2)
+    assert not st.any() and (ov == V).all() and (op == proofs).all()
+    oacc, ost = oracle_c.u64_verify_batch(gens, label, V, proofs, nthreads=2)
+    acc, vst, tr = np.zeros(n, np.uint8), np.zeros(n, np.int32), np.zeros((n, 704), np.uint8)
+    L.emul_u64_verify_batch(tab.ctypes.data, W, label, len(label), n, V.ctypes.data, proofs.ctypes.data, acc.ctypes.data, vst.ctypes.data,
+                            tr.ctypes.data)
+    assert oacc.all() and acc.all() and not ost.any() and not vst.any()

@@ -74,3 +74,18 @@ def test_non_canonical_prover_input_is_flagged(proto):
     rnd[1, 32 * 20:32 * 21] = 0xFF                                                      # one prover draw >= n
     _, _, st = proto.prove_batch(x, s, rnd, workload.LABEL)
     assert (st & 1).all()
+
+
+def test_prover_at_the_edges_of_its_inputs(proto, gold, oracle_c):
+    """GPU twin of tests/test_core_emul.py::test_prover_at_the_edges_of_its_inputs (x = 0 / 2^64 - 1, blinding 0 / n - 1, draws all
+    zero / n - 1 / one): byte-identical to the oracle prover, accepted by the GPU verifier (exact and RLC) and by the oracle."""
+    import workload
+    gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
+    x, s, rnd = workload.edge_prover_inputs()
+    proofs, com, st = proto.prove_batch(x, s, rnd, label)
+    op, ov = oracle_c.u64_prove_batch(gens, label, x, s, rnd, nthreads=2)
+    assert not st.any() and (ov == com).all() and (op == proofs).all()
+    acc, vst = proto.verify_batch(com, proofs, label)
+    acc2, vst2 = proto.verify_batch_rlc(com, proofs, label, seed=bytes(32))
+    oacc, ost = oracle_c.u64_verify_batch(gens, label, com, proofs, nthreads=2)
+    assert acc.all() and acc2.all() and oacc.all() and not vst.any() and not vst2.any() and not ost.any()

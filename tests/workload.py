@@ -50,3 +50,16 @@ def make_batch(n: int, first: int = 0, seed: bytes = SEED, nthreads: int = 0):
 
 def corrupt(proofs: np.ndarray, commitments: np.ndarray = None, every: int = 1024, seed: bytes = SEED):
     return synth.corrupt(proofs, every, seed)
+
+
+def edge_prover_inputs():
+    """Prover inputs at the edges of their domains: x in {0, 2^64 - 1, ...}, blinding 0 / 1 / n - 1, and draws that are all zero, all
+    n - 1, all one, alternating zero, or the draw index (`Scalar::generate_biased` can return any of them): unblinded and barely blinded
+    proofs.  -> (x [5] u64, s [5, 32], rnd [5, 52 * 32])."""
+    sc = lambda v: np.frombuffer((v % N_ORDER).to_bytes(32, "big"), np.uint8)
+    cases = [(0, 0, lambda i: 0), (2**64 - 1, N_ORDER - 1, lambda i: N_ORDER - 1), (123456, 1, lambda i: 1),
+             (0x0123456789ABCDEF, 5, lambda i: 0 if i % 2 else 7), (0xFFFFFFFF00000000, 0, lambda i: i)]
+    x = np.array([c[0] for c in cases], dtype=np.uint64)
+    s = np.stack([sc(c[1]) for c in cases]).copy()
+    rnd = np.stack([np.concatenate([sc(c[2](i)) for i in range(52)]) for c in cases]).copy()
+    return x, s, rnd
