@@ -38,6 +38,29 @@ class BpppError(RuntimeError):
         super().__init__(f"bppp error {code}: {msg}" + (f" ({detail})" if detail else ""))
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (soname libamdhip64.so.7, the soname this library
+    links against); two copies in one process means two ROCr instances, and the second one to initialise finds "no ROCm-capable
+    device".  If torch is installed but not imported yet, its copy is loaded first (by path, without importing torch), so that this
+    library's DT_NEEDED entry and a later `import torch` both resolve to it -- whatever the order of the imports."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("BPPP_NO_TORCH_PRELOAD"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for d in (spec.submodule_search_locations or []) if spec else []:
+        p = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            try:
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def lib():
     """Load libbppp_hip.so.  Import torch first when it is going to be used in the same process: both HIP runtimes carry
     the soname libamdhip64.so.7, so whichever is loaded first serves both and device pointers stay interchangeable."""
@@ -48,6 +71,7 @@ def lib():
     if not os.path.exists(so):
         raise ImportError(f"{_build.SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the bp_pp_amd product path)")
+    _preload_torch_hip_runtime()
     L = C.CDLL(so)
     vp, sz, i32, u8p = C.c_void_p, C.c_size_t, C.c_int, C.c_char_p
     L.bppp_ctx_create.argtypes = [C.POINTER(vp), u8p, u8p, u8p, i32, i32]
