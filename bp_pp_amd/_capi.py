@@ -62,8 +62,8 @@ def _preload_torch_hip_runtime():
 
 
 def lib():
-    """Load libbppp_hip.so.  Import torch first when it is going to be used in the same process: both HIP runtimes carry
-    the soname libamdhip64.so.7, so whichever is loaded first serves both and device pointers stay interchangeable."""
+    """Load libbppp_hip.so (after torch's copy of the HIP runtime, if torch is installed: _preload_torch_hip_runtime), so that one
+    runtime serves both and device pointers stay interchangeable."""
     global _lib
     if _lib is not None:
         return _lib
