@@ -34,8 +34,9 @@ pub struct U64RangeProofProtocolGpu {
     cpu: U64RangeProofProtocol,
 }
 
-// one call at a time per context (include/bppp.h, Concurrency)
+// every exported call holds the context's lock (include/bppp.h, Threading): calls from several threads are serialized by the library
 unsafe impl Send for U64RangeProofProtocolGpu {}
+unsafe impl Sync for U64RangeProofProtocolGpu {}
 
 impl U64RangeProofProtocolGpu {
     /// fb_window_bits: 0 = library default; see bppp_ctx_create.
