@@ -252,9 +252,10 @@ int emul_straus_affine(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64
     verify_tables(ws, 0);
     const int pidx[5] = {0, 1, 2, 3, 4};
     pt acc, viafb;
-    bool ok = (m <= 2) ? straus_affine_fast<2>(acc, atab.data(), pidx, g2) : straus_affine_fast<5>(acc, atab.data(), pidx, g5);
+    const atab_ref tabv = atab_of(atab.data(), 1, 0);
+    bool ok = (m <= 2) ? straus_affine_fast<2>(acc, tabv, pidx, g2) : straus_affine_fast<5>(acc, tabv, pidx, g5);
     *fell_back = !ok;
-    if (m <= 2) straus_affine_complete<2>(viafb, atab.data(), pidx, g2); else straus_affine_complete<5>(viafb, atab.data(), pidx, g5);
+    if (m <= 2) straus_affine_complete<2>(viafb, tabv, pidx, g2); else straus_affine_complete<5>(viafb, tabv, pidx, g5);
     if (ok && !pt_eq(acc, viafb)) return -2;      // both laws must agree whenever the fast one claims success
     apt r;
     pt_to_affine(r, viafb);
