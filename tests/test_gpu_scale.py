@@ -113,3 +113,34 @@ def test_recip256_prove_and_verify_at_batch_scale(torch_mod):
             assert int(acc[i]) == (1 if rc == 1 else 0) and (int(st[i]) != 0) == (rc < 0), (i, rc)
     finally:
         proto.close()
+
+
+def test_u64_verify_beyond_one_internal_part(torch_mod):
+    """More proofs than the default `max_batch` (2^21) in ONE call: the library runs the batch as consecutive parts with a bounded
+    workspace (include/bppp.h, bppp_ctx_set_option).  2^21 + 12,345 proofs resident: every honest proof accepted, every corrupted
+    one rejected, the reject count accumulated across the parts, exact and RLC mode; the workspace stays that of 2^21 proofs."""
+    torch = torch_mod
+    import bench
+    from bp_pp_amd import U64RangeProofProtocol, synth
+    n = (1 << 21) + 12345
+    gens, g, gv, hv = bench.load_generators()
+    proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=16)
+    try:
+        dV, dP, expect, _ = bench.make_resident_batch(torch, proto, synth, 7, 7 + n)
+        dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dS = torch.zeros(n, dtype=torch.int32, device="cuda")
+        dR = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        bytes_before = proto.device_bytes()
+        proto.verify_batch_device(synth.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, dR.data_ptr())
+        proto.synchronize()
+        n_bad = int((expect == 0).sum())
+        assert (dA.cpu().numpy() == expect).all() and not dS.any().item() and int(dR.item()) == n_bad and n_bad >= n // 1024
+        dA.zero_()
+        proto.verify_batch_rlc_device(synth.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), bytes(range(32)), dS.data_ptr(), dR.data_ptr())
+        proto.synchronize()
+        assert (dA.cpu().numpy() == expect).all() and int(dR.item()) == n_bad
+        # workspace growth is that of one part (2^21 proofs at ~30 KB), not of the whole batch
+        assert proto.device_bytes() - bytes_before < 1.25 * (1 << 21) * 40000
+    finally:
+        proto.close()
