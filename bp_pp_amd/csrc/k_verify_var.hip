@@ -4,7 +4,7 @@
 
 using namespace bppp;
 
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables(VerifyWs ws) {
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables(VerifyWs ws) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N) verify_tables(ws, t);
 }

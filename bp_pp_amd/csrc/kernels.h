@@ -23,6 +23,11 @@
 #endif
 // fixed-base MSM kernels: BPPP_FB_LANES lanes per proof, 256-thread workgroups; 2 waves/SIMD (212 VGPRs, no spills) -- forcing 3
 // (168 VGPRs, 52 spilled) slows k_verify_final_check from 42.8 to 61.6 ms per 2^20 proofs (same measurement)
+// k_verify_tables is a chain of dependent loads and short arithmetic (three to five passes over a proof's 13 points): latency-bound,
+// so it is given more wavefronts per SIMD than the arithmetic-bound kernels when its registers allow (measured)
+#ifndef BPPP_TABLES_MIN_WAVES
+#define BPPP_TABLES_MIN_WAVES 3
+#endif
 #define BPPP_FB_BLOCK 256
 #ifndef BPPP_FB_MIN_WAVES
 #define BPPP_FB_MIN_WAVES 2
@@ -72,7 +77,7 @@ using bppp::MsmWs;
 
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_phase1(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed(bppp::VerifyWs ws);
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_c0_var(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_round(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_small(bppp::VerifyWs ws);

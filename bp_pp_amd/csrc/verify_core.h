@@ -628,6 +628,12 @@ HD void straus_msm_glv(pt& out, const pt_slot* tbl, const glv_split* sp, int m) 
 // too, so the inner loop has no beta multiplication.
 #define BPPP_VPOINTS 13
 #define BPPP_ATAB_PER_PROOF (BPPP_VPOINTS * 16)
+// BPPP_VWIN 5: signed 5-bit windows over the 128-bit GLV halves -- 26 windows x 2M mixed additions instead of 33 x 2M (the 4-bit
+// recoding needs a 33rd window for its carry), tables 1P..16P per point (4 levels, 4 batched inversions) with the GLV image
+// (beta x, y) formed on the fly by one multiplication (the table memory stays 13 x 16 entries).  BPPP_VWIN 4: 1P..8P + stored images.
+#ifndef BPPP_VWIN
+#define BPPP_VWIN 5
+#endif
 HD void ws_st_fe(u32* base, size_t N, size_t t, int slot, const fe& a) {
 #pragma unroll
     for (int i = 0; i < 10; i++) base[(size_t)(slot * 10 + i) * N + t] = a.v[i];
@@ -664,21 +670,30 @@ HD atab_ref atab_of(apt_packed* atab, size_t N, size_t t) {
 #endif
     return r;
 }
-HD void atab_store(atab_ref tb, int e, const apt& a, const fe& beta, bool identity) {   // e = 1..8
-    apt_packed k, kb;
-    fe bx;
-    fe_mul(bx, a.x, beta);
+HD void atab_store(atab_ref tb, int e, const apt& a, const fe& beta, bool identity) {   // e = 1..8 (1..16 with 5-bit windows)
+    apt_packed k;
     fe_to_w8(k.x, a.x);
     fe_to_w8(k.y, a.y);
-    fe_to_w8(kb.x, bx);
-#pragma unroll
-    for (int i = 0; i < 8; i++) kb.y[i] = k.y[i];
     if (identity) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) k.x[i] = k.y[i] = kb.x[i] = kb.y[i] = 0;
+        for (int i = 0; i < 8; i++) k.x[i] = k.y[i] = 0;
     }
     tb[e - 1] = k;
+#if BPPP_VWIN != 5
+    apt_packed kb;
+    fe bx;
+    fe_mul(bx, a.x, beta);
+    fe_to_w8(kb.x, bx);
+#pragma unroll
+    for (int i = 0; i < 8; i++) kb.y[i] = identity ? 0u : k.y[i];
+    if (identity) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) kb.x[i] = 0;
+    }
     tb[8 + e - 1] = kb;
+#else
+    (void)beta;
+#endif
 }
 // Window tables by AFFINE arithmetic, three batched inversions per proof.  The multiples of one point form three levels whose
 // slopes only need earlier levels:   2P = 2.P  |  3P = 2P + P, 4P = 2.2P  |  5P = 4P + P, 6P = 2.3P, 7P = 4P + 3P, 8P = 2.4P,
@@ -690,8 +705,13 @@ HD void atab_store(atab_ref tb, int e, const apt& a, const fe& beta, bool identi
 // No exceptional cases arise: the group has prime order n > 8, so for a point P != O none of P .. 8P is O, 2y != 0, and the
 // additions jP + P (j = 2, 4) and 4P + 3P never meet equal x.  P = O (the (0, 0) sentinel, also what a malformed proof's
 // points are replaced by) gives zero denominators: they are replaced by 1 and every multiple is stored as O.
+#if BPPP_VWIN == 5
+#define BPPP_TSCR_FE 182  // running products: levels 1 and 3 share slots 0..51 (13, then 52), level 2 lives in 52..77 (26), level 4 in 78..181 (104)
+#else
 #define BPPP_TSCR_FE 78   // running products: levels 1 and 3 share slots 0..51 (13, then 52), level 2 lives in 52..77 (26)
+#endif
 #define BPPP_TSCR_L2 52
+#define BPPP_TSCR_L4 78
 struct aff_src { fe x, y; };
 HD void aff_ld(aff_src& r, atab_ref tb, int e) {   // multiple e (1..8) of the point whose table is tb
     const apt_packed k = tb[e - 1];
@@ -817,7 +837,10 @@ HD void verify_tables(const VerifyWs& ws, size_t t) {
         aff_push(ws, t, 4 * p + 3, run, d);
     }
     fe_inv(inv, run);
-    // ---- pass D (down): 8P, 7P, 6P, 5P
+    // ---- pass D (down): 8P, 7P, 6P, 5P  [5-bit windows: + level-4 denominators for 9P .. 16P]
+#if BPPP_VWIN == 5
+    fe_set_u32(run, 1);
+#endif
 #pragma nounroll
     for (int p = BPPP_VPOINTS - 1; p >= 0; p--) {
         const atab_ref tb = tab + p * 16;
@@ -826,26 +849,211 @@ HD void verify_tables(const VerifyWs& ws, size_t t) {
         aff_ld(a3, tb, 3);
         aff_ld(a4, tb, 4);
         const bool pid = fe_is_zero(a.x) & fe_is_zero(a.y);
-        apt R;
+        apt R8, R;
         aff_den_dbl(d, a4, pid, one);
         aff_pop(dinv, ws, t, 4 * p + 3, inv, d);
-        aff_dbl(R, a4, dinv);
-        atab_store(tb, 8, R, beta, pid);
+        aff_dbl(R8, a4, dinv);
+        atab_store(tb, 8, R8, beta, pid);
+#if BPPP_VWIN == 5
+        // level 4 needs 8P against 7P, 5P, 3P, P (odd multiples 15, 13, 11, 9) and the doublings of 8P, 7P, 6P, 5P
+        aff_src a8, ax;
+        aff_take(a8, R8);
+        const int q4 = BPPP_TSCR_L4 + 8 * p;
+        aff_den_dbl(d, a8, pid, one);       aff_push(ws, t, q4 + 7, run, d);     // 16P = 2 . 8P
+#endif
         aff_den_add(d, a4, a3, pid, one);
         aff_pop(dinv, ws, t, 4 * p + 2, inv, d);
         aff_add(R, a4, a3, dinv);
         atab_store(tb, 7, R, beta, pid);
+#if BPPP_VWIN == 5
+        aff_take(ax, R);
+        aff_den_add(d, a8, ax, pid, one);   aff_push(ws, t, q4 + 6, run, d);     // 15P = 8P + 7P
+        aff_den_dbl(d, ax, pid, one);       aff_push(ws, t, q4 + 5, run, d);     // 14P = 2 . 7P
+#endif
         aff_den_dbl(d, a3, pid, one);
         aff_pop(dinv, ws, t, 4 * p + 1, inv, d);
         aff_dbl(R, a3, dinv);
         atab_store(tb, 6, R, beta, pid);
+#if BPPP_VWIN == 5
+        aff_take(ax, R);
+        aff_den_dbl(d, ax, pid, one);       aff_push(ws, t, q4 + 3, run, d);     // 12P = 2 . 6P
+#endif
         aff_den_add(d, a4, a, pid, one);
         aff_pop(dinv, ws, t, 4 * p, inv, d);
         aff_add(R, a4, a, dinv);
         atab_store(tb, 5, R, beta, pid);
+#if BPPP_VWIN == 5
+        aff_take(ax, R);
+        aff_den_add(d, a8, ax, pid, one);   aff_push(ws, t, q4 + 4, run, d);     // 13P = 8P + 5P
+        aff_den_dbl(d, ax, pid, one);       aff_push(ws, t, q4 + 1, run, d);     // 10P = 2 . 5P
+        aff_den_add(d, a8, a3, pid, one);   aff_push(ws, t, q4 + 2, run, d);     // 11P = 8P + 3P
+        aff_den_add(d, a8, a, pid, one);    aff_push(ws, t, q4 + 0, run, d);     //  9P = 8P + P
+#endif
     }
+#if BPPP_VWIN == 5
+    fe_inv(inv, run);
+    // ---- pass E (up): 9P .. 16P, unwinding in the reverse of the order the denominators were multiplied in
+#pragma nounroll
+    for (int p = 0; p < BPPP_VPOINTS; p++) {
+        const atab_ref tb = tab + p * 16;
+        aff_src a, a3, a5, a6, a7, a8;
+        aff_ld(a, tb, 1);
+        aff_ld(a3, tb, 3);
+        aff_ld(a5, tb, 5);
+        aff_ld(a8, tb, 8);
+        const bool pid = fe_is_zero(a.x) & fe_is_zero(a.y);
+        const int q4 = BPPP_TSCR_L4 + 8 * p;
+        apt R;
+        aff_den_add(d, a8, a, pid, one);    aff_pop(dinv, ws, t, q4 + 0, inv, d);  aff_add(R, a8, a, dinv);   atab_store(tb, 9, R, beta, pid);
+        aff_den_add(d, a8, a3, pid, one);   aff_pop(dinv, ws, t, q4 + 2, inv, d);  aff_add(R, a8, a3, dinv);  atab_store(tb, 11, R, beta, pid);
+        aff_den_dbl(d, a5, pid, one);       aff_pop(dinv, ws, t, q4 + 1, inv, d);  aff_dbl(R, a5, dinv);      atab_store(tb, 10, R, beta, pid);
+        aff_den_add(d, a8, a5, pid, one);   aff_pop(dinv, ws, t, q4 + 4, inv, d);  aff_add(R, a8, a5, dinv);  atab_store(tb, 13, R, beta, pid);
+        aff_ld(a6, tb, 6);
+        aff_den_dbl(d, a6, pid, one);       aff_pop(dinv, ws, t, q4 + 3, inv, d);  aff_dbl(R, a6, dinv);      atab_store(tb, 12, R, beta, pid);
+        aff_ld(a7, tb, 7);
+        aff_den_dbl(d, a7, pid, one);       aff_pop(dinv, ws, t, q4 + 5, inv, d);  aff_dbl(R, a7, dinv);      atab_store(tb, 14, R, beta, pid);
+        aff_den_add(d, a8, a7, pid, one);   aff_pop(dinv, ws, t, q4 + 6, inv, d);  aff_add(R, a8, a7, dinv);  atab_store(tb, 15, R, beta, pid);
+        aff_den_dbl(d, a8, pid, one);       aff_pop(dinv, ws, t, q4 + 7, inv, d);  aff_dbl(R, a8, dinv);      atab_store(tb, 16, R, beta, pid);
+    }
+#endif
     BPPP_STAMP(t, 19);
 }
+#if BPPP_VWIN == 5
+// The 2M GLV half-scalars of an M-point sum, kept in registers, recoded for signed 5-bit windows:
+//   w = |k| + OFF5,  OFF5 = sum_{i < 26} 16 * 32^i   (|k| < 2^128, so w < 2^130: 26 digits),  digit_i = ((w >> 5 i) & 31) - 16 in [-16, 15].
+// glv_decompose hands over |k| + 0x8...8 (the 4-bit offset of the generic path); the difference of the two offsets is added here.
+template <int M>
+struct glv_words {
+    u32 w[2 * M][5];
+    bool neg[2 * M];
+};
+#define BPPP_VWINDOWS 26
+HD void glv_recode5(u32 out[5], const u32 k4[5]) {
+    const u32 D[5] = {0x987FB988u, 0x7FB987FBu, 0xB987FB98u, 0x87FB987Fu, 0xFFFFFFF9u};   // OFF5 - OFF4 mod 2^160
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) out[i] = addc(k4[i], D[i], c);
+}
+template <int M>
+HD void glv_words_set(glv_words<M>& g, int j, const glv_split& sp) {
+    glv_recode5(g.w[2 * j], sp.k1);
+    glv_recode5(g.w[2 * j + 1], sp.k2);
+    g.neg[2 * j] = sp.neg1;
+    g.neg[2 * j + 1] = sp.neg2;
+}
+// the 2M digits of window i, 5 bits each, packed into one 64-bit word (2M <= 10): the window index is uniform over the wavefront,
+// so this is a handful of selects per stream, once per window instead of once per addition
+template <int M>
+HD u64 glv_window_digits(const glv_words<M>& g, int i) {
+    const int b = 5 * i, l = b >> 5, sh = b & 31;
+    u64 pk = 0;
+#pragma unroll
+    for (int st = 0; st < 2 * M; st++) {
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            lo = (q == l) ? g.w[st][q] : lo;
+            hi = (q == l + 1) ? g.w[st][q] : hi;
+        }
+        const u32 v = (u32)(((((u64)hi) << 32) | lo) >> sh) & 31u;
+        pk |= (u64)v << (5 * st);
+    }
+    return pk;
+}
+template <int M>
+HD void glv_digit_of(const glv_words<M>& g, u64 pk, int r, int& mag, bool& neg) {
+    bool sneg = false;
+#pragma unroll
+    for (int st = 0; st < 2 * M; st++) sneg = (st == r) ? g.neg[st] : sneg;
+    const int dg = (int)((pk >> (5 * r)) & 31u) - 16;
+    mag = dg < 0 ? -dg : dg;
+    neg = (dg < 0) != sneg;
+}
+// sum_j k_j P_j over the affine tables; pidx[j] = table (proof point slot) of P_j.  26 windows x (5 doublings + 2M mixed
+// additions); stream 2j is k1 of P_j, stream 2j + 1 its GLV partner (the entry's x times beta: the stream index is uniform over
+// the wavefront, so that multiplication is behind a real branch).  The table entry of the next addition is requested before the
+// current one starts.  Returns false when an exceptional addition was met (re-do with straus_affine_complete).
+template <int M>
+HD bool straus_affine_fast(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g) {
+    const int total = BPPP_VWINDOWS * 2 * M;
+    fe beta;
+    glv_beta(beta);
+    ptj acc;
+    ptj_init(acc);
+    bool empty = true;
+    apt_packed cur_e, nxt_e;
+    int cur_mag, nxt_mag;
+    bool cur_neg, nxt_neg;
+    u64 pk_cur = glv_window_digits<M>(g, BPPP_VWINDOWS - 1), pk_nxt = glv_window_digits<M>(g, BPPP_VWINDOWS - 2);
+    glv_digit_of<M>(g, pk_cur, 0, cur_mag, cur_neg);
+    cur_e = tab[pidx[0] * 16 + (cur_mag ? cur_mag - 1 : 0)];
+    int r = 0, i = BPPP_VWINDOWS - 1;
+#pragma nounroll
+    for (int s = 0; s < total; s++) {
+        // successor step (clamped at the end: requested, never consumed)
+        int rn = r + 1, in = i;
+        if (rn == 2 * M) { rn = 0; in = i - 1; }
+        if (in < 0) { rn = r; in = i; }
+        glv_digit_of<M>(g, in == i ? pk_cur : pk_nxt, rn, nxt_mag, nxt_neg);
+        int pn = 0;
+#pragma unroll
+        for (int j = 0; j < M; j++) pn = (j == (rn >> 1)) ? pidx[j] : pn;
+        nxt_e = tab[pn * 16 + (nxt_mag ? nxt_mag - 1 : 0)];
+        if (r == 0 && s != 0) {
+#pragma nounroll
+            for (int d = 0; d < 5; d++) ptj_dbl(acc);
+        }
+        apt e;
+        bool id;
+        apt_unpack(e, id, cur_e);
+        if (r & 1) fe_mul(e.x, e.x, beta);            // wave-uniform: the GLV image (beta x, y)
+        fe ny;
+        fe_neg_m<1>(ny, e.y);
+        fe_cmov(e.y, cur_neg, ny);
+        ptj_madd(acc, empty, e, (cur_mag == 0) | id);
+        cur_e = nxt_e;
+        cur_mag = nxt_mag;
+        cur_neg = nxt_neg;
+        if (in != i) { pk_cur = pk_nxt; pk_nxt = glv_window_digits<M>(g, in > 0 ? in - 1 : 0); }
+        r = rn;
+        i = in;
+    }
+    const bool exceptional = !empty && fe_is_zero(acc.Z);
+    ptj_to_pt(out, acc, empty);
+    return !exceptional;
+}
+template <int M>
+HD void straus_affine_complete(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g) {
+    fe beta;
+    glv_beta(beta);
+    pt acc;
+    pt_set_identity(acc);
+#pragma nounroll
+    for (int i = BPPP_VWINDOWS - 1; i >= 0; i--) {
+        if (i != BPPP_VWINDOWS - 1) {
+#pragma nounroll
+            for (int d = 0; d < 5; d++) pt_dbl(acc, acc);
+        }
+        const u64 pk = glv_window_digits<M>(g, i);
+#pragma nounroll
+        for (int r = 0; r < 2 * M; r++) {
+            int mag, pn = 0;
+            bool neg, id;
+            glv_digit_of<M>(g, pk, r, mag, neg);
+#pragma unroll
+            for (int j = 0; j < M; j++) pn = (j == (r >> 1)) ? pidx[j] : pn;
+            apt e;
+            apt_unpack(e, id, tab[pn * 16 + (mag ? mag - 1 : 0)]);
+            if (r & 1) fe_mul(e.x, e.x, beta);
+            fe ny;
+            fe_neg_m<1>(ny, e.y);
+            fe_cmov(e.y, neg, ny);
+            pt_madd(acc, acc, e, (mag == 0) | id);
+        }
+    }
+    out = acc;
+}
+#else
 // The 2M GLV half-scalars of an M-point sum, kept in registers; digits are picked with select chains (no dynamic indexing).
 template <int M>
 struct glv_words {
@@ -948,6 +1156,7 @@ HD void straus_affine_complete(pt& out, atab_ref tab, const int* pidx, const glv
     }
     out = acc;
 }
+#endif   // BPPP_VWIN
 template <int M>
 HD void straus_affine(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g) {
     if (!straus_affine_fast<M>(out, tab, pidx, g)) {
