@@ -44,7 +44,7 @@ enum KernelId {
     K_PROVE_STAGES, K_PROVE_MSM, K_PROVE_ROUND_SCALARS, K_PROVE_ROUND_FOLD,
     // generic reciprocal / WNLA verifier
     K_RECIP_PHASE1, K_RECIP_C0_FIXED, K_RECIP_C0_VAR, K_RECIP_C0_FINISH, K_WNLA_BEGIN, K_WNLA_ROUND, K_WNLA_FINAL_SCALARS, K_WNLA_MSM, K_WNLA_ACCEPT,
-    K_WNLA_RLC_LHS, K_WNLA_RLC_CHUNK, K_WNLA_RLC_CHECK,
+    K_WNLA_RLC_LHS, K_WNLA_RLC_CHUNK, K_WNLA_RLC_CHECK, K_WNLA_TABLES,
     K_COUNT
 };
 static const char* const kKernelNames[K_COUNT] = {
@@ -52,7 +52,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "k_verify_accept", "k_verify_tables", "k_rlc_lhs", "k_rlc_chunk", "k_bkt_prepare", "k_bkt_accumulate", "k_bkt_scalars", "k_bkt_check",
     "k_prove_stage_*", "k_prove_msm", "k_prove_round_scalars", "k_prove_round_fold",
     "k_recip_phase1", "k_recip_c0_fixed", "k_recip_c0_var", "k_recip_c0_finish", "k_wnla_begin", "k_wnla_round", "k_wnla_final_scalars",
-    "k_wnla_msm", "k_wnla_accept", "k_wnla_rlc_lhs", "k_wnla_rlc_chunk", "k_wnla_rlc_check"};
+    "k_wnla_msm", "k_wnla_accept", "k_wnla_rlc_lhs", "k_wnla_rlc_chunk", "k_wnla_rlc_check", "k_wnla_tables"};
 
 static size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 
@@ -106,6 +106,8 @@ struct bppp_ctx {
     size_t io_bytes = 0;
     uint8_t* d_gws = nullptr;    // workspace of bppp_reciprocal_verify_batch_device
     size_t gws_bytes = 0;
+    uint8_t* d_gtab = nullptr;   // generic verifiers: affine window tables of the round points + build scratch (wnla_core.h, fast path)
+    size_t gtab_bytes = 0;
     // expanded (64-byte) form of SEC1-compressed inputs
     uint8_t* d_expand = nullptr;
     size_t expand_bytes = 0;
@@ -113,7 +115,7 @@ struct bppp_ctx {
     int n_simds = 1024;            // CUs x 4 (device property), decides between the small-batch and the 2-waves/SIMD lane kernels
     bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
-    bool serial_c0 = false, rlc_debug = false;   // diagnostics, read from the environment once at context creation
+    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false;   // diagnostics, read from the environment once at context creation
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> event_pool;
     double total_ms[K_COUNT] = {0};
@@ -335,6 +337,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     c->fb_w = W;
     c->n_simds = device_simds(device);
     c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;
+    c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // diagnostic: projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
     c->ng = (int)ng; c->nh = (int)nh; c->nbases = NB;
     auto fail = [&](int code) { bppp_ctx_destroy(c); return code; };
@@ -416,6 +419,7 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_io) (void)hipFree(c->d_io);
     if (c->d_gws) (void)hipFree(c->d_gws);
+    if (c->d_gtab) (void)hipFree(c->d_gtab);
     if (c->d_expand) (void)hipFree(c->d_expand);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
@@ -467,7 +471,7 @@ int bppp_ctx_synchronize(bppp_ctx* c) {
 
 size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
     if (!c) return 0;
-    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->bkt_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + c->gws_bytes + (size_t)c->nbases * sizeof(apt);
+    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->bkt_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + c->gws_bytes + c->gtab_bytes + (size_t)c->nbases * sizeof(apt);
 }
 
 int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
@@ -1058,6 +1062,24 @@ struct TxDev {
         return BPPP_OK;
     }
 };
+// fast variable-base path of the generic verifiers' rounds: per instance 2 x rounds window tables (16 entries of 64 B per point), the
+// running products of their build (14 per point) and the decoded round points -- 1.2 KB + 0.55 KB + 64 B per point, grow-only
+static int wnla_fast_setup(bppp_ctx* c, WnlaWs& w, size_t n, size_t rounds) {
+    w.atab = nullptr; w.tscr = nullptr; w.rpts = nullptr;
+    if (rounds == 0 || c->generic_slow_rounds) return BPPP_OK;
+    const size_t np = 2 * rounds;
+    const size_t b_tab = align16(np * 16 * sizeof(apt_packed) * n), b_scr = align16(14 * np * 10 * sizeof(u32) * n), b_pts = align16(np * 16 * sizeof(u32) * n);
+    const size_t need = b_tab + b_scr + b_pts;
+    if (need > c->gtab_bytes) {
+        if (c->d_gtab) { (void)hipFree(c->d_gtab); c->d_gtab = nullptr; c->gtab_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->d_gtab, need));
+        c->gtab_bytes = need;
+    }
+    w.atab = (apt_packed*)c->d_gtab;
+    w.tscr = (u32*)(c->d_gtab + b_tab);
+    w.rpts = (u32*)(c->d_gtab + b_tab + b_scr);
+    return BPPP_OK;
+}
 // ---- generic WeightNormLinearArgument entry points (host pointers; one device blob per call)
 struct WnlaBlob {
     uint8_t* d = nullptr;
@@ -1124,7 +1146,10 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out_points, d + o_out, n * 64, hipMemcpyDeviceToHost, s));
     } else {
+        rc = wnla_fast_setup(c, w, n, rounds);
+        if (rc != BPPP_OK) return rc;
         k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        if (w.atab) k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w);
         for (int k = 1; k <= (int)rounds; k++) k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
         k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
         k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
@@ -1240,7 +1265,10 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
     GLAUNCH(K_RECIP_C0_VAR, k_recip_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r));
     GLAUNCH(K_RECIP_C0_FINISH, k_recip_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    rc = wnla_fast_setup(c, w, n, rounds);
+    if (rc != BPPP_OK) return rc;
     GLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (w.atab) GLAUNCH(K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     for (int k = 1; k <= (int)rounds; k++) GLAUNCH(K_WNLA_ROUND, k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
     GLAUNCH(K_WNLA_FINAL_SCALARS, k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     if (!rlc_seed) {
@@ -1510,7 +1538,12 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
     k_circuit_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r);
     k_circuit_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r);
     k_circuit_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    {
+        int rcf = wnla_fast_setup(c, w, n, rounds);
+        if (rcf != BPPP_OK) return rcf;
+    }
     k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    if (w.atab) k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     for (int kk = 1; kk <= (int)rounds; kk++) k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
     k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
@@ -2056,6 +2089,7 @@ static int ctx_alloc_common(bppp_ctx* c) {
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRY(hipMalloc(&c->d_flags, sizeof(int)));
     c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;
+    c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // diagnostic: projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
     c->n_simds = device_simds(c->device);
     return BPPP_OK;

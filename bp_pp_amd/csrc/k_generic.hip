@@ -21,6 +21,11 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round(WnlaWs w, int k) {
     const u32 key = w.divergent_positions ? w.tstate[(size_t)50 * w.N + t] : 0u;
     for_each_position_group(key, [&]() { wnla_verify_round(w, t, k); });
 }
+// window tables of every round's X and R (fast path of the rounds; wnla_core.h)
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_wnla_tables(WnlaWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_verify_tables(w, t);
+}
 // per-instance advanced transcripts back to the caller (any of the generic verifiers: they all end in the WNLA stage)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_generic_export_states(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;

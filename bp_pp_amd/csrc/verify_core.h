@@ -661,12 +661,13 @@ struct atab_ref {
     HD apt_packed& operator[](int i) const { return p[(size_t)i * s]; }
     HD atab_ref operator+(int k) const { atab_ref r = {p + (size_t)k * s, s}; return r; }
 };
-HD atab_ref atab_of(apt_packed* atab, size_t N, size_t t) {
+HD atab_ref atab_of(apt_packed* atab, size_t N, size_t t, int entries_per_instance = 13 * 16) {
 #if BPPP_ATAB_SOA
+    (void)entries_per_instance;
     atab_ref r = {atab + t, N};
 #else
     (void)N;
-    atab_ref r = {atab + t * (size_t)(13 * 16), 1};
+    atab_ref r = {atab + t * (size_t)entries_per_instance, 1};
 #endif
     return r;
 }
@@ -750,77 +751,76 @@ HD void aff_take(aff_src& r, const apt& a) {   // a freshly computed point as th
     fe_mul_small(r.y, a.y, 1);
 }
 // one Montgomery-trick step forward: store the running product, multiply the denominator in
-HD void aff_push(const VerifyWs& ws, size_t t, int slot, fe& run, const fe& den) {
-    ws_st_fe(ws.tscr, ws.N, t, slot, run);
+HD void aff_push(u32* tscr, size_t N, size_t t, int slot, fe& run, const fe& den) {
+    ws_st_fe(tscr, N, t, slot, run);
     fe_mul(run, run, den);
 }
 // ... and backward: dinv = 1 / den, inv loses den
-HD void aff_pop(fe& dinv, const VerifyWs& ws, size_t t, int slot, fe& inv, const fe& den) {
+HD void aff_pop(fe& dinv, const u32* tscr, size_t N, size_t t, int slot, fe& inv, const fe& den) {
     fe pre;
-    ws_ld_fe(pre, ws.tscr, ws.N, t, slot, 1);
+    ws_ld_fe(pre, tscr, N, t, slot, 1);
     fe_mul(dinv, inv, pre);
     fe_mul(inv, inv, den);
 }
-HD void verify_tables(const VerifyWs& ws, size_t t) {
-    const size_t N = ws.N;
-    BPPP_STAMP(t, 16);
+// Window tables of NP points per instance (the u64 verifier's 13 proof points; the generic WNLA verifier's 2 x rounds round points):
+// pts = the points in packed affine words [NP * 16][N], tscr = 14 NP running products [14 NP * 10][N], tab = the instance's table view.
+HD void affine_tables_build(const atab_ref tab, u32* tscr, const u32* pts, size_t N, size_t t, const int NP) {
+    const int L2 = 4 * NP, L4 = 6 * NP;      // running products: levels 1 and 3 share slots 0 .. 4 NP, level 2 lives in 4 NP .. 6 NP, level 4 in 6 NP .. 14 NP
+    (void)L4;
     fe run, inv, beta, one, d, dinv;
     fe_set_u32(one, 1);
     glv_beta(beta);
-    const atab_ref tab = atab_of(ws.atab, N, t);
     // ---- pass A (up): entry 1 of every table; level-1 denominators 2 y_P
     fe_set_u32(run, 1);
 #pragma nounroll
-    for (int p = 0; p < BPPP_VPOINTS; p++) {
+    for (int p = 0; p < NP; p++) {
         apt P;
-        ws_ld_apt(P, ws.pts, N, t, p);
+        ws_ld_apt(P, pts, N, t, p);
         const bool pid = apt_is_identity(P);
         atab_store(tab + p * 16, 1, P, beta, pid);
         aff_src a = {P.x, P.y};
         aff_den_dbl(d, a, pid, one);
-        aff_push(ws, t, p, run, d);
+        aff_push(tscr, N, t, p, run, d);
     }
     fe_inv(inv, run);
-    BPPP_STAMP(t, 17);
     // ---- pass B (down): 2P; level-2 denominators x_2P - x_P (3P = 2P + P), 2 y_2P (4P)
     fe_set_u32(run, 1);
 #pragma nounroll
-    for (int p = BPPP_VPOINTS - 1; p >= 0; p--) {
+    for (int p = NP - 1; p >= 0; p--) {
         apt P;
-        ws_ld_apt(P, ws.pts, N, t, p);
+        ws_ld_apt(P, pts, N, t, p);
         const bool pid = apt_is_identity(P);
         aff_src a = {P.x, P.y};
         aff_den_dbl(d, a, pid, one);
-        aff_pop(dinv, ws, t, p, inv, d);
+        aff_pop(dinv, tscr, N, t, p, inv, d);
         apt P2;
         aff_dbl(P2, a, dinv);
         atab_store(tab + p * 16, 2, P2, beta, pid);
         aff_src a2;
         aff_take(a2, P2);
-        const int q = BPPP_TSCR_L2 + (BPPP_VPOINTS - 1 - p) * 2;
+        const int q = L2 + (NP - 1 - p) * 2;
         aff_den_add(d, a2, a, pid, one);
-        aff_push(ws, t, q, run, d);
+        aff_push(tscr, N, t, q, run, d);
         aff_den_dbl(d, a2, pid, one);
-        aff_push(ws, t, q + 1, run, d);
+        aff_push(tscr, N, t, q + 1, run, d);
     }
     fe_inv(inv, run);
-    BPPP_STAMP(t, 18);
     // ---- pass C (up): 4P, 3P; level-3 denominators x_4P - x_P (5P), 2 y_3P (6P), x_4P - x_3P (7P), 2 y_4P (8P)
     fe_set_u32(run, 1);
 #pragma nounroll
-    for (int p = 0; p < BPPP_VPOINTS; p++) {
+    for (int p = 0; p < NP; p++) {
         const atab_ref tb = tab + p * 16;
         aff_src a, a2;
         aff_ld(a, tb, 1);
         aff_ld(a2, tb, 2);
         const bool pid = fe_is_zero(a.x) & fe_is_zero(a.y);
-        const int q = BPPP_TSCR_L2 + (BPPP_VPOINTS - 1 - p) * 2;
+        const int q = L2 + (NP - 1 - p) * 2;
         apt P3, P4;
         aff_den_dbl(d, a2, pid, one);
-        aff_pop(dinv, ws, t, q + 1, inv, d);
+        aff_pop(dinv, tscr, N, t, q + 1, inv, d);
         aff_dbl(P4, a2, dinv);
         aff_den_add(d, a2, a, pid, one);
-        aff_pop(dinv, ws, t, q, inv, d);
+        aff_pop(dinv, tscr, N, t, q, inv, d);
         aff_add(P3, a2, a, dinv);
         atab_store(tb, 3, P3, beta, pid);
         atab_store(tb, 4, P4, beta, pid);
@@ -828,13 +828,13 @@ HD void verify_tables(const VerifyWs& ws, size_t t) {
         aff_take(a3, P3);
         aff_take(a4, P4);
         aff_den_add(d, a4, a, pid, one);
-        aff_push(ws, t, 4 * p, run, d);
+        aff_push(tscr, N, t, 4 * p, run, d);
         aff_den_dbl(d, a3, pid, one);
-        aff_push(ws, t, 4 * p + 1, run, d);
+        aff_push(tscr, N, t, 4 * p + 1, run, d);
         aff_den_add(d, a4, a3, pid, one);
-        aff_push(ws, t, 4 * p + 2, run, d);
+        aff_push(tscr, N, t, 4 * p + 2, run, d);
         aff_den_dbl(d, a4, pid, one);
-        aff_push(ws, t, 4 * p + 3, run, d);
+        aff_push(tscr, N, t, 4 * p + 3, run, d);
     }
     fe_inv(inv, run);
     // ---- pass D (down): 8P, 7P, 6P, 5P  [5-bit windows: + level-4 denominators for 9P .. 16P]
@@ -842,7 +842,7 @@ HD void verify_tables(const VerifyWs& ws, size_t t) {
     fe_set_u32(run, 1);
 #endif
 #pragma nounroll
-    for (int p = BPPP_VPOINTS - 1; p >= 0; p--) {
+    for (int p = NP - 1; p >= 0; p--) {
         const atab_ref tb = tab + p * 16;
         aff_src a, a3, a4;
         aff_ld(a, tb, 1);
@@ -851,50 +851,50 @@ HD void verify_tables(const VerifyWs& ws, size_t t) {
         const bool pid = fe_is_zero(a.x) & fe_is_zero(a.y);
         apt R8, R;
         aff_den_dbl(d, a4, pid, one);
-        aff_pop(dinv, ws, t, 4 * p + 3, inv, d);
+        aff_pop(dinv, tscr, N, t, 4 * p + 3, inv, d);
         aff_dbl(R8, a4, dinv);
         atab_store(tb, 8, R8, beta, pid);
 #if BPPP_VWIN == 5
         // level 4 needs 8P against 7P, 5P, 3P, P (odd multiples 15, 13, 11, 9) and the doublings of 8P, 7P, 6P, 5P
         aff_src a8, ax;
         aff_take(a8, R8);
-        const int q4 = BPPP_TSCR_L4 + 8 * p;
-        aff_den_dbl(d, a8, pid, one);       aff_push(ws, t, q4 + 7, run, d);     // 16P = 2 . 8P
+        const int q4 = L4 + 8 * p;
+        aff_den_dbl(d, a8, pid, one);       aff_push(tscr, N, t, q4 + 7, run, d);     // 16P = 2 . 8P
 #endif
         aff_den_add(d, a4, a3, pid, one);
-        aff_pop(dinv, ws, t, 4 * p + 2, inv, d);
+        aff_pop(dinv, tscr, N, t, 4 * p + 2, inv, d);
         aff_add(R, a4, a3, dinv);
         atab_store(tb, 7, R, beta, pid);
 #if BPPP_VWIN == 5
         aff_take(ax, R);
-        aff_den_add(d, a8, ax, pid, one);   aff_push(ws, t, q4 + 6, run, d);     // 15P = 8P + 7P
-        aff_den_dbl(d, ax, pid, one);       aff_push(ws, t, q4 + 5, run, d);     // 14P = 2 . 7P
+        aff_den_add(d, a8, ax, pid, one);   aff_push(tscr, N, t, q4 + 6, run, d);     // 15P = 8P + 7P
+        aff_den_dbl(d, ax, pid, one);       aff_push(tscr, N, t, q4 + 5, run, d);     // 14P = 2 . 7P
 #endif
         aff_den_dbl(d, a3, pid, one);
-        aff_pop(dinv, ws, t, 4 * p + 1, inv, d);
+        aff_pop(dinv, tscr, N, t, 4 * p + 1, inv, d);
         aff_dbl(R, a3, dinv);
         atab_store(tb, 6, R, beta, pid);
 #if BPPP_VWIN == 5
         aff_take(ax, R);
-        aff_den_dbl(d, ax, pid, one);       aff_push(ws, t, q4 + 3, run, d);     // 12P = 2 . 6P
+        aff_den_dbl(d, ax, pid, one);       aff_push(tscr, N, t, q4 + 3, run, d);     // 12P = 2 . 6P
 #endif
         aff_den_add(d, a4, a, pid, one);
-        aff_pop(dinv, ws, t, 4 * p, inv, d);
+        aff_pop(dinv, tscr, N, t, 4 * p, inv, d);
         aff_add(R, a4, a, dinv);
         atab_store(tb, 5, R, beta, pid);
 #if BPPP_VWIN == 5
         aff_take(ax, R);
-        aff_den_add(d, a8, ax, pid, one);   aff_push(ws, t, q4 + 4, run, d);     // 13P = 8P + 5P
-        aff_den_dbl(d, ax, pid, one);       aff_push(ws, t, q4 + 1, run, d);     // 10P = 2 . 5P
-        aff_den_add(d, a8, a3, pid, one);   aff_push(ws, t, q4 + 2, run, d);     // 11P = 8P + 3P
-        aff_den_add(d, a8, a, pid, one);    aff_push(ws, t, q4 + 0, run, d);     //  9P = 8P + P
+        aff_den_add(d, a8, ax, pid, one);   aff_push(tscr, N, t, q4 + 4, run, d);     // 13P = 8P + 5P
+        aff_den_dbl(d, ax, pid, one);       aff_push(tscr, N, t, q4 + 1, run, d);     // 10P = 2 . 5P
+        aff_den_add(d, a8, a3, pid, one);   aff_push(tscr, N, t, q4 + 2, run, d);     // 11P = 8P + 3P
+        aff_den_add(d, a8, a, pid, one);    aff_push(tscr, N, t, q4 + 0, run, d);     //  9P = 8P + P
 #endif
     }
 #if BPPP_VWIN == 5
     fe_inv(inv, run);
     // ---- pass E (up): 9P .. 16P, unwinding in the reverse of the order the denominators were multiplied in
 #pragma nounroll
-    for (int p = 0; p < BPPP_VPOINTS; p++) {
+    for (int p = 0; p < NP; p++) {
         const atab_ref tb = tab + p * 16;
         aff_src a, a3, a5, a6, a7, a8;
         aff_ld(a, tb, 1);
@@ -902,20 +902,24 @@ HD void verify_tables(const VerifyWs& ws, size_t t) {
         aff_ld(a5, tb, 5);
         aff_ld(a8, tb, 8);
         const bool pid = fe_is_zero(a.x) & fe_is_zero(a.y);
-        const int q4 = BPPP_TSCR_L4 + 8 * p;
+        const int q4 = L4 + 8 * p;
         apt R;
-        aff_den_add(d, a8, a, pid, one);    aff_pop(dinv, ws, t, q4 + 0, inv, d);  aff_add(R, a8, a, dinv);   atab_store(tb, 9, R, beta, pid);
-        aff_den_add(d, a8, a3, pid, one);   aff_pop(dinv, ws, t, q4 + 2, inv, d);  aff_add(R, a8, a3, dinv);  atab_store(tb, 11, R, beta, pid);
-        aff_den_dbl(d, a5, pid, one);       aff_pop(dinv, ws, t, q4 + 1, inv, d);  aff_dbl(R, a5, dinv);      atab_store(tb, 10, R, beta, pid);
-        aff_den_add(d, a8, a5, pid, one);   aff_pop(dinv, ws, t, q4 + 4, inv, d);  aff_add(R, a8, a5, dinv);  atab_store(tb, 13, R, beta, pid);
+        aff_den_add(d, a8, a, pid, one);    aff_pop(dinv, tscr, N, t, q4 + 0, inv, d);  aff_add(R, a8, a, dinv);   atab_store(tb, 9, R, beta, pid);
+        aff_den_add(d, a8, a3, pid, one);   aff_pop(dinv, tscr, N, t, q4 + 2, inv, d);  aff_add(R, a8, a3, dinv);  atab_store(tb, 11, R, beta, pid);
+        aff_den_dbl(d, a5, pid, one);       aff_pop(dinv, tscr, N, t, q4 + 1, inv, d);  aff_dbl(R, a5, dinv);      atab_store(tb, 10, R, beta, pid);
+        aff_den_add(d, a8, a5, pid, one);   aff_pop(dinv, tscr, N, t, q4 + 4, inv, d);  aff_add(R, a8, a5, dinv);  atab_store(tb, 13, R, beta, pid);
         aff_ld(a6, tb, 6);
-        aff_den_dbl(d, a6, pid, one);       aff_pop(dinv, ws, t, q4 + 3, inv, d);  aff_dbl(R, a6, dinv);      atab_store(tb, 12, R, beta, pid);
+        aff_den_dbl(d, a6, pid, one);       aff_pop(dinv, tscr, N, t, q4 + 3, inv, d);  aff_dbl(R, a6, dinv);      atab_store(tb, 12, R, beta, pid);
         aff_ld(a7, tb, 7);
-        aff_den_dbl(d, a7, pid, one);       aff_pop(dinv, ws, t, q4 + 5, inv, d);  aff_dbl(R, a7, dinv);      atab_store(tb, 14, R, beta, pid);
-        aff_den_add(d, a8, a7, pid, one);   aff_pop(dinv, ws, t, q4 + 6, inv, d);  aff_add(R, a8, a7, dinv);  atab_store(tb, 15, R, beta, pid);
-        aff_den_dbl(d, a8, pid, one);       aff_pop(dinv, ws, t, q4 + 7, inv, d);  aff_dbl(R, a8, dinv);      atab_store(tb, 16, R, beta, pid);
+        aff_den_dbl(d, a7, pid, one);       aff_pop(dinv, tscr, N, t, q4 + 5, inv, d);  aff_dbl(R, a7, dinv);      atab_store(tb, 14, R, beta, pid);
+        aff_den_add(d, a8, a7, pid, one);   aff_pop(dinv, tscr, N, t, q4 + 6, inv, d);  aff_add(R, a8, a7, dinv);  atab_store(tb, 15, R, beta, pid);
+        aff_den_dbl(d, a8, pid, one);       aff_pop(dinv, tscr, N, t, q4 + 7, inv, d);  aff_dbl(R, a8, dinv);      atab_store(tb, 16, R, beta, pid);
     }
 #endif
+}
+HD void verify_tables(const VerifyWs& ws, size_t t) {
+    BPPP_STAMP(t, 16);
+    affine_tables_build(atab_of(ws.atab, ws.N, t), ws.tscr, ws.pts, ws.N, t, BPPP_VPOINTS);
     BPPP_STAMP(t, 19);
 }
 #if BPPP_VWIN == 5

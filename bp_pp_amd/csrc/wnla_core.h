@@ -32,6 +32,12 @@ struct WnlaWs {
     u32* tab;              // [2 * 2^rounds * 8][N]: ch table then cg table
     u32* msc;              // [(1+ng+nh)*8][N]
     pt_slot* straus;       // [N][2][9]
+    // fast variable-base path for the rounds (null: the generic projective tables above are used): affine window tables of the
+    // 2 x rounds round points of every instance, built by one kernel with four batched inversions (verify_core.h:
+    // affine_tables_build), then Jacobian accumulators with mixed additions over signed 5-bit windows (straus_affine)
+    apt_packed* atab;      // [2 * rounds * 16][N] 64-byte entries: point 2 (k - 1) = X of round k, 2 (k - 1) + 1 = R of round k
+    u32* tscr;             // [14 * 2 * rounds * 10][N] running products of the table build
+    u32* rpts;             // [2 * rounds * 16][N] the decoded round points (packed affine words)
     FbTable fb;
     strobe base;
     TranscriptIo tio;      // caller's transcripts (wnla.rs:75 `t: &mut Transcript`); the input side is ignored when transcript_preloaded
@@ -101,6 +107,21 @@ HD void wnla_verify_begin(const WnlaWs& w, size_t t) {
     }
     w.status[t] = w.transcript_preloaded ? (w.status[t] | status) : status;
 }
+// ---- verify, fast path: decode the round points of all rounds and build their window tables.  A round whose X or R does not
+// decode gets the identity for both (exactly what wnla_verify_round substitutes when it flags the instance).
+HD void wnla_verify_tables(const WnlaWs& w, size_t t) {
+    const size_t N = w.N;
+#pragma nounroll
+    for (int k = 1; k <= w.rounds; k++) {
+        apt X, R;
+        bool ok = apt_from_xy64(X, w.proof_x + (size_t)t * w.stride_x + (size_t)(w.rounds - k) * 64);
+        ok &= apt_from_xy64(R, w.proof_r + (size_t)t * w.stride_r + (size_t)(w.rounds - k) * 64);
+        if (!ok) { fe_set_u32(X.x, 0); fe_set_u32(X.y, 0); R = X; }
+        ws_st_apt(w.rpts, N, t, 2 * (k - 1), X);
+        ws_st_apt(w.rpts, N, t, 2 * (k - 1) + 1, R);
+    }
+    affine_tables_build(atab_of(w.atab, N, t, 2 * w.rounds * 16), w.tscr, w.rpts, N, t, 2 * w.rounds);
+}
 // ---- verify: round k = 1..rounds (wnla.rs:84-102), X = proof.x[rounds - k], R = proof.r[rounds - k]
 HD void wnla_verify_round(const WnlaWs& w, size_t t, int k) {
     const size_t N = w.N;
@@ -127,14 +148,25 @@ HD void wnla_verify_round(const WnlaWs& w, size_t t, int k) {
     sc_set_u32(one, 1);
     sc_mul(y2m1, y, y);
     sc_sub(y2m1, y2m1, one);
-    pt_slot* tbl = w.straus + t * (2 * BPPP_STRAUS_ENTRIES);
-    glv_split rs[2];
-    straus_build_table(tbl, X);
-    straus_build_table(tbl + BPPP_STRAUS_ENTRIES, R);
-    glv_decompose(rs[0], y);
-    glv_decompose(rs[1], y2m1);
     pt acc;
-    straus_msm_glv(acc, tbl, rs, 2);
+    if (w.atab) {
+        const int pslot[2] = {2 * (k - 1), 2 * (k - 1) + 1};
+        glv_words<2> g;
+        glv_split sp;
+        glv_decompose(sp, y);
+        glv_words_set<2>(g, 0, sp);
+        glv_decompose(sp, y2m1);
+        glv_words_set<2>(g, 1, sp);
+        straus_affine<2>(acc, atab_of(w.atab, N, t, 2 * w.rounds * 16), pslot, g);
+    } else {
+        pt_slot* tbl = w.straus + t * (2 * BPPP_STRAUS_ENTRIES);
+        glv_split rs[2];
+        straus_build_table(tbl, X);
+        straus_build_table(tbl + BPPP_STRAUS_ENTRIES, R);
+        glv_decompose(rs[0], y);
+        glv_decompose(rs[1], y2m1);
+        straus_msm_glv(acc, tbl, rs, 2);
+    }
     pt_madd(acc, acc, Ca, apt_is_identity(Ca));
     ws_st_pt(w.acc, N, t, acc);
     w.status[t] = status;

@@ -462,6 +462,23 @@ void emul_sec1_expand(size_t n, const uint8_t* c33, const uint8_t* p525, uint8_t
 // generic WNLA commit / verify, every stage in thread order (commit: out_points; verify: accept)
 // Pre-loaded transcripts for the NEXT generic verify call (emul_wnla_run / emul_recip_verify / emul_circuit_verify): states in
 // (n_states = 1 or n), per-instance advanced states out; consumed by that call.
+// the generic verifiers' fast variable-base path (affine window tables of the round points): buffers for the emulation; switched off
+// with emul_set_generic_slow_rounds(1) so that both paths are covered
+static int g_generic_slow_rounds = 0;
+void emul_set_generic_slow_rounds(int on) { g_generic_slow_rounds = on; }
+struct FastRounds {
+    std::vector<apt_packed> atab;
+    std::vector<u32> tscr, rpts;
+    void attach(WnlaWs& w, size_t n, int rounds) {
+        w.atab = nullptr; w.tscr = nullptr; w.rpts = nullptr;
+        if (rounds == 0 || g_generic_slow_rounds) return;
+        const size_t np = 2 * (size_t)rounds;
+        atab.assign(np * 16 * n, apt_packed());
+        tscr.assign(14 * np * 10 * n, 0u);
+        rpts.assign(np * 16 * n, 0u);
+        w.atab = atab.data(); w.tscr = tscr.data(); w.rpts = rpts.data();
+    }
+};
 static TranscriptIo g_tio = {nullptr, 0, nullptr, 0};
 // random-linear-combination mode for the NEXT emul_recip_verify call (consumed by it); flags_out: 1 per chunk of 8 re-checked exactly
 static const uint8_t* g_rlc_seed = nullptr;
@@ -504,7 +521,10 @@ int emul_wnla_run(int commit, const uint8_t* table, int W, int ng, int nh, const
         t_new(w.base, label, (u32)label_len);
         w.tio = take_tio();
         w.tio.no_ops = rounds == 0;
+        FastRounds fastr;
+        fastr.attach(w, n, rounds);
         for (size_t t = 0; t < n; t++) wnla_verify_begin(w, t);
+        if (w.atab) for (size_t t = 0; t < n; t++) wnla_verify_tables(w, t);
         for (int k = 1; k <= rounds; k++)
             for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, k);
         for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);
@@ -552,7 +572,10 @@ int emul_recip_verify(const uint8_t* table, int W, int NG, int NH, int nd, int n
     }
     for (size_t t = 0; t < n; t++) recip_c0_var(r, t);
     for (size_t t = 0; t < n; t++) recip_c0_finish(r, t);
+    FastRounds fastr;
+    fastr.attach(w, n, rounds);
     for (size_t t = 0; t < n; t++) wnla_verify_begin(w, t);
+    if (w.atab) for (size_t t = 0; t < n; t++) wnla_verify_tables(w, t);
     for (int k = 1; k <= rounds; k++)
         for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, k);
     for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);
@@ -642,7 +665,10 @@ int emul_circuit_verify(const uint8_t* table, int W, int NG, int NH, const size_
     for (size_t t = 0; t < n; t++) circuit_c0_finish(r, t);
     if (c0_out) memcpy(c0_out, wc.data(), wc.size());
     if (c_out) memcpy(c_out, wcv.data(), wcv.size());
+    FastRounds fastr;
+    fastr.attach(w, n, rounds);
     for (size_t t = 0; t < n; t++) wnla_verify_begin(w, t);
+    if (w.atab) for (size_t t = 0; t < n; t++) wnla_verify_tables(w, t);
     for (int kk = 1; kk <= rounds; kk++)
         for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, kk);
     for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);

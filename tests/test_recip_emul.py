@@ -101,3 +101,37 @@ def test_generic_reciprocal_verify_rlc_mode_equals_exact_mode():
     for b in (8, 9, 12, 17, 18):
         rc = recip_cases.oracle_verify(case, bytes(com[b]), bytes(P[b]))
         assert int(acc1[b]) == (1 if rc == 1 else 0)
+
+
+def test_fast_and_projective_round_paths_agree():
+    """The generic verifiers' rounds run on affine window tables of all round points (one table-build pass, Jacobian accumulators,
+    signed 5-bit windows) by default; the projective tables + complete additions they replaced are still there
+    (emul_set_generic_slow_rounds / BPPP_GENERIC_SLOW_ROUNDS).  Same verdicts and statuses, tampered and malformed round points
+    included."""
+    L = load()
+    nd, npp, B = 12, 10, 6
+    case = recip_cases.make(nd, npp, B=B)
+    W = 4
+    gens = case["g"] + b"".join(case["gv"]) + b"".join(case["gv_"]) + b"".join(case["hv"]) + b"".join(case["hv_"])
+    NB = 1 + case["NG"] + case["NH"]
+    tab = np.zeros(L.emul_fb_table_entries(NB, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, NB, W, tab.ctypes.data) == 0
+    P, com = case["proofs"].copy(), case["commitments"].copy()
+    r = case["rounds"]
+    P[1, 256 + 5] ^= 0x10                          # r[0] coordinate: off the curve
+    P[2, 256 + 64 * r + 64 * (r - 1) + 40] ^= 1    # x[rounds - 1] (the first round's X): off the curve
+    P[3, 256:320] = P[3, 256 + 64 * r:320 + 64 * r]  # r[0] := x[0]: a valid but wrong point
+    P[4, 256:320] = 0                              # the identity as a round point
+    res = []
+    for slow in (0, 1):
+        L.emul_set_generic_slow_rounds(slow)
+        acc, st = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        L.emul_recip_verify(tab.ctypes.data, W, case["NG"], case["NH"], nd, npp, case["label"], len(case["label"]), B, com.ctypes.data,
+                            P.ctypes.data, r, case["nl"], case["nn"], acc.ctypes.data, st.ctypes.data)
+        res.append((acc.copy(), st.copy()))
+    L.emul_set_generic_slow_rounds(0)
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
+    assert res[0][0].tolist() == [1, 0, 0, 0, 0, 1] and res[0][1].tolist() == [0, 1, 1, 0, 0, 0]
+    for b in range(B):
+        rc = recip_cases.oracle_verify(case, bytes(com[b]), bytes(P[b]))
+        assert int(res[0][0][b]) == (1 if rc == 1 else 0) and (int(res[0][1][b]) != 0) == (rc < 0)
