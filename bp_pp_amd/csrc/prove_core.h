@@ -48,7 +48,7 @@ struct ProveWs {
     u32* sv;                // [SV_COUNT*8][N]
     u32* msc;               // [4*49*8][N]
     u32* pbuf;              // [PB_COUNT*30][N]
-    pt_slot* straus;        // [N][2][9]
+    pt_slot* straus;        // [N][5][9] projective slots: prove_round_fold re-uses the bytes as affine window tables + build scratch
     FbTable fb;
     strobe base;
     // pre-loaded transcripts (the reference's `t: &mut Transcript`, u64_proof.rs:57): as VerifyWs::states
@@ -619,14 +619,26 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
         sc_set_u32(one, 1);
         sc_mul(y2m1, y, y);
         sc_sub(y2m1, y2m1, one);
-        pt_slot* tbl = w.straus + t * (2 * BPPP_STRAUS_ENTRIES);
-        glv_split rs[2];
-        straus_build_table(tbl, A[1]);
-        straus_build_table(tbl + BPPP_STRAUS_ENTRIES, A[2]);
-        glv_decompose(rs[0], y);
-        glv_decompose(rs[1], y2m1);
+        // the verifier's fast variable-base path (verify_core.h): affine window tables 1..16 of X and R from one four-level pass,
+        // Jacobian accumulator, mixed additions, signed 5-bit windows.  Its buffers are carved out of the window-table workspace
+        // (45 projective slots = 5.4 KB per proof): 32 table entries (2 KB), 28 running products (1.1 KB), the two points (128 B).
+        uint8_t* sb = (uint8_t*)w.straus;
+        apt_packed* atab = (apt_packed*)sb;
+        u32* tscr = (u32*)(sb + (size_t)32 * sizeof(apt_packed) * N);
+        u32* rpts = tscr + (size_t)28 * 10 * N;
+        ws_st_apt(rpts, N, t, 0, A[1]);
+        ws_st_apt(rpts, N, t, 1, A[2]);
+        const atab_ref tab = atab_of(atab, N, t, 32);
+        affine_tables_build(tab, tscr, rpts, N, t, 2);
+        const int pslot[2] = {0, 1};
+        glv_words<2> g;
+        glv_split sp;
+        glv_decompose(sp, y);
+        glv_words_set<2>(g, 0, sp);
+        glv_decompose(sp, y2m1);
+        glv_words_set<2>(g, 1, sp);
         pt acc;
-        straus_msm_glv(acc, tbl, rs, 2);
+        straus_affine<2>(acc, tab, pslot, g);
         pt_madd(acc, acc, A[0], apt_is_identity(A[0]));
         pw_st_pt(w, t, PB_C, acc);
     } else {

@@ -433,7 +433,7 @@ static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label
     w.states = states; w.n_states = n_states; w.states_out = states_out;
     w.x = x; w.s = s; w.rnd = rnd; w.proofs = proofs; w.commitments = V; w.status = status;
     std::vector<u32> tstate(52 * n), sv((size_t)SV_COUNT * 8 * n), msc((size_t)BPPP_MSC_SETS * BPPP_NG * 8 * n), pbuf((size_t)PB_COUNT * 30 * n);
-    std::vector<pt_slot> straus(n * 2 * BPPP_STRAUS_ENTRIES);
+    std::vector<pt_slot> straus(n * 5 * BPPP_STRAUS_ENTRIES);      // as the library sizes it: prove_round_fold carves its window tables out of it
     w.tstate = tstate.data(); w.sv = sv.data(); w.msc = msc.data(); w.pbuf = pbuf.data(); w.straus = straus.data();
     w.fb.table = (const apt_packed*)table; w.fb.W = W; w.fb.N = n;
     t_new(w.base, label, (u32)label_len);
