@@ -79,18 +79,28 @@ def test_complete_point_formulas_and_straus(L):
 
 
 def test_glv_split_and_straus(L):
-    """k = k1 + k2*lambda (mod n) with both halves below 2^129, then the full GLV shared-doubling MSM."""
+    """k = k1 + k2*lambda (mod n) with both halves below 2^128 (the lattice bound is (|a1| + |a2|) / 2 < 2^127.4; the signed 5-bit
+    recoding of the u64 verifier needs |k_i| + OFF5 < 2^130, i.e. |k_i| < 1.93 * 2^128), then the full GLV shared-doubling MSM."""
     rnd = random.Random(13)
     OFF = int("8" * 33, 16)
     k1p, k2p = (C.c_uint32 * 5)(), (C.c_uint32 * 5)()
     n1, n2 = C.c_int(), C.c_int()
-    for k in [0, 1, 2, O.N - 1, O.N // 2, O.LAMBDA, O.N - O.LAMBDA, 2**128, 2**255] + [rnd.getrandbits(256) % O.N for _ in range(300)]:
+    # the basis of the decomposition lattice: the halves are largest near the corners of its fundamental cell
+    a1, b1 = 0x3086D221A7D46BCDE86C90E49284EB15, -0xE4437ED6010E88286F547FA90ABFE4C3
+    a2, b2 = 0x114CA50F7A8E2F3F657C1108D9D44CFD8, 0x3086D221A7D46BCDE86C90E49284EB15
+    corners = [((u * a1 + v * a2) // 2 + (u * b1 + v * b2) // 2 * O.LAMBDA + d) % O.N for u in (-1, 1) for v in (-1, 1) for d in range(-3, 4)]
+    structured = [(i * O.N) // 64 + j for i in range(64) for j in (-1, 0, 1)] + [(1 << i) % O.N for i in range(0, 256, 7)]
+    worst = 0
+    for k in [0, 1, 2, O.N - 1, O.N // 2, O.LAMBDA, O.N - O.LAMBDA, 2**128, 2**255] + corners + [x % O.N for x in structured] + \
+            [rnd.getrandbits(256) % O.N for _ in range(1500)]:
         L.emul_glv_split(b32(k), k1p, k2p, C.byref(n1), C.byref(n2))
         a = sum(int(k1p[i]) << (32 * i) for i in range(5)) - OFF
         b = sum(int(k2p[i]) << (32 * i) for i in range(5)) - OFF
-        assert 0 <= a < 2**129 and 0 <= b < 2**129
+        assert 0 <= a < 2**128 and 0 <= b < 2**128
+        worst = max(worst, a, b)
         a, b = (-a if n1.value else a), (-b if n2.value else b)
         assert (a + b * O.LAMBDA) % O.N == k
+    assert 2**126 < worst < 2**128                 # the corners do get close to the bound, and stay under it
     pts = [None, O.G, O.pt_neg(O.G)] + [O.pt_mul(O.G, rnd.getrandbits(256)) for _ in range(5)]
     out = C.create_string_buffer(64)
     for m in (1, 2, 5):
