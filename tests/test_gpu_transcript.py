@@ -207,3 +207,58 @@ def test_generic_provers_over_preloaded_transcripts_on_the_gpu():
         assert acc.tolist() == [1] + [0] * (len(acc) - 1)
     finally:
         ckt.close()
+
+
+def test_every_sponge_position_in_one_batch():
+    """166 proofs whose transcripts sit at ALL 166 byte positions of the STROBE-128 rate (context messages of every length mod
+    166): three wavefronts in which every lane is its own position group.  Proofs from the GPU prover over those transcripts, then
+    verified over them: all accepted, the advanced states equal the prover's, and a sample (every 17th position) reproduced by the
+    Python oracle -- proof bytes, verdict and both advanced states."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import bppp_oracle as O
+    import workload
+    from transcript_cases import ser
+    from bp_pp_amd import U64RangeProofProtocol, synth
+    from bp_pp_amd.transcript import Transcript
+    gens = workload.generators()
+    g, gv, hv = workload.split_generators(gens)
+    ts, seen = [], set()
+    for j in range(400):
+        t = Transcript(synth.LABEL)
+        t.append_message(b"ctx", bytes([j & 0xFF]) * j)
+        pos = t.state[200]
+        if pos not in seen:
+            seen.add(pos)
+            ts.append((pos, j, t))
+        if len(seen) == 166:
+            break
+    assert len(seen) == 166
+    ts.sort()
+    n = len(ts)
+    S = np.frombuffer(b"".join(t.state for _, _, t in ts), np.uint8).reshape(n, 203).copy()
+    x, s, rnd = synth.bulk_values(n, first=900), synth.bulk_blindings(n, first=900), synth.bulk_prover_randomness(n, first=900)
+    proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
+    try:
+        proofs, com, st, after_prove = proto.prove_batch_transcript(x, s, rnd, S)
+        assert not st.any()
+        acc, vst, after_verify = proto.verify_batch_transcript(com, proofs, S)
+        assert acc.all() and not vst.any() and (after_verify == after_prove).all()       # prover and verifier leave the same transcript
+        acc2, _, _ = proto.verify_batch_transcript(com, proofs, np.roll(S, 1, axis=0))  # everybody on a neighbour's transcript
+        assert not acc2.any()
+    finally:
+        proto.close()
+    pts = [O.pt_from_xy64(gens[64 * i:64 * i + 64]) for i in range(49)]
+    oproto = O.U64RangeProofProtocol(pts[0], pts[1:17], pts[17:49])
+    for i in range(0, n, 17):
+        _, j, _ = ts[i]
+        t = O.Transcript(synth.LABEL)
+        t.append_message(b"ctx", bytes([j & 0xFF]) * j)
+        assert ser(t) == bytes(S[i])
+        tp = t.clone()
+        rs = [int.from_bytes(bytes(rnd[i, 32 * k:32 * k + 32]), "big") for k in range(52)]
+        pr = oproto.prove(int(x[i]), int.from_bytes(bytes(s[i]), "big"), tp, O.ScalarRng(rs))
+        assert O.u64_proof_to_bytes(pr) == bytes(proofs[i]) and ser(tp) == bytes(after_prove[i])
+        tv = t.clone()
+        assert oproto.verify(O.pt_from_xy64(bytes(com[i])), pr, tv) and ser(tv) == bytes(after_verify[i])
