@@ -115,7 +115,7 @@ struct bppp_ctx {
     int n_simds = 1024;            // CUs x 4 (device property), decides between the small-batch and the 2-waves/SIMD lane kernels
     bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
-    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false;   // diagnostics, read from the environment once at context creation
+    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false, no_lane_groups = false;   // diagnostics, read from the environment once at context creation
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> event_pool;
     double total_ms[K_COUNT] = {0};
@@ -337,6 +337,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     c->fb_w = W;
     c->n_simds = device_simds(device);
     c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;
+    c->no_lane_groups = std::getenv("BPPP_NO_LANE_GROUPS") != nullptr;   // diagnostic: one lane per proof at every batch size
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // diagnostic: projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
     c->ng = (int)ng; c->nh = (int)nh; c->nbases = NB;
@@ -607,11 +608,16 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
     LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_join, a));
-    if (small) LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    // a batch whose four-lanes-per-proof grid still leaves the SIMDs under-filled runs its variable-base sums on lane groups
+    const bool grouped = !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds;
+    const unsigned g4_blocks = (unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    if (grouped) LAUNCH(K_C0_VAR, k_verify_c0_var_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws));
+    else if (small) LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     else LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     for (int k = 1; k <= 4; k++) {
-        if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+        if (grouped) LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+        else if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
         else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
     }
     LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
@@ -908,7 +914,10 @@ static int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len
     for (int k = 1; k <= 4; k++) {
         PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         PMSM(job_x()); PMSM(job_r());
-        PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        if (!c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
+            PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
+        else
+            PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
     }
     if (w.states_out) k_prove_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
 #undef PMSM
@@ -2089,6 +2098,7 @@ static int ctx_alloc_common(bppp_ctx* c) {
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRY(hipMalloc(&c->d_flags, sizeof(int)));
     c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;
+    c->no_lane_groups = std::getenv("BPPP_NO_LANE_GROUPS") != nullptr;   // diagnostic: one lane per proof at every batch size
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // diagnostic: projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
     c->n_simds = device_simds(c->device);

@@ -43,6 +43,14 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(ProveWs w, int 
     if (t >= w.N) return;
     for_each_position_group(prove_position_key(w, t), [&]() { prove_round_fold(w, t, k); });
 }
+// small batches: four lanes per proof, the next-commitment sum split into its four GLV streams (verify_core.h: straus_affine_g4)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold_g4(ProveWs w, int k) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 2;
+    if (t >= w.N) return;
+    const int q = (int)(g & 3);
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_round_fold(w, t, k, q); });
+}
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(ProveWs w, MsmJob job) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
     size_t t = g / BPPP_FB_LANES;

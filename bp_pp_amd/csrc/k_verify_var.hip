@@ -36,3 +36,19 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(VerifyWs ws, RlcWs r) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N && !rlc_done_by_bucket_stage(r, t)) rlc_lhs(ws, r, t);
 }
+
+// small batches (4 n lanes still leave SIMDs empty): four lanes per proof, the round's two-point sum split into its four GLV
+// streams (verify_core.h: straus_affine_g4); everything else is done identically by the four lanes
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g4(VerifyWs ws, int k) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 2;
+    if (t >= ws.N) return;                    // whole groups leave together
+    const int q = (int)(g & 3);
+    const u32 key = (ws.states && ws.n_states != 1) ? ws.tstate[(size_t)50 * ws.N + t] : 0u;
+    for_each_position_group(key, [&]() { verify_round(ws, t, k, q); });
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g4(VerifyWs ws) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 2;
+    if (t < ws.N) verify_c0_var(ws, t, (int)(g & 3));
+}

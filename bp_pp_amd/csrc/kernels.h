@@ -83,6 +83,8 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_roun
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_small(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_small(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_small(bppp::VerifyWs ws, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g4(bppp::VerifyWs ws, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g4(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(bppp::VerifyWs ws, int* reject_count);
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_export_states(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(bppp::ProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold_g4(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(bppp::ProveWs w, bppp::MsmJob job);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_scalars(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(bppp::WnlaWs w);

@@ -551,7 +551,9 @@ HD void prove_round_scalars(const ProveWs& w, size_t t, int k) {
     }
 }
 // ---------------------------------------------------------------- WNLA round k: transcript, challenge, folds, next commitment (wnla.rs:162-188)
-HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
+// group_lane >= 0: one of four consecutive lanes that all run the round for proof t (identical work and stores; the next-commitment
+// sum is shared through straus_affine_g4) -- small batches; -1: one lane per proof
+HD void prove_round_fold(const ProveWs& w, size_t t, int k, int group_lane = -1) {
     const size_t N = w.N;
     const int sh = k - 1, nl = 32 >> sh, nn = 16 >> sh;
     int32_t status = w.status[t];
@@ -638,7 +640,11 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
         glv_decompose(sp, y2m1);
         glv_words_set<2>(g, 1, sp);
         pt acc;
-        straus_affine<2>(acc, tab, pslot, g);
+#if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
+        if (group_lane >= 0) straus_affine_g4<2>(acc, tab, pslot, g, group_lane);
+        else
+#endif
+            straus_affine<2>(acc, tab, pslot, g);
         pt_madd(acc, acc, A[0], apt_is_identity(A[0]));
         pw_st_pt(w, t, PB_C, acc);
     } else {
@@ -649,6 +655,7 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
         sc_to_be(pb + 864, l1);
         sc_to_be(pb + 896, n0);
     }
+    (void)group_lane;
     w.status[t] = status;
 }
 

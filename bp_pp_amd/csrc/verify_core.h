@@ -1175,6 +1175,98 @@ HD void straus_affine(pt& out, atab_ref tab, const int* pidx, const glv_words<M>
     }
 }
 
+#if defined(__HIPCC__) && BPPP_VWIN == 5
+// The same M-point sum spread over a GROUP OF FOUR LANES: lane q takes the GLV streams q, q + 4, q + 8 (< 2M; stream r is point
+// r >> 1, its image if r & 1), i.e. 26 windows x (5 doublings + 1 .. 3 mixed additions) per lane instead of 26 x (5 + 2M), then a
+// two-step shuffle tree.  For batches so small that the chip is mostly empty (one lane per proof leaves SIMDs without a wavefront)
+// this shortens the dependent chain a call has to wait for; the doublings are repeated on every lane, so it is not used once one lane
+// per proof fills the SIMDs.  All four lanes of a group must be active and hold the same g / pidx; every lane ends with the total.
+template <int M>
+__device__ __forceinline__ void straus_affine_g4(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g, int q) {
+    constexpr int NS = (2 * M + 3) / 4;          // streams per lane (the last one may be missing on lanes 2M mod 4 .. 3)
+    fe beta;
+    glv_beta(beta);
+    u32 w[NS][5];
+    bool sneg[NS], img[NS], have[NS];
+    int pn[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        const int r = q + 4 * j;                 // my j-th stream
+        have[j] = r < 2 * M;
+        sneg[j] = false;
+        pn[j] = 0;
+#pragma unroll
+        for (int l = 0; l < 5; l++) w[j][l] = 0;
+#pragma unroll
+        for (int st = 0; st < 2 * M; st++) {
+#pragma unroll
+            for (int l = 0; l < 5; l++) w[j][l] = (st == r) ? g.w[st][l] : w[j][l];
+            sneg[j] = (st == r) ? g.neg[st] : sneg[j];
+            pn[j] = (st == r) ? pidx[st >> 1] : pn[j];
+        }
+        img[j] = (r & 1) != 0;
+    }
+    auto digit = [&](const u32 (&ww)[5], bool sn, int i, int& mag, bool& neg) {
+        const int b = 5 * i, l = b >> 5, sh = b & 31;
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { lo = (k == l) ? ww[k] : lo; hi = (k == l + 1) ? ww[k] : hi; }
+        const int dg = (int)((u32)(((((u64)hi) << 32) | lo) >> sh) & 31u) - 16;
+        mag = dg < 0 ? -dg : dg;
+        neg = (dg < 0) != sn;
+    };
+    ptj acc;
+    ptj_init(acc);
+    bool empty = true;
+    int cur_mag[NS], nxt_mag[NS];
+    bool cur_neg[NS], nxt_neg[NS];
+    apt_packed cur_e[NS], nxt_e[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        digit(w[j], sneg[j], BPPP_VWINDOWS - 1, cur_mag[j], cur_neg[j]);
+        cur_e[j] = tab[pn[j] * 16 + (cur_mag[j] ? cur_mag[j] - 1 : 0)];
+    }
+#pragma nounroll
+    for (int i = BPPP_VWINDOWS - 1; i >= 0; i--) {
+#pragma unroll
+        for (int j = 0; j < NS; j++) {           // the next window's entries are requested before this window's doublings
+            digit(w[j], sneg[j], i > 0 ? i - 1 : 0, nxt_mag[j], nxt_neg[j]);
+            nxt_e[j] = tab[pn[j] * 16 + (nxt_mag[j] ? nxt_mag[j] - 1 : 0)];
+        }
+        if (i != BPPP_VWINDOWS - 1) {
+#pragma nounroll
+            for (int d = 0; d < 5; d++) ptj_dbl(acc);
+        }
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            apt e;
+            bool id;
+            apt_unpack(e, id, cur_e[j]);
+            fe bx, ny;
+            fe_mul(bx, e.x, beta);
+            fe_cmov(e.x, img[j], bx);
+            fe_neg_m<1>(ny, e.y);
+            fe_cmov(e.y, cur_neg[j], ny);
+            ptj_madd(acc, empty, e, (cur_mag[j] == 0) | id | !have[j]);
+            cur_e[j] = nxt_e[j];
+            cur_mag[j] = nxt_mag[j];
+            cur_neg[j] = nxt_neg[j];
+        }
+    }
+    int bad = (!empty && fe_is_zero(acc.Z)) ? 1 : 0;
+    bad |= __shfl_xor(bad, 1, 64);
+    bad |= __shfl_xor(bad, 2, 64);
+    if (bad) {                      // an exceptional addition somewhere in the group: every lane re-does the whole sum completely
+        straus_affine_complete<M>(out, tab, pidx, g);
+        return;
+    }
+    pt part;
+    ptj_to_pt(part, acc, empty);
+    lane_group_sum<4>(part);
+    out = part;
+}
+#endif
+
 // ---------------------------------------------------------------- phase 1: decode, transcript up to tau, scalar derivation
 // reciprocal.rs:98-104 + circuit.rs:155-228 (closed forms of SURVEY.md 8a)
 HD void verify_phase1(const VerifyWs& ws, size_t t) {
@@ -1405,7 +1497,7 @@ HD void verify_c0_fixed(const VerifyWs& ws, size_t t) {
     verify_c0_fixed_store(ws, t, acc);
 }
 // ---------------------------------------------------------------- phase 2a: C0 variable-base part (circuit.rs:230-235)
-HD void verify_c0_var(const VerifyWs& ws, size_t t) {
+HD void verify_c0_var(const VerifyWs& ws, size_t t, int group_lane = -1) {
     const size_t N = ws.N;
     const int pslot[5] = {3, 2, 0, 1, 12};  // c_s, c_o, c_l, c_r, V+r  <->  sc0 slots 17..21
     glv_words<5> g;
@@ -1419,12 +1511,19 @@ HD void verify_c0_var(const VerifyWs& ws, size_t t) {
     }
     BPPP_STAMP(t, 20);
     pt acc;
-    straus_affine<5>(acc, atab_of(ws.atab, ws.N, t), pslot, g);
+#if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
+    if (group_lane >= 0) straus_affine_g4<5>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
+    else
+#endif
+        straus_affine<5>(acc, atab_of(ws.atab, ws.N, t), pslot, g);
+    (void)group_lane;
     BPPP_STAMP(t, 21);
     ws_st_pt(ws.acc, N, t, acc);   // the fixed-base part (pfix) is added at the top of round 1
 }
 // ---------------------------------------------------------------- phase 3 (k = 1..4): one WNLA round (wnla.rs:84-102)
-HD void verify_round(const VerifyWs& ws, size_t t, int k) {
+// group_lane >= 0: this lane is one of four consecutive lanes that all run the round for proof t (identical work and identical
+// stores, except the sum, which they share: straus_affine_g4) -- the small-batch kernels; -1: one lane per proof
+HD void verify_round(const VerifyWs& ws, size_t t, int k, int group_lane = -1) {
     const size_t N = ws.N;
     pt C;
     ws_ld_pt(C, ws.acc, N, t);
@@ -1478,7 +1577,12 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k) {
     glv_words_set<2>(g, 1, sp);
     BPPP_STAMP(t, 12);
     pt acc;
-    straus_affine<2>(acc, atab_of(ws.atab, ws.N, t), pslot, g);
+#if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
+    if (group_lane >= 0) straus_affine_g4<2>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
+    else
+#endif
+        straus_affine<2>(acc, atab_of(ws.atab, ws.N, t), pslot, g);
+    (void)group_lane;
     BPPP_STAMP(t, 13);
     pt_madd(acc, acc, Ca, apt_is_identity(Ca));
     ws_st_pt(ws.acc, N, t, acc);
