@@ -617,6 +617,8 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     for (int k = 1; k <= 4; k++) {
         if (grouped) LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+        else if (!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds)
+            LAUNCH(K_ROUND, k_verify_round_g2<<<(unsigned)((2 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
         else if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
         else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
     }
@@ -1089,6 +1091,13 @@ static int wnla_fast_setup(bppp_ctx* c, WnlaWs& w, size_t n, size_t rounds) {
     w.rpts = (u32*)(c->d_gtab + b_tab + b_scr);
     return BPPP_OK;
 }
+// lanes per instance for the generic rounds: 4 or 2 while that still leaves wavefront slots free (and the fast path's tables exist)
+static int wnla_round_group(const bppp_ctx* c, const WnlaWs& w, unsigned blocks) {
+    if (!w.atab || c->no_lane_groups) return 1;
+    if (4 * (size_t)blocks <= (size_t)c->n_simds) return 4;
+    if (2 * (size_t)blocks <= (size_t)c->n_simds) return 2;
+    return 1;
+}
 // ---- generic WeightNormLinearArgument entry points (host pointers; one device blob per call)
 struct WnlaBlob {
     uint8_t* d = nullptr;
@@ -1159,7 +1168,13 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
         if (rc != BPPP_OK) return rc;
         k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
         if (w.atab) k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w);
-        for (int k = 1; k <= (int)rounds; k++) k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+        {
+            const int grp = wnla_round_group(c, w, blocks);
+            for (int k = 1; k <= (int)rounds; k++) {
+                if (grp > 1) k_wnla_round_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k, grp);
+                else k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+            }
+        }
         k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
         k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
         k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
@@ -1278,7 +1293,13 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     if (rc != BPPP_OK) return rc;
     GLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     if (w.atab) GLAUNCH(K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-    for (int k = 1; k <= (int)rounds; k++) GLAUNCH(K_WNLA_ROUND, k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+    {
+        const int grp = wnla_round_group(c, w, blocks);
+        for (int k = 1; k <= (int)rounds; k++) {
+            if (grp > 1) GLAUNCH(K_WNLA_ROUND, k_wnla_round_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k, grp));
+            else GLAUNCH(K_WNLA_ROUND, k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        }
+    }
     GLAUNCH(K_WNLA_FINAL_SCALARS, k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     if (!rlc_seed) {
         GLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
@@ -1553,7 +1574,13 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
     }
     k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     if (w.atab) k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w);
-    for (int kk = 1; kk <= (int)rounds; kk++) k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
+    {
+        const int grp = wnla_round_group(c, w, blocks);
+        for (int kk = 1; kk <= (int)rounds; kk++) {
+            if (grp > 1) k_wnla_round_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, kk, grp);
+            else k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
+        }
+    }
     k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
     k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);

@@ -26,6 +26,15 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_wnla_tabl
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) wnla_verify_tables(w, t);
 }
+// the round on lane groups (group = 2 or 4 lanes per instance), for batches that under-fill the chip; needs the fast path's tables
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round_grp(WnlaWs w, int k, int group) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g / (size_t)group;
+    if (t >= w.N) return;
+    const int q = (int)(g % (size_t)group);
+    const u32 key = w.divergent_positions ? w.tstate[(size_t)50 * w.N + t] : 0u;
+    for_each_position_group(key, [&]() { wnla_verify_round(w, t, k, q, group); });
+}
 // per-instance advanced transcripts back to the caller (any of the generic verifiers: they all end in the WNLA stage)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_generic_export_states(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;

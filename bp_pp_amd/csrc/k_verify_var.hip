@@ -52,3 +52,12 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g4(VerifyWs ws) {
     const size_t t = g >> 2;
     if (t < ws.N) verify_c0_var(ws, t, (int)(g & 3));
 }
+// two lanes per proof: batches between a quarter and a half of the wavefront slots (one lane per proof would leave half the SIMDs empty)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g2(VerifyWs ws, int k) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 1;
+    if (t >= ws.N) return;
+    const int q = (int)(g & 1);
+    const u32 key = (ws.states && ws.n_states != 1) ? ws.tstate[(size_t)50 * ws.N + t] : 0u;
+    for_each_position_group(key, [&]() { verify_round(ws, t, k, q, 2); });
+}

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_small(bppp::Verify
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_small(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g4(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g4(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g2(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(bppp::VerifyWs ws, int* reject_count);
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round(bppp::WnlaWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_generic_export_states(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_wnla_tables(bppp::WnlaWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round_grp(bppp::WnlaWs w, int k, int group);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_rlc_lhs(bppp::WnlaWs w, bppp::RlcWs r);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_rlc_chunk(bppp::WnlaWs w, bppp::RlcWs r);
 __global__ __launch_bounds__(64) void k_wnla_rlc_check(bppp::WnlaWs w, bppp::RlcWs r);

@@ -1181,9 +1181,10 @@ HD void straus_affine(pt& out, atab_ref tab, const int* pidx, const glv_words<M>
 // two-step shuffle tree.  For batches so small that the chip is mostly empty (one lane per proof leaves SIMDs without a wavefront)
 // this shortens the dependent chain a call has to wait for; the doublings are repeated on every lane, so it is not used once one lane
 // per proof fills the SIMDs.  All four lanes of a group must be active and hold the same g / pidx; every lane ends with the total.
-template <int M>
+template <int M, int G = 4>
 __device__ __forceinline__ void straus_affine_g4(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g, int q) {
-    constexpr int NS = (2 * M + 3) / 4;          // streams per lane (the last one may be missing on lanes 2M mod 4 .. 3)
+    // (G = 2: groups of two lanes, streams q, q + 2, ... -- for batches that fill half of the wavefront slots with one lane per proof)
+    constexpr int NS = (2 * M + G - 1) / G;      // streams per lane (the last one may be missing on the last lanes of the group)
     fe beta;
     glv_beta(beta);
     u32 w[NS][5];
@@ -1191,7 +1192,7 @@ __device__ __forceinline__ void straus_affine_g4(pt& out, atab_ref tab, const in
     int pn[NS];
 #pragma unroll
     for (int j = 0; j < NS; j++) {
-        const int r = q + 4 * j;                 // my j-th stream
+        const int r = q + G * j;                 // my j-th stream
         have[j] = r < 2 * M;
         sneg[j] = false;
         pn[j] = 0;
@@ -1254,15 +1255,15 @@ __device__ __forceinline__ void straus_affine_g4(pt& out, atab_ref tab, const in
         }
     }
     int bad = (!empty && fe_is_zero(acc.Z)) ? 1 : 0;
-    bad |= __shfl_xor(bad, 1, 64);
-    bad |= __shfl_xor(bad, 2, 64);
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) bad |= __shfl_xor(bad, m, 64);
     if (bad) {                      // an exceptional addition somewhere in the group: every lane re-does the whole sum completely
         straus_affine_complete<M>(out, tab, pidx, g);
         return;
     }
     pt part;
     ptj_to_pt(part, acc, empty);
-    lane_group_sum<4>(part);
+    lane_group_sum<G>(part);
     out = part;
 }
 #endif
@@ -1523,7 +1524,7 @@ HD void verify_c0_var(const VerifyWs& ws, size_t t, int group_lane = -1) {
 // ---------------------------------------------------------------- phase 3 (k = 1..4): one WNLA round (wnla.rs:84-102)
 // group_lane >= 0: this lane is one of four consecutive lanes that all run the round for proof t (identical work and identical
 // stores, except the sum, which they share: straus_affine_g4) -- the small-batch kernels; -1: one lane per proof
-HD void verify_round(const VerifyWs& ws, size_t t, int k, int group_lane = -1) {
+HD void verify_round(const VerifyWs& ws, size_t t, int k, int group_lane = -1, int group_size = 4) {
     const size_t N = ws.N;
     pt C;
     ws_ld_pt(C, ws.acc, N, t);
@@ -1578,11 +1579,12 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k, int group_lane = -1) {
     BPPP_STAMP(t, 12);
     pt acc;
 #if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
-    if (group_lane >= 0) straus_affine_g4<2>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
+    if (group_lane >= 0 && group_size == 4) straus_affine_g4<2, 4>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
+    else if (group_lane >= 0) straus_affine_g4<2, 2>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
     else
 #endif
         straus_affine<2>(acc, atab_of(ws.atab, ws.N, t), pslot, g);
-    (void)group_lane;
+    (void)group_lane; (void)group_size;
     BPPP_STAMP(t, 13);
     pt_madd(acc, acc, Ca, apt_is_identity(Ca));
     ws_st_pt(ws.acc, N, t, acc);

@@ -123,7 +123,9 @@ HD void wnla_verify_tables(const WnlaWs& w, size_t t) {
     affine_tables_build(atab_of(w.atab, N, t, 2 * w.rounds * 16), w.tscr, w.rpts, N, t, 2 * w.rounds);
 }
 // ---- verify: round k = 1..rounds (wnla.rs:84-102), X = proof.x[rounds - k], R = proof.r[rounds - k]
-HD void wnla_verify_round(const WnlaWs& w, size_t t, int k) {
+// group_lane >= 0: one of group_size (2 or 4) consecutive lanes that all run the round for instance t and share its sum
+// (verify_core.h: straus_affine_g4) -- batches that under-fill the chip with one lane per instance; -1: one lane per instance
+HD void wnla_verify_round(const WnlaWs& w, size_t t, int k, int group_lane = -1, int group_size = 4) {
     const size_t N = w.N;
     int32_t status = w.status[t];
     pt C;
@@ -157,7 +159,13 @@ HD void wnla_verify_round(const WnlaWs& w, size_t t, int k) {
         glv_words_set<2>(g, 0, sp);
         glv_decompose(sp, y2m1);
         glv_words_set<2>(g, 1, sp);
-        straus_affine<2>(acc, atab_of(w.atab, N, t, 2 * w.rounds * 16), pslot, g);
+#if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
+        if (group_lane >= 0 && group_size == 4) straus_affine_g4<2, 4>(acc, atab_of(w.atab, N, t, 2 * w.rounds * 16), pslot, g, group_lane);
+        else if (group_lane >= 0) straus_affine_g4<2, 2>(acc, atab_of(w.atab, N, t, 2 * w.rounds * 16), pslot, g, group_lane);
+        else
+#endif
+            straus_affine<2>(acc, atab_of(w.atab, N, t, 2 * w.rounds * 16), pslot, g);
+        (void)group_lane; (void)group_size;
     } else {
         pt_slot* tbl = w.straus + t * (2 * BPPP_STRAUS_ENTRIES);
         glv_split rs[2];
