@@ -7,6 +7,7 @@
 #include "../k_verify_misc.hip"
 #include "../k_verify_var.hip"
 #include "../k_verify_fixed.hip"
+#include "../k_verify_bucket.hip"
 #include "../k_prove.hip"
 #include "../k_generic.hip"
 #include "../k_gprove.hip"
