@@ -1,6 +1,7 @@
 """Soak test on one GPU: fresh 2^16-proof batches (product prover), random byte corruptions, exact mode vs RLC mode (bucket stage at
 several superchunk sizes, chunks of 8, exact re-check) vs expectation,
-and a random sample of every batch re-verified by the CPU oracle.   python tools/soak.py [batches]"""
+and a random sample of every batch re-verified by the CPU oracle.   python tools/soak.py [batches] [log2 of the batch size, default 16]
+(batch sizes <= 2^15 run the lane-group kernels of the small-batch path)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
@@ -10,7 +11,7 @@ from bp_pp_amd import U64RangeProofProtocol, synth as workload
 import bppp_oracle_c as OC
 gens = bytes.fromhex(json.load(open(os.path.join(ROOT, "tests", "golden", "u64_golden.json")))["generators"])
 g, gv, hv = gens[:64], [gens[64 * i:64 * i + 64] for i in range(1, 17)], [gens[64 * i:64 * i + 64] for i in range(17, 49)]
-n = 1 << 16
+n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 16)
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 proto = U64RangeProofProtocol(g, gv, hv, device=0)
 torch.cuda.synchronize()   # inputs ready; the context runs on its own (non-blocking) stream, joined by proto.synchronize()
