@@ -347,7 +347,8 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
         hipError_t e_ = (expr);                                                     \
         if (e_ != hipSuccess) {                                                     \
             g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);       \
-            return fail(BPPP_ERR_HIP);                                              \
+            (void)hipGetLastError();                                                \
+            return fail(e_ == hipErrorOutOfMemory ? BPPP_ERR_NOMEM : BPPP_ERR_HIP); \
         }                                                                           \
     } while (0)
     HIP_TRY_C(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
