@@ -115,7 +115,7 @@ struct bppp_ctx {
     int n_simds = 1024;            // CUs x 4 (device property), decides between the small-batch and the 2-waves/SIMD lane kernels
     bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
-    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false, no_lane_groups = false;   // diagnostics, read from the environment once at context creation
+    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false, no_lane_groups = false, force_pairs = false;   // diagnostics, read from the environment once at context creation
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> event_pool;
     double total_ms[K_COUNT] = {0};
@@ -337,6 +337,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     c->fb_w = W;
     c->n_simds = device_simds(device);
     c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;
+    c->force_pairs = std::getenv("BPPP_FORCE_LANE_PAIRS") != nullptr;   // diagnostic: rounds on two lanes per proof at every batch size
     c->no_lane_groups = std::getenv("BPPP_NO_LANE_GROUPS") != nullptr;   // diagnostic: one lane per proof at every batch size
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // diagnostic: projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
@@ -618,7 +619,7 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     for (int k = 1; k <= 4; k++) {
         if (grouped) LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k));
-        else if (!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds)
+        else if (c->force_pairs || (!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds))
             LAUNCH(K_ROUND, k_verify_round_g2<<<(unsigned)((2 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
         else if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
         else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
@@ -2126,6 +2127,7 @@ static int ctx_alloc_common(bppp_ctx* c) {
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRY(hipMalloc(&c->d_flags, sizeof(int)));
     c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;
+    c->force_pairs = std::getenv("BPPP_FORCE_LANE_PAIRS") != nullptr;   // diagnostic: rounds on two lanes per proof at every batch size
     c->no_lane_groups = std::getenv("BPPP_NO_LANE_GROUPS") != nullptr;   // diagnostic: one lane per proof at every batch size
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // diagnostic: projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
