@@ -104,14 +104,18 @@ def run_recip256(args):
     import bench
     world, rank, local_rank = bench.setup_dist(args)
     assert world == 1
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import recip_cases                                                # seeded instances; the oracle proves / verifies the sample only
+    from bp_pp_amd import derive_generators, synth
     from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
     nd, npp, n = 256, 16, args.total_proofs
     n_or = 0 if args.no_cpu_baseline else 48                      # ~10 s of single-thread oracle work (prove + verify)
     t0 = time.time()
-    case = recip_cases.make_bulk(nd, npp, n, n_oracle=n_or)
+    # generators from the product's own derivation (SHAKE256 try-and-increment, host code), inputs from bp_pp_amd/synth.py: the oracle
+    # is only touched by the cpu_baseline leg below
+    nh, NG, NH = nd + 10, 256, 512
+    raw = derive_generators(b"bppp-bench-recip256", 1 + NG + NH)
+    pts = [raw[64 * i:64 * i + 64] for i in range(1 + NG + NH)]
+    gens5 = (pts[0], pts[1:1 + nd], pts[1 + NG:1 + NG + nh], pts[1 + nd:1 + NG], pts[1 + NG + nh:])
+    case = dict(synth.bulk_reciprocal_inputs(nd, n), g=gens5[0], gv=gens5[1], hv=gens5[2], gv_=gens5[3], hv_=gens5[4], label=b"reciprocal bench")
     t_inputs = time.time() - t0
     W = args.fb_window_bits or 16
     t0 = time.time()
@@ -192,16 +196,22 @@ def run_recip256(args):
                           "note": "optional mode (bppp_reciprocal_verify_batch_rlc_device): the final 769-base MSM once per chunk of 8 instances, "
                                   "chunks that fail re-checked exactly (1/256 corrupted here = 3 % of the chunks); NOT the headline metric"}
     if n_or:
+        # the checker: the reference-shaped C prover and verifier on the first n_or instances (same generators, same inputs)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import recip_cases
+        ocase = recip_cases.make_bulk(nd, npp, n_or, n_oracle=n_or, label=case["label"], generators=gens5,
+                                      inputs={k: np.ascontiguousarray(case[k][:n_or]) for k in ("x", "s", "digits", "m", "rnd")})
         t0 = time.perf_counter()
         agree = True
         for i in range(n_or):
-            rc = recip_cases.oracle_verify(case, bytes(com[i]), bytes(proofs[i]))
+            rc = recip_cases.oracle_verify(ocase, bytes(com[i]), bytes(proofs[i]))
             agree &= (rc == 1) == bool(acc[i])
         dt = time.perf_counter() - t0
         result["cpu_baseline"] = {"value": n_or / dt, "unit": "verifies/s", "cores": 1, "kind": "port",
                                   "sample": f"first {n_or} proofs of the same batch, reference-shaped C verifier (oracle/bppp_ref.c), one thread, {dt:.2f} s",
                                   "agrees_with_gpu": bool(agree),
-                                  "prover_bytes_equal_oracle": bool((proofs[1:n_or] == case["proofs"][1:n_or]).all())}
+                                  "prover_bytes_equal_oracle": bool((proofs[1:n_or] == ocase["proofs"][1:n_or]).all())}
     print(json.dumps(result), flush=True)
     proto.close()
     if not ok:

@@ -110,3 +110,29 @@ def bulk_blindings(n: int, first: int = 0, seed: bytes = SEED) -> np.ndarray:
 
 def bulk_prover_randomness(n: int, first: int = 0, seed: bytes = SEED) -> np.ndarray:
     return _bulk_scalars(b"rng", first, n, N_RNG_DRAWS_U64, seed)
+
+
+def bulk_reciprocal_inputs(dim_nd: int, n: int, seed: int = 20260):
+    """Seeded inputs of n ReciprocalRangeProofProtocol instances with dim_np = 16 (hex digits), drawn with numpy (Philox): digits
+    [n, dim_nd, 32], multiplicities m [n, 16, 32], the committed value x = sum d_i 16^i mod n [n, 32], blinding s [n, 32] and the
+    20 + 2 dim_nd prover scalars rnd [n, 20 + 2 dim_nd, 32] (top nibble cleared: canonical without a wide reduction).  Instance 0 is all
+    zeros, instance 1 all fifteens.  No curve arithmetic, no oracle."""
+    n_rnd = 20 + 2 * dim_nd
+    rng = np.random.Generator(np.random.Philox(key=seed))
+    dig = rng.integers(0, 16, size=(n, dim_nd), dtype=np.uint8)
+    dig[0] = 0
+    if n > 1:
+        dig[1] = 15
+    digits = np.zeros((n, dim_nd, 32), np.uint8)
+    digits[:, :, 31] = dig
+    m = np.zeros((n, 16, 32), np.uint8)
+    counts = np.stack([(dig == v).sum(axis=1) for v in range(16)], axis=1).astype(np.uint32)      # multiplicities, < 2^16
+    m[:, :, 31] = counts & 0xFF
+    m[:, :, 30] = counts >> 8
+    x = np.zeros((n, 32), np.uint8)
+    for b in range(n):      # the digit string read as one hexadecimal number
+        v = int("".join("%x" % d for d in dig[b][::-1]), 16) % N_ORDER
+        x[b] = np.frombuffer(v.to_bytes(32, "big"), np.uint8)
+    raw = rng.integers(0, 256, size=(n, 1 + n_rnd, 32), dtype=np.uint8)
+    raw[:, :, 0] &= 0x0F
+    return dict(x=x, s=raw[:, 0, :].copy(), digits=digits, m=m, rnd=raw[:, 1:, :].copy())

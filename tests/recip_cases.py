@@ -99,7 +99,7 @@ def oracle_verify(case, commitment: bytes, proof: bytes) -> int:
                                            sz(case["nn"]))
 
 
-def make_bulk(dim_nd: int, dim_np: int, B: int, n_oracle: int = 0, label: bytes = b"reciprocal bench", seed: int = 20260):
+def make_bulk(dim_nd: int, dim_np: int, B: int, n_oracle: int = 0, label: bytes = b"reciprocal bench", seed: int = 20260, generators=None, inputs=None):
     """Large batches: the same generators as make(), witnesses drawn with numpy (Philox, seeded) instead of one hash call per
     digit -- dim_np must be 16 (hex digits, so x is one big-integer conversion per instance).  The oracle proves the first
     `n_oracle` instances from exactly these inputs (case["proofs"] / case["commitments"] hold those rows)."""
@@ -108,31 +108,19 @@ def make_bulk(dim_nd: int, dim_np: int, B: int, n_oracle: int = 0, label: bytes 
     sz = C.c_size_t
     nh = dim_nd + 10
     NH, NG = _pow2_at_least(nh), _pow2_at_least(dim_nd)
-    pt = lambda tag, i: OC.point_mul(None, O.sc_to_bytes(_sc(tag, i)))
-    g = pt(b"g", 0)
-    gv = [pt(b"gv", i) for i in range(dim_nd)]
-    hv = [pt(b"hv", i) for i in range(nh)]
-    gv_ = [pt(b"gv_", i) for i in range(NG - dim_nd)]
-    hv_ = [pt(b"hv_", i) for i in range(NH - nh)]
+    if generators is not None:                       # (g, gv, hv, gv_, hv_) given by the caller (bench_other.py derives them with the product)
+        g, gv, hv, gv_, hv_ = generators
+    else:
+        pt = lambda tag, i: OC.point_mul(None, O.sc_to_bytes(_sc(tag, i)))
+        g = pt(b"g", 0)
+        gv = [pt(b"gv", i) for i in range(dim_nd)]
+        hv = [pt(b"hv", i) for i in range(nh)]
+        gv_ = [pt(b"gv_", i) for i in range(NG - dim_nd)]
+        hv_ = [pt(b"hv_", i) for i in range(NH - nh)]
     n_rnd = 20 + 2 * dim_nd
-    rng = np.random.Generator(np.random.Philox(key=seed))
-    dig = rng.integers(0, 16, size=(B, dim_nd), dtype=np.uint8)
-    dig[0] = 0
-    if B > 1:
-        dig[1] = 15
-    digits = np.zeros((B, dim_nd, 32), np.uint8)
-    digits[:, :, 31] = dig
-    m = np.zeros((B, 16, 32), np.uint8)
-    counts = np.stack([(dig == v).sum(axis=1) for v in range(16)], axis=1).astype(np.uint32)      # multiplicities, < 2^16
-    m[:, :, 31] = counts & 0xFF
-    m[:, :, 30] = counts >> 8
-    x = np.zeros((B, 32), np.uint8)
-    for b in range(B):      # x = sum d_i 16^i mod n: the digit string read as one hexadecimal number
-        v = int("".join("%x" % d for d in dig[b][::-1]), 16) % O.N
-        x[b] = np.frombuffer(v.to_bytes(32, "big"), np.uint8)
-    raw = rng.integers(0, 256, size=(B, 1 + n_rnd, 32), dtype=np.uint8)
-    raw[:, :, 0] &= 0x0F                                                   # canonical without a wide reduction
-    s, rnd = raw[:, 0, :].copy(), raw[:, 1:, :].copy()
+    from bp_pp_amd import synth
+    w = inputs if inputs is not None else synth.bulk_reciprocal_inputs(dim_nd, B, seed)   # inputs: rows the caller already drew
+    x, s, digits, m, rnd = w["x"], w["s"], w["digits"], w["m"], w["rnd"]
     case = dict(g=g, gv=gv, hv=hv, gv_=gv_, hv_=hv_, nd=dim_nd, np=dim_np, label=label, NG=NG, NH=NH, x=x, s=s, digits=digits, m=m, rnd=rnd)
     rounds, nl, nn = 0, NH, NG
     while nl + nn >= 6:

@@ -1,9 +1,9 @@
 """Soak test on one GPU: fresh 2^16-proof batches (product prover), random byte corruptions, exact mode vs RLC mode (bucket stage at
 several superchunk sizes, chunks of 8, exact re-check) vs expectation,
-and a random sample of every batch re-verified by the CPU oracle.   python tools/soak.py [batches] [log2 of the batch size, default 16]
+and a random sample of every batch re-verified by the CPU oracle.   python tests/soak.py [batches] [log2 of the batch size, default 16]
 (batch sizes <= 2^15 run the lane-group kernels of the small-batch path)"""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/soak.py: test infrastructure (it uses the oracle as its checker)
 for p in (ROOT, os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 import numpy as np, torch

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path[:0] = ['.', 'tests', 'oracle']
+sys.path[:0] = ['.']
 import torch, bench
 from bp_pp_amd import U64RangeProofProtocol, synth
 gens, g, gv, hv = bench.load_generators()
