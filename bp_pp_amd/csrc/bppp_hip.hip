@@ -115,7 +115,7 @@ struct bppp_ctx {
     int n_simds = 1024;            // CUs x 4 (device property), decides between the small-batch and the 2-waves/SIMD lane kernels
     bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
-    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false, no_lane_groups = false, force_pairs = false;   // diagnostics, read from the environment once at context creation
+    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false, no_lane_groups = false, force_pairs = false, no_small = false;   // diagnostics, read from the environment once at context creation
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> event_pool;
     double total_ms[K_COUNT] = {0};
@@ -339,6 +339,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;
     c->force_pairs = std::getenv("BPPP_FORCE_LANE_PAIRS") != nullptr;   // diagnostic: rounds on two lanes per proof at every batch size
     c->no_lane_groups = std::getenv("BPPP_NO_LANE_GROUPS") != nullptr;   // diagnostic: one lane per proof at every batch size
+    c->no_small = std::getenv("BPPP_NO_SMALL_KERNELS") != nullptr;       // diagnostic: the 256-VGPR builds (two wavefronts per SIMD) at every batch size
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // diagnostic: projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
     c->ng = (int)ng; c->nh = (int)nh; c->nbases = NB;
@@ -597,7 +598,7 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     } while (0)
 #define LAUNCH(id, ...) LAUNCH_ON(s, id, __VA_ARGS__)
     // a grid that does not even fill one wavefront per SIMD gains nothing from the 256-VGPR cap: use the uncapped builds
-    const bool small = blocks <= (unsigned)c->n_simds;
+    const bool small = !c->no_small && blocks <= (unsigned)c->n_simds;
     if (small) LAUNCH(K_PHASE1, k_verify_phase1_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     else LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
@@ -2129,6 +2130,7 @@ static int ctx_alloc_common(bppp_ctx* c) {
     c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;
     c->force_pairs = std::getenv("BPPP_FORCE_LANE_PAIRS") != nullptr;   // diagnostic: rounds on two lanes per proof at every batch size
     c->no_lane_groups = std::getenv("BPPP_NO_LANE_GROUPS") != nullptr;   // diagnostic: one lane per proof at every batch size
+    c->no_small = std::getenv("BPPP_NO_SMALL_KERNELS") != nullptr;       // diagnostic: the 256-VGPR builds (two wavefronts per SIMD) at every batch size
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // diagnostic: projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
     c->n_simds = device_simds(c->device);

@@ -7,7 +7,7 @@ from bp_pp_amd import U64RangeProofProtocol, synth
 gens, g, gv, hv = bench.load_generators()
 proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=20)
 other = proto.clone_shared()
-for n in (1 << 16, 1 << 17, 1 << 18):
+for n in [int(a) for a in sys.argv[1:]] or (1 << 16, 1 << 17, 1 << 18):
     dV, dP, expect, _ = bench.make_resident_batch(torch, proto, synth, 0, n)
     dA = torch.zeros(n, dtype=torch.uint8, device="cuda"); dS = torch.zeros(n, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
