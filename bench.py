@@ -51,6 +51,14 @@ def _load_json(path):
         return None
 
 
+def launched_kernel(kernel, n_proofs, lanes_per_proof):
+    """The library's timing slots are per stage; from 2^17 proofs per launch the u64 verifier's two fixed-base stages run their
+    one-lane-per-proof kernels (k_verify_*_l1), which is the name the rocprofv3 summaries carry."""
+    if kernel in ("k_verify_c0_fixed", "k_verify_final_check") and n_proofs >= (1 << 17):
+        return kernel + "_l1", 1
+    return kernel, lanes_per_proof
+
+
 def valu_roofline(kernel, avg_ms, n_proofs, lanes_per_proof):
     """Compute-side ceiling of one kernel: VALU wave-instructions per launch (SQ_INSTS_VALU per wave from the committed
     rocprofv3 --pmc pass, times the waves this launch ran) over the live-measured launch time, against the issue rate of the
@@ -61,6 +69,7 @@ def valu_roofline(kernel, avg_ms, n_proofs, lanes_per_proof):
     micro-benchmark (tools/intbench.hip, which includes the clock the chip actually holds under load)."""
     pv = _load_json(os.path.join(ROOT, "profiles", "pmc_valu.json")) or {}
     mix = _load_json(os.path.join(ROOT, "profiles", "isa_mix.json")) or {}
+    kernel, lanes_per_proof = launched_kernel(kernel, n_proofs, lanes_per_proof)
     kv = pv.get(kernel, {})
     per_wave = kv.get("valu_insts_per_wave")
     half_static = (mix.get(kernel) or {}).get("half_rate_frac")
@@ -86,6 +95,7 @@ def pmc_traffic(kernel, n_proofs):
     """Measured HBM bytes per launch of `kernel` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, corrected
     as tools/pmc_summarize.py documents), scaled linearly if the committed pass ran a different batch size."""
     tr = _load_json(os.path.join(ROOT, "profiles", "pmc_traffic.json")) or {}
+    kernel = launched_kernel(kernel, n_proofs, 1)[0]
     k = (tr.get("kernels") or {}).get(kernel) or {}
     b = k.get("hbm_bytes_per_launch")
     if b is None:

@@ -115,7 +115,8 @@ struct bppp_ctx {
     int n_simds = 1024;            // CUs x 4 (device property), decides between the small-batch and the 2-waves/SIMD lane kernels
     bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
-    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false, no_lane_groups = false, force_pairs = false, no_small = false;   // diagnostics, read from the environment once at context creation
+    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false, no_lane_groups = false, force_pairs = false, no_small = false;
+    int fb_one_lane_mode = -1;   // diagnostic BPPP_FB_ONE_LANE: 1 = one lane per proof in the u64 verifier's fixed-base kernels at every size, 0 = never, unset = by size   // diagnostics, read from the environment once at context creation
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> event_pool;
     double total_ms[K_COUNT] = {0};
@@ -340,6 +341,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     c->force_pairs = std::getenv("BPPP_FORCE_LANE_PAIRS") != nullptr;   // diagnostic: rounds on two lanes per proof at every batch size
     c->no_lane_groups = std::getenv("BPPP_NO_LANE_GROUPS") != nullptr;   // diagnostic: one lane per proof at every batch size
     c->no_small = std::getenv("BPPP_NO_SMALL_KERNELS") != nullptr;       // diagnostic: the 256-VGPR builds (two wavefronts per SIMD) at every batch size
+    if (const char* e = std::getenv("BPPP_FB_ONE_LANE")) c->fb_one_lane_mode = e[0] == '0' ? 0 : 1;
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // diagnostic: projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
     c->ng = (int)ng; c->nh = (int)nh; c->nbases = NB;
@@ -609,7 +611,11 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
-    LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
+    // the two fixed-base sums: 8 lanes per proof, or one from the size at which one lane per proof fills the SIMDs twice over
+    const bool fb_one_lane = c->fb_one_lane_mode >= 0 ? c->fb_one_lane_mode == 1 : n >= (size_t)128 * (size_t)c->n_simds;
+    const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    if (fb_one_lane) LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
+    else LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_join, a));
     // a batch whose four-lanes-per-proof grid still leaves the SIMDs under-filled runs its variable-base sums on lane groups
     const bool grouped = !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds;
@@ -627,7 +633,8 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     }
     LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     if (!rlc_seed) {
-        LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+        if (fb_one_lane) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+        else LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
         LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
     } else {
         // combined check per chunk of 8 proofs; chunks that fail it (or hold a flagged proof) fall through to the exact kernels
@@ -2131,6 +2138,7 @@ static int ctx_alloc_common(bppp_ctx* c) {
     c->force_pairs = std::getenv("BPPP_FORCE_LANE_PAIRS") != nullptr;   // diagnostic: rounds on two lanes per proof at every batch size
     c->no_lane_groups = std::getenv("BPPP_NO_LANE_GROUPS") != nullptr;   // diagnostic: one lane per proof at every batch size
     c->no_small = std::getenv("BPPP_NO_SMALL_KERNELS") != nullptr;       // diagnostic: the 256-VGPR builds (two wavefronts per SIMD) at every batch size
+    if (const char* e = std::getenv("BPPP_FB_ONE_LANE")) c->fb_one_lane_mode = e[0] == '0' ? 0 : 1;
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // diagnostic: projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
     c->n_simds = device_simds(c->device);

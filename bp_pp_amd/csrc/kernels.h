@@ -77,6 +77,7 @@ using bppp::MsmWs;
 
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_phase1(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed_l1(bppp::VerifyWs ws);      // one lane per proof (full batches)
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_c0_var(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_round(bppp::VerifyWs ws, int k);
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g4(bppp::VerifyWs 
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g2(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_l1(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(bppp::VerifyWs ws, int* reject_count);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_export_states(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(bppp::VerifyWs ws, bppp::RlcWs r);

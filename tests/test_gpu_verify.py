@@ -388,3 +388,34 @@ def test_lane_groups_and_one_lane_per_proof_agree(torch_mod, gold, oracle_c, n):
     for i in ([0, 1, 2] if n < 300 else [0, 5, 6, 7, 9, 18, n - 1]):
         rc, otr = oracle_c.u64_verify(gens, workload.LABEL, bytes(V[i]), bytes(P[i]), trace=True)
         assert int(a0[i]) == (1 if rc == 1 else 0) and (rc < 0 or bytes(t0[i]) == otr)
+
+
+@pytest.mark.gpu
+def test_fixed_base_one_lane_and_eight_lanes_agree(torch_mod, gold, oracle_c):
+    """From 2^17 proofs up the two fixed-base sums of the u64 verifier (C0's fixed half, the final check) run on one lane per proof
+    instead of eight (k_verify_*_l1); BPPP_FB_ONE_LANE=1 / =0 forces either form at any size.  Same accept bits, statuses, reject
+    count and byte-identical traces, including proofs whose points make the sums degenerate."""
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    gens, V, P, _ = workload.make_batch(300, first=81000)
+    P, expect = workload.corrupt(P, V, every=7)
+    P[5, 64 * 8:64 * 9] = P[5, 64 * 4:64 * 5]
+    P[6, 64 * 4:64 * 5] = 0
+    g, gv, hv = workload.split_generators(gens)
+    res = []
+    for mode in ("0", "1"):
+        os.environ["BPPP_FB_ONE_LANE"] = mode
+        try:
+            proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
+        finally:
+            os.environ.pop("BPPP_FB_ONE_LANE", None)
+        try:
+            res.append(_device_verify(torch_mod, proto, workload.LABEL, V, P))
+        finally:
+            proto.close()
+    (a0, s0, t0, r0), (a1, s1, t1, r1) = res
+    assert (a0 == a1).all() and (s0 == s1).all() and r0 == r1 and (t0 == t1).all()
+    assert (a0[[i for i in range(300) if i not in (5, 6)]] == expect[[i for i in range(300) if i not in (5, 6)]]).all()
+    for i in (0, 5, 6, 7, 14, 299):
+        rc, otr = oracle_c.u64_verify(gens, workload.LABEL, bytes(V[i]), bytes(P[i]), trace=True)
+        assert int(a1[i]) == (1 if rc == 1 else 0) and (rc < 0 or bytes(t1[i]) == otr)
