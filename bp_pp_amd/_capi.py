@@ -26,6 +26,10 @@ EXPORTS = [
     "bppp_derive_generators", "bppp_ctx_save_tables", "bppp_ctx_create_from_tables", "bppp_ctx_create_shared",
     "bppp_shard_range", "bppp_group_create", "bppp_group_destroy", "bppp_group_size", "bppp_group_ctx", "bppp_u64_verify_batch_sharded",
     "bppp_u64_verify_batch_sharded_device",
+    "bppp_wnla_group_create", "bppp_group_set_option", "bppp_u64_verify_batch_rlc_sharded", "bppp_u64_verify_batch_rlc_sharded_device",
+    "bppp_u64_verify_batch_sec1_sharded", "bppp_u64_verify_batch_sec1_sharded_device", "bppp_u64_verify_batch_transcript_sharded",
+    "bppp_u64_verify_batch_transcript_sharded_device", "bppp_reciprocal_verify_batch_sharded", "bppp_reciprocal_verify_batch_rlc_sharded",
+    "bppp_reciprocal_verify_batch_sharded_device", "bppp_reciprocal_verify_batch_rlc_sharded_device",
 ]
 
 _lib = None
@@ -138,6 +142,19 @@ def lib():
     L.bppp_group_ctx.restype = vp
     L.bppp_u64_verify_batch_sharded.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, C.POINTER(C.c_int32)]
     L.bppp_u64_verify_batch_sharded_device.argtypes = [vp, u8p, sz, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    pvp = C.POINTER(vp)
+    L.bppp_wnla_group_create.argtypes = [C.POINTER(vp), u8p, u8p, sz, u8p, sz, C.POINTER(i32), i32, i32]
+    L.bppp_group_set_option.argtypes = [vp, u8p, C.c_long]
+    L.bppp_u64_verify_batch_rlc_sharded.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, C.POINTER(C.c_int32), u8p]
+    L.bppp_u64_verify_batch_rlc_sharded_device.argtypes = [vp, u8p, sz, sz, pvp, pvp, pvp, pvp, pvp, u8p]
+    L.bppp_u64_verify_batch_sec1_sharded.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, C.POINTER(C.c_int32)]
+    L.bppp_u64_verify_batch_sec1_sharded_device.argtypes = [vp, u8p, sz, sz, pvp, pvp, pvp, pvp, pvp]
+    L.bppp_u64_verify_batch_transcript_sharded.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, vp, C.POINTER(C.c_int32)]
+    L.bppp_u64_verify_batch_transcript_sharded_device.argtypes = [vp, sz, pvp, sz, pvp, pvp, pvp, pvp, pvp, pvp]
+    L.bppp_reciprocal_verify_batch_sharded.argtypes = [vp, u8p, sz, sz, sz, sz, vp, vp, sz, sz, sz, vp, vp, C.POINTER(C.c_int32)]
+    L.bppp_reciprocal_verify_batch_rlc_sharded.argtypes = [vp, u8p, sz, sz, sz, sz, vp, vp, sz, sz, sz, vp, vp, C.POINTER(C.c_int32), u8p]
+    L.bppp_reciprocal_verify_batch_sharded_device.argtypes = [vp, u8p, sz, sz, sz, sz, pvp, pvp, sz, sz, sz, pvp, pvp, pvp]
+    L.bppp_reciprocal_verify_batch_rlc_sharded_device.argtypes = [vp, u8p, sz, sz, sz, sz, pvp, pvp, sz, sz, sz, pvp, pvp, pvp, u8p]
     L.bppp_strerror.argtypes = [i32]
     L.bppp_strerror.restype = C.c_char_p
     L.bppp_last_error.restype = C.c_char_p

@@ -1,0 +1,451 @@
+// libbppp_hip.so, host side: contexts (generators -> fixed-base tables in HBM, streams, workspace bookkeeping), options, kernel timing, merlin on
+// serialized states (host only), generator derivation and the table artefact.
+#include "host.h"
+#if defined(BPPP_PHASE_TIMING)
+namespace bppp { __device__ unsigned long long g_bppp_stamps[1024 * 32]; }
+#endif
+
+thread_local std::string g_last_error;
+
+// Diagnostic switches (A/B measurements), read from the environment once per context, here and nowhere else.
+static void read_diagnostics(bppp_ctx* c) {
+    c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;             // the two halves of C0 on one stream
+    c->force_pairs = std::getenv("BPPP_FORCE_LANE_PAIRS") != nullptr;     // rounds on two lanes per proof at every batch size
+    c->no_lane_groups = std::getenv("BPPP_NO_LANE_GROUPS") != nullptr;    // one lane per proof at every batch size
+    c->no_small = std::getenv("BPPP_NO_SMALL_KERNELS") != nullptr;        // the 256-VGPR builds (two wavefronts per SIMD) at every batch size
+    if (const char* e = std::getenv("BPPP_FB_ONE_LANE")) c->fb_one_lane_mode = e[0] == '0' ? 0 : 1;
+    c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // projective tables + complete additions
+    c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
+}
+
+extern "C" {
+
+const char* bppp_strerror(int code) {
+    switch (code) {
+        case BPPP_OK: return "ok";
+        case BPPP_ERR_NO_DEVICE: return "no usable gfx950 HIP device (this library has no CPU fallback)";
+        case BPPP_ERR_INVALID_ARG: return "invalid argument";
+        case BPPP_ERR_HIP: return "HIP runtime error";
+        case BPPP_ERR_ENCODING: return "generator is not a valid secp256k1 point";
+        case BPPP_ERR_NOMEM: return "out of memory";
+        case BPPP_ERR_RCCL: return "RCCL unavailable or an RCCL call failed";
+        default: return "unknown error";
+    }
+}
+const char* bppp_last_error(void) { return g_last_error.c_str(); }
+
+int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, const uint8_t* h_vec, int device, int fb_window_bits) {
+    return bppp_wnla_ctx_create(out, g, g_vec, 16, h_vec, 32, device, fb_window_bits);
+}
+
+int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, size_t ng, const uint8_t* h_vec, size_t nh, int device,
+                         int fb_window_bits) {
+    if (!out || !g || (!g_vec && ng) || (!h_vec && nh) || ng > 4096 || nh > 4096) return BPPP_ERR_INVALID_ARG;
+    *out = nullptr;
+    const int NB = 1 + (int)ng + (int)nh;
+    int W = fb_window_bits ? fb_window_bits : 20;
+    if (W != 4 && W != 8 && W != 16 && W != 10 && W != 20 && W != 22) return BPPP_ERR_INVALID_ARG;
+    int rc = check_device(device);
+    if (rc != BPPP_OK) return rc;
+    HIP_TRY(hipSetDevice(device));
+    bppp_ctx* c = new (std::nothrow) bppp_ctx();
+    if (!c) return BPPP_ERR_NOMEM;
+    c->device = device;
+    c->fb_w = W;
+    c->n_simds = device_simds(device);
+    read_diagnostics(c);
+    c->ng = (int)ng; c->nh = (int)nh; c->nbases = NB;
+    auto fail = [&](int code) { bppp_ctx_destroy(c); return code; };
+#define HIP_TRY_C(expr)                                                             \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);       \
+            (void)hipGetLastError();                                                \
+            return fail(e_ == hipErrorOutOfMemory ? BPPP_ERR_NOMEM : BPPP_ERR_HIP); \
+        }                                                                           \
+    } while (0)
+    HIP_TRY_C(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY_C(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIP_TRY_C(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY_C(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRY_C(hipMalloc(&c->d_gens, NB * sizeof(apt)));
+    HIP_TRY_C(hipMalloc(&c->d_flags, sizeof(int)));
+    HIP_TRY_C(hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
+    // upload + decode generators
+    std::vector<uint8_t> hg((size_t)NB * 64);
+    std::memcpy(hg.data(), g, 64);
+    if (ng) std::memcpy(hg.data() + 64, g_vec, ng * 64);
+    if (nh) std::memcpy(hg.data() + (1 + ng) * 64, h_vec, nh * 64);
+    uint8_t* d_raw = nullptr;
+    HIP_TRY_C(hipMalloc(&d_raw, hg.size()));
+    HIP_TRY_C(hipMemcpyAsync(d_raw, hg.data(), hg.size(), hipMemcpyHostToDevice, c->stream));
+    k_decode_generators<<<(NB + 63) / 64, 64, 0, c->stream>>>(d_raw, c->d_gens, NB, c->d_flags);
+    int flags = 0;
+    HIP_TRY_C(hipMemcpyAsync(&flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY_C(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_raw);
+    if (flags) return fail(BPPP_ERR_ENCODING);
+    // fixed-base tables
+    const int nwin = fb_nwin(W);
+    const size_t per_win = fb_per_win(W);
+    const size_t entries = (size_t)NB * nwin * per_win;
+    c->table_bytes = entries * sizeof(apt_packed);
+    HIP_TRY_C(hipMalloc(&c->d_table, c->table_bytes));
+    // built in passes over groups of bases so that the scratch (x, y, z, prefix product: 160 B per entry) stays below ~32 GB
+    const size_t per_base = (size_t)nwin * per_win;
+    size_t group = ((size_t)32 << 30) / (per_base * 4 * sizeof(fe));
+    if (group < 1) group = 1;
+    if (group > (size_t)NB) group = (size_t)NB;
+    fe* d_tmp = nullptr;
+    const size_t gentries = group * per_base;
+    HIP_TRY_C(hipMalloc(&d_tmp, gentries * 4 * sizeof(fe)));
+    for (size_t b0 = 0; b0 < (size_t)NB; b0 += group) {
+        const size_t nb = (size_t)NB - b0 < group ? (size_t)NB - b0 : group;
+        FbBuild fb{c->d_gens, NB, W, c->d_table, d_tmp, d_tmp + gentries, d_tmp + 2 * gentries, d_tmp + 3 * gentries, (int)b0, (int)nb};
+        size_t nthreads = nb * nwin * fb_chunks_per_window(W);
+        unsigned blocks = (unsigned)((nthreads + BPPP_BLOCK - 1) / BPPP_BLOCK);
+        k_fb_build_pass1<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
+        k_fb_build_pass2<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
+    }
+    HIP_TRY_C(hipGetLastError());
+    HIP_TRY_C(hipStreamSynchronize(c->stream));
+    (void)hipFree(d_tmp);
+#undef HIP_TRY_C
+    *out = c;
+    return BPPP_OK;
+}
+
+void bppp_ctx_destroy(bppp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& tl : c->pending) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); }
+    for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
+    if (c->d_gens && !c->borrows_tables) (void)hipFree(c->d_gens);
+    if (c->d_table && !c->borrows_tables) (void)hipFree(c->d_table);
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_straus) (void)hipFree(c->d_straus);
+    if (c->d_rlc) (void)hipFree(c->d_rlc);
+    if (c->d_bkt) (void)hipFree(c->d_bkt);
+    if (c->d_atab) (void)hipFree(c->d_atab);
+    if (c->d_tscr) (void)hipFree(c->d_tscr);
+    if (c->d_pws) (void)hipFree(c->d_pws);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_io) (void)hipFree(c->d_io);
+    if (c->d_gws) (void)hipFree(c->d_gws);
+    if (c->d_gtab) (void)hipFree(c->d_gtab);
+    if (c->d_expand) (void)hipFree(c->d_expand);
+    if (c->d_flags) (void)hipFree(c->d_flags);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int bppp_ctx_set_stream(bppp_ctx* c, void* hip_stream) {
+    CtxLock lock_(c);
+    if (!c) return BPPP_ERR_INVALID_ARG;
+    int rc = drain_timings(c);
+    if (rc != BPPP_OK) return rc;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return BPPP_OK;
+}
+
+int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
+    CtxLock lock_(c);
+    if (!c || !name) return BPPP_ERR_INVALID_ARG;
+    if (std::strcmp(name, "rlc_superchunk") == 0) {
+        if (value != 0 && (value < 64 || value > BPPP_BKT_MAX_M || (value & 7))) return BPPP_ERR_INVALID_ARG;
+        c->rlc_super_m = (unsigned)value;
+        return BPPP_OK;
+    }
+    if (std::strcmp(name, "max_batch") == 0) {
+        if (value < 1024 || (value & 63)) return BPPP_ERR_INVALID_ARG;
+        c->max_batch = (size_t)value;
+        return BPPP_OK;
+    }
+    if (std::strcmp(name, "host_chunk") == 0) {
+        if (value != 0 && (value < 1024 || (value & 63))) return BPPP_ERR_INVALID_ARG;
+        c->host_chunk = (size_t)value;
+        return BPPP_OK;
+    }
+    return BPPP_ERR_INVALID_ARG;
+}
+int bppp_ctx_synchronize(bppp_ctx* c) {
+    CtxLock lock_(c);
+    if (!c) return BPPP_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->aux_stream));
+    return BPPP_OK;
+}
+
+size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
+    if (!c) return 0;
+    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->bkt_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + c->gws_bytes + c->gtab_bytes + (size_t)c->nbases * sizeof(apt);
+}
+
+int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
+    CtxLock lock_(c);
+    if (!c) return BPPP_ERR_INVALID_ARG;
+    int rc = drain_timings(c);
+    c->timing = enable != 0;
+    return rc;
+}
+int bppp_ctx_get_timings(bppp_ctx* c, int max_entries, const char** names, double* total_ms, int64_t* launches, int reset) {
+    CtxLock lock_(c);
+    if (!c) return BPPP_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    int rc = drain_timings(c);
+    if (rc != BPPP_OK) return rc;
+    int n = max_entries < K_COUNT ? max_entries : K_COUNT;
+    for (int i = 0; i < n; i++) {
+        if (names) names[i] = kKernelNames[i];
+        if (total_ms) total_ms[i] = c->total_ms[i];
+        if (launches) launches[i] = c->launches[i];
+    }
+    if (reset)
+        for (int i = 0; i < K_COUNT; i++) { c->total_ms[i] = 0; c->launches[i] = 0; }
+    return n;
+}
+// merlin::Transcript as 203 serialized bytes, on the host: lets a C caller build the pre-loaded states without merlin and lets
+// the tests follow the reference's `t: &mut Transcript` contract end to end (no GPU involved)
+int bppp_transcript_new(const uint8_t* label, size_t label_len, uint8_t state_out[203]) {
+    if ((!label && label_len) || !state_out) return BPPP_ERR_INVALID_ARG;
+    strobe t;
+    t_new(t, label, (u32)label_len);
+    strobe_to_bytes(state_out, t, 2);       // the last operation of Transcript::new is the AD of the dom-sep message
+    return BPPP_OK;
+}
+int bppp_transcript_append_message(uint8_t state[203], const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len) {
+    if (!state || (!label && label_len) || (!msg && msg_len) || msg_len > 0xFFFFFFFFu) return BPPP_ERR_INVALID_ARG;
+    strobe t;
+    if (!strobe_from_bytes(t, state)) return BPPP_ERR_INVALID_ARG;
+    uint8_t len4[4] = {(uint8_t)msg_len, (uint8_t)(msg_len >> 8), (uint8_t)(msg_len >> 16), (uint8_t)(msg_len >> 24)};
+    strobe_meta_ad(t, label, (u32)label_len, false);
+    strobe_meta_ad(t, len4, 4, true);
+    strobe_ad(t, msg, (u32)msg_len, false);
+    strobe_to_bytes(state, t, 2);
+    return BPPP_OK;
+}
+int bppp_transcript_challenge_bytes(uint8_t state[203], const uint8_t* label, size_t label_len, uint8_t* out, size_t n) {
+    if (!state || (!label && label_len) || (!out && n) || n > 0xFFFFFFFFu) return BPPP_ERR_INVALID_ARG;
+    strobe t;
+    if (!strobe_from_bytes(t, state)) return BPPP_ERR_INVALID_ARG;
+    uint8_t len4[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
+    strobe_meta_ad(t, label, (u32)label_len, false);
+    strobe_meta_ad(t, len4, 4, true);
+    strobe_prf(t, out, (u32)n);
+    strobe_to_bytes(state, t, 7);
+    return BPPP_OK;
+}
+#if defined(BPPP_PHASE_TIMING)
+// diagnostic builds only (not declared in include/bppp.h): copy the phase stamps out
+BPPP_API int bppp_debug_read_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bppp::g_bppp_stamps), sizeof(unsigned long long) * 1024 * 32) == hipSuccess ? 0 : -1;
+}
+#endif
+
+
+// ---------------------------------------------------------------- setup: generator derivation, table artefact, shared tables
+// SHAKE256 (FIPS 202) on the host, over the same Keccak-f[1600] the device transcripts use
+static void shake256(const uint8_t* msg, size_t len, uint8_t* out, size_t outlen) {
+    u64 st[25];
+    for (int i = 0; i < 25; i++) st[i] = 0;
+    const size_t R = 136;
+    auto xor_byte = [&](size_t pos, uint8_t b) { st[pos >> 3] ^= (u64)b << (8 * (pos & 7)); };
+    size_t pos = 0;
+    for (size_t i = 0; i < len; i++) {
+        xor_byte(pos++, msg[i]);
+        if (pos == R) { keccak_f1600(st); pos = 0; }
+    }
+    xor_byte(pos, 0x1F);
+    xor_byte(R - 1, 0x80);
+    keccak_f1600(st);
+    pos = 0;
+    for (size_t i = 0; i < outlen; i++) {
+        if (pos == R) { keccak_f1600(st); pos = 0; }
+        out[i] = (uint8_t)(st[pos >> 3] >> (8 * (pos & 7)));
+        pos++;
+    }
+}
+
+// Nothing-up-my-sleeve generators (the step before the path: benches/range_proof.rs:18-20 draws random points; a deployment
+// needs reproducible ones whose discrete logarithms nobody knows).  Try-and-increment: candidate x = SHAKE256(seed || "bppp-gen"
+// || u32le(index) || u32le(counter)) read big-endian; accepted when x < p and x^3 + 7 is a square; y = the EVEN root.  Host only.
+int bppp_derive_generators(const uint8_t* seed, size_t seed_len, size_t first_index, size_t n, uint8_t* out /* n x 64 */) {
+    if ((!seed && seed_len) || !out || seed_len > 4096) return BPPP_ERR_INVALID_ARG;
+    std::vector<uint8_t> msg(seed_len + 8 + 8);
+    if (seed_len) std::memcpy(msg.data(), seed, seed_len);
+    std::memcpy(msg.data() + seed_len, "bppp-gen", 8);
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t idx = (uint32_t)(first_index + i);
+        for (uint32_t ctr = 0;; ctr++) {
+            for (int k = 0; k < 4; k++) { msg[seed_len + 8 + k] = (uint8_t)(idx >> (8 * k)); msg[seed_len + 12 + k] = (uint8_t)(ctr >> (8 * k)); }
+            uint8_t xb[32];
+            shake256(msg.data(), msg.size(), xb, 32);
+            fe x, rhs, y, y2, seven;
+            if (!fe_from_be(x, xb)) continue;
+            fe_sqr(rhs, x);
+            fe_mul(rhs, rhs, x);
+            fe_set_u32(seven, 7);
+            fe_add(rhs, rhs, seven);
+            fe_sqrt_candidate(y, rhs);
+            fe_sqr(y2, y);
+            if (!fe_eq(y2, rhs)) continue;
+            if (fe_is_odd(y)) { fe ny; fe_neg_m<1>(ny, y); y = ny; }
+            fe_to_be(out + 64 * i, x);
+            fe_to_be(out + 64 * i + 32, y);
+            break;
+        }
+    }
+    return BPPP_OK;
+}
+
+// ---- fixed-base tables as an artefact.  File = header | generators (nbases x 64 B, the device's decoded form re-encoded) | table.
+struct TableFileHeader {
+    char magic[8];             // "BPPPTAB2"
+    uint32_t nbases, ng, nh, window_bits, nwin, reserved;
+    uint64_t per_win, table_bytes;
+    uint64_t checksum;         // TableChecksum over the generator block and the table body, in file order
+};
+// A verifier running on a truncated, stale or tampered table would accept bad proofs and nothing would report it, so the file
+// carries a checksum of everything after the header: four interleaved 64-bit FNV-1a lanes over little-endian words (host speed
+// of a few GB/s -- the disk is slower), folded at the end.  Not a MAC: it catches damage and mix-ups, not an adversary who can
+// also rewrite the header; a deployment that distrusts its storage rebuilds the tables (0.2-0.5 s on the GPU) instead.
+struct TableChecksum {
+    uint64_t h[4] = {0xcbf29ce484222325ull, 0x84222325cbf29ce4ull, 0x9ce484222325cbf2ull, 0x2325cbf29ce48422ull};
+    size_t words = 0;
+    void update(const void* data, size_t bytes) {                 // bytes is a multiple of 8 (apt = 80 B, apt_packed = 64 B)
+        const uint8_t* p = (const uint8_t*)data;
+        for (size_t i = 0; i + 8 <= bytes; i += 8, words++) {
+            uint64_t w;
+            std::memcpy(&w, p + i, 8);
+            uint64_t& x = h[words & 3];
+            x = (x ^ w) * 0x100000001b3ull;
+        }
+    }
+    uint64_t digest() const {
+        uint64_t d = (uint64_t)words;
+        for (int i = 0; i < 4; i++) d = (d ^ h[i]) * 0x100000001b3ull;
+        return d;
+    }
+};
+int bppp_ctx_save_tables(bppp_ctx* c, const char* path) {
+    CtxLock lock_(c);
+    if (!c || !path) return BPPP_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { g_last_error = std::string("cannot open ") + path; return BPPP_ERR_INVALID_ARG; }
+    TableFileHeader h;
+    std::memset(&h, 0, sizeof h);
+    std::memcpy(h.magic, "BPPPTAB2", 8);
+    h.nbases = (uint32_t)c->nbases; h.ng = (uint32_t)c->ng; h.nh = (uint32_t)c->nh; h.window_bits = (uint32_t)c->fb_w;
+    h.nwin = (uint32_t)fb_nwin(c->fb_w); h.per_win = fb_per_win(c->fb_w); h.table_bytes = c->table_bytes;
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+    std::vector<apt> gens(c->nbases);
+    if (hipMemcpy(gens.data(), c->d_gens, gens.size() * sizeof(apt), hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+    ok = ok && std::fwrite(gens.data(), sizeof(apt), gens.size(), f) == gens.size();
+    TableChecksum sum;
+    sum.update(gens.data(), gens.size() * sizeof(apt));
+    const size_t CH = (size_t)256 << 20;
+    std::vector<uint8_t> buf(c->table_bytes < CH ? c->table_bytes : CH);
+    for (size_t off = 0; ok && off < c->table_bytes; off += CH) {
+        const size_t m = c->table_bytes - off < CH ? c->table_bytes - off : CH;
+        if (hipMemcpy(buf.data(), (const uint8_t*)c->d_table + off, m, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+        sum.update(buf.data(), m);
+        ok = ok && std::fwrite(buf.data(), 1, m, f) == m;
+    }
+    h.checksum = sum.digest();                               // known only now: the header is written a second time, complete
+    ok = ok && std::fseek(f, 0, SEEK_SET) == 0 && std::fwrite(&h, sizeof h, 1, f) == 1;
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) { g_last_error = std::string("writing ") + path + " failed"; return BPPP_ERR_HIP; }
+    return BPPP_OK;
+}
+static int ctx_alloc_common(bppp_ctx* c) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipMalloc(&c->d_flags, sizeof(int)));
+    read_diagnostics(c);
+    c->n_simds = device_simds(c->device);
+    return BPPP_OK;
+}
+int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device) {
+    if (!out || !path) return BPPP_ERR_INVALID_ARG;
+    *out = nullptr;
+    int rc = check_device(device);
+    if (rc != BPPP_OK) return rc;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { g_last_error = std::string("cannot open ") + path; return BPPP_ERR_INVALID_ARG; }
+    TableFileHeader h;
+    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "BPPPTAB2", 8) == 0;
+    const int W = (int)h.window_bits;
+    ok = ok && (W == 4 || W == 8 || W == 10 || W == 16 || W == 20 || W == 22) && h.nbases == 1 + h.ng + h.nh && h.nbases <= 8193 &&
+         h.nwin == (uint32_t)fb_nwin(W) && h.per_win == fb_per_win(W) && h.table_bytes == (uint64_t)h.nbases * h.nwin * h.per_win * sizeof(apt_packed);
+    if (!ok) { std::fclose(f); g_last_error = std::string(path) + " is not a table file of this library"; return BPPP_ERR_INVALID_ARG; }
+    if (hipSetDevice(device) != hipSuccess) { std::fclose(f); g_last_error = "hipSetDevice failed"; (void)hipGetLastError(); return BPPP_ERR_HIP; }
+    bppp_ctx* c = new (std::nothrow) bppp_ctx();
+    if (!c) { std::fclose(f); return BPPP_ERR_NOMEM; }
+    c->device = device; c->fb_w = W; c->ng = (int)h.ng; c->nh = (int)h.nh; c->nbases = (int)h.nbases; c->table_bytes = h.table_bytes;
+    auto fail = [&](int code) { std::fclose(f); bppp_ctx_destroy(c); return code; };
+    rc = ctx_alloc_common(c);
+    if (rc != BPPP_OK) return fail(rc);
+    std::vector<apt> gens(h.nbases);
+    if (std::fread(gens.data(), sizeof(apt), gens.size(), f) != gens.size()) return fail(BPPP_ERR_INVALID_ARG);
+    // the generators get the validation bppp_ctx_create gives them (k_decode_generators): canonical limbs, on the curve
+    for (const apt& a : gens) {
+        uint8_t xy[64];
+        apt back;
+        apt_to_xy64(xy, a);                                   // through the wire form and back: the stored limbs must be exactly the
+        if (!apt_from_xy64(back, xy) || std::memcmp(&back, &a, sizeof(apt)) != 0) {                        // decoder's, on the curve
+            g_last_error = std::string(path) + ": a stored generator is not a valid secp256k1 point";
+            return fail(BPPP_ERR_ENCODING);
+        }
+    }
+    TableChecksum sum;
+    sum.update(gens.data(), gens.size() * sizeof(apt));
+    if (hipMalloc(&c->d_gens, gens.size() * sizeof(apt)) != hipSuccess || hipMalloc(&c->d_table, c->table_bytes) != hipSuccess) return fail(BPPP_ERR_NOMEM);
+    if (hipMemcpy(c->d_gens, gens.data(), gens.size() * sizeof(apt), hipMemcpyHostToDevice) != hipSuccess) return fail(BPPP_ERR_HIP);
+    const size_t CH = (size_t)256 << 20;
+    std::vector<uint8_t> buf(c->table_bytes < CH ? c->table_bytes : CH);
+    for (size_t off = 0; off < c->table_bytes; off += CH) {
+        const size_t m = c->table_bytes - off < CH ? c->table_bytes - off : CH;
+        if (std::fread(buf.data(), 1, m, f) != m) { g_last_error = std::string(path) + " is truncated"; return fail(BPPP_ERR_INVALID_ARG); }
+        sum.update(buf.data(), m);
+        if (hipMemcpy((uint8_t*)c->d_table + off, buf.data(), m, hipMemcpyHostToDevice) != hipSuccess) return fail(BPPP_ERR_HIP);
+    }
+    if (sum.digest() != h.checksum) {
+        g_last_error = std::string(path) + ": checksum mismatch (the table body or the generators differ from what was saved)";
+        return fail(BPPP_ERR_INVALID_ARG);
+    }
+    std::fclose(f);
+    *out = c;
+    return BPPP_OK;
+}
+// A second context on the SAME device that shares `parent`'s generators and fixed-base tables (read-only data) and owns its
+// streams and workspaces: several host threads can then verify concurrently on one GPU without a second 21 GB table.  The
+// parent must outlive its children.
+int bppp_ctx_create_shared(bppp_ctx** out, bppp_ctx* parent) {
+    if (!out || !parent) return BPPP_ERR_INVALID_ARG;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(parent->device));
+    bppp_ctx* c = new (std::nothrow) bppp_ctx();
+    if (!c) return BPPP_ERR_NOMEM;
+    c->device = parent->device; c->fb_w = parent->fb_w; c->ng = parent->ng; c->nh = parent->nh; c->nbases = parent->nbases;
+    c->d_gens = parent->d_gens; c->d_table = parent->d_table; c->table_bytes = 0; c->borrows_tables = true;
+    int rc = ctx_alloc_common(c);
+    if (rc != BPPP_OK) { bppp_ctx_destroy(c); return rc; }
+    *out = c;
+    return BPPP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,996 @@
+// libbppp_hip.so, host side: generic WeightNormLinearArgument / ReciprocalRangeProofProtocol / ArithmeticCircuit verifiers and provers, and the
+// generic fixed-base linear combination (the crate's commit functions).
+#include "host.h"
+
+extern "C" {
+
+// caller transcripts of the generic verifiers (host pointers): n_states x 203 in, n x 203 out (optional)
+struct HostTranscripts { const uint8_t* states; size_t n_states; uint8_t* states_out; };
+static int check_host_transcripts(const HostTranscripts* tx, size_t n) {
+    if (!tx) return BPPP_OK;
+    if (!tx->states || (tx->n_states != 1 && tx->n_states != n)) return BPPP_ERR_INVALID_ARG;
+    for (size_t i = 0; i < tx->n_states; i++)
+        if (tx->states[203 * i + 200] >= BPPP_STROBE_R || tx->states[203 * i + 201] > BPPP_STROBE_R) return BPPP_ERR_INVALID_ARG;
+    return BPPP_OK;
+}
+// device copies of a prover call's transcripts (host-buffer entry points): states in, advanced states out
+struct TxDev {
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    ~TxDev() { if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); }
+    int begin(const HostTranscripts* tx, size_t n, hipStream_t s, TranscriptIo& io, int& divergent) {
+        io.states = nullptr; io.n_states = 0; io.states_out = nullptr; io.no_ops = 0;
+        divergent = 0;
+        if (!tx) return BPPP_OK;
+        int rc = check_host_transcripts(tx, n);
+        if (rc != BPPP_OK) return rc;
+        HIP_TRY(hipMalloc(&d_in, tx->n_states * 203));
+        HIP_TRY(hipMemcpyAsync(d_in, tx->states, tx->n_states * 203, hipMemcpyHostToDevice, s));
+        if (tx->states_out) HIP_TRY(hipMalloc(&d_out, n * 203));
+        io.states = d_in; io.n_states = tx->n_states; io.states_out = d_out;
+        divergent = tx->n_states != 1;
+        return BPPP_OK;
+    }
+    // after the last prover kernel: serialize every instance's transcript and queue the copy back
+    int finish(const HostTranscripts* tx, const TranscriptIo& io, const strobe& base, const u32* tstate, size_t n, const int32_t* status, hipStream_t s) {
+        if (!tx || !tx->states_out) return BPPP_OK;
+        k_gprove_export_states<<<(unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(io, base, tstate, n, status);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(tx->states_out, d_out, n * 203, hipMemcpyDeviceToHost, s));
+        return BPPP_OK;
+    }
+};
+// fast variable-base path of the generic verifiers' rounds: per instance 2 x rounds window tables (16 entries of 64 B per point), the
+// running products of their build (14 per point) and the decoded round points -- 1.2 KB + 0.55 KB + 64 B per point, grow-only
+static int wnla_fast_setup(bppp_ctx* c, WnlaWs& w, size_t n, size_t rounds) {
+    w.atab = nullptr; w.tscr = nullptr; w.rpts = nullptr;
+    if (rounds == 0 || c->generic_slow_rounds) return BPPP_OK;
+    const size_t np = 2 * rounds;
+    const size_t b_tab = align16(np * 16 * sizeof(apt_packed) * n), b_scr = align16(14 * np * 10 * sizeof(u32) * n), b_pts = align16(np * 16 * sizeof(u32) * n);
+    const size_t need = b_tab + b_scr + b_pts;
+    if (need > c->gtab_bytes) {
+        if (c->d_gtab) { (void)hipFree(c->d_gtab); c->d_gtab = nullptr; c->gtab_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->d_gtab, need));
+        c->gtab_bytes = need;
+    }
+    w.atab = (apt_packed*)c->d_gtab;
+    w.tscr = (u32*)(c->d_gtab + b_tab);
+    w.rpts = (u32*)(c->d_gtab + b_tab + b_scr);
+    return BPPP_OK;
+}
+// lanes per instance for the generic rounds: 4 or 2 while that still leaves wavefront slots free (and the fast path's tables exist)
+static int wnla_round_group(const bppp_ctx* c, const WnlaWs& w, unsigned blocks) {
+    if (!w.atab || c->no_lane_groups) return 1;
+    if (4 * (size_t)blocks <= (size_t)c->n_simds) return 4;
+    if (2 * (size_t)blocks <= (size_t)c->n_simds) return 2;
+    return 1;
+}
+// ---- generic WeightNormLinearArgument entry points (host pointers; one device blob per call)
+struct WnlaBlob {
+    uint8_t* d = nullptr;
+    ~WnlaBlob() { if (d) (void)hipFree(d); }
+};
+
+static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                    const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, size_t rounds, const uint8_t* proof_r,
+                    const uint8_t* proof_x, const uint8_t* proof_l, size_t nl, const uint8_t* proof_n, size_t nn, uint8_t* out_points,
+                    uint8_t* accept, int32_t* status, const HostTranscripts* tx = nullptr) {
+    HIP_TRY(hipSetDevice(c->device));
+    if (rounds > 12 || nl > 4096 || nn > 4096) return BPPP_ERR_INVALID_ARG;
+    int rc = check_host_transcripts(tx, n);
+    if (rc != BPPP_OK) return rc;
+    rc = ensure_straus_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds;
+    // layout of the blob: inputs | outputs | workspace
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    const size_t o_com = take(n * 64), o_c = take(n * (size_t)c->nh * 32), o_rho = take(n * 32), o_mu = take(n * 32),
+                 o_r = take(n * rounds * 64), o_x = take(n * rounds * 64), o_l = take(n * nl * 32), o_n = take(n * nn * 32),
+                 o_out = take(n * 64), o_acc = take(n), o_st = take(n * 4), o_ts = take(52 * n * 4), o_a = take(30 * n * 4),
+                 o_pf = take(30 * n * 4), o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4),
+                 o_msc = take(NB * 8 * n * 4), o_ti = take(tx ? tx->n_states * 203 : 0), o_to = take(tx && tx->states_out ? n * 203 : 0);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off + 16));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    auto up = [&](size_t o, const uint8_t* src, size_t bytes) -> hipError_t {
+        return (src && bytes) ? hipMemcpyAsync(d + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+    };
+    if (tx) HIP_TRY(up(o_ti, tx->states, tx->n_states * 203));
+    HIP_TRY(up(o_com, commitments, n * 64));
+    HIP_TRY(up(o_c, cvec, n * (size_t)c->nh * 32));
+    HIP_TRY(up(o_rho, rho, n * 32));
+    HIP_TRY(up(o_mu, mu, n * 32));
+    HIP_TRY(up(o_r, proof_r, n * rounds * 64));
+    HIP_TRY(up(o_x, proof_x, n * rounds * 64));
+    HIP_TRY(up(o_l, proof_l, n * nl * 32));
+    HIP_TRY(up(o_n, proof_n, n * nn * 32));
+    WnlaWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.ng = c->ng; w.nh = c->nh; w.rounds = (int)rounds; w.nl = (int)nl; w.nn = (int)nn;
+    w.commitments = d + o_com; w.c = d + o_c; w.rho = d + o_rho; w.mu = d + o_mu; w.proof_r = d + o_r; w.proof_x = d + o_x;
+    w.proof_l = d + o_l; w.proof_n = d + o_n; w.out_points = d + o_out; w.accept = d + o_acc; w.status = (int32_t*)(d + o_st);
+    w.tstate = (u32*)(d + o_ts); w.acc = (u32*)(d + o_a); w.pfix = (u32*)(d + o_pf); w.ys = (u32*)(d + o_ys);
+    w.tab = (u32*)(d + o_tab); w.msc = (u32*)(d + o_msc);
+    w.stride_r = rounds * 64; w.stride_x = rounds * 64; w.stride_l = nl * 32; w.stride_n = nn * 32;
+    w.straus = c->d_straus;
+    w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    if (!commit) t_new(w.base, label, (u32)label_len);
+    if (tx) {
+        w.tio.states = d + o_ti; w.tio.n_states = tx->n_states; w.tio.states_out = tx->states_out ? d + o_to : nullptr;
+        w.tio.no_ops = rounds == 0;
+        w.divergent_positions = tx->n_states != 1;
+    }
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    if (commit) {
+        k_wnla_commit_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1);
+        k_wnla_commit_store<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out_points, d + o_out, n * 64, hipMemcpyDeviceToHost, s));
+    } else {
+        rc = wnla_fast_setup(c, w, n, rounds);
+        if (rc != BPPP_OK) return rc;
+        k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        if (w.atab) k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        {
+            const int grp = wnla_round_group(c, w, blocks);
+            for (int k = 1; k <= (int)rounds; k++) {
+                if (grp > 1) k_wnla_round_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k, grp);
+                else k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+            }
+        }
+        k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
+        k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
+        if (w.tio.states_out) HIP_TRY(hipMemcpyAsync(tx->states_out, d + o_to, n * 203, hipMemcpyDeviceToHost, s));
+    }
+    if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return BPPP_OK;
+}
+
+int bppp_wnla_commit_batch(bppp_ctx* c, size_t n, const uint8_t* cvec, const uint8_t* mu, const uint8_t* l, size_t nl,
+                           const uint8_t* nvec, size_t nn, uint8_t* out, int32_t* status) {
+    CtxLock lock_(c);
+    if (!c || !cvec || !mu || (!l && nl) || (!nvec && nn) || !out) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    return wnla_run(c, true, nullptr, 0, n, nullptr, cvec, nullptr, mu, 0, nullptr, nullptr, l, nl, nvec, nn, out, nullptr, status);
+}
+
+int bppp_wnla_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                           const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, size_t rounds, const uint8_t* proof_r,
+                           const uint8_t* proof_x, const uint8_t* proof_l, size_t nl, const uint8_t* proof_n, size_t nn,
+                           uint8_t* accept, int32_t* status) {
+    CtxLock lock_(c);
+    if (!c || (!label && label_len) || !commitments || !cvec || !rho || !mu || (rounds && (!proof_r || !proof_x)) || (!proof_l && nl) ||
+        (!proof_n && nn) || !accept)
+        return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    return wnla_run(c, false, label, label_len, n, commitments, cvec, rho, mu, rounds, proof_r, proof_x, proof_l, nl, proof_n, nn, nullptr,
+                    accept, status);
+}
+
+int bppp_wnla_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, const uint8_t* commitments,
+                                      const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, size_t rounds, const uint8_t* proof_r,
+                                      const uint8_t* proof_x, const uint8_t* proof_l, size_t nl, const uint8_t* proof_n, size_t nn,
+                                      uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
+    if (!c || !states || !commitments || !cvec || !rho || !mu || (rounds && (!proof_r || !proof_x)) || (!proof_l && nl) || (!proof_n && nn) ||
+        !accept)
+        return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HostTranscripts tx = {states, n_states, states_out};
+    return wnla_run(c, false, nullptr, 0, n, commitments, cvec, rho, mu, rounds, proof_r, proof_x, proof_l, nl, proof_n, nn, nullptr, accept,
+                    status, &tx);
+}
+
+// ---- generic ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) on a context built by bppp_wnla_ctx_create over
+//      g, g_vec || g_vec_, h_vec || h_vec_
+// workspace bytes (beyond the caller's commitments / proofs / accept / status) of one reciprocal verify call
+static size_t recip_verify_ws_bytes(const bppp_ctx* c, size_t n, size_t dim_nd, size_t dim_np, size_t rounds, bool rlc = false) {
+    const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = align16(off + bytes); };
+    take(52 * n * 4); take((dim_nd + 6) * 8 * n * 4); take(5 * 16 * n * 4); take(30 * n * 4); take(30 * n * 4); take(dim_np * 8 * n * 4);
+    take(n * 64); take(n * NH * 32); take(n * 32); take(n * 32); take((rounds ? rounds : 1) * 8 * n * 4); take(2 * T * 8 * n * 4);
+    take(NB * 8 * n * 4);
+    if (rlc) { take(30 * n * 4); take(NB * 8 * n * 4); take((n + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK); take(((n + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK + 4) * 4); }
+    return off;
+}
+// the launch sequence, every buffer in device memory; d_ws holds recip_verify_ws_bytes()
+static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                    const uint8_t* d_com, const uint8_t* d_proofs, size_t rounds, size_t nl, size_t nn, uint8_t* d_acc,
+                                    int32_t* d_st, uint8_t* d_ws, const TranscriptIo* dtio = nullptr, const uint8_t* rlc_seed = nullptr) {
+    const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh;
+    const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    const size_t o_ts = take(52 * n * 4), o_sc0 = take((dim_nd + 6) * 8 * n * 4), o_pts = take(5 * 16 * n * 4), o_a = take(30 * n * 4),
+                 o_pf = take(30 * n * 4), o_inv = take(dim_np * 8 * n * 4), o_wc = take(n * 64), o_wcv = take(n * NH * 32), o_rho = take(n * 32),
+                 o_mu = take(n * 32), o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4), o_msc = take(NB * 8 * n * 4);
+    const size_t nchunks = (n + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    const size_t o_rl = rlc_seed ? take(30 * n * 4) : 0, o_rs = rlc_seed ? take(NB * 8 * n * 4) : 0, o_rf = rlc_seed ? take(nchunks) : 0,
+                 o_rli = rlc_seed ? take((nchunks + 4) * 4) : 0;
+    uint8_t* d = d_ws;
+    hipStream_t s = c->stream;
+    RecipWs r;
+    std::memset(&r, 0, sizeof r);
+    r.N = n; r.nd = (int)dim_nd; r.np = (int)dim_np; r.rounds = (int)rounds; r.nl = (int)nl; r.nn = (int)nn;
+    r.NG = c->ng; r.NH = c->nh; r.proof_bytes = proof_bytes;
+    r.commitments = d_com; r.proofs = d_proofs; r.status = d_st; r.tstate = (u32*)(d + o_ts);
+    r.sc0 = (u32*)(d + o_sc0); r.pts = (u32*)(d + o_pts); r.acc = (u32*)(d + o_a); r.pfix = (u32*)(d + o_pf); r.inv = (u32*)(d + o_inv);
+    r.straus = c->d_straus;
+    r.wn_commit = d + o_wc; r.wn_c = d + o_wcv; r.wn_rho = d + o_rho; r.wn_mu = d + o_mu;
+    r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
+    t_new(r.base, label, (u32)label_len);
+    if (dtio) r.tio = *dtio;
+    WnlaWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.ng = c->ng; w.nh = c->nh; w.rounds = (int)rounds; w.nl = (int)nl; w.nn = (int)nn;
+    w.base = r.base;
+    if (dtio) { w.tio = *dtio; w.divergent_positions = dtio->n_states != 1; }
+    w.commitments = r.wn_commit; w.c = r.wn_c; w.rho = r.wn_rho; w.mu = r.wn_mu;
+    w.proof_r = r.proofs + 256; w.proof_x = r.proofs + 256 + 64 * rounds; w.proof_l = r.proofs + 320 + 128 * rounds;
+    w.proof_n = w.proof_l + 32 * nl;
+    w.stride_r = w.stride_x = w.stride_l = w.stride_n = proof_bytes;
+    w.transcript_preloaded = 1;
+    w.accept = d_acc; w.status = r.status; w.tstate = r.tstate; w.acc = r.acc; w.pfix = r.pfix;
+    w.ys = (u32*)(d + o_ys); w.tab = (u32*)(d + o_tab); w.msc = (u32*)(d + o_msc);
+    w.straus = c->d_straus;
+    w.fb = r.fb;
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    int rc;
+#define GLAUNCH(id, ...)                                       \
+    do {                                                       \
+        rc = timed(c, id, s, [&]() { __VA_ARGS__; });          \
+        if (rc != BPPP_OK) return rc;                          \
+    } while (0)
+    GLAUNCH(K_RECIP_PHASE1, k_recip_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
+    GLAUNCH(K_RECIP_C0_VAR, k_recip_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    GLAUNCH(K_RECIP_C0_FINISH, k_recip_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    rc = wnla_fast_setup(c, w, n, rounds);
+    if (rc != BPPP_OK) return rc;
+    GLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (w.atab) GLAUNCH(K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    {
+        const int grp = wnla_round_group(c, w, blocks);
+        for (int k = 1; k <= (int)rounds; k++) {
+            if (grp > 1) GLAUNCH(K_WNLA_ROUND, k_wnla_round_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k, grp));
+            else GLAUNCH(K_WNLA_ROUND, k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        }
+    }
+    GLAUNCH(K_WNLA_FINAL_SCALARS, k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (!rlc_seed) {
+        GLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
+        GLAUNCH(K_WNLA_ACCEPT, k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    } else {
+        // one MSM per chunk of 8 instances instead of one per instance; what does not pass is re-checked exactly (wnla_rlc_core.h)
+        RlcWs rl;
+        std::memset(&rl, 0, sizeof rl);
+        for (int i = 0; i < 4; i++) {
+            u64 v = 0;
+            for (int k = 0; k < 8; k++) v |= (u64)rlc_seed[8 * i + k] << (8 * k);
+            rl.seed[i] = v;
+        }
+        rl.lhs = (u32*)(d + o_rl); rl.sc = (u32*)(d + o_rs); rl.flag = d + o_rf;
+        rl.list = (u32*)(d + o_rli); rl.count = (int*)(rl.list + nchunks + 1);
+        const unsigned chunk_blocks = (unsigned)((nchunks * BPPP_RLC_CHUNK + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+        const unsigned check_blocks = (unsigned)(nchunks < 16384 ? nchunks : 16384);
+        HIP_TRY(hipMemsetAsync(d_acc, 0, n, s));
+        HIP_TRY(hipMemsetAsync(rl.count, 0, sizeof(int), s));
+        GLAUNCH(K_WNLA_RLC_LHS, k_wnla_rlc_lhs<<<blocks, BPPP_BLOCK, 0, s>>>(w, rl));
+        GLAUNCH(K_WNLA_RLC_CHUNK, k_wnla_rlc_chunk<<<chunk_blocks, BPPP_FB_BLOCK, 0, s>>>(w, rl));
+        GLAUNCH(K_WNLA_RLC_CHECK, k_wnla_rlc_check<<<check_blocks, 64, 0, s>>>(w, rl));
+        GLAUNCH(K_WNLA_MSM, k_wnla_msm_flagged<<<1024, 64, 0, s>>>(w, rl));
+        GLAUNCH(K_WNLA_MSM, k_wnla_msm_flagged_dense<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, rl));
+        GLAUNCH(K_WNLA_ACCEPT, k_wnla_accept_flagged<<<blocks, BPPP_BLOCK, 0, s>>>(w, rl));
+    }
+    if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+#undef GLAUNCH
+    HIP_TRY(hipGetLastError());
+    return BPPP_OK;
+}
+static int recip_verify_check_args(const bppp_ctx* c, size_t dim_nd, size_t dim_np, size_t rounds, size_t nl, size_t nn) {
+    if (dim_nd == 0 || dim_np == 0 || dim_nd > (size_t)c->ng || dim_nd + 10 > (size_t)c->nh || dim_np > dim_nd + 1 || rounds > 12 ||
+        nl > 4096 || nn > 4096)
+        return BPPP_ERR_INVALID_ARG;
+    return BPPP_OK;
+}
+int recip_verify_device_entry(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                              const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn, void* d_accept,
+                              void* d_status, const uint8_t* rlc_seed, void* d_reject_count) {
+    if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept || !d_status) return BPPP_ERR_INVALID_ARG;
+    int rc = recip_verify_check_args(c, dim_nd, dim_np, rounds, nl, nn);
+    if (rc != BPPP_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (d_reject_count) HIP_TRY(hipMemsetAsync(d_reject_count, 0, sizeof(int), c->stream));
+    if (n == 0) return BPPP_OK;
+    rc = ensure_straus_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    // persistent, grow-only workspace (the host-pointer entry point allocates per call instead)
+    const size_t need = recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds, rlc_seed != nullptr);
+    if (need > c->gws_bytes) {
+        if (c->d_gws) { (void)hipFree(c->d_gws); c->d_gws = nullptr; c->gws_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->d_gws, need));
+        c->gws_bytes = need;
+    }
+    rc = recip_verify_device_impl(c, label, label_len, n, dim_nd, dim_np, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, rounds, nl,
+                                  nn, (uint8_t*)d_accept, (int32_t*)d_status, c->d_gws, nullptr, rlc_seed);
+    if (rc != BPPP_OK || !d_reject_count) return rc;
+    k_count_rejects<<<(unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), 256, 0, c->stream>>>((const uint8_t*)d_accept, n, (int*)d_reject_count);
+    HIP_TRY(hipGetLastError());
+    return BPPP_OK;
+}
+int bppp_reciprocal_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                        const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn,
+                                        void* d_accept, void* d_status) {
+    CtxLock lock_(c);
+    return recip_verify_device_entry(c, label, label_len, n, dim_nd, dim_np, d_commitments, d_proofs, rounds, nl, nn, d_accept, d_status, nullptr, nullptr);
+}
+int bppp_reciprocal_verify_batch_rlc_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                            const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn,
+                                            void* d_accept, void* d_status, const uint8_t seed[32]) {
+    CtxLock lock_(c);
+    if (!seed) return BPPP_ERR_INVALID_ARG;
+    return recip_verify_device_entry(c, label, label_len, n, dim_nd, dim_np, d_commitments, d_proofs, rounds, nl, nn, d_accept, d_status, seed, nullptr);
+}
+static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                  const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                  int32_t* status, const HostTranscripts* tx, const uint8_t* rlc_seed = nullptr);
+int bppp_reciprocal_verify_batch_rlc(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                     const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                     int32_t* status, const uint8_t seed[32]) {
+    CtxLock lock_(c);
+    if (!seed) return BPPP_ERR_INVALID_ARG;
+    return recip_verify_host_impl(c, label, label_len, n, dim_nd, dim_np, commitments, proofs, rounds, nl, nn, accept, status, nullptr, seed);
+}
+int bppp_reciprocal_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                 const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                 int32_t* status) {
+    CtxLock lock_(c);
+    return recip_verify_host_impl(c, label, label_len, n, dim_nd, dim_np, commitments, proofs, rounds, nl, nn, accept, status, nullptr);
+}
+int bppp_reciprocal_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, size_t dim_nd, size_t dim_np,
+                                            const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn,
+                                            uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
+    if (!states) return BPPP_ERR_INVALID_ARG;
+    HostTranscripts tx = {states, n_states, states_out};
+    return recip_verify_host_impl(c, nullptr, 0, n, dim_nd, dim_np, commitments, proofs, rounds, nl, nn, accept, status, &tx);
+}
+static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                  const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                  int32_t* status, const HostTranscripts* tx, const uint8_t* rlc_seed) {
+    if (!c || (!label && label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
+    int rc = recip_verify_check_args(c, dim_nd, dim_np, rounds, nl, nn);
+    if (rc != BPPP_OK) return rc;
+    if (n == 0) return BPPP_OK;
+    rc = check_host_transcripts(tx, n);
+    if (rc != BPPP_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    rc = ensure_straus_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
+    const size_t o_com = 0, o_pr = align16(n * 64), o_acc = align16(o_pr + n * proof_bytes), o_st = align16(o_acc + n),
+                 o_ti = align16(o_st + n * 4), o_to = align16(o_ti + (tx ? tx->n_states * 203 : 0)),
+                 o_ws = align16(o_to + (tx && tx->states_out ? n * 203 : 0)),
+                 total = o_ws + recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds, rlc_seed != nullptr);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, total));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * 64, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_pr, proofs, n * proof_bytes, hipMemcpyHostToDevice, s));
+    TranscriptIo dtio = {nullptr, 0, nullptr, 0};
+    if (tx) {
+        HIP_TRY(hipMemcpyAsync(d + o_ti, tx->states, tx->n_states * 203, hipMemcpyHostToDevice, s));
+        dtio.states = d + o_ti; dtio.n_states = tx->n_states; dtio.states_out = tx->states_out ? d + o_to : nullptr;
+    }
+    rc = recip_verify_device_impl(c, label, label_len, n, dim_nd, dim_np, d + o_com, d + o_pr, rounds, nl, nn, d + o_acc, (int32_t*)(d + o_st),
+                                  d + o_ws, tx ? &dtio : nullptr, rlc_seed);
+    if (rc != BPPP_OK) return rc;
+    if (dtio.states_out) HIP_TRY(hipMemcpyAsync(tx->states_out, d + o_to, n * 203, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return BPPP_OK;
+}
+
+// ---------------------------------------------------------------- generic ArithmeticCircuit (circuit.rs:95-256)
+struct bppp_circuit {
+    CircuitDev cd;
+    const int* d_part = nullptr;     // [3 nv + nm]: LO | LL | LR | NO (the prover places w_o with it)
+    uint8_t* d_blob = nullptr;
+    size_t blob_bytes = 0;
+};
+int bppp_circuit_create(bppp_ctx* c, bppp_circuit** out, const size_t dims[6], int f_l, int f_m, const uint8_t* W_m, const uint8_t* W_l,
+                        const uint8_t* a_m, const uint8_t* a_l, const int32_t* part_lo, const int32_t* part_ll, const int32_t* part_lr,
+                        const int32_t* part_no) {
+    CtxLock lock_(c);
+    if (!c || !out || !dims || !W_m || !W_l || !a_m || !a_l || !part_lo || !part_ll || !part_lr || !part_no) return BPPP_ERR_INVALID_ARG;
+    const size_t nm = dims[0], no = dims[1], k = dims[2], nl = dims[3], nv = dims[4], nw = dims[5];
+    // the reference's own definitions (circuit.rs:100-106) and what the context's generators can serve
+    if (nm == 0 || nv == 0 || k == 0 || nl != nv * k || nw != 2 * nm + no || nm > (size_t)c->ng || nv + 9 > (size_t)c->nh || k > 1024 ||
+        nm > 65536 || nv > 65536 || no > 65536)
+        return BPPP_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    CircuitHostData hd;
+    if (!circuit_host_build(hd, dims, W_m, W_l, a_m, a_l, part_lo, part_ll, part_lr, part_no)) return BPPP_ERR_INVALID_ARG;
+    std::vector<int>&cpl = hd.cpl, &rl = hd.rl, &cpm = hd.cpm, &rm = hd.rm, &colmap = hd.colmap;
+    std::vector<u32>&vl = hd.vl, &vm = hd.vm, &al = hd.al, &am = hd.am;
+    bppp_circuit* q = new (std::nothrow) bppp_circuit();
+    if (!q) return BPPP_ERR_INVALID_ARG;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes + 16); return o; };
+    const size_t o_cpl = take(cpl.size() * 4), o_rl = take(rl.size() * 4), o_vl = take(vl.size() * 4), o_cpm = take(cpm.size() * 4),
+                 o_rm = take(rm.size() * 4), o_vm = take(vm.size() * 4), o_cm = take(colmap.size() * 4), o_al = take(al.size() * 4),
+                 o_am = take(am.size() * 4);
+    std::vector<int> parts(3 * nv + nm);
+    for (size_t j = 0; j < nv; j++) { parts[j] = part_lo[j]; parts[nv + j] = part_ll[j]; parts[2 * nv + j] = part_lr[j]; }
+    for (size_t j = 0; j < nm; j++) parts[3 * nv + j] = part_no[j];
+    const size_t o_part = take(parts.size() * 4);
+    hipError_t e = hipMalloc(&q->d_blob, off);
+    if (e != hipSuccess) { delete q; g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
+    q->blob_bytes = off;
+    auto up = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpy(q->d_blob + o, src, bytes, hipMemcpyHostToDevice) : hipSuccess; };
+    if (up(o_cpl, cpl.data(), cpl.size() * 4) != hipSuccess || up(o_rl, rl.data(), rl.size() * 4) != hipSuccess ||
+        up(o_vl, vl.data(), vl.size() * 4) != hipSuccess || up(o_cpm, cpm.data(), cpm.size() * 4) != hipSuccess ||
+        up(o_rm, rm.data(), rm.size() * 4) != hipSuccess || up(o_vm, vm.data(), vm.size() * 4) != hipSuccess ||
+        up(o_cm, colmap.data(), colmap.size() * 4) != hipSuccess || up(o_al, al.data(), al.size() * 4) != hipSuccess ||
+        up(o_am, am.data(), am.size() * 4) != hipSuccess || up(o_part, parts.data(), parts.size() * 4) != hipSuccess) {
+        (void)hipFree(q->d_blob);
+        delete q;
+        g_last_error = "circuit upload failed";
+        return BPPP_ERR_HIP;
+    }
+    CircuitDev& cd = q->cd;
+    cd.nm = (int)nm; cd.no = (int)no; cd.k = (int)k; cd.nl = (int)nl; cd.nv = (int)nv; cd.nw = (int)nw; cd.f_l = f_l ? 1 : 0; cd.f_m = f_m ? 1 : 0;
+    cd.colptr_l = (const int*)(q->d_blob + o_cpl); cd.rows_l = (const int*)(q->d_blob + o_rl); cd.vals_l = (const u32*)(q->d_blob + o_vl);
+    cd.colptr_m = (const int*)(q->d_blob + o_cpm); cd.rows_m = (const int*)(q->d_blob + o_rm); cd.vals_m = (const u32*)(q->d_blob + o_vm);
+    cd.colmap = (const int*)(q->d_blob + o_cm); cd.a_l = (const u32*)(q->d_blob + o_al); cd.a_m = (const u32*)(q->d_blob + o_am);
+    q->d_part = (const int*)(q->d_blob + o_part);
+    *out = q;
+    return BPPP_OK;
+}
+void bppp_circuit_destroy(bppp_circuit* q) {
+    if (!q) return;
+    if (q->d_blob) (void)hipFree(q->d_blob);
+    delete q;
+}
+static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n,
+                                    const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                    int32_t* status, const HostTranscripts* tx);
+int bppp_circuit_verify_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                              const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept, int32_t* status) {
+    CtxLock lock_(c);
+    return circuit_verify_host_impl(c, q, label, label_len, n, commitments, proofs, rounds, nl, nn, accept, status, nullptr);
+}
+int bppp_circuit_verify_batch_transcript(bppp_ctx* c, const bppp_circuit* q, size_t n, const uint8_t* states, size_t n_states,
+                                         const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn,
+                                         uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
+    if (!states) return BPPP_ERR_INVALID_ARG;
+    HostTranscripts tx = {states, n_states, states_out};
+    return circuit_verify_host_impl(c, q, nullptr, 0, n, commitments, proofs, rounds, nl, nn, accept, status, &tx);
+}
+static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n,
+                                    const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                    int32_t* status, const HostTranscripts* tx) {
+    if (!c || !q || (!label && label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
+    const CircuitDev& cd = q->cd;
+    if (cd.nm > c->ng || cd.nv + 9 > c->nh || rounds > 12 || nl > 4096 || nn > 4096) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    int rc = check_host_transcripts(tx, n);
+    if (rc != BPPP_OK) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    rc = ensure_straus_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh, k = (size_t)cd.k, nm = (size_t)cd.nm, nv = (size_t)cd.nv;
+    const size_t proof_bytes = 64 * (4 + 2 * rounds) + 32 * (nl + nn);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    const size_t o_com = take(n * k * 64), o_pr = take(n * proof_bytes), o_acc = take(n), o_st = take(n * 4), o_ts = take(52 * n * 4),
+                 o_lam = take((size_t)cd.nl * 8 * n * 4), o_muv = take(nm * 8 * n * 4), o_coef = take((3 * nm + 3 * nv) * 8 * n * 4),
+                 o_sc0 = take((nm + 5 + k) * 8 * n * 4), o_pts = take((4 + k) * 16 * n * 4), o_a = take(30 * n * 4), o_pf = take(30 * n * 4),
+                 o_wc = take(n * 64), o_wcv = take(n * NH * 32), o_rho = take(n * 32), o_mu = take(n * 32),
+                 o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4), o_msc = take(NB * 8 * n * 4),
+                 o_ti = take(tx ? tx->n_states * 203 : 0), o_to = take(tx && tx->states_out ? n * 203 : 0);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off + 16));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    if (tx) HIP_TRY(hipMemcpyAsync(d + o_ti, tx->states, tx->n_states * 203, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * k * 64, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_pr, proofs, n * proof_bytes, hipMemcpyHostToDevice, s));
+    CircuitWs r;
+    std::memset(&r, 0, sizeof r);
+    r.N = n; r.cd = cd; r.rounds = (int)rounds; r.NG = c->ng; r.NH = c->nh; r.proof_bytes = proof_bytes;
+    r.commitments = d + o_com; r.proofs = d + o_pr; r.status = (int32_t*)(d + o_st); r.tstate = (u32*)(d + o_ts);
+    r.lamv = (u32*)(d + o_lam); r.muv = (u32*)(d + o_muv); r.coef = (u32*)(d + o_coef); r.sc0 = (u32*)(d + o_sc0); r.pts = (u32*)(d + o_pts);
+    r.acc = (u32*)(d + o_a); r.pfix = (u32*)(d + o_pf);
+    r.straus = c->d_straus;
+    r.wn_commit = d + o_wc; r.wn_c = d + o_wcv; r.wn_rho = d + o_rho; r.wn_mu = d + o_mu;
+    r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
+    t_new(r.base, label, (u32)label_len);
+    if (tx) { r.tio.states = d + o_ti; r.tio.n_states = tx->n_states; r.tio.states_out = tx->states_out ? d + o_to : nullptr; }
+    WnlaWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.ng = c->ng; w.nh = c->nh; w.rounds = (int)rounds; w.nl = (int)nl; w.nn = (int)nn;
+    w.base = r.base; w.tio = r.tio; w.divergent_positions = tx && tx->n_states != 1;
+    w.commitments = r.wn_commit; w.c = r.wn_c; w.rho = r.wn_rho; w.mu = r.wn_mu;
+    w.proof_r = r.proofs + 256; w.proof_x = r.proofs + 256 + 64 * rounds; w.proof_l = r.proofs + 256 + 128 * rounds;
+    w.proof_n = w.proof_l + 32 * nl;
+    w.stride_r = w.stride_x = w.stride_l = w.stride_n = proof_bytes;
+    w.transcript_preloaded = 1;
+    w.accept = d + o_acc; w.status = r.status; w.tstate = r.tstate; w.acc = r.acc; w.pfix = r.pfix;
+    w.ys = (u32*)(d + o_ys); w.tab = (u32*)(d + o_tab); w.msc = (u32*)(d + o_msc);
+    w.straus = c->d_straus;
+    w.fb = r.fb;
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    k_circuit_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    k_circuit_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r);
+    k_circuit_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    k_circuit_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    {
+        int rcf = wnla_fast_setup(c, w, n, rounds);
+        if (rcf != BPPP_OK) return rcf;
+    }
+    k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    if (w.atab) k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    {
+        const int grp = wnla_round_group(c, w, blocks);
+        for (int kk = 1; kk <= (int)rounds; kk++) {
+            if (grp > 1) k_wnla_round_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, kk, grp);
+            else k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
+        }
+    }
+    k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
+    k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
+    if (w.tio.states_out) HIP_TRY(hipMemcpyAsync(tx->states_out, d + o_to, n * 203, hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return BPPP_OK;
+}
+
+// sum_j scalars[i][j] * generator[base_index[j]] for n independent rows, through the context's fixed-base tables: the crate's
+// commit functions (circuit.rs:146-151, reciprocal.rs:88-95, u64_proof.rs:37-39) are instances of this with fixed index lists.
+int bppp_msm_batch(bppp_ctx* c, size_t n, size_t nterms, const int32_t* base_index, const uint8_t* scalars, uint8_t* out, int32_t* status) {
+    CtxLock lock_(c);
+    if (!c || !base_index || !scalars || !out || nterms == 0 || nterms > 65536) return BPPP_ERR_INVALID_ARG;
+    for (size_t j = 0; j < nterms; j++) {
+        if (base_index[j] < 0 || base_index[j] >= c->nbases) return BPPP_ERR_INVALID_ARG;
+        if (j && base_index[j] <= base_index[j - 1]) return BPPP_ERR_INVALID_ARG;      // strictly increasing
+    }
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<int> runs;
+    for (size_t j = 0; j < nterms;) {
+        size_t e = j + 1;
+        while (e < nterms && base_index[e] == base_index[e - 1] + 1) e++;
+        runs.push_back((int)j); runs.push_back(base_index[j]); runs.push_back((int)(e - j));
+        j = e;
+    }
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    const size_t o_sc = take(n * nterms * 32), o_runs = take(runs.size() * 4), o_msc = take(nterms * 8 * n * 4), o_pf = take(30 * n * 4),
+                 o_st = take(n * 4), o_out = take(n * 64);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(d + o_sc, scalars, n * nterms * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_runs, runs.data(), runs.size() * 4, hipMemcpyHostToDevice, s));
+    MsmWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.nterms = (int)nterms; w.nruns = (int)(runs.size() / 3);
+    w.scalars = d + o_sc; w.runs = (const int*)(d + o_runs); w.msc = (u32*)(d + o_msc); w.pfix = (u32*)(d + o_pf);
+    w.status = (int32_t*)(d + o_st); w.out = d + o_out;
+    w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    k_msm_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    k_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w);
+    k_msm_store<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d + o_out, n * 64, hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return BPPP_OK;
+}
+
+// WeightNormLinearArgument::prove (wnla.rs:125-190) for n instances sharing the context's generators.
+void bppp_wnla_proof_shape(size_t nl, size_t nn, size_t* rounds, size_t* nl_out, size_t* nn_out) {
+    size_t r, a, b;
+    wnla_proof_shape(nl, nn, r, a, b);
+    if (rounds) *rounds = r;
+    if (nl_out) *nl_out = a;
+    if (nn_out) *nn_out = b;
+}
+static int wnla_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, const HostTranscripts* tx, size_t n, const uint8_t* commitments,
+                           const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl, const uint8_t* nvec, size_t nn,
+                           uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l, uint8_t* proof_n, int32_t* status) {
+    if (!c || (!label && label_len) || !commitments || !cvec || !rho || !mu || (!l && nl) || (!nvec && nn) || nl > 65536 || nn > 65536)
+        return BPPP_ERR_INVALID_ARG;
+    size_t rounds, nl_f, nn_f;
+    wnla_proof_shape(nl, nn, rounds, nl_f, nn_f);
+    if ((rounds && (!proof_r || !proof_x)) || (nl_f && !proof_l) || (nn_f && !proof_n)) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t NB = (size_t)c->nbases, ng = (size_t)c->ng, nh = (size_t)c->nh;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes); return o; };
+    const size_t o_com = take(n * 64), o_c = take(n * nh * 32), o_rho = take(n * 32), o_mu = take(n * 32), o_l = take(n * nl * 32 + 16),
+                 o_n = take(n * nn * 32 + 16), o_pr = take(n * rounds * 64 + 16), o_px = take(n * rounds * 64 + 16),
+                 o_pl = take(n * nl_f * 32 + 16), o_pn = take(n * nn_f * 32 + 16), o_st = take(n * 4), o_ts = take(52 * n * 4),
+                 o_vl = take((nl + 1) * 8 * n * 4), o_vn = take((nn + 1) * 8 * n * 4), o_vc = take(nh * 8 * n * 4), o_ch = take(nh * 8 * n * 4),
+                 o_cg = take((ng + 1) * 8 * n * 4), o_prm = take(3 * 8 * n * 4), o_cm = take(16 * n * 4), o_msc = take(3 * NB * 8 * n * 4),
+                 o_pb = take(3 * 30 * n * 4);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * 64, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_c, cvec, n * nh * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_rho, rho, n * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_mu, mu, n * 32, hipMemcpyHostToDevice, s));
+    if (nl) HIP_TRY(hipMemcpyAsync(d + o_l, l, n * nl * 32, hipMemcpyHostToDevice, s));
+    if (nn) HIP_TRY(hipMemcpyAsync(d + o_n, nvec, n * nn * 32, hipMemcpyHostToDevice, s));
+    WnlaProveWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.ng = c->ng; w.nh = c->nh; w.nl = (int)nl; w.nn = (int)nn; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
+    w.commitments = d + o_com; w.c = d + o_c; w.rho = d + o_rho; w.mu = d + o_mu; w.l_in = d + o_l; w.n_in = d + o_n;
+    w.proof_r = d + o_pr; w.proof_x = d + o_px; w.proof_l = d + o_pl; w.proof_n = d + o_pn;
+    w.status = (int32_t*)(d + o_st); w.tstate = (u32*)(d + o_ts); w.vl = (u32*)(d + o_vl); w.vn = (u32*)(d + o_vn); w.vc = (u32*)(d + o_vc);
+    w.ch = (u32*)(d + o_ch); w.cg = (u32*)(d + o_cg); w.prm = (u32*)(d + o_prm); w.com = (u32*)(d + o_cm); w.msc = (u32*)(d + o_msc);
+    w.pbuf = (u32*)(d + o_pb);
+    w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    t_new(w.base, label, (u32)label_len);
+    TxDev txd;
+    int rc = txd.begin(tx, n, s, w.tio, w.divergent_positions);
+    if (rc != BPPP_OK) return rc;
+    w.tio.no_ops = rounds == 0;
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    k_wprove_init<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    for (int k = 0; k < (int)rounds; k++) {
+        k_wprove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1);
+        k_wprove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+        if (k + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2);
+    }
+    k_wprove_finish<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    HIP_TRY(hipGetLastError());
+    if (rounds) {
+        HIP_TRY(hipMemcpyAsync(proof_r, d + o_pr, n * rounds * 64, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(proof_x, d + o_px, n * rounds * 64, hipMemcpyDeviceToHost, s));
+    }
+    if (nl_f) HIP_TRY(hipMemcpyAsync(proof_l, d + o_pl, n * nl_f * 32, hipMemcpyDeviceToHost, s));
+    if (nn_f) HIP_TRY(hipMemcpyAsync(proof_n, d + o_pn, n * nn_f * 32, hipMemcpyDeviceToHost, s));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    rc = txd.finish(tx, w.tio, w.base, w.tstate, n, w.status, s);
+    if (rc != BPPP_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    return BPPP_OK;
+}
+int bppp_wnla_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments, const uint8_t* cvec,
+                          const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl, const uint8_t* nvec, size_t nn,
+                          uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l, uint8_t* proof_n, int32_t* status) {
+    CtxLock lock_(c);
+    return wnla_prove_impl(c, label, label_len, nullptr, n, commitments, cvec, rho, mu, l, nl, nvec, nn, proof_r, proof_x, proof_l, proof_n, status);
+}
+int bppp_wnla_prove_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, const uint8_t* commitments,
+                                     const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl, const uint8_t* nvec,
+                                     size_t nn, uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l, uint8_t* proof_n, int32_t* status,
+                                     uint8_t* states_out) {
+    CtxLock lock_(c);
+    if (!states) return BPPP_ERR_INVALID_ARG;
+    HostTranscripts tx = {states, n_states, states_out};
+    return wnla_prove_impl(c, nullptr, 0, &tx, n, commitments, cvec, rho, mu, l, nl, nvec, nn, proof_r, proof_x, proof_l, proof_n, status);
+}
+
+// ArithmeticCircuit::prove (circuit.rs:260-556) for n instances of a shared circuit.
+static int circuit_prove_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, const HostTranscripts* tx, size_t n,
+                              const uint8_t* v_commitments, const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l, const uint8_t* w_r,
+                              const uint8_t* w_o, const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
+    if (!c || !q || (!label && label_len) || !v_commitments || !v || !s_v || !w_l || !w_r || !rnd || !proofs) return BPPP_ERR_INVALID_ARG;
+    const CircuitDev& cd = q->cd;
+    if ((cd.no && !w_o) || cd.nm > c->ng || cd.nv + 9 > c->nh) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t NB = (size_t)c->nbases, NG = (size_t)c->ng, NH = (size_t)c->nh, k = (size_t)cd.k, nm = (size_t)cd.nm, nv = (size_t)cd.nv,
+                 no = (size_t)cd.no, nl = (size_t)cd.nl, n_rnd = 18 + nv + nm;
+    size_t rounds, nl_f, nn_f;
+    wnla_proof_shape(NH, NG, rounds, nl_f, nn_f);
+    const size_t proof_bytes = 64 * (4 + 2 * rounds) + 32 * (nl_f + nn_f);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes + 16); return o; };
+    const size_t o_vp = take(n * k * 64), o_v = take(n * k * nv * 32), o_sv = take(n * k * 32), o_wl = take(n * nm * 32), o_wr = take(n * nm * 32),
+                 o_wo = take(n * no * 32), o_rnd = take(n * n_rnd * 32), o_head = take(n * 256), o_st = take(n * 4), o_ts = take(52 * n * 4),
+                 o_r9 = take(4 * 9 * 8 * n * 4), o_lv = take(6 * nv * 8 * n * 4), o_nv = take(4 * nm * 8 * n * 4), o_lam = take(nl * 8 * n * 4),
+                 o_muv = take(nm * 8 * n * 4), o_coef = take((3 * nm + 3 * nv) * 8 * n * 4), o_misc = take(8 * 8 * n * 4),
+                 o_msc = take(3 * NB * 8 * n * 4), o_pb = take(3 * 30 * n * 4), o_wc = take(n * 64), o_wcv = take(n * NH * 32),
+                 o_rho = take(n * 32), o_mu = take(n * 32), o_wlv = take(n * NH * 32), o_wnv = take(n * NG * 32),
+                 // WNLA prover state
+                 o_pr = take(n * rounds * 64), o_px = take(n * rounds * 64), o_pl = take(n * nl_f * 32), o_pn = take(n * nn_f * 32),
+                 o_vl = take((NH + 1) * 8 * n * 4), o_vn = take((NG + 1) * 8 * n * 4), o_vc = take(NH * 8 * n * 4), o_ch = take(NH * 8 * n * 4),
+                 o_cg = take((NG + 1) * 8 * n * 4), o_prm = take(3 * 8 * n * 4), o_cm = take(16 * n * 4), o_proofs = take(n * proof_bytes);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(d + o_vp, v_commitments, n * k * 64, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_v, v, n * k * nv * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_sv, s_v, n * k * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_wl, w_l, n * nm * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_wr, w_r, n * nm * 32, hipMemcpyHostToDevice, s));
+    if (no) HIP_TRY(hipMemcpyAsync(d + o_wo, w_o, n * no * 32, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d + o_rnd, rnd, n * n_rnd * 32, hipMemcpyHostToDevice, s));
+    CircuitProveWs p;
+    std::memset(&p, 0, sizeof p);
+    p.N = n; p.cd = cd; p.NG = c->ng; p.NH = c->nh; p.n_rnd = (int)n_rnd; p.rnd_stride = n_rnd * 32; p.part = q->d_part;
+    p.v_pts = d + o_vp; p.v = d + o_v; p.s_v = d + o_sv; p.w_l = d + o_wl; p.w_r = d + o_wr; p.w_o = d + o_wo; p.rnd = d + o_rnd;
+    p.proof_head = d + o_head; p.status = (int32_t*)(d + o_st); p.tstate = (u32*)(d + o_ts);
+    u32* r9 = (u32*)(d + o_r9);
+    p.ro = r9; p.rl = r9 + 72 * n; p.rr = r9 + 144 * n; p.rs = r9 + 216 * n;
+    u32* lv = (u32*)(d + o_lv);
+    p.lo = lv; p.ll = lv + nv * 8 * n; p.lr = lv + 2 * nv * 8 * n; p.ls = lv + 3 * nv * 8 * n; p.v1 = lv + 4 * nv * 8 * n; p.cl0 = lv + 5 * nv * 8 * n;
+    u32* nvv = (u32*)(d + o_nv);
+    p.no = nvv; p.nl = nvv + nm * 8 * n; p.nr = nvv + 2 * nm * 8 * n; p.ns = nvv + 3 * nm * 8 * n;
+    p.lamv = (u32*)(d + o_lam); p.muv = (u32*)(d + o_muv); p.coef = (u32*)(d + o_coef); p.misc = (u32*)(d + o_misc);
+    p.msc = (u32*)(d + o_msc); p.pbuf = (u32*)(d + o_pb);
+    p.wn_commit = d + o_wc; p.wn_c = d + o_wcv; p.wn_rho = d + o_rho; p.wn_mu = d + o_mu; p.wn_l = d + o_wlv; p.wn_n = d + o_wnv;
+    p.fb.table = c->d_table; p.fb.W = c->fb_w; p.fb.N = n;
+    t_new(p.base, label, (u32)label_len);
+    TxDev txd;
+    int rc = txd.begin(tx, n, s, p.tio, p.divergent_positions);
+    if (rc != BPPP_OK) return rc;
+    WnlaProveWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.ng = c->ng; w.nh = c->nh; w.nl = (int)NH; w.nn = (int)NG; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
+    w.transcript_preloaded = 1;
+    w.base = p.base; w.tio = p.tio; w.divergent_positions = p.divergent_positions;
+    w.commitments = p.wn_commit; w.c = p.wn_c; w.rho = p.wn_rho; w.mu = p.wn_mu; w.l_in = p.wn_l; w.n_in = p.wn_n;
+    w.proof_r = d + o_pr; w.proof_x = d + o_px; w.proof_l = d + o_pl; w.proof_n = d + o_pn;
+    w.status = p.status; w.tstate = p.tstate; w.vl = (u32*)(d + o_vl); w.vn = (u32*)(d + o_vn); w.vc = (u32*)(d + o_vc);
+    w.ch = (u32*)(d + o_ch); w.cg = (u32*)(d + o_cg); w.prm = (u32*)(d + o_prm); w.com = (u32*)(d + o_cm); w.msc = p.msc; w.pbuf = p.pbuf;
+    w.fb = p.fb;
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    HIP_TRY(hipMemsetAsync(p.msc, 0, 3 * NB * 8 * n * 4, s));     // the sets are written sparsely (slot = base index)
+    k_cprove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    for (int set = 0; set < 3; set++) k_cprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(p, set, 0);
+    k_cprove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    k_cprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(p, 0, 0);
+    k_cprove_stage_c<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    k_cprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(p, 0, 1);
+    k_cprove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    k_wprove_init<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    for (int kk = 0; kk < (int)rounds; kk++) {
+        k_wprove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1);
+        k_wprove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
+        if (kk + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2);
+    }
+    k_wprove_finish<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    HIP_TRY(hipGetLastError());
+    // assemble the proofs on the host side of the copy: head | r | x | l | n per instance
+    std::vector<uint8_t> head(n * 256), pr(n * rounds * 64), px(n * rounds * 64), pl(n * nl_f * 32), pn(n * nn_f * 32);
+    std::vector<int32_t> st(n);
+    HIP_TRY(hipMemcpyAsync(head.data(), d + o_head, head.size(), hipMemcpyDeviceToHost, s));
+    if (rounds) {
+        HIP_TRY(hipMemcpyAsync(pr.data(), d + o_pr, pr.size(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(px.data(), d + o_px, px.size(), hipMemcpyDeviceToHost, s));
+    }
+    if (nl_f) HIP_TRY(hipMemcpyAsync(pl.data(), d + o_pl, pl.size(), hipMemcpyDeviceToHost, s));
+    if (nn_f) HIP_TRY(hipMemcpyAsync(pn.data(), d + o_pn, pn.size(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(st.data(), d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    rc = txd.finish(tx, p.tio, p.base, p.tstate, n, p.status, s);
+    if (rc != BPPP_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; i++) {
+        uint8_t* o = proofs + i * proof_bytes;
+        if (st[i] != 0) { std::memset(o, 0, proof_bytes); continue; }
+        std::memcpy(o, &head[i * 256], 256);
+        o += 256;
+        std::memcpy(o, &pr[i * rounds * 64], rounds * 64); o += rounds * 64;
+        std::memcpy(o, &px[i * rounds * 64], rounds * 64); o += rounds * 64;
+        std::memcpy(o, &pl[i * nl_f * 32], nl_f * 32); o += nl_f * 32;
+        std::memcpy(o, &pn[i * nn_f * 32], nn_f * 32);
+    }
+    if (status) std::memcpy(status, st.data(), n * 4);
+    (void)o_proofs;
+    return BPPP_OK;
+}
+int bppp_circuit_prove_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n, const uint8_t* v_commitments,
+                             const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l, const uint8_t* w_r, const uint8_t* w_o,
+                             const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
+    CtxLock lock_(c);
+    return circuit_prove_impl(c, q, label, label_len, nullptr, n, v_commitments, v, s_v, w_l, w_r, w_o, rnd, proofs, status);
+}
+int bppp_circuit_prove_batch_transcript(bppp_ctx* c, const bppp_circuit* q, size_t n, const uint8_t* states, size_t n_states,
+                                        const uint8_t* v_commitments, const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l, const uint8_t* w_r,
+                                        const uint8_t* w_o, const uint8_t* rnd, uint8_t* proofs, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
+    if (!states) return BPPP_ERR_INVALID_ARG;
+    HostTranscripts tx = {states, n_states, states_out};
+    return circuit_prove_impl(c, q, nullptr, 0, &tx, n, v_commitments, v, s_v, w_l, w_r, w_o, rnd, proofs, status);
+}
+
+// ReciprocalRangeProofProtocol::prove (reciprocal.rs:110-146) for runtime dim_nd / dim_np.
+static int recip_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, const HostTranscripts* tx, size_t n, size_t dim_nd, size_t dim_np,
+                            const uint8_t* commitments, const uint8_t* x, const uint8_t* sblind, const uint8_t* digits, const uint8_t* m,
+                            const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
+    if (!c || (!label && label_len) || !commitments || !x || !sblind || !digits || !m || !rnd || !proofs) return BPPP_ERR_INVALID_ARG;
+    if (dim_nd == 0 || dim_np == 0 || dim_nd > (size_t)c->ng || dim_nd + 10 > (size_t)c->nh || dim_np > dim_nd + 1 || dim_nd > 4096)
+        return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    RecipPattern P;
+    recip_pattern_build(P, dim_nd, dim_np);
+    const size_t NB = (size_t)c->nbases, NG = (size_t)c->ng, NH = (size_t)c->nh, nd = dim_nd, np = dim_np, nm = nd, nv = nd + 1, nl = nv,
+                 n_rnd = 20 + 2 * nd;
+    size_t rounds, nl_f, nn_f;
+    wnla_proof_shape(NH, NG, rounds, nl_f, nn_f);
+    const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl_f + nn_f);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align16(off + bytes + 16); return o; };
+    const CircuitHostData& hd = P.hd;
+    // circuit pattern
+    const size_t o_cpl = take(hd.cpl.size() * 4), o_rl = take(hd.rl.size() * 4), o_vl = take(hd.vl.size() * 4), o_cpm = take(hd.cpm.size() * 4),
+                 o_rm = take(hd.rm.size() * 4), o_vm = take(hd.vm.size() * 4), o_cmp = take(hd.colmap.size() * 4), o_al = take(hd.al.size() * 4),
+                 o_am = take(hd.am.size() * 4), o_il = take(P.inst_l.size() * 4), o_im = take(P.inst_m.size() * 4), o_part = take(P.parts.size() * 4);
+    // inputs
+    const size_t o_com = take(n * 64), o_x = take(n * 32), o_s = take(n * 32), o_dig = take(n * nd * 32), o_m = take(n * np * 32),
+                 o_rnd = take(n * n_rnd * 32);
+    // reciprocal stage
+    const size_t o_st = take(n * 4), o_ts = take(52 * n * 4), o_inst = take((1 + np) * 8 * n * 4), o_scr = take((nd + np) * 8 * n * 4),
+                 o_cpv = take(n * nv * 32), o_cpsv = take(n * 32), o_cpwr = take(n * nm * 32), o_cpvp = take(n * 64), o_prr = take(n * 64);
+    // circuit prover
+    const size_t o_head = take(n * 256), o_r9 = take(4 * 9 * 8 * n * 4), o_lv = take(6 * nv * 8 * n * 4), o_nv = take(4 * nm * 8 * n * 4),
+                 o_lam = take(nl * 8 * n * 4), o_muv = take(nm * 8 * n * 4), o_coef = take((3 * nm + 3 * nv) * 8 * n * 4), o_misc = take(8 * 8 * n * 4),
+                 o_msc = take(3 * NB * 8 * n * 4), o_pb = take(3 * 30 * n * 4), o_wc = take(n * 64), o_wcv = take(n * NH * 32),
+                 o_rho = take(n * 32), o_mu = take(n * 32), o_wlv = take(n * NH * 32), o_wnv = take(n * NG * 32);
+    // WNLA prover
+    const size_t o_pr = take(n * rounds * 64), o_px = take(n * rounds * 64), o_pl = take(n * nl_f * 32), o_pn = take(n * nn_f * 32),
+                 o_vl2 = take((NH + 1) * 8 * n * 4), o_vn2 = take((NG + 1) * 8 * n * 4), o_vc = take(NH * 8 * n * 4), o_ch = take(NH * 8 * n * 4),
+                 o_cg = take((NG + 1) * 8 * n * 4), o_prm = take(3 * 8 * n * 4), o_cm = take(16 * n * 4);
+    WnlaBlob blob;
+    HIP_TRY(hipMalloc(&blob.d, off));
+    uint8_t* d = blob.d;
+    hipStream_t s = c->stream;
+    auto up = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(d + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess; };
+    HIP_TRY(up(o_cpl, hd.cpl.data(), hd.cpl.size() * 4)); HIP_TRY(up(o_rl, hd.rl.data(), hd.rl.size() * 4)); HIP_TRY(up(o_vl, hd.vl.data(), hd.vl.size() * 4));
+    HIP_TRY(up(o_cpm, hd.cpm.data(), hd.cpm.size() * 4)); HIP_TRY(up(o_rm, hd.rm.data(), hd.rm.size() * 4)); HIP_TRY(up(o_vm, hd.vm.data(), hd.vm.size() * 4));
+    HIP_TRY(up(o_cmp, hd.colmap.data(), hd.colmap.size() * 4)); HIP_TRY(up(o_al, hd.al.data(), hd.al.size() * 4)); HIP_TRY(up(o_am, hd.am.data(), hd.am.size() * 4));
+    HIP_TRY(up(o_il, P.inst_l.data(), P.inst_l.size() * 4)); HIP_TRY(up(o_im, P.inst_m.data(), P.inst_m.size() * 4));
+    HIP_TRY(up(o_part, P.parts.data(), P.parts.size() * 4));
+    HIP_TRY(up(o_com, commitments, n * 64)); HIP_TRY(up(o_x, x, n * 32)); HIP_TRY(up(o_s, sblind, n * 32));
+    HIP_TRY(up(o_dig, digits, n * nd * 32)); HIP_TRY(up(o_m, m, n * np * 32)); HIP_TRY(up(o_rnd, rnd, n * n_rnd * 32));
+    HIP_TRY(hipStreamSynchronize(s));                      // the pattern vectors live on this stack frame
+    RecipProveWs r;
+    std::memset(&r, 0, sizeof r);
+    r.N = n; r.nd = (int)nd; r.np = (int)np; r.NG = c->ng; r.NH = c->nh; r.n_rnd = (int)n_rnd;
+    r.commitments = d + o_com; r.x = d + o_x; r.s = d + o_s; r.digits = d + o_dig; r.m = d + o_m; r.rnd = d + o_rnd;
+    r.status = (int32_t*)(d + o_st); r.tstate = (u32*)(d + o_ts); r.inst_vals = (u32*)(d + o_inst); r.scr = (u32*)(d + o_scr);
+    r.msc = (u32*)(d + o_msc); r.pbuf = (u32*)(d + o_pb);
+    r.cp_v = d + o_cpv; r.cp_sv = d + o_cpsv; r.cp_wr = d + o_cpwr; r.cp_vpts = d + o_cpvp; r.proof_r = d + o_prr;
+    r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
+    t_new(r.base, label, (u32)label_len);
+    TxDev txd;
+    int rc = txd.begin(tx, n, s, r.tio, r.divergent_positions);
+    if (rc != BPPP_OK) return rc;
+    CircuitProveWs p;
+    std::memset(&p, 0, sizeof p);
+    p.base = r.base; p.tio = r.tio; p.divergent_positions = r.divergent_positions;
+    CircuitDev& cd = p.cd;
+    cd.nm = (int)nm; cd.no = (int)np; cd.k = 1; cd.nl = (int)nl; cd.nv = (int)nv; cd.nw = (int)P.dims[5]; cd.f_l = 1; cd.f_m = 0;
+    cd.colptr_l = (const int*)(d + o_cpl); cd.rows_l = (const int*)(d + o_rl); cd.vals_l = (const u32*)(d + o_vl);
+    cd.colptr_m = (const int*)(d + o_cpm); cd.rows_m = (const int*)(d + o_rm); cd.vals_m = (const u32*)(d + o_vm);
+    cd.colmap = (const int*)(d + o_cmp); cd.a_l = (const u32*)(d + o_al); cd.a_m = (const u32*)(d + o_am);
+    cd.inst_l = (const int*)(d + o_il); cd.inst_m = (const int*)(d + o_im); cd.inst_vals = r.inst_vals;
+    p.N = n; p.NG = c->ng; p.NH = c->nh; p.n_rnd = (int)(18 + nv + nm); p.rnd_stride = n_rnd * 32; p.part = (const int*)(d + o_part);
+    p.transcript_preloaded = 1;
+    p.v_pts = r.cp_vpts; p.v = r.cp_v; p.s_v = r.cp_sv; p.w_l = r.digits; p.w_r = r.cp_wr; p.w_o = r.m; p.rnd = r.rnd + 32;
+    p.proof_head = d + o_head; p.status = r.status; p.tstate = r.tstate;
+    u32* r9 = (u32*)(d + o_r9);
+    p.ro = r9; p.rl = r9 + 72 * n; p.rr = r9 + 144 * n; p.rs = r9 + 216 * n;
+    u32* lv = (u32*)(d + o_lv);
+    p.lo = lv; p.ll = lv + nv * 8 * n; p.lr = lv + 2 * nv * 8 * n; p.ls = lv + 3 * nv * 8 * n; p.v1 = lv + 4 * nv * 8 * n; p.cl0 = lv + 5 * nv * 8 * n;
+    u32* nvv = (u32*)(d + o_nv);
+    p.no = nvv; p.nl = nvv + nm * 8 * n; p.nr = nvv + 2 * nm * 8 * n; p.ns = nvv + 3 * nm * 8 * n;
+    p.lamv = (u32*)(d + o_lam); p.muv = (u32*)(d + o_muv); p.coef = (u32*)(d + o_coef); p.misc = (u32*)(d + o_misc);
+    p.msc = r.msc; p.pbuf = r.pbuf;
+    p.wn_commit = d + o_wc; p.wn_c = d + o_wcv; p.wn_rho = d + o_rho; p.wn_mu = d + o_mu; p.wn_l = d + o_wlv; p.wn_n = d + o_wnv;
+    p.fb = r.fb;
+    WnlaProveWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n; w.ng = c->ng; w.nh = c->nh; w.nl = (int)NH; w.nn = (int)NG; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
+    w.transcript_preloaded = 1;
+    w.base = r.base; w.tio = r.tio; w.divergent_positions = r.divergent_positions;
+    w.commitments = p.wn_commit; w.c = p.wn_c; w.rho = p.wn_rho; w.mu = p.wn_mu; w.l_in = p.wn_l; w.n_in = p.wn_n;
+    w.proof_r = d + o_pr; w.proof_x = d + o_px; w.proof_l = d + o_pl; w.proof_n = d + o_pn;
+    w.status = r.status; w.tstate = r.tstate; w.vl = (u32*)(d + o_vl2); w.vn = (u32*)(d + o_vn2); w.vc = (u32*)(d + o_vc);
+    w.ch = (u32*)(d + o_ch); w.cg = (u32*)(d + o_cg); w.prm = (u32*)(d + o_prm); w.com = (u32*)(d + o_cm); w.msc = p.msc; w.pbuf = p.pbuf;
+    w.fb = p.fb;
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    HIP_TRY(hipMemsetAsync(p.msc, 0, 3 * NB * 8 * n * 4, s));
+    k_rprove_stage_r1<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    k_rprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r);
+    k_rprove_stage_r2<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    HIP_TRY(hipMemsetAsync(p.msc, 0, 3 * NB * 8 * n * 4, s));
+    k_cprove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    for (int set = 0; set < 3; set++) k_cprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(p, set, 0);
+    k_cprove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    k_cprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(p, 0, 0);
+    k_cprove_stage_c<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    k_cprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(p, 0, 1);
+    k_cprove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(p);
+    k_wprove_init<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    for (int kk = 0; kk < (int)rounds; kk++) {
+        k_wprove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1);
+        k_wprove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
+        if (kk + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2);
+    }
+    k_wprove_finish<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint8_t> head(n * 256), prr(n * 64), pr(n * rounds * 64 + 1), px(n * rounds * 64 + 1), pl(n * nl_f * 32 + 1), pn(n * nn_f * 32 + 1);
+    std::vector<int32_t> st(n);
+    HIP_TRY(hipMemcpyAsync(head.data(), d + o_head, n * 256, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(prr.data(), d + o_prr, n * 64, hipMemcpyDeviceToHost, s));
+    if (rounds) {
+        HIP_TRY(hipMemcpyAsync(pr.data(), d + o_pr, n * rounds * 64, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(px.data(), d + o_px, n * rounds * 64, hipMemcpyDeviceToHost, s));
+    }
+    if (nl_f) HIP_TRY(hipMemcpyAsync(pl.data(), d + o_pl, n * nl_f * 32, hipMemcpyDeviceToHost, s));
+    if (nn_f) HIP_TRY(hipMemcpyAsync(pn.data(), d + o_pn, n * nn_f * 32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(st.data(), d + o_st, n * 4, hipMemcpyDeviceToHost, s));
+    rc = txd.finish(tx, r.tio, r.base, r.tstate, n, r.status, s);
+    if (rc != BPPP_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; i++) {
+        uint8_t* o = proofs + i * proof_bytes;
+        if (st[i] != 0) { std::memset(o, 0, proof_bytes); continue; }
+        std::memcpy(o, &head[i * 256], 256); o += 256;
+        std::memcpy(o, &pr[i * rounds * 64], rounds * 64); o += rounds * 64;
+        std::memcpy(o, &px[i * rounds * 64], rounds * 64); o += rounds * 64;
+        std::memcpy(o, &prr[i * 64], 64); o += 64;
+        std::memcpy(o, &pl[i * nl_f * 32], nl_f * 32); o += nl_f * 32;
+        std::memcpy(o, &pn[i * nn_f * 32], nn_f * 32);
+    }
+    if (status) std::memcpy(status, st.data(), n * 4);
+    return BPPP_OK;
+}
+int bppp_reciprocal_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                                const uint8_t* commitments, const uint8_t* x, const uint8_t* sblind, const uint8_t* digits, const uint8_t* m,
+                                const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
+    CtxLock lock_(c);
+    return recip_prove_impl(c, label, label_len, nullptr, n, dim_nd, dim_np, commitments, x, sblind, digits, m, rnd, proofs, status);
+}
+int bppp_reciprocal_prove_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, size_t dim_nd, size_t dim_np,
+                                           const uint8_t* commitments, const uint8_t* x, const uint8_t* sblind, const uint8_t* digits,
+                                           const uint8_t* m, const uint8_t* rnd, uint8_t* proofs, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
+    if (!states) return BPPP_ERR_INVALID_ARG;
+    HostTranscripts tx = {states, n_states, states_out};
+    return recip_prove_impl(c, nullptr, 0, &tx, n, dim_nd, dim_np, commitments, x, sblind, digits, m, rnd, proofs, status);
+}
+
+
+}  // extern "C"

@@ -1,0 +1,523 @@
+// libbppp_hip.so, host side: launch sequences of the u64 range-proof verifier (exact and RLC modes), commit_value and the batch prover.
+// One lane per proof; 64-thread workgroups (one wavefront) so that a 2^16-proof batch yields 1024 workgroups (4 per CU) and no
+// lane ever waits on a workgroup barrier.  The per-lane work is in verify_core.h / prove_core.h.
+#include "host.h"
+
+extern "C" {
+
+static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
+                              const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count,
+                              const uint8_t* rlc_seed, const VerifyTranscripts* tx, bool reset_reject_count);
+// One call = one batch for the caller; internally a batch larger than max_batch proofs runs as consecutive parts on the same
+// stream, so the per-proof workspace (~30 KB per proof) is bounded by max_batch whatever n is.  Proofs are independent, the reject
+// counter accumulates across parts, and every per-proof array is simply offset.
+int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments, const void* d_proofs,
+                       void* d_accept, void* d_status, void* d_trace, void* d_reject_count, const uint8_t* rlc_seed,
+                       const VerifyTranscripts* tx) {
+    if (!c) return BPPP_ERR_INVALID_ARG;
+    const size_t cap = c->max_batch;
+    if (n <= cap || !d_commitments || !d_proofs || !d_accept)
+        return verify_device_part(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, d_trace, d_reject_count, rlc_seed, tx, true);
+    if (tx && tx->d_states && tx->n_states != 1 && tx->n_states != n) return BPPP_ERR_INVALID_ARG;
+    const size_t SB = BPPP_TRANSCRIPT_STATE_BYTES;
+    for (size_t lo = 0; lo < n; lo += cap) {
+        const size_t m = n - lo < cap ? n - lo : cap;
+        VerifyTranscripts part;
+        if (tx) {
+            part.d_states = tx->d_states && tx->n_states != 1 ? (const uint8_t*)tx->d_states + lo * SB : tx->d_states;
+            part.n_states = tx->n_states == 1 ? 1 : m;
+            part.d_states_out = tx->d_states_out ? (uint8_t*)tx->d_states_out + lo * SB : nullptr;
+        }
+        int rc = verify_device_part(c, label, label_len, m, (const uint8_t*)d_commitments + lo * 64,
+                                    (const uint8_t*)d_proofs + lo * (size_t)BPPP_U64_PROOF_BYTES, (uint8_t*)d_accept + lo,
+                                    d_status ? (int32_t*)d_status + lo : nullptr, d_trace ? (uint8_t*)d_trace + lo * (size_t)BPPP_U64_TRACE_BYTES : nullptr,
+                                    d_reject_count, rlc_seed, tx ? &part : nullptr, lo == 0);
+        if (rc != BPPP_OK) return rc;
+    }
+    return BPPP_OK;
+}
+static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
+                              const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count,
+                              const uint8_t* rlc_seed, const VerifyTranscripts* tx, bool reset_reject_count) {
+    if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept) return BPPP_ERR_INVALID_ARG;
+    if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;   // u64 entry points need the u64 generator shape
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    rc = ensure_vtab_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    VerifyWs ws;
+    std::memset(&ws, 0, sizeof ws);
+    carve(c, ws, n);
+    ws.atab = c->d_atab;
+    ws.tscr = c->d_tscr;
+    RlcWs rl;
+    std::memset(&rl, 0, sizeof rl);
+    if (rlc_seed) {
+        rc = ensure_rlc_capacity(c, n);
+        if (rc != BPPP_OK) return rc;
+        rc = ensure_straus_capacity(c, n);   // k_rlc_lhs keeps the window table of C4 there
+        if (rc != BPPP_OK) return rc;
+        ws.straus = c->d_straus;
+        for (int i = 0; i < 4; i++) {
+            u64 v = 0;
+            for (int k = 0; k < 8; k++) v |= (u64)rlc_seed[8 * i + k] << (8 * k);
+            rl.seed[i] = v;
+        }
+        rl.lhs = c->d_rlc;
+        rl.sc = c->d_rlc + 30 * n;
+        rl.flag = (uint8_t*)(c->d_rlc + (30 + (size_t)BPPP_NG * 8) * n);
+        rl.list = c->d_rlc + (30 + (size_t)BPPP_NG * 8) * c->rcap + c->rcap / 4;
+        rl.count = (int*)(rl.list + c->rcap / BPPP_RLC_CHUNK + 1);
+    }
+    ws.commitments = (const uint8_t*)d_commitments;
+    ws.proofs = (const uint8_t*)d_proofs;
+    ws.accept = (uint8_t*)d_accept;
+    ws.trace = (uint8_t*)d_trace;
+    // per-proof status lives in caller memory when given, else in a spare corner of the staging buffer
+    if (d_status) ws.status = (int32_t*)d_status;
+    else {
+        rc = ensure_stage(c, c->cap * sizeof(int32_t));
+        if (rc != BPPP_OK) return rc;
+        ws.status = (int32_t*)c->d_stage;
+    }
+    t_new(ws.base, label, (u32)label_len);   // Transcript::new(label), shared by every proof of the batch
+    if (tx) {
+        if (tx->d_states && tx->n_states != 1 && tx->n_states != n) return BPPP_ERR_INVALID_ARG;
+        ws.states = (const uint8_t*)tx->d_states;
+        ws.n_states = tx->n_states;
+        ws.states_out = (uint8_t*)tx->d_states_out;
+    }
+    if (d_reject_count && reset_reject_count) HIP_TRY(hipMemsetAsync(d_reject_count, 0, sizeof(int), c->stream));
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    hipStream_t s = c->stream;
+#define LAUNCH_ON(st, id, ...)                                  \
+    do {                                                        \
+        rc = timed(c, id, st, [&]() { __VA_ARGS__; });          \
+        if (rc != BPPP_OK) return rc;                           \
+    } while (0)
+#define LAUNCH(id, ...) LAUNCH_ON(s, id, __VA_ARGS__)
+    // a grid that does not even fill one wavefront per SIMD gains nothing from the 256-VGPR cap: use the uncapped builds
+    const bool small = !c->no_small && blocks <= (unsigned)c->n_simds;
+    if (small) LAUNCH(K_PHASE1, k_verify_phase1_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    else LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    // C0 = variable-base half (window tables of the proof points, then the shared-doubling sum: one lane per proof, 1 wave
+    // per SIMD) + fixed-base half (8 lanes per proof): independent, so they run concurrently on two streams and share the
+    // SIMDs; round 1 adds the halves.
+    hipStream_t a = c->serial_c0 ? s : c->aux_stream;   // diagnostic: un-overlapped kernel times
+    LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    HIP_TRY(hipEventRecord(c->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
+    // the two fixed-base sums: 8 lanes per proof, or one from the size at which one lane per proof fills the SIMDs twice over
+    const bool fb_one_lane = c->fb_one_lane_mode >= 0 ? c->fb_one_lane_mode == 1 : n >= (size_t)128 * (size_t)c->n_simds;
+    const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    if (fb_one_lane) LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
+    else LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
+    HIP_TRY(hipEventRecord(c->ev_join, a));
+    // a batch whose four-lanes-per-proof grid still leaves the SIMDs under-filled runs its variable-base sums on lane groups
+    const bool grouped = !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds;
+    const unsigned g4_blocks = (unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    if (grouped) LAUNCH(K_C0_VAR, k_verify_c0_var_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws));
+    else if (small) LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    else LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+    for (int k = 1; k <= 4; k++) {
+        if (grouped) LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+        else if (c->force_pairs || (!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds))
+            LAUNCH(K_ROUND, k_verify_round_g2<<<(unsigned)((2 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
+        else if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+        else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+    }
+    LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    if (!rlc_seed) {
+        if (fb_one_lane) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+        else LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+        LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
+    } else {
+        // combined check per chunk of 8 proofs; chunks that fail it (or hold a flagged proof) fall through to the exact kernels
+        const size_t nchunks = (n + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+        const unsigned chunk_blocks = (unsigned)((nchunks * BPPP_RLC_CHUNK + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+        HIP_TRY(hipMemsetAsync(d_accept, 0, n, s));
+        HIP_TRY(hipMemsetAsync(rl.count, 0, sizeof(int), s));
+        if (c->rlc_super_m) {
+            // bucket stage first: superchunks of rlc_super_m proofs, one combined check each; the chunk-of-8 kernels below only see
+            // the proofs of superchunks that failed it
+            const size_t SM = c->rlc_super_m, nsuper = (n + SM - 1) / SM;
+            rc = ensure_bucket_capacity(c, n);
+            if (rc != BPPP_OK) return rc;
+            BucketWs bw;
+            std::memset(&bw, 0, sizeof bw);
+            bw.N = n; bw.M = (u32)SM;
+            for (int i = 0; i < 4; i++) bw.seed[i] = rl.seed[i];
+            bw.status = ws.status; bw.acc = ws.acc; bw.fsc = ws.fsc; bw.accept = ws.accept;
+            uint8_t* p = c->d_bkt;
+            const size_t capn = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+            bw.wab = (u64*)p; p += align16(capn * 16);
+            bw.c4 = (c4_packed*)p; p += align16(capn * sizeof(c4_packed));
+            bw.lhs = (u32*)p; p += align16(nsuper * 30 * 4);
+            bw.asc = (u32*)p; p += align16(nsuper * (size_t)BPPP_NG * 32);
+            bw.sflag = p;
+            bw.fb.table = c->d_table; bw.fb.W = c->fb_w; bw.fb.N = nsuper;
+            const size_t lds_bytes = ((size_t)4 * (512 + SM) + 8 * 30) * sizeof(u32);
+            (void)hipFuncSetAttribute((const void*)k_bkt_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            LAUNCH(K_BKT_PREPARE, k_bkt_prepare<<<blocks, BPPP_BLOCK, 0, s>>>(bw));
+            LAUNCH(K_BKT_ACCUMULATE, k_bkt_accumulate<<<(unsigned)nsuper, 256, lds_bytes, s>>>(bw));
+            LAUNCH(K_BKT_SCALARS, k_bkt_scalars<<<(unsigned)nsuper, 256, 0, s>>>(bw));
+            LAUNCH(K_BKT_CHECK, k_bkt_check<<<(unsigned)nsuper, 64, 0, s>>>(bw));
+            rl.sflag = bw.sflag;
+            rl.super_m = (u32)SM;
+        }
+        LAUNCH(K_RLC_LHS, k_rlc_lhs<<<blocks, BPPP_BLOCK, 0, s>>>(ws, rl));
+        LAUNCH(K_RLC_CHUNK, k_rlc_chunk<<<chunk_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
+        LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged<<<1024, 64, 0, s>>>(ws, rl));
+        LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged_dense<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
+        LAUNCH(K_ACCEPT, k_verify_accept_flagged<<<blocks, BPPP_BLOCK, 0, s>>>(ws, rl, (int*)d_reject_count));
+        if (c->rlc_debug) {   // diagnostic: how many chunks went to the exact kernels
+            std::vector<uint8_t> hf(nchunks);
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipMemcpy(hf.data(), rl.flag, nchunks, hipMemcpyDeviceToHost));
+            size_t cnt = 0;
+            for (uint8_t f : hf) cnt += f ? 1 : 0;
+            std::fprintf(stderr, "bppp rlc: %zu of %zu chunks re-checked exactly\n", cnt, nchunks);
+        }
+    }
+    if (ws.states_out) k_verify_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
+#undef LAUNCH
+#undef LAUNCH_ON
+    HIP_TRY(hipGetLastError());
+    return BPPP_OK;
+}
+int bppp_u64_verify_batch_transcript_device(bppp_ctx* c, size_t n, const void* d_states, size_t n_states, const void* d_commitments,
+                                            const void* d_proofs, void* d_accept, void* d_status, void* d_reject_count, void* d_states_out) {
+    CtxLock lock_(c);
+    if (!d_states) return BPPP_ERR_INVALID_ARG;
+    VerifyTranscripts tx = {d_states, n_states, d_states_out};
+    return verify_device_impl(c, nullptr, 0, n, d_commitments, d_proofs, d_accept, d_status, nullptr, d_reject_count, nullptr, &tx);
+}
+int bppp_u64_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, const uint8_t* commitments,
+                                     const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
+    if (!c || !states || !commitments || !proofs || !accept || (n_states != 1 && n_states != n)) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    for (size_t i = 0; i < n_states; i++)
+        if (states[203 * i + 200] >= BPPP_STROBE_R || states[203 * i + 201] > BPPP_STROBE_R) return BPPP_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    uint8_t* d = nullptr;
+    const size_t SB = BPPP_TRANSCRIPT_STATE_BYTES;
+    const size_t o_c = 0, o_p = align16(o_c + n * 64), o_a = align16(o_p + n * (size_t)BPPP_U64_PROOF_BYTES), o_s = align16(o_a + n),
+                 o_ti = align16(o_s + n * sizeof(int32_t)), o_to = align16(o_ti + n_states * SB), total = align16(o_to + n * SB);
+    HIP_TRY(hipMalloc(&d, total));
+    int rc = BPPP_OK;
+    hipStream_t st = c->stream;
+    hipError_t e = hipMemcpyAsync(d + o_c, commitments, n * 64, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_p, proofs, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_ti, states, n_states * SB, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        rc = bppp_u64_verify_batch_transcript_device(c, n, d + o_ti, n_states, d + o_c, d + o_p, d + o_a, d + o_s, nullptr,
+                                                     states_out ? d + o_to : nullptr);
+        if (rc == BPPP_OK) {
+            e = hipMemcpyAsync(accept, d + o_a, n, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && status) e = hipMemcpyAsync(status, d + o_s, n * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && states_out) e = hipMemcpyAsync(states_out, d + o_to, n * SB, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) { g_last_error = std::string("verify_batch_transcript: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
+    return rc;
+}
+int bppp_u64_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
+                                 const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count) {
+    CtxLock lock_(c);
+    return verify_device_impl(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, d_trace, d_reject_count, nullptr, nullptr);
+}
+int bppp_u64_verify_batch_rlc_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
+                                     const void* d_proofs, void* d_accept, void* d_status, void* d_reject_count, const uint8_t seed[32]) {
+    CtxLock lock_(c);
+    if (!seed) return BPPP_ERR_INVALID_ARG;
+    return verify_device_impl(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, nullptr, d_reject_count, seed, nullptr);
+}
+
+static int verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                            const uint8_t* proofs, uint8_t* accept, int32_t* status, const uint8_t* rlc_seed) {
+    if (!c || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    // persistent I/O staging of the host-buffer entry points (grow-only; separate from d_stage, which the device call may use)
+    const size_t o_c = 0, o_p = align16(o_c + n * 64), o_a = align16(o_p + n * (size_t)BPPP_U64_PROOF_BYTES), o_s = align16(o_a + n),
+                 need = align16(o_s + n * sizeof(int32_t));
+    if (need > c->io_bytes) {
+        if (c->d_io) { (void)hipFree(c->d_io); c->d_io = nullptr; c->io_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->d_io, need));
+        c->io_bytes = need;
+    }
+    uint8_t *d_c = c->d_io + o_c, *d_p = c->d_io + o_p, *d_a = c->d_io + o_a;
+    int32_t* d_s = (int32_t*)(c->d_io + o_s);
+    const size_t CH = c->host_chunk;
+    if (CH == 0 || n <= CH + CH / 2) {
+        HIP_TRY(hipMemcpyAsync(d_c, commitments, n * 64, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_p, proofs, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, c->stream));
+        int rc = verify_device_impl(c, label, label_len, n, d_c, d_p, d_a, d_s, nullptr, nullptr, rlc_seed, nullptr);
+        if (rc != BPPP_OK) return rc;
+    } else {
+        // Large batch: proofs are independent, so the batch is verified chunk by chunk while the next chunk crosses PCIe on a second
+        // stream (from pageable memory the runtime stages the copy and this thread blocks in it; the GPU keeps verifying meanwhile).
+        // A chunk is one full grid of the lane kernels, so the kernels run exactly as they do for a resident batch.
+        if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        if (!c->ev_copy) HIP_TRY(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
+        // the staging buffer may still be read by kernels of an earlier call on c->stream only if that call returned early on an
+        // error; order the first upload after whatever is queued there
+        HIP_TRY(hipEventRecord(c->ev_copy, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
+        for (size_t lo = 0; lo < n; lo += CH) {
+            size_t m = n - lo;
+            if (m > CH + CH / 2) m = CH;          // the tail joins the last chunk rather than running as a sliver
+            HIP_TRY(hipMemcpyAsync(d_c + lo * 64, commitments + lo * 64, m * 64, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(hipMemcpyAsync(d_p + lo * (size_t)BPPP_U64_PROOF_BYTES, proofs + lo * (size_t)BPPP_U64_PROOF_BYTES,
+                                   m * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(hipEventRecord(c->ev_copy, c->copy_stream));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_copy, 0));
+            int rc = verify_device_impl(c, label, label_len, m, d_c + lo * 64, d_p + lo * (size_t)BPPP_U64_PROOF_BYTES, d_a + lo, d_s + lo,
+                                        nullptr, nullptr, rlc_seed, nullptr);
+            if (rc != BPPP_OK) return rc;
+            if (m != CH) break;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(accept, d_a, n, hipMemcpyDeviceToHost, c->stream));
+    if (status) HIP_TRY(hipMemcpyAsync(status, d_s, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BPPP_OK;
+}
+int bppp_u64_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                          const uint8_t* proofs, uint8_t* accept, int32_t* status) {
+    CtxLock lock_(c);
+    return verify_host_impl(c, label, label_len, n, commitments, proofs, accept, status, nullptr);
+}
+int bppp_u64_verify_batch_rlc(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                              const uint8_t* proofs, uint8_t* accept, int32_t* status, const uint8_t seed[32]) {
+    CtxLock lock_(c);
+    if (!seed) return BPPP_ERR_INVALID_ARG;
+    return verify_host_impl(c, label, label_len, n, commitments, proofs, accept, status, seed);
+}
+
+int bppp_u64_commit_value_batch(bppp_ctx* c, size_t n, const uint64_t* x, const uint8_t* s, uint8_t* out) {
+    CtxLock lock_(c);
+    if (!c || !x || !s || !out) return BPPP_ERR_INVALID_ARG;
+    if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    size_t need = n * 8 + n * 32 + n * 64;
+    rc = ensure_stage(c, need);
+    if (rc != BPPP_OK) return rc;
+    uint64_t* d_x = (uint64_t*)c->d_stage;
+    uint8_t* d_s = c->d_stage + n * 8;
+    uint8_t* d_o = d_s + n * 32;
+    VerifyWs ws;
+    std::memset(&ws, 0, sizeof ws);
+    carve(c, ws, n);
+    HIP_TRY(hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
+    HIP_TRY(hipMemcpyAsync(d_x, x, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_s, s, n * 32, hipMemcpyHostToDevice, c->stream));
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    k_commit_value<<<blocks, BPPP_BLOCK, 0, c->stream>>>(ws, d_x, d_s, d_o, c->d_flags);
+    HIP_TRY(hipGetLastError());
+    int flags = 0;
+    HIP_TRY(hipMemcpyAsync(out, d_o, n * 64, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return flags ? BPPP_ERR_INVALID_ARG : BPPP_OK;
+}
+
+static int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
+                             const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status, const VerifyTranscripts* tx);
+int bppp_u64_prove_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
+                                const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status) {
+    CtxLock lock_(c);
+    return prove_device_impl(c, label, label_len, n, d_x, d_s, d_rnd, d_proofs, d_commitments, d_status, nullptr);
+}
+int bppp_u64_prove_batch_transcript_device(bppp_ctx* c, size_t n, const void* d_states, size_t n_states, const void* d_x, const void* d_s,
+                                           const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status, void* d_states_out) {
+    CtxLock lock_(c);
+    if (!d_states || (n_states != 1 && n_states != n)) return BPPP_ERR_INVALID_ARG;
+    VerifyTranscripts tx = {d_states, n_states, d_states_out};
+    return prove_device_impl(c, nullptr, 0, n, d_x, d_s, d_rnd, d_proofs, d_commitments, d_status, &tx);
+}
+static int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
+                             const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status, const VerifyTranscripts* tx) {
+    if (!c || (!label && label_len) || !d_x || !d_s || !d_rnd || !d_proofs || !d_commitments) return BPPP_ERR_INVALID_ARG;
+    if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_prove_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    ProveWs w;
+    std::memset(&w, 0, sizeof w);
+    w.N = n;
+    w.x = (const uint64_t*)d_x; w.s = (const uint8_t*)d_s; w.rnd = (const uint8_t*)d_rnd;
+    w.proofs = (uint8_t*)d_proofs; w.commitments = (uint8_t*)d_commitments;
+    if (d_status) w.status = (int32_t*)d_status;
+    else {
+        rc = ensure_stage(c, c->cap * sizeof(int32_t));
+        if (rc != BPPP_OK) return rc;
+        w.status = (int32_t*)c->d_stage;
+    }
+    u32* p = c->d_pws;
+    w.tstate = p; p += 52 * n;
+    w.sv = p; p += (size_t)SV_COUNT * 8 * n;
+    w.msc = p; p += (size_t)BPPP_MSC_SETS * BPPP_NG * 8 * n;
+    w.pbuf = p;
+    w.straus = c->d_straus;
+    w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    t_new(w.base, label, (u32)label_len);
+    if (tx) { w.states = (const uint8_t*)tx->d_states; w.n_states = tx->n_states; w.states_out = (uint8_t*)tx->d_states_out; }
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    hipStream_t s = c->stream;
+#define PLAUNCH(id, ...)                                       \
+    do {                                                       \
+        rc = timed(c, id, s, [&]() { __VA_ARGS__; });          \
+        if (rc != BPPP_OK) return rc;                          \
+    } while (0)
+#define PMSM(job) PLAUNCH(K_PROVE_MSM, k_prove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job))
+    PLAUNCH(K_PROVE_STAGES, k_prove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    PMSM(job_v());
+    PLAUNCH(K_PROVE_STAGES, k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    PMSM(job_rcom()); PMSM(job_co()); PMSM(job_cl()); PMSM(job_cr());
+    PLAUNCH(K_PROVE_STAGES, k_prove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    PMSM(job_cs());
+    PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    PMSM(job_c0());
+    for (int k = 1; k <= 4; k++) {
+        PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        PMSM(job_x()); PMSM(job_r());
+        if (!c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
+            PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
+        else
+            PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+    }
+    if (w.states_out) k_prove_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+#undef PMSM
+#undef PLAUNCH
+    HIP_TRY(hipGetLastError());
+    return BPPP_OK;
+}
+// U64RangeProofProtocol::prove with the caller's transcripts (u64_proof.rs:57: `t: &mut Transcript`), host buffers
+int bppp_u64_prove_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, const uint64_t* x, const uint8_t* s,
+                                    const uint8_t* rnd, uint8_t* proofs, uint8_t* commitments, int32_t* status, uint8_t* states_out) {
+    CtxLock lock_(c);
+    if (!c || !states || !x || !s || !rnd || !proofs || !commitments || (n_states != 1 && n_states != n)) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    for (size_t i = 0; i < n_states; i++)
+        if (states[203 * i + 200] >= BPPP_STROBE_R || states[203 * i + 201] > BPPP_STROBE_R) return BPPP_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t SB = BPPP_TRANSCRIPT_STATE_BYTES;
+    uint8_t* d = nullptr;
+    const size_t o_x = 0, o_s = align16(o_x + n * 8), o_r = align16(o_s + n * 32), o_p = align16(o_r + n * 52 * 32),
+                 o_c = align16(o_p + n * (size_t)BPPP_U64_PROOF_BYTES), o_st = align16(o_c + n * 64), o_ti = align16(o_st + n * sizeof(int32_t)),
+                 o_to = align16(o_ti + n_states * SB), total = align16(o_to + n * SB);
+    HIP_TRY(hipMalloc(&d, total));
+    int rc = BPPP_OK;
+    hipStream_t st = c->stream;
+    hipError_t e = hipMemcpyAsync(d + o_x, x, n * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_s, s, n * 32, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_r, rnd, n * 52 * 32, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_ti, states, n_states * SB, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        rc = bppp_u64_prove_batch_transcript_device(c, n, d + o_ti, n_states, d + o_x, d + o_s, d + o_r, d + o_p, d + o_c, d + o_st,
+                                                    states_out ? d + o_to : nullptr);
+        if (rc == BPPP_OK) {
+            e = hipMemcpyAsync(proofs, d + o_p, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(commitments, d + o_c, n * 64, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && status) e = hipMemcpyAsync(status, d + o_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && states_out) e = hipMemcpyAsync(states_out, d + o_to, n * SB, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) { g_last_error = std::string("prove_batch_transcript: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
+    return rc;
+}
+
+int bppp_u64_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x, const uint8_t* s,
+                         const uint8_t* rnd, uint8_t* proofs, uint8_t* commitments, int32_t* status) {
+    CtxLock lock_(c);
+    if (!c || !x || !s || !rnd || !proofs || !commitments) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    uint8_t* d = nullptr;
+    const size_t o_x = 0, o_s = o_x + n * 8, o_r = o_s + n * 32, o_p = o_r + n * 52 * 32, o_c = o_p + n * (size_t)BPPP_U64_PROOF_BYTES,
+                 o_st = o_c + n * 64, total = o_st + n * sizeof(int32_t);
+    HIP_TRY(hipMalloc(&d, total));
+    int rc = BPPP_OK;
+    hipError_t e = hipMemcpyAsync(d + o_x, x, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_s, s, n * 32, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_r, rnd, n * 52 * 32, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rc = bppp_u64_prove_batch_device(c, label, label_len, n, d + o_x, d + o_s, d + o_r, d + o_p, d + o_c, d + o_st);
+        if (rc == BPPP_OK) {
+            e = hipMemcpyAsync(proofs, d + o_p, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(commitments, d + o_c, n * 64, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess && status) e = hipMemcpyAsync(status, d + o_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) { g_last_error = std::string("prove_batch: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
+    return rc;
+}
+
+int verify_sec1_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments33, const void* d_proofs525,
+                            void* d_accept, void* d_status, void* d_trace, void* d_reject_count) {
+    if (!c || !d_commitments33 || !d_proofs525 || !d_accept) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t need = n * (64 + (size_t)BPPP_U64_PROOF_BYTES);
+    if (need > c->expand_bytes) {
+        if (c->d_expand) { (void)hipFree(c->d_expand); c->d_expand = nullptr; c->expand_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->d_expand, need));
+        c->expand_bytes = need;
+    }
+    uint8_t* d_c64 = c->d_expand;
+    uint8_t* d_p928 = c->d_expand + n * 64;
+    const unsigned blocks = (unsigned)((n * 16 + 255) / 256);
+    k_sec1_expand<<<blocks, 256, 0, c->stream>>>(d_c64, d_p928, (const uint8_t*)d_commitments33, (const uint8_t*)d_proofs525, n);
+    HIP_TRY(hipGetLastError());
+    return verify_device_impl(c, label, label_len, n, d_c64, d_p928, d_accept, d_status, d_trace, d_reject_count, nullptr, nullptr);
+}
+int bppp_u64_verify_batch_sec1_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments33,
+                                      const void* d_proofs525, void* d_accept, void* d_status, void* d_trace, void* d_reject_count) {
+    CtxLock lock_(c);
+    return verify_sec1_device_impl(c, label, label_len, n, d_commitments33, d_proofs525, d_accept, d_status, d_trace, d_reject_count);
+}
+
+int bppp_u64_verify_batch_sec1(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments33,
+                               const uint8_t* proofs525, uint8_t* accept, int32_t* status) {
+    CtxLock lock_(c);
+    if (!c || !commitments33 || !proofs525 || !accept) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    uint8_t* d = nullptr;
+    const size_t o_c = 0, o_p = o_c + n * 33, o_a = o_p + n * (size_t)BPPP_U64_PROOF_SEC1_BYTES, o_s = (o_a + n + 3) / 4 * 4,
+                 total = o_s + n * sizeof(int32_t);
+    HIP_TRY(hipMalloc(&d, total));
+    int rc = BPPP_OK;
+    hipError_t e = hipMemcpyAsync(d + o_c, commitments33, n * 33, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_p, proofs525, n * (size_t)BPPP_U64_PROOF_SEC1_BYTES, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rc = bppp_u64_verify_batch_sec1_device(c, label, label_len, n, d + o_c, d + o_p, d + o_a, d + o_s, nullptr, nullptr);
+        if (rc == BPPP_OK) {
+            e = hipMemcpyAsync(accept, d + o_a, n, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess && status) e = hipMemcpyAsync(status, d + o_s, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) { g_last_error = std::string("verify_batch_sec1: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+// One sharded call over the ranks of a device group, as host-side control flow with no HIP in it: one host thread per rank, and
+// the rule that makes the group FAIL CLOSED instead of hanging --
+//
+//   phase 1  prepare(r)     fallible: stage the shard, enqueue its verification on rank r's stream
+//   vote                    every rank thread publishes its return code and waits for the others (host-side latch)
+//   phase 2  collective(r)  only if EVERY rank's phase 1 succeeded: enqueue the accept-reduce (ncclAllReduce) on rank r's stream
+//   vote                    as above, on the collectives' return codes
+//   phase 3  finish(r)      copy results back, wait for rank r's stream
+//
+// A rank that failed phase 1 never reaches the collective, and because of the vote neither does any other rank: nobody is left
+// blocked in an all-reduce whose peer will not come (round 2's group returned the failing rank early and hung the rest).  If a
+// collective call itself fails on some rank, the ranks that did enqueue theirs would wait for it forever: abort(r) (ncclCommAbort)
+// releases them and the group is marked unusable by the caller.  After a failed vote every rank still runs drain(r)
+// (wait for the work it enqueued) so no kernel is left reading caller memory when the call returns.
+//
+// The same template drives libbppp_hip.so's groups (bppp_group.hip: HIP streams + RCCL) and the CPU tier's emulated group
+// (tests/emul: the device code compiled for the host + a blocking in-process all-reduce), which is how the vote is tested without
+// a GPU: with the vote removed, the emulated all-reduce of a two-rank group with one failing rank never returns.
+#pragma once
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace bppp_host {
+
+// Reusable vote: arrive(code) blocks until all `parties` have arrived and returns the first (lowest rank) non-zero code, or 0.
+class Vote {
+public:
+    explicit Vote(int parties) : parties_(parties), codes_(parties, 0) {}
+    int arrive(int rank, int code) {
+        std::unique_lock<std::mutex> lk(mu_);
+        codes_[rank] = code;
+        const unsigned gen = generation_;
+        if (++arrived_ == parties_) {
+            result_ = 0;
+            for (int c : codes_)
+                if (c != 0) { result_ = c; break; }
+            arrived_ = 0;
+            generation_++;
+            cv_.notify_all();
+            return result_;
+        }
+        cv_.wait(lk, [&] { return generation_ != gen; });
+        return result_;
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    int parties_, arrived_ = 0, result_ = 0;
+    unsigned generation_ = 0;
+    std::vector<int> codes_;
+};
+
+struct ShardedResult {
+    int code = 0;              // 0, or the failing rank's code (lowest failing rank)
+    int failed_rank = -1;
+    bool collective_failed = false;   // a collective call failed after the phase-1 vote passed: communicators were aborted
+    std::string error;         // the failing rank's message
+};
+
+// prepare / collective / finish / drain return 0 on success; last_error() returns the calling thread's error text.  enter(r) /
+// leave(r) bracket everything rank r's thread does (the caller takes and releases rank r's context lock there: a recursive mutex
+// has to be released by the thread that took it).
+template <class Enter, class Prepare, class Collective, class Finish, class Drain, class Abort, class Leave, class LastError>
+ShardedResult run_sharded(int G, Enter&& enter, Prepare&& prepare, Collective&& collective, Finish&& finish, Drain&& drain, Abort&& abort,
+                          Leave&& leave, LastError&& last_error) {
+    ShardedResult res;
+    std::vector<int> rcs(G, 0);
+    std::vector<std::string> errs(G);
+    Vote vote1(G), vote2(G);
+    auto rank_body = [&](int r) {
+        int rc = prepare(r);
+        if (rc != 0) errs[r] = last_error();
+        const int v1 = vote1.arrive(r, rc);
+        if (v1 != 0) {                       // somebody failed before the collective: nobody enters it
+            (void)drain(r);                  // whatever this rank did enqueue finishes before the call returns
+            rcs[r] = rc;
+            return;
+        }
+        rc = collective(r);
+        if (rc != 0) errs[r] = last_error();
+        const int v2 = vote2.arrive(r, rc);
+        if (v2 != 0) {                       // a collective failed somewhere: release every rank that is (or will be) waiting in one
+            abort(r);
+            (void)drain(r);
+            rcs[r] = rc;
+            if (r == 0) res.collective_failed = true;
+            return;
+        }
+        rc = finish(r);
+        if (rc != 0) errs[r] = last_error();
+        rcs[r] = rc;
+    };
+    auto rank_main = [&](int r) { enter(r); rank_body(r); leave(r); };
+    if (G == 1) rank_main(0);
+    else {
+        std::vector<std::thread> th;
+        th.reserve(G);
+        for (int r = 0; r < G; r++) th.emplace_back(rank_main, r);
+        for (auto& t : th) t.join();
+    }
+    for (int r = 0; r < G; r++)
+        if (rcs[r] != 0) { res.code = rcs[r]; res.failed_rank = r; res.error = errs[r]; break; }
+    return res;
+}
+
+}  // namespace bppp_host

@@ -1,0 +1,313 @@
+// Host side of libbppp_hip.so, shared by its translation units: bppp_ctx.hip (contexts, options, tables, setup), bppp_u64.hip
+// (launch sequences of the u64 verifier / prover), bppp_generic.hip (generic wnla / reciprocal / circuit verifiers and provers) and
+// bppp_group.hip (one batch over the GPUs of a node).  Nothing here is exported; the C ABI is include/bppp.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/bppp.h"
+#include "kernels.h"
+
+using namespace bppp;
+
+extern thread_local std::string g_last_error;   // defined in bppp_ctx.hip
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+            (void)hipGetLastError(); /* a failed allocation must not poison the next call */          \
+            return e_ == hipErrorOutOfMemory ? BPPP_ERR_NOMEM : BPPP_ERR_HIP;                          \
+        }                                                                                              \
+    } while (0)
+
+enum KernelId {
+    K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_ACCEPT, K_TABLES, K_RLC_LHS, K_RLC_CHUNK, K_BKT_PREPARE, K_BKT_ACCUMULATE, K_BKT_SCALARS, K_BKT_CHECK,
+    // u64 batch prover
+    K_PROVE_STAGES, K_PROVE_MSM, K_PROVE_ROUND_SCALARS, K_PROVE_ROUND_FOLD,
+    // generic reciprocal / WNLA verifier
+    K_RECIP_PHASE1, K_RECIP_C0_FIXED, K_RECIP_C0_VAR, K_RECIP_C0_FINISH, K_WNLA_BEGIN, K_WNLA_ROUND, K_WNLA_FINAL_SCALARS, K_WNLA_MSM, K_WNLA_ACCEPT,
+    K_WNLA_RLC_LHS, K_WNLA_RLC_CHUNK, K_WNLA_RLC_CHECK, K_WNLA_TABLES,
+    K_COUNT
+};
+static const char* const kKernelNames[K_COUNT] = {
+    "k_verify_phase1", "k_verify_c0_fixed", "k_verify_c0_var", "k_verify_round", "k_verify_final_scalars", "k_verify_final_check",
+    "k_verify_accept", "k_verify_tables", "k_rlc_lhs", "k_rlc_chunk", "k_bkt_prepare", "k_bkt_accumulate", "k_bkt_scalars", "k_bkt_check",
+    "k_prove_stage_*", "k_prove_msm", "k_prove_round_scalars", "k_prove_round_fold",
+    "k_recip_phase1", "k_recip_c0_fixed", "k_recip_c0_var", "k_recip_c0_finish", "k_wnla_begin", "k_wnla_round", "k_wnla_final_scalars",
+    "k_wnla_msm", "k_wnla_accept", "k_wnla_rlc_lhs", "k_wnla_rlc_chunk", "k_wnla_rlc_check", "k_wnla_tables"};
+
+static inline size_t align16(size_t x) { return (x + 15) / 16 * 16; }
+
+struct TimedLaunch { int id; hipEvent_t a, b; };
+
+struct bppp_ctx {
+    std::recursive_mutex mu;   // every exported call on a context holds it: overlapping calls from several host threads are serialized
+    int device = 0;
+    int fb_w = 16;
+    int ng = 16, nh = 32, nbases = BPPP_NG;   // generator set: g, g_vec[ng], h_vec[nh]
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;   // runs the fixed-base half of C0 concurrently with the variable-base half
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t copy_stream = nullptr;  // host-buffer entry points: uploads chunk k + 1 while chunk k is being verified (created on first use)
+    hipEvent_t ev_copy = nullptr;
+    size_t max_batch = (size_t)1 << 21;    // proofs verified per internal part of one call: bounds the workspace (~63 GB at 2^21)
+    size_t host_chunk = (size_t)1 << 17;   // proofs per pipelined chunk (one full grid at 2 waves/SIMD); 0 = upload the whole batch first
+    apt* d_gens = nullptr;       // 49
+    apt_packed* d_table = nullptr;
+    size_t table_bytes = 0;
+    // per-proof workspace
+    size_t cap = 0;
+    u32* d_ws = nullptr;
+    size_t ws_bytes = 0;
+    size_t scap = 0;
+    pt_slot* d_straus = nullptr;
+    size_t straus_bytes = 0;
+    // u64 verifier: affine window tables of the 13 proof points + the scratch of the kernel that builds them
+    size_t vcap = 0;
+    apt_packed* d_atab = nullptr;
+    u32* d_tscr = nullptr;
+    size_t vtab_bytes = 0;
+    // random-linear-combination mode: per-proof weighted commitments, chunk scalars, chunk flags
+    size_t rcap = 0;
+    u32* d_rlc = nullptr;
+    size_t rlc_bytes = 0;
+    // bucket stage of the RLC mode (bucket_core.h): superchunk size (0 = stage off) and its workspace
+    unsigned rlc_super_m = 4096;
+    size_t bcap = 0;
+    uint8_t* d_bkt = nullptr;
+    size_t bkt_bytes = 0;
+    // prover workspace
+    size_t pcap = 0;
+    u32* d_pws = nullptr;
+    size_t pws_bytes = 0;
+    // staging for the host-pointer entry points
+    uint8_t* d_stage = nullptr;
+    size_t stage_bytes = 0;
+    uint8_t* d_io = nullptr;     // inputs / outputs of bppp_u64_verify_batch (host buffers)
+    size_t io_bytes = 0;
+    uint8_t* d_gws = nullptr;    // workspace of bppp_reciprocal_verify_batch_device
+    size_t gws_bytes = 0;
+    uint8_t* d_gtab = nullptr;   // generic verifiers: affine window tables of the round points + build scratch (wnla_core.h, fast path)
+    size_t gtab_bytes = 0;
+    // expanded (64-byte) form of SEC1-compressed inputs
+    uint8_t* d_expand = nullptr;
+    size_t expand_bytes = 0;
+    int* d_flags = nullptr;
+    int n_simds = 1024;            // CUs x 4 (device property), decides between the small-batch and the 2-waves/SIMD lane kernels
+    bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
+    bool timing = false;
+    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false, no_lane_groups = false, force_pairs = false, no_small = false;
+    int fb_one_lane_mode = -1;   // diagnostic BPPP_FB_ONE_LANE: 1 = one lane per proof in the u64 verifier's fixed-base kernels at every size, 0 = never, unset = by size   // diagnostics, read from the environment once at context creation
+    std::vector<TimedLaunch> pending;
+    std::vector<hipEvent_t> event_pool;
+    double total_ms[K_COUNT] = {0};
+    int64_t launches[K_COUNT] = {0};
+};
+
+struct CtxLock {
+    bppp_ctx* c;
+    explicit CtxLock(bppp_ctx* ctx) : c(ctx) { if (c) c->mu.lock(); }
+    ~CtxLock() { if (c) c->mu.unlock(); }
+    CtxLock(const CtxLock&) = delete;
+    CtxLock& operator=(const CtxLock&) = delete;
+};
+
+static const size_t WS_WORDS_PER_PROOF = 52 + 80 + 176 + 200 + 208 + 24 + 30 + 30 + 392;
+
+static inline int ensure_capacity(bppp_ctx* c, size_t n) {
+    if (n <= c->cap) return BPPP_OK;
+    if (c->d_ws) { (void)hipFree(c->d_ws); c->d_ws = nullptr; }
+    c->cap = 0;
+    c->ws_bytes = 0;
+    size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    const size_t bytes = cap * WS_WORDS_PER_PROOF * sizeof(u32);
+    HIP_TRY(hipMalloc(&c->d_ws, bytes));
+    c->ws_bytes = bytes;
+    c->cap = cap;
+    return BPPP_OK;
+}
+// projective window tables of the generic WNLA / circuit / reciprocal paths and of the provers (5.6 KB per instance); the u64
+// verifier keeps its own affine tables (ensure_vtab_capacity) and never touches these
+static inline int ensure_straus_capacity(bppp_ctx* c, size_t n) {
+    if (n <= c->scap) return BPPP_OK;
+    if (c->d_straus) { (void)hipFree(c->d_straus); c->d_straus = nullptr; }
+    c->scap = 0;
+    c->straus_bytes = 0;
+    size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    const size_t bytes = cap * 5 * BPPP_STRAUS_ENTRIES * sizeof(pt_slot);
+    HIP_TRY(hipMalloc(&c->d_straus, bytes));
+    c->straus_bytes = bytes;
+    c->scap = cap;
+    return BPPP_OK;
+}
+static inline int ensure_vtab_capacity(bppp_ctx* c, size_t n) {
+    if (n <= c->vcap) return BPPP_OK;
+    if (c->d_atab) { (void)hipFree(c->d_atab); c->d_atab = nullptr; }
+    if (c->d_tscr) { (void)hipFree(c->d_tscr); c->d_tscr = nullptr; }
+    c->vcap = 0;
+    c->vtab_bytes = 0;
+    size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    const size_t atab_bytes = cap * BPPP_ATAB_PER_PROOF * sizeof(apt_packed);
+    const size_t tscr_bytes = cap * (size_t)(BPPP_TSCR_FE * 10) * sizeof(u32);
+    HIP_TRY(hipMalloc(&c->d_atab, atab_bytes));
+    HIP_TRY(hipMalloc(&c->d_tscr, tscr_bytes));
+    c->vtab_bytes = atab_bytes + tscr_bytes;
+    c->vcap = cap;
+    return BPPP_OK;
+}
+static inline int ensure_rlc_capacity(bppp_ctx* c, size_t n) {
+    if (n <= c->rcap) return BPPP_OK;
+    if (c->d_rlc) { (void)hipFree(c->d_rlc); c->d_rlc = nullptr; }
+    c->rcap = 0;
+    c->rlc_bytes = 0;
+    size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    const size_t rbytes = cap * (30 + (size_t)BPPP_NG * 8) * sizeof(u32) + cap + (cap / BPPP_RLC_CHUNK + 4) * sizeof(u32);   // lhs, sc | flags (cap bytes) | list, count
+    HIP_TRY(hipMalloc(&c->d_rlc, rbytes));
+    c->rlc_bytes = rbytes;
+    c->rcap = cap;
+    return BPPP_OK;
+}
+// workspace of the bucket stage: half-weights, packed commitments | per superchunk: lhs, combined scalars, flag
+static inline size_t bkt_bytes_for(size_t cap, size_t nsuper) {
+    return align16(cap * 16) + align16(cap * sizeof(c4_packed)) + align16(nsuper * 30 * 4) + align16(nsuper * (size_t)BPPP_NG * 32) + align16(nsuper + 16);
+}
+static inline int ensure_bucket_capacity(bppp_ctx* c, size_t n) {
+    const size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    const size_t need = bkt_bytes_for(cap, cap / 64 + 1);      // enough for any superchunk size >= 64
+    if (need <= c->bkt_bytes) return BPPP_OK;
+    if (c->d_bkt) { (void)hipFree(c->d_bkt); c->d_bkt = nullptr; c->bkt_bytes = 0; }
+    HIP_TRY(hipMalloc(&c->d_bkt, need));
+    c->bkt_bytes = need;
+    return BPPP_OK;
+}
+static const size_t PWS_WORDS_PER_PROOF = 52 + (size_t)SV_COUNT * 8 + (size_t)BPPP_MSC_SETS * BPPP_NG * 8 + (size_t)PB_COUNT * 30;
+static inline int ensure_prove_capacity(bppp_ctx* c, size_t n) {
+    int rc = ensure_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    rc = ensure_straus_capacity(c, n);
+    if (rc != BPPP_OK) return rc;
+    if (n <= c->pcap) return BPPP_OK;
+    if (c->d_pws) { (void)hipFree(c->d_pws); c->d_pws = nullptr; }
+    c->pcap = 0;
+    c->pws_bytes = 0;
+    size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    const size_t pbytes = cap * PWS_WORDS_PER_PROOF * sizeof(u32);
+    HIP_TRY(hipMalloc(&c->d_pws, pbytes));
+    c->pws_bytes = pbytes;
+    c->pcap = cap;
+    return BPPP_OK;
+}
+static inline int ensure_stage(bppp_ctx* c, size_t bytes) {
+    if (bytes <= c->stage_bytes) return BPPP_OK;
+    if (c->d_stage) { (void)hipFree(c->d_stage); c->d_stage = nullptr; c->stage_bytes = 0; }
+    HIP_TRY(hipMalloc(&c->d_stage, bytes));
+    c->stage_bytes = bytes;
+    return BPPP_OK;
+}
+// workspace carve-up: the SoA stride is the batch size n of THIS call (so lanes stay coalesced for any n <= cap)
+static inline void carve(bppp_ctx* c, VerifyWs& ws, size_t n) {
+    u32* p = c->d_ws;
+    ws.N = n;
+    ws.tstate = p; p += 52 * n;
+    ws.chal = p; p += 80 * n;
+    ws.sc0 = p; p += 176 * n;
+    ws.cvec = p; p += 200 * n;
+    ws.pts = p; p += 208 * n;
+    ws.lns = p; p += 24 * n;
+    ws.acc = p; p += 30 * n;
+    ws.pfix = p; p += 30 * n;
+    ws.fsc = p; p += 392 * n;
+    ws.straus = c->d_straus;
+    ws.fb_table = c->d_table;
+    ws.fb_w = c->fb_w;
+}
+
+template <typename F>
+static inline int timed(bppp_ctx* c, int id, hipStream_t st, F&& launch) {
+    if (!c->timing) {
+        launch();
+        return BPPP_OK;
+    }
+    auto get_event = [&](hipEvent_t& ev) -> hipError_t {
+        if (!c->event_pool.empty()) { ev = c->event_pool.back(); c->event_pool.pop_back(); return hipSuccess; }
+        return hipEventCreate(&ev);
+    };
+    TimedLaunch tl;
+    tl.id = id;
+    HIP_TRY(get_event(tl.a));
+    HIP_TRY(get_event(tl.b));
+    HIP_TRY(hipEventRecord(tl.a, st));
+    launch();
+    HIP_TRY(hipEventRecord(tl.b, st));
+    c->pending.push_back(tl);
+    return BPPP_OK;
+}
+static inline int drain_timings(bppp_ctx* c) {
+    if (c->pending.empty()) return BPPP_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->aux_stream));
+    for (auto& tl : c->pending) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, tl.a, tl.b));
+        c->total_ms[tl.id] += ms;
+        c->launches[tl.id] += 1;
+        c->event_pool.push_back(tl.a);
+        c->event_pool.push_back(tl.b);
+    }
+    c->pending.clear();
+    return BPPP_OK;
+}
+
+static inline int device_simds(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount <= 0) return 1024;
+    return prop.multiProcessorCount * 4;
+}
+static inline int check_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_last_error = std::string("no HIP device: ") + hipGetErrorString(e);
+        return BPPP_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        g_last_error = "device index out of range";
+        return BPPP_ERR_INVALID_ARG;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BPPP_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_last_error = std::string("this library is built for gfx950 only, found ") + prop.gcnArchName;
+        return BPPP_ERR_NO_DEVICE;
+    }
+    return BPPP_OK;
+}
+
+// ---- launch sequences used across translation units (hidden symbols; C linkage only because their definitions sit inside the
+//      extern "C" blocks of the entry points they serve)
+// optional pre-loaded transcripts of a verify call (device pointers): see VerifyWs::states
+struct VerifyTranscripts { const void* d_states; size_t n_states; void* d_states_out; };
+extern "C" {
+// bppp_u64.hip: the u64 verifier over device buffers, asynchronous on c->stream (the caller holds the context's lock)
+int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments, const void* d_proofs,
+                       void* d_accept, void* d_status, void* d_trace, void* d_reject_count, const uint8_t* rlc_seed,
+                       const VerifyTranscripts* tx);
+// bppp_u64.hip: SEC1-compressed inputs expanded into the context's buffer, then verify_device_impl
+int verify_sec1_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments33, const void* d_proofs525,
+                            void* d_accept, void* d_status, void* d_trace, void* d_reject_count);
+// bppp_generic.hip: the reciprocal verifier over device buffers (exact, or RLC when rlc_seed is given); d_reject_count (device
+// int32, optional) receives the number of rejected instances
+int recip_verify_device_entry(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
+                              const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn, void* d_accept,
+                              void* d_status, const uint8_t* rlc_seed, void* d_reject_count);
+}

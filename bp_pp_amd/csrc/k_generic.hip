@@ -68,6 +68,16 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) wnla_verify_accept(w, t);
 }
+// number of rejected instances of a finished batch (the sharded entry points all-reduce it): grid-stride, one ballot and one
+// device-scope atomic per wavefront that saw a reject
+__global__ __launch_bounds__(256) void k_count_rejects(const uint8_t* accept, size_t n, int* reject_count) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    int mine = 0;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += stride) mine += accept[t] == 0;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(reject_count, mine);
+}
 // ---- random-linear-combination mode of the final MSM (wnla_rlc_core.h)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_rlc_lhs(WnlaWs w, RlcWs r) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_msm_store(MsmWs w) {
 __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_phase1(CircuitWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= w.N) return;
-    const u32 key = (w.tio.states && w.tio.n_states != 1) ? w.tio.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
+    const u32 key = preloaded_position_key(w.tio.states, w.tio.n_states, t);
     for_each_position_group(key, [&]() { circuit_phase1(w, t); });
 }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_circuit_c0_fixed(CircuitWs w) {
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_finish(CircuitWs w) {
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1(RecipWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= w.N) return;
-    const u32 key = (w.tio.states && w.tio.n_states != 1) ? w.tio.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
+    const u32 key = preloaded_position_key(w.tio.states, w.tio.n_states, t);
     for_each_position_group(key, [&]() { recip_phase1(w, t); });
 }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed(RecipWs w) {

@@ -10,7 +10,7 @@ using namespace bppp;
 // same byte counts, so instances that start at one position stay together: the key is the position the caller handed in.
 template <typename Ws>
 __device__ __forceinline__ u32 gprove_position_key(const Ws& w, size_t t) {
-    return w.divergent_positions ? (u32)w.tio.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
+    return w.divergent_positions ? preloaded_position_key(w.tio.states, w.tio.n_states, t) : 0u;
 }
 // the caller's `&mut Transcript` after a prove (any generic prover: they all end in the WNLA prover's state array)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_gprove_export_states(TranscriptIo io, strobe base, const u32* tstate, size_t N, const int32_t* status) {

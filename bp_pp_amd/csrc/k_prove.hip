@@ -17,7 +17,7 @@ __device__ __forceinline__ u32 prove_position_key(const ProveWs& w, size_t t) {
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_b(ProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= w.N) return;
-    const u32 key = (w.states && w.n_states != 1) ? w.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
+    const u32 key = preloaded_position_key(w.states, w.n_states, t);
     for_each_position_group(key, [&]() { prove_stage_b(w, t); });
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d(ProveWs w) {

@@ -11,13 +11,13 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_phas
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= ws.N) return;
     // per-proof pre-loaded transcripts may sit at different byte positions (byte 200 of the serialized state)
-    const u32 key = (ws.states && ws.n_states != 1) ? ws.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
+    const u32 key = preloaded_position_key(ws.states, ws.n_states, t);
     for_each_position_group(key, [&]() { verify_phase1(ws, t); });
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_small(VerifyWs ws) {     // see k_verify_round_small
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= ws.N) return;
-    const u32 key = (ws.states && ws.n_states != 1) ? ws.states[(size_t)BPPP_TRANSCRIPT_STATE_BYTES * t + 200] : 0u;
+    const u32 key = preloaded_position_key(ws.states, ws.n_states, t);
     for_each_position_group(key, [&]() { verify_phase1(ws, t); });
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(VerifyWs ws) {

@@ -1,4 +1,4 @@
-// Kernel declarations shared by the kernel translation units (k_*.hip) and the host side (bppp_hip.hip).
+// Kernel declarations shared by the kernel translation units (k_*.hip) and the host side (bppp_*.hip).
 // The kernels are split over several translation units so that hipcc compiles them in parallel (the u64 verifier's
 // shared-doubling kernels alone take minutes); a kernel is launched from the host TU through its declaration here.
 #pragma once
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars(bppp::WnlaWs 
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(bppp::WnlaWs w, int commit_mode);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(bppp::WnlaWs w);
+__global__ __launch_bounds__(256) void k_count_rejects(const uint8_t* accept, size_t n, int* reject_count);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_init(bppp::WnlaProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_scalars(bppp::WnlaProveWs w, int k);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wprove_msm(bppp::WnlaProveWs w, int set);

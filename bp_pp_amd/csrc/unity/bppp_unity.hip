@@ -3,7 +3,10 @@
 // compiles the units separately and in parallel (bp_pp_amd/_build.py); this file only includes them.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden -DBPPP_PHASE_TIMING \
 //         -o bp_pp_amd/libbppp_hip_pt.so bp_pp_amd/csrc/unity/bppp_unity.hip
-#include "../bppp_hip.hip"
+#include "../bppp_ctx.hip"
+#include "../bppp_u64.hip"
+#include "../bppp_generic.hip"
+#include "../bppp_group.hip"
 #include "../k_verify_misc.hip"
 #include "../k_verify_var.hip"
 #include "../k_verify_fixed.hip"

@@ -107,6 +107,16 @@ struct TranscriptIo {
     int no_ops;              // 1: the protocol performs no transcript operation for this shape (WNLA base case, wnla.rs:80-82):
                              // the caller's transcript comes back exactly as it went in, cur_flags included
 };
+// Position-group key of instance t's pre-loaded transcript (kernels.h: for_each_position_group): its byte position -- but only if the
+// state is one strobe_from_bytes accepts.  A rejected state makes its lane start from `base` instead, i.e. at base.pos: keyed by its
+// raw byte 200 it would share a group with valid lanes at that position and, as the group's leader, force base.pos onto them.  Such a
+// lane gets a key no valid lane can have (bit 8 set), so it runs alone and per-proof isolation holds.
+HD u32 preloaded_position_key(const uint8_t* states, size_t n_states, size_t t) {
+    if (!states || n_states == 1) return 0u;
+    const uint8_t* b = states + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * t;
+    const bool valid = b[200] < BPPP_STROBE_R && b[201] <= BPPP_STROBE_R;
+    return valid ? (u32)b[200] : 0x100u;
+}
 HD void tio_begin(strobe& tr, int32_t& status, const TranscriptIo& io, const strobe& base, size_t t) {
     tr = base;
     if (!io.states) return;

@@ -69,11 +69,23 @@ extern "C" {
     pub fn bppp_transcript_challenge_bytes(state: *mut u8, label: *const u8, label_len: usize, out: *mut u8, n: usize) -> c_int;
     pub fn bppp_shard_range(n_total: usize, rank: c_int, world: c_int, lo: *mut usize, hi: *mut usize);
     pub fn bppp_group_create(out: *mut *mut BpppGroup, g: *const u8, g_vec: *const u8, h_vec: *const u8, devices: *const c_int, n_devices: c_int, fb_window_bits: c_int) -> c_int;
+    pub fn bppp_wnla_group_create(out: *mut *mut BpppGroup, g: *const u8, g_vec: *const u8, ng: usize, h_vec: *const u8, nh: usize, devices: *const c_int, n_devices: c_int, fb_window_bits: c_int) -> c_int;
     pub fn bppp_group_destroy(grp: *mut BpppGroup);
     pub fn bppp_group_size(grp: *const BpppGroup) -> c_int;
     pub fn bppp_group_ctx(grp: *mut BpppGroup, rank: c_int) -> *mut BpppCtx;
+    pub fn bppp_group_set_option(grp: *mut BpppGroup, name: *const c_char, value: c_long) -> c_int;
     pub fn bppp_u64_verify_batch_sharded(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, commitments: *const u8, proofs: *const u8, accept: *mut u8, status: *mut i32, reject_count: *mut i32) -> c_int;
     pub fn bppp_u64_verify_batch_sharded_device(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, d_commitments: *const *const c_void, d_proofs: *const *const c_void, d_accept: *const *mut c_void, d_status: *const *mut c_void, d_reject_count: *const *mut c_void) -> c_int;
+    pub fn bppp_u64_verify_batch_rlc_sharded(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, commitments: *const u8, proofs: *const u8, accept: *mut u8, status: *mut i32, reject_count: *mut i32, seed: *const u8) -> c_int;
+    pub fn bppp_u64_verify_batch_rlc_sharded_device(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, d_commitments: *const *const c_void, d_proofs: *const *const c_void, d_accept: *const *mut c_void, d_status: *const *mut c_void, d_reject_count: *const *mut c_void, seed: *const u8) -> c_int;
+    pub fn bppp_u64_verify_batch_sec1_sharded(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, commitments33: *const u8, proofs525: *const u8, accept: *mut u8, status: *mut i32, reject_count: *mut i32) -> c_int;
+    pub fn bppp_u64_verify_batch_sec1_sharded_device(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, d_commitments33: *const *const c_void, d_proofs525: *const *const c_void, d_accept: *const *mut c_void, d_status: *const *mut c_void, d_reject_count: *const *mut c_void) -> c_int;
+    pub fn bppp_u64_verify_batch_transcript_sharded(grp: *mut BpppGroup, n: usize, states: *const u8, n_states: usize, commitments: *const u8, proofs: *const u8, accept: *mut u8, status: *mut i32, states_out: *mut u8, reject_count: *mut i32) -> c_int;
+    pub fn bppp_u64_verify_batch_transcript_sharded_device(grp: *mut BpppGroup, n: usize, d_states: *const *const c_void, n_states: usize, d_commitments: *const *const c_void, d_proofs: *const *const c_void, d_accept: *const *mut c_void, d_status: *const *mut c_void, d_reject_count: *const *mut c_void, d_states_out: *const *mut c_void) -> c_int;
+    pub fn bppp_reciprocal_verify_batch_sharded(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, commitments: *const u8, proofs: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32, reject_count: *mut i32) -> c_int;
+    pub fn bppp_reciprocal_verify_batch_rlc_sharded(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, commitments: *const u8, proofs: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32, reject_count: *mut i32, seed: *const u8) -> c_int;
+    pub fn bppp_reciprocal_verify_batch_sharded_device(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, d_commitments: *const *const c_void, d_proofs: *const *const c_void, rounds: usize, nl: usize, nn: usize, d_accept: *const *mut c_void, d_status: *const *mut c_void, d_reject_count: *const *mut c_void) -> c_int;
+    pub fn bppp_reciprocal_verify_batch_rlc_sharded_device(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, d_commitments: *const *const c_void, d_proofs: *const *const c_void, rounds: usize, nl: usize, nn: usize, d_accept: *const *mut c_void, d_status: *const *mut c_void, d_reject_count: *const *mut c_void, seed: *const u8) -> c_int;
     pub fn bppp_reciprocal_verify_batch_device(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, d_commitments: *const c_void, d_proofs: *const c_void, rounds: usize, nl: usize, nn: usize, d_accept: *mut c_void, d_status: *mut c_void) -> c_int;
     pub fn bppp_reciprocal_verify_batch_rlc(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, commitments: *const u8, proofs: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32, seed: *const u8) -> c_int;
     pub fn bppp_reciprocal_verify_batch_rlc_device(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, d_commitments: *const c_void, d_proofs: *const c_void, rounds: usize, nl: usize, nn: usize, d_accept: *mut c_void, d_status: *mut c_void, seed: *const u8) -> c_int;

@@ -345,9 +345,22 @@ BPPP_API void bppp_shard_range(size_t n_total, int rank, int world, size_t* lo, 
 /* devices: n_devices distinct HIP device ordinals.  Every device gets the same generators / window width (see bppp_ctx_create). */
 BPPP_API int bppp_group_create(bppp_group** out, const uint8_t g[64], const uint8_t* g_vec, const uint8_t* h_vec, const int* devices,
                                int n_devices, int fb_window_bits);
+/* The same over any generator set (bppp_wnla_ctx_create on every device): the group the generic reciprocal verifier shards over. */
+BPPP_API int bppp_wnla_group_create(bppp_group** out, const uint8_t g[64], const uint8_t* g_vec, size_t ng, const uint8_t* h_vec, size_t nh,
+                                    const int* devices, int n_devices, int fb_window_bits);
 BPPP_API void bppp_group_destroy(bppp_group* grp);
 BPPP_API int bppp_group_size(const bppp_group* grp);
 BPPP_API bppp_ctx* bppp_group_ctx(bppp_group* grp, int rank); /* the rank-th device's context (owned by the group) */
+/* Options: every name bppp_ctx_set_option takes (applied to each rank's context), and "inject_fault_rank" = r (testing aid: rank r's
+ * part of the NEXT sharded call fails with BPPP_ERR_NOMEM before it enqueues anything; -1 clears it). */
+BPPP_API int bppp_group_set_option(bppp_group* grp, const char* name, long value);
+/* Failure semantics of every *_sharded* call (csrc/group_core.h).  A group serves ONE sharded call at a time (calls from several
+ * host threads are serialized by the group's lock).  The ranks agree on their return codes through a host-side vote BEFORE any of
+ * them enqueues the all-reduce: if one rank fails (BPPP_ERR_NOMEM for its workspace, a HIP error, an invalid argument), no rank
+ * enters the collective, the ranks that had already enqueued work wait for it, and the call returns the failing rank's code with
+ * the group intact.  If an RCCL call itself fails, every communicator of the group is aborted (ncclCommAbort) so that no rank stays
+ * blocked, the call returns BPPP_ERR_RCCL, and so does every later sharded call on that group (destroy it and create a new one). */
+
 /* U64RangeProofProtocol::verify for ONE batch of n proofs in HOST memory, sharded over the group.  accept / status as in
  * bppp_u64_verify_batch; *reject_count (optional) receives the all-reduced number of rejected proofs. */
 BPPP_API int bppp_u64_verify_batch_sharded(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
@@ -358,6 +371,51 @@ BPPP_API int bppp_u64_verify_batch_sharded(bppp_group* grp, const uint8_t* label
 BPPP_API int bppp_u64_verify_batch_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n,
                                                   const void* const* d_commitments, const void* const* d_proofs, void* const* d_accept,
                                                   void* const* d_status /* entries may be NULL */, void* const* d_reject_count);
+/* The optional random-linear-combination mode (bppp_u64_verify_batch_rlc), sharded: each device checks its own shard's
+ * combinations (sound per shard: the weights are a PRF of seed and the proof's index within its shard) and contributes its
+ * reject count.  accept / status stay per proof. */
+BPPP_API int bppp_u64_verify_batch_rlc_sharded(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                                               const uint8_t* proofs, uint8_t* accept, int32_t* status, int32_t* reject_count,
+                                               const uint8_t seed[32]);
+BPPP_API int bppp_u64_verify_batch_rlc_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n,
+                                                      const void* const* d_commitments, const void* const* d_proofs, void* const* d_accept,
+                                                      void* const* d_status, void* const* d_reject_count, const uint8_t seed[32]);
+/* SEC1-compressed inputs (bppp_u64_verify_batch_sec1: 33-byte commitments, 525-byte proofs), sharded; expanded on each device. */
+BPPP_API int bppp_u64_verify_batch_sec1_sharded(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments33,
+                                                const uint8_t* proofs525, uint8_t* accept, int32_t* status, int32_t* reject_count);
+BPPP_API int bppp_u64_verify_batch_sec1_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n,
+                                                       const void* const* d_commitments33, const void* const* d_proofs525,
+                                                       void* const* d_accept, void* const* d_status, void* const* d_reject_count);
+/* The caller's transcripts (`t: &mut Transcript`, u64_proof.rs:42; bppp_u64_verify_batch_transcript), sharded: states = one
+ * 203-byte state shared by the batch (n_states = 1, every rank receives it) or one per proof (n_states = n, split like the
+ * proofs); states_out (optional) = each proof's transcript after verify.  Device form: d_states[r] is rank r's share (or the one
+ * shared state, resident on device r), d_states_out entries may be NULL. */
+BPPP_API int bppp_u64_verify_batch_transcript_sharded(bppp_group* grp, size_t n, const uint8_t* states, size_t n_states,
+                                                      const uint8_t* commitments, const uint8_t* proofs, uint8_t* accept, int32_t* status,
+                                                      uint8_t* states_out, int32_t* reject_count);
+BPPP_API int bppp_u64_verify_batch_transcript_sharded_device(bppp_group* grp, size_t n, const void* const* d_states, size_t n_states,
+                                                             const void* const* d_commitments, const void* const* d_proofs,
+                                                             void* const* d_accept, void* const* d_status, void* const* d_reject_count,
+                                                             void* const* d_states_out);
+/* ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) for ONE batch of n instances sharded over a group made by
+ * bppp_wnla_group_create -- BASELINE configs[4]: 2^18 instances of the (dim_nd 256, dim_np 16) shape over 8 GPUs.  Arguments as
+ * bppp_reciprocal_verify_batch[_rlc][_device]; same contiguous split, same 4-byte all-reduce of the reject count.  In the device
+ * form d_status[r] is required wherever rank r's shard is not empty. */
+BPPP_API int bppp_reciprocal_verify_batch_sharded(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd,
+                                                  size_t dim_np, const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl,
+                                                  size_t nn, uint8_t* accept, int32_t* status, int32_t* reject_count);
+BPPP_API int bppp_reciprocal_verify_batch_rlc_sharded(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd,
+                                                      size_t dim_np, const uint8_t* commitments, const uint8_t* proofs, size_t rounds,
+                                                      size_t nl, size_t nn, uint8_t* accept, int32_t* status, int32_t* reject_count,
+                                                      const uint8_t seed[32]);
+BPPP_API int bppp_reciprocal_verify_batch_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd,
+                                                         size_t dim_np, const void* const* d_commitments, const void* const* d_proofs,
+                                                         size_t rounds, size_t nl, size_t nn, void* const* d_accept, void* const* d_status,
+                                                         void* const* d_reject_count);
+BPPP_API int bppp_reciprocal_verify_batch_rlc_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd,
+                                                             size_t dim_np, const void* const* d_commitments, const void* const* d_proofs,
+                                                             size_t rounds, size_t nl, size_t nn, void* const* d_accept,
+                                                             void* const* d_status, void* const* d_reject_count, const uint8_t seed[32]);
 
 /* the same with DEVICE buffers (d_status required), asynchronous on the context's stream; the workspace lives in the context */
 BPPP_API int bppp_reciprocal_verify_batch_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd,

@@ -916,4 +916,117 @@ int emul_recip_prove(const uint8_t* table, int W, int NG, int NH, int nd, int np
     }
     return (int)proof_bytes;
 }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- an emulated device group (CPU tier of bppp_group.hip)
+// The product's sharded call is csrc/group_core.h's run_sharded() over HIP streams and RCCL.  Here the SAME template runs over
+// "devices" that are host threads executing the device code above on their shard, and over an in-process stand-in for
+// ncclAllReduce that behaves like the real one where it matters: it does not return until every rank of the communicator has
+// entered it (or the communicator is aborted), so a rank that never comes means a hang -- reported after `timeout_ms` as
+// EMUL_GROUP_HANG instead of blocking the test run forever.
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+
+#include "../../bp_pp_amd/csrc/group_core.h"
+
+namespace {
+const int EMUL_GROUP_HANG = -100, EMUL_ERR_NOMEM = -5, EMUL_ERR_RCCL = -6;
+struct FakeComm {
+    std::mutex mu;
+    std::condition_variable cv;
+    int world, arrived = 0, sum = 0, result = 0;
+    unsigned generation = 0;
+    bool aborted = false;
+    explicit FakeComm(int w) : world(w) {}
+    // ncclAllReduce is asynchronous: the call enqueues the rank's part on its stream and returns; what blocks is the stream
+    // synchronisation afterwards.  enqueue() = the call, wait() = hipStreamSynchronize on a stream that holds an all-reduce.
+    int enqueue(int value, unsigned* ticket) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (aborted) return EMUL_ERR_RCCL;
+        sum += value;
+        *ticket = generation;
+        if (++arrived == world) { result = sum; sum = 0; arrived = 0; generation++; cv.notify_all(); }
+        return 0;
+    }
+    // returns 0 and the global sum in *value; EMUL_GROUP_HANG when the peers did not arrive in time; EMUL_ERR_RCCL when aborted
+    int wait(unsigned ticket, int* value, int timeout_ms) {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return generation != ticket || aborted; })) return EMUL_GROUP_HANG;
+        if (generation == ticket) return EMUL_ERR_RCCL;     // released by abort()
+        *value = result;
+        return 0;
+    }
+    void abort() { std::lock_guard<std::mutex> lk(mu); aborted = true; cv.notify_all(); }
+};
+}  // namespace
+
+extern "C" {
+// One sharded verify over G emulated devices.  kind 0: u64 proofs (928 B); kind 1: reciprocal proofs of the given shape.
+// fail_rank >= 0: that rank's prepare fails with NOMEM before it does anything; fail_collective_rank >= 0: that rank's all-reduce
+// call fails.  use_vote = 0 reproduces round 2's control flow (a failing rank simply returns; the others go on into the
+// collective) so that the test can show what the vote prevents.
+// Returns the call's code; reject_out[r] = the count rank r ended with (global when the collective ran); aborted_out = 1 when the
+// communicator was aborted.
+int emul_group_verify(int kind, int G, int fail_rank, int fail_collective_rank, int use_vote, int timeout_ms, const uint8_t* table, int W,
+                      int NG, int NH, int nd, int np, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
+                      const uint8_t* proofs, int rounds, int nl, int nn, uint8_t* accept, int32_t* status, int* reject_out, int* aborted_out) {
+    const size_t proof_bytes = kind == 0 ? 928 : 64 * (5 + 2 * (size_t)rounds) + 32 * ((size_t)nl + nn);
+    FakeComm comm(G);
+    std::vector<int> rej(G, 0);
+    auto range = [&](int r, size_t& lo, size_t& m) {
+        const size_t q = n / G, rem = n % G;
+        auto at = [&](size_t k) { return q * k + (rem * k) / G; };
+        lo = at(r); m = at(r + 1) - lo;
+    };
+    auto prepare = [&](int r) -> int {
+        if (r == fail_rank) return EMUL_ERR_NOMEM;
+        size_t lo, m;
+        range(r, lo, m);
+        if (m) {
+            int rc = kind == 0 ? emul_u64_verify_batch(table, W, label, label_len, m, commitments + lo * 64, proofs + lo * proof_bytes, accept + lo,
+                                                       status + lo, nullptr)
+                               : emul_recip_verify(table, W, NG, NH, nd, np, label, label_len, m, commitments + lo * 64, proofs + lo * proof_bytes,
+                                                   rounds, nl, nn, accept + lo, status + lo);
+            if (rc != 0) return rc;
+        }
+        int c = 0;
+        for (size_t i = 0; i < m; i++) c += accept[lo + i] == 0;
+        rej[r] = c;
+        return 0;
+    };
+    std::vector<unsigned> ticket(G, 0);
+    std::vector<char> enqueued(G, 0);
+    auto collective = [&](int r) -> int {
+        if (r == fail_collective_rank) return EMUL_ERR_RCCL;
+        int rc = comm.enqueue(rej[r], &ticket[r]);
+        if (rc == 0) enqueued[r] = 1;
+        return rc;
+    };
+    // "synchronize the stream": blocks while an enqueued all-reduce is incomplete
+    auto sync = [&](int r) -> int { return enqueued[r] ? comm.wait(ticket[r], &rej[r], timeout_ms) : 0; };
+    int code = 0;
+    if (use_vote) {
+        auto res = bppp_host::run_sharded(G, [](int) {}, prepare, collective, sync, sync, [&](int) { comm.abort(); }, [](int) {},
+                                          []() { return std::string(); });
+        code = res.code;
+    } else {
+        std::vector<int> rcs(G, 0);
+        std::vector<std::thread> th;
+        for (int r = 0; r < G; r++)
+            th.emplace_back([&, r]() {
+                rcs[r] = prepare(r);
+                if (rcs[r] == 0) rcs[r] = collective(r);
+                if (rcs[r] == 0) rcs[r] = sync(r);
+            });
+        for (auto& t : th) t.join();
+        for (int r = 0; r < G; r++)
+            if (rcs[r] == EMUL_GROUP_HANG) code = EMUL_GROUP_HANG;
+        for (int r = 0; r < G && code == 0; r++) code = rcs[r];
+    }
+    for (int r = 0; r < G; r++) reject_out[r] = rej[r];
+    *aborted_out = comm.aborted ? 1 : 0;
+    return code;
+}
 }

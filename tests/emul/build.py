@@ -17,7 +17,7 @@ def load():
     deps = [src] + glob.glob(os.path.join(ROOT, "bp_pp_amd", "csrc", "*.h"))
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"] if SANITIZE else ["-O2"]
-        subprocess.check_call(["g++", *flags, "-shared", "-fPIC", "-std=c++17", "-o", SO, src])
+        subprocess.check_call(["g++", *flags, "-shared", "-fPIC", "-std=c++17", "-pthread", "-o", SO, src])
     L = C.CDLL(SO)
     vp, sz, i32, cp = C.c_void_p, C.c_size_t, C.c_int, C.c_char_p
     L.emul_fb_table_entries.restype = sz
@@ -52,4 +52,5 @@ def load():
     L.emul_wnla_prove.argtypes = [vp, i32, i32, i32, cp, sz, sz, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.emul_circuit_prove.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, cp, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.emul_recip_prove.argtypes = [vp, i32, i32, i32, i32, i32, cp, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.emul_group_verify.argtypes = [i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, cp, sz, sz, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     return L

@@ -262,3 +262,48 @@ def test_every_sponge_position_in_one_batch():
         assert O.u64_proof_to_bytes(pr) == bytes(proofs[i]) and ser(tp) == bytes(after_prove[i])
         tv = t.clone()
         assert oproto.verify(O.pt_from_xy64(bytes(com[i])), pr, tv) and ser(tv) == bytes(after_verify[i])
+
+
+def test_invalid_state_does_not_disturb_its_wavefront():
+    """Per-proof isolation through the DEVICE entry point (the host variants refuse such a state up front): one pre-loaded state merlin
+    cannot be in (pos_begin = 200) sits in lane 0 -- the wavefront's first active lane, the leader of its position group -- among valid
+    per-proof states at the same byte position.  That lane is flagged and rejected; its transcript restarts from the context's base, at
+    ANOTHER position, and must not drag its neighbours there: they are accepted and come back with the prover's advanced states."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol, _capi, synth
+    from bp_pp_amd.transcript import Transcript
+    g, gv, hv = workload.split_generators(workload.generators())
+    n = 70                                                  # two wavefronts; the bad lanes are 0 (leader) and 64 + 3
+    ts = []
+    for j in range(n):
+        t = Transcript(synth.LABEL)
+        t.append_message(b"ctx", bytes([j]) * 37)           # same length => same sponge position, different contents
+        ts.append(t)
+    S = np.frombuffer(b"".join(t.state for t in ts), np.uint8).reshape(n, 203).copy()
+    assert len(set(S[:, 200].tolist())) == 1 and S[0, 200] != Transcript(b"").state[200]
+    x, s, rnd = synth.bulk_values(n, first=40), synth.bulk_blindings(n, first=40), synth.bulk_prover_randomness(n, first=40)
+    proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
+    try:
+        proofs, com, st, after = proto.prove_batch_transcript(x, s, rnd, S)
+        assert not st.any()
+        bad = S.copy()
+        bad[0, 201] = 200
+        bad[67, 201] = 200
+        dV, dP, dS = torch.from_numpy(com).cuda(), torch.from_numpy(proofs).cuda(), torch.from_numpy(bad).cuda()
+        dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dSt = torch.zeros(n, dtype=torch.int32, device="cuda")
+        dR = torch.zeros(1, dtype=torch.int32, device="cuda")
+        dO = torch.zeros((n, 203), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        _capi.check(_capi.lib().bppp_u64_verify_batch_transcript_device(proto._ctx, n, dS.data_ptr(), n, dV.data_ptr(), dP.data_ptr(),
+                                                                        dA.data_ptr(), dSt.data_ptr(), dR.data_ptr(), dO.data_ptr()))
+        proto.synchronize()
+        acc, vst, out = dA.cpu().numpy(), dSt.cpu().numpy(), dO.cpu().numpy()
+        good = np.ones(n, bool); good[[0, 67]] = False
+        assert acc[good].all() and not vst[good].any() and (out[good] == after[good]).all()
+        assert not acc[~good].any() and (vst[~good] == 1).all() and int(dR.item()) == 2
+    finally:
+        proto.close()
