@@ -18,8 +18,9 @@ Secondary objects (never `value`): configs[1] (2^16 proofs on one GPU), the opti
 
 Other workloads, each printing its own JSON line with `roofline` and `cpu_baseline`:
   --workload prove     BASELINE configs[3]: batch-prove 2^14 u64 values on one GPU (2262 algorithmic B/prove)
-  --workload recip256  BASELINE configs[4]'s shape: ReciprocalRangeProofProtocol (dim_nd 256, dim_np 16) batch verify
-                       (823 algorithmic B/verify)
+  --workload recip256  BASELINE configs[4]: ONE fixed batch of 2^18 ReciprocalRangeProofProtocol (dim_nd 256, dim_np 16) proofs
+                       split over the N GPUs like the headline metric (823 algorithmic B/verify)
+The default line carries reduced-size runs of both as the secondary objects `prove_2pow14` and `recip256_2pow15`.
 """
 import argparse
 import json
@@ -357,6 +358,20 @@ def run_verify(args):
                 dP[ti, to] = dP[ti, to] ^ 1
             torch.cuda.synchronize()
 
+    # BASELINE configs[3] and configs[4] at one GPU's size, so that the driver's default run records them too (their full lines:
+    # --workload prove, --workload recip256).  Same measurement code as those workloads, reduced cpu_baseline samples.
+    prove14 = recip15 = None
+    ok_extra = True
+    if world == 1 and not args.no_secondary:
+        import bench_other
+        keep = ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline", "kernels_ms_per_step", "cpu_baseline")
+        r, okp = bench_other.measure_prove(args, proto, gens, 1 << 14, cpu_baseline=not args.no_cpu_baseline, cpu_sample=2048)
+        prove14 = {k: r[k] for k in keep if k in r}
+        prove14["proofs_verify"] = okp
+        r, okr = bench_other.measure_recip256(args, 1 << 15, 16, cpu_baseline=not args.no_cpu_baseline, rlc=True)
+        recip15 = {k: r[k] for k in keep + ("rlc_mode", "accept_bits_ok", "device_bytes") if k in r}
+        ok_extra = okp and okr
+
     elapsed = max_over_ranks(elapsed)
     ok_all = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device="cuda")
     if dist_on:
@@ -413,6 +428,8 @@ def run_verify(args):
             "configs1_2pow16": cfg1,
             "rlc_mode": rlc,
             "host_buffer_path": host_path,
+            "prove_2pow14": prove14,
+            "recip256_2pow15": recip15,
             "setup_s": {"context_tables": t_ctx, "inputs_and_gpu_batch_prove": t_setup, "gpu_batch_prove_only": t_prove},
             "prover": {"proofs_per_s_device_buffers": n / t_prove, "note": "setup only; see --workload prove for BASELINE configs[3]"},
             "device_bytes": proto.device_bytes(),
@@ -425,7 +442,7 @@ def run_verify(args):
     proto.close()
     if dist_on:
         dist.destroy_process_group()
-    if not ok:
+    if not (ok and ok_extra):
         sys.exit(1)
 
 
@@ -435,7 +452,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["verify", "prove", "recip256"], default="verify")
-    ap.add_argument("--total-proofs", type=int, default=0, help="size of the fixed global batch (default: 2^20 verify, 2^14 prove, 2^15 recip256)")
+    ap.add_argument("--total-proofs", type=int, default=0, help="size of the fixed global batch (default: 2^20 verify, 2^14 prove, 2^18 recip256)")
     ap.add_argument("--fb-window-bits", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="proofs verified by the CPU baseline (rank 0, N=1): ~10-20 s of host work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -446,7 +463,7 @@ def main():
         run_verify(args)
     else:
         import bench_other
-        args.total_proofs = args.total_proofs or ((1 << 14) if args.workload == "prove" else (1 << 15))
+        args.total_proofs = args.total_proofs or ((1 << 14) if args.workload == "prove" else (1 << 18))
         (bench_other.run_prove if args.workload == "prove" else bench_other.run_recip256)(args)
 
 

@@ -78,6 +78,14 @@ class U64RangeProofGroup(_Group):
             raise ValueError("the u64 protocol has 16 + 32 generators")
         self._create(g, g_vec, h_vec, devices, fb_window_bits)
 
+    def protocol(self, rank: int = 0):
+        """Rank `rank`'s context as a U64RangeProofProtocol view (the group keeps ownership)."""
+        from .range_proof import U64RangeProofProtocol
+        ctx = self._capi.lib().bppp_group_ctx(self._grp, rank)
+        if not ctx:
+            raise ValueError("rank out of range")
+        return U64RangeProofProtocol.borrowed(ctx)
+
     def _host(self, commitments, proofs, cw, pw):
         import numpy as np
         commitments = np.ascontiguousarray(commitments, dtype=np.uint8).reshape(-1, cw)
@@ -154,7 +162,17 @@ class ReciprocalRangeProofGroup(_Group):
         if len(g_vec) != dim_nd or len(h_vec) != dim_nd + 10:
             raise ValueError("g_vec must hold dim_nd points and h_vec dim_nd + 10")
         self.dim_nd, self.dim_np = dim_nd, dim_np
+        self._ng, self._nh = len(g_vec) + len(g_vec_), len(h_vec) + len(h_vec_)
         self._create(g, list(g_vec) + list(g_vec_), list(h_vec) + list(h_vec_), devices, fb_window_bits)
+
+    def protocol(self, rank: int = 0):
+        """Rank `rank`'s context as a ReciprocalRangeProofProtocol (prove / commit / single-device verify on that GPU, over the
+        group's own tables); the group keeps ownership."""
+        from .wnla import ReciprocalRangeProofProtocol
+        ctx = self._capi.lib().bppp_group_ctx(self._grp, rank)
+        if not ctx:
+            raise ValueError("rank out of range")
+        return ReciprocalRangeProofProtocol.borrowed(self.dim_nd, self.dim_np, ctx, self._ng, self._nh)
 
     def verify_batch(self, label: bytes, commitments, proofs, rounds: int, nl: int, nn: int, rlc_seed: bytes = None):
         """Host buffers -> (accept[n] u8, status[n] i32, global reject count)."""

@@ -82,9 +82,17 @@ class U64RangeProofProtocol:
         _capi.check(_capi.lib().bppp_ctx_create_shared(C.byref(ctx), self._ctx))
         return type(self)._wrap(ctx, self.g, self.g_vec, self.h_vec, self.device, parent=self)
 
+    @classmethod
+    def borrowed(cls, ctx: int) -> "U64RangeProofProtocol":
+        """A view over a context owned elsewhere (a device group's rank context: bppp_group_ctx); close() leaves it alone."""
+        self = cls._wrap(C.c_void_p(ctx))
+        self._is_borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
-            _capi.lib().bppp_ctx_destroy(self._ctx)
+            if not getattr(self, "_is_borrowed", False):
+                _capi.lib().bppp_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
     def __del__(self):

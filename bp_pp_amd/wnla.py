@@ -33,9 +33,17 @@ class WeightNormLinearArgument:
         _capi.check(_capi.lib().bppp_wnla_ctx_create(C.byref(self._ctx), bytes(g), b"".join(g_vec), self.ng, b"".join(h_vec),
                                                      self.nh, device, fb_window_bits))
 
+    @classmethod
+    def borrowed(cls, ctx: int, ng: int, nh: int) -> "WeightNormLinearArgument":
+        """A view over a context somebody else owns (a device group's rank context: bppp_group_ctx); close() leaves it alone."""
+        self = cls.__new__(cls)
+        self.ng, self.nh, self._ctx, self._borrowed = ng, nh, C.c_void_p(ctx), True
+        return self
+
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
-            _capi.lib().bppp_ctx_destroy(self._ctx)
+            if not getattr(self, "_borrowed", False):
+                _capi.lib().bppp_ctx_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
     def __del__(self):
@@ -134,6 +142,14 @@ class ReciprocalRangeProofProtocol:
         self.dim_nd, self.dim_np = dim_nd, dim_np
         self._w = WeightNormLinearArgument(g, list(g_vec) + list(g_vec_), list(h_vec) + list(h_vec_), device, fb_window_bits)
 
+    @classmethod
+    def borrowed(cls, dim_nd: int, dim_np: int, ctx: int, ng: int, nh: int) -> "ReciprocalRangeProofProtocol":
+        """The protocol over a context owned elsewhere (bp_pp_amd.distributed.ReciprocalRangeProofGroup.protocol)."""
+        self = cls.__new__(cls)
+        self.dim_nd, self.dim_np = dim_nd, dim_np
+        self._w = WeightNormLinearArgument.borrowed(ctx, ng, nh)
+        return self
+
     def close(self):
         self._w.close()
 
@@ -221,6 +237,10 @@ class ReciprocalRangeProofProtocol:
 
     def synchronize(self) -> None:
         _capi.check(_capi.lib().bppp_ctx_synchronize(self._w._ctx))
+
+    def set_stream(self, hip_stream: int) -> None:
+        """Run this context's kernels on the caller's HIP stream (0 = back to the context's own)."""
+        _capi.check(_capi.lib().bppp_ctx_set_stream(self._w._ctx, hip_stream or None))
 
     def enable_timing(self, on: bool = True) -> None:
         _capi.check(_capi.lib().bppp_ctx_enable_timing(self._w._ctx, 1 if on else 0))
