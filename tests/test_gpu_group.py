@@ -117,3 +117,181 @@ def test_table_file_round_trip_and_shared_tables(batch, tmp_path):
         for p in (c, b, a):
             if p is not None:
                 p.close()
+
+
+def test_one_device_group_serves_every_sharded_form(batch, monkeypatch):
+    """RLC, SEC1 and caller-transcript verifies through the group (host and device buffers) equal the single-context entry points;
+    the RCCL accept-reduce really runs (one-rank communicator)."""
+    import torch
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol, wire
+    from bp_pp_amd.distributed import U64RangeProofGroup
+    from bp_pp_amd.transcript import Transcript
+    gens, V, P, expect = batch
+    g, gv, hv = workload.split_generators(gens)
+    monkeypatch.setenv("BPPP_FORCE_RCCL", "1")
+    grp = U64RangeProofGroup(g, gv, hv, [0], fb_window_bits=8)
+    single = grp.protocol(0)                      # the same context, through the single-device entry points
+    n = V.shape[0]
+    n_bad = int((expect == 0).sum())
+    seed = bytes(range(32))
+    try:
+        # RLC mode
+        acc, st, rej = grp.verify_batch(V, P, workload.LABEL, rlc_seed=seed)
+        a1, s1 = single.verify_batch_rlc(V, P, workload.LABEL, seed)
+        assert (acc == a1).all() and (st == s1).all() and (acc == expect).all() and rej == n_bad
+        dV, dP = torch.from_numpy(V).cuda(), torch.from_numpy(P).cuda()
+        dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dS = torch.zeros(n, dtype=torch.int32, device="cuda")
+        dR = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        grp.verify_batch_device(workload.LABEL, n, [dV.data_ptr()], [dP.data_ptr()], [dA.data_ptr()], [dS.data_ptr()], [dR.data_ptr()], rlc_seed=seed)
+        assert (dA.cpu().numpy() == expect).all() and int(dR.item()) == n_bad
+        # SEC1-compressed inputs
+        V33 = np.frombuffer(b"".join(wire.compress_point(bytes(v)) for v in V), np.uint8).reshape(n, 33)
+        P525 = np.zeros((n, 525), np.uint8)
+        ok_rows = [i for i in range(n) if i != 5]                      # row 5 holds an off-curve point: it has no SEC1 form
+        for i in ok_rows:
+            P525[i] = np.frombuffer(wire.abi_to_sec1(bytes(P[i])), np.uint8)
+        P525[5] = P525[4]
+        acc, st, rej = grp.verify_batch_sec1(V33, P525, workload.LABEL)
+        a1, s1 = single.verify_batch_sec1(V33, P525, workload.LABEL)
+        exp5 = expect.copy(); exp5[5] = 0                               # proof 4's bytes under commitment 5
+        assert (acc == a1).all() and (st == s1).all() and (acc == exp5).all() and rej == int((exp5 == 0).sum())
+        d33, d525 = torch.from_numpy(V33).cuda(), torch.from_numpy(P525).cuda()
+        dA.zero_(); dR.fill_(-7)
+        torch.cuda.synchronize()
+        grp.verify_batch_sec1_device(workload.LABEL, n, [d33.data_ptr()], [d525.data_ptr()], [dA.data_ptr()], [dS.data_ptr()], [dR.data_ptr()])
+        assert (dA.cpu().numpy() == exp5).all() and int(dR.item()) == int((exp5 == 0).sum())
+        # the caller's transcripts: Transcript::new(label) shared by the batch must reproduce the label entry point, and the
+        # per-proof form must give each proof its own advanced state
+        t0 = Transcript(workload.LABEL)
+        acc, st, out, rej = grp.verify_batch_transcripts(np.frombuffer(t0.state, np.uint8), V, P)
+        a1, s1, o1 = single.verify_batch_transcript(V, P, t0)
+        assert (acc == a1).all() and (acc == expect).all() and (st == s1).all() and (out == o1).all() and rej == n_bad
+        S = np.tile(np.frombuffer(t0.state, np.uint8), (n, 1))
+        acc2, st2, out2, rej2 = grp.verify_batch_transcripts(S, V, P)
+        assert (acc2 == acc).all() and (out2 == out).all() and rej2 == rej
+        dSt_in, dO = torch.from_numpy(S).cuda(), torch.zeros((n, 203), dtype=torch.uint8, device="cuda")
+        dA.zero_(); dR.fill_(-7)
+        torch.cuda.synchronize()
+        grp.verify_batch_transcripts_device(n, [dSt_in.data_ptr()], n, [dV.data_ptr()], [dP.data_ptr()], [dA.data_ptr()], [dS.data_ptr()],
+                                            [dR.data_ptr()], [dO.data_ptr()])
+        assert (dA.cpu().numpy() == expect).all() and int(dR.item()) == n_bad and (dO.cpu().numpy() == out).all()
+    finally:
+        single.close()
+        grp.close()
+
+
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_injected_fault_returns_the_error_and_the_group_stays_usable(batch, force_rccl, monkeypatch):
+    """A rank that fails before the collective (here: injected; in production an out-of-memory workspace) makes the sharded call
+    return that rank's error -- within the test's timeout, i.e. nobody waits in an all-reduce -- and the next call works."""
+    import workload
+    from bp_pp_amd import BpppError, _capi
+    from bp_pp_amd.distributed import U64RangeProofGroup
+    gens, V, P, expect = batch
+    g, gv, hv = workload.split_generators(gens)
+    if force_rccl:
+        monkeypatch.setenv("BPPP_FORCE_RCCL", "1")
+    else:
+        monkeypatch.delenv("BPPP_FORCE_RCCL", raising=False)
+    grp = U64RangeProofGroup(g, gv, hv, [0], fb_window_bits=8)
+    try:
+        grp.set_option("inject_fault_rank", 0)
+        with pytest.raises(BpppError) as e:
+            grp.verify_batch(V, P, workload.LABEL)
+        assert e.value.code == _capi.ERR_NOMEM and "injected" in str(e.value)
+        acc, st, rej = grp.verify_batch(V, P, workload.LABEL)            # the fault was one-shot; the group is intact
+        assert (acc == expect).all() and rej == int((expect == 0).sum())
+        with pytest.raises(BpppError):
+            grp.set_option("inject_fault_rank", 1)                       # no such rank
+        grp.set_option("rlc_superchunk", 256)                            # context options reach every rank
+        acc, st, rej = grp.verify_batch(V, P, workload.LABEL, rlc_seed=bytes(32))
+        assert (acc == expect).all()
+    finally:
+        grp.close()
+
+
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_reciprocal_group_equals_single_context(force_rccl, monkeypatch):
+    """bppp_wnla_group_create + bppp_reciprocal_verify_batch[_rlc]_sharded[_device] (BASELINE configs[4]'s path) on one device: equal
+    to the single-context verifier and to the oracle, exact and RLC, host and device buffers, ragged and empty batches."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import recip_cases
+    from bp_pp_amd.distributed import ReciprocalRangeProofGroup
+    if force_rccl:
+        monkeypatch.setenv("BPPP_FORCE_RCCL", "1")
+    else:
+        monkeypatch.delenv("BPPP_FORCE_RCCL", raising=False)
+    nd, npp, B = 32, 16, 21
+    case = recip_cases.make(nd, npp, B)
+    grp = ReciprocalRangeProofGroup(nd, npp, case["g"], case["gv"], case["hv"], case["gv_"], case["hv_"], [0], fb_window_bits=8)
+    single = grp.protocol(0)
+    try:
+        shape = (case["rounds"], case["nl"], case["nn"])
+        P, com = case["proofs"].copy(), case["commitments"].copy()
+        P[0, -1] ^= 1
+        P[7, 256 + 64 * case["rounds"] + 5] ^= 0x40                      # a round point leaves the curve
+        com[12] = case["commitments"][13]
+        exp = np.array([1 if recip_cases.oracle_verify(case, bytes(com[b]), bytes(P[b])) == 1 else 0 for b in range(B)], np.uint8)
+        assert exp.sum() == B - 3
+        acc, st, rej = grp.verify_batch(case["label"], com, P, *shape)
+        a1, s1 = single.verify_batch(case["label"], com, P, *shape)
+        assert (acc == a1).all() and (st == s1).all() and (acc == exp).all() and rej == 3 and st[7] == 1
+        acc, st, rej = grp.verify_batch(case["label"], com, P, *shape, rlc_seed=bytes(range(32)))
+        assert (acc == exp).all() and (st == s1).all() and rej == 3
+        for m in (0, 1, 9):
+            a, s, r = grp.verify_batch(case["label"], com[:m], P[:m], *shape)
+            assert a.tolist() == exp[:m].tolist() and r == int((exp[:m] == 0).sum())
+        dV, dP = torch.from_numpy(com).cuda(), torch.from_numpy(P).cuda()
+        dA = torch.zeros(B, dtype=torch.uint8, device="cuda")
+        dS = torch.zeros(B, dtype=torch.int32, device="cuda")
+        dR = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for seed in (None, bytes(32)):
+            dA.zero_(); dR.fill_(-7)
+            torch.cuda.synchronize()
+            grp.verify_batch_device(case["label"], B, [dV.data_ptr()], [dP.data_ptr()], *shape, [dA.data_ptr()], [dS.data_ptr()], [dR.data_ptr()],
+                                    rlc_seed=seed)
+            assert (dA.cpu().numpy() == exp).all() and int(dR.item()) == 3 and (dS.cpu().numpy() == s1).all()
+        grp.set_option("inject_fault_rank", 0)
+        with pytest.raises(Exception):
+            grp.verify_batch(case["label"], com, P, *shape)
+        acc, _, rej = grp.verify_batch(case["label"], com, P, *shape)
+        assert (acc == exp).all() and rej == 3
+    finally:
+        single.close()
+        grp.close()
+
+
+def test_damaged_table_file_is_refused(batch, tmp_path):
+    """The table artefact carries a checksum over generators and table body: a flipped byte anywhere, a truncated file or a generator
+    moved off the curve is refused at load time instead of yielding a verifier with wrong bases."""
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    gens, V, P, expect = batch
+    g, gv, hv = workload.split_generators(gens)
+    a = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
+    path = str(tmp_path / "t.bin")
+    try:
+        a.save_tables(path)
+        good = open(path, "rb").read()
+        b = U64RangeProofProtocol.from_tables(path, device=0)
+        acc, _ = b.verify_batch(V, P, workload.LABEL)
+        b.close()
+        assert (acc == expect).all()
+        hdr = 56                                                        # magic, 6 x u32, 3 x u64
+        for off in (hdr + 3, hdr + 49 * 80 + 12345, len(good) - 1):    # a generator limb, the table body, the last byte
+            bad = bytearray(good)
+            bad[off] ^= 0x04
+            open(path, "wb").write(bad)
+            with pytest.raises(Exception):
+                U64RangeProofProtocol.from_tables(path, device=0)
+        open(path, "wb").write(good[:-64])
+        with pytest.raises(Exception):
+            U64RangeProofProtocol.from_tables(path, device=0)
+    finally:
+        a.close()

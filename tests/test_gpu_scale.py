@@ -115,6 +115,73 @@ def test_recip256_prove_and_verify_at_batch_scale(torch_mod):
         proto.close()
 
 
+def test_recip256_16bit_windows_at_the_benchmarked_size(torch_mod):
+    """The configuration `bench.py --workload recip256` measures, tested as it is benchmarked: the (256, 16) shape with 16-bit unsigned
+    windows (769 bases x 16 windows x 65,535 entries = 52 GB of tables) at 2^15 proofs -- one GPU's share of BASELINE configs[4] --
+    through a one-device bppp_wnla_group (the sharded entry points) AND the single-context entry points on the same context:
+    prover bytes equal the oracle's on a 48-proof sample, accept bits equal the expectation over the whole batch (1/256 corrupted by
+    the bench's rule + four other kinds of damage), the oracle agrees on the sample, exact == RLC == sharded, reject count == damage."""
+    torch = torch_mod
+    import bench_other as BO
+    import recip_cases
+    from bp_pp_amd.distributed import ReciprocalRangeProofGroup
+    nd, npp, n, n_or = BO.RECIP_ND, BO.RECIP_NP, 1 << 15, 48
+    gens5 = BO.recip256_generators()
+    grp = ReciprocalRangeProofGroup(nd, npp, *gens5, [0], fb_window_bits=16)
+    proto = grp.protocol(0)
+    try:
+        assert proto.device_bytes() > 50e9                                  # the 52 GB tables, not a smaller stand-in
+        dV, dP, expect, shape, _, head = BO.recip256_resident_batch(torch, proto, 0, n)
+        assert shape == (8, 2, 1) and int((expect == 0).sum()) == n // 256
+        # the checker: reference-shaped C prover on the first n_or instances, same generators and inputs
+        ocase = recip_cases.make_bulk(nd, npp, n_or, n_oracle=n_or, label=BO.RECIP_LABEL, generators=gens5,
+                                      inputs={k: np.ascontiguousarray(head[k][:n_or]) for k in ("x", "s", "digits", "m", "rnd")})
+        assert (head["com"][:n_or] == ocase["commitments"]).all() and (head["proofs"][:n_or] == ocase["proofs"]).all()
+        # more damage, inside the oracle sample and spread over the batch (different wavefronts and chunks)
+        P, V = dP.cpu().numpy(), dV.cpu().numpy()
+        extra = [5, 17, 33, 41] + list(range(1000, n, 4099))
+        for k, i in enumerate(extra):
+            kind = k % 4
+            if kind == 0:
+                P[i, 64 * (4 + (k % 16)) + 9] ^= 0x20                       # a round point's x
+            elif kind == 1:
+                V[i] = V[(i + 1) % n]                                       # someone else's commitment
+            elif kind == 2:
+                P[i, 192:256] = P[i, 0:64]                                  # c_s := c_l
+            else:
+                P[i, -40] ^= 0x01                                           # l1
+            expect[i] = 0
+        dV, dP = torch.from_numpy(V).cuda(), torch.from_numpy(P).cuda()
+        dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dS = torch.zeros(n, dtype=torch.int32, device="cuda")
+        dR = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        n_bad = int((expect == 0).sum())
+        proto.verify_batch_device(BO.RECIP_LABEL, n, dV.data_ptr(), dP.data_ptr(), *shape, dA.data_ptr(), dS.data_ptr())
+        proto.synchronize()
+        acc, st = dA.cpu().numpy(), dS.cpu().numpy()
+        assert (acc == expect).all() and ((st != 0) <= (expect == 0)).all()
+        for i in range(n_or):                                               # the oracle on the sample, damaged rows included
+            rc = recip_cases.oracle_verify(ocase, bytes(V[i]), bytes(P[i]))
+            assert int(acc[i]) == (1 if rc == 1 else 0) and (int(st[i]) != 0) == (rc < 0), (i, rc)
+        for seed in (None, bytes(range(32))):                               # sharded entry points, exact and RLC
+            dA.zero_(); dR.fill_(-7)
+            torch.cuda.synchronize()
+            grp.verify_batch_device(BO.RECIP_LABEL, n, [dV.data_ptr()], [dP.data_ptr()], *shape, [dA.data_ptr()], [dS.data_ptr()], [dR.data_ptr()],
+                                    rlc_seed=seed)
+            assert (dA.cpu().numpy() == expect).all() and int(dR.item()) == n_bad and (dS.cpu().numpy() == st).all()
+        dA.zero_()
+        proto.verify_batch_rlc_device(BO.RECIP_LABEL, n, dV.data_ptr(), dP.data_ptr(), *shape, dA.data_ptr(), dS.data_ptr(), bytes(32))
+        proto.synchronize()
+        assert (dA.cpu().numpy() == expect).all()
+        # host-buffer form of the sharded call on a ragged slice
+        a, s_, r = grp.verify_batch(BO.RECIP_LABEL, V[:3001], P[:3001], *shape)
+        assert (a == expect[:3001]).all() and r == int((expect[:3001] == 0).sum())
+    finally:
+        proto.close()
+        grp.close()
+
+
 def test_u64_verify_beyond_one_internal_part(torch_mod):
     """More proofs than the default `max_batch` (2^21) in ONE call: the library runs the batch as consecutive parts with a bounded
     workspace (include/bppp.h, bppp_ctx_set_option).  2^21 + 12,345 proofs resident: every honest proof accepted, every corrupted
