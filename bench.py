@@ -38,10 +38,25 @@ ALGO_BYTES_PER_RECIP256 = 21 * 33 + 96 + 33 + 1     # 823 B (confi
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8.0 TB/s spec
 # VALU issue ceilings for the 256-bit integer mix (G wave-instructions/s per chip):
 #   datasheet: 1024 SIMDs x 2.4 GHz; a wave64 full-rate op issues in 2 cycles, v_mad_u64_u32 / 64-bit shifts in 4
-#   measured : tools/intbench.hip on this chip (profiles/r01_a_intbench.txt): 29 T lane-ops/s for v_mad_u64_u32, 67 T for add/logic
+#   measured : tools/ratebench (built by __graft_entry__.build()) run by THIS bench process on THIS box before the timed region:
+#              lane-ops/s of v_mad_u64_u32 and of add/shift/xor at 8 waves per SIMD, with the shader clock the chip held meanwhile
 DATASHEET_SIMD_HZ = 1024 * 2.4e9
-MEASURED_MAD_LANE_OPS = 29e12
-MEASURED_ADD_LANE_OPS = 67e12
+_SESSION_RATES = None
+
+
+def session_rates():
+    """Issue rates of this box, measured now (a child process: tools/ratebench, ~1 s).  None if the tool is missing or fails --
+    roofline_valu then reports the datasheet ceiling only; it never falls back to another session's numbers."""
+    global _SESSION_RATES
+    if _SESSION_RATES is None:
+        import subprocess
+        exe = os.path.join(ROOT, "tools", "ratebench")
+        try:
+            out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+            _SESSION_RATES = json.loads(out.stdout) if out.returncode == 0 else {}
+        except Exception:
+            _SESSION_RATES = {}
+    return _SESSION_RATES or None
 
 
 def _load_json(path):
@@ -66,8 +81,8 @@ def valu_roofline(kernel, avg_ms, n_proofs, lanes_per_proof):
     kernel's own instruction mix.  The mix -- the fraction of half-rate instructions (v_mad_u64_u32, 64-bit shifts / adds) -- is
     MEASURED per kernel: SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU from the same PMC passes (profiles/pmc_valu.json), with the static
     count of the shipped code object (tools/isa_mix.py -> profiles/isa_mix.json) printed beside it as a cross-check.  Two peaks:
-    datasheet (1024 SIMDs x 2.4 GHz, 2 cycles per full-rate and 4 per half-rate wave64 instruction) and this chip's
-    micro-benchmark (tools/intbench.hip, which includes the clock the chip actually holds under load)."""
+    datasheet (1024 SIMDs x 2.4 GHz, 2 cycles per full-rate and 4 per half-rate wave64 instruction) and this box's own
+    micro-benchmark, run by this process (session_rates: tools/ratebench, which also reports the shader clock the chip held)."""
     pv = _load_json(os.path.join(ROOT, "profiles", "pmc_valu.json")) or {}
     mix = _load_json(os.path.join(ROOT, "profiles", "isa_mix.json")) or {}
     kernel, lanes_per_proof = launched_kernel(kernel, n_proofs, lanes_per_proof)
@@ -81,12 +96,16 @@ def valu_roofline(kernel, avg_ms, n_proofs, lanes_per_proof):
     insts = per_wave * waves
     ach = insts / (avg_ms * 1e-3) / 1e9
     peak_ds = DATASHEET_SIMD_HZ / (half * 4 + (1 - half) * 2) / 1e9
-    peak_ms = 1.0 / (half / (MEASURED_MAD_LANE_OPS / 64) + (1 - half) / (MEASURED_ADD_LANE_OPS / 64)) / 1e9
+    rates = session_rates()
+    peak_ms = None
+    if rates:
+        peak_ms = 1.0 / (half / (rates["mad_u64_u32"] / 64) + (1 - half) / (rates["add_xor_shift"] / 64)) / 1e9
     return {"kernel": kernel, "wave_insts_per_launch": insts, "achieved": ach, "unit": "G wave-instructions/s",
             "half_rate_inst_frac": half, "half_rate_inst_frac_source": "SQ_INSTS_VALU_INT64 / SQ_INSTS_VALU (rocprofv3 --pmc)" if "int64_frac_of_valu" in kv else "static ISA count",
             "half_rate_inst_frac_static_isa": half_static,
             "peak_datasheet": peak_ds, "frac_of_datasheet": ach / peak_ds,
-            "peak_microbench": peak_ms, "frac_of_microbench": ach / peak_ms,
+            "peak_microbench": peak_ms, "frac_of_microbench": (ach / peak_ms) if peak_ms else None,
+            "peak_microbench_session": dict(rates, source="tools/ratebench run by this bench process on this box, before the timed region") if rates else None,
             "valu_active_frac_of_wave_cycles": kv.get("SQ_ACTIVE_INST_VALU_frac_of_wave_cycles"),
             "issue_stall_frac_of_wave_cycles": kv.get("SQ_WAIT_INST_ANY_frac_of_wave_cycles"),
             "wait_frac_of_wave_cycles": kv.get("SQ_WAIT_ANY_frac_of_wave_cycles")}
@@ -217,6 +236,8 @@ def run_verify(args):
     total = args.total_proofs
     lo, hi = shard_range(total, rank, world)
     n = hi - lo
+    if rank == 0:
+        session_rates()                  # the chip's issue rates and clock, measured now, while the GPU is otherwise idle
     t0 = time.time()
     proto = U64RangeProofProtocol(g, gv, hv, device=local_rank, fb_window_bits=args.fb_window_bits)
     proto.synchronize()

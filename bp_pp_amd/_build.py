@@ -107,3 +107,14 @@ def build(force: bool = False, verbose: bool = False, so: str = SO, objdir: str 
     subprocess.check_call(link)
     os.replace(so + ".tmp", so)
     return so
+
+
+def build_tool(name: str) -> str:
+    """hipcc one stand-alone measurement program tools/<name>.hip -> tools/<name> (git-ignored; travels to the GPU box)."""
+    src, exe = os.path.join(ROOT, "tools", name + ".hip"), os.path.join(ROOT, "tools", name)
+    if os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(src):
+        return exe
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-o", exe + ".tmp", src])
+    os.replace(exe + ".tmp", exe)
+    return exe

@@ -106,7 +106,9 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     // C0 = variable-base half (window tables of the proof points, then the shared-doubling sum: one lane per proof, 1 wave
     // per SIMD) + fixed-base half (8 lanes per proof): independent, so they run concurrently on two streams and share the
     // SIMDs; round 1 adds the halves.
-    hipStream_t a = c->serial_c0 ? s : c->aux_stream;   // diagnostic: un-overlapped kernel times
+    // with per-kernel timing on, the two halves run back to back so that the kernel times add up to the step (overlapped, each
+    // half's events also cover the other's share of the SIMDs; the overlap itself buys nothing at 2 waves/SIMD: DESIGN.md 4)
+    hipStream_t a = (c->serial_c0 || c->timing) ? s : c->aux_stream;
     LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
