@@ -16,6 +16,7 @@ static void read_diagnostics(bppp_ctx* c) {
     if (const char* e = std::getenv("BPPP_FB_ONE_LANE")) c->fb_one_lane_mode = e[0] == '0' ? 0 : 1;
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
+    c->no_fused_final = std::getenv("BPPP_NO_FUSED_FINAL") != nullptr;            // final scalars in their own kernel at every batch size
 }
 
 extern "C" {

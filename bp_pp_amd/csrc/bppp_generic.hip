@@ -40,12 +40,12 @@ struct TxDev {
     }
 };
 // fast variable-base path of the generic verifiers' rounds: per instance 2 x rounds window tables (16 entries of 64 B per point), the
-// running products of their build (14 per point) and the decoded round points -- 1.2 KB + 0.55 KB + 64 B per point, grow-only
+// running products of their build (BPPP_TSCR_PER_POINT per point) and the decoded round points -- 1.2 KB + 0.55 KB + 64 B per point, grow-only
 static int wnla_fast_setup(bppp_ctx* c, WnlaWs& w, size_t n, size_t rounds) {
     w.atab = nullptr; w.tscr = nullptr; w.rpts = nullptr;
     if (rounds == 0 || c->generic_slow_rounds) return BPPP_OK;
     const size_t np = 2 * rounds;
-    const size_t b_tab = align16(np * 16 * sizeof(apt_packed) * n), b_scr = align16(14 * np * 10 * sizeof(u32) * n), b_pts = align16(np * 16 * sizeof(u32) * n);
+    const size_t b_tab = align16(np * 16 * sizeof(apt_packed) * n), b_scr = align16((size_t)BPPP_TSCR_PER_POINT * np * 10 * sizeof(u32) * n), b_pts = align16(np * 16 * sizeof(u32) * n);
     const size_t need = b_tab + b_scr + b_pts;
     if (need > c->gtab_bytes) {
         if (c->d_gtab) { (void)hipFree(c->d_gtab); c->d_gtab = nullptr; c->gtab_bytes = 0; }

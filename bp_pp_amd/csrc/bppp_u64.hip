@@ -132,9 +132,12 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         else if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
         else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
     }
-    LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    // exact mode on one lane per proof forms the 49 base-case scalars inside the final check; every other form takes them from fsc
+    const bool fused_final = !rlc_seed && fb_one_lane && !c->no_fused_final;
+    if (!fused_final) LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     if (!rlc_seed) {
-        if (fb_one_lane) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+        if (fused_final) LAUNCH(K_FINAL_CHECK, k_verify_final_check_fused<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+        else if (fb_one_lane) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
         else LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
         LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
     } else {

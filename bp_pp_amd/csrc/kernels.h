@@ -90,6 +90,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g2(bppp::VerifyWs w
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_l1(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_fused(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(bppp::VerifyWs ws, int* reject_count);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_export_states(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(bppp::VerifyWs ws, bppp::RlcWs r);

@@ -63,7 +63,7 @@ struct VerifyWs {
     u32* fsc;                    // [49*8][N]
     pt_slot* straus;             // [N][5][9]  (generic WNLA / reciprocal paths)
     apt_packed* atab;            // [13][2][8][N] (entry-major, see atab_of) affine multiples 1..8 of the 13 proof points, and of their GLV images (beta x, y)
-    u32* tscr;                   // [78*10][N] scratch of verify_tables: running products of the slope denominators
+    u32* tscr;                   // [BPPP_TSCR_FE * 10][N] scratch of verify_tables: running products of the slope denominators
     const apt_packed* fb_table;  // [49][nwin][2^W - 1]
     int fb_w;                    // window bits: 4, 8 or 16
     strobe base;                 // Transcript::new(label)
@@ -716,13 +716,7 @@ HD void atab_store(atab_ref tb, int e, const apt& a, const fe& beta, bool identi
 // No exceptional cases arise: the group has prime order n > 8, so for a point P != O none of P .. 8P is O, 2y != 0, and the
 // additions jP + P (j = 2, 4) and 4P + 3P never meet equal x.  P = O (the (0, 0) sentinel, also what a malformed proof's
 // points are replaced by) gives zero denominators: they are replaced by 1 and every multiple is stored as O.
-#if BPPP_VWIN == 5
-#define BPPP_TSCR_FE 182  // running products: levels 1 and 3 share slots 0..51 (13, then 52), level 2 lives in 52..77 (26), level 4 in 78..181 (104)
-#else
-#define BPPP_TSCR_FE 78   // running products: levels 1 and 3 share slots 0..51 (13, then 52), level 2 lives in 52..77 (26)
-#endif
-#define BPPP_TSCR_L2 52
-#define BPPP_TSCR_L4 78
+#define BPPP_TSCR_FE (5 * BPPP_VPOINTS)   // running products per proof (BPPP_TSCR_PER_POINT below): 65 field elements, was 182 with one per denominator
 struct aff_src { fe x, y; };
 HD void aff_ld(aff_src& r, atab_ref tb, int e) {   // multiple e (1..8) of the point whose table is tb
     const apt_packed k = tb[e - 1];
@@ -772,10 +766,36 @@ HD void aff_pop(fe& dinv, const u32* tscr, size_t N, size_t t, int slot, fe& inv
     fe_mul(dinv, inv, pre);
     fe_mul(inv, inv, den);
 }
+// ---- blocks of four denominators (levels 3 and 4): ONE running product per block instead of one per denominator.  The running
+// products are the table builder's scratch traffic (written in one pass, read back in the next, through HBM: at one lane per proof
+// nothing of that size stays on chip), so a block costs a quarter of the stores and loads for three more multiplications when it is
+// unwound (the block product is re-formed from the denominators, which the unwinding pass has in registers anyway).
+HD void aff_push_block(u32* tscr, size_t N, size_t t, int slot, fe& run, const fe& block_product) {
+    ws_st_fe(tscr, N, t, slot, run);
+    fe_mul(run, run, block_product);
+}
+// di[k] = 1 / d[k] for the block pushed at `slot`; inv (the inverse of everything not yet unwound) loses the block
+HD void aff_pop_block(fe di[4], const fe d[4], const u32* tscr, size_t N, size_t t, int slot, fe& inv) {
+    fe t01, t23, B, pre, q;
+    fe_mul(t01, d[0], d[1]);
+    fe_mul(t23, d[2], d[3]);
+    fe_mul(B, t01, t23);
+    ws_ld_fe(pre, tscr, N, t, slot, 1);
+    fe_mul(q, inv, pre);                 // 1 / (d0 d1 d2 d3)
+    fe_mul(inv, inv, B);
+    fe_mul(B, q, t23);                   // 1 / (d0 d1)
+    fe_mul(q, q, t01);                   // 1 / (d2 d3)
+    fe_mul(di[0], B, d[1]);
+    fe_mul(di[1], B, d[0]);
+    fe_mul(di[2], q, d[3]);
+    fe_mul(di[3], q, d[2]);
+}
 // Window tables of NP points per instance (the u64 verifier's 13 proof points; the generic WNLA verifier's 2 x rounds round points):
-// pts = the points in packed affine words [NP * 16][N], tscr = 14 NP running products [14 NP * 10][N], tab = the instance's table view.
+// pts = the points in packed affine words [NP * 16][N], tscr = BPPP_TSCR_PER_POINT NP running products [.. * 10][N], tab = the
+// instance's table view.
+#define BPPP_TSCR_PER_POINT 5    // level 1: 1 (slots 0 .. NP, re-used by level 3: 1 block) | level 2: 2 | level 4: 2 blocks
 HD void affine_tables_build(const atab_ref tab, u32* tscr, const u32* pts, size_t N, size_t t, const int NP) {
-    const int L2 = 4 * NP, L4 = 6 * NP;      // running products: levels 1 and 3 share slots 0 .. 4 NP, level 2 lives in 4 NP .. 6 NP, level 4 in 6 NP .. 14 NP
+    const int L2 = NP, L4 = 3 * NP;          // running products: levels 1 and 3 share slots 0 .. NP, level 2 lives in NP .. 3 NP, level 4 in 3 NP .. 5 NP
     (void)L4;
     fe run, inv, beta, one, d, dinv;
     fe_set_u32(one, 1);
@@ -815,7 +835,7 @@ HD void affine_tables_build(const atab_ref tab, u32* tscr, const u32* pts, size_
         aff_push(tscr, N, t, q + 1, run, d);
     }
     fe_inv(inv, run);
-    // ---- pass C (up): 4P, 3P; level-3 denominators x_4P - x_P (5P), 2 y_3P (6P), x_4P - x_3P (7P), 2 y_4P (8P)
+    // ---- pass C (up): 4P, 3P; level-3 denominators x_4P - x_P (5P), 2 y_3P (6P), x_4P - x_3P (7P), 2 y_4P (8P): one block per point
     fe_set_u32(run, 1);
 #pragma nounroll
     for (int p = 0; p < NP; p++) {
@@ -837,17 +857,18 @@ HD void affine_tables_build(const atab_ref tab, u32* tscr, const u32* pts, size_
         aff_src a3, a4;
         aff_take(a3, P3);
         aff_take(a4, P4);
-        aff_den_add(d, a4, a, pid, one);
-        aff_push(tscr, N, t, 4 * p, run, d);
+        fe bp;
+        aff_den_add(bp, a4, a, pid, one);
         aff_den_dbl(d, a3, pid, one);
-        aff_push(tscr, N, t, 4 * p + 1, run, d);
+        fe_mul(bp, bp, d);
         aff_den_add(d, a4, a3, pid, one);
-        aff_push(tscr, N, t, 4 * p + 2, run, d);
+        fe_mul(bp, bp, d);
         aff_den_dbl(d, a4, pid, one);
-        aff_push(tscr, N, t, 4 * p + 3, run, d);
+        fe_mul(bp, bp, d);
+        aff_push_block(tscr, N, t, p, run, bp);
     }
     fe_inv(inv, run);
-    // ---- pass D (down): 8P, 7P, 6P, 5P  [5-bit windows: + level-4 denominators for 9P .. 16P]
+    // ---- pass D (down): 5P, 6P, 7P, 8P  [5-bit windows: + level-4 denominators for 9P .. 16P, two blocks per point]
 #if BPPP_VWIN == 5
     fe_set_u32(run, 1);
 #endif
@@ -859,71 +880,85 @@ HD void affine_tables_build(const atab_ref tab, u32* tscr, const u32* pts, size_
         aff_ld(a3, tb, 3);
         aff_ld(a4, tb, 4);
         const bool pid = fe_is_zero(a.x) & fe_is_zero(a.y);
-        apt R8, R;
-        aff_den_dbl(d, a4, pid, one);
-        aff_pop(dinv, tscr, N, t, 4 * p + 3, inv, d);
-        aff_dbl(R8, a4, dinv);
-        atab_store(tb, 8, R8, beta, pid);
+        fe dd[4], di[4];
+        aff_den_add(dd[0], a4, a, pid, one);      // 5P = 4P + P
+        aff_den_dbl(dd[1], a3, pid, one);         // 6P = 2 . 3P
+        aff_den_add(dd[2], a4, a3, pid, one);     // 7P = 4P + 3P
+        aff_den_dbl(dd[3], a4, pid, one);         // 8P = 2 . 4P
+        aff_pop_block(di, dd, tscr, N, t, p, inv);
+        apt R;
 #if BPPP_VWIN == 5
-        // level 4 needs 8P against 7P, 5P, 3P, P (odd multiples 15, 13, 11, 9) and the doublings of 8P, 7P, 6P, 5P
-        aff_src a8, ax;
-        aff_take(a8, R8);
-        const int q4 = L4 + 8 * p;
-        aff_den_dbl(d, a8, pid, one);       aff_push(tscr, N, t, q4 + 7, run, d);     // 16P = 2 . 8P
+        // level 4: 8P against P, 3P, 5P, 7P (9P, 11P, 13P, 15P: block "odd") and the doublings of 5P .. 8P (10P .. 16P: block "even")
+        fe x8, bo, be;
+        aff_src ax;
 #endif
-        aff_den_add(d, a4, a3, pid, one);
-        aff_pop(dinv, tscr, N, t, 4 * p + 2, inv, d);
-        aff_add(R, a4, a3, dinv);
+        aff_dbl(R, a4, di[3]);
+        atab_store(tb, 8, R, beta, pid);
+#if BPPP_VWIN == 5
+        aff_take(ax, R);
+        x8 = ax.x;
+        aff_den_dbl(be, ax, pid, one);                                          // 16P = 2 . 8P
+        fe_sub_m<1>(bo, x8, a.x);  fe_cmov(bo, pid, one);                       //  9P = 8P + P
+        fe_sub_m<1>(d, x8, a3.x);  fe_cmov(d, pid, one);  fe_mul(bo, bo, d);    // 11P = 8P + 3P
+#endif
+        aff_add(R, a4, a3, di[2]);
         atab_store(tb, 7, R, beta, pid);
 #if BPPP_VWIN == 5
         aff_take(ax, R);
-        aff_den_add(d, a8, ax, pid, one);   aff_push(tscr, N, t, q4 + 6, run, d);     // 15P = 8P + 7P
-        aff_den_dbl(d, ax, pid, one);       aff_push(tscr, N, t, q4 + 5, run, d);     // 14P = 2 . 7P
+        fe_sub_m<1>(d, x8, ax.x);  fe_cmov(d, pid, one);  fe_mul(bo, bo, d);    // 15P = 8P + 7P
+        aff_den_dbl(d, ax, pid, one);                     fe_mul(be, be, d);    // 14P = 2 . 7P
 #endif
-        aff_den_dbl(d, a3, pid, one);
-        aff_pop(dinv, tscr, N, t, 4 * p + 1, inv, d);
-        aff_dbl(R, a3, dinv);
+        aff_dbl(R, a3, di[1]);
         atab_store(tb, 6, R, beta, pid);
 #if BPPP_VWIN == 5
         aff_take(ax, R);
-        aff_den_dbl(d, ax, pid, one);       aff_push(tscr, N, t, q4 + 3, run, d);     // 12P = 2 . 6P
+        aff_den_dbl(d, ax, pid, one);                     fe_mul(be, be, d);    // 12P = 2 . 6P
 #endif
-        aff_den_add(d, a4, a, pid, one);
-        aff_pop(dinv, tscr, N, t, 4 * p, inv, d);
-        aff_add(R, a4, a, dinv);
+        aff_add(R, a4, a, di[0]);
         atab_store(tb, 5, R, beta, pid);
 #if BPPP_VWIN == 5
         aff_take(ax, R);
-        aff_den_add(d, a8, ax, pid, one);   aff_push(tscr, N, t, q4 + 4, run, d);     // 13P = 8P + 5P
-        aff_den_dbl(d, ax, pid, one);       aff_push(tscr, N, t, q4 + 1, run, d);     // 10P = 2 . 5P
-        aff_den_add(d, a8, a3, pid, one);   aff_push(tscr, N, t, q4 + 2, run, d);     // 11P = 8P + 3P
-        aff_den_add(d, a8, a, pid, one);    aff_push(tscr, N, t, q4 + 0, run, d);     //  9P = 8P + P
+        fe_sub_m<1>(d, x8, ax.x);  fe_cmov(d, pid, one);  fe_mul(bo, bo, d);    // 13P = 8P + 5P
+        aff_den_dbl(d, ax, pid, one);                     fe_mul(be, be, d);    // 10P = 2 . 5P
+        aff_push_block(tscr, N, t, L4 + 2 * p, run, bo);
+        aff_push_block(tscr, N, t, L4 + 2 * p + 1, run, be);
 #endif
     }
 #if BPPP_VWIN == 5
     fe_inv(inv, run);
-    // ---- pass E (up): 9P .. 16P, unwinding in the reverse of the order the denominators were multiplied in
+    // ---- pass E (up): 9P .. 16P; per point the even block (pushed last) unwinds first
 #pragma nounroll
     for (int p = 0; p < NP; p++) {
         const atab_ref tb = tab + p * 16;
-        aff_src a, a3, a5, a6, a7, a8;
-        aff_ld(a, tb, 1);
-        aff_ld(a3, tb, 3);
+        aff_src a5, a6, a7, a8;
         aff_ld(a5, tb, 5);
         aff_ld(a8, tb, 8);
-        const bool pid = fe_is_zero(a.x) & fe_is_zero(a.y);
-        const int q4 = L4 + 8 * p;
+        const bool pid = fe_is_zero(a8.x) & fe_is_zero(a8.y);       // P = O <=> every stored multiple is the (0, 0) sentinel
+        fe dd[4], di[4];
         apt R;
-        aff_den_add(d, a8, a, pid, one);    aff_pop(dinv, tscr, N, t, q4 + 0, inv, d);  aff_add(R, a8, a, dinv);   atab_store(tb, 9, R, beta, pid);
-        aff_den_add(d, a8, a3, pid, one);   aff_pop(dinv, tscr, N, t, q4 + 2, inv, d);  aff_add(R, a8, a3, dinv);  atab_store(tb, 11, R, beta, pid);
-        aff_den_dbl(d, a5, pid, one);       aff_pop(dinv, tscr, N, t, q4 + 1, inv, d);  aff_dbl(R, a5, dinv);      atab_store(tb, 10, R, beta, pid);
-        aff_den_add(d, a8, a5, pid, one);   aff_pop(dinv, tscr, N, t, q4 + 4, inv, d);  aff_add(R, a8, a5, dinv);  atab_store(tb, 13, R, beta, pid);
         aff_ld(a6, tb, 6);
-        aff_den_dbl(d, a6, pid, one);       aff_pop(dinv, tscr, N, t, q4 + 3, inv, d);  aff_dbl(R, a6, dinv);      atab_store(tb, 12, R, beta, pid);
         aff_ld(a7, tb, 7);
-        aff_den_dbl(d, a7, pid, one);       aff_pop(dinv, tscr, N, t, q4 + 5, inv, d);  aff_dbl(R, a7, dinv);      atab_store(tb, 14, R, beta, pid);
-        aff_den_add(d, a8, a7, pid, one);   aff_pop(dinv, tscr, N, t, q4 + 6, inv, d);  aff_add(R, a8, a7, dinv);  atab_store(tb, 15, R, beta, pid);
-        aff_den_dbl(d, a8, pid, one);       aff_pop(dinv, tscr, N, t, q4 + 7, inv, d);  aff_dbl(R, a8, dinv);      atab_store(tb, 16, R, beta, pid);
+        aff_den_dbl(dd[0], a5, pid, one);
+        aff_den_dbl(dd[1], a6, pid, one);
+        aff_den_dbl(dd[2], a7, pid, one);
+        aff_den_dbl(dd[3], a8, pid, one);
+        aff_pop_block(di, dd, tscr, N, t, L4 + 2 * p + 1, inv);
+        aff_dbl(R, a5, di[0]);  atab_store(tb, 10, R, beta, pid);
+        aff_dbl(R, a6, di[1]);  atab_store(tb, 12, R, beta, pid);
+        aff_dbl(R, a7, di[2]);  atab_store(tb, 14, R, beta, pid);
+        aff_dbl(R, a8, di[3]);  atab_store(tb, 16, R, beta, pid);
+        aff_src a, a3;                                              // a6 is done with: its registers serve P and 3P
+        aff_ld(a, tb, 1);
+        aff_ld(a3, tb, 3);
+        aff_den_add(dd[0], a8, a, pid, one);
+        aff_den_add(dd[1], a8, a3, pid, one);
+        aff_den_add(dd[2], a8, a5, pid, one);
+        aff_den_add(dd[3], a8, a7, pid, one);
+        aff_pop_block(di, dd, tscr, N, t, L4 + 2 * p, inv);
+        aff_add(R, a8, a, di[0]);   atab_store(tb, 9, R, beta, pid);
+        aff_add(R, a8, a3, di[1]);  atab_store(tb, 11, R, beta, pid);
+        aff_add(R, a8, a5, di[2]);  atab_store(tb, 13, R, beta, pid);
+        aff_add(R, a8, a7, di[3]);  atab_store(tb, 15, R, beta, pid);
     }
 #endif
 }
@@ -1674,6 +1709,126 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
         sc_mul(tmp, l1, chv);
         ws_st8(ws.fsc, N, t, 33 + i, tmp.v);
     }
+}
+// ---- the same 49 scalars formed ON THE FLY by the one-lane-per-proof final check (full batches): no k_verify_final_scalars launch,
+// no 1.5 KB of scalars per proof written and read back 13 times.  What a scalar needs -- y_1..y_4, rho and its three squarings,
+// l0, l1, n0 -- is re-read from the workspace when its base comes up (coalesced SoA reads, every 13th table addition): the final
+// check already sits at its register cap, so nothing of this stays live across the additions except the 8 words of the current scalar.
+// fsc slot 0 holds v, slots 1..3 rho^2, rho^4, rho^8 (written by the prologue).
+HD void final_ch(sc& r, const VerifyWs& ws, size_t t, int b) {          // ch[b] = prod_{k: bit k of b} y_{k+1}; b is uniform over the wavefront
+    sc_set_u32(r, 1);
+    bool first = true;
+#pragma nounroll
+    for (int k = 0; k < 4; k++) {
+        if (!((b >> k) & 1)) continue;
+        sc y;
+        ws_ld8(y.v, ws.chal, ws.N, t, 6 + k);
+        if (first) r = y;
+        else sc_mul(r, r, y);
+        first = false;
+    }
+}
+HD void final_cg(sc& r, const VerifyWs& ws, size_t t, int b) {          // cg[b] = prod_k (bit k of b ? y_{k+1} : rho^(2^k))
+#pragma nounroll
+    for (int k = 0; k < 4; k++) {
+        sc f;
+        if ((b >> k) & 1) ws_ld8(f.v, ws.chal, ws.N, t, 6 + k);
+        else if (k == 0) ws_ld8(f.v, ws.chal, ws.N, t, 1);
+        else ws_ld8(f.v, ws.fsc, ws.N, t, k);
+        if (k == 0) r = f;
+        else sc_mul(r, r, f);
+    }
+}
+HD void final_fused_prologue(const VerifyWs& ws, size_t t) {
+    const size_t N = ws.N;
+    sc rk, mu5, l, tmp, cv, ch, c0f, c1f, v, w;
+    ws_ld8(rk.v, ws.chal, N, t, 1);
+#pragma nounroll
+    for (int k = 1; k < 4; k++) {
+        sc_mul(rk, rk, rk);
+        ws_st8(ws.fsc, N, t, k, rk.v);
+    }
+    sc_mul(mu5, rk, rk);
+    sc_mul(mu5, mu5, mu5);
+    sc_set_u32(c0f, 0);
+    sc_set_u32(c1f, 0);
+#pragma nounroll
+    for (int i = 0; i < 25; i++) {
+        ws_ld8(cv.v, ws.cvec, N, t, i);
+        final_ch(ch, ws, t, i & 15);
+        sc_mul(tmp, cv, ch);
+        if (i < 16) sc_add(c0f, c0f, tmp);
+        else sc_add(c1f, c1f, tmp);
+    }
+    ws_ld8(l.v, ws.lns, N, t, 0);
+    sc_mul(v, c0f, l);
+    ws_ld8(l.v, ws.lns, N, t, 1);
+    sc_mul(w, c1f, l);
+    sc_add(v, v, w);
+    ws_ld8(l.v, ws.lns, N, t, 2);
+    sc_mul(w, l, l);
+    sc_mul(w, w, mu5);
+    sc_add(v, v, w);
+    ws_st8(ws.fsc, N, t, 0, v.v);
+}
+HD void final_scalar_j(u32 k[8], const VerifyWs& ws, size_t t, int j) {   // scalar of base j (0 = g, 1..16 = g_vec, 17..48 = h_vec)
+    if (j == 0) { ws_ld8(k, ws.fsc, ws.N, t, 0); return; }
+    sc r, f;
+    if (j <= 16) final_cg(r, ws, t, j - 1);
+    else final_ch(r, ws, t, (j - 17) & 15);
+    ws_ld8(f.v, ws.lns, ws.N, t, j <= 16 ? 2 : (j <= 32 ? 0 : 1));         // n0 | l0 | l1
+    sc_mul(r, r, f);
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = r.v[i];
+}
+// the fast (XYZZ) sum over all 49 bases on ONE lane, software-pipelined as fb_lane_accumulate_fast is -- entry of step i + 1
+// requested before the addition of step i, address of step i + 2 derived after it -- with the scalar of the address frontier held
+// in registers and replaced when the frontier reaches a new base.  false = an exceptional addition occurred.
+HD bool final_check_fused_fast(pt& total, const VerifyWs& ws, size_t t) {
+    const FbTable fbt = fb_of(ws);
+    const int nwin = fb_nwin(fbt.W), steps = BPPP_NG * nwin;
+    ptz acc;
+    ptz_init(acc);
+    bool empty = true;
+    u32 k[8];
+    FbStep cur_st, nxt_st;
+    apt_packed cur_e, nxt_e;
+    int j2 = 0, w2 = 0;                                   // (base, window) of the address frontier
+    final_scalar_j(k, ws, t, 0);
+    fb_step_from_scalar(cur_st, fbt, k, 0, 0);
+    cur_e = fbt.table[cur_st.addr];
+    if (++w2 == nwin) { w2 = 0; j2++; final_scalar_j(k, ws, t, j2); }
+    fb_step_from_scalar(nxt_st, fbt, k, j2, w2);
+#pragma nounroll
+    for (int i = 0; i < steps; i++) {
+        nxt_e = fbt.table[nxt_st.addr];                   // step i + 1's entry (the last iteration re-requests its own, unused)
+        fb_sched_fence();
+        fb_consume_fast(acc, empty, cur_e, cur_st.skip, cur_st.neg);
+        cur_e = nxt_e;
+        cur_st = nxt_st;
+        if (++w2 == nwin) { w2 = 0; j2++; }
+        if (j2 < BPPP_NG) {
+            if (w2 == 0) final_scalar_j(k, ws, t, j2);
+            fb_step_from_scalar(nxt_st, fbt, k, j2, w2);
+        }
+    }
+    return fb_lane_finish_fast(total, acc, empty);
+}
+HD void verify_final_check_ranges(FbRanges& rg);
+HD void verify_final_scalars(const VerifyWs& ws, size_t t);
+// rare (an exceptional addition in the fast sum): the complete formulas over the stored scalars.  Out of line, so that its registers
+// and scratch do not count against the loop above.
+HD __attribute__((noinline)) void final_check_fused_redo(pt& total, const VerifyWs& ws, size_t t) {
+    verify_final_scalars(ws, t);
+    FbRanges rg;
+    fb_ranges_one(rg, 0, 0, BPPP_NG);
+    fb_lane_sum_complete(total, fb_of(ws), t, 0, ws.fsc, rg, 1);
+}
+HD void verify_final_check_fused(const VerifyWs& ws, size_t t, bool force_complete = false) {   // force_complete: tests only
+    final_fused_prologue(ws, t);
+    pt total;
+    if (!final_check_fused_fast(total, ws, t) || force_complete) final_check_fused_redo(total, ws, t);
+    ws_st_pt(ws.pfix, ws.N, t, total);
 }
 HD void verify_final_check_ranges(FbRanges& rg) { fb_ranges_one(rg, 0, 0, BPPP_NG); }
 HD void verify_final_check_store(const VerifyWs& ws, size_t t, const pt& rhs) { ws_st_pt(ws.pfix, ws.N, t, rhs); }

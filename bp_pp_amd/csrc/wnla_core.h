@@ -36,7 +36,7 @@ struct WnlaWs {
     // 2 x rounds round points of every instance, built by one kernel with four batched inversions (verify_core.h:
     // affine_tables_build), then Jacobian accumulators with mixed additions over signed 5-bit windows (straus_affine)
     apt_packed* atab;      // [2 * rounds * 16][N] 64-byte entries: point 2 (k - 1) = X of round k, 2 (k - 1) + 1 = R of round k
-    u32* tscr;             // [14 * 2 * rounds * 10][N] running products of the table build
+    u32* tscr;             // [BPPP_TSCR_PER_POINT * 2 * rounds * 10][N] running products of the table build
     u32* rpts;             // [2 * rounds * 16][N] the decoded round points (packed affine words)
     FbTable fb;
     strobe base;

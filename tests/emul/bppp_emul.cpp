@@ -275,6 +275,9 @@ int emul_u64_verify_batch_transcript(const uint8_t* table, int W, size_t n, cons
                                      const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* states_out) {
     return emul_u64_verify_impl(table, W, nullptr, 0, n, V, proofs, accept, status, nullptr, states, n_states, states_out);
 }
+// 1: the final check forms its scalars on the fly (verify_final_check_fused: the one-lane kernel of full batches); 0: two stages
+static int g_fused_final = 0;
+void emul_set_fused_final(int on) { g_fused_final = on; }
 static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
                                 const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* trace, const uint8_t* states,
                                 size_t n_states, uint8_t* states_out) {
@@ -300,8 +303,13 @@ static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* labe
     for (size_t t = 0; t < n; t++) verify_c0_fixed(ws, t);
     for (int k = 1; k <= 4; k++)
         for (size_t t = 0; t < n; t++) verify_round(ws, t, k);
-    for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);
-    for (size_t t = 0; t < n; t++) verify_final_check(ws, t);
+    if (g_fused_final) {
+        for (size_t t = 0; t < n; t++) verify_final_check_fused(ws, t, g_fused_final == 2);   // 2: take the complete-formula fallback
+        for (size_t t = 0; t < n; t++) verify_accept(ws, t);
+    } else {
+        for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);
+        for (size_t t = 0; t < n; t++) verify_final_check(ws, t);
+    }
     for (size_t t = 0; t < n; t++) verify_export_state(ws, t);
     return 0;
 }
