@@ -16,7 +16,6 @@ static void read_diagnostics(bppp_ctx* c) {
     if (const char* e = std::getenv("BPPP_FB_ONE_LANE")) c->fb_one_lane_mode = e[0] == '0' ? 0 : 1;
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
-    c->no_fused_final = std::getenv("BPPP_NO_FUSED_FINAL") != nullptr;            // final scalars in their own kernel at every batch size
 }
 
 extern "C" {
@@ -163,6 +162,7 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
     if (std::strcmp(name, "rlc_superchunk") == 0) {
         if (value != 0 && (value < 64 || value > BPPP_BKT_MAX_M || (value & 7))) return BPPP_ERR_INVALID_ARG;
         c->rlc_super_m = (unsigned)value;
+        c->rlc_super_auto = false;           // an explicit size is taken as it is (0 switches the stage off)
         return BPPP_OK;
     }
     if (std::strcmp(name, "max_batch") == 0) {

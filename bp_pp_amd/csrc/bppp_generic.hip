@@ -285,6 +285,16 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
         const unsigned check_blocks = (unsigned)(nchunks < 16384 ? nchunks : 16384);
         HIP_TRY(hipMemsetAsync(d_acc, 0, n, s));
         HIP_TRY(hipMemsetAsync(rl.count, 0, sizeof(int), s));
+        if (const unsigned SM = bucket_superchunk_for(c, n)) {
+            // bucket (Pippenger) stage first, as in the u64 verifier: superchunks of SM instances, the weighted commitments summed by
+            // bucket accumulation and ONE 1 + ng + nh-base MSM per superchunk; the chunk-of-8 kernels only see what failed it
+            BucketWs bw;
+            rc = launch_bucket_stage(c, bw, n, SM, rl.seed, w.status, w.acc, w.msc, (int)NB, d_acc, s,
+                                     [&](int id, auto&& f) { return timed(c, id, s, f); });
+            if (rc != BPPP_OK) return rc;
+            rl.sflag = bw.sflag;
+            rl.super_m = SM;
+        }
         GLAUNCH(K_WNLA_RLC_LHS, k_wnla_rlc_lhs<<<blocks, BPPP_BLOCK, 0, s>>>(w, rl));
         GLAUNCH(K_WNLA_RLC_CHUNK, k_wnla_rlc_chunk<<<chunk_blocks, BPPP_FB_BLOCK, 0, s>>>(w, rl));
         GLAUNCH(K_WNLA_RLC_CHECK, k_wnla_rlc_check<<<check_blocks, 64, 0, s>>>(w, rl));

@@ -132,12 +132,9 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         else if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
         else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
     }
-    // exact mode on one lane per proof forms the 49 base-case scalars inside the final check; every other form takes them from fsc
-    const bool fused_final = !rlc_seed && fb_one_lane && !c->no_fused_final;
-    if (!fused_final) LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     if (!rlc_seed) {
-        if (fused_final) LAUNCH(K_FINAL_CHECK, k_verify_final_check_fused<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
-        else if (fb_one_lane) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+        if (fb_one_lane) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
         else LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
         LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
     } else {
@@ -146,33 +143,15 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         const unsigned chunk_blocks = (unsigned)((nchunks * BPPP_RLC_CHUNK + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
         HIP_TRY(hipMemsetAsync(d_accept, 0, n, s));
         HIP_TRY(hipMemsetAsync(rl.count, 0, sizeof(int), s));
-        if (c->rlc_super_m) {
-            // bucket stage first: superchunks of rlc_super_m proofs, one combined check each; the chunk-of-8 kernels below only see
-            // the proofs of superchunks that failed it
-            const size_t SM = c->rlc_super_m, nsuper = (n + SM - 1) / SM;
-            rc = ensure_bucket_capacity(c, n);
-            if (rc != BPPP_OK) return rc;
+        if (const unsigned SM = bucket_superchunk_for(c, n)) {
+            // bucket stage first: superchunks of SM proofs, one combined check each; the chunk-of-8 kernels below only see the proofs
+            // of superchunks that failed it
             BucketWs bw;
-            std::memset(&bw, 0, sizeof bw);
-            bw.N = n; bw.M = (u32)SM;
-            for (int i = 0; i < 4; i++) bw.seed[i] = rl.seed[i];
-            bw.status = ws.status; bw.acc = ws.acc; bw.fsc = ws.fsc; bw.accept = ws.accept;
-            uint8_t* p = c->d_bkt;
-            const size_t capn = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
-            bw.wab = (u64*)p; p += align16(capn * 16);
-            bw.c4 = (c4_packed*)p; p += align16(capn * sizeof(c4_packed));
-            bw.lhs = (u32*)p; p += align16(nsuper * 30 * 4);
-            bw.asc = (u32*)p; p += align16(nsuper * (size_t)BPPP_NG * 32);
-            bw.sflag = p;
-            bw.fb.table = c->d_table; bw.fb.W = c->fb_w; bw.fb.N = nsuper;
-            const size_t lds_bytes = ((size_t)4 * (512 + SM) + 8 * 30) * sizeof(u32);
-            (void)hipFuncSetAttribute((const void*)k_bkt_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            LAUNCH(K_BKT_PREPARE, k_bkt_prepare<<<blocks, BPPP_BLOCK, 0, s>>>(bw));
-            LAUNCH(K_BKT_ACCUMULATE, k_bkt_accumulate<<<(unsigned)nsuper, 256, lds_bytes, s>>>(bw));
-            LAUNCH(K_BKT_SCALARS, k_bkt_scalars<<<(unsigned)nsuper, 256, 0, s>>>(bw));
-            LAUNCH(K_BKT_CHECK, k_bkt_check<<<(unsigned)nsuper, 64, 0, s>>>(bw));
+            rc = launch_bucket_stage(c, bw, n, SM, rl.seed, ws.status, ws.acc, ws.fsc, BPPP_NG, ws.accept, s,
+                                     [&](int id, auto&& f) { return timed(c, id, s, f); });
+            if (rc != BPPP_OK) return rc;
             rl.sflag = bw.sflag;
-            rl.super_m = (u32)SM;
+            rl.super_m = SM;
         }
         LAUNCH(K_RLC_LHS, k_rlc_lhs<<<blocks, BPPP_BLOCK, 0, s>>>(ws, rl));
         LAUNCH(K_RLC_CHUNK, k_rlc_chunk<<<chunk_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));

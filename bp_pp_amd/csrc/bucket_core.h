@@ -16,7 +16,8 @@
 //   3. reduces across the wavefront with shuffles: a suffix scan of A (sum_l l A_l = sum_{m>=1} sum_{l>=m} A_l) and a tree sum.
 // The eight window sums are combined by Horner (8 w doublings on lane w, 3-step shuffle tree).  Scalars: A_i = sum_j w_j s_ji is
 // accumulated UNREDUCED in 12-limb integers per half-weight (64 x 256-bit products, 4096 terms) and reduced mod n once per
-// superchunk; one 49-base fixed-base MSM gives the right-hand side.  A superchunk whose check fails falls through to the chunk-of-8
+// superchunk; one fixed-base MSM over the bases (49 for the u64 protocol, 769 for the generic reciprocal verifier at BASELINE
+// configs[4]'s shape: the stage is shared, BucketWs::nb) gives the right-hand side.  A superchunk whose check fails falls through to the chunk-of-8
 // kernels (rlc_core.h) and from there to the exact per-proof check, so accept bits stay per proof.  Flagged proofs (status != 0)
 // get weight zero and are rejected directly.
 #pragma once
@@ -35,11 +36,12 @@ struct BucketWs {
     u64 seed[4];
     const int32_t* status;
     const u32* acc;         // [30][N] C4 (projective limbs)
-    const u32* fsc;         // [49*8][N] final-check scalars s_ji
+    int nb;                 // bases of the final check (49 for the u64 protocol; 1 + |g_vec| + |h_vec| for the generic verifiers)
+    const u32* fsc;         // [nb*8][N] final-check scalars s_ji
     u64* wab;               // [N][2] half-weights a_j, b_j (0, 0 for a flagged proof)
     c4_packed* c4;          // [N]
     u32* lhs;               // [30][nsuper]
-    u32* asc;               // [49*8][nsuper] combined scalars A_i
+    u32* asc;               // [nb*8][nsuper] combined scalars A_i
     uint8_t* sflag;         // [nsuper] 1 = the superchunk's check failed (or could not be made): fall through to chunks of 8
     uint8_t* accept;
     FbTable fb;             // N = nsuper
@@ -125,7 +127,7 @@ HD bool bkt_superchunk_serial(const BucketWs& w, size_t chunk) {
         pt_add(total, total, sum);
     }
     const size_t ns = w.fb.N;
-    for (int i = 0; i < BPPP_NG; i++) {
+    for (int i = 0; i < w.nb; i++) {
         u32 aa[12], ab[12];
         for (int k = 0; k < 12; k++) aa[k] = ab[k] = 0;
         for (size_t j = first; j < first + w.M && j < w.N; j++) {
@@ -139,7 +141,7 @@ HD bool bkt_superchunk_serial(const BucketWs& w, size_t chunk) {
         ws_st8(w.asc, ns, chunk, i, A.v);
     }
     FbRanges rg;
-    rlc_ranges(rg);
+    fb_ranges_one(rg, 0, 0, w.nb);
     pt rhs;
     fb_sum_serial(rhs, w.fb, chunk, w.asc, rg);
     return pt_eq(total, rhs);

@@ -82,7 +82,8 @@ struct bppp_ctx {
     u32* d_rlc = nullptr;
     size_t rlc_bytes = 0;
     // bucket stage of the RLC mode (bucket_core.h): superchunk size (0 = stage off) and its workspace
-    unsigned rlc_super_m = 4096;
+    unsigned rlc_super_m = 4096;       // cap of the automatic choice, or the explicit size (bucket_superchunk_for)
+    bool rlc_super_auto = true;
     size_t bcap = 0;
     uint8_t* d_bkt = nullptr;
     size_t bkt_bytes = 0;
@@ -106,7 +107,7 @@ struct bppp_ctx {
     int n_simds = 1024;            // CUs x 4 (device property), decides between the small-batch and the 2-waves/SIMD lane kernels
     bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
-    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false, no_lane_groups = false, force_pairs = false, no_small = false, no_fused_final = false;
+    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false, no_lane_groups = false, force_pairs = false, no_small = false;
     int fb_one_lane_mode = -1;   // diagnostic BPPP_FB_ONE_LANE: 1 = one lane per proof in the u64 verifier's fixed-base kernels at every size, 0 = never, unset = by size   // diagnostics, read from the environment once at context creation
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> event_pool;
@@ -177,19 +178,6 @@ static inline int ensure_rlc_capacity(bppp_ctx* c, size_t n) {
     c->rcap = cap;
     return BPPP_OK;
 }
-// workspace of the bucket stage: half-weights, packed commitments | per superchunk: lhs, combined scalars, flag
-static inline size_t bkt_bytes_for(size_t cap, size_t nsuper) {
-    return align16(cap * 16) + align16(cap * sizeof(c4_packed)) + align16(nsuper * 30 * 4) + align16(nsuper * (size_t)BPPP_NG * 32) + align16(nsuper + 16);
-}
-static inline int ensure_bucket_capacity(bppp_ctx* c, size_t n) {
-    const size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
-    const size_t need = bkt_bytes_for(cap, cap / 64 + 1);      // enough for any superchunk size >= 64
-    if (need <= c->bkt_bytes) return BPPP_OK;
-    if (c->d_bkt) { (void)hipFree(c->d_bkt); c->d_bkt = nullptr; c->bkt_bytes = 0; }
-    HIP_TRY(hipMalloc(&c->d_bkt, need));
-    c->bkt_bytes = need;
-    return BPPP_OK;
-}
 static const size_t PWS_WORDS_PER_PROOF = 52 + (size_t)SV_COUNT * 8 + (size_t)BPPP_MSC_SETS * BPPP_NG * 8 + (size_t)PB_COUNT * 30;
 static inline int ensure_prove_capacity(bppp_ctx* c, size_t n) {
     int rc = ensure_capacity(c, n);
@@ -251,6 +239,59 @@ static inline int timed(bppp_ctx* c, int id, hipStream_t st, F&& launch) {
     HIP_TRY(hipEventRecord(tl.b, st));
     c->pending.push_back(tl);
     return BPPP_OK;
+}
+// workspace of the bucket stage: half-weights, packed commitments | per superchunk: lhs, combined scalars, flag
+static inline size_t bkt_bytes_for(size_t cap, size_t nsuper, size_t nb) {
+    return align16(cap * 16) + align16(cap * sizeof(c4_packed)) + align16(nsuper * 30 * 4) + align16(nsuper * nb * 32) + align16(nsuper + 16);
+}
+static inline int ensure_bucket_capacity(bppp_ctx* c, size_t n, size_t nb) {
+    const size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    const size_t need = bkt_bytes_for(cap, cap / 64 + 1, nb);      // enough for any superchunk size >= 64
+    if (need <= c->bkt_bytes) return BPPP_OK;
+    if (c->d_bkt) { (void)hipFree(c->d_bkt); c->d_bkt = nullptr; c->bkt_bytes = 0; }
+    HIP_TRY(hipMalloc(&c->d_bkt, need));
+    c->bkt_bytes = need;
+    return BPPP_OK;
+}
+// Superchunk size of a call.  An explicit "rlc_superchunk" option is taken as it is; the default adapts to the batch: one workgroup
+// works on one superchunk for ~1-3 ms whatever their number, so a batch is cut into about as many superchunks as the chip has CUs
+// (2^20 proofs: 4096, the measured optimum; 2^17, one GPU's share of the 8-GPU split: 512; never below 256: emptier buckets cost more
+// than idle CUs save).
+static inline unsigned bucket_superchunk_for(const bppp_ctx* c, size_t n) {
+    if (!c->rlc_super_m || !c->rlc_super_auto) return c->rlc_super_m;
+    size_t m = 256;
+    while (m * 2 <= n / (size_t)(c->n_simds / 4 > 0 ? c->n_simds / 4 : 256) && m * 2 <= c->rlc_super_m) m *= 2;
+    return (unsigned)m;
+}
+// The bucket stage in front of the chunk-of-8 kernels, shared by the u64 verifier (nb = 49 bases, scalars in fsc) and the generic
+// verifiers (nb = 1 + |g_vec| + |h_vec|, scalars in msc): fills bw and launches prepare / accumulate / scalars / check on s.
+template <typename Launch>
+static inline int launch_bucket_stage(bppp_ctx* c, BucketWs& bw, size_t n, unsigned SM, const u64 seed[4], const int32_t* status, const u32* acc,
+                                      const u32* scalars, int nb, uint8_t* accept, hipStream_t s, Launch&& timed_launch) {
+    const size_t nsuper = (n + SM - 1) / SM;
+    int rc = ensure_bucket_capacity(c, n, (size_t)nb);
+    if (rc != BPPP_OK) return rc;
+    std::memset(&bw, 0, sizeof bw);
+    bw.N = n; bw.M = SM; bw.nb = nb;
+    for (int i = 0; i < 4; i++) bw.seed[i] = seed[i];
+    bw.status = status; bw.acc = acc; bw.fsc = scalars; bw.accept = accept;
+    uint8_t* p = c->d_bkt;
+    const size_t capn = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+    bw.wab = (u64*)p; p += align16(capn * 16);
+    bw.c4 = (c4_packed*)p; p += align16(capn * sizeof(c4_packed));
+    bw.lhs = (u32*)p; p += align16(nsuper * 30 * 4);
+    bw.asc = (u32*)p; p += align16(nsuper * (size_t)nb * 32);
+    bw.sflag = p;
+    bw.fb.table = c->d_table; bw.fb.W = c->fb_w; bw.fb.N = nsuper;
+    const size_t lds_bytes = ((size_t)4 * (512 + SM) + 8 * 30) * sizeof(u32);
+    (void)hipFuncSetAttribute((const void*)k_bkt_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const dim3 sgrid((unsigned)nsuper, (unsigned)((nb + BPPP_BKT_SCALAR_GROUP - 1) / BPPP_BKT_SCALAR_GROUP));
+    rc = timed_launch(K_BKT_PREPARE, [&]() { k_bkt_prepare<<<blocks, BPPP_BLOCK, 0, s>>>(bw); });
+    if (rc == BPPP_OK) rc = timed_launch(K_BKT_ACCUMULATE, [&]() { k_bkt_accumulate<<<(unsigned)nsuper, 256, lds_bytes, s>>>(bw); });
+    if (rc == BPPP_OK) rc = timed_launch(K_BKT_SCALARS, [&]() { k_bkt_scalars<<<sgrid, 256, 0, s>>>(bw); });
+    if (rc == BPPP_OK) rc = timed_launch(K_BKT_CHECK, [&]() { k_bkt_check<<<(unsigned)nsuper, 64, 0, s>>>(bw); });
+    return rc;
 }
 static inline int drain_timings(bppp_ctx* c) {
     if (c->pending.empty()) return BPPP_OK;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_count_rejects(const uint8_t* accept, si
 // ---- random-linear-combination mode of the final MSM (wnla_rlc_core.h)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_rlc_lhs(WnlaWs w, RlcWs r) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    if (t < w.N && w.status[t] == ST_OK) wnla_rlc_lhs(w, r, t);
+    if (t < w.N && w.status[t] == ST_OK && !rlc_done_by_bucket_stage(r, t)) wnla_rlc_lhs(w, r, t);
 }
 // combined scalars: one lane group (8 lanes) per chunk of 8 instances, lane j owns instance j's weight; A_i = sum_j w_j s_ji is
 // summed across the group with shuffles and stored once per chunk (at the chunk's first instance)
@@ -92,6 +92,10 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_rlc_c
     const size_t N = w.N, nchunks = (N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
     if (chunk >= nchunks) return;            // whole lane groups leave together
     const size_t first = chunk * BPPP_RLC_CHUNK, t = first + lane;
+    if (rlc_done_by_bucket_stage(r, first)) {          // whole lane groups leave together (the superchunk size is a multiple of 8)
+        if (lane == 0) r.flag[chunk] = 0;
+        return;
+    }
     int bad = (t < N) ? (w.status[t] != ST_OK) : 1;
 #pragma unroll
     for (int m = 1; m < BPPP_RLC_CHUNK; m <<= 1) bad |= __shfl_xor(bad, m, 64);

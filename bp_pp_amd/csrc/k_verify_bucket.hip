@@ -159,14 +159,17 @@ __global__ __launch_bounds__(256) void k_bkt_accumulate(BucketWs w) {
     }
 }
 
-// combined scalars A_i = sum_j w_j s_ji of one superchunk: thread t takes proofs first + t + 256 r; unreduced 12-limb sums per
-// half-weight, shuffle tree inside a wavefront, LDS across the four, one reduction mod n per i
+// combined scalars A_i = sum_j w_j s_ji of one superchunk (blockIdx.x) for a group of BPPP_BKT_SCALAR_GROUP bases (blockIdx.y):
+// thread t takes proofs first + t + 256 r; unreduced 12-limb sums per half-weight, shuffle tree inside a wavefront, LDS across the
+// four, one reduction mod n per i.  The base groups give the generic verifiers' 769 bases a grid that fills the chip even when there
+// are only a few superchunks.
 __global__ __launch_bounds__(256) void k_bkt_scalars(BucketWs w) {
     __shared__ u32 part[4][24];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t chunk = blockIdx.x, first = chunk * (size_t)w.M;
+    const int i0 = (int)blockIdx.y * BPPP_BKT_SCALAR_GROUP, i1 = i0 + BPPP_BKT_SCALAR_GROUP < w.nb ? i0 + BPPP_BKT_SCALAR_GROUP : w.nb;
 #pragma nounroll
-    for (int i = 0; i < BPPP_NG; i++) {
+    for (int i = i0; i < i1; i++) {
         u32 aa[12], ab[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) aa[k] = ab[k] = 0;
@@ -207,13 +210,13 @@ __global__ __launch_bounds__(256) void k_bkt_scalars(BucketWs w) {
     }
 }
 
-// right-hand side (one 49-base fixed-base MSM over the whole wavefront) and the verdict of one superchunk; a passing superchunk
+// right-hand side (one fixed-base MSM over the whole wavefront) and the verdict of one superchunk; a passing superchunk
 // accepts every proof of it that carries no status flag
 __global__ __launch_bounds__(64) void k_bkt_check(BucketWs w) {
     const int lane = (int)threadIdx.x;
     const size_t chunk = blockIdx.x, first = chunk * (size_t)w.M;
     FbRanges rg;
-    rlc_ranges(rg);
+    fb_ranges_one(rg, 0, 0, w.nb);
     pt rhs, lhs;
     fb_group_sum<64>(rhs, w.fb, chunk, lane, w.asc, rg);
     ws_ld_pt(lhs, w.lhs, w.fb.N, chunk);

@@ -36,12 +36,6 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed_l1(VerifyWs ws) { verify_c0_fixed_lanes<1>(ws); }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(VerifyWs ws) { verify_final_check_lanes<BPPP_FB_LANES>(ws); }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_l1(VerifyWs ws) { verify_final_check_lanes<1>(ws); }
-// one lane per proof with the 49 scalars formed on the fly (verify_core.h: verify_final_check_fused): replaces k_verify_final_scalars +
-// k_verify_final_check_l1 in exact mode at full batch sizes
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_fused(VerifyWs ws) {
-    const size_t t = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    if (t < ws.N) verify_final_check_fused(ws, t);
-}
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(VerifyWs ws, RlcWs r) {
     const size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
     const size_t chunk = g / BPPP_RLC_CHUNK;

@@ -23,10 +23,12 @@
 #endif
 // fixed-base MSM kernels: BPPP_FB_LANES lanes per proof, 256-thread workgroups; 2 waves/SIMD (212 VGPRs, no spills) -- forcing 3
 // (168 VGPRs, 52 spilled) slows k_verify_final_check from 42.8 to 61.6 ms per 2^20 proofs (same measurement)
-// k_verify_tables is a chain of dependent loads and short arithmetic (three to five passes over a proof's 13 points): latency-bound,
-// so it is given more wavefronts per SIMD than the arithmetic-bound kernels when its registers allow (measured)
+// k_verify_tables: chains of dependent loads and short arithmetic (five passes over a proof's 13 points).  Round 2 ran it at 3 waves per
+// SIMD (168 VGPRs) with one running product per denominator; with one per block of four (verify_core.h: aff_push_block) the unwinding
+// passes hold four denominators and their inverses at once: 229 spilled VGPRs at 168, 7 at 256.  Measured on 2^20 proofs
+// (profiles/r03_c_*): 3 waves 17.2-17.4 ms, 2 waves 14.5-14.6 ms (round 2's form: 14.6-14.75 ms at 3 waves).
 #ifndef BPPP_TABLES_MIN_WAVES
-#define BPPP_TABLES_MIN_WAVES 3
+#define BPPP_TABLES_MIN_WAVES 2
 #endif
 #define BPPP_FB_BLOCK 256
 #ifndef BPPP_FB_MIN_WAVES
@@ -90,7 +92,6 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g2(bppp::VerifyWs w
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_l1(bppp::VerifyWs ws);
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_fused(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(bppp::VerifyWs ws, int* reject_count);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_export_states(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(bppp::VerifyWs ws, bppp::RlcWs r);
@@ -156,5 +157,6 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var(bppp::RecipWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_finish(bppp::RecipWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_bkt_prepare(bppp::BucketWs w);
 __global__ __launch_bounds__(256) void k_bkt_accumulate(bppp::BucketWs w);
+#define BPPP_BKT_SCALAR_GROUP 16
 __global__ __launch_bounds__(256) void k_bkt_scalars(bppp::BucketWs w);
 __global__ __launch_bounds__(64) void k_bkt_check(bppp::BucketWs w);

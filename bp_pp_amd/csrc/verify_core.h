@@ -1710,126 +1710,6 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
         ws_st8(ws.fsc, N, t, 33 + i, tmp.v);
     }
 }
-// ---- the same 49 scalars formed ON THE FLY by the one-lane-per-proof final check (full batches): no k_verify_final_scalars launch,
-// no 1.5 KB of scalars per proof written and read back 13 times.  What a scalar needs -- y_1..y_4, rho and its three squarings,
-// l0, l1, n0 -- is re-read from the workspace when its base comes up (coalesced SoA reads, every 13th table addition): the final
-// check already sits at its register cap, so nothing of this stays live across the additions except the 8 words of the current scalar.
-// fsc slot 0 holds v, slots 1..3 rho^2, rho^4, rho^8 (written by the prologue).
-HD void final_ch(sc& r, const VerifyWs& ws, size_t t, int b) {          // ch[b] = prod_{k: bit k of b} y_{k+1}; b is uniform over the wavefront
-    sc_set_u32(r, 1);
-    bool first = true;
-#pragma nounroll
-    for (int k = 0; k < 4; k++) {
-        if (!((b >> k) & 1)) continue;
-        sc y;
-        ws_ld8(y.v, ws.chal, ws.N, t, 6 + k);
-        if (first) r = y;
-        else sc_mul(r, r, y);
-        first = false;
-    }
-}
-HD void final_cg(sc& r, const VerifyWs& ws, size_t t, int b) {          // cg[b] = prod_k (bit k of b ? y_{k+1} : rho^(2^k))
-#pragma nounroll
-    for (int k = 0; k < 4; k++) {
-        sc f;
-        if ((b >> k) & 1) ws_ld8(f.v, ws.chal, ws.N, t, 6 + k);
-        else if (k == 0) ws_ld8(f.v, ws.chal, ws.N, t, 1);
-        else ws_ld8(f.v, ws.fsc, ws.N, t, k);
-        if (k == 0) r = f;
-        else sc_mul(r, r, f);
-    }
-}
-HD void final_fused_prologue(const VerifyWs& ws, size_t t) {
-    const size_t N = ws.N;
-    sc rk, mu5, l, tmp, cv, ch, c0f, c1f, v, w;
-    ws_ld8(rk.v, ws.chal, N, t, 1);
-#pragma nounroll
-    for (int k = 1; k < 4; k++) {
-        sc_mul(rk, rk, rk);
-        ws_st8(ws.fsc, N, t, k, rk.v);
-    }
-    sc_mul(mu5, rk, rk);
-    sc_mul(mu5, mu5, mu5);
-    sc_set_u32(c0f, 0);
-    sc_set_u32(c1f, 0);
-#pragma nounroll
-    for (int i = 0; i < 25; i++) {
-        ws_ld8(cv.v, ws.cvec, N, t, i);
-        final_ch(ch, ws, t, i & 15);
-        sc_mul(tmp, cv, ch);
-        if (i < 16) sc_add(c0f, c0f, tmp);
-        else sc_add(c1f, c1f, tmp);
-    }
-    ws_ld8(l.v, ws.lns, N, t, 0);
-    sc_mul(v, c0f, l);
-    ws_ld8(l.v, ws.lns, N, t, 1);
-    sc_mul(w, c1f, l);
-    sc_add(v, v, w);
-    ws_ld8(l.v, ws.lns, N, t, 2);
-    sc_mul(w, l, l);
-    sc_mul(w, w, mu5);
-    sc_add(v, v, w);
-    ws_st8(ws.fsc, N, t, 0, v.v);
-}
-HD void final_scalar_j(u32 k[8], const VerifyWs& ws, size_t t, int j) {   // scalar of base j (0 = g, 1..16 = g_vec, 17..48 = h_vec)
-    if (j == 0) { ws_ld8(k, ws.fsc, ws.N, t, 0); return; }
-    sc r, f;
-    if (j <= 16) final_cg(r, ws, t, j - 1);
-    else final_ch(r, ws, t, (j - 17) & 15);
-    ws_ld8(f.v, ws.lns, ws.N, t, j <= 16 ? 2 : (j <= 32 ? 0 : 1));         // n0 | l0 | l1
-    sc_mul(r, r, f);
-#pragma unroll
-    for (int i = 0; i < 8; i++) k[i] = r.v[i];
-}
-// the fast (XYZZ) sum over all 49 bases on ONE lane, software-pipelined as fb_lane_accumulate_fast is -- entry of step i + 1
-// requested before the addition of step i, address of step i + 2 derived after it -- with the scalar of the address frontier held
-// in registers and replaced when the frontier reaches a new base.  false = an exceptional addition occurred.
-HD bool final_check_fused_fast(pt& total, const VerifyWs& ws, size_t t) {
-    const FbTable fbt = fb_of(ws);
-    const int nwin = fb_nwin(fbt.W), steps = BPPP_NG * nwin;
-    ptz acc;
-    ptz_init(acc);
-    bool empty = true;
-    u32 k[8];
-    FbStep cur_st, nxt_st;
-    apt_packed cur_e, nxt_e;
-    int j2 = 0, w2 = 0;                                   // (base, window) of the address frontier
-    final_scalar_j(k, ws, t, 0);
-    fb_step_from_scalar(cur_st, fbt, k, 0, 0);
-    cur_e = fbt.table[cur_st.addr];
-    if (++w2 == nwin) { w2 = 0; j2++; final_scalar_j(k, ws, t, j2); }
-    fb_step_from_scalar(nxt_st, fbt, k, j2, w2);
-#pragma nounroll
-    for (int i = 0; i < steps; i++) {
-        nxt_e = fbt.table[nxt_st.addr];                   // step i + 1's entry (the last iteration re-requests its own, unused)
-        fb_sched_fence();
-        fb_consume_fast(acc, empty, cur_e, cur_st.skip, cur_st.neg);
-        cur_e = nxt_e;
-        cur_st = nxt_st;
-        if (++w2 == nwin) { w2 = 0; j2++; }
-        if (j2 < BPPP_NG) {
-            if (w2 == 0) final_scalar_j(k, ws, t, j2);
-            fb_step_from_scalar(nxt_st, fbt, k, j2, w2);
-        }
-    }
-    return fb_lane_finish_fast(total, acc, empty);
-}
-HD void verify_final_check_ranges(FbRanges& rg);
-HD void verify_final_scalars(const VerifyWs& ws, size_t t);
-// rare (an exceptional addition in the fast sum): the complete formulas over the stored scalars.  Out of line, so that its registers
-// and scratch do not count against the loop above.
-HD __attribute__((noinline)) void final_check_fused_redo(pt& total, const VerifyWs& ws, size_t t) {
-    verify_final_scalars(ws, t);
-    FbRanges rg;
-    fb_ranges_one(rg, 0, 0, BPPP_NG);
-    fb_lane_sum_complete(total, fb_of(ws), t, 0, ws.fsc, rg, 1);
-}
-HD void verify_final_check_fused(const VerifyWs& ws, size_t t, bool force_complete = false) {   // force_complete: tests only
-    final_fused_prologue(ws, t);
-    pt total;
-    if (!final_check_fused_fast(total, ws, t) || force_complete) final_check_fused_redo(total, ws, t);
-    ws_st_pt(ws.pfix, ws.N, t, total);
-}
 HD void verify_final_check_ranges(FbRanges& rg) { fb_ranges_one(rg, 0, 0, BPPP_NG); }
 HD void verify_final_check_store(const VerifyWs& ws, size_t t, const pt& rhs) { ws_st_pt(ws.pfix, ws.N, t, rhs); }
 // accept bit: C4 == rhs as projective classes (wnla.rs:81), and no status flag

@@ -275,9 +275,6 @@ int emul_u64_verify_batch_transcript(const uint8_t* table, int W, size_t n, cons
                                      const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* states_out) {
     return emul_u64_verify_impl(table, W, nullptr, 0, n, V, proofs, accept, status, nullptr, states, n_states, states_out);
 }
-// 1: the final check forms its scalars on the fly (verify_final_check_fused: the one-lane kernel of full batches); 0: two stages
-static int g_fused_final = 0;
-void emul_set_fused_final(int on) { g_fused_final = on; }
 static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
                                 const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* trace, const uint8_t* states,
                                 size_t n_states, uint8_t* states_out) {
@@ -303,13 +300,8 @@ static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* labe
     for (size_t t = 0; t < n; t++) verify_c0_fixed(ws, t);
     for (int k = 1; k <= 4; k++)
         for (size_t t = 0; t < n; t++) verify_round(ws, t, k);
-    if (g_fused_final) {
-        for (size_t t = 0; t < n; t++) verify_final_check_fused(ws, t, g_fused_final == 2);   // 2: take the complete-formula fallback
-        for (size_t t = 0; t < n; t++) verify_accept(ws, t);
-    } else {
-        for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);
-        for (size_t t = 0; t < n; t++) verify_final_check(ws, t);
-    }
+    for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);
+    for (size_t t = 0; t < n; t++) verify_final_check(ws, t);
     for (size_t t = 0; t < n; t++) verify_export_state(ws, t);
     return 0;
 }
@@ -403,7 +395,7 @@ int emul_u64_bucket_stage(const uint8_t* table, int W, const uint8_t* label, siz
     const size_t nsuper = (n + M - 1) / M;
     BucketWs bw;
     memset(&bw, 0, sizeof bw);
-    bw.N = n; bw.M = M;
+    bw.N = n; bw.M = M; bw.nb = BPPP_NG;
     for (int i = 0; i < 4; i++) {
         u64 v = 0;
         for (int k = 0; k < 8; k++) v |= (u64)seed[8 * i + k] << (8 * k);
@@ -492,6 +484,11 @@ static TranscriptIo g_tio = {nullptr, 0, nullptr, 0};
 static const uint8_t* g_rlc_seed = nullptr;
 static uint8_t* g_rlc_flags = nullptr;
 void emul_set_rlc(const uint8_t* seed32, uint8_t* flags_out) { g_rlc_seed = seed32; g_rlc_flags = flags_out; }
+// superchunk size of the bucket stage in front of the generic RLC mode (0 = chunks of 8 only); passed_out[nsuper] (optional)
+// receives each superchunk's verdict.  Consumed by the next emul_recip_verify call in RLC mode.
+static unsigned g_rlc_super_m = 0;
+static uint8_t* g_rlc_super_passed = nullptr;
+void emul_set_rlc_superchunk(unsigned m, uint8_t* passed_out) { g_rlc_super_m = m; g_rlc_super_passed = passed_out; }
 void emul_set_transcripts(const uint8_t* states, size_t n_states, uint8_t* states_out) {
     g_tio.states = states; g_tio.n_states = n_states; g_tio.states_out = states_out;
 }
@@ -599,8 +596,35 @@ int emul_recip_verify(const uint8_t* table, int W, int NG, int NH, int nd, int n
         for (int i = 0; i < 4; i++) { u64 v = 0; for (int k = 0; k < 8; k++) v |= (u64)seed[8 * i + k] << (8 * k); rl.seed[i] = v; }
         rl.lhs = rl_lhs.data(); rl.sc = rl_sc.data(); rl.flag = flag.data();
         memset(accept, 0, n);
-        for (size_t t = 0; t < n; t++) if (status[t] == ST_OK) wnla_rlc_lhs(w, rl, t);
+        const unsigned SM = g_rlc_super_m;
+        uint8_t* passed_out = g_rlc_super_passed;
+        g_rlc_super_m = 0; g_rlc_super_passed = nullptr;
+        std::vector<uint8_t> sflag;
+        std::vector<u64> wab;
+        std::vector<c4_packed> c4;
+        std::vector<u32> blhs, basc;
+        if (SM) {       // the kernels' order: bucket stage over superchunks of SM instances, then chunks of 8 for what failed it
+            const size_t nsuper = (n + SM - 1) / SM;
+            BucketWs bw;
+            memset(&bw, 0, sizeof bw);
+            bw.N = n; bw.M = SM; bw.nb = (int)NB;
+            for (int i = 0; i < 4; i++) bw.seed[i] = rl.seed[i];
+            sflag.assign(nsuper, 1); wab.assign(2 * n, 0); c4.resize(n); blhs.assign(30 * nsuper, 0); basc.assign(NB * 8 * nsuper, 0);
+            bw.status = status; bw.acc = w.acc; bw.fsc = w.msc; bw.wab = wab.data(); bw.c4 = c4.data(); bw.lhs = blhs.data();
+            bw.asc = basc.data(); bw.accept = accept; bw.sflag = sflag.data();
+            bw.fb = w.fb; bw.fb.N = nsuper;
+            for (size_t t = 0; t < n; t++) bkt_prepare(bw, t);
+            for (size_t c = 0; c < nsuper; c++) {
+                const bool ok = bkt_superchunk_serial(bw, c);
+                sflag[c] = ok ? 0 : 1;
+                if (passed_out) passed_out[c] = ok ? 1 : 0;
+                if (ok) for (size_t t = c * SM; t < (c + 1) * (size_t)SM && t < n; t++) accept[t] = status[t] == ST_OK ? 1 : 0;
+            }
+            rl.sflag = sflag.data(); rl.super_m = SM;
+        }
+        for (size_t t = 0; t < n; t++) if (status[t] == ST_OK && !rlc_done_by_bucket_stage(rl, t)) wnla_rlc_lhs(w, rl, t);
         for (size_t ch = 0; ch < nchunks; ch++) {
+            if (rlc_done_by_bucket_stage(rl, ch * BPPP_RLC_CHUNK)) { flag[ch] = 0; continue; }
             const bool ok = wnla_rlc_chunk_serial(w, rl, ch);
             flag[ch] = ok ? 0 : 1;
             if (ok) for (size_t t = ch * BPPP_RLC_CHUNK; t < (ch + 1) * BPPP_RLC_CHUNK; t++) accept[t] = 1;

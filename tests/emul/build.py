@@ -52,7 +52,7 @@ def load():
     L.emul_wnla_prove.argtypes = [vp, i32, i32, i32, cp, sz, sz, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.emul_circuit_prove.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, cp, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.emul_recip_prove.argtypes = [vp, i32, i32, i32, i32, i32, cp, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp]
-    L.emul_set_fused_final.argtypes = [i32]
-    L.emul_set_fused_final.restype = None
+    L.emul_set_rlc_superchunk.argtypes = [C.c_uint32, vp]
+    L.emul_set_rlc_superchunk.restype = None
     L.emul_group_verify.argtypes = [i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, cp, sz, sz, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     return L

@@ -279,40 +279,6 @@ def test_full_verify_pipeline_against_golden(L, gold, oracle_c, W):
             assert rc == items[k][2] and bytes(tr[k]) == otr
 
 
-@pytest.mark.parametrize("W", [4, 10])
-def test_fused_final_check_equals_the_two_stage_form(L, gold, oracle_c, W):
-    """The one-lane final check of full batches forms the 49 base-case scalars on the fly (verify_final_check_fused: cg / ch products
-    re-derived per base from the challenges) instead of reading them from k_verify_final_scalars' array: accept bits, statuses and the
-    whole 704-byte trace (every challenge, every hashed point, C4) equal the two-stage form's and the C oracle's, on the golden
-    vectors, their negatives and a fresh corrupted batch."""
-    import workload
-    gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
-    tab = np.zeros(L.emul_fb_table_entries(49, W) * 64, dtype=np.uint8)
-    assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0
-    items = [(c["commitment"], c["proof"]) for c in gold["cases"]] + [(c["commitment"], c["proof"]) for c in gold["negative_cases"]]
-    V = np.frombuffer(b"".join(bytes.fromhex(i[0]) for i in items), dtype=np.uint8).reshape(-1, 64).copy()
-    P = np.frombuffer(b"".join(bytes.fromhex(i[1]) for i in items), dtype=np.uint8).reshape(-1, 928).copy()
-    g2, V2, P2, _ = workload.make_batch(24, first=4100, nthreads=2)
-    assert g2 == gens
-    P2, _ = workload.corrupt(P2, V2, every=3)
-    V, P = np.concatenate([V, V2]), np.concatenate([P, P2])
-    n = V.shape[0]
-    out = {}
-    try:
-        for fused in (0, 1, 2):                  # 2 = the fused form's complete-formula fallback, forced
-            L.emul_set_fused_final(fused)
-            acc, st, tr = np.zeros(n, np.uint8), np.zeros(n, np.int32), np.zeros((n, 704), np.uint8)
-            L.emul_u64_verify_batch(tab.ctypes.data, W, label, len(label), n, V.ctypes.data, P.ctypes.data, acc.ctypes.data, st.ctypes.data,
-                                    tr.ctypes.data)
-            out[fused] = (acc, st, tr)
-    finally:
-        L.emul_set_fused_final(0)
-    for f in (1, 2):
-        assert (out[0][0] == out[f][0]).all() and (out[0][1] == out[f][1]).all() and (out[0][2] == out[f][2]).all()
-    oacc, ost = oracle_c.u64_verify_batch(gens, label, V, P, nthreads=2)
-    assert (out[1][0] == oacc).all() and ((out[1][1] != 0) == (ost != 0)).all() and 0 < int(oacc.sum()) < n
-
-
 def test_full_prove_pipeline_is_byte_identical_to_the_oracle(L, gold, oracle_c):
     """The device prover code (prove_core.h) on CPU: proofs must equal the reference-shaped prover's bytes for the same
     (x, s, 52 random scalars), on the golden cases and on fresh seeded cases incl. x = 0 and x = 2^64 - 1."""

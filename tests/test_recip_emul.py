@@ -103,6 +103,47 @@ def test_generic_reciprocal_verify_rlc_mode_equals_exact_mode():
         assert int(acc1[b]) == (1 if rc == 1 else 0)
 
 
+def test_generic_rlc_bucket_stage_in_front_of_the_chunks():
+    """The bucket (Pippenger) stage carried over from the u64 verifier to the generic RLC mode (bucket_core.h with nb = 1 + ng + nh
+    bases): superchunks of 8 instances here (the device uses 256 .. 4096).  A clean superchunk passes on its one combined check and
+    its instances are accepted without any chunk-of-8 work; a superchunk holding a bad instance falls through to the chunk kernels
+    and from there to the exact check.  Accept bits and statuses equal exact mode's."""
+    L = load()
+    nd, npp, B = 8, 4, 19
+    case = recip_cases.make(nd, npp, B=B, n_oracle=B)
+    W = 4
+    gens = case["g"] + b"".join(case["gv"]) + b"".join(case["gv_"]) + b"".join(case["hv"]) + b"".join(case["hv_"])
+    NB = 1 + case["NG"] + case["NH"]
+    tab = np.zeros(L.emul_fb_table_entries(NB, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, NB, W, tab.ctypes.data) == 0
+    seed = bytes(range(7, 39))
+
+    def run(com, proofs, mode, M=8):
+        acc, st, flags = np.zeros(B, np.uint8), np.zeros(B, np.int32), np.full(3, 9, np.uint8)
+        passed = np.full((B + M - 1) // M, 9, np.uint8)
+        com, proofs = np.ascontiguousarray(com), np.ascontiguousarray(proofs)
+        if mode:
+            L.emul_set_rlc(seed, flags.ctypes.data)
+        if mode == 2:
+            L.emul_set_rlc_superchunk(M, passed.ctypes.data)
+        L.emul_recip_verify(tab.ctypes.data, W, case["NG"], case["NH"], nd, npp, case["label"], len(case["label"]), B, com.ctypes.data,
+                            proofs.ctypes.data, case["rounds"], case["nl"], case["nn"], acc.ctypes.data, st.ctypes.data)
+        return acc, st, flags, passed
+
+    acc, st, flags, passed = run(case["commitments"], case["proofs"], 2)
+    assert acc.all() and not st.any() and passed.tolist() == [1, 1, 1] and flags.tolist() == [0, 0, 0]   # even the ragged tail passes
+    P, com = case["proofs"].copy(), case["commitments"].copy()
+    P[9, -1] ^= 1                                   # superchunk 1: wrong final scalar
+    P[18, 70] ^= 1                                  # superchunk 2: c_r off the curve (flagged: weight zero, rejected directly)
+    acc0, st0, _, _ = run(com, P, 0)
+    acc2, st2, flags, passed = run(com, P, 2)
+    assert (acc2 == acc0).all() and (st2 == st0).all()
+    assert passed.tolist() == [1, 0, 1] and flags.tolist() == [0, 1, 0]
+    assert acc2.tolist() == [0 if b in (9, 18) else 1 for b in range(B)] and st2[18] == 1
+    acc3, st3, _, passed = run(com, P, 2, M=16)     # two superchunks of 16 (the second ragged)
+    assert (acc3 == acc0).all() and (st3 == st0).all() and passed.tolist() == [0, 1]
+
+
 def test_fast_and_projective_round_paths_agree():
     """The generic verifiers' rounds run on affine window tables of all round points (one table-build pass, Jacobian accumulators,
     signed 5-bit windows) by default; the projective tables + complete additions they replaced are still there

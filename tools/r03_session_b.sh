@@ -1,5 +1,6 @@
 #!/bin/bash
-# round-3 session B: microbenchmarks of the session (ratebench: issue rates + shader clock; fe52bench: FP64-FMA limb products against
+# round-3 session B (the fused final check it A/B-tested was 16 % slower -- final_check 50.7 against 41.9 + 1.9 ms -- and was removed;
+# BPPP_NO_FUSED_FINAL no longer exists): microbenchmarks of the session (ratebench: issue rates + shader clock; fe52bench: FP64-FMA limb products against
 # v_mad_u64_u32), then A/B of the fused final check on the headline workload, then the GPU tests that run at the sizes selecting it.
 # usage: tools/r03_session_b.sh <tag>
 set -u
