@@ -238,6 +238,11 @@ class ReciprocalRangeProofProtocol:
     def synchronize(self) -> None:
         _capi.check(_capi.lib().bppp_ctx_synchronize(self._w._ctx))
 
+    def set_option(self, name: str, value: int) -> None:
+        """bppp_ctx_set_option ("rlc_superchunk": 0 = no bucket stage in front of the RLC mode, else the superchunk size 64..8192;
+        unset = chosen per call from the batch size)."""
+        _capi.check(_capi.lib().bppp_ctx_set_option(self._w._ctx, name.encode(), int(value)))
+
     def set_stream(self, hip_stream: int) -> None:
         """Run this context's kernels on the caller's HIP stream (0 = back to the context's own)."""
         _capi.check(_capi.lib().bppp_ctx_set_stream(self._w._ctx, hip_stream or None))

@@ -120,6 +120,43 @@ def test_reciprocal_verify_rlc_mode_on_the_gpu(nd, npp, B):
         proto.close()
 
 
+@pytest.mark.parametrize("nd,npp,B", [(32, 16, 700), (256, 16, 1100)])
+def test_reciprocal_rlc_bucket_stage_superchunk_sizes(nd, npp, B):
+    """The bucket (Pippenger) stage in front of the generic RLC mode (k_bkt_* with nb = 1 + ng + nh bases): superchunk sizes 0 (off),
+    64, 256, 1024 and the automatic choice give exact mode's accept bits and statuses -- clean batch, damaged batch (so that some
+    superchunks pass on their single combined check and others fall through to the chunks of 8 and the exact MSM), ragged tail."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import recip_cases
+    from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
+    case = recip_cases.make_bulk(nd, npp, B, n_oracle=0) if nd == 256 else recip_cases.make(nd, npp, B, n_oracle=1)
+    proto = ReciprocalRangeProofProtocol(nd, npp, case["g"], case["gv"], case["hv"], case["gv_"], case["hv_"], device=0, fb_window_bits=8)
+    try:
+        com, st = proto.commit_value_batch(case["x"], case["s"])
+        proofs, st, shape = proto.prove_batch(case["label"], com, case["x"], case["s"], case["digits"], case["m"], case["rnd"])
+        assert not st.any()
+        P, V = proofs.copy(), com.copy()
+        bad = [5, 70, 71, 300, B - 1]
+        P[5, -1] ^= 1
+        P[70, 70] ^= 1                                   # off-curve c_r: flagged, weight zero in the bucket stage
+        V[71] = com[72]
+        P[300, -40] ^= 2
+        P[B - 1, 192:256] = P[B - 1, 0:64]
+        acc0, st0 = proto.verify_batch(case["label"], V, P, *shape)
+        assert [i for i in range(B) if not acc0[i]] == bad and st0[70] == 1
+        seed = bytes(range(90, 122))
+        for M in (None, 0, 64, 256, 1024):
+            if M is not None:
+                proto.set_option("rlc_superchunk", M)
+            acc, st = proto.verify_batch_rlc(case["label"], com, proofs, *shape, seed=seed)
+            assert acc.all() and not st.any(), M
+            acc1, st1 = proto.verify_batch_rlc(case["label"], V, P, *shape, seed=seed)
+            assert (acc1 == acc0).all() and (st1 == st0).all(), M
+    finally:
+        proto.close()
+
+
 @pytest.mark.parametrize("nd,npp", [(16, 16), (12, 10)])
 def test_generic_reciprocal_fuzz_vs_oracle(nd, npp):
     """Fuzz of the generic path: one random byte of every proof (or commitment) of a 240-instance batch is XOR-ed with a random
