@@ -367,19 +367,26 @@ static int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len
         if (rc != BPPP_OK) return rc;                          \
     } while (0)
 #define PMSM(job) PLAUNCH(K_PROVE_MSM, k_prove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job))
+    // a grid that gives every SIMD more than one wavefront runs the 256-register builds of the lane kernels (two wavefronts per SIMD)
+    const bool w2 = !c->prove_uncapped && (c->no_small || blocks > (unsigned)c->n_simds);
     PLAUNCH(K_PROVE_STAGES, k_prove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_v());
-    PLAUNCH(K_PROVE_STAGES, k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_b_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    else PLAUNCH(K_PROVE_STAGES, k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_rcom()); PMSM(job_co()); PMSM(job_cl()); PMSM(job_cr());
-    PLAUNCH(K_PROVE_STAGES, k_prove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    else PLAUNCH(K_PROVE_STAGES, k_prove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_cs());
-    PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    else PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_c0());
     for (int k = 1; k <= 4; k++) {
         PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         PMSM(job_x()); PMSM(job_r());
         if (!c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
             PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
+        else if (w2)
+            PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         else
             PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
     }

@@ -62,3 +62,29 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(
     fb_group_sum(part, w.fb, t, lane, w.msc, rg);
     if (lane == 0) prove_msm_store(w, job, t, part);
 }
+
+// ---- the lane kernels above at two wavefronts per SIMD (256 VGPR + AGPR), for prove batches that give every SIMD more than one
+// wavefront (beyond 2^16 values; BASELINE configs[3]'s 2^14 values are 256 workgroups on 1024 SIMDs and keep the uncapped builds):
+// uncapped they allocate 332-398 registers, i.e. ONE wavefront per SIMD, which is the cliff the u64 verifier's lane kernels fell off
+// in round 1 (kernels.h, BPPP_LANE_MIN_WAVES).  Same per-lane code.
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_b_w2(ProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= w.N) return;
+    const u32 key = preloaded_position_key(w.states, w.n_states, t);
+    for_each_position_group(key, [&]() { prove_stage_b(w, t); });
+}
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_d_w2(ProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= w.N) return;
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_stage_d(w, t); });
+}
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_f_w2(ProveWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= w.N) return;
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_stage_f(w, t); });
+}
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_fold_w2(ProveWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= w.N) return;
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_round_fold(w, t, k); });
+}

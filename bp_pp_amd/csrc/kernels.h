@@ -112,6 +112,10 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_export_states(bppp::ProveW
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold_g4(bppp::ProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_b_w2(bppp::ProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_d_w2(bppp::ProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_f_w2(bppp::ProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_fold_w2(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(bppp::ProveWs w, bppp::MsmJob job);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_scalars(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(bppp::WnlaWs w);
