@@ -424,7 +424,7 @@ def run_verify(args):
                             "reject-count all-reduce per step",
                 "total_proofs_per_step": total,
                 "proofs_per_gpu": n,
-                "fb_window_bits": args.fb_window_bits or 20,
+                "fb_window_bits": args.fb_window_bits or 22,
                 "label": workload.LABEL.decode(),
                 "parallelism": f"shard{world}" if world > 1 else "single",
             },

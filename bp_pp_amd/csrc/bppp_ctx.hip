@@ -19,6 +19,16 @@ static void read_diagnostics(bppp_ctx* c) {
     c->prove_uncapped = std::getenv("BPPP_PROVE_UNCAPPED") != nullptr;            // the prover's lane kernels without the 256-register cap at every size
 }
 
+// fb_window_bits = 0: the widest windows whose tables stay below 100 GB -- 22 bits for the u64 protocol's 49 generators (79 GB of the
+// 288: -2.4 ... -3.1 % per 2^20-proof batch against 20 bits / 21 GB, profiles/r03_e_bench_fbwindow_*), 16 bits for the 769 generators
+// of BASELINE configs[4]'s shape (52 GB)
+static int default_window_bits(int nbases) {
+    const int cand[5] = {22, 20, 16, 8, 4};
+    for (int W : cand)
+        if ((double)nbases * fb_nwin(W) * (double)fb_per_win(W) * sizeof(apt_packed) <= 100e9) return W;
+    return 4;
+}
+
 extern "C" {
 
 const char* bppp_strerror(int code) {
@@ -44,7 +54,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     if (!out || !g || (!g_vec && ng) || (!h_vec && nh) || ng > 4096 || nh > 4096) return BPPP_ERR_INVALID_ARG;
     *out = nullptr;
     const int NB = 1 + (int)ng + (int)nh;
-    int W = fb_window_bits ? fb_window_bits : 20;
+    int W = fb_window_bits ? fb_window_bits : default_window_bits(NB);
     if (W != 4 && W != 8 && W != 16 && W != 10 && W != 20 && W != 22) return BPPP_ERR_INVALID_ARG;
     int rc = check_device(device);
     if (rc != BPPP_OK) return rc;
