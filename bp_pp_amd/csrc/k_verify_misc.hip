@@ -8,11 +8,16 @@ using namespace bppp;
 // (2 => at most 256 VGPR + AGPR per lane, so two wavefronts share a SIMD and cover each other's table-gather latency).
 
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_phase1(VerifyWs ws) {
+    __shared__ u32 sponge[50 * BPPP_LDS_STRIDE];     // the wavefront's 64 sponge states, word-major (merlin.h: strobe_lds): 12.5 KB
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= ws.N) return;
     // per-proof pre-loaded transcripts may sit at different byte positions (byte 200 of the serialized state)
     const u32 key = preloaded_position_key(ws.states, ws.n_states, t);
-    for_each_position_group(key, [&]() { verify_phase1(ws, t); });
+#if defined(__HIP_DEVICE_COMPILE__)
+    for_each_position_group(key, [&]() { verify_phase1_lds(ws, t, sponge + threadIdx.x); });
+#else
+    (void)key; (void)sponge;
+#endif
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_small(VerifyWs ws) {     // see k_verify_round_small
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;

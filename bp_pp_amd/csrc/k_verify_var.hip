@@ -13,10 +13,15 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_c0_v
     if (t < ws.N) verify_c0_var(ws, t);
 }
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_round(VerifyWs ws, int k) {
+    __shared__ u32 sponge[50 * BPPP_LDS_STRIDE];     // the wavefront's sponge states while they are hashed (merlin.h: strobe_lds)
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= ws.N) return;
     const u32 key = (ws.states && ws.n_states != 1) ? ws.tstate[(size_t)50 * ws.N + t] : 0u;   // the stored sponge position
-    for_each_position_group(key, [&]() { verify_round(ws, t, k); });
+#if defined(__HIP_DEVICE_COMPILE__)
+    for_each_position_group(key, [&]() { verify_round_lds(ws, t, k, sponge + threadIdx.x); });
+#else
+    (void)key; (void)sponge;
+#endif
 }
 // Small-batch variants (at most one wavefront per SIMD anyway: 2^16 proofs = 1024 workgroups on 1024 SIMDs): no register cap, so
 // nothing spills -- the latency of the lone wavefront is what the batch takes.  The host picks them when the lane-kernel grid does

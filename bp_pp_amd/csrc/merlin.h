@@ -142,8 +142,69 @@ HD void strobe_run_f(strobe& s) {
     s.pos = 0;
     s.pos_begin = 0;
 }
+// bytes 0..31 of the state as four words, read and zeroed (the PRF output right after a forced permutation)
+HD u64 st_take_word(strobe& s, int k) {
+    const u64 v = s.st[k];
+    s.st[k] = 0;
+    return v;
+}
+#define BPPP_LDS_STRIDE 64
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- the same sponge with its 200 state bytes in LDS (device only; k_verify_phase1).  A kernel that hashes a lot -- phase 1 is
+// ~15 permutations and ~1.3 KB of absorbed bytes per proof -- keeps the 50 state words live in VGPRs across code that also wants
+// registers for field arithmetic; at the 256-register cap of a two-wave kernel they end up in scratch (HBM-backed).  Here the state
+// lives in the workgroup's LDS, word-major: 32-bit word i of lane l at col[i * 64] with col = block + l, so a wavefront's access to
+// one word is 64 consecutive banks (no conflicts), the byte position being wave-uniform.  Absorbing is a read-modify-write of one or
+// two words; the permutation loads the 50 words, runs in registers, stores them back, out of line (one copy of Keccak-f per kernel
+// and no register pressure on its callers).
+struct strobe_lds {
+    u32* col;
+    u32 pos, pos_begin;
+};
+__device__ __noinline__ void keccak_f1600_lds(u32* col) {
+    u64 a[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = (u64)col[(2 * i) * BPPP_LDS_STRIDE] | ((u64)col[(2 * i + 1) * BPPP_LDS_STRIDE] << 32);
+    keccak_f1600(a);
+#pragma unroll
+    for (int i = 0; i < 25; i++) { col[(2 * i) * BPPP_LDS_STRIDE] = (u32)a[i]; col[(2 * i + 1) * BPPP_LDS_STRIDE] = (u32)(a[i] >> 32); }
+}
+__device__ __forceinline__ void st_xor_bytes(strobe_lds& s, u32 pos, u32 word) {      // pos + 4 <= 172 < 200: both words exist
+    const u32 w = st_uniform(pos >> 2), sh = 8 * (st_uniform(pos) & 3);
+    s.col[w * BPPP_LDS_STRIDE] ^= word << sh;
+    if (sh) s.col[(w + 1) * BPPP_LDS_STRIDE] ^= word >> (32 - sh);
+}
+__device__ __forceinline__ void strobe_run_f(strobe_lds& s) {
+    st_xor_bytes(s, s.pos, (s.pos_begin & 0xFFu) | (0x04u << 8));
+    s.col[((BPPP_STROBE_R + 1) >> 2) * BPPP_LDS_STRIDE] ^= 0x80u << (8 * ((BPPP_STROBE_R + 1) & 3));
+    keccak_f1600_lds(s.col);
+    s.pos = 0;
+    s.pos_begin = 0;
+}
+__device__ __forceinline__ u64 st_take_word(strobe_lds& s, int k) {
+    const u64 v = (u64)s.col[(2 * k) * BPPP_LDS_STRIDE] | ((u64)s.col[(2 * k + 1) * BPPP_LDS_STRIDE] << 32);
+    s.col[(2 * k) * BPPP_LDS_STRIDE] = 0;
+    s.col[(2 * k + 1) * BPPP_LDS_STRIDE] = 0;
+    return v;
+}
+__device__ __forceinline__ u32 strobe_squeeze_byte(strobe_lds& s) {   // read and zero
+    const u32 w = st_uniform(s.pos >> 2), sh = 8 * (st_uniform(s.pos) & 3);
+    const u32 v = s.col[w * BPPP_LDS_STRIDE];
+    s.col[w * BPPP_LDS_STRIDE] = v & ~(0xFFu << sh);
+    s.pos++;
+    if (s.pos == BPPP_STROBE_R) strobe_run_f(s);
+    return (v >> sh) & 0xFFu;
+}
+__device__ __forceinline__ void strobe_lds_load(strobe_lds& d, const strobe& s) {
+#pragma unroll
+    for (int i = 0; i < 25; i++) { d.col[(2 * i) * BPPP_LDS_STRIDE] = (u32)s.st[i]; d.col[(2 * i + 1) * BPPP_LDS_STRIDE] = (u32)(s.st[i] >> 32); }
+    d.pos = s.pos;
+    d.pos_begin = s.pos_begin;
+}
+#endif
 // absorb nb <= 4 bytes of `word`; the sponge permutation appears once here, whatever the chunk straddles
-HD void strobe_absorb_chunk(strobe& s, u32 word, u32 nb) {
+template <typename S>
+HD void strobe_absorb_chunk(S& s, u32 word, u32 nb) {
 #pragma nounroll
     while (nb) {
         s.pos = st_uniform(s.pos);
@@ -169,7 +230,8 @@ HD u32 strobe_squeeze_byte(strobe& s) {   // read and zero
     if (s.pos == BPPP_STROBE_R) strobe_run_f(s);
     return b;
 }
-HD void strobe_squeeze(strobe& s, uint8_t* d, u32 n) {
+template <typename S>
+HD void strobe_squeeze(S& s, uint8_t* d, u32 n) {
 #pragma nounroll
     for (u32 i = 0; i < n; i++) d[i] = (uint8_t)strobe_squeeze_byte(s);
 }
@@ -213,8 +275,8 @@ HD u32 label_word(const char (&label)[L], u32 c) {
 // message go through ONE loop of 4-byte chunks, so the (inlined) sponge permutation appears once per operation.
 // `msg_word(c)` supplies message bytes 4c .. 4c+3 (little-endian, bytes past the end zero); kind 0 = append_message,
 // kind 1 = challenge_bytes (ends after the PRF header and the forced permutation; the caller squeezes).
-template <int L, typename F>
-HD void t_op_absorb(strobe& t, const char (&label)[L], u32 nbytes, int kind, F msg_word) {
+template <typename S, int L, typename F>
+HD void t_op_absorb(S& t, const char (&label)[L], u32 nbytes, int kind, F msg_word) {
     const u32 LL = (u32)(L - 1), NLC = (LL + 3) / 4, NMC = kind == 0 ? (nbytes + 3) / 4 : 0;
     const u32 total = 1 + NLC + 1 + 1 + NMC;
 #pragma nounroll
@@ -251,8 +313,8 @@ HD void t_append(strobe& t, const char (&label)[L], const uint8_t* m, u32 n) {
     });
 }
 // append_message with the message in registers: message byte i = byte (i & 3) of mw[i >> 2], bytes past the end zero
-template <int L, int NW>
-HD void t_append_words(strobe& t, const char (&label)[L], const u32 (&mw)[NW], u32 nbytes) {
+template <typename S, int L, int NW>
+HD void t_append_words(S& t, const char (&label)[L], const u32 (&mw)[NW], u32 nbytes) {
     t_op_absorb(t, label, nbytes, 0, [&](u32 c) -> u32 {
         u32 wsel = 0;
 #pragma unroll
@@ -265,8 +327,8 @@ HD void t_new(strobe& t, const uint8_t* label, u32 n) {
     strobe_init(t, proto, 11);
     t_append(t, "dom-sep", label, n);
 }
-template <int L>
-HD void t_append_u64(strobe& t, const char (&label)[L], u64 x) {
+template <typename S, int L>
+HD void t_append_u64(S& t, const char (&label)[L], u64 x) {
     const u32 mw[2] = {(u32)x, (u32)(x >> 32)};
     t_append_words(t, label, mw, 8);
 }
@@ -277,17 +339,17 @@ HD void t_challenge_bytes(strobe& t, const char (&label)[L], uint8_t* out, u32 n
 }
 // transcript.rs:10-14: 32 PRF bytes, big-endian, Scalar::from_repr(..).unwrap().  Returns false where the reference
 // would panic (value >= n, probability ~2^-128); the caller records a DEGENERATE status for that proof.
-template <int L>
-HD bool t_get_challenge(strobe& t, const char (&label)[L], sc& out) {
+template <typename S, int L>
+HD bool t_get_challenge(S& t, const char (&label)[L], sc& out) {
     t_op_absorb(t, label, 32, 1, [](u32) -> u32 { return 0; });
     if (t.pos == 0) {
         // the usual case (the forced permutation leaves pos = 0): PRF bytes 0..31 are state words 0..3, read then zeroed;
         // byte i of the output is byte (31 - i) of the little-endian scalar
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            out.v[7 - 2 * k] = bswap32((u32)t.st[k]);
-            out.v[6 - 2 * k] = bswap32((u32)(t.st[k] >> 32));
-            t.st[k] = 0;
+            const u64 wk = st_take_word(t, k);
+            out.v[7 - 2 * k] = bswap32((u32)wk);
+            out.v[6 - 2 * k] = bswap32((u32)(wk >> 32));
         }
         t.pos = 32;
     } else {

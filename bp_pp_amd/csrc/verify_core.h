@@ -184,6 +184,22 @@ HD void ws_st_strobe(u32* base, size_t N, size_t t, const strobe& s) {
 
 // the caller's `&mut Transcript` after a verify: the stored state of instance t (its last operation was a challenge: cur_flags 7);
 // an instance flagged BPPP_ST_BAD_ENCODING gets its input state back
+HD void ws_st_transcript(u32* base, size_t N, size_t t, const strobe& s) { ws_st_strobe(base, N, t, s); }
+HD void ws_ld_transcript(strobe& s, const u32* base, size_t N, size_t t) { ws_ld_strobe(s, base, N, t); }
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void ws_ld_transcript(strobe_lds& s, const u32* base, size_t N, size_t t) {
+#pragma unroll
+    for (int i = 0; i < 50; i++) s.col[i * BPPP_LDS_STRIDE] = base[(size_t)i * N + t];
+    s.pos = base[(size_t)50 * N + t];
+    s.pos_begin = base[(size_t)51 * N + t];
+}
+__device__ __forceinline__ void ws_st_transcript(u32* base, size_t N, size_t t, const strobe_lds& s) {   // same workspace layout as ws_st_strobe
+#pragma unroll
+    for (int i = 0; i < 50; i++) base[(size_t)i * N + t] = s.col[i * BPPP_LDS_STRIDE];
+    base[(size_t)50 * N + t] = s.pos;
+    base[(size_t)51 * N + t] = s.pos_begin;
+}
+#endif
 HD void tio_export(const TranscriptIo& io, const strobe& base, const u32* tstate, size_t N, const int32_t* status, size_t t) {
     if (!io.states_out) return;
     uint8_t* out = io.states_out + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * t;
@@ -201,8 +217,8 @@ HD void tio_export(const TranscriptIo& io, const strobe& base, const u32* tstate
     ws_ld_strobe(tr, tstate, N, t);
     strobe_to_bytes(out, tr, 7);
 }
-template <int L>
-HD void app_point(strobe& t, const char (&label)[L], const apt& a) {  // transcript.rs:6-8
+template <typename S, int L>
+HD void app_point(S& t, const char (&label)[L], const apt& a) {  // transcript.rs:6-8
     // SEC1 compressed bytes (tag, then x big-endian) packed little-endian into 9 message words, all in registers
     const bool id = apt_is_identity(a);
     const u32 tag = id ? 0u : (2u + (fe_is_odd(a.y) ? 1u : 0u));
@@ -1315,9 +1331,12 @@ __device__ __forceinline__ void straus_affine_g4(pt& out, atab_ref tab, const in
 
 // ---------------------------------------------------------------- phase 1: decode, transcript up to tau, scalar derivation
 // reciprocal.rs:98-104 + circuit.rs:155-228 (closed forms of SURVEY.md 8a)
-HD void verify_phase1(const VerifyWs& ws, size_t t) {
+// TR = strobe (sponge state in registers: host emulation, small batches) or strobe_lds (state in the workgroup's LDS: k_verify_phase1).
+// `tr` arrives holding the transcript every proof starts from (ws.base); status_in carries flags the caller already raised.
+template <typename TR>
+HD void verify_phase1_on(const VerifyWs& ws, size_t t, TR& tr, int32_t status_in) {
     const size_t N = ws.N;
-    int32_t status = ST_OK;
+    int32_t status = status_in;
     BPPP_STAMP(t, 0);
     const uint8_t* pv = ws.commitments + 64 * t;
     const uint8_t* pp = ws.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
@@ -1348,13 +1367,6 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
 #pragma nounroll
         for (int i = 0; i < 12; i++) ws_st_apt(ws.pts, N, t, i, zero);
         sc_set_u32(l0, 0); sc_set_u32(l1, 0); sc_set_u32(n0, 0);
-    }
-    strobe tr = ws.base;
-    if (ws.states) {
-        strobe pre;
-        const bool sok = strobe_from_bytes(pre, ws.states + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * (ws.n_states == 1 ? 0 : t));
-        if (sok) tr = pre;
-        else status |= ST_BAD_ENCODING;      // not a state merlin could be in: flag the proof, run on the shared base
     }
     sc e, rho, lambda, beta, delta, tau;
     BPPP_STAMP(t, 1);
@@ -1396,7 +1408,7 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
         status |= ST_DEGENERATE;
         sc_set_u32(e, 1); sc_set_u32(rho, 1); sc_set_u32(lambda, 1); sc_set_u32(beta, 1); sc_set_u32(delta, 1); sc_set_u32(tau, 1);
     }
-    ws_st_strobe(ws.tstate, N, t, tr);
+    ws_st_transcript(ws.tstate, N, t, tr);
     ws_st8(ws.chal, N, t, 0, e.v); ws_st8(ws.chal, N, t, 1, rho.v); ws_st8(ws.chal, N, t, 2, lambda.v);
     ws_st8(ws.chal, N, t, 3, beta.v); ws_st8(ws.chal, N, t, 4, delta.v); ws_st8(ws.chal, N, t, 5, tau.v);
     ws_st8(ws.lns, N, t, 0, l0.v); ws_st8(ws.lns, N, t, 1, l1.v); ws_st8(ws.lns, N, t, 2, n0.v);
@@ -1529,6 +1541,36 @@ HD void verify_phase1(const VerifyWs& ws, size_t t) {
         apt_to_xy64(tb + 320, Vr);
     }
 }
+// the transcript a proof starts from: the caller's pre-loaded state if there is one (and merlin could be in it), else ws.base
+HD void phase1_start_state(strobe& tr, int32_t& status, const VerifyWs& ws, size_t t) {
+    tr = ws.base;
+    if (ws.states) {
+        strobe pre;
+        const bool sok = strobe_from_bytes(pre, ws.states + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * (ws.n_states == 1 ? 0 : t));
+        if (sok) tr = pre;
+        else status |= ST_BAD_ENCODING;      // not a state merlin could be in: flag the proof, run on the shared base
+    }
+}
+HD void verify_phase1(const VerifyWs& ws, size_t t) {          // sponge state in registers
+    int32_t status = ST_OK;
+    strobe tr;
+    phase1_start_state(tr, status, ws, t);
+    verify_phase1_on(ws, t, tr, status);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+// sponge state in LDS: lds_col = this lane's column of the workgroup's [50][64]-word block (merlin.h: strobe_lds)
+__device__ __forceinline__ void verify_phase1_lds(const VerifyWs& ws, size_t t, u32* lds_col) {
+    int32_t status = ST_OK;
+    strobe_lds tl;
+    tl.col = lds_col;
+    {
+        strobe tr;
+        phase1_start_state(tr, status, ws, t);
+        strobe_lds_load(tl, tr);
+    }
+    verify_phase1_on(ws, t, tl, status);
+}
+#endif
 
 // ---------------------------------------------------------------- phase 2b: C0 fixed-base part: ps_tau*g + <g_vec, pn_tau>  (circuit.rs:206) -> pfix
 // lane-group form: every lane of the proof's group computes a partial sum; the group total is stored by _store.
@@ -1569,7 +1611,9 @@ HD void verify_c0_var(const VerifyWs& ws, size_t t, int group_lane = -1) {
 // ---------------------------------------------------------------- phase 3 (k = 1..4): one WNLA round (wnla.rs:84-102)
 // group_lane >= 0: this lane is one of four consecutive lanes that all run the round for proof t (identical work and identical
 // stores, except the sum, which they share: straus_affine_g4) -- the small-batch kernels; -1: one lane per proof
-HD void verify_round(const VerifyWs& ws, size_t t, int k, int group_lane = -1, int group_size = 4) {
+// TR = strobe (sponge state in registers) or strobe_lds (in the workgroup's LDS: k_verify_round); tr arrives unloaded
+template <typename TR>
+HD void verify_round_on(const VerifyWs& ws, size_t t, int k, TR& tr, int group_lane = -1, int group_size = 4) {
     const size_t N = ws.N;
     pt C;
     ws_ld_pt(C, ws.acc, N, t);
@@ -1582,8 +1626,7 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k, int group_lane = -1, i
     apt Ca;
     pt_to_affine(Ca, C);
     BPPP_STAMP(t, 10);
-    strobe tr;
-    ws_ld_strobe(tr, ws.tstate, N, t);
+    ws_ld_transcript(tr, ws.tstate, N, t);
     app_point(tr, "wnla_com", Ca);                                       // wnla.rs:88-92
     {   // the round's proof points are only hashed here (the sum below reads their window tables): loaded one at a time, right
         // before their append, so that nothing but the sponge state and C is live across the permutations
@@ -1602,7 +1645,7 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k, int group_lane = -1, i
         sc_set_u32(y, 1);
     }
     BPPP_STAMP(t, 11);
-    ws_st_strobe(ws.tstate, N, t, tr);
+    ws_st_transcript(ws.tstate, N, t, tr);
     ws_st8(ws.chal, N, t, 5 + k, y.v);
     if (ws.trace) {
         uint8_t* tb = ws.trace + 704 * t;
@@ -1634,6 +1677,17 @@ HD void verify_round(const VerifyWs& ws, size_t t, int k, int group_lane = -1, i
     pt_madd(acc, acc, Ca, apt_is_identity(Ca));
     ws_st_pt(ws.acc, N, t, acc);
 }
+HD void verify_round(const VerifyWs& ws, size_t t, int k, int group_lane = -1, int group_size = 4) {
+    strobe tr;
+    verify_round_on(ws, t, k, tr, group_lane, group_size);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void verify_round_lds(const VerifyWs& ws, size_t t, int k, u32* lds_col) {
+    strobe_lds tl;
+    tl.col = lds_col;
+    verify_round_on(ws, t, k, tl);
+}
+#endif
 // ---------------------------------------------------------------- phase 4: base case (wnla.rs:80-82 with :66-72), generators unrolled
 HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
     const size_t N = ws.N;
