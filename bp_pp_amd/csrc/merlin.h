@@ -161,7 +161,7 @@ struct strobe_lds {
     u32* col;
     u32 pos, pos_begin;
 };
-__device__ __noinline__ void keccak_f1600_lds(u32* col) {
+__device__ __noinline__ inline void keccak_f1600_lds(u32* col) {
     u64 a[25];
 #pragma unroll
     for (int i = 0; i < 25; i++) a[i] = (u64)col[(2 * i) * BPPP_LDS_STRIDE] | ((u64)col[(2 * i + 1) * BPPP_LDS_STRIDE] << 32);
