@@ -52,6 +52,40 @@ def test_no_device_means_error_not_fallback():
     assert L.bppp_group_size(None) == 0
 
 
+def test_sharded_entry_points_refuse_bad_arguments_without_touching_a_gpu():
+    """Every *_sharded* entry point and the group housekeeping calls validate their arguments before anything else: a NULL group (what
+    a caller is left with after group creation failed for want of a GPU) is BPPP_ERR_INVALID_ARG, never a crash.  No GPU needed."""
+    import numpy as np
+    from bp_pp_amd import _build, _capi
+    if not os.path.exists(_build.SO):
+        pytest.skip("libbppp_hip.so not built yet")
+    L = _capi.lib()
+    E = _capi.ERR_INVALID_ARG
+    buf = np.zeros(4096, np.uint8)
+    p = buf.ctypes.data
+    rej = C.c_int32(7)
+    arr = (C.c_void_p * 1)(C.c_void_p(p))
+    seed = bytes(32)
+    assert L.bppp_group_set_option(None, b"rlc_superchunk", 256) == E
+    assert L.bppp_u64_verify_batch_sharded(None, b"x", 1, 1, p, p, p, p, C.byref(rej)) == E
+    assert L.bppp_u64_verify_batch_rlc_sharded(None, b"x", 1, 1, p, p, p, p, C.byref(rej), seed) == E
+    assert L.bppp_u64_verify_batch_sec1_sharded(None, b"x", 1, 1, p, p, p, p, C.byref(rej)) == E
+    assert L.bppp_u64_verify_batch_transcript_sharded(None, 1, p, 1, p, p, p, p, p, C.byref(rej)) == E
+    assert L.bppp_reciprocal_verify_batch_sharded(None, b"x", 1, 1, 16, 16, p, p, 4, 2, 1, p, p, C.byref(rej)) == E
+    assert L.bppp_reciprocal_verify_batch_rlc_sharded(None, b"x", 1, 1, 16, 16, p, p, 4, 2, 1, p, p, C.byref(rej), seed) == E
+    assert L.bppp_u64_verify_batch_sharded_device(None, b"x", 1, 1, arr, arr, arr, arr, arr) == E
+    assert L.bppp_u64_verify_batch_rlc_sharded_device(None, b"x", 1, 1, arr, arr, arr, arr, arr, seed) == E
+    assert L.bppp_u64_verify_batch_sec1_sharded_device(None, b"x", 1, 1, arr, arr, arr, arr, arr) == E
+    assert L.bppp_u64_verify_batch_transcript_sharded_device(None, 1, arr, 1, arr, arr, arr, arr, arr, arr) == E
+    assert L.bppp_reciprocal_verify_batch_sharded_device(None, b"x", 1, 1, 16, 16, arr, arr, 4, 2, 1, arr, arr, arr) == E
+    assert L.bppp_reciprocal_verify_batch_rlc_sharded_device(None, b"x", 1, 1, 16, 16, arr, arr, 4, 2, 1, arr, arr, arr, seed) == E
+    grp, dev = C.c_void_p(), (C.c_int * 2)(0, 0)
+    assert L.bppp_wnla_group_create(C.byref(grp), bytes(64), bytes(64), 1, bytes(64), 1, dev, 2, 8) == E and not grp.value   # a device twice
+    assert L.bppp_wnla_group_create(C.byref(grp), bytes(64), bytes(64), 1, bytes(64), 1, dev, 0, 8) == E                       # no devices
+    assert L.bppp_group_ctx(None, 0) is None and L.bppp_group_size(None) == 0
+    L.bppp_group_destroy(None)                                                                                                  # a no-op
+
+
 def test_header_is_plain_c_and_a_c_program_links(tmp_path):
     """The boundary is a C ABI: include/bppp.h must compile as C99 (no C++-isms, no torch / HIP types), and a C program must link
     against libbppp_hip.so and get BPPP_ERR_NO_DEVICE -- not a crash, not a fallback -- on a machine without a gfx950 device."""
