@@ -76,6 +76,67 @@ def test_u64_verify_at_baseline_sizes(torch_mod, oracle_c, log_n, wbits):
         proto.close()
 
 
+def test_u64_sharded_forms_at_one_gpus_share(torch_mod, monkeypatch):
+    """One GPU's share of BASELINE configs[2] (2^17 proofs) through the SHARDED entry points of a one-device group with its RCCL
+    communicator (the path a node-level caller takes): exact, RLC, SEC1 and caller-transcript forms on resident shards give the
+    expectation over the whole shard and the all-reduced reject count; the RLC form with every proof valid passes on its bucket stage."""
+    torch = torch_mod
+    import bench
+    from bp_pp_amd import synth, wire
+    from bp_pp_amd.distributed import U64RangeProofGroup
+    from bp_pp_amd.transcript import Transcript
+    n = 1 << 17
+    gens, g, gv, hv = bench.load_generators()
+    monkeypatch.setenv("BPPP_FORCE_RCCL", "1")
+    grp = U64RangeProofGroup(g, gv, hv, [0], fb_window_bits=16)
+    proto = grp.protocol(0)
+    try:
+        dV, dP, expect, _ = bench.make_resident_batch(torch, proto, synth, 1 << 19, (1 << 19) + n)
+        n_bad = int((expect == 0).sum())
+        assert n_bad == n // 1024
+        dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dS = torch.zeros(n, dtype=torch.int32, device="cuda")
+        dR = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        L = synth.LABEL
+        for seed in (None, bytes(range(32))):
+            dA.zero_(); dR.fill_(-7)
+            torch.cuda.synchronize()
+            grp.verify_batch_device(L, n, [dV.data_ptr()], [dP.data_ptr()], [dA.data_ptr()], [dS.data_ptr()], [dR.data_ptr()], rlc_seed=seed)
+            assert (dA.cpu().numpy() == expect).all() and int(dR.item()) == n_bad and not dS.any().item()
+        # caller transcripts: Transcript::new(label) shared by the shard == the label form
+        t0 = torch.from_numpy(np.frombuffer(Transcript(L).state, np.uint8).copy()).cuda()
+        dO = torch.zeros((n, 203), dtype=torch.uint8, device="cuda")
+        dA.zero_(); dR.fill_(-7)
+        torch.cuda.synchronize()
+        grp.verify_batch_transcripts_device(n, [t0.data_ptr()], 1, [dV.data_ptr()], [dP.data_ptr()], [dA.data_ptr()], [dS.data_ptr()], [dR.data_ptr()],
+                                            [dO.data_ptr()])
+        assert (dA.cpu().numpy() == expect).all() and int(dR.item()) == n_bad
+        assert bool((dO[:, 200] < 166).all().item())                       # every proof got an advanced, well-formed state back
+        # SEC1 form of the first 4096 proofs (the compression runs on the host in Python)
+        m = 4096
+        V, P = dV[:m].cpu().numpy(), dP[:m].cpu().numpy()
+        V33 = np.frombuffer(b"".join(wire.compress_point(bytes(v)) for v in V), np.uint8).reshape(m, 33)
+        P525 = np.frombuffer(b"".join(wire.abi_to_sec1(bytes(p)) for p in P), np.uint8).reshape(m, 525)
+        d33, d525 = torch.from_numpy(V33.copy()).cuda(), torch.from_numpy(P525.copy()).cuda()
+        dA.zero_(); dR.fill_(-7)
+        torch.cuda.synchronize()
+        grp.verify_batch_sec1_device(L, m, [d33.data_ptr()], [d525.data_ptr()], [dA.data_ptr()], [dS.data_ptr()], [dR.data_ptr()])
+        assert (dA[:m].cpu().numpy() == expect[:m]).all() and int(dR.item()) == int((expect[:m] == 0).sum())
+        # all valid: flip the corrupted bytes back; the RLC form accepts everything (bucket stage, superchunks of 512 at this size)
+        bad = np.nonzero(expect == 0)[0]
+        ti = torch.from_numpy(bad).cuda()
+        to = torch.from_numpy(np.array([synth.corrupt_offset((1 << 19) + int(j)) for j in bad], dtype=np.int64)).cuda()
+        dP[ti, to] = dP[ti, to] ^ 1
+        dA.zero_(); dR.fill_(-7)
+        torch.cuda.synchronize()
+        grp.verify_batch_device(L, n, [dV.data_ptr()], [dP.data_ptr()], [dA.data_ptr()], [dS.data_ptr()], [dR.data_ptr()], rlc_seed=bytes(32))
+        assert bool(dA.all().item()) and int(dR.item()) == 0
+    finally:
+        proto.close()
+        grp.close()
+
+
 def test_recip256_prove_and_verify_at_batch_scale(torch_mod):
     """BASELINE configs[4]'s shape at B = 2^12: multi-wavefront indexing, workspace growth and the fixed-base path of the
     generic kernels at batch scale (they were only exercised at B <= 4 before)."""
