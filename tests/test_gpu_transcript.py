@@ -209,7 +209,8 @@ def test_generic_provers_over_preloaded_transcripts_on_the_gpu():
         ckt.close()
 
 
-def test_every_sponge_position_in_one_batch():
+@pytest.mark.parametrize("full_batch_kernels", [False, True])
+def test_every_sponge_position_in_one_batch(full_batch_kernels, monkeypatch):
     """166 proofs whose transcripts sit at ALL 166 byte positions of the STROBE-128 rate (context messages of every length mod
     166): three wavefronts in which every lane is its own position group.  Proofs from the GPU prover over those transcripts, then
     verified over them: all accepted, the advanced states equal the prover's, and a sample (every 17th position) reproduced by the
@@ -217,6 +218,11 @@ def test_every_sponge_position_in_one_batch():
     import torch
     if torch.cuda.device_count() == 0:
         pytest.fail("needs a GPU")
+    if full_batch_kernels:
+        # the two-wave builds that full batches run -- sponge state in LDS (merlin.h: strobe_lds), one lane per proof -- forced onto
+        # this 166-proof batch, so that the position groups are exercised on THEM too (the context reads the switches when it is made)
+        monkeypatch.setenv("BPPP_NO_SMALL_KERNELS", "1")
+        monkeypatch.setenv("BPPP_NO_LANE_GROUPS", "1")
     import bppp_oracle as O
     import workload
     from transcript_cases import ser
@@ -264,7 +270,8 @@ def test_every_sponge_position_in_one_batch():
         assert oproto.verify(O.pt_from_xy64(bytes(com[i])), pr, tv) and ser(tv) == bytes(after_verify[i])
 
 
-def test_invalid_state_does_not_disturb_its_wavefront():
+@pytest.mark.parametrize("full_batch_kernels", [False, True])
+def test_invalid_state_does_not_disturb_its_wavefront(full_batch_kernels, monkeypatch):
     """Per-proof isolation through the DEVICE entry point (the host variants refuse such a state up front): one pre-loaded state merlin
     cannot be in (pos_begin = 200) sits in lane 0 -- the wavefront's first active lane, the leader of its position group -- among valid
     per-proof states at the same byte position.  That lane is flagged and rejected; its transcript restarts from the context's base, at
@@ -272,6 +279,9 @@ def test_invalid_state_does_not_disturb_its_wavefront():
     import torch
     if torch.cuda.device_count() == 0:
         pytest.fail("needs a GPU")
+    if full_batch_kernels:                                  # the LDS-sponge builds of full batches, forced onto this small one
+        monkeypatch.setenv("BPPP_NO_SMALL_KERNELS", "1")
+        monkeypatch.setenv("BPPP_NO_LANE_GROUPS", "1")
     import workload
     from bp_pp_amd import U64RangeProofProtocol, _capi, synth
     from bp_pp_amd.transcript import Transcript
