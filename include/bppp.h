@@ -258,7 +258,10 @@ BPPP_API int bppp_derive_generators(const uint8_t* seed, size_t seed_len, size_t
 /* The fixed-base tables of a context as a file, and a context created from such a file instead of from the generators (any of the
  * bppp_ctx_create / bppp_wnla_ctx_create shapes).  NOTE: the tables are BUILT on the GPU in 0.5 s (79 GB, 22-bit) to 3 s -- faster than any
  * disk or PCIe can deliver them -- so the file is for reproducibility and inspection, not for start-up time; what saves memory and
- * time is bppp_ctx_create_shared. */
+ * time is bppp_ctx_create_shared.  The file (magic "BPPPTAB2") carries a checksum over the generators and the table body, and the
+ * stored generators are validated as bppp_ctx_create validates them: a truncated, damaged or foreign file makes
+ * bppp_ctx_create_from_tables fail (BPPP_ERR_INVALID_ARG / BPPP_ERR_ENCODING) instead of yielding a verifier over wrong bases.  The
+ * checksum is not a MAC: whoever can rewrite the file can rewrite it too -- rebuild the tables when the storage is not trusted. */
 BPPP_API int bppp_ctx_save_tables(bppp_ctx* ctx, const char* path);
 BPPP_API int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device);
 /* A further context on the same GPU that shares `parent`'s generators and tables (read-only) and owns its streams and workspaces:
