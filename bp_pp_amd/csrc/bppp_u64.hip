@@ -382,7 +382,7 @@ static int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len
     PMSM(job_c0());
     for (int k = 1; k <= 4; k++) {
         PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
-        PMSM(job_x()); PMSM(job_r());
+        PMSM(job_x()); PMSM(job_r(k));
         if (!c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
             PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
         else if (w2)

@@ -56,9 +56,11 @@ struct ProveWs {
     size_t n_states;
     uint8_t* states_out;
 };
-struct MsmJob {             // one fixed-base MSM per proof: sum over up to 3 contiguous base ranges of scalar set `set`
+struct MsmJob {             // one fixed-base MSM per proof: sum over runs of bases of scalar set `set` (verify_core.h: FbRanges)
     int set, out_slot, nranges;
-    int first[3], count[3];
+    int first[BPPP_FB_MAX_RUNS], count[BPPP_FB_MAX_RUNS];
+    int bits[BPPP_FB_MAX_RUNS];     // > 0: the run's scalars are below 2^bits (hex digits, multiplicities, the u64 value)
+    int oddsh[BPPP_FB_MAX_RUNS];    // >= 0: only the odd blocks of 2^oddsh terms are present; count = present terms
 };
 
 HD void pw_ld_sc(sc& r, const ProveWs& w, size_t t, int slot) { ws_ld8(r.v, w.sv, w.N, t, slot); }
@@ -72,7 +74,10 @@ HD bool pw_rnd(sc& r, const ProveWs& w, size_t t, int i) { return sc_from_be(r, 
 // MSM lane work (8 lanes per proof on the device; fb_group_sum tree-adds the partial sums)
 HD void prove_msm_ranges(FbRanges& rg, const MsmJob& job) {
     rg.n = job.nranges;
-    for (int r = 0; r < job.nranges; r++) { rg.slot[r] = job.set * BPPP_NG + job.first[r]; rg.base[r] = job.first[r]; rg.count[r] = job.count[r]; }
+    for (int r = 0; r < job.nranges; r++) {
+        rg.slot[r] = job.set * BPPP_NG + job.first[r]; rg.base[r] = job.first[r]; rg.count[r] = job.count[r];
+        rg.bits[r] = job.bits[r]; rg.oddsh[r] = job.oddsh[r];
+    }
 }
 HD void prove_msm_store(const ProveWs& w, const MsmJob& job, size_t t, const pt& total) { pw_st_pt(w, t, job.out_slot, total); }
 HD void prove_msm(const ProveWs& w, const MsmJob& job, size_t t) {   // single-thread form (host emulation)
@@ -660,15 +665,23 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k, int group_lane = -1)
 }
 
 // the MSM jobs of the pipeline, in launch order
-HD MsmJob job_v() { MsmJob j = {0, PB_V, 2, {0, 17, 0}, {1, 1, 0}}; return j; }
-HD MsmJob job_rcom() { MsmJob j = {0, PB_RCOM, 2, {17, 26, 0}, {1, 16, 0}}; return j; }
-HD MsmJob job_co() { MsmJob j = {1, PB_CO, 1, {17, 0, 0}, {9, 0, 0}}; return j; }
-HD MsmJob job_cl() { MsmJob j = {2, PB_CL, 1, {1, 0, 0}, {41, 0, 0}}; return j; }
-HD MsmJob job_cr() { MsmJob j = {3, PB_CR, 1, {1, 0, 0}, {25, 0, 0}}; return j; }
-HD MsmJob job_cs() { MsmJob j = {0, PB_CS, 1, {1, 0, 0}, {42, 0, 0}}; return j; }
-HD MsmJob job_c0() { MsmJob j = {0, PB_C, 1, {0, 0, 0}, {43, 0, 0}}; return j; }
-HD MsmJob job_x() { MsmJob j = {1, PB_X, 1, {0, 0, 0}, {49, 0, 0}}; return j; }
-HD MsmJob job_r() { MsmJob j = {2, PB_R, 1, {0, 0, 0}, {49, 0, 0}}; return j; }
+// The MSMs of the prover, over exactly the terms that are there.  Round 2 summed every slot of a contiguous range at full width; a
+// quarter of those table additions had a zero digit by construction: hexadecimal digits and multiplicities below 2^5, the u64 value,
+// blinding slots the reference leaves at zero (circuit.rs:264-298), and the even halves of R's folded vectors (wnla.rs:140-150).
+#define BPPP_JOB(...) MsmJob j = __VA_ARGS__; return j
+#define NOODD {-1, -1, -1, -1, -1}
+HD MsmJob job_v() { BPPP_JOB({0, PB_V, 2, {0, 17}, {1, 1}, {64, 0}, NOODD}); }                                    // x g + s h[0]
+HD MsmJob job_rcom() { BPPP_JOB({0, PB_RCOM, 2, {17, 26}, {1, 16}, {0, 0}, NOODD}); }
+HD MsmJob job_co() { BPPP_JOB({1, PB_CO, 2, {17, 22}, {4, 3}, {0, 0}, NOODD}); }                                  // ro: h[4], h[8] stay zero
+HD MsmJob job_cl() { BPPP_JOB({2, PB_CL, 4, {1, 17, 21, 26}, {16, 3, 3, 16}, {4, 0, 0, 5}, NOODD}); }            // digits | rl: h[3], h[7], h[8] zero | multiplicities
+HD MsmJob job_cr() { BPPP_JOB({3, PB_CR, 3, {1, 17, 20}, {16, 2, 3}, {0, 0, 0}, NOODD}); }                        // r | rr: h[2], h[6..8] zero
+HD MsmJob job_cs() { BPPP_JOB({0, PB_CS, 1, {1}, {42}, {0}, NOODD}); }
+HD MsmJob job_c0() { BPPP_JOB({0, PB_C, 1, {0}, {43}, {0}, NOODD}); }
+HD MsmJob job_x() { BPPP_JOB({1, PB_X, 1, {0}, {49}, {0}, NOODD}); }
+// R of round k: v_r g + the odd halves (blocks of 2^(k-1) original generators) of g_vec and h_vec
+HD MsmJob job_r(int k) { BPPP_JOB({2, PB_R, 3, {0, 1, 17}, {1, 8, 16}, {0, 0, 0}, {-1, k - 1, k - 1}}); }
+#undef NOODD
+#undef BPPP_JOB
 
 // the caller's `&mut Transcript` after prove: the state after the last wnla_challenge (a PRF operation: cur_flags = 7); a flagged
 // instance (malformed input scalar or state) gets its input state back

@@ -247,6 +247,20 @@ HD bool fb_signed(int W) { return W == 20 || W == 10 || W == 22; }
 HD int fb_nwin(int W) { return fb_signed(W) ? (W == 22 ? 12 : 260 / W) : 256 / W; }   // signed: ceil(257 / W) windows
 HD size_t fb_per_win(int W) { return fb_signed(W) ? ((size_t)1 << (W - 1)) : (((size_t)1 << W) - 1); }
 HD FbTable fb_of(const VerifyWs& ws) { FbTable f = {ws.fb_table, ws.fb_w, ws.N}; return f; }
+// windows a scalar below 2^bits can reach (0 = full width).  Signed digits: the recoded value is sum d_i 2^(W i) with d_i in
+// [-2^(W-1), 2^(W-1)), and the top digit absorbs a carry of at most one, so ceil((bits + 1) / W) windows hold everything.
+HD int fb_windows_for(int bits, int W) {
+    const int all = fb_nwin(W);
+    if (bits <= 0) return all;
+    const int need = fb_signed(W) ? (bits + 1 + W - 1) / W : (bits + W - 1) / W;
+    return need < all ? need : all;
+}
+// index (within its run) of the a-th PRESENT term
+HD int fb_term_index(int a, int oddsh) {
+    if (oddsh < 0) return a;
+    const int B = 1 << oddsh;
+    return (((a >> oddsh) << 1) + 1) * B + (a & (B - 1));
+}
 // digit of window w: returns the table index (|d| - 1), whether to skip (d == 0) and whether to negate
 HD void fb_digit(const u32 k[8], int W, int w, size_t& idx, bool& skip, bool& neg) {
     if (!fb_signed(W)) {
@@ -316,14 +330,15 @@ HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, 
 // path has intra-proof parallelism; it lifts the kernel from 1 to 4 resident wavefronts per SIMD at 2^16 proofs.
 #define BPPP_FB_LANES 8
 HD void fixed_base_msm_partial(pt& accp, const FbTable& fbt, size_t t, int lane, const u32* scal, int first_slot, int first_base,
-                               int count, int nl = BPPP_FB_LANES) {
-    const int nwin = fb_nwin(fbt.W);
+                               int count, int nl = BPPP_FB_LANES, int bits = 0, int oddsh = -1) {
+    const int nwin = fb_windows_for(bits, fbt.W);
     pt acc;
     pt_set_identity(acc);
     if (nwin % nl == 0) {
         // every lane takes the windows congruent to it: the scalar is loaded once per base and shared by the group
 #pragma nounroll
-        for (int j = 0; j < count; j++) {
+        for (int a = 0; a < count; a++) {
+            const int j = fb_term_index(a, oddsh);
             u32 k[8];
             ws_ld8(k, scal, fbt.N, t, first_slot + j);
 #pragma nounroll
@@ -334,7 +349,7 @@ HD void fixed_base_msm_partial(pt& accp, const FbTable& fbt, size_t t, int lane,
         const int pairs = count * nwin;
 #pragma nounroll
         for (int q = lane; q < pairs; q += nl) {
-            const int j = q / nwin, w = q - j * nwin;
+            const int a = q / nwin, w = q - a * nwin, j = fb_term_index(a, oddsh);
             u32 k[8];
             ws_ld8(k, scal, fbt.N, t, first_slot + j);
             fb_lookup_add(acc, fbt, first_base + j, w, k);
@@ -384,8 +399,8 @@ HD void fb_consume_fast(ptz& acc, bool& empty, const apt_packed& pe, bool skip, 
     ptz_madd(acc, empty, e, skip | id);
 }
 HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, size_t t, int lane, const u32* scal, int first_slot,
-                                int first_base, int count, int nl = BPPP_FB_LANES) {
-    const int nwin = fb_nwin(fbt.W);
+                                int first_base, int count, int nl = BPPP_FB_LANES, int bits = 0, int oddsh = -1) {
+    const int nwin = fb_windows_for(bits, fbt.W);
     // step i of this lane -> (base j, window w): windows congruent to the lane when they divide evenly, else the
     // (base, window) pairs dealt round-robin (13 windows do not divide over 8 lanes)
     const bool by_window = (nwin % nl) == 0;
@@ -394,14 +409,16 @@ HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, size_
     if (steps <= 0) return;
     auto locate = [&](int i, int& j, int& w) {      // steps past the end re-use the last one (requested, never consumed)
         if (i > steps - 1) i = steps - 1;
+        int a;                                      // the step's term, counted among the PRESENT terms of the run
         if (by_window) {
-            j = i / per_base;
-            w = lane + nl * (i - j * per_base);
+            a = i / per_base;
+            w = lane + nl * (i - a * per_base);
         } else {
             const int q = lane + nl * i;
-            j = q / nwin;
-            w = q - j * nwin;
+            a = q / nwin;
+            w = q - a * nwin;
         }
+        j = fb_term_index(a, oddsh);
     };
     int j, w, j2, w2;
     u32 k[8];
@@ -434,18 +451,27 @@ HD bool fb_lane_finish_fast(pt& part, const ptz& acc, bool empty) {
     return !exceptional;
 }
 // The sums every fixed-base kernel computes are described as up to 3 runs of consecutive (scalar slot, base) pairs.
+// A run can say two things about its scalars that spare table additions (the provers use both; every verifier sum is full-width):
+//   bits  > 0: every scalar of the run is below 2^bits (a hexadecimal digit, a multiplicity, a u64 value): only the windows such a
+//              value reaches are looked up (fb_windows_for) -- the others hold the zero digit by construction;
+//   oddsh >= 0: only the ODD blocks of 2^oddsh consecutive terms are present (terms (2 b + 1) 2^oddsh + r, r < 2^oddsh): the WNLA
+//              prover's R is a sum over the odd halves of the folded vectors, the even ones have scalar zero (wnla.rs:140-150);
+//              `count` then counts the terms that ARE present.
+#define BPPP_FB_MAX_RUNS 5
 struct FbRanges {
     int n;
-    int slot[3], base[3], count[3];
+    int slot[BPPP_FB_MAX_RUNS], base[BPPP_FB_MAX_RUNS], count[BPPP_FB_MAX_RUNS];
+    int bits[BPPP_FB_MAX_RUNS] = {0, 0, 0, 0, 0};
+    int oddsh[BPPP_FB_MAX_RUNS] = {-1, -1, -1, -1, -1};
 };
-HD void fb_ranges_one(FbRanges& r, int slot, int base, int count) { r.n = 1; r.slot[0] = slot; r.base[0] = base; r.count[0] = count; }
+HD void fb_ranges_one(FbRanges& r, int slot, int base, int count) { r.n = 1; r.slot[0] = slot; r.base[0] = base; r.count[0] = count; r.bits[0] = 0; r.oddsh[0] = -1; }
 HD void fb_lane_sum_complete(pt& part, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg, int nl = BPPP_FB_LANES) {
     pt acc;
     pt_set_identity(acc);
 #pragma nounroll
     for (int r = 0; r < rg.n; r++) {
         pt p;
-        fixed_base_msm_partial(p, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r], nl);
+        fixed_base_msm_partial(p, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r], nl, rg.bits[r], rg.oddsh[r]);
         pt_add(acc, acc, p);
     }
     part = acc;
@@ -455,7 +481,7 @@ HD bool fb_lane_sum_fast(pt& part, const FbTable& fbt, size_t t, int lane, const
     ptz_init(acc);
     bool empty = true;
 #pragma nounroll
-    for (int r = 0; r < rg.n; r++) fb_lane_accumulate_fast(acc, empty, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r], nl);
+    for (int r = 0; r < rg.n; r++) fb_lane_accumulate_fast(acc, empty, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r], nl, rg.bits[r], rg.oddsh[r]);
     return fb_lane_finish_fast(part, acc, empty);
 }
 // single-thread form of the group sum (host emulation, and device code that runs one thread per proof)

@@ -448,7 +448,7 @@ static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label
     msm(job_c0());
     for (int k = 1; k <= 4; k++) {
         for (size_t t = 0; t < n; t++) prove_round_scalars(w, t, k);
-        msm(job_x()); msm(job_r());
+        msm(job_x()); msm(job_r(k));
         for (size_t t = 0; t < n; t++) prove_round_fold(w, t, k);
     }
     for (size_t t = 0; t < n; t++) prove_export_state(w, t);
