@@ -676,10 +676,10 @@ static int wnla_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, 
     k_wprove_init<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     for (int k = 0; k < (int)rounds; k++) {
         k_wprove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
-        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
-        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0, -1);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1, k);
         k_wprove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
-        if (k + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2);
+        if (k + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2, -1);
     }
     k_wprove_finish<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     HIP_TRY(hipGetLastError());
@@ -790,10 +790,10 @@ static int circuit_prove_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t*
     k_wprove_init<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     for (int kk = 0; kk < (int)rounds; kk++) {
         k_wprove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
-        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
-        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0, -1);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1, kk);
         k_wprove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
-        if (kk + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2);
+        if (kk + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2, -1);
     }
     k_wprove_finish<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     HIP_TRY(hipGetLastError());
@@ -953,10 +953,10 @@ static int recip_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
     k_wprove_init<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     for (int kk = 0; kk < (int)rounds; kk++) {
         k_wprove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
-        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
-        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0, -1);
+        k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1, kk);
         k_wprove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
-        if (kk + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2);
+        if (kk + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2, -1);
     }
     k_wprove_finish<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     HIP_TRY(hipGetLastError());

@@ -366,7 +366,13 @@ static int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len
         rc = timed(c, id, s, [&]() { __VA_ARGS__; });          \
         if (rc != BPPP_OK) return rc;                          \
     } while (0)
-#define PMSM(job) PLAUNCH(K_PROVE_MSM, k_prove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job))
+    const bool fb_one_lane = c->fb_one_lane_mode >= 0 ? c->fb_one_lane_mode == 1 : n >= (size_t)128 * (size_t)c->n_simds;
+    const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+#define PMSM(job)                                                                                         \
+    do {                                                                                                  \
+        if (fb_one_lane) PLAUNCH(K_PROVE_MSM, k_prove_msm_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job)); \
+        else PLAUNCH(K_PROVE_MSM, k_prove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job));               \
+    } while (0)
     // a grid that gives every SIMD more than one wavefront runs the 256-register builds of the lane kernels (two wavefronts per SIMD)
     const bool w2 = !c->prove_uncapped && (c->no_small || blocks > (unsigned)c->n_simds);
     PLAUNCH(K_PROVE_STAGES, k_prove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(w));

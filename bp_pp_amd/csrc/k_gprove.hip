@@ -25,14 +25,14 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_scalars(WnlaProveWs
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) wnla_prove_round_scalars(w, t, k);
 }
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wprove_msm(WnlaProveWs w, int set) {
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wprove_msm(WnlaProveWs w, int set, int oddsh) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
     size_t t = g / BPPP_FB_LANES;
     int lane = (int)(g % BPPP_FB_LANES);
     if (t >= w.N) return;
     pt part;
     FbRanges rg;
-    wnla_prove_msm_ranges(rg, w);
+    wnla_prove_msm_ranges(rg, w, oddsh);
     fb_group_sum(part, w.fb, t, lane, w.msc + (size_t)set * wp_set_words(w), rg);
     if (lane == 0) ws_st_pt(w.pbuf + (size_t)set * 30 * w.N, w.N, t, part);
 }

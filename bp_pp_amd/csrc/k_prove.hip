@@ -51,17 +51,22 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold_g4(ProveWs w, i
     const int q = (int)(g & 3);
     for_each_position_group(prove_position_key(w, t), [&]() { prove_round_fold(w, t, k, q); });
 }
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(ProveWs w, MsmJob job) {
+// NL lanes per proof: 8 while the batch is small, 1 from the size at which one lane per proof fills the SIMDs twice over (as in the
+// verifier's fixed-base kernels, k_verify_fixed.hip): no idle lanes in the short runs, no 3-step tree of complete additions per sum
+template <int NL>
+__device__ __forceinline__ void prove_msm_lanes(const ProveWs& w, const MsmJob& job) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
+    size_t t = g / NL;
+    int lane = (int)(g % NL);
     if (t >= w.N) return;
     pt part;
     FbRanges rg;
     prove_msm_ranges(rg, job);
-    fb_group_sum(part, w.fb, t, lane, w.msc, rg);
+    fb_group_sum<NL>(part, w.fb, t, lane, w.msc, rg);
     if (lane == 0) prove_msm_store(w, job, t, part);
 }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(ProveWs w, MsmJob job) { prove_msm_lanes<BPPP_FB_LANES>(w, job); }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l1(ProveWs w, MsmJob job) { prove_msm_lanes<1>(w, job); }
 
 // ---- the lane kernels above at two wavefronts per SIMD (256 VGPR + AGPR), for prove batches that give every SIMD more than one
 // wavefront (beyond 2^16 values; BASELINE configs[3]'s 2^14 values are 256 workgroups on 1024 SIMDs and keep the uncapped builds):

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_f_w2(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_fold_w2(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(bppp::ProveWs w, bppp::MsmJob job);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l1(bppp::ProveWs w, bppp::MsmJob job);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_scalars(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round(bppp::WnlaWs w, int k);
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(bppp::WnlaWs w);
 __global__ __launch_bounds__(256) void k_count_rejects(const uint8_t* accept, size_t n, int* reject_count);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_init(bppp::WnlaProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_scalars(bppp::WnlaProveWs w, int k);
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wprove_msm(bppp::WnlaProveWs w, int set);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wprove_msm(bppp::WnlaProveWs w, int set, int oddsh);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_fold(bppp::WnlaProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_gprove_export_states(bppp::TranscriptIo io, bppp::strobe base, const bppp::u32* tstate, size_t N, const int32_t* status);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_finish(bppp::WnlaProveWs w);

@@ -156,7 +156,17 @@ HD void wnla_prove_round_scalars(const WnlaProveWs& w, size_t t, int k) {
         ws_st8(mr, N, t, 1 + i, (p & 1) ? t2.v : zero.v);
     }
 }
-HD void wnla_prove_msm_ranges(FbRanges& rg, const WnlaProveWs& w) { fb_ranges_one(rg, 0, 0, 1 + w.ng + w.nh); }
+// terms of the three MSMs of a round.  X and the next commitment take every generator; R (oddsh = the round number k) only the
+// generators whose folded slot i >> k is odd -- wnla_prove_round_scalars stores zero for the others -- so its two generator runs
+// enumerate the odd blocks of 2^k terms only (fb_term_index)
+HD int wnla_odd_block_terms(int n, int sh) { const int B = 1 << sh, rem = n & (2 * B - 1); return ((n >> (sh + 1)) << sh) + (rem > B ? rem - B : 0); }
+HD void wnla_prove_msm_ranges(FbRanges& rg, const WnlaProveWs& w, int oddsh = -1) {
+    if (oddsh < 0) { fb_ranges_one(rg, 0, 0, 1 + w.ng + w.nh); return; }
+    rg.n = 3;
+    rg.slot[0] = 0; rg.base[0] = 0; rg.count[0] = 1; rg.bits[0] = 0; rg.oddsh[0] = -1;
+    rg.slot[1] = 1; rg.base[1] = 1; rg.count[1] = wnla_odd_block_terms(w.ng, oddsh); rg.bits[1] = 0; rg.oddsh[1] = oddsh;
+    rg.slot[2] = 1 + w.ng; rg.base[2] = 1 + w.ng; rg.count[2] = wnla_odd_block_terms(w.nh, oddsh); rg.bits[2] = 0; rg.oddsh[2] = oddsh;
+}
 // round k: X, R (and, from round 1 on, this level's commitment) to affine, transcript, challenge, fold, next commitment's scalars
 HD void wnla_prove_round_fold(const WnlaProveWs& w, size_t t, int k) {
     const size_t N = w.N;

@@ -738,11 +738,11 @@ int emul_wnla_prove(const uint8_t* table, int W, int ng, int nh, const uint8_t* 
     t_new(w.base, label, (u32)label_len);
     w.tio = take_tio();
     w.tio.no_ops = rounds == 0;
-    auto msm = [&](int set) {
+    auto msm = [&](int set, int oddsh = -1) {
         for (size_t t = 0; t < n; t++) {
             pt a;
             FbRanges rg;
-            wnla_prove_msm_ranges(rg, w);
+            wnla_prove_msm_ranges(rg, w, oddsh);
             fb_sum_serial(a, w.fb, t, w.msc + (size_t)set * wp_set_words(w), rg);
             ws_st_pt(w.pbuf + (size_t)set * 30 * n, n, t, a);
         }
@@ -751,7 +751,7 @@ int emul_wnla_prove(const uint8_t* table, int W, int ng, int nh, const uint8_t* 
     for (int k = 0; k < (int)rounds; k++) {
         for (size_t t = 0; t < n; t++) wnla_prove_round_scalars(w, t, k);
         msm(0);
-        msm(1);
+        msm(1, k);
         for (size_t t = 0; t < n; t++) wnla_prove_round_fold(w, t, k);
         if (k + 1 < (int)rounds) msm(2);
     }
@@ -818,11 +818,11 @@ int emul_circuit_prove(const uint8_t* table, int W, int NG, int NH, const size_t
             ws_st_pt(p.pbuf + (size_t)set * 30 * n, n, t, a);
         }
     };
-    auto wmsm = [&](int set) {
+    auto wmsm = [&](int set, int oddsh = -1) {
         for (size_t t = 0; t < n; t++) {
             pt a;
             FbRanges rg;
-            wnla_prove_msm_ranges(rg, w);
+            wnla_prove_msm_ranges(rg, w, oddsh);
             fb_sum_serial(a, w.fb, t, w.msc + (size_t)set * wp_set_words(w), rg);
             ws_st_pt(w.pbuf + (size_t)set * 30 * n, n, t, a);
         }
@@ -838,7 +838,7 @@ int emul_circuit_prove(const uint8_t* table, int W, int NG, int NH, const size_t
     for (int kk = 0; kk < (int)rounds; kk++) {
         for (size_t t = 0; t < n; t++) wnla_prove_round_scalars(w, t, kk);
         wmsm(0);
-        wmsm(1);
+        wmsm(1, kk);
         for (size_t t = 0; t < n; t++) wnla_prove_round_fold(w, t, kk);
         if (kk + 1 < (int)rounds) wmsm(2);
     }
@@ -930,7 +930,7 @@ int emul_recip_prove(const uint8_t* table, int W, int NG, int NH, int nd, int np
     for (int kk = 0; kk < (int)rounds; kk++) {
         for (size_t t = 0; t < n; t++) wnla_prove_round_scalars(w, t, kk);
         sum(rg, w.msc, w.pbuf);
-        sum(rg, w.msc + wp_set_words(w), w.pbuf + 30 * n);
+        { FbRanges rr; wnla_prove_msm_ranges(rr, w, kk); sum(rr, w.msc + wp_set_words(w), w.pbuf + 30 * n); }
         for (size_t t = 0; t < n; t++) wnla_prove_round_fold(w, t, kk);
         if (kk + 1 < (int)rounds) sum(rg, w.msc + 2 * wp_set_words(w), w.pbuf + 60 * n);
     }
