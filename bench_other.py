@@ -1,7 +1,8 @@
 """bench.py --workload prove | recip256: the two BASELINE.json configurations beside the headline verify metric, each with its own
 JSON line carrying `roofline` (dominant kernel, live HIP-event time, algorithmic bytes of SURVEY.md 8d) and `cpu_baseline`
-(the oracle on a bounded sample).  Inputs resident in HBM when the timed region starts.  `prove` is a one-GPU configuration;
-`recip256` shards ONE fixed batch over the ranks like the headline metric does (BASELINE configs[4]: 2^18 instances on 8 GPUs).
+(the oracle on a bounded sample).  Inputs resident in HBM when the timed region starts.  Both shard ONE fixed batch over the ranks like
+the headline metric does (`prove`: BASELINE configs[3] is 2^14 values on one GPU, N > 1 has no exchange step; `recip256`: BASELINE
+configs[4], 2^18 instances on 8 GPUs).
 The measure_* functions return the JSON object: bench.py's default line embeds reduced-size runs of both as secondary objects."""
 import json
 import os
@@ -16,14 +17,21 @@ def _dominant(kernel_times):
     return name, t, t["total_ms"] / max(1, t["launches"])
 
 
-def measure_prove(args, proto, gens, n, cpu_baseline=True, cpu_sample=4096):
-    """BASELINE configs[3] on an existing u64 context: batch-prove n u64 values resident in HBM (u64_proof.rs:57-82 ->
-    circuit.rs:260-556 -> wnla.rs:125-190).  Returns the JSON object (value, ms_per_step, roofline, cpu_baseline, ...)."""
+def measure_prove(args, proto, gens, total, cpu_baseline=True, cpu_sample=4096, world=1, rank=0):
+    """BASELINE configs[3] on an existing u64 context: batch-prove ONE fixed batch of `total` u64 values, this rank's contiguous shard
+    of it resident in HBM (u64_proof.rs:57-82 -> circuit.rs:260-556 -> wnla.rs:125-190).  Proofs are independent: with world > 1
+    there is no exchange step at all, only the barrier and the max-over-ranks clock of the bench contract.  Returns the JSON object
+    (value, ms_per_step, roofline, cpu_baseline, ...)."""
     import numpy as np
     import torch
+    import torch.distributed as dist
     import bench
     from bp_pp_amd import synth as workload
-    x_h, s_h, r_h = workload.bulk_values(n), workload.bulk_blindings(n), workload.bulk_prover_randomness(n)
+    from bp_pp_amd.distributed import shard_range
+    lo, hi = shard_range(total, rank, world)
+    n = hi - lo
+    dist_on = world > 1 and dist.is_initialized()
+    x_h, s_h, r_h = workload.bulk_values(n, first=lo), workload.bulk_blindings(n, first=lo), workload.bulk_prover_randomness(n, first=lo)
     dx = torch.from_numpy(x_h.view(np.int64)).cuda()
     ds, dr = torch.from_numpy(s_h).cuda(), torch.from_numpy(r_h).cuda()
     dP = torch.zeros((n, 928), dtype=torch.uint8, device="cuda")
@@ -40,27 +48,44 @@ def measure_prove(args, proto, gens, n, cpu_baseline=True, cpu_sample=4096):
     proto.enable_timing(True)
     proto.timings(reset=True)
     proto.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     proto.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
     kt = {k: v for k, v in proto.timings(reset=True).items() if v["launches"]}
     proto.enable_timing(False)
     # what was timed is correct: no status flag, and the product verifier accepts every proof
     P, V = dP.cpu().numpy(), dV.cpu().numpy()
     acc, vst = proto.verify_batch(V, P, workload.LABEL)
     ok = bool(acc.all()) and not vst.any() and not bool(dSt.any().item())
+    if dist_on:
+        ok_t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        ok = bool(ok_t.item())
     dom, dom_t, avg_ms = _dominant(kt)
     launches_per_step = dom_t["launches"] / args.steps
     achieved = bench.ALGO_BYTES_PER_PROVE * n / (avg_ms * 1e-3) / 1e9
     result = {
-        "metric": "u64 range proofs proved/sec (batch)", "value": n * args.steps / elapsed, "unit": "proves/s", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": "u64 range proofs proved/sec (batch)", "value": total * args.steps / elapsed, "unit": "proves/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"batch prove {n} u64 values on one GPU (BASELINE configs[3]); x, s and the 52 prover scalars per proof resident "
-                               "in HBM, device-side transcripts, proofs byte-identical to the CPU prover's for the same draws",
-                   "proofs_per_step": n, "fb_window_bits": args.fb_window_bits or "library default", "label": workload.LABEL.decode()},
+        "config": {"workload": f"batch prove ONE fixed batch of {total} u64 values (BASELINE configs[3]: 2^14 on one GPU)"
+                               + (f", sharded contiguously over {world} GPUs ({n} per GPU), no exchange step" if world > 1 else " on one GPU")
+                               + "; x, s and the 52 prover scalars per proof resident in HBM, device-side transcripts, proofs byte-identical "
+                               "to the CPU prover's for the same draws",
+                   "total_proofs_per_step": total, "proofs_per_gpu": n, "fb_window_bits": args.fb_window_bits or "library default",
+                   "label": workload.LABEL.decode(), "parallelism": "single" if world == 1 else f"shard{world}"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / bench.HBM_PEAK_GBS,
                      "traffic": bench.pmc_traffic(dom, n), "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_launch": bench.ALGO_BYTES_PER_PROVE * n,
@@ -69,7 +94,7 @@ def measure_prove(args, proto, gens, n, cpu_baseline=True, cpu_sample=4096):
         "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kt.items()},
         "proofs_verify": ok,
     }
-    if cpu_baseline:
+    if cpu_baseline and rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import bppp_oracle_c as OC                                   # the oracle, as the timed CPU baseline ONLY
         m = min(cpu_sample, n)                                       # ~10 s of host work on 64 threads
@@ -92,13 +117,16 @@ def run_prove(args):
     """bench.py --workload prove: BASELINE configs[3], its own JSON line."""
     import bench
     world, rank, local_rank = bench.setup_dist(args)
-    assert world == 1, "the prove workload is a single-GPU configuration (BASELINE configs[3])"
     from bp_pp_amd import U64RangeProofProtocol
     gens, g, gv, hv = bench.load_generators()
-    proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=args.fb_window_bits)
-    result, ok = measure_prove(args, proto, gens, args.total_proofs, cpu_baseline=not args.no_cpu_baseline)
-    print(json.dumps(result), flush=True)
+    proto = U64RangeProofProtocol(g, gv, hv, device=local_rank, fb_window_bits=args.fb_window_bits)
+    result, ok = measure_prove(args, proto, gens, args.total_proofs, cpu_baseline=not args.no_cpu_baseline, world=world, rank=rank)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
     proto.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     if not ok:
         sys.exit(1)
 

@@ -30,6 +30,7 @@ EXPORTS = [
     "bppp_u64_verify_batch_sec1_sharded", "bppp_u64_verify_batch_sec1_sharded_device", "bppp_u64_verify_batch_transcript_sharded",
     "bppp_u64_verify_batch_transcript_sharded_device", "bppp_reciprocal_verify_batch_sharded", "bppp_reciprocal_verify_batch_rlc_sharded",
     "bppp_reciprocal_verify_batch_sharded_device", "bppp_reciprocal_verify_batch_rlc_sharded_device",
+    "bppp_u64_prove_batch_sharded", "bppp_u64_prove_batch_sharded_device",
 ]
 
 _lib = None
@@ -151,6 +152,8 @@ def lib():
     L.bppp_u64_verify_batch_sec1_sharded_device.argtypes = [vp, u8p, sz, sz, pvp, pvp, pvp, pvp, pvp]
     L.bppp_u64_verify_batch_transcript_sharded.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, vp, C.POINTER(C.c_int32)]
     L.bppp_u64_verify_batch_transcript_sharded_device.argtypes = [vp, sz, pvp, sz, pvp, pvp, pvp, pvp, pvp, pvp]
+    L.bppp_u64_prove_batch_sharded.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, vp, vp]
+    L.bppp_u64_prove_batch_sharded_device.argtypes = [vp, u8p, sz, sz, pvp, pvp, pvp, pvp, pvp, pvp]
     L.bppp_reciprocal_verify_batch_sharded.argtypes = [vp, u8p, sz, sz, sz, sz, vp, vp, sz, sz, sz, vp, vp, C.POINTER(C.c_int32)]
     L.bppp_reciprocal_verify_batch_rlc_sharded.argtypes = [vp, u8p, sz, sz, sz, sz, vp, vp, sz, sz, sz, vp, vp, C.POINTER(C.c_int32), u8p]
     L.bppp_reciprocal_verify_batch_sharded_device.argtypes = [vp, u8p, sz, sz, sz, sz, pvp, pvp, sz, sz, sz, pvp, pvp, pvp]

@@ -167,6 +167,7 @@ struct ShardedCall {
     bool device_form = false;
     void* const* d_reject_count = nullptr;   // device form: per-rank int32[1], receives the global count
     int32_t* reject_count = nullptr;         // host form (optional)
+    bool exchange = true;                    // false: a call with no exchange step (prove) -- no reject counter, no collective
     // enqueue rank r's shard: m proofs, p[i] = device pointer of array i, d_rej = device reject counter
     std::function<int(int r, bppp_ctx* c, size_t m, void* const* p, void* d_rej)> enqueue;
 };
@@ -192,7 +193,7 @@ int run_call(ShardedCall& call) {
         if (r == fault_rank) { g_last_error = "injected fault (bppp_group_set_option inject_fault_rank)"; return BPPP_ERR_NOMEM; }
         if (call.device_form) {
             for (size_t i = 0; i < NA; i++) ptrs[r][i] = const_cast<void*>(call.arrays[i].dev ? call.arrays[i].dev[r] : nullptr);
-            rej[r] = call.d_reject_count[r];
+            rej[r] = call.exchange ? call.d_reject_count[r] : nullptr;
         } else {
             // the shard goes through the context's persistent I/O staging, exactly as the single-device host entry points do
             size_t off = 0;
@@ -216,13 +217,16 @@ int run_call(ShardedCall& call) {
                 const size_t rows = a.shared_rows ? a.shared_rows : m, first = a.shared_rows ? 0 : lo;
                 if (rows) HIP_TRY(hipMemcpyAsync(ptrs[r][i], (const uint8_t*)a.host_in + first * a.stride, rows * a.stride, hipMemcpyHostToDevice, c->stream));
             }
-            rej[r] = grp->d_rej[r];
+            rej[r] = call.exchange ? grp->d_rej[r] : nullptr;
         }
-        if (m == 0) { HIP_TRY(hipMemsetAsync(rej[r], 0, sizeof(int), c->stream)); return BPPP_OK; }
+        if (m == 0) {
+            if (rej[r]) HIP_TRY(hipMemsetAsync(rej[r], 0, sizeof(int), c->stream));
+            return BPPP_OK;
+        }
         return call.enqueue(r, c, m, ptrs[r].data(), rej[r]);
     };
     auto collective = [&](int r) -> int {
-        if (grp->comm.empty()) return BPPP_OK;
+        if (grp->comm.empty() || !call.exchange) return BPPP_OK;
         const int e = grp->rccl.AllReduce(rej[r], rej[r], 1, kRcclInt32, kRcclSum, grp->comm[r], grp->ctx[r]->stream);
         if (e != 0) {
             g_last_error = std::string("ncclAllReduce: ") + (grp->rccl.GetErrorString ? grp->rccl.GetErrorString(e) : "failed");
@@ -246,7 +250,7 @@ int run_call(ShardedCall& call) {
                 const ShardArray& a = call.arrays[i];
                 if (a.host_out) HIP_TRY(hipMemcpyAsync((uint8_t*)a.host_out + lo * a.stride, ptrs[r][i], m * a.stride, hipMemcpyDeviceToHost, c->stream));
             }
-            HIP_TRY(hipMemcpyAsync(&counts[r], rej[r], sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            if (rej[r]) HIP_TRY(hipMemcpyAsync(&counts[r], rej[r], sizeof(int), hipMemcpyDeviceToHost, c->stream));
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipStreamSynchronize(c->aux_stream));
@@ -470,6 +474,43 @@ int bppp_reciprocal_verify_batch_rlc_sharded_device(bppp_group* grp, const uint8
     if (!seed) return BPPP_ERR_INVALID_ARG;
     return recip_sharded_device(grp, label, label_len, n, dim_nd, dim_np, d_commitments, d_proofs, rounds, nl, nn, d_accept, d_status,
                                 d_reject_count, seed);
+}
+
+// ---- U64RangeProofProtocol::prove, sharded: independent proofs, no exchange step -- the ranks only vote on their return codes
+int bppp_u64_prove_batch_sharded(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x, const uint8_t* s,
+                                 const uint8_t* rnd, uint8_t* proofs, uint8_t* commitments, int32_t* status) {
+    if (!grp || (!label && label_len) || !x || !s || !rnd || !proofs || !commitments || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    ShardedCall call;
+    call.grp = grp; call.n = n; call.exchange = false;
+    call.arrays = {host_in(x, 8), host_in(s, 32), host_in(rnd, 52 * 32), host_out(proofs, BPPP_U64_PROOF_BYTES), host_out(commitments, 64),
+                   host_out(status, 4)};
+    call.enqueue = [=](int, bppp_ctx* c, size_t m, void* const* p, void*) {
+        return prove_device_impl(c, label, label_len, m, p[0], p[1], p[2], p[3], p[4], p[5], nullptr);
+    };
+    return run_call(call);
+}
+int bppp_u64_prove_batch_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const void* const* d_x,
+                                        const void* const* d_s, const void* const* d_rnd, void* const* d_proofs, void* const* d_commitments,
+                                        void* const* d_status) {
+    if (!grp || (!label && label_len) || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
+    const int G = (int)grp->devices.size();
+    for (const void* const* a : {d_x, d_s, d_rnd, cv(d_proofs), cv(d_commitments)}) {
+        if (!a) return BPPP_ERR_INVALID_ARG;
+        for (int r = 0; r < G; r++) {
+            size_t lo, hi;
+            bppp_shard_range(n, r, G, &lo, &hi);
+            if (hi > lo && !a[r]) return BPPP_ERR_INVALID_ARG;
+        }
+    }
+    ShardedCall call;
+    call.grp = grp; call.n = n; call.device_form = true; call.exchange = false;
+    call.arrays = {dev_arr(d_x, 8), dev_arr(d_s, 32), dev_arr(d_rnd, 52 * 32), dev_arr(cv(d_proofs), BPPP_U64_PROOF_BYTES),
+                   dev_arr(cv(d_commitments), 64), dev_arr(cv(d_status), 4)};
+    call.enqueue = [=](int, bppp_ctx* c, size_t m, void* const* p, void*) {
+        return prove_device_impl(c, label, label_len, m, p[0], p[1], p[2], p[3], p[4], p[5], nullptr);
+    };
+    return run_call(call);
 }
 
 }  // extern "C"

@@ -316,8 +316,6 @@ int bppp_u64_commit_value_batch(bppp_ctx* c, size_t n, const uint64_t* x, const 
     return flags ? BPPP_ERR_INVALID_ARG : BPPP_OK;
 }
 
-static int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
-                             const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status, const VerifyTranscripts* tx);
 int bppp_u64_prove_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
                                 const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status) {
     CtxLock lock_(c);
@@ -330,8 +328,8 @@ int bppp_u64_prove_batch_transcript_device(bppp_ctx* c, size_t n, const void* d_
     VerifyTranscripts tx = {d_states, n_states, d_states_out};
     return prove_device_impl(c, nullptr, 0, n, d_x, d_s, d_rnd, d_proofs, d_commitments, d_status, &tx);
 }
-static int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
-                             const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status, const VerifyTranscripts* tx) {
+int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s, const void* d_rnd,
+                      void* d_proofs, void* d_commitments, void* d_status, const VerifyTranscripts* tx) {
     if (!c || (!label && label_len) || !d_x || !d_s || !d_rnd || !d_proofs || !d_commitments) return BPPP_ERR_INVALID_ARG;
     if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;

@@ -346,6 +346,9 @@ int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size
 // bppp_u64.hip: SEC1-compressed inputs expanded into the context's buffer, then verify_device_impl
 int verify_sec1_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments33, const void* d_proofs525,
                             void* d_accept, void* d_status, void* d_trace, void* d_reject_count);
+// bppp_u64.hip: the u64 prover over device buffers, asynchronous on c->stream (the caller holds the context's lock)
+int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s, const void* d_rnd,
+                      void* d_proofs, void* d_commitments, void* d_status, const VerifyTranscripts* tx);
 // bppp_generic.hip: the reciprocal verifier over device buffers (exact, or RLC when rlc_seed is given); d_reject_count (device
 // int32, optional) receives the number of rejected instances
 int recip_verify_device_entry(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,

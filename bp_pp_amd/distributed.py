@@ -153,6 +153,27 @@ class U64RangeProofGroup(_Group):
                                                                                           mk(d_proofs), mk(d_accept), mk(d_status),
                                                                                           mk(d_reject_count), mk(d_states_out)))
 
+    def prove_batch(self, x, s, rnd, label: bytes):
+        """U64RangeProofProtocol::prove (u64_proof.rs:57-82) for one batch over the group's devices, host buffers: x [n] u64, s [n, 32],
+        rnd [n, 52, 32] (the reference's draw order) -> (proofs [n, 928], commitments [n, 64], status [n]); byte-identical to
+        U64RangeProofProtocol.prove_batch on one device.  No collective: proofs are independent."""
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.uint64).reshape(-1)
+        n = x.shape[0]
+        s = np.ascontiguousarray(s, dtype=np.uint8).reshape(n, 32)
+        rnd = np.ascontiguousarray(rnd, dtype=np.uint8).reshape(n, 52 * 32)
+        proofs, commitments, status = np.zeros((n, 928), np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.int32)
+        self._capi.check(self._capi.lib().bppp_u64_prove_batch_sharded(self._grp, label, len(label), n, x.ctypes.data, s.ctypes.data,
+                                                                       rnd.ctypes.data, proofs.ctypes.data, commitments.ctypes.data,
+                                                                       status.ctypes.data))
+        return proofs, commitments, status
+
+    def prove_batch_device(self, label: bytes, n: int, d_x, d_s, d_rnd, d_proofs, d_commitments, d_status=None) -> None:
+        """Per-device lists of raw device addresses of each rank's shard; blocks until every device is done."""
+        mk = self._ptrs
+        self._capi.check(self._capi.lib().bppp_u64_prove_batch_sharded_device(self._grp, label, len(label), n, mk(d_x), mk(d_s), mk(d_rnd),
+                                                                              mk(d_proofs), mk(d_commitments), mk(d_status)))
+
 
 class ReciprocalRangeProofGroup(_Group):
     """ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) for one batch over the GPUs of a node -- BASELINE configs[4]: the

@@ -82,6 +82,8 @@ extern "C" {
     pub fn bppp_u64_verify_batch_sec1_sharded_device(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, d_commitments33: *const *const c_void, d_proofs525: *const *const c_void, d_accept: *const *mut c_void, d_status: *const *mut c_void, d_reject_count: *const *mut c_void) -> c_int;
     pub fn bppp_u64_verify_batch_transcript_sharded(grp: *mut BpppGroup, n: usize, states: *const u8, n_states: usize, commitments: *const u8, proofs: *const u8, accept: *mut u8, status: *mut i32, states_out: *mut u8, reject_count: *mut i32) -> c_int;
     pub fn bppp_u64_verify_batch_transcript_sharded_device(grp: *mut BpppGroup, n: usize, d_states: *const *const c_void, n_states: usize, d_commitments: *const *const c_void, d_proofs: *const *const c_void, d_accept: *const *mut c_void, d_status: *const *mut c_void, d_reject_count: *const *mut c_void, d_states_out: *const *mut c_void) -> c_int;
+    pub fn bppp_u64_prove_batch_sharded(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, x: *const u64, s: *const u8, rnd: *const u8, proofs: *mut u8, commitments: *mut u8, status: *mut i32) -> c_int;
+    pub fn bppp_u64_prove_batch_sharded_device(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, d_x: *const *const c_void, d_s: *const *const c_void, d_rnd: *const *const c_void, d_proofs: *const *mut c_void, d_commitments: *const *mut c_void, d_status: *const *mut c_void) -> c_int;
     pub fn bppp_reciprocal_verify_batch_sharded(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, commitments: *const u8, proofs: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32, reject_count: *mut i32) -> c_int;
     pub fn bppp_reciprocal_verify_batch_rlc_sharded(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, commitments: *const u8, proofs: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32, reject_count: *mut i32, seed: *const u8) -> c_int;
     pub fn bppp_reciprocal_verify_batch_sharded_device(grp: *mut BpppGroup, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, d_commitments: *const *const c_void, d_proofs: *const *const c_void, rounds: usize, nl: usize, nn: usize, d_accept: *const *mut c_void, d_status: *const *mut c_void, d_reject_count: *const *mut c_void) -> c_int;

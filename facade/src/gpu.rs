@@ -168,6 +168,28 @@ impl U64RangeProofGroupGpu {
         }
         Ok((acc.iter().map(|a| *a == 1).collect(), rej))
     }
+
+    /// `U64RangeProofProtocol::prove` for one batch over the group's GPUs (bppp_u64_prove_batch_sharded): the 52 scalars per proof
+    /// are drawn here, in the reference's order, so the proofs equal the reference prover's for the same RNG stream.
+    pub fn prove_batch<R: RngCore + CryptoRng>(&self, label: &'static [u8], xs: &[u64], ss: &[Scalar], rng: &mut R) -> Result<(Vec<Proof>, Vec<ProjectivePoint>), GpuError> {
+        assert_eq!(xs.len(), ss.len());
+        let n = xs.len();
+        let mut rnd = Vec::with_capacity(n * 52 * 32);
+        for _ in 0..n * 52 {
+            put_scalar(&mut rnd, &Scalar::generate_biased(&mut *rng));
+        }
+        let mut sb = Vec::with_capacity(n * 32);
+        ss.iter().for_each(|s| put_scalar(&mut sb, s));
+        let (mut proofs, mut coms, mut st) = (vec![0u8; 928 * n], vec![0u8; 64 * n], vec![0i32; n]);
+        check(unsafe {
+            bppp_u64_prove_batch_sharded(self.grp, label.as_ptr(), label.len(), n, xs.as_ptr(), sb.as_ptr(), rnd.as_ptr(), proofs.as_mut_ptr(), coms.as_mut_ptr(), st.as_mut_ptr())
+        })?;
+        if let Some(i) = st.iter().position(|s| *s != 0) {
+            return Err(GpuError::ReferenceWouldPanic { index: i });
+        }
+        Ok((proofs.chunks(928).map(|b| get_u64_proof(b).expect("library emitted an invalid proof")).collect(),
+            coms.chunks(64).map(|b| get_point(b).expect("library emitted a point off the curve")).collect()))
+    }
 }
 
 impl Drop for U64RangeProofGroupGpu {

@@ -401,6 +401,18 @@ BPPP_API int bppp_u64_verify_batch_transcript_sharded_device(bppp_group* grp, si
                                                              const void* const* d_commitments, const void* const* d_proofs,
                                                              void* const* d_accept, void* const* d_status, void* const* d_reject_count,
                                                              void* const* d_states_out);
+/* U64RangeProofProtocol::prove (u64_proof.rs:57-82; bppp_u64_prove_batch[_device]) for ONE batch of n values sharded over the
+ * group: the same contiguous split, every proof byte-identical to the single-device call's.  Proofs are independent, so there is
+ * no exchange step and no collective; the ranks only agree on their return codes (failure semantics above).  Host form: x, s, rnd
+ * in, proofs, commitments and (optional) status out for the whole batch.  Device form: per-device arrays of pointers to each
+ * rank's resident shard (d_status optional as a whole or per rank). */
+BPPP_API int bppp_u64_prove_batch_sharded(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x,
+                                          const uint8_t* s /* n x 32 */, const uint8_t* rnd /* n x 52 x 32 */,
+                                          uint8_t* proofs /* n x 928 */, uint8_t* commitments /* n x 64 */, int32_t* status /* n or NULL */);
+BPPP_API int bppp_u64_prove_batch_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n,
+                                                 const void* const* d_x, const void* const* d_s, const void* const* d_rnd,
+                                                 void* const* d_proofs, void* const* d_commitments, void* const* d_status);
+
 /* ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) for ONE batch of n instances sharded over a group made by
  * bppp_wnla_group_create -- BASELINE configs[4]: 2^18 instances of the (dim_nd 256, dim_np 16) shape over 8 GPUs.  Arguments as
  * bppp_reciprocal_verify_batch[_rlc][_device]; same contiguous split, same 4-byte all-reduce of the reject count.  In the device

@@ -1061,4 +1061,25 @@ int emul_group_verify(int kind, int G, int fail_rank, int fail_collective_rank, 
     *aborted_out = comm.aborted ? 1 : 0;
     return code;
 }
+// The sharded prover over G emulated devices (bppp_u64_prove_batch_sharded): rank r proves rows [lo, hi) of the batch; there is no
+// exchange step, so the collective of run_sharded is a no-op and the vote is all the ranks share.  fail_rank as above.
+int emul_group_prove(int G, int fail_rank, const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x,
+                     const uint8_t* s, const uint8_t* rnd, uint8_t* proofs, uint8_t* V, int32_t* status) {
+    auto range = [&](int r, size_t& lo, size_t& m) {
+        const size_t q = n / G, rem = n % G;
+        auto at = [&](size_t k) { return q * k + (rem * k) / G; };
+        lo = at(r); m = at(r + 1) - lo;
+    };
+    auto prepare = [&](int r) -> int {
+        if (r == fail_rank) return EMUL_ERR_NOMEM;
+        size_t lo, m;
+        range(r, lo, m);
+        return m ? emul_u64_prove_batch(table, W, label, label_len, m, x + lo, s + 32 * lo, rnd + 52 * 32 * lo, proofs + 928 * lo, V + 64 * lo,
+                                        status + lo)
+                 : 0;
+    };
+    auto nop = [](int) -> int { return 0; };
+    auto res = bppp_host::run_sharded(G, [](int) {}, prepare, nop, nop, nop, [](int) {}, [](int) {}, []() { return std::string(); });
+    return res.code;
+}
 }

@@ -55,4 +55,5 @@ def load():
     L.emul_set_rlc_superchunk.argtypes = [C.c_uint32, vp]
     L.emul_set_rlc_superchunk.restype = None
     L.emul_group_verify.argtypes = [i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, cp, sz, sz, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.emul_group_prove.argtypes = [i32, i32, vp, i32, cp, sz, sz, vp, vp, vp, vp, vp, vp]
     return L

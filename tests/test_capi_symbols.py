@@ -79,6 +79,8 @@ def test_sharded_entry_points_refuse_bad_arguments_without_touching_a_gpu():
     assert L.bppp_u64_verify_batch_transcript_sharded_device(None, 1, arr, 1, arr, arr, arr, arr, arr, arr) == E
     assert L.bppp_reciprocal_verify_batch_sharded_device(None, b"x", 1, 1, 16, 16, arr, arr, 4, 2, 1, arr, arr, arr) == E
     assert L.bppp_reciprocal_verify_batch_rlc_sharded_device(None, b"x", 1, 1, 16, 16, arr, arr, 4, 2, 1, arr, arr, arr, seed) == E
+    assert L.bppp_u64_prove_batch_sharded(None, b"x", 1, 1, p, p, p, p, p, p) == E
+    assert L.bppp_u64_prove_batch_sharded_device(None, b"x", 1, 1, arr, arr, arr, arr, arr, arr) == E
     grp, dev = C.c_void_p(), (C.c_int * 2)(0, 0)
     assert L.bppp_wnla_group_create(C.byref(grp), bytes(64), bytes(64), 1, bytes(64), 1, dev, 2, 8) == E and not grp.value   # a device twice
     assert L.bppp_wnla_group_create(C.byref(grp), bytes(64), bytes(64), 1, bytes(64), 1, dev, 0, 8) == E                       # no devices

@@ -213,6 +213,56 @@ def test_injected_fault_returns_the_error_and_the_group_stays_usable(batch, forc
         grp.close()
 
 
+def test_one_device_group_proves_like_the_single_context():
+    """bppp_u64_prove_batch_sharded[_device] (u64_proof.rs:57-82): byte-identical to the single-context prover and to the oracle
+    prover on a sample, host and device forms, ragged sizes; an injected fault returns its error and the next call works."""
+    import torch
+    import bppp_oracle_c as OC
+    import workload
+    from bp_pp_amd import BpppError, U64RangeProofProtocol, _capi
+    from bp_pp_amd.distributed import U64RangeProofGroup
+    gens = workload.generators()
+    g, gv, hv = workload.split_generators(gens)
+    n = 777
+    x = np.ascontiguousarray(workload.values(n, first=5100))
+    s, rnd = np.ascontiguousarray(workload.blindings(n, first=5100)), np.ascontiguousarray(workload.prover_randomness(n, first=5100))
+    grp = U64RangeProofGroup(g, gv, hv, [0], fb_window_bits=8)
+    single = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
+    try:
+        P, V, st = grp.prove_batch(x, s, rnd, workload.LABEL)
+        P1, V1, st1 = single.prove_batch(x, s, rnd, workload.LABEL)
+        assert (P == P1).all() and (V == V1).all() and not st.any() and not st1.any()
+        op, ov = OC.u64_prove_batch(gens, workload.LABEL, x[:24], s[:24], rnd[:24], nthreads=4)      # the checker
+        assert (P[:24] == op).all() and (V[:24] == ov).all()
+        acc, _ = single.verify_batch(V, P, workload.LABEL)
+        assert acc.all()
+        for m in (0, 1, 65):
+            Pm, Vm, _ = grp.prove_batch(x[:m], s[:m], rnd[:m], workload.LABEL)
+            assert (Pm == P[:m]).all() and (Vm == V[:m]).all()
+        dx, ds, dr = torch.from_numpy(x.view(np.int64)).cuda(), torch.from_numpy(s).cuda(), torch.from_numpy(rnd).cuda()
+        dP = torch.zeros((n, 928), dtype=torch.uint8, device="cuda")
+        dV = torch.zeros((n, 64), dtype=torch.uint8, device="cuda")
+        dS = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        grp.prove_batch_device(workload.LABEL, n, [dx.data_ptr()], [ds.data_ptr()], [dr.data_ptr()], [dP.data_ptr()], [dV.data_ptr()],
+                               [dS.data_ptr()])
+        assert (dP.cpu().numpy() == P).all() and (dV.cpu().numpy() == V).all() and not dS.cpu().numpy().any()
+        dP.zero_()
+        grp.prove_batch_device(workload.LABEL, n, [dx.data_ptr()], [ds.data_ptr()], [dr.data_ptr()], [dP.data_ptr()], [dV.data_ptr()])  # no status
+        assert (dP.cpu().numpy() == P).all()
+        with pytest.raises(BpppError):
+            grp.prove_batch_device(workload.LABEL, n, [dx.data_ptr()], [0], [dr.data_ptr()], [dP.data_ptr()], [dV.data_ptr()])      # a missing shard
+        grp.set_option("inject_fault_rank", 0)
+        with pytest.raises(BpppError) as e:
+            grp.prove_batch(x, s, rnd, workload.LABEL)
+        assert e.value.code == _capi.ERR_NOMEM
+        P2, _, _ = grp.prove_batch(x, s, rnd, workload.LABEL)
+        assert (P2 == P).all()
+    finally:
+        grp.close()
+        single.close()
+
+
 @pytest.mark.parametrize("force_rccl", [False, True])
 def test_reciprocal_group_equals_single_context(force_rccl, monkeypatch):
     """bppp_wnla_group_create + bppp_reciprocal_verify_batch[_rlc]_sharded[_device] (BASELINE configs[4]'s path) on one device: equal

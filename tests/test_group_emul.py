@@ -80,6 +80,35 @@ def test_failing_collective_aborts_instead_of_hanging(u64_case):
     assert rc == ERR_RCCL and aborted == 1 and dt < 30
 
 
+@pytest.mark.parametrize("G", [1, 2, 3])
+def test_sharded_prove_equals_unsharded_and_oracle(u64_case, G):
+    """bppp_u64_prove_batch_sharded's flow (u64_proof.rs:57-82 per proof, no exchange step): every proof and commitment of the
+    sharded batch equals the unsharded device code's and the oracle prover's bytes; more ranks than values leaves a shard empty."""
+    import bppp_oracle_c as OC
+    L, gens, _, _, _, tab, W = u64_case
+    for n in (7, 2):
+        x = np.ascontiguousarray(workload.values(n, first=40))
+        s, rnd = np.ascontiguousarray(workload.blindings(n, first=40)), np.ascontiguousarray(workload.prover_randomness(n, first=40))
+        P, V, st = np.zeros((n, 928), np.uint8), np.zeros((n, 64), np.uint8), np.full(n, -1, np.int32)
+        rc = L.emul_group_prove(G, -1, tab.ctypes.data, W, workload.LABEL, len(workload.LABEL), n, x.ctypes.data, s.ctypes.data, rnd.ctypes.data,
+                                P.ctypes.data, V.ctypes.data, st.ctypes.data)
+        assert rc == 0 and not st.any()
+        op, ov = OC.u64_prove_batch(gens, workload.LABEL, x, s, rnd, nthreads=2)        # the checker
+        assert (P == op).all() and (V == ov).all()
+
+
+def test_sharded_prove_fails_closed(u64_case):
+    L, gens, _, _, _, tab, W = u64_case
+    n = 5
+    x = np.ascontiguousarray(workload.values(n, first=40))
+    s, rnd = np.ascontiguousarray(workload.blindings(n, first=40)), np.ascontiguousarray(workload.prover_randomness(n, first=40))
+    P, V, st = np.zeros((n, 928), np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.int32)
+    t0 = time.time()
+    rc = L.emul_group_prove(2, 1, tab.ctypes.data, W, workload.LABEL, len(workload.LABEL), n, x.ctypes.data, s.ctypes.data, rnd.ctypes.data,
+                            P.ctypes.data, V.ctypes.data, st.ctypes.data)
+    assert rc == ERR_NOMEM and time.time() - t0 < 30
+
+
 @pytest.fixture(scope="module")
 def recip_case():
     L = load()
