@@ -55,7 +55,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     *out = nullptr;
     const int NB = 1 + (int)ng + (int)nh;
     int W = fb_window_bits ? fb_window_bits : default_window_bits(NB);
-    if (W != 4 && W != 8 && W != 16 && W != 10 && W != 20 && W != 22) return BPPP_ERR_INVALID_ARG;
+    if (W != 4 && W != 8 && W != 16 && W != 10 && W != 18 && W != 19 && W != 20 && W != 22) return BPPP_ERR_INVALID_ARG;
     int rc = check_device(device);
     if (rc != BPPP_OK) return rc;
     HIP_TRY(hipSetDevice(device));
@@ -401,7 +401,7 @@ int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device) {
     TableFileHeader h;
     bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "BPPPTAB2", 8) == 0;
     const int W = (int)h.window_bits;
-    ok = ok && (W == 4 || W == 8 || W == 10 || W == 16 || W == 20 || W == 22) && h.nbases == 1 + h.ng + h.nh && h.nbases <= 8193 &&
+    ok = ok && (W == 4 || W == 8 || W == 10 || W == 16 || W == 18 || W == 19 || W == 20 || W == 22) && h.nbases == 1 + h.ng + h.nh && h.nbases <= 8193 &&
          h.nwin == (uint32_t)fb_nwin(W) && h.per_win == fb_per_win(W) && h.table_bytes == (uint64_t)h.nbases * h.nwin * h.per_win * sizeof(apt_packed);
     if (!ok) { std::fclose(f); g_last_error = std::string(path) + " is not a table file of this library"; return BPPP_ERR_INVALID_ARG; }
     if (hipSetDevice(device) != hipSuccess) { std::fclose(f); g_last_error = "hipSetDevice failed"; (void)hipGetLastError(); return BPPP_ERR_HIP; }

@@ -659,6 +659,8 @@ static int wnla_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, 
     if (nn) HIP_TRY(hipMemcpyAsync(d + o_n, nvec, n * nn * 32, hipMemcpyHostToDevice, s));
     WnlaProveWs w;
     std::memset(&w, 0, sizeof w);
+    { const int rc_s = ensure_straus_capacity(c, n); if (rc_s != BPPP_OK) return rc_s; }   // window tables of X, R (next commitment by the relation)
+    w.straus = c->d_straus;
     w.N = n; w.ng = c->ng; w.nh = c->nh; w.nl = (int)nl; w.nn = (int)nn; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
     w.commitments = d + o_com; w.c = d + o_c; w.rho = d + o_rho; w.mu = d + o_mu; w.l_in = d + o_l; w.n_in = d + o_n;
     w.proof_r = d + o_pr; w.proof_x = d + o_px; w.proof_l = d + o_pl; w.proof_n = d + o_pn;
@@ -679,7 +681,7 @@ static int wnla_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, 
         k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0, -1);
         k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1, k);
         k_wprove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
-        if (k + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2, -1);
+        if (k == 0 && rounds > 1) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2, -1);   // level 1's commitment; later levels by the relation
     }
     k_wprove_finish<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     HIP_TRY(hipGetLastError());
@@ -769,6 +771,8 @@ static int circuit_prove_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t*
     if (rc != BPPP_OK) return rc;
     WnlaProveWs w;
     std::memset(&w, 0, sizeof w);
+    { const int rc_s = ensure_straus_capacity(c, n); if (rc_s != BPPP_OK) return rc_s; }   // window tables of X, R (next commitment by the relation)
+    w.straus = c->d_straus;
     w.N = n; w.ng = c->ng; w.nh = c->nh; w.nl = (int)NH; w.nn = (int)NG; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
     w.transcript_preloaded = 1;
     w.base = p.base; w.tio = p.tio; w.divergent_positions = p.divergent_positions;
@@ -793,7 +797,7 @@ static int circuit_prove_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t*
         k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0, -1);
         k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1, kk);
         k_wprove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
-        if (kk + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2, -1);
+        if (kk == 0 && rounds > 1) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2, -1);   // level 1's commitment; later levels by the relation
     }
     k_wprove_finish<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     HIP_TRY(hipGetLastError());
@@ -928,6 +932,8 @@ static int recip_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
     p.fb = r.fb;
     WnlaProveWs w;
     std::memset(&w, 0, sizeof w);
+    { const int rc_s = ensure_straus_capacity(c, n); if (rc_s != BPPP_OK) return rc_s; }   // window tables of X, R (next commitment by the relation)
+    w.straus = c->d_straus;
     w.N = n; w.ng = c->ng; w.nh = c->nh; w.nl = (int)NH; w.nn = (int)NG; w.rounds = (int)rounds; w.nl_f = (int)nl_f; w.nn_f = (int)nn_f;
     w.transcript_preloaded = 1;
     w.base = r.base; w.tio = r.tio; w.divergent_positions = r.divergent_positions;
@@ -956,7 +962,7 @@ static int recip_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
         k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0, -1);
         k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 1, kk);
         k_wprove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
-        if (kk + 1 < (int)rounds) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2, -1);
+        if (kk == 0 && rounds > 1) k_wprove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 2, -1);   // level 1's commitment; later levels by the relation
     }
     k_wprove_finish<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     HIP_TRY(hipGetLastError());

@@ -243,8 +243,8 @@ HD void app_point(S& t, const char (&label)[L], const apt& a) {  // transcript.r
 // above the ~12 G/s the arithmetic can consume.
 // (W = 10 is the same signed scheme with a table small enough for the CPU emulation tests: 26 windows of 512 entries.)
 struct FbTable { const apt_packed* table; int W; size_t N; };
-HD bool fb_signed(int W) { return W == 20 || W == 10 || W == 22; }
-HD int fb_nwin(int W) { return fb_signed(W) ? (W == 22 ? 12 : 260 / W) : 256 / W; }   // signed: ceil(257 / W) windows
+HD bool fb_signed(int W) { return W == 20 || W == 10 || W == 22 || W == 18 || W == 19; }
+HD int fb_nwin(int W) { return fb_signed(W) ? (257 + W - 1) / W : 256 / W; }           // signed: ceil(257 / W) windows
 HD size_t fb_per_win(int W) { return fb_signed(W) ? ((size_t)1 << (W - 1)) : (((size_t)1 << W) - 1); }
 HD FbTable fb_of(const VerifyWs& ws) { FbTable f = {ws.fb_table, ws.fb_w, ws.N}; return f; }
 // windows a scalar below 2^bits can reach (0 = full width).  Signed digits: the recoded value is sum d_i 2^(W i) with d_i in
@@ -279,9 +279,11 @@ HD void fb_digit(const u32 k[8], int W, int w, size_t& idx, bool& skip, bool& ne
     const u32 off20[9] = {0x00080000u, 0x08000080u, 0x00008000u, 0x00800008u, 0x80000800u, 0x00080000u, 0x08000080u, 0x00008000u, 0x00000008u};
     const u32 off10[9] = {0x20080200u, 0x08020080u, 0x02008020u, 0x00802008u, 0x80200802u, 0x20080200u, 0x08020080u, 0x02008020u, 0x00000008u};
     const u32 off22[9] = {0x00200000u, 0x00000800u, 0x00800002u, 0x00002000u, 0x02000008u, 0x00008000u, 0x08000020u, 0x00020000u, 0x00000080u};
+    const u32 off18[9] = {0x00020000u, 0x00200008u, 0x02000080u, 0x20000800u, 0x00008000u, 0x00080002u, 0x00800020u, 0x08000200u, 0x00002000u};
+    const u32 off19[9] = {0x00040000u, 0x01000020u, 0x40000800u, 0x00020000u, 0x00800010u, 0x20000400u, 0x00010000u, 0x00400008u, 0x00000200u};
     u32 off[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) off[i] = (W == 20) ? off20[i] : (W == 22) ? off22[i] : off10[i];
+    for (int i = 0; i < 9; i++) off[i] = (W == 20) ? off20[i] : (W == 22) ? off22[i] : (W == 18) ? off18[i] : (W == 19) ? off19[i] : off10[i];
     u32 kp[10];
     u32 c = 0;
 #pragma unroll

@@ -32,6 +32,7 @@ struct WnlaProveWs {
     u32* com;         // [16][N]       current commitment, packed affine (hashed first thing in a round)
     u32* msc;         // [3][(1 + ng + nh) * 8][N]  scalar sets: X, R, next commitment
     u32* pbuf;        // [3][30][N]    X, R, next commitment (projective)
+    pt_slot* straus;  // [N][2 * BPPP_STRAUS_ENTRIES]  window tables of X and R for the next commitment by the verifier's relation
     FbTable fb;
     strobe base;
     TranscriptIo tio;                                            // caller's transcripts (wnla.rs:125 `t: &mut Transcript`); input side ignored when transcript_preloaded
@@ -167,7 +168,12 @@ HD void wnla_prove_msm_ranges(FbRanges& rg, const WnlaProveWs& w, int oddsh = -1
     rg.slot[1] = 1; rg.base[1] = 1; rg.count[1] = wnla_odd_block_terms(w.ng, oddsh); rg.bits[1] = 0; rg.oddsh[1] = oddsh;
     rg.slot[2] = 1 + w.ng; rg.base[2] = 1 + w.ng; rg.count[2] = wnla_odd_block_terms(w.nh, oddsh); rg.bits[2] = 0; rg.oddsh[2] = oddsh;
 }
-// round k: X, R (and, from round 1 on, this level's commitment) to affine, transcript, challenge, fold, next commitment's scalars
+// round k: X, R (and, from round 1 on, this level's commitment) to affine, transcript, challenge, fold, next level's commitment.
+// The reference recomputes every level's commitment from the folded vectors (wnla.rs:186 `wnla.commit(&l_, &n_)`).  Level 1 is
+// done that way here too (its scalars -> the third MSM of round 0), because level 0's commitment is the CALLER's and need not be
+// commit(l, n); from then on C_k IS commit(l_k, n_k), for which the argument's completeness gives
+// commit(l_{k+1}, n_{k+1}) = C_k + y X_k + (y^2 - 1) R_k -- the verifier's own update (wnla.rs:84-102): two variable-base
+// multiplications instead of an MSM over all 1 + |g_vec| + |h_vec| generators per round.
 HD void wnla_prove_round_fold(const WnlaProveWs& w, size_t t, int k) {
     const size_t N = w.N;
     const int Lk = (int)wnla_ceil_shift((size_t)w.nl, k), Nk = (int)wnla_ceil_shift((size_t)w.nn, k), Ck = (int)wnla_ceil_shift((size_t)w.nh, k);
@@ -241,7 +247,23 @@ HD void wnla_prove_round_fold(const WnlaProveWs& w, size_t t, int k) {
     }
     ws_st8(w.prm, N, t, 0, mu.v);                       // rho <- mu, mu <- mu^2 (wnla.rs:180-181)
     ws_st8(w.prm, N, t, 1, mu2.v);
-    if (k + 1 < w.rounds) {
+    if (k + 1 < w.rounds && k > 0) {
+        sc y2m1, one;
+        sc_set_u32(one, 1);
+        sc_mul(y2m1, y, y);
+        sc_sub(y2m1, y2m1, one);
+        pt_slot* tbl = w.straus + t * (2 * BPPP_STRAUS_ENTRIES);
+        glv_split rs[2];
+        straus_build_table(tbl, A[0]);
+        straus_build_table(tbl + BPPP_STRAUS_ENTRIES, A[1]);
+        glv_decompose(rs[0], y);
+        glv_decompose(rs[1], y2m1);
+        pt acc;
+        straus_msm_glv(acc, tbl, rs, 2);
+        pt_madd(acc, acc, Ca, apt_is_identity(Ca));
+        ws_st_pt(w.pbuf + 60 * N, N, t, acc);
+    }
+    if (k + 1 < w.rounds && k == 0) {
         // scalars of the next level's commitment  v g + <h', l'> + <g', n'>,  v = <c', l'> + |n'|^2_{mu'}   (wnla.rs:66-72 via :186)
         u32* mc = w.msc + 2 * wp_set_words(w);
         sc v, mp = mu2;

@@ -734,6 +734,8 @@ int emul_wnla_prove(const uint8_t* table, int W, int ng, int nh, const uint8_t* 
         cg((size_t)(ng + 1) * 8 * n), prm(24 * n), com(16 * n), msc(3 * NB * 8 * n), pb(90 * n);
     w.tstate = ts.data(); w.vl = vl.data(); w.vn = vn.data(); w.vc = vc.data(); w.ch = ch.data(); w.cg = cg.data(); w.prm = prm.data();
     w.com = com.data(); w.msc = msc.data(); w.pbuf = pb.data();
+    std::vector<pt_slot> wstraus(n * 2 * BPPP_STRAUS_ENTRIES);
+    w.straus = wstraus.data();
     w.fb.table = (const apt_packed*)table; w.fb.W = W; w.fb.N = n;
     t_new(w.base, label, (u32)label_len);
     w.tio = take_tio();
@@ -753,7 +755,7 @@ int emul_wnla_prove(const uint8_t* table, int W, int ng, int nh, const uint8_t* 
         msm(0);
         msm(1, k);
         for (size_t t = 0; t < n; t++) wnla_prove_round_fold(w, t, k);
-        if (k + 1 < (int)rounds) msm(2);
+        if (k == 0 && rounds > 1) msm(2);
     }
     for (size_t t = 0; t < n; t++) wnla_prove_finish(w, t);
     for (size_t t = 0; t < n; t++) tio_export(w.tio, w.base, w.tstate, n, w.status, t);
@@ -809,6 +811,8 @@ int emul_circuit_prove(const uint8_t* table, int W, int NG, int NH, const size_t
         cg((size_t)(NG + 1) * 8 * n), prm(24 * n), com(16 * n);
     w.tstate = p.tstate; w.vl = vl.data(); w.vn = vn.data(); w.vc = vc.data(); w.ch = ch.data(); w.cg = cg.data(); w.prm = prm.data();
     w.com = com.data(); w.msc = p.msc; w.pbuf = p.pbuf; w.fb = p.fb;
+    std::vector<pt_slot> wstraus(n * 2 * BPPP_STRAUS_ENTRIES);
+    w.straus = wstraus.data();
     auto cmsm = [&](int set, bool with_g) {
         for (size_t t = 0; t < n; t++) {
             pt a;
@@ -840,7 +844,7 @@ int emul_circuit_prove(const uint8_t* table, int W, int NG, int NH, const size_t
         wmsm(0);
         wmsm(1, kk);
         for (size_t t = 0; t < n; t++) wnla_prove_round_fold(w, t, kk);
-        if (kk + 1 < (int)rounds) wmsm(2);
+        if (kk == 0 && rounds > 1) wmsm(2);
     }
     for (size_t t = 0; t < n; t++) wnla_prove_finish(w, t);
     for (size_t t = 0; t < n; t++) tio_export(p.tio, p.base, p.tstate, n, status, t);
@@ -907,6 +911,8 @@ int emul_recip_prove(const uint8_t* table, int W, int NG, int NH, int nd, int np
         cg((size_t)(NG + 1) * 8 * n), prm(24 * n), com(16 * n);
     w.tstate = p.tstate; w.vl = vl.data(); w.vn = vn.data(); w.vc = vc.data(); w.ch = ch.data(); w.cg = cg.data(); w.prm = prm.data();
     w.com = com.data(); w.msc = p.msc; w.pbuf = p.pbuf; w.fb = p.fb;
+    std::vector<pt_slot> wstraus(n * 2 * BPPP_STRAUS_ENTRIES);
+    w.straus = wstraus.data();
     auto sum = [&](const FbRanges& rg, const u32* scal, u32* out) {
         for (size_t t = 0; t < n; t++) { pt a; fb_sum_serial(a, r.fb, t, scal, rg); ws_st_pt(out, n, t, a); }
     };
@@ -932,7 +938,7 @@ int emul_recip_prove(const uint8_t* table, int W, int NG, int NH, int nd, int np
         sum(rg, w.msc, w.pbuf);
         { FbRanges rr; wnla_prove_msm_ranges(rr, w, kk); sum(rr, w.msc + wp_set_words(w), w.pbuf + 30 * n); }
         for (size_t t = 0; t < n; t++) wnla_prove_round_fold(w, t, kk);
-        if (kk + 1 < (int)rounds) sum(rg, w.msc + 2 * wp_set_words(w), w.pbuf + 60 * n);
+        if (kk == 0 && rounds > 1) sum(rg, w.msc + 2 * wp_set_words(w), w.pbuf + 60 * n);
     }
     for (size_t t = 0; t < n; t++) wnla_prove_finish(w, t);
     for (size_t t = 0; t < n; t++) tio_export(r.tio, r.base, r.tstate, n, status, t);

@@ -179,18 +179,19 @@ def gold():
         return json.load(f)
 
 
-@pytest.mark.parametrize("W", [4, 8, 16, 10, 20, 22])
+@pytest.mark.parametrize("W", [4, 8, 16, 10, 18, 19, 20, 22])
 def test_fixed_base_window_digits_recompose_the_scalar(L, W):
-    """k == sum_w d_w 2^(W w) for the unsigned (4/8/16) and signed (10/20/22) window schemes, incl. the extreme scalars."""
+    """k == sum_w d_w 2^(W w) for the unsigned (4/8/16) and signed (10/18/19/20/22) window schemes, incl. the extreme scalars."""
     rnd = random.Random(W)
     idx, skip, neg = C.c_uint64(), C.c_int(), C.c_int()
-    for k in [0, 1, O.N - 1, 2**255, 2**256 % O.N, int("8" * 64, 16) % O.N, int("7" * 64, 16)] + [rnd.getrandbits(256) % O.N for _ in range(20)]:
+    edge = [sum(1 << (W * i + W - 1) for i in range(256 // W)) % O.N, sum(((1 << (W - 1)) - 1) << (W * i) for i in range(256 // W)) % O.N]
+    for k in [0, 1, O.N - 1, 2**255, 2**256 % O.N, int("8" * 64, 16) % O.N, int("7" * 64, 16)] + edge + [rnd.getrandbits(256) % O.N for _ in range(20)]:
         nwin = L.emul_fb_digit(W, b32(k), 0, C.byref(idx), C.byref(skip), C.byref(neg))
         total = 0
         for w in range(nwin):
             L.emul_fb_digit(W, b32(k), w, C.byref(idx), C.byref(skip), C.byref(neg))
             d = 0 if skip.value else (idx.value + 1)
-            assert d <= (2**(W - 1) if W in (10, 20, 22) else 2**W - 1)
+            assert d <= (2**(W - 1) if W in (10, 18, 19, 20, 22) else 2**W - 1)
             total += (-d if neg.value else d) << (W * w)
         assert total == k
 

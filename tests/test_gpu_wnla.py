@@ -47,6 +47,36 @@ def test_wnla_commit_verify_vs_oracle(ng, nh, B):
         w.close()
 
 
+@pytest.mark.parametrize("W", [4, 8, 10, 16, 18, 19, 20, 22])
+def test_every_fixed_base_window_width_vs_oracle(W):
+    """The same WNLA instances (commit, verify, prove: wnla.rs:66-190) through fixed-base tables of every window width the library
+    accepts -- unsigned 4 / 8 / 16 bits, signed 10 / 18 / 19 / 20 / 22 bits (verify_core.h: fb_digit) -- against the oracle; few
+    generators, so that even the 22-bit tables stay small (7 bases x 12 windows x 2^21 entries = 11 GB)."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import wnla_cases
+    from bp_pp_amd.wnla import WeightNormLinearArgument
+    B = 9
+    case = wnla_cases.make(2, 4, B)
+    w = WeightNormLinearArgument(case["g"], case["gv"], case["hv"], device=0, fb_window_bits=W)
+    try:
+        out, st = w.commit_batch(case["c"], case["mu"], case["l"], case["n"])
+        assert not st.any() and (out == case["commitments"]).all()
+        args = dict(commitments=case["commitments"], c=case["c"], rho=case["rho"], mu=case["mu"], proof_r=case["proof_r"],
+                    proof_x=case["proof_x"], proof_l=case["proof_l"], proof_n=case["proof_n"])
+        acc, st = w.verify_batch(case["label"], **args)
+        assert acc.all() and not st.any()
+        pl = case["proof_l"].copy(); pl[3, 0, 31] ^= 1
+        acc, st = w.verify_batch(case["label"], **dict(args, proof_l=pl))
+        assert acc.tolist() == [1, 1, 1, 0, 1, 1, 1, 1, 1]
+        pr, px, plv, pnv, st = w.prove_batch(case["label"], case["commitments"], case["c"], case["rho"], case["mu"], case["l"], case["n"])
+        assert not st.any() and (pr == case["proof_r"]).all() and (px == case["proof_x"]).all()
+        assert (plv == case["proof_l"]).all() and (pnv == case["proof_n"]).all()
+    finally:
+        w.close()
+
+
 def test_fixed_base_fast_accumulator_fallback_on_device():
     """Repeated generators + a scalar pattern that makes one lane add a table entry to itself: the incomplete (XYZZ) fixed-base
     accumulator must notice and the lane group must re-do the sum with the complete law (verify_core.h: fb_group_sum)."""
