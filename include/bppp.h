@@ -69,8 +69,9 @@ typedef struct bppp_ctx bppp_ctx;
  * 100 GB of HBM -- for the 49 generators 22 (signed 22-bit digits: 49 x 12 x 2^21 affine points = 79 GB, 12 table additions per
  * scalar, built in passes with <= 32 GB of temporaries; 2.4-3.1 % faster end to end on a 2^20-proof batch than 20); 20 (signed, 49
  * x 13 x 2^19 points = 21 GB, 13 additions per scalar: the choice when HBM is shared with something else); 16 (unsigned, 3.3 GB,
- * 16 additions); 4, 8, 10 (small tables for tests).  For bppp_wnla_ctx_create the same rule over 1 + ng + nh generators (769
- * generators: 16-bit windows, 52 GB).  bppp_ctx_save_tables / bppp_ctx_create_from_tables keep a built table set as a file. */
+ * 16 additions); 18, 19 (signed, 15 / 14 additions: for large generator sets with HBM to spare -- 769 generators: 97 / 181 GB);
+ * 4, 8, 10 (small tables for tests).  For bppp_wnla_ctx_create the same rule over 1 + ng + nh generators (769 generators: 16-bit
+ * windows, 52 GB).  bppp_ctx_save_tables / bppp_ctx_create_from_tables keep a built table set as a file. */
 BPPP_API int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec /* 16 x 64 */,
                     const uint8_t* h_vec /* 32 x 64 */, int device, int fb_window_bits);
 BPPP_API void bppp_ctx_destroy(bppp_ctx* ctx);
