@@ -13,6 +13,8 @@ static void read_diagnostics(bppp_ctx* c) {
     c->force_pairs = std::getenv("BPPP_FORCE_LANE_PAIRS") != nullptr;     // rounds on two lanes per proof at every batch size
     c->no_lane_groups = std::getenv("BPPP_NO_LANE_GROUPS") != nullptr;    // one lane per proof at every batch size
     c->no_small = std::getenv("BPPP_NO_SMALL_KERNELS") != nullptr;        // the 256-VGPR builds (two wavefronts per SIMD) at every batch size
+    if (const char* e = std::getenv("BPPP_SPLIT_MAX")) c->split_max = std::atol(e);
+    c->no_split = std::getenv("BPPP_NO_SPLIT") != nullptr;                // no half-stream lanes / per-table lanes for calls of <= one proof per SIMD
     if (const char* e = std::getenv("BPPP_FB_ONE_LANE")) c->fb_one_lane_mode = e[0] == '0' ? 0 : 1;
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
@@ -81,6 +83,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     HIP_TRY_C(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIP_TRY_C(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY_C(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRY_C(hipEventCreateWithFlags(&c->ev_tab, hipEventDisableTiming));
     HIP_TRY_C(hipMalloc(&c->d_gens, NB * sizeof(apt)));
     HIP_TRY_C(hipMalloc(&c->d_flags, sizeof(int)));
     HIP_TRY_C(hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
@@ -154,6 +157,7 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_tab) (void)hipEventDestroy(c->ev_tab);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -386,6 +390,7 @@ static int ctx_alloc_common(bppp_ctx* c) {
     HIP_TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_tab, hipEventDisableTiming));
     HIP_TRY(hipMalloc(&c->d_flags, sizeof(int)));
     read_diagnostics(c);
     c->n_simds = device_simds(c->device);

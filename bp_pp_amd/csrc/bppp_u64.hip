@@ -45,7 +45,10 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_capacity(c, n);
     if (rc != BPPP_OK) return rc;
-    rc = ensure_vtab_capacity(c, n);
+    // a call of at most one proof per SIMD: the dependent chains are cut further (a lane per window table and per half GLV stream,
+    // a wavefront per fixed-base sum), which takes a second set of window tables per proof
+    const bool split = !c->no_small && !c->no_lane_groups && !c->no_split && n <= (c->split_max >= 0 ? (size_t)c->split_max : 4 * (size_t)c->n_simds);
+    rc = ensure_vtab_capacity(c, split ? 2 * n : n);
     if (rc != BPPP_OK) return rc;
     VerifyWs ws;
     std::memset(&ws, 0, sizeof ws);
@@ -100,6 +103,14 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
 #define LAUNCH(id, ...) LAUNCH_ON(s, id, __VA_ARGS__)
     // a grid that does not even fill one wavefront per SIMD gains nothing from the 256-VGPR cap: use the uncapped builds
     const bool small = !c->no_small && blocks <= (unsigned)c->n_simds;
+    hipStream_t a = (c->serial_c0 || c->timing) ? s : c->aux_stream;
+    if (split) {
+        // the small-call table kernel decodes its points itself, so it runs on the helper stream beside phase 1
+        HIP_TRY(hipEventRecord(c->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
+        LAUNCH_ON(a, K_TABLES, k_verify_tables_split<<<(unsigned)((32 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, a>>>(ws));
+        HIP_TRY(hipEventRecord(c->ev_tab, a));
+    }
     if (small) LAUNCH(K_PHASE1, k_verify_phase1_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     else LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
@@ -108,25 +119,29 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     // SIMDs; round 1 adds the halves.
     // with per-kernel timing on, the two halves run back to back so that the kernel times add up to the step (overlapped, each
     // half's events also cover the other's share of the SIMDs; the overlap itself buys nothing at 2 waves/SIMD: DESIGN.md 4)
-    hipStream_t a = (c->serial_c0 || c->timing) ? s : c->aux_stream;
-    LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    if (split) HIP_TRY(hipStreamWaitEvent(s, c->ev_tab, 0));
+    else LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
     // the two fixed-base sums: 8 lanes per proof, or one from the size at which one lane per proof fills the SIMDs twice over
     const bool fb_one_lane = c->fb_one_lane_mode >= 0 ? c->fb_one_lane_mode == 1 : n >= (size_t)128 * (size_t)c->n_simds;
     const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
-    if (fb_one_lane) LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
+    const unsigned fb64_blocks = (unsigned)((n * 64 + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    if (split) LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed_l64<<<fb64_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
+    else if (fb_one_lane) LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
     else LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_join, a));
     // a batch whose four-lanes-per-proof grid still leaves the SIMDs under-filled runs its variable-base sums on lane groups
     const bool grouped = !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds;
     const unsigned g4_blocks = (unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
-    if (grouped) LAUNCH(K_C0_VAR, k_verify_c0_var_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws));
+    if (split) LAUNCH(K_C0_VAR, k_verify_c0_var_g32<<<(unsigned)((32 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
+    else if (grouped) LAUNCH(K_C0_VAR, k_verify_c0_var_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws));
     else if (small) LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     else LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     for (int k = 1; k <= 4; k++) {
-        if (grouped) LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+        if (split) LAUNCH(K_ROUND, k_verify_round_g8<<<(unsigned)((8 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
+        else if (grouped) LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k));
         else if (c->force_pairs || (!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds))
             LAUNCH(K_ROUND, k_verify_round_g2<<<(unsigned)((2 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
         else if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
@@ -134,7 +149,8 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     }
     LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     if (!rlc_seed) {
-        if (fb_one_lane) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+        if (split) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l64<<<fb64_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+        else if (fb_one_lane) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
         else LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
         LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
     } else {
@@ -366,9 +382,13 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     } while (0)
     const bool fb_one_lane = c->fb_one_lane_mode >= 0 ? c->fb_one_lane_mode == 1 : n >= (size_t)128 * (size_t)c->n_simds;
     const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    // a call of at most one value per SIMD: a wavefront per sum (the chip is empty; 6 additions per lane and a 6-step tree instead of 44 and 3)
+    const bool fb_wave = !c->no_small && !c->no_split && n <= (size_t)c->n_simds;
+    const unsigned fb64_blocks = (unsigned)((n * 64 + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
 #define PMSM(job)                                                                                         \
     do {                                                                                                  \
-        if (fb_one_lane) PLAUNCH(K_PROVE_MSM, k_prove_msm_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job)); \
+        if (fb_wave) PLAUNCH(K_PROVE_MSM, k_prove_msm_l64<<<fb64_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job));  \
+        else if (fb_one_lane) PLAUNCH(K_PROVE_MSM, k_prove_msm_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job)); \
         else PLAUNCH(K_PROVE_MSM, k_prove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job));               \
     } while (0)
     // a grid that gives every SIMD more than one wavefront runs the 256-register builds of the lane kernels (two wavefronts per SIMD)

@@ -57,7 +57,7 @@ struct bppp_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;   // runs the fixed-base half of C0 concurrently with the variable-base half
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tab = nullptr;
     hipStream_t copy_stream = nullptr;  // host-buffer entry points: uploads chunk k + 1 while chunk k is being verified (created on first use)
     hipEvent_t ev_copy = nullptr;
     size_t max_batch = (size_t)1 << 21;    // proofs verified per internal part of one call: bounds the workspace (~63 GB at 2^21)
@@ -107,7 +107,8 @@ struct bppp_ctx {
     int n_simds = 1024;            // CUs x 4 (device property), decides between the small-batch and the 2-waves/SIMD lane kernels
     bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
-    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false, no_lane_groups = false, force_pairs = false, no_small = false, prove_uncapped = false;
+    bool serial_c0 = false, rlc_debug = false, generic_slow_rounds = false, no_lane_groups = false, force_pairs = false, no_small = false, prove_uncapped = false, no_split = false;
+    long split_max = -1;         // diagnostic BPPP_SPLIT_MAX: largest call (proofs) that takes the small-call path; unset = 4 per SIMD
     int fb_one_lane_mode = -1;   // diagnostic BPPP_FB_ONE_LANE: 1 = one lane per proof in the u64 verifier's fixed-base kernels at every size, 0 = never, unset = by size   // diagnostics, read from the environment once at context creation
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> event_pool;

@@ -36,6 +36,10 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed_l1(VerifyWs ws) { verify_c0_fixed_lanes<1>(ws); }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(VerifyWs ws) { verify_final_check_lanes<BPPP_FB_LANES>(ws); }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_l1(VerifyWs ws) { verify_final_check_lanes<1>(ws); }
+// a whole wavefront per proof: calls of a handful of proofs (the chip is empty; 204 / 588 table additions over 64 lanes and a 6-step tree
+// instead of 26 / 74 additions per lane and a 3-step tree)
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed_l64(VerifyWs ws) { verify_c0_fixed_lanes<64>(ws); }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_l64(VerifyWs ws) { verify_final_check_lanes<64>(ws); }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(VerifyWs ws, RlcWs r) {
     const size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
     const size_t chunk = g / BPPP_RLC_CHUNK;

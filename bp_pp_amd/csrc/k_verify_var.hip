@@ -66,3 +66,28 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g2(VerifyWs ws, int
     const u32 key = (ws.states && ws.n_states != 1) ? ws.tstate[(size_t)50 * ws.N + t] : 0u;
     for_each_position_group(key, [&]() { verify_round(ws, t, k, q, 2); });
 }
+
+// ---- calls so small that the chip is empty (at most one proof per SIMD): what a call takes is the longest dependent chain of one
+// proof, so the chains are cut further.  Window tables: a lane per table (13 points x {P, 2^65 P}: 32 lanes per proof, 26 active);
+// sums: a lane per HALF of a GLV stream (verify_core.h: straus_affine_split) -- 8 lanes per proof in a round, 32 (20 active) for C0.
+#if BPPP_VWIN == 5
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables_split(VerifyWs ws) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 5;
+    const int p = (int)(g & 15), h = (int)((g >> 4) & 1);
+    if (t < ws.N && p < BPPP_VPOINTS) verify_table_one(ws, t, p, h, true);   // from the caller's bytes: runs beside phase 1
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g8(VerifyWs ws, int k) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 3;
+    if (t >= ws.N) return;                    // whole groups leave together
+    const int q = (int)(g & 7);
+    const u32 key = (ws.states && ws.n_states != 1) ? ws.tstate[(size_t)50 * ws.N + t] : 0u;
+    for_each_position_group(key, [&]() { verify_round(ws, t, k, q, 8); });
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g32(VerifyWs ws) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 5;
+    if (t < ws.N) verify_c0_var(ws, t, (int)(g & 31), 32);
+}
+#endif

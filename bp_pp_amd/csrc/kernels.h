@@ -89,6 +89,11 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_small(bppp::VerifyW
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g4(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g4(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g2(bppp::VerifyWs ws, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables_split(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g8(bppp::VerifyWs ws, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g32(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed_l64(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_l64(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_l1(bppp::VerifyWs ws);
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_fold_w2(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(bppp::ProveWs w, bppp::MsmJob job);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l1(bppp::ProveWs w, bppp::MsmJob job);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l64(bppp::ProveWs w, bppp::MsmJob job);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_scalars(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round(bppp::WnlaWs w, int k);

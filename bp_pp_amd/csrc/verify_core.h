@@ -1012,6 +1012,98 @@ HD void verify_tables(const VerifyWs& ws, size_t t) {
     BPPP_STAMP(t, 19);
 }
 #if BPPP_VWIN == 5
+// The window table of ONE point by ONE lane -- for calls so small that the chip is empty and what counts is the length of the dependent
+// chain a proof has to wait for (a lane per table instead of a lane per proof: k_verify_tables_split).  pre_doublings > 0 first replaces
+// P by 2^pre_doublings P: the table of the HIGH half of a 26-window stream (13 windows x 5 bits = 65 doublings), so that a sum can walk
+// the two halves of every stream on two lanes (straus_affine_split).  The multiples 2P .. 16P as a Jacobian chain (one doubling, 14
+// mixed additions: kP + P is never exceptional for 2 <= k <= 15 in a group of prime order), one inversion for their 15 Z's.
+#define BPPP_SPLIT_WINDOWS 13
+#define BPPP_SPLIT_DOUBLINGS (5 * BPPP_SPLIT_WINDOWS)
+HD void affine_table_one(atab_ref tb, const apt& Pin, int pre_doublings) {
+    fe beta;
+    glv_beta(beta);
+    apt P = Pin;
+    const bool pid = apt_is_identity(Pin);
+    if (pre_doublings) {
+        ptj a;
+        bool e0 = true;
+        ptj_init(a);
+        ptj_madd(a, e0, P, false);
+#pragma nounroll
+        for (int d = 0; d < pre_doublings; d++) ptj_dbl(a);
+        fe zi, zi2;
+        fe_inv(zi, a.Z);                          // the identity's Z is 0 and stays 0: every entry is stored as the identity below
+        fe_sqr(zi2, zi);
+        fe_mul(P.x, a.X, zi2);
+        fe_mul(zi2, zi2, zi);
+        fe_mul(P.y, a.Y, zi2);
+    }
+    atab_store(tb, 1, P, beta, pid);
+    ptj T;
+    bool empty = true;
+    ptj_init(T);
+    ptj_madd(T, empty, P, false);
+    ptj_dbl(T);
+    fe jx[15], jy[15], jz[15], pre[15];
+#pragma nounroll
+    for (int k = 0; k < 15; k++) {                // entry k holds (k + 2) P
+        if (k) ptj_madd(T, empty, P, false);
+        jx[k] = T.X; jy[k] = T.Y; jz[k] = T.Z;
+        if (k) fe_mul(pre[k], pre[k - 1], T.Z);
+        else fe_mul_small(pre[0], T.Z, 1);
+    }
+    fe inv;
+    fe_inv(inv, pre[14]);
+#pragma nounroll
+    for (int k = 14; k >= 0; k--) {
+        fe zi, zi2;
+        if (k) { fe_mul(zi, inv, pre[k - 1]); fe_mul(inv, inv, jz[k]); }
+        else zi = inv;
+        apt R;
+        fe_sqr(zi2, zi);
+        fe_mul(R.x, jx[k], zi2);
+        fe_mul(zi2, zi2, zi);
+        fe_mul(R.y, jy[k], zi2);
+        atab_store(tb, k + 2, R, beta, pid);
+    }
+}
+// Point p of proof t's window tables straight from the caller's bytes -- what verify_phase1 parks in ws.pts: the 12 proof points it
+// decodes and circuit_commitment = V + proof.r (reciprocal.rs:104), all of them the identity when anything in the proof is malformed
+// -- so that the table kernel of a small call can run beside phase 1 instead of after it.
+HD void verify_table_source(apt& P, const VerifyWs& ws, size_t t, int p) {
+    const uint8_t* pv = ws.commitments + 64 * t;
+    const uint8_t* pp = ws.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
+    apt V, Pr, Q;
+    fe_set_u32(P.x, 0);
+    fe_set_u32(P.y, 0);
+    bool ok = apt_from_xy64(V, pv);
+#pragma nounroll
+    for (int i = 0; i < 12; i++) {
+        ok &= apt_from_xy64(Q, pp + 64 * i);
+        if (i == p) P = Q;
+    }
+    ok &= apt_from_xy64(Pr, pp + 64 * 12);
+    sc k;
+    ok &= sc_from_be(k, pp + 832);
+    ok &= sc_from_be(k, pp + 864);
+    ok &= sc_from_be(k, pp + 896);
+    if (p == 12 && ok) {
+        pt s;
+        pt_from_affine(s, V);
+        pt_madd(s, s, Pr, apt_is_identity(Pr));
+        pt_to_affine(P, s);
+    }
+    if (!ok) { fe_set_u32(P.x, 0); fe_set_u32(P.y, 0); }
+}
+// lane (point p, half h) of proof t: table slot p for the low half, BPPP_VPOINTS + p for the high half
+HD void verify_table_one(const VerifyWs& ws, size_t t, int p, int h, bool from_bytes = false) {
+    apt P;
+    if (from_bytes) verify_table_source(P, ws, t, p);
+    else ws_ld_apt(P, ws.pts, ws.N, t, p);
+    affine_table_one(atab_of(ws.atab, ws.N, t) + (h * BPPP_VPOINTS + p) * 16, P, h ? BPPP_SPLIT_DOUBLINGS : 0);
+}
+#endif
+#if BPPP_VWIN == 5
 // The 2M GLV half-scalars of an M-point sum, kept in registers, recoded for signed 5-bit windows:
 //   w = |k| + OFF5,  OFF5 = sum_{i < 26} 16 * 32^i   (|k| < 2^128, so w < 2^130: 26 digits),  digit_i = ((w >> 5 i) & 31) - 16 in [-16, 15].
 // glv_decompose hands over |k| + 0x8...8 (the 4-bit offset of the generic path); the difference of the two offsets is added here.
@@ -1264,6 +1356,72 @@ HD void straus_affine(pt& out, atab_ref tab, const int* pidx, const glv_words<M>
     }
 }
 
+#if BPPP_VWIN == 5
+// lane q's share of the split sum (below): half h = q / 2M (windows 13 h .. 13 h + 12) of stream r = q % 2M over the table of
+// 2^(65 h) P (slot pidx + BPPP_VPOINTS h: verify_table_one); q >= 4M: nothing.  False on an exceptional addition.
+template <int M>
+HD bool straus_split_lane(pt& part, atab_ref tab, const int* pidx, const glv_words<M>& g, int q) {
+    fe beta;
+    glv_beta(beta);
+    const bool have = q < 4 * M;
+    const int h = q >= 2 * M ? 1 : 0, r = q - 2 * M * h;
+    u32 w[5];
+    bool sneg = false;
+    int pn = 0;
+#pragma unroll
+    for (int l = 0; l < 5; l++) w[l] = 0;
+#pragma unroll
+    for (int st = 0; st < 2 * M; st++) {
+#pragma unroll
+        for (int l = 0; l < 5; l++) w[l] = (st == r) ? g.w[st][l] : w[l];
+        sneg = (st == r) ? g.neg[st] : sneg;
+        pn = (st == r) ? pidx[st >> 1] : pn;
+    }
+    const bool img = (r & 1) != 0;
+    const int base = (pn + BPPP_VPOINTS * h) * 16, w0 = BPPP_SPLIT_WINDOWS * h;
+    auto digit = [&](int i, int& mag, bool& neg) {
+        const int b = 5 * i, l = b >> 5, sh = b & 31;
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { lo = (k == l) ? w[k] : lo; hi = (k == l + 1) ? w[k] : hi; }
+        const int dg = (int)((u32)(((((u64)hi) << 32) | lo) >> sh) & 31u) - 16;
+        mag = dg < 0 ? -dg : dg;
+        neg = (dg < 0) != sneg;
+    };
+    ptj acc;
+    ptj_init(acc);
+    bool empty = true;
+    int cur_mag, nxt_mag;
+    bool cur_neg, nxt_neg;
+    apt_packed cur_e, nxt_e;
+    digit(w0 + BPPP_SPLIT_WINDOWS - 1, cur_mag, cur_neg);
+    cur_e = tab[base + (cur_mag ? cur_mag - 1 : 0)];
+#pragma nounroll
+    for (int i = BPPP_SPLIT_WINDOWS - 1; i >= 0; i--) {
+        digit(w0 + (i > 0 ? i - 1 : 0), nxt_mag, nxt_neg);       // the next window's entry is requested before this window's doublings
+        nxt_e = tab[base + (nxt_mag ? nxt_mag - 1 : 0)];
+        if (i != BPPP_SPLIT_WINDOWS - 1) {
+#pragma nounroll
+            for (int d = 0; d < 5; d++) ptj_dbl(acc);
+        }
+        apt e;
+        bool id;
+        apt_unpack(e, id, cur_e);
+        fe bx, ny;
+        fe_mul(bx, e.x, beta);
+        fe_cmov(e.x, img, bx);
+        fe_neg_m<1>(ny, e.y);
+        fe_cmov(e.y, cur_neg, ny);
+        ptj_madd(acc, empty, e, (cur_mag == 0) | id | !have);
+        cur_e = nxt_e;
+        cur_mag = nxt_mag;
+        cur_neg = nxt_neg;
+    }
+    const bool exceptional = !empty && fe_is_zero(acc.Z);
+    ptj_to_pt(part, acc, empty);
+    return !exceptional;
+}
+#endif
 #if defined(__HIPCC__) && BPPP_VWIN == 5
 // The same M-point sum spread over a GROUP OF FOUR LANES: lane q takes the GLV streams q, q + 4, q + 8 (< 2M; stream r is point
 // r >> 1, its image if r & 1), i.e. 26 windows x (5 doublings + 1 .. 3 mixed additions) per lane instead of 26 x (5 + 2M), then a
@@ -1352,6 +1510,25 @@ __device__ __forceinline__ void straus_affine_g4(pt& out, atab_ref tab, const in
     }
     pt part;
     ptj_to_pt(part, acc, empty);
+    lane_group_sum<G>(part);
+    out = part;
+}
+// The same sum with every stream cut in two: lane q < 4M of a group of G walks half h = q / 2M (windows 13 h .. 13 h + 12) of stream
+// r = q % 2M over the table of 2^(65 h) P (slot pidx + BPPP_VPOINTS h: verify_table_one) -- 12 x 5 doublings + 13 mixed additions per
+// lane instead of 25 x 5 + 26 ... 78, then a log2(G)-step shuffle tree.  For calls that leave the chip empty (a handful of proofs): the
+// length of the chain is all that counts there.  Lanes q >= 4M of the group hold no stream and add the identity.  All G lanes of a
+// group must be active and hold the same g / pidx; every lane ends with the total.
+template <int M, int G>
+__device__ __forceinline__ void straus_affine_split(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g, int q) {
+    static_assert(4 * M <= G, "a lane per half-stream");
+    pt part;
+    int bad = straus_split_lane<M>(part, tab, pidx, g, q) ? 0 : 1;
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) bad |= __shfl_xor(bad, m, 64);
+    if (bad) {                      // an exceptional addition somewhere in the group: every lane re-does the whole sum completely
+        straus_affine_complete<M>(out, tab, pidx, g);
+        return;
+    }
     lane_group_sum<G>(part);
     out = part;
 }
@@ -1613,7 +1790,7 @@ HD void verify_c0_fixed(const VerifyWs& ws, size_t t) {
     verify_c0_fixed_store(ws, t, acc);
 }
 // ---------------------------------------------------------------- phase 2a: C0 variable-base part (circuit.rs:230-235)
-HD void verify_c0_var(const VerifyWs& ws, size_t t, int group_lane = -1) {
+HD void verify_c0_var(const VerifyWs& ws, size_t t, int group_lane = -1, int group_size = 4) {
     const size_t N = ws.N;
     const int pslot[5] = {3, 2, 0, 1, 12};  // c_s, c_o, c_l, c_r, V+r  <->  sc0 slots 17..21
     glv_words<5> g;
@@ -1628,11 +1805,12 @@ HD void verify_c0_var(const VerifyWs& ws, size_t t, int group_lane = -1) {
     BPPP_STAMP(t, 20);
     pt acc;
 #if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
-    if (group_lane >= 0) straus_affine_g4<5>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
+    if (group_lane >= 0 && group_size == 32) straus_affine_split<5, 32>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
+    else if (group_lane >= 0) straus_affine_g4<5>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
     else
 #endif
         straus_affine<5>(acc, atab_of(ws.atab, ws.N, t), pslot, g);
-    (void)group_lane;
+    (void)group_lane; (void)group_size;
     BPPP_STAMP(t, 21);
     ws_st_pt(ws.acc, N, t, acc);   // the fixed-base part (pfix) is added at the top of round 1
 }
@@ -1695,7 +1873,8 @@ HD void verify_round_on(const VerifyWs& ws, size_t t, int k, TR& tr, int group_l
     BPPP_STAMP(t, 12);
     pt acc;
 #if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
-    if (group_lane >= 0 && group_size == 4) straus_affine_g4<2, 4>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
+    if (group_lane >= 0 && group_size == 8) straus_affine_split<2, 8>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
+    else if (group_lane >= 0 && group_size == 4) straus_affine_g4<2, 4>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
     else if (group_lane >= 0) straus_affine_g4<2, 2>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
     else
 #endif

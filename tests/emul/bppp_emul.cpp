@@ -262,6 +262,60 @@ int emul_straus_affine(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64
     apt_to_xy64(out, r);
     return 0;
 }
+// the small-call path: a lane per window table (verify_table_one: P and 2^65 P) and a lane per half GLV stream (straus_split_lane);
+// the lanes of a group run here one after the other and their shares are added with the complete law, as the shuffle tree does.
+// tables_out (optional): the 2 x 13 x 16 table entries as 64-byte affine points (identity = zeros).
+int emul_straus_split(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64], int* fell_back, uint8_t* tables_out) {
+    VerifyWs ws;
+    memset(&ws, 0, sizeof ws);
+    ws.N = 1;
+    std::vector<u32> pts(208, 0);
+    std::vector<apt_packed> atab(2 * BPPP_ATAB_PER_PROOF);
+    ws.pts = pts.data(); ws.atab = atab.data();
+    glv_words<5> g5;
+    glv_words<2> g2;
+    for (int j = 0; j < 5; j++) {
+        sc s;
+        sc_set_u32(s, 0);
+        if (j < m) {
+            apt a;
+            if (!apt_from_xy64(a, P + 64 * j) || !sc_from_be(s, k + 32 * j)) return -1;
+            ws_st_apt(ws.pts, 1, 0, j, a);
+        }
+        glv_split sp;
+        glv_decompose(sp, s);
+        glv_words_set<5>(g5, j, sp);
+        if (j < 2) glv_words_set<2>(g2, j, sp);
+    }
+    for (int h = 0; h < 2; h++)
+        for (int p = 0; p < BPPP_VPOINTS; p++) verify_table_one(ws, 0, p, h);
+    if (tables_out)
+        for (int i = 0; i < 2 * BPPP_VPOINTS * 16; i++) {
+            apt e;
+            bool id;
+            apt_unpack(e, id, atab[i]);
+            if (id) memset(tables_out + 64 * i, 0, 64);
+            else apt_to_xy64(tables_out + 64 * i, e);
+        }
+    const int pidx[5] = {0, 1, 2, 3, 4};
+    const atab_ref tabv = atab_of(atab.data(), 1, 0);
+    pt total, viafb;
+    pt_set_identity(total);
+    bool ok = true;
+    const int lanes = m <= 2 ? 8 : 32;
+    for (int q = 0; q < lanes; q++) {
+        pt part;
+        ok &= (m <= 2) ? straus_split_lane<2>(part, tabv, pidx, g2, q) : straus_split_lane<5>(part, tabv, pidx, g5, q);
+        pt_add(total, total, part);
+    }
+    *fell_back = !ok;
+    if (m <= 2) straus_affine_complete<2>(viafb, tabv, pidx, g2); else straus_affine_complete<5>(viafb, tabv, pidx, g5);
+    if (ok && !pt_eq(total, viafb)) return -2;
+    apt r;
+    pt_to_affine(r, viafb);
+    apt_to_xy64(out, r);
+    return 0;
+}
 // full exact verify pipeline, every phase in thread order
 static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
                                 const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* trace, const uint8_t* states,
@@ -295,6 +349,18 @@ static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* labe
     ws.fb_w = W;
     t_new(ws.base, label, (u32)label_len);
     for (size_t t = 0; t < n; t++) verify_phase1(ws, t);
+    // self-check of the small-call table kernel's own decode (verify_table_source): it must reproduce what phase 1 parked in ws.pts,
+    // for well-formed and malformed proofs alike
+    for (size_t t = 0; t < n; t++)
+        for (int p = 0; p < BPPP_VPOINTS; p++) {
+            apt a, b;
+            verify_table_source(a, ws, t, p);
+            ws_ld_apt(b, ws.pts, n, t, p);
+            uint8_t ea[64], eb[64];
+            apt_to_xy64(ea, a);
+            apt_to_xy64(eb, b);
+            if (memcmp(ea, eb, 64) != 0) return -77;
+        }
     for (size_t t = 0; t < n; t++) verify_tables(ws, t);
     for (size_t t = 0; t < n; t++) verify_c0_var(ws, t);
     for (size_t t = 0; t < n; t++) verify_c0_fixed(ws, t);

@@ -167,6 +167,49 @@ def test_affine_tables_and_jacobian_straus(L):
         assert fb.value == 1
 
 
+def test_per_lane_tables_and_half_stream_sums(L):
+    """The small-call path of the u64 verifier (verify_core.h: affine_table_one, straus_split_lane): a lane builds ONE window table
+    -- of P, or of 2^65 P for the high half of a stream -- and a lane walks HALF a GLV stream; the lanes' shares added up must be
+    sum k_j P_j, and every table entry must be the oracle's multiple.  Identity points, special scalars, exceptional additions."""
+    rnd = random.Random(31)
+    pts = [None, O.G, O.pt_neg(O.G)] + [O.pt_mul(O.G, rnd.getrandbits(256)) for _ in range(6)]
+    out, fb = C.create_string_buffer(64), C.c_int(0)
+    tabs = C.create_string_buffer(2 * 13 * 16 * 64)
+    special = [0, 1, O.N - 1, O.LAMBDA, 2**255, 16, O.N - 16, 2**65, 2**65 - 1, (1 << 130) - 1, int("8" * 64, 16) % O.N]
+    n_fast = 0
+    for m in (1, 2, 5):
+        for it in range(8):
+            P = [pts[rnd.randrange(len(pts))] for _ in range(m)]
+            ks = [rnd.choice(special + [rnd.getrandbits(256) % O.N] * 8) for _ in range(m)]
+            assert L.emul_straus_split(m, b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out, C.byref(fb), tabs if it == 0 else None) == 0
+            exp = None
+            for p, k in zip(P, ks):
+                exp = O.pt_add(exp, O.pt_mul(p, k))
+            assert out.raw == O.pt_to_xy64(exp)
+            n_fast += 1 - fb.value
+            if it == 0:
+                for h in range(2):
+                    for j in range(13):
+                        base = O.pt_mul(P[j], 2**(65 * h)) if j < m else None
+                        for e in range(16):
+                            got = tabs.raw[64 * ((13 * h + j) * 16 + e):][:64]
+                            assert got == O.pt_to_xy64(O.pt_mul(base, e + 1)), (m, h, j, e)
+    assert n_fast >= 12
+    for m in (2, 5):
+        P = [O.pt_mul(O.G, rnd.getrandbits(256)) for _ in range(m)]
+        ks = [rnd.getrandbits(256) % O.N for _ in range(m)]
+        assert L.emul_straus_split(m, b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out, C.byref(fb), None) == 0
+        assert fb.value == 0
+    # an exceptional addition inside one lane's half stream (a table entry added to its own value) is flagged, the result still right
+    A = O.pt_mul(O.G, 0xABCDEF)
+    for P, ks in (([A, O.pt_neg(A)], [77, 77]), ([A], [33 * 32 + 1])):
+        assert L.emul_straus_split(len(P), b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out, C.byref(fb), None) == 0
+        exp = None
+        for p, k in zip(P, ks):
+            exp = O.pt_add(exp, O.pt_mul(p, k))
+        assert out.raw == O.pt_to_xy64(exp)
+
+
 def test_merlin_known_answer_on_device_code(L):
     kat = C.create_string_buffer(32)
     L.emul_merlin_kat(b"test protocol", 13, b"some data", 9, kat, 32)
@@ -267,7 +310,7 @@ def test_full_verify_pipeline_against_golden(L, gold, oracle_c, W):
     V = np.frombuffer(b"".join(bytes.fromhex(i[0]) for i in items), dtype=np.uint8).reshape(n, 64).copy()
     P = np.frombuffer(b"".join(bytes.fromhex(i[1]) for i in items), dtype=np.uint8).reshape(n, 928).copy()
     acc, st, tr = np.zeros(n, np.uint8), np.zeros(n, np.int32), np.zeros((n, 704), np.uint8)
-    L.emul_u64_verify_batch(tab.ctypes.data, W, label, len(label), n, V.ctypes.data, P.ctypes.data, acc.ctypes.data,
+    assert 0 == L.emul_u64_verify_batch(tab.ctypes.data, W, label, len(label), n, V.ctypes.data, P.ctypes.data, acc.ctypes.data,
                             st.ctypes.data, tr.ctypes.data)
     assert acc.tolist() == [i[2] for i in items]
     assert st.tolist() == [i[3] for i in items]
@@ -343,7 +386,7 @@ def test_identity_and_repeated_points_in_a_proof(L, gold, oracle_c):
     n = len(rows)
     V, P = np.stack([r[0] for r in rows]), np.stack([r[1] for r in rows])
     acc, st, tr = np.zeros(n, np.uint8), np.zeros(n, np.int32), np.zeros((n, 704), np.uint8)
-    L.emul_u64_verify_batch(tab.ctypes.data, W, label, len(label), n, V.ctypes.data, P.ctypes.data, acc.ctypes.data, st.ctypes.data, tr.ctypes.data)
+    assert 0 == L.emul_u64_verify_batch(tab.ctypes.data, W, label, len(label), n, V.ctypes.data, P.ctypes.data, acc.ctypes.data, st.ctypes.data, tr.ctypes.data)
     assert acc.tolist() == [0] * (n - 1) + [1] and not st.any()
     for k in range(n):
         rc, otr = oracle_c.u64_verify(gens, label, bytes(V[k]), bytes(P[k]), trace=True)
@@ -367,6 +410,6 @@ def test_prover_at_the_edges_of_its_inputs(L, gold, oracle_c):
     assert not st.any() and (ov == V).all() and (op == proofs).all()
     oacc, ost = oracle_c.u64_verify_batch(gens, label, V, proofs, nthreads=2)
     acc, vst, tr = np.zeros(n, np.uint8), np.zeros(n, np.int32), np.zeros((n, 704), np.uint8)
-    L.emul_u64_verify_batch(tab.ctypes.data, W, label, len(label), n, V.ctypes.data, proofs.ctypes.data, acc.ctypes.data, vst.ctypes.data,
+    assert 0 == L.emul_u64_verify_batch(tab.ctypes.data, W, label, len(label), n, V.ctypes.data, proofs.ctypes.data, acc.ctypes.data, vst.ctypes.data,
                             tr.ctypes.data)
     assert oacc.all() and acc.all() and not ost.any() and not vst.any()

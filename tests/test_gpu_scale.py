@@ -272,3 +272,33 @@ def test_u64_verify_beyond_one_internal_part(torch_mod):
         assert proto.device_bytes() - bytes_before < 1.25 * (1 << 21) * 40000
     finally:
         proto.close()
+
+
+def test_wnla_at_the_generator_count_limit(torch_mod):
+    """The C ABI's own limits (the reference has none): |g_vec| = |h_vec| = 4096 generators, |l| = |n| = 4096, 11 rounds -- commit, verify
+    and prove of WeightNormLinearArgument (wnla.rs:66-190) against the oracle at that size; one generator more is refused."""
+    import wnla_cases
+    from bp_pp_amd import BpppError
+    from bp_pp_amd.wnla import WeightNormLinearArgument
+    NG = NH = 4096
+    B = 2
+    case = wnla_cases.make(NG, NH, B)
+    assert case["rounds"] == 11
+    w = WeightNormLinearArgument(case["g"], case["gv"], case["hv"], device=0, fb_window_bits=8)
+    try:
+        out, st = w.commit_batch(case["c"], case["mu"], case["l"], case["n"])
+        assert not st.any() and (out == case["commitments"]).all()
+        args = dict(commitments=case["commitments"], c=case["c"], rho=case["rho"], mu=case["mu"], proof_r=case["proof_r"],
+                    proof_x=case["proof_x"], proof_l=case["proof_l"], proof_n=case["proof_n"])
+        acc, st = w.verify_batch(case["label"], **args)
+        assert acc.all() and not st.any()
+        pn = case["proof_n"].copy(); pn[1, 0, 31] ^= 1
+        acc, st = w.verify_batch(case["label"], **dict(args, proof_n=pn))
+        assert acc.tolist() == [1, 0]
+        pr, px, pl, pnv, st = w.prove_batch(case["label"], case["commitments"], case["c"], case["rho"], case["mu"], case["l"], case["n"])
+        assert not st.any() and (pr == case["proof_r"]).all() and (px == case["proof_x"]).all()
+        assert (pl == case["proof_l"]).all() and (pnv == case["proof_n"]).all()
+    finally:
+        w.close()
+    with pytest.raises(BpppError):
+        WeightNormLinearArgument(case["g"], case["gv"] + [case["gv"][0]], case["hv"], device=0, fb_window_bits=8)     # 4097 generators
