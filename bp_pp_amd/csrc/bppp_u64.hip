@@ -384,6 +384,7 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     // a call of at most one value per SIMD: a wavefront per sum (the chip is empty; 6 additions per lane and a 6-step tree instead of 44 and 3)
     const bool fb_wave = !c->no_small && !c->no_split && n <= (size_t)c->n_simds;
+    w.next_by_msm = fb_wave ? 1 : 0;     // ... and the next level's commitment as one more of those sums (prove_core.h: job_cnext)
     const unsigned fb64_blocks = (unsigned)((n * 64 + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
 #define PMSM(job)                                                                                         \
     do {                                                                                                  \
@@ -407,12 +408,13 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     for (int k = 1; k <= 4; k++) {
         PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         PMSM(job_x()); PMSM(job_r(k));
-        if (!c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
+        if (!w.next_by_msm && !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
             PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
         else if (w2)
             PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         else
             PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        if (w.next_by_msm && k < 4) PMSM(job_cnext());
     }
     if (w.states_out) k_prove_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
 #undef PMSM

@@ -55,6 +55,7 @@ struct ProveWs {
     const uint8_t* states;
     size_t n_states;
     uint8_t* states_out;
+    int next_by_msm;        // 1: prove_round_fold leaves the next commitment's scalars in set 0 for job_cnext (small calls) instead of summing it itself
 };
 struct MsmJob {             // one fixed-base MSM per proof: sum over runs of bases of scalar set `set` (verify_core.h: FbRanges)
     int set, out_slot, nranges;
@@ -621,6 +622,45 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k, int group_lane = -1)
         pw_st_sc(w, t, SV_MU, t1);
         sc_mul(t1, rho_inv, rho_inv);
         pw_st_sc(w, t, SV_RHOINV, t1);
+        if (w.next_by_msm) {
+            // next commitment = wnla.commit(l_, n_) as the reference computes it (wnla.rs:186, :66-72): v g + <h', l_> + <g', n_> over the
+            // ORIGINAL generators (h'_j = sum ch[i] h_i, g'_j = sum cg[i] g_i over i >> k == j), v = <c_, l_> + |n_|^2_{mu'} -- one more
+            // fixed-base sum (job_cnext).  For a call of a few proofs that is a wavefront's 10 table additions and a 6-step tree, against
+            // the 125 doublings of the variable-base form below, which is the cheaper one once the chip is full.
+            sc v, mun, mp, a, b;
+            pw_ld_sc(mun, w, t, SV_MU);         // mu' (already advanced above)
+            mp = mun;
+            sc_set_u32(v, 0);
+#pragma nounroll
+            for (int m = 0; m < nn / 2; m++) {
+                pw_ld_sc(a, w, t, SV_N0 + m);
+                sc_mul(t1, a, a); sc_mul(t1, t1, mp); sc_add(v, v, t1);
+                sc_mul(mp, mp, mun);
+            }
+#pragma nounroll
+            for (int m = 0; m < nl / 2; m++) {
+                pw_ld_sc(a, w, t, SV_C0 + m);
+                pw_ld_sc(b, w, t, SV_L0 + m);
+                sc_mul(t1, a, b); sc_add(v, v, t1);
+            }
+            pw_st_msc(w, t, 0, 0, v);
+#pragma nounroll
+            for (int i = 0; i < 16; i++) {
+                pw_ld_sc(a, w, t, SV_CG0 + i);
+                pw_ld_sc(b, w, t, SV_N0 + (i >> k));
+                sc_mul(t1, a, b);
+                pw_st_msc(w, t, 0, 1 + i, t1);
+            }
+#pragma nounroll
+            for (int i = 0; i < 32; i++) {
+                pw_ld_sc(a, w, t, SV_CH0 + i);
+                pw_ld_sc(b, w, t, SV_L0 + (i >> k));
+                sc_mul(t1, a, b);
+                pw_st_msc(w, t, 0, 17 + i, t1);
+            }
+            w.status[t] = status;
+            return;
+        }
         // next commitment = com + y X + (y^2 - 1) R             (= wnla.commit(l_, n_), wnla.rs:186)
         sc y2m1, one;
         sc_set_u32(one, 1);
@@ -677,6 +717,7 @@ HD MsmJob job_cl() { BPPP_JOB({2, PB_CL, 4, {1, 17, 21, 26}, {16, 3, 3, 16}, {4,
 HD MsmJob job_cr() { BPPP_JOB({3, PB_CR, 3, {1, 17, 20}, {16, 2, 3}, {0, 0, 0}, NOODD}); }                        // r | rr: h[2], h[6..8] zero
 HD MsmJob job_cs() { BPPP_JOB({0, PB_CS, 1, {1}, {42}, {0}, NOODD}); }
 HD MsmJob job_c0() { BPPP_JOB({0, PB_C, 1, {0}, {43}, {0}, NOODD}); }
+HD MsmJob job_cnext() { BPPP_JOB({0, PB_C, 1, {0}, {49}, {0}, NOODD}); }                                           // small calls: the next level's commitment
 HD MsmJob job_x() { BPPP_JOB({1, PB_X, 1, {0}, {49}, {0}, NOODD}); }
 // R of round k: v_r g + the odd halves (blocks of 2^(k-1) original generators) of g_vec and h_vec
 HD MsmJob job_r(int k) { BPPP_JOB({2, PB_R, 3, {0, 1, 17}, {1, 8, 16}, {0, 0, 0}, {-1, k - 1, k - 1}}); }

@@ -478,6 +478,7 @@ int emul_u64_bucket_stage(const uint8_t* table, int W, const uint8_t* label, siz
     return 0;
 }
 // full prover pipeline, every stage in thread order
+static int g_prove_next_by_msm = 0;   // emul_set_prove_next_by_msm
 static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x,
                                const uint8_t* s, const uint8_t* rnd, uint8_t* proofs, uint8_t* V, int32_t* status, const uint8_t* states,
                                size_t n_states, uint8_t* states_out);
@@ -512,14 +513,18 @@ static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label
     msm(job_cs());
     for (size_t t = 0; t < n; t++) prove_stage_f(w, t);
     msm(job_c0());
+    w.next_by_msm = g_prove_next_by_msm;
     for (int k = 1; k <= 4; k++) {
         for (size_t t = 0; t < n; t++) prove_round_scalars(w, t, k);
         msm(job_x()); msm(job_r(k));
         for (size_t t = 0; t < n; t++) prove_round_fold(w, t, k);
+        if (w.next_by_msm && k < 4) msm(job_cnext());
     }
     for (size_t t = 0; t < n; t++) prove_export_state(w, t);
     return 0;
 }
+// the small-call form of the u64 prover: next commitments as fixed-base sums (prove_core.h: ProveWs::next_by_msm)
+void emul_set_prove_next_by_msm(int on) { g_prove_next_by_msm = on; }
 // wire format: SEC1 compressed inputs -> 64-byte form, lane by lane
 void emul_sec1_expand(size_t n, const uint8_t* c33, const uint8_t* p525, uint8_t* c64, uint8_t* p928) {
     for (size_t t = 0; t < n; t++)

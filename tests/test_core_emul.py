@@ -351,6 +351,30 @@ def test_full_prove_pipeline_is_byte_identical_to_the_oracle(L, gold, oracle_c):
     assert (ov == V).all() and (op == proofs).all()
 
 
+def test_prover_next_commitments_as_fixed_base_sums(L, gold, oracle_c):
+    """The small-call form of the u64 prover (ProveWs::next_by_msm): each WNLA level's commitment as wnla.commit(l_, n_) over the
+    original generators (wnla.rs:186, :66-72: one more fixed-base sum) instead of com + y X + (y^2 - 1) R -- the same points, so
+    the same proof bytes as the oracle prover's."""
+    import workload
+    gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
+    W = 4
+    tab = np.zeros(L.emul_fb_table_entries(49, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0
+    n = 5
+    x = np.ascontiguousarray(workload.values(n, first=0))               # includes 0, 2^64 - 1, 123456
+    s, rnd = np.ascontiguousarray(workload.blindings(n, first=0)), np.ascontiguousarray(workload.prover_randomness(n, first=0))
+    proofs, V, st = np.zeros((n, 928), np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.int32)
+    L.emul_set_prove_next_by_msm(1)
+    try:
+        assert 0 == L.emul_u64_prove_batch(tab.ctypes.data, W, label, len(label), n, x.ctypes.data, s.ctypes.data, rnd.ctypes.data,
+                                           proofs.ctypes.data, V.ctypes.data, st.ctypes.data)
+    finally:
+        L.emul_set_prove_next_by_msm(0)
+    assert not st.any()
+    op, ov = oracle_c.u64_prove_batch(gens, label, x, s, rnd, nthreads=2)
+    assert (ov == V).all() and (op == proofs).all()
+
+
 def test_identity_and_repeated_points_in_a_proof(L, gold, oracle_c):
     """CPU twin of tests/test_gpu_verify.py::test_identity_points_in_proofs_vs_oracle on the device code: each of the 14 points of
     a golden proof replaced by the identity (64 zero bytes: well-formed, hashed as 33 zero bytes, the neutral element of every

@@ -45,7 +45,7 @@ def test_golden_proofs_byte_exact(proto, gold):
     assert proto.verify(bytes.fromhex(c["commitment"]), bytes.fromhex(c["proof"]), label)
 
 
-@pytest.mark.parametrize("n", [1, 65, 1 << 14])
+@pytest.mark.parametrize("n", [1, 65, 1024, 1500, 1 << 14])   # 1, 65, 1024: small-call path (a wavefront per sum, next commitments as sums); 1500, 2^14: lane groups
 def test_batch_prove_vs_oracle(proto, oracle_c, n):
     """n = 2^14 is BASELINE config 4.  Every proof equals the oracle's trapdoor prover byte for byte (itself equal to the
     honest reference-shaped prover, tests/test_oracle_c.py); a sample is also proved by the honest prover directly."""

@@ -87,7 +87,7 @@ def test_commit_value_matches_reference_formula(torch_mod, proto, gold, oracle_c
         assert bytes(out[i]) == oracle_c.u64_commit_value(gens, int(x[i]), bytes(s[i]))
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000, 4096, 6000])   # <= 4096: small-call path (a lane per table / half stream); 6000: lane groups
 def test_ragged_batches_vs_oracle(torch_mod, proto, oracle_c, n):
     import workload
     gens, V, P, _ = workload.make_batch(n, first=1000)
