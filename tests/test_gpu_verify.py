@@ -351,12 +351,14 @@ def test_identity_points_in_proofs_vs_oracle(torch_mod, proto, oracle_c):
     assert (acc2 == acc).all() and (acc3 == acc).all() and not st2.any() and not st3.any()
 
 
-@pytest.mark.parametrize("n", [3, 300, 20000])
+@pytest.mark.parametrize("n", [3, 300, 6000, 20000])
 def test_lane_groups_and_one_lane_per_proof_agree(torch_mod, gold, oracle_c, n):
-    """Small batches run their variable-base sums on groups of four (n <= 16,384) or two (n <= 32,768) lanes per proof; a context
-    created with BPPP_NO_LANE_GROUPS keeps one lane per proof.  Same accept bits, statuses, reject count and -- byte for byte --
-    the same trace (every challenge and every hashed commitment), also for proofs with repeated / negated / identity points, whose
-    sums hit the exceptional-addition fallback inside a group."""
+    """Calls of up to 4,096 proofs take the small-call path (a lane per window table and per HALF GLV stream, a wavefront per
+    fixed-base sum); beyond that the variable-base sums run on groups of four (n <= 16,384) or two (n <= 32,768) lanes per proof.
+    A context created with BPPP_NO_SPLIT falls back to the lane groups at every small size, one created with BPPP_NO_LANE_GROUPS
+    keeps one lane per proof.  All three: same accept bits, statuses, reject count and -- byte for byte -- the same trace (every
+    challenge and every hashed commitment), also for proofs with repeated / negated / identity points, whose sums hit the
+    exceptional-addition fallback inside a group."""
     import workload
     from bp_pp_amd import U64RangeProofProtocol
     gens, V, P, _ = workload.make_batch(min(n, 400), first=70000)
@@ -372,19 +374,21 @@ def test_lane_groups_and_one_lane_per_proof_agree(torch_mod, gold, oracle_c, n):
         P[7, 64 * 8 + 32:64 * 9] = np.frombuffer(((2**256 - 2**32 - 977) - y).to_bytes(32, "big"), np.uint8)   # X_1 := -R_1
     g, gv, hv = workload.split_generators(gens)
     res = []
-    for off in (False, True):
-        if off:
-            os.environ["BPPP_NO_LANE_GROUPS"] = "1"
+    for switch in (None, "BPPP_NO_SPLIT", "BPPP_NO_LANE_GROUPS"):
+        if switch:
+            os.environ[switch] = "1"
         try:
             proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
         finally:
-            os.environ.pop("BPPP_NO_LANE_GROUPS", None)
+            if switch:
+                os.environ.pop(switch, None)
         try:
             res.append(_device_verify(torch_mod, proto, workload.LABEL, V, P))
         finally:
             proto.close()
-    (a0, s0, t0, r0), (a1, s1, t1, r1) = res
-    assert (a0 == a1).all() and (s0 == s1).all() and r0 == r1 and (t0 == t1).all()
+    (a0, s0, t0, r0) = res[0]
+    for (a1, s1, t1, r1) in res[1:]:
+        assert (a0 == a1).all() and (s0 == s1).all() and r0 == r1 and (t0 == t1).all()
     for i in ([0, 1, 2] if n < 300 else [0, 5, 6, 7, 9, 18, n - 1]):
         rc, otr = oracle_c.u64_verify(gens, workload.LABEL, bytes(V[i]), bytes(P[i]), trace=True)
         assert int(a0[i]) == (1 if rc == 1 else 0) and (rc < 0 or bytes(t0[i]) == otr)
