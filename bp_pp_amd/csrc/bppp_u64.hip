@@ -46,9 +46,12 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     int rc = ensure_capacity(c, n);
     if (rc != BPPP_OK) return rc;
     // a call of at most one proof per SIMD: the dependent chains are cut further (a lane per window table and per half GLV stream,
-    // a wavefront per fixed-base sum), which takes a second set of window tables per proof
+    // a wavefront per fixed-base sum), which takes three more sets of window tables per proof
     const bool split = !c->no_small && !c->no_lane_groups && !c->no_split && n <= (c->split_max >= 0 ? (size_t)c->split_max : 4 * (size_t)c->n_simds);
-    rc = ensure_vtab_capacity(c, split ? 2 * n : n);
+    // four parts per GLV stream up to one proof per SIMD, two beyond (the extra lanes start to queue: 2,048 proofs 3.5 ms either way, 4,096
+    // proofs 4.3 ms in two parts against 5.1 in four)
+    const int parts = n <= (size_t)c->n_simds ? 4 : 2;
+    rc = ensure_vtab_capacity(c, split ? (size_t)parts * n : n);
     if (rc != BPPP_OK) return rc;
     VerifyWs ws;
     std::memset(&ws, 0, sizeof ws);
@@ -108,7 +111,9 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         // the small-call table kernel decodes its points itself, so it runs on the helper stream beside phase 1
         HIP_TRY(hipEventRecord(c->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
-        LAUNCH_ON(a, K_TABLES, k_verify_tables_split<<<(unsigned)((32 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, a>>>(ws));
+        const unsigned tb = (unsigned)((16 * (size_t)parts * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+        if (parts == 4) LAUNCH_ON(a, K_TABLES, k_verify_tables_split4<<<tb, BPPP_BLOCK, 0, a>>>(ws));
+        else LAUNCH_ON(a, K_TABLES, k_verify_tables_split2<<<tb, BPPP_BLOCK, 0, a>>>(ws));
         HIP_TRY(hipEventRecord(c->ev_tab, a));
     }
     if (small) LAUNCH(K_PHASE1, k_verify_phase1_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
@@ -134,13 +139,15 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     // a batch whose four-lanes-per-proof grid still leaves the SIMDs under-filled runs its variable-base sums on lane groups
     const bool grouped = !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds;
     const unsigned g4_blocks = (unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
-    if (split) LAUNCH(K_C0_VAR, k_verify_c0_var_g32<<<(unsigned)((32 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
+    if (split && parts == 4) LAUNCH(K_C0_VAR, k_verify_c0_var_g64<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
+    else if (split) LAUNCH(K_C0_VAR, k_verify_c0_var_g32<<<(unsigned)((32 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
     else if (grouped) LAUNCH(K_C0_VAR, k_verify_c0_var_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws));
     else if (small) LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     else LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     for (int k = 1; k <= 4; k++) {
-        if (split) LAUNCH(K_ROUND, k_verify_round_g8<<<(unsigned)((8 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
+        if (split && parts == 4) LAUNCH(K_ROUND, k_verify_round_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
+        else if (split) LAUNCH(K_ROUND, k_verify_round_g8<<<(unsigned)((8 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
         else if (grouped) LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k));
         else if (c->force_pairs || (!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds))
             LAUNCH(K_ROUND, k_verify_round_g2<<<(unsigned)((2 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
@@ -398,7 +405,12 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     PMSM(job_v());
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_b_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-    PMSM(job_rcom()); PMSM(job_co()); PMSM(job_cl()); PMSM(job_cr());
+    if (fb_wave) {
+        MsmJobs js = {{job_rcom(), job_co(), job_cl(), job_cr()}};
+        PLAUNCH(K_PROVE_MSM, k_prove_msm_l64x<<<dim3(fb64_blocks, 4), BPPP_FB_BLOCK, 0, s>>>(w, js));
+    } else {
+        PMSM(job_rcom()); PMSM(job_co()); PMSM(job_cl()); PMSM(job_cr());
+    }
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_cs());
@@ -407,7 +419,12 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     PMSM(job_c0());
     for (int k = 1; k <= 4; k++) {
         PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
-        PMSM(job_x()); PMSM(job_r(k));
+        if (fb_wave) {
+            MsmJobs js = {{job_x(), job_r(k), job_x(), job_x()}};
+            PLAUNCH(K_PROVE_MSM, k_prove_msm_l64x<<<dim3(fb64_blocks, 2), BPPP_FB_BLOCK, 0, s>>>(w, js));
+        } else {
+            PMSM(job_x()); PMSM(job_r(k));
+        }
         if (!w.next_by_msm && !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
             PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
         else if (w2)

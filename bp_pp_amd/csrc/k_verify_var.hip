@@ -67,27 +67,37 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g2(VerifyWs ws, int
     for_each_position_group(key, [&]() { verify_round(ws, t, k, q, 2); });
 }
 
-// ---- calls so small that the chip is empty (at most one proof per SIMD): what a call takes is the longest dependent chain of one
-// proof, so the chains are cut further.  Window tables: a lane per table (13 points x {P, 2^65 P}: 32 lanes per proof, 26 active);
-// sums: a lane per HALF of a GLV stream (verify_core.h: straus_affine_split) -- 8 lanes per proof in a round, 32 (20 active) for C0.
+// ---- calls so small that the chip is empty (a few proofs per SIMD at most): what a call takes is the longest dependent chain of one
+// proof, so the chains are cut further.  Window tables: a lane per table (13 points x PARTS tables: P and 2^65 P, or P, 2^35 P, 2^70 P,
+// 2^100 P -- 16 PARTS lanes per proof, 13 PARTS active); sums: a lane per part of a GLV stream (verify_core.h: straus_affine_split) --
+// 4 PARTS lanes per proof in a round, 16 PARTS (10 PARTS active) for C0.  Four parts up to one proof per SIMD, two up to four per SIMD.
 #if BPPP_VWIN == 5
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables_split(VerifyWs ws) {
+template <int PARTS>
+__device__ __forceinline__ void verify_tables_split(const VerifyWs& ws) {
     const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    const size_t t = g >> 5;
-    const int p = (int)(g & 15), h = (int)((g >> 4) & 1);
-    if (t < ws.N && p < BPPP_VPOINTS) verify_table_one(ws, t, p, h, true);   // from the caller's bytes: runs beside phase 1
+    const size_t t = g / (16 * PARTS);
+    const int p = (int)(g & 15), h = (int)((g >> 4) % PARTS);
+    if (t < ws.N && p < BPPP_VPOINTS) verify_table_one(ws, t, p, h, PARTS, true);   // from the caller's bytes: runs beside phase 1
 }
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g8(VerifyWs ws, int k) {
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables_split2(VerifyWs ws) { verify_tables_split<2>(ws); }
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables_split4(VerifyWs ws) { verify_tables_split<4>(ws); }
+template <int G>
+__device__ __forceinline__ void verify_round_group(const VerifyWs& ws, int k) {
     const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    const size_t t = g >> 3;
+    const size_t t = g / G;
     if (t >= ws.N) return;                    // whole groups leave together
-    const int q = (int)(g & 7);
+    const int q = (int)(g % G);
     const u32 key = (ws.states && ws.n_states != 1) ? ws.tstate[(size_t)50 * ws.N + t] : 0u;
-    for_each_position_group(key, [&]() { verify_round(ws, t, k, q, 8); });
+    for_each_position_group(key, [&]() { verify_round(ws, t, k, q, G); });
 }
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g32(VerifyWs ws) {
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g8(VerifyWs ws, int k) { verify_round_group<8>(ws, k); }
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g16(VerifyWs ws, int k) { verify_round_group<16>(ws, k); }
+template <int G>
+__device__ __forceinline__ void verify_c0_var_group(const VerifyWs& ws) {
     const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    const size_t t = g >> 5;
-    if (t < ws.N) verify_c0_var(ws, t, (int)(g & 31), 32);
+    const size_t t = g / G;
+    if (t < ws.N) verify_c0_var(ws, t, (int)(g % G), G);
 }
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g32(VerifyWs ws) { verify_c0_var_group<32>(ws); }
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g64(VerifyWs ws) { verify_c0_var_group<64>(ws); }
 #endif

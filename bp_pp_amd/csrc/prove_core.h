@@ -64,6 +64,8 @@ struct MsmJob {             // one fixed-base MSM per proof: sum over runs of ba
     int oddsh[BPPP_FB_MAX_RUNS];    // >= 0: only the odd blocks of 2^oddsh terms are present; count = present terms
 };
 
+struct MsmJobs { MsmJob j[4]; };   // independent sums of one stage, launched together in a small call (k_prove_msm_l64x: blockIdx.y = job)
+
 HD void pw_ld_sc(sc& r, const ProveWs& w, size_t t, int slot) { ws_ld8(r.v, w.sv, w.N, t, slot); }
 HD void pw_st_sc(const ProveWs& w, size_t t, int slot, const sc& r) { ws_st8(w.sv, w.N, t, slot, r.v); }
 HD void pw_st_msc(const ProveWs& w, size_t t, int set, int base, const sc& r) { ws_st8(w.msc, w.N, t, set * BPPP_NG + base, r.v); }

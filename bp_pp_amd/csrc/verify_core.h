@@ -1014,11 +1014,16 @@ HD void verify_tables(const VerifyWs& ws, size_t t) {
 #if BPPP_VWIN == 5
 // The window table of ONE point by ONE lane -- for calls so small that the chip is empty and what counts is the length of the dependent
 // chain a proof has to wait for (a lane per table instead of a lane per proof: k_verify_tables_split).  pre_doublings > 0 first replaces
-// P by 2^pre_doublings P: the table of the HIGH half of a 26-window stream (13 windows x 5 bits = 65 doublings), so that a sum can walk
-// the two halves of every stream on two lanes (straus_affine_split).  The multiples 2P .. 16P as a Jacobian chain (one doubling, 14
+// P by 2^pre_doublings P: the table of a LATER part of a 26-window stream (part j starts at window split_begin(parts, j): 65, or 35 / 70 / 100, doublings),
+// so that a sum can walk the parts of every stream on separate lanes (straus_affine_split).  The multiples 2P .. 16P as a Jacobian chain (one doubling, 14
 // mixed additions: kP + P is never exceptional for 2 <= k <= 15 in a group of prime order), one inversion for their 15 Z's.
-#define BPPP_SPLIT_WINDOWS 13
-#define BPPP_SPLIT_DOUBLINGS (5 * BPPP_SPLIT_WINDOWS)
+// A 26-window stream in `parts` parts (2 or 4): part j covers windows split_begin(parts, j) .. split_begin(parts, j + 1) - 1 over the
+// table of 2^(5 split_begin(parts, j)) P -- 13 + 13 windows (tables of P, 2^65 P) or 7 + 7 + 6 + 6 (P, 2^35 P, 2^70 P, 2^100 P).
+#define BPPP_SPLIT_PARTS_MAX 4
+HD int split_begin(int parts, int part) {   // 26 = BPPP_VWINDOWS (defined below)
+    if (parts == 2) return part == 0 ? 0 : part == 1 ? 13 : 26;
+    return part == 0 ? 0 : part == 1 ? 7 : part == 2 ? 14 : part == 3 ? 20 : 26;
+}
 HD void affine_table_one(atab_ref tb, const apt& Pin, int pre_doublings) {
     fe beta;
     glv_beta(beta);
@@ -1095,12 +1100,12 @@ HD void verify_table_source(apt& P, const VerifyWs& ws, size_t t, int p) {
     }
     if (!ok) { fe_set_u32(P.x, 0); fe_set_u32(P.y, 0); }
 }
-// lane (point p, half h) of proof t: table slot p for the low half, BPPP_VPOINTS + p for the high half
-HD void verify_table_one(const VerifyWs& ws, size_t t, int p, int h, bool from_bytes = false) {
+// lane (point p, part h) of proof t: table slot h BPPP_VPOINTS + p
+HD void verify_table_one(const VerifyWs& ws, size_t t, int p, int h, int parts, bool from_bytes = false) {
     apt P;
     if (from_bytes) verify_table_source(P, ws, t, p);
     else ws_ld_apt(P, ws.pts, ws.N, t, p);
-    affine_table_one(atab_of(ws.atab, ws.N, t) + (h * BPPP_VPOINTS + p) * 16, P, h ? BPPP_SPLIT_DOUBLINGS : 0);
+    affine_table_one(atab_of(ws.atab, ws.N, t) + (h * BPPP_VPOINTS + p) * 16, P, 5 * split_begin(parts, h));
 }
 #endif
 #if BPPP_VWIN == 5
@@ -1357,14 +1362,15 @@ HD void straus_affine(pt& out, atab_ref tab, const int* pidx, const glv_words<M>
 }
 
 #if BPPP_VWIN == 5
-// lane q's share of the split sum (below): half h = q / 2M (windows 13 h .. 13 h + 12) of stream r = q % 2M over the table of
-// 2^(65 h) P (slot pidx + BPPP_VPOINTS h: verify_table_one); q >= 4M: nothing.  False on an exceptional addition.
+// lane q's share of the split sum (below): part h = q / 2M (windows split_begin(parts, h) .. split_begin(parts, h + 1) - 1) of stream
+// r = q % 2M over the table of 2^(5 split_begin(parts, h)) P (slot pidx + BPPP_VPOINTS h: verify_table_one); q >= 2M parts: nothing.
+// False on an exceptional addition.
 template <int M>
-HD bool straus_split_lane(pt& part, atab_ref tab, const int* pidx, const glv_words<M>& g, int q) {
+HD bool straus_split_lane(pt& part, atab_ref tab, const int* pidx, const glv_words<M>& g, int q, int parts) {
     fe beta;
     glv_beta(beta);
-    const bool have = q < 4 * M;
-    const int h = q >= 2 * M ? 1 : 0, r = q - 2 * M * h;
+    const bool have = q < 2 * M * parts;
+    const int h = have ? q / (2 * M) : 0, r = have ? q - 2 * M * h : 0;
     u32 w[5];
     bool sneg = false;
     int pn = 0;
@@ -1378,7 +1384,7 @@ HD bool straus_split_lane(pt& part, atab_ref tab, const int* pidx, const glv_wor
         pn = (st == r) ? pidx[st >> 1] : pn;
     }
     const bool img = (r & 1) != 0;
-    const int base = (pn + BPPP_VPOINTS * h) * 16, w0 = BPPP_SPLIT_WINDOWS * h;
+    const int base = (pn + BPPP_VPOINTS * h) * 16, w0 = split_begin(parts, h), nw = split_begin(parts, h + 1) - w0;   // 13, or 7 / 6, windows
     auto digit = [&](int i, int& mag, bool& neg) {
         const int b = 5 * i, l = b >> 5, sh = b & 31;
         u32 lo = 0, hi = 0;
@@ -1394,13 +1400,13 @@ HD bool straus_split_lane(pt& part, atab_ref tab, const int* pidx, const glv_wor
     int cur_mag, nxt_mag;
     bool cur_neg, nxt_neg;
     apt_packed cur_e, nxt_e;
-    digit(w0 + BPPP_SPLIT_WINDOWS - 1, cur_mag, cur_neg);
+    digit(w0 + nw - 1, cur_mag, cur_neg);
     cur_e = tab[base + (cur_mag ? cur_mag - 1 : 0)];
 #pragma nounroll
-    for (int i = BPPP_SPLIT_WINDOWS - 1; i >= 0; i--) {
+    for (int i = nw - 1; i >= 0; i--) {
         digit(w0 + (i > 0 ? i - 1 : 0), nxt_mag, nxt_neg);       // the next window's entry is requested before this window's doublings
         nxt_e = tab[base + (nxt_mag ? nxt_mag - 1 : 0)];
-        if (i != BPPP_SPLIT_WINDOWS - 1) {
+        if (i != nw - 1) {
 #pragma nounroll
             for (int d = 0; d < 5; d++) ptj_dbl(acc);
         }
@@ -1513,16 +1519,16 @@ __device__ __forceinline__ void straus_affine_g4(pt& out, atab_ref tab, const in
     lane_group_sum<G>(part);
     out = part;
 }
-// The same sum with every stream cut in two: lane q < 4M of a group of G walks half h = q / 2M (windows 13 h .. 13 h + 12) of stream
-// r = q % 2M over the table of 2^(65 h) P (slot pidx + BPPP_VPOINTS h: verify_table_one) -- 12 x 5 doublings + 13 mixed additions per
-// lane instead of 25 x 5 + 26 ... 78, then a log2(G)-step shuffle tree.  For calls that leave the chip empty (a handful of proofs): the
-// length of the chain is all that counts there.  Lanes q >= 4M of the group hold no stream and add the identity.  All G lanes of a
-// group must be active and hold the same g / pidx; every lane ends with the total.
-template <int M, int G>
+// The same sum with every stream cut in PARTS (2 or 4): lane q < 2M PARTS of a group of G walks part h = q / 2M of stream r = q % 2M
+// over the table of 2^(5 split_begin(PARTS, h)) P (slot pidx + BPPP_VPOINTS h: verify_table_one) -- 12 x 5 doublings + 13 mixed additions
+// (two parts) or at most 6 x 5 + 7 (four) per lane instead of 25 x 5 + 26 ... 78, then a log2(G)-step shuffle tree.  For calls that leave the chip empty (a handful of proofs):
+// the length of the chain is all that counts there.  The other lanes of the group hold no stream and add the identity.  All G lanes of
+// a group must be active and hold the same g / pidx; every lane ends with the total.
+template <int M, int G, int PARTS>
 __device__ __forceinline__ void straus_affine_split(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g, int q) {
-    static_assert(4 * M <= G, "a lane per half-stream");
+    static_assert(2 * M * PARTS <= G, "a lane per part of a stream");
     pt part;
-    int bad = straus_split_lane<M>(part, tab, pidx, g, q) ? 0 : 1;
+    int bad = straus_split_lane<M>(part, tab, pidx, g, q, PARTS) ? 0 : 1;
 #pragma unroll
     for (int m = 1; m < G; m <<= 1) bad |= __shfl_xor(bad, m, 64);
     if (bad) {                      // an exceptional addition somewhere in the group: every lane re-does the whole sum completely
@@ -1805,7 +1811,8 @@ HD void verify_c0_var(const VerifyWs& ws, size_t t, int group_lane = -1, int gro
     BPPP_STAMP(t, 20);
     pt acc;
 #if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
-    if (group_lane >= 0 && group_size == 32) straus_affine_split<5, 32>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
+    if (group_lane >= 0 && group_size == 64) straus_affine_split<5, 64, 4>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
+    else if (group_lane >= 0 && group_size == 32) straus_affine_split<5, 32, 2>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
     else if (group_lane >= 0) straus_affine_g4<5>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
     else
 #endif
@@ -1873,7 +1880,8 @@ HD void verify_round_on(const VerifyWs& ws, size_t t, int k, TR& tr, int group_l
     BPPP_STAMP(t, 12);
     pt acc;
 #if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
-    if (group_lane >= 0 && group_size == 8) straus_affine_split<2, 8>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
+    if (group_lane >= 0 && group_size == 16) straus_affine_split<2, 16, 4>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
+    else if (group_lane >= 0 && group_size == 8) straus_affine_split<2, 8, 2>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
     else if (group_lane >= 0 && group_size == 4) straus_affine_g4<2, 4>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
     else if (group_lane >= 0) straus_affine_g4<2, 2>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
     else

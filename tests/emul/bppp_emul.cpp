@@ -262,15 +262,15 @@ int emul_straus_affine(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64
     apt_to_xy64(out, r);
     return 0;
 }
-// the small-call path: a lane per window table (verify_table_one: P and 2^65 P) and a lane per half GLV stream (straus_split_lane);
+// the small-call path: a lane per window table (verify_table_one: P and 2^65 P, or P, 2^35 P, 2^70 P, 2^100 P) and a lane per half / quarter of a GLV stream (straus_split_lane);
 // the lanes of a group run here one after the other and their shares are added with the complete law, as the shuffle tree does.
-// tables_out (optional): the 2 x 13 x 16 table entries as 64-byte affine points (identity = zeros).
-int emul_straus_split(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64], int* fell_back, uint8_t* tables_out) {
+// tables_out (optional): the parts x 13 x 16 table entries as 64-byte affine points (identity = zeros).
+int emul_straus_split(int m, int parts, const uint8_t* P, const uint8_t* k, uint8_t out[64], int* fell_back, uint8_t* tables_out) {
     VerifyWs ws;
     memset(&ws, 0, sizeof ws);
     ws.N = 1;
     std::vector<u32> pts(208, 0);
-    std::vector<apt_packed> atab(2 * BPPP_ATAB_PER_PROOF);
+    std::vector<apt_packed> atab(BPPP_SPLIT_PARTS_MAX * BPPP_ATAB_PER_PROOF);
     ws.pts = pts.data(); ws.atab = atab.data();
     glv_words<5> g5;
     glv_words<2> g2;
@@ -287,10 +287,10 @@ int emul_straus_split(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64]
         glv_words_set<5>(g5, j, sp);
         if (j < 2) glv_words_set<2>(g2, j, sp);
     }
-    for (int h = 0; h < 2; h++)
-        for (int p = 0; p < BPPP_VPOINTS; p++) verify_table_one(ws, 0, p, h);
+    for (int h = 0; h < parts; h++)
+        for (int p = 0; p < BPPP_VPOINTS; p++) verify_table_one(ws, 0, p, h, parts);
     if (tables_out)
-        for (int i = 0; i < 2 * BPPP_VPOINTS * 16; i++) {
+        for (int i = 0; i < parts * BPPP_VPOINTS * 16; i++) {
             apt e;
             bool id;
             apt_unpack(e, id, atab[i]);
@@ -302,10 +302,10 @@ int emul_straus_split(int m, const uint8_t* P, const uint8_t* k, uint8_t out[64]
     pt total, viafb;
     pt_set_identity(total);
     bool ok = true;
-    const int lanes = m <= 2 ? 8 : 32;
+    const int lanes = (m <= 2 ? 4 : 16) * parts;
     for (int q = 0; q < lanes; q++) {
         pt part;
-        ok &= (m <= 2) ? straus_split_lane<2>(part, tabv, pidx, g2, q) : straus_split_lane<5>(part, tabv, pidx, g5, q);
+        ok &= (m <= 2) ? straus_split_lane<2>(part, tabv, pidx, g2, q, parts) : straus_split_lane<5>(part, tabv, pidx, g5, q, parts);
         pt_add(total, total, part);
     }
     *fell_back = !ok;

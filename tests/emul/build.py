@@ -56,7 +56,7 @@ def load():
     L.emul_set_rlc_superchunk.restype = None
     L.emul_group_verify.argtypes = [i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, cp, sz, sz, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.emul_group_prove.argtypes = [i32, i32, vp, i32, cp, sz, sz, vp, vp, vp, vp, vp, vp]
-    L.emul_straus_split.argtypes = [i32, cp, cp, vp, vp, vp]
+    L.emul_straus_split.argtypes = [i32, i32, cp, cp, vp, vp, vp]
     L.emul_set_prove_next_by_msm.argtypes = [i32]
     L.emul_set_prove_next_by_msm.restype = None
     return L

@@ -167,30 +167,35 @@ def test_affine_tables_and_jacobian_straus(L):
         assert fb.value == 1
 
 
-def test_per_lane_tables_and_half_stream_sums(L):
+@pytest.mark.parametrize("parts", [2, 4])
+def test_per_lane_tables_and_half_stream_sums(L, parts):
     """The small-call path of the u64 verifier (verify_core.h: affine_table_one, straus_split_lane): a lane builds ONE window table
-    -- of P, or of 2^65 P for the high half of a stream -- and a lane walks HALF a GLV stream; the lanes' shares added up must be
-    sum k_j P_j, and every table entry must be the oracle's multiple.  Identity points, special scalars, exceptional additions."""
-    rnd = random.Random(31)
+    -- of P, or of 2^65 P (two parts per stream) / 2^35 P, 2^70 P, 2^100 P (four parts) for the later parts of a stream -- and a
+    lane walks ONE part of a GLV stream; the lanes' shares added up must be sum k_j P_j, and every table entry must be the oracle's
+    multiple.  Identity points, special scalars, exceptional additions."""
+    rnd = random.Random(31 + parts)
+    starts = (0, 13) if parts == 2 else (0, 7, 14, 20)
     pts = [None, O.G, O.pt_neg(O.G)] + [O.pt_mul(O.G, rnd.getrandbits(256)) for _ in range(6)]
     out, fb = C.create_string_buffer(64), C.c_int(0)
-    tabs = C.create_string_buffer(2 * 13 * 16 * 64)
-    special = [0, 1, O.N - 1, O.LAMBDA, 2**255, 16, O.N - 16, 2**65, 2**65 - 1, (1 << 130) - 1, int("8" * 64, 16) % O.N]
+    tabs = C.create_string_buffer(4 * 13 * 16 * 64)
+    special = [0, 1, O.N - 1, O.LAMBDA, 2**255, 16, O.N - 16, 2**35, 2**35 - 1, 2**65, 2**65 - 1, 2**70, 2**100 - 1, (1 << 130) - 1,
+               int("8" * 64, 16) % O.N]
     n_fast = 0
     for m in (1, 2, 5):
         for it in range(8):
             P = [pts[rnd.randrange(len(pts))] for _ in range(m)]
             ks = [rnd.choice(special + [rnd.getrandbits(256) % O.N] * 8) for _ in range(m)]
-            assert L.emul_straus_split(m, b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out, C.byref(fb), tabs if it == 0 else None) == 0
+            assert L.emul_straus_split(m, parts, b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out, C.byref(fb),
+                                       tabs if it == 0 else None) == 0
             exp = None
             for p, k in zip(P, ks):
                 exp = O.pt_add(exp, O.pt_mul(p, k))
             assert out.raw == O.pt_to_xy64(exp)
             n_fast += 1 - fb.value
             if it == 0:
-                for h in range(2):
+                for h in range(parts):
                     for j in range(13):
-                        base = O.pt_mul(P[j], 2**(65 * h)) if j < m else None
+                        base = O.pt_mul(P[j], 2**(5 * starts[h])) if j < m else None
                         for e in range(16):
                             got = tabs.raw[64 * ((13 * h + j) * 16 + e):][:64]
                             assert got == O.pt_to_xy64(O.pt_mul(base, e + 1)), (m, h, j, e)
@@ -198,12 +203,12 @@ def test_per_lane_tables_and_half_stream_sums(L):
     for m in (2, 5):
         P = [O.pt_mul(O.G, rnd.getrandbits(256)) for _ in range(m)]
         ks = [rnd.getrandbits(256) % O.N for _ in range(m)]
-        assert L.emul_straus_split(m, b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out, C.byref(fb), None) == 0
+        assert L.emul_straus_split(m, parts, b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out, C.byref(fb), None) == 0
         assert fb.value == 0
-    # an exceptional addition inside one lane's half stream (a table entry added to its own value) is flagged, the result still right
+    # an exceptional addition inside one lane's part of a stream (a table entry added to its own value) is flagged, the result still right
     A = O.pt_mul(O.G, 0xABCDEF)
     for P, ks in (([A, O.pt_neg(A)], [77, 77]), ([A], [33 * 32 + 1])):
-        assert L.emul_straus_split(len(P), b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out, C.byref(fb), None) == 0
+        assert L.emul_straus_split(len(P), parts, b"".join(map(O.pt_to_xy64, P)), b"".join(map(b32, ks)), out, C.byref(fb), None) == 0
         exp = None
         for p, k in zip(P, ks):
             exp = O.pt_add(exp, O.pt_mul(p, k))
