@@ -335,6 +335,28 @@ def run_verify(args):
             proto.set_option("host_chunk", 1 << 17)
             host_path["full_batch"] = dict(full, proofs=n, unit="verifies/s")
             del Vh, Ph
+    call_latency = None
+    if world == 1 and not args.no_secondary:
+        # one call of a few proofs, host buffers in and out (the reference's own usage is one verify / prove at a time: BASELINE
+        # configs[0], benches/range_proof.rs): what a caller waits for, not a throughput
+        call_latency = {"unit": "ms per call, host buffers", "note": "bppp_u64_verify_batch / bppp_u64_prove_batch on n proofs, median of 7 calls; "
+                        "the reference's bench on an M3 Pro core: 3.808 ms per verify, 14.361 ms per prove (BASELINE.md)"}
+        xs, ss, rs = workload.bulk_values(1024), workload.bulk_blindings(1024), workload.bulk_prover_randomness(1024)
+        for m in (1, 64, 1024):
+            Vm, Pm = dV[:m].cpu().numpy(), dP[:m].cpu().numpy()
+            tv, tp, okm = [], [], True
+            for it in range(8):
+                t0 = time.perf_counter()
+                a_m, _ = proto.verify_batch(Vm, Pm, workload.LABEL)
+                tv.append(time.perf_counter() - t0)
+                okm &= bool((a_m == expect[:m]).all())
+                t0 = time.perf_counter()
+                pp, cc, st_m = proto.prove_batch(xs[:m], ss[:m], rs[:m], workload.LABEL)
+                tp.append(time.perf_counter() - t0)
+                okm &= not bool(st_m.any())
+            a_m, _ = proto.verify_batch(cc, pp, workload.LABEL)          # what the small prove calls made verifies
+            okm &= bool(a_m.all())
+            call_latency[f"n{m}"] = {"verify_ms": float(np.median(tv[1:]) * 1e3), "prove_ms": float(np.median(tp[1:]) * 1e3), "ok": okm}
     if not args.no_secondary:
         dA2 = torch.zeros(n, dtype=torch.uint8, device="cuda")
         dR2 = torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -449,6 +471,7 @@ def run_verify(args):
             "configs1_2pow16": cfg1,
             "rlc_mode": rlc,
             "host_buffer_path": host_path,
+            "call_latency": call_latency,
             "prove_2pow14": prove14,
             "recip256_2pow15": recip15,
             "setup_s": {"context_tables": t_ctx, "inputs_and_gpu_batch_prove": t_setup, "gpu_batch_prove_only": t_prove},

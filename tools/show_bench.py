@@ -15,6 +15,8 @@ def show(l):
             print(f"  {k}:", round(v["value"]), v.get("unit"), {a: b for a, b in v.items() if a in ("ms_per_step", "ms_per_batch", "cores", "accept_bits_ok", "accept_bits_equal_exact_mode", "agrees_with_gpu")})
             if isinstance(v.get("all_valid"), dict):
                 print(f"    {k}.all_valid:", round(v["all_valid"]["value"]), round(v["all_valid"]["ms_per_step"], 2), v["all_valid"].get("all_accepted"))
+    if d.get("call_latency"):
+        print("  call_latency:", {k: v for k, v in d["call_latency"].items() if k.startswith("n")})
     print("  setup:", d.get("setup_s"), " device GB", round((d.get("device_bytes") or 0) / 1e9, 1))
 files = sys.argv[1:]
 if files:
