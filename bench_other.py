@@ -90,7 +90,7 @@ def measure_prove(args, proto, gens, total, cpu_baseline=True, cpu_sample=4096, 
                      "traffic": bench.pmc_traffic(dom, n), "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_launch": bench.ALGO_BYTES_PER_PROVE * n,
                      "note": "2262 B/prove (SURVEY.md 8d) per launch of the dominant kernel; that kernel runs launches_per_step times per proof "
-                             "batch (15 fixed-base MSMs per proof), so the per-step figure is value x 2262 B"},
+                             "batch (15 fixed-base MSMs per proof; the independent ones of a stage go out as one launch), so the per-step figure is value x 2262 B"},
         "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kt.items()},
         "proofs_verify": ok,
     }

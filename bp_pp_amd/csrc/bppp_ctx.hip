@@ -20,6 +20,7 @@ static void read_diagnostics(bppp_ctx* c) {
     if (const char* e = std::getenv("BPPP_FB_ONE_LANE")) c->fb_one_lane_mode = e[0] == '0' ? 0 : 1;
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // projective tables + complete additions
     c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
+    c->prove_separate_sums = std::getenv("BPPP_PROVE_SEPARATE_SUMS") != nullptr;  // one launch per prover MSM (A/B of the fused launches)
     c->prove_uncapped = std::getenv("BPPP_PROVE_UNCAPPED") != nullptr;            // the prover's lane kernels without the 256-register cap at every size
 }
 

@@ -405,12 +405,17 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     PMSM(job_v());
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_b_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-    if (fb_wave) {
-        MsmJobs js = {{job_rcom(), job_co(), job_cl(), job_cr()}};
-        PLAUNCH(K_PROVE_MSM, k_prove_msm_l64x<<<dim3(fb64_blocks, 4), BPPP_FB_BLOCK, 0, s>>>(w, js));
-    } else {
-        PMSM(job_rcom()); PMSM(job_co()); PMSM(job_cl()); PMSM(job_cr());
-    }
+    // the independent sums of a stage go out as ONE launch (blockIdx.y = job): no gap between them, and the short ones (c_o: 84 table
+    // additions per proof) fill in beside the long ones
+#define PMSMX(NJ, ...)                                                                                                     \
+    do {                                                                                                                    \
+        MsmJobs js = {{__VA_ARGS__}};                                                                                        \
+        if (c->prove_separate_sums) { for (int q_ = 0; q_ < NJ; q_++) PMSM(js.j[q_]); }                                      \
+        else if (fb_wave) PLAUNCH(K_PROVE_MSM, k_prove_msm_l64x<<<dim3(fb64_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));     \
+        else if (fb_one_lane) PLAUNCH(K_PROVE_MSM, k_prove_msm_l1x<<<dim3(fb1_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));   \
+        else PLAUNCH(K_PROVE_MSM, k_prove_msm_x<<<dim3(fb_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));                       \
+    } while (0)
+    PMSMX(4, job_rcom(), job_co(), job_cl(), job_cr());
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_cs());
@@ -419,12 +424,7 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     PMSM(job_c0());
     for (int k = 1; k <= 4; k++) {
         PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
-        if (fb_wave) {
-            MsmJobs js = {{job_x(), job_r(k), job_x(), job_x()}};
-            PLAUNCH(K_PROVE_MSM, k_prove_msm_l64x<<<dim3(fb64_blocks, 2), BPPP_FB_BLOCK, 0, s>>>(w, js));
-        } else {
-            PMSM(job_x()); PMSM(job_r(k));
-        }
+        PMSMX(2, job_x(), job_r(k), job_x(), job_x());
         if (!w.next_by_msm && !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
             PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
         else if (w2)
@@ -434,6 +434,7 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
         if (w.next_by_msm && k < 4) PMSM(job_cnext());
     }
     if (w.states_out) k_prove_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+#undef PMSMX
 #undef PMSM
 #undef PLAUNCH
     HIP_TRY(hipGetLastError());
