@@ -31,6 +31,7 @@ EXPORTS = [
     "bppp_u64_verify_batch_transcript_sharded_device", "bppp_reciprocal_verify_batch_sharded", "bppp_reciprocal_verify_batch_rlc_sharded",
     "bppp_reciprocal_verify_batch_sharded_device", "bppp_reciprocal_verify_batch_rlc_sharded_device",
     "bppp_u64_prove_batch_sharded", "bppp_u64_prove_batch_sharded_device",
+    "bppp_u64_prove_batch_sec1", "bppp_u64_prove_batch_sec1_device",
 ]
 
 _lib = None
@@ -152,6 +153,8 @@ def lib():
     L.bppp_u64_verify_batch_sec1_sharded_device.argtypes = [vp, u8p, sz, sz, pvp, pvp, pvp, pvp, pvp]
     L.bppp_u64_verify_batch_transcript_sharded.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp, vp, C.POINTER(C.c_int32)]
     L.bppp_u64_verify_batch_transcript_sharded_device.argtypes = [vp, sz, pvp, sz, pvp, pvp, pvp, pvp, pvp, pvp]
+    L.bppp_u64_prove_batch_sec1.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, vp, vp]
+    L.bppp_u64_prove_batch_sec1_device.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, vp, vp]
     L.bppp_u64_prove_batch_sharded.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, vp, vp]
     L.bppp_u64_prove_batch_sharded_device.argtypes = [vp, u8p, sz, sz, pvp, pvp, pvp, pvp, pvp, pvp]
     L.bppp_reciprocal_verify_batch_sharded.argtypes = [vp, u8p, sz, sz, sz, sz, vp, vp, sz, sz, sz, vp, vp, C.POINTER(C.c_int32)]

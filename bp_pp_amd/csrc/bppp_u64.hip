@@ -555,4 +555,54 @@ int bppp_u64_verify_batch_sec1(bppp_ctx* c, const uint8_t* label, size_t label_l
     return rc;
 }
 
+// ---- the prover's output in the wire format (33-byte commitments, 525-byte proofs): proved into the context's 64-byte staging
+//      (the buffer the SEC1 verify entry points expand into), compressed on the device
+int bppp_u64_prove_batch_sec1_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s,
+                                     const void* d_rnd, void* d_proofs525, void* d_commitments33, void* d_status) {
+    CtxLock lock_(c);
+    if (!c || !d_proofs525 || !d_commitments33) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t need = n * (64 + (size_t)BPPP_U64_PROOF_BYTES);
+    if (need > c->expand_bytes) {
+        if (c->d_expand) { (void)hipFree(c->d_expand); c->d_expand = nullptr; c->expand_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->d_expand, need));
+        c->expand_bytes = need;
+    }
+    uint8_t* d_c64 = c->d_expand;
+    uint8_t* d_p928 = c->d_expand + n * 64;
+    int rc = prove_device_impl(c, label, label_len, n, d_x, d_s, d_rnd, d_p928, d_c64, d_status, nullptr);
+    if (rc != BPPP_OK) return rc;
+    k_sec1_compress<<<(unsigned)((n * 16 + 255) / 256), 256, 0, c->stream>>>((uint8_t*)d_commitments33, (uint8_t*)d_proofs525, d_c64, d_p928, n);
+    HIP_TRY(hipGetLastError());
+    return BPPP_OK;
+}
+int bppp_u64_prove_batch_sec1(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x, const uint8_t* s,
+                              const uint8_t* rnd, uint8_t* proofs525, uint8_t* commitments33, int32_t* status) {
+    CtxLock lock_(c);
+    if (!c || !x || !s || !rnd || !proofs525 || !commitments33) return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    uint8_t* d = nullptr;
+    const size_t o_x = 0, o_s = o_x + n * 8, o_r = o_s + n * 32, o_p = o_r + n * 52 * 32, o_c = o_p + n * (size_t)BPPP_U64_PROOF_SEC1_BYTES,
+                 o_st = (o_c + n * 33 + 3) / 4 * 4, total = o_st + n * sizeof(int32_t);
+    HIP_TRY(hipMalloc(&d, total));
+    int rc = BPPP_OK;
+    hipError_t e = hipMemcpyAsync(d + o_x, x, n * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_s, s, n * 32, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + o_r, rnd, n * 52 * 32, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        rc = bppp_u64_prove_batch_sec1_device(c, label, label_len, n, d + o_x, d + o_s, d + o_r, d + o_p, d + o_c, d + o_st);
+        if (rc == BPPP_OK) {
+            e = hipMemcpyAsync(proofs525, d + o_p, n * (size_t)BPPP_U64_PROOF_SEC1_BYTES, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(commitments33, d + o_c, n * 33, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess && status) e = hipMemcpyAsync(status, d + o_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
+    (void)hipFree(d);
+    if (e != hipSuccess) { g_last_error = std::string("prove_batch_sec1: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
+    return rc;
+}
+
 }  // extern "C"

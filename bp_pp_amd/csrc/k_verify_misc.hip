@@ -58,6 +58,14 @@ __global__ __launch_bounds__(256) void k_sec1_expand(uint8_t* commitments64, uin
     int j = (int)(g % 16);
     if (t < n && j < 15) sec1_expand_lane(commitments64, proofs928, commitments33, proofs525, t, j);
 }
+// the prover's output in the wire format: 16 lanes per proof, 64-byte form -> SEC1 compressed
+__global__ __launch_bounds__(256) void k_sec1_compress(uint8_t* commitments33, uint8_t* proofs525, const uint8_t* commitments64,
+                                                       const uint8_t* proofs928, size_t n) {
+    size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    size_t t = g / 16;
+    int j = (int)(g % 16);
+    if (t < n && j < 15) sec1_compress_lane(commitments33, proofs525, commitments64, proofs928, t, j);
+}
 // pre-loaded transcript variant: each proof's advanced STROBE state back to the caller (203 bytes per proof)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_export_states(VerifyWs ws) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;

@@ -112,6 +112,8 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass2(bppp::FbBuild fb,
 __global__ void k_decode_generators(const uint8_t* in, bppp::apt* out, int n, int* flags);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(bppp::VerifyWs ws, const uint64_t* x, const uint8_t* s, uint8_t* out, int* flags);
 __global__ __launch_bounds__(256) void k_sec1_expand(uint8_t* commitments64, uint8_t* proofs928, const uint8_t* commitments33, const uint8_t* proofs525, size_t n);
+__global__ __launch_bounds__(256) void k_sec1_compress(uint8_t* commitments33, uint8_t* proofs525, const uint8_t* commitments64,
+                                                       const uint8_t* proofs928, size_t n);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_a(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_b(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d(bppp::ProveWs w);

@@ -2077,6 +2077,26 @@ HD void sec1_expand_lane(uint8_t* commitments64, uint8_t* proofs928, const uint8
     }
 }
 
+// the other direction (the prover's output as the crate serialises it: GroupEncoding / serde of SerializableProof, wnla.rs:33-61,
+// circuit.rs:36-76): lane j of proof t: j = 0 commitment, 1..13 proof points, 14 copies the three scalars.  The 64-byte points are the
+// library's own output (canonical, on the curve): tag 02 / 03 by the parity of y, the identity (64 zero bytes) -> 33 zero bytes.
+HD void sec1_compress_lane(uint8_t* commitments33, uint8_t* proofs525, const uint8_t* commitments64, const uint8_t* proofs928, size_t t, int j) {
+    if (j <= 13) {
+        const uint8_t* in = j == 0 ? commitments64 + 64 * t : proofs928 + (size_t)BPPP_U64_PROOF_BYTES * t + 64 * (j - 1);
+        uint8_t* out = j == 0 ? commitments33 + 33 * t : proofs525 + (size_t)BPPP_U64_PROOF_SEC1_BYTES * t + 33 * (j - 1);
+        uint8_t any = 0;
+#pragma nounroll
+        for (int i = 0; i < 64; i++) any |= in[i];
+        out[0] = any ? (uint8_t)(2 + (in[63] & 1)) : 0;
+#pragma nounroll
+        for (int i = 0; i < 32; i++) out[1 + i] = in[i];
+    } else if (j == 14) {
+#pragma nounroll
+        for (int i = 0; i < 96; i++)
+            proofs525[(size_t)BPPP_U64_PROOF_SEC1_BYTES * t + 429 + i] = proofs928[(size_t)BPPP_U64_PROOF_BYTES * t + 832 + i];
+    }
+}
+
 // ---------------------------------------------------------------- fixed-base table construction (context creation)
 // Pass 1: thread (b, w, chunk c) writes projective d * 2^(W w) * G_b for d in (c*CH, (c+1)*CH] into X/Y (table slots) and Z (ztmp).
 // Pass 2: same thread batch-inverts its Z's (Montgomery trick) and normalises the slots to affine.

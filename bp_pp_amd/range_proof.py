@@ -209,6 +209,18 @@ class U64RangeProofProtocol:
                                                      rnd.ctypes.data, proofs.ctypes.data, com.ctypes.data, status.ctypes.data))
         return proofs, com, status
 
+    def prove_batch_sec1(self, x: np.ndarray, s, rnd, label: bytes):
+        """prove_batch with the output in the crate's wire format: (proofs [n, 525], commitments [n, 33], status [n]) -- SEC1-compressed
+        points, what verify_batch_sec1 takes."""
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        n = x.shape[0]
+        s, rnd = _as_u8(s, (n, 32)), _as_u8(rnd, (n, 52 * 32))
+        proofs, com = np.zeros((n, 525), dtype=np.uint8), np.zeros((n, 33), dtype=np.uint8)
+        status = np.zeros(n, dtype=np.int32)
+        _capi.check(_capi.lib().bppp_u64_prove_batch_sec1(self._ctx, label, len(label), n, x.ctypes.data, s.ctypes.data, rnd.ctypes.data,
+                                                          proofs.ctypes.data, com.ctypes.data, status.ctypes.data))
+        return proofs, com, status
+
     def prove_batch_transcript(self, x: np.ndarray, s, rnd, transcripts, want_states: bool = True):
         """prove with the caller's transcripts (u64_proof.rs:57: `t: &mut Transcript`): ONE serialized state shared by the batch
         or a sequence of n.  Returns (proofs, commitments, status, states_out [n, 203] or None)."""

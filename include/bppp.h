@@ -156,6 +156,15 @@ BPPP_API int bppp_u64_prove_batch(bppp_ctx* ctx, const uint8_t* label, size_t la
 BPPP_API int bppp_u64_prove_batch_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, const void* d_x,
                                          const void* d_s, const void* d_rnd, void* d_proofs, void* d_commitments, void* d_status);
 
+/* The same with the output in the crate's wire format -- what serde gives for SerializableProof (wnla.rs:33-61, circuit.rs:36-76,
+ * reciprocal.rs:37-59) and what bppp_u64_verify_batch_sec1 takes: 13 SEC1-compressed points + 3 scalars = 525 bytes per proof,
+ * 33-byte commitments (the identity as 33 zero bytes).  Compressed on the device. */
+BPPP_API int bppp_u64_prove_batch_sec1(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x,
+                                       const uint8_t* s /* n x 32 */, const uint8_t* rnd /* n x 52 x 32 */,
+                                       uint8_t* proofs525 /* n x 525 */, uint8_t* commitments33 /* n x 33 */, int32_t* status /* n or NULL */);
+BPPP_API int bppp_u64_prove_batch_sec1_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, const void* d_x,
+                                              const void* d_s, const void* d_rnd, void* d_proofs525, void* d_commitments33, void* d_status);
+
 /* U64RangeProofProtocol::commit_value (u64_proof.rs:37-39): out[i] = x[i]*g + s[i]*h_vec[0], host pointers. */
 BPPP_API int bppp_u64_commit_value_batch(bppp_ctx* ctx, size_t n, const uint64_t* x, const uint8_t* s /* n x 32 */,
                                 uint8_t* out /* n x 64 */);

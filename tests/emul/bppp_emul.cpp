@@ -525,6 +525,11 @@ static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label
 }
 // the small-call form of the u64 prover: next commitments as fixed-base sums (prove_core.h: ProveWs::next_by_msm)
 void emul_set_prove_next_by_msm(int on) { g_prove_next_by_msm = on; }
+// wire format, the other way: the prover's 64-byte output -> SEC1 compressed, lane by lane
+void emul_sec1_compress(size_t n, const uint8_t* c64, const uint8_t* p928, uint8_t* c33, uint8_t* p525) {
+    for (size_t t = 0; t < n; t++)
+        for (int j = 0; j < 15; j++) sec1_compress_lane(c33, p525, c64, p928, t, j);
+}
 // wire format: SEC1 compressed inputs -> 64-byte form, lane by lane
 void emul_sec1_expand(size_t n, const uint8_t* c33, const uint8_t* p525, uint8_t* c64, uint8_t* p928) {
     for (size_t t = 0; t < n; t++)

@@ -46,6 +46,8 @@ def load():
     L.emul_set_generic_slow_rounds.argtypes = [i32]
     L.emul_set_generic_slow_rounds.restype = None
     L.emul_sec1_expand.argtypes = [sz, vp, vp, vp, vp]
+    L.emul_sec1_compress.argtypes = [sz, vp, vp, vp, vp]
+    L.emul_sec1_compress.restype = None
     L.emul_wnla_run.argtypes = [i32, vp, i32, i32, i32, cp, sz, sz, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp]
     L.emul_recip_verify.argtypes = [vp, i32, i32, i32, i32, i32, cp, sz, sz, vp, vp, i32, i32, i32, vp, vp]
     L.emul_circuit_verify.argtypes = [vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, cp, sz, sz, vp, vp, i32, i32, i32, vp, vp, vp, vp]

@@ -67,6 +67,23 @@ def test_batch_prove_vs_oracle(proto, oracle_c, n):
     assert oacc.all() and not ost.any()
 
 
+@pytest.mark.parametrize("n", [1, 300, 5000])
+def test_prover_output_in_the_wire_format(proto, n):
+    """bppp_u64_prove_batch_sec1: the same proofs as bppp_u64_prove_batch, SEC1-compressed on the device (what serde gives for
+    SerializableProof, circuit.rs:36-76) -- equal to the wire module's host-side compression, and accepted by the SEC1 verifier."""
+    import workload
+    from bp_pp_amd import wire
+    first = 9100
+    x, s, rnd = workload.values(n, first), workload.blindings(n, first), workload.prover_randomness(n, first)
+    p525, c33, st = proto.prove_batch_sec1(x, s, rnd, workload.LABEL)
+    proofs, com, st0 = proto.prove_batch(x, s, rnd, workload.LABEL)
+    assert not st.any() and not st0.any()
+    for i in range(0, n, max(1, n // 50)):
+        assert bytes(p525[i]) == wire.abi_to_sec1(bytes(proofs[i])) and bytes(c33[i]) == wire.compress_point(bytes(com[i])), i
+    acc, vst = proto.verify_batch_sec1(c33, p525, workload.LABEL)
+    assert acc.all() and not vst.any()
+
+
 def test_non_canonical_prover_input_is_flagged(proto):
     import workload
     x, s, rnd = workload.values(2, 9), workload.blindings(2, 9).copy(), workload.prover_randomness(2, 9).copy()

@@ -93,6 +93,29 @@ def test_device_decompression_code(gold):
     assert bytes(C64[64 * (n - 1):64 * n]) == sentinel
 
 
+def test_device_compression_equals_the_wire_module(gold):
+    """The prover's output in the wire format (bppp_u64_prove_batch_sec1: sec1_compress_lane on the device code): equal to
+    bp_pp_amd.wire's host-side compression for every golden proof, for a proof with identity points, and back again through the
+    expansion the SEC1 verifier uses."""
+    from emul.build import load
+    L = load()
+    abi = [bytes.fromhex(c["proof"]) for c in gold["cases"]]
+    com = [bytes.fromhex(c["commitment"]) for c in gold["cases"]]
+    idp = bytearray(abi[0]); idp[64 * 5:64 * 6] = bytes(64); idp[64 * 12:64 * 13] = bytes(64)
+    abi.append(bytes(idp)); com.append(bytes(64))
+    n = len(abi)
+    C64 = np.frombuffer(b"".join(com), np.uint8).copy()
+    P928 = np.frombuffer(b"".join(abi), np.uint8).copy()
+    C33, P525 = np.zeros(n * 33, np.uint8), np.zeros(n * 525, np.uint8)
+    L.emul_sec1_compress(n, C64.ctypes.data, P928.ctypes.data, C33.ctypes.data, P525.ctypes.data)
+    for i in range(n):
+        assert bytes(P525[525 * i:525 * i + 525]) == wire.abi_to_sec1(abi[i]), i
+        assert bytes(C33[33 * i:33 * i + 33]) == wire.compress_point(com[i]), i
+    B64, B928 = np.zeros(n * 64, np.uint8), np.zeros(n * 928, np.uint8)
+    L.emul_sec1_expand(n, C33.ctypes.data, P525.ctypes.data, B64.ctypes.data, B928.ctypes.data)
+    assert (B64 == C64).all() and (B928 == P928).all()
+
+
 def test_identity_in_json_is_00(gold):
     """serde writes the identity AffinePoint as the one SEC1 byte 0x00 ("00"), not as 33 zero bytes."""
     abi = bytearray(bytes.fromhex(gold["cases"][0]["proof"]))
