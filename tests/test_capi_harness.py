@@ -64,6 +64,7 @@ def test_c_caller_gets_the_fixture_verdicts(harness, fixture_file, wbits):
     assert out["null_ctx_rc"] == "-2" and out["empty_rc"] == "0"
     assert out["verify"] == ones and out["status"].split() == ["0"] * n
     assert out["prove_same_proofs"] == "1" and out["prove_same_commitments"] == "1"
+    assert out["sec1_same_x"] == "1" and out["verify_sec1"] == ones
     assert out["verify_transcript"] == ones and out["verify_other_transcript"] == "0" * n
     assert out["verify_flipped"] == out["verify_clone"] == out["verify_group"] == alt
     assert out["shard_range"] == "0 %d" % n and out["group_size"] == "1" and out["reject_count"] == str((n + 1) // 2)

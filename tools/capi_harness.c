@@ -102,6 +102,19 @@ int main(int argc, char** argv) {
     printf("prove_same_proofs %d\n", memcmp(P2, P, n * BPPP_U64_PROOF_BYTES) == 0);
     printf("prove_same_commitments %d\n", memcmp(V2, V, n * BPPP_POINT_BYTES) == 0);
 
+    /* the same proofs in the crate's wire format (SEC1-compressed points), straight back into the SEC1 verifier */
+    {
+        uint8_t* P525 = malloc(n * BPPP_U64_PROOF_SEC1_BYTES);
+        uint8_t* V33 = malloc(n * 33);
+        if (!P525 || !V33) return 4;
+        CHECK(bppp_u64_prove_batch_sec1(ctx, label, label_len, n, x, s, rnd, P525, V33, status));
+        printf("sec1_same_x %d\n", memcmp(P525 + 1, P, 32) == 0 && memcmp(V33 + 1, V, 32) == 0 && (P525[0] == 2 || P525[0] == 3));
+        CHECK(bppp_u64_verify_batch_sec1(ctx, label, label_len, n, V33, P525, accept, status));
+        print_bits("verify_sec1", accept, n);
+        free(P525);
+        free(V33);
+    }
+
     /* the caller's own transcript: Transcript::new(label) by hand gives the same verdicts; one with extra context does not */
     CHECK(bppp_transcript_new(label, label_len, st0));
     CHECK(bppp_u64_verify_batch_transcript(ctx, n, st0, 1, V, P, accept, status, states_out));
