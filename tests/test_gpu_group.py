@@ -345,3 +345,53 @@ def test_damaged_table_file_is_refused(batch, tmp_path):
             U64RangeProofProtocol.from_tables(path, device=0)
     finally:
         a.close()
+
+
+def test_concurrent_callers_on_shared_contexts(batch):
+    """Several host threads, each with its own context over ONE set of tables (bppp_ctx_create_shared), verifying and proving small
+    batches at the same time -- the way a service with a thread per request would call the library (the reference's verify is a
+    plain function: callers parallelise it freely).  Every call's result must equal the single-threaded one; a context is also hit
+    from two threads at once (its lock serialises them)."""
+    import threading
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    gens, V, P, expect = batch
+    g, gv, hv = workload.split_generators(gens)
+    base = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
+    clones = [base.clone_shared() for _ in range(3)]
+    ctxs = [base] + clones
+    n = V.shape[0]
+    x, s, rnd = workload.values(64, 4200), workload.blindings(64, 4200), workload.prover_randomness(64, 4200)
+    ref_p, ref_v, _ = base.prove_batch(x, s, rnd, workload.LABEL)
+    errors = []
+
+    def worker(tid):
+        try:
+            ctx = ctxs[tid % len(ctxs)]                      # threads 4, 5 share contexts 0, 1 with threads 0, 1
+            rng = np.random.default_rng(tid)
+            for it in range(25):
+                lo = int(rng.integers(0, n - 1))
+                m = int(rng.integers(1, min(64, n - lo) + 1))
+                acc, st = ctx.verify_batch(V[lo:lo + m], P[lo:lo + m], workload.LABEL)
+                if acc.tolist() != expect[lo:lo + m].tolist():
+                    errors.append((tid, it, "verify"))
+                if it % 5 == 0:
+                    k = int(rng.integers(1, 17))
+                    pp, vv, pst = ctx.prove_batch(x[:k], s[:k], rnd[:k], workload.LABEL)
+                    if pst.any() or not (pp == ref_p[:k]).all() or not (vv == ref_v[:k]).all():
+                        errors.append((tid, it, "prove"))
+        except Exception as e:                               # noqa: BLE001 -- reported below
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    try:
+        assert not any(t.is_alive() for t in threads), "a caller is stuck"
+        assert not errors, errors[:5]
+    finally:
+        for c in clones:
+            c.close()
+        base.close()

@@ -1,0 +1,32 @@
+"""Latency of one call of the generic entry points (WeightNormLinearArgument N = 4: tests.rs:139-171; ReciprocalRangeProofProtocol
+with the u64 shape dim_nd = dim_np = 16) -- for comparison with the u64-specialised path.  usage: python tools/latency_generic.py"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np
+import wnla_cases, recip_cases
+from bp_pp_amd.wnla import WeightNormLinearArgument, ReciprocalRangeProofProtocol
+
+def med(f, reps=9):
+    f(); ts = []
+    for _ in range(reps):
+        t = time.perf_counter(); f(); ts.append(time.perf_counter() - t)
+    return float(np.median(ts)) * 1e3
+
+for ng, nh in ((4, 4), (16, 32)):
+    for B in (1, 64):
+        case = wnla_cases.make(ng, nh, B)
+        w = WeightNormLinearArgument(case["g"], case["gv"], case["hv"], device=0, fb_window_bits=16)
+        args = dict(commitments=case["commitments"], c=case["c"], rho=case["rho"], mu=case["mu"], proof_r=case["proof_r"],
+                    proof_x=case["proof_x"], proof_l=case["proof_l"], proof_n=case["proof_n"])
+        tv = med(lambda: w.verify_batch(case["label"], **args))
+        tp = med(lambda: w.prove_batch(case["label"], case["commitments"], case["c"], case["rho"], case["mu"], case["l"], case["n"]))
+        print(f"wnla ng {ng} nh {nh} rounds {case['rounds']}  B {B:3d}  verify {tv:7.3f} ms  prove {tp:7.3f} ms")
+        w.close()
+for B in (1, 64):
+    case = recip_cases.make(16, 16, B=B)
+    r = ReciprocalRangeProofProtocol(16, 16, case["g"], case["gv"], case["hv"], case["gv_"], case["hv_"], device=0, fb_window_bits=16)
+    tv = med(lambda: r.verify_batch(case["label"], case["commitments"], case["proofs"], case["rounds"], case["nl"], case["nn"]))
+    print(f"reciprocal (16, 16)  B {B:3d}  verify {tv:7.3f} ms")
+    r.close()
