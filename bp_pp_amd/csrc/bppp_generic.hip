@@ -313,12 +313,21 @@ static int recip_verify_check_args(const bppp_ctx* c, size_t dim_nd, size_t dim_
         return BPPP_ERR_INVALID_ARG;
     return BPPP_OK;
 }
+// ReciprocalRangeProofProtocol { dim_nd: 16, dim_np: 16 } over 16 + 32 generators with a standard-shape proof IS the u64 protocol
+// (u64_proof.rs:42-54 builds exactly this and calls reciprocal verify), and its proof layout is the 928-byte u64 form: the specialised
+// kernels (closed-form scalars, affine window tables, fixed-base tables shared with the generic path) take such calls -- an order of
+// magnitude faster than the generic kernels, same verdicts and statuses.  BPPP_GENERIC_U64_SHAPE=1 keeps the generic kernels (A/B, tests).
+static bool recip_is_u64_shape(const bppp_ctx* c, size_t dim_nd, size_t dim_np, size_t rounds, size_t nl, size_t nn) {
+    return !c->generic_u64_shape && c->ng == 16 && c->nh == 32 && dim_nd == 16 && dim_np == 16 && rounds == 4 && nl == 2 && nn == 1;
+}
 int recip_verify_device_entry(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                               const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn, void* d_accept,
                               void* d_status, const uint8_t* rlc_seed, void* d_reject_count) {
     if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept || !d_status) return BPPP_ERR_INVALID_ARG;
     int rc = recip_verify_check_args(c, dim_nd, dim_np, rounds, nl, nn);
     if (rc != BPPP_OK) return rc;
+    if (recip_is_u64_shape(c, dim_nd, dim_np, rounds, nl, nn))
+        return verify_device_impl(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, nullptr, d_reject_count, rlc_seed, nullptr);
     HIP_TRY(hipSetDevice(c->device));
     if (d_reject_count) HIP_TRY(hipMemsetAsync(d_reject_count, 0, sizeof(int), c->stream));
     if (n == 0) return BPPP_OK;
@@ -384,6 +393,11 @@ static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t labe
     if (n == 0) return BPPP_OK;
     rc = check_host_transcripts(tx, n);
     if (rc != BPPP_OK) return rc;
+    if (recip_is_u64_shape(c, dim_nd, dim_np, rounds, nl, nn)) {      // the u64 protocol under its generic name: the specialised path
+        if (tx) return bppp_u64_verify_batch_transcript(c, n, tx->states, tx->n_states, commitments, proofs, accept, status, tx->states_out);
+        if (rlc_seed) return bppp_u64_verify_batch_rlc(c, label, label_len, n, commitments, proofs, accept, status, rlc_seed);
+        return bppp_u64_verify_batch(c, label, label_len, n, commitments, proofs, accept, status);
+    }
     HIP_TRY(hipSetDevice(c->device));
     rc = ensure_straus_capacity(c, n);
     if (rc != BPPP_OK) return rc;

@@ -254,7 +254,9 @@ BPPP_API int bppp_wnla_prove_batch(bppp_ctx* ctx, const uint8_t* label, size_t l
  * dim_nd = 256, dim_np = 16 -> |g_vec| = 256, |h_vec| + |h_vec_| = 512, 8 WNLA rounds (BASELINE configs[4]).  The context
  * comes from bppp_wnla_ctx_create(g, g_vec || g_vec_, NG, h_vec || h_vec_, NH) with NG >= dim_nd, NH >= dim_nd + 10.
  * Proof layout per instance, 64 (5 + 2 rounds) + 32 (nl + nn) bytes:
- *   c_l, c_r, c_o, c_s | r[rounds] | x[rounds] | reciprocal r | l[nl] | n[nn]       (for dim_nd = 16 this is the 928-byte u64 form) */
+ *   c_l, c_r, c_o, c_s | r[rounds] | x[rounds] | reciprocal r | l[nl] | n[nn]       (for dim_nd = 16 this is the 928-byte u64 form)
+ * dim_nd = dim_np = 16 over a context of 16 + 32 generators with the standard proof shape (rounds 4, nl 2, nn 1) IS the u64 protocol
+ * (u64_proof.rs:42-54): such calls run on the u64 entry points' specialised kernels -- same verdicts and statuses, ten times the rate. */
 BPPP_API int bppp_reciprocal_verify_batch(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                           const uint8_t* commitments /* n x 64 */, const uint8_t* proofs, size_t rounds, size_t nl,
                                           size_t nn, uint8_t* accept /* n */, int32_t* status /* n or NULL */);

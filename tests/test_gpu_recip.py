@@ -6,14 +6,24 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("nd,npp,B", [(16, 16, 40), (32, 16, 9), (12, 10, 5), (256, 16, 4)])
-def test_generic_reciprocal_verify_vs_oracle(nd, npp, B):
+def _generic_kernels(monkeypatch, on):
+    """Reciprocal (16, 16) calls on 16 + 32 generators are the u64 protocol and go to its specialised kernels; a context created with
+    BPPP_GENERIC_U64_SHAPE keeps them on the generic ones (read once, at context creation)."""
+    if on:
+        monkeypatch.setenv("BPPP_GENERIC_U64_SHAPE", "1")
+    else:
+        monkeypatch.delenv("BPPP_GENERIC_U64_SHAPE", raising=False)
+
+
+@pytest.mark.parametrize("nd,npp,B,generic", [(16, 16, 40, True), (16, 16, 40, False), (32, 16, 9, True), (12, 10, 5, True), (256, 16, 4, True)])
+def test_generic_reciprocal_verify_vs_oracle(nd, npp, B, generic, monkeypatch):
     import torch
     if torch.cuda.device_count() == 0:
         pytest.fail("needs a GPU")
     import recip_cases
     from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
     case = recip_cases.make(nd, npp, B)
+    _generic_kernels(monkeypatch, generic)
     proto = ReciprocalRangeProofProtocol(nd, npp, case["g"], case["gv"], case["hv"], case["gv_"], case["hv_"], device=0,
                                          fb_window_bits=8 if nd > 64 else 16)
     try:
@@ -38,23 +48,37 @@ def test_generic_reciprocal_verify_vs_oracle(nd, npp, B):
         proto.close()
 
 
-def test_u64_dimensions_agree_with_the_specialised_path():
-    """dim_nd = dim_np = 16 through the generic kernels must give the accept bits of the u64 kernels on the same proofs."""
+def test_u64_dimensions_agree_with_the_specialised_path(monkeypatch):
+    """dim_nd = dim_np = 16 through the generic entry point -- on the generic kernels, and on the u64 kernels such calls are handed to --
+    must give the accept bits and statuses of the u64 entry point on the same proofs (malformed ones included), exact and RLC; a proof
+    shape other than the standard one stays on the generic kernels."""
     import workload
     from bp_pp_amd import U64RangeProofProtocol
     from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
     n = 200
     gens, V, P, _ = workload.make_batch(n, first=9000)
     P, expect = workload.corrupt(P, V, every=9)
+    P = P.copy(); expect = expect.copy()
+    P[3, 70] ^= 1                                       # c_r off the curve: status flag
+    expect[3] = 0
     g, gv, hv = workload.split_generators(gens)
     u = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=16)
-    r = ReciprocalRangeProofProtocol(16, 16, g, gv, hv[:26], [], hv[26:], device=0, fb_window_bits=16)
-    try:
-        a1, s1 = u.verify_batch(V, P, workload.LABEL)
-        a2, s2 = r.verify_batch(workload.LABEL, V, P, 4, 2, 1)
-        assert (a1 == a2).all() and (a1 == expect).all() and not s1.any() and not s2.any()
-    finally:
-        u.close(); r.close()
+    a1, s1 = u.verify_batch(V, P, workload.LABEL)
+    u.close()
+    assert (a1 == expect).all() and s1[3] == 1 and not np.delete(s1, 3).any()
+    for generic in (True, False):
+        _generic_kernels(monkeypatch, generic)
+        r = ReciprocalRangeProofProtocol(16, 16, g, gv, hv[:26], [], hv[26:], device=0, fb_window_bits=16)
+        try:
+            a2, s2 = r.verify_batch(workload.LABEL, V, P, 4, 2, 1)
+            assert (a1 == a2).all() and (s1 == s2).all(), generic
+            a3, s3 = r.verify_batch_rlc(workload.LABEL, V, P, 4, 2, 1, seed=bytes(range(32)))
+            assert (a1 == a3).all() and (s1 == s3).all(), generic
+            short = np.concatenate([P[:8, 0:256], P[:8, 256:448], P[:8, 512:704], P[:8, 768:928]], axis=1)   # three rounds' r and x only
+            a4, _ = r.verify_batch(workload.LABEL, V[:8], np.ascontiguousarray(short), 3, 2, 1)
+            assert not a4.any()
+        finally:
+            r.close()
 
 
 @pytest.mark.parametrize("nd,npp,B", [(16, 16, 40), (8, 4, 5), (12, 10, 3), (256, 16, 2)])
