@@ -146,7 +146,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(VerifyWs ws, const 
     ws_st8(ws.fsc, ws.N, t, 1, ss.v);
     pt acc;
     pt_set_identity(acc);
-    fixed_base_msm(acc, fb_of(ws), t, ws.fsc, 0, 0, 1);
+    fixed_base_msm(acc, fb_of(ws), t, ws.fsc, 0, 0, 1, 64);     // x is a u64: 3 of the 12 windows at 22 bits
     fixed_base_msm(acc, fb_of(ws), t, ws.fsc, 1, 17, 1);
     apt a;
     pt_to_affine(a, acc);

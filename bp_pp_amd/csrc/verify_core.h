@@ -313,8 +313,8 @@ HD void fb_lookup_add(pt& acc, const FbTable& fbt, int base, int w, const u32 k[
     fe_cmov(e.y, neg, ny);
     pt_madd(acc, acc, e, skip | id);
 }
-HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, int first_slot, int first_base, int count) {
-    const int nwin = fb_nwin(fbt.W);
+HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, int first_slot, int first_base, int count, int bits = 0) {
+    const int nwin = fb_windows_for(bits, fbt.W);     // bits > 0: the scalars are below 2^bits -- only the windows they can reach
     pt acc = accp;
 #pragma nounroll
     for (int j = 0; j < count; j++) {

@@ -35,6 +35,12 @@ def test_u64_verify_at_baseline_sizes(torch_mod, oracle_c, log_n, wbits):
     assert gens == workload.generators()
     proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=wbits)     # 0 = the library default bench.py runs with
     try:
+        # commit_value (u64_proof.rs:37-39) through these tables: x walks only the windows a u64 can reach (3 of 12 / 4 of 13 signed)
+        xs = np.array([0, 1, 2**64 - 1, 2**63, 2**43, 2**44 - 1, 123456], dtype=np.uint64)
+        ss = np.frombuffer(b"".join(int(v).to_bytes(32, "big") for v in [0, 1, 5, 2**200, 7, 2**255, 3]), dtype=np.uint8).reshape(7, 32)
+        cv = proto.commit_value_batch(xs, ss)
+        for i in range(7):
+            assert bytes(cv[i]) == oracle_c.u64_commit_value(gens, int(xs[i]), bytes(ss[i])), i
         lo = 3 << 20                        # a shard that does not start at proof 0 of the synthetic stream
         dV, dP, expect, _ = bench.make_resident_batch(torch, proto, synth, lo, lo + n)
         assert int((expect == 0).sum()) == n // 1024
