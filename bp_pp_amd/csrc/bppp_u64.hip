@@ -423,7 +423,8 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_c0());
     for (int k = 1; k <= 4; k++) {
-        PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        if (fb_wave) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_wide<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
+        else PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         PMSMX(2, job_x(), job_r(k), job_x(), job_x());
         if (!w.next_by_msm && !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
             PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));

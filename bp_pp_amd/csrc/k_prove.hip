@@ -38,6 +38,16 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(ProveWs w, i
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) prove_round_scalars(w, t, k);
 }
+// small calls: a wavefront per proof, a lane per generator (the loop over the 49 terms is a chain of dependent loads on one lane)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars_wide(ProveWs w, int k) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 6;
+    const int lane = (int)(g & 63);
+    if (t >= w.N) return;
+    if (lane < 32) prove_round_scalars_h(w, t, k, lane);
+    else if (lane < 48) prove_round_scalars_g(w, t, k, lane - 32);
+    else if (lane == 48) prove_round_scalars_v(w, t, k);
+}
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(ProveWs w, int k) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= w.N) return;

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_export_states(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(bppp::ProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars_wide(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold_g4(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_b_w2(bppp::ProveWs w);

@@ -497,11 +497,12 @@ HD void prove_stage_f(const ProveWs& w, size_t t) {
     w.status[t] = status;
 }
 // ---------------------------------------------------------------- WNLA round k: scalars of X (set 1) and R (set 2)   (wnla.rs:135-160)
-HD void prove_round_scalars(const ProveWs& w, size_t t, int k) {
+// in three pieces, so that a small call can give every generator its own lane (k_prove_round_scalars_wide): the two leading scalars,
+// the h_vec terms, the g_vec terms
+HD void prove_round_scalars_v(const ProveWs& w, size_t t, int k) {
     const int sh = k - 1, nl = 32 >> sh, nn = 16 >> sh;
-    sc rho, rho_inv, mu, mu2, t1, t2, vx, vr, zero;
-    sc_set_u32(zero, 0);
-    pw_ld_sc(rho, w, t, SV_RHO); pw_ld_sc(rho_inv, w, t, SV_RHOINV); pw_ld_sc(mu, w, t, SV_MU);
+    sc rho_inv, mu, mu2, t1, vx, vr;
+    pw_ld_sc(rho_inv, w, t, SV_RHOINV); pw_ld_sc(mu, w, t, SV_MU);
     sc_mul(mu2, mu, mu);
     // vx = wvm(n0, n1, mu2) * 2 rho^-1 + <c0, l1> + <c1, l0>;  vr = wvm(n1, n1, mu2) + <c1, l1>
     sc wx, wr, wpow = mu2;
@@ -530,33 +531,41 @@ HD void prove_round_scalars(const ProveWs& w, size_t t, int k) {
     }
     pw_st_msc(w, t, 1, 0, vx);
     pw_st_msc(w, t, 2, 0, vr);
-    // original h_i sits in folded slot j = i >> (k-1) with coefficient ch[i]:  X gets ch[i] l[j^1], R gets (j odd) ch[i] l[j]
+}
+// original h_i sits in folded slot j = i >> (k-1) with coefficient ch[i]:  X gets ch[i] l[j^1], R gets (j odd) ch[i] l[j]
+HD void prove_round_scalars_h(const ProveWs& w, size_t t, int k, int i) {
+    const int j = i >> (k - 1);
+    sc ch, lx, lr, t1, t2, zero;
+    sc_set_u32(zero, 0);
+    pw_ld_sc(ch, w, t, SV_CH0 + i);
+    pw_ld_sc(lx, w, t, SV_L0 + (j ^ 1));
+    sc_mul(t1, ch, lx);
+    pw_st_msc(w, t, 1, 17 + i, t1);
+    pw_ld_sc(lr, w, t, SV_L0 + j);
+    sc_mul(t2, ch, lr);
+    pw_st_msc(w, t, 2, 17 + i, (j & 1) ? t2 : zero);
+}
+// g_i: X gets cg[i] * (j even ? rho n[j+1] : rho^-1 n[j-1]);  R gets (j odd) cg[i] n[j]
+HD void prove_round_scalars_g(const ProveWs& w, size_t t, int k, int i) {
+    const int j = i >> (k - 1);
+    sc rho, rho_inv, cg, nx, nr, t1, t2, zero;
+    sc_set_u32(zero, 0);
+    pw_ld_sc(rho, w, t, SV_RHO); pw_ld_sc(rho_inv, w, t, SV_RHOINV);
+    pw_ld_sc(cg, w, t, SV_CG0 + i);
+    pw_ld_sc(nx, w, t, SV_N0 + (j ^ 1));
+    sc_mul(t1, nx, (j & 1) ? rho_inv : rho);
+    sc_mul(t1, t1, cg);
+    pw_st_msc(w, t, 1, 1 + i, t1);
+    pw_ld_sc(nr, w, t, SV_N0 + j);
+    sc_mul(t2, cg, nr);
+    pw_st_msc(w, t, 2, 1 + i, (j & 1) ? t2 : zero);
+}
+HD void prove_round_scalars(const ProveWs& w, size_t t, int k) {
+    prove_round_scalars_v(w, t, k);
 #pragma nounroll
-    for (int i = 0; i < 32; i++) {
-        int j = i >> sh;
-        sc ch, lx, lr;
-        pw_ld_sc(ch, w, t, SV_CH0 + i);
-        pw_ld_sc(lx, w, t, SV_L0 + (j ^ 1));
-        sc_mul(t1, ch, lx);
-        pw_st_msc(w, t, 1, 17 + i, t1);
-        pw_ld_sc(lr, w, t, SV_L0 + j);
-        sc_mul(t2, ch, lr);
-        pw_st_msc(w, t, 2, 17 + i, (j & 1) ? t2 : zero);
-    }
-    // g_i: X gets cg[i] * (j even ? rho n[j+1] : rho^-1 n[j-1]);  R gets (j odd) cg[i] n[j]
+    for (int i = 0; i < 32; i++) prove_round_scalars_h(w, t, k, i);
 #pragma nounroll
-    for (int i = 0; i < 16; i++) {
-        int j = i >> sh;
-        sc cg, nx, nr;
-        pw_ld_sc(cg, w, t, SV_CG0 + i);
-        pw_ld_sc(nx, w, t, SV_N0 + (j ^ 1));
-        sc_mul(t1, nx, (j & 1) ? rho_inv : rho);
-        sc_mul(t1, t1, cg);
-        pw_st_msc(w, t, 1, 1 + i, t1);
-        pw_ld_sc(nr, w, t, SV_N0 + j);
-        sc_mul(t2, cg, nr);
-        pw_st_msc(w, t, 2, 1 + i, (j & 1) ? t2 : zero);
-    }
+    for (int i = 0; i < 16; i++) prove_round_scalars_g(w, t, k, i);
 }
 // ---------------------------------------------------------------- WNLA round k: transcript, challenge, folds, next commitment (wnla.rs:162-188)
 // group_lane >= 0: one of four consecutive lanes that all run the round for proof t (identical work and stores; the next-commitment
