@@ -25,7 +25,7 @@ for it in range(K):
     proto.set_option("rlc_superchunk", sm)
     assert not pst.any()
     P, V = P.copy(), V.copy()
-    idx = rng.choice(n, size=int(rng.integers(0, 400)) if it % 3 else int(rng.integers(0, 4)), replace=False)   # every third batch nearly clean
+    idx = rng.choice(n, size=min(n, int(rng.integers(0, 400)) if it % 3 else int(rng.integers(0, 4))), replace=False)   # every third batch nearly clean
     P0, V0 = P.copy(), V.copy()
     for i in idx:
         kind = int(rng.integers(0, 6))
@@ -60,7 +60,7 @@ for it in range(K):
     untouched = np.ones(n, bool); untouched[idx] = False
     assert a0[untouched].all() and not s0[untouched].any(), "an honest proof was rejected"
     assert not a0[idx].any(), "a corrupted proof was accepted"
-    sample = np.concatenate([idx[:64], rng.choice(n, size=192, replace=False)])
+    sample = np.concatenate([idx[:64], rng.choice(n, size=min(n, 192), replace=False)])
     oacc, ost = OC.u64_verify_batch(gens, workload.LABEL, V[sample].copy(), P[sample].copy(), nthreads=min(64, os.cpu_count() or 1))
     assert (oacc == a0[sample]).all() and ((ost != 0) == (s0[sample] != 0)).all(), "GPU and CPU oracle disagree"
     bad_total += len(idx)

@@ -11,6 +11,6 @@ cp $S/pmc/pmc_traffic.json $P/${T}_pmc_traffic.json; cp $S/pmc/pmc_traffic.json 
 cp $S/sq/pmc_valu.json $P/${T}_pmc_valu.json; cp $S/sq/pmc_valu.json $P/pmc_valu.json
 cp $S/box.txt $P/${T}_box.txt
 [ -f $S/pytest_gpu.txt ] && cp $S/pytest_gpu.txt $P/${T}_pytest_gpu.txt
-for f in soak_2pow10 soak_2pow12 soak_2pow16 soak_2pow20 stress_mixed soak_generic; do [ -s $S/$f.txt ] && tail -n 6 $S/$f.txt > $P/${T}_$f.txt; done
+for f in soak_2pow1 soak_2pow5 soak_2pow10 soak_2pow12 soak_2pow16 soak_2pow20 stress_mixed soak_generic; do [ -s $S/$f.txt ] && tail -n 6 $S/$f.txt > $P/${T}_$f.txt; done
 ls -la $P | grep ${T}_
 [ -f $S/latency_w22.txt ] && cp $S/latency_w22.txt $P/${T}_latency_w22.txt; true

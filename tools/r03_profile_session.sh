@@ -75,6 +75,8 @@ find $OUT -name "*counter_collection.csv" -size +8M -delete
 cd "$REPO"
 timeout 900 python tests/soak.py 40 16 > $OUT/soak_2pow16.txt 2>&1; echo "soak16 rc=$?" >> $OUT/log.txt
 timeout 900 python tests/soak.py 6 20 > $OUT/soak_2pow20.txt 2>&1; echo "soak20 rc=$?" >> $OUT/log.txt
+timeout 900 python tests/soak.py 200 1 > $OUT/soak_2pow1.txt 2>&1; echo "soak1 rc=$?" >> $OUT/log.txt
+timeout 900 python tests/soak.py 200 5 > $OUT/soak_2pow5.txt 2>&1; echo "soak5 rc=$?" >> $OUT/log.txt
 timeout 900 python tests/soak.py 100 10 > $OUT/soak_2pow10.txt 2>&1; echo "soak10 rc=$?" >> $OUT/log.txt
 timeout 900 python tests/soak.py 60 12 > $OUT/soak_2pow12.txt 2>&1; echo "soak12 rc=$?" >> $OUT/log.txt
 timeout 600 python tools/latency_breakdown.py 22 > $OUT/latency_w22.txt 2>&1; echo "latency rc=$?" >> $OUT/log.txt
