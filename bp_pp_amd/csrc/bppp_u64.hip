@@ -47,7 +47,7 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     if (rc != BPPP_OK) return rc;
     // a call of at most one proof per SIMD: the dependent chains are cut further (a lane per window table and per half GLV stream,
     // a wavefront per fixed-base sum), which takes three more sets of window tables per proof
-    const bool split = !c->no_small && !c->no_lane_groups && !c->no_split && n <= (c->split_max >= 0 ? (size_t)c->split_max : 4 * (size_t)c->n_simds);
+    const bool split = !c->no_small && !c->no_lane_groups && !c->no_split && n <= 4 * (size_t)c->n_simds;
     // four parts per GLV stream up to one proof per SIMD, two beyond (the extra lanes start to queue: 2,048 proofs 3.5 ms either way, 4,096
     // proofs 4.3 ms in two parts against 5.1 in four)
     const int parts = n <= (size_t)c->n_simds ? 4 : 2;
@@ -141,15 +141,15 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     const unsigned g4_blocks = (unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     if (split && parts == 4) LAUNCH(K_C0_VAR, k_verify_c0_var_g64<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
     else if (split) LAUNCH(K_C0_VAR, k_verify_c0_var_g32<<<(unsigned)((32 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
-    else if (c->c0var_form == 4 || (grouped && !c->c0var_form)) LAUNCH(K_C0_VAR, k_verify_c0_var_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws));
+    else if (grouped) LAUNCH(K_C0_VAR, k_verify_c0_var_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws));
     else if (small) LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     else LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     for (int k = 1; k <= 4; k++) {
         if (split && parts == 4) LAUNCH(K_ROUND, k_verify_round_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
         else if (split) LAUNCH(K_ROUND, k_verify_round_g8<<<(unsigned)((8 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
-        else if (c->round_form == 4 || (grouped && !c->round_form)) LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k));
-        else if (c->round_form == 2 || (!c->round_form && (c->force_pairs || (!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds))))
+        else if (grouped) LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+        else if (c->force_pairs || (!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds))
             LAUNCH(K_ROUND, k_verify_round_g2<<<(unsigned)((2 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
         else if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
         else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
@@ -410,8 +410,7 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
 #define PMSMX(NJ, ...)                                                                                                     \
     do {                                                                                                                    \
         MsmJobs js = {{__VA_ARGS__}};                                                                                        \
-        if (c->prove_separate_sums) { for (int q_ = 0; q_ < NJ; q_++) PMSM(js.j[q_]); }                                      \
-        else if (fb_wave) PLAUNCH(K_PROVE_MSM, k_prove_msm_l64x<<<dim3(fb64_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));     \
+        if (fb_wave) PLAUNCH(K_PROVE_MSM, k_prove_msm_l64x<<<dim3(fb64_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));     \
         else if (fb_one_lane) PLAUNCH(K_PROVE_MSM, k_prove_msm_l1x<<<dim3(fb1_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));   \
         else PLAUNCH(K_PROVE_MSM, k_prove_msm_x<<<dim3(fb_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));                       \
     } while (0)

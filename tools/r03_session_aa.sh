@@ -1,5 +1,6 @@
 #!/bin/bash
 # round-3 session AA: the prover's independent sums of a stage as one launch, at every size (A/B against one launch per sum)
+# (BPPP_PROVE_SEPARATE_SUMS was the A/B switch of this session; removed afterwards, the result is in profiles/r03_aa_*)
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; OUT=gpurun_out/${1:-r03_aa}; mkdir -p $OUT
 timeout 1500 python -m pytest tests/test_gpu_prove.py tests/test_gpu_transcript.py tests/test_gpu_scale.py -m gpu -x -q > $OUT/pytest.txt 2>&1; echo "pytest rc=$?" >> $OUT/log.txt

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round-3 session S: small-call path with the table kernel beside phase 1; where the path should hand over to the lane-group kernels
+# (BPPP_SPLIT_MAX was this session's sweep switch; removed afterwards: profiles/r03_s_latency_w22_splitmax16384.txt)
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; OUT=gpurun_out/${1:-r03_s}; mkdir -p $OUT
 timeout 1500 python -m pytest tests/test_gpu_verify.py tests/test_gpu_transcript.py tests/test_gpu_rlc.py tests/test_gpu_group.py tests/test_capi_harness.py tests/test_gpu_prove.py -m gpu -x -q > $OUT/pytest.txt 2>&1; echo "pytest rc=$?" >> $OUT/log.txt

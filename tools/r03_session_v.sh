@@ -1,5 +1,6 @@
 #!/bin/bash
 # round-3 session V/W: small-call path with four parts per GLV stream up to one proof per SIMD, two parts up to four per SIMD; prover sums of a stage in one launch
+# (BPPP_SPLIT_MAX was a sweep switch of these sessions; removed afterwards)
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; OUT=gpurun_out/${1:-r03_v}; mkdir -p $OUT
 timeout 1800 python -m pytest tests/test_gpu_verify.py tests/test_gpu_transcript.py tests/test_gpu_rlc.py tests/test_gpu_group.py tests/test_capi_harness.py tests/test_gpu_prove.py -m gpu -x -q > $OUT/pytest.txt 2>&1; echo "pytest rc=$?" >> $OUT/log.txt
