@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-3 session Y: forms of the variable-base kernels for batches of about one wavefront per SIMD (2^15 .. 2^17 proofs)
-# (BPPP_ROUND_FORM / BPPP_C0VAR_FORM were experiment switches of commit 7a1ccf6..; removed once the sweep was recorded in profiles/r03_y_forms.txt)
+# (BPPP_ROUND_FORM / BPPP_C0VAR_FORM were experiment switches of commit 8d7a956; removed once the sweep was recorded in profiles/r03_y_forms.txt)
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; OUT=gpurun_out/${1:-r03_y}; mkdir -p $OUT
 run() {  # name, total, env...
