@@ -9,16 +9,12 @@ thread_local std::string g_last_error;
 
 // Diagnostic switches (A/B measurements), read from the environment once per context, here and nowhere else.
 static void read_diagnostics(bppp_ctx* c) {
-    c->serial_c0 = std::getenv("BPPP_SERIAL_C0") != nullptr;             // the two halves of C0 on one stream
-    c->force_pairs = std::getenv("BPPP_FORCE_LANE_PAIRS") != nullptr;     // rounds on two lanes per proof at every batch size
     c->no_lane_groups = std::getenv("BPPP_NO_LANE_GROUPS") != nullptr;    // one lane per proof at every batch size
     c->no_small = std::getenv("BPPP_NO_SMALL_KERNELS") != nullptr;        // the 256-VGPR builds (two wavefronts per SIMD) at every batch size
     c->no_split = std::getenv("BPPP_NO_SPLIT") != nullptr;                // no half-stream lanes / per-table lanes for calls of <= one proof per SIMD
     if (const char* e = std::getenv("BPPP_FB_ONE_LANE")) c->fb_one_lane_mode = e[0] == '0' ? 0 : 1;
     c->generic_u64_shape = std::getenv("BPPP_GENERIC_U64_SHAPE") != nullptr;     // reciprocal (16, 16) calls stay on the generic kernels
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // projective tables + complete additions
-    c->rlc_debug = std::getenv("BPPP_RLC_DEBUG") != nullptr;
-    c->prove_uncapped = std::getenv("BPPP_PROVE_UNCAPPED") != nullptr;            // the prover's lane kernels without the 256-register cap at every size
 }
 
 // fb_window_bits = 0: the widest windows whose tables stay below 100 GB -- 22 bits for the u64 protocol's 49 generators (79 GB of the

@@ -106,7 +106,7 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
 #define LAUNCH(id, ...) LAUNCH_ON(s, id, __VA_ARGS__)
     // a grid that does not even fill one wavefront per SIMD gains nothing from the 256-VGPR cap: use the uncapped builds
     const bool small = !c->no_small && blocks <= (unsigned)c->n_simds;
-    hipStream_t a = (c->serial_c0 || c->timing) ? s : c->aux_stream;
+    hipStream_t a = c->timing ? s : c->aux_stream;
     if (split) {
         // the small-call table kernel decodes its points itself, so it runs on the helper stream beside phase 1
         HIP_TRY(hipEventRecord(c->ev_fork, s));
@@ -149,7 +149,7 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         if (split && parts == 4) LAUNCH(K_ROUND, k_verify_round_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
         else if (split) LAUNCH(K_ROUND, k_verify_round_g8<<<(unsigned)((8 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
         else if (grouped) LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k));
-        else if (c->force_pairs || (!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds))
+        else if (!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds)
             LAUNCH(K_ROUND, k_verify_round_g2<<<(unsigned)((2 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
         else if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
         else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
@@ -181,14 +181,6 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged<<<1024, 64, 0, s>>>(ws, rl));
         LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged_dense<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
         LAUNCH(K_ACCEPT, k_verify_accept_flagged<<<blocks, BPPP_BLOCK, 0, s>>>(ws, rl, (int*)d_reject_count));
-        if (c->rlc_debug) {   // diagnostic: how many chunks went to the exact kernels
-            std::vector<uint8_t> hf(nchunks);
-            HIP_TRY(hipStreamSynchronize(s));
-            HIP_TRY(hipMemcpy(hf.data(), rl.flag, nchunks, hipMemcpyDeviceToHost));
-            size_t cnt = 0;
-            for (uint8_t f : hf) cnt += f ? 1 : 0;
-            std::fprintf(stderr, "bppp rlc: %zu of %zu chunks re-checked exactly\n", cnt, nchunks);
-        }
     }
     if (ws.states_out) k_verify_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
 #undef LAUNCH
@@ -400,7 +392,7 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
         else PLAUNCH(K_PROVE_MSM, k_prove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job));               \
     } while (0)
     // a grid that gives every SIMD more than one wavefront runs the 256-register builds of the lane kernels (two wavefronts per SIMD)
-    const bool w2 = !c->prove_uncapped && (c->no_small || blocks > (unsigned)c->n_simds);
+    const bool w2 = c->no_small || blocks > (unsigned)c->n_simds;
     PLAUNCH(K_PROVE_STAGES, k_prove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_v());
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_b_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));

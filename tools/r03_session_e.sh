@@ -1,5 +1,6 @@
 #!/bin/bash
 # round-3 session E: SQ-counter passes of the headline workload on the current build (pmc_valu), fixed-base window width A/B (20 vs
+# (BPPP_PROVE_UNCAPPED was this session's A/B switch; removed afterwards: profiles/r03_e_prove_*)
 # 22 bits), prover lane kernels capped / uncapped at 2^16..2^18 values, TCC hit/miss of k_wnla_msm.
 # usage: tools/r03_session_e.sh <tag>
 set -u
