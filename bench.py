@@ -72,6 +72,12 @@ def launched_kernel(kernel, n_proofs, lanes_per_proof):
     one-lane-per-proof kernels (k_verify_*_l1), which is the name the rocprofv3 summaries carry."""
     if kernel in ("k_verify_c0_fixed", "k_verify_final_check") and n_proofs >= (1 << 17):
         return kernel + "_l1", 1
+    if kernel == "k_prove_msm":        # the prover's sums: lanes per proof by batch size (bppp_u64.hip: PMSMX); the fused launches dominate
+        if n_proofs >= (1 << 17):
+            return "k_prove_msm_l1x", 1
+        if n_proofs >= (1 << 14):
+            return "k_prove_msm_l4x", 4
+        return ("k_prove_msm_l64x", 64) if n_proofs <= 1024 else ("k_prove_msm_x", 8)
     return kernel, lanes_per_proof
 
 

@@ -383,29 +383,31 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     // a call of at most one value per SIMD: a wavefront per sum (the chip is empty; 6 additions per lane and a 6-step tree instead of 44 and 3)
     const bool fb_wave = !c->no_small && !c->no_split && n <= (size_t)c->n_simds;
-    w.next_by_msm = fb_wave ? 1 : 0;     // ... and the next level's commitment as one more of those sums (prove_core.h: job_cnext)
+    // ... and the next level's commitment as one more of those sums (prove_core.h: job_cnext), fused with the next round's X | R.  That form
+    // wins while the variable-base one is a latency chain on an under-filled chip: up to 8 values per SIMD (2^11 values 8.4 -> 6.3 ms, 2^12
+    // 8.6 -> 7.2, 2^13 9.2 -> 8.3; at 2^14 the extra 588 table additions per level cost what the chain did: 12.1 against 12.3 ms)
+    w.next_by_msm = (fb_wave || (!c->no_split && !c->no_lane_groups && n <= 8 * (size_t)c->n_simds)) ? 1 : 0;
     const unsigned fb64_blocks = (unsigned)((n * 64 + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
-#define PMSM(job)                                                                                         \
-    do {                                                                                                  \
-        if (fb_wave) PLAUNCH(K_PROVE_MSM, k_prove_msm_l64<<<fb64_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job));  \
-        else if (fb_one_lane) PLAUNCH(K_PROVE_MSM, k_prove_msm_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job)); \
-        else PLAUNCH(K_PROVE_MSM, k_prove_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, job));               \
+    // The prover's fixed-base sums.  Lanes per proof: a wavefront in a small call; otherwise 8, 4 or 1 -- the fewest that still give
+    // every SIMD two wavefronts in the launch (fewer lanes = fewer idle lanes in the short runs and a shorter tree of complete additions
+    // per sum: 2^14 values 12.38 -> 12.03 ms with 4 lanes in the fused launches).  The independent sums of a stage go out as ONE launch
+    // (blockIdx.y = job): no gap between them, and the short ones (c_o: 84 table additions per proof) fill in beside the long ones.
+#define PMSMX(NJ, ...)                                                                                                     \
+    do {                                                                                                                    \
+        MsmJobs js = {{__VA_ARGS__}};                                                                                        \
+        if (fb_wave) PLAUNCH(K_PROVE_MSM, k_prove_msm_l64x<<<dim3(fb64_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));          \
+        else if (fb_one_lane) PLAUNCH(K_PROVE_MSM, k_prove_msm_l1x<<<dim3(fb1_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));   \
+        else if ((size_t)(NJ) * 4 * n >= (size_t)128 * c->n_simds)                                                          \
+            PLAUNCH(K_PROVE_MSM, k_prove_msm_l4x<<<dim3((unsigned)((n * 4 + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK), NJ), BPPP_FB_BLOCK, 0, s>>>(w, js)); \
+        else PLAUNCH(K_PROVE_MSM, k_prove_msm_x<<<dim3(fb_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));                       \
     } while (0)
+#define PMSM(job) PMSMX(1, job, job, job, job)
     // a grid that gives every SIMD more than one wavefront runs the 256-register builds of the lane kernels (two wavefronts per SIMD)
     const bool w2 = c->no_small || blocks > (unsigned)c->n_simds;
     PLAUNCH(K_PROVE_STAGES, k_prove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_v());
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_b_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-    // the independent sums of a stage go out as ONE launch (blockIdx.y = job): no gap between them, and the short ones (c_o: 84 table
-    // additions per proof) fill in beside the long ones
-#define PMSMX(NJ, ...)                                                                                                     \
-    do {                                                                                                                    \
-        MsmJobs js = {{__VA_ARGS__}};                                                                                        \
-        if (fb_wave) PLAUNCH(K_PROVE_MSM, k_prove_msm_l64x<<<dim3(fb64_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));     \
-        else if (fb_one_lane) PLAUNCH(K_PROVE_MSM, k_prove_msm_l1x<<<dim3(fb1_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));   \
-        else PLAUNCH(K_PROVE_MSM, k_prove_msm_x<<<dim3(fb_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));                       \
-    } while (0)
     PMSMX(4, job_rcom(), job_co(), job_cl(), job_cr());
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(w));
@@ -413,17 +415,19 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_c0());
+    bool pending_cnext = false;
     for (int k = 1; k <= 4; k++) {
         if (fb_wave) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_wide<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
         else PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
-        PMSMX(2, job_x(), job_r(k), job_x(), job_x());
+        if (pending_cnext) PMSMX(3, job_x(), job_r(k), job_cnext(), job_x());
+        else PMSMX(2, job_x(), job_r(k), job_x(), job_x());
         if (!w.next_by_msm && !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
             PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
         else if (w2)
             PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         else
             PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
-        if (w.next_by_msm && k < 4) PMSM(job_cnext());
+        pending_cnext = w.next_by_msm && k < 4;     // its scalars are in set 0 now; the sum rides with the next round's X | R
     }
     if (w.states_out) k_prove_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
 #undef PMSMX

@@ -75,13 +75,11 @@ __device__ __forceinline__ void prove_msm_lanes(const ProveWs& w, const MsmJob& 
     fb_group_sum<NL>(part, w.fb, t, lane, w.msc, rg);
     if (lane == 0) prove_msm_store(w, job, t, part);
 }
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm(ProveWs w, MsmJob job) { prove_msm_lanes<BPPP_FB_LANES>(w, job); }
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l1(ProveWs w, MsmJob job) { prove_msm_lanes<1>(w, job); }
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l64(ProveWs w, MsmJob job) { prove_msm_lanes<64>(w, job); }
 // the independent sums of one stage in ONE launch (small calls: r_com | c_o | c_l | c_r, and X | R of a round)
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l64x(ProveWs w, MsmJobs jobs) { prove_msm_lanes<64>(w, jobs.j[blockIdx.y]); }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_x(ProveWs w, MsmJobs jobs) { prove_msm_lanes<BPPP_FB_LANES>(w, jobs.j[blockIdx.y]); }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l1x(ProveWs w, MsmJobs jobs) { prove_msm_lanes<1>(w, jobs.j[blockIdx.y]); }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l4x(ProveWs w, MsmJobs jobs) { prove_msm_lanes<4>(w, jobs.j[blockIdx.y]); }
 
 // ---- the lane kernels above at two wavefronts per SIMD (256 VGPR + AGPR), for prove batches that give every SIMD more than one
 // wavefront (beyond 2^16 values; BASELINE configs[3]'s 2^14 values are 256 workgroups on 1024 SIMDs and keep the uncapped builds):

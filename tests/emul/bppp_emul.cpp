@@ -517,8 +517,8 @@ static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label
     for (int k = 1; k <= 4; k++) {
         for (size_t t = 0; t < n; t++) prove_round_scalars(w, t, k);
         msm(job_x()); msm(job_r(k));
+        if (w.next_by_msm && k > 1) msm(job_cnext());       // the level's commitment, scalars left by the previous fold (the library fuses the three launches)
         for (size_t t = 0; t < n; t++) prove_round_fold(w, t, k);
-        if (w.next_by_msm && k < 4) msm(job_cnext());
     }
     for (size_t t = 0; t < n; t++) prove_export_state(w, t);
     return 0;

@@ -49,7 +49,7 @@ def factor(kernel, counter):
 f_stream = factor("k_copy_dword", "FETCH_SIZE") or 2.0
 f_gather = factor("k_gather64", "FETCH_SIZE") or 1.0
 wf = factor("k_copy_dword", "WRITE_SIZE") or 1.0
-GATHER_DOMINATED = ("k_verify_c0_fixed", "k_verify_final_check", "k_verify_c0_fixed_l1", "k_verify_final_check_l1", "k_verify_c0_var", "k_verify_round", "k_prove_msm", "k_prove_round_fold",
+GATHER_DOMINATED = ("k_verify_c0_fixed", "k_verify_final_check", "k_verify_c0_fixed_l1", "k_verify_final_check_l1", "k_verify_c0_var", "k_verify_round", "k_prove_msm_x", "k_prove_msm_l4x", "k_prove_msm_l1x", "k_prove_msm_l64x", "k_prove_round_fold",
                     "k_wnla_msm", "k_recip_c0_fixed", "k_rlc_chunk")
 for k, v in res["kernels"].items():
     fr, wr = v.get("FETCH_SIZE_raw_bytes", 0.0), v.get("WRITE_SIZE_raw_bytes", 0.0)
