@@ -79,6 +79,8 @@ __device__ __forceinline__ void verify_tables_split(const VerifyWs& ws) {
     const int p = (int)(g & 15), h = (int)((g >> 4) % PARTS);
     if (t < ws.N && p < BPPP_VPOINTS) verify_table_one(ws, t, p, h, PARTS, true);   // from the caller's bytes: runs beside phase 1
 }
+// one table per point (the lane groups' tables: 4,096 < n <= 16,384 proofs), a lane each, beside phase 1
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables_split1(VerifyWs ws) { verify_tables_split<1>(ws); }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables_split2(VerifyWs ws) { verify_tables_split<2>(ws); }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables_split4(VerifyWs ws) { verify_tables_split<4>(ws); }
 template <int G>

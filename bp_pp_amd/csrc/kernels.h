@@ -89,6 +89,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_small(bppp::VerifyW
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g4(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g4(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g2(bppp::VerifyWs ws, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables_split1(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables_split2(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_tables_split4(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g8(bppp::VerifyWs ws, int k);

@@ -1021,6 +1021,7 @@ HD void verify_tables(const VerifyWs& ws, size_t t) {
 // table of 2^(5 split_begin(parts, j)) P -- 13 + 13 windows (tables of P, 2^65 P) or 7 + 7 + 6 + 6 (P, 2^35 P, 2^70 P, 2^100 P).
 #define BPPP_SPLIT_PARTS_MAX 4
 HD int split_begin(int parts, int part) {   // 26 = BPPP_VWINDOWS (defined below)
+    if (parts == 1) return part == 0 ? 0 : 26;
     if (parts == 2) return part == 0 ? 0 : part == 1 ? 13 : 26;
     return part == 0 ? 0 : part == 1 ? 7 : part == 2 ? 14 : part == 3 ? 20 : 26;
 }

@@ -8,11 +8,11 @@ from bp_pp_amd import U64RangeProofProtocol, synth
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 gens, g, gv, hv = bench.load_generators()
 proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=W)
-dV, dP, expect, _ = bench.make_resident_batch(torch, proto, synth, 0, 1 << 13)
+dV, dP, expect, _ = bench.make_resident_batch(torch, proto, synth, 0, 1 << 14)
 V, P = dV.cpu().numpy(), dP.cpu().numpy()
-dA = torch.zeros(1 << 13, dtype=torch.uint8, device="cuda")
-dS = torch.zeros(1 << 13, dtype=torch.int32, device="cuda")
-for n in (1, 64, 1024, 2048, 4096, 8192):
+dA = torch.zeros(1 << 14, dtype=torch.uint8, device="cuda")
+dS = torch.zeros(1 << 14, dtype=torch.int32, device="cuda")
+for n in (1, 64, 1024, 2048, 4096, 8192, 16384):
     for mode in ("host", "device"):
         def call():
             if mode == "host":
