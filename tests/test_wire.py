@@ -153,3 +153,27 @@ def test_generic_proof_documents_round_trip():
     assert len(d["r"]) == w["rounds"] and len(d["l"]) == w["nl"] and len(d["n"]) == w["nn"]
     with pytest.raises(ValueError):
         wire.circuit_proof_to_doc(c["proofs"][0].tobytes()[:-1], c["rounds"], c["pl"], c["pn"])
+
+
+def test_compress_expand_round_trip_on_random_points():
+    """sec1_compress_lane then sec1_expand_lane (the device code of both wire directions, compiled for the host) is the identity on
+    well-formed 64-byte points -- random multiples of G, both parities of y, the identity -- and agrees with the wire module."""
+    import random
+    L = load()
+    rnd = random.Random(77)
+    n = 24
+    pts = [O.pt_mul(O.G, rnd.getrandbits(256) % O.N) for _ in range(14 * n - 3)] + [None, None, None]
+    rnd.shuffle(pts)
+    enc = [O.pt_to_xy64(p) for p in pts]
+    C64 = np.frombuffer(b"".join(enc[:n]), np.uint8).copy()
+    scal = [rnd.getrandbits(256).to_bytes(32, "big") for _ in range(3 * n)]
+    P928 = np.frombuffer(b"".join(b"".join(enc[n + 13 * i:n + 13 * i + 13]) + b"".join(scal[3 * i:3 * i + 3]) for i in range(n)), np.uint8).copy()
+    C33, P525 = np.zeros(n * 33, np.uint8), np.zeros(n * 525, np.uint8)
+    L.emul_sec1_compress(n, C64.ctypes.data, P928.ctypes.data, C33.ctypes.data, P525.ctypes.data)
+    for i in range(n):
+        assert bytes(C33[33 * i:33 * i + 33]) == wire.compress_point(enc[i])
+        assert bytes(P525[525 * i:525 * i + 525]) == wire.abi_to_sec1(bytes(P928[928 * i:928 * i + 928]))
+    B64, B928 = np.zeros(n * 64, np.uint8), np.zeros(n * 928, np.uint8)
+    L.emul_sec1_expand(n, C33.ctypes.data, P525.ctypes.data, B64.ctypes.data, B928.ctypes.data)
+    assert (B64 == C64).all() and (B928 == P928).all()
+    assert {int(C33[33 * i]) for i in range(n)} | {int(P525[525 * i + 33 * j]) for i in range(n) for j in range(13)} >= {0, 2, 3}
