@@ -8,7 +8,7 @@ import os
 from . import _build
 
 OK = 0
-ERR_NO_DEVICE, ERR_INVALID_ARG, ERR_HIP, ERR_ENCODING, ERR_NOMEM, ERR_RCCL = -1, -2, -3, -4, -5, -6
+ERR_NO_DEVICE, ERR_INVALID_ARG, ERR_HIP, ERR_ENCODING, ERR_NOMEM, ERR_RCCL, ERR_CLOSED = -1, -2, -3, -4, -5, -6, -7
 ST_BAD_ENCODING, ST_DEGENERATE = 1, 2
 POINT_BYTES, SCALAR_BYTES, U64_PROOF_BYTES, U64_TRACE_BYTES = 64, 32, 928, 704
 
@@ -32,6 +32,8 @@ EXPORTS = [
     "bppp_reciprocal_verify_batch_sharded_device", "bppp_reciprocal_verify_batch_rlc_sharded_device",
     "bppp_u64_prove_batch_sharded", "bppp_u64_prove_batch_sharded_device",
     "bppp_u64_prove_batch_sec1", "bppp_u64_prove_batch_sec1_device",
+    "bppp_u64_verify_one", "bppp_u64_verify_one_transcript", "bppp_u64_prove_one", "bppp_u64_prove_one_transcript",
+    "bppp_ctx_get_coalesce_stats",
 ]
 
 _lib = None
@@ -161,6 +163,11 @@ def lib():
     L.bppp_reciprocal_verify_batch_rlc_sharded.argtypes = [vp, u8p, sz, sz, sz, sz, vp, vp, sz, sz, sz, vp, vp, C.POINTER(C.c_int32), u8p]
     L.bppp_reciprocal_verify_batch_sharded_device.argtypes = [vp, u8p, sz, sz, sz, sz, pvp, pvp, sz, sz, sz, pvp, pvp, pvp]
     L.bppp_reciprocal_verify_batch_rlc_sharded_device.argtypes = [vp, u8p, sz, sz, sz, sz, pvp, pvp, sz, sz, sz, pvp, pvp, pvp, u8p]
+    L.bppp_u64_verify_one.argtypes = [vp, u8p, sz, vp, vp, vp, vp]
+    L.bppp_u64_verify_one_transcript.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.bppp_u64_prove_one.argtypes = [vp, u8p, sz, C.c_uint64, vp, vp, vp, vp, vp]
+    L.bppp_u64_prove_one_transcript.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, vp]
+    L.bppp_ctx_get_coalesce_stats.argtypes = [vp, i32, C.POINTER(C.c_uint64)]
     L.bppp_strerror.argtypes = [i32]
     L.bppp_strerror.restype = C.c_char_p
     L.bppp_last_error.restype = C.c_char_p

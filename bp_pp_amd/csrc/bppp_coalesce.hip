@@ -1,0 +1,269 @@
+// libbppp_hip.so, host side: the reference's own calling pattern -- ONE proof per call from many threads (u64_proof.rs:42, :57;
+// benches/range_proof.rs:47-50) -- served at batch speed.  bppp_u64_verify_one / bppp_u64_prove_one do not launch anything: they hand
+// their request to the context's front end (coalesce_core.h), whose dispatcher threads run what has gathered as ONE batched call of the
+// device verify / prove sequences (bppp_u64.hip) on contexts that share the caller's tables, and wake each caller with its own row.
+#include <memory>
+
+#include "coalesce_core.h"
+#include "host.h"
+
+using bppp_host::CoalesceShape;
+using bppp_host::Coalescer;
+
+static const size_t SB = BPPP_TRANSCRIPT_STATE_BYTES;
+static const size_t RND_BYTES = 52 * 32;
+
+// One front end = one kind of request (verify or prove) of one context: `lanes` child contexts over the parent's tables (own streams,
+// own workspaces, own device staging), pinned host staging for the rows, and the coalescer that fills and flushes them.
+struct bppp_front {
+    bppp_ctx* parent;
+    bool prove;
+    size_t max;
+    std::vector<bppp_ctx*> lanes;
+    Coalescer<bppp_front> co;
+
+    static CoalesceShape shape_of(bool prove) {
+        CoalesceShape s;
+        if (!prove) {               // in: commitment, proof, transcript | out: accept, status, transcript after verify
+            s.n_in = 3; s.in_stride[0] = 64; s.in_stride[1] = BPPP_U64_PROOF_BYTES; s.in_stride[2] = SB;
+            s.n_out = 3; s.out_stride[0] = 1; s.out_stride[1] = sizeof(int32_t); s.out_stride[2] = SB;
+        } else {                    // in: x, s, the 52 draws, transcript | out: proof, commitment, status, transcript after prove
+            s.n_in = 4; s.in_stride[0] = 8; s.in_stride[1] = 32; s.in_stride[2] = RND_BYTES; s.in_stride[3] = SB;
+            s.n_out = 4; s.out_stride[0] = BPPP_U64_PROOF_BYTES; s.out_stride[1] = 64; s.out_stride[2] = sizeof(int32_t); s.out_stride[3] = SB;
+        }
+        return s;
+    }
+    bppp_front(bppp_ctx* p, bool prove_, size_t max_, long wait_us, int nlanes)
+        : parent(p), prove(prove_), max(max_), co(this, shape_of(prove_), max_, wait_us, nlanes, BPPP_ERR_CLOSED, BPPP_ERR_NOMEM) {}
+
+    // ---- Backend of the coalescer
+    void* alloc_staging(size_t bytes) {
+        void* p = nullptr;
+        if (hipSetDevice(parent->device) != hipSuccess || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return p;
+    }
+    void free_staging(void* p) { (void)hipHostFree(p); }
+    bool start_lane(int lane) { return hipSetDevice(lanes[lane]->device) == hipSuccess; }
+    void stop_lane(int) {}
+
+    // device staging of one lane: the rows' arrays, each at an offset fixed by `max` (grow-only buffer of the lane's context)
+    static int device_staging(bppp_ctx* c, size_t bytes) {
+        if (bytes <= c->io_bytes) return BPPP_OK;
+        if (c->d_io) { (void)hipFree(c->d_io); c->d_io = nullptr; c->io_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->d_io, bytes));
+        c->io_bytes = bytes;
+        return BPPP_OK;
+    }
+    int run(int lane, size_t n, uint8_t* const in[], uint8_t* const out[]) {
+        bppp_ctx* c = lanes[lane];
+        CtxLock lock_(c);
+        const int rc = run_locked(c, n, in, out);
+        // a failed call must not leave copies in flight over staging rows that the next batch is about to overwrite
+        if (rc != BPPP_OK) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->aux_stream); (void)hipGetLastError(); }
+        return rc;
+    }
+    int run_locked(bppp_ctx* c, size_t n, uint8_t* const in[], uint8_t* const out[]) {
+        HIP_TRY(hipSetDevice(c->device));
+        hipStream_t st = c->stream;
+        if (!prove) {
+            const size_t o_c = 0, o_p = align16(o_c + max * 64), o_ti = align16(o_p + max * (size_t)BPPP_U64_PROOF_BYTES), o_a = align16(o_ti + max * SB),
+                         o_s = align16(o_a + max), o_to = align16(o_s + max * sizeof(int32_t)), total = align16(o_to + max * SB);
+            int rc = device_staging(c, total);
+            if (rc != BPPP_OK) return rc;
+            uint8_t* d = c->d_io;
+            HIP_TRY(hipMemcpyAsync(d + o_c, in[0], n * 64, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d + o_p, in[1], n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d + o_ti, in[2], n * SB, hipMemcpyHostToDevice, st));
+            VerifyTranscripts tx = {d + o_ti, n, d + o_to};
+            rc = verify_device_impl(c, nullptr, 0, n, d + o_c, d + o_p, d + o_a, d + o_s, nullptr, nullptr, nullptr, &tx);
+            if (rc != BPPP_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(out[0], d + o_a, n, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out[1], d + o_s, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out[2], d + o_to, n * SB, hipMemcpyDeviceToHost, st));
+        } else {
+            const size_t o_x = 0, o_s = align16(o_x + max * 8), o_r = align16(o_s + max * 32), o_ti = align16(o_r + max * RND_BYTES),
+                         o_p = align16(o_ti + max * SB), o_c = align16(o_p + max * (size_t)BPPP_U64_PROOF_BYTES), o_st = align16(o_c + max * 64),
+                         o_to = align16(o_st + max * sizeof(int32_t)), total = align16(o_to + max * SB);
+            int rc = device_staging(c, total);
+            if (rc != BPPP_OK) return rc;
+            uint8_t* d = c->d_io;
+            HIP_TRY(hipMemcpyAsync(d + o_x, in[0], n * 8, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d + o_s, in[1], n * 32, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d + o_r, in[2], n * RND_BYTES, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(d + o_ti, in[3], n * SB, hipMemcpyHostToDevice, st));
+            VerifyTranscripts tx = {d + o_ti, n, d + o_to};
+            rc = prove_device_impl(c, nullptr, 0, n, d + o_x, d + o_s, d + o_r, d + o_p, d + o_c, d + o_st, &tx);
+            if (rc != BPPP_OK) return rc;
+            HIP_TRY(hipMemcpyAsync(out[0], d + o_p, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out[1], d + o_c, n * 64, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out[2], d + o_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out[3], d + o_to, n * SB, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        return BPPP_OK;
+    }
+
+    // lane contexts + their workspaces for a full batch up front (no allocation on the request path), then the coalescer's threads
+    int start() {
+        const int nl = co.lanes();
+        for (int l = 0; l < nl; l++) {
+            bppp_ctx* ch = nullptr;
+            int rc = bppp_ctx_create_shared(&ch, parent);
+            if (rc != BPPP_OK) return rc;
+            lanes.push_back(ch);
+            CtxLock lock_(ch);
+            if (prove) rc = ensure_prove_capacity(ch, max);
+            else {
+                rc = ensure_capacity(ch, max);
+                // the small-call forms keep up to four sets of window tables per proof (bppp_u64.hip: verify_device_part)
+                const size_t S = (size_t)ch->n_simds;
+                size_t vt = max;
+                if (4 * (max < S ? max : S) > vt) vt = 4 * (max < S ? max : S);
+                if (2 * (max < 4 * S ? max : 4 * S) > vt) vt = 2 * (max < 4 * S ? max : 4 * S);
+                if (rc == BPPP_OK) rc = ensure_vtab_capacity(ch, vt);
+            }
+            if (rc != BPPP_OK) return rc;
+        }
+        return co.start();
+    }
+    ~bppp_front() {
+        co.shutdown();
+        for (bppp_ctx* ch : lanes) bppp_ctx_destroy(ch);
+    }
+};
+
+// The context's front ends, created at the first *_one call and torn down (drained) by bppp_ctx_destroy or by a change of the
+// "coalesce_*" options.  Callers hold a shared_ptr while they are inside, so a teardown never frees a front end under a caller.
+struct bppp_fronts {
+    std::mutex mu;
+    std::shared_ptr<bppp_front> f[2];     // 0 verify, 1 prove
+    bool closed = false;
+};
+
+static bppp_fronts* fronts_of(bppp_ctx* c) {
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    if (!c->fronts) c->fronts = new (std::nothrow) bppp_fronts();
+    return c->fronts;
+}
+static int get_front(bppp_ctx* c, int which, std::shared_ptr<bppp_front>& out) {
+    bppp_fronts* fs = fronts_of(c);
+    if (!fs) return BPPP_ERR_NOMEM;
+    std::lock_guard<std::mutex> lk(fs->mu);
+    if (fs->closed) return BPPP_ERR_CLOSED;
+    if (!fs->f[which]) {
+        std::shared_ptr<bppp_front> f;
+        try {
+            f = std::make_shared<bppp_front>(c, which == 1, (size_t)c->coalesce_max, c->coalesce_us, c->coalesce_lanes);
+        } catch (...) { return BPPP_ERR_NOMEM; }
+        int rc = f->start();
+        if (rc != BPPP_OK) return rc;
+        fs->f[which] = f;
+    }
+    out = fs->f[which];
+    return BPPP_OK;
+}
+// drain and drop the front ends (hidden; bppp_ctx.hip calls it from bppp_ctx_destroy with final = true and from bppp_ctx_set_option)
+void bppp_fronts_teardown(bppp_ctx* c, bool final) {
+    bppp_fronts* fs;
+    {
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        fs = c->fronts;
+    }
+    if (!fs) return;
+    std::shared_ptr<bppp_front> old[2];
+    {
+        std::lock_guard<std::mutex> lk(fs->mu);
+        if (final) fs->closed = true;
+        old[0].swap(fs->f[0]);
+        old[1].swap(fs->f[1]);
+    }
+    for (auto& f : old)
+        if (f) f->co.shutdown();      // drains; returns when no caller is inside.  The object itself goes with its last shared_ptr
+    old[0].reset();
+    old[1].reset();
+    if (final) {
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        delete c->fronts;
+        c->fronts = nullptr;
+    }
+}
+
+static bool state_ok(const uint8_t* st) { return st[200] < BPPP_STROBE_R && st[201] <= BPPP_STROBE_R; }
+
+static int submit_retry(bppp_ctx* c, int which, const void* const in[], void* const out[]) {
+    // a front end torn down by an option change while this caller was on its way in answers CLOSED: take the new one
+    for (int attempt = 0; attempt < 4; attempt++) {
+        std::shared_ptr<bppp_front> f;
+        int rc = get_front(c, which, f);
+        if (rc != BPPP_OK) return rc;
+        rc = f->co.submit(in, out);
+        if (rc != BPPP_ERR_CLOSED) return rc;
+    }
+    return BPPP_ERR_CLOSED;
+}
+
+extern "C" {
+
+int bppp_u64_verify_one_transcript(bppp_ctx* c, uint8_t state[203], const uint8_t commitment[64], const uint8_t proof[928], uint8_t* accept,
+                                   int32_t* status) {
+    if (!c || !state || !commitment || !proof || !accept) return BPPP_ERR_INVALID_ARG;
+    if (c->ng != 16 || c->nh != 32 || !state_ok(state)) return BPPP_ERR_INVALID_ARG;
+    const void* in[4] = {commitment, proof, state, nullptr};
+    void* out[4] = {accept, status, state, nullptr};
+    return submit_retry(c, 0, in, out);
+}
+int bppp_u64_verify_one(bppp_ctx* c, const uint8_t* label, size_t label_len, const uint8_t commitment[64], const uint8_t proof[928],
+                        uint8_t* accept, int32_t* status) {
+    if (!c || (!label && label_len) || !commitment || !proof || !accept) return BPPP_ERR_INVALID_ARG;
+    if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
+    uint8_t st[SB];
+    int rc = bppp_transcript_new(label, label_len, st);      // Transcript::new(label) on the host: one Keccak permutation
+    if (rc != BPPP_OK) return rc;
+    const void* in[4] = {commitment, proof, st, nullptr};
+    void* out[4] = {accept, status, nullptr, nullptr};
+    return submit_retry(c, 0, in, out);
+}
+int bppp_u64_prove_one_transcript(bppp_ctx* c, uint8_t state[203], uint64_t x, const uint8_t s[32], const uint8_t* rnd, uint8_t proof[928],
+                                  uint8_t commitment[64], int32_t* status) {
+    if (!c || !state || !s || !rnd || !proof || !commitment) return BPPP_ERR_INVALID_ARG;
+    if (c->ng != 16 || c->nh != 32 || !state_ok(state)) return BPPP_ERR_INVALID_ARG;
+    const void* in[4] = {&x, s, rnd, state};
+    void* out[4] = {proof, commitment, status, state};
+    return submit_retry(c, 1, in, out);
+}
+int bppp_u64_prove_one(bppp_ctx* c, const uint8_t* label, size_t label_len, uint64_t x, const uint8_t s[32], const uint8_t* rnd,
+                       uint8_t proof[928], uint8_t commitment[64], int32_t* status) {
+    if (!c || (!label && label_len) || !s || !rnd || !proof || !commitment) return BPPP_ERR_INVALID_ARG;
+    if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
+    uint8_t st[SB];
+    int rc = bppp_transcript_new(label, label_len, st);
+    if (rc != BPPP_OK) return rc;
+    const void* in[4] = {&x, s, rnd, st};
+    void* out[4] = {proof, commitment, status, nullptr};
+    return submit_retry(c, 1, in, out);
+}
+int bppp_ctx_get_coalesce_stats(bppp_ctx* c, int which, uint64_t out[8]) {
+    if (!c || !out || which < 0 || which > 1) return BPPP_ERR_INVALID_ARG;
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    bppp_fronts* fs;
+    {
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        fs = c->fronts;
+    }
+    if (!fs) return BPPP_OK;
+    std::shared_ptr<bppp_front> f;
+    {
+        std::lock_guard<std::mutex> lk(fs->mu);
+        f = fs->f[which];
+    }
+    if (!f) return BPPP_OK;
+    const bppp_host::CoalesceStats s = f->co.stats();
+    out[0] = s.requests; out[1] = s.batches; out[2] = s.largest_batch; out[3] = s.sealed_full; out[4] = s.sealed_deadline;
+    out[5] = s.run_us; out[6] = s.fill_wait_us;
+    return BPPP_OK;
+}
+
+}  // extern "C"

@@ -38,6 +38,7 @@ const char* bppp_strerror(int code) {
         case BPPP_ERR_ENCODING: return "generator is not a valid secp256k1 point";
         case BPPP_ERR_NOMEM: return "out of memory";
         case BPPP_ERR_RCCL: return "RCCL unavailable or an RCCL call failed";
+        case BPPP_ERR_CLOSED: return "the context is being destroyed";
         default: return "unknown error";
     }
 }
@@ -129,6 +130,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
 
 void bppp_ctx_destroy(bppp_ctx* c) {
     if (!c) return;
+    bppp_fronts_teardown(c, true);      // single-proof callers still inside complete first; the front ends' contexts borrow this one's tables
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& tl : c->pending) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); }
@@ -179,6 +181,18 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
     if (std::strcmp(name, "max_batch") == 0) {
         if (value < 1024 || (value & 63)) return BPPP_ERR_INVALID_ARG;
         c->max_batch = (size_t)value;
+        return BPPP_OK;
+    }
+    // the single-proof front end (bppp_u64_verify_one / bppp_u64_prove_one); a change drains the running front ends, the next call
+    // starts new ones
+    if (std::strcmp(name, "coalesce_max") == 0 || std::strcmp(name, "coalesce_us") == 0 || std::strcmp(name, "coalesce_lanes") == 0) {
+        const char k = name[9];      // 'm' / 'u' / 'l'
+        if ((k == 'm' && (value < 1 || value > 65536)) || (k == 'u' && (value < 0 || value > 1000000)) || (k == 'l' && (value < 1 || value > 8)))
+            return BPPP_ERR_INVALID_ARG;
+        bppp_fronts_teardown(c, false);
+        if (k == 'm') c->coalesce_max = value;
+        else if (k == 'u') c->coalesce_us = value;
+        else c->coalesce_lanes = (int)value;
         return BPPP_OK;
     }
     if (std::strcmp(name, "host_chunk") == 0) {

@@ -109,6 +109,10 @@ struct bppp_ctx {
     bool timing = false;
     bool generic_slow_rounds = false, no_lane_groups = false, no_small = false, no_split = false, generic_u64_shape = false;
     int fb_one_lane_mode = -1;   // diagnostic BPPP_FB_ONE_LANE: 1 = one lane per proof in the u64 verifier's fixed-base kernels at every size, 0 = never, unset = by size   // diagnostics, read from the environment once at context creation
+    // single-proof front end (bppp_coalesce.hip): created at the first *_one call; options "coalesce_max" / "coalesce_us" / "coalesce_lanes"
+    struct bppp_fronts* fronts = nullptr;
+    long coalesce_max = 1024, coalesce_us = 100;
+    int coalesce_lanes = 2;
     std::vector<TimedLaunch> pending;
     std::vector<hipEvent_t> event_pool;
     double total_ms[K_COUNT] = {0};
@@ -333,6 +337,9 @@ static inline int check_device(int device) {
     }
     return BPPP_OK;
 }
+
+// bppp_coalesce.hip: drain and drop the context's single-proof front ends (final: refuse later *_one calls with BPPP_ERR_CLOSED)
+void bppp_fronts_teardown(bppp_ctx* c, bool final);
 
 // ---- launch sequences used across translation units (hidden symbols; C linkage only because their definitions sit inside the
 //      extern "C" blocks of the entry points they serve)

@@ -118,6 +118,39 @@ class U64RangeProofProtocol:
         acc, _ = self.verify_batch(_as_u8(v, (1, 64)), _as_u8(proof, (1, U64_PROOF_BYTES)), label)
         return bool(acc[0])
 
+    def verify_one(self, v: bytes, proof: bytes, transcript) -> Tuple[bool, int]:
+        """The reference's own call -- ONE proof, from any number of threads at once (u64_proof.rs:42: `verify(&self, v, proof, t)`) --
+        through the coalescing front end (include/bppp.h: bppp_u64_verify_one[_transcript]): the request joins whatever other
+        threads have submitted and runs as part of one batched GPU call.  `transcript`: a label (bytes: Transcript::new(label)) or
+        a bp_pp_amd.transcript.Transcript, which is advanced in place as the reference's `t: &mut Transcript` is.
+        Returns (accept, status).  Blocking; ctypes releases the GIL while it waits."""
+        acc, st = C.c_uint8(0), C.c_int32(0)
+        L = _capi.lib()
+        if isinstance(transcript, (bytes, bytearray)):
+            _capi.check(L.bppp_u64_verify_one(self._ctx, bytes(transcript), len(transcript), bytes(v), bytes(proof), C.byref(acc), C.byref(st)))
+        else:
+            _capi.check(L.bppp_u64_verify_one_transcript(self._ctx, transcript._buf, bytes(v), bytes(proof), C.byref(acc), C.byref(st)))
+        return bool(acc.value), int(st.value)
+
+    def prove_one(self, x: int, s: bytes, transcript, rnd: bytes) -> Tuple[bytes, bytes, int]:
+        """`prove(&self, x, s, t, rng)` (u64_proof.rs:57) for ONE value through the coalescing front end; `rnd` = the 52 draws.
+        Returns (proof 928 B, commitment 64 B, status)."""
+        if len(rnd) != 52 * 32 or len(s) != 32:
+            raise ValueError("s is 32 bytes, rnd 52 x 32 bytes")
+        proof, com, st = C.create_string_buffer(U64_PROOF_BYTES), C.create_string_buffer(64), C.c_int32(0)
+        L = _capi.lib()
+        if isinstance(transcript, (bytes, bytearray)):
+            _capi.check(L.bppp_u64_prove_one(self._ctx, bytes(transcript), len(transcript), x, bytes(s), bytes(rnd), proof, com, C.byref(st)))
+        else:
+            _capi.check(L.bppp_u64_prove_one_transcript(self._ctx, transcript._buf, x, bytes(s), bytes(rnd), proof, com, C.byref(st)))
+        return proof.raw, com.raw, int(st.value)
+
+    def coalesce_stats(self, which: str = "verify") -> dict:
+        """Counters of the single-proof front end (bppp_ctx_get_coalesce_stats)."""
+        out = (C.c_uint64 * 8)()
+        _capi.check(_capi.lib().bppp_ctx_get_coalesce_stats(self._ctx, 1 if which == "prove" else 0, out))
+        return dict(zip(("requests", "batches", "largest_batch", "sealed_full", "sealed_deadline", "run_us", "fill_wait_us"), (int(v) for v in out)))
+
     def verify_batch(self, commitments, proofs, label: bytes) -> Tuple[np.ndarray, np.ndarray]:
         """Host buffers in, host buffers out.  Returns (accept[n] u8, status[n] i32)."""
         commitments = _as_u8(commitments, (-1, 64))
@@ -257,7 +290,8 @@ class U64RangeProofProtocol:
 
     def set_option(self, name: str, value: int) -> None:
         """include/bppp.h: bppp_ctx_set_option ("rlc_superchunk": 0 = bucket stage off, else 64..8192; "host_chunk": proofs per
-        pipelined upload chunk of the host-buffer verify calls, 0 = upload first)."""
+        pipelined upload chunk of the host-buffer verify calls, 0 = upload first; "coalesce_max" / "coalesce_us" / "coalesce_lanes":
+        the single-proof front end of verify_one / prove_one)."""
         _capi.check(_capi.lib().bppp_ctx_set_option(self._ctx, name.encode(), int(value)))
 
     def synchronize(self) -> None:

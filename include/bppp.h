@@ -45,6 +45,8 @@ extern "C" {
 #define BPPP_ERR_HIP (-3)         /* a HIP call failed; see bppp_last_error() */
 #define BPPP_ERR_ENCODING (-4)    /* a generator is not a valid curve point */
 #define BPPP_ERR_NOMEM (-5)
+/* BPPP_ERR_RCCL (-6) is defined with the device groups below */
+#define BPPP_ERR_CLOSED (-7)      /* a single-proof call (bppp_u64_*_one) arrived while its context was being destroyed */
 
 /* per-proof status written by the verify kernels (0 = fine) */
 #define BPPP_ST_BAD_ENCODING 1 /* off-curve point / coordinate >= p / scalar >= n: k256 deserialisation would fail */
@@ -87,7 +89,9 @@ BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
  * chunk k + 1 on a second stream while chunk k is being verified (proofs are independent: the results are those of one call) --
  * a multiple of 64, >= 1024; default 131072 (one full grid of the per-proof kernels); 0 = upload the whole batch first.  "max_batch": the u64 verify entry
  * points run a batch of more than max_batch proofs as consecutive parts of max_batch on the same stream, which bounds the per-proof
- * workspace (about 30 KB per proof) whatever n is -- a multiple of 64, >= 1024; default 2097152 (63 GB of workspace). */
+ * workspace (about 30 KB per proof) whatever n is -- a multiple of 64, >= 1024; default 2097152 (63 GB of workspace).
+ * "coalesce_max" (1 .. 65536, default 1024), "coalesce_us" (0 .. 1000000, default 100), "coalesce_lanes" (1 .. 8, default 2): the
+ * single-proof front end below (bppp_u64_verify_one / bppp_u64_prove_one); changing one drains the running front end. */
 BPPP_API int bppp_ctx_set_option(bppp_ctx* ctx, const char* name, long value);
 /* Block the calling host thread until everything queued by this context (current stream + its helper stream) has finished. */
 BPPP_API int bppp_ctx_synchronize(bppp_ctx* ctx);
@@ -164,6 +168,39 @@ BPPP_API int bppp_u64_prove_batch_sec1(bppp_ctx* ctx, const uint8_t* label, size
                                        uint8_t* proofs525 /* n x 525 */, uint8_t* commitments33 /* n x 33 */, int32_t* status /* n or NULL */);
 BPPP_API int bppp_u64_prove_batch_sec1_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, const void* d_x,
                                               const void* d_s, const void* d_rnd, void* d_proofs525, void* d_commitments33, void* d_status);
+
+/* ---- the reference's own calling pattern: ONE proof per call, from as many host threads as the caller likes ----
+ * `U64RangeProofProtocol::verify(&self, v, proof, t) -> bool` (u64_proof.rs:42-54) and `::prove(&self, x, s, t, rng) -> Proof`
+ * (u64_proof.rs:57-82) take one proof; the crate's types are Send + Sync, so a service calls them from N threads at once
+ * (benches/range_proof.rs:47-50 is the single-threaded form).  A GPU call of one proof costs a full dependent chain (2.3 ms) however
+ * empty the chip is, so these entry points do not launch anything themselves: the request joins the context's open batch and the
+ * calling thread sleeps; dispatcher threads of the context run what has gathered -- everything that arrived within "coalesce_us"
+ * microseconds of the batch's first request, or "coalesce_max" requests, whichever comes first -- as ONE call of the batched
+ * verifier / prover on pinned staging, up to "coalesce_lanes" batches overlapping on the GPU, and wake each caller with its own row.
+ * The answer is exactly the batched entry point's for that row (same accept bit, same status, same bytes), whoever shared the batch:
+ * every row has its own transcript, so callers may use different labels or transcripts, and a malformed proof flags only itself.
+ * Only a failure of the batched call as a whole (BPPP_ERR_NOMEM, BPPP_ERR_HIP) is shared: it is every caller's return code.
+ * Blocking, callable from any number of threads on the same context (the context lock is NOT held while waiting).  The front end
+ * (dispatcher threads, `coalesce_lanes` contexts over this context's tables, staging for coalesce_max rows) is created by the first
+ * call.  bppp_ctx_destroy drains it: calls already inside complete normally, calls arriving later return BPPP_ERR_CLOSED.
+ *   label form:       the proof's transcript starts as Transcript::new(label) (what every call site of the reference does);
+ *   transcript form:  `state` is the caller's merlin transcript (203 bytes, see bppp_u64_verify_batch_transcript below), advanced in
+ *                     place exactly as the reference's `t: &mut Transcript` is (left untouched when the call fails or the proof is
+ *                     flagged BPPP_ST_BAD_ENCODING); a state merlin cannot be in is refused with BPPP_ERR_INVALID_ARG.
+ * *accept = 1 iff the reference's verify returns true; *status (optional) = BPPP_ST_* flags. */
+BPPP_API int bppp_u64_verify_one(bppp_ctx* ctx, const uint8_t* label, size_t label_len, const uint8_t commitment[64],
+                                 const uint8_t proof[928], uint8_t* accept, int32_t* status /* or NULL */);
+BPPP_API int bppp_u64_verify_one_transcript(bppp_ctx* ctx, uint8_t state[203], const uint8_t commitment[64], const uint8_t proof[928],
+                                            uint8_t* accept, int32_t* status /* or NULL */);
+/* rnd: the 52 scalars of bppp_u64_prove_batch (52 x 32 bytes, the reference's draw order); proof and commitment = x*g + s*h_vec[0] out. */
+BPPP_API int bppp_u64_prove_one(bppp_ctx* ctx, const uint8_t* label, size_t label_len, uint64_t x, const uint8_t s[32],
+                                const uint8_t* rnd /* 52 x 32 */, uint8_t proof[928], uint8_t commitment[64], int32_t* status /* or NULL */);
+BPPP_API int bppp_u64_prove_one_transcript(bppp_ctx* ctx, uint8_t state[203], uint64_t x, const uint8_t s[32], const uint8_t* rnd /* 52 x 32 */,
+                                           uint8_t proof[928], uint8_t commitment[64], int32_t* status /* or NULL */);
+/* Counters of the front end since it was created: out = {requests, batches, largest batch, batches sealed full, batches sealed by the
+ * deadline, microseconds its dispatchers spent inside batched calls, microseconds they waited for callers' row copies, 0}; which = 0
+ * verify, 1 prove.  All zero before the first call. */
+BPPP_API int bppp_ctx_get_coalesce_stats(bppp_ctx* ctx, int which, uint64_t out[8]);
 
 /* U64RangeProofProtocol::commit_value (u64_proof.rs:37-39): out[i] = x[i]*g + s[i]*h_vec[0], host pointers. */
 BPPP_API int bppp_u64_commit_value_batch(bppp_ctx* ctx, size_t n, const uint64_t* x, const uint8_t* s /* n x 32 */,

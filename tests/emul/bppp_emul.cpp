@@ -1165,3 +1165,85 @@ int emul_group_prove(int G, int fail_rank, const uint8_t* table, int W, const ui
     return res.code;
 }
 }
+
+// ------------------------------------------------------------------ the single-proof front end (csrc/coalesce_core.h) over the emulator
+// The same Coalescer template libbppp_hip.so instantiates (bppp_coalesce.hip), with malloc staging and the host build of the device
+// code as the batched call: `threads` callers submit the requests i = t, t + threads, ... one after the other, exactly like the
+// reference's one-proof-per-call pattern from many threads.  kind 0: verify (rows: commitment, proof, transcript -> accept, status,
+// transcript out); kind 1: prove (rows: x, s, rnd, transcript -> proof, commitment, status, transcript out).
+//   fail_batch >= 0         the fail_batch-th batched call (in start order) fails as a whole with NOMEM: its callers, and only they,
+//                           get -5 and their outputs stay untouched
+//   shutdown_after_ms >= 0  the main thread calls shutdown() that long after the callers started, with callers still submitting:
+//                           every caller returns -- 0 with its proper outputs (it was drained) or -7 (it came too late)
+//   run_delay_ms            extra time per batched call (stands for the GPU's latency, so that requests gather behind it)
+#include "../../bp_pp_amd/csrc/coalesce_core.h"
+namespace {
+const int EMUL_ERR_CLOSED = -7;
+struct EmulFront {
+    const uint8_t* table; int W; int kind; int fail_batch; int run_delay_ms;
+    std::atomic<int> batch_no{0};
+    std::atomic<int> live_staging{0};
+    std::mutex sizes_mu;
+    std::vector<size_t> batch_sizes;
+    void* alloc_staging(size_t bytes) { live_staging++; return std::malloc(bytes ? bytes : 1); }
+    void free_staging(void* p) { live_staging--; std::free(p); }
+    bool start_lane(int) { return true; }
+    void stop_lane(int) {}
+    int run(int, size_t n, uint8_t* const in[], uint8_t* const out[]) {
+        const int no = batch_no.fetch_add(1);
+        { std::lock_guard<std::mutex> lk(sizes_mu); batch_sizes.push_back(n); }
+        if (run_delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(run_delay_ms));
+        if (no == fail_batch) return EMUL_ERR_NOMEM;
+        if (kind == 0)
+            return emul_u64_verify_batch_transcript(table, W, n, in[2], n, in[0], in[1], out[0], (int32_t*)out[1], out[2]);
+        return emul_u64_prove_batch_transcript(table, W, n, in[3], n, (const uint64_t*)in[0], in[1], in[2], out[0], out[1], (int32_t*)out[2], out[3]);
+    }
+};
+}  // namespace
+extern "C" int emul_coalesce_run(int kind, const uint8_t* table, int W, int threads, size_t nreq, const uint8_t* const* in_arrays,
+                                 uint8_t* const* out_arrays, int* rcs, size_t max_batch, long wait_us, int lanes, int fail_batch,
+                                 int shutdown_after_ms, int run_delay_ms, uint64_t stats_out[5], size_t* batch_sizes_out, size_t batch_sizes_cap,
+                                 int* live_staging_after) {
+    EmulFront be{table, W, kind, fail_batch, run_delay_ms};
+    bppp_host::CoalesceShape sh;
+    if (kind == 0) {
+        sh.n_in = 3; sh.in_stride[0] = 64; sh.in_stride[1] = 928; sh.in_stride[2] = 203;
+        sh.n_out = 3; sh.out_stride[0] = 1; sh.out_stride[1] = 4; sh.out_stride[2] = 203;
+    } else {
+        sh.n_in = 4; sh.in_stride[0] = 8; sh.in_stride[1] = 32; sh.in_stride[2] = 52 * 32; sh.in_stride[3] = 203;
+        sh.n_out = 4; sh.out_stride[0] = 928; sh.out_stride[1] = 64; sh.out_stride[2] = 4; sh.out_stride[3] = 203;
+    }
+    {
+        bppp_host::Coalescer<EmulFront> co(&be, sh, max_batch, wait_us, lanes, EMUL_ERR_CLOSED, EMUL_ERR_NOMEM);
+        int rc = co.start();
+        if (rc != 0) return rc;
+        std::vector<std::thread> th;
+        for (int t = 0; t < threads; t++)
+            th.emplace_back([&, t]() {
+                for (size_t i = (size_t)t; i < nreq; i += (size_t)threads) {
+                    const void* in[4];
+                    void* out[4];
+                    for (int k = 0; k < sh.n_in; k++) in[k] = in_arrays[k] + i * sh.in_stride[k];
+                    for (int k = 0; k < sh.n_out; k++) out[k] = out_arrays[k] + i * sh.out_stride[k];
+                    rcs[i] = co.submit(in, out);
+                }
+            });
+        if (shutdown_after_ms >= 0) {
+            std::this_thread::sleep_for(std::chrono::milliseconds(shutdown_after_ms));
+            co.shutdown();
+        }
+        for (auto& t : th) t.join();
+        const bppp_host::CoalesceStats s = co.stats();
+        stats_out[0] = s.requests; stats_out[1] = s.batches; stats_out[2] = s.largest_batch; stats_out[3] = s.sealed_full; stats_out[4] = s.sealed_deadline;
+        co.shutdown();
+        // after shutdown a submission is refused, not queued
+        const void* in[4];
+        void* out[4];
+        for (int k = 0; k < sh.n_in; k++) in[k] = in_arrays[k];
+        for (int k = 0; k < sh.n_out; k++) out[k] = nullptr;
+        if (co.submit(in, out) != EMUL_ERR_CLOSED) return -99;
+    }
+    for (size_t i = 0; i < be.batch_sizes.size() && i < batch_sizes_cap; i++) batch_sizes_out[i] = be.batch_sizes[i];
+    *live_staging_after = be.live_staging.load();
+    return (int)be.batch_sizes.size();
+}

@@ -61,4 +61,6 @@ def load():
     L.emul_straus_split.argtypes = [i32, i32, cp, cp, vp, vp, vp]
     L.emul_set_prove_next_by_msm.argtypes = [i32]
     L.emul_set_prove_next_by_msm.restype = None
+    pvp = C.POINTER(vp)
+    L.emul_coalesce_run.argtypes = [i32, vp, i32, i32, sz, pvp, pvp, vp, sz, C.c_long, i32, i32, i32, i32, vp, vp, sz, vp]
     return L

@@ -1,32 +1,99 @@
-"""Aggregate rate of SINGLE-proof verify calls from T host threads, each with its own context over one set of tables
-(bppp_ctx_create_shared) -- a service with a thread per request.  usage: python tools/concurrent_callers.py"""
-import os, sys, threading, time
-sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
+"""The reference's calling pattern at GPU speed: T host threads, each making SINGLE-proof verify calls one after the other
+(u64_proof.rs:42; a service with a thread per request).  Native threads (tools/cc_callers.c), so the numbers are the library's, not
+the interpreter's.
+
+Every thread calls bppp_u64_verify_one on ONE context: the coalescing front end (csrc/coalesce_core.h) gathers the callers' requests
+into batched GPU calls.  (Round 3's pattern -- bppp_u64_verify_batch with n = 1, a context per thread over shared tables -- got 601
+verifies/s at 64 threads: profiles/r03_cc_concurrent_callers.txt.)
+
+usage: python tools/concurrent_callers.py [--threads 1,8,64,256,1024] [--calls 0] [--us 100] [--max 1024] [--lanes 2] [--json out]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tools")]
 import numpy as np
-import torch, bench
-from bp_pp_amd import U64RangeProofProtocol, synth
-gens, g, gv, hv = bench.load_generators()
-base = U64RangeProofProtocol(g, gv, hv, device=0)
-dV, dP, expect, _ = bench.make_resident_batch(torch, base, synth, 0, 4096)
-V, P = dV.cpu().numpy(), dP.cpu().numpy()
-for T in (1, 2, 4, 8, 16, 32, 64):
-    ctxs = [base] + [base.clone_shared() for _ in range(T - 1)]
-    calls, bad = 100, []
-    def worker(i):
-        c = ctxs[i]
-        for k in range(calls):
-            j = (i * calls + k) % 4096
-            acc, _ = c.verify_batch(V[j:j + 1], P[j:j + 1], synth.LABEL)
-            if int(acc[0]) != int(expect[j]):
-                bad.append((i, k))
-    for c in ctxs:                                   # warm every context (workspace allocation)
-        c.verify_batch(V[:1], P[:1], synth.LABEL)
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(T)]
-    t0 = time.perf_counter()
-    for t in th: t.start()
-    for t in th: t.join()
-    dt = time.perf_counter() - t0
-    print(f"threads {T:3d}: {T * calls / dt:9.0f} single-proof verifies/s  ({dt / calls * 1e3:6.2f} ms per call per thread)  wrong {len(bad)}", flush=True)
-    for c in ctxs[1:]:
-        c.close()
-base.close()
+import hostinfo
+
+
+def build_harness() -> C.CDLL:
+    src, so = os.path.join(ROOT, "tools", "cc_callers.c"), os.path.join(ROOT, "tools", "libcc_callers.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-pthread", "-o", so + ".tmp", src])
+        os.replace(so + ".tmp", so)
+    H = C.CDLL(so)
+    vp = C.c_void_p
+    H.cc_run.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_char_p, C.c_size_t, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, C.POINTER(C.c_double),
+                         C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    return H
+
+
+def run_callers(H, fn, ctxs, label, V, P, expect, threads, calls):
+    """-> dict(rate, p50/p99/max latency in ms, wrong, failed)."""
+    lat = np.zeros(threads * calls, np.float64)
+    el, wrong, failed = C.c_double(0), C.c_long(0), C.c_long(0)
+    arr = (C.c_void_p * len(ctxs))(*ctxs)
+    rc = H.cc_run(C.cast(fn, C.c_void_p), arr, len(ctxs), label, len(label), V.ctypes.data, P.ctypes.data, expect.ctypes.data, V.shape[0], threads,
+                  calls, lat.ctypes.data, C.byref(el), C.byref(wrong), C.byref(failed))
+    if rc != 0:
+        raise RuntimeError("could not start the caller threads")
+    return {"threads": threads, "calls_per_thread": calls, "verifies_per_s": round(threads * calls / el.value, 1),
+            "latency_ms": {"mean": round(float(lat.mean()) / 1e3, 3), "p50": round(float(np.percentile(lat, 50)) / 1e3, 3),
+                           "p90": round(float(np.percentile(lat, 90)) / 1e3, 3), "p99": round(float(np.percentile(lat, 99)) / 1e3, 3),
+                           "max": round(float(lat.max()) / 1e3, 3)},
+            "wrong": int(wrong.value), "failed": int(failed.value)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--threads", default="1,8,64,256,1024")
+    ap.add_argument("--calls", type=int, default=0, help="calls per thread (0: enough for ~1-2 s per point)")
+    ap.add_argument("--us", type=int, default=-1)
+    ap.add_argument("--max", type=int, default=-1)
+    ap.add_argument("--lanes", type=int, default=-1)
+    ap.add_argument("--pool", type=int, default=4096)
+    ap.add_argument("--json", default="")
+    a = ap.parse_args()
+    H = build_harness()
+    import torch
+    import bench
+    from bp_pp_amd import U64RangeProofProtocol, _capi, synth
+    gens, g, gv, hv = bench.load_generators()
+    base = U64RangeProofProtocol(g, gv, hv, device=0)
+    dV, dP, expect, _ = bench.make_resident_batch(torch, base, synth, 0, a.pool)
+    V, P = np.ascontiguousarray(dV.cpu().numpy()), np.ascontiguousarray(dP.cpu().numpy())
+    expect = np.ascontiguousarray(np.asarray(expect, dtype=np.uint8))
+    for name, v in (("coalesce_us", a.us), ("coalesce_max", a.max), ("coalesce_lanes", a.lanes)):
+        if v >= 0:
+            base.set_option(name, v)
+    L = _capi.lib()
+    rows = []
+    print(json.dumps({"host": hostinfo.summary()}), flush=True)
+    for T in [int(t) for t in a.threads.split(",")]:
+        calls = a.calls or max(20, min(400, 60000 // T))
+        run_callers(H, L.bppp_u64_verify_one, [base._ctx.value], synth.LABEL, V, P, expect, T, 3)          # warm: front end, workspaces
+        before, thr0 = base.coalesce_stats(), hostinfo.throttle_stats()
+        r = run_callers(H, L.bppp_u64_verify_one, [base._ctx.value], synth.LABEL, V, P, expect, T, calls)
+        after, thr1 = base.coalesce_stats(), hostinfo.throttle_stats()
+        nb = after["batches"] - before["batches"]
+        r["mean_batch"] = round((after["requests"] - before["requests"]) / max(1, nb), 1)
+        r["batched_call_ms"] = round((after["run_us"] - before["run_us"]) / max(1, nb) / 1e3, 3)
+        r["fill_wait_ms"] = round((after["fill_wait_us"] - before["fill_wait_us"]) / max(1, nb) / 1e3, 3)
+        r["cgroup_throttled"] = {"periods": thr1["nr_throttled"] - thr0["nr_throttled"], "seconds": round(thr1["throttled_s"] - thr0["throttled_s"], 3)}
+        r["mode"] = "one"
+        rows.append(r)
+        print(json.dumps(r), flush=True)
+    base.close()
+    if a.json:
+        with open(a.json, "w") as f:
+            json.dump({"tool": "tools/concurrent_callers.py", "options": {"coalesce_us": a.us, "coalesce_max": a.max, "coalesce_lanes": a.lanes},
+                       "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default"), "host": hostinfo.summary(), "rows": rows}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
