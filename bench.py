@@ -44,10 +44,19 @@ DATASHEET_SIMD_HZ = 1024 * 2.4e9
 _SESSION_RATES = None
 
 
-def session_rates():
-    """Issue rates of this box, measured now (a child process: tools/ratebench, ~1 s).  None if the tool is missing or fails --
-    roofline_valu then reports the datasheet ceiling only; it never falls back to another session's numbers."""
+def under_profiler():
+    """rocprofv3 preloads its tool library into this process (and into any child it starts): no child processes then."""
+    return "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ)
+
+
+def session_rates(measure=False):
+    """Issue rates of this box (a child process: tools/ratebench, ~1 s).  Measured ONLY when main() asks for it -- at the very top,
+    before this process has imported torch or made any HIP call, so the child is started from a process that has never touched the
+    GPU -- and never under rocprofv3; every later call returns what was measured then.  None if the tool is missing, fails or was
+    skipped: roofline_valu then reports the datasheet ceiling only; it never falls back to another session's numbers."""
     global _SESSION_RATES
+    if _SESSION_RATES is None and not measure:
+        _SESSION_RATES = {}
     if _SESSION_RATES is None:
         import subprocess
         exe = os.path.join(ROOT, "tools", "ratebench")
@@ -57,6 +66,32 @@ def session_rates():
         except Exception:
             _SESSION_RATES = {}
     return _SESSION_RATES or None
+
+
+_BUILD_ID = None
+
+
+def build_id():
+    """SHA-256 of the device code of the library this process loads (bp_pp_amd/_build.py: device_code_sha256)."""
+    global _BUILD_ID
+    if _BUILD_ID is None:
+        from bp_pp_amd import _build
+        _BUILD_ID = _build.device_code_sha256(os.environ.get("BPPP_LIB", _build.SO)) or "unknown"
+    return _BUILD_ID
+
+
+def pmc_file(name):
+    """A committed PMC summary (profiles/pmc_traffic.json, profiles/pmc_valu.json) -- or None when it was collected on other kernels
+    than the ones being timed: tools/pmc_summarize.py / tools/sq_summarize.py stamp the summaries with the device code's hash."""
+    d = _load_json(os.path.join(ROOT, "profiles", name))
+    if not d:
+        return None
+    have = d.get("code_object_sha256") or (d.get("_meta") or {}).get("code_object_sha256")
+    return d if have == build_id() else None
+
+
+def pmc_matches_build():
+    return {"traffic": pmc_file("pmc_traffic.json") is not None, "valu": pmc_file("pmc_valu.json") is not None, "code_object_sha256": build_id()}
 
 
 def _load_json(path):
@@ -89,7 +124,9 @@ def valu_roofline(kernel, avg_ms, n_proofs, lanes_per_proof):
     count of the shipped code object (tools/isa_mix.py -> profiles/isa_mix.json) printed beside it as a cross-check.  Two peaks:
     datasheet (1024 SIMDs x 2.4 GHz, 2 cycles per full-rate and 4 per half-rate wave64 instruction) and this box's own
     micro-benchmark, run by this process (session_rates: tools/ratebench, which also reports the shader clock the chip held)."""
-    pv = _load_json(os.path.join(ROOT, "profiles", "pmc_valu.json")) or {}
+    pv = pmc_file("pmc_valu.json")
+    if pv is None:
+        return None          # no counters for THIS build: say nothing rather than quote another build's
     mix = _load_json(os.path.join(ROOT, "profiles", "isa_mix.json")) or {}
     kernel, lanes_per_proof = launched_kernel(kernel, n_proofs, lanes_per_proof)
     kv = pv.get(kernel, {})
@@ -120,7 +157,7 @@ def valu_roofline(kernel, avg_ms, n_proofs, lanes_per_proof):
 def pmc_traffic(kernel, n_proofs):
     """Measured HBM bytes per launch of `kernel` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, corrected
     as tools/pmc_summarize.py documents), scaled linearly if the committed pass ran a different batch size."""
-    tr = _load_json(os.path.join(ROOT, "profiles", "pmc_traffic.json")) or {}
+    tr = pmc_file("pmc_traffic.json") or {}
     kernel = launched_kernel(kernel, n_proofs, 1)[0]
     k = (tr.get("kernels") or {}).get(kernel) or {}
     b = k.get("hbm_bytes_per_launch")
@@ -128,6 +165,22 @@ def pmc_traffic(kernel, n_proofs):
         return None
     n_ref = k.get("proofs_per_launch") or tr.get("proofs_per_launch") or 65536
     return b * (n_proofs / n_ref)      # the PMC pass of this kernel ran n_ref proofs per launch
+
+
+def pmc_traffic_per_step(kernel_times, steps, n_proofs):
+    """Counter bytes of ALL kernels of one step (each kernel's measured bytes per launch x its launches per step), or None when a
+    kernel of the step has no counters for this build."""
+    total = 0.0
+    for k, v in kernel_times.items():
+        if not v["launches"]:
+            continue
+        b = pmc_traffic(k, n_proofs)
+        if b is None:
+            if k in ("k_verify_accept",):      # (a few bytes per proof; absent from some passes)
+                continue
+            return None
+        total += b * v["launches"] / steps
+    return total
 
 
 FB_KERNELS = ("k_verify_c0_fixed", "k_verify_final_check", "k_prove_msm", "k_wnla_msm", "k_recip_c0_fixed")
@@ -207,17 +260,49 @@ def make_resident_batch(torch, proto, workload, lo, hi, corrupt_every=1024, slic
     return dV, dP, expect, t_prove
 
 
+def host_summary():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import hostinfo
+    return hostinfo.summary()
+
+
+def concurrent_callers(proto, label, V, P, expect, thread_counts=(64, 1024)):
+    """The reference's calling pattern -- ONE proof per call, T native host threads (tools/cc_callers.c) -- through the library's
+    coalescing front end (bppp_u64_verify_one): aggregate rate and per-call latency.  Each point runs ~0.5 s."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import concurrent_callers as cc
+    import hostinfo
+    from bp_pp_amd import _capi
+    import numpy as np
+    H = cc.build_harness()
+    L = _capi.lib()
+    V, P, expect = np.ascontiguousarray(V), np.ascontiguousarray(P), np.ascontiguousarray(np.asarray(expect, dtype=np.uint8))
+    out = {"unit": "verifies/s", "entry_point": "bppp_u64_verify_one", "pool_proofs": int(V.shape[0]),
+           "note": "T threads each calling verify for ONE proof in a loop (u64_proof.rs:42 from many threads); default coalesce_* options; "
+                   "round 3, same pattern through one-proof batched calls: 601 verifies/s at 64 threads"}
+    for T in thread_counts:
+        cc.run_callers(H, L.bppp_u64_verify_one, [proto._ctx.value], label, V, P, expect, T, 3)
+        thr0, st0 = hostinfo.throttle_stats(), proto.coalesce_stats()
+        r = cc.run_callers(H, L.bppp_u64_verify_one, [proto._ctx.value], label, V, P, expect, T, max(20, min(200, 30000 // T)))
+        thr1, st1 = hostinfo.throttle_stats(), proto.coalesce_stats()
+        r["mean_batch"] = round((st1["requests"] - st0["requests"]) / max(1, st1["batches"] - st0["batches"]), 1)
+        r["cgroup_throttled_periods"] = thr1["nr_throttled"] - thr0["nr_throttled"]
+        out[f"threads_{T}"] = r
+    return out
+
+
 def cpu_baseline_verify(gens, label, V, P, acc_gpu, sample_note):
     """The oracle, as the timed CPU baseline ONLY: reference-shaped C restatement on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import bppp_oracle_c as OC
     m = V.shape[0]
-    hw = os.cpu_count() or 1
+    host = host_summary()
+    hw = host["usable_cpus"]           # min(affinity, cgroup CPU quota): what a thread pool here can really keep busy
     t0 = time.perf_counter()
     OC.u64_verify_batch(gens, label, V[:64].copy(), P[:64].copy(), nthreads=1)
     single = 64 / (time.perf_counter() - t0)
     best = None
-    ladder = sorted({hw, max(1, hw // 4), min(hw, 16)}, reverse=True)
+    ladder = sorted({hw, 2 * hw, max(1, hw // 2)}, reverse=True)
     for th in ladder:
         t0 = time.perf_counter()
         oacc, _ = OC.u64_verify_batch(gens, label, V.copy(), P.copy(), nthreads=th)
@@ -226,8 +311,9 @@ def cpu_baseline_verify(gens, label, V, P, acc_gpu, sample_note):
             best = (m / dt, th, dt, bool((oacc == acc_gpu[:m]).all()))
     return {"value": best[0], "unit": "verifies/s", "cores": best[1], "kind": "port",
             "sample": f"{sample_note}, reference-shaped C restatement (oracle/bppp_ref.c); best of thread counts {ladder} = "
-                      f"{best[1]} threads, {best[2]:.2f} s wall; box reports {hw} hardware threads",
-            "single_thread_value": single, "agrees_with_gpu": best[3]}
+                      f"{best[1]} threads, {best[2]:.2f} s wall; {host['cpu_model']}: {host['affinity_cpus']} CPUs in the affinity mask, "
+                      f"cgroup CPU quota {host['cgroup_cpu_quota']}",
+            "host": host, "single_thread_value": single, "agrees_with_gpu": best[3]}
 
 
 def run_verify(args):
@@ -242,8 +328,6 @@ def run_verify(args):
     total = args.total_proofs
     lo, hi = shard_range(total, rank, world)
     n = hi - lo
-    if rank == 0:
-        session_rates()                  # the chip's issue rates and clock, measured now, while the GPU is otherwise idle
     t0 = time.time()
     proto = U64RangeProofProtocol(g, gv, hv, device=local_rank, fb_window_bits=args.fb_window_bits)
     proto.synchronize()
@@ -341,6 +425,24 @@ def run_verify(args):
             proto.set_option("host_chunk", 1 << 17)
             host_path["full_batch"] = dict(full, proofs=n, unit="verifies/s")
             del Vh, Ph
+    shard17 = None
+    if world == 1 and not args.no_secondary and n >= (1 << 17):
+        m = 1 << 17
+        dA7 = torch.zeros(m, dtype=torch.uint8, device="cuda")
+        dR7 = torch.zeros(1, dtype=torch.int32, device="cuda")
+        step(m, dA7, dR7)
+        fence()
+        t7 = time.perf_counter()
+        for _ in range(max(args.steps, 10)):
+            step(m, dA7, dR7)
+        fence()
+        t7 = (time.perf_counter() - t7) / max(args.steps, 10)
+        shard17 = {"workload": f"one GPU's share of BASELINE configs[2]'s 8-GPU split: the first {m} proofs of the same resident batch", "value": m / t7,
+                   "unit": "verifies/s", "ms_per_step": t7 * 1e3, "accept_bits_ok": bool((dA7.cpu().numpy() == expect[:m]).all())}
+    callers = None
+    if world == 1 and not args.no_secondary and not under_profiler():
+        m = min(n, 4096)
+        callers = concurrent_callers(proto, workload.LABEL, dV[:m].cpu().numpy(), dP[:m].cpu().numpy(), expect[:m])
     call_latency = None
     if world == 1 and not args.no_secondary:
         # one call of a few proofs, host buffers in and out (the reference's own usage is one verify / prove at a time: BASELINE
@@ -432,6 +534,7 @@ def run_verify(args):
         dom_name, dom_t = max(kernel_times.items(), key=lambda kv: kv[1]["total_ms"])
         avg_ms = dom_t["total_ms"] / max(1, dom_t["launches"])
         achieved = ALGO_BYTES_PER_VERIFY * n / (avg_ms * 1e-3) / 1e9
+        traffic_step = pmc_traffic_per_step(kernel_times, args.steps, n)
         result = {
             "metric": "u64 range-proof batch verifies/sec",
             "value": value,
@@ -452,7 +555,7 @@ def run_verify(args):
                             "reject-count all-reduce per step",
                 "total_proofs_per_step": total,
                 "proofs_per_gpu": n,
-                "fb_window_bits": args.fb_window_bits or 22,
+                "fb_window_bits": args.fb_window_bits or "library default (chosen from free HBM)",
                 "label": workload.LABEL.decode(),
                 "parallelism": f"shard{world}" if world > 1 else "single",
             },
@@ -467,14 +570,20 @@ def run_verify(args):
                 "avg_launch_ms": avg_ms,
                 "launches_per_step": dom_t["launches"] / args.steps,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_VERIFY * n,
+                "traffic_all_kernels_per_step": traffic_step,
+                "traffic_all_kernels_over_algorithmic": (traffic_step / (ALGO_BYTES_PER_VERIFY * n)) if traffic_step else None,
                 "note": "256-bit modular integer path: VALU issue bound, HBM fraction is small by construction "
-                        "(SURVEY.md 8d); roofline_valu is the ceiling that binds",
+                        "(SURVEY.md 8d); roofline_valu is the ceiling that binds.  traffic* come from the committed rocprofv3 --pmc "
+                        "summaries and are null unless those were collected on the device code this run loaded (pmc_matches_build)",
             },
+            "pmc_matches_build": pmc_matches_build(),
             "roofline_valu": valu_roofline(dom_name, avg_ms, n, 8 if dom_name in FB_KERNELS else 1),
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kernel_times.items() if v["launches"]},
             "accept_bits_ok": ok,
             "reject_count_all_reduced": rejects,
             "configs1_2pow16": cfg1,
+            "shard_2pow17": shard17,
+            "concurrent_callers": callers,
             "rlc_mode": rlc,
             "host_buffer_path": host_path,
             "call_latency": call_latency,
@@ -507,7 +616,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8192, help="proofs verified by the CPU baseline (rank 0, N=1): ~10-20 s of host work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs[1], RLC mode, host-buffer path)")
+    ap.add_argument("--no-session-rates", action="store_true", help="do not run tools/ratebench (the profiler command lines pass this)")
     args = ap.parse_args()
+    # the chip's issue rates and clock, measured by a child process NOW: nothing in this process has touched the GPU yet (torch is
+    # not even imported), and the GPU is idle
+    if int(os.environ.get("RANK", "0")) == 0 and not args.no_session_rates and not under_profiler():
+        session_rates(measure=True)
     if args.workload == "verify":
         args.total_proofs = args.total_proofs or (1 << 20)
         run_verify(args)

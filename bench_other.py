@@ -97,9 +97,10 @@ def measure_prove(args, proto, gens, total, cpu_baseline=True, cpu_sample=4096, 
     if cpu_baseline and rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import bppp_oracle_c as OC                                   # the oracle, as the timed CPU baseline ONLY
-        m = min(cpu_sample, n)                                       # ~10 s of host work on 64 threads
-        hw = os.cpu_count() or 1
-        th = min(hw, 64)
+        m = min(cpu_sample, n)                                       # ~10-20 s of host work
+        host = bench.host_summary()
+        hw = host["usable_cpus"]                                     # min(affinity, cgroup CPU quota)
+        th = hw
         t0 = time.perf_counter()
         Pref, Vref = OC.u64_prove_batch(gens, workload.LABEL, x_h[:m], s_h[:m], r_h[:m], nthreads=th)
         dt = time.perf_counter() - t0
@@ -108,8 +109,9 @@ def measure_prove(args, proto, gens, total, cpu_baseline=True, cpu_sample=4096, 
         single = 8 / (time.perf_counter() - t1)
         result["cpu_baseline"] = {"value": m / dt, "unit": "proves/s", "cores": th, "kind": "port",
                                   "sample": f"first {m} values of the same batch, reference-shaped C prover (oracle/bppp_ref.c), {th} threads, "
-                                            f"{dt:.2f} s wall; box reports {hw} hardware threads",
-                                  "single_thread_value": single, "byte_identical_to_gpu": bool((Pref == P[:m]).all() and (Vref == V[:m]).all())}
+                                            f"{dt:.2f} s wall; {host['cpu_model']}: {host['affinity_cpus']} CPUs in the affinity mask, cgroup CPU quota "
+                                            f"{host['cgroup_cpu_quota']}",
+                                  "host": host, "single_thread_value": single, "byte_identical_to_gpu": bool((Pref == P[:m]).all() and (Vref == V[:m]).all())}
     return result, ok
 
 

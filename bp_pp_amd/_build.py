@@ -109,6 +109,30 @@ def build(force: bool = False, verbose: bool = False, so: str = SO, objdir: str 
     return so
 
 
+def device_code_sha256(so: str = SO) -> str | None:
+    """SHA-256 of the gfx950 code objects embedded in the library (the ELF section .hip_fatbin): the identity of the kernels a
+    measurement ran.  The PMC summaries under profiles/ carry it, and bench.py only trusts them for the build that is loaded."""
+    import hashlib
+    import struct
+    try:
+        with open(so, "rb") as f:
+            data = f.read()
+    except OSError:
+        return None
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        return None
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    sec = lambda i: struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize)
+    str_off = sec(shstrndx)[4]
+    for i in range(shnum):
+        name_off, _, _, _, off, size = sec(i)[:6]
+        end = data.index(b"\0", str_off + name_off)
+        if data[str_off + name_off:end] == b".hip_fatbin":
+            return hashlib.sha256(data[off:off + size]).hexdigest()
+    return None
+
+
 def build_tool(name: str) -> str:
     """hipcc one stand-alone measurement program tools/<name>.hip -> tools/<name> (git-ignored; travels to the GPU box)."""
     src, exe = os.path.join(ROOT, "tools", name + ".hip"), os.path.join(ROOT, "tools", name)

@@ -33,7 +33,7 @@ EXPORTS = [
     "bppp_u64_prove_batch_sharded", "bppp_u64_prove_batch_sharded_device",
     "bppp_u64_prove_batch_sec1", "bppp_u64_prove_batch_sec1_device",
     "bppp_u64_verify_one", "bppp_u64_verify_one_transcript", "bppp_u64_prove_one", "bppp_u64_prove_one_transcript",
-    "bppp_ctx_get_coalesce_stats",
+    "bppp_ctx_get_coalesce_stats", "bppp_ctx_get_option",
 ]
 
 _lib = None
@@ -106,6 +106,8 @@ def lib():
     L.bppp_ctx_set_stream.argtypes = [vp, vp]
     L.bppp_ctx_synchronize.argtypes = [vp]
     L.bppp_ctx_set_option.argtypes = [vp, u8p, C.c_long]
+    L.bppp_ctx_get_option.argtypes = [vp, u8p]
+    L.bppp_ctx_get_option.restype = C.c_long
     L.bppp_u64_verify_batch.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp]
     L.bppp_u64_verify_batch_device.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, vp, vp]
     L.bppp_u64_verify_batch_rlc_device.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, vp, u8p]

@@ -50,19 +50,13 @@ struct bppp_front {
     void stop_lane(int) {}
 
     // device staging of one lane: the rows' arrays, each at an offset fixed by `max` (grow-only buffer of the lane's context)
-    static int device_staging(bppp_ctx* c, size_t bytes) {
-        if (bytes <= c->io_bytes) return BPPP_OK;
-        if (c->d_io) { (void)hipFree(c->d_io); c->d_io = nullptr; c->io_bytes = 0; }
-        HIP_TRY(hipMalloc(&c->d_io, bytes));
-        c->io_bytes = bytes;
-        return BPPP_OK;
-    }
+    static int device_staging(bppp_ctx* c, size_t bytes) { return ensure_io(c, bytes); }
     int run(int lane, size_t n, uint8_t* const in[], uint8_t* const out[]) {
         bppp_ctx* c = lanes[lane];
         CtxLock lock_(c);
         const int rc = run_locked(c, n, in, out);
         // a failed call must not leave copies in flight over staging rows that the next batch is about to overwrite
-        if (rc != BPPP_OK) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->aux_stream); (void)hipGetLastError(); }
+        if (rc != BPPP_OK) quiesce(c);
         return rc;
     }
     int run_locked(bppp_ctx* c, size_t n, uint8_t* const in[], uint8_t* const out[]) {

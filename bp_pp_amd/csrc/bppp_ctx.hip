@@ -17,14 +17,65 @@ static void read_diagnostics(bppp_ctx* c) {
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // projective tables + complete additions
 }
 
-// fb_window_bits = 0: the widest windows whose tables stay below 100 GB -- 22 bits for the u64 protocol's 49 generators (79 GB of the
-// 288: -2.4 ... -3.1 % per 2^20-proof batch against 20 bits / 21 GB, profiles/r03_e_bench_fbwindow_*), 16 bits for the 769 generators
-// of BASELINE configs[4]'s shape (52 GB)
-static int default_window_bits(int nbases) {
-    const int cand[5] = {22, 20, 16, 8, 4};
-    for (int W : cand)
-        if ((double)nbases * fb_nwin(W) * (double)fb_per_win(W) * sizeof(apt_packed) <= 100e9) return W;
-    return 4;
+// fb_window_bits = 0: the widest windows whose tables take at most 35 % of the HBM that is FREE when the context is created (and whose
+// build scratch still fits beside them) -- on an otherwise empty MI355X 22 bits for the u64 protocol's 49 generators (79 GB of 288:
+// -2.4 ... -3.1 % per 2^20-proof batch against 20 bits / 21 GB, profiles/r03_e_bench_fbwindow_*), 20 bits when some 60 GB are already
+// taken, 16 bits for the 769 generators of BASELINE configs[4]'s shape (52 GB).  Candidates, widest first:
+static const int kDefaultWindows[5] = {22, 20, 16, 8, 4};
+static double table_bytes_for(int nbases, int W) { return (double)nbases * fb_nwin(W) * (double)fb_per_win(W) * sizeof(apt_packed); }
+static size_t build_group_for(int nbases, int W) {          // bases per build pass: scratch (x, y, z, prefix: 160 B per entry) <= ~32 GB
+    const size_t per_base = (size_t)fb_nwin(W) * fb_per_win(W);
+    size_t group = ((size_t)32 << 30) / (per_base * 4 * sizeof(fe));
+    if (group < 1) group = 1;
+    if (group > (size_t)nbases) group = (size_t)nbases;
+    return group;
+}
+static bool window_fits(int nbases, int W, size_t free_bytes) {
+    const double tb = table_bytes_for(nbases, W);
+    const double scratch = (double)build_group_for(nbases, W) * fb_nwin(W) * (double)fb_per_win(W) * 4 * sizeof(fe);
+    return tb <= 0.35 * (double)free_bytes && tb + scratch <= 0.90 * (double)free_bytes;
+}
+// Build the fixed-base tables of c->d_gens at window width W into a fresh c->d_table.  On failure nothing stays allocated.
+static int build_tables(bppp_ctx* c, int W) {
+    const int NB = c->nbases;
+    const int nwin = fb_nwin(W);
+    const size_t per_win = fb_per_win(W);
+    const size_t per_base = (size_t)nwin * per_win;
+    const size_t bytes = (size_t)NB * per_base * sizeof(apt_packed);
+    const size_t group = build_group_for(NB, W);
+    const size_t gentries = group * per_base;
+    apt_packed* d_table = nullptr;
+    fe* d_tmp = nullptr;
+    auto release = [&]() { if (d_tmp) (void)hipFree(d_tmp); if (d_table) (void)hipFree(d_table); };
+#define HIP_TRY_T(expr)                                                             \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(e_);       \
+            (void)hipGetLastError();                                                \
+            release();                                                              \
+            return e_ == hipErrorOutOfMemory ? BPPP_ERR_NOMEM : BPPP_ERR_HIP;       \
+        }                                                                           \
+    } while (0)
+    if (c->inject_alloc_fault > 0 && --c->inject_alloc_fault == 0) { g_last_error = "injected allocation failure (tables)"; return BPPP_ERR_NOMEM; }
+    HIP_TRY_T(hipMalloc(&d_table, bytes));
+    HIP_TRY_T(hipMalloc(&d_tmp, gentries * 4 * sizeof(fe)));
+    for (size_t b0 = 0; b0 < (size_t)NB; b0 += group) {
+        const size_t nb = (size_t)NB - b0 < group ? (size_t)NB - b0 : group;
+        FbBuild fb{c->d_gens, NB, W, d_table, d_tmp, d_tmp + gentries, d_tmp + 2 * gentries, d_tmp + 3 * gentries, (int)b0, (int)nb};
+        size_t nthreads = nb * nwin * fb_chunks_per_window(W);
+        unsigned blocks = (unsigned)((nthreads + BPPP_BLOCK - 1) / BPPP_BLOCK);
+        k_fb_build_pass1<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
+        k_fb_build_pass2<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
+    }
+    HIP_TRY_T(hipGetLastError());
+    HIP_TRY_T(hipStreamSynchronize(c->stream));
+#undef HIP_TRY_T
+    (void)hipFree(d_tmp);
+    c->d_table = d_table;
+    c->table_bytes = bytes;
+    c->fb_w = W;
+    return BPPP_OK;
 }
 
 extern "C" {
@@ -53,19 +104,19 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     if (!out || !g || (!g_vec && ng) || (!h_vec && nh) || ng > 4096 || nh > 4096) return BPPP_ERR_INVALID_ARG;
     *out = nullptr;
     const int NB = 1 + (int)ng + (int)nh;
-    int W = fb_window_bits ? fb_window_bits : default_window_bits(NB);
-    if (W != 4 && W != 8 && W != 16 && W != 10 && W != 18 && W != 19 && W != 20 && W != 22) return BPPP_ERR_INVALID_ARG;
+    const int W0 = fb_window_bits;
+    if (W0 != 0 && W0 != 4 && W0 != 8 && W0 != 16 && W0 != 10 && W0 != 18 && W0 != 19 && W0 != 20 && W0 != 22) return BPPP_ERR_INVALID_ARG;
     int rc = check_device(device);
     if (rc != BPPP_OK) return rc;
     HIP_TRY(hipSetDevice(device));
     bppp_ctx* c = new (std::nothrow) bppp_ctx();
     if (!c) return BPPP_ERR_NOMEM;
     c->device = device;
-    c->fb_w = W;
     c->n_simds = device_simds(device);
     read_diagnostics(c);
     c->ng = (int)ng; c->nh = (int)nh; c->nbases = NB;
-    auto fail = [&](int code) { bppp_ctx_destroy(c); return code; };
+    uint8_t* d_raw = nullptr;
+    auto fail = [&](int code) { if (d_raw) (void)hipFree(d_raw); bppp_ctx_destroy(c); return code; };
 #define HIP_TRY_C(expr)                                                             \
     do {                                                                            \
         hipError_t e_ = (expr);                                                     \
@@ -85,11 +136,11 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     HIP_TRY_C(hipMalloc(&c->d_flags, sizeof(int)));
     HIP_TRY_C(hipMemsetAsync(c->d_flags, 0, sizeof(int), c->stream));
     // upload + decode generators
-    std::vector<uint8_t> hg((size_t)NB * 64);
+    std::vector<uint8_t> hg;
+    try { hg.resize((size_t)NB * 64); } catch (...) { return fail(BPPP_ERR_NOMEM); }
     std::memcpy(hg.data(), g, 64);
     if (ng) std::memcpy(hg.data() + 64, g_vec, ng * 64);
     if (nh) std::memcpy(hg.data() + (1 + ng) * 64, h_vec, nh * 64);
-    uint8_t* d_raw = nullptr;
     HIP_TRY_C(hipMalloc(&d_raw, hg.size()));
     HIP_TRY_C(hipMemcpyAsync(d_raw, hg.data(), hg.size(), hipMemcpyHostToDevice, c->stream));
     k_decode_generators<<<(NB + 63) / 64, 64, 0, c->stream>>>(d_raw, c->d_gens, NB, c->d_flags);
@@ -97,33 +148,26 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     HIP_TRY_C(hipMemcpyAsync(&flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY_C(hipStreamSynchronize(c->stream));
     (void)hipFree(d_raw);
+    d_raw = nullptr;
     if (flags) return fail(BPPP_ERR_ENCODING);
-    // fixed-base tables
-    const int nwin = fb_nwin(W);
-    const size_t per_win = fb_per_win(W);
-    const size_t entries = (size_t)NB * nwin * per_win;
-    c->table_bytes = entries * sizeof(apt_packed);
-    HIP_TRY_C(hipMalloc(&c->d_table, c->table_bytes));
-    // built in passes over groups of bases so that the scratch (x, y, z, prefix product: 160 B per entry) stays below ~32 GB
-    const size_t per_base = (size_t)nwin * per_win;
-    size_t group = ((size_t)32 << 30) / (per_base * 4 * sizeof(fe));
-    if (group < 1) group = 1;
-    if (group > (size_t)NB) group = (size_t)NB;
-    fe* d_tmp = nullptr;
-    const size_t gentries = group * per_base;
-    HIP_TRY_C(hipMalloc(&d_tmp, gentries * 4 * sizeof(fe)));
-    for (size_t b0 = 0; b0 < (size_t)NB; b0 += group) {
-        const size_t nb = (size_t)NB - b0 < group ? (size_t)NB - b0 : group;
-        FbBuild fb{c->d_gens, NB, W, c->d_table, d_tmp, d_tmp + gentries, d_tmp + 2 * gentries, d_tmp + 3 * gentries, (int)b0, (int)nb};
-        size_t nthreads = nb * nwin * fb_chunks_per_window(W);
-        unsigned blocks = (unsigned)((nthreads + BPPP_BLOCK - 1) / BPPP_BLOCK);
-        k_fb_build_pass1<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
-        k_fb_build_pass2<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
-    }
-    HIP_TRY_C(hipGetLastError());
-    HIP_TRY_C(hipStreamSynchronize(c->stream));
-    (void)hipFree(d_tmp);
 #undef HIP_TRY_C
+    // fixed-base tables: the requested width, or (0) the widest that fits the HBM free right now -- and if even that allocation fails
+    // (another process took the memory meanwhile), the next narrower one
+    if (W0 != 0) {
+        rc = build_tables(c, W0);
+        if (rc != BPPP_OK) return fail(rc);
+    } else {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        if (const char* e = std::getenv("BPPP_ASSUME_FREE_GB")) free_b = (size_t)(std::atof(e) * 1e9);      // diagnostic: exercise the choice
+        rc = BPPP_ERR_NOMEM;
+        for (int W : kDefaultWindows) {
+            if (W > 4 && free_b && !window_fits(NB, W, free_b)) continue;
+            rc = build_tables(c, W);
+            if (rc != BPPP_ERR_NOMEM) break;
+        }
+        if (rc != BPPP_OK) return fail(rc);
+    }
     *out = c;
     return BPPP_OK;
 }
@@ -146,6 +190,8 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->d_pws) (void)hipFree(c->d_pws);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_io) (void)hipFree(c->d_io);
+    if (c->d_blob) (void)hipFree(c->d_blob);
+    if (c->d_txio) (void)hipFree(c->d_txio);
     if (c->d_gws) (void)hipFree(c->d_gws);
     if (c->d_gtab) (void)hipFree(c->d_gtab);
     if (c->d_expand) (void)hipFree(c->d_expand);
@@ -195,11 +241,33 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
         else c->coalesce_lanes = (int)value;
         return BPPP_OK;
     }
+    // testing aid: the value-th device allocation from now on (workspaces, staging, tables) fails with BPPP_ERR_NOMEM; 0 clears it
+    if (std::strcmp(name, "inject_alloc_fault") == 0) {
+        if (value < 0) return BPPP_ERR_INVALID_ARG;
+        c->inject_alloc_fault = (int)value;
+        return BPPP_OK;
+    }
     if (std::strcmp(name, "host_chunk") == 0) {
         if (value != 0 && (value < 1024 || (value & 63))) return BPPP_ERR_INVALID_ARG;
         c->host_chunk = (size_t)value;
         return BPPP_OK;
     }
+    return BPPP_ERR_INVALID_ARG;
+}
+// read back a tunable, or one of the read-only facts "fb_window_bits" (the window width in use -- the library's choice when the
+// context was created with 0), "device", "n_generators"
+long bppp_ctx_get_option(bppp_ctx* c, const char* name) {
+    CtxLock lock_(c);
+    if (!c || !name) return BPPP_ERR_INVALID_ARG;
+    if (std::strcmp(name, "fb_window_bits") == 0) return c->fb_w;
+    if (std::strcmp(name, "device") == 0) return c->device;
+    if (std::strcmp(name, "n_generators") == 0) return c->nbases;
+    if (std::strcmp(name, "rlc_superchunk") == 0) return (long)c->rlc_super_m;
+    if (std::strcmp(name, "max_batch") == 0) return (long)c->max_batch;
+    if (std::strcmp(name, "host_chunk") == 0) return (long)c->host_chunk;
+    if (std::strcmp(name, "coalesce_max") == 0) return c->coalesce_max;
+    if (std::strcmp(name, "coalesce_us") == 0) return c->coalesce_us;
+    if (std::strcmp(name, "coalesce_lanes") == 0) return c->coalesce_lanes;
     return BPPP_ERR_INVALID_ARG;
 }
 int bppp_ctx_synchronize(bppp_ctx* c) {
@@ -213,7 +281,7 @@ int bppp_ctx_synchronize(bppp_ctx* c) {
 
 size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
     if (!c) return 0;
-    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->bkt_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + c->gws_bytes + c->gtab_bytes + (size_t)c->nbases * sizeof(apt);
+    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->bkt_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + c->blob_bytes + c->txio_bytes + c->gws_bytes + c->gtab_bytes + (size_t)c->nbases * sizeof(apt);
 }
 
 int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
@@ -335,11 +403,12 @@ int bppp_derive_generators(const uint8_t* seed, size_t seed_len, size_t first_in
 
 // ---- fixed-base tables as an artefact.  File = header | generators (nbases x 64 B, the device's decoded form re-encoded) | table.
 struct TableFileHeader {
-    char magic[8];             // "BPPPTAB2"
+    char magic[8];             // "BPPPTAB3"
     uint32_t nbases, ng, nh, window_bits, nwin, reserved;
     uint64_t per_win, table_bytes;
-    uint64_t checksum;         // TableChecksum over the generator block and the table body, in file order
+    uint64_t checksum;         // TableChecksum over the header (this field zero), the generator block and the table body, in file order
 };
+static_assert(sizeof(TableFileHeader) % 8 == 0, "the checksum runs over 8-byte words");
 // A verifier running on a truncated, stale or tampered table would accept bad proofs and nothing would report it, so the file
 // carries a checksum of everything after the header: four interleaved 64-bit FNV-1a lanes over little-endian words (host speed
 // of a few GB/s -- the disk is slower), folded at the end.  Not a MAC: it catches damage and mix-ups, not an adversary who can
@@ -371,17 +440,22 @@ int bppp_ctx_save_tables(bppp_ctx* c, const char* path) {
     if (!f) { g_last_error = std::string("cannot open ") + path; return BPPP_ERR_INVALID_ARG; }
     TableFileHeader h;
     std::memset(&h, 0, sizeof h);
-    std::memcpy(h.magic, "BPPPTAB2", 8);
+    std::memcpy(h.magic, "BPPPTAB3", 8);
     h.nbases = (uint32_t)c->nbases; h.ng = (uint32_t)c->ng; h.nh = (uint32_t)c->nh; h.window_bits = (uint32_t)c->fb_w;
     h.nwin = (uint32_t)fb_nwin(c->fb_w); h.per_win = fb_per_win(c->fb_w); h.table_bytes = c->table_bytes;
     bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
-    std::vector<apt> gens(c->nbases);
+    std::vector<apt> gens;
+    std::vector<uint8_t> buf;
+    const size_t CH = (size_t)256 << 20;
+    try {
+        gens.resize(c->nbases);
+        buf.resize(c->table_bytes < CH ? c->table_bytes : CH);
+    } catch (...) { std::fclose(f); g_last_error = "out of host memory"; return BPPP_ERR_NOMEM; }
     if (hipMemcpy(gens.data(), c->d_gens, gens.size() * sizeof(apt), hipMemcpyDeviceToHost) != hipSuccess) ok = false;
     ok = ok && std::fwrite(gens.data(), sizeof(apt), gens.size(), f) == gens.size();
     TableChecksum sum;
+    sum.update(&h, sizeof h);                                  // the header too (checksum field still zero): ng / nh / window width are covered
     sum.update(gens.data(), gens.size() * sizeof(apt));
-    const size_t CH = (size_t)256 << 20;
-    std::vector<uint8_t> buf(c->table_bytes < CH ? c->table_bytes : CH);
     for (size_t off = 0; ok && off < c->table_bytes; off += CH) {
         const size_t m = c->table_bytes - off < CH ? c->table_bytes - off : CH;
         if (hipMemcpy(buf.data(), (const uint8_t*)c->d_table + off, m, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
@@ -414,9 +488,9 @@ int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device) {
     FILE* f = std::fopen(path, "rb");
     if (!f) { g_last_error = std::string("cannot open ") + path; return BPPP_ERR_INVALID_ARG; }
     TableFileHeader h;
-    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "BPPPTAB2", 8) == 0;
+    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "BPPPTAB3", 8) == 0;
     const int W = (int)h.window_bits;
-    ok = ok && (W == 4 || W == 8 || W == 10 || W == 16 || W == 18 || W == 19 || W == 20 || W == 22) && h.nbases == 1 + h.ng + h.nh && h.nbases <= 8193 &&
+    ok = ok && (W == 4 || W == 8 || W == 10 || W == 16 || W == 18 || W == 19 || W == 20 || W == 22) && h.ng <= 4096 && h.nh <= 4096 && h.nbases == 1 + h.ng + h.nh &&
          h.nwin == (uint32_t)fb_nwin(W) && h.per_win == fb_per_win(W) && h.table_bytes == (uint64_t)h.nbases * h.nwin * h.per_win * sizeof(apt_packed);
     if (!ok) { std::fclose(f); g_last_error = std::string(path) + " is not a table file of this library"; return BPPP_ERR_INVALID_ARG; }
     if (hipSetDevice(device) != hipSuccess) { std::fclose(f); g_last_error = "hipSetDevice failed"; (void)hipGetLastError(); return BPPP_ERR_HIP; }
@@ -426,7 +500,13 @@ int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device) {
     auto fail = [&](int code) { std::fclose(f); bppp_ctx_destroy(c); return code; };
     rc = ctx_alloc_common(c);
     if (rc != BPPP_OK) return fail(rc);
-    std::vector<apt> gens(h.nbases);
+    std::vector<apt> gens;
+    std::vector<uint8_t> buf;
+    const size_t CH = (size_t)256 << 20;
+    try {
+        gens.resize(h.nbases);
+        buf.resize(c->table_bytes < CH ? c->table_bytes : CH);
+    } catch (...) { g_last_error = "out of host memory"; return fail(BPPP_ERR_NOMEM); }
     if (std::fread(gens.data(), sizeof(apt), gens.size(), f) != gens.size()) return fail(BPPP_ERR_INVALID_ARG);
     // the generators get the validation bppp_ctx_create gives them (k_decode_generators): canonical limbs, on the curve
     for (const apt& a : gens) {
@@ -439,11 +519,14 @@ int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device) {
         }
     }
     TableChecksum sum;
+    {
+        TableFileHeader hz = h;
+        hz.checksum = 0;
+        sum.update(&hz, sizeof hz);
+    }
     sum.update(gens.data(), gens.size() * sizeof(apt));
-    if (hipMalloc(&c->d_gens, gens.size() * sizeof(apt)) != hipSuccess || hipMalloc(&c->d_table, c->table_bytes) != hipSuccess) return fail(BPPP_ERR_NOMEM);
+    if (hipMalloc(&c->d_gens, gens.size() * sizeof(apt)) != hipSuccess || hipMalloc(&c->d_table, c->table_bytes) != hipSuccess) { (void)hipGetLastError(); return fail(BPPP_ERR_NOMEM); }
     if (hipMemcpy(c->d_gens, gens.data(), gens.size() * sizeof(apt), hipMemcpyHostToDevice) != hipSuccess) return fail(BPPP_ERR_HIP);
-    const size_t CH = (size_t)256 << 20;
-    std::vector<uint8_t> buf(c->table_bytes < CH ? c->table_bytes : CH);
     for (size_t off = 0; off < c->table_bytes; off += CH) {
         const size_t m = c->table_bytes - off < CH ? c->table_bytes - off : CH;
         if (std::fread(buf.data(), 1, m, f) != m) { g_last_error = std::string(path) + " is truncated"; return fail(BPPP_ERR_INVALID_ARG); }
@@ -451,7 +534,7 @@ int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device) {
         if (hipMemcpy((uint8_t*)c->d_table + off, buf.data(), m, hipMemcpyHostToDevice) != hipSuccess) return fail(BPPP_ERR_HIP);
     }
     if (sum.digest() != h.checksum) {
-        g_last_error = std::string(path) + ": checksum mismatch (the table body or the generators differ from what was saved)";
+        g_last_error = std::string(path) + ": checksum mismatch (the header, the generators or the table body differ from what was saved)";
         return fail(BPPP_ERR_INVALID_ARG);
     }
     std::fclose(f);

@@ -15,17 +15,19 @@ static int check_host_transcripts(const HostTranscripts* tx, size_t n) {
 }
 // device copies of a prover call's transcripts (host-buffer entry points): states in, advanced states out
 struct TxDev {
-    uint8_t *d_in = nullptr, *d_out = nullptr;
-    ~TxDev() { if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); }
-    int begin(const HostTranscripts* tx, size_t n, hipStream_t s, TranscriptIo& io, int& divergent) {
+    uint8_t *d_in = nullptr, *d_out = nullptr;      // carved out of the context's grow-only transcript staging
+    int begin(bppp_ctx* c, const HostTranscripts* tx, size_t n, hipStream_t s, TranscriptIo& io, int& divergent) {
         io.states = nullptr; io.n_states = 0; io.states_out = nullptr; io.no_ops = 0;
         divergent = 0;
         if (!tx) return BPPP_OK;
         int rc = check_host_transcripts(tx, n);
         if (rc != BPPP_OK) return rc;
-        HIP_TRY(hipMalloc(&d_in, tx->n_states * 203));
+        const size_t b_in = align16(tx->n_states * 203);
+        rc = ensure_buffer(c, c->d_txio, c->txio_bytes, b_in + (tx->states_out ? n * 203 : 0));
+        if (rc != BPPP_OK) return rc;
+        d_in = c->d_txio;
+        if (tx->states_out) d_out = c->d_txio + b_in;
         HIP_TRY(hipMemcpyAsync(d_in, tx->states, tx->n_states * 203, hipMemcpyHostToDevice, s));
-        if (tx->states_out) HIP_TRY(hipMalloc(&d_out, n * 203));
         io.states = d_in; io.n_states = tx->n_states; io.states_out = d_out;
         divergent = tx->n_states != 1;
         return BPPP_OK;
@@ -47,10 +49,9 @@ static int wnla_fast_setup(bppp_ctx* c, WnlaWs& w, size_t n, size_t rounds) {
     const size_t np = 2 * rounds;
     const size_t b_tab = align16(np * 16 * sizeof(apt_packed) * n), b_scr = align16((size_t)BPPP_TSCR_PER_POINT * np * 10 * sizeof(u32) * n), b_pts = align16(np * 16 * sizeof(u32) * n);
     const size_t need = b_tab + b_scr + b_pts;
-    if (need > c->gtab_bytes) {
-        if (c->d_gtab) { (void)hipFree(c->d_gtab); c->d_gtab = nullptr; c->gtab_bytes = 0; }
-        HIP_TRY(hipMalloc(&c->d_gtab, need));
-        c->gtab_bytes = need;
+    {
+        const int rc_t = ensure_buffer(c, c->d_gtab, c->gtab_bytes, need);
+        if (rc_t != BPPP_OK) return rc_t;
     }
     w.atab = (apt_packed*)c->d_gtab;
     w.tscr = (u32*)(c->d_gtab + b_tab);
@@ -65,9 +66,18 @@ static int wnla_round_group(const bppp_ctx* c, const WnlaWs& w, unsigned blocks)
     return 1;
 }
 // ---- generic WeightNormLinearArgument entry points (host pointers; one device blob per call)
+// (the context's grow-only buffer: no allocator round trip per call.  Whatever way the call ends, nothing of it is still running
+// when the blob goes out of scope -- on the success path the stream has just been waited for and this costs nothing)
 struct WnlaBlob {
+    bppp_ctx* c = nullptr;
     uint8_t* d = nullptr;
-    ~WnlaBlob() { if (d) (void)hipFree(d); }
+    int take(bppp_ctx* ctx, size_t bytes) {
+        c = ctx;
+        int rc = ensure_blob(ctx, bytes);
+        d = ctx->d_blob;
+        return rc;
+    }
+    ~WnlaBlob() { if (c) quiesce(c); }
 };
 
 static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
@@ -90,7 +100,7 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
                  o_pf = take(30 * n * 4), o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4),
                  o_msc = take(NB * 8 * n * 4), o_ti = take(tx ? tx->n_states * 203 : 0), o_to = take(tx && tx->states_out ? n * 203 : 0);
     WnlaBlob blob;
-    HIP_TRY(hipMalloc(&blob.d, off + 16));
+    { const int rc_b = blob.take(c, off + 16); if (rc_b != BPPP_OK) return rc_b; }
     uint8_t* d = blob.d;
     hipStream_t s = c->stream;
     auto up = [&](size_t o, const uint8_t* src, size_t bytes) -> hipError_t {
@@ -335,11 +345,8 @@ int recip_verify_device_entry(bppp_ctx* c, const uint8_t* label, size_t label_le
     if (rc != BPPP_OK) return rc;
     // persistent, grow-only workspace (the host-pointer entry point allocates per call instead)
     const size_t need = recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds, rlc_seed != nullptr);
-    if (need > c->gws_bytes) {
-        if (c->d_gws) { (void)hipFree(c->d_gws); c->d_gws = nullptr; c->gws_bytes = 0; }
-        HIP_TRY(hipMalloc(&c->d_gws, need));
-        c->gws_bytes = need;
-    }
+    rc = ensure_buffer(c, c->d_gws, c->gws_bytes, need);
+    if (rc != BPPP_OK) return rc;
     rc = recip_verify_device_impl(c, label, label_len, n, dim_nd, dim_np, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, rounds, nl,
                                   nn, (uint8_t*)d_accept, (int32_t*)d_status, c->d_gws, nullptr, rlc_seed);
     if (rc != BPPP_OK || !d_reject_count) return rc;
@@ -407,7 +414,7 @@ static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t labe
                  o_ws = align16(o_to + (tx && tx->states_out ? n * 203 : 0)),
                  total = o_ws + recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds, rlc_seed != nullptr);
     WnlaBlob blob;
-    HIP_TRY(hipMalloc(&blob.d, total));
+    { const int rc_b = blob.take(c, total); if (rc_b != BPPP_OK) return rc_b; }
     uint8_t* d = blob.d;
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * 64, hipMemcpyHostToDevice, s));
@@ -460,8 +467,13 @@ int bppp_circuit_create(bppp_ctx* c, bppp_circuit** out, const size_t dims[6], i
     for (size_t j = 0; j < nv; j++) { parts[j] = part_lo[j]; parts[nv + j] = part_ll[j]; parts[2 * nv + j] = part_lr[j]; }
     for (size_t j = 0; j < nm; j++) parts[3 * nv + j] = part_no[j];
     const size_t o_part = take(parts.size() * 4);
-    hipError_t e = hipMalloc(&q->d_blob, off);
-    if (e != hipSuccess) { delete q; g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
+    hipError_t e = ctx_malloc(c, (void**)&q->d_blob, off);
+    if (e != hipSuccess) {
+        delete q;
+        g_last_error = std::string("hipMalloc: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+        return e == hipErrorOutOfMemory ? BPPP_ERR_NOMEM : BPPP_ERR_HIP;
+    }
     q->blob_bytes = off;
     auto up = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpy(q->d_blob + o, src, bytes, hipMemcpyHostToDevice) : hipSuccess; };
     if (up(o_cpl, cpl.data(), cpl.size() * 4) != hipSuccess || up(o_rl, rl.data(), rl.size() * 4) != hipSuccess ||
@@ -527,7 +539,7 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
                  o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4), o_msc = take(NB * 8 * n * 4),
                  o_ti = take(tx ? tx->n_states * 203 : 0), o_to = take(tx && tx->states_out ? n * 203 : 0);
     WnlaBlob blob;
-    HIP_TRY(hipMalloc(&blob.d, off + 16));
+    { const int rc_b = blob.take(c, off + 16); if (rc_b != BPPP_OK) return rc_b; }
     uint8_t* d = blob.d;
     hipStream_t s = c->stream;
     if (tx) HIP_TRY(hipMemcpyAsync(d + o_ti, tx->states, tx->n_states * 203, hipMemcpyHostToDevice, s));
@@ -611,7 +623,7 @@ int bppp_msm_batch(bppp_ctx* c, size_t n, size_t nterms, const int32_t* base_ind
     const size_t o_sc = take(n * nterms * 32), o_runs = take(runs.size() * 4), o_msc = take(nterms * 8 * n * 4), o_pf = take(30 * n * 4),
                  o_st = take(n * 4), o_out = take(n * 64);
     WnlaBlob blob;
-    HIP_TRY(hipMalloc(&blob.d, off));
+    { const int rc_b = blob.take(c, off); if (rc_b != BPPP_OK) return rc_b; }
     uint8_t* d = blob.d;
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(d + o_sc, scalars, n * nterms * 32, hipMemcpyHostToDevice, s));
@@ -662,7 +674,7 @@ static int wnla_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, 
                  o_cg = take((ng + 1) * 8 * n * 4), o_prm = take(3 * 8 * n * 4), o_cm = take(16 * n * 4), o_msc = take(3 * NB * 8 * n * 4),
                  o_pb = take(3 * 30 * n * 4);
     WnlaBlob blob;
-    HIP_TRY(hipMalloc(&blob.d, off));
+    { const int rc_b = blob.take(c, off); if (rc_b != BPPP_OK) return rc_b; }
     uint8_t* d = blob.d;
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * 64, hipMemcpyHostToDevice, s));
@@ -684,7 +696,7 @@ static int wnla_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, 
     w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
     t_new(w.base, label, (u32)label_len);
     TxDev txd;
-    int rc = txd.begin(tx, n, s, w.tio, w.divergent_positions);
+    int rc = txd.begin(c, tx, n, s, w.tio, w.divergent_positions);
     if (rc != BPPP_OK) return rc;
     w.tio.no_ops = rounds == 0;
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
@@ -754,7 +766,7 @@ static int circuit_prove_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t*
                  o_vl = take((NH + 1) * 8 * n * 4), o_vn = take((NG + 1) * 8 * n * 4), o_vc = take(NH * 8 * n * 4), o_ch = take(NH * 8 * n * 4),
                  o_cg = take((NG + 1) * 8 * n * 4), o_prm = take(3 * 8 * n * 4), o_cm = take(16 * n * 4), o_proofs = take(n * proof_bytes);
     WnlaBlob blob;
-    HIP_TRY(hipMalloc(&blob.d, off));
+    { const int rc_b = blob.take(c, off); if (rc_b != BPPP_OK) return rc_b; }
     uint8_t* d = blob.d;
     hipStream_t s = c->stream;
     HIP_TRY(hipMemcpyAsync(d + o_vp, v_commitments, n * k * 64, hipMemcpyHostToDevice, s));
@@ -781,7 +793,7 @@ static int circuit_prove_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t*
     p.fb.table = c->d_table; p.fb.W = c->fb_w; p.fb.N = n;
     t_new(p.base, label, (u32)label_len);
     TxDev txd;
-    int rc = txd.begin(tx, n, s, p.tio, p.divergent_positions);
+    int rc = txd.begin(c, tx, n, s, p.tio, p.divergent_positions);
     if (rc != BPPP_OK) return rc;
     WnlaProveWs w;
     std::memset(&w, 0, sizeof w);
@@ -897,7 +909,7 @@ static int recip_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
                  o_vl2 = take((NH + 1) * 8 * n * 4), o_vn2 = take((NG + 1) * 8 * n * 4), o_vc = take(NH * 8 * n * 4), o_ch = take(NH * 8 * n * 4),
                  o_cg = take((NG + 1) * 8 * n * 4), o_prm = take(3 * 8 * n * 4), o_cm = take(16 * n * 4);
     WnlaBlob blob;
-    HIP_TRY(hipMalloc(&blob.d, off));
+    { const int rc_b = blob.take(c, off); if (rc_b != BPPP_OK) return rc_b; }
     uint8_t* d = blob.d;
     hipStream_t s = c->stream;
     auto up = [&](size_t o, const void* src, size_t bytes) { return bytes ? hipMemcpyAsync(d + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess; };
@@ -919,7 +931,7 @@ static int recip_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
     r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
     t_new(r.base, label, (u32)label_len);
     TxDev txd;
-    int rc = txd.begin(tx, n, s, r.tio, r.divergent_positions);
+    int rc = txd.begin(c, tx, n, s, r.tio, r.divergent_positions);
     if (rc != BPPP_OK) return rc;
     CircuitProveWs p;
     std::memset(&p, 0, sizeof p);

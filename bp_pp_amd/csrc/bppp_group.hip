@@ -204,10 +204,9 @@ int run_call(ShardedCall& call) {
                 off = align16(off + (a.shared_rows ? a.shared_rows : m) * a.stride);
             }
             const size_t need = off + 16;
-            if (need > c->io_bytes) {
-                if (c->d_io) { (void)hipFree(c->d_io); c->d_io = nullptr; c->io_bytes = 0; }
-                HIP_TRY(hipMalloc(&c->d_io, need));
-                c->io_bytes = need;
+            {
+                const int rc_io = ensure_io(c, need);
+                if (rc_io != BPPP_OK) return rc_io;
             }
             for (size_t i = 0; i < NA; i++) {
                 const ShardArray& a = call.arrays[i];
@@ -237,8 +236,12 @@ int run_call(ShardedCall& call) {
     auto drain = [&](int r) -> int {
         bppp_ctx* c = grp->ctx[r];
         (void)hipSetDevice(grp->devices[r]);
-        (void)hipStreamSynchronize(c->stream);
-        (void)hipStreamSynchronize(c->aux_stream);
+        const hipError_t e1 = hipStreamSynchronize(c->stream), e2 = hipStreamSynchronize(c->aux_stream);     // both, whatever the first says
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            g_last_error = std::string("draining rank ") + std::to_string(r) + ": " + hipGetErrorString(e1 != hipSuccess ? e1 : e2);
+            (void)hipGetLastError();
+            return BPPP_ERR_HIP;
+        }
         return BPPP_OK;
     };
     auto finish = [&](int r) -> int {
@@ -259,9 +262,13 @@ int run_call(ShardedCall& call) {
     auto abort_comm = [&](int r) {
         if (!grp->comm.empty() && grp->comm[r] && grp->rccl.CommAbort) { (void)grp->rccl.CommAbort(grp->comm[r]); grp->comm[r] = nullptr; }
     };
+    // a group of one device runs on the CALLER's thread: its current device is put back afterwards
+    int caller_device = -1;
+    if (G == 1 && hipGetDevice(&caller_device) != hipSuccess) { caller_device = -1; (void)hipGetLastError(); }
     bppp_host::ShardedResult res = bppp_host::run_sharded(
         G, [&](int r) { grp->ctx[r]->mu.lock(); }, prepare, collective, finish, drain, abort_comm, [&](int r) { grp->ctx[r]->mu.unlock(); },
         []() { return g_last_error; });
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
     if (res.collective_failed) grp->broken = true;
     if (res.code != BPPP_OK) { g_last_error = res.error; return res.code; }
     if (call.reject_count) {

@@ -208,12 +208,12 @@ int bppp_u64_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* state
     for (size_t i = 0; i < n_states; i++)
         if (states[203 * i + 200] >= BPPP_STROBE_R || states[203 * i + 201] > BPPP_STROBE_R) return BPPP_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
-    uint8_t* d = nullptr;
     const size_t SB = BPPP_TRANSCRIPT_STATE_BYTES;
     const size_t o_c = 0, o_p = align16(o_c + n * 64), o_a = align16(o_p + n * (size_t)BPPP_U64_PROOF_BYTES), o_s = align16(o_a + n),
                  o_ti = align16(o_s + n * sizeof(int32_t)), o_to = align16(o_ti + n_states * SB), total = align16(o_to + n * SB);
-    HIP_TRY(hipMalloc(&d, total));
-    int rc = BPPP_OK;
+    int rc = ensure_io(c, total);
+    if (rc != BPPP_OK) return rc;
+    uint8_t* d = c->d_io;
     hipStream_t st = c->stream;
     hipError_t e = hipMemcpyAsync(d + o_c, commitments, n * 64, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_p, proofs, n * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, st);
@@ -228,7 +228,7 @@ int bppp_u64_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* state
             if (e == hipSuccess) e = hipStreamSynchronize(st);
         }
     }
-    (void)hipFree(d);
+    if (e != hipSuccess || rc != BPPP_OK) quiesce(c);
     if (e != hipSuccess) { g_last_error = std::string("verify_batch_transcript: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
     return rc;
 }
@@ -252,10 +252,9 @@ static int verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
     // persistent I/O staging of the host-buffer entry points (grow-only; separate from d_stage, which the device call may use)
     const size_t o_c = 0, o_p = align16(o_c + n * 64), o_a = align16(o_p + n * (size_t)BPPP_U64_PROOF_BYTES), o_s = align16(o_a + n),
                  need = align16(o_s + n * sizeof(int32_t));
-    if (need > c->io_bytes) {
-        if (c->d_io) { (void)hipFree(c->d_io); c->d_io = nullptr; c->io_bytes = 0; }
-        HIP_TRY(hipMalloc(&c->d_io, need));
-        c->io_bytes = need;
+    {
+        int rc = ensure_io(c, need);
+        if (rc != BPPP_OK) return rc;
     }
     uint8_t *d_c = c->d_io + o_c, *d_p = c->d_io + o_p, *d_a = c->d_io + o_a;
     int32_t* d_s = (int32_t*)(c->d_io + o_s);
@@ -451,12 +450,12 @@ int bppp_u64_prove_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states
         if (states[203 * i + 200] >= BPPP_STROBE_R || states[203 * i + 201] > BPPP_STROBE_R) return BPPP_ERR_INVALID_ARG;
     HIP_TRY(hipSetDevice(c->device));
     const size_t SB = BPPP_TRANSCRIPT_STATE_BYTES;
-    uint8_t* d = nullptr;
     const size_t o_x = 0, o_s = align16(o_x + n * 8), o_r = align16(o_s + n * 32), o_p = align16(o_r + n * 52 * 32),
                  o_c = align16(o_p + n * (size_t)BPPP_U64_PROOF_BYTES), o_st = align16(o_c + n * 64), o_ti = align16(o_st + n * sizeof(int32_t)),
                  o_to = align16(o_ti + n_states * SB), total = align16(o_to + n * SB);
-    HIP_TRY(hipMalloc(&d, total));
-    int rc = BPPP_OK;
+    int rc = ensure_io(c, total);
+    if (rc != BPPP_OK) return rc;
+    uint8_t* d = c->d_io;
     hipStream_t st = c->stream;
     hipError_t e = hipMemcpyAsync(d + o_x, x, n * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_s, s, n * 32, hipMemcpyHostToDevice, st);
@@ -473,7 +472,7 @@ int bppp_u64_prove_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states
             if (e == hipSuccess) e = hipStreamSynchronize(st);
         }
     }
-    (void)hipFree(d);
+    if (e != hipSuccess || rc != BPPP_OK) quiesce(c);
     if (e != hipSuccess) { g_last_error = std::string("prove_batch_transcript: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
     return rc;
 }
@@ -484,11 +483,11 @@ int bppp_u64_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, si
     if (!c || !x || !s || !rnd || !proofs || !commitments) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    uint8_t* d = nullptr;
     const size_t o_x = 0, o_s = o_x + n * 8, o_r = o_s + n * 32, o_p = o_r + n * 52 * 32, o_c = o_p + n * (size_t)BPPP_U64_PROOF_BYTES,
                  o_st = o_c + n * 64, total = o_st + n * sizeof(int32_t);
-    HIP_TRY(hipMalloc(&d, total));
-    int rc = BPPP_OK;
+    int rc = ensure_io(c, total);
+    if (rc != BPPP_OK) return rc;
+    uint8_t* d = c->d_io;
     hipError_t e = hipMemcpyAsync(d + o_x, x, n * 8, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_s, s, n * 32, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_r, rnd, n * 52 * 32, hipMemcpyHostToDevice, c->stream);
@@ -501,7 +500,7 @@ int bppp_u64_prove_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, si
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
     }
-    (void)hipFree(d);
+    if (e != hipSuccess || rc != BPPP_OK) quiesce(c);
     if (e != hipSuccess) { g_last_error = std::string("prove_batch: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
     return rc;
 }
@@ -512,10 +511,9 @@ int verify_sec1_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
     const size_t need = n * (64 + (size_t)BPPP_U64_PROOF_BYTES);
-    if (need > c->expand_bytes) {
-        if (c->d_expand) { (void)hipFree(c->d_expand); c->d_expand = nullptr; c->expand_bytes = 0; }
-        HIP_TRY(hipMalloc(&c->d_expand, need));
-        c->expand_bytes = need;
+    {
+        int rc_e = ensure_buffer(c, c->d_expand, c->expand_bytes, need);
+        if (rc_e != BPPP_OK) return rc_e;
     }
     uint8_t* d_c64 = c->d_expand;
     uint8_t* d_p928 = c->d_expand + n * 64;
@@ -536,11 +534,11 @@ int bppp_u64_verify_batch_sec1(bppp_ctx* c, const uint8_t* label, size_t label_l
     if (!c || !commitments33 || !proofs525 || !accept) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    uint8_t* d = nullptr;
     const size_t o_c = 0, o_p = o_c + n * 33, o_a = o_p + n * (size_t)BPPP_U64_PROOF_SEC1_BYTES, o_s = (o_a + n + 3) / 4 * 4,
                  total = o_s + n * sizeof(int32_t);
-    HIP_TRY(hipMalloc(&d, total));
-    int rc = BPPP_OK;
+    int rc = ensure_io(c, total);
+    if (rc != BPPP_OK) return rc;
+    uint8_t* d = c->d_io;
     hipError_t e = hipMemcpyAsync(d + o_c, commitments33, n * 33, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_p, proofs525, n * (size_t)BPPP_U64_PROOF_SEC1_BYTES, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
@@ -551,7 +549,7 @@ int bppp_u64_verify_batch_sec1(bppp_ctx* c, const uint8_t* label, size_t label_l
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
     }
-    (void)hipFree(d);
+    if (e != hipSuccess || rc != BPPP_OK) quiesce(c);
     if (e != hipSuccess) { g_last_error = std::string("verify_batch_sec1: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
     return rc;
 }
@@ -565,10 +563,9 @@ int bppp_u64_prove_batch_sec1_device(bppp_ctx* c, const uint8_t* label, size_t l
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
     const size_t need = n * (64 + (size_t)BPPP_U64_PROOF_BYTES);
-    if (need > c->expand_bytes) {
-        if (c->d_expand) { (void)hipFree(c->d_expand); c->d_expand = nullptr; c->expand_bytes = 0; }
-        HIP_TRY(hipMalloc(&c->d_expand, need));
-        c->expand_bytes = need;
+    {
+        int rc_e = ensure_buffer(c, c->d_expand, c->expand_bytes, need);
+        if (rc_e != BPPP_OK) return rc_e;
     }
     uint8_t* d_c64 = c->d_expand;
     uint8_t* d_p928 = c->d_expand + n * 64;
@@ -584,11 +581,11 @@ int bppp_u64_prove_batch_sec1(bppp_ctx* c, const uint8_t* label, size_t label_le
     if (!c || !x || !s || !rnd || !proofs525 || !commitments33) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
-    uint8_t* d = nullptr;
     const size_t o_x = 0, o_s = o_x + n * 8, o_r = o_s + n * 32, o_p = o_r + n * 52 * 32, o_c = o_p + n * (size_t)BPPP_U64_PROOF_SEC1_BYTES,
                  o_st = (o_c + n * 33 + 3) / 4 * 4, total = o_st + n * sizeof(int32_t);
-    HIP_TRY(hipMalloc(&d, total));
-    int rc = BPPP_OK;
+    int rc = ensure_io(c, total);
+    if (rc != BPPP_OK) return rc;
+    uint8_t* d = c->d_io;
     hipError_t e = hipMemcpyAsync(d + o_x, x, n * 8, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_s, s, n * 32, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + o_r, rnd, n * 52 * 32, hipMemcpyHostToDevice, c->stream);
@@ -601,7 +598,7 @@ int bppp_u64_prove_batch_sec1(bppp_ctx* c, const uint8_t* label, size_t label_le
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         }
     }
-    (void)hipFree(d);
+    if (e != hipSuccess || rc != BPPP_OK) quiesce(c);
     if (e != hipSuccess) { g_last_error = std::string("prove_batch_sec1: ") + hipGetErrorString(e); return BPPP_ERR_HIP; }
     return rc;
 }

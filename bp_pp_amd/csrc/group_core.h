@@ -18,6 +18,7 @@
 // a GPU: with the vote removed, the emulated all-reduce of a two-rank group with one failing rank never returns.
 #pragma once
 #include <condition_variable>
+#include <new>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -54,6 +55,9 @@ private:
     std::vector<int> codes_;
 };
 
+// what a phase that threw is reported as (the values of BPPP_ERR_NOMEM / BPPP_ERR_HIP in include/bppp.h)
+static const int kShardErrNoMem = -5, kShardErrInternal = -3;
+
 struct ShardedResult {
     int code = 0;              // 0, or the failing rank's code (lowest failing rank)
     int failed_rank = -1;
@@ -71,35 +75,62 @@ ShardedResult run_sharded(int G, Enter&& enter, Prepare&& prepare, Collective&& 
     std::vector<int> rcs(G, 0);
     std::vector<std::string> errs(G);
     Vote vote1(G), vote2(G);
+    // A phase must never leave its thread by an exception: a rank that dies before a vote would leave the others blocked in it for
+    // ever (holding the group's and the contexts' locks).  Whatever a phase throws becomes that rank's return code, and the rank
+    // still arrives at both votes.
+    auto guarded = [&](auto&& phase, int r) -> int {
+        try {
+            const int rc = phase(r);
+            if (rc != 0) errs[r] = last_error();
+            return rc;
+        } catch (const std::bad_alloc&) {
+            errs[r] = "out of host memory in a rank thread";
+            return kShardErrNoMem;
+        } catch (...) {
+            errs[r] = "exception in a rank thread";
+            return kShardErrInternal;
+        }
+    };
+    // wait for what this rank enqueued; a failure there is reported unless the rank already has an error of its own
+    auto drained = [&](int r, int rc) -> int {
+        std::string keep = errs[r];
+        const int d = guarded(drain, r);
+        if (rc != 0) { errs[r] = keep; return rc; }
+        return d;
+    };
     auto rank_body = [&](int r) {
-        int rc = prepare(r);
-        if (rc != 0) errs[r] = last_error();
+        int rc = guarded(prepare, r);
         const int v1 = vote1.arrive(r, rc);
         if (v1 != 0) {                       // somebody failed before the collective: nobody enters it
-            (void)drain(r);                  // whatever this rank did enqueue finishes before the call returns
-            rcs[r] = rc;
+            rcs[r] = drained(r, rc);         // whatever this rank did enqueue finishes before the call returns
             return;
         }
-        rc = collective(r);
-        if (rc != 0) errs[r] = last_error();
+        rc = guarded(collective, r);
         const int v2 = vote2.arrive(r, rc);
         if (v2 != 0) {                       // a collective failed somewhere: release every rank that is (or will be) waiting in one
-            abort(r);
-            (void)drain(r);
-            rcs[r] = rc;
+            try { abort(r); } catch (...) {}
+            rcs[r] = drained(r, rc);
             if (r == 0) res.collective_failed = true;
             return;
         }
-        rc = finish(r);
-        if (rc != 0) errs[r] = last_error();
-        rcs[r] = rc;
+        rcs[r] = guarded(finish, r);
     };
     auto rank_main = [&](int r) { enter(r); rank_body(r); leave(r); };
     if (G == 1) rank_main(0);
     else {
         std::vector<std::thread> th;
-        th.reserve(G);
-        for (int r = 0; r < G; r++) th.emplace_back(rank_main, r);
+        int started = 0;
+        try {
+            th.reserve(G);
+            for (; started < G; started++) th.emplace_back(rank_main, started);
+        } catch (...) {
+            // could not start every rank: the missing ranks vote "failed" from here, so that the ones running leave their votes
+            for (int r = started; r < G; r++) {
+                errs[r] = "could not start a rank thread";
+                rcs[r] = kShardErrNoMem;
+                if (vote1.arrive(r, kShardErrNoMem) == 0) (void)vote2.arrive(r, kShardErrNoMem);
+            }
+        }
         for (auto& t : th) t.join();
     }
     for (int r = 0; r < G; r++)

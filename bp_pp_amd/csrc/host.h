@@ -96,6 +96,11 @@ struct bppp_ctx {
     size_t stage_bytes = 0;
     uint8_t* d_io = nullptr;     // inputs / outputs of bppp_u64_verify_batch (host buffers)
     size_t io_bytes = 0;
+    uint8_t* d_blob = nullptr;   // inputs | outputs | workspace of ONE generic host-buffer call (bppp_generic.hip), grow-only
+    size_t blob_bytes = 0;
+    uint8_t* d_txio = nullptr;   // transcripts in / out of a generic prover call
+    size_t txio_bytes = 0;
+    int inject_alloc_fault = 0;  // testing aid ("inject_alloc_fault"): the k-th device allocation from now on fails
     uint8_t* d_gws = nullptr;    // workspace of bppp_reciprocal_verify_batch_device
     size_t gws_bytes = 0;
     uint8_t* d_gtab = nullptr;   // generic verifiers: affine window tables of the round points + build scratch (wnla_core.h, fast path)
@@ -127,6 +132,35 @@ struct CtxLock {
     CtxLock& operator=(const CtxLock&) = delete;
 };
 
+// Every device allocation of a context's workspaces and staging goes through here: a failure is an honest BPPP_ERR_NOMEM (HIP_TRY maps
+// hipErrorOutOfMemory), and the "inject_alloc_fault" option can make the k-th one fail so that the tests can walk every such path.
+static inline hipError_t ctx_malloc(bppp_ctx* c, void** p, size_t bytes) {
+    *p = nullptr;
+    if (c->inject_alloc_fault > 0 && --c->inject_alloc_fault == 0) return hipErrorOutOfMemory;
+    return hipMalloc(p, bytes);
+}
+// grow-only buffer: keeps what it has when it is large enough, otherwise frees and allocates `bytes` (contents are not preserved)
+static inline int ensure_buffer(bppp_ctx* c, uint8_t*& d, size_t& have, size_t bytes) {
+    if (bytes <= have && d) return BPPP_OK;
+    if (d) { (void)hipFree(d); d = nullptr; have = 0; }
+    HIP_TRY(ctx_malloc(c, (void**)&d, bytes ? bytes : 16));
+    have = bytes ? bytes : 16;
+    return BPPP_OK;
+}
+// staging of the host-buffer entry points (inputs and outputs of one call; every such call holds the context's lock and waits for its
+// stream before it returns, so one buffer serves them all -- no allocator round trip and no implicit device sync per call)
+static inline int ensure_io(bppp_ctx* c, size_t bytes) { return ensure_buffer(c, c->d_io, c->io_bytes, bytes); }
+static inline int ensure_blob(bppp_ctx* c, size_t bytes) { return ensure_buffer(c, c->d_blob, c->blob_bytes, bytes); }
+
+// after a failed call: nothing of it may still be running when the entry point returns (the staging is reused by the next call, and
+// copies from / to the caller's memory may be queued) -- what the implicit synchronisation of a per-call hipFree used to provide
+static inline void quiesce(bppp_ctx* c) {
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipGetLastError();
+}
+
 static const size_t WS_WORDS_PER_PROOF = 52 + 80 + 176 + 200 + 208 + 24 + 30 + 30 + 392;
 
 static inline int ensure_capacity(bppp_ctx* c, size_t n) {
@@ -136,7 +170,7 @@ static inline int ensure_capacity(bppp_ctx* c, size_t n) {
     c->ws_bytes = 0;
     size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
     const size_t bytes = cap * WS_WORDS_PER_PROOF * sizeof(u32);
-    HIP_TRY(hipMalloc(&c->d_ws, bytes));
+    HIP_TRY(ctx_malloc(c, (void**)&c->d_ws, bytes));
     c->ws_bytes = bytes;
     c->cap = cap;
     return BPPP_OK;
@@ -150,7 +184,7 @@ static inline int ensure_straus_capacity(bppp_ctx* c, size_t n) {
     c->straus_bytes = 0;
     size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
     const size_t bytes = cap * 5 * BPPP_STRAUS_ENTRIES * sizeof(pt_slot);
-    HIP_TRY(hipMalloc(&c->d_straus, bytes));
+    HIP_TRY(ctx_malloc(c, (void**)&c->d_straus, bytes));
     c->straus_bytes = bytes;
     c->scap = cap;
     return BPPP_OK;
@@ -164,8 +198,8 @@ static inline int ensure_vtab_capacity(bppp_ctx* c, size_t n) {
     size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
     const size_t atab_bytes = cap * BPPP_ATAB_PER_PROOF * sizeof(apt_packed);
     const size_t tscr_bytes = cap * (size_t)(BPPP_TSCR_FE * 10) * sizeof(u32);
-    HIP_TRY(hipMalloc(&c->d_atab, atab_bytes));
-    HIP_TRY(hipMalloc(&c->d_tscr, tscr_bytes));
+    HIP_TRY(ctx_malloc(c, (void**)&c->d_atab, atab_bytes));
+    HIP_TRY(ctx_malloc(c, (void**)&c->d_tscr, tscr_bytes));
     c->vtab_bytes = atab_bytes + tscr_bytes;
     c->vcap = cap;
     return BPPP_OK;
@@ -177,7 +211,7 @@ static inline int ensure_rlc_capacity(bppp_ctx* c, size_t n) {
     c->rlc_bytes = 0;
     size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
     const size_t rbytes = cap * (30 + (size_t)BPPP_NG * 8) * sizeof(u32) + cap + (cap / BPPP_RLC_CHUNK + 4) * sizeof(u32);   // lhs, sc | flags (cap bytes) | list, count
-    HIP_TRY(hipMalloc(&c->d_rlc, rbytes));
+    HIP_TRY(ctx_malloc(c, (void**)&c->d_rlc, rbytes));
     c->rlc_bytes = rbytes;
     c->rcap = cap;
     return BPPP_OK;
@@ -194,7 +228,7 @@ static inline int ensure_prove_capacity(bppp_ctx* c, size_t n) {
     c->pws_bytes = 0;
     size_t cap = (n + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
     const size_t pbytes = cap * PWS_WORDS_PER_PROOF * sizeof(u32);
-    HIP_TRY(hipMalloc(&c->d_pws, pbytes));
+    HIP_TRY(ctx_malloc(c, (void**)&c->d_pws, pbytes));
     c->pws_bytes = pbytes;
     c->pcap = cap;
     return BPPP_OK;
@@ -202,7 +236,7 @@ static inline int ensure_prove_capacity(bppp_ctx* c, size_t n) {
 static inline int ensure_stage(bppp_ctx* c, size_t bytes) {
     if (bytes <= c->stage_bytes) return BPPP_OK;
     if (c->d_stage) { (void)hipFree(c->d_stage); c->d_stage = nullptr; c->stage_bytes = 0; }
-    HIP_TRY(hipMalloc(&c->d_stage, bytes));
+    HIP_TRY(ctx_malloc(c, (void**)&c->d_stage, bytes));
     c->stage_bytes = bytes;
     return BPPP_OK;
 }
@@ -253,7 +287,7 @@ static inline int ensure_bucket_capacity(bppp_ctx* c, size_t n, size_t nb) {
     const size_t need = bkt_bytes_for(cap, cap / 64 + 1, nb);      // enough for any superchunk size >= 64
     if (need <= c->bkt_bytes) return BPPP_OK;
     if (c->d_bkt) { (void)hipFree(c->d_bkt); c->d_bkt = nullptr; c->bkt_bytes = 0; }
-    HIP_TRY(hipMalloc(&c->d_bkt, need));
+    HIP_TRY(ctx_malloc(c, (void**)&c->d_bkt, need));
     c->bkt_bytes = need;
     return BPPP_OK;
 }

@@ -15,6 +15,14 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, hi
 
 
+def _seed32(rlc_seed) -> bytes:
+    """The RLC seed as the 32 bytes the C side reads (a shorter buffer would be read out of bounds and silently change the weights)."""
+    b = bytes(rlc_seed)
+    if len(b) != 32:
+        raise ValueError("rlc_seed must be exactly 32 bytes")
+    return b
+
+
 def all_reduce_reject_count(count_tensor):
     """Sum the per-rank reject counts in place; returns the global number of rejected proofs (0 => batch accepted).
     `count_tensor` is a 1-element int32 tensor on this rank's device (the `d_reject_count` of bppp_u64_verify_batch_device)."""
@@ -41,8 +49,27 @@ class _Group:
         _capi.check(_capi.lib().bppp_wnla_group_create(C.byref(self._grp), bytes(g), b"".join(gv), len(gv), b"".join(hv), len(hv), arr,
                                                        len(self.devices), fb_window_bits))
 
+    def _lend(self, view):
+        """A rank context handed out as a protocol view: the view keeps the group alive, and close() invalidates it (its raw context
+        pointer dies with the group)."""
+        import weakref
+        view._parent = self
+        if not hasattr(self, "_views"):
+            self._views = []
+        self._views.append(weakref.ref(view))
+        return view
+
     def close(self):
         if getattr(self, "_grp", None) is not None and self._grp.value:
+            import ctypes as C
+            for ref in getattr(self, "_views", []):
+                v = ref()
+                if v is not None:                       # a use after close raises instead of touching freed memory
+                    if hasattr(v, "_w"):
+                        v._w._ctx = C.c_void_p()
+                    if hasattr(v, "_ctx"):
+                        v._ctx = C.c_void_p()
+            self._views = []
             self._capi.lib().bppp_group_destroy(self._grp)
             self._grp.value = None
 
@@ -84,7 +111,7 @@ class U64RangeProofGroup(_Group):
         ctx = self._capi.lib().bppp_group_ctx(self._grp, rank)
         if not ctx:
             raise ValueError("rank out of range")
-        return U64RangeProofProtocol.borrowed(ctx)
+        return self._lend(U64RangeProofProtocol.borrowed(ctx))
 
     def _host(self, commitments, proofs, cw, pw):
         import numpy as np
@@ -103,7 +130,7 @@ class U64RangeProofGroup(_Group):
                                                  accept.ctypes.data, status.ctypes.data, C.byref(rej))
         else:
             rc = L.bppp_u64_verify_batch_rlc_sharded(self._grp, label, len(label), n, commitments.ctypes.data, proofs.ctypes.data,
-                                                     accept.ctypes.data, status.ctypes.data, C.byref(rej), bytes(rlc_seed))
+                                                     accept.ctypes.data, status.ctypes.data, C.byref(rej), _seed32(rlc_seed))
         self._capi.check(rc)
         return accept, status, int(rej.value)
 
@@ -137,7 +164,7 @@ class U64RangeProofGroup(_Group):
                                                         mk(d_status), mk(d_reject_count))
         else:
             rc = L.bppp_u64_verify_batch_rlc_sharded_device(self._grp, label, len(label), n, mk(d_commitments), mk(d_proofs), mk(d_accept),
-                                                            mk(d_status), mk(d_reject_count), bytes(rlc_seed))
+                                                            mk(d_status), mk(d_reject_count), _seed32(rlc_seed))
         self._capi.check(rc)
 
     def verify_batch_sec1_device(self, label: bytes, n: int, d_commitments33, d_proofs525, d_accept, d_status, d_reject_count) -> None:
@@ -193,7 +220,7 @@ class ReciprocalRangeProofGroup(_Group):
         ctx = self._capi.lib().bppp_group_ctx(self._grp, rank)
         if not ctx:
             raise ValueError("rank out of range")
-        return ReciprocalRangeProofProtocol.borrowed(self.dim_nd, self.dim_np, ctx, self._ng, self._nh)
+        return self._lend(ReciprocalRangeProofProtocol.borrowed(self.dim_nd, self.dim_np, ctx, self._ng, self._nh))
 
     def verify_batch(self, label: bytes, commitments, proofs, rounds: int, nl: int, nn: int, rlc_seed: bytes = None):
         """Host buffers -> (accept[n] u8, status[n] i32, global reject count)."""
@@ -209,7 +236,7 @@ class ReciprocalRangeProofGroup(_Group):
         else:
             rc = L.bppp_reciprocal_verify_batch_rlc_sharded(self._grp, label, len(label), n, self.dim_nd, self.dim_np, commitments.ctypes.data,
                                                             proofs.ctypes.data, rounds, nl, nn, accept.ctypes.data, status.ctypes.data,
-                                                            C.byref(rej), bytes(rlc_seed))
+                                                            C.byref(rej), _seed32(rlc_seed))
         self._capi.check(rc)
         return accept, status, int(rej.value)
 
@@ -222,5 +249,5 @@ class ReciprocalRangeProofGroup(_Group):
         else:
             rc = L.bppp_reciprocal_verify_batch_rlc_sharded_device(self._grp, label, len(label), n, self.dim_nd, self.dim_np, mk(d_commitments),
                                                                    mk(d_proofs), rounds, nl, nn, mk(d_accept), mk(d_status), mk(d_reject_count),
-                                                                   bytes(rlc_seed))
+                                                                   _seed32(rlc_seed))
         self._capi.check(rc)

@@ -294,6 +294,10 @@ class U64RangeProofProtocol:
         the single-proof front end of verify_one / prove_one)."""
         _capi.check(_capi.lib().bppp_ctx_set_option(self._ctx, name.encode(), int(value)))
 
+    def get_option(self, name: str) -> int:
+        """bppp_ctx_get_option: a tunable read back, or "fb_window_bits" (the table width in use), "device", "n_generators"."""
+        return int(_capi.check(_capi.lib().bppp_ctx_get_option(self._ctx, name.encode())))
+
     def synchronize(self) -> None:
         """Block until everything queued on the context's current stream (and its helper stream) has finished."""
         _capi.check(_capi.lib().bppp_ctx_synchronize(self._ctx))

@@ -28,6 +28,7 @@ extern "C" {
     pub fn bppp_ctx_destroy(ctx: *mut BpppCtx);
     pub fn bppp_ctx_set_stream(ctx: *mut BpppCtx, hip_stream: *mut c_void) -> c_int;
     pub fn bppp_ctx_set_option(ctx: *mut BpppCtx, name: *const c_char, value: c_long) -> c_int;
+    pub fn bppp_ctx_get_option(ctx: *mut BpppCtx, name: *const c_char) -> c_long;
     pub fn bppp_ctx_synchronize(ctx: *mut BpppCtx) -> c_int;
     pub fn bppp_u64_verify_batch(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, commitments: *const u8, proofs: *const u8, accept: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_u64_verify_batch_device(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, d_commitments: *const c_void, d_proofs: *const c_void, d_accept: *mut c_void, d_status: *mut c_void, d_trace: *mut c_void, d_reject_count: *mut c_void) -> c_int;
@@ -39,6 +40,11 @@ extern "C" {
     pub fn bppp_u64_prove_batch_device(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, d_x: *const c_void, d_s: *const c_void, d_rnd: *const c_void, d_proofs: *mut c_void, d_commitments: *mut c_void, d_status: *mut c_void) -> c_int;
     pub fn bppp_u64_prove_batch_sec1(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, x: *const u64, s: *const u8, rnd: *const u8, proofs525: *mut u8, commitments33: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_u64_prove_batch_sec1_device(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, d_x: *const c_void, d_s: *const c_void, d_rnd: *const c_void, d_proofs525: *mut c_void, d_commitments33: *mut c_void, d_status: *mut c_void) -> c_int;
+    pub fn bppp_u64_verify_one(ctx: *mut BpppCtx, label: *const u8, label_len: usize, commitment: *const u8, proof: *const u8, accept: *mut u8, status: *mut i32) -> c_int;
+    pub fn bppp_u64_verify_one_transcript(ctx: *mut BpppCtx, state: *mut u8, commitment: *const u8, proof: *const u8, accept: *mut u8, status: *mut i32) -> c_int;
+    pub fn bppp_u64_prove_one(ctx: *mut BpppCtx, label: *const u8, label_len: usize, x: u64, s: *const u8, rnd: *const u8, proof: *mut u8, commitment: *mut u8, status: *mut i32) -> c_int;
+    pub fn bppp_u64_prove_one_transcript(ctx: *mut BpppCtx, state: *mut u8, x: u64, s: *const u8, rnd: *const u8, proof: *mut u8, commitment: *mut u8, status: *mut i32) -> c_int;
+    pub fn bppp_ctx_get_coalesce_stats(ctx: *mut BpppCtx, which: c_int, out: *mut u64) -> c_int;
     pub fn bppp_u64_commit_value_batch(ctx: *mut BpppCtx, n: usize, x: *const u64, s: *const u8, out: *mut u8) -> c_int;
     pub fn bppp_wnla_ctx_create(out: *mut *mut BpppCtx, g: *const u8, g_vec: *const u8, ng: usize, h_vec: *const u8, nh: usize, device: c_int, fb_window_bits: c_int) -> c_int;
     pub fn bppp_wnla_commit_batch(ctx: *mut BpppCtx, n: usize, c: *const u8, mu: *const u8, l: *const u8, nl: usize, nvec: *const u8, nn: usize, out: *mut u8, status: *mut i32) -> c_int;

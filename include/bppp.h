@@ -67,8 +67,11 @@ typedef struct bppp_ctx bppp_ctx;
  * after the results have been copied back. */
 
 /* U64RangeProofProtocol { g, g_vec[16], h_vec[32] } (u64_proof.rs:19-28) bound to GPU `device`.
- * Builds the fixed-base tables for the 49 generators on the GPU.  fb_window_bits: 0 = the widest windows whose tables stay below
- * 100 GB of HBM -- for the 49 generators 22 (signed 22-bit digits: 49 x 12 x 2^21 affine points = 79 GB, 12 table additions per
+ * Builds the fixed-base tables for the 49 generators on the GPU.  fb_window_bits: 0 = the widest windows among {22, 20, 16, 8, 4}
+ * whose tables take at most 35 % of the HBM that is FREE on the device when the context is created (hipMemGetInfo) and whose build
+ * scratch still fits beside them; should that allocation fail anyway, the next narrower width is tried (bppp_ctx_get_option
+ * "fb_window_bits" tells which one was taken).  On an otherwise empty MI355X that is, for the 49 generators, 22 (signed 22-bit
+ * digits: 49 x 12 x 2^21 affine points = 79 GB, 12 table additions per
  * scalar, built in passes with <= 32 GB of temporaries; 2.4-3.1 % faster end to end on a 2^20-proof batch than 20); 20 (signed, 49
  * x 13 x 2^19 points = 21 GB, 13 additions per scalar: the choice when HBM is shared with something else); 16 (unsigned, 3.3 GB,
  * 16 additions); 18, 19 (signed, 15 / 14 additions: for large generator sets with HBM to spare -- 769 generators: 97 / 181 GB);
@@ -87,12 +90,17 @@ BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
  * off (chunks of 8 only), otherwise a multiple of 8 in [64, 8192]; default 4096.  "host_chunk": the host-buffer verify entry points
  * (bppp_u64_verify_batch, bppp_u64_verify_batch_rlc) cut a batch of more than 1.5 x host_chunk proofs into chunks of host_chunk proofs and upload
  * chunk k + 1 on a second stream while chunk k is being verified (proofs are independent: the results are those of one call) --
- * a multiple of 64, >= 1024; default 131072 (one full grid of the per-proof kernels); 0 = upload the whole batch first.  "max_batch": the u64 verify entry
+ * a multiple of 64, >= 1024; default 131072 (one full grid of the per-proof kernels); 0 = upload the whole batch first.  "inject_alloc_fault" = k
+ * (testing aid): the k-th device allocation this context makes from now on fails, so the call that makes it returns BPPP_ERR_NOMEM and
+ * the context stays usable; 0 clears it.  "max_batch": the u64 verify entry
  * points run a batch of more than max_batch proofs as consecutive parts of max_batch on the same stream, which bounds the per-proof
  * workspace (about 30 KB per proof) whatever n is -- a multiple of 64, >= 1024; default 2097152 (63 GB of workspace).
  * "coalesce_max" (1 .. 65536, default 1024), "coalesce_us" (0 .. 1000000, default 100), "coalesce_lanes" (1 .. 8, default 2): the
  * single-proof front end below (bppp_u64_verify_one / bppp_u64_prove_one); changing one drains the running front end. */
 BPPP_API int bppp_ctx_set_option(bppp_ctx* ctx, const char* name, long value);
+/* Reads a tunable back, or one of the read-only facts "fb_window_bits" (the width in use: the library's choice when the context was
+ * created with 0), "device", "n_generators".  Negative = BPPP_ERR_INVALID_ARG (unknown name). */
+BPPP_API long bppp_ctx_get_option(bppp_ctx* ctx, const char* name);
 /* Block the calling host thread until everything queued by this context (current stream + its helper stream) has finished. */
 BPPP_API int bppp_ctx_synchronize(bppp_ctx* ctx);
 
@@ -307,7 +315,7 @@ BPPP_API int bppp_derive_generators(const uint8_t* seed, size_t seed_len, size_t
 /* The fixed-base tables of a context as a file, and a context created from such a file instead of from the generators (any of the
  * bppp_ctx_create / bppp_wnla_ctx_create shapes).  NOTE: the tables are BUILT on the GPU in 0.5 s (79 GB, 22-bit) to 3 s -- faster than any
  * disk or PCIe can deliver them -- so the file is for reproducibility and inspection, not for start-up time; what saves memory and
- * time is bppp_ctx_create_shared.  The file (magic "BPPPTAB2") carries a checksum over the generators and the table body, and the
+ * time is bppp_ctx_create_shared.  The file (magic "BPPPTAB3") carries a checksum over its header (generator counts, window width), the generators and the table body, and the
  * stored generators are validated as bppp_ctx_create validates them: a truncated, damaged or foreign file makes
  * bppp_ctx_create_from_tables fail (BPPP_ERR_INVALID_ARG / BPPP_ERR_ENCODING) instead of yielding a verifier over wrong bases.  The
  * checksum is not a MAC: whoever can rewrite the file can rewrite it too -- rebuild the tables when the storage is not trusted. */

@@ -1096,6 +1096,7 @@ int emul_group_verify(int kind, int G, int fail_rank, int fail_collective_rank, 
     };
     auto prepare = [&](int r) -> int {
         if (r == fail_rank) return EMUL_ERR_NOMEM;
+        if (r == fail_rank - 100) throw std::bad_alloc();      // fail_rank = 100 + r: rank r's prepare THROWS instead of returning a code
         size_t lo, m;
         range(r, lo, m);
         if (m) {

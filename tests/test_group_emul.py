@@ -75,6 +75,15 @@ def test_failing_rank_fails_closed(u64_case):
     assert rc == 0 and (acc == u64_case[4]).all()
 
 
+def test_throwing_rank_still_votes(u64_case):
+    """A rank whose prepare phase throws (std::bad_alloc in its host-side bookkeeping) must not die before the vote -- the others
+    would wait for it for ever: the exception becomes that rank's return code and the call fails closed like any other failure."""
+    rc, _, _, _, aborted, dt = _group_u64(u64_case, 3, fail_rank=101, timeout_ms=60000)
+    assert rc == ERR_NOMEM and not aborted and dt < 30
+    rc, acc, _, _, _, _ = _group_u64(u64_case, 3)
+    assert rc == 0 and (acc == u64_case[4]).all()
+
+
 def test_failing_collective_aborts_instead_of_hanging(u64_case):
     rc, _, _, _, aborted, dt = _group_u64(u64_case, 3, fail_coll=1, timeout_ms=60000)
     assert rc == ERR_RCCL and aborted == 1 and dt < 30

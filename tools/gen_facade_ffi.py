@@ -6,14 +6,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TMAP = [(r'const uint8_t\s*\*\s*const\s*\*', '*const *const u8'), (r'const void\s*\*\s*const\s*\*', '*const *const c_void'),
         (r'void\s*\*\s*const\s*\*', '*const *mut c_void'),
         (r'const uint8_t\s*\*', '*const u8'), (r'uint8_t\s*\*', '*mut u8'), (r'const int32_t\s*\*', '*const i32'), (r'int32_t\s*\*', '*mut i32'),
-        (r'const uint64_t\s*\*', '*const u64'), (r'const size_t\s*\*', '*const usize'), (r'size_t\s*\*', '*mut usize'),
+        (r'const uint64_t\s*\*', '*const u64'), (r'uint64_t\s*\*', '*mut u64'), (r'const size_t\s*\*', '*const usize'), (r'size_t\s*\*', '*mut usize'),
         (r'const void\s*\*', '*const c_void'), (r'void\s*\*', '*mut c_void'), (r'const char\s*\*\s*\*', '*mut *const c_char'),
         (r'const char\s*\*', '*const c_char'), (r'double\s*\*', '*mut f64'), (r'int64_t\s*\*', '*mut i64'), (r'const int\s*\*', '*const c_int'),
         (r'bppp_ctx\s*\*\s*\*', '*mut *mut BpppCtx'), (r'const bppp_ctx\s*\*', '*const BpppCtx'), (r'bppp_ctx\s*\*', '*mut BpppCtx'),
         (r'bppp_circuit\s*\*\s*\*', '*mut *mut BpppCircuit'), (r'const bppp_circuit\s*\*', '*const BpppCircuit'), (r'bppp_circuit\s*\*', '*mut BpppCircuit'),
         (r'bppp_group\s*\*\s*\*', '*mut *mut BpppGroup'), (r'const bppp_group\s*\*', '*const BpppGroup'), (r'bppp_group\s*\*', '*mut BpppGroup'),
         (r'size_t', 'usize'), (r'uint64_t', 'u64'), (r'int32_t', 'i32'), (r'int', 'c_int'), (r'long', 'c_long')]
-RET = {'int': ' -> c_int', 'void': '', 'size_t': ' -> usize', 'const char*': ' -> *const c_char', 'const char *': ' -> *const c_char',
+RET = {'int': ' -> c_int', 'long': ' -> c_long', 'void': '', 'size_t': ' -> usize', 'const char*': ' -> *const c_char', 'const char *': ' -> *const c_char',
        'bppp_ctx*': ' -> *mut BpppCtx', 'bppp_ctx *': ' -> *mut BpppCtx'}
 HEAD = '''//! `extern "C"` declarations of EVERY entry point of include/bppp.h (libbppp_hip.so).  Generated from the header by
 //! tools/gen_facade_ffi.py and checked against it by tests/test_facade_tree.py.  UNCOMPILED (no Rust toolchain in the build

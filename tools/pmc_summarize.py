@@ -10,6 +10,8 @@ import sys
 from collections import defaultdict
 
 out_dir = sys.argv[1]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bp_pp_amd import _build   # noqa: E402  (no GPU call: only reads the library file)
 
 
 def load(prefix, counter):
@@ -29,7 +31,9 @@ def load(prefix, counter):
 N_PER_LAUNCH = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 KEEP = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 and sys.argv[3] else ("k_",)
 BENCH_PREFIX = sys.argv[4] if len(sys.argv) > 4 else "bench"
-res = {"units": "bytes per launch; raw = counter * 1024", "calibration": {}, "kernels": {}, "proofs_per_launch": N_PER_LAUNCH}
+# code_object_sha256: the kernels these counters were collected on (bench.py nulls `traffic` when the loaded library differs)
+res = {"units": "bytes per launch; raw = counter * 1024", "calibration": {}, "kernels": {}, "proofs_per_launch": N_PER_LAUNCH,
+       "code_object_sha256": _build.device_code_sha256()}
 GIB = float(1 << 30)
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     cal = load("cal", counter)
