@@ -523,6 +523,15 @@ def run_verify(args):
         recip15 = {k: r[k] for k in keep + ("rlc_mode", "accept_bits_ok", "device_bytes") if k in r}
         ok_extra = okp and okr
 
+    # every rank's own clock over the timed region, gathered (what the max below is taken over)
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    if dist_on:
+        mine = torch.tensor([elapsed / args.steps * 1e3], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [float(x.item()) for x in allr]
+    ranks = {"backend": (dist.get_backend() if dist_on else None), "rccl_nranks": (world if dist_on and dist.get_backend() == "nccl" else 0),
+             "per_rank_ms": [round(x, 3) for x in per_rank_ms], "max_ms": round(max(per_rank_ms), 3), "one_device_dry_run": bool(os.environ.get("BENCH_ONE_DEVICE"))}
     elapsed = max_over_ranks(elapsed)
     ok_all = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device="cuda")
     if dist_on:
@@ -581,6 +590,7 @@ def run_verify(args):
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kernel_times.items() if v["launches"]},
             "accept_bits_ok": ok,
             "reject_count_all_reduced": rejects,
+            "ranks": ranks,
             "configs1_2pow16": cfg1,
             "shard_2pow17": shard17,
             "concurrent_callers": callers,

@@ -109,6 +109,7 @@ struct bppp_front {
             if (rc != BPPP_OK) return rc;
             lanes.push_back(ch);
             CtxLock lock_(ch);
+            ch->ct_prover = parent->ct_prover;       // (the 4-bit table is shared with the parent: bppp_ctx_create_shared)
             if (prove) rc = ensure_prove_capacity(ch, max);
             else {
                 rc = ensure_capacity(ch, max);

@@ -35,8 +35,9 @@ static bool window_fits(int nbases, int W, size_t free_bytes) {
     const double scratch = (double)build_group_for(nbases, W) * fb_nwin(W) * (double)fb_per_win(W) * 4 * sizeof(fe);
     return tb <= 0.35 * (double)free_bytes && tb + scratch <= 0.90 * (double)free_bytes;
 }
-// Build the fixed-base tables of c->d_gens at window width W into a fresh c->d_table.  On failure nothing stays allocated.
-static int build_tables(bppp_ctx* c, int W) {
+// Build the fixed-base tables of c->d_gens at window width W into a fresh c->d_table (ct = false) or into c->d_table_ct (the 4-bit
+// table of the "ct_prover" mode).  On failure nothing stays allocated.
+static int build_tables(bppp_ctx* c, int W, bool ct = false) {
     const int NB = c->nbases;
     const int nwin = fb_nwin(W);
     const size_t per_win = fb_per_win(W);
@@ -72,10 +73,21 @@ static int build_tables(bppp_ctx* c, int W) {
     HIP_TRY_T(hipStreamSynchronize(c->stream));
 #undef HIP_TRY_T
     (void)hipFree(d_tmp);
+    if (ct) { c->d_table_ct = d_table; c->table_ct_bytes = bytes; return BPPP_OK; }
     c->d_table = d_table;
     c->table_bytes = bytes;
     c->fb_w = W;
     return BPPP_OK;
+}
+int ensure_ct_table(bppp_ctx* c) {
+    if (c->d_table_ct) return BPPP_OK;
+    if (c->fb_w == 4 && c->d_table) {          // the context's own tables already have that shape
+        c->d_table_ct = c->d_table;
+        c->borrows_table_ct = true;
+        return BPPP_OK;
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    return build_tables(c, 4, true);
 }
 
 extern "C" {
@@ -181,6 +193,7 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->d_gens && !c->borrows_tables) (void)hipFree(c->d_gens);
     if (c->d_table && !c->borrows_tables) (void)hipFree(c->d_table);
+    if (c->d_table_ct && !c->borrows_table_ct) (void)hipFree(c->d_table_ct);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_straus) (void)hipFree(c->d_straus);
     if (c->d_rlc) (void)hipFree(c->d_rlc);
@@ -241,6 +254,18 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
         else c->coalesce_lanes = (int)value;
         return BPPP_OK;
     }
+    // the provers' secret-scalar sums in the constant-address form (include/bppp.h); the running single-proof front ends are drained
+    // so that their lane contexts pick the setting up
+    if (std::strcmp(name, "ct_prover") == 0) {
+        if (value != 0 && value != 1) return BPPP_ERR_INVALID_ARG;
+        if (value) {
+            int rc = ensure_ct_table(c);
+            if (rc != BPPP_OK) return rc;
+        }
+        bppp_fronts_teardown(c, false);
+        c->ct_prover = value != 0;
+        return BPPP_OK;
+    }
     // testing aid: the value-th device allocation from now on (workspaces, staging, tables) fails with BPPP_ERR_NOMEM; 0 clears it
     if (std::strcmp(name, "inject_alloc_fault") == 0) {
         if (value < 0) return BPPP_ERR_INVALID_ARG;
@@ -268,6 +293,7 @@ long bppp_ctx_get_option(bppp_ctx* c, const char* name) {
     if (std::strcmp(name, "coalesce_max") == 0) return c->coalesce_max;
     if (std::strcmp(name, "coalesce_us") == 0) return c->coalesce_us;
     if (std::strcmp(name, "coalesce_lanes") == 0) return c->coalesce_lanes;
+    if (std::strcmp(name, "ct_prover") == 0) return c->ct_prover ? 1 : 0;
     return BPPP_ERR_INVALID_ARG;
 }
 int bppp_ctx_synchronize(bppp_ctx* c) {
@@ -281,7 +307,7 @@ int bppp_ctx_synchronize(bppp_ctx* c) {
 
 size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
     if (!c) return 0;
-    return c->table_bytes + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->bkt_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + c->blob_bytes + c->txio_bytes + c->gws_bytes + c->gtab_bytes + (size_t)c->nbases * sizeof(apt);
+    return c->table_bytes + (c->borrows_table_ct ? 0 : c->table_ct_bytes) + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->bkt_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + c->blob_bytes + c->txio_bytes + c->gws_bytes + c->gtab_bytes + (size_t)c->nbases * sizeof(apt);
 }
 
 int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
@@ -552,6 +578,7 @@ int bppp_ctx_create_shared(bppp_ctx** out, bppp_ctx* parent) {
     if (!c) return BPPP_ERR_NOMEM;
     c->device = parent->device; c->fb_w = parent->fb_w; c->ng = parent->ng; c->nh = parent->nh; c->nbases = parent->nbases;
     c->d_gens = parent->d_gens; c->d_table = parent->d_table; c->table_bytes = 0; c->borrows_tables = true;
+    if (parent->d_table_ct) { c->d_table_ct = parent->d_table_ct; c->borrows_table_ct = true; c->ct_prover = parent->ct_prover; }
     int rc = ctx_alloc_common(c);
     if (rc != BPPP_OK) { bppp_ctx_destroy(c); return rc; }
     *out = c;

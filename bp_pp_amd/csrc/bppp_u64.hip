@@ -326,7 +326,13 @@ int bppp_u64_commit_value_batch(bppp_ctx* c, size_t n, const uint64_t* x, const 
     HIP_TRY(hipMemcpyAsync(d_x, x, n * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_s, s, n * 32, hipMemcpyHostToDevice, c->stream));
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
-    k_commit_value<<<blocks, BPPP_BLOCK, 0, c->stream>>>(ws, d_x, d_s, d_o, c->d_flags);
+    FbTable ct = {nullptr, 4, n};
+    if (c->ct_prover) {
+        rc = ensure_ct_table(c);
+        if (rc != BPPP_OK) return rc;
+        ct.table = c->d_table_ct;
+    }
+    k_commit_value<<<blocks, BPPP_BLOCK, 0, c->stream>>>(ws, d_x, d_s, d_o, c->d_flags, ct);
     HIP_TRY(hipGetLastError());
     int flags = 0;
     HIP_TRY(hipMemcpyAsync(out, d_o, n * 64, hipMemcpyDeviceToHost, c->stream));
@@ -373,6 +379,12 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     w.pbuf = p;
     w.straus = c->d_straus;
     w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    if (c->ct_prover) {
+        rc = ensure_ct_table(c);
+        if (rc != BPPP_OK) return rc;
+        w.ct = 1;
+        w.fb_ct.table = c->d_table_ct; w.fb_ct.W = 4; w.fb_ct.N = n;
+    }
     t_new(w.base, label, (u32)label_len);
     if (tx) { w.states = (const uint8_t*)tx->d_states; w.n_states = tx->n_states; w.states_out = (uint8_t*)tx->d_states_out; }
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
@@ -406,16 +418,25 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
         else PLAUNCH(K_PROVE_MSM, k_prove_msm_x<<<dim3(fb_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));                       \
     } while (0)
 #define PMSM(job) PMSMX(1, job, job, job, job)
+    // the sums over the witness and its blindings: as above, or -- "ct_prover" -- in the form that reads every table entry of every window
+#define PSECRETX(NJ, ...)                                                                                                  \
+    do {                                                                                                                    \
+        if (w.ct) {                                                                                                         \
+            MsmJobs js = {{__VA_ARGS__}};                                                                                    \
+            PLAUNCH(K_PROVE_MSM, k_prove_msm_ct<<<dim3(fb_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));                        \
+        } else PMSMX(NJ, __VA_ARGS__);                                                                                      \
+    } while (0)
+#define PSECRET(job) PSECRETX(1, job, job, job, job)
     // a grid that gives every SIMD more than one wavefront runs the 256-register builds of the lane kernels (two wavefronts per SIMD)
     const bool w2 = c->no_small || blocks > (unsigned)c->n_simds;
     PLAUNCH(K_PROVE_STAGES, k_prove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-    PMSM(job_v());
+    PSECRET(job_v());
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_b_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-    PMSMX(4, job_rcom(), job_co(), job_cl(), job_cr());
+    PSECRETX(4, job_rcom(), job_co(), job_cl(), job_cr());
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-    PMSM(job_cs());
+    PSECRET(job_cs());
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_c0());
@@ -434,6 +455,8 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
         pending_cnext = w.next_by_msm && k < 4;     // its scalars are in set 0 now; the sum rides with the next round's X | R
     }
     if (w.states_out) k_prove_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+#undef PSECRETX
+#undef PSECRET
 #undef PMSMX
 #undef PMSM
 #undef PLAUNCH

@@ -65,6 +65,10 @@ struct bppp_ctx {
     apt* d_gens = nullptr;       // 49
     apt_packed* d_table = nullptr;
     size_t table_bytes = 0;
+    // "ct_prover": the 4-bit table the provers' secret-scalar sums scan in full (verify_core.h: fb_lookup_add_ct), built when the option is set
+    apt_packed* d_table_ct = nullptr;
+    size_t table_ct_bytes = 0;
+    bool ct_prover = false, borrows_table_ct = false;
     // per-proof workspace
     size_t cap = 0;
     u32* d_ws = nullptr;
@@ -372,6 +376,8 @@ static inline int check_device(int device) {
     return BPPP_OK;
 }
 
+// bppp_ctx.hip: make sure the context has the 4-bit table of the "ct_prover" mode (built once, 3 MB for the u64 generators)
+int ensure_ct_table(bppp_ctx* c);
 // bppp_coalesce.hip: drain and drop the context's single-proof front ends (final: refuse later *_one calls with BPPP_ERR_CLOSED)
 void bppp_fronts_teardown(bppp_ctx* c, bool final);
 

@@ -81,6 +81,20 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l1x(ProveWs w, MsmJobs jobs) { prove_msm_lanes<1>(w, jobs.j[blockIdx.y]); }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l4x(ProveWs w, MsmJobs jobs) { prove_msm_lanes<4>(w, jobs.j[blockIdx.y]); }
 
+// "ct_prover": the stage's sums over secret scalars, 8 lanes per proof, every window's entries read and masked (fb_lookup_add_ct)
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_ct(ProveWs w, MsmJobs jobs) {
+    const MsmJob& job = jobs.j[blockIdx.y];
+    size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
+    size_t t = g / BPPP_FB_LANES;
+    int lane = (int)(g % BPPP_FB_LANES);
+    if (t >= w.N) return;
+    pt part;
+    FbRanges rg;
+    prove_msm_ranges(rg, job);
+    fb_group_sum_ct<BPPP_FB_LANES>(part, w.fb_ct, t, lane, w.msc, rg);
+    if (lane == 0) prove_msm_store(w, job, t, part);
+}
+
 // ---- the lane kernels above at two wavefronts per SIMD (256 VGPR + AGPR), for prove batches that give every SIMD more than one
 // wavefront (beyond 2^16 values; BASELINE configs[3]'s 2^14 values are 256 workgroups on 1024 SIMDs and keep the uncapped builds):
 // uncapped they allocate 332-398 registers, i.e. ONE wavefront per SIMD, which is the cliff the u64 verifier's lane kernels fell off

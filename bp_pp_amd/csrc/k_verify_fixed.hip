@@ -132,7 +132,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass2(FbBuild fb, size_
 }
 // U64RangeProofProtocol::commit_value (u64_proof.rs:37-39): x*g + s*h_vec[0] through the fixed-base tables
 __global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(VerifyWs ws, const uint64_t* x, const uint8_t* s, uint8_t* out,
-                                                             int* flags) {
+                                                             int* flags, FbTable ct) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= ws.N) return;
     sc xs, ss;
@@ -146,8 +146,15 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(VerifyWs ws, const 
     ws_st8(ws.fsc, ws.N, t, 1, ss.v);
     pt acc;
     pt_set_identity(acc);
-    fixed_base_msm(acc, fb_of(ws), t, ws.fsc, 0, 0, 1, 64);     // x is a u64: 3 of the 12 windows at 22 bits
-    fixed_base_msm(acc, fb_of(ws), t, ws.fsc, 1, 17, 1);
+    if (ct.table) {            // "ct_prover": x and s are the committer's secrets -- every entry of every window read, selected by mask
+#pragma nounroll
+        for (int w = 0; w < 16; w++) fb_lookup_add_ct(acc, ct, 0, w, xs.v);
+#pragma nounroll
+        for (int w = 0; w < 64; w++) fb_lookup_add_ct(acc, ct, 17, w, ss.v);
+    } else {
+        fixed_base_msm(acc, fb_of(ws), t, ws.fsc, 0, 0, 1, 64);     // x is a u64: 3 of the 12 windows at 22 bits
+        fixed_base_msm(acc, fb_of(ws), t, ws.fsc, 1, 17, 1);
+    }
     apt a;
     pt_to_affine(a, acc);
     apt_to_xy64(out + 64 * t, a);

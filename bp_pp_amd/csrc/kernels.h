@@ -111,7 +111,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept_flagged(bppp::Veri
 __global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass1(bppp::FbBuild fb, size_t nthreads);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass2(bppp::FbBuild fb, size_t nthreads);
 __global__ void k_decode_generators(const uint8_t* in, bppp::apt* out, int n, int* flags);
-__global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(bppp::VerifyWs ws, const uint64_t* x, const uint8_t* s, uint8_t* out, int* flags);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(bppp::VerifyWs ws, const uint64_t* x, const uint8_t* s, uint8_t* out, int* flags, bppp::FbTable ct);
 __global__ __launch_bounds__(256) void k_sec1_expand(uint8_t* commitments64, uint8_t* proofs928, const uint8_t* commitments33, const uint8_t* proofs525, size_t n);
 __global__ __launch_bounds__(256) void k_sec1_compress(uint8_t* commitments33, uint8_t* proofs525, const uint8_t* commitments64,
                                                        const uint8_t* proofs928, size_t n);
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_x(bppp::ProveWs w, bppp::MsmJobs jobs);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l1x(bppp::ProveWs w, bppp::MsmJobs jobs);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l4x(bppp::ProveWs w, bppp::MsmJobs jobs);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_ct(bppp::ProveWs w, bppp::MsmJobs jobs);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_scalars(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round(bppp::WnlaWs w, int k);

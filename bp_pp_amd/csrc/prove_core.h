@@ -56,6 +56,11 @@ struct ProveWs {
     size_t n_states;
     uint8_t* states_out;
     int next_by_msm;        // 1: prove_round_fold leaves the next commitment's scalars in set 0 for job_cnext (small calls) instead of summing it itself
+    // "ct_prover": the sums over the witness and its blindings (V, r_com, c_o, c_l, c_r, c_s) read every entry of every window of this
+    // 4-bit table and select by mask (verify_core.h: fb_lookup_add_ct); the WNLA stage's sums, whose vectors the argument reveals by
+    // design (the circuit layer blinds them: circuit.rs:371-372), keep the fast gathers
+    FbTable fb_ct;
+    int ct;
 };
 struct MsmJob {             // one fixed-base MSM per proof: sum over runs of bases of scalar set `set` (verify_core.h: FbRanges)
     int set, out_slot, nranges;
@@ -88,6 +93,14 @@ HD void prove_msm(const ProveWs& w, const MsmJob& job, size_t t) {   // single-t
     prove_msm_ranges(rg, job);
     pt acc;
     fb_sum_serial(acc, w.fb, t, w.msc, rg);
+    prove_msm_store(w, job, t, acc);
+}
+
+HD void prove_msm_ct(const ProveWs& w, const MsmJob& job, size_t t) {   // the same sum in the secret-scalar form (single-thread form)
+    FbRanges rg;
+    prove_msm_ranges(rg, job);
+    pt acc;
+    fb_sum_serial_ct(acc, w.fb_ct, t, w.msc, rg);
     prove_msm_store(w, job, t, acc);
 }
 

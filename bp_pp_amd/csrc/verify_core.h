@@ -529,6 +529,79 @@ __device__ __forceinline__ void fb_group_sum(pt& total, const FbTable& fbt, size
 }
 #endif
 
+// ---------------------------------------------------------------- fixed-base sums over SECRET scalars: the provers' opt-in "ct_prover" mode
+// The fast sums above gather ONE table entry per window at an address the scalar's digit selects, skip zero digits' work by a flag
+// and use an incomplete addition law with a fall-back: fine for public scalars (every verifier sum; the WNLA prover's sums, whose
+// vectors the argument reveals by design), but for the witness and its blindings the addresses are a memory-access side channel
+// (cache / TLB / DRAM-row timing observable by whoever shares the GPU).  k256, which the reference uses, multiplies in constant time
+// (reciprocal.rs:88-95,118; circuit.rs:146-151,335-345,469-470).  This form restores that: 4-bit unsigned windows over a small table
+// (64 windows x 15 entries x 64 B per generator: 3 MB for the 49 generators), EVERY entry of the window is read and the wanted one
+// kept by mask, the zero digit is the all-zero (identity) entry of the same masked select, and the accumulation uses the complete
+// RCB16 mixed addition with a masked result -- no secret-dependent address, branch or instruction count.  (The `bits` / `oddsh` hints
+// stay in force: that a hexadecimal digit is below 2^4 or that a slot is structurally zero is public.)
+HD void fb_lookup_add_ct(pt& acc, const FbTable& fbt, int base, int w, const u32 k[8]) {
+    u32 limb = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) limb = (i == (w >> 3)) ? k[i] : limb;
+    const u32 d = (limb >> (4 * (w & 7))) & 15u;
+    const apt_packed* tb = fbt.table + ((size_t)base * 64 + w) * 15;
+    apt_packed sel;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { sel.x[i] = 0; sel.y[i] = 0; }
+#pragma nounroll
+    for (u32 e = 1; e <= 15; e++) {
+        const apt_packed v = tb[e - 1];
+        const u32 m = 0u - (u32)(d == e);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { sel.x[i] |= v.x[i] & m; sel.y[i] |= v.y[i] & m; }
+    }
+    apt a;
+    bool id;
+    apt_unpack(a, id, sel);           // all zero (digit 0, or an identity entry): the addition below is computed and discarded
+    pt_madd(acc, acc, a, id);
+}
+HD void fixed_base_msm_partial_ct(pt& accp, const FbTable& fbt, size_t t, int lane, const u32* scal, int first_slot, int first_base, int count, int nl,
+                                  int bits, int oddsh) {
+    const int nwin = fb_windows_for(bits, 4);
+    pt acc;
+    pt_set_identity(acc);
+    const int pairs = count * nwin;
+#pragma nounroll
+    for (int q = lane; q < pairs; q += nl) {
+        const int a = q / nwin, w = q - a * nwin, j = fb_term_index(a, oddsh);
+        u32 k[8];
+        ws_ld8(k, scal, fbt.N, t, first_slot + j);
+        fb_lookup_add_ct(acc, fbt, first_base + j, w, k);
+    }
+    accp = acc;
+}
+HD void fb_lane_sum_ct(pt& part, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg, int nl = BPPP_FB_LANES) {
+    pt acc;
+    pt_set_identity(acc);
+#pragma nounroll
+    for (int r = 0; r < rg.n; r++) {
+        pt p;
+        fixed_base_msm_partial_ct(p, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r], nl, rg.bits[r], rg.oddsh[r]);
+        pt_add(acc, acc, p);
+    }
+    part = acc;
+}
+HD void fb_sum_serial_ct(pt& total, const FbTable& fbt, size_t t, const u32* scal, const FbRanges& rg, int nl = BPPP_FB_LANES) {
+    pt part;
+    pt_set_identity(total);
+    for (int lane = 0; lane < nl; lane++) {
+        fb_lane_sum_ct(part, fbt, t, lane, scal, rg, nl);
+        pt_add(total, total, part);
+    }
+}
+#if defined(__HIPCC__)
+template <int NL = BPPP_FB_LANES>
+__device__ __forceinline__ void fb_group_sum_ct(pt& total, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg) {
+    fb_lane_sum_ct(total, fbt, t, lane, scal, rg, NL);
+    lane_group_sum<NL>(total);
+}
+#endif
+
 // ---------------------------------------------------------------- variable-base shared-doubling MSM (Straus), signed 4-bit windows
 // k = sum_{i<64} (nib_i(k') - 8) 16^i + c 16^64 with k' = k + 0x88..8 (mod 2^256), c = carry out; digits in [-8, 7].
 struct straus_scalar { u32 kp[8]; u32 top; };

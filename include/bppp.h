@@ -95,6 +95,12 @@ BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
  * the context stays usable; 0 clears it.  "max_batch": the u64 verify entry
  * points run a batch of more than max_batch proofs as consecutive parts of max_batch on the same stream, which bounds the per-proof
  * workspace (about 30 KB per proof) whatever n is -- a multiple of 64, >= 1024; default 2097152 (63 GB of workspace).
+ * "ct_prover" = 1: the provers' and committers' sums over SECRET scalars -- x, s, the reciprocals and every blinding draw, i.e. V, r_com,
+ * c_o, c_l, c_r, c_s (and bppp_u64_commit_value_batch) -- run in a form with no secret-dependent address, branch or instruction count
+ * (4-bit windows over a 3 MB table, every entry of every window read and selected by mask, complete addition law), as k256 does for
+ * the reference (reciprocal.rs:88-95,118); the default (0) gathers one table entry per window at an address the digit selects, which
+ * is a memory-access side channel towards whoever shares the GPU.  The proofs are byte-identical either way; the cost is reported in
+ * bench.py's prove_2pow14.  INTEGRATION.md section 7 lists what is secret, what is public, and what the mode covers.
  * "coalesce_max" (1 .. 65536, default 1024), "coalesce_us" (0 .. 1000000, default 100), "coalesce_lanes" (1 .. 8, default 2): the
  * single-proof front end below (bppp_u64_verify_one / bppp_u64_prove_one); changing one drains the running front end. */
 BPPP_API int bppp_ctx_set_option(bppp_ctx* ctx, const char* name, long value);

@@ -479,6 +479,7 @@ int emul_u64_bucket_stage(const uint8_t* table, int W, const uint8_t* label, siz
 }
 // full prover pipeline, every stage in thread order
 static int g_prove_next_by_msm = 0;   // emul_set_prove_next_by_msm
+static int g_prove_ct = 0;            // emul_set_prove_ct: the secret-scalar sums in the "ct_prover" form (needs a 4-bit table)
 static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x,
                                const uint8_t* s, const uint8_t* rnd, uint8_t* proofs, uint8_t* V, int32_t* status, const uint8_t* states,
                                size_t n_states, uint8_t* states_out);
@@ -505,12 +506,19 @@ static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label
     w.fb.table = (const apt_packed*)table; w.fb.W = W; w.fb.N = n;
     t_new(w.base, label, (u32)label_len);
     auto msm = [&](MsmJob job) { for (size_t t = 0; t < n; t++) prove_msm(w, job, t); };
+    if (g_prove_ct) {
+        if (W != 4) return -78;
+        w.ct = 1; w.fb_ct = w.fb;
+    }
+    auto secret = [&](MsmJob job) {          // the sums over the witness and its blindings (bppp_u64.hip: PSECRET)
+        for (size_t t = 0; t < n; t++) { if (w.ct) prove_msm_ct(w, job, t); else prove_msm(w, job, t); }
+    };
     for (size_t t = 0; t < n; t++) prove_stage_a(w, t);
-    msm(job_v());
+    secret(job_v());
     for (size_t t = 0; t < n; t++) prove_stage_b(w, t);
-    msm(job_rcom()); msm(job_co()); msm(job_cl()); msm(job_cr());
+    secret(job_rcom()); secret(job_co()); secret(job_cl()); secret(job_cr());
     for (size_t t = 0; t < n; t++) prove_stage_d(w, t);
-    msm(job_cs());
+    secret(job_cs());
     for (size_t t = 0; t < n; t++) prove_stage_f(w, t);
     msm(job_c0());
     w.next_by_msm = g_prove_next_by_msm;
@@ -525,6 +533,25 @@ static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label
 }
 // the small-call form of the u64 prover: next commitments as fixed-base sums (prove_core.h: ProveWs::next_by_msm)
 void emul_set_prove_next_by_msm(int on) { g_prove_next_by_msm = on; }
+void emul_set_prove_ct(int on) { g_prove_ct = on; }
+// one window's table addition in both forms -- the digit-addressed gather and the full scan with masked select -- on the same
+// accumulator: the two results (affine) and, for the scan, the number of table entries it read (always 15)
+int emul_fb_lookup_both(const uint8_t* table, int base, int w, const uint8_t k32[32], const uint8_t acc_in[64], uint8_t out_fast[64], uint8_t out_ct[64]) {
+    FbTable fbt = {(const apt_packed*)table, 4, 1};
+    sc k;
+    if (!sc_from_be(k, k32)) return -1;
+    apt a0;
+    if (!apt_from_xy64(a0, acc_in)) return -1;
+    pt p, q;
+    pt_from_affine(p, a0);
+    q = p;
+    fb_lookup_add(p, fbt, base, w, k.v);
+    fb_lookup_add_ct(q, fbt, base, w, k.v);
+    apt r;
+    pt_to_affine(r, p); apt_to_xy64(out_fast, r);
+    pt_to_affine(r, q); apt_to_xy64(out_ct, r);
+    return 0;
+}
 // wire format, the other way: the prover's 64-byte output -> SEC1 compressed, lane by lane
 void emul_sec1_compress(size_t n, const uint8_t* c64, const uint8_t* p928, uint8_t* c33, uint8_t* p525) {
     for (size_t t = 0; t < n; t++)

@@ -61,6 +61,9 @@ def load():
     L.emul_straus_split.argtypes = [i32, i32, cp, cp, vp, vp, vp]
     L.emul_set_prove_next_by_msm.argtypes = [i32]
     L.emul_set_prove_next_by_msm.restype = None
+    L.emul_set_prove_ct.argtypes = [i32]
+    L.emul_set_prove_ct.restype = None
+    L.emul_fb_lookup_both.argtypes = [vp, i32, i32, cp, cp, vp, vp]
     pvp = C.POINTER(vp)
     L.emul_coalesce_run.argtypes = [i32, vp, i32, i32, sz, pvp, pvp, vp, sz, C.c_long, i32, i32, i32, i32, vp, vp, sz, vp]
     return L

@@ -356,6 +356,48 @@ def test_full_prove_pipeline_is_byte_identical_to_the_oracle(L, gold, oracle_c):
     assert (ov == V).all() and (op == proofs).all()
 
 
+def test_secret_scalar_sums_in_the_constant_address_form(L, gold, oracle_c):
+    """ "ct_prover" (verify_core.h: fb_lookup_add_ct): the prover's sums over the witness and its blindings read EVERY entry of every
+    4-bit window and select by mask.  Same points as the digit-addressed gathers -- window by window, including the zero digit and
+    an accumulator that equals the table entry (the doubling case of the complete law) -- and the same proof bytes as the oracle
+    prover's, on the golden cases and at the edges of the inputs (x = 0, 2^64 - 1; zero and n - 1 blindings and draws)."""
+    import workload
+    gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
+    W = 4
+    tab = np.zeros(L.emul_fb_table_entries(49, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0
+    # one table addition, both forms: every digit of one window (0 .. 15), a few windows and bases, two accumulators
+    G = gens[:64]
+    for base, w in ((0, 0), (17, 5), (48, 63), (3, 31)):
+        for d in range(16):
+            k = (d << (4 * w)).to_bytes(32, "big")
+            entry = oracle_c.point_mul(gens[64 * base:64 * base + 64], k) if d else None
+            for acc in (G, entry) if entry else (G,):
+                fast, ct = np.zeros(64, np.uint8), np.zeros(64, np.uint8)
+                assert L.emul_fb_lookup_both(tab.ctypes.data, base, w, k, acc, fast.ctypes.data, ct.ctypes.data) == 0
+                want = oracle_c.point_add(acc, entry) if entry else acc
+                assert bytes(ct) == bytes(fast) == want, (base, w, d)
+    ex, es, ernd = workload.edge_prover_inputs()
+    cases = gold["cases"]
+    x = np.array([c["x"] for c in cases] + [int(v) for v in ex], dtype=np.uint64)
+    s = np.concatenate([np.frombuffer(b"".join(bytes.fromhex(c["s"]) for c in cases), dtype=np.uint8).reshape(-1, 32), es])
+    rnd = np.concatenate([np.frombuffer(b"".join(bytes.fromhex(c["rnd"]) for c in cases), dtype=np.uint8).reshape(-1, 52 * 32), ernd])
+    x, s, rnd = np.ascontiguousarray(x), np.ascontiguousarray(s), np.ascontiguousarray(rnd)
+    n = len(x)
+    proofs, V, st = np.zeros((n, 928), np.uint8), np.zeros((n, 64), np.uint8), np.zeros(n, np.int32)
+    L.emul_set_prove_ct(1)
+    try:
+        assert 0 == L.emul_u64_prove_batch(tab.ctypes.data, W, label, len(label), n, x.ctypes.data, s.ctypes.data, rnd.ctypes.data,
+                                           proofs.ctypes.data, V.ctypes.data, st.ctypes.data)
+    finally:
+        L.emul_set_prove_ct(0)
+    assert not st.any()
+    for i, c in enumerate(cases):
+        assert bytes(V[i]).hex() == c["commitment"] and bytes(proofs[i]).hex() == c["proof"], f"case {i}"
+    op, ov = oracle_c.u64_prove_batch(gens, label, x, s, rnd, nthreads=2)
+    assert (ov == V).all() and (op == proofs).all()
+
+
 def test_prover_next_commitments_as_fixed_base_sums(L, gold, oracle_c):
     """The small-call form of the u64 prover (ProveWs::next_by_msm): each WNLA level's commitment as wnla.commit(l_, n_) over the
     original generators (wnla.rs:186, :66-72: one more fixed-base sum) instead of com + y X + (y^2 - 1) R -- the same points, so

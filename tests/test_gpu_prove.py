@@ -106,3 +106,36 @@ def test_prover_at_the_edges_of_its_inputs(proto, gold, oracle_c):
     acc2, vst2 = proto.verify_batch_rlc(com, proofs, label, seed=bytes(32))
     oacc, ost = oracle_c.u64_verify_batch(gens, label, com, proofs, nthreads=2)
     assert acc.all() and acc2.all() and oacc.all() and not vst.any() and not vst2.any() and not ost.any()
+
+
+@pytest.mark.parametrize("n", [1, 100, 3000, 1 << 14])
+def test_ct_prover_mode_emits_the_same_bytes(proto, oracle_c, gold, n):
+    """ "ct_prover" (include/bppp.h): the sums over the witness and its blindings -- V, r_com, c_o, c_l, c_r, c_s, and commit_value --
+    in the form with no secret-dependent address (every entry of every 4-bit window read, masked select, complete additions).  Same
+    points, so the same proofs and commitments, byte for byte, as the default mode and as the oracle prover; edge inputs included."""
+    import workload
+    first = 9000
+    x, s, rnd = workload.values(n, first), workload.blindings(n, first), workload.prover_randomness(n, first)
+    if n >= 100:
+        ex, es, ernd = workload.edge_prover_inputs()
+        x, s, rnd = np.concatenate([ex, x[5:]]), np.concatenate([es, s[5:]]), np.concatenate([ernd, rnd[5:]])
+    x, s, rnd = np.ascontiguousarray(x), np.ascontiguousarray(s), np.ascontiguousarray(rnd)
+    p0, c0, st0 = proto.prove_batch(x, s, rnd, workload.LABEL)
+    v0 = proto.commit_value_batch(x, s)
+    proto.set_option("ct_prover", 1)
+    try:
+        assert proto.get_option("ct_prover") == 1
+        p1, c1, st1 = proto.prove_batch(x, s, rnd, workload.LABEL)
+        v1 = proto.commit_value_batch(x, s)
+        if n == 100:                                   # the single-proof front end picks the mode up (its lanes share the 4-bit table)
+            one = proto.prove_one(int(x[7]), bytes(s[7]), workload.LABEL, bytes(rnd[7]))
+            assert one[0] == bytes(p0[7]) and one[1] == bytes(c0[7]) and one[2] == 0
+    finally:
+        proto.set_option("ct_prover", 0)
+    assert not st0.any() and not st1.any()
+    assert (p1 == p0).all() and (c1 == c0).all() and (v1 == v0).all() and (v0 == c0).all()
+    k = min(n, 64)
+    hp, hv = oracle_c.u64_prove_batch(workload.generators(), workload.LABEL, x[:k], s[:k], rnd[:k], nthreads=8)
+    assert (hp == p1[:k]).all() and (hv == c1[:k]).all()
+    with pytest.raises(Exception):
+        proto.set_option("ct_prover", 2)

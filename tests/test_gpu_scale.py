@@ -308,3 +308,24 @@ def test_wnla_at_the_generator_count_limit(torch_mod):
         w.close()
     with pytest.raises(BpppError):
         WeightNormLinearArgument(case["g"], case["gv"] + [case["gv"][0]], case["hv"], device=0, fb_window_bits=8)     # 4097 generators
+
+
+def test_scale_run_kit_dry_run(tmp_path):
+    """tools/scale_run.sh N dry: the one-command multi-GPU readiness kit on ONE device -- bench.py --gpus 2 as two gloo ranks on
+    device 0, and tools/group_run.py as a one-device group behind a one-rank RCCL communicator.  Control flow of N > 1 only (shards,
+    barrier, reject-count reduce, max-over-ranks clock, per-rank report), never a measurement: it must keep running so that the day
+    a multi-GPU node exists the same command produces the curve."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCALE_TOTAL_PROOFS="8192", SCALE_STEPS="2")
+    env.pop("BPPP_FORCE_RCCL", None)
+    r = subprocess.run(["bash", os.path.join(root, "tools", "scale_run.sh"), "2", "dry", str(tmp_path)], capture_output=True, text=True, timeout=1500, env=env)
+    assert "bench.py --gpus 2 rc=0" in r.stdout and "group_run.py --gpus 2 rc=0" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    b = [json.loads(l) for l in open(tmp_path / "bench_gpus2.json") if '"value"' in l][0]
+    assert b["n_gpus"] == 2 and b["accept_bits_ok"] and b["reject_count_all_reduced"] == 8 and b["config"]["proofs_per_gpu"] == 4096
+    assert len(b["ranks"]["per_rank_ms"]) == 2 and b["ranks"]["backend"] == "gloo" and b["ranks"]["one_device_dry_run"]
+    assert abs(b["ranks"]["max_ms"] - b["ms_per_step"]) < 0.5 * b["ms_per_step"] + 1.0
+    g = [json.loads(l) for l in open(tmp_path / "group_gpus2.json") if '"value"' in l][0]
+    assert g["accept_bits_ok"] and g["rccl_nranks"] == 1 and g["reject_count_on_every_device"] == [8] and g["dry_run_one_device"]
