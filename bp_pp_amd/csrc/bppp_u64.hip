@@ -147,7 +147,8 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     if (split && parts == 4) LAUNCH(K_C0_VAR, k_verify_c0_var_g64<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
     else if (split) LAUNCH(K_C0_VAR, k_verify_c0_var_g32<<<(unsigned)((32 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
     else if (grouped) LAUNCH(K_C0_VAR, k_verify_c0_var_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws));
-    else if (small) LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    // (256-thread workgroups: their four wavefronts land one per SIMD -- see k_verify_var.hip)
+    else if (small) LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<(unsigned)((n + BPPP_C0VAR_SMALL_BLOCK - 1) / BPPP_C0VAR_SMALL_BLOCK), BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws));
     else LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     for (int k = 1; k <= 4; k++) {
@@ -441,17 +442,33 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_c0());
     bool pending_cnext = false;
+    // Round k's next commitment C_k (prove_core.h: prove_round_next -- window tables of X and R and a two-point GLV Straus sum, 125
+    // dependent doublings) is not needed before round k + 1 appends it to the transcript: it runs on the helper stream, under round
+    // k + 1's scalar kernel and X | R sums, and the main stream picks it up just before that round's fold -- from 2^15 values on: at
+    // 2^14 the fixed-base sums already keep every SIMD busy and the overlap only adds contention (12.45 against 11.8 ms per batch;
+    // 2^15: 18.9 against 19.65, profiles/r04_g_size_probe2.txt).  (With per-kernel timing on it stays on the main stream so that the
+    // kernel times add up to the step.)
+    hipStream_t a = (c->timing || 2 * (size_t)blocks < (size_t)c->n_simds) ? s : c->aux_stream;
+    bool next_in_flight = false;
     for (int k = 1; k <= 4; k++) {
         if (fb_wave) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_wide<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
         else PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         if (pending_cnext) PMSMX(3, job_x(), job_r(k), job_cnext(), job_x());
         else PMSMX(2, job_x(), job_r(k), job_x(), job_x());
-        if (!w.next_by_msm && !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
-            PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
-        else if (w2)
-            PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
-        else
-            PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        if (next_in_flight) { HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); next_in_flight = false; }      // C_{k-1} is there
+        if (w2) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        else PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        if (!w.next_by_msm && k < 4) {
+            if (a != s) { HIP_TRY(hipEventRecord(c->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0)); }
+            if (!c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
+                rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, a>>>(w, k); });
+            else if (w2)
+                rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next_w2<<<blocks, BPPP_BLOCK, 0, a>>>(w, k); });
+            else
+                rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next<<<blocks, BPPP_BLOCK, 0, a>>>(w, k); });
+            if (rc != BPPP_OK) return rc;
+            if (a != s) { HIP_TRY(hipEventRecord(c->ev_join, a)); next_in_flight = true; }
+        }
         pending_cnext = w.next_by_msm && k < 4;     // its scalars are in set 0 now; the sum rides with the next round's X | R
     }
     if (w.states_out) k_prove_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);

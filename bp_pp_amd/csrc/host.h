@@ -32,7 +32,7 @@ extern thread_local std::string g_last_error;   // defined in bppp_ctx.hip
 enum KernelId {
     K_PHASE1 = 0, K_C0_FIXED, K_C0_VAR, K_ROUND, K_FINAL_SCALARS, K_FINAL_CHECK, K_ACCEPT, K_TABLES, K_RLC_LHS, K_RLC_CHUNK, K_BKT_PREPARE, K_BKT_ACCUMULATE, K_BKT_SCALARS, K_BKT_CHECK,
     // u64 batch prover
-    K_PROVE_STAGES, K_PROVE_MSM, K_PROVE_ROUND_SCALARS, K_PROVE_ROUND_FOLD,
+    K_PROVE_STAGES, K_PROVE_MSM, K_PROVE_ROUND_SCALARS, K_PROVE_ROUND_FOLD, K_PROVE_ROUND_NEXT,
     // generic reciprocal / WNLA verifier
     K_RECIP_PHASE1, K_RECIP_C0_FIXED, K_RECIP_C0_VAR, K_RECIP_C0_FINISH, K_WNLA_BEGIN, K_WNLA_ROUND, K_WNLA_FINAL_SCALARS, K_WNLA_MSM, K_WNLA_ACCEPT,
     K_WNLA_RLC_LHS, K_WNLA_RLC_CHUNK, K_WNLA_RLC_CHECK, K_WNLA_TABLES,
@@ -41,7 +41,7 @@ enum KernelId {
 static const char* const kKernelNames[K_COUNT] = {
     "k_verify_phase1", "k_verify_c0_fixed", "k_verify_c0_var", "k_verify_round", "k_verify_final_scalars", "k_verify_final_check",
     "k_verify_accept", "k_verify_tables", "k_rlc_lhs", "k_rlc_chunk", "k_bkt_prepare", "k_bkt_accumulate", "k_bkt_scalars", "k_bkt_check",
-    "k_prove_stage_*", "k_prove_msm", "k_prove_round_scalars", "k_prove_round_fold",
+    "k_prove_stage_*", "k_prove_msm", "k_prove_round_scalars", "k_prove_round_fold", "k_prove_round_next",
     "k_recip_phase1", "k_recip_c0_fixed", "k_recip_c0_var", "k_recip_c0_finish", "k_wnla_begin", "k_wnla_round", "k_wnla_final_scalars",
     "k_wnla_msm", "k_wnla_accept", "k_wnla_rlc_lhs", "k_wnla_rlc_chunk", "k_wnla_rlc_check", "k_wnla_tables"};
 

@@ -53,13 +53,16 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(ProveWs w, int 
     if (t >= w.N) return;
     for_each_position_group(prove_position_key(w, t), [&]() { prove_round_fold(w, t, k); });
 }
-// small batches: four lanes per proof, the next-commitment sum split into its four GLV streams (verify_core.h: straus_affine_g4)
-__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold_g4(ProveWs w, int k) {
+// part two of a round (prove_core.h: prove_round_next): the next commitment by the variable-base path, no transcript in it
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_next(ProveWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_round_next(w, t, k);
+}
+// small batches: four lanes per proof, the sum split into its four GLV streams (verify_core.h: straus_affine_g4)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_next_g4(ProveWs w, int k) {
     const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     const size_t t = g >> 2;
-    if (t >= w.N) return;
-    const int q = (int)(g & 3);
-    for_each_position_group(prove_position_key(w, t), [&]() { prove_round_fold(w, t, k, q); });
+    if (t < w.N) prove_round_next(w, t, k, (int)(g & 3));
 }
 // NL lanes per proof: 8 while the batch is small, 1 from the size at which one lane per proof fills the SIMDs twice over (as in the
 // verifier's fixed-base kernels, k_verify_fixed.hip): no idle lanes in the short runs, no 3-step tree of complete additions per sum
@@ -119,4 +122,8 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= w.N) return;
     for_each_position_group(prove_position_key(w, t), [&]() { prove_round_fold(w, t, k); });
+}
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_next_w2(ProveWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) prove_round_next(w, t, k);
 }

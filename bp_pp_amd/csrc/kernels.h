@@ -84,7 +84,8 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_ta
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_c0_var(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_round(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_small(bppp::VerifyWs ws);
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_small(bppp::VerifyWs ws);
+#define BPPP_C0VAR_SMALL_BLOCK 256   // k_verify_var.hip: four wavefronts per workgroup, one per SIMD
+__global__ __launch_bounds__(BPPP_C0VAR_SMALL_BLOCK) void k_verify_c0_var_small(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_small(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g4(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g4(bppp::VerifyWs ws);
@@ -123,7 +124,9 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_export_states(bppp::ProveW
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars_wide(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(bppp::ProveWs w, int k);
-__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold_g4(bppp::ProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_next(bppp::ProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_next_g4(bppp::ProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_next_w2(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_b_w2(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_d_w2(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_f_w2(bppp::ProveWs w);

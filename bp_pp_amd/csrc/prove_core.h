@@ -581,9 +581,17 @@ HD void prove_round_scalars(const ProveWs& w, size_t t, int k) {
     for (int i = 0; i < 16; i++) prove_round_scalars_g(w, t, k, i);
 }
 // ---------------------------------------------------------------- WNLA round k: transcript, challenge, folds, next commitment (wnla.rs:162-188)
-// group_lane >= 0: one of four consecutive lanes that all run the round for proof t (identical work and stores; the next-commitment
-// sum is shared through straus_affine_g4) -- small batches; -1: one lane per proof
-HD void prove_round_fold(const ProveWs& w, size_t t, int k, int group_lane = -1) {
+// In two parts, because only the first is on the prover's critical path:
+//   prove_round_fold    transcript, challenge y_k, the folded l / n / c, the generator coefficients -- what round k + 1's scalars and
+//                       sums (X, R) need.  Leaves y_k (SV_Y) and the affine X, R, C_{k-1} (the table scratch's point slots) for
+//   prove_round_next    C_k = C_{k-1} + y X + (y^2 - 1) R by the verifier's variable-base path (window tables of X and R, GLV Straus):
+//                       ~125 doublings of dependent work that nobody needs before round k + 1 appends C_k to the transcript, so the
+//                       host runs it on the helper stream UNDER round k + 1's scalars and fixed-base sums (bppp_u64.hip).
+// (small calls, next_by_msm: the next commitment is one more fixed-base sum whose scalars part one prepares; there is no part two.)
+// The point slots behind the running products: 0 = X, 1 = R (the table builder's inputs), 2 = C_{k-1}.
+HD u32* prove_fold_rpts(const ProveWs& w) { return (u32*)((uint8_t*)w.straus + (size_t)32 * sizeof(apt_packed) * w.N) + (size_t)28 * 10 * w.N; }
+HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane = -1);
+HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
     const size_t N = w.N;
     const int sh = k - 1, nl = 32 >> sh, nn = 16 >> sh;
     int32_t status = w.status[t];
@@ -685,37 +693,12 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k, int group_lane = -1)
             w.status[t] = status;
             return;
         }
-        // next commitment = com + y X + (y^2 - 1) R             (= wnla.commit(l_, n_), wnla.rs:186)
-        sc y2m1, one;
-        sc_set_u32(one, 1);
-        sc_mul(y2m1, y, y);
-        sc_sub(y2m1, y2m1, one);
-        // the verifier's fast variable-base path (verify_core.h): affine window tables 1..16 of X and R from one four-level pass,
-        // Jacobian accumulator, mixed additions, signed 5-bit windows.  Its buffers are carved out of the window-table workspace
-        // (45 projective slots = 5.4 KB per proof): 32 table entries (2 KB), 28 running products (1.1 KB), the two points (128 B).
-        uint8_t* sb = (uint8_t*)w.straus;
-        apt_packed* atab = (apt_packed*)sb;
-        u32* tscr = (u32*)(sb + (size_t)32 * sizeof(apt_packed) * N);
-        u32* rpts = tscr + (size_t)28 * 10 * N;
+        // what prove_round_next needs: the challenge and the three affine points
+        pw_st_sc(w, t, SV_Y, y);
+        u32* rpts = prove_fold_rpts(w);
         ws_st_apt(rpts, N, t, 0, A[1]);
         ws_st_apt(rpts, N, t, 1, A[2]);
-        const atab_ref tab = atab_of(atab, N, t, 32);
-        affine_tables_build(tab, tscr, rpts, N, t, 2);
-        const int pslot[2] = {0, 1};
-        glv_words<2> g;
-        glv_split sp;
-        glv_decompose(sp, y);
-        glv_words_set<2>(g, 0, sp);
-        glv_decompose(sp, y2m1);
-        glv_words_set<2>(g, 1, sp);
-        pt acc;
-#if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
-        if (group_lane >= 0) straus_affine_g4<2>(acc, tab, pslot, g, group_lane);
-        else
-#endif
-            straus_affine<2>(acc, tab, pslot, g);
-        pt_madd(acc, acc, A[0], apt_is_identity(A[0]));
-        pw_st_pt(w, t, PB_C, acc);
+        ws_st_apt(rpts, N, t, 2, A[0]);
     } else {
         // proof.l = [l0, l1], proof.n = [n0]   (wnla.rs:126-133)
         sc l0, l1, n0;
@@ -724,8 +707,46 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k, int group_lane = -1)
         sc_to_be(pb + 864, l1);
         sc_to_be(pb + 896, n0);
     }
-    (void)group_lane;
     w.status[t] = status;
+}
+// next commitment = com + y X + (y^2 - 1) R             (= wnla.commit(l_, n_), wnla.rs:186), rounds 1 .. 3 of the chain form
+// group_lane >= 0: one of four consecutive lanes that share the sum (straus_affine_g4; identical table build and stores) -- small
+// batches; -1: one lane per proof
+HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane) {
+    const size_t N = w.N;
+    (void)k;
+    sc y, y2m1, one;
+    pw_ld_sc(y, w, t, SV_Y);
+    sc_set_u32(one, 1);
+    sc_mul(y2m1, y, y);
+    sc_sub(y2m1, y2m1, one);
+    // the verifier's fast variable-base path (verify_core.h): affine window tables 1..16 of X and R from one four-level pass,
+    // Jacobian accumulator, mixed additions, signed 5-bit windows.  Its buffers are carved out of the window-table workspace
+    // (45 projective slots = 5.4 KB per proof): 32 table entries (2 KB), 28 running products (1.1 KB), the three points (192 B).
+    uint8_t* sb = (uint8_t*)w.straus;
+    apt_packed* atab = (apt_packed*)sb;
+    u32* tscr = (u32*)(sb + (size_t)32 * sizeof(apt_packed) * N);
+    u32* rpts = prove_fold_rpts(w);
+    apt C;
+    ws_ld_apt(C, rpts, N, t, 2);
+    const atab_ref tab = atab_of(atab, N, t, 32);
+    affine_tables_build(tab, tscr, rpts, N, t, 2);
+    const int pslot[2] = {0, 1};
+    glv_words<2> g;
+    glv_split sp;
+    glv_decompose(sp, y);
+    glv_words_set<2>(g, 0, sp);
+    glv_decompose(sp, y2m1);
+    glv_words_set<2>(g, 1, sp);
+    pt acc;
+#if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
+    if (group_lane >= 0) straus_affine_g4<2>(acc, tab, pslot, g, group_lane);
+    else
+#endif
+        straus_affine<2>(acc, tab, pslot, g);
+    pt_madd(acc, acc, C, apt_is_identity(C));
+    pw_st_pt(w, t, PB_C, acc);
+    (void)group_lane;
 }
 
 // the MSM jobs of the pipeline, in launch order

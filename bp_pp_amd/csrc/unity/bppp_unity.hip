@@ -7,6 +7,7 @@
 #include "../bppp_u64.hip"
 #include "../bppp_generic.hip"
 #include "../bppp_group.hip"
+#include "../bppp_coalesce.hip"
 #include "../k_verify_misc.hip"
 #include "../k_verify_var.hip"
 #include "../k_verify_fixed.hip"

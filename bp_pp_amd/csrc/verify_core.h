@@ -22,11 +22,12 @@
 
 namespace bppp {
 
-// Optional phase stamps (diagnostic builds only: -DBPPP_PHASE_TIMING): lane 0 of every wavefront records the shader clock at
-// marked points of verify_phase1 / verify_round into g_bppp_stamps; tools/phase_probe.py reads them back.
+// Optional phase stamps (diagnostic builds only: -DBPPP_PHASE_TIMING): lane 0 of every wavefront records the constant-rate 100 MHz
+// counter (s_memrealtime: one time base for all eight XCDs, unlike the per-XCD shader-clock counter of clock64()) at marked points of
+// verify_phase1 / verify_round / verify_tables / verify_c0_var into g_bppp_stamps; tools/phase_probe.py and tools/wave_timeline.py read them back.
 #if defined(BPPP_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 extern __device__ unsigned long long g_bppp_stamps[1024 * 32];
-#define BPPP_STAMP(t, i) do { if (((t) & 63) == 0 && ((t) >> 6) < 1024) g_bppp_stamps[((t) >> 6) * 32 + (i)] = (unsigned long long)clock64(); } while (0)
+#define BPPP_STAMP(t, i) do { if (((t) & 63) == 0 && ((t) >> 6) < 1024) g_bppp_stamps[((t) >> 6) * 32 + (i)] = (unsigned long long)wall_clock64(); } while (0)
 #else
 #define BPPP_STAMP(t, i) ((void)0)
 #endif

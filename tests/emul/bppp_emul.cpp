@@ -527,6 +527,8 @@ static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label
         msm(job_x()); msm(job_r(k));
         if (w.next_by_msm && k > 1) msm(job_cnext());       // the level's commitment, scalars left by the previous fold (the library fuses the three launches)
         for (size_t t = 0; t < n; t++) prove_round_fold(w, t, k);
+        if (k < 4 && !w.next_by_msm)                            // part two: the next commitment (the library runs it under the next round's sums)
+            for (size_t t = 0; t < n; t++) prove_round_next(w, t, k);
     }
     for (size_t t = 0; t < n; t++) prove_export_state(w, t);
     return 0;
