@@ -564,7 +564,8 @@ def run_verify(args):
                             "reject-count all-reduce per step",
                 "total_proofs_per_step": total,
                 "proofs_per_gpu": n,
-                "fb_window_bits": args.fb_window_bits or "library default (chosen from free HBM)",
+                "fb_window_bits": proto.get_option("fb_window_bits"),
+                "fb_window_bits_chosen_by": "--fb-window-bits" if args.fb_window_bits else "the library, from the HBM free at context creation",
                 "label": workload.LABEL.decode(),
                 "parallelism": f"shard{world}" if world > 1 else "single",
             },
