@@ -515,7 +515,7 @@ def run_verify(args):
     ok_extra = True
     if world == 1 and not args.no_secondary:
         import bench_other
-        keep = ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline", "kernels_ms_per_step", "cpu_baseline")
+        keep = ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline", "kernels_ms_per_step", "cpu_baseline", "ct_prover")
         r, okp = bench_other.measure_prove(args, proto, gens, 1 << 14, cpu_baseline=not args.no_cpu_baseline, cpu_sample=2048)
         prove14 = {k: r[k] for k in keep if k in r}
         prove14["proofs_verify"] = okp

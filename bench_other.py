@@ -94,6 +94,27 @@ def measure_prove(args, proto, gens, total, cpu_baseline=True, cpu_sample=4096, 
         "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kt.items()},
         "proofs_verify": ok,
     }
+    if world == 1:
+        # the same batch with the secret-scalar sums in the constant-address form (bppp_ctx_set_option "ct_prover")
+        dP2 = torch.zeros_like(dP)
+        dV2 = torch.zeros_like(dV)
+        proto.set_option("ct_prover", 1)
+        try:
+            def step_ct():
+                proto.prove_batch_device(workload.LABEL, n, dx.data_ptr(), ds.data_ptr(), dr.data_ptr(), dP2.data_ptr(), dV2.data_ptr(), dSt.data_ptr())
+            step_ct()
+            proto.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step_ct()
+            proto.synchronize()
+            t_ct = (time.perf_counter() - t0) / args.steps
+        finally:
+            proto.set_option("ct_prover", 0)
+        result["ct_prover"] = {"value": n / t_ct, "unit": "proves/s", "ms_per_step": t_ct * 1e3, "cost_vs_default": t_ct / (elapsed / args.steps),
+                               "byte_identical_to_default": bool((dP2 == dP).all().item() and (dV2 == dV).all().item()),
+                               "note": "V, r_com, c_o, c_l, c_r, c_s over a 3 MB 4-bit table: every entry of every window read, masked select, complete additions"}
+        del dP2, dV2
     if cpu_baseline and rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import bppp_oracle_c as OC                                   # the oracle, as the timed CPU baseline ONLY

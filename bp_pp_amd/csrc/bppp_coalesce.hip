@@ -153,7 +153,8 @@ static int get_front(bppp_ctx* c, int which, std::shared_ptr<bppp_front>& out) {
         try {
             f = std::make_shared<bppp_front>(c, which == 1, (size_t)c->coalesce_max, c->coalesce_us, c->coalesce_lanes);
         } catch (...) { return BPPP_ERR_NOMEM; }
-        int rc = f->start();
+        int rc;
+        try { rc = f->start(); } catch (...) { rc = BPPP_ERR_NOMEM; }      // (nothing may throw across the C ABI)
         if (rc != BPPP_OK) return rc;
         fs->f[which] = f;
     }
