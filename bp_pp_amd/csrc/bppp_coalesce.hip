@@ -150,8 +150,14 @@ static int get_front(bppp_ctx* c, int which, std::shared_ptr<bppp_front>& out) {
     if (fs->closed) return BPPP_ERR_CLOSED;
     if (!fs->f[which]) {
         std::shared_ptr<bppp_front> f;
+        long cmax, cus;
+        int clanes;
+        {
+            std::lock_guard<std::recursive_mutex> lk(c->mu);       // (bppp_ctx_set_option writes them under this lock)
+            cmax = c->coalesce_max; cus = c->coalesce_us; clanes = c->coalesce_lanes;
+        }
         try {
-            f = std::make_shared<bppp_front>(c, which == 1, (size_t)c->coalesce_max, c->coalesce_us, c->coalesce_lanes);
+            f = std::make_shared<bppp_front>(c, which == 1, (size_t)cmax, cus, clanes);
         } catch (...) { return BPPP_ERR_NOMEM; }
         int rc;
         try { rc = f->start(); } catch (...) { rc = BPPP_ERR_NOMEM; }      // (nothing may throw across the C ABI)
@@ -190,15 +196,15 @@ void bppp_fronts_teardown(bppp_ctx* c, bool final) {
 static bool state_ok(const uint8_t* st) { return st[200] < BPPP_STROBE_R && st[201] <= BPPP_STROBE_R; }
 
 static int submit_retry(bppp_ctx* c, int which, const void* const in[], void* const out[]) {
-    // a front end torn down by an option change while this caller was on its way in answers CLOSED: take the new one
-    for (int attempt = 0; attempt < 4; attempt++) {
+    // A front end torn down by an option change while this caller was on its way in answers CLOSED: take the new one, as often as it
+    // takes (a caller never sees an option change).  Only bppp_ctx_destroy ends the loop: get_front then answers CLOSED itself.
+    for (;;) {
         std::shared_ptr<bppp_front> f;
         int rc = get_front(c, which, f);
         if (rc != BPPP_OK) return rc;
         rc = f->co.submit(in, out);
         if (rc != BPPP_ERR_CLOSED) return rc;
     }
-    return BPPP_ERR_CLOSED;
 }
 
 extern "C" {

@@ -248,10 +248,10 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
         const char k = name[9];      // 'm' / 'u' / 'l'
         if ((k == 'm' && (value < 1 || value > 65536)) || (k == 'u' && (value < 0 || value > 1000000)) || (k == 'l' && (value < 1 || value > 8)))
             return BPPP_ERR_INVALID_ARG;
-        bppp_fronts_teardown(c, false);
-        if (k == 'm') c->coalesce_max = value;
+        if (k == 'm') c->coalesce_max = value;           // first the value, then the drain: a front end started meanwhile has it
         else if (k == 'u') c->coalesce_us = value;
         else c->coalesce_lanes = (int)value;
+        bppp_fronts_teardown(c, false);
         return BPPP_OK;
     }
     // the provers' secret-scalar sums in the constant-address form (include/bppp.h); the running single-proof front ends are drained
@@ -262,8 +262,8 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
             int rc = ensure_ct_table(c);
             if (rc != BPPP_OK) return rc;
         }
-        bppp_fronts_teardown(c, false);
         c->ct_prover = value != 0;
+        bppp_fronts_teardown(c, false);
         return BPPP_OK;
     }
     // testing aid: the value-th device allocation from now on (workspaces, staging, tables) fails with BPPP_ERR_NOMEM; 0 clears it
