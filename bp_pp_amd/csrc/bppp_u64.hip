@@ -441,6 +441,10 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_c0());
+    // the round's 49 + 25 scalar products: a lane per generator (a wavefront per proof) while one lane per proof would leave SIMDs
+    // without a wavefront -- the loop over the terms is a chain of dependent loads and two multiplications each, 0.2 ms per launch
+    // whatever the batch size up to 2^15 values
+    const bool scal_wide = fb_wave || (!c->no_lane_groups && std::getenv("BPPP_SCALARS_WIDE_MAX") ? n <= (size_t)std::atol(std::getenv("BPPP_SCALARS_WIDE_MAX")) : false);
     bool pending_cnext = false;
     // Round k's next commitment C_k (prove_core.h: prove_round_next -- window tables of X and R and a two-point GLV Straus sum, 125
     // dependent doublings) is not needed before round k + 1 appends it to the transcript: it runs on the helper stream, under round
@@ -451,7 +455,7 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     hipStream_t a = (c->timing || 2 * (size_t)blocks < (size_t)c->n_simds) ? s : c->aux_stream;
     bool next_in_flight = false;
     for (int k = 1; k <= 4; k++) {
-        if (fb_wave) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_wide<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
+        if (scal_wide) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_wide<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
         else PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         if (pending_cnext) PMSMX(3, job_x(), job_r(k), job_cnext(), job_x());
         else PMSMX(2, job_x(), job_r(k), job_x(), job_x());

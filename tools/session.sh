@@ -64,7 +64,7 @@ for STEP in "$@"; do
       for S in "200 1" "200 5" "100 10" "60 12" "40 16" "6 20"; do set -- $S; timeout 900 python tests/soak.py $1 $2 > $OUT/soak_2pow$2.txt 2>&1; echo "soak$2 rc=$?" >> $LOG; done
       timeout 900 python tests/stress_mixed.py > $OUT/stress_mixed.txt 2>&1; echo "stress rc=$?" >> $LOG
       timeout 900 python tests/soak_generic.py > $OUT/soak_generic.txt 2>&1; echo "soak_generic rc=$?" >> $LOG
-      tail -2 $OUT/soak_2pow16.txt $OUT/soak_2pow20.txt $OUT/stress_mixed.txt $OUT/soak_generic.txt ;;
+      for f in soak_2pow16 soak_2pow20 stress_mixed soak_generic; do tail -n 2 $OUT/$f.txt; done ;;
     latency) timeout 600 python tools/latency_breakdown.py 22 > $OUT/latency_w22.txt 2>&1; echo "latency rc=$?" >> $LOG ;;
     dry2) bash tools/scale_run.sh 2 dry $OUT >> $LOG 2>&1 ;;
     cmd:*) NCMD=$((NCMD+1)); timeout 1800 bash -c "${STEP#cmd:}" > $OUT/cmd_$NCMD.txt 2>&1; echo "cmd_$NCMD rc=$? : ${STEP#cmd:}" >> $LOG; tail -20 $OUT/cmd_$NCMD.txt ;;
