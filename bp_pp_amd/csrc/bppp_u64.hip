@@ -441,10 +441,9 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_c0());
-    // the round's 49 + 25 scalar products: a lane per generator (a wavefront per proof) while one lane per proof would leave SIMDs
-    // without a wavefront -- the loop over the terms is a chain of dependent loads and two multiplications each, 0.2 ms per launch
-    // whatever the batch size up to 2^15 values
-    const bool scal_wide = fb_wave || (!c->no_lane_groups && std::getenv("BPPP_SCALARS_WIDE_MAX") ? n <= (size_t)std::atol(std::getenv("BPPP_SCALARS_WIDE_MAX")) : false);
+    // (the lane-per-generator form of the scalar kernel pays only while the chip is empty: at 2^13 ... 2^15 values it costs 1.2 / 2.3 /
+    // 4.5 ms per batch against 0.8: profiles/r04_r_size_probe_wide_scalars.txt)
+    const bool scal_wide = fb_wave;
     bool pending_cnext = false;
     // Round k's next commitment C_k (prove_core.h: prove_round_next -- window tables of X and R and a two-point GLV Straus sum, 125
     // dependent doublings) is not needed before round k + 1 appends it to the transcript: it runs on the helper stream, under round
