@@ -166,5 +166,6 @@ def test_ring_under_thread_sanitizer(tmp_path):
     if r.returncode != 0 and "tsan" in (r.stderr or "").lower():
         pytest.skip("no ThreadSanitizer runtime in this toolchain")
     assert r.returncode == 0, r.stderr[-3000:]
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_PRELOAD", "ASAN_OPTIONS", "UBSAN_OPTIONS")}     # (under tools/sanitize_emul.sh)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(env, TSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout[-2000:], r.stderr[-4000:])
