@@ -47,6 +47,8 @@ struct bppp_front {
     }
     void free_staging(void* p) { (void)hipHostFree(p); }
     bool start_lane(int lane) { return hipSetDevice(lanes[lane]->device) == hipSuccess; }
+    std::string last_error() { return g_last_error; }                         // (thread-local: the dispatcher's own)
+    void set_last_error(const std::string& e) { g_last_error = e; }           // ... handed to the caller's thread for bppp_last_error()
     void stop_lane(int) {}
 
     // device staging of one lane: the rows' arrays, each at an offset fixed by `max` (grow-only buffer of the lane's context)

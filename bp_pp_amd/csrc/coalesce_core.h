@@ -35,6 +35,7 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -64,6 +65,8 @@ static inline void futex_wake_all_u32(std::atomic<uint32_t>* w) {
 // Backend:  void* alloc_staging(size_t bytes);  void free_staging(void* p);      host memory the batched call reads / writes
 //           int   run(int lane, size_t n, uint8_t* const in[], uint8_t* const out[]);   ONE batched call over rows 0 .. n-1, synchronous
 //           bool  start_lane(int lane);  void stop_lane(int lane);                bracket a dispatcher thread's life (device binding)
+//           std::string last_error();  void set_last_error(const std::string&);   the calling thread's error text: a failed batched
+//                                                                                 call's message travels from the dispatcher to its callers
 template <class Backend>
 class Coalescer {
 public:
@@ -143,6 +146,7 @@ public:
         std::atomic<uint32_t>& word = b->done_gen[slot % DONE_WORDS];
         while (word.load(std::memory_order_acquire) == gen) futex_wait_u32(&word, gen);
         const int rc = b->rc;
+        if (rc != 0) be_->set_last_error(b->err);
         if (rc == 0)
             for (int k = 0; k < shape_.n_out; k++)
                 if (out[k]) std::memcpy(out[k], b->out[k] + (size_t)slot * shape_.out_stride[k], shape_.out_stride[k]);
@@ -212,6 +216,7 @@ private:
         std::atomic<int64_t> t0_ns{0};      // first request's arrival (0: not stamped yet)
         alignas(64) std::atomic<uint32_t> done_gen[DONE_WORDS];
         int rc = 0;
+        std::string err;                    // the dispatcher's error text when rc != 0 (published with rc)
         Batch() { for (auto& w : done_gen) w.store(0); }
     };
 
@@ -332,6 +337,7 @@ private:
             int rc;
             try { rc = lane_ok ? be_->run(lane, n, b.in, b.out) : nomem_code_; } catch (...) { rc = nomem_code_; }
             const auto t_done = std::chrono::steady_clock::now();
+            if (rc != 0) { try { b.err = be_->last_error(); } catch (...) { b.err.clear(); } }
             b.rc = rc;
             for (int w = 0; w < DONE_WORDS; w++) b.done_gen[w].fetch_add(1, std::memory_order_release);
             for (int w = 0; w < DONE_WORDS && (size_t)w < n; w++) futex_wake_all_u32(&b.done_gen[w]);

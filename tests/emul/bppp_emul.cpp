@@ -1218,6 +1218,8 @@ struct EmulFront {
     void* alloc_staging(size_t bytes) { live_staging++; return std::malloc(bytes ? bytes : 1); }
     void free_staging(void* p) { live_staging--; std::free(p); }
     bool start_lane(int) { return true; }
+    std::string last_error() { return "emulated failure"; }
+    void set_last_error(const std::string&) {}
     void stop_lane(int) {}
     int run(int, size_t n, uint8_t* const in[], uint8_t* const out[]) {
         const int no = batch_no.fetch_add(1);

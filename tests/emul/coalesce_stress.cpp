@@ -4,6 +4,7 @@
 // race detector, at rates the emulated verifier cannot reach.  Exit code 0 = every request got its own row's answer.
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "../../bp_pp_amd/csrc/coalesce_core.h"
 
@@ -13,6 +14,8 @@ struct Backend {
     void* alloc_staging(size_t b) { live++; return std::malloc(b ? b : 1); }
     void free_staging(void* p) { live--; std::free(p); }
     bool start_lane(int) { return true; }
+    std::string last_error() { return "emulated failure"; }
+    void set_last_error(const std::string&) {}
     void stop_lane(int) {}
     int run(int, size_t n, uint8_t* const in[], uint8_t* const out[]) {
         if (delay_us) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
