@@ -33,7 +33,7 @@ EXPORTS = [
     "bppp_u64_prove_batch_sharded", "bppp_u64_prove_batch_sharded_device",
     "bppp_u64_prove_batch_sec1", "bppp_u64_prove_batch_sec1_device",
     "bppp_u64_verify_one", "bppp_u64_verify_one_transcript", "bppp_u64_prove_one", "bppp_u64_prove_one_transcript",
-    "bppp_ctx_get_coalesce_stats", "bppp_ctx_get_option",
+    "bppp_ctx_get_coalesce_stats", "bppp_ctx_get_option", "bppp_reciprocal_verify_one", "bppp_reciprocal_verify_one_transcript",
 ]
 
 _lib = None
@@ -170,6 +170,8 @@ def lib():
     L.bppp_u64_prove_one.argtypes = [vp, u8p, sz, C.c_uint64, vp, vp, vp, vp, vp]
     L.bppp_u64_prove_one_transcript.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, vp]
     L.bppp_ctx_get_coalesce_stats.argtypes = [vp, i32, C.POINTER(C.c_uint64)]
+    L.bppp_reciprocal_verify_one.argtypes = [vp, u8p, sz, sz, sz, vp, vp, sz, sz, sz, vp, vp]
+    L.bppp_reciprocal_verify_one_transcript.argtypes = [vp, vp, sz, sz, vp, vp, sz, sz, sz, vp, vp]
     L.bppp_strerror.argtypes = [i32]
     L.bppp_strerror.restype = C.c_char_p
     L.bppp_last_error.restype = C.c_char_p

@@ -15,9 +15,16 @@ static const size_t RND_BYTES = 52 * 32;
 
 // One front end = one kind of request (verify or prove) of one context: `lanes` child contexts over the parent's tables (own streams,
 // own workspaces, own device staging), pinned host staging for the rows, and the coalescer that fills and flushes them.
+struct RecipShape {          // the runtime shape of a generic reciprocal verify request (bppp_reciprocal_verify_batch's arguments)
+    size_t nd = 0, np = 0, rounds = 0, nl = 0, nn = 0;
+    size_t proof_bytes() const { return 64 * (5 + 2 * rounds) + 32 * (nl + nn); }
+    bool operator==(const RecipShape& o) const { return nd == o.nd && np == o.np && rounds == o.rounds && nl == o.nl && nn == o.nn; }
+};
 struct bppp_front {
     bppp_ctx* parent;
     bool prove;
+    bool recip = false;          // ReciprocalRangeProofProtocol::verify at runtime dimensions (rows: commitment, proof, transcript)
+    RecipShape rs;
     size_t max;
     std::vector<bppp_ctx*> lanes;
     Coalescer<bppp_front> co;
@@ -33,8 +40,16 @@ struct bppp_front {
         }
         return s;
     }
+    static CoalesceShape shape_of_recip(const RecipShape& r) {
+        CoalesceShape s;
+        s.n_in = 3; s.in_stride[0] = 64; s.in_stride[1] = r.proof_bytes(); s.in_stride[2] = SB;
+        s.n_out = 3; s.out_stride[0] = 1; s.out_stride[1] = sizeof(int32_t); s.out_stride[2] = SB;
+        return s;
+    }
     bppp_front(bppp_ctx* p, bool prove_, size_t max_, long wait_us, int nlanes)
         : parent(p), prove(prove_), max(max_), co(this, shape_of(prove_), max_, wait_us, nlanes, BPPP_ERR_CLOSED, BPPP_ERR_NOMEM) {}
+    bppp_front(bppp_ctx* p, const RecipShape& r, size_t max_, long wait_us, int nlanes)
+        : parent(p), prove(false), recip(true), rs(r), max(max_), co(this, shape_of_recip(r), max_, wait_us, nlanes, BPPP_ERR_CLOSED, BPPP_ERR_NOMEM) {}
 
     // ---- Backend of the coalescer
     void* alloc_staging(size_t bytes) {
@@ -56,6 +71,8 @@ struct bppp_front {
     int run(int lane, size_t n, uint8_t* const in[], uint8_t* const out[]) {
         bppp_ctx* c = lanes[lane];
         CtxLock lock_(c);
+        if (recip)      // the generic verifier's host-buffer entry point over the pinned rows (it stages, runs and waits by itself)
+            return bppp_reciprocal_verify_batch_transcript(c, n, in[2], n, rs.nd, rs.np, in[0], in[1], rs.rounds, rs.nl, rs.nn, out[0], (int32_t*)out[1], out[2]);
         const int rc = run_locked(c, n, in, out);
         // a failed call must not leave copies in flight over staging rows that the next batch is about to overwrite
         if (rc != BPPP_OK) quiesce(c);
@@ -112,6 +129,7 @@ struct bppp_front {
             lanes.push_back(ch);
             CtxLock lock_(ch);
             ch->ct_prover = parent->ct_prover;       // (the 4-bit table is shared with the parent: bppp_ctx_create_shared)
+            if (recip) continue;                     // the generic verifier sizes its own (grow-only) buffers at the first batch
             if (prove) rc = ensure_prove_capacity(ch, max);
             else {
                 rc = ensure_capacity(ch, max);
@@ -137,8 +155,10 @@ struct bppp_front {
 struct bppp_fronts {
     std::mutex mu;
     std::shared_ptr<bppp_front> f[2];     // 0 verify, 1 prove
+    std::vector<std::shared_ptr<bppp_front>> generic;     // reciprocal verify, one per shape in use (at most BPPP_MAX_GENERIC_FRONTS)
     bool closed = false;
 };
+static const size_t BPPP_MAX_GENERIC_FRONTS = 4;
 
 static bppp_fronts* fronts_of(bppp_ctx* c) {
     std::lock_guard<std::recursive_mutex> lk(c->mu);
@@ -169,6 +189,34 @@ static int get_front(bppp_ctx* c, int which, std::shared_ptr<bppp_front>& out) {
     out = fs->f[which];
     return BPPP_OK;
 }
+static int get_recip_front(bppp_ctx* c, const RecipShape& r, std::shared_ptr<bppp_front>& out) {
+    bppp_fronts* fs = fronts_of(c);
+    if (!fs) return BPPP_ERR_NOMEM;
+    std::lock_guard<std::mutex> lk(fs->mu);
+    if (fs->closed) return BPPP_ERR_CLOSED;
+    for (auto& f : fs->generic)
+        if (f->rs == r) { out = f; return BPPP_OK; }
+    if (fs->generic.size() >= BPPP_MAX_GENERIC_FRONTS) {
+        g_last_error = "too many different reciprocal shapes in single-proof use on one context";
+        return BPPP_ERR_INVALID_ARG;
+    }
+    long cmax, cus;
+    int clanes;
+    {
+        std::lock_guard<std::recursive_mutex> lk2(c->mu);
+        cmax = c->coalesce_max; cus = c->coalesce_us; clanes = c->coalesce_lanes;
+    }
+    std::shared_ptr<bppp_front> f;
+    int rc;
+    try {
+        f = std::make_shared<bppp_front>(c, r, (size_t)cmax, cus, clanes);
+        rc = f->start();
+        if (rc == BPPP_OK) fs->generic.push_back(f);
+    } catch (...) { rc = BPPP_ERR_NOMEM; }
+    if (rc != BPPP_OK) return rc;
+    out = f;
+    return BPPP_OK;
+}
 // drain and drop the front ends (hidden; bppp_ctx.hip calls it from bppp_ctx_destroy with final = true and from bppp_ctx_set_option)
 void bppp_fronts_teardown(bppp_ctx* c, bool final) {
     bppp_fronts* fs;
@@ -177,17 +225,18 @@ void bppp_fronts_teardown(bppp_ctx* c, bool final) {
         fs = c->fronts;
     }
     if (!fs) return;
-    std::shared_ptr<bppp_front> old[2];
+    std::shared_ptr<bppp_front> old[2 + BPPP_MAX_GENERIC_FRONTS];       // (no allocation on this path)
+    size_t n_old = 0;
     {
         std::lock_guard<std::mutex> lk(fs->mu);
         if (final) fs->closed = true;
-        old[0].swap(fs->f[0]);
-        old[1].swap(fs->f[1]);
+        for (auto& f : fs->f)
+            if (f) old[n_old++].swap(f);
+        for (auto& f : fs->generic) old[n_old++].swap(f);
+        fs->generic.clear();
     }
-    for (auto& f : old)
-        if (f) f->co.shutdown();      // drains; returns when no caller is inside.  The object itself goes with its last shared_ptr
-    old[0].reset();
-    old[1].reset();
+    for (size_t i = 0; i < n_old; i++) old[i]->co.shutdown();      // drains; returns when no caller is inside
+    for (size_t i = 0; i < n_old; i++) old[i].reset();              // the object itself goes with its last shared_ptr
     if (final) {
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         delete c->fronts;
@@ -248,6 +297,38 @@ int bppp_u64_prove_one(bppp_ctx* c, const uint8_t* label, size_t label_len, uint
     const void* in[4] = {&x, s, rnd, st};
     void* out[4] = {proof, commitment, status, nullptr};
     return submit_retry(c, 1, in, out);
+}
+// ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) for ONE instance at runtime dimensions, from any number of threads
+static int recip_one(bppp_ctx* c, uint8_t* state_io, const uint8_t* state_in, size_t dim_nd, size_t dim_np, const uint8_t* commitment,
+                     const uint8_t* proof, size_t rounds, size_t nl, size_t nn, uint8_t* accept, int32_t* status) {
+    if (!c || !commitment || !proof || !accept) return BPPP_ERR_INVALID_ARG;
+    // the shape must be one the context's generators can serve (bppp_generic.hip: recip_verify_check_args) before a front end is made for it
+    if (dim_nd == 0 || dim_np == 0 || dim_nd > (size_t)c->ng || dim_nd + 10 > (size_t)c->nh || dim_np > dim_nd + 1 || rounds > 12 || nl > 4096 || nn > 4096)
+        return BPPP_ERR_INVALID_ARG;
+    RecipShape r;
+    r.nd = dim_nd; r.np = dim_np; r.rounds = rounds; r.nl = nl; r.nn = nn;
+    const void* in[4] = {commitment, proof, state_in, nullptr};
+    void* out[4] = {accept, status, state_io, nullptr};
+    for (;;) {
+        std::shared_ptr<bppp_front> f;
+        int rc = get_recip_front(c, r, f);
+        if (rc != BPPP_OK) return rc;
+        rc = f->co.submit(in, out);
+        if (rc != BPPP_ERR_CLOSED) return rc;
+    }
+}
+int bppp_reciprocal_verify_one(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t dim_nd, size_t dim_np, const uint8_t commitment[64],
+                               const uint8_t* proof, size_t rounds, size_t nl, size_t nn, uint8_t* accept, int32_t* status) {
+    if (!label && label_len) return BPPP_ERR_INVALID_ARG;
+    uint8_t st[SB];
+    int rc = bppp_transcript_new(label, label_len, st);
+    if (rc != BPPP_OK) return rc;
+    return recip_one(c, nullptr, st, dim_nd, dim_np, commitment, proof, rounds, nl, nn, accept, status);
+}
+int bppp_reciprocal_verify_one_transcript(bppp_ctx* c, uint8_t state[203], size_t dim_nd, size_t dim_np, const uint8_t commitment[64],
+                                          const uint8_t* proof, size_t rounds, size_t nl, size_t nn, uint8_t* accept, int32_t* status) {
+    if (!state || !state_ok(state)) return BPPP_ERR_INVALID_ARG;
+    return recip_one(c, state, state, dim_nd, dim_np, commitment, proof, rounds, nl, nn, accept, status);
 }
 int bppp_ctx_get_coalesce_stats(bppp_ctx* c, int which, uint64_t out[8]) {
     if (!c || !out || which < 0 || which > 1) return BPPP_ERR_INVALID_ARG;

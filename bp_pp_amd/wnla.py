@@ -208,6 +208,22 @@ class ReciprocalRangeProofProtocol:
         return acc, st
 
 
+    def verify_one(self, commitment: bytes, proof: bytes, rounds: int, nl: int, nn: int, transcript):
+        """`ReciprocalRangeProofProtocol::verify(&self, commitment, proof, t)` (reciprocal.rs:98-107) for ONE instance, from any number
+        of threads: the call joins the other threads' calls of the same shape in one batched GPU call (include/bppp.h:
+        bppp_reciprocal_verify_one[_transcript]).  `transcript`: a label (bytes) or a bp_pp_amd.transcript.Transcript (advanced in
+        place).  -> (accept, status)"""
+        import ctypes as C
+        acc, st = C.c_uint8(0), C.c_int32(0)
+        L = _capi.lib()
+        if isinstance(transcript, (bytes, bytearray)):
+            _capi.check(L.bppp_reciprocal_verify_one(self._w._ctx, bytes(transcript), len(transcript), self.dim_nd, self.dim_np, bytes(commitment),
+                                                     bytes(proof), rounds, nl, nn, C.byref(acc), C.byref(st)))
+        else:
+            _capi.check(L.bppp_reciprocal_verify_one_transcript(self._w._ctx, transcript._buf, self.dim_nd, self.dim_np, bytes(commitment),
+                                                                bytes(proof), rounds, nl, nn, C.byref(acc), C.byref(st)))
+        return bool(acc.value), int(st.value)
+
     def verify_batch_device(self, label: bytes, n: int, d_commitments: int, d_proofs: int, rounds: int, nl: int, nn: int, d_accept: int,
                             d_status: int) -> None:
         """Everything resident in HBM (raw device addresses); asynchronous on the context's stream."""

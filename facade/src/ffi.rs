@@ -44,6 +44,8 @@ extern "C" {
     pub fn bppp_u64_verify_one_transcript(ctx: *mut BpppCtx, state: *mut u8, commitment: *const u8, proof: *const u8, accept: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_u64_prove_one(ctx: *mut BpppCtx, label: *const u8, label_len: usize, x: u64, s: *const u8, rnd: *const u8, proof: *mut u8, commitment: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_u64_prove_one_transcript(ctx: *mut BpppCtx, state: *mut u8, x: u64, s: *const u8, rnd: *const u8, proof: *mut u8, commitment: *mut u8, status: *mut i32) -> c_int;
+    pub fn bppp_reciprocal_verify_one(ctx: *mut BpppCtx, label: *const u8, label_len: usize, dim_nd: usize, dim_np: usize, commitment: *const u8, proof: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32) -> c_int;
+    pub fn bppp_reciprocal_verify_one_transcript(ctx: *mut BpppCtx, state: *mut u8, dim_nd: usize, dim_np: usize, commitment: *const u8, proof: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_ctx_get_coalesce_stats(ctx: *mut BpppCtx, which: c_int, out: *mut u64) -> c_int;
     pub fn bppp_u64_commit_value_batch(ctx: *mut BpppCtx, n: usize, x: *const u64, s: *const u8, out: *mut u8) -> c_int;
     pub fn bppp_wnla_ctx_create(out: *mut *mut BpppCtx, g: *const u8, g_vec: *const u8, ng: usize, h_vec: *const u8, nh: usize, device: c_int, fb_window_bits: c_int) -> c_int;

@@ -211,6 +211,15 @@ BPPP_API int bppp_u64_prove_one(bppp_ctx* ctx, const uint8_t* label, size_t labe
                                 const uint8_t* rnd /* 52 x 32 */, uint8_t proof[928], uint8_t commitment[64], int32_t* status /* or NULL */);
 BPPP_API int bppp_u64_prove_one_transcript(bppp_ctx* ctx, uint8_t state[203], uint64_t x, const uint8_t s[32], const uint8_t* rnd /* 52 x 32 */,
                                            uint8_t proof[928], uint8_t commitment[64], int32_t* status /* or NULL */);
+/* ReciprocalRangeProofProtocol::verify(&self, commitment, proof, t) (reciprocal.rs:98-107) the same way: ONE instance per call at the
+ * runtime dimensions of bppp_reciprocal_verify_batch (context from bppp_wnla_ctx_create; proof layout as there), gathered with the other
+ * threads' calls of the same shape into one batched call.  A context serves at most four different shapes this way. */
+BPPP_API int bppp_reciprocal_verify_one(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t dim_nd, size_t dim_np,
+                                        const uint8_t commitment[64], const uint8_t* proof, size_t rounds, size_t nl, size_t nn,
+                                        uint8_t* accept, int32_t* status /* or NULL */);
+BPPP_API int bppp_reciprocal_verify_one_transcript(bppp_ctx* ctx, uint8_t state[203], size_t dim_nd, size_t dim_np, const uint8_t commitment[64],
+                                                   const uint8_t* proof, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
+                                                   int32_t* status /* or NULL */);
 /* Counters of the front end since it was created: out = {requests, batches, largest batch, batches sealed full, batches sealed by the
  * deadline, microseconds its dispatchers spent inside batched calls, microseconds they waited for callers' row copies, 0}; which = 0
  * verify, 1 prove.  All zero before the first call. */

@@ -232,3 +232,59 @@ def test_destroy_with_callers_inside_drains():
     round_of_callers(lambda: p.set_option("coalesce_us", 999_999))     # option change: drain, context stays valid
     assert p.verify_one(V[2].tobytes(), P[2].tobytes(), workload.LABEL) == (True, 0)
     round_of_callers(p.close)                                            # destroy: drain, then the context is gone
+
+
+@pytest.mark.parametrize("nd,npp,B", [(32, 16, 12), (12, 10, 7)])
+def test_reciprocal_verify_one_from_many_threads(nd, npp, B):
+    """bppp_reciprocal_verify_one[_transcript]: `ReciprocalRangeProofProtocol::verify` (reciprocal.rs:98-107) one instance per call from
+    several threads at runtime dimensions, gathered per shape; every verdict and status the oracle's, the transcript form advancing
+    the caller's state exactly as the batched transcript entry point does."""
+    import recip_cases
+    from bp_pp_amd.transcript import Transcript
+    from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
+    case = recip_cases.make(nd, npp, B)
+    proto = ReciprocalRangeProofProtocol(nd, npp, case["g"], case["gv"], case["hv"], case["gv_"], case["hv_"], device=0, fb_window_bits=8)
+    try:
+        shape = (case["rounds"], case["nl"], case["nn"])
+        P, com = case["proofs"].copy(), case["commitments"].copy()
+        P[0, -1] ^= 1
+        P[1, 256 + 64 * case["rounds"] + 5] ^= 0x40
+        com[2] = case["commitments"][3]
+        exp = [recip_cases.oracle_verify(case, bytes(com[b]), bytes(P[b])) for b in range(B)]
+        S = [Transcript(case["label"]) for _ in range(B)]
+        _, _, ref_states = proto.verify_batch(b"", com, P, *shape, transcripts=[Transcript(case["label"]) for _ in range(B)])
+        out = [None] * (2 * B)
+        errs = []
+
+        def worker(t):
+            try:
+                for i in range(t, 2 * B, 6):
+                    b = i % B
+                    if i < B:
+                        out[i] = proto.verify_one(bytes(com[b]), bytes(P[b]), *shape, case["label"])
+                    else:
+                        out[i] = proto.verify_one(bytes(com[b]), bytes(P[b]), *shape, S[b])
+            except Exception as e:                # noqa: BLE001
+                errs.append(repr(e))
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs[:3]
+        for i in range(2 * B):
+            b = i % B
+            acc, st = out[i]
+            assert int(acc) == (1 if exp[b] == 1 else 0) and (st != 0) == (exp[b] < 0), (i, out[i], exp[b])
+        for b in range(B):
+            assert S[b].state == bytes(ref_states[b])
+        assert sum(1 for e in exp if e == 1) >= B - 3 and exp[0] != 1
+        # a shape the context's generators cannot serve is refused before any front end exists for it
+        import ctypes as C
+        from bp_pp_amd import _capi
+        a, s_ = C.c_uint8(9), C.c_int32(9)
+        rc = _capi.lib().bppp_reciprocal_verify_one(proto._w._ctx, b"x", 1, 5000, 16, bytes(64), bytes(P[0]), shape[0], shape[1], shape[2], C.byref(a), C.byref(s_))
+        assert rc == _capi.ERR_INVALID_ARG and a.value == 9
+    finally:
+        proto.close()
