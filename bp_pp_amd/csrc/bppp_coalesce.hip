@@ -160,29 +160,29 @@ struct bppp_fronts {
 };
 static const size_t BPPP_MAX_GENERIC_FRONTS = 4;
 
-static bppp_fronts* fronts_of(bppp_ctx* c) {
+// Lock order: the context's lock (c->mu) is never taken while a front-end lock (fs->mu) is held -- bppp_ctx_set_option holds c->mu
+// while it drains the front ends (which takes fs->mu), so the other order would deadlock.  What the front ends need from the context
+// (the bppp_fronts object, the coalesce_* options) is therefore read under c->mu FIRST, then fs->mu is taken.
+struct FrontOptions { long max, us; int lanes; };
+static bppp_fronts* fronts_of(bppp_ctx* c, FrontOptions& o) {
     std::lock_guard<std::recursive_mutex> lk(c->mu);
     if (!c->fronts) c->fronts = new (std::nothrow) bppp_fronts();
+    o.max = c->coalesce_max; o.us = c->coalesce_us; o.lanes = c->coalesce_lanes;
     return c->fronts;
 }
 static int get_front(bppp_ctx* c, int which, std::shared_ptr<bppp_front>& out) {
-    bppp_fronts* fs = fronts_of(c);
+    FrontOptions o;
+    bppp_fronts* fs = fronts_of(c, o);
     if (!fs) return BPPP_ERR_NOMEM;
     std::lock_guard<std::mutex> lk(fs->mu);
     if (fs->closed) return BPPP_ERR_CLOSED;
     if (!fs->f[which]) {
         std::shared_ptr<bppp_front> f;
-        long cmax, cus;
-        int clanes;
-        {
-            std::lock_guard<std::recursive_mutex> lk(c->mu);       // (bppp_ctx_set_option writes them under this lock)
-            cmax = c->coalesce_max; cus = c->coalesce_us; clanes = c->coalesce_lanes;
-        }
-        try {
-            f = std::make_shared<bppp_front>(c, which == 1, (size_t)cmax, cus, clanes);
-        } catch (...) { return BPPP_ERR_NOMEM; }
         int rc;
-        try { rc = f->start(); } catch (...) { rc = BPPP_ERR_NOMEM; }      // (nothing may throw across the C ABI)
+        try {
+            f = std::make_shared<bppp_front>(c, which == 1, (size_t)o.max, o.us, o.lanes);
+            rc = f->start();
+        } catch (...) { rc = BPPP_ERR_NOMEM; }      // (nothing may throw across the C ABI)
         if (rc != BPPP_OK) return rc;
         fs->f[which] = f;
     }
@@ -190,7 +190,8 @@ static int get_front(bppp_ctx* c, int which, std::shared_ptr<bppp_front>& out) {
     return BPPP_OK;
 }
 static int get_recip_front(bppp_ctx* c, const RecipShape& r, std::shared_ptr<bppp_front>& out) {
-    bppp_fronts* fs = fronts_of(c);
+    FrontOptions o;
+    bppp_fronts* fs = fronts_of(c, o);
     if (!fs) return BPPP_ERR_NOMEM;
     std::lock_guard<std::mutex> lk(fs->mu);
     if (fs->closed) return BPPP_ERR_CLOSED;
@@ -200,16 +201,10 @@ static int get_recip_front(bppp_ctx* c, const RecipShape& r, std::shared_ptr<bpp
         g_last_error = "too many different reciprocal shapes in single-proof use on one context";
         return BPPP_ERR_INVALID_ARG;
     }
-    long cmax, cus;
-    int clanes;
-    {
-        std::lock_guard<std::recursive_mutex> lk2(c->mu);
-        cmax = c->coalesce_max; cus = c->coalesce_us; clanes = c->coalesce_lanes;
-    }
     std::shared_ptr<bppp_front> f;
     int rc;
     try {
-        f = std::make_shared<bppp_front>(c, r, (size_t)cmax, cus, clanes);
+        f = std::make_shared<bppp_front>(c, r, (size_t)o.max, o.us, o.lanes);
         rc = f->start();
         if (rc == BPPP_OK) fs->generic.push_back(f);
     } catch (...) { rc = BPPP_ERR_NOMEM; }
