@@ -95,8 +95,9 @@ BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
  * the context stays usable; 0 clears it.  "max_batch": the u64 verify entry
  * points run a batch of more than max_batch proofs as consecutive parts of max_batch on the same stream, which bounds the per-proof
  * workspace (about 30 KB per proof) whatever n is -- a multiple of 64, >= 1024; default 2097152 (63 GB of workspace).
- * "ct_prover" = 1: the provers' and committers' sums over SECRET scalars -- x, s, the reciprocals and every blinding draw, i.e. V, r_com,
- * c_o, c_l, c_r, c_s (and bppp_u64_commit_value_batch) -- run in a form with no secret-dependent address, branch or instruction count
+ * "ct_prover" = 1: the u64 prover's and committer's sums over SECRET scalars (bppp_u64_prove_*, bppp_u64_commit_value_batch; the generic
+ * provers and bppp_msm_batch are NOT covered) -- x, s, the reciprocals and every blinding draw, i.e. V, r_com, c_o, c_l, c_r, c_s --
+ * run in a form with no secret-dependent address, branch or instruction count
  * (4-bit windows over a 3 MB table, every entry of every window read and selected by mask, complete addition law), as k256 does for
  * the reference (reciprocal.rs:88-95,118); the default (0) gathers one table entry per window at an address the digit selects, which
  * is a memory-access side channel towards whoever shares the GPU.  The proofs are byte-identical either way; the cost is reported in
