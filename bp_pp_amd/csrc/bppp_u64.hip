@@ -160,7 +160,9 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         else if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
         else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
     }
-    LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    // the 49 unrolled generator coefficients: sixteen lanes per proof while that still leaves the chip under-filled
+    if (split) LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
+    else LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     if (!rlc_seed) {
         if (split) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l64<<<fb64_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
         else if (fb_one_lane) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
@@ -435,10 +437,15 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_b_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PSECRETX(4, job_rcom(), job_co(), job_cl(), job_cr());
-    if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    // a small call waits for one lane's chain: the stages' 16-term loops on sixteen lanes per value (prove_core.h: "lane forms")
+    const bool stage_lanes = fb_wave && !c->no_lane_groups;
+    const unsigned g16_blocks = (unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    if (stage_lanes) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_g16<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w));
+    else if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PSECRET(job_cs());
-    if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (stage_lanes) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_g16<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w));
+    else if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_c0());
     // (the lane-per-generator form of the scalar kernel pays only while the chip is empty: at 2^13 ... 2^15 values it costs 1.2 / 2.3 /

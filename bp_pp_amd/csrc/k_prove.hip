@@ -25,6 +25,21 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d(ProveWs w) {
     if (t >= w.N) return;
     for_each_position_group(prove_position_key(w, t), [&]() { prove_stage_d(w, t); });
 }
+// small calls: sixteen lanes per value, a lane per term of the stage's 16-term loop (prove_core.h: "lane forms")
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d_g16(ProveWs w) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 4;
+    if (t >= w.N) return;
+    const int lane = (int)(g & 15);
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_stage_d(w, t, lane); });
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f_g16(ProveWs w) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 4;
+    if (t >= w.N) return;
+    const int lane = (int)(g & 15);
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_stage_f(w, t, lane); });
+}
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f(ProveWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= w.N) return;

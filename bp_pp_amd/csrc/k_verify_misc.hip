@@ -25,6 +25,12 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_small(VerifyWs ws)
     const u32 key = preloaded_position_key(ws.states, ws.n_states, t);
     for_each_position_group(key, [&]() { verify_phase1(ws, t); });
 }
+// small calls: sixteen lanes per proof (verify_core.h: verify_final_scalars_lane); whole groups are active or leave together
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars_g16(VerifyWs ws) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 4;
+    if (t < ws.N) verify_final_scalars_lane(ws, t, (int)(g & 15));
+}
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(VerifyWs ws) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N) verify_final_scalars(ws, t);

@@ -100,6 +100,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g64(bppp::VerifyWs
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed_l64(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_l64(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars_g16(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_l1(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(bppp::VerifyWs ws, int* reject_count);
@@ -119,6 +120,8 @@ __global__ __launch_bounds__(256) void k_sec1_compress(uint8_t* commitments33, u
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_a(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_b(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d(bppp::ProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d_g16(bppp::ProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f_g16(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_export_states(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(bppp::ProveWs w, int k);

@@ -244,8 +244,43 @@ HD void prove_stage_b(const ProveWs& w, size_t t) {
     pw_st_sc(w, t, SV_SV, svv);
     w.status[t] = status;
 }
+// ---- lane forms of the stage kernels' 16-term loops (small calls: bppp_u64.hip).  A call of a few values waits for ONE lane's chain of
+// dependent multiplications -- 416 in stage D's loop over the 16 digits, 272 in stage F's --, and the terms are independent: lane j of a
+// group of sixteen takes term j (its powers mu^(j+1), mu^-(j+1), lambda^(j+1) by ten multiplications each instead of the running
+// products), the seven sums meet by shuffles, and everything outside the loop is done by all sixteen lanes alike (identical values,
+// identical stores).  lane = -1 is the one-lane form (and the only one the host emulation runs).
+HD void sc_pow_u5(sc& r, const sc& a, unsigned e) {      // a^e for 1 <= e <= 31, the same ten multiplications whatever e is
+    sc acc, tmp;
+    sc_set_u32(acc, 1);
+#pragma unroll
+    for (int bit = 4; bit >= 0; bit--) {
+        sc_mul(acc, acc, acc);
+        sc_mul(tmp, acc, a);
+        const bool take = ((e >> bit) & 1u) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc.v[i] = take ? tmp.v[i] : acc.v[i];
+    }
+    r = acc;
+}
+HD void prove_group_sum16(sc& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sc_group_sum16(a);
+#else
+    (void)a;
+#endif
+}
+HD bool prove_group_all16(bool ok) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r = ok ? 1 : 0;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) r &= __shfl_xor(r, m, 64);
+    return r != 0;
+#else
+    return ok;
+#endif
+}
 // ---------------------------------------------------------------- stage D: transcript to delta; f_, rs; scalars of c_s
-HD void prove_stage_d(const ProveWs& w, size_t t) {
+HD void prove_stage_d(const ProveWs& w, size_t t, int lane = -1) {
     const size_t N = w.N;
     const uint64_t x = w.x[t];
     int32_t status = w.status[t];
@@ -317,8 +352,14 @@ HD void prove_stage_d(const ProveWs& w, size_t t) {
     sc_set_u32(f0, 0); sc_set_u32(f1, 0); sc_set_u32(f2, 0); sc_set_u32(f3, 0); sc_set_u32(f4, 0); sc_set_u32(f5, 0); sc_set_u32(f6, 0);
     sc mip = mu_inv, mp = mu;
     lp = lambda;
+    const int j_begin = lane >= 0 ? lane : 0, j_end = lane >= 0 ? lane + 1 : 16;
+    if (lane >= 0) {            // this lane's term only: its powers directly
+        sc_pow_u5(mip, mu_inv, (unsigned)lane + 1);
+        sc_pow_u5(mp, mu, (unsigned)lane + 1);
+        sc_pow_u5(lp, lambda, (unsigned)lane + 1);
+    }
 #pragma nounroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = j_begin; j < j_end; j++) {
         sc ls_j, ns_j, r_j, einv_j, d_j, m_j, p16;
         rok &= pw_rnd(ls_j, w, t, 19 + j);
         rok &= pw_rnd(ns_j, w, t, 36 + j);
@@ -361,6 +402,11 @@ HD void prove_stage_d(const ProveWs& w, size_t t) {
         sc_mul(lp, lp, lambda);
         sc_mul(mp, mp, mu);
     }
+    if (lane >= 0) {            // the group's seven sums, and whether every lane's draws decoded
+        prove_group_sum16(f0); prove_group_sum16(f1); prove_group_sum16(f2); prove_group_sum16(f3);
+        prove_group_sum16(f4); prove_group_sum16(f5); prove_group_sum16(f6);
+        rok = prove_group_all16(rok);
+    }
     sc ls16;
     rok &= pw_rnd(ls16, w, t, 19 + 16);
     pw_st_msc(w, t, 0, 26 + 16, ls16);
@@ -386,7 +432,7 @@ HD void prove_stage_d(const ProveWs& w, size_t t) {
     w.status[t] = status;
 }
 // ---------------------------------------------------------------- stage F: c_s -> tau; l, n, c, v; scalars of C0; WNLA state
-HD void prove_stage_f(const ProveWs& w, size_t t) {
+HD void prove_stage_f(const ProveWs& w, size_t t, int lane = -1) {
     const size_t N = w.N;
     const uint64_t x = w.x[t];
     int32_t status = w.status[t];
@@ -422,6 +468,7 @@ HD void prove_stage_f(const ProveWs& w, size_t t) {
         sc_mul(t1, tau2, rr_i); sc_sub(li, li, t1);
         if (i == 0) { sc_add(t1, svv, svv); sc_mul(t1, t1, tau3); sc_add(li, li, t1); }   // rv[0] = 2 (s + r_blind)
         pw_st_sc(w, t, SV_L0 + i, li);
+        if (lane >= 0) pw_st_msc(w, t, 0, 17 + i, li);      // (lane form: the scalars of C0 are written where they are made, see below)
     }
     // S, closed forms as in the verifier
     sc S = lambda, lp = lambda, mp = mu, musum = mu;
@@ -436,8 +483,16 @@ HD void prove_stage_f(const ProveWs& w, size_t t) {
     sc mip = mu_inv;
     lp = lambda;
     mp = mu;
+    const int j_begin = lane >= 0 ? lane : 0, j_end = lane >= 0 ? lane + 1 : 16;
+    sc ls16_in;                                                  // c_s's scalar of h[25] = ls[16]: read before the C0 scalars overwrite set 0
+    pw_ld_msc(ls16_in, w, t, 0, 26 + 16);
+    if (lane >= 0) {
+        sc_pow_u5(mip, mu_inv, (unsigned)lane + 1);
+        sc_pow_u5(mp, mu, (unsigned)lane + 1);
+        sc_pow_u5(lp, lambda, (unsigned)lane + 1);
+    }
 #pragma nounroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = j_begin; j < j_end; j++) {
         sc ls_j, ns_j, r_j, einv_j, d_j, m_j, p16, pn, lj, nj, cj;
         pw_ld_msc(ls_j, w, t, 0, 26 + j);
         pw_ld_msc(ns_j, w, t, 0, 1 + j);
@@ -450,6 +505,7 @@ HD void prove_stage_f(const ProveWs& w, size_t t) {
         sc_mul(t1, tau, m_j); sc_add(lj, lj, t1);
         sc_mul(t1, two_tau3, r_j); sc_add(lj, lj, t1);
         pw_st_sc(w, t, SV_L0 + 9 + j, lj);
+        if (lane >= 0) pw_st_msc(w, t, 0, 17 + 9 + j, lj);        // (read above as ls_j: this lane's own slot)
         // pn_tau[j] (circuit.rs:485-487)
         sc_set_u64(p16, (u64)1 << (4 * j));
         sc_mul(t1, tau2, p16);
@@ -465,6 +521,7 @@ HD void prove_stage_f(const ProveWs& w, size_t t) {
         sc_mul(t1, tau2, r_j); sc_sub(nj, nj, t1);
         sc_add(nj, nj, pn);
         pw_st_sc(w, t, SV_N0 + j, nj);
+        if (lane >= 0) pw_st_msc(w, t, 0, 1 + j, nj);             // (read above as ns_j: this lane's own slot)
         // c[9+j] = cl_tau[j] = 2 tau^2 S (e+j)^-1 - lambda^(j+1)
         sc_mul(cj, two_tau2_S, einv_j);
         sc_sub(cj, cj, lp);
@@ -473,11 +530,12 @@ HD void prove_stage_f(const ProveWs& w, size_t t) {
         sc_mul(lp, lp, lambda);
         sc_mul(mp, mp, mu);
     }
+    if (lane >= 0) prove_group_sum16(ps);
     {   // l[25] = tau^-1 ls[16]; l[26..32) = 0; c[25..32) = 0     (circuit.rs:526-529)
-        sc ls16, l25;
-        pw_ld_msc(ls16, w, t, 0, 26 + 16);
-        sc_mul(l25, tau_inv, ls16);
+        sc l25;
+        sc_mul(l25, tau_inv, ls16_in);
         pw_st_sc(w, t, SV_L0 + 25, l25);
+        if (lane >= 0) pw_st_msc(w, t, 0, 17 + 25, l25);
         pw_st_sc(w, t, SV_C0 + 25, zero);
 #pragma nounroll
         for (int i = 26; i < 32; i++) { pw_st_sc(w, t, SV_L0 + i, zero); pw_st_sc(w, t, SV_C0 + i, zero); }
@@ -498,10 +556,12 @@ HD void prove_stage_f(const ProveWs& w, size_t t) {
     sc_add(ps, ps, t1);
     // scalars of C0 = v g + <h, l> + <g_vec, n>  (set 0: bases 0..42)   circuit.rs:520-524
     pw_st_msc(w, t, 0, 0, ps);
+    if (lane < 0) {             // (the lane form has written these where it made them: no lane reads what another lane of its group stored)
 #pragma nounroll
-    for (int j = 0; j < 16; j++) { sc nj; pw_ld_sc(nj, w, t, SV_N0 + j); pw_st_msc(w, t, 0, 1 + j, nj); }
+        for (int j = 0; j < 16; j++) { sc nj; pw_ld_sc(nj, w, t, SV_N0 + j); pw_st_msc(w, t, 0, 1 + j, nj); }
 #pragma nounroll
-    for (int i = 0; i < 26; i++) { sc li; pw_ld_sc(li, w, t, SV_L0 + i); pw_st_msc(w, t, 0, 17 + i, li); }
+        for (int i = 0; i < 26; i++) { sc li; pw_ld_sc(li, w, t, SV_L0 + i); pw_st_msc(w, t, 0, 17 + i, li); }
+    }
     // generator unrolling coefficients start at 1
 #pragma nounroll
     for (int i = 0; i < 32; i++) pw_st_sc(w, t, SV_CH0 + i, one);

@@ -2054,6 +2054,75 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
         ws_st8(ws.fsc, N, t, 33 + i, tmp.v);
     }
 }
+#if defined(__HIPCC__)
+// The same scalars by SIXTEEN lanes per proof, for calls that leave the chip empty (bppp_u64.hip: the small-call path): lane b forms
+// ch[b] and cg[b] -- four conditional multiplications each, in registers -- and its three output scalars; the two folded c values are
+// a sum over the group (shuffles).  The one-lane form above walks 118 multiplications whose operands travel through the workspace
+// (a store-to-load round trip per step): 145 us for a lone proof, a seventh of it here.  Every lane of a group must be active.
+__device__ __forceinline__ void sc_group_sum16(sc& a) {
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) {
+        sc o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.v[i] = __shfl_xor(a.v[i], m, 64);
+        sc_add(a, a, o);
+    }
+}
+__device__ __forceinline__ void verify_final_scalars_lane(const VerifyWs& ws, size_t t, int b) {
+    const size_t N = ws.N;
+    sc rho, y[4], rk[4], l0, l1, n0, mu5, tmp;
+    ws_ld8(rho.v, ws.chal, N, t, 1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) ws_ld8(y[k].v, ws.chal, N, t, 6 + k);
+    ws_ld8(l0.v, ws.lns, N, t, 0);
+    ws_ld8(l1.v, ws.lns, N, t, 1);
+    ws_ld8(n0.v, ws.lns, N, t, 2);
+    rk[0] = rho;
+#pragma unroll
+    for (int k = 1; k < 4; k++) sc_mul(rk[k], rk[k - 1], rk[k - 1]);
+    sc_mul(mu5, rk[3], rk[3]);
+    sc_mul(mu5, mu5, mu5);
+    sc ch, cg;
+    sc_set_u32(ch, 1);
+    sc_set_u32(cg, 1);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool bit = ((b >> k) & 1) != 0;
+        sc_mul(tmp, ch, y[k]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) ch.v[i] = bit ? tmp.v[i] : ch.v[i];
+        sc f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) f.v[i] = bit ? y[k].v[i] : rk[k].v[i];
+        sc_mul(cg, cg, f);
+    }
+    // c'_0 = sum_{i < 16} c[i] ch[i], c'_1 = sum_{16 <= i < 25} c[i] ch[i - 16]
+    sc c0f, c1f, cv;
+    ws_ld8(cv.v, ws.cvec, N, t, b);
+    sc_mul(c0f, cv, ch);
+    ws_ld8(cv.v, ws.cvec, N, t, b < 9 ? 16 + b : 16);
+    sc_mul(c1f, cv, ch);
+    if (b >= 9) sc_set_u32(c1f, 0);
+    sc_group_sum16(c0f);
+    sc_group_sum16(c1f);
+    if (b == 0) {
+        sc v, w;
+        sc_mul(v, c0f, l0);
+        sc_mul(w, c1f, l1);
+        sc_add(v, v, w);
+        sc_mul(w, n0, n0);
+        sc_mul(w, w, mu5);
+        sc_add(v, v, w);
+        ws_st8(ws.fsc, N, t, 0, v.v);
+    }
+    sc_mul(tmp, n0, cg);
+    ws_st8(ws.fsc, N, t, 1 + b, tmp.v);
+    sc_mul(tmp, l0, ch);
+    ws_st8(ws.fsc, N, t, 17 + b, tmp.v);
+    sc_mul(tmp, l1, ch);
+    ws_st8(ws.fsc, N, t, 33 + b, tmp.v);
+}
+#endif
 HD void verify_final_check_ranges(FbRanges& rg) { fb_ranges_one(rg, 0, 0, BPPP_NG); }
 HD void verify_final_check_store(const VerifyWs& ws, size_t t, const pt& rhs) { ws_st_pt(ws.pfix, ws.N, t, rhs); }
 // accept bit: C4 == rhs as projective classes (wnla.rs:81), and no status flag
