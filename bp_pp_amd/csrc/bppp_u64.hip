@@ -466,7 +466,8 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
         if (pending_cnext) PMSMX(3, job_x(), job_r(k), job_cnext(), job_x());
         else PMSMX(2, job_x(), job_r(k), job_x(), job_x());
         if (next_in_flight) { HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); next_in_flight = false; }      // C_{k-1} is there
-        if (w2) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        if (stage_lanes) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g16<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        else if (w2) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         else PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         if (!w.next_by_msm && k < 4) {
             if (a != s) { HIP_TRY(hipEventRecord(c->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0)); }

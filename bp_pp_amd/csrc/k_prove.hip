@@ -68,6 +68,15 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(ProveWs w, int 
     if (t >= w.N) return;
     for_each_position_group(prove_position_key(w, t), [&]() { prove_round_fold(w, t, k); });
 }
+// small calls: sixteen lanes per value for part one of a round (prove_core.h: prove_round_fold_lanes; the next commitment is a fixed-base
+// sum there).  Groups are whole or absent: a group's sixteen lanes share t, so the bounds test is uniform over the group.
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold_g16(ProveWs w, int k) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 4;
+    if (t >= w.N) return;
+    const int lane = (int)(g & 15);
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_round_fold_lanes(w, t, k, lane); });
+}
 // part two of a round (prove_core.h: prove_round_next): the next commitment by the variable-base path, no transcript in it
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_next(ProveWs w, int k) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_b(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d_g16(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f_g16(bppp::ProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold_g16(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_export_states(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(bppp::ProveWs w, int k);

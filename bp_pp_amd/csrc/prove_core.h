@@ -651,15 +651,14 @@ HD void prove_round_scalars(const ProveWs& w, size_t t, int k) {
 // The point slots behind the running products: 0 = X, 1 = R (the table builder's inputs), 2 = C_{k-1}.
 HD u32* prove_fold_rpts(const ProveWs& w) { return (u32*)((uint8_t*)w.straus + (size_t)32 * sizeof(apt_packed) * w.N) + (size_t)28 * 10 * w.N; }
 HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane = -1);
-HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
+// the part every form shares: C_{k-1}, X, R to affine (one inversion), X and R into the proof, the round's transcript, y_k
+HD void prove_round_fold_head(const ProveWs& w, size_t t, int k, apt A[3], sc& y, int32_t& status) {
     const size_t N = w.N;
     const int sh = k - 1, nl = 32 >> sh, nn = 16 >> sh;
-    int32_t status = w.status[t];
     pt P[3];   // C_{k-1}, X, R
     pw_ld_pt(P[0], w, t, PB_C);
     pw_ld_pt(P[1], w, t, PB_X);
     pw_ld_pt(P[2], w, t, PB_R);
-    apt A[3];
     batch_to_affine<3>(A, P);
     uint8_t* pb = w.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
     apt_to_xy64(pb + 64 * (8 + (4 - k)), A[1]);     // proof.x is pushed innermost-first (wnla.rs:188): x[4-k] = X of round k
@@ -671,9 +670,17 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
     app_point(tr, "wnla_r", A[2]);
     t_append_u64(tr, "l.sz", (u64)nl);
     t_append_u64(tr, "n.sz", (u64)nn);
-    sc y;
     if (!t_get_challenge(tr, "wnla_challenge", y)) { status |= ST_DEGENERATE; sc_set_u32(y, 1); }
     ws_st_strobe(w.tstate, N, t, tr);
+}
+HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
+    const size_t N = w.N;
+    const int sh = k - 1, nl = 32 >> sh, nn = 16 >> sh;
+    int32_t status = w.status[t];
+    apt A[3];
+    sc y;
+    prove_round_fold_head(w, t, k, A, y, status);
+    uint8_t* pb = w.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
     sc rho, rho_inv, mu, t1;
     pw_ld_sc(rho, w, t, SV_RHO); pw_ld_sc(rho_inv, w, t, SV_RHOINV); pw_ld_sc(mu, w, t, SV_MU);
     // l_ = l0 + y l1; c_ = c0 + y c1; n_ = rho^-1 n0 + y n1   (in place: slot m is written after slots 2m, 2m+1 are read)
@@ -808,6 +815,85 @@ HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane) {
     pw_st_pt(w, t, PB_C, acc);
     (void)group_lane;
 }
+#if defined(__HIPCC__)
+// Small calls (next_by_msm): part one of a round on SIXTEEN lanes per value.  Every lane runs the head (identical values and stores);
+// then lane q folds l, c (q < nl / 2), n (q < nn / 2), updates the generator coefficients ch[q], ch[q + 16], cg[q], forms its share of
+// the next commitment's scalars -- cg[q] n_[q >> k], ch[i] l_[i >> k] for i = q, q + 16, with the folded entries of OTHER lanes read by
+// shuffle, never through memory -- and its terms of v = <c_, l_> + |n_|^2_mu', which meet by a group sum.  One lane's chain is then the
+// head plus a dozen multiplications instead of the head plus 150.  Every lane of a group must be active.
+__device__ __forceinline__ void sc_group_read16(sc& r, const sc& a, int src) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = __shfl(a.v[i], src, 16);
+}
+__device__ __forceinline__ void prove_round_fold_lanes(const ProveWs& w, size_t t, int k, int q) {
+    const int sh = k - 1, nl = 32 >> sh, nn = 16 >> sh;
+    int32_t status = w.status[t];
+    apt A[3];
+    sc y;
+    prove_round_fold_head(w, t, k, A, y, status);
+    uint8_t* pb = w.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
+    sc rho, rho_inv, mu, t1, zero;
+    sc_set_u32(zero, 0);
+    pw_ld_sc(rho, w, t, SV_RHO); pw_ld_sc(rho_inv, w, t, SV_RHOINV); pw_ld_sc(mu, w, t, SV_MU);
+    // folds, in place: every lane's loads are consumed before its store is issued, and a wavefront's requests are served in order
+    sc lq = zero, cq = zero, nq = zero;
+    const bool has_l = q < nl / 2, has_n = q < nn / 2;
+    {
+        sc a0, a1;
+        const int m = has_l ? q : 0;
+        pw_ld_sc(a0, w, t, SV_L0 + 2 * m); pw_ld_sc(a1, w, t, SV_L0 + 2 * m + 1);
+        sc_mul(t1, a1, y); sc_add(lq, a0, t1);
+        pw_ld_sc(a0, w, t, SV_C0 + 2 * m); pw_ld_sc(a1, w, t, SV_C0 + 2 * m + 1);
+        sc_mul(t1, a1, y); sc_add(cq, a0, t1);
+        const int mn = has_n ? q : 0;
+        pw_ld_sc(a0, w, t, SV_N0 + 2 * mn); pw_ld_sc(a1, w, t, SV_N0 + 2 * mn + 1);
+        sc_mul(a0, a0, rho_inv);
+        sc_mul(t1, a1, y); sc_add(nq, a0, t1);
+        if (has_l) { pw_st_sc(w, t, SV_L0 + q, lq); pw_st_sc(w, t, SV_C0 + q, cq); }
+        if (has_n) pw_st_sc(w, t, SV_N0 + q, nq);
+    }
+    if (k < 4) {
+        // generator coefficients pick up this round's factor: ch[q], ch[q + 16], cg[q]
+        sc ch0, ch1, cg;
+        pw_ld_sc(ch0, w, t, SV_CH0 + q); pw_ld_sc(ch1, w, t, SV_CH0 + q + 16); pw_ld_sc(cg, w, t, SV_CG0 + q);
+        if ((q >> sh) & 1) { sc_mul(ch0, ch0, y); pw_st_sc(w, t, SV_CH0 + q, ch0); }
+        if (((q + 16) >> sh) & 1) { sc_mul(ch1, ch1, y); pw_st_sc(w, t, SV_CH0 + q + 16, ch1); }
+        sc_mul(cg, cg, ((q >> sh) & 1) ? y : rho);
+        pw_st_sc(w, t, SV_CG0 + q, cg);
+        // rho <- mu, mu <- mu^2, rho^-1 <- (rho^-1)^2           (wnla.rs:180-181)
+        sc mun;
+        sc_mul(mun, mu, mu);
+        pw_st_sc(w, t, SV_RHO, mu);
+        pw_st_sc(w, t, SV_MU, mun);
+        sc_mul(t1, rho_inv, rho_inv);
+        pw_st_sc(w, t, SV_RHOINV, t1);
+        // next commitment = wnla.commit(l_, n_) as one more fixed-base sum (job_cnext): v g + <h', l_> + <g', n_>
+        sc v = zero, mp;
+        sc_pow_u5(mp, mun, (unsigned)q + 1);                  // mu'^(q+1)
+        sc_mul(t1, nq, nq); sc_mul(t1, t1, mp);
+        if (has_n) v = t1;
+        sc_mul(t1, cq, lq);
+        if (has_l) sc_add(v, v, t1);
+        sc_group_sum16(v);
+        pw_st_msc(w, t, 0, 0, v);
+        sc nsrc, l0src, l1src;
+        sc_group_read16(nsrc, nq, q >> k);                    // n_[q >> k]: lane q >> k < nn / 2 holds it
+        sc_group_read16(l0src, lq, q >> k);                   // l_[q >> k]
+        sc_group_read16(l1src, lq, (q + 16) >> k);            // l_[(q + 16) >> k] < nl / 2
+        sc_mul(t1, cg, nsrc);
+        pw_st_msc(w, t, 0, 1 + q, t1);
+        sc_mul(t1, ch0, l0src);
+        pw_st_msc(w, t, 0, 17 + q, t1);
+        sc_mul(t1, ch1, l1src);
+        pw_st_msc(w, t, 0, 17 + q + 16, t1);
+    } else {
+        // proof.l = [l0, l1], proof.n = [n0]   (wnla.rs:126-133): lanes 0 and 1 hold them
+        if (q == 0) { sc_to_be(pb + 832, lq); sc_to_be(pb + 896, nq); }
+        if (q == 1) sc_to_be(pb + 864, lq);
+    }
+    w.status[t] = status;
+}
+#endif
 
 // the MSM jobs of the pipeline, in launch order
 // The MSMs of the prover, over exactly the terms that are there.  Round 2 summed every slot of a contiguous range at full width; a
