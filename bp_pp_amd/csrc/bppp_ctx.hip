@@ -13,6 +13,13 @@ static void read_diagnostics(bppp_ctx* c) {
     c->no_small = std::getenv("BPPP_NO_SMALL_KERNELS") != nullptr;        // the 256-VGPR builds (two wavefronts per SIMD) at every batch size
     c->no_split = std::getenv("BPPP_NO_SPLIT") != nullptr;                // no half-stream lanes / per-table lanes for calls of <= one proof per SIMD
     if (const char* e = std::getenv("BPPP_FB_ONE_LANE")) c->fb_one_lane_mode = e[0] == '0' ? 0 : 1;
+    if (const char* e = std::getenv("BPPP_LANE_FORMS_MAX")) c->lane_forms_max = std::atol(e);
+    if (const char* e = std::getenv("BPPP_NEXT_OVERLAP")) c->next_overlap = std::atoi(e);
+    if (const char* e = std::getenv("BPPP_NEXT_G4_W2")) c->next_g4_w2 = std::atoi(e);
+    if (const char* e = std::getenv("BPPP_SCAL_PARTS_MAX")) c->scal_parts_max = std::atol(e);
+    if (const char* e = std::getenv("BPPP_LANE4_MAX")) c->lane4_max = std::atol(e);
+    if (const char* e = std::getenv("BPPP_NEXT_LANES")) c->next_lanes = std::atoi(e);
+    if (const char* e = std::getenv("BPPP_NEXT_MSM_MAX")) c->next_msm_max = std::atol(e);
     c->generic_u64_shape = std::getenv("BPPP_GENERIC_U64_SHAPE") != nullptr;     // reciprocal (16, 16) calls stay on the generic kernels
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // projective tables + complete additions
 }

@@ -405,7 +405,8 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     // ... and the next level's commitment as one more of those sums (prove_core.h: job_cnext), fused with the next round's X | R.  That form
     // wins while the variable-base one is a latency chain on an under-filled chip: up to 8 values per SIMD (2^11 values 8.4 -> 6.3 ms, 2^12
     // 8.6 -> 7.2, 2^13 9.2 -> 8.3; at 2^14 the extra 588 table additions per level cost what the chain did: 12.1 against 12.3 ms)
-    w.next_by_msm = (fb_wave || (!c->no_split && !c->no_lane_groups && n <= 8 * (size_t)c->n_simds)) ? 1 : 0;
+    const size_t next_msm_max = c->next_msm_max >= 0 ? (size_t)c->next_msm_max : 8 * (size_t)c->n_simds;
+    w.next_by_msm = (fb_wave || (!c->no_split && !c->no_lane_groups && n <= next_msm_max)) ? 1 : 0;
     const unsigned fb64_blocks = (unsigned)((n * 64 + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     // The prover's fixed-base sums.  Lanes per proof: a wavefront in a small call; otherwise 8, 4 or 1 -- the fewest that still give
     // every SIMD two wavefronts in the launch (fewer lanes = fewer idle lanes in the short runs and a shorter tree of complete additions
@@ -438,19 +439,33 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PSECRETX(4, job_rcom(), job_co(), job_cl(), job_cr());
     // a small call waits for one lane's chain: the stages' 16-term loops on sixteen lanes per value (prove_core.h: "lane forms")
-    const bool stage_lanes = fb_wave && !c->no_lane_groups;
+    const size_t lane_forms_max = c->lane_forms_max >= 0 ? (size_t)c->lane_forms_max : 4 * (size_t)c->n_simds;
+    const bool stage_lanes = !c->no_lane_groups && !c->no_split && !c->no_small && n <= lane_forms_max;
+    const bool fold_lanes = stage_lanes && w.next_by_msm;
     const unsigned g16_blocks = (unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
-    if (stage_lanes) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_g16<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w));
+    const bool g16_w2 = g16_blocks > (unsigned)c->n_simds;
+    // ... and on four lanes per value while that still leaves SIMDs idle
+    const bool stage_lanes4 = !stage_lanes && !c->no_lane_groups && !c->no_split && n <= (c->lane4_max >= 0 ? (size_t)c->lane4_max : 16 * (size_t)c->n_simds);
+    const unsigned g4_blocks = (unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    const bool g4_w2 = c->no_small || g4_blocks > (unsigned)c->n_simds;
+    if (stage_lanes && g16_w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_g16_w2<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w));
+    else if (stage_lanes) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_g16<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w));
+    else if (stage_lanes4 && g4_w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_g4<2><<<g4_blocks, BPPP_BLOCK, 0, s>>>(w));
+    else if (stage_lanes4) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_g4<1><<<g4_blocks, BPPP_BLOCK, 0, s>>>(w));
     else if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_d<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PSECRET(job_cs());
-    if (stage_lanes) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_g16<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (stage_lanes && g16_w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_g16_w2<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w));
+    else if (stage_lanes) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_g16<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w));
+    else if (stage_lanes4 && g4_w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_g4<2><<<g4_blocks, BPPP_BLOCK, 0, s>>>(w));
+    else if (stage_lanes4) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_g4<1><<<g4_blocks, BPPP_BLOCK, 0, s>>>(w));
     else if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PMSM(job_c0());
     // (the lane-per-generator form of the scalar kernel pays only while the chip is empty: at 2^13 ... 2^15 values it costs 1.2 / 2.3 /
     // 4.5 ms per batch against 0.8: profiles/r04_r_size_probe_wide_scalars.txt)
     const bool scal_wide = fb_wave;
+    const bool scal_parts = !scal_wide && !c->no_split && n <= (c->scal_parts_max >= 0 ? (size_t)c->scal_parts_max : 128 * (size_t)c->n_simds);
     bool pending_cnext = false;
     // Round k's next commitment C_k (prove_core.h: prove_round_next -- window tables of X and R and a two-point GLV Straus sum, 125
     // dependent doublings) is not needed before round k + 1 appends it to the transcript: it runs on the helper stream, under round
@@ -458,22 +473,30 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     // 2^14 the fixed-base sums already keep every SIMD busy and the overlap only adds contention (12.45 against 11.8 ms per batch;
     // 2^15: 18.9 against 19.65, profiles/r04_g_size_probe2.txt).  (With per-kernel timing on it stays on the main stream so that the
     // kernel times add up to the step.)
-    hipStream_t a = (c->timing || 2 * (size_t)blocks < (size_t)c->n_simds) ? s : c->aux_stream;
+    const bool overlap_next = c->next_overlap >= 0 ? c->next_overlap == 1 : 4 * (size_t)blocks >= (size_t)c->n_simds;
+    hipStream_t a = (c->timing || !overlap_next) ? s : c->aux_stream;
     bool next_in_flight = false;
     for (int k = 1; k <= 4; k++) {
         if (scal_wide) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_wide<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
+        else if (scal_parts) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_parts<<<dim3(blocks, 4), BPPP_BLOCK, 0, s>>>(w, k));
         else PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         if (pending_cnext) PMSMX(3, job_x(), job_r(k), job_cnext(), job_x());
         else PMSMX(2, job_x(), job_r(k), job_x(), job_x());
         if (next_in_flight) { HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); next_in_flight = false; }      // C_{k-1} is there
-        if (stage_lanes) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g16<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        if (fold_lanes && g16_w2) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g16_w2<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        else if (fold_lanes) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g16<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w, k));
         else if (w2) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         else PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         if (!w.next_by_msm && k < 4) {
             if (a != s) { HIP_TRY(hipEventRecord(c->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0)); }
-            if (!c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds)      // small batch: lane groups (see verify_device_part)
+            const bool next_g4 = !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds && c->next_lanes != 1;
+            if (c->next_lanes == 2)
+                rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next_g2_w2<<<(unsigned)((2 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, a>>>(w, k); });
+            else if (next_g4 && (c->next_g4_w2 || a != s))
+                rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next_g4_w2<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, a>>>(w, k); });
+            else if (next_g4)      // small batch: lane groups (see verify_device_part)
                 rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, a>>>(w, k); });
-            else if (w2)
+            else if (w2 || a != s)
                 rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next_w2<<<blocks, BPPP_BLOCK, 0, a>>>(w, k); });
             else
                 rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next<<<blocks, BPPP_BLOCK, 0, a>>>(w, k); });

@@ -117,6 +117,11 @@ struct bppp_ctx {
     bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
     bool generic_slow_rounds = false, no_lane_groups = false, no_small = false, no_split = false, generic_u64_shape = false;
+    int next_lanes = -1;   // diagnostic BPPP_NEXT_LANES: 1 = the one-lane next-commitment kernel at every size
+    int next_overlap = -1, next_g4_w2 = 0;   // diagnostics BPPP_NEXT_OVERLAP (1 always / 0 never), BPPP_NEXT_G4_W2
+    long scal_parts_max = -1;   // diagnostic BPPP_SCAL_PARTS_MAX: largest prove call whose round scalars go out as four workgroups per 64 values
+    long lane4_max = -1;   // diagnostic BPPP_LANE4_MAX: largest prove call on the four-lane stage kernels
+    long lane_forms_max = -1, next_msm_max = -1;   // diagnostics BPPP_LANE_FORMS_MAX / BPPP_NEXT_MSM_MAX: largest prove call on the 16-lane stage / fold kernels, on the fixed-base next commitment (-1 = by n_simds)
     int fb_one_lane_mode = -1;   // diagnostic BPPP_FB_ONE_LANE: 1 = one lane per proof in the u64 verifier's fixed-base kernels at every size, 0 = never, unset = by size   // diagnostics, read from the environment once at context creation
     // single-proof front end (bppp_coalesce.hip): created at the first *_one call; options "coalesce_max" / "coalesce_us" / "coalesce_lanes"
     struct bppp_fronts* fronts = nullptr;

@@ -63,6 +63,22 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars_wide(ProveWs
     else if (lane < 48) prove_round_scalars_g(w, t, k, lane - 32);
     else if (lane == 48) prove_round_scalars_v(w, t, k);
 }
+// batches that leave the chip under-filled: the same scalars from FOUR workgroups per 64 values (blockIdx.y: the two leading scalars, h
+// 0..15, h 16..31, g) -- the pieces are independent, every piece keeps the one-lane form's coalesced loads, and the chain one wavefront
+// walks drops from 200 / 156 / 134 / 123 multiplications (rounds 1..4) to 88 / 48 / 48 / 48
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_scalars_parts(ProveWs w, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= w.N) return;
+    const int part = (int)blockIdx.y;
+    if (part == 0) prove_round_scalars_v(w, t, k);
+    else if (part == 3) {
+#pragma nounroll
+        for (int i = 0; i < 16; i++) prove_round_scalars_g(w, t, k, i);
+    } else {
+#pragma nounroll
+        for (int i = 16 * (part - 1); i < 16 * part; i++) prove_round_scalars_h(w, t, k, i);
+    }
+}
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(ProveWs w, int k) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= w.N) return;
@@ -150,4 +166,60 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_next_w2(ProveWs w, int k) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) prove_round_next(w, t, k);
+}
+// ... and the sixteen-lane forms at two wavefronts per SIMD, for calls whose groups give every SIMD more than one wavefront
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_d_g16_w2(ProveWs w) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 4;
+    if (t >= w.N) return;
+    const int lane = (int)(g & 15);
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_stage_d(w, t, lane); });
+}
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_f_g16_w2(ProveWs w) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 4;
+    if (t >= w.N) return;
+    const int lane = (int)(g & 15);
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_stage_f(w, t, lane); });
+}
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_fold_g16_w2(ProveWs w, int k) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 4;
+    if (t >= w.N) return;
+    const int lane = (int)(g & 15);
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_round_fold_lanes(w, t, k, lane); });
+}
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_next_g4_w2(ProveWs w, int k) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 2;
+    if (t < w.N) prove_round_next(w, t, k, (int)(g & 3));
+}
+// batches of a few values per SIMD: FOUR lanes per value, a lane per run of four terms (prove_core.h: "lane forms", group = 4); MINW = 2
+// is the 256-register build for launches that give every SIMD more than one wavefront
+template <int MINW>
+__global__ __launch_bounds__(BPPP_BLOCK, MINW) void k_prove_stage_d_g4(ProveWs w) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 2;
+    if (t >= w.N) return;
+    const int lane = (int)(g & 3);
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_stage_d(w, t, lane, 4); });
+}
+template <int MINW>
+__global__ __launch_bounds__(BPPP_BLOCK, MINW) void k_prove_stage_f_g4(ProveWs w) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 2;
+    if (t >= w.N) return;
+    const int lane = (int)(g & 3);
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_stage_f(w, t, lane, 4); });
+}
+template __global__ void k_prove_stage_d_g4<1>(ProveWs w);
+template __global__ void k_prove_stage_d_g4<2>(ProveWs w);
+template __global__ void k_prove_stage_f_g4<1>(ProveWs w);
+template __global__ void k_prove_stage_f_g4<2>(ProveWs w);
+// ... and two lanes per value (two GLV streams each): half the repeated doublings of the four-lane form, twice its chain -- for the
+// batch sizes where the kernel runs on the helper stream under the next round's sums and the chain has that long to finish
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_next_g2_w2(ProveWs w, int k) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 1;
+    if (t < w.N) prove_round_next(w, t, k, (int)(g & 1), 2);
 }

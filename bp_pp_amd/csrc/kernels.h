@@ -127,6 +127,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_f(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_export_states(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_scalars_wide(bppp::ProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_scalars_parts(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_fold(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_next(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_next_g4(bppp::ProveWs w, int k);
@@ -135,6 +136,13 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_d_w2(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_f_w2(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_fold_w2(bppp::ProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_d_g16_w2(bppp::ProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_f_g16_w2(bppp::ProveWs w);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_fold_g16_w2(bppp::ProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_next_g4_w2(bppp::ProveWs w, int k);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_next_g2_w2(bppp::ProveWs w, int k);
+template <int MINW> __global__ __launch_bounds__(BPPP_BLOCK, MINW) void k_prove_stage_d_g4(bppp::ProveWs w);
+template <int MINW> __global__ __launch_bounds__(BPPP_BLOCK, MINW) void k_prove_stage_f_g4(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l64x(bppp::ProveWs w, bppp::MsmJobs jobs);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_x(bppp::ProveWs w, bppp::MsmJobs jobs);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l1x(bppp::ProveWs w, bppp::MsmJobs jobs);

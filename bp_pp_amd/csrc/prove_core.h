@@ -262,25 +262,25 @@ HD void sc_pow_u5(sc& r, const sc& a, unsigned e) {      // a^e for 1 <= e <= 31
     }
     r = acc;
 }
-HD void prove_group_sum16(sc& a) {
+HD void prove_group_sum16(sc& a, int group = 16) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    sc_group_sum16(a);
+    sc_group_sum16(a, group);
 #else
-    (void)a;
+    (void)a; (void)group;
 #endif
 }
-HD bool prove_group_all16(bool ok) {
+HD bool prove_group_all16(bool ok, int group = 16) {
 #if defined(__HIP_DEVICE_COMPILE__)
     int r = ok ? 1 : 0;
 #pragma unroll
-    for (int m = 1; m < 16; m <<= 1) r &= __shfl_xor(r, m, 64);
+    for (int m = 1; m < group; m <<= 1) r &= __shfl_xor(r, m, 64);
     return r != 0;
 #else
     return ok;
 #endif
 }
 // ---------------------------------------------------------------- stage D: transcript to delta; f_, rs; scalars of c_s
-HD void prove_stage_d(const ProveWs& w, size_t t, int lane = -1) {
+HD void prove_stage_d(const ProveWs& w, size_t t, int lane = -1, int group = 16) {
     const size_t N = w.N;
     const uint64_t x = w.x[t];
     int32_t status = w.status[t];
@@ -352,11 +352,11 @@ HD void prove_stage_d(const ProveWs& w, size_t t, int lane = -1) {
     sc_set_u32(f0, 0); sc_set_u32(f1, 0); sc_set_u32(f2, 0); sc_set_u32(f3, 0); sc_set_u32(f4, 0); sc_set_u32(f5, 0); sc_set_u32(f6, 0);
     sc mip = mu_inv, mp = mu;
     lp = lambda;
-    const int j_begin = lane >= 0 ? lane : 0, j_end = lane >= 0 ? lane + 1 : 16;
-    if (lane >= 0) {            // this lane's term only: its powers directly
-        sc_pow_u5(mip, mu_inv, (unsigned)lane + 1);
-        sc_pow_u5(mp, mu, (unsigned)lane + 1);
-        sc_pow_u5(lp, lambda, (unsigned)lane + 1);
+    const int per = 16 / group, j_begin = lane >= 0 ? lane * per : 0, j_end = lane >= 0 ? j_begin + per : 16;      // a lane's run of terms
+    if (lane >= 0) {            // this lane's terms only: the powers of its first one directly
+        sc_pow_u5(mip, mu_inv, (unsigned)j_begin + 1);
+        sc_pow_u5(mp, mu, (unsigned)j_begin + 1);
+        sc_pow_u5(lp, lambda, (unsigned)j_begin + 1);
     }
 #pragma nounroll
     for (int j = j_begin; j < j_end; j++) {
@@ -403,9 +403,9 @@ HD void prove_stage_d(const ProveWs& w, size_t t, int lane = -1) {
         sc_mul(mp, mp, mu);
     }
     if (lane >= 0) {            // the group's seven sums, and whether every lane's draws decoded
-        prove_group_sum16(f0); prove_group_sum16(f1); prove_group_sum16(f2); prove_group_sum16(f3);
-        prove_group_sum16(f4); prove_group_sum16(f5); prove_group_sum16(f6);
-        rok = prove_group_all16(rok);
+        prove_group_sum16(f0, group); prove_group_sum16(f1, group); prove_group_sum16(f2, group); prove_group_sum16(f3, group);
+        prove_group_sum16(f4, group); prove_group_sum16(f5, group); prove_group_sum16(f6, group);
+        rok = prove_group_all16(rok, group);
     }
     sc ls16;
     rok &= pw_rnd(ls16, w, t, 19 + 16);
@@ -432,7 +432,7 @@ HD void prove_stage_d(const ProveWs& w, size_t t, int lane = -1) {
     w.status[t] = status;
 }
 // ---------------------------------------------------------------- stage F: c_s -> tau; l, n, c, v; scalars of C0; WNLA state
-HD void prove_stage_f(const ProveWs& w, size_t t, int lane = -1) {
+HD void prove_stage_f(const ProveWs& w, size_t t, int lane = -1, int group = 16) {
     const size_t N = w.N;
     const uint64_t x = w.x[t];
     int32_t status = w.status[t];
@@ -483,13 +483,13 @@ HD void prove_stage_f(const ProveWs& w, size_t t, int lane = -1) {
     sc mip = mu_inv;
     lp = lambda;
     mp = mu;
-    const int j_begin = lane >= 0 ? lane : 0, j_end = lane >= 0 ? lane + 1 : 16;
+    const int per = 16 / group, j_begin = lane >= 0 ? lane * per : 0, j_end = lane >= 0 ? j_begin + per : 16;      // a lane's run of terms
     sc ls16_in;                                                  // c_s's scalar of h[25] = ls[16]: read before the C0 scalars overwrite set 0
     pw_ld_msc(ls16_in, w, t, 0, 26 + 16);
     if (lane >= 0) {
-        sc_pow_u5(mip, mu_inv, (unsigned)lane + 1);
-        sc_pow_u5(mp, mu, (unsigned)lane + 1);
-        sc_pow_u5(lp, lambda, (unsigned)lane + 1);
+        sc_pow_u5(mip, mu_inv, (unsigned)j_begin + 1);
+        sc_pow_u5(mp, mu, (unsigned)j_begin + 1);
+        sc_pow_u5(lp, lambda, (unsigned)j_begin + 1);
     }
 #pragma nounroll
     for (int j = j_begin; j < j_end; j++) {
@@ -530,7 +530,7 @@ HD void prove_stage_f(const ProveWs& w, size_t t, int lane = -1) {
         sc_mul(lp, lp, lambda);
         sc_mul(mp, mp, mu);
     }
-    if (lane >= 0) prove_group_sum16(ps);
+    if (lane >= 0) prove_group_sum16(ps, group);
     {   // l[25] = tau^-1 ls[16]; l[26..32) = 0; c[25..32) = 0     (circuit.rs:526-529)
         sc l25;
         sc_mul(l25, tau_inv, ls16_in);
@@ -650,7 +650,7 @@ HD void prove_round_scalars(const ProveWs& w, size_t t, int k) {
 // (small calls, next_by_msm: the next commitment is one more fixed-base sum whose scalars part one prepares; there is no part two.)
 // The point slots behind the running products: 0 = X, 1 = R (the table builder's inputs), 2 = C_{k-1}.
 HD u32* prove_fold_rpts(const ProveWs& w) { return (u32*)((uint8_t*)w.straus + (size_t)32 * sizeof(apt_packed) * w.N) + (size_t)28 * 10 * w.N; }
-HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane = -1);
+HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane = -1, int group = 4);
 // the part every form shares: C_{k-1}, X, R to affine (one inversion), X and R into the proof, the round's transcript, y_k
 HD void prove_round_fold_head(const ProveWs& w, size_t t, int k, apt A[3], sc& y, int32_t& status) {
     const size_t N = w.N;
@@ -777,9 +777,9 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
     w.status[t] = status;
 }
 // next commitment = com + y X + (y^2 - 1) R             (= wnla.commit(l_, n_), wnla.rs:186), rounds 1 .. 3 of the chain form
-// group_lane >= 0: one of four consecutive lanes that share the sum (straus_affine_g4; identical table build and stores) -- small
+// group_lane >= 0: one of `group` (four or two) consecutive lanes that share the sum (straus_affine_g4; identical table build and stores) -- small
 // batches; -1: one lane per proof
-HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane) {
+HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane, int group) {
     const size_t N = w.N;
     (void)k;
     sc y, y2m1, one;
@@ -807,13 +807,14 @@ HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane) {
     glv_words_set<2>(g, 1, sp);
     pt acc;
 #if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
-    if (group_lane >= 0) straus_affine_g4<2>(acc, tab, pslot, g, group_lane);
+    if (group_lane >= 0 && group == 2) straus_affine_g4<2, 2>(acc, tab, pslot, g, group_lane);      // two GLV streams per lane
+    else if (group_lane >= 0) straus_affine_g4<2>(acc, tab, pslot, g, group_lane);
     else
 #endif
         straus_affine<2>(acc, tab, pslot, g);
     pt_madd(acc, acc, C, apt_is_identity(C));
     pw_st_pt(w, t, PB_C, acc);
-    (void)group_lane;
+    (void)group_lane; (void)group;
 }
 #if defined(__HIPCC__)
 // Small calls (next_by_msm): part one of a round on SIXTEEN lanes per value.  Every lane runs the head (identical values and stores);

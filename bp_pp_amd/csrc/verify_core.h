@@ -2059,9 +2059,9 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
 // ch[b] and cg[b] -- four conditional multiplications each, in registers -- and its three output scalars; the two folded c values are
 // a sum over the group (shuffles).  The one-lane form above walks 118 multiplications whose operands travel through the workspace
 // (a store-to-load round trip per step): 145 us for a lone proof, a seventh of it here.  Every lane of a group must be active.
-__device__ __forceinline__ void sc_group_sum16(sc& a) {
+__device__ __forceinline__ void sc_group_sum16(sc& a, int group = 16) {      // group: 16 or a smaller power of two
 #pragma unroll
-    for (int m = 1; m < 16; m <<= 1) {
+    for (int m = 1; m < group; m <<= 1) {
         sc o;
 #pragma unroll
         for (int i = 0; i < 8; i++) o.v[i] = __shfl_xor(a.v[i], m, 64);

@@ -45,7 +45,11 @@ def test_golden_proofs_byte_exact(proto, gold):
     assert proto.verify(bytes.fromhex(c["commitment"]), bytes.fromhex(c["proof"]), label)
 
 
-@pytest.mark.parametrize("n", [1, 65, 1024, 1500, 1 << 14])   # 1, 65, 1024: small-call path (a wavefront per sum, next commitments as sums); 1500, 2^14: lane groups
+# the prover's dispatch regimes (bppp_u64.hip): 1, 65, 1024 the small-call path (a wavefront per sum, sixteen lanes per value in the stage
+# and fold kernels, next commitments as sums); 1500 the same lane forms in their 256-register builds; 5000 four lanes per value in the
+# stage kernels, round scalars from four workgroups, next commitments still sums; 9000 next commitments by the variable-base path on
+# four lanes, in line; 2^14 the same on the helper stream under the next round's sums; 20000 one lane per value, helper stream
+@pytest.mark.parametrize("n", [1, 65, 1024, 1500, 5000, 9000, 1 << 14, 20000])
 def test_batch_prove_vs_oracle(proto, oracle_c, n):
     """n = 2^14 is BASELINE config 4.  Every proof equals the oracle's trapdoor prover byte for byte (itself equal to the
     honest reference-shaped prover, tests/test_oracle_c.py); a sample is also proved by the honest prover directly."""
