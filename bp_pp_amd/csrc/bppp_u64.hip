@@ -402,10 +402,11 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     // a call of at most one value per SIMD: a wavefront per sum (the chip is empty; 6 additions per lane and a 6-step tree instead of 44 and 3)
     const bool fb_wave = !c->no_small && !c->no_split && n <= (size_t)c->n_simds;
-    // ... and the next level's commitment as one more of those sums (prove_core.h: job_cnext), fused with the next round's X | R.  That form
-    // wins while the variable-base one is a latency chain on an under-filled chip: up to 8 values per SIMD (2^11 values 8.4 -> 6.3 ms, 2^12
-    // 8.6 -> 7.2, 2^13 9.2 -> 8.3; at 2^14 the extra 588 table additions per level cost what the chain did: 12.1 against 12.3 ms)
-    const size_t next_msm_max = c->next_msm_max >= 0 ? (size_t)c->next_msm_max : 8 * (size_t)c->n_simds;
+    // ... and the next level's commitment from fixed-base sums too: its even folded slots as one more sum (prove_core.h: job_e, 25 terms)
+    // fused with the next round's X | R, its odd ones being that round's R.  That form wins while the variable-base one is a latency chain
+    // on an under-filled chip: up to 32 values per SIMD (2^14 values: 300 more table additions per level against 0.8 ms of chain, of
+    // which the helper stream hides a quarter: 10.5 -> 9.8 ms; 2^15: 17.65 -> 17.1; 2^16: 31.0 against 32.1, so not there).
+    const size_t next_msm_max = c->next_msm_max >= 0 ? (size_t)c->next_msm_max : 32 * (size_t)c->n_simds;
     w.next_by_msm = (fb_wave || (!c->no_split && !c->no_lane_groups && n <= next_msm_max)) ? 1 : 0;
     const unsigned fb64_blocks = (unsigned)((n * 64 + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     // The prover's fixed-base sums.  Lanes per proof: a wavefront in a small call; otherwise 8, 4 or 1 -- the fewest that still give
@@ -448,6 +449,7 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     const bool stage_lanes4 = !stage_lanes && !c->no_lane_groups && !c->no_split && n <= (c->lane4_max >= 0 ? (size_t)c->lane4_max : 16 * (size_t)c->n_simds);
     const unsigned g4_blocks = (unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     const bool g4_w2 = c->no_small || g4_blocks > (unsigned)c->n_simds;
+    const bool fold_lanes4 = stage_lanes4 && w.next_by_msm;
     if (stage_lanes && g16_w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_g16_w2<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w));
     else if (stage_lanes) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_g16<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w));
     else if (stage_lanes4 && g4_w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_g4<2><<<g4_blocks, BPPP_BLOCK, 0, s>>>(w));
@@ -461,7 +463,6 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     else if (stage_lanes4) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_g4<1><<<g4_blocks, BPPP_BLOCK, 0, s>>>(w));
     else if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-    PMSM(job_c0());
     // (the lane-per-generator form of the scalar kernel pays only while the chip is empty: at 2^13 ... 2^15 values it costs 1.2 / 2.3 /
     // 4.5 ms per batch against 0.8: profiles/r04_r_size_probe_wide_scalars.txt)
     const bool scal_wide = fb_wave;
@@ -480,11 +481,13 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
         if (scal_wide) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_wide<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
         else if (scal_parts) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_parts<<<dim3(blocks, 4), BPPP_BLOCK, 0, s>>>(w, k));
         else PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
-        if (pending_cnext) PMSMX(3, job_x(), job_r(k), job_cnext(), job_x());
+        if (pending_cnext || k == 1) PMSMX(3, job_x(), job_r(k), job_e(k), job_x());       // C_{k-1} = E + R (prove_core.h: job_e); C_0 always
         else PMSMX(2, job_x(), job_r(k), job_x(), job_x());
         if (next_in_flight) { HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); next_in_flight = false; }      // C_{k-1} is there
         if (fold_lanes && g16_w2) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g16_w2<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w, k));
         else if (fold_lanes) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g16<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        else if (fold_lanes4 && g4_w2) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g4<2><<<g4_blocks, BPPP_BLOCK, 0, s>>>(w, k));
+        else if (fold_lanes4) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_g4<1><<<g4_blocks, BPPP_BLOCK, 0, s>>>(w, k));
         else if (w2) PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         else PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         if (!w.next_by_msm && k < 4) {

@@ -212,6 +212,16 @@ __global__ __launch_bounds__(BPPP_BLOCK, MINW) void k_prove_stage_f_g4(ProveWs w
     const int lane = (int)(g & 3);
     for_each_position_group(prove_position_key(w, t), [&]() { prove_stage_f(w, t, lane, 4); });
 }
+template <int MINW>
+__global__ __launch_bounds__(BPPP_BLOCK, MINW) void k_prove_round_fold_g4(ProveWs w, int k) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 2;
+    if (t >= w.N) return;
+    const int lane = (int)(g & 3);
+    for_each_position_group(prove_position_key(w, t), [&]() { prove_round_fold_lanes4(w, t, k, lane); });
+}
+template __global__ void k_prove_round_fold_g4<1>(ProveWs w, int k);
+template __global__ void k_prove_round_fold_g4<2>(ProveWs w, int k);
 template __global__ void k_prove_stage_d_g4<1>(ProveWs w);
 template __global__ void k_prove_stage_d_g4<2>(ProveWs w);
 template __global__ void k_prove_stage_f_g4<1>(ProveWs w);

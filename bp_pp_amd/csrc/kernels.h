@@ -143,6 +143,7 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_next_g2_w2(bppp::ProveWs w, int k);
 template <int MINW> __global__ __launch_bounds__(BPPP_BLOCK, MINW) void k_prove_stage_d_g4(bppp::ProveWs w);
 template <int MINW> __global__ __launch_bounds__(BPPP_BLOCK, MINW) void k_prove_stage_f_g4(bppp::ProveWs w);
+template <int MINW> __global__ __launch_bounds__(BPPP_BLOCK, MINW) void k_prove_round_fold_g4(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l64x(bppp::ProveWs w, bppp::MsmJobs jobs);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_x(bppp::ProveWs w, bppp::MsmJobs jobs);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_prove_msm_l1x(bppp::ProveWs w, bppp::MsmJobs jobs);

@@ -55,7 +55,7 @@ struct ProveWs {
     const uint8_t* states;
     size_t n_states;
     uint8_t* states_out;
-    int next_by_msm;        // 1: prove_round_fold leaves the next commitment's scalars in set 0 for job_cnext (small calls) instead of summing it itself
+    int next_by_msm;        // 1: prove_round_fold leaves the next commitment's scalars in set 0 for job_e (calls that leave SIMDs idle) instead of handing it to prove_round_next
     // "ct_prover": the sums over the witness and its blindings (V, r_com, c_o, c_l, c_r, c_s) read every entry of every window of this
     // 4-bit table and select by mask (verify_core.h: fb_lookup_add_ct); the WNLA stage's sums, whose vectors the argument reveals by
     // design (the circuit layer blinds them: circuit.rs:371-372), keep the fast gathers
@@ -604,6 +604,12 @@ HD void prove_round_scalars_v(const ProveWs& w, size_t t, int k) {
     }
     pw_st_msc(w, t, 1, 0, vx);
     pw_st_msc(w, t, 2, 0, vr);
+    if (w.next_by_msm || k == 1) {      // job_e: stage F / the previous fold left v of C_{k-1} in set 0; its odd-slot part is v_r, which R carries
+        sc v;
+        pw_ld_msc(v, w, t, 0, 0);
+        sc_sub(v, v, vr);
+        pw_st_msc(w, t, 0, 0, v);
+    }
 }
 // original h_i sits in folded slot j = i >> (k-1) with coefficient ch[i]:  X gets ch[i] l[j^1], R gets (j odd) ch[i] l[j]
 HD void prove_round_scalars_h(const ProveWs& w, size_t t, int k, int i) {
@@ -659,6 +665,7 @@ HD void prove_round_fold_head(const ProveWs& w, size_t t, int k, apt A[3], sc& y
     pw_ld_pt(P[0], w, t, PB_C);
     pw_ld_pt(P[1], w, t, PB_X);
     pw_ld_pt(P[2], w, t, PB_R);
+    if (w.next_by_msm || k == 1) pt_add(P[0], P[0], P[2]);     // C_{k-1} = E + R (job_e)
     batch_to_affine<3>(A, P);
     uint8_t* pb = w.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
     apt_to_xy64(pb + 64 * (8 + (4 - k)), A[1]);     // proof.x is pushed innermost-first (wnla.rs:188): x[4-k] = X of round k
@@ -723,9 +730,10 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
         pw_st_sc(w, t, SV_RHOINV, t1);
         if (w.next_by_msm) {
             // next commitment = wnla.commit(l_, n_) as the reference computes it (wnla.rs:186, :66-72): v g + <h', l_> + <g', n_> over the
-            // ORIGINAL generators (h'_j = sum ch[i] h_i, g'_j = sum cg[i] g_i over i >> k == j), v = <c_, l_> + |n_|^2_{mu'} -- one more
-            // fixed-base sum (job_cnext).  For a call of a few proofs that is a wavefront's 10 table additions and a 6-step tree, against
-            // the 125 doublings of the variable-base form below, which is the cheaper one once the chip is full.
+            // ORIGINAL generators (h'_j = sum ch[i] h_i, g'_j = sum cg[i] g_i over i >> k == j), v = <c_, l_> + |n_|^2_{mu'} -- as a
+            // fixed-base sum.  Only its EVEN folded slots j are summed for it (job_e, riding with the next round's X | R): the odd ones are
+            // that round's R.  25 table-driven terms and no dependent chain, against the 125 doublings of the variable-base form below,
+            // which is the cheaper one once the chip is full.
             sc v, mun, mp, a, b;
             pw_ld_sc(mun, w, t, SV_MU);         // mu' (already advanced above)
             mp = mun;
@@ -745,6 +753,7 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
             pw_st_msc(w, t, 0, 0, v);
 #pragma nounroll
             for (int i = 0; i < 16; i++) {
+                if ((i >> k) & 1) continue;         // R's term
                 pw_ld_sc(a, w, t, SV_CG0 + i);
                 pw_ld_sc(b, w, t, SV_N0 + (i >> k));
                 sc_mul(t1, a, b);
@@ -752,6 +761,7 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
             }
 #pragma nounroll
             for (int i = 0; i < 32; i++) {
+                if ((i >> k) & 1) continue;
                 pw_ld_sc(a, w, t, SV_CH0 + i);
                 pw_ld_sc(b, w, t, SV_L0 + (i >> k));
                 sc_mul(t1, a, b);
@@ -868,7 +878,7 @@ __device__ __forceinline__ void prove_round_fold_lanes(const ProveWs& w, size_t 
         pw_st_sc(w, t, SV_MU, mun);
         sc_mul(t1, rho_inv, rho_inv);
         pw_st_sc(w, t, SV_RHOINV, t1);
-        // next commitment = wnla.commit(l_, n_) as one more fixed-base sum (job_cnext): v g + <h', l_> + <g', n_>
+        // next commitment = wnla.commit(l_, n_) as one more fixed-base sum (job_e takes the even folded slots): v g + <h', l_> + <g', n_>
         sc v = zero, mp;
         sc_pow_u5(mp, mun, (unsigned)q + 1);                  // mu'^(q+1)
         sc_mul(t1, nq, nq); sc_mul(t1, t1, mp);
@@ -894,6 +904,93 @@ __device__ __forceinline__ void prove_round_fold_lanes(const ProveWs& w, size_t 
     }
     w.status[t] = status;
 }
+// The same on FOUR lanes per value, for batches of a few values per SIMD (next_by_msm): lane q owns the folded slots j = q, q + 4, ... of
+// l | c and of n, and everything that hangs off a slot -- the 2^k generator coefficients of its block (ch / cg pick up this round's
+// factor), their products with the folded entry for the next commitment's even slots (job_e), the slot's term of v -- so nothing one
+// lane computes is read by another except through the group sum of v.  In-place folds: pass `it` reads slots 8 it .. 8 it + 7 and
+// writes 4 it .. 4 it + 3, every lane's loads of a pass are issued before any of its stores, and a later pass reads beyond what
+// earlier ones wrote.  One lane's chain: the head plus ~40 multiplications instead of ~150.
+__device__ __forceinline__ void prove_round_fold_lanes4(const ProveWs& w, size_t t, int k, int q) {
+    const int sh = k - 1, nls = 16 >> sh, nns = 8 >> sh;       // folded lengths
+    int32_t status = w.status[t];
+    apt A[3];
+    sc y;
+    prove_round_fold_head(w, t, k, A, y, status);
+    uint8_t* pb = w.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
+    sc rho, rho_inv, mu, mun, t1, v;
+    pw_ld_sc(rho, w, t, SV_RHO); pw_ld_sc(rho_inv, w, t, SV_RHOINV); pw_ld_sc(mu, w, t, SV_MU);
+    sc_mul(mun, mu, mu);                                          // mu' of the next level
+    sc_set_u32(v, 0);
+    const int blk = 1 << k;                                       // original generators per folded slot
+#pragma nounroll
+    for (int it = 0; it < (nls + 3) / 4; it++) {
+        const int j = 4 * it + q;
+        const bool has = j < nls;
+        const int jj = has ? j : 0;
+        sc a0, a1, lj, cj;
+        pw_ld_sc(a0, w, t, SV_L0 + 2 * jj); pw_ld_sc(a1, w, t, SV_L0 + 2 * jj + 1);
+        sc_mul(t1, a1, y); sc_add(lj, a0, t1);
+        pw_ld_sc(a0, w, t, SV_C0 + 2 * jj); pw_ld_sc(a1, w, t, SV_C0 + 2 * jj + 1);
+        sc_mul(t1, a1, y); sc_add(cj, a0, t1);
+        if (has) { pw_st_sc(w, t, SV_L0 + j, lj); pw_st_sc(w, t, SV_C0 + j, cj); }
+        if (k < 4) {
+            sc_mul(t1, cj, lj);
+            if (has) sc_add(v, v, t1);
+#pragma nounroll
+            for (int r = 0; r < blk; r++) {
+                const int i = jj * blk + r;
+                sc ch;
+                pw_ld_sc(ch, w, t, SV_CH0 + i);
+                if (r >> sh) { sc_mul(ch, ch, y); if (has) pw_st_sc(w, t, SV_CH0 + i, ch); }
+                sc_mul(t1, ch, lj);
+                if (has && !(j & 1)) pw_st_msc(w, t, 0, 17 + i, t1);
+            }
+        } else if (has) {
+            sc_to_be(pb + 832 + 32 * j, lj);                      // proof.l = [l0, l1]   (wnla.rs:126-133)
+        }
+    }
+    sc mp, m4;
+    sc_pow_u5(mp, mun, (unsigned)q + 1);                          // mu'^(j + 1) for this lane's first slot; the next one is mu'^4 further
+    sc_mul(m4, mun, mun); sc_mul(m4, m4, m4);
+#pragma nounroll
+    for (int it = 0; it < (nns + 3) / 4; it++) {
+        const int j = 4 * it + q;
+        const bool has = j < nns;
+        const int jj = has ? j : 0;
+        sc a0, a1, nj;
+        pw_ld_sc(a0, w, t, SV_N0 + 2 * jj); pw_ld_sc(a1, w, t, SV_N0 + 2 * jj + 1);
+        sc_mul(a0, a0, rho_inv);
+        sc_mul(t1, a1, y); sc_add(nj, a0, t1);
+        if (has) pw_st_sc(w, t, SV_N0 + j, nj);
+        if (k < 4) {
+            sc_mul(t1, nj, nj); sc_mul(t1, t1, mp);
+            if (has) sc_add(v, v, t1);
+            sc_mul(mp, mp, m4);
+#pragma nounroll
+            for (int r = 0; r < blk; r++) {
+                const int i = jj * blk + r;
+                sc cg;
+                pw_ld_sc(cg, w, t, SV_CG0 + i);
+                sc_mul(cg, cg, (r >> sh) ? y : rho);
+                if (has) pw_st_sc(w, t, SV_CG0 + i, cg);
+                sc_mul(t1, cg, nj);
+                if (has && !(j & 1)) pw_st_msc(w, t, 0, 1 + i, t1);
+            }
+        } else if (has) {
+            sc_to_be(pb + 896, nj);                               // proof.n = [n0]
+        }
+    }
+    if (k < 4) {
+        // rho <- mu, mu <- mu^2, rho^-1 <- (rho^-1)^2           (wnla.rs:180-181)
+        pw_st_sc(w, t, SV_RHO, mu);
+        pw_st_sc(w, t, SV_MU, mun);
+        sc_mul(t1, rho_inv, rho_inv);
+        pw_st_sc(w, t, SV_RHOINV, t1);
+        prove_group_sum16(v, 4);
+        pw_st_msc(w, t, 0, 0, v);
+    }
+    w.status[t] = status;
+}
 #endif
 
 // the MSM jobs of the pipeline, in launch order
@@ -908,11 +1005,15 @@ HD MsmJob job_co() { BPPP_JOB({1, PB_CO, 2, {17, 22}, {4, 3}, {0, 0}, NOODD}); }
 HD MsmJob job_cl() { BPPP_JOB({2, PB_CL, 4, {1, 17, 21, 26}, {16, 3, 3, 16}, {4, 0, 0, 5}, NOODD}); }            // digits | rl: h[3], h[7], h[8] zero | multiplicities
 HD MsmJob job_cr() { BPPP_JOB({3, PB_CR, 3, {1, 17, 20}, {16, 2, 3}, {0, 0, 0}, NOODD}); }                        // r | rr: h[2], h[6..8] zero
 HD MsmJob job_cs() { BPPP_JOB({0, PB_CS, 1, {1}, {42}, {0}, NOODD}); }
-HD MsmJob job_c0() { BPPP_JOB({0, PB_C, 1, {0}, {43}, {0}, NOODD}); }
-HD MsmJob job_cnext() { BPPP_JOB({0, PB_C, 1, {0}, {49}, {0}, NOODD}); }                                           // small calls: the next level's commitment
 HD MsmJob job_x() { BPPP_JOB({1, PB_X, 1, {0}, {49}, {0}, NOODD}); }
 // R of round k: v_r g + the odd halves (blocks of 2^(k-1) original generators) of g_vec and h_vec
 HD MsmJob job_r(int k) { BPPP_JOB({2, PB_R, 3, {0, 1, 17}, {1, 8, 16}, {0, 0, 0}, {-1, k - 1, k - 1}}); }
+// E of round k: the EVEN halves of the commitment C_{k-1} = wnla.commit(l, n) the round starts from, over the original generators with
+// the coefficients stage F (k = 1) or the previous fold (k >= 2, next_by_msm) left in set 0.  Its odd halves ARE R of round k, term by
+// term (R takes the odd folded slots of l and n with the same generator coefficients, wnla.rs:140-150), so C_{k-1} = E + R once slot 0
+// holds v - v_r (prove_round_scalars_v) -- 22 or 25 terms here instead of the 43 or 49 of the whole commitment, no launch of its own
+// (it rides with X | R), and one point addition in the fold's head.  (Round 1: l[25..32) is zero, so 13 even slots of h.)
+HD MsmJob job_e(int k) { BPPP_JOB({0, PB_C, 3, {0, 1, 17}, {1, 8, k == 1 ? 13 : 16}, {0, 0, 0}, {-1, (k - 1) | BPPP_FB_EVEN, (k - 1) | BPPP_FB_EVEN}}); }
 #undef NOODD
 #undef BPPP_JOB
 

@@ -259,8 +259,8 @@ HD int fb_windows_for(int bits, int W) {
 // index (within its run) of the a-th PRESENT term
 HD int fb_term_index(int a, int oddsh) {
     if (oddsh < 0) return a;
-    const int B = 1 << oddsh;
-    return (((a >> oddsh) << 1) + 1) * B + (a & (B - 1));
+    const int sh = oddsh & 15, odd = ((oddsh >> 4) & 1) ^ 1, B = 1 << sh;      // bit 4 (BPPP_FB_EVEN): the EVEN blocks instead
+    return (((a >> sh) << 1) + odd) * B + (a & (B - 1));
 }
 // digit of window w: returns the table index (|d| - 1), whether to skip (d == 0) and whether to negate
 HD void fb_digit(const u32 k[8], int W, int w, size_t& idx, bool& skip, bool& neg) {
@@ -459,7 +459,9 @@ HD bool fb_lane_finish_fast(pt& part, const ptz& acc, bool empty) {
 //              value reaches are looked up (fb_windows_for) -- the others hold the zero digit by construction;
 //   oddsh >= 0: only the ODD blocks of 2^oddsh consecutive terms are present (terms (2 b + 1) 2^oddsh + r, r < 2^oddsh): the WNLA
 //              prover's R is a sum over the odd halves of the folded vectors, the even ones have scalar zero (wnla.rs:140-150);
-//              `count` then counts the terms that ARE present.
+//              `count` then counts the terms that ARE present.  oddsh | BPPP_FB_EVEN: the EVEN blocks instead (the u64 prover's next
+//              commitment = those + R of the next round: prove_core.h, job_e).
+#define BPPP_FB_EVEN 16
 #define BPPP_FB_MAX_RUNS 5
 struct FbRanges {
     int n;

@@ -520,12 +520,11 @@ static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label
     for (size_t t = 0; t < n; t++) prove_stage_d(w, t);
     secret(job_cs());
     for (size_t t = 0; t < n; t++) prove_stage_f(w, t);
-    msm(job_c0());
     w.next_by_msm = g_prove_next_by_msm;
     for (int k = 1; k <= 4; k++) {
         for (size_t t = 0; t < n; t++) prove_round_scalars(w, t, k);
         msm(job_x()); msm(job_r(k));
-        if (w.next_by_msm && k > 1) msm(job_cnext());       // the level's commitment, scalars left by the previous fold (the library fuses the three launches)
+        if (w.next_by_msm || k == 1) msm(job_e(k));          // the even halves of the level's commitment, scalars left by the previous fold (the library fuses the three launches)
         for (size_t t = 0; t < n; t++) prove_round_fold(w, t, k);
         if (k < 4 && !w.next_by_msm)                            // part two: the next commitment (the library runs it under the next round's sums)
             for (size_t t = 0; t < n; t++) prove_round_next(w, t, k);
