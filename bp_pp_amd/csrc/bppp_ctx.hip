@@ -15,10 +15,8 @@ static void read_diagnostics(bppp_ctx* c) {
     if (const char* e = std::getenv("BPPP_FB_ONE_LANE")) c->fb_one_lane_mode = e[0] == '0' ? 0 : 1;
     if (const char* e = std::getenv("BPPP_LANE_FORMS_MAX")) c->lane_forms_max = std::atol(e);
     if (const char* e = std::getenv("BPPP_NEXT_OVERLAP")) c->next_overlap = std::atoi(e);
-    if (const char* e = std::getenv("BPPP_NEXT_G4_W2")) c->next_g4_w2 = std::atoi(e);
     if (const char* e = std::getenv("BPPP_SCAL_PARTS_MAX")) c->scal_parts_max = std::atol(e);
     if (const char* e = std::getenv("BPPP_LANE4_MAX")) c->lane4_max = std::atol(e);
-    if (const char* e = std::getenv("BPPP_NEXT_LANES")) c->next_lanes = std::atoi(e);
     if (const char* e = std::getenv("BPPP_NEXT_MSM_MAX")) c->next_msm_max = std::atol(e);
     c->generic_u64_shape = std::getenv("BPPP_GENERIC_U64_SHAPE") != nullptr;     // reciprocal (16, 16) calls stay on the generic kernels
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // projective tables + complete additions

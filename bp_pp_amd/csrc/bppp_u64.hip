@@ -468,17 +468,18 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     const bool scal_wide = fb_wave;
     const bool scal_parts = !scal_wide && !c->no_split && n <= (c->scal_parts_max >= 0 ? (size_t)c->scal_parts_max : 128 * (size_t)c->n_simds);
     bool pending_cnext = false;
-    // Round k's next commitment C_k (prove_core.h: prove_round_next -- window tables of X and R and a two-point GLV Straus sum, 125
-    // dependent doublings) is not needed before round k + 1 appends it to the transcript: it runs on the helper stream, under round
-    // k + 1's scalar kernel and X | R sums, and the main stream picks it up just before that round's fold -- from 2^15 values on: at
-    // 2^14 the fixed-base sums already keep every SIMD busy and the overlap only adds contention (12.45 against 11.8 ms per batch;
-    // 2^15: 18.9 against 19.65, profiles/r04_g_size_probe2.txt).  (With per-kernel timing on it stays on the main stream so that the
-    // kernel times add up to the step.)
+    // Beyond the sizes of next_by_msm: round k's next commitment C_k (prove_core.h: prove_round_next -- window tables of X and R and a
+    // two-point GLV Straus sum, 125 dependent doublings) is not needed before round k + 1 appends it to the transcript: it runs on the
+    // helper stream, under round k + 1's scalar kernel and X | R sums, and the main stream picks it up just before that round's fold.
+    // On the helper stream it runs in its 256-register build: the uncapped one leaves no room on its SIMDs for a wavefront of the sums
+    // it is meant to run under (profiles/r04_zd_prove_next_overlap_probe.txt).  (With per-kernel timing on it stays on the main stream
+    // so that the kernel times add up to the step.)
     const bool overlap_next = c->next_overlap >= 0 ? c->next_overlap == 1 : 4 * (size_t)blocks >= (size_t)c->n_simds;
     hipStream_t a = (c->timing || !overlap_next) ? s : c->aux_stream;
     bool next_in_flight = false;
     for (int k = 1; k <= 4; k++) {
-        if (scal_wide) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_wide<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
+        if (k > 1 && (fold_lanes || fold_lanes4)) {}       // the previous round's lane-form fold left this round's scalars (prove_core.h: prove_round_fold_lanes*)
+        else if (scal_wide) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_wide<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
         else if (scal_parts) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_parts<<<dim3(blocks, 4), BPPP_BLOCK, 0, s>>>(w, k));
         else PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         if (pending_cnext || k == 1) PMSMX(3, job_x(), job_r(k), job_e(k), job_x());       // C_{k-1} = E + R (prove_core.h: job_e); C_0 always
@@ -492,12 +493,10 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
         else PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         if (!w.next_by_msm && k < 4) {
             if (a != s) { HIP_TRY(hipEventRecord(c->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0)); }
-            const bool next_g4 = !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds && c->next_lanes != 1;
-            if (c->next_lanes == 2)
-                rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next_g2_w2<<<(unsigned)((2 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, a>>>(w, k); });
-            else if (next_g4 && (c->next_g4_w2 || a != s))
+            const bool next_g4 = !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds;      // (only with BPPP_NEXT_MSM_MAX lowered: A/B runs)
+            if (next_g4 && a != s)
                 rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next_g4_w2<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, a>>>(w, k); });
-            else if (next_g4)      // small batch: lane groups (see verify_device_part)
+            else if (next_g4)
                 rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next_g4<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, a>>>(w, k); });
             else if (w2 || a != s)
                 rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next_w2<<<blocks, BPPP_BLOCK, 0, a>>>(w, k); });

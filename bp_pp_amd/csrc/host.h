@@ -117,8 +117,7 @@ struct bppp_ctx {
     bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
     bool generic_slow_rounds = false, no_lane_groups = false, no_small = false, no_split = false, generic_u64_shape = false;
-    int next_lanes = -1;   // diagnostic BPPP_NEXT_LANES: 1 = the one-lane next-commitment kernel at every size
-    int next_overlap = -1, next_g4_w2 = 0;   // diagnostics BPPP_NEXT_OVERLAP (1 always / 0 never), BPPP_NEXT_G4_W2
+    int next_overlap = -1;   // diagnostic BPPP_NEXT_OVERLAP: the variable-base next commitment on the helper stream always (1) / never (0)
     long scal_parts_max = -1;   // diagnostic BPPP_SCAL_PARTS_MAX: largest prove call whose round scalars go out as four workgroups per 64 values
     long lane4_max = -1;   // diagnostic BPPP_LANE4_MAX: largest prove call on the four-lane stage kernels
     long lane_forms_max = -1, next_msm_max = -1;   // diagnostics BPPP_LANE_FORMS_MAX / BPPP_NEXT_MSM_MAX: largest prove call on the 16-lane stage / fold kernels, on the fixed-base next commitment (-1 = by n_simds)

@@ -226,10 +226,3 @@ template __global__ void k_prove_stage_d_g4<1>(ProveWs w);
 template __global__ void k_prove_stage_d_g4<2>(ProveWs w);
 template __global__ void k_prove_stage_f_g4<1>(ProveWs w);
 template __global__ void k_prove_stage_f_g4<2>(ProveWs w);
-// ... and two lanes per value (two GLV streams each): half the repeated doublings of the four-lane form, twice its chain -- for the
-// batch sizes where the kernel runs on the helper stream under the next round's sums and the chain has that long to finish
-__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_next_g2_w2(ProveWs w, int k) {
-    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    const size_t t = g >> 1;
-    if (t < w.N) prove_round_next(w, t, k, (int)(g & 1), 2);
-}

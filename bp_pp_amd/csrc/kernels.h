@@ -140,7 +140,6 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_stage_f_g16_w2(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_fold_g16_w2(bppp::ProveWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_next_g4_w2(bppp::ProveWs w, int k);
-__global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_prove_round_next_g2_w2(bppp::ProveWs w, int k);
 template <int MINW> __global__ __launch_bounds__(BPPP_BLOCK, MINW) void k_prove_stage_d_g4(bppp::ProveWs w);
 template <int MINW> __global__ __launch_bounds__(BPPP_BLOCK, MINW) void k_prove_stage_f_g4(bppp::ProveWs w);
 template <int MINW> __global__ __launch_bounds__(BPPP_BLOCK, MINW) void k_prove_round_fold_g4(bppp::ProveWs w, int k);

@@ -656,7 +656,7 @@ HD void prove_round_scalars(const ProveWs& w, size_t t, int k) {
 // (small calls, next_by_msm: the next commitment is one more fixed-base sum whose scalars part one prepares; there is no part two.)
 // The point slots behind the running products: 0 = X, 1 = R (the table builder's inputs), 2 = C_{k-1}.
 HD u32* prove_fold_rpts(const ProveWs& w) { return (u32*)((uint8_t*)w.straus + (size_t)32 * sizeof(apt_packed) * w.N) + (size_t)28 * 10 * w.N; }
-HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane = -1, int group = 4);
+HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane = -1);
 // the part every form shares: C_{k-1}, X, R to affine (one inversion), X and R into the proof, the round's transcript, y_k
 HD void prove_round_fold_head(const ProveWs& w, size_t t, int k, apt A[3], sc& y, int32_t& status) {
     const size_t N = w.N;
@@ -787,9 +787,9 @@ HD void prove_round_fold(const ProveWs& w, size_t t, int k) {
     w.status[t] = status;
 }
 // next commitment = com + y X + (y^2 - 1) R             (= wnla.commit(l_, n_), wnla.rs:186), rounds 1 .. 3 of the chain form
-// group_lane >= 0: one of `group` (four or two) consecutive lanes that share the sum (straus_affine_g4; identical table build and stores) -- small
+// group_lane >= 0: one of four consecutive lanes that share the sum (straus_affine_g4; identical table build and stores) -- small
 // batches; -1: one lane per proof
-HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane, int group) {
+HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane) {
     const size_t N = w.N;
     (void)k;
     sc y, y2m1, one;
@@ -817,21 +817,25 @@ HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane, int 
     glv_words_set<2>(g, 1, sp);
     pt acc;
 #if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
-    if (group_lane >= 0 && group == 2) straus_affine_g4<2, 2>(acc, tab, pslot, g, group_lane);      // two GLV streams per lane
-    else if (group_lane >= 0) straus_affine_g4<2>(acc, tab, pslot, g, group_lane);
+    if (group_lane >= 0) straus_affine_g4<2>(acc, tab, pslot, g, group_lane);
     else
 #endif
         straus_affine<2>(acc, tab, pslot, g);
     pt_madd(acc, acc, C, apt_is_identity(C));
     pw_st_pt(w, t, PB_C, acc);
-    (void)group_lane; (void)group;
+    (void)group_lane;
 }
 #if defined(__HIPCC__)
 // Small calls (next_by_msm): part one of a round on SIXTEEN lanes per value.  Every lane runs the head (identical values and stores);
 // then lane q folds l, c (q < nl / 2), n (q < nn / 2), updates the generator coefficients ch[q], ch[q + 16], cg[q], forms its share of
-// the next commitment's scalars -- cg[q] n_[q >> k], ch[i] l_[i >> k] for i = q, q + 16, with the folded entries of OTHER lanes read by
-// shuffle, never through memory -- and its terms of v = <c_, l_> + |n_|^2_mu', which meet by a group sum.  One lane's chain is then the
+// the next round's scalars -- cg[q] n_[q >> k], ch[i] l_[i >> k] for i = q, q + 16 (the level's commitment, even slots | R, odd slots) and
+// the same with the partner slot (X), the folded entries of OTHER lanes read by shuffle, never through memory -- and its terms of the
+// three leading scalars, which meet by group sums.  The host launches no scalar kernel for the next round.  One lane's chain is then the
 // head plus a dozen multiplications instead of the head plus 150.  Every lane of a group must be active.
+__device__ __forceinline__ void sc_group_xor1(sc& r, const sc& a) {          // the value of the neighbouring lane (lane ^ 1)
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = __shfl_xor(a.v[i], 1, 64);
+}
 __device__ __forceinline__ void sc_group_read16(sc& r, const sc& a, int src) {
 #pragma unroll
     for (int i = 0; i < 8; i++) r.v[i] = __shfl(a.v[i], src, 16);
@@ -878,25 +882,55 @@ __device__ __forceinline__ void prove_round_fold_lanes(const ProveWs& w, size_t 
         pw_st_sc(w, t, SV_MU, mun);
         sc_mul(t1, rho_inv, rho_inv);
         pw_st_sc(w, t, SV_RHOINV, t1);
-        // next commitment = wnla.commit(l_, n_) as one more fixed-base sum (job_e takes the even folded slots): v g + <h', l_> + <g', n_>
-        sc v = zero, mp;
+        const sc rinv2 = t1;
+        // What the next round needs, all of it from here (the host launches no scalar kernel after a lane-form fold): per original
+        // generator i in folded slot j = i >> k, coefficient c (ch or cg, updated above), folded entry e_j (l_ or n_):
+        //   c e_j        is the generator's term of the level's commitment wnla.commit(l_, n_) -- summed from set 0 if j is even (job_e),
+        //                and IS its term of the next round's R if j is odd (set 2; wnla.rs:140-150);
+        //   c e_{j ^ 1}  (times rho' for even, rho'^-1 for odd j in g_vec) is its term of the next round's X (set 1; prove_round_scalars_*).
+        // Slot 0 of the three sets: v over the even slots, v_r = v over the odd ones, v_x.  Folded entries of other lanes come by shuffle.
+        sc mp, l_p, n_p, vt = zero, wx = zero, vxl = zero;
+        const bool odd = (q & 1) != 0;
         sc_pow_u5(mp, mun, (unsigned)q + 1);                  // mu'^(q+1)
+        sc_group_read16(l_p, lq, q ^ 1);                      // the slot's partner
+        sc_group_read16(n_p, nq, q ^ 1);
         sc_mul(t1, nq, nq); sc_mul(t1, t1, mp);
-        if (has_n) v = t1;
+        if (has_n) vt = t1;
         sc_mul(t1, cq, lq);
-        if (has_l) sc_add(v, v, t1);
-        sc_group_sum16(v);
-        pw_st_msc(w, t, 0, 0, v);
-        sc nsrc, l0src, l1src;
-        sc_group_read16(nsrc, nq, q >> k);                    // n_[q >> k]: lane q >> k < nn / 2 holds it
-        sc_group_read16(l0src, lq, q >> k);                   // l_[q >> k]
-        sc_group_read16(l1src, lq, (q + 16) >> k);            // l_[(q + 16) >> k] < nl / 2
-        sc_mul(t1, cg, nsrc);
-        pw_st_msc(w, t, 0, 1 + q, t1);
-        sc_mul(t1, ch0, l0src);
-        pw_st_msc(w, t, 0, 17 + q, t1);
-        sc_mul(t1, ch1, l1src);
-        pw_st_msc(w, t, 0, 17 + q + 16, t1);
+        if (has_l) sc_add(vt, vt, t1);
+        sc v_e = odd ? zero : vt, v_o = odd ? vt : zero;
+        sc_mul(t1, nq, n_p); sc_mul(t1, t1, mp); sc_mul(t1, t1, mun);      // n_2m n_2m+1 (mu'^2)^(m+1), q = 2m
+        if (has_n && !odd) wx = t1;
+        sc_mul(t1, cq, l_p);
+        if (has_l) vxl = t1;
+        sc_group_sum16(v_e); sc_group_sum16(v_o); sc_group_sum16(wx); sc_group_sum16(vxl);
+        sc_add(t1, rinv2, rinv2);
+        sc_mul(wx, wx, t1);
+        sc_add(wx, wx, vxl);                                  // v_x = wvm(n0, n1, mu'^2) 2 rho'^-1 + <c0, l1> + <c1, l0>
+        pw_st_msc(w, t, 0, 0, v_e);
+        pw_st_msc(w, t, 1, 0, wx);
+        pw_st_msc(w, t, 2, 0, v_o);
+        const int j0 = q >> k, j1 = (q + 16) >> k;            // slots of h_q | g_q, and of h_{q+16}
+        sc src, srx;
+        sc_group_read16(src, nq, j0);
+        sc_group_read16(srx, nq, j0 ^ 1);
+        sc_mul(t1, cg, src);
+        pw_st_msc(w, t, (j0 & 1) ? 2 : 0, 1 + q, t1);
+        sc_mul(t1, srx, (j0 & 1) ? rinv2 : mu);
+        sc_mul(t1, t1, cg);
+        pw_st_msc(w, t, 1, 1 + q, t1);
+        sc_group_read16(src, lq, j0);
+        sc_group_read16(srx, lq, j0 ^ 1);
+        sc_mul(t1, ch0, src);
+        pw_st_msc(w, t, (j0 & 1) ? 2 : 0, 17 + q, t1);
+        sc_mul(t1, ch0, srx);
+        pw_st_msc(w, t, 1, 17 + q, t1);
+        sc_group_read16(src, lq, j1);
+        sc_group_read16(srx, lq, j1 ^ 1);
+        sc_mul(t1, ch1, src);
+        pw_st_msc(w, t, (j1 & 1) ? 2 : 0, 17 + q + 16, t1);
+        sc_mul(t1, ch1, srx);
+        pw_st_msc(w, t, 1, 17 + q + 16, t1);
     } else {
         // proof.l = [l0, l1], proof.n = [n0]   (wnla.rs:126-133): lanes 0 and 1 hold them
         if (q == 0) { sc_to_be(pb + 832, lq); sc_to_be(pb + 896, nq); }
@@ -906,8 +940,9 @@ __device__ __forceinline__ void prove_round_fold_lanes(const ProveWs& w, size_t 
 }
 // The same on FOUR lanes per value, for batches of a few values per SIMD (next_by_msm): lane q owns the folded slots j = q, q + 4, ... of
 // l | c and of n, and everything that hangs off a slot -- the 2^k generator coefficients of its block (ch / cg pick up this round's
-// factor), their products with the folded entry for the next commitment's even slots (job_e), the slot's term of v -- so nothing one
-// lane computes is read by another except through the group sum of v.  In-place folds: pass `it` reads slots 8 it .. 8 it + 7 and
+// factor), their products with the folded entry (the level's commitment in its even slots, job_e; the next round's R in its odd ones)
+// and with the partner slot's entry (the next round's X; lane q ^ 1 holds it: one shuffle), the slot's terms of the three leading
+// scalars -- so nothing one lane computes is read by another except through shuffles.  No scalar kernel for the next round.  In-place folds: pass `it` reads slots 8 it .. 8 it + 7 and
 // writes 4 it .. 4 it + 3, every lane's loads of a pass are issued before any of its stores, and a later pass reads beyond what
 // earlier ones wrote.  One lane's chain: the head plus ~40 multiplications instead of ~150.
 __device__ __forceinline__ void prove_round_fold_lanes4(const ProveWs& w, size_t t, int k, int q) {
@@ -917,10 +952,11 @@ __device__ __forceinline__ void prove_round_fold_lanes4(const ProveWs& w, size_t
     sc y;
     prove_round_fold_head(w, t, k, A, y, status);
     uint8_t* pb = w.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
-    sc rho, rho_inv, mu, mun, t1, v;
+    sc rho, rho_inv, mu, mun, rinv2, t1, v_e, v_o, wx, vxl;
     pw_ld_sc(rho, w, t, SV_RHO); pw_ld_sc(rho_inv, w, t, SV_RHOINV); pw_ld_sc(mu, w, t, SV_MU);
     sc_mul(mun, mu, mu);                                          // mu' of the next level
-    sc_set_u32(v, 0);
+    sc_mul(rinv2, rho_inv, rho_inv);                              // rho'^-1
+    sc_set_u32(v_e, 0); sc_set_u32(v_o, 0); sc_set_u32(wx, 0); sc_set_u32(vxl, 0);
     const int blk = 1 << k;                                       // original generators per folded slot
 #pragma nounroll
     for (int it = 0; it < (nls + 3) / 4; it++) {
@@ -934,8 +970,12 @@ __device__ __forceinline__ void prove_round_fold_lanes4(const ProveWs& w, size_t
         sc_mul(t1, a1, y); sc_add(cj, a0, t1);
         if (has) { pw_st_sc(w, t, SV_L0 + j, lj); pw_st_sc(w, t, SV_C0 + j, cj); }
         if (k < 4) {
+            sc l_p;
+            sc_group_xor1(l_p, lj);                               // the partner slot j ^ 1 (lane q ^ 1, same pass)
             sc_mul(t1, cj, lj);
-            if (has) sc_add(v, v, t1);
+            if (has) { if (j & 1) sc_add(v_o, v_o, t1); else sc_add(v_e, v_e, t1); }
+            sc_mul(t1, cj, l_p);
+            if (has) sc_add(vxl, vxl, t1);
 #pragma nounroll
             for (int r = 0; r < blk; r++) {
                 const int i = jj * blk + r;
@@ -943,7 +983,9 @@ __device__ __forceinline__ void prove_round_fold_lanes4(const ProveWs& w, size_t
                 pw_ld_sc(ch, w, t, SV_CH0 + i);
                 if (r >> sh) { sc_mul(ch, ch, y); if (has) pw_st_sc(w, t, SV_CH0 + i, ch); }
                 sc_mul(t1, ch, lj);
-                if (has && !(j & 1)) pw_st_msc(w, t, 0, 17 + i, t1);
+                if (has) pw_st_msc(w, t, (j & 1) ? 2 : 0, 17 + i, t1);
+                sc_mul(t1, ch, l_p);
+                if (has) pw_st_msc(w, t, 1, 17 + i, t1);
             }
         } else if (has) {
             sc_to_be(pb + 832 + 32 * j, lj);                      // proof.l = [l0, l1]   (wnla.rs:126-133)
@@ -963,8 +1005,13 @@ __device__ __forceinline__ void prove_round_fold_lanes4(const ProveWs& w, size_t
         sc_mul(t1, a1, y); sc_add(nj, a0, t1);
         if (has) pw_st_sc(w, t, SV_N0 + j, nj);
         if (k < 4) {
+            sc n_p, xn;
+            sc_group_xor1(n_p, nj);
             sc_mul(t1, nj, nj); sc_mul(t1, t1, mp);
-            if (has) sc_add(v, v, t1);
+            if (has) { if (j & 1) sc_add(v_o, v_o, t1); else sc_add(v_e, v_e, t1); }
+            sc_mul(t1, nj, n_p); sc_mul(t1, t1, mp); sc_mul(t1, t1, mun);      // n_2m n_2m+1 (mu'^2)^(m+1), j = 2m
+            if (has && !(j & 1)) sc_add(wx, wx, t1);
+            sc_mul(xn, n_p, (j & 1) ? rinv2 : mu);                 // X's folded entry for this slot: rho' n[j+1] | rho'^-1 n[j-1]
             sc_mul(mp, mp, m4);
 #pragma nounroll
             for (int r = 0; r < blk; r++) {
@@ -974,7 +1021,9 @@ __device__ __forceinline__ void prove_round_fold_lanes4(const ProveWs& w, size_t
                 sc_mul(cg, cg, (r >> sh) ? y : rho);
                 if (has) pw_st_sc(w, t, SV_CG0 + i, cg);
                 sc_mul(t1, cg, nj);
-                if (has && !(j & 1)) pw_st_msc(w, t, 0, 1 + i, t1);
+                if (has) pw_st_msc(w, t, (j & 1) ? 2 : 0, 1 + i, t1);
+                sc_mul(t1, cg, xn);
+                if (has) pw_st_msc(w, t, 1, 1 + i, t1);
             }
         } else if (has) {
             sc_to_be(pb + 896, nj);                               // proof.n = [n0]
@@ -984,10 +1033,15 @@ __device__ __forceinline__ void prove_round_fold_lanes4(const ProveWs& w, size_t
         // rho <- mu, mu <- mu^2, rho^-1 <- (rho^-1)^2           (wnla.rs:180-181)
         pw_st_sc(w, t, SV_RHO, mu);
         pw_st_sc(w, t, SV_MU, mun);
-        sc_mul(t1, rho_inv, rho_inv);
-        pw_st_sc(w, t, SV_RHOINV, t1);
-        prove_group_sum16(v, 4);
-        pw_st_msc(w, t, 0, 0, v);
+        pw_st_sc(w, t, SV_RHOINV, rinv2);
+        // slot 0 of the three sets: v over the even slots (job_e), v_x, v_r = v over the odd slots
+        prove_group_sum16(v_e, 4); prove_group_sum16(v_o, 4); prove_group_sum16(wx, 4); prove_group_sum16(vxl, 4);
+        sc_add(t1, rinv2, rinv2);
+        sc_mul(wx, wx, t1);
+        sc_add(wx, wx, vxl);
+        pw_st_msc(w, t, 0, 0, v_e);
+        pw_st_msc(w, t, 1, 0, wx);
+        pw_st_msc(w, t, 2, 0, v_o);
     }
     w.status[t] = status;
 }
