@@ -111,6 +111,18 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     // while phase 1 runs: the chip has SIMDs to spare at those sizes (8,192 proofs: 5.7 -> 4.9 ms per call)
     const bool tables_aside = split || (!c->no_split && !c->no_lane_groups && !c->no_small && 4 * (size_t)((n + BPPP_BLOCK - 1) / BPPP_BLOCK) <= (size_t)c->n_simds);
     const int tparts = split ? parts : 1;
+    // ... and the sizes above that, up to one proof per lane of a lone wavefront per SIMD (2^15, 2^16 proofs), run the ONE-lane table kernel
+    // there too: phase 1 and the tables are then two wavefronts on every SIMD instead of one after the other (verify_core.h:
+    // verify_tables_own).  Both in their 256-register builds, or they could not share a SIMD.
+    const unsigned wg4_blocks = (unsigned)((n + BPPP_C0VAR_SMALL_BLOCK - 1) / BPPP_C0VAR_SMALL_BLOCK);
+    const bool tables_beside = !tables_aside && !c->timing &&
+                               (c->tables_beside >= 0 ? c->tables_beside == 1 : (!c->no_split && !c->no_small && blocks <= (unsigned)c->n_simds));
+    if (tables_beside) {
+        HIP_TRY(hipEventRecord(c->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
+        LAUNCH_ON(a, K_TABLES, k_verify_tables_own<<<wg4_blocks, BPPP_C0VAR_SMALL_BLOCK, 0, a>>>(ws));
+        HIP_TRY(hipEventRecord(c->ev_tab, a));
+    }
     if (tables_aside) {
         // the table kernel decodes its points itself, so it runs on the helper stream beside phase 1
         HIP_TRY(hipEventRecord(c->ev_fork, s));
@@ -121,7 +133,8 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         else LAUNCH_ON(a, K_TABLES, k_verify_tables_split1<<<tb, BPPP_BLOCK, 0, a>>>(ws));
         HIP_TRY(hipEventRecord(c->ev_tab, a));
     }
-    if (small) LAUNCH(K_PHASE1, k_verify_phase1_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    if (tables_beside) LAUNCH(K_PHASE1, k_verify_phase1_wg4<<<wg4_blocks, BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws));
+    else if (small) LAUNCH(K_PHASE1, k_verify_phase1_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     else LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     // C0 = variable-base half (window tables of the proof points, then the shared-doubling sum: one lane per proof, 1 wave
@@ -129,7 +142,7 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     // SIMDs; round 1 adds the halves.
     // with per-kernel timing on, the two halves run back to back so that the kernel times add up to the step (overlapped, each
     // half's events also cover the other's share of the SIMDs; the overlap itself buys nothing at 2 waves/SIMD: DESIGN.md 4)
-    if (tables_aside) HIP_TRY(hipStreamWaitEvent(s, c->ev_tab, 0));
+    if (tables_aside || tables_beside) HIP_TRY(hipStreamWaitEvent(s, c->ev_tab, 0));
     else LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
@@ -151,7 +164,20 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     else if (small) LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<(unsigned)((n + BPPP_C0VAR_SMALL_BLOCK - 1) / BPPP_C0VAR_SMALL_BLOCK), BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws));
     else LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+    // The last round's two-point sum beside the final fixed-base sum (which needs the challenges, not C_4): for batches whose one-lane
+    // kernels are a lone wavefront per SIMD and not on lane groups (2^15 < n <= 2^16), exact mode.  The round then goes out as head and
+    // tail (k_verify_var.hip); the final scalars and the final sum follow the head on the helper stream; k_verify_accept waits for both.
+    const bool one_lane_rounds = !split && !grouped && !(!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds);
+    const bool tail_beside = !rlc_seed && !c->timing && one_lane_rounds &&
+                             (c->tail_beside >= 0 ? c->tail_beside == 1 : (small && !c->no_split));
     for (int k = 1; k <= 4; k++) {
+        if (k == 4 && tail_beside) {
+            LAUNCH(K_ROUND, k_verify_round_head_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+            HIP_TRY(hipEventRecord(c->ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
+            LAUNCH(K_ROUND, k_verify_round_tail<<<wg4_blocks, BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws, k));
+            continue;
+        }
         if (split && parts == 4) LAUNCH(K_ROUND, k_verify_round_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
         else if (split) LAUNCH(K_ROUND, k_verify_round_g8<<<(unsigned)((8 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
         else if (grouped) LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k));
@@ -161,12 +187,14 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
     }
     // the 49 unrolled generator coefficients: sixteen lanes per proof while that still leaves the chip under-filled
+    hipStream_t fs = tail_beside ? a : s;      // where the final scalars and the final sum go
     if (split) LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
-    else LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    else LAUNCH_ON(fs, K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, fs>>>(ws));
     if (!rlc_seed) {
         if (split) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l64<<<fb64_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
-        else if (fb_one_lane) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
-        else LAUNCH(K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+        else if (fb_one_lane) LAUNCH_ON(fs, K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, fs>>>(ws));
+        else LAUNCH_ON(fs, K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, fs>>>(ws));
+        if (tail_beside) { HIP_TRY(hipEventRecord(c->ev_join, a)); HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); }
         LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
     } else {
         // combined check per chunk of 8 proofs; chunks that fail it (or hold a flagged proof) fall through to the exact kernels

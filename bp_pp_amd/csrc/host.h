@@ -118,6 +118,8 @@ struct bppp_ctx {
     bool timing = false;
     bool generic_slow_rounds = false, no_lane_groups = false, no_small = false, no_split = false, generic_u64_shape = false;
     int next_overlap = -1;   // diagnostic BPPP_NEXT_OVERLAP: the variable-base next commitment on the helper stream always (1) / never (0)
+    int tail_beside = -1;     // diagnostic BPPP_TAIL_BESIDE: the last round's sum beside the final fixed-base sum always (1) / never (0)
+    int tables_beside = -1;   // diagnostic BPPP_TABLES_BESIDE: the one-lane table kernel beside phase 1 always (1) / never (0); unset = where the lane kernels are a lone wavefront per SIMD
     long scal_parts_max = -1;   // diagnostic BPPP_SCAL_PARTS_MAX: largest prove call whose round scalars go out as four workgroups per 64 values
     long lane4_max = -1;   // diagnostic BPPP_LANE4_MAX: largest prove call on the four-lane stage kernels
     long lane_forms_max = -1, next_msm_max = -1;   // diagnostics BPPP_LANE_FORMS_MAX / BPPP_NEXT_MSM_MAX: largest prove call on the 16-lane stage / fold kernels, on the fixed-base next commitment (-1 = by n_simds)

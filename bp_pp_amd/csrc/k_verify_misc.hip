@@ -19,6 +19,21 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_phas
     (void)key; (void)sponge;
 #endif
 }
+// the same in 256-thread workgroups (a sponge block per wavefront), for the batches that run the table kernel BESIDE phase 1 (bppp_u64.hip:
+// tables_beside): the four wavefronts of a workgroup land one per SIMD, so a workgroup of each kernel gives every SIMD of a CU one
+// wavefront of each (single-wavefront workgroups of two-per-SIMD kernels land unevenly: k_verify_var.hip)
+__global__ __launch_bounds__(BPPP_C0VAR_SMALL_BLOCK, 2) void k_verify_phase1_wg4(VerifyWs ws) {
+    __shared__ u32 sponge[(BPPP_C0VAR_SMALL_BLOCK / 64) * 50 * BPPP_LDS_STRIDE];
+    size_t t = (size_t)blockIdx.x * BPPP_C0VAR_SMALL_BLOCK + threadIdx.x;
+    if (t >= ws.N) return;
+    const u32 key = preloaded_position_key(ws.states, ws.n_states, t);
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32* col = sponge + (threadIdx.x >> 6) * 50 * BPPP_LDS_STRIDE + (threadIdx.x & 63);
+    for_each_position_group(key, [&]() { verify_phase1_lds(ws, t, col); });
+#else
+    (void)key; (void)sponge;
+#endif
+}
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_small(VerifyWs ws) {     // see k_verify_round_small
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= ws.N) return;

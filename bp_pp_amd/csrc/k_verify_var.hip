@@ -8,6 +8,11 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_ta
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N) verify_tables(ws, t);
 }
+// beside phase 1 on the helper stream (bppp_u64.hip: tables_beside): decodes the proof's points itself
+__global__ __launch_bounds__(BPPP_C0VAR_SMALL_BLOCK, 2) void k_verify_tables_own(VerifyWs ws) {      // (256 threads: see k_verify_phase1_wg4)
+    size_t t = (size_t)blockIdx.x * BPPP_C0VAR_SMALL_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_tables_own(ws, t);
+}
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_c0_var(VerifyWs ws) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N) verify_c0_var(ws, t);
@@ -42,6 +47,21 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_small(VerifyWs ws, 
     if (t >= ws.N) return;
     const u32 key = (ws.states && ws.n_states != 1) ? ws.tstate[(size_t)50 * ws.N + t] : 0u;
     for_each_position_group(key, [&]() { verify_round(ws, t, k); });
+}
+// a round in two kernels (verify_core.h: verify_round_on, part): the head -- C_{k-1} to affine, transcript, challenge -- and the tail -- the
+// two-point sum.  For the LAST round of batches whose one-lane kernels are a lone wavefront per SIMD the tail runs beside the final
+// fixed-base sum, in a 256-register build so that the two share a SIMD (bppp_u64.hip: tail_beside).
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_head_small(VerifyWs ws, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t >= ws.N) return;
+    const u32 key = (ws.states && ws.n_states != 1) ? ws.tstate[(size_t)50 * ws.N + t] : 0u;
+    for_each_position_group(key, [&]() { verify_round(ws, t, k, -1, 4, 1); });
+}
+// (256-thread workgroups for the reason given at k_verify_c0_var_small: their four wavefronts land one per SIMD, while single-wavefront
+// workgroups of a kernel that fits a SIMD twice can land two on one SIMD and none on its neighbour)
+__global__ __launch_bounds__(BPPP_C0VAR_SMALL_BLOCK, 2) void k_verify_round_tail(VerifyWs ws, int k) {
+    size_t t = (size_t)blockIdx.x * BPPP_C0VAR_SMALL_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_round(ws, t, k, -1, 4, 2);
 }
 // ---- random-linear-combination batch mode (rlc_core.h)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(VerifyWs ws, RlcWs r) {

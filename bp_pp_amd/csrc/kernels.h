@@ -81,11 +81,15 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_phas
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed_l1(bppp::VerifyWs ws);      // one lane per proof (full batches)
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_head_small(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_c0_var(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_round(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_small(bppp::VerifyWs ws);
 #define BPPP_C0VAR_SMALL_BLOCK 256   // k_verify_var.hip: four wavefronts per workgroup, one per SIMD
 __global__ __launch_bounds__(BPPP_C0VAR_SMALL_BLOCK) void k_verify_c0_var_small(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_C0VAR_SMALL_BLOCK, 2) void k_verify_round_tail(bppp::VerifyWs ws, int k);
+__global__ __launch_bounds__(BPPP_C0VAR_SMALL_BLOCK, 2) void k_verify_tables_own(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_C0VAR_SMALL_BLOCK, 2) void k_verify_phase1_wg4(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_small(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g4(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g4(bppp::VerifyWs ws);

@@ -1087,6 +1087,48 @@ HD void verify_tables(const VerifyWs& ws, size_t t) {
     affine_tables_build(atab_of(ws.atab, ws.N, t), ws.tscr, ws.pts, ws.N, t, BPPP_VPOINTS);
     BPPP_STAMP(t, 19);
 }
+// The same tables straight from the caller's BYTES, for batches whose one-lane kernels are a lone wavefront per SIMD (2^15, 2^16 proofs):
+// the kernel then runs on the helper stream BESIDE phase 1 instead of after it, and every SIMD has two wavefronts to interleave.  It
+// decodes the 13 points exactly as verify_phase1_on does -- V + proof.r to affine, ALL points zero if any field of the proof is
+// malformed -- into a private copy (rows 17..42 of the final-scalar buffer, which nothing touches before k_verify_final_scalars; phase 1
+// parks its reciprocals in rows 0..15), so the tables are bit for bit those of the serial order.
+HD void verify_tables_own(const VerifyWs& ws, size_t t) {
+    const size_t N = ws.N;
+    u32* tp = ws.fsc + (size_t)(17 * 8) * N;
+    const uint8_t* pv = ws.commitments + 64 * t;
+    const uint8_t* pp = ws.proofs + (size_t)BPPP_U64_PROOF_BYTES * t;
+    apt V, Pr;
+    bool ok = apt_from_xy64(V, pv);
+#pragma nounroll
+    for (int i = 0; i < 12; i++) {
+        apt Q;
+        ok &= apt_from_xy64(Q, pp + 64 * i);
+        ws_st_apt(tp, N, t, i, Q);
+    }
+    ok &= apt_from_xy64(Pr, pp + 64 * 12);
+    sc l0;
+    ok &= sc_from_be(l0, pp + 832);
+    ok &= sc_from_be(l0, pp + 864);
+    ok &= sc_from_be(l0, pp + 896);
+    if (!ok) {
+        apt zero;
+        fe_set_u32(zero.x, 0);
+        fe_set_u32(zero.y, 0);
+        V = zero;
+        Pr = zero;
+#pragma nounroll
+        for (int i = 0; i < 12; i++) ws_st_apt(tp, N, t, i, zero);
+    }
+    apt Vr;
+    {
+        pt s;
+        pt_from_affine(s, V);
+        pt_madd(s, s, Pr, apt_is_identity(Pr));
+        pt_to_affine(Vr, s);
+    }
+    ws_st_apt(tp, N, t, 12, Vr);
+    affine_tables_build(atab_of(ws.atab, ws.N, t), ws.tscr, tp, N, t, BPPP_VPOINTS);
+}
 #if BPPP_VWIN == 5
 // The window table of ONE point by ONE lane -- for calls so small that the chip is empty and what counts is the length of the dependent
 // chain a proof has to wait for (a lane per table instead of a lane per proof: k_verify_tables_split).  pre_doublings > 0 first replaces
@@ -1902,45 +1944,60 @@ HD void verify_c0_var(const VerifyWs& ws, size_t t, int group_lane = -1, int gro
 // group_lane >= 0: this lane is one of four consecutive lanes that all run the round for proof t (identical work and identical
 // stores, except the sum, which they share: straus_affine_g4) -- the small-batch kernels; -1: one lane per proof
 // TR = strobe (sponge state in registers) or strobe_lds (in the workgroup's LDS: k_verify_round); tr arrives unloaded
+// part: 0 the whole round; 1 its HEAD only (C_{k-1} to affine, transcript, challenge -- leaves the affine C_{k-1} in ws.acc and y_k in
+// ws.chal); 2 its TAIL only (the two-point sum and C_k).  In two kernels the last round's tail runs beside the final fixed-base sum,
+// which needs nothing but the challenges (bppp_u64.hip: batches whose one-lane kernels are a lone wavefront per SIMD).
 template <typename TR>
-HD void verify_round_on(const VerifyWs& ws, size_t t, int k, TR& tr, int group_lane = -1, int group_size = 4) {
+HD void verify_round_on(const VerifyWs& ws, size_t t, int k, TR& tr, int group_lane = -1, int group_size = 4, int part = 0) {
     const size_t N = ws.N;
     pt C;
     ws_ld_pt(C, ws.acc, N, t);
-    if (k == 1) {   // C0 = variable-base part (acc) + fixed-base part (pfix); the two kernels run concurrently on two streams
-        pt F;
-        ws_ld_pt(F, ws.pfix, N, t);
-        pt_add(C, C, F);
-    }
-    BPPP_STAMP(t, 9);
     apt Ca;
-    pt_to_affine(Ca, C);
-    BPPP_STAMP(t, 10);
-    ws_ld_transcript(tr, ws.tstate, N, t);
-    app_point(tr, "wnla_com", Ca);                                       // wnla.rs:88-92
-    {   // the round's proof points are only hashed here (the sum below reads their window tables): loaded one at a time, right
-        // before their append, so that nothing but the sponge state and C is live across the permutations
-        apt Q;
-        ws_ld_apt(Q, ws.pts, N, t, 8 + (4 - k));   // proof.x.last()
-        app_point(tr, "wnla_x", Q);
-        ws_ld_apt(Q, ws.pts, N, t, 4 + (4 - k));   // proof.r.last()
-        app_point(tr, "wnla_r", Q);
-    }
-    t_append_u64(tr, "l.sz", (u64)(32 >> (k - 1)));
-    t_append_u64(tr, "n.sz", (u64)(16 >> (k - 1)));
     sc y;
-    bool cok = t_get_challenge(tr, "wnla_challenge", y);                 // wnla.rs:94
-    if (!cok) {
-        ws.status[t] |= ST_DEGENERATE;
-        sc_set_u32(y, 1);
-    }
-    BPPP_STAMP(t, 11);
-    ws_st_transcript(ws.tstate, N, t, tr);
-    ws_st8(ws.chal, N, t, 5 + k, y.v);
-    if (ws.trace) {
-        uint8_t* tb = ws.trace + 704 * t;
-        sc_to_be(tb + 32 * (5 + k), y);
-        apt_to_xy64(tb + 320 + 64 * k, Ca);
+    if (part == 2) {        // the head left C_{k-1} affine (Z = 1, or the identity) and y_k
+        Ca.x = C.X; Ca.y = C.Y;
+        if (fe_is_zero(C.Z)) { fe_set_u32(Ca.x, 0); fe_set_u32(Ca.y, 0); }
+        ws_ld8(y.v, ws.chal, N, t, 5 + k);
+    } else {
+        if (k == 1) {   // C0 = variable-base part (acc) + fixed-base part (pfix); the two kernels run concurrently on two streams
+            pt F;
+            ws_ld_pt(F, ws.pfix, N, t);
+            pt_add(C, C, F);
+        }
+        BPPP_STAMP(t, 9);
+        pt_to_affine(Ca, C);
+        BPPP_STAMP(t, 10);
+        ws_ld_transcript(tr, ws.tstate, N, t);
+        app_point(tr, "wnla_com", Ca);                                       // wnla.rs:88-92
+        {   // the round's proof points are only hashed here (the sum below reads their window tables): loaded one at a time, right
+            // before their append, so that nothing but the sponge state and C is live across the permutations
+            apt Q;
+            ws_ld_apt(Q, ws.pts, N, t, 8 + (4 - k));   // proof.x.last()
+            app_point(tr, "wnla_x", Q);
+            ws_ld_apt(Q, ws.pts, N, t, 4 + (4 - k));   // proof.r.last()
+            app_point(tr, "wnla_r", Q);
+        }
+        t_append_u64(tr, "l.sz", (u64)(32 >> (k - 1)));
+        t_append_u64(tr, "n.sz", (u64)(16 >> (k - 1)));
+        bool cok = t_get_challenge(tr, "wnla_challenge", y);                 // wnla.rs:94
+        if (!cok) {
+            ws.status[t] |= ST_DEGENERATE;
+            sc_set_u32(y, 1);
+        }
+        BPPP_STAMP(t, 11);
+        ws_st_transcript(ws.tstate, N, t, tr);
+        ws_st8(ws.chal, N, t, 5 + k, y.v);
+        if (ws.trace) {
+            uint8_t* tb = ws.trace + 704 * t;
+            sc_to_be(tb + 32 * (5 + k), y);
+            apt_to_xy64(tb + 320 + 64 * k, Ca);
+        }
+        if (part == 1) {
+            pt Cs;
+            pt_from_affine(Cs, Ca);
+            ws_st_pt(ws.acc, N, t, Cs);
+            return;
+        }
     }
     // com_ = com + y X + (y^2 - 1) R                                     (wnla.rs:100-102)
     sc y2m1, one;
@@ -1969,9 +2026,9 @@ HD void verify_round_on(const VerifyWs& ws, size_t t, int k, TR& tr, int group_l
     pt_madd(acc, acc, Ca, apt_is_identity(Ca));
     ws_st_pt(ws.acc, N, t, acc);
 }
-HD void verify_round(const VerifyWs& ws, size_t t, int k, int group_lane = -1, int group_size = 4) {
+HD void verify_round(const VerifyWs& ws, size_t t, int k, int group_lane = -1, int group_size = 4, int part = 0) {
     strobe tr;
-    verify_round_on(ws, t, k, tr, group_lane, group_size);
+    verify_round_on(ws, t, k, tr, group_lane, group_size, part);
 }
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void verify_round_lds(const VerifyWs& ws, size_t t, int k, u32* lds_col) {

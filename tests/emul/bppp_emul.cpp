@@ -362,12 +362,31 @@ static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* labe
             if (memcmp(ea, eb, 64) != 0) return -77;
         }
     for (size_t t = 0; t < n; t++) verify_tables(ws, t);
+    {   // self-check of the table kernel that runs BESIDE phase 1 at 2^15 / 2^16 proofs (verify_tables_own: its own decode of the caller's
+        // bytes, a private copy of the points): bit for bit the tables of the serial order, for well-formed and malformed proofs alike
+        std::vector<apt_packed> atab2(atab.size());
+        std::vector<u32> tscr2(tscr.size());
+        VerifyWs w2 = ws;
+        w2.atab = atab2.data(); w2.tscr = tscr2.data();
+        for (size_t t = 0; t < n; t++) verify_tables_own(w2, t);
+        if (memcmp(atab.data(), atab2.data(), atab.size() * sizeof(apt_packed)) != 0) return -79;
+    }
     for (size_t t = 0; t < n; t++) verify_c0_var(ws, t);
     for (size_t t = 0; t < n; t++) verify_c0_fixed(ws, t);
-    for (int k = 1; k <= 4; k++)
+    for (int k = 1; k <= 3; k++)
         for (size_t t = 0; t < n; t++) verify_round(ws, t, k);
+    // the last round as the library runs it at 2^16 proofs: head, then -- beside the tail -- the final scalars and the final sum
+    for (size_t t = 0; t < n; t++) verify_round(ws, t, 4, -1, 4, 1);
     for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);
-    for (size_t t = 0; t < n; t++) verify_final_check(ws, t);
+    for (size_t t = 0; t < n; t++) {
+        FbRanges rg;
+        verify_final_check_ranges(rg);
+        pt rhs;
+        fb_sum_serial(rhs, fb_of(ws), t, ws.fsc, rg);
+        verify_final_check_store(ws, t, rhs);
+    }
+    for (size_t t = 0; t < n; t++) verify_round(ws, t, 4, -1, 4, 2);
+    for (size_t t = 0; t < n; t++) verify_accept(ws, t);
     for (size_t t = 0; t < n; t++) verify_export_state(ws, t);
     return 0;
 }

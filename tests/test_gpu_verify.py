@@ -135,6 +135,43 @@ def test_full_size_batch_properties(torch_mod, gold):
         proto.close()
 
 
+@pytest.mark.parametrize("n", [20000, 40000])
+def test_sizes_that_run_kernels_beside_each_other_vs_oracle(torch_mod, proto, oracle_c, n):
+    """2^14 < n <= 2^16: the one-lane table kernel runs BESIDE phase 1 from its own decode of the proof bytes (verify_tables_own);
+    2^15 < n <= 2^16: the last round goes out as head and tail, the tail beside the final fixed-base sum (bppp_u64.hip: tables_beside,
+    tail_beside).  Honest, tampered and MALFORMED proofs (byte flips, a coordinate = p, a scalar = n): accept bits, statuses and -- on a
+    sample that includes every malformed proof's neighbours -- the whole trace of challenges and intermediate commitments equal the
+    oracle's."""
+    import workload
+    gens, V, P, _ = workload.make_batch(n, first=200)
+    P, expect = workload.corrupt(P, V, every=11)
+    V, P = V.copy(), P.copy()
+    rng = np.random.default_rng(n)
+    bad = sorted(set(int(i) for i in rng.integers(0, n, 96)))
+    for i in bad:
+        P[i, int(rng.integers(0, 928))] ^= int(rng.integers(1, 256))
+    pbytes = (2**256 - 2**32 - 977).to_bytes(32, "big")
+    nbytes = int("FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141", 16).to_bytes(32, "big")
+    P[n - 1, 64:96] = np.frombuffer(pbytes, np.uint8)
+    P[n // 2, 864:896] = np.frombuffer(nbytes, np.uint8)
+    bad += [n - 1, n // 2]
+    acc, st, tr, rej = _device_verify(torch_mod, proto, workload.LABEL, V, P)
+    sample = sorted(set(bad + [b + 1 for b in bad if b + 1 < n] + list(range(0, n, n // 64))))
+    flagged = 0
+    for i in sample:
+        rc, otr = oracle_c.u64_verify(gens, workload.LABEL, bytes(V[i]), bytes(P[i]), trace=True)
+        assert int(acc[i]) == (1 if rc == 1 else 0), i
+        assert (int(st[i]) != 0) == (rc < 0), (i, rc, int(st[i]))
+        if rc >= 0:
+            assert bytes(tr[i]) == otr, i
+        flagged += rc < 0
+    assert flagged >= 2 and st[n - 1] != 0 and st[n // 2] != 0
+    clean = np.ones(n, bool)
+    clean[bad] = False
+    assert (acc[clean] == expect[clean]).all() and not st[clean].any()
+    assert rej == int((acc == 0).sum())
+
+
 def test_sec1_wire_inputs(torch_mod, proto, gold, oracle_c):
     """the same verify fed with the reference's wire content (33-byte SEC1 points, 525-byte proofs)."""
     import workload
