@@ -10,9 +10,15 @@
 
 typedef int (*verify_one_fn)(void* ctx, const uint8_t* label, size_t label_len, const uint8_t* commitment, const uint8_t* proof, uint8_t* accept,
                              int32_t* status);
+/* bppp_u64_prove_one (u64_proof.rs:57): the prover's single-value call */
+typedef int (*prove_one_fn)(void* ctx, const uint8_t* label, size_t label_len, uint64_t x, const uint8_t* s32, const uint8_t* rnd, uint8_t* proof,
+                            uint8_t* commitment, int32_t* status);
 
 struct shared {
     verify_one_fn fn;
+    prove_one_fn pfn;           /* prove mode: x / s / rnd are the pool, P / V the proofs and commitments a batched call made of it */
+    const uint64_t* x;
+    const uint8_t *sb, *rnd;
     void* const* ctxs;          /* n_ctx contexts; thread t uses ctxs[t % n_ctx] */
     int n_ctx;
     const uint8_t* label;
@@ -42,6 +48,15 @@ static void* worker(void* p) {
         const size_t j = ((size_t)a->t * (size_t)s->calls + (size_t)k) % s->n_pool;
         uint8_t acc = 0xFF;
         int32_t st = 0;
+        if (s->pfn) {
+            uint8_t proof[928], com[64];
+            const double t0 = now_us();
+            const int rc = s->pfn(ctx, s->label, s->label_len, s->x[j], s->sb + 32 * j, s->rnd + 52 * 32 * j, proof, com, &st);
+            s->lat_us[(size_t)a->t * (size_t)s->calls + (size_t)k] = now_us() - t0;
+            if (rc != 0 || st != 0) failed++;
+            else if (memcmp(proof, s->P + 928 * j, 928) != 0 || memcmp(com, s->V + 64 * j, 64) != 0) wrong++;
+            continue;
+        }
         const double t0 = now_us();
         const int rc = s->fn(ctx, s->label, s->label_len, s->V + 64 * j, s->P + 928 * j, &acc, &st);
         s->lat_us[(size_t)a->t * (size_t)s->calls + (size_t)k] = now_us() - t0;
@@ -54,6 +69,7 @@ static void* worker(void* p) {
     pthread_mutex_unlock(&s->mu);
     return 0;
 }
+static int run(struct shared* sp, double* elapsed_s, long* wrong, long* failed);
 /* returns 0, or -1 when threads could not be created; *elapsed_s = first start to last finish */
 int cc_run(void* fn, void* const* ctxs, int n_ctx, const uint8_t* label, size_t label_len, const uint8_t* V, const uint8_t* P, const uint8_t* expect,
            size_t n_pool, int threads, int calls, double* lat_us, double* elapsed_s, long* wrong, long* failed) {
@@ -61,6 +77,21 @@ int cc_run(void* fn, void* const* ctxs, int n_ctx, const uint8_t* label, size_t 
     memset(&s, 0, sizeof s);
     s.fn = (verify_one_fn)fn; s.ctxs = ctxs; s.n_ctx = n_ctx; s.label = label; s.label_len = label_len; s.V = V; s.P = P; s.expect = expect;
     s.n_pool = n_pool; s.threads = threads; s.calls = calls; s.lat_us = lat_us;
+    return run(&s, elapsed_s, wrong, failed);
+}
+/* the same with bppp_u64_prove_one: every returned proof and commitment must equal the batched call's (P, V) byte for byte */
+int cc_run_prove(void* fn, void* const* ctxs, int n_ctx, const uint8_t* label, size_t label_len, const uint64_t* x, const uint8_t* sb,
+                 const uint8_t* rnd, const uint8_t* V, const uint8_t* P, size_t n_pool, int threads, int calls, double* lat_us, double* elapsed_s,
+                 long* wrong, long* failed) {
+    struct shared s;
+    memset(&s, 0, sizeof s);
+    s.pfn = (prove_one_fn)fn; s.ctxs = ctxs; s.n_ctx = n_ctx; s.label = label; s.label_len = label_len; s.x = x; s.sb = sb; s.rnd = rnd; s.V = V; s.P = P;
+    s.n_pool = n_pool; s.threads = threads; s.calls = calls; s.lat_us = lat_us;
+    return run(&s, elapsed_s, wrong, failed);
+}
+static int run(struct shared* sp, double* elapsed_s, long* wrong, long* failed) {
+    struct shared s = *sp;
+    const int threads = s.threads;
     pthread_barrier_init(&s.start, 0, (unsigned)threads + 1);
     pthread_mutex_init(&s.mu, 0);
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);

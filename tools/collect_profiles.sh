@@ -17,7 +17,7 @@ cpif $S/pmc/pmc_traffic.json $P/${T}_pmc_traffic.json; cpif $S/sq/pmc_valu.json 
 if [ "${2:-}" = "also-as-current" ]; then cpif $S/pmc/pmc_traffic.json $P/pmc_traffic.json; cpif $S/sq/pmc_valu.json $P/pmc_valu.json; fi
 cpif $S/box.txt $P/${T}_box.txt; cpif $S/log.txt $P/${T}_log.txt
 cpif $S/pytest_gpu.txt $P/${T}_pytest_gpu.txt; cpif $S/smoke.txt $P/${T}_smoke.txt
-cpif $S/concurrent_callers.json $P/${T}_concurrent_callers.json
+cpif $S/concurrent_callers.json $P/${T}_concurrent_callers.json; cpif $S/concurrent_callers_prove.json $P/${T}_concurrent_callers_prove.json; cpif $S/concurrent_callers_prove.txt $P/${T}_concurrent_callers_prove.txt
 for f in soak_2pow1 soak_2pow5 soak_2pow10 soak_2pow12 soak_2pow16 soak_2pow20 stress_mixed soak_generic; do [ -s $S/$f.txt ] && tail -n 6 $S/$f.txt > $P/${T}_$f.txt; done
 cpif $S/latency_w22.txt $P/${T}_latency_w22.txt
 for f in $S/cmd_*.txt; do [ -s "$f" ] && cp "$f" $P/${T}_$(basename $f); done

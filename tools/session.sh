@@ -9,7 +9,7 @@
 #   prof       rocprofv3 --kernel-trace --stats of the default bench command (no secondaries), plus prove / recip256 (prof_prove, prof_recip)
 #   pmc        FETCH_SIZE / WRITE_SIZE passes (separate runs, --kernel-trace only) + the calibration stream -> pmc/pmc_traffic.json
 #   sq         SQ_* counter passes -> sq/pmc_valu.json            (both summaries carry the code-object hash of the library they ran)
-#   cc         tools/concurrent_callers.py (single-proof callers through the coalescing front end)
+#   cc         tools/concurrent_callers.py (single-proof callers through the coalescing front end)      cc_prove   the same with prove_one
 #   soak       tests/soak.py at 2^1 .. 2^20, stress_mixed, soak_generic
 #   latency    tools/latency_breakdown.py 22
 #   dry2       two-rank gloo dry runs of the three workloads on one device (control flow of N > 1 only)
@@ -60,6 +60,7 @@ for STEP in "$@"; do
       python3 tools/sq_summarize.py $OUT/sq > $OUT/sq_summary.txt 2>&1; cut -c1-300 $OUT/sq_summary.txt
       find $OUT -name "*counter_collection.csv" -size +8M -delete ;;
     cc) timeout 600 python tools/concurrent_callers.py --json $OUT/concurrent_callers.json 2>&1 | grep -v amdgpu.ids | tee $OUT/concurrent_callers.txt; echo "cc rc=$?" >> $LOG ;;
+    cc_prove) timeout 600 python tools/concurrent_callers.py --prove --json $OUT/concurrent_callers_prove.json 2>&1 | grep -v amdgpu.ids | tee $OUT/concurrent_callers_prove.txt; echo "cc_prove rc=$?" >> $LOG ;;
     soak)
       for S in "200 1" "200 5" "100 10" "60 12" "40 16" "6 20"; do set -- $S; timeout 900 python tests/soak.py $1 $2 > $OUT/soak_2pow$2.txt 2>&1; echo "soak$2 rc=$?" >> $LOG; done
       timeout 900 python tests/stress_mixed.py > $OUT/stress_mixed.txt 2>&1; echo "stress rc=$?" >> $LOG
