@@ -86,7 +86,9 @@ def build(force: bool = False, verbose: bool = False, so: str = SO, objdir: str 
 
     def compile_one(so_pair):
         src, obj = so_pair
-        cmd = [hipcc] + flags + ["-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj + ".tmp"]
+        # -cuid: hipcc names a translation unit's registration symbol after a hash of its PATH and options by default, so the same sources
+        # built in another directory gave another device-code hash (device_code_sha256: what the PMC summaries are stamped with)
+        cmd = [hipcc] + flags + ["-cuid=bppp-" + os.path.basename(src), "-MD", "-MF", obj[:-2] + ".d", "-c", src, "-o", obj + ".tmp"]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         r = subprocess.run(cmd, capture_output=True, text=True)
