@@ -283,7 +283,7 @@ def concurrent_callers(proto, label, V, P, expect, thread_counts=(64, 1024)):
     for T in thread_counts:
         cc.run_callers(H, L.bppp_u64_verify_one, [proto._ctx.value], label, V, P, expect, T, 3)
         thr0, st0 = hostinfo.throttle_stats(), proto.coalesce_stats()
-        r = cc.run_callers(H, L.bppp_u64_verify_one, [proto._ctx.value], label, V, P, expect, T, max(20, min(200, 30000 // T)))
+        r = cc.run_callers(H, L.bppp_u64_verify_one, [proto._ctx.value], label, V, P, expect, T, max(20, min(400, 120000 // T)))          # ~0.5 s per point
         thr1, st1 = hostinfo.throttle_stats(), proto.coalesce_stats()
         r["mean_batch"] = round((st1["requests"] - st0["requests"]) / max(1, st1["batches"] - st0["batches"]), 1)
         r["cgroup_throttled_periods"] = thr1["nr_throttled"] - thr0["nr_throttled"]
