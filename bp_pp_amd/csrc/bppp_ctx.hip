@@ -17,6 +17,7 @@ static void read_diagnostics(bppp_ctx* c) {
     if (const char* e = std::getenv("BPPP_NEXT_OVERLAP")) c->next_overlap = std::atoi(e);
     if (const char* e = std::getenv("BPPP_SCAL_PARTS_MAX")) c->scal_parts_max = std::atol(e);
     if (const char* e = std::getenv("BPPP_LANE4_MAX")) c->lane4_max = std::atol(e);
+    if (const char* e = std::getenv("BPPP_TWIN")) c->twin_mode = std::atoi(e);
     if (const char* e = std::getenv("BPPP_TAIL_BESIDE")) c->tail_beside = std::atoi(e);
     if (const char* e = std::getenv("BPPP_TABLES_BESIDE")) c->tables_beside = std::atoi(e);
     if (const char* e = std::getenv("BPPP_NEXT_MSM_MAX")) c->next_msm_max = std::atol(e);
@@ -196,6 +197,9 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     bppp_fronts_teardown(c, true);      // single-proof callers still inside complete first; the front ends' contexts borrow this one's tables
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->twin) { bppp_ctx_destroy(c->twin); c->twin = nullptr; }      // borrows this context's tables
+    if (c->ev_twin_fork) (void)hipEventDestroy(c->ev_twin_fork);
+    if (c->ev_twin_join) (void)hipEventDestroy(c->ev_twin_join);
     for (auto& tl : c->pending) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); }
     for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->d_gens && !c->borrows_tables) (void)hipFree(c->d_gens);
@@ -284,10 +288,16 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
         c->host_chunk = (size_t)value;
         return BPPP_OK;
     }
+    // exact-mode verify batches of 2^18 proofs or more as two halves on two stream pairs (bppp_u64.hip: verify_twin)
+    if (std::strcmp(name, "two_stream_halves") == 0) {
+        if (value != 0 && value != 1) return BPPP_ERR_INVALID_ARG;
+        c->two_stream_halves = value == 1;
+        return BPPP_OK;
+    }
     return BPPP_ERR_INVALID_ARG;
 }
 // read back a tunable, or one of the read-only facts "fb_window_bits" (the window width in use -- the library's choice when the
-// context was created with 0), "device", "n_generators"
+// context was created with 0), "device", "n_generators", "twin_context"
 long bppp_ctx_get_option(bppp_ctx* c, const char* name) {
     CtxLock lock_(c);
     if (!c || !name) return BPPP_ERR_INVALID_ARG;
@@ -301,6 +311,8 @@ long bppp_ctx_get_option(bppp_ctx* c, const char* name) {
     if (std::strcmp(name, "coalesce_us") == 0) return c->coalesce_us;
     if (std::strcmp(name, "coalesce_lanes") == 0) return c->coalesce_lanes;
     if (std::strcmp(name, "ct_prover") == 0) return c->ct_prover ? 1 : 0;
+    if (std::strcmp(name, "two_stream_halves") == 0) return c->two_stream_halves ? 1 : 0;
+    if (std::strcmp(name, "twin_context") == 0) return c->twin ? 1 : 0;      // has a large batch made the second stream pair yet
     return BPPP_ERR_INVALID_ARG;
 }
 int bppp_ctx_synchronize(bppp_ctx* c) {

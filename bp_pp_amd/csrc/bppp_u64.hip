@@ -8,6 +8,56 @@ extern "C" {
 static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
                               const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count,
                               const uint8_t* rlc_seed, const VerifyTranscripts* tx, bool reset_reject_count);
+// Option "two_stream_halves": exact-mode batches from 2^18 proofs on run as TWO HALVES on two stream pairs -- this context's and a
+// child context's over the same tables (bppp_ctx_create_shared, created here at first use): proofs are independent, and the two
+// launch sequences fill each other's kernel tails and pair kernels with different bottlenecks on the SIMDs (2^18 proofs 39.5 ->
+// 38.3 ms, 2^20 149.9 -> 147.3; profiles/r04_zl_twin_probe.txt; below 2^18 the halves lose more to their own under-filled kernels).
+// Off by default: with two launch sequences in flight a kernel's own duration no longer says how well it uses the chip, and
+// bench.py's roofline / the rocprofv3 summaries are quoted on the one-sequence form (bench.py reports this one beside it).  The caller's stream semantics
+// hold: the child's stream starts after everything queued on this context's stream and this stream ends after the child.
+// TWIN_UNAVAILABLE = no child context or workspace could be had (memory): the caller falls back to one context.
+static const int TWIN_UNAVAILABLE = 1000;      // internal, never leaves this file
+static int verify_twin(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments, const void* d_proofs,
+                       void* d_accept, void* d_status, void* d_trace, void* d_reject_count, const VerifyTranscripts* tx) {
+    if (tx && tx->d_states && tx->n_states != 1 && tx->n_states != n) return BPPP_ERR_INVALID_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->twin) {
+        bppp_ctx* t = nullptr;
+        if (bppp_ctx_create_shared(&t, c) != BPPP_OK) { (void)hipGetLastError(); return TWIN_UNAVAILABLE; }
+        t->twin_mode = 0;
+        c->twin = t;
+    }
+    if (!c->ev_twin_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_twin_fork, hipEventDisableTiming));
+    if (!c->ev_twin_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_twin_join, hipEventDisableTiming));
+    bppp_ctx* t = c->twin;
+    t->max_batch = c->max_batch; t->inject_alloc_fault = 0;
+    const size_t h = ((n / 2 + BPPP_BLOCK - 1) / BPPP_BLOCK) * BPPP_BLOCK, m = n - h;      // first half, second half
+    // workspaces first: a half that cannot get its memory sends the whole call down the one-context path, nothing launched yet
+    if (ensure_capacity(t, m) != BPPP_OK || ensure_vtab_capacity(t, m) != BPPP_OK) { (void)hipGetLastError(); return TWIN_UNAVAILABLE; }
+    if (d_reject_count) HIP_TRY(hipMemsetAsync(d_reject_count, 0, sizeof(int), c->stream));
+    HIP_TRY(hipEventRecord(c->ev_twin_fork, c->stream));
+    HIP_TRY(hipStreamWaitEvent(t->stream, c->ev_twin_fork, 0));
+    const size_t SB = BPPP_TRANSCRIPT_STATE_BYTES;
+    VerifyTranscripts p0, p1;
+    if (tx) {
+        p0 = *tx; p1 = *tx;
+        p0.n_states = tx->n_states == 1 ? 1 : h;
+        p1.n_states = tx->n_states == 1 ? 1 : m;
+        if (tx->d_states && tx->n_states != 1) p1.d_states = (const uint8_t*)tx->d_states + h * SB;
+        if (tx->d_states_out) p1.d_states_out = (uint8_t*)tx->d_states_out + h * SB;
+    }
+    int rc = verify_device_part(c, label, label_len, h, d_commitments, d_proofs, d_accept, d_status, d_trace, d_reject_count, nullptr,
+                                tx ? &p0 : nullptr, false);
+    if (rc == BPPP_OK)
+        rc = verify_device_part(t, label, label_len, m, (const uint8_t*)d_commitments + h * 64,
+                                (const uint8_t*)d_proofs + h * (size_t)BPPP_U64_PROOF_BYTES, (uint8_t*)d_accept + h,
+                                d_status ? (int32_t*)d_status + h : nullptr, d_trace ? (uint8_t*)d_trace + h * (size_t)BPPP_U64_TRACE_BYTES : nullptr,
+                                d_reject_count, nullptr, tx ? &p1 : nullptr, false);
+    if (rc != BPPP_OK) { quiesce(c); return rc; }
+    HIP_TRY(hipEventRecord(c->ev_twin_join, t->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_twin_join, 0));
+    return BPPP_OK;
+}
 // One call = one batch for the caller; internally a batch larger than max_batch proofs runs as consecutive parts on the same
 // stream, so the per-proof workspace (~30 KB per proof) is bounded by max_batch whatever n is.  Proofs are independent, the reject
 // counter accumulates across parts, and every per-proof array is simply offset.
@@ -16,6 +66,11 @@ int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size
                        const VerifyTranscripts* tx) {
     if (!c) return BPPP_ERR_INVALID_ARG;
     const size_t cap = c->max_batch;
+    if (n <= cap && d_commitments && d_proofs && d_accept && !rlc_seed && !c->timing && !c->borrows_tables &&
+        (c->twin_mode >= 0 ? (c->twin_mode == 1 && n >= 128) : (c->two_stream_halves && n >= 256 * (size_t)c->n_simds))) {
+        const int rc = verify_twin(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, d_trace, d_reject_count, tx);
+        if (rc != TWIN_UNAVAILABLE) return rc;      // (no twin to be had: the one-context path below)
+    }
     if (n <= cap || !d_commitments || !d_proofs || !d_accept)
         return verify_device_part(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, d_trace, d_reject_count, rlc_seed, tx, true);
     if (tx && tx->d_states && tx->n_states != 1 && tx->n_states != n) return BPPP_ERR_INVALID_ARG;

@@ -57,6 +57,12 @@ struct bppp_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;   // runs the fixed-base half of C0 concurrently with the variable-base half
+    // Large exact-mode verify batches run as two halves on two stream pairs (bppp_u64.hip: verify_twin): the second half on this child
+    // context (bppp_ctx_create_shared: own streams and workspaces, these tables), created at the first such call
+    struct bppp_ctx* twin = nullptr;
+    hipEvent_t ev_twin_fork = nullptr, ev_twin_join = nullptr;
+    bool two_stream_halves = false;      // option "two_stream_halves": from 256 proofs per SIMD (2^18) on
+    int twin_mode = -1;          // diagnostic BPPP_TWIN (tests): 1 = from 128 proofs on whatever the option says, 0 = never
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tab = nullptr;
     hipStream_t copy_stream = nullptr;  // host-buffer entry points: uploads chunk k + 1 while chunk k is being verified (created on first use)
     hipEvent_t ev_copy = nullptr;
@@ -165,6 +171,10 @@ static inline int ensure_blob(bppp_ctx* c, size_t bytes) { return ensure_buffer(
 // after a failed call: nothing of it may still be running when the entry point returns (the staging is reused by the next call, and
 // copies from / to the caller's memory may be queued) -- what the implicit synchronisation of a per-call hipFree used to provide
 static inline void quiesce(bppp_ctx* c) {
+    if (c->twin) {
+        if (c->twin->stream) (void)hipStreamSynchronize(c->twin->stream);
+        if (c->twin->aux_stream) (void)hipStreamSynchronize(c->twin->aux_stream);
+    }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);

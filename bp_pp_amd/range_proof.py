@@ -291,7 +291,8 @@ class U64RangeProofProtocol:
     def set_option(self, name: str, value: int) -> None:
         """include/bppp.h: bppp_ctx_set_option ("rlc_superchunk": 0 = bucket stage off, else 64..8192; "host_chunk": proofs per
         pipelined upload chunk of the host-buffer verify calls, 0 = upload first; "coalesce_max" / "coalesce_us" / "coalesce_lanes":
-        the single-proof front end of verify_one / prove_one)."""
+        the single-proof front end of verify_one / prove_one; "two_stream_halves": exact-mode verify batches of >= 2^18 proofs as two halves
+        on two stream pairs)."""
         _capi.check(_capi.lib().bppp_ctx_set_option(self._ctx, name.encode(), int(value)))
 
     def get_option(self, name: str) -> int:

@@ -5,7 +5,7 @@ sys.path[:0] = ['.']
 import torch, bench
 from bp_pp_amd import U64RangeProofProtocol, synth
 gens, g, gv, hv = bench.load_generators()
-proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=20)
+proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=int(__import__("os").environ.get("PROBE_W", "0")))
 other = proto.clone_shared()
 for n in [int(a) for a in sys.argv[1:]] or (1 << 16, 1 << 17, 1 << 18):
     dV, dP, expect, _ = bench.make_resident_batch(torch, proto, synth, 0, n)
@@ -20,7 +20,10 @@ for n in [int(a) for a in sys.argv[1:]] or (1 << 16, 1 << 17, 1 << 18):
         for i in range(parts):
             ctxs[i % 2].verify_batch_device(synth.LABEL, m, dV.data_ptr() + i * m * 64, dP.data_ptr() + i * m * 928, dA.data_ptr() + i * m, dS.data_ptr() + i * m * 4, 0, 0)
         proto.synchronize(); other.synchronize()
-    for name, fn in (("one batch", one), ("2 halves on 2 streams", lambda: split(2)), ("4 quarters on 2 streams", lambda: split(4))):
+    cases = [("one batch", one), ("2 halves on 2 streams", lambda: split(2)), ("4 quarters on 2 streams", lambda: split(4))]
+    if n >= (1 << 19):
+        cases.append(("8 eighths on 2 streams", lambda: split(8)))
+    for name, fn in cases:
         fn(); dA.zero_(); torch.cuda.synchronize()
         best = 1e9
         for _ in range(3):
