@@ -244,11 +244,12 @@ HD void prove_stage_b(const ProveWs& w, size_t t) {
     pw_st_sc(w, t, SV_SV, svv);
     w.status[t] = status;
 }
-// ---- lane forms of the stage kernels' 16-term loops (small calls: bppp_u64.hip).  A call of a few values waits for ONE lane's chain of
-// dependent multiplications -- 416 in stage D's loop over the 16 digits, 272 in stage F's --, and the terms are independent: lane j of a
-// group of sixteen takes term j (its powers mu^(j+1), mu^-(j+1), lambda^(j+1) by ten multiplications each instead of the running
-// products), the seven sums meet by shuffles, and everything outside the loop is done by all sixteen lanes alike (identical values,
-// identical stores).  lane = -1 is the one-lane form (and the only one the host emulation runs).
+// ---- lane forms of the stage kernels' 16-term loops (calls that leave SIMDs idle: bppp_u64.hip).  A call of a few values waits for ONE
+// lane's chain of dependent multiplications -- 416 in stage D's loop over the 16 digits, 272 in stage F's --, and the terms are
+// independent: lane j of a group of sixteen takes term j, or lane q of a group of four the run of terms 4 q .. 4 q + 3 (the powers
+// mu^(j+1), mu^-(j+1), lambda^(j+1) of a lane's first term by ten multiplications each instead of the running products), the seven sums
+// meet by shuffles, and everything outside the loop is done by all lanes of the group alike (identical values, identical stores).
+// lane = -1 is the one-lane form (and the only one the host emulation runs); group = 16 up to 2^12 values, 4 up to 2^14.
 HD void sc_pow_u5(sc& r, const sc& a, unsigned e) {      // a^e for 1 <= e <= 31, the same ten multiplications whatever e is
     sc acc, tmp;
     sc_set_u32(acc, 1);
