@@ -96,6 +96,35 @@ def test_prover_over_preloaded_transcripts_on_the_gpu():
         proto.close()
 
 
+@pytest.mark.parametrize("reps", [300, 1300, 4200])
+def test_prover_lane_forms_with_mixed_sponge_positions(reps):
+    """The prover's dispatch regimes beyond the small call -- sixteen lanes per value in their 256-register builds (1,200 values), four
+    lanes per value with the fold leaving the next round's scalars (5,200), one lane per value with the round scalars from four
+    workgroups (16,800) -- each over PER-PROOF transcripts at two different sponge positions alternating inside every wavefront, so the
+    lane groups run inside for_each_position_group's divergent trips.  Four oracle-made cases repeated: proofs, commitments and
+    advanced transcripts byte-identical to the oracle prover's."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import ref_fixture_check as RC
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    doc = RC.oracle_made_document(4)
+    cs = doc["cases"]
+    g, gv, hv = workload.split_generators(bytes.fromhex(doc["generators"]))
+    proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
+    try:
+        u8 = lambda key, w: np.tile(np.frombuffer(b"".join(bytes.fromhex(c[key]) for c in cs), dtype=np.uint8).reshape(len(cs), w), (reps, 1))
+        x = np.tile(np.array([int(c["x"]) for c in cs], dtype=np.uint64), reps)
+        S = u8("state_before", 203)
+        assert len({bytes(s)[200] for s in S[:4]}) >= 2                       # different byte positions among neighbours
+        proofs, com, st, out = proto.prove_batch_transcript(x, u8("s", 32), u8("rnd", 52 * 32), [s.tobytes() for s in S])
+        assert not st.any() and (proofs == u8("proof", 928)).all() and (com == u8("commitment", 64)).all()
+        assert (out == u8("state_after_prove", 203)).all()
+    finally:
+        proto.close()
+
+
 def test_generic_verifiers_over_preloaded_transcripts_on_the_gpu():
     """bppp_wnla_verify_batch_transcript and bppp_reciprocal_verify_batch_transcript (instances at different sponge positions in one
     wavefront), against the Python oracle's verdicts and advanced states."""
