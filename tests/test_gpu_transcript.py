@@ -96,6 +96,36 @@ def test_prover_over_preloaded_transcripts_on_the_gpu():
         proto.close()
 
 
+@pytest.mark.parametrize("reps", [1700, 3400])
+def test_verifier_beside_modes_with_mixed_sponge_positions(reps):
+    """20,400 and 40,800 proofs over PER-PROOF transcripts whose sponge positions differ inside every wavefront: the sizes at which phase 1
+    runs in 256-thread workgroups (a sponge block per wavefront in LDS) beside the table kernel, and the last round as head + tail.
+    Twelve oracle-made cases repeated: verdicts and advanced transcripts as the oracle's; one wrong proof judged by the oracle."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import transcript_cases as TC
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    case = TC.make(12, shared=False)
+    g, gv, hv = workload.split_generators(case["gens"])
+    proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
+    try:
+        V, P, S = np.tile(case["V"], (reps, 1)), np.tile(case["P"], (reps, 1)), np.tile(case["states_in"], (reps, 1))
+        n = V.shape[0]
+        assert len({bytes(s)[200] for s in S[:12]}) >= 3
+        j = n - 7
+        P[j, 901] ^= 4
+        acc, st, out = proto.verify_batch_transcript(V, P, [s.tobytes() for s in S])
+        good = np.ones(n, bool); good[j] = False
+        assert acc[good].all() and not acc[j] and not st.any()
+        assert (out[good] == np.tile(case["states_after"], (reps, 1))[good]).all()
+        okj, after = TC.oracle_verify(case, j % 12, bytes(V[j]), bytes(P[j]), bytes(S[j]))
+        assert not okj and bytes(out[j]) == after
+    finally:
+        proto.close()
+
+
 @pytest.mark.parametrize("reps", [300, 1300, 4200])
 def test_prover_lane_forms_with_mixed_sponge_positions(reps):
     """The prover's dispatch regimes beyond the small call -- sixteen lanes per value in their 256-register builds (1,200 values), four
