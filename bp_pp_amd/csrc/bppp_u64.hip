@@ -188,7 +188,8 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         else LAUNCH_ON(a, K_TABLES, k_verify_tables_split1<<<tb, BPPP_BLOCK, 0, a>>>(ws));
         HIP_TRY(hipEventRecord(c->ev_tab, a));
     }
-    if (tables_beside) LAUNCH(K_PHASE1, k_verify_phase1_wg4<<<wg4_blocks, BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws));
+    if (split) LAUNCH(K_PHASE1, k_verify_phase1_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
+    else if (tables_beside) LAUNCH(K_PHASE1, k_verify_phase1_wg4<<<wg4_blocks, BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws));
     else if (small) LAUNCH(K_PHASE1, k_verify_phase1_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     else LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);

@@ -40,6 +40,20 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_small(VerifyWs ws)
     const u32 key = preloaded_position_key(ws.states, ws.n_states, t);
     for_each_position_group(key, [&]() { verify_phase1(ws, t); });
 }
+// small calls: sixteen lanes per proof for phase 1 too (verify_core.h: verify_phase1_on, lane) -- the scalar section's chain is spread
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_g16(VerifyWs ws) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g >> 4;
+    if (t >= ws.N) return;
+    const int lane = (int)(g & 15);
+    const u32 key = preloaded_position_key(ws.states, ws.n_states, t);
+    for_each_position_group(key, [&]() {
+        int32_t status = ST_OK;
+        strobe tr;
+        phase1_start_state(tr, status, ws, t);
+        verify_phase1_on(ws, t, tr, status, lane);
+    });
+}
 // small calls: sixteen lanes per proof (verify_core.h: verify_final_scalars_lane); whole groups are active or leave together
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_final_scalars_g16(VerifyWs ws) {
     const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;

@@ -250,19 +250,6 @@ HD void prove_stage_b(const ProveWs& w, size_t t) {
 // mu^(j+1), mu^-(j+1), lambda^(j+1) of a lane's first term by ten multiplications each instead of the running products), the seven sums
 // meet by shuffles, and everything outside the loop is done by all lanes of the group alike (identical values, identical stores).
 // lane = -1 is the one-lane form (and the only one the host emulation runs); group = 16 up to 2^12 values, 4 up to 2^14.
-HD void sc_pow_u5(sc& r, const sc& a, unsigned e) {      // a^e for 1 <= e <= 31, the same ten multiplications whatever e is
-    sc acc, tmp;
-    sc_set_u32(acc, 1);
-#pragma unroll
-    for (int bit = 4; bit >= 0; bit--) {
-        sc_mul(acc, acc, acc);
-        sc_mul(tmp, acc, a);
-        const bool take = ((e >> bit) & 1u) != 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) acc.v[i] = take ? tmp.v[i] : acc.v[i];
-    }
-    r = acc;
-}
 HD void prove_group_sum16(sc& a, int group = 16) {
 #if defined(__HIP_DEVICE_COMPILE__)
     sc_group_sum16(a, group);

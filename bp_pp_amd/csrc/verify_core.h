@@ -1663,8 +1663,29 @@ __device__ __forceinline__ void straus_affine_split(pt& out, atab_ref tab, const
 // reciprocal.rs:98-104 + circuit.rs:155-228 (closed forms of SURVEY.md 8a)
 // TR = strobe (sponge state in registers: host emulation, small batches) or strobe_lds (state in the workgroup's LDS: k_verify_phase1).
 // `tr` arrives holding the transcript every proof starts from (ws.base); status_in carries flags the caller already raised.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void sc_group_sum16(sc& a, int group = 16);      // the sum over a group of lanes, on every lane (shuffles; below)
+#endif
+// a^e for 1 <= e <= 31, the same ten multiplications whatever e is (the lane forms: a lane's power of mu, lambda, ... directly)
+HD void sc_pow_u5(sc& r, const sc& a, unsigned e) {      // a^e for 1 <= e <= 31, the same ten multiplications whatever e is
+    sc acc, tmp;
+    sc_set_u32(acc, 1);
+#pragma unroll
+    for (int bit = 4; bit >= 0; bit--) {
+        sc_mul(acc, acc, acc);
+        sc_mul(tmp, acc, a);
+        const bool take = ((e >> bit) & 1u) != 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc.v[i] = take ? tmp.v[i] : acc.v[i];
+    }
+    r = acc;
+}
+// lane >= 0: one of SIXTEEN lanes that run phase 1 for proof t together (small calls: k_verify_phase1_g16).  Decode, transcript and
+// challenges are done by all sixteen alike (identical values, identical stores); the scalar section -- a chain of ~245 dependent
+// multiplications and 36 workspace round trips on one lane -- is spread: lane j inverts e + j itself (and every lane mu tau), takes term
+// j of the 16-term loop with its powers by sc_pow_u5, and the three sums meet by shuffles.  Every lane of a group must be active.
 template <typename TR>
-HD void verify_phase1_on(const VerifyWs& ws, size_t t, TR& tr, int32_t status_in) {
+HD void verify_phase1_on(const VerifyWs& ws, size_t t, TR& tr, int32_t status_in, int lane = -1) {
     const size_t N = ws.N;
     int32_t status = status_in;
     BPPP_STAMP(t, 0);
@@ -1762,81 +1783,139 @@ HD void verify_phase1_on(const VerifyWs& ws, size_t t, TR& tr, int32_t status_in
     bool zero_inv = sc_is_zero(delta);                                   // circuit.rs:196 unwraps delta^-1 although u64 never uses it
     sc one;
     sc_set_u32(one, 1);
-    sc run = one;
-#pragma nounroll
-    for (int i = 0; i < 18; i++) {
-        sc v;
-        batch_value(i, v);
-        const bool z = sc_is_zero(v);
-        zero_inv |= z;
-        if (z) v = one;
-        ws_st8(ws.cvec, N, t, i, run.v);      // product of a_0 .. a_{i-1}
-        sc_mul(run, run, v);
-    }
-    if (zero_inv) status |= ST_DEGENERATE;
-    sc inv;
-    sc_inv(inv, run);
-    sc mu_inv, tau_inv;
-#pragma nounroll
-    for (int i = 17; i >= 0; i--) {
-        sc v, pre, ai;
-        batch_value(i, v);
-        if (sc_is_zero(v)) v = one;
-        ws_ld8(pre.v, ws.cvec, N, t, i);
-        sc_mul(ai, inv, pre);                 // a_i^-1
-        sc_mul(inv, inv, v);
-        if (i >= 2) ws_st8(ws.fsc, N, t, i - 2, ai.v);      // (e + j)^-1 at fsc slot j
-        else if (i == 1) tau_inv = ai;
-        else mu_inv = ai;
-    }
-    sc tau2, tau3, S, t1, t2;
+    sc mu_inv, tau_inv, tau2, tau3, S, t1, t2, musum, ps;
     sc_mul(tau2, tau, tau);
     sc_mul(tau3, tau2, tau);
-    BPPP_STAMP(t, 6);
-    // S = sum_{i=1..16} lambda^i ; musum = sum_{i=1..16} mu^i
-    sc lp = lambda, mp = mu, musum;
-    S = lambda;
-    musum = mu;
-#pragma nounroll
-    for (int i = 1; i < 16; i++) {
-        sc_mul(lp, lp, lambda);
-        sc_add(S, S, lp);
-        sc_mul(mp, mp, mu);
-        sc_add(musum, musum, mp);
-    }
-    sc tau_e, two_tau2_S, ps;
-    sc_mul(tau_e, tau, e);
-    sc_mul(two_tau2_S, tau2, S);
-    sc_add(two_tau2_S, two_tau2_S, two_tau2_S);
-    sc_set_u32(ps, 0);
-    sc mip = mu_inv;   // mu^-(j+1)
-    lp = lambda;       // lambda^(j+1)
-    mp = mu;           // mu^(j+1)
-#pragma nounroll
-    for (int j = 0; j < 16; j++) {
-        // pn_tau[j] = mu^-(j+1) (tau^2 16^j + tau (S - lambda^(j+1))) + tau e          (circuit.rs:198-200)
-        sc p16, pn;
-        sc_set_u64(p16, (u64)1 << (4 * j));
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (lane >= 0) {
+        // inverses: (mu tau)^-1 on every lane, (e + lane)^-1 on its lane; a zero is replaced by one, as in the one-lane form below
+        sc m1 = mu, tq = tau, ej, js, inv;
+        bool z = sc_is_zero(mu);
+        zero_inv |= z;
+        if (z) m1 = one;
+        z = sc_is_zero(tau);
+        zero_inv |= z;
+        if (z) tq = one;
+        sc_mul(t1, m1, tq);
+        sc_inv(inv, t1);
+        sc_mul(mu_inv, inv, tq);
+        sc_mul(tau_inv, inv, m1);
+        sc_set_u32(js, (u32)lane);
+        sc_add(ej, e, js);
+        z = sc_is_zero(ej);
+        if (z) ej = one;
+        int zany = z ? 1 : 0;
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) zany |= __shfl_xor(zany, m, 64);
+        zero_inv |= zany != 0;
+        if (zero_inv) status |= ST_DEGENERATE;
+        sc einv;
+        sc_inv(einv, ej);
+        ws_st8(ws.fsc, N, t, lane, einv.v);                  // (e + j)^-1 at fsc slot j
+        BPPP_STAMP(t, 6);
+        // this lane's powers; S = sum lambda^i, musum = sum mu^i over the group
+        sc lp, mp, mip;
+        sc_pow_u5(lp, lambda, (unsigned)lane + 1);
+        sc_pow_u5(mp, mu, (unsigned)lane + 1);
+        sc_pow_u5(mip, mu_inv, (unsigned)lane + 1);
+        S = lp;
+        musum = mp;
+        sc_group_sum16(S);
+        sc_group_sum16(musum);
+        sc tau_e, two_tau2_S, p16, pn;
+        sc_mul(tau_e, tau, e);
+        sc_mul(two_tau2_S, tau2, S);
+        sc_add(two_tau2_S, two_tau2_S, two_tau2_S);
+        // term j = lane of the loop below
+        sc_set_u64(p16, (u64)1 << (4 * lane));
         sc_mul(t1, tau2, p16);
         sc_sub(t2, S, lp);
         sc_mul(t2, t2, tau);
         sc_add(t1, t1, t2);
         sc_mul(pn, t1, mip);
         sc_add(pn, pn, tau_e);
-        ws_st8(ws.sc0, N, t, 1 + j, pn.v);
-        // ps_tau += mu^(j+1) pn^2                                                       (circuit.rs:202)
-        sc_mul(t1, pn, pn);
-        sc_mul(t1, t1, mp);
-        sc_add(ps, ps, t1);
-        // cl_tau[j] = 2 tau^2 S (e+j)^-1 - lambda^(j+1)                                 (circuit.rs:222-226)
-        sc einv;
-        ws_ld8(einv.v, ws.fsc, N, t, j);
+        ws_st8(ws.sc0, N, t, 1 + lane, pn.v);
+        sc_mul(ps, pn, pn);
+        sc_mul(ps, ps, mp);
+        sc_group_sum16(ps);
         sc_mul(t1, two_tau2_S, einv);
         sc_sub(t1, t1, lp);
-        ws_st8(ws.cvec, N, t, 9 + j, t1.v);
-        sc_mul(mip, mip, mu_inv);
-        sc_mul(lp, lp, lambda);
-        sc_mul(mp, mp, mu);
+        ws_st8(ws.cvec, N, t, 9 + lane, t1.v);
+    } else
+#endif
+    {
+        sc run = one;
+#pragma nounroll
+        for (int i = 0; i < 18; i++) {
+            sc v;
+            batch_value(i, v);
+            const bool z = sc_is_zero(v);
+            zero_inv |= z;
+            if (z) v = one;
+            ws_st8(ws.cvec, N, t, i, run.v);      // product of a_0 .. a_{i-1}
+            sc_mul(run, run, v);
+        }
+        if (zero_inv) status |= ST_DEGENERATE;
+        sc inv;
+        sc_inv(inv, run);
+#pragma nounroll
+        for (int i = 17; i >= 0; i--) {
+            sc v, pre, ai;
+            batch_value(i, v);
+            if (sc_is_zero(v)) v = one;
+            ws_ld8(pre.v, ws.cvec, N, t, i);
+            sc_mul(ai, inv, pre);                 // a_i^-1
+            sc_mul(inv, inv, v);
+            if (i >= 2) ws_st8(ws.fsc, N, t, i - 2, ai.v);      // (e + j)^-1 at fsc slot j
+            else if (i == 1) tau_inv = ai;
+            else mu_inv = ai;
+        }
+        BPPP_STAMP(t, 6);
+        // S = sum_{i=1..16} lambda^i ; musum = sum_{i=1..16} mu^i
+        sc lp = lambda, mp = mu;
+        S = lambda;
+        musum = mu;
+#pragma nounroll
+        for (int i = 1; i < 16; i++) {
+            sc_mul(lp, lp, lambda);
+            sc_add(S, S, lp);
+            sc_mul(mp, mp, mu);
+            sc_add(musum, musum, mp);
+        }
+        sc tau_e, two_tau2_S;
+        sc_mul(tau_e, tau, e);
+        sc_mul(two_tau2_S, tau2, S);
+        sc_add(two_tau2_S, two_tau2_S, two_tau2_S);
+        sc_set_u32(ps, 0);
+        sc mip = mu_inv;   // mu^-(j+1)
+        lp = lambda;       // lambda^(j+1)
+        mp = mu;           // mu^(j+1)
+#pragma nounroll
+        for (int j = 0; j < 16; j++) {
+            // pn_tau[j] = mu^-(j+1) (tau^2 16^j + tau (S - lambda^(j+1))) + tau e          (circuit.rs:198-200)
+            sc p16, pn;
+            sc_set_u64(p16, (u64)1 << (4 * j));
+            sc_mul(t1, tau2, p16);
+            sc_sub(t2, S, lp);
+            sc_mul(t2, t2, tau);
+            sc_add(t1, t1, t2);
+            sc_mul(pn, t1, mip);
+            sc_add(pn, pn, tau_e);
+            ws_st8(ws.sc0, N, t, 1 + j, pn.v);
+            // ps_tau += mu^(j+1) pn^2                                                       (circuit.rs:202)
+            sc_mul(t1, pn, pn);
+            sc_mul(t1, t1, mp);
+            sc_add(ps, ps, t1);
+            // cl_tau[j] = 2 tau^2 S (e+j)^-1 - lambda^(j+1)                                 (circuit.rs:222-226)
+            sc einv;
+            ws_ld8(einv.v, ws.fsc, N, t, j);
+            sc_mul(t1, two_tau2_S, einv);
+            sc_sub(t1, t1, lp);
+            ws_st8(ws.cvec, N, t, 9 + j, t1.v);
+            sc_mul(mip, mip, mu_inv);
+            sc_mul(lp, lp, lambda);
+            sc_mul(mp, mp, mu);
+        }
     }
     // ps_tau -= 2 tau^3 sum mu^i   (a_l = 0, a_m = 1s; circuit.rs:203-204)
     sc two_tau3;
@@ -2118,7 +2197,7 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
 // ch[b] and cg[b] -- four conditional multiplications each, in registers -- and its three output scalars; the two folded c values are
 // a sum over the group (shuffles).  The one-lane form above walks 118 multiplications whose operands travel through the workspace
 // (a store-to-load round trip per step): 145 us for a lone proof, a seventh of it here.  Every lane of a group must be active.
-__device__ __forceinline__ void sc_group_sum16(sc& a, int group = 16) {      // group: 16 or a smaller power of two
+__device__ __forceinline__ void sc_group_sum16(sc& a, int group) {      // group: 16 or a smaller power of two (declared above, default 16)
 #pragma unroll
     for (int m = 1; m < group; m <<= 1) {
         sc o;
