@@ -446,31 +446,6 @@ def run_verify(args):
         t7 = (time.perf_counter() - t7) / max(args.steps, 10)
         shard17 = {"workload": f"one GPU's share of BASELINE configs[2]'s 8-GPU split: the first {m} proofs of the same resident batch", "value": m / t7,
                    "unit": "verifies/s", "ms_per_step": t7 * 1e3, "accept_bits_ok": bool((dA7.cpu().numpy() == expect[:m]).all())}
-    halves = None
-    if world == 1 and not args.no_secondary and n >= (1 << 18):
-        # the opt-in "two_stream_halves" form of the SAME step (include/bppp.h): the batch as two halves on two stream pairs.  Beside the
-        # headline, not in it: with two launch sequences in flight a kernel's duration no longer measures the kernel, and `roofline`,
-        # `kernels_ms_per_step` and the rocprofv3 summaries are quoted on the one-sequence form
-        dAh = torch.zeros(n, dtype=torch.uint8, device="cuda")
-        dRh = torch.zeros(1, dtype=torch.int32, device="cuda")
-        best = {0: None, 1: None}
-        for opt in (1, 0, 1, 0):                 # interleaved with the one-sequence form: the chip's clocks drift over a run
-            proto.set_option("two_stream_halves", opt)
-            step(n, dAh, dRh)
-            fence()
-            th = time.perf_counter()
-            for _ in range(max(3, args.steps // 2)):
-                step(n, dAh, dRh)
-            fence()
-            th = (time.perf_counter() - th) / max(3, args.steps // 2)
-            best[opt] = th if best[opt] is None else min(best[opt], th)
-            if opt == 1:
-                ok_h, rej_h = bool((dAh.cpu().numpy() == expect).all()), int(dRh.item())
-        proto.set_option("two_stream_halves", 0)
-        halves = {"value": n / best[1], "unit": "verifies/s", "ms_per_step": best[1] * 1e3, "one_sequence_ms_per_step_same_moment": best[0] * 1e3,
-                  "accept_bits_ok": ok_h, "reject_count": rej_h,
-                  "note": "option two_stream_halves = 1: same batch, same results, two launch sequences; measured in turns with the default form"}
-        del dAh
     callers = None
     if world == 1 and not args.no_secondary and not under_profiler():
         m = min(n, 4096)
@@ -626,7 +601,6 @@ def run_verify(args):
             "ranks": ranks,
             "configs1_2pow16": cfg1,
             "shard_2pow17": shard17,
-            "two_stream_halves": halves,
             "concurrent_callers": callers,
             "rlc_mode": rlc,
             "host_buffer_path": host_path,

@@ -33,7 +33,7 @@ EXPORTS = [
     "bppp_u64_prove_batch_sharded", "bppp_u64_prove_batch_sharded_device",
     "bppp_u64_prove_batch_sec1", "bppp_u64_prove_batch_sec1_device",
     "bppp_u64_verify_one", "bppp_u64_verify_one_transcript", "bppp_u64_prove_one", "bppp_u64_prove_one_transcript",
-    "bppp_ctx_get_coalesce_stats", "bppp_ctx_get_option", "bppp_reciprocal_verify_one", "bppp_reciprocal_verify_one_transcript",
+    "bppp_ctx_get_coalesce_stats", "bppp_ctx_get_option", "bppp_u64_plan", "bppp_plan_describe", "bppp_reciprocal_verify_one", "bppp_reciprocal_verify_one_transcript",
 ]
 
 _lib = None
@@ -108,6 +108,10 @@ def lib():
     L.bppp_ctx_set_option.argtypes = [vp, u8p, C.c_long]
     L.bppp_ctx_get_option.argtypes = [vp, u8p]
     L.bppp_ctx_get_option.restype = C.c_long
+    if "BPPP_LIB" not in os.environ or hasattr(L, "bppp_u64_plan"):      # (an A/B library of an earlier round lacks the plan exports)
+        L.bppp_u64_plan.argtypes = [i32, sz, i32, i32]
+        L.bppp_u64_plan.restype = C.c_long
+        L.bppp_plan_describe.argtypes = [C.c_long, i32, C.c_char_p, sz]
     L.bppp_u64_verify_batch.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp]
     L.bppp_u64_verify_batch_device.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, vp, vp]
     L.bppp_u64_verify_batch_rlc_device.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, vp, u8p]

@@ -46,10 +46,11 @@ struct bppp_front {
         s.n_out = 3; s.out_stride[0] = 1; s.out_stride[1] = sizeof(int32_t); s.out_stride[2] = SB;
         return s;
     }
-    bppp_front(bppp_ctx* p, bool prove_, size_t max_, long wait_us, int nlanes)
-        : parent(p), prove(prove_), max(max_), co(this, shape_of(prove_), max_, wait_us, nlanes, BPPP_ERR_CLOSED, BPPP_ERR_NOMEM) {}
-    bppp_front(bppp_ctx* p, const RecipShape& r, size_t max_, long wait_us, int nlanes)
-        : parent(p), prove(false), recip(true), rs(r), max(max_), co(this, shape_of_recip(r), max_, wait_us, nlanes, BPPP_ERR_CLOSED, BPPP_ERR_NOMEM) {}
+    CtShare ct;                  // the parent's "ct_prover" state when this front end was asked for (read under the parent's lock: fronts_of)
+    bppp_front(bppp_ctx* p, bool prove_, size_t max_, long wait_us, int nlanes, const CtShare& ct_)
+        : parent(p), prove(prove_), max(max_), co(this, shape_of(prove_), max_, wait_us, nlanes, BPPP_ERR_CLOSED, BPPP_ERR_NOMEM), ct(ct_) {}
+    bppp_front(bppp_ctx* p, const RecipShape& r, size_t max_, long wait_us, int nlanes, const CtShare& ct_)
+        : parent(p), prove(false), recip(true), rs(r), max(max_), co(this, shape_of_recip(r), max_, wait_us, nlanes, BPPP_ERR_CLOSED, BPPP_ERR_NOMEM), ct(ct_) {}
 
     // ---- Backend of the coalescer
     void* alloc_staging(size_t bytes) {
@@ -124,11 +125,11 @@ struct bppp_front {
         const int nl = co.lanes();
         for (int l = 0; l < nl; l++) {
             bppp_ctx* ch = nullptr;
-            int rc = bppp_ctx_create_shared(&ch, parent);
+            int rc = ctx_create_shared_with(&ch, parent, ct);      // (the 4-bit table is shared with the parent)
             if (rc != BPPP_OK) return rc;
             lanes.push_back(ch);
             CtxLock lock_(ch);
-            ch->ct_prover = parent->ct_prover;       // (the 4-bit table is shared with the parent: bppp_ctx_create_shared)
+            ch->ct_prover = ct.ct_prover;
             if (recip) continue;                     // the generic verifier sizes its own (grow-only) buffers at the first batch
             if (prove) rc = ensure_prove_capacity(ch, max);
             else {
@@ -163,24 +164,34 @@ static const size_t BPPP_MAX_GENERIC_FRONTS = 4;
 // Lock order: the context's lock (c->mu) is never taken while a front-end lock (fs->mu) is held -- bppp_ctx_set_option holds c->mu
 // while it drains the front ends (which takes fs->mu), so the other order would deadlock.  What the front ends need from the context
 // (the bppp_fronts object, the coalesce_* options) is therefore read under c->mu FIRST, then fs->mu is taken.
-struct FrontOptions { long max, us; int lanes; };
+struct FrontOptions { long max, us; int lanes; CtShare ct; };
 static bppp_fronts* fronts_of(bppp_ctx* c, FrontOptions& o) {
     std::lock_guard<std::recursive_mutex> lk(c->mu);
-    if (!c->fronts) c->fronts = new (std::nothrow) bppp_fronts();
+    if (!c->fronts && !c->fronts_closed.load()) c->fronts = new (std::nothrow) bppp_fronts();
     o.max = c->coalesce_max; o.us = c->coalesce_us; o.lanes = c->coalesce_lanes;
+    o.ct.d_table_ct = c->d_table_ct; o.ct.ct_prover = c->ct_prover;
     return c->fronts;
 }
+// A thread inside a *_one entry point.  The count is the FIRST thing such a call touches and the last thing it leaves behind: it is
+// what lets bppp_ctx_destroy run while callers are arriving, waiting for a batch, or on their way out (include/bppp.h), without ever
+// freeing the context, its bppp_fronts or a front end under one of them.
+struct OneCaller {
+    bppp_ctx* c;
+    explicit OneCaller(bppp_ctx* c_) : c(c_) { c->one_callers.fetch_add(1, std::memory_order_acq_rel); }
+    ~OneCaller() { c->one_callers.fetch_sub(1, std::memory_order_acq_rel); }
+    bool closed() const { return c->fronts_closed.load(std::memory_order_acquire); }
+};
 static int get_front(bppp_ctx* c, int which, std::shared_ptr<bppp_front>& out) {
     FrontOptions o;
     bppp_fronts* fs = fronts_of(c, o);
-    if (!fs) return BPPP_ERR_NOMEM;
+    if (!fs) return c->fronts_closed.load() ? BPPP_ERR_CLOSED : BPPP_ERR_NOMEM;
     std::lock_guard<std::mutex> lk(fs->mu);
     if (fs->closed) return BPPP_ERR_CLOSED;
     if (!fs->f[which]) {
         std::shared_ptr<bppp_front> f;
         int rc;
         try {
-            f = std::make_shared<bppp_front>(c, which == 1, (size_t)o.max, o.us, o.lanes);
+            f = std::make_shared<bppp_front>(c, which == 1, (size_t)o.max, o.us, o.lanes, o.ct);
             rc = f->start();
         } catch (...) { rc = BPPP_ERR_NOMEM; }      // (nothing may throw across the C ABI)
         if (rc != BPPP_OK) return rc;
@@ -192,7 +203,7 @@ static int get_front(bppp_ctx* c, int which, std::shared_ptr<bppp_front>& out) {
 static int get_recip_front(bppp_ctx* c, const RecipShape& r, std::shared_ptr<bppp_front>& out) {
     FrontOptions o;
     bppp_fronts* fs = fronts_of(c, o);
-    if (!fs) return BPPP_ERR_NOMEM;
+    if (!fs) return c->fronts_closed.load() ? BPPP_ERR_CLOSED : BPPP_ERR_NOMEM;
     std::lock_guard<std::mutex> lk(fs->mu);
     if (fs->closed) return BPPP_ERR_CLOSED;
     for (auto& f : fs->generic)
@@ -204,7 +215,7 @@ static int get_recip_front(bppp_ctx* c, const RecipShape& r, std::shared_ptr<bpp
     std::shared_ptr<bppp_front> f;
     int rc;
     try {
-        f = std::make_shared<bppp_front>(c, r, (size_t)o.max, o.us, o.lanes);
+        f = std::make_shared<bppp_front>(c, r, (size_t)o.max, o.us, o.lanes, o.ct);
         rc = f->start();
         if (rc == BPPP_OK) fs->generic.push_back(f);
     } catch (...) { rc = BPPP_ERR_NOMEM; }
@@ -217,6 +228,7 @@ void bppp_fronts_teardown(bppp_ctx* c, bool final) {
     bppp_fronts* fs;
     {
         std::lock_guard<std::recursive_mutex> lk(c->mu);
+        if (final) c->fronts_closed.store(true, std::memory_order_release);     // sticky: no front end is ever started on this context again
         fs = c->fronts;
     }
     if (!fs) return;
@@ -232,11 +244,15 @@ void bppp_fronts_teardown(bppp_ctx* c, bool final) {
     }
     for (size_t i = 0; i < n_old; i++) old[i]->co.shutdown();      // drains; returns when no caller is inside
     for (size_t i = 0; i < n_old; i++) old[i].reset();              // the object itself goes with its last shared_ptr
-    if (final) {
-        std::lock_guard<std::recursive_mutex> lk(c->mu);
-        delete c->fronts;
-        c->fronts = nullptr;
-    }
+}
+// The last step of bppp_ctx_destroy.  A caller that got BPPP_ERR_CLOSED from its batch (or arrived during the teardown) is still inside
+// its entry point for a few instructions -- it reads fronts_closed, may lock fs->mu once more, drops its shared_ptr: wait for the last
+// of them, then free the (closed, empty) bppp_fronts.  Round 4 freed it right after the drain and re-created it for such a caller,
+// which then started a new front end on a context that was being destroyed.
+void bppp_fronts_delete(bppp_ctx* c) {
+    while (c->one_callers.load(std::memory_order_acquire) != 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    delete c->fronts;
+    c->fronts = nullptr;
 }
 
 static bool state_ok(const uint8_t* st) { return st[200] < BPPP_STROBE_R && st[201] <= BPPP_STROBE_R; }
@@ -244,7 +260,9 @@ static bool state_ok(const uint8_t* st) { return st[200] < BPPP_STROBE_R && st[2
 static int submit_retry(bppp_ctx* c, int which, const void* const in[], void* const out[]) {
     // A front end torn down by an option change while this caller was on its way in answers CLOSED: take the new one, as often as it
     // takes (a caller never sees an option change).  Only bppp_ctx_destroy ends the loop: get_front then answers CLOSED itself.
+    OneCaller inside(c);
     for (;;) {
+        if (inside.closed()) return BPPP_ERR_CLOSED;
         std::shared_ptr<bppp_front> f;
         int rc = get_front(c, which, f);
         if (rc != BPPP_OK) return rc;
@@ -265,7 +283,7 @@ int bppp_u64_verify_one_transcript(bppp_ctx* c, uint8_t state[203], const uint8_
 }
 int bppp_u64_verify_one(bppp_ctx* c, const uint8_t* label, size_t label_len, const uint8_t commitment[64], const uint8_t proof[928],
                         uint8_t* accept, int32_t* status) {
-    if (!c || (!label && label_len) || !commitment || !proof || !accept) return BPPP_ERR_INVALID_ARG;
+    if (!c || !label_ok(label, label_len) || !commitment || !proof || !accept) return BPPP_ERR_INVALID_ARG;
     if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
     uint8_t st[SB];
     int rc = bppp_transcript_new(label, label_len, st);      // Transcript::new(label) on the host: one Keccak permutation
@@ -284,7 +302,7 @@ int bppp_u64_prove_one_transcript(bppp_ctx* c, uint8_t state[203], uint64_t x, c
 }
 int bppp_u64_prove_one(bppp_ctx* c, const uint8_t* label, size_t label_len, uint64_t x, const uint8_t s[32], const uint8_t* rnd,
                        uint8_t proof[928], uint8_t commitment[64], int32_t* status) {
-    if (!c || (!label && label_len) || !s || !rnd || !proof || !commitment) return BPPP_ERR_INVALID_ARG;
+    if (!c || !label_ok(label, label_len) || !s || !rnd || !proof || !commitment) return BPPP_ERR_INVALID_ARG;
     if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
     uint8_t st[SB];
     int rc = bppp_transcript_new(label, label_len, st);
@@ -304,7 +322,9 @@ static int recip_one(bppp_ctx* c, uint8_t* state_io, const uint8_t* state_in, si
     r.nd = dim_nd; r.np = dim_np; r.rounds = rounds; r.nl = nl; r.nn = nn;
     const void* in[4] = {commitment, proof, state_in, nullptr};
     void* out[4] = {accept, status, state_io, nullptr};
+    OneCaller inside(c);
     for (;;) {
+        if (inside.closed()) return BPPP_ERR_CLOSED;
         std::shared_ptr<bppp_front> f;
         int rc = get_recip_front(c, r, f);
         if (rc != BPPP_OK) return rc;
@@ -314,7 +334,7 @@ static int recip_one(bppp_ctx* c, uint8_t* state_io, const uint8_t* state_in, si
 }
 int bppp_reciprocal_verify_one(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t dim_nd, size_t dim_np, const uint8_t commitment[64],
                                const uint8_t* proof, size_t rounds, size_t nl, size_t nn, uint8_t* accept, int32_t* status) {
-    if (!label && label_len) return BPPP_ERR_INVALID_ARG;
+    if (!label_ok(label, label_len)) return BPPP_ERR_INVALID_ARG;
     uint8_t st[SB];
     int rc = bppp_transcript_new(label, label_len, st);
     if (rc != BPPP_OK) return rc;

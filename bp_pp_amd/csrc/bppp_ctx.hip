@@ -1,6 +1,7 @@
 // libbppp_hip.so, host side: contexts (generators -> fixed-base tables in HBM, streams, workspace bookkeeping), options, kernel timing, merlin on
 // serialized states (host only), generator derivation and the table artefact.
 #include "host.h"
+#include "plan_core.h"
 #if defined(BPPP_PHASE_TIMING)
 namespace bppp { __device__ unsigned long long g_bppp_stamps[1024 * 32]; }
 #endif
@@ -17,7 +18,6 @@ static void read_diagnostics(bppp_ctx* c) {
     if (const char* e = std::getenv("BPPP_NEXT_OVERLAP")) c->next_overlap = std::atoi(e);
     if (const char* e = std::getenv("BPPP_SCAL_PARTS_MAX")) c->scal_parts_max = std::atol(e);
     if (const char* e = std::getenv("BPPP_LANE4_MAX")) c->lane4_max = std::atol(e);
-    if (const char* e = std::getenv("BPPP_TWIN")) c->twin_mode = std::atoi(e);
     if (const char* e = std::getenv("BPPP_TAIL_BESIDE")) c->tail_beside = std::atoi(e);
     if (const char* e = std::getenv("BPPP_TABLES_BESIDE")) c->tables_beside = std::atoi(e);
     if (const char* e = std::getenv("BPPP_NEXT_MSM_MAX")) c->next_msm_max = std::atol(e);
@@ -194,12 +194,12 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
 
 void bppp_ctx_destroy(bppp_ctx* c) {
     if (!c) return;
-    bppp_fronts_teardown(c, true);      // single-proof callers still inside complete first; the front ends' contexts borrow this one's tables
+    // single-proof callers still inside complete first (the front ends' contexts borrow this one's tables); callers on their way in or
+    // out of a *_one entry point get BPPP_ERR_CLOSED, and nothing is freed before the last of them has left
+    bppp_fronts_teardown(c, true);
+    bppp_fronts_delete(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->twin) { bppp_ctx_destroy(c->twin); c->twin = nullptr; }      // borrows this context's tables
-    if (c->ev_twin_fork) (void)hipEventDestroy(c->ev_twin_fork);
-    if (c->ev_twin_join) (void)hipEventDestroy(c->ev_twin_join);
     for (auto& tl : c->pending) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); }
     for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->d_gens && !c->borrows_tables) (void)hipFree(c->d_gens);
@@ -288,16 +288,10 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
         c->host_chunk = (size_t)value;
         return BPPP_OK;
     }
-    // exact-mode verify batches of 2^18 proofs or more as two halves on two stream pairs (bppp_u64.hip: verify_twin)
-    if (std::strcmp(name, "two_stream_halves") == 0) {
-        if (value != 0 && value != 1) return BPPP_ERR_INVALID_ARG;
-        c->two_stream_halves = value == 1;
-        return BPPP_OK;
-    }
     return BPPP_ERR_INVALID_ARG;
 }
 // read back a tunable, or one of the read-only facts "fb_window_bits" (the window width in use -- the library's choice when the
-// context was created with 0), "device", "n_generators", "twin_context"
+// context was created with 0), "device", "n_generators", "last_verify_plan", "last_prove_plan"
 long bppp_ctx_get_option(bppp_ctx* c, const char* name) {
     CtxLock lock_(c);
     if (!c || !name) return BPPP_ERR_INVALID_ARG;
@@ -311,9 +305,21 @@ long bppp_ctx_get_option(bppp_ctx* c, const char* name) {
     if (std::strcmp(name, "coalesce_us") == 0) return c->coalesce_us;
     if (std::strcmp(name, "coalesce_lanes") == 0) return c->coalesce_lanes;
     if (std::strcmp(name, "ct_prover") == 0) return c->ct_prover ? 1 : 0;
-    if (std::strcmp(name, "two_stream_halves") == 0) return c->two_stream_halves ? 1 : 0;
-    if (std::strcmp(name, "twin_context") == 0) return c->twin ? 1 : 0;      // has a large batch made the second stream pair yet
+    // the kernels the last u64 verify / prove call on this context ran (plan_core.h; text form: bppp_plan_describe)
+    if (std::strcmp(name, "last_verify_plan") == 0) return (long)c->last_verify_plan;
+    if (std::strcmp(name, "last_prove_plan") == 0) return (long)c->last_prove_plan;
     return BPPP_ERR_INVALID_ARG;
+}
+long bppp_u64_plan(int prove, size_t n, int n_simds, int flags) {
+    if (n_simds < 1 || (prove != 0 && prove != 1) || flags < 0 || flags > 3) return BPPP_ERR_INVALID_ARG;
+    bppp_host::PlanKnobs k;
+    k.n_simds = n_simds;
+    k.timing = (flags & 2) != 0;
+    return prove ? (long)bppp_host::plan_prove(n, k, (flags & 1) != 0).code() : (long)bppp_host::plan_verify(n, k, (flags & 1) != 0).code();
+}
+int bppp_plan_describe(long code, int prove, char* buf, size_t cap) {
+    if (code < 0 || code > 0xFFFFFFFFl || (!buf && cap)) return BPPP_ERR_INVALID_ARG;
+    return bppp_host::plan_describe((uint32_t)code, prove != 0, buf, cap);
 }
 int bppp_ctx_synchronize(bppp_ctx* c) {
     CtxLock lock_(c);
@@ -355,14 +361,14 @@ int bppp_ctx_get_timings(bppp_ctx* c, int max_entries, const char** names, doubl
 // merlin::Transcript as 203 serialized bytes, on the host: lets a C caller build the pre-loaded states without merlin and lets
 // the tests follow the reference's `t: &mut Transcript` contract end to end (no GPU involved)
 int bppp_transcript_new(const uint8_t* label, size_t label_len, uint8_t state_out[203]) {
-    if ((!label && label_len) || !state_out) return BPPP_ERR_INVALID_ARG;
+    if (!label_ok(label, label_len) || !state_out) return BPPP_ERR_INVALID_ARG;
     strobe t;
     t_new(t, label, (u32)label_len);
     strobe_to_bytes(state_out, t, 2);       // the last operation of Transcript::new is the AD of the dom-sep message
     return BPPP_OK;
 }
 int bppp_transcript_append_message(uint8_t state[203], const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len) {
-    if (!state || (!label && label_len) || (!msg && msg_len) || msg_len > 0xFFFFFFFFu) return BPPP_ERR_INVALID_ARG;
+    if (!state || !label_ok(label, label_len) || (!msg && msg_len) || msg_len > 0xFFFFFFFFu) return BPPP_ERR_INVALID_ARG;
     strobe t;
     if (!strobe_from_bytes(t, state)) return BPPP_ERR_INVALID_ARG;
     uint8_t len4[4] = {(uint8_t)msg_len, (uint8_t)(msg_len >> 8), (uint8_t)(msg_len >> 16), (uint8_t)(msg_len >> 24)};
@@ -373,7 +379,7 @@ int bppp_transcript_append_message(uint8_t state[203], const uint8_t* label, siz
     return BPPP_OK;
 }
 int bppp_transcript_challenge_bytes(uint8_t state[203], const uint8_t* label, size_t label_len, uint8_t* out, size_t n) {
-    if (!state || (!label && label_len) || (!out && n) || n > 0xFFFFFFFFu) return BPPP_ERR_INVALID_ARG;
+    if (!state || !label_ok(label, label_len) || (!out && n) || n > 0xFFFFFFFFu) return BPPP_ERR_INVALID_ARG;
     strobe t;
     if (!strobe_from_bytes(t, state)) return BPPP_ERR_INVALID_ARG;
     uint8_t len4[4] = {(uint8_t)n, (uint8_t)(n >> 8), (uint8_t)(n >> 16), (uint8_t)(n >> 24)};
@@ -591,17 +597,29 @@ int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device) {
 // parent must outlive its children.
 int bppp_ctx_create_shared(bppp_ctx** out, bppp_ctx* parent) {
     if (!out || !parent) return BPPP_ERR_INVALID_ARG;
+    CtShare ct;
+    {       // the "ct_prover" option may be changing on another thread: its two fields are read under the parent's lock
+        std::lock_guard<std::recursive_mutex> lk(parent->mu);
+        ct.d_table_ct = parent->d_table_ct;
+        ct.ct_prover = parent->ct_prover;
+    }
+    return ctx_create_shared_with(out, parent, ct);
+}
+
+}  // extern "C"
+
+// (everything else a child reads from its parent -- device, generator counts, window width, table pointers -- is fixed at creation)
+int ctx_create_shared_with(bppp_ctx** out, bppp_ctx* parent, const CtShare& ct) {
+    if (!out || !parent) return BPPP_ERR_INVALID_ARG;
     *out = nullptr;
     HIP_TRY(hipSetDevice(parent->device));
     bppp_ctx* c = new (std::nothrow) bppp_ctx();
     if (!c) return BPPP_ERR_NOMEM;
     c->device = parent->device; c->fb_w = parent->fb_w; c->ng = parent->ng; c->nh = parent->nh; c->nbases = parent->nbases;
     c->d_gens = parent->d_gens; c->d_table = parent->d_table; c->table_bytes = 0; c->borrows_tables = true;
-    if (parent->d_table_ct) { c->d_table_ct = parent->d_table_ct; c->borrows_table_ct = true; c->ct_prover = parent->ct_prover; }
+    if (ct.d_table_ct) { c->d_table_ct = ct.d_table_ct; c->borrows_table_ct = true; c->ct_prover = ct.ct_prover; }
     int rc = ctx_alloc_common(c);
     if (rc != BPPP_OK) { bppp_ctx_destroy(c); return rc; }
     *out = c;
     return BPPP_OK;
 }
-
-}  // extern "C"

@@ -177,7 +177,7 @@ int bppp_wnla_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, 
                            const uint8_t* proof_x, const uint8_t* proof_l, size_t nl, const uint8_t* proof_n, size_t nn,
                            uint8_t* accept, int32_t* status) {
     CtxLock lock_(c);
-    if (!c || (!label && label_len) || !commitments || !cvec || !rho || !mu || (rounds && (!proof_r || !proof_x)) || (!proof_l && nl) ||
+    if (!c || !label_ok(label, label_len) || !commitments || !cvec || !rho || !mu || (rounds && (!proof_r || !proof_x)) || (!proof_l && nl) ||
         (!proof_n && nn) || !accept)
         return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
@@ -333,7 +333,7 @@ static bool recip_is_u64_shape(const bppp_ctx* c, size_t dim_nd, size_t dim_np, 
 int recip_verify_device_entry(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                               const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn, void* d_accept,
                               void* d_status, const uint8_t* rlc_seed, void* d_reject_count) {
-    if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept || !d_status) return BPPP_ERR_INVALID_ARG;
+    if (!c || !label_ok(label, label_len) || !d_commitments || !d_proofs || !d_accept || !d_status) return BPPP_ERR_INVALID_ARG;
     int rc = recip_verify_check_args(c, dim_nd, dim_np, rounds, nl, nn);
     if (rc != BPPP_OK) return rc;
     if (recip_is_u64_shape(c, dim_nd, dim_np, rounds, nl, nn))
@@ -394,7 +394,7 @@ int bppp_reciprocal_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t
 static int recip_verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                   const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
                                   int32_t* status, const HostTranscripts* tx, const uint8_t* rlc_seed) {
-    if (!c || (!label && label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
+    if (!c || !label_ok(label, label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
     int rc = recip_verify_check_args(c, dim_nd, dim_np, rounds, nl, nn);
     if (rc != BPPP_OK) return rc;
     if (n == 0) return BPPP_OK;
@@ -519,7 +519,7 @@ int bppp_circuit_verify_batch_transcript(bppp_ctx* c, const bppp_circuit* q, siz
 static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n,
                                     const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
                                     int32_t* status, const HostTranscripts* tx) {
-    if (!c || !q || (!label && label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
+    if (!c || !q || !label_ok(label, label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
     const CircuitDev& cd = q->cd;
     if (cd.nm > c->ng || cd.nv + 9 > c->nh || rounds > 12 || nl > 4096 || nn > 4096) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
@@ -657,7 +657,7 @@ void bppp_wnla_proof_shape(size_t nl, size_t nn, size_t* rounds, size_t* nl_out,
 static int wnla_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, const HostTranscripts* tx, size_t n, const uint8_t* commitments,
                            const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl, const uint8_t* nvec, size_t nn,
                            uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l, uint8_t* proof_n, int32_t* status) {
-    if (!c || (!label && label_len) || !commitments || !cvec || !rho || !mu || (!l && nl) || (!nvec && nn) || nl > 65536 || nn > 65536)
+    if (!c || !label_ok(label, label_len) || !commitments || !cvec || !rho || !mu || (!l && nl) || (!nvec && nn) || nl > 65536 || nn > 65536)
         return BPPP_ERR_INVALID_ARG;
     size_t rounds, nl_f, nn_f;
     wnla_proof_shape(nl, nn, rounds, nl_f, nn_f);
@@ -743,7 +743,7 @@ int bppp_wnla_prove_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* state
 static int circuit_prove_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, const HostTranscripts* tx, size_t n,
                               const uint8_t* v_commitments, const uint8_t* v, const uint8_t* s_v, const uint8_t* w_l, const uint8_t* w_r,
                               const uint8_t* w_o, const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
-    if (!c || !q || (!label && label_len) || !v_commitments || !v || !s_v || !w_l || !w_r || !rnd || !proofs) return BPPP_ERR_INVALID_ARG;
+    if (!c || !q || !label_ok(label, label_len) || !v_commitments || !v || !s_v || !w_l || !w_r || !rnd || !proofs) return BPPP_ERR_INVALID_ARG;
     const CircuitDev& cd = q->cd;
     if ((cd.no && !w_o) || cd.nm > c->ng || cd.nv + 9 > c->nh) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
@@ -874,7 +874,7 @@ int bppp_circuit_prove_batch_transcript(bppp_ctx* c, const bppp_circuit* q, size
 static int recip_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, const HostTranscripts* tx, size_t n, size_t dim_nd, size_t dim_np,
                             const uint8_t* commitments, const uint8_t* x, const uint8_t* sblind, const uint8_t* digits, const uint8_t* m,
                             const uint8_t* rnd, uint8_t* proofs, int32_t* status) {
-    if (!c || (!label && label_len) || !commitments || !x || !sblind || !digits || !m || !rnd || !proofs) return BPPP_ERR_INVALID_ARG;
+    if (!c || !label_ok(label, label_len) || !commitments || !x || !sblind || !digits || !m || !rnd || !proofs) return BPPP_ERR_INVALID_ARG;
     if (dim_nd == 0 || dim_np == 0 || dim_nd > (size_t)c->ng || dim_nd + 10 > (size_t)c->nh || dim_np > dim_nd + 1 || dim_nd > 4096)
         return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;

@@ -311,7 +311,7 @@ extern "C" {
 // ---- U64RangeProofProtocol::verify, exact and RLC, host and device buffers
 static int u64_sharded_host(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments, const uint8_t* proofs,
                             uint8_t* accept, int32_t* status, int32_t* reject_count, const uint8_t* seed) {
-    if (!grp || (!label && label_len) || !commitments || !proofs || !accept || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
+    if (!grp || !label_ok(label, label_len) || !commitments || !proofs || !accept || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
     if (reject_count) *reject_count = 0;
     if (n == 0) return BPPP_OK;
     ShardedCall call;
@@ -325,7 +325,7 @@ static int u64_sharded_host(bppp_group* grp, const uint8_t* label, size_t label_
 static int u64_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const void* const* d_commitments,
                               const void* const* d_proofs, void* const* d_accept, void* const* d_status, void* const* d_reject_count,
                               const uint8_t* seed) {
-    if (!grp || (!label && label_len) || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
+    if (!grp || !label_ok(label, label_len) || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
     int rc = check_device_form(grp, n, d_reject_count, {d_commitments, d_proofs, cv(d_accept)});
     if (rc != BPPP_OK) return rc;
     ShardedCall call;
@@ -360,7 +360,7 @@ int bppp_u64_verify_batch_rlc_sharded_device(bppp_group* grp, const uint8_t* lab
 // ---- SEC1-compressed inputs (33-byte commitments, 525-byte proofs), expanded on each device
 int bppp_u64_verify_batch_sec1_sharded(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments33,
                                        const uint8_t* proofs525, uint8_t* accept, int32_t* status, int32_t* reject_count) {
-    if (!grp || (!label && label_len) || !commitments33 || !proofs525 || !accept || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
+    if (!grp || !label_ok(label, label_len) || !commitments33 || !proofs525 || !accept || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
     if (reject_count) *reject_count = 0;
     if (n == 0) return BPPP_OK;
     ShardedCall call;
@@ -374,7 +374,7 @@ int bppp_u64_verify_batch_sec1_sharded(bppp_group* grp, const uint8_t* label, si
 int bppp_u64_verify_batch_sec1_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n,
                                               const void* const* d_commitments33, const void* const* d_proofs525, void* const* d_accept,
                                               void* const* d_status, void* const* d_reject_count) {
-    if (!grp || (!label && label_len) || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
+    if (!grp || !label_ok(label, label_len) || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
     int rc = check_device_form(grp, n, d_reject_count, {d_commitments33, d_proofs525, cv(d_accept)});
     if (rc != BPPP_OK) return rc;
     ShardedCall call;
@@ -430,7 +430,7 @@ int bppp_u64_verify_batch_transcript_sharded_device(bppp_group* grp, size_t n, c
 static int recip_sharded_host(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                               const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
                               int32_t* status, int32_t* reject_count, const uint8_t* seed) {
-    if (!grp || (!label && label_len) || !commitments || !proofs || !accept || rounds > 12) return BPPP_ERR_INVALID_ARG;
+    if (!grp || !label_ok(label, label_len) || !commitments || !proofs || !accept || rounds > 12) return BPPP_ERR_INVALID_ARG;
     if (reject_count) *reject_count = 0;
     if (n == 0) return BPPP_OK;
     const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
@@ -445,7 +445,7 @@ static int recip_sharded_host(bppp_group* grp, const uint8_t* label, size_t labe
 static int recip_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                 const void* const* d_commitments, const void* const* d_proofs, size_t rounds, size_t nl, size_t nn,
                                 void* const* d_accept, void* const* d_status, void* const* d_reject_count, const uint8_t* seed) {
-    if (!grp || (!label && label_len) || rounds > 12) return BPPP_ERR_INVALID_ARG;
+    if (!grp || !label_ok(label, label_len) || rounds > 12) return BPPP_ERR_INVALID_ARG;
     int rc = check_device_form(grp, n, d_reject_count, {d_commitments, d_proofs, cv(d_accept), cv(d_status)});
     if (rc != BPPP_OK) return rc;
     const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
@@ -486,7 +486,7 @@ int bppp_reciprocal_verify_batch_rlc_sharded_device(bppp_group* grp, const uint8
 // ---- U64RangeProofProtocol::prove, sharded: independent proofs, no exchange step -- the ranks only vote on their return codes
 int bppp_u64_prove_batch_sharded(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const uint64_t* x, const uint8_t* s,
                                  const uint8_t* rnd, uint8_t* proofs, uint8_t* commitments, int32_t* status) {
-    if (!grp || (!label && label_len) || !x || !s || !rnd || !proofs || !commitments || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
+    if (!grp || !label_ok(label, label_len) || !x || !s || !rnd || !proofs || !commitments || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     ShardedCall call;
     call.grp = grp; call.n = n; call.exchange = false;
@@ -500,7 +500,7 @@ int bppp_u64_prove_batch_sharded(bppp_group* grp, const uint8_t* label, size_t l
 int bppp_u64_prove_batch_sharded_device(bppp_group* grp, const uint8_t* label, size_t label_len, size_t n, const void* const* d_x,
                                         const void* const* d_s, const void* const* d_rnd, void* const* d_proofs, void* const* d_commitments,
                                         void* const* d_status) {
-    if (!grp || (!label && label_len) || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
+    if (!grp || !label_ok(label, label_len) || !u64_shape(grp)) return BPPP_ERR_INVALID_ARG;
     const int G = (int)grp->devices.size();
     for (const void* const* a : {d_x, d_s, d_rnd, cv(d_proofs), cv(d_commitments)}) {
         if (!a) return BPPP_ERR_INVALID_ARG;

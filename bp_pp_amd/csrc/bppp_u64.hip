@@ -2,62 +2,24 @@
 // One lane per proof; 64-thread workgroups (one wavefront) so that a 2^16-proof batch yields 1024 workgroups (4 per CU) and no
 // lane ever waits on a workgroup barrier.  The per-lane work is in verify_core.h / prove_core.h.
 #include "host.h"
+#include "plan_core.h"
+
+static_assert(bppp_host::PLAN_BLOCK == BPPP_BLOCK, "plan_core.h counts workgroups of BPPP_BLOCK lanes");
+// the switches of a context that the plans depend on
+static bppp_host::PlanKnobs knobs_of(const bppp_ctx* c) {
+    bppp_host::PlanKnobs k;
+    k.n_simds = c->n_simds;
+    k.no_small = c->no_small; k.no_lane_groups = c->no_lane_groups; k.no_split = c->no_split; k.timing = c->timing;
+    k.tables_beside = c->tables_beside; k.tail_beside = c->tail_beside; k.fb_one_lane_mode = c->fb_one_lane_mode; k.next_overlap = c->next_overlap;
+    k.next_msm_max = c->next_msm_max; k.lane_forms_max = c->lane_forms_max; k.lane4_max = c->lane4_max; k.scal_parts_max = c->scal_parts_max;
+    return k;
+}
 
 extern "C" {
 
 static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
                               const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count,
                               const uint8_t* rlc_seed, const VerifyTranscripts* tx, bool reset_reject_count);
-// Option "two_stream_halves": exact-mode batches from 2^18 proofs on run as TWO HALVES on two stream pairs -- this context's and a
-// child context's over the same tables (bppp_ctx_create_shared, created here at first use): proofs are independent, and the two
-// launch sequences fill each other's kernel tails and pair kernels with different bottlenecks on the SIMDs (2^18 proofs 39.5 ->
-// 38.3 ms, 2^20 149.9 -> 147.3; profiles/r04_zl_twin_probe.txt; below 2^18 the halves lose more to their own under-filled kernels).
-// Off by default: with two launch sequences in flight a kernel's own duration no longer says how well it uses the chip, and
-// bench.py's roofline / the rocprofv3 summaries are quoted on the one-sequence form (bench.py reports this one beside it).  The caller's stream semantics
-// hold: the child's stream starts after everything queued on this context's stream and this stream ends after the child.
-// TWIN_UNAVAILABLE = no child context or workspace could be had (memory): the caller falls back to one context.
-static const int TWIN_UNAVAILABLE = 1000;      // internal, never leaves this file
-static int verify_twin(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments, const void* d_proofs,
-                       void* d_accept, void* d_status, void* d_trace, void* d_reject_count, const VerifyTranscripts* tx) {
-    if (tx && tx->d_states && tx->n_states != 1 && tx->n_states != n) return BPPP_ERR_INVALID_ARG;
-    HIP_TRY(hipSetDevice(c->device));
-    if (!c->twin) {
-        bppp_ctx* t = nullptr;
-        if (bppp_ctx_create_shared(&t, c) != BPPP_OK) { (void)hipGetLastError(); return TWIN_UNAVAILABLE; }
-        t->twin_mode = 0;
-        c->twin = t;
-    }
-    if (!c->ev_twin_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_twin_fork, hipEventDisableTiming));
-    if (!c->ev_twin_join) HIP_TRY(hipEventCreateWithFlags(&c->ev_twin_join, hipEventDisableTiming));
-    bppp_ctx* t = c->twin;
-    t->max_batch = c->max_batch; t->inject_alloc_fault = 0;
-    const size_t h = ((n / 2 + BPPP_BLOCK - 1) / BPPP_BLOCK) * BPPP_BLOCK, m = n - h;      // first half, second half
-    // workspaces first: a half that cannot get its memory sends the whole call down the one-context path, nothing launched yet
-    if (ensure_capacity(t, m) != BPPP_OK || ensure_vtab_capacity(t, m) != BPPP_OK) { (void)hipGetLastError(); return TWIN_UNAVAILABLE; }
-    if (d_reject_count) HIP_TRY(hipMemsetAsync(d_reject_count, 0, sizeof(int), c->stream));
-    HIP_TRY(hipEventRecord(c->ev_twin_fork, c->stream));
-    HIP_TRY(hipStreamWaitEvent(t->stream, c->ev_twin_fork, 0));
-    const size_t SB = BPPP_TRANSCRIPT_STATE_BYTES;
-    VerifyTranscripts p0, p1;
-    if (tx) {
-        p0 = *tx; p1 = *tx;
-        p0.n_states = tx->n_states == 1 ? 1 : h;
-        p1.n_states = tx->n_states == 1 ? 1 : m;
-        if (tx->d_states && tx->n_states != 1) p1.d_states = (const uint8_t*)tx->d_states + h * SB;
-        if (tx->d_states_out) p1.d_states_out = (uint8_t*)tx->d_states_out + h * SB;
-    }
-    int rc = verify_device_part(c, label, label_len, h, d_commitments, d_proofs, d_accept, d_status, d_trace, d_reject_count, nullptr,
-                                tx ? &p0 : nullptr, false);
-    if (rc == BPPP_OK)
-        rc = verify_device_part(t, label, label_len, m, (const uint8_t*)d_commitments + h * 64,
-                                (const uint8_t*)d_proofs + h * (size_t)BPPP_U64_PROOF_BYTES, (uint8_t*)d_accept + h,
-                                d_status ? (int32_t*)d_status + h : nullptr, d_trace ? (uint8_t*)d_trace + h * (size_t)BPPP_U64_TRACE_BYTES : nullptr,
-                                d_reject_count, nullptr, tx ? &p1 : nullptr, false);
-    if (rc != BPPP_OK) { quiesce(c); return rc; }
-    HIP_TRY(hipEventRecord(c->ev_twin_join, t->stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_twin_join, 0));
-    return BPPP_OK;
-}
 // One call = one batch for the caller; internally a batch larger than max_batch proofs runs as consecutive parts on the same
 // stream, so the per-proof workspace (~30 KB per proof) is bounded by max_batch whatever n is.  Proofs are independent, the reject
 // counter accumulates across parts, and every per-proof array is simply offset.
@@ -66,11 +28,6 @@ int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size
                        const VerifyTranscripts* tx) {
     if (!c) return BPPP_ERR_INVALID_ARG;
     const size_t cap = c->max_batch;
-    if (n <= cap && d_commitments && d_proofs && d_accept && !rlc_seed && !c->timing && !c->borrows_tables &&
-        (c->twin_mode >= 0 ? (c->twin_mode == 1 && n >= 128) : (c->two_stream_halves && n >= 256 * (size_t)c->n_simds))) {
-        const int rc = verify_twin(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, d_trace, d_reject_count, tx);
-        if (rc != TWIN_UNAVAILABLE) return rc;      // (no twin to be had: the one-context path below)
-    }
     if (n <= cap || !d_commitments || !d_proofs || !d_accept)
         return verify_device_part(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, d_trace, d_reject_count, rlc_seed, tx, true);
     if (tx && tx->d_states && tx->n_states != 1 && tx->n_states != n) return BPPP_ERR_INVALID_ARG;
@@ -94,19 +51,18 @@ int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size
 static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
                               const void* d_proofs, void* d_accept, void* d_status, void* d_trace, void* d_reject_count,
                               const uint8_t* rlc_seed, const VerifyTranscripts* tx, bool reset_reject_count) {
-    if (!c || (!label && label_len) || !d_commitments || !d_proofs || !d_accept) return BPPP_ERR_INVALID_ARG;
+    if (!c || !label_ok(label, label_len) || !d_commitments || !d_proofs || !d_accept) return BPPP_ERR_INVALID_ARG;
     if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;   // u64 entry points need the u64 generator shape
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_capacity(c, n);
     if (rc != BPPP_OK) return rc;
-    // a call of at most one proof per SIMD: the dependent chains are cut further (a lane per window table and per half GLV stream,
-    // a wavefront per fixed-base sum), which takes three more sets of window tables per proof
-    const bool split = !c->no_small && !c->no_lane_groups && !c->no_split && n <= 4 * (size_t)c->n_simds;
-    // four parts per GLV stream up to one proof per SIMD, two beyond (the extra lanes start to queue: 2,048 proofs 3.5 ms either way, 4,096
-    // proofs 4.3 ms in two parts against 5.1 in four)
-    const int parts = n <= (size_t)c->n_simds ? 4 : 2;
-    rc = ensure_vtab_capacity(c, split ? (size_t)parts * n : n);
+    // which kernels this size runs: ONE pure function of (n, SIMDs, switches) -- plan_core.h, where the regimes are described
+    const bppp_host::VerifyPlan plan = bppp_host::plan_verify(n, knobs_of(c), rlc_seed != nullptr);
+    c->last_verify_plan = plan.code();
+    const bool split = plan.split;
+    const int parts = plan.parts;
+    rc = ensure_vtab_capacity(c, plan.vtab_sets * n);
     if (rc != BPPP_OK) return rc;
     VerifyWs ws;
     std::memset(&ws, 0, sizeof ws);
@@ -159,19 +115,12 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         if (rc != BPPP_OK) return rc;                           \
     } while (0)
 #define LAUNCH(id, ...) LAUNCH_ON(s, id, __VA_ARGS__)
-    // a grid that does not even fill one wavefront per SIMD gains nothing from the 256-VGPR cap: use the uncapped builds
-    const bool small = !c->no_small && blocks <= (unsigned)c->n_simds;
     hipStream_t a = c->timing ? s : c->aux_stream;
-    // batches that the lane groups serve (up to 16 proofs per SIMD) build their tables the same way -- a lane per point, one table each --
-    // while phase 1 runs: the chip has SIMDs to spare at those sizes (8,192 proofs: 5.7 -> 4.9 ms per call)
-    const bool tables_aside = split || (!c->no_split && !c->no_lane_groups && !c->no_small && 4 * (size_t)((n + BPPP_BLOCK - 1) / BPPP_BLOCK) <= (size_t)c->n_simds);
-    const int tparts = split ? parts : 1;
-    // ... and the sizes above that, up to one proof per lane of a lone wavefront per SIMD (2^15, 2^16 proofs), run the ONE-lane table kernel
-    // there too: phase 1 and the tables are then two wavefronts on every SIMD instead of one after the other (verify_core.h:
-    // verify_tables_own).  Both in their 256-register builds, or they could not share a SIMD.
+    // (tables: a lane per point on the helper stream while phase 1 runs, or the one-lane kernel beside phase 1 -- both decode their points
+    // themselves -- or after phase 1 on the main stream)
+    const bool tables_aside = plan.tables == bppp_host::TABLES_ASIDE, tables_beside = plan.tables == bppp_host::TABLES_BESIDE;
+    const int tparts = plan.tparts;
     const unsigned wg4_blocks = (unsigned)((n + BPPP_C0VAR_SMALL_BLOCK - 1) / BPPP_C0VAR_SMALL_BLOCK);
-    const bool tables_beside = !tables_aside && !c->timing &&
-                               (c->tables_beside >= 0 ? c->tables_beside == 1 : (!c->no_split && !c->no_small && blocks <= (unsigned)c->n_simds));
     if (tables_beside) {
         HIP_TRY(hipEventRecord(c->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
@@ -188,10 +137,12 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         else LAUNCH_ON(a, K_TABLES, k_verify_tables_split1<<<tb, BPPP_BLOCK, 0, a>>>(ws));
         HIP_TRY(hipEventRecord(c->ev_tab, a));
     }
-    if (split) LAUNCH(K_PHASE1, k_verify_phase1_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
-    else if (tables_beside) LAUNCH(K_PHASE1, k_verify_phase1_wg4<<<wg4_blocks, BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws));
-    else if (small) LAUNCH(K_PHASE1, k_verify_phase1_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
-    else LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    switch (plan.phase1) {
+    case bppp_host::P1_G16: LAUNCH(K_PHASE1, k_verify_phase1_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws)); break;
+    case bppp_host::P1_WG4: LAUNCH(K_PHASE1, k_verify_phase1_wg4<<<wg4_blocks, BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws)); break;
+    case bppp_host::P1_SMALL: LAUNCH(K_PHASE1, k_verify_phase1_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws)); break;
+    default: LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws)); break;
+    }
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     // C0 = variable-base half (window tables of the proof points, then the shared-doubling sum: one lane per proof, 1 wave
     // per SIMD) + fixed-base half (8 lanes per proof): independent, so they run concurrently on two streams and share the
@@ -202,30 +153,29 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     else LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
-    // the two fixed-base sums: 8 lanes per proof, or one from the size at which one lane per proof fills the SIMDs twice over
-    const bool fb_one_lane = c->fb_one_lane_mode >= 0 ? c->fb_one_lane_mode == 1 : n >= (size_t)128 * (size_t)c->n_simds;
+    // the two fixed-base sums: a wavefront per sum in a small call, 8 lanes per proof, or one from the size at which one lane per proof
+    // fills the SIMDs twice over
     const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     const unsigned fb64_blocks = (unsigned)((n * 64 + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
-    if (split) LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed_l64<<<fb64_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
-    else if (fb_one_lane) LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
+    if (plan.fb == bppp_host::FB_L64) LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed_l64<<<fb64_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
+    else if (plan.fb == bppp_host::FB_L1) LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
     else LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_join, a));
-    // a batch whose four-lanes-per-proof grid still leaves the SIMDs under-filled runs its variable-base sums on lane groups
-    const bool grouped = !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds;
+    // the variable-base half: 64 / 32 lanes per proof in a small call, lane groups of 4 while the grid leaves the SIMDs under-filled,
+    // else one lane per proof (uncapped build: 256-thread workgroups, their four wavefronts land one per SIMD -- see k_verify_var.hip)
     const unsigned g4_blocks = (unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
-    if (split && parts == 4) LAUNCH(K_C0_VAR, k_verify_c0_var_g64<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
-    else if (split) LAUNCH(K_C0_VAR, k_verify_c0_var_g32<<<(unsigned)((32 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
-    else if (grouped) LAUNCH(K_C0_VAR, k_verify_c0_var_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws));
-    // (256-thread workgroups: their four wavefronts land one per SIMD -- see k_verify_var.hip)
-    else if (small) LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<(unsigned)((n + BPPP_C0VAR_SMALL_BLOCK - 1) / BPPP_C0VAR_SMALL_BLOCK), BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws));
-    else LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    switch (plan.c0var) {
+    case bppp_host::C0V_G64: LAUNCH(K_C0_VAR, k_verify_c0_var_g64<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws)); break;
+    case bppp_host::C0V_G32: LAUNCH(K_C0_VAR, k_verify_c0_var_g32<<<(unsigned)((32 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws)); break;
+    case bppp_host::C0V_G4: LAUNCH(K_C0_VAR, k_verify_c0_var_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws)); break;
+    case bppp_host::C0V_SMALL: LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<wg4_blocks, BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws)); break;
+    default: LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws)); break;
+    }
     HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
     // The last round's two-point sum beside the final fixed-base sum (which needs the challenges, not C_4): for batches whose one-lane
     // kernels are a lone wavefront per SIMD and not on lane groups (2^15 < n <= 2^16), exact mode.  The round then goes out as head and
     // tail (k_verify_var.hip); the final scalars and the final sum follow the head on the helper stream; k_verify_accept waits for both.
-    const bool one_lane_rounds = !split && !grouped && !(!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds);
-    const bool tail_beside = !rlc_seed && !c->timing && one_lane_rounds &&
-                             (c->tail_beside >= 0 ? c->tail_beside == 1 : (small && !c->no_split));
+    const bool tail_beside = plan.tail_beside;
     for (int k = 1; k <= 4; k++) {
         if (k == 4 && tail_beside) {
             LAUNCH(K_ROUND, k_verify_round_head_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
@@ -234,21 +184,22 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
             LAUNCH(K_ROUND, k_verify_round_tail<<<wg4_blocks, BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws, k));
             continue;
         }
-        if (split && parts == 4) LAUNCH(K_ROUND, k_verify_round_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
-        else if (split) LAUNCH(K_ROUND, k_verify_round_g8<<<(unsigned)((8 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
-        else if (grouped) LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k));
-        else if (!c->no_lane_groups && 2 * (size_t)blocks <= (size_t)c->n_simds)
-            LAUNCH(K_ROUND, k_verify_round_g2<<<(unsigned)((2 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k));
-        else if (small) LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
-        else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+        switch (plan.round) {
+        case bppp_host::R_G16: LAUNCH(K_ROUND, k_verify_round_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k)); break;
+        case bppp_host::R_G8: LAUNCH(K_ROUND, k_verify_round_g8<<<(unsigned)((8 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k)); break;
+        case bppp_host::R_G4: LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k)); break;
+        case bppp_host::R_G2: LAUNCH(K_ROUND, k_verify_round_g2<<<(unsigned)((2 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k)); break;
+        case bppp_host::R_SMALL: LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k)); break;
+        default: LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k)); break;
+        }
     }
     // the 49 unrolled generator coefficients: sixteen lanes per proof while that still leaves the chip under-filled
     hipStream_t fs = tail_beside ? a : s;      // where the final scalars and the final sum go
-    if (split) LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
+    if (plan.final_scalars_g16) LAUNCH(K_FINAL_SCALARS, k_verify_final_scalars_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws));
     else LAUNCH_ON(fs, K_FINAL_SCALARS, k_verify_final_scalars<<<blocks, BPPP_BLOCK, 0, fs>>>(ws));
     if (!rlc_seed) {
-        if (split) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l64<<<fb64_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
-        else if (fb_one_lane) LAUNCH_ON(fs, K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, fs>>>(ws));
+        if (plan.fb == bppp_host::FB_L64) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l64<<<fb64_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
+        else if (plan.fb == bppp_host::FB_L1) LAUNCH_ON(fs, K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, fs>>>(ws));
         else LAUNCH_ON(fs, K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, fs>>>(ws));
         if (tail_beside) { HIP_TRY(hipEventRecord(c->ev_join, a)); HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); }
         LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
@@ -442,7 +393,7 @@ int bppp_u64_prove_batch_transcript_device(bppp_ctx* c, size_t n, const void* d_
 }
 int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_x, const void* d_s, const void* d_rnd,
                       void* d_proofs, void* d_commitments, void* d_status, const VerifyTranscripts* tx) {
-    if (!c || (!label && label_len) || !d_x || !d_s || !d_rnd || !d_proofs || !d_commitments) return BPPP_ERR_INVALID_ARG;
+    if (!c || !label_ok(label, label_len) || !d_x || !d_s || !d_rnd || !d_proofs || !d_commitments) return BPPP_ERR_INVALID_ARG;
     if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
     if (n == 0) return BPPP_OK;
     HIP_TRY(hipSetDevice(c->device));
@@ -482,16 +433,15 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
         rc = timed(c, id, s, [&]() { __VA_ARGS__; });          \
         if (rc != BPPP_OK) return rc;                          \
     } while (0)
-    const bool fb_one_lane = c->fb_one_lane_mode >= 0 ? c->fb_one_lane_mode == 1 : n >= (size_t)128 * (size_t)c->n_simds;
+    // which kernels this size runs: ONE pure function of (n, SIMDs, switches) -- plan_core.h
+    const bppp_host::ProvePlan plan = bppp_host::plan_prove(n, knobs_of(c), c->ct_prover);
+    c->last_prove_plan = plan.code();
     const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
-    // a call of at most one value per SIMD: a wavefront per sum (the chip is empty; 6 additions per lane and a 6-step tree instead of 44 and 3)
-    const bool fb_wave = !c->no_small && !c->no_split && n <= (size_t)c->n_simds;
-    // ... and the next level's commitment from fixed-base sums too: its even folded slots as one more sum (prove_core.h: job_e, 25 terms)
-    // fused with the next round's X | R, its odd ones being that round's R.  That form wins while the variable-base one is a latency chain
-    // on an under-filled chip: up to 32 values per SIMD (2^14 values: 300 more table additions per level against 0.8 ms of chain, of
-    // which the helper stream hides a quarter: 10.5 -> 9.8 ms; 2^15: 17.65 -> 17.1; 2^16: 31.0 against 32.1, so not there).
-    const size_t next_msm_max = c->next_msm_max >= 0 ? (size_t)c->next_msm_max : 32 * (size_t)c->n_simds;
-    w.next_by_msm = (fb_wave || (!c->no_split && !c->no_lane_groups && n <= next_msm_max)) ? 1 : 0;
+    // A level's commitment from fixed-base sums too: its even folded slots as one more sum (prove_core.h: job_e, 25 terms) fused with the
+    // next round's X | R, its odd ones being that round's R.  That form wins while the variable-base one is a latency chain on an
+    // under-filled chip: up to 32 values per SIMD (2^14 values: 300 more table additions per level against 0.8 ms of chain, of which the
+    // helper stream hides a quarter: 10.5 -> 9.8 ms; 2^15: 17.65 -> 17.1; 2^16: 31.0 against 32.1, so not there).
+    w.next_by_msm = plan.next_by_msm ? 1 : 0;
     const unsigned fb64_blocks = (unsigned)((n * 64 + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     // The prover's fixed-base sums.  Lanes per proof: a wavefront in a small call; otherwise 8, 4 or 1 -- the fewest that still give
     // every SIMD two wavefronts in the launch (fewer lanes = fewer idle lanes in the short runs and a shorter tree of complete additions
@@ -500,9 +450,9 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
 #define PMSMX(NJ, ...)                                                                                                     \
     do {                                                                                                                    \
         MsmJobs js = {{__VA_ARGS__}};                                                                                        \
-        if (fb_wave) PLAUNCH(K_PROVE_MSM, k_prove_msm_l64x<<<dim3(fb64_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));          \
-        else if (fb_one_lane) PLAUNCH(K_PROVE_MSM, k_prove_msm_l1x<<<dim3(fb1_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));   \
-        else if ((size_t)(NJ) * 4 * n >= (size_t)128 * c->n_simds)                                                          \
+        if (plan.fb == bppp_host::FB_L64) PLAUNCH(K_PROVE_MSM, k_prove_msm_l64x<<<dim3(fb64_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));          \
+        else if (plan.fb == bppp_host::FB_L1) PLAUNCH(K_PROVE_MSM, k_prove_msm_l1x<<<dim3(fb1_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));   \
+        else if (plan.fb4_from_jobs && (NJ) >= plan.fb4_from_jobs)                                                          \
             PLAUNCH(K_PROVE_MSM, k_prove_msm_l4x<<<dim3((unsigned)((n * 4 + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK), NJ), BPPP_FB_BLOCK, 0, s>>>(w, js)); \
         else PLAUNCH(K_PROVE_MSM, k_prove_msm_x<<<dim3(fb_blocks, NJ), BPPP_FB_BLOCK, 0, s>>>(w, js));                       \
     } while (0)
@@ -517,23 +467,20 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     } while (0)
 #define PSECRET(job) PSECRETX(1, job, job, job, job)
     // a grid that gives every SIMD more than one wavefront runs the 256-register builds of the lane kernels (two wavefronts per SIMD)
-    const bool w2 = c->no_small || blocks > (unsigned)c->n_simds;
+    const bool w2 = plan.w2;
     PLAUNCH(K_PROVE_STAGES, k_prove_stage_a<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PSECRET(job_v());
     if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_b_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_b<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     PSECRETX(4, job_rcom(), job_co(), job_cl(), job_cr());
-    // a small call waits for one lane's chain: the stages' 16-term loops on sixteen lanes per value (prove_core.h: "lane forms")
-    const size_t lane_forms_max = c->lane_forms_max >= 0 ? (size_t)c->lane_forms_max : 4 * (size_t)c->n_simds;
-    const bool stage_lanes = !c->no_lane_groups && !c->no_split && !c->no_small && n <= lane_forms_max;
-    const bool fold_lanes = stage_lanes && w.next_by_msm;
+    // a small call waits for one lane's chain: the stages' 16-term loops on sixteen lanes per value (prove_core.h: "lane forms"), on four
+    // lanes per value while that still leaves SIMDs idle
+    using bppp_host::ST_G16; using bppp_host::ST_G16_W2; using bppp_host::ST_G4; using bppp_host::ST_G4_W2;
+    const bool stage_lanes = plan.stage == ST_G16 || plan.stage == ST_G16_W2, g16_w2 = plan.stage == ST_G16_W2 || plan.fold == ST_G16_W2;
+    const bool stage_lanes4 = plan.stage == ST_G4 || plan.stage == ST_G4_W2, g4_w2 = plan.stage == ST_G4_W2 || plan.fold == ST_G4_W2;
+    const bool fold_lanes = plan.fold == ST_G16 || plan.fold == ST_G16_W2, fold_lanes4 = plan.fold == ST_G4 || plan.fold == ST_G4_W2;
     const unsigned g16_blocks = (unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
-    const bool g16_w2 = g16_blocks > (unsigned)c->n_simds;
-    // ... and on four lanes per value while that still leaves SIMDs idle
-    const bool stage_lanes4 = !stage_lanes && !c->no_lane_groups && !c->no_split && n <= (c->lane4_max >= 0 ? (size_t)c->lane4_max : 16 * (size_t)c->n_simds);
     const unsigned g4_blocks = (unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
-    const bool g4_w2 = c->no_small || g4_blocks > (unsigned)c->n_simds;
-    const bool fold_lanes4 = stage_lanes4 && w.next_by_msm;
     if (stage_lanes && g16_w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_g16_w2<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w));
     else if (stage_lanes) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_g16<<<g16_blocks, BPPP_BLOCK, 0, s>>>(w));
     else if (stage_lanes4 && g4_w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_d_g4<2><<<g4_blocks, BPPP_BLOCK, 0, s>>>(w));
@@ -549,8 +496,7 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     // (the lane-per-generator form of the scalar kernel pays only while the chip is empty: at 2^13 ... 2^15 values it costs 1.2 / 2.3 /
     // 4.5 ms per batch against 0.8: profiles/r04_r_size_probe_wide_scalars.txt)
-    const bool scal_wide = fb_wave;
-    const bool scal_parts = !scal_wide && !c->no_split && n <= (c->scal_parts_max >= 0 ? (size_t)c->scal_parts_max : 128 * (size_t)c->n_simds);
+    const bool scal_wide = plan.scalars == bppp_host::SC_WIDE, scal_parts = plan.scalars == bppp_host::SC_PARTS;
     bool pending_cnext = false;
     // Beyond the sizes of next_by_msm: round k's next commitment C_k (prove_core.h: prove_round_next -- window tables of X and R and a
     // two-point GLV Straus sum, 125 dependent doublings) is not needed before round k + 1 appends it to the transcript: it runs on the
@@ -558,11 +504,10 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     // On the helper stream it runs in its 256-register build: the uncapped one leaves no room on its SIMDs for a wavefront of the sums
     // it is meant to run under (profiles/r04_zd_prove_next_overlap_probe.txt).  (With per-kernel timing on it stays on the main stream
     // so that the kernel times add up to the step.)
-    const bool overlap_next = c->next_overlap >= 0 ? c->next_overlap == 1 : 4 * (size_t)blocks >= (size_t)c->n_simds;
-    hipStream_t a = (c->timing || !overlap_next) ? s : c->aux_stream;
+    hipStream_t a = plan.overlap_next ? c->aux_stream : s;
     bool next_in_flight = false;
     for (int k = 1; k <= 4; k++) {
-        if (k > 1 && (fold_lanes || fold_lanes4)) {}       // the previous round's lane-form fold left this round's scalars (prove_core.h: prove_round_fold_lanes*)
+        if (k > 1 && plan.fold_leaves_scalars) {}       // the previous round's lane-form fold left this round's scalars (prove_core.h: prove_round_fold_lanes*)
         else if (scal_wide) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_wide<<<(unsigned)((64 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k));
         else if (scal_parts) PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars_parts<<<dim3(blocks, 4), BPPP_BLOCK, 0, s>>>(w, k));
         else PLAUNCH(K_PROVE_ROUND_SCALARS, k_prove_round_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
@@ -577,7 +522,7 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
         else PLAUNCH(K_PROVE_ROUND_FOLD, k_prove_round_fold<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         if (!w.next_by_msm && k < 4) {
             if (a != s) { HIP_TRY(hipEventRecord(c->ev_fork, s)); HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0)); }
-            const bool next_g4 = !c->no_lane_groups && 4 * (size_t)blocks <= (size_t)c->n_simds;      // (only with BPPP_NEXT_MSM_MAX lowered: A/B runs)
+            const bool next_g4 = plan.next_g4;      // (only with BPPP_NEXT_MSM_MAX lowered: A/B runs)
             if (next_g4 && a != s)
                 rc = timed(c, K_PROVE_ROUND_NEXT, a, [&]() { k_prove_round_next_g4_w2<<<(unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, a>>>(w, k); });
             else if (next_g4)

@@ -144,6 +144,7 @@ public:
         for (int k = 0; k < shape_.n_in; k++) std::memcpy(b->in[k] + (size_t)slot * shape_.in_stride[k], in[k], shape_.in_stride[k]);
         b->filled.fetch_add(1, std::memory_order_release);
         std::atomic<uint32_t>& word = b->done_gen[slot % DONE_WORDS];
+        if (test_bump_delay_us_) std::this_thread::sleep_for(std::chrono::microseconds(test_bump_delay_us_ / 2));     // (a caller late to its wait)
         while (word.load(std::memory_order_acquire) == gen) futex_wait_u32(&word, gen);
         const int rc = b->rc;
         if (rc != 0) be_->set_last_error(b->err);
@@ -153,9 +154,7 @@ public:
         // only the batch's last reader takes the lock again
         if (b->readers.fetch_sub(1, std::memory_order_acq_rel) == 1) {
             std::lock_guard<std::mutex> lk(mu_);
-            b->state = FREE;
-            if (is_none(ticket_.load(std::memory_order_relaxed)) && !stopping_.load()) open_locked(bidx);
-            cv_space_.notify_all();
+            release_locked(bidx);
         }
         callers_inside_.fetch_sub(1, std::memory_order_release);      // the caller's last touch of this object (shutdown polls the counter)
         return rc;
@@ -196,6 +195,8 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         return stats_;
     }
+    // testing aid (tests/emul/coalesce_stress.cpp): a dispatcher pre-empted between two completion words, made certain instead of rare
+    void set_test_bump_delay_us(int us) { test_bump_delay_us_ = us; }
     size_t max_batch() const { return max_; }
     int lanes() const { return lanes_; }
 
@@ -261,7 +262,9 @@ private:
         Batch& b = *batches_[idx];
         b.count = cnt;
         b.state = READY;
-        b.readers.store(cnt, std::memory_order_relaxed);
+        // the rows' callers + the dispatcher that will run the batch: the staging set cannot be re-opened before the dispatcher has
+        // bumped ALL of its completion words (a caller of the next use must never snapshot a word the previous use still has to bump)
+        b.readers.store((size_t)cnt + 1, std::memory_order_release);
         ready_.push_back(idx);
         stats_.requests += cnt;
         stats_.batches++;
@@ -293,6 +296,12 @@ private:
             if (f >= 0) { open_locked(f); return; }
             cv_space_.wait(lk);
         }
+    }
+    // the batch's last reference is gone (mu_ held): the staging set is free, and becomes the open batch if there is none
+    void release_locked(int idx) {
+        batches_[idx]->state = FREE;
+        if (is_none(ticket_.load(std::memory_order_relaxed)) && !stopping_.load()) open_locked(idx);
+        cv_space_.notify_all();
     }
     void free_all() {
         for (auto& bp : batches_) {
@@ -339,9 +348,13 @@ private:
             const auto t_done = std::chrono::steady_clock::now();
             if (rc != 0) { try { b.err = be_->last_error(); } catch (...) { b.err.clear(); } }
             b.rc = rc;
-            for (int w = 0; w < DONE_WORDS; w++) b.done_gen[w].fetch_add(1, std::memory_order_release);
+            for (int w = 0; w < DONE_WORDS; w++) {
+                b.done_gen[w].fetch_add(1, std::memory_order_release);
+                if (test_bump_delay_us_ && w + 1 < DONE_WORDS) std::this_thread::sleep_for(std::chrono::microseconds(test_bump_delay_us_));
+            }
             for (int w = 0; w < DONE_WORDS && (size_t)w < n; w++) futex_wake_all_u32(&b.done_gen[w]);
             lk.lock();
+            if (b.readers.fetch_sub(1, std::memory_order_acq_rel) == 1) release_locked(idx);      // the dispatcher's own reference
             stats_.fill_wait_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t_run - t_seal).count();
             stats_.run_us += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(t_done - t_run).count();
         }
@@ -372,6 +385,7 @@ private:
     alignas(64) std::atomic<size_t> callers_inside_{0};
     std::vector<std::thread> threads_;
     CoalesceStats stats_;
+    int test_bump_delay_us_ = 0;
 };
 
 }  // namespace bppp_host

@@ -46,6 +46,21 @@ public:
         cv_.wait(lk, [&] { return generation_ != gen; });
         return result_;
     }
+    // A vote cast on behalf of a party that does not exist as a thread (a rank whose thread could not be started): recorded without
+    // waiting for the others, so one thread can cast several -- arrive() from the main thread blocked at the first of two missing ranks,
+    // which only the same thread could have voted in.
+    void post(int rank, int code) {
+        std::lock_guard<std::mutex> lk(mu_);
+        codes_[rank] = code;
+        if (++arrived_ == parties_) {
+            result_ = 0;
+            for (int c : codes_)
+                if (c != 0) { result_ = c; break; }
+            arrived_ = 0;
+            generation_++;
+            cv_.notify_all();
+        }
+    }
 
 private:
     std::mutex mu_;
@@ -70,7 +85,7 @@ struct ShardedResult {
 // has to be released by the thread that took it).
 template <class Enter, class Prepare, class Collective, class Finish, class Drain, class Abort, class Leave, class LastError>
 ShardedResult run_sharded(int G, Enter&& enter, Prepare&& prepare, Collective&& collective, Finish&& finish, Drain&& drain, Abort&& abort,
-                          Leave&& leave, LastError&& last_error) {
+                          Leave&& leave, LastError&& last_error, int fail_thread_start_at = -1 /* testing aid: that rank's thread "cannot be started" */) {
     ShardedResult res;
     std::vector<int> rcs(G, 0);
     std::vector<std::string> errs(G);
@@ -122,13 +137,17 @@ ShardedResult run_sharded(int G, Enter&& enter, Prepare&& prepare, Collective&& 
         int started = 0;
         try {
             th.reserve(G);
-            for (; started < G; started++) th.emplace_back(rank_main, started);
+            for (; started < G; started++) {
+                if (started == fail_thread_start_at) throw std::bad_alloc();
+                th.emplace_back(rank_main, started);
+            }
         } catch (...) {
-            // could not start every rank: the missing ranks vote "failed" from here, so that the ones running leave their votes
+            // could not start every rank: the missing ranks vote "failed" from here (without waiting: there may be several of them and
+            // this is the only thread that can cast their votes), so the ranks that run see a failed first vote, drain and leave
             for (int r = started; r < G; r++) {
                 errs[r] = "could not start a rank thread";
                 rcs[r] = kShardErrNoMem;
-                if (vote1.arrive(r, kShardErrNoMem) == 0) (void)vote2.arrive(r, kShardErrNoMem);
+                vote1.post(r, kShardErrNoMem);
             }
         }
         for (auto& t : th) t.join();

@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +48,9 @@ static const char* const kKernelNames[K_COUNT] = {
     "k_wnla_msm", "k_wnla_accept", "k_wnla_rlc_lhs", "k_wnla_rlc_chunk", "k_wnla_rlc_check", "k_wnla_tables"};
 
 static inline size_t align16(size_t x) { return (x + 15) / 16 * 16; }
+// a transcript label as the ABI takes it: a null pointer only with length 0, and no longer than merlin can frame (its length prefix is a
+// u32: `Transcript::append_message` asserts that; here the call returns BPPP_ERR_INVALID_ARG instead of hashing a truncated length)
+static inline bool label_ok(const uint8_t* label, size_t label_len) { return (label || !label_len) && label_len <= 0xFFFFFFFFu; }
 
 struct TimedLaunch { int id; hipEvent_t a, b; };
 
@@ -57,12 +62,6 @@ struct bppp_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;   // runs the fixed-base half of C0 concurrently with the variable-base half
-    // Large exact-mode verify batches run as two halves on two stream pairs (bppp_u64.hip: verify_twin): the second half on this child
-    // context (bppp_ctx_create_shared: own streams and workspaces, these tables), created at the first such call
-    struct bppp_ctx* twin = nullptr;
-    hipEvent_t ev_twin_fork = nullptr, ev_twin_join = nullptr;
-    bool two_stream_halves = false;      // option "two_stream_halves": from 256 proofs per SIMD (2^18) on
-    int twin_mode = -1;          // diagnostic BPPP_TWIN (tests): 1 = from 128 proofs on whatever the option says, 0 = never
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_tab = nullptr;
     hipStream_t copy_stream = nullptr;  // host-buffer entry points: uploads chunk k + 1 while chunk k is being verified (created on first use)
     hipEvent_t ev_copy = nullptr;
@@ -131,7 +130,11 @@ struct bppp_ctx {
     long lane_forms_max = -1, next_msm_max = -1;   // diagnostics BPPP_LANE_FORMS_MAX / BPPP_NEXT_MSM_MAX: largest prove call on the 16-lane stage / fold kernels, on the fixed-base next commitment (-1 = by n_simds)
     int fb_one_lane_mode = -1;   // diagnostic BPPP_FB_ONE_LANE: 1 = one lane per proof in the u64 verifier's fixed-base kernels at every size, 0 = never, unset = by size   // diagnostics, read from the environment once at context creation
     // single-proof front end (bppp_coalesce.hip): created at the first *_one call; options "coalesce_max" / "coalesce_us" / "coalesce_lanes"
-    struct bppp_fronts* fronts = nullptr;
+    uint32_t last_verify_plan = 0, last_prove_plan = 0;      // plan_core.h: the kernels the context's last u64 verify / prove call (or part) ran
+    struct bppp_fronts* fronts = nullptr;      // lives until the context itself is deleted (closure is sticky: never re-created once closed)
+    std::atomic<bool> fronts_closed{false};    // set by bppp_ctx_destroy before it drains: *_one callers return BPPP_ERR_CLOSED instead of retrying
+    std::atomic<int> one_callers{0};           // threads inside a *_one entry point (counted before they touch anything else of the context);
+                                               // bppp_ctx_destroy frees nothing before the count is back to zero
     long coalesce_max = 1024, coalesce_us = 100;
     int coalesce_lanes = 2;
     std::vector<TimedLaunch> pending;
@@ -171,10 +174,6 @@ static inline int ensure_blob(bppp_ctx* c, size_t bytes) { return ensure_buffer(
 // after a failed call: nothing of it may still be running when the entry point returns (the staging is reused by the next call, and
 // copies from / to the caller's memory may be queued) -- what the implicit synchronisation of a per-call hipFree used to provide
 static inline void quiesce(bppp_ctx* c) {
-    if (c->twin) {
-        if (c->twin->stream) (void)hipStreamSynchronize(c->twin->stream);
-        if (c->twin->aux_stream) (void)hipStreamSynchronize(c->twin->aux_stream);
-    }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
@@ -396,6 +395,10 @@ static inline int check_device(int device) {
 int ensure_ct_table(bppp_ctx* c);
 // bppp_coalesce.hip: drain and drop the context's single-proof front ends (final: refuse later *_one calls with BPPP_ERR_CLOSED)
 void bppp_fronts_teardown(bppp_ctx* c, bool final);
+void bppp_fronts_delete(bppp_ctx* c);      // bppp_ctx_destroy only, after the final teardown: frees the (closed, empty) bppp_fronts object
+// what a child context takes from its parent besides the immutable tables: read under the parent's lock by whoever creates the child
+struct CtShare { apt_packed* d_table_ct; bool ct_prover; };
+int ctx_create_shared_with(bppp_ctx** out, bppp_ctx* parent, const CtShare& ct);
 
 // ---- launch sequences used across translation units (hidden symbols; C linkage only because their definitions sit inside the
 //      extern "C" blocks of the entry points they serve)

@@ -383,14 +383,55 @@ HD void fb_order_after(u32 k[8], const ptz& a) {
     (void)a;
 #endif
 }
-struct FbStep {          // where step i's table entry lives, and how to use it
-    size_t addr;
+// Geometry of a table, derived ONCE per sum: inside the loops below a digit is a shift and a mask of a scalar that was recoded when
+// its first window was reached, and a table address is an increment -- no division, no per-window recoding, no choice by window
+// width (round 4's loop made that choice per step: 12.8 % of its dynamic instructions were scalar-unit bookkeeping).
+struct FbGeom {
+    int W, nwin;           // window width; windows of a full-width scalar
+    u32 mask, half;        // 2^W - 1; 2^(W-1) for signed digits (the digit is field - half), 0 for unsigned ones
+    size_t per_win;        // entries per window
+    u32 off[9];            // signed digits: sum_i 2^(W-1 + W i) -- k + off carries digit + 2^(W-1) in every W-bit field
+};
+HD void fb_geom(FbGeom& g, int W) {
+    g.W = W;
+    g.nwin = fb_nwin(W);
+    g.per_win = fb_per_win(W);
+    g.mask = (1u << W) - 1u;
+    g.half = fb_signed(W) ? (1u << (W - 1)) : 0u;
+#pragma unroll
+    for (int l = 0; l < 9; l++) g.off[l] = 0;
+    if (fb_signed(W)) {
+#pragma nounroll
+        for (int i = 0; i < g.nwin; i++) {
+            const int bit = W - 1 + W * i;
+#pragma unroll
+            for (int l = 0; l < 9; l++) g.off[l] |= (l == (bit >> 5)) ? (1u << (bit & 31)) : 0u;
+        }
+    }
+}
+HD void fb_recode(u32 kp[9], const u32 k[8], const FbGeom& g) {      // kp = k + off, 9 limbs (< 2^264)
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) kp[i] = addc(k[i], g.off[i], c);
+    kp[8] = g.off[8] + c;
+}
+HD u32 funnel_shr(u32 hi, u32 lo, int sh) {      // low word of (hi:lo) >> sh, 0 < sh < 32: one v_alignbit_b32
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, (u32)sh);
+#else
+    return (u32)((((u64)hi << 32) | lo) >> sh);
+#endif
+}
+struct FbStep {          // where a step's table entry lives, and how to use it
+    const apt_packed* ptr;
     bool skip, neg;
 };
-HD void fb_step_from_scalar(FbStep& st, const FbTable& fbt, const u32 k[8], int base, int w) {
-    size_t idx;
-    fb_digit(k, fbt.W, w, idx, st.skip, st.neg);
-    st.addr = ((size_t)base * fb_nwin(fbt.W) + w) * fb_per_win(fbt.W) + idx;
+HD void fb_step_from_field(FbStep& st, const apt_packed* win, u32 field, const FbGeom& g) {
+    const int d = (int)field - (int)g.half;
+    const u32 mag = (u32)(d < 0 ? -d : d);
+    st.skip = mag == 0;
+    st.neg = d < 0;
+    st.ptr = win + (mag ? mag - 1u : 0u);
 }
 HD void fb_consume_fast(ptz& acc, bool& empty, const apt_packed& pe, bool skip, bool neg) {
     apt e;
@@ -401,53 +442,127 @@ HD void fb_consume_fast(ptz& acc, bool& empty, const apt_packed& pe, bool skip, 
     fe_cmov(e.y, neg, ny);
     ptz_madd(acc, empty, e, skip | id);
 }
-HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, size_t t, int lane, const u32* scal, int first_slot,
-                                int first_base, int count, int nl = BPPP_FB_LANES, int bits = 0, int oddsh = -1) {
-    const int nwin = fb_windows_for(bits, fbt.W);
-    // step i of this lane -> (base j, window w): windows congruent to the lane when they divide evenly, else the
-    // (base, window) pairs dealt round-robin (13 windows do not divide over 8 lanes)
-    const bool by_window = (nwin % nl) == 0;
-    const int per_base = nwin / nl;
-    const int steps = by_window ? count * per_base : (count * nwin - lane + nl - 1) / nl;
+// One lane per sum (nl == 1, every batch from 2^17 proofs up): the lane walks a scalar's windows in order, so the recoded scalar is
+// a shift register -- recoded when the producer reaches the term, shifted right by W per step.  Term and window are wave-uniform
+// here: the window's base address lives in scalar registers and moves by per_win entries per step.
+HD void fb_lane_accumulate_seq(ptz& acc, bool& empty, const FbTable& fbt, const FbGeom& g, size_t t, const u32* scal, int first_slot,
+                               int first_base, int count, int bits, int oddsh) {
+    const int nw = fb_windows_for(bits, g.W);          // windows walked per scalar
+    const int steps = count * nw;
     if (steps <= 0) return;
-    auto locate = [&](int i, int& j, int& w) {      // steps past the end re-use the last one (requested, never consumed)
-        if (i > steps - 1) i = steps - 1;
-        int a;                                      // the step's term, counted among the PRESENT terms of the run
-        if (by_window) {
-            a = i / per_base;
-            w = lane + nl * (i - a * per_base);
-        } else {
-            const int q = lane + nl * i;
-            a = q / nwin;
-            w = q - a * nwin;
+    const size_t base_stride = (size_t)g.nwin * g.per_win;
+    // the producer hands out window pw of term pa next; past the last term it walks the last term again (requested, never consumed)
+    int pa = 0, pw = 0;
+    int j = fb_term_index(0, oddsh), jn = fb_term_index(count > 1 ? 1 : 0, oddsh);
+    const apt_packed* win = fbt.table + (size_t)(first_base + j) * base_stride;
+    u32 k[8], kp[9];
+    ws_ld8(k, scal, fbt.N, t, first_slot + j);
+    fb_recode(kp, k, g);
+    auto produce = [&](FbStep& st) {
+        if (pw == nw) {          // the scalar words of term jn were requested at the top of this step
+            pa = pa + 1 < count ? pa + 1 : count - 1;
+            j = jn;
+            jn = fb_term_index(pa + 1 < count ? pa + 1 : count - 1, oddsh);
+            win = fbt.table + (size_t)(first_base + j) * base_stride;
+            fb_recode(kp, k, g);
+            pw = 0;
         }
-        j = fb_term_index(a, oddsh);
+        fb_step_from_field(st, win, kp[0] & g.mask, g);
+#pragma unroll
+        for (int i = 0; i < 8; i++) kp[i] = funnel_shr(kp[i + 1], kp[i], g.W);
+        kp[8] >>= g.W;
+        win += g.per_win;
+        pw++;
     };
-    int j, w, j2, w2;
-    u32 k[8];
     FbStep cur_st, nxt_st;
     apt_packed cur_e, nxt_e;
-    // prologue: entry of step 0, address of step 1
-    locate(0, j, w);
-    ws_ld8(k, scal, fbt.N, t, first_slot + j);
-    fb_step_from_scalar(cur_st, fbt, k, first_base + j, w);
-    cur_e = fbt.table[cur_st.addr];
-    locate(1, j, w);
-    ws_ld8(k, scal, fbt.N, t, first_slot + j);
-    fb_step_from_scalar(nxt_st, fbt, k, first_base + j, w);
+    produce(cur_st);
+    cur_e = *cur_st.ptr;
+    ws_ld8(k, scal, fbt.N, t, first_slot + jn);
+    produce(nxt_st);
 #pragma nounroll
     for (int i = 0; i < steps; i++) {
-        nxt_e = fbt.table[nxt_st.addr];                         // step i+1's entry
-        locate(i + 2, j2, w2);
-        ws_ld8(k, scal, fbt.N, t, first_slot + j2);             // step i+2's scalar
+        nxt_e = *nxt_st.ptr;                                    // step i+1's entry
+        ws_ld8(k, scal, fbt.N, t, first_slot + jn);             // the producer's next scalar (used when step i+2 starts a term)
         fb_sched_fence();
         fb_consume_fast(acc, empty, cur_e, cur_st.skip, cur_st.neg);
         fb_order_after(k, acc);
         cur_e = nxt_e;
         cur_st = nxt_st;
-        fb_step_from_scalar(nxt_st, fbt, k, first_base + j2, w2);
+        produce(nxt_st);
     }
 }
+// nl lanes per sum: lane `lane` takes the (term, window) pairs lane, lane + nl, lane + 2 nl, ... of the run (pairs counted window-fastest),
+// so term and window differ from lane to lane: the step's scalar is recoded and its field picked by selects, the pair advances by
+// (nl div nw, nl mod nw) with one conditional carry.
+HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, const FbGeom& g, size_t t, int lane, const u32* scal,
+                                int first_slot, int first_base, int count, int nl, int bits, int oddsh) {
+    if (nl == 1) {
+        fb_lane_accumulate_seq(acc, empty, fbt, g, t, scal, first_slot, first_base, count, bits, oddsh);
+        return;
+    }
+    const int nw = fb_windows_for(bits, g.W);
+    const int pairs = count * nw;
+    if (lane >= pairs) return;
+    const int steps = (pairs - lane + nl - 1) / nl;
+    const int da = nl / nw, dw = nl - da * nw;
+    int a = lane / nw, w = lane - a * nw;
+    auto advance = [&]() {      // steps past the end re-use the last one (requested, never consumed)
+        int na = a + da, nwn = w + dw;
+        if (nwn >= nw) { nwn -= nw; na++; }
+        const bool in = na < count;
+        a = in ? na : a;
+        w = in ? nwn : w;
+    };
+    auto produce = [&](FbStep& st, const u32 k[8]) {      // k: the scalar of term a
+        u32 kp[10];
+        fb_recode(kp, k, g);
+        kp[9] = 0;
+        const int bit = g.W * w, li = bit >> 5, sh = bit & 31;
+        u32 lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { lo = (i == li) ? kp[i] : lo; hi = (i == li) ? kp[i + 1] : hi; }
+        const u32 field = (u32)((((u64)hi << 32) | lo) >> sh) & g.mask;
+        const int j = fb_term_index(a, oddsh);
+        fb_step_from_field(st, fbt.table + ((size_t)(first_base + j) * g.nwin + w) * g.per_win, field, g);
+    };
+    u32 k[8];
+    FbStep cur_st, nxt_st;
+    apt_packed cur_e, nxt_e;
+    // prologue: entry of step 0, address of step 1
+    ws_ld8(k, scal, fbt.N, t, first_slot + fb_term_index(a, oddsh));
+    produce(cur_st, k);
+    cur_e = *cur_st.ptr;
+    advance();
+    ws_ld8(k, scal, fbt.N, t, first_slot + fb_term_index(a, oddsh));
+    produce(nxt_st, k);
+    advance();
+#pragma nounroll
+    for (int i = 0; i < steps; i++) {
+        nxt_e = *nxt_st.ptr;                                                    // step i+1's entry
+        ws_ld8(k, scal, fbt.N, t, first_slot + fb_term_index(a, oddsh));        // step i+2's scalar
+        fb_sched_fence();
+        fb_consume_fast(acc, empty, cur_e, cur_st.skip, cur_st.neg);
+        fb_order_after(k, acc);
+        cur_e = nxt_e;
+        cur_st = nxt_st;
+        produce(nxt_st, k);
+        advance();
+    }
+}
+// The lane sums start from a fixed point T (x from SHA-256 of "bp_pp_amd fixed-base accumulator offset 1") instead of an empty
+// accumulator and take it off again at the end with one complete addition: the incomplete law then never sees an empty operand, and
+// the four selects per addition that the "first point" case cost are gone.  (Should a sum ever pass through -T or T, ZZ = 0 reports
+// it like any other exceptional addition and the complete path re-does the sum.)  A whole wavefront per sum (nl = 64: a handful of
+// additions per lane) keeps the empty start: there the extra addition would cost more than the selects.
+HD void fb_offset_point(apt& T, bool negated) {
+    const u32 X[8] = {0x3003A5ABu, 0x0CC9A3AFu, 0xC7A4AC74u, 0xB36E34E9u, 0xF816F85Eu, 0xC7857C12u, 0x72CF9444u, 0x39DE2EB9u};
+    const u32 Y[8] = {0x186C3A6Cu, 0x93FE7D16u, 0x02363020u, 0x24F39B91u, 0x0E9EDE9Fu, 0x61EC1755u, 0x8C1AFEDBu, 0x8F845346u};
+    const u32 NY[8] = {0xE793C1C3u, 0x6C0182E8u, 0xFDC9CFDFu, 0xDB0C646Eu, 0xF1612160u, 0x9E13E8AAu, 0x73E50124u, 0x707BACB9u};
+    fe_from_w8(T.x, X);
+    fe_from_w8(T.y, negated ? NY : Y);
+}
+HD bool fb_offset_start(int nl) { return nl < 64; }
 HD bool fb_lane_finish_fast(pt& part, const ptz& acc, bool empty) {
     const bool exceptional = !empty && fe_is_zero(acc.ZZ);
     ptz_to_pt(part, acc, empty);
@@ -482,12 +597,27 @@ HD void fb_lane_sum_complete(pt& part, const FbTable& fbt, size_t t, int lane, c
     part = acc;
 }
 HD bool fb_lane_sum_fast(pt& part, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg, int nl = BPPP_FB_LANES) {
+    FbGeom g;
+    fb_geom(g, fbt.W);
     ptz acc;
     ptz_init(acc);
     bool empty = true;
+    if (fb_offset_start(nl)) {
+        apt T;
+        fb_offset_point(T, false);
+        acc.X = T.x;
+        acc.Y = T.y;
+        empty = false;
+    }
 #pragma nounroll
-    for (int r = 0; r < rg.n; r++) fb_lane_accumulate_fast(acc, empty, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r], nl, rg.bits[r], rg.oddsh[r]);
-    return fb_lane_finish_fast(part, acc, empty);
+    for (int r = 0; r < rg.n; r++) fb_lane_accumulate_fast(acc, empty, fbt, g, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r], nl, rg.bits[r], rg.oddsh[r]);
+    const bool ok = fb_lane_finish_fast(part, acc, empty);
+    if (fb_offset_start(nl)) {
+        apt T;
+        fb_offset_point(T, true);
+        pt_madd(part, part, T, false);
+    }
+    return ok;
 }
 // single-thread form of the group sum (host emulation, and device code that runs one thread per proof)
 HD void fb_sum_serial(pt& total, const FbTable& fbt, size_t t, const u32* scal, const FbRanges& rg, int nl = BPPP_FB_LANES) {

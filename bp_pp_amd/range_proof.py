@@ -45,6 +45,19 @@ def ctx_timings(ctx, reset: bool = True) -> dict:
     return {names[i].decode(): {"total_ms": ms[i], "launches": cnt[i]} for i in range(k)}
 
 
+def describe_plan(code: int, prove: bool = False) -> str:
+    """Text form of a plan code (bppp_plan_describe)."""
+    buf = C.create_string_buffer(256)
+    _capi.check(_capi.lib().bppp_plan_describe(int(code), 1 if prove else 0, buf, len(buf)))
+    return buf.value.decode()
+
+
+def plan_for(n: int, prove: bool = False, n_simds: int = 1024, rlc_or_ct: bool = False, timing: bool = False) -> str:
+    """The launch sequence a call of n proofs takes on a device of n_simds SIMDs (bppp_u64_plan: a pure function, no GPU needed)."""
+    code = _capi.check(_capi.lib().bppp_u64_plan(1 if prove else 0, int(n), int(n_simds), (1 if rlc_or_ct else 0) | (2 if timing else 0)))
+    return describe_plan(code, prove)
+
+
 class U64RangeProofProtocol:
     """Public parameters g, g_vec[16], h_vec[32] (u64_proof.rs:19-28) resident on one GPU."""
 
@@ -124,12 +137,15 @@ class U64RangeProofProtocol:
         threads have submitted and runs as part of one batched GPU call.  `transcript`: a label (bytes: Transcript::new(label)) or
         a bp_pp_amd.transcript.Transcript, which is advanced in place as the reference's `t: &mut Transcript` is.
         Returns (accept, status).  Blocking; ctypes releases the GIL while it waits."""
+        v, proof = bytes(v), bytes(proof)
+        if len(v) != 64 or len(proof) != U64_PROOF_BYTES:      # the C side copies exactly this many bytes from the pointers it is handed
+            raise ValueError(f"commitment is 64 bytes and a u64 proof {U64_PROOF_BYTES} bytes (got {len(v)}, {len(proof)})")
         acc, st = C.c_uint8(0), C.c_int32(0)
         L = _capi.lib()
         if isinstance(transcript, (bytes, bytearray)):
-            _capi.check(L.bppp_u64_verify_one(self._ctx, bytes(transcript), len(transcript), bytes(v), bytes(proof), C.byref(acc), C.byref(st)))
+            _capi.check(L.bppp_u64_verify_one(self._ctx, bytes(transcript), len(transcript), v, proof, C.byref(acc), C.byref(st)))
         else:
-            _capi.check(L.bppp_u64_verify_one_transcript(self._ctx, transcript._buf, bytes(v), bytes(proof), C.byref(acc), C.byref(st)))
+            _capi.check(L.bppp_u64_verify_one_transcript(self._ctx, transcript._buf, v, proof, C.byref(acc), C.byref(st)))
         return bool(acc.value), int(st.value)
 
     def prove_one(self, x: int, s: bytes, transcript, rnd: bytes) -> Tuple[bytes, bytes, int]:
@@ -291,13 +307,17 @@ class U64RangeProofProtocol:
     def set_option(self, name: str, value: int) -> None:
         """include/bppp.h: bppp_ctx_set_option ("rlc_superchunk": 0 = bucket stage off, else 64..8192; "host_chunk": proofs per
         pipelined upload chunk of the host-buffer verify calls, 0 = upload first; "coalesce_max" / "coalesce_us" / "coalesce_lanes":
-        the single-proof front end of verify_one / prove_one; "two_stream_halves": exact-mode verify batches of >= 2^18 proofs as two halves
-        on two stream pairs)."""
+        the single-proof front end of verify_one / prove_one)."""
         _capi.check(_capi.lib().bppp_ctx_set_option(self._ctx, name.encode(), int(value)))
 
     def get_option(self, name: str) -> int:
         """bppp_ctx_get_option: a tunable read back, or "fb_window_bits" (the table width in use), "device", "n_generators"."""
         return int(_capi.check(_capi.lib().bppp_ctx_get_option(self._ctx, name.encode())))
+
+    def last_plan(self, prove: bool = False) -> str:
+        """Which kernels the context's last u64 verify (or prove) call ran, as text (include/bppp.h: "last_verify_plan" / "last_prove_plan"
+        + bppp_plan_describe) -- e.g. "phase1=wg4 tables=beside/1 fb=l8 c0var=small round=small tail_beside=1 small=1 split=0"."""
+        return describe_plan(self.get_option("last_prove_plan" if prove else "last_verify_plan"), prove)
 
     def synchronize(self) -> None:
         """Block until everything queued on the context's current stream (and its helper stream) has finished."""

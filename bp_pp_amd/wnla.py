@@ -214,14 +214,18 @@ class ReciprocalRangeProofProtocol:
         bppp_reciprocal_verify_one[_transcript]).  `transcript`: a label (bytes) or a bp_pp_amd.transcript.Transcript (advanced in
         place).  -> (accept, status)"""
         import ctypes as C
+        commitment, proof = bytes(commitment), bytes(proof)
+        want = 64 * (5 + 2 * rounds) + 32 * (nl + nn)      # what the C side reads from the proof pointer (include/bppp.h)
+        if len(commitment) != 64 or len(proof) != want:
+            raise ValueError(f"commitment is 64 bytes and this shape's proof {want} bytes (got {len(commitment)}, {len(proof)})")
         acc, st = C.c_uint8(0), C.c_int32(0)
         L = _capi.lib()
         if isinstance(transcript, (bytes, bytearray)):
-            _capi.check(L.bppp_reciprocal_verify_one(self._w._ctx, bytes(transcript), len(transcript), self.dim_nd, self.dim_np, bytes(commitment),
-                                                     bytes(proof), rounds, nl, nn, C.byref(acc), C.byref(st)))
+            _capi.check(L.bppp_reciprocal_verify_one(self._w._ctx, bytes(transcript), len(transcript), self.dim_nd, self.dim_np, commitment,
+                                                     proof, rounds, nl, nn, C.byref(acc), C.byref(st)))
         else:
-            _capi.check(L.bppp_reciprocal_verify_one_transcript(self._w._ctx, transcript._buf, self.dim_nd, self.dim_np, bytes(commitment),
-                                                                bytes(proof), rounds, nl, nn, C.byref(acc), C.byref(st)))
+            _capi.check(L.bppp_reciprocal_verify_one_transcript(self._w._ctx, transcript._buf, self.dim_nd, self.dim_np, commitment,
+                                                                proof, rounds, nl, nn, C.byref(acc), C.byref(st)))
         return bool(acc.value), int(st.value)
 
     def verify_batch_device(self, label: bytes, n: int, d_commitments: int, d_proofs: int, rounds: int, nl: int, nn: int, d_accept: int,

@@ -29,6 +29,8 @@ extern "C" {
     pub fn bppp_ctx_set_stream(ctx: *mut BpppCtx, hip_stream: *mut c_void) -> c_int;
     pub fn bppp_ctx_set_option(ctx: *mut BpppCtx, name: *const c_char, value: c_long) -> c_int;
     pub fn bppp_ctx_get_option(ctx: *mut BpppCtx, name: *const c_char) -> c_long;
+    pub fn bppp_u64_plan(prove: c_int, n: usize, n_simds: c_int, flags: c_int) -> c_long;
+    pub fn bppp_plan_describe(code: c_long, prove: c_int, buf: *mut c_char, cap: usize) -> c_int;
     pub fn bppp_ctx_synchronize(ctx: *mut BpppCtx) -> c_int;
     pub fn bppp_u64_verify_batch(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, commitments: *const u8, proofs: *const u8, accept: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_u64_verify_batch_device(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, d_commitments: *const c_void, d_proofs: *const c_void, d_accept: *mut c_void, d_status: *mut c_void, d_trace: *mut c_void, d_reject_count: *mut c_void) -> c_int;

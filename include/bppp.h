@@ -95,11 +95,6 @@ BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
  * the context stays usable; 0 clears it.  "max_batch": the u64 verify entry
  * points run a batch of more than max_batch proofs as consecutive parts of max_batch on the same stream, which bounds the per-proof
  * workspace (about 30 KB per proof) whatever n is -- a multiple of 64, >= 1024; default 2097152 (63 GB of workspace).
- * "two_stream_halves" = 1 (default 0): an exact-mode u64 verify batch of 2^18 proofs or more, up to max_batch, runs as two halves on two
- * stream pairs -- the second on an internal child context over the same tables, made at the first such call and released with this
- * context; results, order on the context's stream and the reject counter are those of one call, the two halves' workspaces together
- * are what one undivided batch would take; up to 3 % faster per batch where the process's streams do not already share the GPU's
- * four hardware queues, nothing otherwise.
  * "ct_prover" = 1: the u64 prover's and committer's sums over SECRET scalars (bppp_u64_prove_*, bppp_u64_commit_value_batch; the generic
  * provers and bppp_msm_batch are NOT covered) -- x, s, the reciprocals and every blinding draw, i.e. V, r_com, c_o, c_l, c_r, c_s --
  * run in a form with no secret-dependent address, branch or instruction count
@@ -111,9 +106,19 @@ BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
  * single-proof front end below (bppp_u64_verify_one / bppp_u64_prove_one); changing one drains the running front end. */
 BPPP_API int bppp_ctx_set_option(bppp_ctx* ctx, const char* name, long value);
 /* Reads a tunable back, or one of the read-only facts "fb_window_bits" (the width in use: the library's choice when the context was
- * created with 0), "device", "n_generators", "twin_context" (1 once a large batch has made the second stream pair).  Negative =
+ * created with 0), "device", "n_generators", "last_verify_plan" / "last_prove_plan" (the plan code -- see bppp_u64_plan -- of the
+ * context's last u64 verify / prove call, or of the last part of a call that ran in parts; 0 before the first).  Negative =
  * BPPP_ERR_INVALID_ARG (unknown name). */
 BPPP_API long bppp_ctx_get_option(bppp_ctx* ctx, const char* name);
+/* Which kernels a u64 verify (prove = 0) or prove (prove = 1) call of n proofs runs on a device of n_simds SIMDs (CUs x 4; MI355X: 1024):
+ * the size decides among seven (six) launch sequences, from a wavefront per sum for a handful of proofs to one lane per proof from 2^17
+ * on (csrc/plan_core.h lists them with their thresholds).  A pure function -- no device, no context; flags: bit 0 = RLC mode (verify) /
+ * "ct_prover" (prove), bit 1 = per-kernel timing on.  Returns the plan as a non-negative code whose fields bppp_plan_describe spells out
+ * ("phase1=wg4 tables=beside/1 fb=l8 c0var=small round=small tail_beside=1 small=1 split=0"), or BPPP_ERR_INVALID_ARG.  A context's
+ * diagnostic environment switches (BPPP_NO_SMALL_KERNELS etc.) are not visible here; "last_verify_plan" reports what really ran. */
+BPPP_API long bppp_u64_plan(int prove, size_t n, int n_simds, int flags);
+/* Text form of a plan code into buf (NUL-terminated, at most cap bytes); returns the length the full text needs, as snprintf does. */
+BPPP_API int bppp_plan_describe(long code, int prove, char* buf, size_t cap);
 /* Block the calling host thread until everything queued by this context (current stream + its helper stream) has finished. */
 BPPP_API int bppp_ctx_synchronize(bppp_ctx* ctx);
 

@@ -2,6 +2,7 @@
 // the HIP kernels call) with g++ and runs each "thread" in a CPU loop, so the kernel logic can be checked against the
 // oracle in the CPU-only test tier.  This is a development aid: the product library (libbppp_hip.so) never loads or
 // falls back to it, and fails loudly without a GPU.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -194,7 +195,13 @@ int emul_fb_msm(const uint8_t* table, int W, int first_base, int count, const ui
 }
 // the 8-lane form the device kernels use: XYZZ fast partial sums, complete-formula re-do when a lane reports an exceptional
 // addition.  *fell_back tells the test which path produced the result.
+int emul_fb_msm_lanes_nl(const uint8_t* table, int W, int first_base, int count, const uint8_t* k, uint8_t out[64], int* fell_back, int nl);
 int emul_fb_msm_lanes(const uint8_t* table, int W, int first_base, int count, const uint8_t* k, uint8_t out[64], int* fell_back) {
+    return emul_fb_msm_lanes_nl(table, W, first_base, count, k, out, fell_back, BPPP_FB_LANES);
+}
+// nl lanes per sum: 1 (the shift-register walk of the large batches), 8, 64 (a wavefront per sum: the accumulator starts empty there,
+// the other forms start from the offset point)
+int emul_fb_msm_lanes_nl(const uint8_t* table, int W, int first_base, int count, const uint8_t* k, uint8_t out[64], int* fell_back, int nl) {
     FbTable fbt;
     fbt.table = (const apt_packed*)table;
     fbt.W = W;
@@ -210,13 +217,13 @@ int emul_fb_msm_lanes(const uint8_t* table, int W, int first_base, int count, co
     pt acc, part;
     pt_set_identity(acc);
     bool ok = true;
-    for (int lane = 0; lane < BPPP_FB_LANES; lane++) {
-        ok &= fb_lane_sum_fast(part, fbt, 0, lane, scal.data(), rg);
+    for (int lane = 0; lane < nl; lane++) {
+        ok &= fb_lane_sum_fast(part, fbt, 0, lane, scal.data(), rg, nl);
         pt_add(acc, acc, part);
     }
     *fell_back = !ok;
     pt viaserial;
-    fb_sum_serial(viaserial, fbt, 0, scal.data(), rg);      // fast + fallback, as the kernels do
+    fb_sum_serial(viaserial, fbt, 0, scal.data(), rg, nl);      // fast + fallback, as the kernels do
     if (ok && !pt_eq(acc, viaserial)) return -2;
     acc = viaserial;
     apt r;
@@ -1190,6 +1197,17 @@ int emul_group_verify(int kind, int G, int fail_rank, int fail_collective_rank, 
     for (int r = 0; r < G; r++) reject_out[r] = rej[r];
     *aborted_out = comm.aborted ? 1 : 0;
     return code;
+}
+// A group whose rank threads from `start_fails_at` on cannot be started (std::thread throwing): the running ranks must come back from
+// their vote with the failure instead of waiting for ever for parties that do not exist -- also when SEVERAL ranks are missing.
+// Returns the call's code; *ran = how many ranks got as far as their first phase.
+int emul_group_missing_ranks(int G, int start_fails_at, int* ran) {
+    std::atomic<int> n{0};
+    auto prepare = [&](int) -> int { n++; return 0; };
+    auto nop = [](int) -> int { return 0; };
+    auto res = bppp_host::run_sharded(G, [](int) {}, prepare, nop, nop, nop, [](int) {}, [](int) {}, []() { return std::string(); }, start_fails_at);
+    *ran = n.load();
+    return res.code;
 }
 // The sharded prover over G emulated devices (bppp_u64_prove_batch_sharded): rank r proves rows [lo, hi) of the batch; there is no
 // exchange step, so the collective of run_sharded is a no-op and the vote is all the ranks share.  fail_rank as above.

@@ -26,6 +26,7 @@ def load():
     L.emul_fb_digit.argtypes = [i32, cp, i32, vp, vp, vp]
     L.emul_fb_msm.argtypes = [vp, i32, i32, i32, cp, vp]
     L.emul_fb_msm_lanes.argtypes = [vp, i32, i32, i32, cp, vp, vp]
+    L.emul_fb_msm_lanes_nl.argtypes = [vp, i32, i32, i32, cp, vp, vp, i32]
     L.emul_straus.argtypes = [i32, cp, cp, vp]
     L.emul_inv.argtypes = [i32, cp, vp, vp]
     L.emul_straus_affine.argtypes = [i32, cp, cp, vp, vp]
@@ -57,6 +58,7 @@ def load():
     L.emul_set_rlc_superchunk.argtypes = [C.c_uint32, vp]
     L.emul_set_rlc_superchunk.restype = None
     L.emul_group_verify.argtypes = [i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, cp, sz, sz, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.emul_group_missing_ranks.argtypes = [i32, i32, vp]
     L.emul_group_prove.argtypes = [i32, i32, vp, i32, cp, sz, sz, vp, vp, vp, vp, vp, vp]
     L.emul_straus_split.argtypes = [i32, i32, cp, cp, vp, vp, vp]
     L.emul_set_prove_next_by_msm.argtypes = [i32]

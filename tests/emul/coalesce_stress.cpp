@@ -29,7 +29,8 @@ struct Backend {
     }
 };
 
-static int phase(int threads, int per_thread, size_t max_batch, long wait_us, int lanes, int delay_us, int shutdown_after_us) {
+static int phase(int threads, int per_thread, size_t max_batch, long wait_us, int lanes, int delay_us, int shutdown_after_us, int bump_delay_us = 0,
+                 int think_us = 0) {
     Backend be;
     be.delay_us = delay_us;
     bppp_host::CoalesceShape sh;
@@ -38,6 +39,7 @@ static int phase(int threads, int per_thread, size_t max_batch, long wait_us, in
     std::atomic<long> ok{0}, closed{0}, wrong{0};
     {
         bppp_host::Coalescer<Backend> co(&be, sh, max_batch, wait_us, lanes, -7, -5);
+        co.set_test_bump_delay_us(bump_delay_us);
         if (co.start() != 0) return 2;
         std::vector<std::thread> th;
         for (int t = 0; t < threads; t++)
@@ -48,6 +50,7 @@ static int phase(int threads, int per_thread, size_t max_batch, long wait_us, in
                     uint64_t r = 0;
                     const void* in[4] = {&a, &b, nullptr, nullptr};
                     void* out[4] = {&r, nullptr, nullptr, nullptr};
+                    if (think_us) std::this_thread::sleep_for(std::chrono::microseconds((unsigned)((t * 7919 + k * 104729) % (think_us + 1))));
                     const int rc = co.submit(in, out);
                     if (rc == 0) { if (r == a * 3 + b) ok++; else wrong++; }
                     else if (rc == -7) closed++;
@@ -79,5 +82,10 @@ int main() {
     if ((rc = phase(64, 200, 2, 10, 1, 30, -1))) return rc;         // back-pressure: 64 callers, staging for 6 rows
     if ((rc = phase(16, 2000, 4, 20, 1, 50, 3000))) return rc;      // shut down with callers inside
     if ((rc = phase(16, 2000, 4, 20, 4, 50, 0))) return rc;         // shut down at once
+    // batches of 1 .. 12 rows sealed by the deadline, their staging sets re-used at once, and a dispatcher that is slow between two of its
+    // eight completion words: a caller of the NEXT use of a staging set must never be woken by the previous use's bumps (round 4: it was,
+    // and returned the previous batch's row -- a stale accept)
+    if ((rc = phase(12, 150, 16, 30, 1, 0, -1, 300, 400))) return rc;
+    if ((rc = phase(12, 150, 16, 30, 2, 20, -1, 100, 150))) return rc;
     return 0;
 }

@@ -125,3 +125,24 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert out.stdout.split()[0] == "-1" and "no CPU fallback" in out.stdout
+
+
+def test_labels_longer_than_merlin_can_frame_are_refused():
+    """merlin frames a label's length as a u32 (`Transcript::append_message` asserts that); round 4 cast `label_len` to u32 unchecked and
+    would have hashed a truncated length.  The ABI answers BPPP_ERR_INVALID_ARG before it reads a byte of the label.  No GPU needed: the
+    transcript helpers run on the host."""
+    from bp_pp_amd import _build, _capi
+    if not os.path.exists(_build.SO):
+        pytest.skip("libbppp_hip.so not built yet")
+    L = _capi.lib()
+    E = _capi.ERR_INVALID_ARG
+    state = C.create_string_buffer(203)
+    too_long = C.c_size_t(1 << 32)
+    assert L.bppp_transcript_new(b"x", too_long, state) == E
+    assert L.bppp_transcript_new(b"u64 range proof", 15, state) == 0
+    assert L.bppp_transcript_append_message(state, b"x", too_long, b"m", 1) == E
+    out = C.create_string_buffer(32)
+    assert L.bppp_transcript_challenge_bytes(state, b"x", too_long, out, 32) == E
+    # the single-proof entry points build their transcript first: same answer, with or without a device
+    acc, st = C.c_uint8(0), C.c_int32(0)
+    assert L.bppp_u64_verify_one(None, b"x", too_long, bytes(64), bytes(928), C.byref(acc), C.byref(st)) == E

@@ -261,9 +261,10 @@ def test_fixed_base_tables(L, gold, W):
 
 @pytest.mark.parametrize("W", [4, 8, 10])
 def test_fixed_base_fast_accumulator_and_its_fallback(L, gold, W):
-    """The device's 8-lane fixed-base sums use an incomplete (XYZZ) accumulator with deferred exception detection.  Independent
-    generators never trip it; a REPEATED generator with equal window digits does (acc == table entry), and must still give
-    the right sum through the complete-formula re-do."""
+    """The device's fixed-base lane sums use an incomplete (XYZZ) accumulator with deferred exception detection.  Independent
+    generators never trip it.  A REPEATED generator with equal window digits makes a lane add a table entry to itself: the sums that
+    start from an EMPTY accumulator (a wavefront per sum, nl = 64) must detect that and re-do it with the complete formulas; the sums
+    that start from the offset point (nl = 1, 8) do not even see an exceptional addition there.  Every form gives the right sum."""
     gens = bytes.fromhex(gold["generators"])
     G0, G1 = O.pt_from_xy64(gens[:64]), O.pt_from_xy64(gens[64:128])
     out, fb = C.create_string_buffer(64), C.c_int(0)
@@ -274,33 +275,38 @@ def test_fixed_base_fast_accumulator_and_its_fallback(L, gold, W):
     ent = L.emul_fb_table_entries(3, W)
     tab = np.zeros(ent * 64, dtype=np.uint8)
     assert L.emul_fb_build(g3, 3, W, tab.ctypes.data) == 0
-    for _ in range(6):
-        ks = [int.from_bytes(rng.bytes(32), "big") % O.N for _ in range(3)]
-        assert L.emul_fb_msm_lanes(tab.ctypes.data, W, 0, 3, b"".join(map(b32, ks)), out, C.byref(fb)) == 0
-        exp = O.pt_add(O.pt_add(O.pt_mul(G0, ks[0]), O.pt_mul(G1, ks[1])), O.pt_mul(G2, ks[2]))
-        assert out.raw == O.pt_to_xy64(exp) and fb.value == 0
-    for ks in ([0, 0, 0], [1, 0, 0], [0, O.N - 1, 0], [5, 5, 5]):
-        L.emul_fb_msm_lanes(tab.ctypes.data, W, 0, 3, b"".join(map(b32, ks)), out, C.byref(fb))
-        exp = O.pt_add(O.pt_add(O.pt_mul(G0, ks[0]), O.pt_mul(G1, ks[1])), O.pt_mul(G2, ks[2]))
-        assert out.raw == O.pt_to_xy64(exp) and fb.value == 0
-    # (b) generator list G0, G1, G2, G3, G0: copies 0 and 4 of G0 fall to the same lane in both dealing schemes, so a scalar with a
-    # single non-zero window on both copies makes that lane add a table entry to itself (the doubling case of the incomplete law)
+    for nl in (1, 8, 64):
+        for _ in range(4):
+            ks = [int.from_bytes(rng.bytes(32), "big") % O.N for _ in range(3)]
+            assert L.emul_fb_msm_lanes_nl(tab.ctypes.data, W, 0, 3, b"".join(map(b32, ks)), out, C.byref(fb), nl) == 0
+            exp = O.pt_add(O.pt_add(O.pt_mul(G0, ks[0]), O.pt_mul(G1, ks[1])), O.pt_mul(G2, ks[2]))
+            assert out.raw == O.pt_to_xy64(exp) and fb.value == 0
+        for ks in ([0, 0, 0], [1, 0, 0], [0, O.N - 1, 0], [5, 5, 5], [O.N - 1, O.N - 1, O.N - 1]):
+            assert L.emul_fb_msm_lanes_nl(tab.ctypes.data, W, 0, 3, b"".join(map(b32, ks)), out, C.byref(fb), nl) == 0
+            exp = O.pt_add(O.pt_add(O.pt_mul(G0, ks[0]), O.pt_mul(G1, ks[1])), O.pt_mul(G2, ks[2]))
+            assert out.raw == O.pt_to_xy64(exp) and fb.value == 0
+    # (b) generator list G0, G1, G2, G3, G0: a scalar with a single non-zero window on both copies of G0 makes the lane that holds both
+    # add a table entry to itself (the doubling case of the incomplete law)
     gd = gens[:256] + gens[:64]
     G3 = O.pt_from_xy64(gens[192:256])
     ent = L.emul_fb_table_entries(5, W)
     tab = np.zeros(ent * 64, dtype=np.uint8)
     assert L.emul_fb_build(gd, 5, W, tab.ctypes.data) == 0
-    hits = 0
     cases = [[7, 0, 0, 0, 7], [3 << (2 * W), 0, 0, 0, 3 << (2 * W)], [5 << (8 * W), 0, 0, 0, 5 << (8 * W)],
              [7, 1, 2, 3, 7], [11, 0, 0, 0, 12], [int("5" * 64, 16) % O.N] * 5]
-    for ks in cases:
-        L.emul_fb_msm_lanes(tab.ctypes.data, W, 0, 5, b"".join(map(b32, ks)), out, C.byref(fb))
-        exp = O.pt_mul(G0, (ks[0] + ks[4]) % O.N)
-        for Gi, k in ((G1, ks[1]), (G2, ks[2]), (G3, ks[3])):
-            exp = O.pt_add(exp, O.pt_mul(Gi, k))
-        assert out.raw == O.pt_to_xy64(exp)
-        hits += fb.value
-    assert hits >= 3          # the self-additions were detected (and re-done), not silently mis-added
+    for nl in (1, 8, 64):
+        hits = 0
+        for ks in cases:
+            assert L.emul_fb_msm_lanes_nl(tab.ctypes.data, W, 0, 5, b"".join(map(b32, ks)), out, C.byref(fb), nl) == 0
+            exp = O.pt_mul(G0, (ks[0] + ks[4]) % O.N)
+            for Gi, k in ((G1, ks[1]), (G2, ks[2]), (G3, ks[3])):
+                exp = O.pt_add(exp, O.pt_mul(Gi, k))
+            assert out.raw == O.pt_to_xy64(exp)
+            hits += fb.value
+        if nl == 64 and (4 * (256 // W)) % 64 == 0:       # copies 0 and 4 land on one lane when 4 * windows is a multiple of 64 (W = 4, 8)
+            assert hits >= 3          # the self-additions were detected (and re-done), not silently mis-added
+        if nl < 64:
+            assert hits == 0          # from the offset point the same sums are ordinary additions
 
 
 @pytest.mark.parametrize("W", [4, 10])            # 10 = the signed-window scheme (26 windows: pairs dealt round-robin over the lanes)

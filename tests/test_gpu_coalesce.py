@@ -234,6 +234,86 @@ def test_destroy_with_callers_inside_drains():
     round_of_callers(p.close)                                            # destroy: drain, then the context is gone
 
 
+@pytest.mark.parametrize("cmax,lanes", [(2, 1), (64, 2)])
+def test_destroy_while_callers_loop_in_and_out(cmax, lanes):
+    """bppp_ctx_destroy while 16 threads LOOP over bppp_u64_verify_one: at the moment of the destroy some are asleep with a claimed row,
+    some wait for an open batch (back-pressure: staging for `cmax` rows per set), some are between the front end and their return.
+    Round 4 freed the front-end registry after the drain and re-created it -- and a new front end, on a context that was being freed --
+    for a caller that came back from a closed batch.  Now closure is sticky and the context counts the callers inside: every call
+    returns 0 with the oracle's verdict or BPPP_ERR_CLOSED, nobody hangs, nothing is started on the dying context."""
+    import ctypes as C
+    import time
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol, _capi
+    g, gv, hv = workload.split_generators(workload.generators())
+    _, V, P, _ = workload.make_batch(8, first=70)
+    P = P.copy()
+    P[5, 901] ^= 1
+    L = _capi.lib()
+    for rep in range(4):
+        p = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=4)
+        p.set_option("coalesce_max", cmax)
+        p.set_option("coalesce_lanes", lanes)
+        p.set_option("coalesce_us", 50)
+        ctx = p._ctx.value
+        assert p.verify_one(V[0].tobytes(), P[0].tobytes(), workload.LABEL) == (True, 0)
+        gate = threading.Lock()
+        state = {"stop": False}
+        counts = {"ok": 0, "closed": 0}
+        bad = []
+
+        def worker(t):
+            k = t
+            while True:
+                with gate:                      # a call is only started while the context is certainly alive
+                    if state["stop"]:
+                        return
+                acc, st = C.c_uint8(7), C.c_int32(0)
+                i = k % 8
+                rc = L.bppp_u64_verify_one(ctx, workload.LABEL, len(workload.LABEL), V[i].tobytes(), P[i].tobytes(), C.byref(acc), C.byref(st))
+                if rc == 0:
+                    if acc.value != (0 if i == 5 else 1):
+                        bad.append((t, k, acc.value))
+                    counts["ok"] += 1
+                elif rc == _capi.ERR_CLOSED:
+                    counts["closed"] += 1
+                    return                      # the context is gone: no further call
+                else:
+                    bad.append((t, k, "rc", rc))
+                    return
+                k += 1
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(16)]
+        for t in th:
+            t.start()
+        time.sleep(0.15 + 0.05 * rep)
+        with gate:
+            state["stop"] = True
+        time.sleep(0.005)                       # whoever passed the gate is inside its call by now
+        p.close()                               # destroy with callers inside
+        for t in th:
+            t.join(timeout=60)
+        assert not any(t.is_alive() for t in th), "a caller hangs"
+        assert not bad, bad[:5]
+        assert counts["ok"] > 16
+
+
+def test_python_single_proof_wrappers_check_buffer_lengths():
+    """verify_one hands raw pointers to C, which copies 64 / 928 / proof_bytes() bytes from them: a short buffer is refused in Python."""
+    from bp_pp_amd import U64RangeProofProtocol
+    from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
+    p = object.__new__(U64RangeProofProtocol)       # (the check comes before anything touches the context)
+    with pytest.raises(ValueError):
+        p.verify_one(bytes(63), bytes(928), b"label")
+    with pytest.raises(ValueError):
+        p.verify_one(bytes(64), bytes(927), b"label")
+    r = object.__new__(ReciprocalRangeProofProtocol)
+    with pytest.raises(ValueError):
+        r.verify_one(bytes(64), bytes(64 * 13 + 32 * 3 - 1), 4, 2, 1, b"label")
+    with pytest.raises(ValueError):
+        r.verify_one(bytes(10), bytes(64 * 13 + 32 * 3), 4, 2, 1, b"label")
+
+
 @pytest.mark.parametrize("nd,npp,B", [(32, 16, 12), (12, 10, 7)])
 def test_reciprocal_verify_one_from_many_threads(nd, npp, B):
     """bppp_reciprocal_verify_one[_transcript]: `ReciprocalRangeProofProtocol::verify` (reciprocal.rs:98-107) one instance per call from

@@ -1,0 +1,110 @@
+"""Every size threshold of the u64 verifier's and prover's launch sequences (csrc/plan_core.h) at T-1, T, T+1 proofs on an MI355X,
+against the oracle, with the plan that ran asserted ("last_verify_plan" / "last_prove_plan" of bppp_ctx_get_option): an off-by-one in a
+threshold, or a regime that is never entered, fails here.  One batch of 2^17 + 1 proofs from the oracle's trapdoor prover serves every
+size as a prefix; the CPU-tier twin (the thresholds themselves) is tests/test_plan.py."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+THRESHOLDS = [1024, 4096, 16384, 32768, 65536, 131072]
+NMAX = THRESHOLDS[-1] + 1
+FIRST = 31000
+
+
+@pytest.fixture(scope="module")
+def batch():
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import workload
+    gens, V, P, x = workload.make_batch(NMAX, first=FIRST)
+    return dict(gens=gens, V=V, P=P, x=x, s=workload.blindings(NMAX, FIRST), rnd=workload.prover_randomness(NMAX, FIRST))
+
+
+@pytest.fixture(scope="module")
+def proto(batch):
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    g, gv, hv = workload.split_generators(batch["gens"])
+    p = U64RangeProofProtocol(g, gv, hv, device=0)
+    assert p.get_option("last_verify_plan") == 0 and p.get_option("last_prove_plan") == 0
+    yield p
+    p.close()
+
+
+def _device_verify(torch, proto, label, V, P):
+    n = V.shape[0]
+    dV, dP = torch.from_numpy(V).cuda(), torch.from_numpy(P).cuda()
+    dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    dS = torch.zeros(n, dtype=torch.int32, device="cuda")
+    dT = torch.zeros((n, 704), dtype=torch.uint8, device="cuda")
+    dR = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    proto.verify_batch_device(label, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), dT.data_ptr(), dR.data_ptr())
+    torch.cuda.synchronize()
+    return dA.cpu().numpy(), dS.cpu().numpy(), dT.cpu().numpy(), int(dR.item())
+
+
+@pytest.mark.parametrize("T", THRESHOLDS)
+@pytest.mark.parametrize("d", [-1, 0, 1])
+def test_verify_at_every_threshold_vs_oracle(batch, proto, oracle_c, T, d):
+    """Honest, tampered (every 13th) and malformed proofs (random byte flips; a coordinate = p; a scalar = n -- among them the batch's last
+    proof, the one a wrong grid size would drop): accept bits, statuses, the reject count, and on a sample that holds every malformed
+    proof and its neighbours the whole 704-byte trace of challenges and commitments, equal the oracle's; and the call took the plan
+    the size is meant to take."""
+    import torch
+    import workload
+    from bp_pp_amd.range_proof import plan_for
+    n = T + d
+    V, P = batch["V"][:n].copy(), batch["P"][:n]
+    P, expect = workload.corrupt(P, V, every=13)
+    P = P.copy()
+    rng = np.random.default_rng(n)
+    bad = sorted(set(int(i) for i in rng.integers(0, n, 24)) | {0, n - 1})
+    for i in bad[1:-1]:
+        P[i, int(rng.integers(0, 928))] ^= int(rng.integers(1, 256))
+    P[0, 864:896] = np.frombuffer(workload.N_ORDER.to_bytes(32, "big"), np.uint8)            # a scalar = n
+    P[n - 1, 64:96] = np.frombuffer((2**256 - 2**32 - 977).to_bytes(32, "big"), np.uint8)     # a coordinate = p
+    acc, st, tr, rej = _device_verify(torch, proto, workload.LABEL, V, P)
+    assert proto.last_plan() == plan_for(n), (n, proto.last_plan())
+    sample = sorted(set(bad + [b + 1 for b in bad if b + 1 < n] + [b - 1 for b in bad if b > 0] + list(range(0, n, max(1, n // 24)))))
+    flagged = 0
+    for i in sample:
+        rc, otr = oracle_c.u64_verify(batch["gens"], workload.LABEL, bytes(V[i]), bytes(P[i]), trace=True)
+        assert int(acc[i]) == (1 if rc == 1 else 0), (n, i)
+        assert (int(st[i]) != 0) == (rc < 0), (n, i, rc, int(st[i]))
+        if rc >= 0:
+            assert bytes(tr[i]) == otr, (n, i)
+        flagged += rc < 0
+    assert flagged >= 2 and st[0] != 0 and st[n - 1] != 0
+    clean = np.ones(n, bool)
+    clean[bad] = False
+    assert (acc[clean] == expect[clean]).all() and not st[clean].any()
+    assert rej == int((acc == 0).sum())
+
+
+@pytest.mark.parametrize("T", THRESHOLDS)
+@pytest.mark.parametrize("d", [-1, 0, 1])
+def test_prove_at_every_threshold_vs_oracle(batch, proto, T, d):
+    """The batch prover at T-1, T, T+1 values: every proof and commitment byte-identical to the oracle's trapdoor prover (the fixture),
+    and the plan that ran is the one the size is meant to take."""
+    import workload
+    from bp_pp_amd.range_proof import plan_for
+    n = T + d
+    proofs, com, st = proto.prove_batch(batch["x"][:n], batch["s"][:n], batch["rnd"][:n], workload.LABEL)
+    assert proto.last_plan(prove=True) == plan_for(n, prove=True), (n, proto.last_plan(prove=True))
+    assert not st.any()
+    assert (com == batch["V"][:n]).all()
+    assert (proofs == batch["P"][:n]).all()
+
+
+def test_every_regime_was_entered():
+    """The sweep above is only worth its name if the sizes really span all the regimes: seven for the verifier, and for the prover every
+    change of its plan within the sweep's range."""
+    from bp_pp_amd.range_proof import plan_for
+    sizes = [T + d for T in THRESHOLDS for d in (-1, 0, 1)]
+    assert len({plan_for(n) for n in sizes}) == 7
+    assert len({plan_for(n, prove=True) for n in sizes}) >= 7

@@ -172,63 +172,6 @@ def test_sizes_that_run_kernels_beside_each_other_vs_oracle(torch_mod, proto, or
     assert rej == int((acc == 0).sum())
 
 
-def test_two_halves_on_two_stream_pairs(torch_mod, monkeypatch, oracle_c):
-    """With option "two_stream_halves" exact-mode batches from 2^18 proofs on run as two halves on two stream pairs, the second on a child
-    context over the same tables (bppp_u64.hip: verify_twin); BPPP_TWIN=1 sends every batch of >= 128 proofs that way.  An odd split (1,000 = 512 + 488): accept
-    bits, statuses, the reject counter summed over both halves, traces, per-proof transcripts in and out -- equal to the oracle's and to
-    a context that never splits; the child context is reused by the next call and goes with its parent."""
-    import transcript_cases as TC
-    import workload
-    from bp_pp_amd import U64RangeProofProtocol
-    n = 1000
-    gens, V, P, _ = workload.make_batch(n, first=7000)
-    P, expect = workload.corrupt(P, V, every=9)
-    P = P.copy()
-    P[3, 10] ^= 0x80
-    P[700, 850] ^= 0xFF                      # a malformed proof in each half (most likely: judged by the oracle below)
-    g, gv, hv = workload.split_generators(gens)
-    monkeypatch.setenv("BPPP_TWIN", "1")
-    twin = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
-    monkeypatch.setenv("BPPP_TWIN", "0")
-    plain = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=8)
-    monkeypatch.delenv("BPPP_TWIN")
-    try:
-        for _ in range(2):
-            acc, st, tr, rej = _device_verify(torch_mod, twin, workload.LABEL, V, P)
-            acc0, st0, tr0, rej0 = _device_verify(torch_mod, plain, workload.LABEL, V, P)
-            assert (acc == acc0).all() and (st == st0).all() and rej == rej0 == int((acc == 0).sum())
-            ok = st == 0
-            assert (tr[ok] == tr0[ok]).all()
-        for i in [0, 3, 4, 511, 512, 513, 700, 701, 999]:
-            rc, otr = oracle_c.u64_verify(gens, workload.LABEL, bytes(V[i]), bytes(P[i]), trace=True)
-            assert int(acc[i]) == (1 if rc == 1 else 0) and (int(st[i]) != 0) == (rc < 0), i
-            if rc >= 0:
-                assert bytes(tr[i]) == otr, i
-        assert twin.get_option("twin_context") == 1 and plain.get_option("twin_context") == 0
-        # the production switch: option "two_stream_halves" (takes effect from 2^18 proofs; BPPP_TWIN is the tests' way to small sizes)
-        assert plain.get_option("two_stream_halves") == 0
-        plain.set_option("two_stream_halves", 1)
-        assert plain.get_option("two_stream_halves") == 1
-        with pytest.raises(Exception):
-            plain.set_option("two_stream_halves", 2)
-        plain.set_option("two_stream_halves", 0)
-        clean = np.ones(n, bool); clean[[3, 700]] = False
-        assert (acc[clean] == expect[clean]).all() and not st[clean].any()
-        # per-proof pre-loaded transcripts, 144 = 128 + 16 over the two contexts: advanced states come back in the caller's order
-        case = TC.make(12, shared=False)      # (the Python oracle makes these: 12 proofs on 12 different transcripts, repeated 12 times)
-        assert case["gens"] == gens
-        Vt, Pt, S = np.tile(case["V"], (12, 1)), np.tile(case["P"], (12, 1)), np.tile(case["states_in"], (12, 1))
-        Pt[130, 900] ^= 1                     # second half, a wrong proof: its state still advances (judged by the oracle)
-        a, s_, out = twin.verify_batch_transcript(Vt, Pt, [x.tobytes() for x in S])
-        good = np.ones(144, bool); good[130] = False
-        assert a[good].all() and not a[130] and not s_.any() and (out[good] == np.tile(case["states_after"], (12, 1))[good]).all()
-        okj, after = TC.oracle_verify(case, 130 % 12, bytes(Vt[130]), bytes(Pt[130]), bytes(S[130]))
-        assert not okj and bytes(out[130]) == after
-    finally:
-        twin.close()
-        plain.close()
-
-
 def test_sec1_wire_inputs(torch_mod, proto, gold, oracle_c):
     """the same verify fed with the reference's wire content (33-byte SEC1 points, 525-byte proofs)."""
     import workload

@@ -84,6 +84,27 @@ def test_throwing_rank_still_votes(u64_case):
     assert rc == 0 and (acc == u64_case[4]).all()
 
 
+@pytest.mark.parametrize("G,first_missing", [(2, 1), (4, 3), (4, 1), (8, 2), (4, 0)])
+def test_ranks_whose_threads_cannot_start_fail_the_call_instead_of_hanging(G, first_missing):
+    """group_core.h: when rank threads cannot be started, the main thread votes for ALL the missing ranks without blocking (round 4
+    blocked in the first missing rank's vote, which only the same thread could have completed: two or more missing ranks hung the
+    group with every lock held)."""
+    import ctypes as C
+    from emul.build import load
+    L = load()
+    ran = C.c_int(-1)
+    done = []
+
+    def call():
+        done.append(L.emul_group_missing_ranks(G, first_missing, C.byref(ran)))
+    import threading
+    th = threading.Thread(target=call, daemon=True)
+    th.start()
+    th.join(20)
+    assert not th.is_alive(), "run_sharded did not return"
+    assert done == [-5] and ran.value == first_missing
+
+
 def test_failing_collective_aborts_instead_of_hanging(u64_case):
     rc, _, _, _, aborted, dt = _group_u64(u64_case, 3, fail_coll=1, timeout_ms=60000)
     assert rc == ERR_RCCL and aborted == 1 and dt < 30

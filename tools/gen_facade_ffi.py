@@ -8,7 +8,7 @@ TMAP = [(r'const uint8_t\s*\*\s*const\s*\*', '*const *const u8'), (r'const void\
         (r'const uint8_t\s*\*', '*const u8'), (r'uint8_t\s*\*', '*mut u8'), (r'const int32_t\s*\*', '*const i32'), (r'int32_t\s*\*', '*mut i32'),
         (r'const uint64_t\s*\*', '*const u64'), (r'uint64_t\s*\*', '*mut u64'), (r'const size_t\s*\*', '*const usize'), (r'size_t\s*\*', '*mut usize'),
         (r'const void\s*\*', '*const c_void'), (r'void\s*\*', '*mut c_void'), (r'const char\s*\*\s*\*', '*mut *const c_char'),
-        (r'const char\s*\*', '*const c_char'), (r'double\s*\*', '*mut f64'), (r'int64_t\s*\*', '*mut i64'), (r'const int\s*\*', '*const c_int'),
+        (r'const char\s*\*', '*const c_char'), (r'char\s*\*', '*mut c_char'), (r'double\s*\*', '*mut f64'), (r'int64_t\s*\*', '*mut i64'), (r'const int\s*\*', '*const c_int'),
         (r'bppp_ctx\s*\*\s*\*', '*mut *mut BpppCtx'), (r'const bppp_ctx\s*\*', '*const BpppCtx'), (r'bppp_ctx\s*\*', '*mut BpppCtx'),
         (r'bppp_circuit\s*\*\s*\*', '*mut *mut BpppCircuit'), (r'const bppp_circuit\s*\*', '*const BpppCircuit'), (r'bppp_circuit\s*\*', '*mut BpppCircuit'),
         (r'bppp_group\s*\*\s*\*', '*mut *mut BpppGroup'), (r'const bppp_group\s*\*', '*const BpppGroup'), (r'bppp_group\s*\*', '*mut BpppGroup'),

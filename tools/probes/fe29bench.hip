@@ -5,7 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/fe29bench tools/fe29bench.hip && ./tools/fe29bench
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../bp_pp_amd/csrc/field.h"
+#include "../../bp_pp_amd/csrc/field.h"
 using namespace bppp;
 #define M29 0x1FFFFFFFu
 #define R0_29 0x7A20u   // 2^261 mod p = 2^37 + 0x7A20  ->  0x7A20 at limb 0, 2^8 at limb 1

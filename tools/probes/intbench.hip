@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../bp_pp_amd/csrc/point.h"
+#include "../../bp_pp_amd/csrc/point.h"
 #include "fe26.h"
 using namespace bppp;
 

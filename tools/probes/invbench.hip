@@ -2,7 +2,7 @@
 // verifier's per-proof kernels run at) and 4 per SIMD.   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/invbench tools/invbench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../bp_pp_amd/csrc/field.h"
+#include "../../bp_pp_amd/csrc/field.h"
 using namespace bppp;
 template <int MODE>
 __global__ __launch_bounds__(64) void k_inv(u32* out, int iters) {

@@ -1,7 +1,7 @@
 """Latency of one call of the generic entry points (WeightNormLinearArgument N = 4: tests.rs:139-171; ReciprocalRangeProofProtocol
 with the u64 shape dim_nd = dim_np = 16) -- for comparison with the u64-specialised path.  usage: python tools/latency_generic.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 import numpy as np

@@ -1,7 +1,7 @@
 """Reads the phase stamps of a -DBPPP_PHASE_TIMING build (see verify_core.h: BPPP_STAMP): shader-clock deltas between the marked
 points of verify_phase1 and verify_round, averaged over the wavefronts.   BPPP_LIB=.../libbppp_hip_pt.so python tools/phase_probe.py"""
 import ctypes as C, json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from bp_pp_amd import U64RangeProofProtocol, synth as workload, _capi

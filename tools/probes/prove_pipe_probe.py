@@ -3,7 +3,7 @@ sub-batch under the fixed-base sums of another?  Diagnostics from the environmen
 every lane kernel, so that they can share a SIMD with a sum's wavefront; BPPP_NEXT_MSM_MAX, BPPP_NEXT_G4_W2, BPPP_NEXT_OVERLAP).
 usage: python tools/prove_pipe_probe.py [log2 sizes ...]"""
 import os, sys, time
-sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))]
 import numpy as np
 import torch, bench
 from bp_pp_amd import U64RangeProofProtocol, synth

@@ -1,7 +1,7 @@
 """20 small prove calls and 20 small verify calls (n = 64) -- the workload for `rocprofv3 --kernel-trace --stats` when looking at
 where a small call's time goes kernel by kernel."""
 import os, sys
-sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.abspath(__file__)))]
+sys.path[:0] = [os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))]
 import bench
 from bp_pp_amd import U64RangeProofProtocol, synth
 gens, g, gv, hv = bench.load_generators()

@@ -5,7 +5,7 @@ automatic size -- with the bench's 1/256 corrupted instances and with every inst
 verifies/s, per-kernel ms of the final-check stages, accept bits equal to the expectation.
 usage: python tools/recip_rlc_sweep.py [log2 n = 15]"""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

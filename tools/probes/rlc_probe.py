@@ -1,6 +1,6 @@
 """Per-kernel times of the RLC batch mode (2^16 proofs resident in HBM)."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from bp_pp_amd import U64RangeProofProtocol, synth as workload

@@ -2,7 +2,7 @@
 stage with M in {64, 256, 1024, 4096, 8192}, at corruption rates 0 and 1/1024.  Prints one line per point: ms per batch, M
 verifies/s, per-kernel ms of the final-check stages, accept bits equal to exact mode.  usage: python tools/rlc_sweep.py [log2 n]"""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import bench

@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-#include "../bp_pp_amd/csrc/verify_core.h"
+#include "../../bp_pp_amd/csrc/verify_core.h"
 using namespace bppp;
 __global__ __launch_bounds__(64) void k_straus(const apt_packed* tab, int shared_table, u32* out, int reps) {
     size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;

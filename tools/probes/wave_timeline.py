@@ -1,7 +1,7 @@
 """When do the wavefronts of k_verify_c0_var start and end?  (-DBPPP_PHASE_TIMING build: lane 0 of every wavefront stamps s_memtime
 before and after the 5-point sum, stamps 20 / 21.)   BPPP_LIB=bp_pp_amd/libbppp_hip_pt.so python tools/wave_timeline.py [log2 n ...]"""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch, bench
 from bp_pp_amd import U64RangeProofProtocol, synth, _capi

@@ -9,7 +9,7 @@ def show(l):
     print("  kernels ms/step:", {k: round(v, 3) for k, v in (d.get("kernels_ms_per_step") or {}).items()})
     r = d.get("roofline") or {}
     print("  roofline:", r.get("kernel"), "avg launch ms", round(r.get("avg_launch_ms", 0), 4), "frac", round(r.get("frac", 0), 5), "traffic", r.get("traffic"))
-    for k in ("configs1_2pow16", "shard_2pow17", "two_stream_halves", "rlc_mode", "host_buffer_path", "cpu_baseline", "prove_2pow14", "recip256_2pow15"):
+    for k in ("configs1_2pow16", "shard_2pow17", "rlc_mode", "host_buffer_path", "cpu_baseline", "prove_2pow14", "recip256_2pow15"):
         v = d.get(k)
         if v:
             print(f"  {k}:", round(v["value"]), v.get("unit"), {a: b for a, b in v.items() if a in ("ms_per_step", "one_sequence_ms_per_step_same_moment", "ms_per_batch", "cores", "accept_bits_ok", "accept_bits_equal_exact_mode", "agrees_with_gpu")})
