@@ -414,9 +414,22 @@ def run_verify(args):
         host_path = {"value": m / t_h, "unit": "verifies/s", "ms_per_batch": t_h * 1e3, "proofs": m,
                      "accept_bits_ok": bool((hacc == expect[:m]).all()),
                      "note": "bppp_u64_verify_batch with pageable host buffers: 65 MB host-to-device per batch included"}
+        # the same proofs in the reference's wire form (33-byte SEC1 points: 525 + 33 bytes per proof instead of 928 + 64 over PCIe,
+        # and 14 square roots per proof on the device to decompress them)
+        from bp_pp_amd import wire
+        C33 = np.frombuffer(b"".join(wire.compress_point(bytes(V16[i])) for i in range(m)), dtype=np.uint8).reshape(m, 33).copy() if m <= (1 << 16) else None
+        if C33 is not None:
+            P525 = np.frombuffer(b"".join(wire.abi_to_sec1(bytes(P16[i])) for i in range(m)), dtype=np.uint8).reshape(m, 525).copy()
+            proto.verify_batch_sec1(C33, P525, workload.LABEL)
+            t_s = time.perf_counter()
+            sacc, _ = proto.verify_batch_sec1(C33, P525, workload.LABEL)
+            t_s = time.perf_counter() - t_s
+            host_path["sec1_form"] = {"value": m / t_s, "unit": "verifies/s", "ms_per_batch": t_s * 1e3, "accept_bits_ok": bool((sacc == expect[:m]).all()),
+                                      "note": "bppp_u64_verify_batch_sec1: 36.6 MB over PCIe instead of 65 MB, then on-device decompression"}
         if n > m:
-            # the whole batch from pageable host memory (1 GB at 2^20): uploaded in chunks of 2^17 proofs while the previous chunk is
-            # being verified (default), and -- for comparison -- uploaded in one piece before the first kernel
+            # the whole batch from pageable host memory (1 GB at 2^20): in parts that grow -- the first 2^17 proofs, then what can be
+            # uploaded while that part is verified, 7 times as much (bppp_u64.hip: verify_host_impl) -- and, for comparison, uploaded in
+            # one piece before the first kernel
             Vh, Ph = dV.cpu().numpy(), dP.cpu().numpy()
             full = {}
             for name, chunk in (("pipelined", 1 << 17), ("upload_first", 0)):
@@ -482,18 +495,36 @@ def run_verify(args):
                 proto.verify_batch_rlc_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA2.data_ptr(), seed, dS.data_ptr(), dR2.data_ptr())
                 all_reduce_reject_count(dR2)
 
-        rlc_step()
-        fence()
-        t_r = time.perf_counter()
-        for _ in range(args.steps):
+        def rlc_measure():
+            """-> (seconds for args.steps steps, per-kernel ms per step of one more step with kernel timing on, the group sizes used)"""
+            proto.set_option("rlc_history", 0)
+            rlc_step()                      # first call on this input stream: no history yet (round 4's group sizes) ...
+            fence()
+            rlc_step()                      # ... the following ones plan with the previous call's reject rate (plan_core.h: plan_rlc)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                rlc_step()
+            fence()
+            t = max_over_ranks(time.perf_counter() - t0)
+            proto.enable_timing(True)
+            proto.timings(reset=True)
             rlc_step()
-        fence()
-        t_r = max_over_ranks(time.perf_counter() - t_r)
+            fence()
+            kt = proto.timings(reset=True)
+            proto.enable_timing(False)
+            used = {"superchunk": proto.get_option("last_rlc_superchunk"), "chunk": proto.get_option("last_rlc_chunk"),
+                    "reject_ppm_planned_with": proto.get_option("rlc_reject_ppm")}
+            return t, {k: v["total_ms"] for k, v in kt.items() if v["launches"]}, used
+
+        t_r, kt_r, used_r = rlc_measure()
         rlc = {"value": total * args.steps / t_r, "unit": "verifies/s", "ms_per_step": t_r / args.steps * 1e3,
                "accept_bits_equal_exact_mode": bool((dA2 == dA).all().item()) and int(dR2.item()) == rejects,
-               "note": "optional mode (bppp_u64_verify_batch_rlc_device) on the SAME batch (1/1024 proofs corrupted, so every superchunk "
-                       "of the bucket stage fails and falls through to chunks of 8): random linear combinations of the final checks, "
-                       "failing chunks re-checked exactly; NOT the headline metric"}
+               "kernels_ms_per_step": kt_r, "group_sizes": used_r,
+               "roofline_valu": valu_roofline("k_verify_round", kt_r.get("k_verify_round", 0.0) / 4, n, 1) if kt_r.get("k_verify_round") else None,
+               "note": "optional mode (bppp_u64_verify_batch_rlc_device) on the SAME batch (1/1024 proofs corrupted): random linear combinations "
+                       "of the final checks, failing groups re-checked exactly; group sizes follow the previous call's reject rate (here: no "
+                       "bucket stage -- every superchunk would hold a bad proof -- and chunks of 32); NOT the headline metric"}
         # the regime the bucket stage is for: every proof valid.  The corrupted bytes are flipped back for this measurement only.
         bad_idx = np.nonzero(expect == 0)[0]
         if expected_rejects:        # a GLOBAL condition: every rank takes part in the collectives below, with or without local repairs
@@ -502,15 +533,10 @@ def run_verify(args):
             if len(bad_idx):
                 dP[ti, to] = dP[ti, to] ^ 1
             torch.cuda.synchronize()
-            rlc_step()
-            fence()
-            t_v = time.perf_counter()
-            for _ in range(args.steps):
-                rlc_step()
-            fence()
-            t_v = max_over_ranks(time.perf_counter() - t_v)
+            t_v, kt_v, used_v = rlc_measure()
             rlc["all_valid"] = {"value": total * args.steps / t_v, "unit": "verifies/s", "ms_per_step": t_v / args.steps * 1e3,
                                 "all_accepted": bool(dA2.all().item()) and int(dR2.item()) == 0,
+                                "kernels_ms_per_step": kt_v, "group_sizes": used_v,
                                 "note": "same batch with the corrupted bytes restored: the bucket (Pippenger) stage passes every superchunk"}
             if len(bad_idx):
                 dP[ti, to] = dP[ti, to] ^ 1

@@ -220,6 +220,9 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->d_gtab) (void)hipFree(c->d_gtab);
     if (c->d_expand) (void)hipFree(c->d_expand);
     if (c->d_flags) (void)hipFree(c->d_flags);
+    if (c->d_rlc_hist) (void)hipFree(c->d_rlc_hist);
+    if (c->h_rlc_hist) (void)hipHostFree(c->h_rlc_hist);
+    if (c->ev_rlc_hist) (void)hipEventDestroy(c->ev_rlc_hist);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
@@ -246,6 +249,19 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
         if (value != 0 && (value < 64 || value > BPPP_BKT_MAX_M || (value & 7))) return BPPP_ERR_INVALID_ARG;
         c->rlc_super_m = (unsigned)value;
         c->rlc_super_auto = false;           // an explicit size is taken as it is (0 switches the stage off)
+        return BPPP_OK;
+    }
+    // RLC mode: proofs per chunk after the bucket stage (8, 32; 0 = chosen per call from the previous call's reject rate), and
+    // "rlc_history" = 0: forget that rate (the next call plans as a first call does)
+    if (std::strcmp(name, "rlc_chunk") == 0) {
+        if (value != 0 && value != 8 && value != 32) return BPPP_ERR_INVALID_ARG;
+        c->rlc_chunk_opt = (int)value;
+        return BPPP_OK;
+    }
+    if (std::strcmp(name, "rlc_history") == 0) {
+        if (value != 0) return BPPP_ERR_INVALID_ARG;
+        c->rlc_rate = -1.0;
+        c->rlc_hist_n = 0;
         return BPPP_OK;
     }
     if (std::strcmp(name, "max_batch") == 0) {
@@ -299,6 +315,18 @@ long bppp_ctx_get_option(bppp_ctx* c, const char* name) {
     if (std::strcmp(name, "device") == 0) return c->device;
     if (std::strcmp(name, "n_generators") == 0) return c->nbases;
     if (std::strcmp(name, "rlc_superchunk") == 0) return (long)c->rlc_super_m;
+    if (std::strcmp(name, "rlc_chunk") == 0) return (long)c->rlc_chunk_opt;
+    // what the last RLC call on this context used, and the reject rate (parts per million; -1 = none yet) the next one will plan with
+    if (std::strcmp(name, "last_rlc_superchunk") == 0) return (long)c->last_rlc_super_m;
+    if (std::strcmp(name, "last_rlc_chunk") == 0) return (long)c->last_rlc_chunk;
+    if (std::strcmp(name, "rlc_reject_ppm") == 0) {
+        if (c->rlc_hist_n && c->ev_rlc_hist && hipEventQuery(c->ev_rlc_hist) == hipSuccess) {
+            c->rlc_rate = (double)*c->h_rlc_hist / (double)c->rlc_hist_n;
+            c->rlc_hist_n = 0;
+        }
+        (void)hipGetLastError();
+        return c->rlc_rate < 0 ? -1 : (long)(c->rlc_rate * 1e6 + 0.5);
+    }
     if (std::strcmp(name, "max_batch") == 0) return (long)c->max_batch;
     if (std::strcmp(name, "host_chunk") == 0) return (long)c->host_chunk;
     if (std::strcmp(name, "coalesce_max") == 0) return c->coalesce_max;

@@ -654,6 +654,17 @@ void bppp_wnla_proof_shape(size_t nl, size_t nn, size_t* rounds, size_t* nl_out,
     if (nl_out) *nl_out = a;
     if (nn_out) *nn_out = b;
 }
+// "ct_prover" for the generic provers: the 4-bit table over THIS context's generators (built at the first use) for the sums over secret
+// scalars -- every entry of every window read and selected by mask, complete additions (verify_core.h: fb_lookup_add_ct)
+static int ct_setup(bppp_ctx* c, FbTable& fb_ct, int& ct, size_t n) {
+    ct = 0;
+    if (!c->ct_prover) return BPPP_OK;
+    const int rc = ensure_ct_table(c);
+    if (rc != BPPP_OK) return rc;
+    fb_ct.table = c->d_table_ct; fb_ct.W = 4; fb_ct.N = n;
+    ct = 1;
+    return BPPP_OK;
+}
 static int wnla_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, const HostTranscripts* tx, size_t n, const uint8_t* commitments,
                            const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, const uint8_t* l, size_t nl, const uint8_t* nvec, size_t nn,
                            uint8_t* proof_r, uint8_t* proof_x, uint8_t* proof_l, uint8_t* proof_n, int32_t* status) {
@@ -694,6 +705,7 @@ static int wnla_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, 
     w.ch = (u32*)(d + o_ch); w.cg = (u32*)(d + o_cg); w.prm = (u32*)(d + o_prm); w.com = (u32*)(d + o_cm); w.msc = (u32*)(d + o_msc);
     w.pbuf = (u32*)(d + o_pb);
     w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    { const int rc_ct = ct_setup(c, w.fb_ct, w.ct, n); if (rc_ct != BPPP_OK) return rc_ct; }      // l, n are the caller's secrets here (wnla.rs:152-160)
     t_new(w.base, label, (u32)label_len);
     TxDev txd;
     int rc = txd.begin(c, tx, n, s, w.tio, w.divergent_positions);
@@ -791,6 +803,7 @@ static int circuit_prove_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t*
     p.msc = (u32*)(d + o_msc); p.pbuf = (u32*)(d + o_pb);
     p.wn_commit = d + o_wc; p.wn_c = d + o_wcv; p.wn_rho = d + o_rho; p.wn_mu = d + o_mu; p.wn_l = d + o_wlv; p.wn_n = d + o_wnv;
     p.fb.table = c->d_table; p.fb.W = c->fb_w; p.fb.N = n;
+    { const int rc_ct = ct_setup(c, p.fb_ct, p.ct, n); if (rc_ct != BPPP_OK) return rc_ct; }      // c_l, c_r, c_o, c_s: witness and blindings (circuit.rs:336-345, 469-470)
     t_new(p.base, label, (u32)label_len);
     TxDev txd;
     int rc = txd.begin(c, tx, n, s, p.tio, p.divergent_positions);
@@ -929,6 +942,7 @@ static int recip_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
     r.msc = (u32*)(d + o_msc); r.pbuf = (u32*)(d + o_pb);
     r.cp_v = d + o_cpv; r.cp_sv = d + o_cpsv; r.cp_wr = d + o_cpwr; r.cp_vpts = d + o_cpvp; r.proof_r = d + o_prr;
     r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
+    { const int rc_ct = ct_setup(c, r.fb_ct, r.ct, n); if (rc_ct != BPPP_OK) return rc_ct; }      // the reciprocals 1 / (e + d_i) (reciprocal.rs:118)
     t_new(r.base, label, (u32)label_len);
     TxDev txd;
     int rc = txd.begin(c, tx, n, s, r.tio, r.divergent_positions);
@@ -955,7 +969,7 @@ static int recip_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
     p.lamv = (u32*)(d + o_lam); p.muv = (u32*)(d + o_muv); p.coef = (u32*)(d + o_coef); p.misc = (u32*)(d + o_misc);
     p.msc = r.msc; p.pbuf = r.pbuf;
     p.wn_commit = d + o_wc; p.wn_c = d + o_wcv; p.wn_rho = d + o_rho; p.wn_mu = d + o_mu; p.wn_l = d + o_wlv; p.wn_n = d + o_wnv;
-    p.fb = r.fb;
+    p.fb = r.fb; p.fb_ct = r.fb_ct; p.ct = r.ct;
     WnlaProveWs w;
     std::memset(&w, 0, sizeof w);
     { const int rc_s = ensure_straus_capacity(c, n); if (rc_s != BPPP_OK) return rc_s; }   // window tables of X, R (next commitment by the relation)

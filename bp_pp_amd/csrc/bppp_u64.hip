@@ -4,6 +4,8 @@
 #include "host.h"
 #include "plan_core.h"
 
+// host-buffer verify calls: each pipelined part is this many times the previous one (what crosses PCIe while a part is verified)
+#define BPPP_HOST_PART_GROWTH 7
 static_assert(bppp_host::PLAN_BLOCK == BPPP_BLOCK, "plan_core.h counts workgroups of BPPP_BLOCK lanes");
 // the switches of a context that the plans depend on
 static bppp_host::PlanKnobs knobs_of(const bppp_ctx* c) {
@@ -204,12 +206,26 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         if (tail_beside) { HIP_TRY(hipEventRecord(c->ev_join, a)); HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); }
         LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
     } else {
-        // combined check per chunk of 8 proofs; chunks that fail it (or hold a flagged proof) fall through to the exact kernels
-        const size_t nchunks = (n + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
-        const unsigned chunk_blocks = (unsigned)((nchunks * BPPP_RLC_CHUNK + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+        // How the final checks are grouped -- superchunks of the bucket stage, then chunks of 8 or 32 -- follows what the previous RLC
+        // call on this context rejected (plan_core.h: plan_rlc).  That call's counter was copied to pinned host memory when it ended;
+        // if the copy has landed, it is the rate this call plans with.
+        if (c->rlc_hist_n && c->ev_rlc_hist && hipEventQuery(c->ev_rlc_hist) == hipSuccess) {
+            c->rlc_rate = (double)*c->h_rlc_hist / (double)c->rlc_hist_n;
+            c->rlc_hist_n = 0;
+        }
+        (void)hipGetLastError();      // (hipErrorNotReady from the query is not an error of this call)
+        const bppp_host::RlcPlan rp = bppp_host::plan_rlc(bucket_superchunk_for(c, n), c->rlc_super_auto, c->rlc_chunk_opt, c->rlc_rate);
+        c->last_rlc_super_m = rp.super_m; c->last_rlc_chunk = rp.chunk;
+        rl.chunk = rp.chunk;
+        // combined check per chunk; chunks that fail it (or hold a flagged proof) fall through to the exact kernels
+        const size_t nchunks = (n + rp.chunk - 1) / rp.chunk;
+        const unsigned chunk_blocks = (unsigned)((nchunks * rp.chunk + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
         HIP_TRY(hipMemsetAsync(d_accept, 0, n, s));
         HIP_TRY(hipMemsetAsync(rl.count, 0, sizeof(int), s));
-        if (const unsigned SM = bucket_superchunk_for(c, n)) {
+        rc = ensure_rlc_history(c);
+        if (rc != BPPP_OK) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_rlc_hist, 0, sizeof(int), s));
+        if (const unsigned SM = rp.super_m) {
             // bucket stage first: superchunks of SM proofs, one combined check each; the chunk-of-8 kernels below only see the proofs
             // of superchunks that failed it
             BucketWs bw;
@@ -220,10 +236,15 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
             rl.super_m = SM;
         }
         LAUNCH(K_RLC_LHS, k_rlc_lhs<<<blocks, BPPP_BLOCK, 0, s>>>(ws, rl));
-        LAUNCH(K_RLC_CHUNK, k_rlc_chunk<<<chunk_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
+        if (rp.chunk == 32) LAUNCH(K_RLC_CHUNK, k_rlc_chunk_c32<<<chunk_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
+        else LAUNCH(K_RLC_CHUNK, k_rlc_chunk<<<chunk_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
         LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged<<<1024, 64, 0, s>>>(ws, rl));
         LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged_dense<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
-        LAUNCH(K_ACCEPT, k_verify_accept_flagged<<<blocks, BPPP_BLOCK, 0, s>>>(ws, rl, (int*)d_reject_count));
+        LAUNCH(K_ACCEPT, k_verify_accept_flagged<<<blocks, BPPP_BLOCK, 0, s>>>(ws, rl, (int*)d_reject_count, c->d_rlc_hist));
+        // this call's reject count, for the next call's plan (a call that runs in parts leaves the last part's)
+        HIP_TRY(hipMemcpyAsync(c->h_rlc_hist, c->d_rlc_hist, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(c->ev_rlc_hist, s));
+        c->rlc_hist_n = n;
     }
     if (ws.states_out) k_verify_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
 #undef LAUNCH
@@ -303,18 +324,24 @@ static int verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
         int rc = verify_device_impl(c, label, label_len, n, d_c, d_p, d_a, d_s, nullptr, nullptr, rlc_seed, nullptr);
         if (rc != BPPP_OK) return rc;
     } else {
-        // Large batch: proofs are independent, so the batch is verified chunk by chunk while the next chunk crosses PCIe on a second
-        // stream (from pageable memory the runtime stages the copy and this thread blocks in it; the GPU keeps verifying meanwhile).
-        // A chunk is one full grid of the lane kernels, so the kernels run exactly as they do for a resident batch.
+        // Large batch: proofs are independent, so the batch is verified in parts while the next part crosses PCIe on a second stream.
+        // Round 4 cut it into equal chunks of host_chunk proofs and lost 9 of the 13 ms it was behind a resident batch to the chunks
+        // themselves: eight 2^17-proof batches take 158 ms where one 2^20-proof batch takes 149 (the tails of kernels that fill the chip
+        // exactly once).  The link moves a proof (992 B at 56 GB/s: 18 ns) eight times faster than the chip verifies it (142 ns), so the
+        // parts GROW: the first is one host_chunk -- the only upload nothing hides -- and each next one is what can be uploaded while the
+        // previous one is verified, 7 times its size: 2^20 proofs = 2^17 + 7 * 2^17, the second part a 917,504-proof batch at the
+        // resident rate (profiles/r05_d_hostpath_probe.txt).  (From pageable memory the runtime stages the copy and this thread blocks
+        // in it, at the same 56 GB/s; the GPU keeps verifying meanwhile.)
         if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         if (!c->ev_copy) HIP_TRY(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
         // the staging buffer may still be read by kernels of an earlier call on c->stream only if that call returned early on an
         // error; order the first upload after whatever is queued there
         HIP_TRY(hipEventRecord(c->ev_copy, c->stream));
         HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_copy, 0));
-        for (size_t lo = 0; lo < n; lo += CH) {
+        size_t part = CH;
+        for (size_t lo = 0; lo < n;) {
             size_t m = n - lo;
-            if (m > CH + CH / 2) m = CH;          // the tail joins the last chunk rather than running as a sliver
+            if (m > part + part / 2) m = part;          // a tail of less than half a part joins the last part rather than running as a sliver
             HIP_TRY(hipMemcpyAsync(d_c + lo * 64, commitments + lo * 64, m * 64, hipMemcpyHostToDevice, c->copy_stream));
             HIP_TRY(hipMemcpyAsync(d_p + lo * (size_t)BPPP_U64_PROOF_BYTES, proofs + lo * (size_t)BPPP_U64_PROOF_BYTES,
                                    m * (size_t)BPPP_U64_PROOF_BYTES, hipMemcpyHostToDevice, c->copy_stream));
@@ -323,7 +350,9 @@ static int verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
             int rc = verify_device_impl(c, label, label_len, m, d_c + lo * 64, d_p + lo * (size_t)BPPP_U64_PROOF_BYTES, d_a + lo, d_s + lo,
                                         nullptr, nullptr, rlc_seed, nullptr);
             if (rc != BPPP_OK) return rc;
-            if (m != CH) break;
+            lo += m;
+            part = m * BPPP_HOST_PART_GROWTH;
+            if (part > c->max_batch) part = c->max_batch;
         }
     }
     HIP_TRY(hipMemcpyAsync(accept, d_a, n, hipMemcpyDeviceToHost, c->stream));

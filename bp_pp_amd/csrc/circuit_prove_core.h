@@ -36,6 +36,8 @@ struct CircuitProveWs {
     // outputs for the WNLA prover (C-ABI layouts, device)
     uint8_t *wn_commit, *wn_c, *wn_rho, *wn_mu, *wn_l, *wn_n;
     FbTable fb;
+    FbTable fb_ct;                   // "ct_prover": the commitments to the witness and its blindings (circuit.rs:336-345, 469-470) in the full-scan form when ct != 0
+    int ct;
     strobe base;
     TranscriptIo tio;                // caller's transcripts (circuit.rs:260 `t: &mut Transcript`); input side ignored when transcript_preloaded
     int divergent_positions;

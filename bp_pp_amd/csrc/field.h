@@ -190,7 +190,7 @@ HD void limbs_to_be32(uint8_t* b, const u32 a[8]) {
 }
 
 // ---------------------------------------------------------------- Fp: p = 2^256 - 2^32 - 977, 10 x 26-bit limbs (unsaturated)
-// Why not the saturated 8 x 32 form used for Fn below: measured on MI355X (tools/intbench.hip), a lone wavefront per SIMD --
+// Why not the saturated 8 x 32 form used for Fn below: measured on MI355X (tools/probes/intbench.hip), a lone wavefront per SIMD --
 // the regime of the shared-doubling kernels at 2^16 proofs -- pays per INSTRUCTION, and the saturated product needs a carry
 // counter per limb product plus canonical selects after every add/sub.  With 26-bit limbs the 100 limb products accumulate
 // into 64-bit columns with no carries at all (v_mad_u64_u32 chains), add is 10 plain adds, sub is 10 add-sub pairs against a
@@ -328,75 +328,14 @@ HD void fe_reduce_cols(fe& r, const u64 c[19]) {
     FE_SETMAG(r, 1);
     FE_CHECK(r, 1);
 }
-// The same reduction with the carries riding in the multiply-adds (BPPP_FE_CHAINED, the default).  fe_reduce_cols takes 19 finished
-// column sums and then pays, per column, a 64-bit addition to bring the carry in (2 issue slots) plus mask + 64-bit shift to take the
-// next one out (3).  Here a column's chain of v_mad_u64_u32 STARTS from the carry of the column below -- the addend of a multiply-add is
-// free -- and the high walk hands on overlapping 32-bit digits instead of exact 26-bit ones: digit = the low register as it is, carry =
-// the high register times 2^6 (the columns are 2^26 apart).  Per multiplication that removes 18 64-bit additions, 9 masks and 9 of the
-// 64-bit shifts: ~ 54 of ~ 375 issue slots.  The price is a serial dependency through the columns (the 19 sums were independent
-// chains); two wavefronts per SIMD and the independent multiplications of a point operation cover it.
-//   col(k, acc): adds every limb product of column k to acc.
-// Bounds: a column sum stays <= 10 * 2^60 (fe_mul2_add's contract), a carry <= 2^38, a fold term u * R0 <= 2^46: below 2^64.
-template <class Col>
-HD void fe_reduce_chained(fe& r, Col&& col) {
-    const u32 k1024 = opaque_u32(1024u), k64 = opaque_u32(64u);
-    u64 acc = 0;
-    col(9, acc);
-    const u32 t9 = (u32)acc;                              // 32 bits at column 9 (the tail below takes any width)
-    u64 cy = (u64)(u32)(acc >> 32) << 6;
-    u32 u[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        acc = cy;
-        col(k + 10, acc);
-        u[k] = (u32)acc;                                  // overlapping digit: < 2^32, folded with 14- and 11-bit constants below
-        cy = (u64)(u32)(acc >> 32) << 6;
-    }
-    const u64 d = cy;                                     // column 19: < 2^35
-    u64 e = 0;
-    u32 t[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        acc = e;
-        col(k, acc);
-        acc += (u64)u[k] * BPPP_R0;
-        if (k > 0) acc += (u64)u[k - 1] * k1024;
-        t[k] = (u32)acc & BPPP_M26;
-        e = acc >> 26;
-    }
-    e += (u64)u[8] * k1024;
-    const u32 d_lo = (u32)d, d_hi = (u32)(d >> 32);
-    e += (u64)t9 + (u64)d_lo * BPPP_R0 + (((u64)d_hi * BPPP_R0) << 32);
-    r.v[9] = (u32)e & BPPP_M22;
-    e >>= 22;
-    e += d << 14;
-    const u32 e0 = (u32)e & BPPP_M26, e1 = (u32)(e >> 26);
-    u64 f = (u64)t[0] + (u64)e0 * BPPP_PC0;
-    r.v[0] = (u32)f & BPPP_M26; f >>= 26;
-    f += (u64)t[1] + (u64)e0 * k64 + (u64)e1 * BPPP_PC0;
-    r.v[1] = (u32)f & BPPP_M26; f >>= 26;
-    f += (u64)t[2] + (u64)e1 * k64;
-    r.v[2] = (u32)f & BPPP_M26; f >>= 26;
-    r.v[3] = t[3] + (u32)f;
-#pragma unroll
-    for (int k = 4; k < 9; k++) r.v[k] = t[k];
-    FE_SETMAG(r, 1);
-    FE_CHECK(r, 1);
-}
-#ifndef BPPP_FE_CHAINED
-#define BPPP_FE_CHAINED 1
-#endif
+// (Round 5 measured a form of this reduction with the carries riding in the multiply-adds -- a column's v_mad_u64_u32 chain starting from
+// the carry of the column below, overlapping 32-bit digits in the high walk: 54 of ~ 375 issue slots per multiplication fewer on paper.
+// hipcc turns `carry + a b + c d` back into products plus a 64-bit addition, so it took one asm statement per multiply-add; that build
+// ran the fixed-base sums 1.3 % faster, the four rounds 1.6 % SLOWER and a 2^16-proof batch 12 % slower -- a lone wavefront per SIMD
+// cannot cover a 118-deep dependent chain.  Not kept: docs/design/06-measurements.md, "Round 5".)
 HD void fe_mul(fe& r, const fe& a, const fe& b) {
     FE_CHECK(a, 8);
     FE_CHECK(b, 8);
-#if BPPP_FE_CHAINED
-    fe_reduce_chained(r, [&](int k, u64& acc) {
-        const int i0 = k < 10 ? 0 : k - 9, i1 = k < 10 ? k : 9;
-#pragma unroll
-        for (int i = i0; i <= i1; i++) acc += (u64)a.v[i] * b.v[k - i];
-    });
-    return;
-#endif
     u64 c[19];
 #pragma unroll
     for (int k = 0; k < 19; k++) {
@@ -416,16 +355,6 @@ HD void fe_mul2_add(fe& r, const fe& a, const fe& b, const fe& c, const fe& d) {
 #ifdef BPPP_FE_DEBUG
     assert(a.mag * b.mag + c.mag * d.mag <= 64);
 #endif
-#if BPPP_FE_CHAINED
-    fe_reduce_chained(r, [&](int k, u64& acc) {
-        const int i0 = k < 10 ? 0 : k - 9, i1 = k < 10 ? k : 9;
-#pragma unroll
-        for (int i = i0; i <= i1; i++) acc += (u64)a.v[i] * b.v[k - i];
-#pragma unroll
-        for (int i = i0; i <= i1; i++) acc += (u64)c.v[i] * d.v[k - i];
-    });
-    return;
-#endif
     u64 col[19];
 #pragma unroll
     for (int k = 0; k < 19; k++) {
@@ -444,15 +373,6 @@ HD void fe_sqr(fe& r, const fe& a) {   // 55 limb products: cross terms use the 
     u32 a2[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) a2[i] = a.v[i] << 1;   // <= 2^31
-#if BPPP_FE_CHAINED
-    fe_reduce_chained(r, [&](int k, u64& acc) {
-        const int i0 = k < 10 ? 0 : k - 9;
-#pragma unroll
-        for (int i = i0; 2 * i < k; i++) acc += (u64)a2[i] * a.v[k - i];
-        if ((k & 1) == 0) acc += (u64)a.v[k / 2] * a.v[k / 2];
-    });
-    return;
-#endif
     u64 c[19];
 #pragma unroll
     for (int k = 0; k < 19; k++) {

@@ -93,6 +93,15 @@ struct bppp_ctx {
     // bucket stage of the RLC mode (bucket_core.h): superchunk size (0 = stage off) and its workspace
     unsigned rlc_super_m = 4096;       // cap of the automatic choice, or the explicit size (bucket_superchunk_for)
     bool rlc_super_auto = true;
+    int rlc_chunk_opt = 0;             // option "rlc_chunk": proofs per chunk after the bucket stage, 8 or 32; 0 = from the previous call's reject rate
+    // what the previous RLC call on this context rejected (plan_core.h: plan_rlc): a device counter, copied to pinned host memory at the
+    // end of the call; read by the next call if the copy has landed by then
+    int* d_rlc_hist = nullptr;
+    int* h_rlc_hist = nullptr;
+    hipEvent_t ev_rlc_hist = nullptr;
+    size_t rlc_hist_n = 0;             // proofs of the call the counter belongs to (0: no call in flight or recorded)
+    double rlc_rate = -1.0;            // last known reject rate; < 0: none
+    unsigned last_rlc_super_m = 0, last_rlc_chunk = 0;      // what the last RLC call used ("last_rlc_superchunk" / "last_rlc_chunk")
     size_t bcap = 0;
     uint8_t* d_bkt = nullptr;
     size_t bkt_bytes = 0;
@@ -349,6 +358,15 @@ static inline int launch_bucket_stage(bppp_ctx* c, BucketWs& bw, size_t n, unsig
     if (rc == BPPP_OK) rc = timed_launch(K_BKT_SCALARS, [&]() { k_bkt_scalars<<<sgrid, 256, 0, s>>>(bw); });
     if (rc == BPPP_OK) rc = timed_launch(K_BKT_CHECK, [&]() { k_bkt_check<<<(unsigned)nsuper, 64, 0, s>>>(bw); });
     return rc;
+}
+// the RLC mode's reject history: a device counter, its pinned host copy and the event that says the copy has landed
+static inline int ensure_rlc_history(bppp_ctx* c) {
+    if (c->d_rlc_hist) return BPPP_OK;
+    HIP_TRY(hipMalloc(&c->d_rlc_hist, sizeof(int)));
+    HIP_TRY(hipHostMalloc((void**)&c->h_rlc_hist, sizeof(int), hipHostMallocDefault));
+    *c->h_rlc_hist = 0;
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_rlc_hist, hipEventDisableTiming));
+    return BPPP_OK;
 }
 static inline int drain_timings(bppp_ctx* c) {
     if (c->pending.empty()) return BPPP_OK;

@@ -33,7 +33,9 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wprove_msm
     pt part;
     FbRanges rg;
     wnla_prove_msm_ranges(rg, w, oddsh);
-    fb_group_sum(part, w.fb, t, lane, w.msc + (size_t)set * wp_set_words(w), rg);
+    // (ct: wave-uniform -- the secret-scalar form reads every entry of every window and selects by mask)
+    if (w.ct) fb_group_sum_ct<BPPP_FB_LANES>(part, w.fb_ct, t, lane, w.msc + (size_t)set * wp_set_words(w), rg);
+    else fb_group_sum(part, w.fb, t, lane, w.msc + (size_t)set * wp_set_words(w), rg);
     if (lane == 0) ws_st_pt(w.pbuf + (size_t)set * 30 * w.N, w.N, t, part);
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wprove_round_fold(WnlaProveWs w, int k) {
@@ -72,7 +74,8 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_cprove_msm
     pt part;
     FbRanges rg;
     cp_ranges(rg, w, with_g != 0);
-    fb_group_sum(part, w.fb, t, lane, w.msc + (size_t)set * cp_set_words(w), rg);
+    if (w.ct) fb_group_sum_ct<BPPP_FB_LANES>(part, w.fb_ct, t, lane, w.msc + (size_t)set * cp_set_words(w), rg);
+    else fb_group_sum(part, w.fb, t, lane, w.msc + (size_t)set * cp_set_words(w), rg);
     if (lane == 0) ws_st_pt(w.pbuf + (size_t)set * 30 * w.N, w.N, t, part);
 }
 // ---- generic reciprocal prover kernels (recip_prove_core.h)
@@ -89,7 +92,8 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rprove_msm
     pt part;
     FbRanges rg;
     recip_prove_ranges(rg, w);
-    fb_group_sum(part, w.fb, t, lane, w.msc, rg);
+    if (w.ct) fb_group_sum_ct<BPPP_FB_LANES>(part, w.fb_ct, t, lane, w.msc, rg);
+    else fb_group_sum(part, w.fb, t, lane, w.msc, rg);
     if (lane == 0) ws_st_pt(w.pbuf, w.N, t, part);
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_rprove_stage_r2(RecipProveWs w) {

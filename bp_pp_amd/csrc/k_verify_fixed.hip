@@ -40,21 +40,26 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_fin
 // instead of 26 / 74 additions per lane and a 3-step tree)
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed_l64(VerifyWs ws) { verify_c0_fixed_lanes<64>(ws); }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_l64(VerifyWs ws) { verify_final_check_lanes<64>(ws); }
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(VerifyWs ws, RlcWs r) {
+// RLC mode, one combined final check per chunk of C proofs (rlc_core.h): C lanes per chunk, a lane per proof -- its 49 weighted
+// scalars, summed over the chunk with shuffles; the chunk's ONE 49-base fixed-base sum on the same C lanes; the weighted commitments
+// summed the same way.  C = 8 (round 1) or 32: the right-hand side's 588 table additions are then shared by four times the proofs
+// (74 -> 18 per proof), and a chunk holds a bad proof four times as often -- bppp_u64.hip picks C from the previous call's reject rate.
+template <int C>
+__device__ __forceinline__ void rlc_chunk_lanes(const VerifyWs& ws, const RlcWs& r) {
     const size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    const size_t chunk = g / BPPP_RLC_CHUNK;
-    const int lane = (int)(g % BPPP_RLC_CHUNK);
-    const size_t N = ws.N, nchunks = (N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    const size_t chunk = g / C;
+    const int lane = (int)(g % C);
+    const size_t N = ws.N, nchunks = (N + C - 1) / C;
     if (chunk >= nchunks) return;            // whole lane groups leave together
-    const size_t t = chunk * BPPP_RLC_CHUNK + lane;
-    if (rlc_done_by_bucket_stage(r, chunk * BPPP_RLC_CHUNK)) {     // whole lane groups leave together (super_m is a multiple of 8)
+    const size_t t = chunk * C + lane;
+    if (rlc_done_by_bucket_stage(r, chunk * C)) {     // whole lane groups leave together (super_m is a multiple of C)
         if (lane == 0) r.flag[chunk] = 0;
         return;
     }
     // a chunk with a missing or flagged proof goes to the exact kernels
     int bad = (t < N) ? (ws.status[t] != ST_OK) : 1;
 #pragma unroll
-    for (int m = 1; m < BPPP_RLC_CHUNK; m <<= 1) bad |= __shfl_xor(bad, m, 64);
+    for (int m = 1; m < C; m <<= 1) bad |= __shfl_xor(bad, m, 64);
     if (bad) {
         if (lane == 0) { r.flag[chunk] = 1; r.list[atomicAdd(r.count, 1)] = (u32)chunk; }
         return;
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(
         sc p;
         rlc_product(p, ws, w, t, i);
 #pragma unroll
-        for (int m = 1; m < BPPP_RLC_CHUNK; m <<= 1) {
+        for (int m = 1; m < C; m <<= 1) {
             sc o;
 #pragma unroll
             for (int k = 0; k < 8; k++) o.v[k] = __shfl_xor(p.v[k], m, 64);
@@ -79,9 +84,9 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(
     FbRanges rg;
     rlc_ranges(rg);
     pt rhs, lhs;
-    fb_group_sum(rhs, fb_of(ws), t, lane, r.sc, rg);
+    fb_group_sum<C>(rhs, fb_of(ws), t, lane, r.sc, rg);
     ws_ld_pt(lhs, r.lhs, N, t);
-    lane_group_sum(lhs);
+    lane_group_sum<C>(lhs);
     const bool ok = pt_eq(lhs, rhs);
     if (ok) ws.accept[t] = 1;
     if (lane == 0) {
@@ -89,16 +94,18 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(
         if (!ok) r.list[atomicAdd(r.count, 1)] = (u32)chunk;
     }
 }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(VerifyWs ws, RlcWs r) { rlc_chunk_lanes<BPPP_RLC_CHUNK>(ws, r); }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk_c32(VerifyWs ws, RlcWs r) { rlc_chunk_lanes<32>(ws, r); }
 // exact final check of the proofs of the flagged chunks: a whole wavefront per proof (637 table additions over 64 lanes, 6-step
 // tree), because only a few proofs are expected here and an 8-lane group would take the full 80-addition latency for each
 __global__ __launch_bounds__(64) void k_verify_final_check_flagged(VerifyWs ws, RlcWs r) {
     const int lane = (int)threadIdx.x;
-    const size_t nchunks = (ws.N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
-    if ((size_t)(*r.count) * 8 > nchunks) return;   // many flagged chunks: k_verify_final_check_flagged_dense does them
-    const size_t items = (size_t)(*r.count) * BPPP_RLC_CHUNK;
+    const size_t C = rlc_chunk_of(r);
+    const size_t items = (size_t)(*r.count) * C;
+    if (items * 8 > ws.N) return;   // more than an eighth of the batch flagged: k_verify_final_check_flagged_dense does them
 #pragma nounroll
     for (size_t item = blockIdx.x; item < items; item += gridDim.x) {
-        const size_t t = (size_t)r.list[item / BPPP_RLC_CHUNK] * BPPP_RLC_CHUNK + item % BPPP_RLC_CHUNK;
+        const size_t t = (size_t)r.list[item / C] * C + item % C;
         if (t >= ws.N) continue;
         pt part;
         FbRanges rg;
@@ -107,15 +114,15 @@ __global__ __launch_bounds__(64) void k_verify_final_check_flagged(VerifyWs ws, 
         if (lane == 0) verify_final_check_store(ws, t, part);
     }
 }
-// the same for a batch where more than 1/8 of the chunks failed (an adversarial or broken input stream): the regular 8-lane
-// kernel over the whole batch, skipping the chunks that passed
+// the same for a batch where more than 1/8 of the proofs sit in chunks that failed (an adversarial or broken input stream): the regular
+// 8-lane kernel over the whole batch, skipping the chunks that passed
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_flagged_dense(VerifyWs ws, RlcWs r) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
     size_t t = g / BPPP_FB_LANES;
     int lane = (int)(g % BPPP_FB_LANES);
-    const size_t nchunks = (ws.N + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
-    if ((size_t)(*r.count) * 8 <= nchunks) return;
-    if (t >= ws.N || !r.flag[t / BPPP_RLC_CHUNK]) return;
+    const size_t C = rlc_chunk_of(r);
+    if ((size_t)(*r.count) * C * 8 <= ws.N) return;
+    if (t >= ws.N || !r.flag[t / C]) return;
     pt part;
     FbRanges rg;
     verify_final_check_ranges(rg);

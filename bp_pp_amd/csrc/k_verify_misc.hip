@@ -71,11 +71,15 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(VerifyWs ws, int* 
         if (reject_count && !ws.accept[t]) atomicAdd(reject_count, 1);
     }
 }
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept_flagged(VerifyWs ws, RlcWs r, int* reject_count) {
+// (hist_count: the context's own reject counter of its RLC calls -- what the next call's choice of chunk sizes is made from)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept_flagged(VerifyWs ws, RlcWs r, int* reject_count, int* hist_count) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t >= ws.N) return;
-    if (r.flag[t / BPPP_RLC_CHUNK]) verify_accept(ws, t);
-    if (reject_count && !ws.accept[t]) atomicAdd(reject_count, 1);
+    if (r.flag[t / rlc_chunk_of(r)]) verify_accept(ws, t);
+    if (!ws.accept[t]) {
+        if (reject_count) atomicAdd(reject_count, 1);
+        if (hist_count) atomicAdd(hist_count, 1);
+    }
 }
 // generator decoding + validation (context creation): 64-B big-endian -> device affine; flags[0] |= 1 on a bad point
 __global__ void k_decode_generators(const uint8_t* in, apt* out, int n, int* flags) {

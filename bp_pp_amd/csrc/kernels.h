@@ -112,9 +112,10 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept(bppp::VerifyWs ws,
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_export_states(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(bppp::VerifyWs ws, bppp::RlcWs r);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(bppp::VerifyWs ws, bppp::RlcWs r);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk_c32(bppp::VerifyWs ws, bppp::RlcWs r);      // chunks of 32 proofs
 __global__ __launch_bounds__(64) void k_verify_final_check_flagged(bppp::VerifyWs ws, bppp::RlcWs r);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_flagged_dense(bppp::VerifyWs ws, bppp::RlcWs r);
-__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept_flagged(bppp::VerifyWs ws, bppp::RlcWs r, int* reject_count);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept_flagged(bppp::VerifyWs ws, bppp::RlcWs r, int* reject_count, int* hist_count);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass1(bppp::FbBuild fb, size_t nthreads);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_fb_build_pass2(bppp::FbBuild fb, size_t nthreads);
 __global__ void k_decode_generators(const uint8_t* in, bppp::apt* out, int n, int* flags);
@@ -122,6 +123,13 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_commit_value(bppp::VerifyWs ws, 
 __global__ __launch_bounds__(256) void k_sec1_expand(uint8_t* commitments64, uint8_t* proofs928, const uint8_t* commitments33, const uint8_t* proofs525, size_t n);
 __global__ __launch_bounds__(256) void k_sec1_compress(uint8_t* commitments33, uint8_t* proofs525, const uint8_t* commitments64,
                                                        const uint8_t* proofs928, size_t n);
+// the u64 prover's stages that touch the transcript run once per distinct sponge position in the wavefront (for_each_position_group
+// above; one trip unless the caller passed per-proof pre-loaded transcripts of different lengths) -- shared by k_prove.hip and k_prove_w2.hip
+#if defined(__HIPCC__)
+__device__ __forceinline__ bppp::u32 prove_position_key(const bppp::ProveWs& w, size_t t) {
+    return (w.states && w.n_states != 1) ? w.tstate[(size_t)50 * w.N + t] : 0u;
+}
+#endif
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_a(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_b(bppp::ProveWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_stage_d(bppp::ProveWs w);

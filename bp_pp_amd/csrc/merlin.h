@@ -89,7 +89,7 @@ HD void keccak_f1600(u64 a[25]) {
 // ---- sponge state access.  The byte position is a runtime value, but every lane of a wavefront runs the same transcript
 // schedule, so it is wave-uniform: it is read into a scalar register and the state word is picked with a scalar switch, which
 // keeps the 25 state words in VGPRs (a dynamically indexed `st[pos >> 3]` would put the state in scratch memory and make every
-// absorbed byte a ~500-900 cycle store-load round trip; measured with tools/phase_probe.py: 58 k cycles per challenge).
+// absorbed byte a ~500-900 cycle store-load round trip; measured with tools/probes/phase_probe.py: 58 k cycles per challenge).
 // Bytes are absorbed in chunks of up to 4 (one switch per chunk), and a 32-byte challenge is read from the first four words.
 HD u32 st_uniform(u32 x) {
 #if defined(__HIP_DEVICE_COMPILE__)

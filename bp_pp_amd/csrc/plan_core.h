@@ -139,6 +139,32 @@ inline ProvePlan plan_prove(size_t n, const PlanKnobs& k, bool ct) {
     return p;
 }
 
+// ---- RLC mode: how the final checks of a batch are grouped, from what the previous RLC call on the context rejected.
+// The stages (docs/design/09): bucket stage over superchunks of M proofs (Pippenger, ~ 4 ms per 2^20 proofs at M = 4096, more for
+// smaller M) -> chunks of C proofs for the superchunks that failed (per proof a 64-doubling weighted commitment, ~ 7 ms per 2^20, plus
+// the chunk's 49-base sum: 588 table additions shared by C proofs) -> the exact per-proof check for the chunks that failed.  A group
+// passes only if every proof in it is valid: with a reject rate r a superchunk passes with probability e^(-r M), a chunk with
+// e^(-r C).  Round 4 always took M = 4096 and C = 8: at r = 1/1024 every superchunk failed (its 4 ms wasted) and the chunks of 8 paid
+// 74 table additions per proof where chunks of 32 pay 18.  With the rate of the previous call in hand:
+//   M: the automatic size, halved while r M > 0.3 (down to 1,024: smaller bucket stages cost more than they save), no bucket stage at
+//      all when even that one would fail more often than not (r M > 0.45);
+//   C: 32 while a chunk of 32 still passes nine times in ten (r <= 1/256), else 8.
+// rate < 0 = no history (first call, or the previous one still in flight): round 4's choice.
+struct RlcPlan { unsigned super_m, chunk; };
+inline RlcPlan plan_rlc(unsigned auto_super_m, bool super_is_auto, int chunk_option /* 0 auto, 8, 32 */, double rate) {
+    RlcPlan p;
+    p.super_m = auto_super_m;
+    if (super_is_auto && auto_super_m && rate > 0) {
+        unsigned m = auto_super_m;
+        while (m > 1024 && rate * m > 0.3) m /= 2;
+        p.super_m = rate * m > 0.45 ? 0u : m;
+    }
+    if (chunk_option == 8 || chunk_option == 32) p.chunk = (unsigned)chunk_option;
+    else p.chunk = (rate >= 0 && rate * 256 <= 1.0) ? 32u : 8u;
+    if (p.super_m % 32) p.chunk = 8;      // a superchunk is made of whole chunks (explicit sizes are multiples of 8)
+    return p;
+}
+
 // "phase1=wg4 tables=beside/1 fb=l8 c0var=small round=small tail_beside=1 small=1 split=0" -- what tests assert on
 inline int plan_describe(uint32_t code, bool prove, char* buf, size_t cap) {
     static const char* const P1[] = {"full", "small", "wg4", "g16"};

@@ -25,6 +25,8 @@ struct RecipProveWs {
     uint8_t *cp_v, *cp_sv, *cp_wr, *cp_vpts;   // inputs of the circuit prover: n x (nd + 1) x 32, n x 32, n x nd x 32, n x 64
     uint8_t* proof_r;    // n x 64
     FbTable fb;
+    FbTable fb_ct;       // "ct_prover": the sum over the reciprocals (secret: reciprocal.rs:118) in the full-scan form when ct != 0
+    int ct;
     strobe base;
     TranscriptIo tio;    // caller's transcripts (reciprocal.rs:109 `t: &mut Transcript`)
     int divergent_positions;

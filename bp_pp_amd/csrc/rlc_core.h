@@ -30,7 +30,12 @@ struct RlcWs {
     // their proofs are skipped here; null = no bucket stage, every chunk of 8 is checked
     const uint8_t* sflag;
     u32 super_m;
+    // u64 verifier: proofs per chunk of THIS call, 8 or 32 (0 reads as 8; bppp_u64.hip picks it from the previous call's reject rate:
+    // a chunk of 32 spreads the right-hand side's 49-base sum over four times the proofs, and fails four times as often)
+    u32 chunk;
 };
+#define BPPP_RLC_CHUNK_MAX 32
+HD u32 rlc_chunk_of(const RlcWs& r) { return r.chunk ? r.chunk : (u32)BPPP_RLC_CHUNK; }
 HD bool rlc_done_by_bucket_stage(const RlcWs& r, size_t t) { return r.sflag && !r.sflag[t / r.super_m]; }
 
 // weight halves (a, b): one permutation of  seed[0..3] | index | domain tag | 0...
@@ -130,12 +135,13 @@ HD void rlc_product(sc& out, const VerifyWs& ws, const sc& w, size_t t, int i) {
 HD void rlc_ranges(FbRanges& rg) { fb_ranges_one(rg, 0, 0, BPPP_NG); }
 // host / single-thread form of the chunk check (the device kernel does the same with wavefront shuffles): returns the verdict
 HD bool rlc_chunk_serial(const VerifyWs& ws, const RlcWs& r, size_t chunk) {
-    const size_t N = ws.N, first = chunk * BPPP_RLC_CHUNK;
-    bool usable = first + BPPP_RLC_CHUNK <= N;
-    for (size_t j = first; usable && j < first + BPPP_RLC_CHUNK; j++) usable &= ws.status[j] == ST_OK;
+    const size_t C = rlc_chunk_of(r);
+    const size_t N = ws.N, first = chunk * C;
+    bool usable = first + C <= N;
+    for (size_t j = first; usable && j < first + C; j++) usable &= ws.status[j] == ST_OK;
     if (!usable) return false;
-    sc wv[BPPP_RLC_CHUNK];
-    for (int l = 0; l < BPPP_RLC_CHUNK; l++) {
+    sc wv[BPPP_RLC_CHUNK_MAX];
+    for (size_t l = 0; l < C; l++) {
         u64 a, b;
         rlc_weight(a, b, r, first + l);
         rlc_weight_scalar(wv[l], a, b);
@@ -143,15 +149,15 @@ HD bool rlc_chunk_serial(const VerifyWs& ws, const RlcWs& r, size_t chunk) {
     for (int i = 0; i < BPPP_NG; i++) {
         sc A, p;
         sc_set_u32(A, 0);
-        for (int l = 0; l < BPPP_RLC_CHUNK; l++) { rlc_product(p, ws, wv[l], first + l, i); sc_add(A, A, p); }
-        for (int l = 0; l < BPPP_RLC_CHUNK; l++) ws_st8(r.sc, N, first + l, i, A.v);
+        for (size_t l = 0; l < C; l++) { rlc_product(p, ws, wv[l], first + l, i); sc_add(A, A, p); }
+        for (size_t l = 0; l < C; l++) ws_st8(r.sc, N, first + l, i, A.v);
     }
     FbRanges rg;
     rlc_ranges(rg);
     pt rhs, lhs, L;
     fb_sum_serial(rhs, fb_of(ws), first, r.sc, rg);
     pt_set_identity(lhs);
-    for (int l = 0; l < BPPP_RLC_CHUNK; l++) { ws_ld_pt(L, r.lhs, N, first + l); pt_add(lhs, lhs, L); }
+    for (size_t l = 0; l < C; l++) { ws_ld_pt(L, r.lhs, N, first + l); pt_add(lhs, lhs, L); }
     return pt_eq(lhs, rhs);
 }
 

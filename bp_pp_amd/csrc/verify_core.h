@@ -24,7 +24,7 @@ namespace bppp {
 
 // Optional phase stamps (diagnostic builds only: -DBPPP_PHASE_TIMING): lane 0 of every wavefront records the constant-rate 100 MHz
 // counter (s_memrealtime: one time base for all eight XCDs, unlike the per-XCD shader-clock counter of clock64()) at marked points of
-// verify_phase1 / verify_round / verify_tables / verify_c0_var into g_bppp_stamps; tools/phase_probe.py and tools/wave_timeline.py read them back.
+// verify_phase1 / verify_round / verify_tables / verify_c0_var into g_bppp_stamps; tools/probes/phase_probe.py and tools/probes/wave_timeline.py read them back.
 #if defined(BPPP_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 extern __device__ unsigned long long g_bppp_stamps[1024 * 32];
 #define BPPP_STAMP(t, i) do { if (((t) & 63) == 0 && ((t) >> 6) < 1024) g_bppp_stamps[((t) >> 6) * 32 + (i)] = (unsigned long long)wall_clock64(); } while (0)
@@ -240,10 +240,20 @@ HD void app_point(S& t, const char (&label)[L], const apt& a) {  // transcript.r
 // Window geometry.  W in {4, 8, 16}: unsigned digits, 256/W windows, 2^W - 1 entries per window.
 // W = 20: SIGNED digits in [-2^19, 2^19) (k + sum_i 2^(19+20i) has the digit + 2^19 in every 20-bit field), 13 windows,
 // 2^19 entries per window (|d| = 1..2^19) and a conditional negation of y -- 13 instead of 16 additions per scalar for
-// a 21 GB table; random 64-byte reads from a table of that size still run at ~19 G/s on MI355X (tools/gatherbench.hip),
+// a 21 GB table; random 64-byte reads from a table of that size still run at ~19 G/s on MI355X (tools/probes/gatherbench.hip),
 // above the ~12 G/s the arithmetic can consume.
 // (W = 10 is the same signed scheme with a table small enough for the CPU emulation tests: 26 windows of 512 entries.)
 struct FbTable { const apt_packed* table; int W; size_t N; };
+// TEST HOOK, host emulation only (tests/emul, tests/test_ct_trace.py): every fixed-base table entry a sum requests, as the entry's index
+// in its table.  The emulator records the sequence while a prover's SECRET sums run; the test requires it to be identical for two
+// different secrets in the "ct_prover" forms, and different in the default ones.  Compiled out of the device code and of any host
+// build that does not define BPPP_TRACE_TABLE_READS.
+#if !defined(__HIPCC__) && defined(BPPP_TRACE_TABLE_READS)
+void bppp_trace_table_read(const void* table, size_t index);
+#define FB_TRACE(tab, idx) bppp_trace_table_read((const void*)(tab), (size_t)(idx))
+#else
+#define FB_TRACE(tab, idx) ((void)0)
+#endif
 HD bool fb_signed(int W) { return W == 20 || W == 10 || W == 22 || W == 18 || W == 19; }
 HD int fb_nwin(int W) { return fb_signed(W) ? (257 + W - 1) / W : 256 / W; }           // signed: ceil(257 / W) windows
 HD size_t fb_per_win(int W) { return fb_signed(W) ? ((size_t)1 << (W - 1)) : (((size_t)1 << W) - 1); }
@@ -308,6 +318,7 @@ HD void fb_lookup_add(pt& acc, const FbTable& fbt, int base, int w, const u32 k[
     fb_digit(k, fbt.W, w, idx, skip, neg);
     const apt_packed* tb = fbt.table + ((size_t)base * fb_nwin(fbt.W) + w) * fb_per_win(fbt.W);
     apt e;
+    FB_TRACE(fbt.table, (tb - fbt.table) + idx);
     apt_unpack(e, id, tb[idx]);
     fe ny;
     fe_neg_m<1>(ny, e.y);
@@ -477,11 +488,13 @@ HD void fb_lane_accumulate_seq(ptz& acc, bool& empty, const FbTable& fbt, const 
     FbStep cur_st, nxt_st;
     apt_packed cur_e, nxt_e;
     produce(cur_st);
+    FB_TRACE(fbt.table, cur_st.ptr - fbt.table);
     cur_e = *cur_st.ptr;
     ws_ld8(k, scal, fbt.N, t, first_slot + jn);
     produce(nxt_st);
 #pragma nounroll
     for (int i = 0; i < steps; i++) {
+        FB_TRACE(fbt.table, nxt_st.ptr - fbt.table);
         nxt_e = *nxt_st.ptr;                                    // step i+1's entry
         ws_ld8(k, scal, fbt.N, t, first_slot + jn);             // the producer's next scalar (used when step i+2 starts a term)
         fb_sched_fence();
@@ -532,6 +545,7 @@ HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, const
     // prologue: entry of step 0, address of step 1
     ws_ld8(k, scal, fbt.N, t, first_slot + fb_term_index(a, oddsh));
     produce(cur_st, k);
+    FB_TRACE(fbt.table, cur_st.ptr - fbt.table);
     cur_e = *cur_st.ptr;
     advance();
     ws_ld8(k, scal, fbt.N, t, first_slot + fb_term_index(a, oddsh));
@@ -539,6 +553,7 @@ HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, const
     advance();
 #pragma nounroll
     for (int i = 0; i < steps; i++) {
+        FB_TRACE(fbt.table, nxt_st.ptr - fbt.table);
         nxt_e = *nxt_st.ptr;                                                    // step i+1's entry
         ws_ld8(k, scal, fbt.N, t, first_slot + fb_term_index(a, oddsh));        // step i+2's scalar
         fb_sched_fence();
@@ -683,6 +698,7 @@ HD void fb_lookup_add_ct(pt& acc, const FbTable& fbt, int base, int w, const u32
     for (int i = 0; i < 8; i++) { sel.x[i] = 0; sel.y[i] = 0; }
 #pragma nounroll
     for (u32 e = 1; e <= 15; e++) {
+        FB_TRACE(fbt.table, (tb - fbt.table) + (e - 1));
         const apt_packed v = tb[e - 1];
         const u32 m = 0u - (u32)(d == e);
 #pragma unroll
@@ -2252,53 +2268,58 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
     BPPP_STAMP(t, 22);
     sc rho, y[4], rk[4], l0, l1, n0;
     ws_ld8(rho.v, ws.chal, N, t, 1);
-#pragma nounroll
+#pragma unroll
     for (int k = 0; k < 4; k++) ws_ld8(y[k].v, ws.chal, N, t, 6 + k);
     ws_ld8(l0.v, ws.lns, N, t, 0);
     ws_ld8(l1.v, ws.lns, N, t, 1);
     ws_ld8(n0.v, ws.lns, N, t, 2);
     // rho_1 = rho, rho_{k+1} = mu_k, mu_{k+1} = mu_k^2 (wnla.rs:109-110): rho_k = rho^(2^(k-1)); final mu = rho^32
     rk[0] = rho;
-#pragma nounroll
+#pragma unroll
     for (int k = 1; k < 4; k++) sc_mul(rk[k], rk[k - 1], rk[k - 1]);
     sc mu5;
     sc_mul(mu5, rk[3], rk[3]);
     sc_mul(mu5, mu5, mu5);
     // ch[b] = prod_{k: bit k of b} y_{k+1}        (h_vec / c folding, wnla.rs:96,98 unrolled)
     // cg[b] = prod_k (bit k of b ? y_{k+1} : rho_{k+1})   (g_vec folding, wnla.rs:97 unrolled)
-    // Built in place in the output slots (cg[b] at fsc slot 1 + b, ch[b] at slot 17 + b) instead of two 16-element arrays in
-    // scratch memory; the final products overwrite them.
-    sc one;
+    // Both as (low two bits) x (high two bits): four quarter tables of four scalars, in REGISTERS.  Round 4 grew the two 16-entry tables
+    // in place in the output slots, every product a store the next step loaded back (40 % of the kernel's cycles waited on memory);
+    // here nothing travels through the workspace but the 25 inputs c_i and the 49 results.
+    sc one, ch_lo[4], ch_hi[4], cg_lo[4], cg_hi[4];
     sc_set_u32(one, 1);
-    ws_st8(ws.fsc, N, t, 17, one.v);
-    ws_st8(ws.fsc, N, t, 1, one.v);
-#pragma nounroll
-    for (int k = 0; k < 4; k++) {
-        const int half = 1 << k;
-#pragma nounroll
-        for (int b = 0; b < half; b++) {
-            sc chb, cgb, tmp;
-            ws_ld8(chb.v, ws.fsc, N, t, 17 + b);
-            ws_ld8(cgb.v, ws.fsc, N, t, 1 + b);
-            sc_mul(tmp, chb, y[k]);
-            ws_st8(ws.fsc, N, t, 17 + b + half, tmp.v);
-            sc_mul(tmp, cgb, y[k]);
-            ws_st8(ws.fsc, N, t, 1 + b + half, tmp.v);
-            sc_mul(tmp, cgb, rk[k]);
-            ws_st8(ws.fsc, N, t, 1 + b, tmp.v);
-        }
-    }
-    // c'_0, c'_1 = folded c (c[25..31] = 0)
-    sc c0f, c1f, tmp, cv, chv;
+    ch_lo[0] = one; ch_lo[1] = y[0]; ch_lo[2] = y[1]; sc_mul(ch_lo[3], y[0], y[1]);
+    ch_hi[0] = one; ch_hi[1] = y[2]; ch_hi[2] = y[3]; sc_mul(ch_hi[3], y[2], y[3]);
+    sc_mul(cg_lo[0], rk[0], rk[1]); sc_mul(cg_lo[1], y[0], rk[1]); sc_mul(cg_lo[2], rk[0], y[1]); cg_lo[3] = ch_lo[3];
+    sc_mul(cg_hi[0], rk[2], rk[3]); sc_mul(cg_hi[1], y[2], rk[3]); sc_mul(cg_hi[2], rk[2], y[3]); cg_hi[3] = ch_hi[3];
+    auto pick = [](sc& r, const sc q[4], int i) {           // q[i], i wave-uniform: selects, no indexed registers
+#pragma unroll
+        for (int l = 0; l < 8; l++) r.v[l] = i == 0 ? q[0].v[l] : i == 1 ? q[1].v[l] : i == 2 ? q[2].v[l] : q[3].v[l];
+    };
+    sc c0f, c1f, tmp, cv, a, b;
     sc_set_u32(c0f, 0);
     sc_set_u32(c1f, 0);
 #pragma nounroll
-    for (int i = 0; i < 25; i++) {
+    for (int i = 0; i < 16; i++) {
+        sc chv, cgv;
+        pick(a, ch_lo, i & 3); pick(b, ch_hi, i >> 2);
+        sc_mul(chv, a, b);
+        pick(a, cg_lo, i & 3); pick(b, cg_hi, i >> 2);
+        sc_mul(cgv, a, b);
+        // c'_0, c'_1 = folded c (c[25..31] = 0)
         ws_ld8(cv.v, ws.cvec, N, t, i);
-        ws_ld8(chv.v, ws.fsc, N, t, 17 + (i & 15));
         sc_mul(tmp, cv, chv);
-        if (i < 16) sc_add(c0f, c0f, tmp);
-        else sc_add(c1f, c1f, tmp);
+        sc_add(c0f, c0f, tmp);
+        if (i < 9) {
+            ws_ld8(cv.v, ws.cvec, N, t, 16 + i);
+            sc_mul(tmp, cv, chv);
+            sc_add(c1f, c1f, tmp);
+        }
+        sc_mul(tmp, n0, cgv);
+        ws_st8(ws.fsc, N, t, 1 + i, tmp.v);
+        sc_mul(tmp, l0, chv);
+        ws_st8(ws.fsc, N, t, 17 + i, tmp.v);
+        sc_mul(tmp, l1, chv);
+        ws_st8(ws.fsc, N, t, 33 + i, tmp.v);
     }
     // v = <c', l> + n0^2 mu'   (wnla.rs:67 with weight_vector_mul exponent 1, util.rs:28-44)
     sc v, w;
@@ -2309,18 +2330,6 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
     sc_mul(w, w, mu5);
     sc_add(v, v, w);
     ws_st8(ws.fsc, N, t, 0, v.v);
-#pragma nounroll
-    for (int i = 0; i < 16; i++) {
-        sc cgv;
-        ws_ld8(cgv.v, ws.fsc, N, t, 1 + i);
-        sc_mul(tmp, n0, cgv);
-        ws_st8(ws.fsc, N, t, 1 + i, tmp.v);
-        ws_ld8(chv.v, ws.fsc, N, t, 17 + i);
-        sc_mul(tmp, l0, chv);
-        ws_st8(ws.fsc, N, t, 17 + i, tmp.v);
-        sc_mul(tmp, l1, chv);
-        ws_st8(ws.fsc, N, t, 33 + i, tmp.v);
-    }
 }
 #if defined(__HIPCC__)
 // The same scalars by SIXTEEN lanes per proof, for calls that leave the chip empty (bppp_u64.hip: the small-call path): lane b forms

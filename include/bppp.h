@@ -95,9 +95,19 @@ BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
  * the context stays usable; 0 clears it.  "max_batch": the u64 verify entry
  * points run a batch of more than max_batch proofs as consecutive parts of max_batch on the same stream, which bounds the per-proof
  * workspace (about 30 KB per proof) whatever n is -- a multiple of 64, >= 1024; default 2097152 (63 GB of workspace).
- * "ct_prover" = 1: the u64 prover's and committer's sums over SECRET scalars (bppp_u64_prove_*, bppp_u64_commit_value_batch; the generic
- * provers and bppp_msm_batch are NOT covered) -- x, s, the reciprocals and every blinding draw, i.e. V, r_com, c_o, c_l, c_r, c_s --
- * run in a form with no secret-dependent address, branch or instruction count
+ * "rlc_chunk" = 8 | 32 | 0 (default): in the RLC modes of the u64 verifier, the proofs per chunk of the stage behind the bucket stage; 0 = per call,
+ * from what the previous RLC call on this context rejected -- chunks of 32 while at most one proof in 256 was bad, and the bucket
+ * stage's superchunks halved (or the stage skipped) when most of them would hold a bad proof and fail ("rlc_superchunk" set explicitly
+ * is taken as it is); "rlc_history" = 0 forgets that rate.  bppp_ctx_get_option reads "last_rlc_superchunk" / "last_rlc_chunk" (what
+ * the last call used) and "rlc_reject_ppm" (the rate the next one will plan with, parts per million, -1 = none).  Accept bits never
+ * depend on these choices.
+ * "ct_prover" = 1: the provers' and the committer's sums over SECRET scalars -- bppp_u64_prove_* and bppp_u64_commit_value_batch (x, s,
+ * the reciprocals and every blinding draw, i.e. V, r_com, c_o, c_l, c_r, c_s); bppp_reciprocal_prove_batch* (the commitment to the
+ * reciprocals and the circuit stage below it); bppp_circuit_prove_batch* (c_l, c_r, c_o, c_s and the prover-side commitment of the
+ * blinded vectors); bppp_wnla_prove_batch* called on its own (X and R of every round: there l and n are the caller's secrets) --
+ * run in a form with no secret-dependent address, branch or instruction count.  NOT covered: bppp_msm_batch and bppp_wnla_commit_batch
+ * (plain sums with no notion of what is secret), and the WNLA stage INSIDE the u64 / reciprocal / circuit provers, whose vectors the
+ * argument folds and reveals by design.  The form:
  * (4-bit windows over a 3 MB table, every entry of every window read and selected by mask, complete addition law), as k256 does for
  * the reference (reciprocal.rs:88-95,118); the default (0) gathers one table entry per window at an address the digit selects, which
  * is a memory-access side channel towards whoever shares the GPU.  The proofs are byte-identical either way; the cost is reported in

@@ -7,6 +7,9 @@
 #include <cstring>
 #include <vector>
 
+#include "../../bp_pp_amd/csrc/plan_core.h"      // (before the device headers: field.h pulls <stdio.h> in inside its namespace in the host build)
+
+#define BPPP_TRACE_TABLE_READS 1      // verify_core.h: FB_TRACE reports every fixed-base table entry a sum requests (emulator only)
 #include "../../bp_pp_amd/csrc/prove_core.h"
 #include "../../bp_pp_amd/csrc/circuit_core.h"
 #include "../../bp_pp_amd/csrc/recip_core.h"
@@ -19,7 +22,31 @@
 
 using namespace bppp;
 
+// ---- record of the table entries the provers' SECRET sums request (tests/test_ct_trace.py).  The sequence must not depend on the
+// secrets in the "ct_prover" forms; in the default forms it does (that is the side channel the mode closes).
+static bool g_trace_on = false;               // inside a secret sum, with recording requested
+static bool g_trace_want = false;
+static std::vector<uint64_t> g_trace;
+void bppp::bppp_trace_table_read(const void*, size_t index) {
+    if (g_trace_on) g_trace.push_back((uint64_t)index);
+}
+// one prover sum over secret scalars: the "ct_prover" form or the default one, recorded when asked
+static void secret_sum(pt& a, const FbTable& fb, const FbTable& fb_ct, int ct, size_t t, const u32* scal, const FbRanges& rg) {
+    g_trace_on = g_trace_want;
+    if (ct) fb_sum_serial_ct(a, fb_ct, t, scal, rg);
+    else fb_sum_serial(a, fb, t, scal, rg);
+    g_trace_on = false;
+}
+
 extern "C" {
+void emul_trace_begin() { g_trace.clear(); g_trace_want = true; }
+// -> number of table reads recorded since emul_trace_begin; the first min(count, cap) indices are copied out
+size_t emul_trace_end(uint64_t* out, size_t cap) {
+    g_trace_want = false;
+    const size_t n = g_trace.size();
+    for (size_t i = 0; i < n && i < cap; i++) out[i] = g_trace[i];
+    return n;
+}
 
 void emul_fe_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {
     fe x, y, r;
@@ -397,6 +424,13 @@ static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* labe
     for (size_t t = 0; t < n; t++) verify_export_state(ws, t);
     return 0;
 }
+static int g_rlc_chunk = 8;
+void emul_set_rlc_chunk(int c) { g_rlc_chunk = c; }
+// the RLC mode's choice of group sizes from the previous call's reject rate (plan_core.h: plan_rlc)
+void emul_plan_rlc(unsigned auto_super_m, int super_is_auto, int chunk_option, double rate, unsigned out[2]) {
+    const bppp_host::RlcPlan p = bppp_host::plan_rlc(auto_super_m, super_is_auto != 0, chunk_option, rate);
+    out[0] = p.super_m; out[1] = p.chunk;
+}
 // the random-linear-combination batch mode (rlc_core.h): exact pipeline through the final scalars, weighted commitments, one
 // combined check per chunk of 8 proofs, exact re-check of the chunks that fail it.  Also returns the number of re-checked
 // chunks and, for tests, each proof's weight halves and weighted commitment.
@@ -446,10 +480,12 @@ int emul_u64_verify_batch_rlc(const uint8_t* table, int W, const uint8_t* label,
         }
     }
     int re = 0;
-    const size_t nchunks = (n + BPPP_RLC_CHUNK - 1) / BPPP_RLC_CHUNK;
+    r.chunk = (u32)g_rlc_chunk;                  // 8 (round 1's chunks) or 32 (emul_set_rlc_chunk)
+    const size_t C = rlc_chunk_of(r);
+    const size_t nchunks = (n + C - 1) / C;
     for (size_t c = 0; c < nchunks; c++) {
         const bool ok = rlc_chunk_serial(ws, r, c);
-        for (size_t t = c * BPPP_RLC_CHUNK; t < n && t < (c + 1) * BPPP_RLC_CHUNK; t++) {
+        for (size_t t = c * C; t < n && t < (c + 1) * C; t++) {
             if (ok) accept[t] = 1;
             else verify_final_check(ws, t);        // exact: fixed-base MSM + accept
         }
@@ -537,7 +573,11 @@ static int emul_u64_prove_impl(const uint8_t* table, int W, const uint8_t* label
         w.ct = 1; w.fb_ct = w.fb;
     }
     auto secret = [&](MsmJob job) {          // the sums over the witness and its blindings (bppp_u64.hip: PSECRET)
-        for (size_t t = 0; t < n; t++) { if (w.ct) prove_msm_ct(w, job, t); else prove_msm(w, job, t); }
+        for (size_t t = 0; t < n; t++) {
+            g_trace_on = g_trace_want;
+            if (w.ct) prove_msm_ct(w, job, t); else prove_msm(w, job, t);
+            g_trace_on = false;
+        }
     };
     for (size_t t = 0; t < n; t++) prove_stage_a(w, t);
     secret(job_v());
@@ -870,12 +910,16 @@ int emul_wnla_prove(const uint8_t* table, int W, int ng, int nh, const uint8_t* 
     t_new(w.base, label, (u32)label_len);
     w.tio = take_tio();
     w.tio.no_ops = rounds == 0;
+    if (g_prove_ct) {          // bppp_wnla_prove_batch with "ct_prover": l and n are the caller's secrets (emulator: the 4-bit table is the table)
+        if (W != 4) return -78;
+        w.ct = 1; w.fb_ct = w.fb;
+    }
     auto msm = [&](int set, int oddsh = -1) {
         for (size_t t = 0; t < n; t++) {
             pt a;
             FbRanges rg;
             wnla_prove_msm_ranges(rg, w, oddsh);
-            fb_sum_serial(a, w.fb, t, w.msc + (size_t)set * wp_set_words(w), rg);
+            secret_sum(a, w.fb, w.fb_ct, w.ct, t, w.msc + (size_t)set * wp_set_words(w), rg);
             ws_st_pt(w.pbuf + (size_t)set * 30 * n, n, t, a);
         }
     };
@@ -928,6 +972,10 @@ int emul_circuit_prove(const uint8_t* table, int W, int NG, int NH, const size_t
     p.lamv = lam.data(); p.muv = muv.data(); p.coef = coef.data(); p.misc = misc.data(); p.msc = msc.data(); p.pbuf = pb.data();
     p.wn_commit = wc.data(); p.wn_c = wcv.data(); p.wn_rho = wrho.data(); p.wn_mu = wmu.data(); p.wn_l = wlv.data(); p.wn_n = wnv.data();
     p.fb.table = (const apt_packed*)table; p.fb.W = W; p.fb.N = n;
+    if (g_prove_ct) {          // "ct_prover": c_l, c_r, c_o, c_s and the prover-side WNLA commitment in the full-scan form
+        if (W != 4) return -78;
+        p.ct = 1; p.fb_ct = p.fb;
+    }
     t_new(p.base, label, (u32)label_len);
     p.tio = take_tio();
     std::vector<uint8_t> pr(n * rounds * 64 + 1), px(n * rounds * 64 + 1), pl(n * nl_f * 32 + 1), pn(n * nn_f * 32 + 1);
@@ -948,7 +996,7 @@ int emul_circuit_prove(const uint8_t* table, int W, int NG, int NH, const size_t
             pt a;
             FbRanges rg;
             cp_ranges(rg, p, with_g);
-            fb_sum_serial(a, p.fb, t, p.msc + (size_t)set * cp_set_words(p), rg);
+            secret_sum(a, p.fb, p.fb_ct, p.ct, t, p.msc + (size_t)set * cp_set_words(p), rg);
             ws_st_pt(p.pbuf + (size_t)set * 30 * n, n, t, a);
         }
     };
@@ -1043,23 +1091,30 @@ int emul_recip_prove(const uint8_t* table, int W, int NG, int NH, int nd, int np
     w.com = com.data(); w.msc = p.msc; w.pbuf = p.pbuf; w.fb = p.fb;
     std::vector<pt_slot> wstraus(n * 2 * BPPP_STRAUS_ENTRIES);
     w.straus = wstraus.data();
+    if (g_prove_ct) {          // "ct_prover": the reciprocals' commitment and the circuit stage's commitments in the full-scan form
+        if (W != 4) return -78;
+        r.ct = 1; r.fb_ct = r.fb; p.ct = 1; p.fb_ct = r.fb;
+    }
     auto sum = [&](const FbRanges& rg, const u32* scal, u32* out) {
         for (size_t t = 0; t < n; t++) { pt a; fb_sum_serial(a, r.fb, t, scal, rg); ws_st_pt(out, n, t, a); }
+    };
+    auto ssum = [&](const FbRanges& rg, const u32* scal, u32* out) {          // a sum over secret scalars (k_rprove_msm, k_cprove_msm)
+        for (size_t t = 0; t < n; t++) { pt a; secret_sum(a, r.fb, r.fb_ct, r.ct, t, scal, rg); ws_st_pt(out, n, t, a); }
     };
     FbRanges rg;
     for (size_t t = 0; t < n; t++) recip_prove_stage_r1(r, t);
     recip_prove_ranges(rg, r);
-    sum(rg, r.msc, r.pbuf);
+    ssum(rg, r.msc, r.pbuf);
     for (size_t t = 0; t < n; t++) recip_prove_stage_r2(r, t);
     std::fill(msc.begin(), msc.end(), 0u);
     for (size_t t = 0; t < n; t++) circuit_prove_stage_a(p, t);
     cp_ranges(rg, p, false);
-    for (int set = 0; set < 3; set++) sum(rg, p.msc + (size_t)set * cp_set_words(p), p.pbuf + (size_t)set * 30 * n);
+    for (int set = 0; set < 3; set++) ssum(rg, p.msc + (size_t)set * cp_set_words(p), p.pbuf + (size_t)set * 30 * n);
     for (size_t t = 0; t < n; t++) circuit_prove_stage_b(p, t);
-    sum(rg, p.msc, p.pbuf);
+    ssum(rg, p.msc, p.pbuf);
     for (size_t t = 0; t < n; t++) circuit_prove_stage_c(p, t);
     cp_ranges(rg, p, true);
-    sum(rg, p.msc, p.pbuf);
+    ssum(rg, p.msc, p.pbuf);
     for (size_t t = 0; t < n; t++) circuit_prove_stage_d(p, t);
     for (size_t t = 0; t < n; t++) wnla_prove_init(w, t);
     wnla_prove_msm_ranges(rg, w);

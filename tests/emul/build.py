@@ -59,6 +59,14 @@ def load():
     L.emul_set_rlc_superchunk.restype = None
     L.emul_group_verify.argtypes = [i32, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, cp, sz, sz, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     L.emul_group_missing_ranks.argtypes = [i32, i32, vp]
+    L.emul_set_rlc_chunk.argtypes = [i32]
+    L.emul_set_rlc_chunk.restype = None
+    L.emul_plan_rlc.argtypes = [C.c_uint, i32, i32, C.c_double, vp]
+    L.emul_plan_rlc.restype = None
+    L.emul_trace_begin.argtypes = []
+    L.emul_trace_begin.restype = None
+    L.emul_trace_end.argtypes = [vp, sz]
+    L.emul_trace_end.restype = sz
     L.emul_group_prove.argtypes = [i32, i32, vp, i32, cp, sz, sz, vp, vp, vp, vp, vp, vp]
     L.emul_straus_split.argtypes = [i32, i32, cp, cp, vp, vp, vp]
     L.emul_set_prove_next_by_msm.argtypes = [i32]

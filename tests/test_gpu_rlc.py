@@ -121,3 +121,59 @@ def test_bucket_stage_agrees_with_exact_mode(env, super_m):
         proto.set_option("rlc_superchunk", 4096)
     with pytest.raises(Exception):
         proto.set_option("rlc_superchunk", 100)        # not a multiple of 8 / out of range values are refused
+
+
+@pytest.mark.parametrize("every", [0, 4096, 1024, 64])
+def test_group_sizes_adapt_and_accept_bits_stay_exact(oracle_c, every):
+    """Round 5: an RLC call sizes its groups from what the previous RLC call on the context rejected (plan_core.h: plan_rlc) -- chunks of
+    32 instead of 8 while at most one proof in 256 was bad, smaller superchunks or no bucket stage when most superchunks would fail.
+    At corruption rates 0, 1/4096, 1/1024 and 1/64: the first call (no history) and the following ones (with it) give exact mode's accept
+    bits, statuses and reject count, which are the oracle's; and the calls really took the sizes the rate asks for."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    n = 20000 + 37
+    gens, V, P, _ = workload.make_batch(n, first=12000)
+    if every:
+        P, expect = workload.corrupt(P, V, every=every)
+    else:
+        expect = np.ones(n, np.uint8)
+    P = P.copy()
+    P[n - 1, 64 * 6 + 31] ^= 1                 # and one malformed proof (a status flag), in the last, partial chunk
+    g, gv, hv = workload.split_generators(gens)
+    proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=16)
+    try:
+        assert proto.get_option("rlc_reject_ppm") == -1 and proto.get_option("rlc_chunk") == 0
+        e_acc, e_st, e_rej = _run(torch, proto, V, P, None)                       # exact mode
+        clean = np.ones(n, bool)
+        clean[n - 1] = False
+        assert (e_acc[clean] == expect[clean]).all() and e_acc[n - 1] == 0 and e_st[n - 1] != 0
+        for i in list(np.nonzero(e_acc == 0)[0][:6]) + [0, 1, n - 2]:
+            rc = oracle_c.u64_verify(gens, workload.LABEL, bytes(V[i]), bytes(P[i]))
+            assert int(e_acc[i]) == (1 if rc == 1 else 0)
+        rate = e_rej / n
+        used = []
+        for call in range(3):
+            acc, st, rej = _run(torch, proto, V, P, os.urandom(32))
+            assert acc.tolist() == e_acc.tolist() and st.tolist() == e_st.tolist() and rej == e_rej
+            used.append((proto.get_option("last_rlc_superchunk"), proto.get_option("last_rlc_chunk")))
+            assert abs(proto.get_option("rlc_reject_ppm") - rate * 1e6) <= 1
+        assert used[0] == (256, 8)                                   # no history: the automatic superchunk of this batch size, chunks of 8
+        want_chunk = 32 if rate * 256 <= 1 else 8
+        want_super = 0 if rate * 256 > 0.45 else 256
+        assert used[1] == used[2] == (want_super, want_chunk), (used, rate)
+        # forced sizes: same verdicts
+        for chunk, sup in ((32, 4096), (8, 0), (32, 0)):
+            proto.set_option("rlc_chunk", chunk)
+            proto.set_option("rlc_superchunk", sup)
+            acc, st, rej = _run(torch, proto, V, P, os.urandom(32))
+            assert acc.tolist() == e_acc.tolist() and st.tolist() == e_st.tolist() and rej == e_rej
+            assert (proto.get_option("last_rlc_superchunk"), proto.get_option("last_rlc_chunk")) == (sup, chunk)
+        proto.set_option("rlc_history", 0)
+        assert proto.get_option("rlc_reject_ppm") == -1
+        with pytest.raises(Exception):
+            proto.set_option("rlc_chunk", 16)
+    finally:
+        proto.close()

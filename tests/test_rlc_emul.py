@@ -110,3 +110,52 @@ def test_bucket_stage_superchunk_verdicts(setup):
     V3[26] = V[0]            # someone else's commitment in the partial superchunk
     passed, st = run(V3, P)
     assert passed == [1, 1, 1, 0]
+
+
+def test_chunks_of_32_equal_exact_mode(oracle_c):
+    """Round 5: the chunk stage on 32 proofs per chunk (rlc_core.h: RlcWs::chunk) -- one 49-base sum per 32 proofs instead of per 8.
+    Two full chunks and a partial one: all valid -> both full chunks pass combined; one bad proof fails its whole chunk of 32, which is
+    re-checked exactly, so the accept bits are the oracle's either way."""
+    L = load()
+    n = 70
+    gens, V, P, _ = workload.make_batch(n, first=900)
+    W = 4
+    tab = np.zeros(L.emul_fb_table_entries(49, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0
+    L.emul_set_rlc_chunk(32)
+    try:
+        acc, st, re = _run(L, tab, W, V, P)
+        assert acc.all() and not st.any() and re == 1          # only the partial chunk (6 proofs) is re-checked
+        Pc = P.copy()
+        Pc[40, 900] ^= 1          # chunk 1
+        Pc[69, 5] ^= 0x40         # the partial chunk
+        acc, st, re = _run(L, tab, W, V, Pc)
+        exp = [1 if oracle_c.u64_verify(gens, workload.LABEL, bytes(V[t]), bytes(Pc[t])) == 1 else 0 for t in range(n)]
+        assert acc.tolist() == exp and exp[40] == 0 and re == 2
+    finally:
+        L.emul_set_rlc_chunk(8)
+
+
+def test_group_sizes_follow_the_previous_calls_reject_rate():
+    """plan_core.h: plan_rlc -- the bucket stage's superchunk and the chunk size of an RLC call, from what the previous call rejected."""
+    L = load()
+
+    def plan(auto_m, is_auto, opt, rate):
+        out = (C.c_uint * 2)()
+        L.emul_plan_rlc(auto_m, is_auto, opt, rate, out)
+        return out[0], out[1]
+    assert plan(4096, 1, 0, -1.0) == (4096, 8)            # no history: round 4's choice
+    assert plan(4096, 1, 0, 0.0) == (4096, 32)            # nothing rejected: big superchunks, and chunks of 32 behind them
+    assert plan(4096, 1, 0, 1 / 65536) == (4096, 32)
+    assert plan(4096, 1, 0, 1 / 8192) == (2048, 32)       # r M <= 0.3
+    assert plan(4096, 1, 0, 1 / 4096) == (1024, 32)
+    assert plan(4096, 1, 0, 1 / 1024) == (0, 32)          # every superchunk would fail: no bucket stage; a chunk of 32 still passes 97 %
+    assert plan(4096, 1, 0, 1 / 256) == (0, 32)
+    assert plan(4096, 1, 0, 1 / 255) == (0, 8)
+    assert plan(4096, 1, 0, 0.5) == (0, 8)
+    assert plan(512, 1, 0, 1 / 2048) == (512, 32)         # small batches: the automatic size is already small
+    assert plan(512, 1, 0, 1 / 1000) == (0, 32)
+    assert plan(4096, 0, 0, 1 / 1024) == (4096, 32)       # an explicit superchunk is taken as it is
+    assert plan(72, 0, 0, 0.0) == (72, 8)                 # ... and a superchunk must be made of whole chunks
+    assert plan(0, 0, 0, 0.0) == (0, 32)
+    assert plan(4096, 1, 8, 0.0) == (4096, 8) and plan(4096, 1, 32, 0.5) == (0, 32)
