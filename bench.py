@@ -514,7 +514,7 @@ def run_verify(args):
             kt = proto.timings(reset=True)
             proto.enable_timing(False)
             used = {"superchunk": proto.get_option("last_rlc_superchunk"), "chunk": proto.get_option("last_rlc_chunk"),
-                    "reject_ppm_planned_with": proto.get_option("rlc_reject_ppm")}
+                    "reject_ppm_planned_with": proto.get_option("rlc_reject_ppm") if proto.get_option("rlc_has_history") else None}
             return t, {k: v["total_ms"] for k, v in kt.items() if v["launches"]}, used
 
         t_r, kt_r, used_r = rlc_measure()
@@ -552,7 +552,7 @@ def run_verify(args):
         r, okp = bench_other.measure_prove(args, proto, gens, 1 << 14, cpu_baseline=not args.no_cpu_baseline, cpu_sample=2048)
         prove14 = {k: r[k] for k in keep if k in r}
         prove14["proofs_verify"] = okp
-        r, okr = bench_other.measure_recip256(args, 1 << 15, 16, cpu_baseline=not args.no_cpu_baseline, rlc=True)
+        r, okr = bench_other.measure_recip256(args, 1 << 15, 0, cpu_baseline=not args.no_cpu_baseline, rlc=True)
         recip15 = {k: r[k] for k in keep + ("rlc_mode", "accept_bits_ok", "device_bytes") if k in r}
         ok_extra = okp and okr
 

@@ -295,7 +295,7 @@ def measure_recip256(args, total, W, cpu_baseline=True, rlc=True, dist_on=False,
                                f"{'all resident on one GPU' if world == 1 else f'sharded contiguously over {world} GPUs, {n} proofs per GPU'}, through "
                                "the generic kernels, inputs resident in HBM, 1/256 proofs corrupted, one 4-byte reject-count all-reduce per step; "
                                "proofs made by the product prover (oracle-checked sample)",
-                   "total_proofs_per_step": total, "proofs_per_gpu": n, "fb_window_bits": W,
+                   "total_proofs_per_step": total, "proofs_per_gpu": n, "fb_window_bits": proto.get_option("fb_window_bits"),
                    "parallelism": f"shard{world}" if world > 1 else "single"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / bench.HBM_PEAK_GBS,
                      "traffic": bench.pmc_traffic(dom, n), "avg_launch_ms": avg_ms, "launches_per_step": dom_t["launches"] / args.steps,
@@ -356,7 +356,7 @@ def run_recip256(args):
     import bench
     world, rank, local_rank = bench.setup_dist(args)
     dist_on = dist.is_initialized()
-    result, ok = measure_recip256(args, args.total_proofs, args.fb_window_bits or 16, cpu_baseline=not args.no_cpu_baseline,
+    result, ok = measure_recip256(args, args.total_proofs, args.fb_window_bits, cpu_baseline=not args.no_cpu_baseline,
                                   rlc=not args.no_secondary, dist_on=dist_on, world=world, rank=rank, local_rank=local_rank)
     if rank == 0:
         print(json.dumps(result), flush=True)

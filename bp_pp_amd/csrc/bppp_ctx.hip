@@ -27,9 +27,10 @@ static void read_diagnostics(bppp_ctx* c) {
 
 // fb_window_bits = 0: the widest windows whose tables take at most 35 % of the HBM that is FREE when the context is created (and whose
 // build scratch still fits beside them) -- on an otherwise empty MI355X 22 bits for the u64 protocol's 49 generators (79 GB of 288:
-// -2.4 ... -3.1 % per 2^20-proof batch against 20 bits / 21 GB, profiles/r03_e_bench_fbwindow_*), 20 bits when some 60 GB are already
-// taken, 16 bits for the 769 generators of BASELINE configs[4]'s shape (52 GB).  Candidates, widest first:
-static const int kDefaultWindows[5] = {22, 20, 16, 8, 4};
+// -2.4 ... -3.1 % per 2^20-proof batch against 20 bits / 21 GB, profiles/r03/r03_e_bench_fbwindow_*), 20 bits when some 60 GB are already
+// taken, 18 bits for the 769 generators of BASELINE configs[4]'s shape (97 GB: 15 additions per scalar instead of the 16 of 16-bit
+// windows over 52 GB, round 5).  Candidates, widest first:
+static const int kDefaultWindows[7] = {22, 20, 19, 18, 16, 8, 4};
 static double table_bytes_for(int nbases, int W) { return (double)nbases * fb_nwin(W) * (double)fb_per_win(W) * sizeof(apt_packed); }
 static size_t build_group_for(int nbases, int W) {          // bases per build pass: scratch (x, y, z, prefix: 160 B per entry) <= ~32 GB
     const size_t per_base = (size_t)fb_nwin(W) * fb_per_win(W);
@@ -316,16 +317,17 @@ long bppp_ctx_get_option(bppp_ctx* c, const char* name) {
     if (std::strcmp(name, "n_generators") == 0) return c->nbases;
     if (std::strcmp(name, "rlc_superchunk") == 0) return (long)c->rlc_super_m;
     if (std::strcmp(name, "rlc_chunk") == 0) return (long)c->rlc_chunk_opt;
-    // what the last RLC call on this context used, and the reject rate (parts per million; -1 = none yet) the next one will plan with
+    // what the last RLC call on this context used, and whether / which reject rate (parts per million) the next one will plan with
     if (std::strcmp(name, "last_rlc_superchunk") == 0) return (long)c->last_rlc_super_m;
     if (std::strcmp(name, "last_rlc_chunk") == 0) return (long)c->last_rlc_chunk;
-    if (std::strcmp(name, "rlc_reject_ppm") == 0) {
+    if (std::strcmp(name, "rlc_has_history") == 0 || std::strcmp(name, "rlc_reject_ppm") == 0) {
         if (c->rlc_hist_n && c->ev_rlc_hist && hipEventQuery(c->ev_rlc_hist) == hipSuccess) {
             c->rlc_rate = (double)*c->h_rlc_hist / (double)c->rlc_hist_n;
             c->rlc_hist_n = 0;
         }
         (void)hipGetLastError();
-        return c->rlc_rate < 0 ? -1 : (long)(c->rlc_rate * 1e6 + 0.5);
+        if (name[4] == 'h') return c->rlc_rate < 0 ? 0 : 1;
+        return c->rlc_rate < 0 ? 0 : (long)(c->rlc_rate * 1e6 + 0.5);
     }
     if (std::strcmp(name, "max_batch") == 0) return (long)c->max_batch;
     if (std::strcmp(name, "host_chunk") == 0) return (long)c->host_chunk;

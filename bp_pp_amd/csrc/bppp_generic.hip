@@ -262,7 +262,11 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
         if (rc != BPPP_OK) return rc;                          \
     } while (0)
     GLAUNCH(K_RECIP_PHASE1, k_recip_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r));
-    GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
+    // the two fixed-base sums: 8 lanes per instance, or one from the size at which one lane per instance fills the SIMDs twice over
+    const bool fb_one_lane = c->fb_one_lane_mode >= 0 ? c->fb_one_lane_mode == 1 : n >= (size_t)128 * (size_t)c->n_simds;
+    const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    if (fb_one_lane) GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
+    else GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
     GLAUNCH(K_RECIP_C0_VAR, k_recip_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r));
     GLAUNCH(K_RECIP_C0_FINISH, k_recip_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r));
     rc = wnla_fast_setup(c, w, n, rounds);
@@ -278,7 +282,8 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     }
     GLAUNCH(K_WNLA_FINAL_SCALARS, k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     if (!rlc_seed) {
-        GLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
+        if (fb_one_lane) GLAUNCH(K_WNLA_MSM, k_wnla_msm_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(w));
+        else GLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
         GLAUNCH(K_WNLA_ACCEPT, k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     } else {
         // one MSM per chunk of 8 instances instead of one per instance; what does not pass is re-checked exactly (wnla_rlc_core.h)

@@ -239,6 +239,7 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         if (rp.chunk == 32) LAUNCH(K_RLC_CHUNK, k_rlc_chunk_c32<<<chunk_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
         else LAUNCH(K_RLC_CHUNK, k_rlc_chunk<<<chunk_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
         LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged<<<1024, 64, 0, s>>>(ws, rl));
+        LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged_l8<<<2 * (unsigned)c->n_simds / 4, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
         LAUNCH(K_FINAL_CHECK, k_verify_final_check_flagged_dense<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(ws, rl));
         LAUNCH(K_ACCEPT, k_verify_accept_flagged<<<blocks, BPPP_BLOCK, 0, s>>>(ws, rl, (int*)d_reject_count, c->d_rlc_hist));
         // this call's reject count, for the next call's plan (a call that runs in parts leaves the last part's)
@@ -330,7 +331,7 @@ static int verify_host_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
         // exactly once).  The link moves a proof (992 B at 56 GB/s: 18 ns) eight times faster than the chip verifies it (142 ns), so the
         // parts GROW: the first is one host_chunk -- the only upload nothing hides -- and each next one is what can be uploaded while the
         // previous one is verified, 7 times its size: 2^20 proofs = 2^17 + 7 * 2^17, the second part a 917,504-proof batch at the
-        // resident rate (profiles/r05_d_hostpath_probe.txt).  (From pageable memory the runtime stages the copy and this thread blocks
+        // resident rate (profiles/r05/r05_d_hostpath_probe.txt).  (From pageable memory the runtime stages the copy and this thread blocks
         // in it, at the same 56 GB/s; the GPU keeps verifying meanwhile.)
         if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         if (!c->ev_copy) HIP_TRY(hipEventCreateWithFlags(&c->ev_copy, hipEventDisableTiming));
@@ -524,14 +525,14 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     else if (w2) PLAUNCH(K_PROVE_STAGES, k_prove_stage_f_w2<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     else PLAUNCH(K_PROVE_STAGES, k_prove_stage_f<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     // (the lane-per-generator form of the scalar kernel pays only while the chip is empty: at 2^13 ... 2^15 values it costs 1.2 / 2.3 /
-    // 4.5 ms per batch against 0.8: profiles/r04_r_size_probe_wide_scalars.txt)
+    // 4.5 ms per batch against 0.8: profiles/r04/r04_r_size_probe_wide_scalars.txt)
     const bool scal_wide = plan.scalars == bppp_host::SC_WIDE, scal_parts = plan.scalars == bppp_host::SC_PARTS;
     bool pending_cnext = false;
     // Beyond the sizes of next_by_msm: round k's next commitment C_k (prove_core.h: prove_round_next -- window tables of X and R and a
     // two-point GLV Straus sum, 125 dependent doublings) is not needed before round k + 1 appends it to the transcript: it runs on the
     // helper stream, under round k + 1's scalar kernel and X | R sums, and the main stream picks it up just before that round's fold.
     // On the helper stream it runs in its 256-register build: the uncapped one leaves no room on its SIMDs for a wavefront of the sums
-    // it is meant to run under (profiles/r04_zd_prove_next_overlap_probe.txt).  (With per-kernel timing on it stays on the main stream
+    // it is meant to run under (profiles/r04/r04_zd_prove_next_overlap_probe.txt).  (With per-kernel timing on it stays on the main stream
     // so that the kernel times add up to the step.)
     hipStream_t a = plan.overlap_next ? c->aux_stream : s;
     bool next_in_flight = false;

@@ -44,18 +44,23 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) wnla_verify_final_scalars(w, t);
 }
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(WnlaWs w, int commit_mode) {
+// NL lanes per instance: 8, or ONE from the size at which one lane per instance fills every SIMD twice over (as in the u64 verifier's
+// fixed-base kernels: the lane then walks each scalar's windows in order -- the recoded scalar is a shift register, the window's base
+// address an increment -- and no tree of complete additions joins lane sums)
+template <int NL>
+__device__ __forceinline__ void wnla_msm_lanes(const WnlaWs& w) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
+    size_t t = g / NL;
+    int lane = (int)(g % NL);
     if (t >= w.N) return;
     pt part;
     FbRanges rg;
     wnla_msm_ranges(rg, w);
-    fb_group_sum(part, w.fb, t, lane, w.msc, rg);
+    fb_group_sum<NL>(part, w.fb, t, lane, w.msc, rg);
     if (lane == 0) wnla_verify_store(w, t, part);
-    (void)commit_mode;
 }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(WnlaWs w, int commit_mode) { wnla_msm_lanes<BPPP_FB_LANES>(w); (void)commit_mode; }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm_l1(WnlaWs w) { wnla_msm_lanes<1>(w); }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) {
@@ -260,17 +265,20 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1(RecipWs w) {
     const u32 key = preloaded_position_key(w.tio.states, w.tio.n_states, t);
     for_each_position_group(key, [&]() { recip_phase1(w, t); });
 }
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed(RecipWs w) {
+template <int NL>
+__device__ __forceinline__ void recip_c0_fixed_lanes(const RecipWs& w) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
+    size_t t = g / NL;
+    int lane = (int)(g % NL);
     if (t >= w.N) return;
     pt part;
     FbRanges rg;
     recip_c0_fixed_ranges(rg, w);
-    fb_group_sum(part, w.fb, t, lane, w.sc0, rg);
+    fb_group_sum<NL>(part, w.fb, t, lane, w.sc0, rg);
     if (lane == 0) recip_c0_fixed_store(w, t, part);
 }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed(RecipWs w) { recip_c0_fixed_lanes<BPPP_FB_LANES>(w); }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed_l1(RecipWs w) { recip_c0_fixed_lanes<1>(w); }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var(RecipWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) recip_c0_var(w, t);

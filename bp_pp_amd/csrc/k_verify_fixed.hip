@@ -96,13 +96,19 @@ __device__ __forceinline__ void rlc_chunk_lanes(const VerifyWs& ws, const RlcWs&
 }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(VerifyWs ws, RlcWs r) { rlc_chunk_lanes<BPPP_RLC_CHUNK>(ws, r); }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk_c32(VerifyWs ws, RlcWs r) { rlc_chunk_lanes<32>(ws, r); }
-// exact final check of the proofs of the flagged chunks: a whole wavefront per proof (637 table additions over 64 lanes, 6-step
-// tree), because only a few proofs are expected here and an 8-lane group would take the full 80-addition latency for each
+// exact final check of the proofs of the flagged chunks.  Three forms by how many there are (the count lives on the device: all three are
+// launched and two of them return at once):
+//   a handful (< BPPP_FLAGGED_L8_FROM proofs)  a whole wavefront per proof -- 588 table additions over 64 lanes, 6-step tree: latency of one
+//                                             proof's sum matters, not throughput
+//   up to an eighth of the batch                8 lanes per proof over the compacted list (round 5: chunks of 32 flag 32 proofs per bad
+//                                             proof -- 3 % of a batch at 1/1024 corrupted: 4.7 ms on a wavefront per proof, 1.4 here)
+//   more                                        the regular 8-lane kernel over the whole batch, skipping the chunks that passed
+#define BPPP_FLAGGED_L8_FROM 4096
 __global__ __launch_bounds__(64) void k_verify_final_check_flagged(VerifyWs ws, RlcWs r) {
     const int lane = (int)threadIdx.x;
     const size_t C = rlc_chunk_of(r);
     const size_t items = (size_t)(*r.count) * C;
-    if (items * 8 > ws.N) return;   // more than an eighth of the batch flagged: k_verify_final_check_flagged_dense does them
+    if (items >= BPPP_FLAGGED_L8_FROM) return;   // many: k_verify_final_check_flagged_l8 / _dense do them
 #pragma nounroll
     for (size_t item = blockIdx.x; item < items; item += gridDim.x) {
         const size_t t = (size_t)r.list[item / C] * C + item % C;
@@ -111,6 +117,23 @@ __global__ __launch_bounds__(64) void k_verify_final_check_flagged(VerifyWs ws, 
         FbRanges rg;
         verify_final_check_ranges(rg);
         fb_group_sum<64>(part, fb_of(ws), t, lane, ws.fsc, rg);
+        if (lane == 0) verify_final_check_store(ws, t, part);
+    }
+}
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_flagged_l8(VerifyWs ws, RlcWs r) {
+    const size_t C = rlc_chunk_of(r);
+    const size_t items = (size_t)(*r.count) * C;
+    if (items < BPPP_FLAGGED_L8_FROM || items * 8 > ws.N) return;
+    const int lane = (int)(threadIdx.x % BPPP_FB_LANES);
+    const size_t per_block = BPPP_FB_BLOCK / BPPP_FB_LANES;
+#pragma nounroll
+    for (size_t item = (size_t)blockIdx.x * per_block + threadIdx.x / BPPP_FB_LANES; item < items; item += (size_t)gridDim.x * per_block) {
+        const size_t t = (size_t)r.list[item / C] * C + item % C;
+        if (t >= ws.N) continue;                 // whole lane groups skip together
+        pt part;
+        FbRanges rg;
+        verify_final_check_ranges(rg);
+        fb_group_sum(part, fb_of(ws), t, lane, ws.fsc, rg);
         if (lane == 0) verify_final_check_store(ws, t, part);
     }
 }

@@ -34,8 +34,8 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_roun
 // The 5-point sum needs 231 registers, so TWO of these wavefronts fit a SIMD -- and when a launch of exactly one wavefront per SIMD
 // (2^16 proofs) arrives as 1,024 single-wavefront workgroups, the dispatcher puts two of them on some SIMDs of a CU and none on
 // others: 5-10 % of the wavefronts then take 2.9 ms instead of 1.65 and the kernel waits for them (tools/probes/wave_timeline.py,
-// profiles/r04_f_wave_timeline.txt; reserving LDS so that a CU gets exactly four did not change it -- the imbalance is inside the CU).
-// The four wavefronts of ONE workgroup, however, are dealt one to each SIMD (tools/wgmap: 256 workgroups of 256 threads -> 1,024 SIMDs
+// profiles/r04/r04_f_wave_timeline.txt; reserving LDS so that a CU gets exactly four did not change it -- the imbalance is inside the CU).
+// The four wavefronts of ONE workgroup, however, are dealt one to each SIMD (tools/probes/wgmap: 256 workgroups of 256 threads -> 1,024 SIMDs
 // with one wavefront each), so this variant runs in 256-thread workgroups; the registers still leave room for the fixed-base half of
 // C0 that runs beside it.  No barrier, no LDS: the workgroup size is placement only.
 __global__ __launch_bounds__(BPPP_C0VAR_SMALL_BLOCK) void k_verify_c0_var_small(VerifyWs ws) {

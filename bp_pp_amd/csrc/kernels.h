@@ -16,7 +16,7 @@
 #define BPPP_BLOCK 64
 // One-lane-per-proof kernels of the u64 verifier: minimum waves per SIMD the register allocator must leave room for
 // (2 => at most 256 VGPR + AGPR per lane, so two wavefronts share a SIMD and cover each other's table-gather latency).
-// Measured on MI355X at 2^20 proofs (profiles/r02_occupancy_ab.txt): 1 wave/SIMD (374 / 272 / 312 VGPRs) 182.8 ms per batch, 2 waves
+// Measured on MI355X at 2^20 proofs (profiles/r02/r02_occupancy_ab.txt): 1 wave/SIMD (374 / 272 / 312 VGPRs) 182.8 ms per batch, 2 waves
 // (256, the round kernel spilling 109 VGPRs into transcript-only code) 164.6 ms, 3 waves (168, spills inside the hot loops) 173.4 ms.
 #ifndef BPPP_LANE_MIN_WAVES
 #define BPPP_LANE_MIN_WAVES 2
@@ -26,7 +26,7 @@
 // k_verify_tables: chains of dependent loads and short arithmetic (five passes over a proof's 13 points).  Round 2 ran it at 3 waves per
 // SIMD (168 VGPRs) with one running product per denominator; with one per block of four (verify_core.h: aff_push_block) the unwinding
 // passes hold four denominators and their inverses at once: 229 spilled VGPRs at 168, 7 at 256.  Measured on 2^20 proofs
-// (profiles/r03_c_*): 3 waves 17.2-17.4 ms, 2 waves 14.5-14.6 ms (round 2's form: 14.6-14.75 ms at 3 waves).
+// (profiles/r03/r03_c_*): 3 waves 17.2-17.4 ms, 2 waves 14.5-14.6 ms (round 2's form: 14.6-14.75 ms at 3 waves).
 #ifndef BPPP_TABLES_MIN_WAVES
 #define BPPP_TABLES_MIN_WAVES 2
 #endif
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_export_states(bppp::Verif
 __global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(bppp::VerifyWs ws, bppp::RlcWs r);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk(bppp::VerifyWs ws, bppp::RlcWs r);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_rlc_chunk_c32(bppp::VerifyWs ws, bppp::RlcWs r);      // chunks of 32 proofs
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_flagged_l8(bppp::VerifyWs ws, bppp::RlcWs r);
 __global__ __launch_bounds__(64) void k_verify_final_check_flagged(bppp::VerifyWs ws, bppp::RlcWs r);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_final_check_flagged_dense(bppp::VerifyWs ws, bppp::RlcWs r);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_accept_flagged(bppp::VerifyWs ws, bppp::RlcWs r, int* reject_count, int* hist_count);
@@ -175,6 +176,8 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm_f
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept_flagged(bppp::WnlaWs w, bppp::RlcWs r);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(bppp::WnlaWs w, int commit_mode);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm_l1(bppp::WnlaWs w);               // one lane per instance (full batches)
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed_l1(bppp::RecipWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(bppp::WnlaWs w);
 __global__ __launch_bounds__(256) void k_count_rejects(const uint8_t* accept, size_t n, int* reject_count);

@@ -2263,63 +2263,61 @@ __device__ __forceinline__ void verify_round_lds(const VerifyWs& ws, size_t t, i
 }
 #endif
 // ---------------------------------------------------------------- phase 4: base case (wnla.rs:80-82 with :66-72), generators unrolled
+// (Round 5 measured a form that keeps ch / cg as four register-resident quarter tables -- no store-to-load round trips through the
+// workspace, the cause of this kernel's 40 % memory wait: 2.64 ms against 1.9.  The 128 VGPRs of tables cost the kernel the occupancy
+// that hides its latency today.  Not kept.)
 HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
     const size_t N = ws.N;
     BPPP_STAMP(t, 22);
     sc rho, y[4], rk[4], l0, l1, n0;
     ws_ld8(rho.v, ws.chal, N, t, 1);
-#pragma unroll
+#pragma nounroll
     for (int k = 0; k < 4; k++) ws_ld8(y[k].v, ws.chal, N, t, 6 + k);
     ws_ld8(l0.v, ws.lns, N, t, 0);
     ws_ld8(l1.v, ws.lns, N, t, 1);
     ws_ld8(n0.v, ws.lns, N, t, 2);
     // rho_1 = rho, rho_{k+1} = mu_k, mu_{k+1} = mu_k^2 (wnla.rs:109-110): rho_k = rho^(2^(k-1)); final mu = rho^32
     rk[0] = rho;
-#pragma unroll
+#pragma nounroll
     for (int k = 1; k < 4; k++) sc_mul(rk[k], rk[k - 1], rk[k - 1]);
     sc mu5;
     sc_mul(mu5, rk[3], rk[3]);
     sc_mul(mu5, mu5, mu5);
     // ch[b] = prod_{k: bit k of b} y_{k+1}        (h_vec / c folding, wnla.rs:96,98 unrolled)
     // cg[b] = prod_k (bit k of b ? y_{k+1} : rho_{k+1})   (g_vec folding, wnla.rs:97 unrolled)
-    // Both as (low two bits) x (high two bits): four quarter tables of four scalars, in REGISTERS.  Round 4 grew the two 16-entry tables
-    // in place in the output slots, every product a store the next step loaded back (40 % of the kernel's cycles waited on memory);
-    // here nothing travels through the workspace but the 25 inputs c_i and the 49 results.
-    sc one, ch_lo[4], ch_hi[4], cg_lo[4], cg_hi[4];
+    // Built in place in the output slots (cg[b] at fsc slot 1 + b, ch[b] at slot 17 + b) instead of two 16-element arrays in
+    // scratch memory; the final products overwrite them.
+    sc one;
     sc_set_u32(one, 1);
-    ch_lo[0] = one; ch_lo[1] = y[0]; ch_lo[2] = y[1]; sc_mul(ch_lo[3], y[0], y[1]);
-    ch_hi[0] = one; ch_hi[1] = y[2]; ch_hi[2] = y[3]; sc_mul(ch_hi[3], y[2], y[3]);
-    sc_mul(cg_lo[0], rk[0], rk[1]); sc_mul(cg_lo[1], y[0], rk[1]); sc_mul(cg_lo[2], rk[0], y[1]); cg_lo[3] = ch_lo[3];
-    sc_mul(cg_hi[0], rk[2], rk[3]); sc_mul(cg_hi[1], y[2], rk[3]); sc_mul(cg_hi[2], rk[2], y[3]); cg_hi[3] = ch_hi[3];
-    auto pick = [](sc& r, const sc q[4], int i) {           // q[i], i wave-uniform: selects, no indexed registers
-#pragma unroll
-        for (int l = 0; l < 8; l++) r.v[l] = i == 0 ? q[0].v[l] : i == 1 ? q[1].v[l] : i == 2 ? q[2].v[l] : q[3].v[l];
-    };
-    sc c0f, c1f, tmp, cv, a, b;
+    ws_st8(ws.fsc, N, t, 17, one.v);
+    ws_st8(ws.fsc, N, t, 1, one.v);
+#pragma nounroll
+    for (int k = 0; k < 4; k++) {
+        const int half = 1 << k;
+#pragma nounroll
+        for (int b = 0; b < half; b++) {
+            sc chb, cgb, tmp;
+            ws_ld8(chb.v, ws.fsc, N, t, 17 + b);
+            ws_ld8(cgb.v, ws.fsc, N, t, 1 + b);
+            sc_mul(tmp, chb, y[k]);
+            ws_st8(ws.fsc, N, t, 17 + b + half, tmp.v);
+            sc_mul(tmp, cgb, y[k]);
+            ws_st8(ws.fsc, N, t, 1 + b + half, tmp.v);
+            sc_mul(tmp, cgb, rk[k]);
+            ws_st8(ws.fsc, N, t, 1 + b, tmp.v);
+        }
+    }
+    // c'_0, c'_1 = folded c (c[25..31] = 0)
+    sc c0f, c1f, tmp, cv, chv;
     sc_set_u32(c0f, 0);
     sc_set_u32(c1f, 0);
 #pragma nounroll
-    for (int i = 0; i < 16; i++) {
-        sc chv, cgv;
-        pick(a, ch_lo, i & 3); pick(b, ch_hi, i >> 2);
-        sc_mul(chv, a, b);
-        pick(a, cg_lo, i & 3); pick(b, cg_hi, i >> 2);
-        sc_mul(cgv, a, b);
-        // c'_0, c'_1 = folded c (c[25..31] = 0)
+    for (int i = 0; i < 25; i++) {
         ws_ld8(cv.v, ws.cvec, N, t, i);
+        ws_ld8(chv.v, ws.fsc, N, t, 17 + (i & 15));
         sc_mul(tmp, cv, chv);
-        sc_add(c0f, c0f, tmp);
-        if (i < 9) {
-            ws_ld8(cv.v, ws.cvec, N, t, 16 + i);
-            sc_mul(tmp, cv, chv);
-            sc_add(c1f, c1f, tmp);
-        }
-        sc_mul(tmp, n0, cgv);
-        ws_st8(ws.fsc, N, t, 1 + i, tmp.v);
-        sc_mul(tmp, l0, chv);
-        ws_st8(ws.fsc, N, t, 17 + i, tmp.v);
-        sc_mul(tmp, l1, chv);
-        ws_st8(ws.fsc, N, t, 33 + i, tmp.v);
+        if (i < 16) sc_add(c0f, c0f, tmp);
+        else sc_add(c1f, c1f, tmp);
     }
     // v = <c', l> + n0^2 mu'   (wnla.rs:67 with weight_vector_mul exponent 1, util.rs:28-44)
     sc v, w;
@@ -2330,6 +2328,18 @@ HD void verify_final_scalars(const VerifyWs& ws, size_t t) {
     sc_mul(w, w, mu5);
     sc_add(v, v, w);
     ws_st8(ws.fsc, N, t, 0, v.v);
+#pragma nounroll
+    for (int i = 0; i < 16; i++) {
+        sc cgv;
+        ws_ld8(cgv.v, ws.fsc, N, t, 1 + i);
+        sc_mul(tmp, n0, cgv);
+        ws_st8(ws.fsc, N, t, 1 + i, tmp.v);
+        ws_ld8(chv.v, ws.fsc, N, t, 17 + i);
+        sc_mul(tmp, l0, chv);
+        ws_st8(ws.fsc, N, t, 17 + i, tmp.v);
+        sc_mul(tmp, l1, chv);
+        ws_st8(ws.fsc, N, t, 33 + i, tmp.v);
+    }
 }
 #if defined(__HIPCC__)
 // The same scalars by SIXTEEN lanes per proof, for calls that leave the chip empty (bppp_u64.hip: the small-call path): lane b forms

@@ -263,6 +263,10 @@ class ReciprocalRangeProofProtocol:
         unset = chosen per call from the batch size)."""
         _capi.check(_capi.lib().bppp_ctx_set_option(self._w._ctx, name.encode(), int(value)))
 
+    def get_option(self, name: str) -> int:
+        """bppp_ctx_get_option: a tunable read back, or a fact such as "fb_window_bits" (the table width the library chose)."""
+        return int(_capi.check(_capi.lib().bppp_ctx_get_option(self._w._ctx, name.encode())))
+
     def set_stream(self, hip_stream: int) -> None:
         """Run this context's kernels on the caller's HIP stream (0 = back to the context's own)."""
         _capi.check(_capi.lib().bppp_ctx_set_stream(self._w._ctx, hip_stream or None))

@@ -99,7 +99,7 @@ BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
  * from what the previous RLC call on this context rejected -- chunks of 32 while at most one proof in 256 was bad, and the bucket
  * stage's superchunks halved (or the stage skipped) when most of them would hold a bad proof and fail ("rlc_superchunk" set explicitly
  * is taken as it is); "rlc_history" = 0 forgets that rate.  bppp_ctx_get_option reads "last_rlc_superchunk" / "last_rlc_chunk" (what
- * the last call used) and "rlc_reject_ppm" (the rate the next one will plan with, parts per million, -1 = none).  Accept bits never
+ * the last call used) and "rlc_has_history" (0 / 1) and "rlc_reject_ppm" (the rate the next one will plan with, parts per million).  Accept bits never
  * depend on these choices.
  * "ct_prover" = 1: the provers' and the committer's sums over SECRET scalars -- bppp_u64_prove_* and bppp_u64_commit_value_batch (x, s,
  * the reciprocals and every blinding draw, i.e. V, r_com, c_o, c_l, c_r, c_s); bppp_reciprocal_prove_batch* (the commitment to the

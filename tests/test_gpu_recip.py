@@ -15,8 +15,12 @@ def _generic_kernels(monkeypatch, on):
         monkeypatch.delenv("BPPP_GENERIC_U64_SHAPE", raising=False)
 
 
-@pytest.mark.parametrize("nd,npp,B,generic", [(16, 16, 40, True), (16, 16, 40, False), (32, 16, 9, True), (12, 10, 5, True), (256, 16, 4, True)])
-def test_generic_reciprocal_verify_vs_oracle(nd, npp, B, generic, monkeypatch):
+# one_lane: BPPP_FB_ONE_LANE=1 forces the one-lane-per-instance builds of the two fixed-base kernels (k_recip_c0_fixed_l1, k_wnla_msm_l1:
+# what a call of 2^17 instances or more runs, round 5) at any size
+@pytest.mark.parametrize("nd,npp,B,generic,one_lane", [(16, 16, 40, True, False), (16, 16, 40, False, False), (32, 16, 9, True, False),
+                                                       (12, 10, 5, True, False), (256, 16, 4, True, False), (32, 16, 70, True, True),
+                                                       (256, 16, 4, True, True)])
+def test_generic_reciprocal_verify_vs_oracle(nd, npp, B, generic, one_lane, monkeypatch):
     import torch
     if torch.cuda.device_count() == 0:
         pytest.fail("needs a GPU")
@@ -24,6 +28,10 @@ def test_generic_reciprocal_verify_vs_oracle(nd, npp, B, generic, monkeypatch):
     from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
     case = recip_cases.make(nd, npp, B)
     _generic_kernels(monkeypatch, generic)
+    if one_lane:
+        monkeypatch.setenv("BPPP_FB_ONE_LANE", "1")
+    else:
+        monkeypatch.delenv("BPPP_FB_ONE_LANE", raising=False)
     proto = ReciprocalRangeProofProtocol(nd, npp, case["g"], case["gv"], case["hv"], case["gv_"], case["hv_"], device=0,
                                          fb_window_bits=8 if nd > 64 else 16)
     try:

@@ -145,7 +145,7 @@ def test_group_sizes_adapt_and_accept_bits_stay_exact(oracle_c, every):
     g, gv, hv = workload.split_generators(gens)
     proto = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=16)
     try:
-        assert proto.get_option("rlc_reject_ppm") == -1 and proto.get_option("rlc_chunk") == 0
+        assert proto.get_option("rlc_has_history") == 0 and proto.get_option("rlc_chunk") == 0
         e_acc, e_st, e_rej = _run(torch, proto, V, P, None)                       # exact mode
         clean = np.ones(n, bool)
         clean[n - 1] = False
@@ -159,7 +159,7 @@ def test_group_sizes_adapt_and_accept_bits_stay_exact(oracle_c, every):
             acc, st, rej = _run(torch, proto, V, P, os.urandom(32))
             assert acc.tolist() == e_acc.tolist() and st.tolist() == e_st.tolist() and rej == e_rej
             used.append((proto.get_option("last_rlc_superchunk"), proto.get_option("last_rlc_chunk")))
-            assert abs(proto.get_option("rlc_reject_ppm") - rate * 1e6) <= 1
+            assert proto.get_option("rlc_has_history") == 1 and abs(proto.get_option("rlc_reject_ppm") - rate * 1e6) <= 1
         assert used[0] == (256, 8)                                   # no history: the automatic superchunk of this batch size, chunks of 8
         want_chunk = 32 if rate * 256 <= 1 else 8
         want_super = 0 if rate * 256 > 0.45 else 256
@@ -172,7 +172,7 @@ def test_group_sizes_adapt_and_accept_bits_stay_exact(oracle_c, every):
             assert acc.tolist() == e_acc.tolist() and st.tolist() == e_st.tolist() and rej == e_rej
             assert (proto.get_option("last_rlc_superchunk"), proto.get_option("last_rlc_chunk")) == (sup, chunk)
         proto.set_option("rlc_history", 0)
-        assert proto.get_option("rlc_reject_ppm") == -1
+        assert proto.get_option("rlc_has_history") == 0
         with pytest.raises(Exception):
             proto.set_option("rlc_chunk", 16)
     finally:

@@ -3,7 +3,8 @@
 # usage: tools/collect_profiles.sh <tag> [also-as-current]   ("also-as-current": the PMC summaries become profiles/pmc_{traffic,valu}.json,
 # the files bench.py reads -- do that only for a session that ran the build being shipped)
 set -u
-T=$1; S=gpurun_out/$T; P=profiles
+T=$1; S=gpurun_out/$T; P=profiles/${T%%_*}; mkdir -p $P      # profiles/r05/ for a session tag r05_x
+TOP=profiles
 cpif() { [ -s "$1" ] && cp "$1" "$2"; }
 cpif $S/bench.json $P/${T}_bench.json; cpif $S/bench_shard17.json $P/${T}_shard17_bench.json
 cpif $S/prove.json $P/${T}_prove_bench.json; cpif $S/recip256.json $P/${T}_recip256_bench.json
@@ -14,7 +15,7 @@ done
 [ -f $P/${T}_kernel_stats_prove.csv ] && mv $P/${T}_kernel_stats_prove.csv $P/${T}_prove_kernel_stats.csv
 [ -f $P/${T}_kernel_stats_recip.csv ] && mv $P/${T}_kernel_stats_recip.csv $P/${T}_recip256_kernel_stats.csv
 cpif $S/pmc/pmc_traffic.json $P/${T}_pmc_traffic.json; cpif $S/sq/pmc_valu.json $P/${T}_pmc_valu.json
-if [ "${2:-}" = "also-as-current" ]; then cpif $S/pmc/pmc_traffic.json $P/pmc_traffic.json; cpif $S/sq/pmc_valu.json $P/pmc_valu.json; fi
+if [ "${2:-}" = "also-as-current" ]; then cpif $S/pmc/pmc_traffic.json $TOP/pmc_traffic.json; cpif $S/sq/pmc_valu.json $TOP/pmc_valu.json; fi
 cpif $S/box.txt $P/${T}_box.txt; cpif $S/log.txt $P/${T}_log.txt
 cpif $S/pytest_gpu.txt $P/${T}_pytest_gpu.txt; cpif $S/smoke.txt $P/${T}_smoke.txt
 cpif $S/concurrent_callers.json $P/${T}_concurrent_callers.json; cpif $S/concurrent_callers_prove.json $P/${T}_concurrent_callers_prove.json; cpif $S/concurrent_callers_prove.txt $P/${T}_concurrent_callers_prove.txt

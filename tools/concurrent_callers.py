@@ -4,7 +4,7 @@ the interpreter's.
 
 Every thread calls bppp_u64_verify_one on ONE context: the coalescing front end (csrc/coalesce_core.h) gathers the callers' requests
 into batched GPU calls.  (Round 3's pattern -- bppp_u64_verify_batch with n = 1, a context per thread over shared tables -- got 601
-verifies/s at 64 threads: profiles/r03_cc_concurrent_callers.txt.)
+verifies/s at 64 threads: profiles/r03/r03_cc_concurrent_callers.txt.)
 
 --prove: the same with bppp_u64_prove_one (u64_proof.rs:57): every returned proof and commitment is compared byte for byte with what
 ONE batched call made of the same inputs.
