@@ -88,8 +88,10 @@ BPPP_API void bppp_ctx_destroy(bppp_ctx* ctx);
 BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
 /* Tunables.  "rlc_superchunk": proofs per superchunk of the bucket (Pippenger) stage of the RLC mode below -- 0 switches the stage
  * off (chunks of 8 only), otherwise a multiple of 8 in [64, 8192]; default 4096.  "host_chunk": the host-buffer verify entry points
- * (bppp_u64_verify_batch, bppp_u64_verify_batch_rlc) cut a batch of more than 1.5 x host_chunk proofs into chunks of host_chunk proofs and upload
- * chunk k + 1 on a second stream while chunk k is being verified (proofs are independent: the results are those of one call) --
+ * (bppp_u64_verify_batch, bppp_u64_verify_batch_rlc) run a batch of more than 1.5 x host_chunk proofs in parts and upload part k + 1 on a
+ * second stream while part k is being verified (proofs are independent: the results are those of one call).  The first part is
+ * host_chunk proofs -- the one upload nothing hides -- and every next one 7 times its predecessor, what PCIe moves while a part is
+ * verified (2^20 proofs = 2^17 + 7 * 2^17: the second part runs at the rate of a resident batch) --
  * a multiple of 64, >= 1024; default 131072 (one full grid of the per-proof kernels); 0 = upload the whole batch first.  "inject_alloc_fault" = k
  * (testing aid): the k-th device allocation this context makes from now on fails, so the call that makes it returns BPPP_ERR_NOMEM and
  * the context stays usable; 0 clears it.  "max_batch": the u64 verify entry

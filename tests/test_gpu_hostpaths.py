@@ -126,7 +126,7 @@ def test_default_window_width_follows_free_memory(monkeypatch):
     g, gv, hv = workload.split_generators(workload.generators())
     _, V, P, _ = workload.make_batch(20, first=10)
     P, expect = workload.corrupt(P, V, every=5)
-    for free_gb, want in ((300, 22), (100, 20), (40, 19), (30, 18), (12, 16), (1.0, 8), (0.001, 4)):
+    for free_gb, want in ((300, 22), (100, 20), (58, 19), (30, 18), (14, 16), (1.0, 8), (0.001, 4)):
         monkeypatch.setenv("BPPP_ASSUME_FREE_GB", str(free_gb))
         p = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=0)
         try:

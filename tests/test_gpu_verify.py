@@ -235,7 +235,8 @@ def test_random_byte_corruptions_vs_oracle(torch_mod, proto, oracle_c):
     assert st[16] != 0 and st[32] != 0 and st[48] == 0 and acc[48] == 0
 
 
-@pytest.mark.parametrize("n,chunk", [(5000, 1024), (1537, 1024), (3072, 1024), (4097, 2048)])
+# (13024, 1024): three parts -- 1,024, then 7 x 1,024, then the rest (round 5: the parts of a pipelined host-buffer call grow)
+@pytest.mark.parametrize("n,chunk", [(5000, 1024), (1537, 1024), (3072, 1024), (4097, 2048), (13024, 1024)])
 def test_host_buffer_path_pipelined_in_chunks(torch_mod, proto, oracle_c, n, chunk):
     """bppp_u64_verify_batch over host buffers uploads a large batch chunk by chunk while the previous chunk is verified
     (include/bppp.h, "host_chunk").  With a small chunk size so that a test batch spans several chunks -- tail merged into the

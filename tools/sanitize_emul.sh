@@ -9,5 +9,5 @@ export BPPP_EMUL_SANITIZE=1
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 export LD_PRELOAD="$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so)"
-if [ $# -eq 0 ]; then set -- tests/test_coalesce_emul.py tests/test_core_emul.py tests/test_wnla_emul.py tests/test_recip_emul.py tests/test_circuit_emul.py tests/test_rlc_emul.py tests/test_transcript_state.py tests/test_multi_rank.py; fi
+if [ $# -eq 0 ]; then set -- tests/test_coalesce_emul.py tests/test_core_emul.py tests/test_wnla_emul.py tests/test_recip_emul.py tests/test_circuit_emul.py tests/test_rlc_emul.py tests/test_transcript_state.py tests/test_multi_rank.py tests/test_ct_trace.py tests/test_group_emul.py; fi
 exec python -m pytest -x -q -m "not gpu" "$@"
