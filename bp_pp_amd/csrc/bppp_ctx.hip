@@ -44,15 +44,14 @@ static bool window_fits(int nbases, int W, size_t free_bytes) {
     const double scratch = (double)build_group_for(nbases, W) * fb_nwin(W) * (double)fb_per_win(W) * 4 * sizeof(fe);
     return tb <= 0.35 * (double)free_bytes && tb + scratch <= 0.90 * (double)free_bytes;
 }
-// Build the fixed-base tables of c->d_gens at window width W into a fresh c->d_table (ct = false) or into c->d_table_ct (the 4-bit
-// table of the "ct_prover" mode).  On failure nothing stays allocated.
-static int build_tables(bppp_ctx* c, int W, bool ct = false) {
-    const int NB = c->nbases;
+// Build the fixed-base tables of the generators first .. first + nb - 1 of c->d_gens at window width W into a fresh allocation.
+// On failure nothing stays allocated.
+static int build_table_range(bppp_ctx* c, int W, int first, int nb_total, apt_packed** out, size_t* out_bytes) {
     const int nwin = fb_nwin(W);
     const size_t per_win = fb_per_win(W);
     const size_t per_base = (size_t)nwin * per_win;
-    const size_t bytes = (size_t)NB * per_base * sizeof(apt_packed);
-    const size_t group = build_group_for(NB, W);
+    const size_t bytes = (size_t)nb_total * per_base * sizeof(apt_packed);
+    const size_t group = build_group_for(nb_total, W);
     const size_t gentries = group * per_base;
     apt_packed* d_table = nullptr;
     fe* d_tmp = nullptr;
@@ -70,9 +69,9 @@ static int build_tables(bppp_ctx* c, int W, bool ct = false) {
     if (c->inject_alloc_fault > 0 && --c->inject_alloc_fault == 0) { g_last_error = "injected allocation failure (tables)"; return BPPP_ERR_NOMEM; }
     HIP_TRY_T(hipMalloc(&d_table, bytes));
     HIP_TRY_T(hipMalloc(&d_tmp, gentries * 4 * sizeof(fe)));
-    for (size_t b0 = 0; b0 < (size_t)NB; b0 += group) {
-        const size_t nb = (size_t)NB - b0 < group ? (size_t)NB - b0 : group;
-        FbBuild fb{c->d_gens, NB, W, d_table, d_tmp, d_tmp + gentries, d_tmp + 2 * gentries, d_tmp + 3 * gentries, (int)b0, (int)nb};
+    for (size_t b0 = 0; b0 < (size_t)nb_total; b0 += group) {
+        const size_t nb = (size_t)nb_total - b0 < group ? (size_t)nb_total - b0 : group;
+        FbBuild fb{c->d_gens, c->nbases, W, d_table, d_tmp, d_tmp + gentries, d_tmp + 2 * gentries, d_tmp + 3 * gentries, first + (int)b0, (int)nb, first};
         size_t nthreads = nb * nwin * fb_chunks_per_window(W);
         unsigned blocks = (unsigned)((nthreads + BPPP_BLOCK - 1) / BPPP_BLOCK);
         k_fb_build_pass1<<<blocks, BPPP_BLOCK, 0, c->stream>>>(fb, nthreads);
@@ -82,10 +81,42 @@ static int build_tables(bppp_ctx* c, int W, bool ct = false) {
     HIP_TRY_T(hipStreamSynchronize(c->stream));
 #undef HIP_TRY_T
     (void)hipFree(d_tmp);
+    *out = d_table;
+    *out_bytes = bytes;
+    return BPPP_OK;
+}
+// ... of every generator at width W into c->d_table (ct = false) or into c->d_table_ct (the 4-bit table of the "ct_prover" mode)
+static int build_tables(bppp_ctx* c, int W, bool ct = false) {
+    apt_packed* d_table = nullptr;
+    size_t bytes = 0;
+    const int rc = build_table_range(c, W, 0, c->nbases, &d_table, &bytes);
+    if (rc != BPPP_OK) return rc;
     if (ct) { c->d_table_ct = d_table; c->table_ct_bytes = bytes; return BPPP_OK; }
     c->d_table = d_table;
     c->table_bytes = bytes;
     c->fb_w = W;
+    return BPPP_OK;
+}
+// Two regions (verify_core.h: FbTable; round 5): the u64 protocol's g and g_vec -- the 17 generators that BOTH fixed-base sums of a verify
+// run over (C0's fixed half and the final check) -- at 24-bit windows, 11 additions per scalar, 100 GB; h_vec at 22 bits, 52 GB.  792 ->
+// 758 table additions per proof.  Taken by fb_window_bits = 0 on the u64 generator shape when the two tables take at most 55 % of the free
+// HBM and leave room for the build scratch and a 2^21-proof workspace; BPPP_NO_MIXED_WINDOWS=1 keeps one table.
+static const int kMixedHiW = 24, kMixedLoW = 22;
+static bool mixed_fits(int ng, int nh, size_t free_bytes) {
+    const double tb = table_bytes_for(1 + ng, kMixedHiW) + table_bytes_for(nh, kMixedLoW);
+    const double scratch = (double)build_group_for(nh, kMixedLoW) * fb_nwin(kMixedLoW) * (double)fb_per_win(kMixedLoW) * 4 * sizeof(fe);
+    return tb <= 0.55 * (double)free_bytes && tb + scratch <= 0.90 * (double)free_bytes;
+}
+static int build_tables_mixed(bppp_ctx* c) {
+    const int hi = 1 + c->ng;
+    apt_packed *t_hi = nullptr, *t_lo = nullptr;
+    size_t b_hi = 0, b_lo = 0;
+    int rc = build_table_range(c, kMixedHiW, 0, hi, &t_hi, &b_hi);
+    if (rc != BPPP_OK) return rc;
+    rc = build_table_range(c, kMixedLoW, hi, c->nbases - hi, &t_lo, &b_lo);
+    if (rc != BPPP_OK) { (void)hipFree(t_hi); return rc; }
+    c->d_table_hi = t_hi; c->table_hi_bytes = b_hi; c->fb_w_hi = kMixedHiW; c->fb_hi_bases = hi;
+    c->d_table = t_lo; c->table_bytes = b_lo; c->fb_w = kMixedLoW;
     return BPPP_OK;
 }
 int ensure_ct_table(bppp_ctx* c) {
@@ -182,6 +213,11 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
         if (const char* e = std::getenv("BPPP_ASSUME_FREE_GB")) free_b = (size_t)(std::atof(e) * 1e9);      // diagnostic: exercise the choice
         rc = BPPP_ERR_NOMEM;
+        if (ng == 16 && nh == 32 && free_b && !std::getenv("BPPP_NO_MIXED_WINDOWS") && mixed_fits((int)ng, (int)nh, free_b)) {
+            rc = build_tables_mixed(c);
+            if (rc != BPPP_OK && rc != BPPP_ERR_NOMEM) return fail(rc);
+        }
+        if (rc != BPPP_OK)
         for (int W : kDefaultWindows) {
             if (W > 4 && free_b && !window_fits(NB, W, free_b)) continue;
             rc = build_tables(c, W);
@@ -205,6 +241,7 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     for (auto& ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->d_gens && !c->borrows_tables) (void)hipFree(c->d_gens);
     if (c->d_table && !c->borrows_tables) (void)hipFree(c->d_table);
+    if (c->d_table_hi && !c->borrows_tables) (void)hipFree(c->d_table_hi);
     if (c->d_table_ct && !c->borrows_table_ct) (void)hipFree(c->d_table_ct);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_straus) (void)hipFree(c->d_straus);
@@ -313,6 +350,10 @@ long bppp_ctx_get_option(bppp_ctx* c, const char* name) {
     CtxLock lock_(c);
     if (!c || !name) return BPPP_ERR_INVALID_ARG;
     if (std::strcmp(name, "fb_window_bits") == 0) return c->fb_w;
+    // a table in two regions (the u64 generator shape with fb_window_bits = 0 on an empty MI355X): the first "fb_hi_bases" generators at
+    // "fb_window_bits_hi" bits, the rest at "fb_window_bits"; 0 / 0 = one table
+    if (std::strcmp(name, "fb_window_bits_hi") == 0) return c->fb_w_hi;
+    if (std::strcmp(name, "fb_hi_bases") == 0) return c->fb_hi_bases;
     if (std::strcmp(name, "device") == 0) return c->device;
     if (std::strcmp(name, "n_generators") == 0) return c->nbases;
     if (std::strcmp(name, "rlc_superchunk") == 0) return (long)c->rlc_super_m;
@@ -362,7 +403,7 @@ int bppp_ctx_synchronize(bppp_ctx* c) {
 
 size_t bppp_ctx_device_bytes(const bppp_ctx* c) {
     if (!c) return 0;
-    return c->table_bytes + (c->borrows_table_ct ? 0 : c->table_ct_bytes) + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->bkt_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + c->blob_bytes + c->txio_bytes + c->gws_bytes + c->gtab_bytes + (size_t)c->nbases * sizeof(apt);
+    return c->table_bytes + c->table_hi_bytes + (c->borrows_table_ct ? 0 : c->table_ct_bytes) + c->ws_bytes + c->straus_bytes + c->vtab_bytes + c->rlc_bytes + c->bkt_bytes + c->pws_bytes + c->stage_bytes + c->io_bytes + c->blob_bytes + c->txio_bytes + c->gws_bytes + c->gtab_bytes + (size_t)c->nbases * sizeof(apt);
 }
 
 int bppp_ctx_enable_timing(bppp_ctx* c, int enable) {
@@ -515,6 +556,10 @@ struct TableChecksum {
 int bppp_ctx_save_tables(bppp_ctx* c, const char* path) {
     CtxLock lock_(c);
     if (!c || !path) return BPPP_ERR_INVALID_ARG;
+    if (c->fb_hi_bases) {
+        g_last_error = "this context's tables are in two regions (fb_window_bits = 0 on the u64 shape); create it with an explicit fb_window_bits to save them";
+        return BPPP_ERR_INVALID_ARG;
+    }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     FILE* f = std::fopen(path, "wb");
@@ -647,6 +692,7 @@ int ctx_create_shared_with(bppp_ctx** out, bppp_ctx* parent, const CtShare& ct) 
     if (!c) return BPPP_ERR_NOMEM;
     c->device = parent->device; c->fb_w = parent->fb_w; c->ng = parent->ng; c->nh = parent->nh; c->nbases = parent->nbases;
     c->d_gens = parent->d_gens; c->d_table = parent->d_table; c->table_bytes = 0; c->borrows_tables = true;
+    c->d_table_hi = parent->d_table_hi; c->table_hi_bytes = 0; c->fb_w_hi = parent->fb_w_hi; c->fb_hi_bases = parent->fb_hi_bases;
     if (ct.d_table_ct) { c->d_table_ct = ct.d_table_ct; c->borrows_table_ct = true; c->ct_prover = ct.ct_prover; }
     int rc = ctx_alloc_common(c);
     if (rc != BPPP_OK) { bppp_ctx_destroy(c); return rc; }

@@ -124,7 +124,7 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
     w.tab = (u32*)(d + o_tab); w.msc = (u32*)(d + o_msc);
     w.stride_r = rounds * 64; w.stride_x = rounds * 64; w.stride_l = nl * 32; w.stride_n = nn * 32;
     w.straus = c->d_straus;
-    w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    w.fb = fb_table_of(c, n);
     if (!commit) t_new(w.base, label, (u32)label_len);
     if (tx) {
         w.tio.states = d + o_ti; w.tio.n_states = tx->n_states; w.tio.states_out = tx->states_out ? d + o_to : nullptr;
@@ -236,7 +236,7 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     r.sc0 = (u32*)(d + o_sc0); r.pts = (u32*)(d + o_pts); r.acc = (u32*)(d + o_a); r.pfix = (u32*)(d + o_pf); r.inv = (u32*)(d + o_inv);
     r.straus = c->d_straus;
     r.wn_commit = d + o_wc; r.wn_c = d + o_wcv; r.wn_rho = d + o_rho; r.wn_mu = d + o_mu;
-    r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
+    r.fb = fb_table_of(c, n);
     t_new(r.base, label, (u32)label_len);
     if (dtio) r.tio = *dtio;
     WnlaWs w;
@@ -558,7 +558,7 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
     r.acc = (u32*)(d + o_a); r.pfix = (u32*)(d + o_pf);
     r.straus = c->d_straus;
     r.wn_commit = d + o_wc; r.wn_c = d + o_wcv; r.wn_rho = d + o_rho; r.wn_mu = d + o_mu;
-    r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
+    r.fb = fb_table_of(c, n);
     t_new(r.base, label, (u32)label_len);
     if (tx) { r.tio.states = d + o_ti; r.tio.n_states = tx->n_states; r.tio.states_out = tx->states_out ? d + o_to : nullptr; }
     WnlaWs w;
@@ -638,7 +638,7 @@ int bppp_msm_batch(bppp_ctx* c, size_t n, size_t nterms, const int32_t* base_ind
     w.N = n; w.nterms = (int)nterms; w.nruns = (int)(runs.size() / 3);
     w.scalars = d + o_sc; w.runs = (const int*)(d + o_runs); w.msc = (u32*)(d + o_msc); w.pfix = (u32*)(d + o_pf);
     w.status = (int32_t*)(d + o_st); w.out = d + o_out;
-    w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    w.fb = fb_table_of(c, n);
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     k_msm_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
@@ -709,7 +709,7 @@ static int wnla_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, 
     w.status = (int32_t*)(d + o_st); w.tstate = (u32*)(d + o_ts); w.vl = (u32*)(d + o_vl); w.vn = (u32*)(d + o_vn); w.vc = (u32*)(d + o_vc);
     w.ch = (u32*)(d + o_ch); w.cg = (u32*)(d + o_cg); w.prm = (u32*)(d + o_prm); w.com = (u32*)(d + o_cm); w.msc = (u32*)(d + o_msc);
     w.pbuf = (u32*)(d + o_pb);
-    w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    w.fb = fb_table_of(c, n);
     { const int rc_ct = ct_setup(c, w.fb_ct, w.ct, n); if (rc_ct != BPPP_OK) return rc_ct; }      // l, n are the caller's secrets here (wnla.rs:152-160)
     t_new(w.base, label, (u32)label_len);
     TxDev txd;
@@ -807,7 +807,7 @@ static int circuit_prove_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t*
     p.lamv = (u32*)(d + o_lam); p.muv = (u32*)(d + o_muv); p.coef = (u32*)(d + o_coef); p.misc = (u32*)(d + o_misc);
     p.msc = (u32*)(d + o_msc); p.pbuf = (u32*)(d + o_pb);
     p.wn_commit = d + o_wc; p.wn_c = d + o_wcv; p.wn_rho = d + o_rho; p.wn_mu = d + o_mu; p.wn_l = d + o_wlv; p.wn_n = d + o_wnv;
-    p.fb.table = c->d_table; p.fb.W = c->fb_w; p.fb.N = n;
+    p.fb = fb_table_of(c, n);
     { const int rc_ct = ct_setup(c, p.fb_ct, p.ct, n); if (rc_ct != BPPP_OK) return rc_ct; }      // c_l, c_r, c_o, c_s: witness and blindings (circuit.rs:336-345, 469-470)
     t_new(p.base, label, (u32)label_len);
     TxDev txd;
@@ -946,7 +946,7 @@ static int recip_prove_impl(bppp_ctx* c, const uint8_t* label, size_t label_len,
     r.status = (int32_t*)(d + o_st); r.tstate = (u32*)(d + o_ts); r.inst_vals = (u32*)(d + o_inst); r.scr = (u32*)(d + o_scr);
     r.msc = (u32*)(d + o_msc); r.pbuf = (u32*)(d + o_pb);
     r.cp_v = d + o_cpv; r.cp_sv = d + o_cpsv; r.cp_wr = d + o_cpwr; r.cp_vpts = d + o_cpvp; r.proof_r = d + o_prr;
-    r.fb.table = c->d_table; r.fb.W = c->fb_w; r.fb.N = n;
+    r.fb = fb_table_of(c, n);
     { const int rc_ct = ct_setup(c, r.fb_ct, r.ct, n); if (rc_ct != BPPP_OK) return rc_ct; }      // the reciprocals 1 / (e + d_i) (reciprocal.rs:118)
     t_new(r.base, label, (u32)label_len);
     TxDev txd;

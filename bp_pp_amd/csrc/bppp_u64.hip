@@ -446,7 +446,7 @@ int prove_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_
     w.msc = p; p += (size_t)BPPP_MSC_SETS * BPPP_NG * 8 * n;
     w.pbuf = p;
     w.straus = c->d_straus;
-    w.fb.table = c->d_table; w.fb.W = c->fb_w; w.fb.N = n;
+    w.fb = fb_table_of(c, n);
     if (c->ct_prover) {
         rc = ensure_ct_table(c);
         if (rc != BPPP_OK) return rc;

@@ -70,6 +70,10 @@ struct bppp_ctx {
     apt* d_gens = nullptr;       // 49
     apt_packed* d_table = nullptr;
     size_t table_bytes = 0;
+    // second table region (verify_core.h: FbTable): generators 0 .. fb_hi_bases - 1 at fb_w_hi bits; d_table then holds the rest
+    apt_packed* d_table_hi = nullptr;
+    size_t table_hi_bytes = 0;
+    int fb_w_hi = 0, fb_hi_bases = 0;
     // "ct_prover": the 4-bit table the provers' secret-scalar sums scan in full (verify_core.h: fb_lookup_add_ct), built when the option is set
     apt_packed* d_table_ct = nullptr;
     size_t table_ct_bytes = 0;
@@ -284,6 +288,12 @@ static inline void carve(bppp_ctx* c, VerifyWs& ws, size_t n) {
     ws.straus = c->d_straus;
     ws.fb_table = c->d_table;
     ws.fb_w = c->fb_w;
+    ws.fb_table_hi = c->d_table_hi; ws.fb_w_hi = c->fb_w_hi; ws.fb_hi_bases = c->fb_hi_bases;
+}
+// the context's fixed-base tables as the kernels take them (n = SoA stride of the scalars the sums will read)
+static inline FbTable fb_table_of(const bppp_ctx* c, size_t n) {
+    FbTable f = {c->d_table, c->fb_w, n, c->d_table_hi, c->fb_w_hi, c->fb_hi_bases};
+    return f;
 }
 
 template <typename F>
@@ -348,7 +358,7 @@ static inline int launch_bucket_stage(bppp_ctx* c, BucketWs& bw, size_t n, unsig
     bw.lhs = (u32*)p; p += align16(nsuper * 30 * 4);
     bw.asc = (u32*)p; p += align16(nsuper * (size_t)nb * 32);
     bw.sflag = p;
-    bw.fb.table = c->d_table; bw.fb.W = c->fb_w; bw.fb.N = nsuper;
+    bw.fb = fb_table_of(c, nsuper);
     const size_t lds_bytes = ((size_t)4 * (512 + SM) + 8 * 30) * sizeof(u32);
     (void)hipFuncSetAttribute((const void*)k_bkt_accumulate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);

@@ -67,6 +67,8 @@ struct VerifyWs {
     u32* tscr;                   // [BPPP_TSCR_FE * 10][N] scratch of verify_tables: running products of the slope denominators
     const apt_packed* fb_table;  // [49][nwin][2^W - 1]
     int fb_w;                    // window bits: 4, 8 or 16
+    const apt_packed* fb_table_hi;      // FbTable's second region (0 / null: none)
+    int fb_w_hi, fb_hi_bases;
     strobe base;                 // Transcript::new(label)
     // pre-loaded transcripts (the reference's `t: &mut Transcript`, u64_proof.rs:42): serialized STROBE states, 203 bytes each
     // (200 state bytes, pos, pos_begin, cur_flags); n_states = 1 (one state shared by the batch) or N (one per proof); null =
@@ -243,7 +245,13 @@ HD void app_point(S& t, const char (&label)[L], const apt& a) {  // transcript.r
 // a 21 GB table; random 64-byte reads from a table of that size still run at ~19 G/s on MI355X (tools/probes/gatherbench.hip),
 // above the ~12 G/s the arithmetic can consume.
 // (W = 10 is the same signed scheme with a table small enough for the CPU emulation tests: 26 windows of 512 entries.)
-struct FbTable { const apt_packed* table; int W; size_t N; };
+// Optional second region (round 5): the generators below `hi_bases` -- g and g_vec, the 17 bases that BOTH fixed-base sums of a u64
+// verify run over -- may live in `table_hi` at W_hi = 24 bits (11 additions per scalar instead of 12; 100 GB), and `table` then holds the
+// bases hi_bases .. only, counted from 0.  hi_bases = 0: one table for every base, as before.
+struct FbTable {
+    const apt_packed* table; int W; size_t N;
+    const apt_packed* table_hi; int W_hi; int hi_bases;
+};
 // TEST HOOK, host emulation only (tests/emul, tests/test_ct_trace.py): every fixed-base table entry a sum requests, as the entry's index
 // in its table.  The emulator records the sequence while a prover's SECRET sums run; the test requires it to be identical for two
 // different secrets in the "ct_prover" forms, and different in the default ones.  Compiled out of the device code and of any host
@@ -254,10 +262,10 @@ void bppp_trace_table_read(const void* table, size_t index);
 #else
 #define FB_TRACE(tab, idx) ((void)0)
 #endif
-HD bool fb_signed(int W) { return W == 20 || W == 10 || W == 22 || W == 18 || W == 19; }
+HD bool fb_signed(int W) { return W == 20 || W == 10 || W == 22 || W == 18 || W == 19 || W == 24; }
 HD int fb_nwin(int W) { return fb_signed(W) ? (257 + W - 1) / W : 256 / W; }           // signed: ceil(257 / W) windows
 HD size_t fb_per_win(int W) { return fb_signed(W) ? ((size_t)1 << (W - 1)) : (((size_t)1 << W) - 1); }
-HD FbTable fb_of(const VerifyWs& ws) { FbTable f = {ws.fb_table, ws.fb_w, ws.N}; return f; }
+HD FbTable fb_of(const VerifyWs& ws) { FbTable f = {ws.fb_table, ws.fb_w, ws.N, ws.fb_table_hi, ws.fb_w_hi, ws.fb_hi_bases}; return f; }
 // windows a scalar below 2^bits can reach (0 = full width).  Signed digits: the recoded value is sum d_i 2^(W i) with d_i in
 // [-2^(W-1), 2^(W-1)), and the top digit absorbs a carry of at most one, so ceil((bits + 1) / W) windows hold everything.
 HD int fb_windows_for(int bits, int W) {
@@ -272,68 +280,95 @@ HD int fb_term_index(int a, int oddsh) {
     const int sh = oddsh & 15, odd = ((oddsh >> 4) & 1) ^ 1, B = 1 << sh;      // bit 4 (BPPP_FB_EVEN): the EVEN blocks instead
     return (((a >> sh) << 1) + odd) * B + (a & (B - 1));
 }
-// digit of window w: returns the table index (|d| - 1), whether to skip (d == 0) and whether to negate
-HD void fb_digit(const u32 k[8], int W, int w, size_t& idx, bool& skip, bool& neg) {
-    if (!fb_signed(W)) {
-        const u32 mask = (1u << W) - 1u;
-        const int bit = w * W;
-        u32 limb = 0;
+// Geometry of a table region, derived ONCE per sum: inside the loops below a digit is a shift and a mask of a scalar that was recoded when
+// its first window was reached, and a table address is an increment -- no division, no per-window recoding, no choice by window
+// width (round 4's loop made that choice per step: 12.8 % of its dynamic instructions were scalar-unit bookkeeping).
+struct FbGeom {
+    const apt_packed* table;       // the region's entries: base b, window w at table[((b - base0) nwin + w) per_win ...]
+    int base0;
+    int W, nwin;           // window width; windows of a full-width scalar
+    u32 mask, half;        // 2^W - 1; 2^(W-1) for signed digits (the digit is field - half), 0 for unsigned ones
+    size_t per_win;        // entries per window
+    u32 off[9];            // signed digits: sum_i 2^(W-1 + W i) -- k + off carries digit + 2^(W-1) in every W-bit field
+};
+HD void fb_geom_w(FbGeom& g, int W) {
+    g.W = W;
+    g.nwin = fb_nwin(W);
+    g.per_win = fb_per_win(W);
+    g.mask = (1u << W) - 1u;
+    g.half = fb_signed(W) ? (1u << (W - 1)) : 0u;
 #pragma unroll
-        for (int i = 0; i < 8; i++) limb = (i == (bit >> 5)) ? k[i] : limb;
-        const u32 d = (limb >> (bit & 31)) & mask;
-        idx = d ? d - 1 : 0;
-        skip = d == 0;
-        neg = false;
-        return;
+    for (int l = 0; l < 9; l++) g.off[l] = 0;
+    if (fb_signed(W)) {
+#pragma nounroll
+        for (int i = 0; i < g.nwin; i++) {
+            const int bit = W - 1 + W * i;
+#pragma unroll
+            for (int l = 0; l < 9; l++) g.off[l] |= (l == (bit >> 5)) ? (1u << (bit & 31)) : 0u;
+        }
     }
-    // k' = k + sum_i 2^(W-1 + W i)  (9 limbs; < 2^260)
-    const u32 off20[9] = {0x00080000u, 0x08000080u, 0x00008000u, 0x00800008u, 0x80000800u, 0x00080000u, 0x08000080u, 0x00008000u, 0x00000008u};
-    const u32 off10[9] = {0x20080200u, 0x08020080u, 0x02008020u, 0x00802008u, 0x80200802u, 0x20080200u, 0x08020080u, 0x02008020u, 0x00000008u};
-    const u32 off22[9] = {0x00200000u, 0x00000800u, 0x00800002u, 0x00002000u, 0x02000008u, 0x00008000u, 0x08000020u, 0x00020000u, 0x00000080u};
-    const u32 off18[9] = {0x00020000u, 0x00200008u, 0x02000080u, 0x20000800u, 0x00008000u, 0x00080002u, 0x00800020u, 0x08000200u, 0x00002000u};
-    const u32 off19[9] = {0x00040000u, 0x01000020u, 0x40000800u, 0x00020000u, 0x00800010u, 0x20000400u, 0x00010000u, 0x00400008u, 0x00000200u};
-    u32 off[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) off[i] = (W == 20) ? off20[i] : (W == 22) ? off22[i] : (W == 18) ? off18[i] : (W == 19) ? off19[i] : off10[i];
-    u32 kp[10];
+}
+HD void fb_geom(FbGeom& g, const FbTable& f, bool hi) {
+    g.table = hi ? f.table_hi : f.table;
+    g.base0 = hi ? 0 : f.hi_bases;
+    fb_geom_w(g, hi ? f.W_hi : f.W);
+}
+HD bool fb_in_hi(const FbTable& f, int base) { return base < f.hi_bases; }
+HD const apt_packed* fb_window(const FbGeom& g, int base, int w) { return g.table + ((size_t)(base - g.base0) * g.nwin + w) * g.per_win; }
+HD void fb_recode(u32 kp[9], const u32 k[8], const FbGeom& g) {      // kp = k + off, 9 limbs (< 2^264)
     u32 c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) kp[i] = addc(k[i], off[i], c);
-    kp[8] = off[8] + c;
+    for (int i = 0; i < 8; i++) kp[i] = addc(k[i], g.off[i], c);
+    kp[8] = g.off[8] + c;
+}
+// the W-bit field of window w of the recoded scalar (w differs from lane to lane: selects)
+HD u32 fb_field(const u32 k[8], int w, const FbGeom& g) {
+    u32 kp[10];
+    fb_recode(kp, k, g);
     kp[9] = 0;
-    const int bit = W * w, li = bit >> 5, sh = bit & 31;
+    const int bit = g.W * w, li = bit >> 5, sh = bit & 31;
     u32 lo = 0, hi = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) { lo = (i == li) ? kp[i] : lo; hi = (i == li) ? kp[i + 1] : hi; }
-    const u64 both = ((u64)hi << 32) | lo;
-    const int d = (int)((u32)(both >> sh) & ((1u << W) - 1u)) - (1 << (W - 1));
-    const int mag = d < 0 ? -d : d;
+    return (u32)((((u64)hi << 32) | lo) >> sh) & g.mask;
+}
+// digit of window w: returns the table index (|d| - 1), whether to skip (d == 0) and whether to negate
+HD void fb_digit(const u32 k[8], int W, int w, size_t& idx, bool& skip, bool& neg) {
+    FbGeom g;
+    fb_geom_w(g, W);
+    const int d = (int)fb_field(k, w, g) - (int)g.half;
+    const u32 mag = (u32)(d < 0 ? -d : d);
     idx = mag ? (size_t)(mag - 1) : 0;
     skip = mag == 0;
     neg = d < 0;
 }
-HD void fb_lookup_add(pt& acc, const FbTable& fbt, int base, int w, const u32 k[8]) {
-    size_t idx;
-    bool skip, neg, id;
-    fb_digit(k, fbt.W, w, idx, skip, neg);
-    const apt_packed* tb = fbt.table + ((size_t)base * fb_nwin(fbt.W) + w) * fb_per_win(fbt.W);
+// one table addition with the complete law (the provers' small sums, commit_value, and the re-do of a sum whose fast form met an
+// exceptional addition)
+HD void fb_lookup_add(pt& acc, const FbGeom& g, int base, int w, const u32 k[8]) {
+    const int d = (int)fb_field(k, w, g) - (int)g.half;
+    const u32 mag = (u32)(d < 0 ? -d : d);
+    const apt_packed* tb = fb_window(g, base, w);
+    const size_t idx = mag ? (size_t)(mag - 1) : 0;
     apt e;
-    FB_TRACE(fbt.table, (tb - fbt.table) + idx);
+    bool id;
+    FB_TRACE(g.table, (tb - g.table) + idx);
     apt_unpack(e, id, tb[idx]);
     fe ny;
     fe_neg_m<1>(ny, e.y);
-    fe_cmov(e.y, neg, ny);
-    pt_madd(acc, acc, e, skip | id);
+    fe_cmov(e.y, d < 0, ny);
+    pt_madd(acc, acc, e, (mag == 0) | id);
 }
 HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, int first_slot, int first_base, int count, int bits = 0) {
-    const int nwin = fb_windows_for(bits, fbt.W);     // bits > 0: the scalars are below 2^bits -- only the windows they can reach
     pt acc = accp;
 #pragma nounroll
     for (int j = 0; j < count; j++) {
+        FbGeom g;
+        fb_geom(g, fbt, fb_in_hi(fbt, first_base + j));
+        const int nwin = fb_windows_for(bits, g.W);     // bits > 0: the scalars are below 2^bits -- only the windows they can reach
         u32 k[8];
         ws_ld8(k, scal, fbt.N, t, first_slot + j);
 #pragma nounroll
-        for (int w = 0; w < nwin; w++) fb_lookup_add(acc, fbt, first_base + j, w, k);
+        for (int w = 0; w < nwin; w++) fb_lookup_add(acc, g, first_base + j, w, k);
     }
     accp = acc;
 }
@@ -343,31 +378,20 @@ HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, 
 // (wavefront shuffles on the device).  49 bases x 16 windows = 784 independent table additions per proof is where this
 // path has intra-proof parallelism; it lifts the kernel from 1 to 4 resident wavefronts per SIMD at 2^16 proofs.
 #define BPPP_FB_LANES 8
-HD void fixed_base_msm_partial(pt& accp, const FbTable& fbt, size_t t, int lane, const u32* scal, int first_slot, int first_base,
+HD void fixed_base_msm_partial(pt& accp, const FbGeom& g, size_t N, size_t t, int lane, const u32* scal, int first_slot, int first_base,
                                int count, int nl = BPPP_FB_LANES, int bits = 0, int oddsh = -1) {
-    const int nwin = fb_windows_for(bits, fbt.W);
+    const int nwin = fb_windows_for(bits, g.W);
     pt acc;
     pt_set_identity(acc);
-    if (nwin % nl == 0) {
-        // every lane takes the windows congruent to it: the scalar is loaded once per base and shared by the group
+    // the (term, window) pairs of the run, window-fastest, dealt round-robin over the lanes (the fast form's dealing: verify_core.h,
+    // fb_lane_accumulate_fast)
+    const int pairs = count * nwin;
 #pragma nounroll
-        for (int a = 0; a < count; a++) {
-            const int j = fb_term_index(a, oddsh);
-            u32 k[8];
-            ws_ld8(k, scal, fbt.N, t, first_slot + j);
-#pragma nounroll
-            for (int w = lane; w < nwin; w += nl) fb_lookup_add(acc, fbt, first_base + j, w, k);
-        }
-    } else {
-        // 13 windows do not divide over 8 lanes: deal the (base, window) pairs round-robin instead
-        const int pairs = count * nwin;
-#pragma nounroll
-        for (int q = lane; q < pairs; q += nl) {
-            const int a = q / nwin, w = q - a * nwin, j = fb_term_index(a, oddsh);
-            u32 k[8];
-            ws_ld8(k, scal, fbt.N, t, first_slot + j);
-            fb_lookup_add(acc, fbt, first_base + j, w, k);
-        }
+    for (int q = lane; q < pairs; q += nl) {
+        const int a = q / nwin, w = q - a * nwin, j = fb_term_index(a, oddsh);
+        u32 k[8];
+        ws_ld8(k, scal, N, t, first_slot + j);
+        fb_lookup_add(acc, g, first_base + j, w, k);
     }
     accp = acc;
 }
@@ -393,38 +417,6 @@ HD void fb_order_after(u32 k[8], const ptz& a) {
     (void)k;
     (void)a;
 #endif
-}
-// Geometry of a table, derived ONCE per sum: inside the loops below a digit is a shift and a mask of a scalar that was recoded when
-// its first window was reached, and a table address is an increment -- no division, no per-window recoding, no choice by window
-// width (round 4's loop made that choice per step: 12.8 % of its dynamic instructions were scalar-unit bookkeeping).
-struct FbGeom {
-    int W, nwin;           // window width; windows of a full-width scalar
-    u32 mask, half;        // 2^W - 1; 2^(W-1) for signed digits (the digit is field - half), 0 for unsigned ones
-    size_t per_win;        // entries per window
-    u32 off[9];            // signed digits: sum_i 2^(W-1 + W i) -- k + off carries digit + 2^(W-1) in every W-bit field
-};
-HD void fb_geom(FbGeom& g, int W) {
-    g.W = W;
-    g.nwin = fb_nwin(W);
-    g.per_win = fb_per_win(W);
-    g.mask = (1u << W) - 1u;
-    g.half = fb_signed(W) ? (1u << (W - 1)) : 0u;
-#pragma unroll
-    for (int l = 0; l < 9; l++) g.off[l] = 0;
-    if (fb_signed(W)) {
-#pragma nounroll
-        for (int i = 0; i < g.nwin; i++) {
-            const int bit = W - 1 + W * i;
-#pragma unroll
-            for (int l = 0; l < 9; l++) g.off[l] |= (l == (bit >> 5)) ? (1u << (bit & 31)) : 0u;
-        }
-    }
-}
-HD void fb_recode(u32 kp[9], const u32 k[8], const FbGeom& g) {      // kp = k + off, 9 limbs (< 2^264)
-    u32 c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) kp[i] = addc(k[i], g.off[i], c);
-    kp[8] = g.off[8] + c;
 }
 HD u32 funnel_shr(u32 hi, u32 lo, int sh) {      // low word of (hi:lo) >> sh, 0 < sh < 32: one v_alignbit_b32
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -461,11 +453,10 @@ HD void fb_lane_accumulate_seq(ptz& acc, bool& empty, const FbTable& fbt, const 
     const int nw = fb_windows_for(bits, g.W);          // windows walked per scalar
     const int steps = count * nw;
     if (steps <= 0) return;
-    const size_t base_stride = (size_t)g.nwin * g.per_win;
     // the producer hands out window pw of term pa next; past the last term it walks the last term again (requested, never consumed)
     int pa = 0, pw = 0;
     int j = fb_term_index(0, oddsh), jn = fb_term_index(count > 1 ? 1 : 0, oddsh);
-    const apt_packed* win = fbt.table + (size_t)(first_base + j) * base_stride;
+    const apt_packed* win = fb_window(g, first_base + j, 0);
     u32 k[8], kp[9];
     ws_ld8(k, scal, fbt.N, t, first_slot + j);
     fb_recode(kp, k, g);
@@ -474,7 +465,7 @@ HD void fb_lane_accumulate_seq(ptz& acc, bool& empty, const FbTable& fbt, const 
             pa = pa + 1 < count ? pa + 1 : count - 1;
             j = jn;
             jn = fb_term_index(pa + 1 < count ? pa + 1 : count - 1, oddsh);
-            win = fbt.table + (size_t)(first_base + j) * base_stride;
+            win = fb_window(g, first_base + j, 0);
             fb_recode(kp, k, g);
             pw = 0;
         }
@@ -488,13 +479,13 @@ HD void fb_lane_accumulate_seq(ptz& acc, bool& empty, const FbTable& fbt, const 
     FbStep cur_st, nxt_st;
     apt_packed cur_e, nxt_e;
     produce(cur_st);
-    FB_TRACE(fbt.table, cur_st.ptr - fbt.table);
+    FB_TRACE(g.table, cur_st.ptr - g.table);
     cur_e = *cur_st.ptr;
     ws_ld8(k, scal, fbt.N, t, first_slot + jn);
     produce(nxt_st);
 #pragma nounroll
     for (int i = 0; i < steps; i++) {
-        FB_TRACE(fbt.table, nxt_st.ptr - fbt.table);
+        FB_TRACE(g.table, nxt_st.ptr - g.table);
         nxt_e = *nxt_st.ptr;                                    // step i+1's entry
         ws_ld8(k, scal, fbt.N, t, first_slot + jn);             // the producer's next scalar (used when step i+2 starts a term)
         fb_sched_fence();
@@ -528,16 +519,8 @@ HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, const
         w = in ? nwn : w;
     };
     auto produce = [&](FbStep& st, const u32 k[8]) {      // k: the scalar of term a
-        u32 kp[10];
-        fb_recode(kp, k, g);
-        kp[9] = 0;
-        const int bit = g.W * w, li = bit >> 5, sh = bit & 31;
-        u32 lo = 0, hi = 0;
-#pragma unroll
-        for (int i = 0; i < 9; i++) { lo = (i == li) ? kp[i] : lo; hi = (i == li) ? kp[i + 1] : hi; }
-        const u32 field = (u32)((((u64)hi << 32) | lo) >> sh) & g.mask;
         const int j = fb_term_index(a, oddsh);
-        fb_step_from_field(st, fbt.table + ((size_t)(first_base + j) * g.nwin + w) * g.per_win, field, g);
+        fb_step_from_field(st, fb_window(g, first_base + j, w), fb_field(k, w, g), g);
     };
     u32 k[8];
     FbStep cur_st, nxt_st;
@@ -545,7 +528,7 @@ HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, const
     // prologue: entry of step 0, address of step 1
     ws_ld8(k, scal, fbt.N, t, first_slot + fb_term_index(a, oddsh));
     produce(cur_st, k);
-    FB_TRACE(fbt.table, cur_st.ptr - fbt.table);
+    FB_TRACE(g.table, cur_st.ptr - g.table);
     cur_e = *cur_st.ptr;
     advance();
     ws_ld8(k, scal, fbt.N, t, first_slot + fb_term_index(a, oddsh));
@@ -553,7 +536,7 @@ HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, const
     advance();
 #pragma nounroll
     for (int i = 0; i < steps; i++) {
-        FB_TRACE(fbt.table, nxt_st.ptr - fbt.table);
+        FB_TRACE(g.table, nxt_st.ptr - g.table);
         nxt_e = *nxt_st.ptr;                                                    // step i+1's entry
         ws_ld8(k, scal, fbt.N, t, first_slot + fb_term_index(a, oddsh));        // step i+2's scalar
         fb_sched_fence();
@@ -600,20 +583,40 @@ struct FbRanges {
     int oddsh[BPPP_FB_MAX_RUNS] = {-1, -1, -1, -1, -1};
 };
 HD void fb_ranges_one(FbRanges& r, int slot, int base, int count) { r.n = 1; r.slot[0] = slot; r.base[0] = base; r.count[0] = count; r.bits[0] = 0; r.oddsh[0] = -1; }
+// A run of consecutive (slot, base) terms in the regions of its table: the part below hi_bases (the wide-window region, if the table has
+// one), then the rest.  fn(geometry, slot, base, count).  A run of odd / even blocks (oddsh >= 0: the provers' sums over g_vec or h_vec)
+// never straddles the boundary -- hi_bases is 1 + |g_vec| -- and goes by its first base.
+template <class F>
+HD void fb_run_regions(const FbTable& fbt, const FbGeom& g_lo, const FbGeom& g_hi, int slot, int base, int count, int oddsh, F&& fn) {
+    if (fbt.hi_bases > 0 && base < fbt.hi_bases) {
+        const int room = fbt.hi_bases - base;
+        const int c1 = (oddsh >= 0 || count < room) ? count : room;
+        fn(g_hi, slot, base, c1);
+        if (c1 < count) fn(g_lo, slot + c1, base + c1, count - c1);
+    } else {
+        fn(g_lo, slot, base, count);
+    }
+}
 HD void fb_lane_sum_complete(pt& part, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg, int nl = BPPP_FB_LANES) {
+    FbGeom g_lo, g_hi;
+    fb_geom(g_lo, fbt, false);
+    if (fbt.hi_bases > 0) fb_geom(g_hi, fbt, true); else g_hi = g_lo;
     pt acc;
     pt_set_identity(acc);
 #pragma nounroll
     for (int r = 0; r < rg.n; r++) {
-        pt p;
-        fixed_base_msm_partial(p, fbt, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r], nl, rg.bits[r], rg.oddsh[r]);
-        pt_add(acc, acc, p);
+        fb_run_regions(fbt, g_lo, g_hi, rg.slot[r], rg.base[r], rg.count[r], rg.oddsh[r], [&](const FbGeom& g, int slot, int base, int count) {
+            pt p;
+            fixed_base_msm_partial(p, g, fbt.N, t, lane, scal, slot, base, count, nl, rg.bits[r], rg.oddsh[r]);
+            pt_add(acc, acc, p);
+        });
     }
     part = acc;
 }
 HD bool fb_lane_sum_fast(pt& part, const FbTable& fbt, size_t t, int lane, const u32* scal, const FbRanges& rg, int nl = BPPP_FB_LANES) {
-    FbGeom g;
-    fb_geom(g, fbt.W);
+    FbGeom g_lo, g_hi;
+    fb_geom(g_lo, fbt, false);
+    if (fbt.hi_bases > 0) fb_geom(g_hi, fbt, true); else g_hi = g_lo;
     ptz acc;
     ptz_init(acc);
     bool empty = true;
@@ -625,7 +628,11 @@ HD bool fb_lane_sum_fast(pt& part, const FbTable& fbt, size_t t, int lane, const
         empty = false;
     }
 #pragma nounroll
-    for (int r = 0; r < rg.n; r++) fb_lane_accumulate_fast(acc, empty, fbt, g, t, lane, scal, rg.slot[r], rg.base[r], rg.count[r], nl, rg.bits[r], rg.oddsh[r]);
+    for (int r = 0; r < rg.n; r++) {
+        fb_run_regions(fbt, g_lo, g_hi, rg.slot[r], rg.base[r], rg.count[r], rg.oddsh[r], [&](const FbGeom& g, int slot, int base, int count) {
+            fb_lane_accumulate_fast(acc, empty, fbt, g, t, lane, scal, slot, base, count, nl, rg.bits[r], rg.oddsh[r]);
+        });
+    }
     const bool ok = fb_lane_finish_fast(part, acc, empty);
     if (fb_offset_start(nl)) {
         apt T;
@@ -2539,6 +2546,7 @@ struct FbBuild {
     fe *xtmp, *ytmp, *ztmp; // projective coordinates of the entries of THIS pass (pass 1 -> pass 2)
     fe* ptmp;               // prefix products of Z
     int base0, nb;          // the bases built by this pass: base0 .. base0 + nb - 1 (the scratch holds nb bases' worth of entries)
+    int tbase0;             // the generator whose entries open `table` (0, or FbTable::hi_bases for the region that holds the rest)
 };
 HD size_t fb_chunks_per_window(int W) { return (fb_per_win(W) + BPPP_FB_CHUNK - 1) / BPPP_FB_CHUNK; }
 HD void fb_build_pass1(const FbBuild& fb, size_t tid) {
@@ -2585,7 +2593,7 @@ HD void fb_build_pass2(const FbBuild& fb, size_t tid) {
     if (b >= (size_t)fb.nb) return;
     size_t d0 = c * BPPP_FB_CHUNK;
     size_t off = (b * nwin + w) * per_win + d0;                            // within this pass's scratch
-    const size_t toff = ((size_t)fb.base0 * nwin) * per_win;               // this pass's first table entry
+    const size_t toff = ((size_t)(fb.base0 - fb.tbase0) * nwin) * per_win; // this pass's first table entry
     size_t cnt = per_win - d0 < BPPP_FB_CHUNK ? per_win - d0 : BPPP_FB_CHUNK;
     // identity entries (Z = 0; only when the generator itself is the identity) are skipped in the product
     fe run;

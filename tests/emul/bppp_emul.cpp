@@ -229,7 +229,7 @@ int emul_fb_msm_lanes(const uint8_t* table, int W, int first_base, int count, co
 // nl lanes per sum: 1 (the shift-register walk of the large batches), 8, 64 (a wavefront per sum: the accumulator starts empty there,
 // the other forms start from the offset point)
 int emul_fb_msm_lanes_nl(const uint8_t* table, int W, int first_base, int count, const uint8_t* k, uint8_t out[64], int* fell_back, int nl) {
-    FbTable fbt;
+    FbTable fbt = {};
     fbt.table = (const apt_packed*)table;
     fbt.W = W;
     fbt.N = 1;
@@ -255,6 +255,35 @@ int emul_fb_msm_lanes_nl(const uint8_t* table, int W, int first_base, int count,
     acc = viaserial;
     apt r;
     pt_to_affine(r, acc);
+    apt_to_xy64(out, r);
+    return 0;
+}
+// a sum over a table in TWO regions (FbTable::table_hi: the first hi_bases generators at W_hi bits; table_lo: the rest at W_lo bits, counted
+// from 0), nl lanes, fast form + complete re-do as the kernels run it; first_base / count may straddle the boundary
+int emul_fb_msm_mixed(const uint8_t* table_hi, int W_hi, int hi_bases, const uint8_t* table_lo, int W_lo, int first_base, int count,
+                      const uint8_t* k, uint8_t out[64], int nl) {
+    FbTable fbt = {};
+    fbt.table = (const apt_packed*)table_lo; fbt.W = W_lo; fbt.N = 1;
+    fbt.table_hi = (const apt_packed*)table_hi; fbt.W_hi = W_hi; fbt.hi_bases = hi_bases;
+    std::vector<u32> scal(count * 8);
+    for (int j = 0; j < count; j++) {
+        sc s;
+        if (!sc_from_be(s, k + 32 * j)) return -1;
+        for (int i = 0; i < 8; i++) scal[(j * 8 + i)] = s.v[i];
+    }
+    FbRanges rg;
+    fb_ranges_one(rg, 0, first_base, count);
+    pt fast, comp, part;
+    fb_sum_serial(fast, fbt, 0, scal.data(), rg, nl);
+    pt_set_identity(comp);
+    for (int lane = 0; lane < nl; lane++) { fb_lane_sum_complete(part, fbt, 0, lane, scal.data(), rg, nl); pt_add(comp, comp, part); }
+    if (!pt_eq(fast, comp)) return -2;
+    pt one;             // and term by term with the complete law (commit_value's form)
+    pt_set_identity(one);
+    fixed_base_msm(one, fbt, 0, scal.data(), 0, first_base, count);
+    if (!pt_eq(fast, one)) return -3;
+    apt r;
+    pt_to_affine(r, fast);
     apt_to_xy64(out, r);
     return 0;
 }
@@ -612,7 +641,7 @@ int emul_fb_lookup_both(const uint8_t* table, int base, int w, const uint8_t k32
     pt p, q;
     pt_from_affine(p, a0);
     q = p;
-    fb_lookup_add(p, fbt, base, w, k.v);
+    { FbGeom g; fb_geom(g, fbt, false); fb_lookup_add(p, g, base, w, k.v); }
     fb_lookup_add_ct(q, fbt, base, w, k.v);
     apt r;
     pt_to_affine(r, p); apt_to_xy64(out_fast, r);

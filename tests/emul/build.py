@@ -27,6 +27,7 @@ def load():
     L.emul_fb_msm.argtypes = [vp, i32, i32, i32, cp, vp]
     L.emul_fb_msm_lanes.argtypes = [vp, i32, i32, i32, cp, vp, vp]
     L.emul_fb_msm_lanes_nl.argtypes = [vp, i32, i32, i32, cp, vp, vp, i32]
+    L.emul_fb_msm_mixed.argtypes = [vp, i32, i32, vp, i32, i32, i32, cp, vp, i32]
     L.emul_straus.argtypes = [i32, cp, cp, vp]
     L.emul_inv.argtypes = [i32, cp, vp, vp]
     L.emul_straus_affine.argtypes = [i32, cp, cp, vp, vp]

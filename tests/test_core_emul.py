@@ -309,6 +309,33 @@ def test_fixed_base_fast_accumulator_and_its_fallback(L, gold, W):
             assert hits == 0          # from the offset point the same sums are ordinary additions
 
 
+@pytest.mark.parametrize("W_hi,W_lo", [(10, 8), (10, 4), (8, 10)])
+def test_fixed_base_sums_over_a_table_in_two_regions(L, gold, W_hi, W_lo):
+    """FbTable's second region (round 5: the 17 generators both fixed-base sums of a u64 verify run over get 24-bit windows, the other 32
+    keep 22): the first hi_bases generators in one table at one width, the rest in another table at another width, counted from 0.
+    Runs inside either region and across the boundary, on 1, 8 and 64 lanes, fast form == complete form == term-by-term == the oracle."""
+    gens = bytes.fromhex(gold["generators"])
+    NB, HI = 7, 3
+    pts = [O.pt_from_xy64(gens[64 * i:64 * i + 64]) for i in range(NB)]
+    thi = np.zeros(L.emul_fb_table_entries(HI, W_hi) * 64, dtype=np.uint8)
+    tlo = np.zeros(L.emul_fb_table_entries(NB - HI, W_lo) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens[:64 * HI], HI, W_hi, thi.ctypes.data) == 0
+    assert L.emul_fb_build(gens[64 * HI:64 * NB], NB - HI, W_lo, tlo.ctypes.data) == 0
+    rng = np.random.default_rng(W_hi * 100 + W_lo)
+    out = C.create_string_buffer(64)
+    for first, count in ((0, NB), (0, HI), (HI, NB - HI), (1, 4), (2, 1), (HI - 1, 2), (4, 3)):
+        for nl in (1, 8, 64):
+            ks = [int.from_bytes(rng.bytes(32), "big") % O.N for _ in range(count)]
+            if nl == 8:
+                ks[0] = O.N - 1
+                ks[-1] = 0 if count > 1 else 1
+            assert L.emul_fb_msm_mixed(thi.ctypes.data, W_hi, HI, tlo.ctypes.data, W_lo, first, count, b"".join(map(b32, ks)), out, nl) == 0
+            exp = O.pt_mul(pts[first], ks[0])
+            for j in range(1, count):
+                exp = O.pt_add(exp, O.pt_mul(pts[first + j], ks[j]))
+            assert out.raw == O.pt_to_xy64(exp), (first, count, nl)
+
+
 @pytest.mark.parametrize("W", [4, 10])            # 10 = the signed-window scheme (26 windows: pairs dealt round-robin over the lanes)
 def test_full_verify_pipeline_against_golden(L, gold, oracle_c, W):
     gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
