@@ -131,8 +131,25 @@ def test_default_window_width_follows_free_memory(monkeypatch):
         p = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=0)
         try:
             assert p.get_option("fb_window_bits") == want, (free_gb, p.get_option("fb_window_bits"))
+            # round 5: with 300 GB free the u64 shape gets its table in two regions -- g and g_vec (17 generators) at 24 bits, h_vec at 22
+            assert (p.get_option("fb_window_bits_hi"), p.get_option("fb_hi_bases")) == ((24, 17) if free_gb == 300 else (0, 0))
             acc, st = p.verify_batch(V, P, workload.LABEL)
             assert (acc == expect).all() and not st.any()
+            if free_gb == 300:
+                with pytest.raises(Exception):
+                    p.save_tables("/tmp/never_written.bin")          # two regions: not a saveable layout (create with an explicit width)
+                x = np.array([0, 7, 2**64 - 1], dtype=np.uint64)      # commit_value: g from the wide region, h_vec[0] from the other
+                sb = np.frombuffer(bytes(range(96)), dtype=np.uint8).reshape(3, 32) & 0x7F
+                cv_mixed = p.commit_value_batch(x, sb)
+                monkeypatch.setenv("BPPP_NO_MIXED_WINDOWS", "1")
+                q = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=0)
+                monkeypatch.delenv("BPPP_NO_MIXED_WINDOWS")
+                try:
+                    assert (q.get_option("fb_window_bits"), q.get_option("fb_window_bits_hi")) == (22, 0)      # one table of 79 GB
+                    acc2, st2 = q.verify_batch(V, P, workload.LABEL)
+                    assert (acc2 == acc).all() and (st2 == st).all() and (q.commit_value_batch(x, sb) == cv_mixed).all()
+                finally:
+                    q.close()
         finally:
             p.close()
     monkeypatch.delenv("BPPP_ASSUME_FREE_GB")
