@@ -408,9 +408,12 @@ def run_verify(args):
                 "unit": "verifies/s", "ms_per_step": t1 * 1e3, "accept_bits_ok": bool((dA1.cpu().numpy() == expect[:m]).all())}
         V16, P16 = dV[:m].cpu().numpy(), dP[:m].cpu().numpy()
         proto.verify_batch(V16, P16, workload.LABEL)
-        t_h = time.perf_counter()
-        hacc, _ = proto.verify_batch(V16, P16, workload.LABEL)
-        t_h = time.perf_counter() - t_h
+        t_h = None
+        for _ in range(3):           # best of three: the calling thread does the pageable staging, and the boxes' cgroups throttle it at times
+            t0 = time.perf_counter()
+            hacc, _ = proto.verify_batch(V16, P16, workload.LABEL)
+            t0 = time.perf_counter() - t0
+            t_h = t0 if t_h is None else min(t_h, t0)
         host_path = {"value": m / t_h, "unit": "verifies/s", "ms_per_batch": t_h * 1e3, "proofs": m,
                      "accept_bits_ok": bool((hacc == expect[:m]).all()),
                      "note": "bppp_u64_verify_batch with pageable host buffers: 65 MB host-to-device per batch included"}
@@ -421,9 +424,12 @@ def run_verify(args):
         if C33 is not None:
             P525 = np.frombuffer(b"".join(wire.abi_to_sec1(bytes(P16[i])) for i in range(m)), dtype=np.uint8).reshape(m, 525).copy()
             proto.verify_batch_sec1(C33, P525, workload.LABEL)
-            t_s = time.perf_counter()
-            sacc, _ = proto.verify_batch_sec1(C33, P525, workload.LABEL)
-            t_s = time.perf_counter() - t_s
+            t_s = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                sacc, _ = proto.verify_batch_sec1(C33, P525, workload.LABEL)
+                t0 = time.perf_counter() - t0
+                t_s = t0 if t_s is None else min(t_s, t0)
             host_path["sec1_form"] = {"value": m / t_s, "unit": "verifies/s", "ms_per_batch": t_s * 1e3, "accept_bits_ok": bool((sacc == expect[:m]).all()),
                                       "note": "bppp_u64_verify_batch_sec1: 36.6 MB over PCIe instead of 65 MB, then on-device decompression"}
         if n > m:
