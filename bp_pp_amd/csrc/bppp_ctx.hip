@@ -11,6 +11,10 @@ thread_local std::string g_last_error;
 // Diagnostic switches (A/B measurements), read from the environment once per context, here and nowhere else.
 static void read_diagnostics(bppp_ctx* c) {
     c->no_lane_groups = std::getenv("BPPP_NO_LANE_GROUPS") != nullptr;    // one lane per proof at every batch size
+    if (const char* e = std::getenv("BPPP_GENERIC_LANE_GROUP")) {
+        const int g = std::atoi(e);
+        c->generic_lane_group = (g == 2 || g == 4) ? g : 0;
+    }
     c->no_small = std::getenv("BPPP_NO_SMALL_KERNELS") != nullptr;        // the 256-VGPR builds (two wavefronts per SIMD) at every batch size
     c->no_split = std::getenv("BPPP_NO_SPLIT") != nullptr;                // no half-stream lanes / per-table lanes for calls of <= one proof per SIMD
     if (const char* e = std::getenv("BPPP_FB_ONE_LANE")) c->fb_one_lane_mode = e[0] == '0' ? 0 : 1;

@@ -43,10 +43,11 @@ struct TxDev {
 };
 // fast variable-base path of the generic verifiers' rounds: per instance 2 x rounds window tables (16 entries of 64 B per point), the
 // running products of their build (BPPP_TSCR_PER_POINT per point) and the decoded round points -- 1.2 KB + 0.55 KB + 64 B per point, grow-only
-static int wnla_fast_setup(bppp_ctx* c, WnlaWs& w, size_t n, size_t rounds) {
+// extra_points: tables of that many more points per instance behind the round points' (the reciprocal verifier's five C0 points)
+static int wnla_fast_setup(bppp_ctx* c, WnlaWs& w, size_t n, size_t rounds, size_t extra_points = 0) {
     w.atab = nullptr; w.tscr = nullptr; w.rpts = nullptr;
     if (rounds == 0 || c->generic_slow_rounds) return BPPP_OK;
-    const size_t np = 2 * rounds;
+    const size_t np = 2 * rounds + extra_points;
     const size_t b_tab = align16(np * 16 * sizeof(apt_packed) * n), b_scr = align16((size_t)BPPP_TSCR_PER_POINT * np * 10 * sizeof(u32) * n), b_pts = align16(np * 16 * sizeof(u32) * n);
     const size_t need = b_tab + b_scr + b_pts;
     {
@@ -61,9 +62,27 @@ static int wnla_fast_setup(bppp_ctx* c, WnlaWs& w, size_t n, size_t rounds) {
 // lanes per instance for the generic rounds: 4 or 2 while that still leaves wavefront slots free (and the fast path's tables exist)
 static int wnla_round_group(const bppp_ctx* c, const WnlaWs& w, unsigned blocks) {
     if (!w.atab || c->no_lane_groups) return 1;
+    if (c->generic_lane_group) return c->generic_lane_group;
     if (4 * (size_t)blocks <= (size_t)c->n_simds) return 4;
     if (2 * (size_t)blocks <= (size_t)c->n_simds) return 2;
     return 1;
+}
+// lanes per instance for the final scalars (k_wnla_final_scalars_grp), as log2: up to 8 while the launch stays within four wavefronts
+// per SIMD.  The work is independent per generator, so unlike the rounds it divides by the full group size.
+static int wnla_final_scalars_group_lg(const bppp_ctx* c, unsigned rounds, unsigned blocks) {
+    if (c->no_lane_groups) return 0;
+    if (c->generic_lane_group) return wnla_final_scalars_lg((int)rounds, c->generic_lane_group == 2 ? 1 : 3);   // (tests: 2 or 8 parts)
+    int lg = 0;
+    while (lg < 3 && ((size_t)blocks << (lg + 1)) <= 4 * (size_t)c->n_simds) lg++;
+    return wnla_final_scalars_lg((int)rounds, lg);
+}
+static void launch_wnla_final_scalars(const bppp_ctx* c, const WnlaWs& w, unsigned rounds, size_t n, unsigned blocks, hipStream_t s) {
+    const int lg = wnla_final_scalars_group_lg(c, rounds, blocks);
+    if (lg > 0) {
+        k_wnla_final_scalars_grp<<<blocks << lg, BPPP_BLOCK, 0, s>>>(w, lg);
+        k_wnla_final_scalars_join<<<blocks, BPPP_BLOCK, 0, s>>>(w, lg);
+    } else k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    (void)n;
 }
 // ---- generic WeightNormLinearArgument entry points (host pointers; one device blob per call)
 // (the context's grow-only buffer: no allocator round trip per call.  Whatever way the call ends, nothing of it is still running
@@ -151,7 +170,7 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
                 else k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
             }
         }
-        k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s);
         k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
         k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
         if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
@@ -267,10 +286,21 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     if (fb_one_lane) GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
     else GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
-    GLAUNCH(K_RECIP_C0_VAR, k_recip_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r));
-    GLAUNCH(K_RECIP_C0_FINISH, k_recip_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r));
-    rc = wnla_fast_setup(c, w, n, rounds);
+    // the WNLA stage's table buffer with room for the five C0 points' tables behind the round points': the variable-base part of C0 on
+    // affine window tables too (and on lane groups while one lane per instance leaves wavefront slots free)
+    rc = wnla_fast_setup(c, w, n, rounds, 5);
     if (rc != BPPP_OK) return rc;
+    static_assert(BPPP_ATAB_SOA, "the C0 tables are addressed entry-major behind the round points' tables");
+    r.atab = w.atab; r.tscr = w.tscr; r.atab_first = (int)(2 * rounds * 16);
+    if (r.atab) {
+        const int grp = wnla_round_group(c, w, blocks);
+        GLAUNCH(K_RECIP_C0_VAR, {
+            k_recip_c0_tables<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+            if (grp > 1) k_recip_c0_var_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(r, grp);
+            else k_recip_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+        });
+    } else GLAUNCH(K_RECIP_C0_VAR, k_recip_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    GLAUNCH(K_RECIP_C0_FINISH, k_recip_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r));
     GLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     if (w.atab) GLAUNCH(K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     {
@@ -280,7 +310,7 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
             else GLAUNCH(K_WNLA_ROUND, k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         }
     }
-    GLAUNCH(K_WNLA_FINAL_SCALARS, k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    GLAUNCH(K_WNLA_FINAL_SCALARS, launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s));
     if (!rlc_seed) {
         if (fb_one_lane) GLAUNCH(K_WNLA_MSM, k_wnla_msm_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(w));
         else GLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
@@ -593,7 +623,7 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
             else k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
         }
     }
-    k_wnla_final_scalars<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s);
     k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
     k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);

@@ -135,6 +135,7 @@ struct bppp_ctx {
     bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
     bool generic_slow_rounds = false, no_lane_groups = false, no_small = false, no_split = false, generic_u64_shape = false;
+    int generic_lane_group = 0;                         // BPPP_GENERIC_LANE_GROUP = 2 | 4: that many lanes per instance in the generic verifiers' grouped kernels at any size (tests)
     int next_overlap = -1;   // diagnostic BPPP_NEXT_OVERLAP: the variable-base next commitment on the helper stream always (1) / never (0)
     int tail_beside = -1;     // diagnostic BPPP_TAIL_BESIDE: the last round's sum beside the final fixed-base sum always (1) / never (0)
     int tables_beside = -1;   // diagnostic BPPP_TABLES_BESIDE: the one-lane table kernel beside phase 1 always (1) / never (0); unset = where the lane kernels are a lone wavefront per SIMD

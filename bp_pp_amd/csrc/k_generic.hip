@@ -44,6 +44,18 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) wnla_verify_final_scalars(w, t);
 }
+// 2^lg wavefronts per 64 instances, for batches that leave SIMDs empty with one: block b takes part b mod 2^lg of instances
+// 64 (b >> lg) ..., so a wavefront's accesses stay as coalesced as the one-part kernel's and the part index is uniform in it; every
+// part builds its own eighth (quarter, half) of the coefficient tables and the generator scalars that read it, k_wnla_final_scalars_join
+// adds the shares of v
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars_grp(WnlaWs w, int lg) {
+    const size_t t = (size_t)(blockIdx.x >> lg) * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_final_scalars_part(w, t, (int)(blockIdx.x & ((1u << lg) - 1)), lg);
+}
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars_join(WnlaWs w, int lg) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) wnla_final_scalars_join(w, t, lg);
+}
 // NL lanes per instance: 8, or ONE from the size at which one lane per instance fills every SIMD twice over (as in the u64 verifier's
 // fixed-base kernels: the lane then walks each scalar's windows in order -- the recoded scalar is a shift register, the window's base
 // address an increment -- and no tree of complete additions joins lane sums)
@@ -282,6 +294,17 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_f
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var(RecipWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) recip_c0_var(w, t);
+}
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_recip_c0_tables(RecipWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) recip_c0_tables(w, t);
+}
+// the sum on lane groups (2 or 4 lanes per instance), for batches that under-fill the chip; needs the fast path's tables
+__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var_grp(RecipWs w, int group) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g / (size_t)group;
+    if (t >= w.N) return;
+    recip_c0_var(w, t, (int)(g % (size_t)group), group);
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_finish(RecipWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;

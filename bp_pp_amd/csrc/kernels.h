@@ -175,6 +175,8 @@ __global__ __launch_bounds__(64) void k_wnla_msm_flagged(bppp::WnlaWs w, bppp::R
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm_flagged_dense(bppp::WnlaWs w, bppp::RlcWs r);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept_flagged(bppp::WnlaWs w, bppp::RlcWs r);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars(bppp::WnlaWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars_grp(bppp::WnlaWs w, int lg);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars_join(bppp::WnlaWs w, int lg);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(bppp::WnlaWs w, int commit_mode);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm_l1(bppp::WnlaWs w);               // one lane per instance (full batches)
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed_l1(bppp::RecipWs w);
@@ -205,6 +207,8 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_finish(bppp::CircuitW
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1(bppp::RecipWs w);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed(bppp::RecipWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var(bppp::RecipWs w);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_recip_c0_tables(bppp::RecipWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var_grp(bppp::RecipWs w, int group);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_finish(bppp::RecipWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_bkt_prepare(bppp::BucketWs w);
 __global__ __launch_bounds__(256) void k_bkt_accumulate(bppp::BucketWs w);

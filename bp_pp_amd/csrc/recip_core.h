@@ -29,6 +29,11 @@ struct RecipWs {
     u32* pfix;                       // [30][N]
     u32* inv;                        // [np * 8][N]: (e + j)^-1
     pt_slot* straus;                 // [N][5][9]
+    // fast variable-base path (as the WNLA rounds': wnla_core.h): window tables of the five points, slots atab_first .. + 5 x 16 of the
+    // WNLA stage's table buffer (entry-major, atab_of); null = the Jacobian-table Straus sum on `straus`
+    apt_packed* atab;
+    u32* tscr;
+    int atab_first;
     // outputs for the WNLA stage (C-ABI layouts)
     uint8_t* wn_commit;              // N x 64
     uint8_t* wn_c;                   // N x NH x 32
@@ -188,21 +193,47 @@ HD void recip_phase1(const RecipWs& w, size_t t) {
 HD void recip_c0_fixed_ranges(FbRanges& rg, const RecipWs& w) { fb_ranges_one(rg, 0, 0, 1 + w.nd); }
 HD void recip_c0_fixed_store(const RecipWs& w, size_t t, const pt& total) { ws_st_pt(w.pfix, w.N, t, total); }
 // C0 variable-base half + sum -> affine C0 for the WNLA stage (which hashes it first thing, wnla.rs:88)
-HD void recip_c0_var(const RecipWs& w, size_t t) {
+// window tables of c_s, c_o, c_l, c_r, V + r (fast path; one inversion per instance)
+HD void recip_c0_tables(const RecipWs& w, size_t t) {
+    affine_tables_build(atab_of(w.atab, w.N, t) + w.atab_first, w.tscr, w.pts, w.N, t, 5);
+}
+// group_lane >= 0: one of group_size (2 or 4) consecutive lanes that all run the sum for instance t (verify_core.h: straus_affine_g4)
+HD void recip_c0_var(const RecipWs& w, size_t t, int group_lane = -1, int group_size = 4) {
     const size_t N = w.N;
-    pt_slot* tbl = w.straus + t * (5 * BPPP_STRAUS_ENTRIES);
-    glv_split rs[5];
-#pragma nounroll
-    for (int j = 0; j < 5; j++) {
-        apt P;
-        ws_ld_apt(P, w.pts, N, t, j);
-        straus_build_table(tbl + j * BPPP_STRAUS_ENTRIES, P);
-        sc k;
-        ws_ld8(k.v, w.sc0, N, t, 1 + w.nd + j);
-        glv_decompose(rs[j], k);
-    }
     pt acc;
-    straus_msm_glv(acc, tbl, rs, 5);
+    if (w.atab) {
+        const int pslot[5] = {0, 1, 2, 3, 4};
+        glv_words<5> g;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            sc k;
+            ws_ld8(k.v, w.sc0, N, t, 1 + w.nd + j);
+            glv_split sp;
+            glv_decompose(sp, k);
+            glv_words_set<5>(g, j, sp);
+        }
+        const atab_ref tab = atab_of(w.atab, N, t) + w.atab_first;
+#if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
+        if (group_lane >= 0 && group_size == 4) straus_affine_g4<5, 4>(acc, tab, pslot, g, group_lane);
+        else if (group_lane >= 0) straus_affine_g4<5, 2>(acc, tab, pslot, g, group_lane);
+        else
+#endif
+            straus_affine<5>(acc, tab, pslot, g);
+        (void)group_lane; (void)group_size;
+    } else {
+        pt_slot* tbl = w.straus + t * (5 * BPPP_STRAUS_ENTRIES);
+        glv_split rs[5];
+#pragma nounroll
+        for (int j = 0; j < 5; j++) {
+            apt P;
+            ws_ld_apt(P, w.pts, N, t, j);
+            straus_build_table(tbl + j * BPPP_STRAUS_ENTRIES, P);
+            sc k;
+            ws_ld8(k.v, w.sc0, N, t, 1 + w.nd + j);
+            glv_decompose(rs[j], k);
+        }
+        straus_msm_glv(acc, tbl, rs, 5);
+    }
     ws_st_pt(w.acc, N, t, acc);
 }
 HD void recip_c0_finish(const RecipWs& w, size_t t) {

@@ -180,83 +180,140 @@ HD void wnla_verify_round(const WnlaWs& w, size_t t, int k, int group_lane = -1,
     w.status[t] = status;
 }
 // ---- verify: base case scalars (wnla.rs:80-82 with :66-72), generators unrolled
-HD void wnla_verify_final_scalars(const WnlaWs& w, size_t t) {
+// One of 2^lg parts of instance t (lg = 0: the whole instance).  Part q owns the coefficient-table indices whose top lg bits are q
+// -- it starts its subtree at the product of those bits' factors, so no part reads what another wrote -- and with them every
+// generator i whose low `rounds` bits fall in its range; its share of v is left in the table for wnla_final_scalars_join
+// (arithmetic mod n: the order of the additions and of the factors does not show in the result).
+HD void wnla_final_scalars_part(const WnlaWs& w, size_t t, int q, int lg) {
     const size_t N = w.N;
     const int k = w.rounds;
-    const int T = 1 << k;
-    int32_t status = w.status[t];
+    const int T = 1 << k, kl = k - lg, Tl = 1 << kl, B = q << kl;
     sc rho, mu, one, zero, t1;
     sc_set_u32(one, 1);
     sc_set_u32(zero, 0);
     bool ok = sc_from_be(rho, w.rho + 32 * t);
     ok &= sc_from_be(mu, w.mu + 32 * t);
     // coefficient tables over the low k index bits: ch[b] = prod_{bit t of b} y_{t+1}; cg[b] = prod_t (bit ? y_{t+1} : rho_{t+1})
-    ws_st8(w.tab, N, t, 0, one.v);
-    ws_st8(w.tab, N, t, T, one.v);
+    sc pch = one, pcg = one;
     sc rt = rho, mt = mu;    // rho_{t+1}, mu_{t+1}
+    if (lg > 0) {
+#pragma nounroll
+        for (int r = 0; r < k; r++) {
+            if (r >= kl) {
+                sc y;
+                ws_ld8(y.v, w.ys, N, t, r);
+                const bool bit = (q >> (r - kl)) & 1;
+                sc_mul(t1, pch, y);
+                if (bit) pch = t1;
+                sc f = rt;
+                if (bit) f = y;
+                sc_mul(pcg, pcg, f);
+            }
+            rt = mt;
+            sc_mul(mt, mt, mt);
+        }
+        rt = rho; mt = mu;
+    }
+    ws_st8(w.tab, N, t, B, pch.v);
+    ws_st8(w.tab, N, t, T + B, pcg.v);
 #pragma nounroll
     for (int r = 0; r < k; r++) {
-        sc y;
-        ws_ld8(y.v, w.ys, N, t, r);
-        const int half = 1 << r;
+        if (r < kl) {
+            sc y;
+            ws_ld8(y.v, w.ys, N, t, r);
+            const int half = 1 << r;
 #pragma nounroll
-        for (int b = 0; b < half; b++) {
-            sc ch, cg;
-            ws_ld8(ch.v, w.tab, N, t, b);
-            ws_ld8(cg.v, w.tab, N, t, T + b);
-            sc_mul(t1, ch, y);
-            ws_st8(w.tab, N, t, b + half, t1.v);
-            sc_mul(t1, cg, y);
-            ws_st8(w.tab, N, t, T + b + half, t1.v);
-            sc_mul(t1, cg, rt);
-            ws_st8(w.tab, N, t, T + b, t1.v);
+            for (int b = B; b < B + half; b++) {
+                sc ch, cg;
+                ws_ld8(ch.v, w.tab, N, t, b);
+                ws_ld8(cg.v, w.tab, N, t, T + b);
+                sc_mul(t1, ch, y);
+                ws_st8(w.tab, N, t, b + half, t1.v);
+                sc_mul(t1, cg, y);
+                ws_st8(w.tab, N, t, T + b + half, t1.v);
+                sc_mul(t1, cg, rt);
+                ws_st8(w.tab, N, t, T + b, t1.v);
+            }
         }
         rt = mt;                     // wnla.rs:109-110: rho <- mu, mu <- mu^2
         sc_mul(mt, mt, mt);
     }
     const sc mu_fin = mt;
     // v = <c', l> + sum_j n_j^2 mu_fin^(j+1);  c'_j = sum_{i >> k == j} c_i ch(i)
-    sc v, mp = mu_fin;
+    sc v;
     sc_set_u32(v, 0);
+    if (q == 0) {
+        sc mp = mu_fin;
 #pragma nounroll
-    for (int j = 0; j < w.nn; j++) {
-        sc nj;
-        ok &= sc_from_be(nj, w.proof_n + (size_t)t * w.stride_n + (size_t)j * 32);
-        sc_mul(t1, nj, nj); sc_mul(t1, t1, mp); sc_add(v, v, t1);
-        sc_mul(mp, mp, mu_fin);
+        for (int j = 0; j < w.nn; j++) {
+            sc nj;
+            ok &= sc_from_be(nj, w.proof_n + (size_t)t * w.stride_n + (size_t)j * 32);
+            sc_mul(t1, nj, nj); sc_mul(t1, t1, mp); sc_add(v, v, t1);
+            sc_mul(mp, mp, mu_fin);
+        }
+        // proof.l entries are validated even when they multiply nothing
+#pragma nounroll
+        for (int j = 0; j < w.nl; j++) { sc lj; ok &= sc_from_be(lj, w.proof_l + (size_t)t * w.stride_l + (size_t)j * 32); }
     }
-    const int nlf = (int)wnla_ceil_shift((size_t)w.nh, k), nnf = (int)wnla_ceil_shift((size_t)w.ng, k);
+    const int nnf = (int)wnla_ceil_shift((size_t)w.ng, k);
 #pragma nounroll
-    for (int i = 0; i < w.nh; i++) {
-        const int j = i >> k;
-        sc ci, ch, lj, coef;
-        ok &= sc_from_be(ci, w.c + ((size_t)t * w.nh + i) * 32);
-        ws_ld8(ch.v, w.tab, N, t, i & (T - 1));
-        lj = zero;
+    for (int j = 0; (j << k) + B < w.nh; j++) {
+        sc lj = zero;
         if (j < w.nl) ok &= sc_from_be(lj, w.proof_l + (size_t)t * w.stride_l + (size_t)j * 32);
-        sc_mul(coef, lj, ch);                       // scalar of h_i
-        ws_st8(w.msc, N, t, 1 + w.ng + i, coef.v);
-        sc_mul(t1, ci, coef);                       // c_i ch(i) l_j
-        sc_add(v, v, t1);
-    }
-    (void)nlf;
 #pragma nounroll
-    for (int i = 0; i < w.ng; i++) {
-        const int j = i >> k;
-        sc cg, nj, coef;
-        ws_ld8(cg.v, w.tab, N, t, T + (i & (T - 1)));
-        nj = zero;
+        for (int b = B; b < B + Tl; b++) {
+            const int i = (j << k) + b;
+            if (i >= w.nh) break;
+            sc ci, ch, coef;
+            ok &= sc_from_be(ci, w.c + ((size_t)t * w.nh + i) * 32);
+            ws_ld8(ch.v, w.tab, N, t, b);
+            sc_mul(coef, lj, ch);                       // scalar of h_i
+            ws_st8(w.msc, N, t, 1 + w.ng + i, coef.v);
+            sc_mul(t1, ci, coef);                       // c_i ch(i) l_j
+            sc_add(v, v, t1);
+        }
+    }
+#pragma nounroll
+    for (int j = 0; (j << k) + B < w.ng; j++) {
+        sc nj = zero;
         if (j < w.nn && j < nnf) ok &= sc_from_be(nj, w.proof_n + (size_t)t * w.stride_n + (size_t)j * 32);
-        sc_mul(coef, nj, cg);
-        ws_st8(w.msc, N, t, 1 + i, coef.v);
-    }
-    // proof.l entries are validated even when they multiply nothing
 #pragma nounroll
-    for (int j = 0; j < w.nl; j++) { sc lj; ok &= sc_from_be(lj, w.proof_l + (size_t)t * w.stride_l + (size_t)j * 32); }
-    if (!ok) status |= ST_BAD_ENCODING;
-    ws_st8(w.msc, N, t, 0, v.v);
-    w.status[t] = status;
+        for (int b = B; b < B + Tl; b++) {
+            const int i = (j << k) + b;
+            if (i >= w.ng) break;
+            sc cg, coef;
+            ws_ld8(cg.v, w.tab, N, t, T + b);
+            sc_mul(coef, nj, cg);
+            ws_st8(w.msc, N, t, 1 + i, coef.v);
+        }
+    }
+    // the lane's share of v goes where its part of the ch table began (read for the last time above); the flag by OR
+    ws_st8(w.tab, N, t, B, v.v);
+    if (!ok) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr((int*)&w.status[t], (int)ST_BAD_ENCODING);
+#else
+        w.status[t] |= ST_BAD_ENCODING;
+#endif
+    }
 }
+HD void wnla_final_scalars_join(const WnlaWs& w, size_t t, int lg) {
+    const int kl = w.rounds - lg;
+    sc v, o;
+    ws_ld8(v.v, w.tab, w.N, t, 0);
+#pragma nounroll
+    for (int q = 1; q < (1 << lg); q++) {
+        ws_ld8(o.v, w.tab, w.N, t, q << kl);
+        sc_add(v, v, o);
+    }
+    ws_st8(w.msc, w.N, t, 0, v.v);
+}
+HD void wnla_verify_final_scalars(const WnlaWs& w, size_t t) {
+    wnla_final_scalars_part(w, t, 0, 0);
+    wnla_final_scalars_join(w, t, 0);
+}
+// the lanes one instance's final scalars are dealt to (a power of two <= 8 that the table has room for; 1 = the whole instance)
+HD int wnla_final_scalars_lg(int rounds, int want_lg) { return want_lg < rounds ? want_lg : (rounds > 0 ? rounds - 1 : 0); }
 HD void wnla_msm_ranges(FbRanges& rg, const WnlaWs& w) { fb_ranges_one(rg, 0, 0, 1 + w.ng + w.nh); }
 HD void wnla_verify_store(const WnlaWs& w, size_t t, const pt& rhs) { ws_st_pt(w.pfix, w.N, t, rhs); }
 HD void wnla_verify_accept(const WnlaWs& w, size_t t) {

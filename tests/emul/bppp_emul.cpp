@@ -453,6 +453,15 @@ static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* labe
     for (size_t t = 0; t < n; t++) verify_export_state(ws, t);
     return 0;
 }
+// the final scalars in 2^lg parts per instance (k_wnla_final_scalars_grp): the parts computed one after the other and joined
+static int g_final_scalars_lg = 0;
+void emul_set_final_scalars_lg(int lg) { g_final_scalars_lg = lg; }
+static void emul_final_scalars(const WnlaWs& w, size_t t) {
+    const int lg = wnla_final_scalars_lg(w.rounds, g_final_scalars_lg);
+    if (lg == 0) { wnla_verify_final_scalars(w, t); return; }
+    for (int q = (1 << lg) - 1; q >= 0; q--) wnla_final_scalars_part(w, t, q, lg);      // any order: no part reads another's tables
+    wnla_final_scalars_join(w, t, lg);
+}
 static int g_rlc_chunk = 8;
 void emul_set_rlc_chunk(int c) { g_rlc_chunk = c; }
 // the RLC mode's choice of group sizes from the previous call's reject rate (plan_core.h: plan_rlc)
@@ -668,10 +677,10 @@ void emul_set_generic_slow_rounds(int on) { g_generic_slow_rounds = on; }
 struct FastRounds {
     std::vector<apt_packed> atab;
     std::vector<u32> tscr, rpts;
-    void attach(WnlaWs& w, size_t n, int rounds) {
+    void attach(WnlaWs& w, size_t n, int rounds, size_t extra_points = 0) {
         w.atab = nullptr; w.tscr = nullptr; w.rpts = nullptr;
         if (rounds == 0 || g_generic_slow_rounds) return;
-        const size_t np = 2 * (size_t)rounds;
+        const size_t np = 2 * (size_t)rounds + extra_points;
         atab.assign(np * 16 * n, apt_packed());
         tscr.assign(14 * np * 10 * n, 0u);
         rpts.assign(np * 16 * n, 0u);
@@ -731,7 +740,7 @@ int emul_wnla_run(int commit, const uint8_t* table, int W, int ng, int nh, const
         if (w.atab) for (size_t t = 0; t < n; t++) wnla_verify_tables(w, t);
         for (int k = 1; k <= rounds; k++)
             for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, k);
-        for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);
+        for (size_t t = 0; t < n; t++) emul_final_scalars(w, t);
         msm();
         for (size_t t = 0; t < n; t++) wnla_verify_accept(w, t);
         for (size_t t = 0; t < n; t++) tio_export(w.tio, w.base, w.tstate, n, w.status, t);
@@ -774,15 +783,17 @@ int emul_recip_verify(const uint8_t* table, int W, int NG, int NH, int nd, int n
         fb_sum_serial(a, r.fb, t, r.sc0, rg);
         recip_c0_fixed_store(r, t, a);
     }
+    FastRounds fastr;
+    fastr.attach(w, n, rounds, 5);                    // as recip_verify_device_impl: the five C0 points' tables behind the round points'
+    r.atab = w.atab; r.tscr = w.tscr; r.atab_first = 2 * rounds * 16;
+    if (r.atab) for (size_t t = 0; t < n; t++) recip_c0_tables(r, t);
     for (size_t t = 0; t < n; t++) recip_c0_var(r, t);
     for (size_t t = 0; t < n; t++) recip_c0_finish(r, t);
-    FastRounds fastr;
-    fastr.attach(w, n, rounds);
     for (size_t t = 0; t < n; t++) wnla_verify_begin(w, t);
     if (w.atab) for (size_t t = 0; t < n; t++) wnla_verify_tables(w, t);
     for (int k = 1; k <= rounds; k++)
         for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, k);
-    for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);
+    for (size_t t = 0; t < n; t++) emul_final_scalars(w, t);
     const uint8_t* seed = g_rlc_seed;
     uint8_t* flags_out = g_rlc_flags;
     g_rlc_seed = nullptr; g_rlc_flags = nullptr;
@@ -902,7 +913,7 @@ int emul_circuit_verify(const uint8_t* table, int W, int NG, int NH, const size_
     if (w.atab) for (size_t t = 0; t < n; t++) wnla_verify_tables(w, t);
     for (int kk = 1; kk <= rounds; kk++)
         for (size_t t = 0; t < n; t++) wnla_verify_round(w, t, kk);
-    for (size_t t = 0; t < n; t++) wnla_verify_final_scalars(w, t);
+    for (size_t t = 0; t < n; t++) emul_final_scalars(w, t);
     for (size_t t = 0; t < n; t++) {
         pt a;
         FbRanges rg;

@@ -227,3 +227,48 @@ def test_generic_reciprocal_fuzz_vs_oracle(nd, npp):
         assert acc[::12].all() and n_flag > 20 and int(acc.sum()) == B // 12
     finally:
         proto.close()
+
+
+@pytest.mark.parametrize("group", ["0", "2", "4", "none"])
+def test_c0_points_that_meet_in_the_window_sum(group, monkeypatch):
+    """tests/test_recip_emul.py's case of the same name on the device, where the variable-base part of C0 runs on one, two or four
+    lanes per instance (BPPP_GENERIC_LANE_GROUP forces the group size a batch this small would not get; "none": BPPP_NO_LANE_GROUPS)
+    and the final scalars in 1, 2 or 8 parts: equal, opposite and identity points among the proof's commitments and V + r = identity
+    get the oracle's verdicts."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import recip_cases
+    from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
+    monkeypatch.delenv("BPPP_GENERIC_LANE_GROUP", raising=False)
+    monkeypatch.delenv("BPPP_NO_LANE_GROUPS", raising=False)
+    if group == "none":
+        monkeypatch.setenv("BPPP_NO_LANE_GROUPS", "1")
+    elif group != "0":
+        monkeypatch.setenv("BPPP_GENERIC_LANE_GROUP", group)
+    nd, npp, B = 12, 10, 71
+    case = recip_cases.make(nd, npp, B=B)
+    P, com = case["proofs"].copy(), case["commitments"].copy()
+    r = case["rounds"]
+    p = 2**256 - 2**32 - 977
+
+    def neg(xy):
+        y = int.from_bytes(bytes(xy[32:]), "big")
+        return np.frombuffer(bytes(xy[:32]) + ((p - y) % p).to_bytes(32, "big"), np.uint8)
+
+    P[1, 64:128] = P[1, 0:64]                      # c_r := c_l
+    P[2, 64:128] = neg(P[2, 0:64])                 # c_r := -c_l
+    P[3, 192:256] = 0                              # c_s := identity
+    com[4] = neg(P[4, 256 + 128 * r:320 + 128 * r])  # V := -r, so V + r is the identity
+    P[5, 128:192] = P[5, 0:64]                     # c_o := c_l
+    P[6, 0:256] = np.tile(P[6, 192:256], 4)        # all four the same point
+    P[70, -64:-32] = 0xFF                          # a final l the last part of the final scalars reads: not a canonical scalar
+    proto = ReciprocalRangeProofProtocol(nd, npp, case["g"], case["gv"], case["hv"], case["gv_"], case["hv_"], device=0, fb_window_bits=8)
+    try:
+        acc, st = proto.verify_batch(case["label"], com, P, case["rounds"], case["nl"], case["nn"])
+        for b in list(range(8)) + [69, 70]:
+            rc = recip_cases.oracle_verify(case, bytes(com[b]), bytes(P[b]))
+            assert int(acc[b]) == (1 if rc == 1 else 0) and (int(st[b]) != 0) == (rc < 0), (b, rc)
+        assert acc.tolist() == [1] + [0] * 6 + [1] * 63 + [0] and st[70] != 0 and not st[:70].any()
+    finally:
+        proto.close()

@@ -176,3 +176,43 @@ def test_fast_and_projective_round_paths_agree():
     for b in range(B):
         rc = recip_cases.oracle_verify(case, bytes(com[b]), bytes(P[b]))
         assert int(res[0][0][b]) == (1 if rc == 1 else 0) and (int(res[0][1][b]) != 0) == (rc < 0)
+
+
+def test_c0_points_that_meet_in_the_window_sum():
+    """The variable-base part of C0 runs on affine window tables (recip_c0_tables / recip_c0_var) with incomplete additions and a
+    complete re-run when one of them met its exception: equal, opposite and identity points among c_l, c_r, c_o, c_s and a commitment
+    that cancels the proof's r (V + r = identity) give the verdicts of the projective path and of the oracle."""
+    L = load()
+    nd, npp, B = 12, 10, 7
+    case = recip_cases.make(nd, npp, B=B)
+    W = 4
+    gens = case["g"] + b"".join(case["gv"]) + b"".join(case["gv_"]) + b"".join(case["hv"]) + b"".join(case["hv_"])
+    NB = 1 + case["NG"] + case["NH"]
+    tab = np.zeros(L.emul_fb_table_entries(NB, W) * 64, dtype=np.uint8)
+    assert L.emul_fb_build(gens, NB, W, tab.ctypes.data) == 0
+    P, com = case["proofs"].copy(), case["commitments"].copy()
+    r = case["rounds"]
+    p = 2**256 - 2**32 - 977
+
+    def neg(xy):
+        y = int.from_bytes(bytes(xy[32:]), "big")
+        return np.frombuffer(bytes(xy[:32]) + ((p - y) % p).to_bytes(32, "big"), np.uint8)
+
+    P[1, 64:128] = P[1, 0:64]                      # c_r := c_l
+    P[2, 64:128] = neg(P[2, 0:64])                 # c_r := -c_l
+    P[3, 192:256] = 0                              # c_s := identity
+    com[4] = neg(P[4, 256 + 128 * r:320 + 128 * r])  # V := -r, so V + r is the identity
+    P[5, 128:192] = P[5, 0:64]                     # c_o := c_l
+    P[6, 0:256] = np.tile(P[6, 192:256], 4)        # all four the same point
+    res = []
+    for slow in (0, 1):
+        L.emul_set_generic_slow_rounds(slow)
+        acc, st = np.zeros(B, np.uint8), np.zeros(B, np.int32)
+        L.emul_recip_verify(tab.ctypes.data, W, case["NG"], case["NH"], nd, npp, case["label"], len(case["label"]), B, com.ctypes.data,
+                            P.ctypes.data, r, case["nl"], case["nn"], acc.ctypes.data, st.ctypes.data)
+        res.append((acc.copy(), st.copy()))
+    L.emul_set_generic_slow_rounds(0)
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
+    assert res[0][0].tolist() == [1, 0, 0, 0, 0, 0, 0] and not res[0][1].any()
+    for b in range(B):
+        assert recip_cases.oracle_verify(case, bytes(com[b]), bytes(P[b])) == int(res[0][0][b])

@@ -53,6 +53,32 @@ def test_commit_and_verify_vs_oracle(ng, nh, musq):
     assert acc[0] == 0 and acc[2] == 0
 
 
+@pytest.mark.parametrize("lg", [1, 2, 3])
+@pytest.mark.parametrize("ng,nh", [(16, 32), (3, 5), (7, 9), (1, 2), (4, 4)])
+def test_final_scalars_on_lane_groups(ng, nh, lg):
+    """k_wnla_final_scalars_grp's arithmetic: 2^lg lanes per instance, each with its own part of the coefficient tables and the
+    generators that read it -- accept bits and statuses equal the one-lane form's (and so the oracle's), also with a tampered l,
+    an out-of-range scalar in each of l, n, c (status: bad encoding) and lengths that leave lanes without any generator."""
+    L = load()
+    case = wnla_cases.make(ng, nh, B=4)
+    tab, W = _table(L, case)
+    pl = case["proof_l"].copy(); pl[0, 0, 31] ^= 1
+    pl[1, -1] = 0xFF                                   # >= n: not a canonical scalar
+    pn = case["proof_n"].copy(); pn[2, 0] = 0xFF
+    c = case["c"].copy(); c[3, -1] = 0xFF
+    over = [dict(), dict(proof_l=pl), dict(proof_l=pl, proof_n=pn, c=c)]
+    try:
+        for o in over:
+            L.emul_set_final_scalars_lg(0)
+            _, acc0, st0 = _run(L, case, tab, W, commit=False, **o)
+            L.emul_set_final_scalars_lg(lg)
+            _, acc, st = _run(L, case, tab, W, commit=False, **o)
+            assert acc.tolist() == acc0.tolist() and st.tolist() == st0.tolist()
+        assert acc0.tolist() == [0, 0, 0, 0] and st0[1] != 0 and st0[2] != 0 and st0[3] != 0
+    finally:
+        L.emul_set_final_scalars_lg(0)
+
+
 def test_length_quirks_match_reference():
     """proof.l / proof.n longer than the folded generator vectors: extra l entries multiply identities, extra n entries
     still enter |n|^2_mu (wnla.rs:67, util.rs:24-26) -- so an appended zero is harmless and an appended non-zero n is not."""
