@@ -24,6 +24,7 @@ static void read_diagnostics(bppp_ctx* c) {
     if (const char* e = std::getenv("BPPP_LANE4_MAX")) c->lane4_max = std::atol(e);
     if (const char* e = std::getenv("BPPP_TAIL_BESIDE")) c->tail_beside = std::atoi(e);
     if (const char* e = std::getenv("BPPP_TABLES_BESIDE")) c->tables_beside = std::atoi(e);
+    if (const char* e = std::getenv("BPPP_SHARED_INV")) c->shared_inv = std::atoi(e);
     if (const char* e = std::getenv("BPPP_NEXT_MSM_MAX")) c->next_msm_max = std::atol(e);
     c->generic_u64_shape = std::getenv("BPPP_GENERIC_U64_SHAPE") != nullptr;     // reciprocal (16, 16) calls stay on the generic kernels
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // projective tables + complete additions

@@ -13,8 +13,21 @@ static bppp_host::PlanKnobs knobs_of(const bppp_ctx* c) {
     k.n_simds = c->n_simds;
     k.no_small = c->no_small; k.no_lane_groups = c->no_lane_groups; k.no_split = c->no_split; k.timing = c->timing;
     k.tables_beside = c->tables_beside; k.tail_beside = c->tail_beside; k.fb_one_lane_mode = c->fb_one_lane_mode; k.next_overlap = c->next_overlap;
+    k.shared_inv = c->shared_inv;
     k.next_msm_max = c->next_msm_max; k.lane_forms_max = c->lane_forms_max; k.lane4_max = c->lane4_max; k.scal_parts_max = c->scal_parts_max;
     return k;
+}
+
+// 1 / in[t] for all t < n, one inversion per G elements (k_verify_misc.hip)
+static void launch_fe_batch_inv(int G, const u32* in, u32* out, size_t n, hipStream_t s) {
+    const size_t lanes = (n + (size_t)G - 1) / (size_t)G;
+    const unsigned b = (unsigned)((lanes + BPPP_BLOCK - 1) / BPPP_BLOCK);
+    switch (G) {
+    case 16: k_fe_batch_inv16<<<b, BPPP_BLOCK, 0, s>>>(in, out, n); break;
+    case 8: k_fe_batch_inv8<<<b, BPPP_BLOCK, 0, s>>>(in, out, n); break;
+    case 4: k_fe_batch_inv4<<<b, BPPP_BLOCK, 0, s>>>(in, out, n); break;
+    default: k_fe_batch_inv2<<<b, BPPP_BLOCK, 0, s>>>(in, out, n); break;
+    }
 }
 
 extern "C" {
@@ -71,6 +84,7 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     carve(c, ws, n);
     ws.atab = c->d_atab;
     ws.tscr = c->d_tscr;
+    if (plan.shared_inv) ws.zinv = c->d_zinv;
     RlcWs rl;
     std::memset(&rl, 0, sizeof rl);
     if (rlc_seed) {
@@ -152,7 +166,19 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     // with per-kernel timing on, the two halves run back to back so that the kernel times add up to the step (overlapped, each
     // half's events also cover the other's share of the SIMDs; the overlap itself buys nothing at 2 waves/SIMD: DESIGN.md 4)
     if (tables_aside || tables_beside) HIP_TRY(hipStreamWaitEvent(s, c->ev_tab, 0));
-    else LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+    else if (plan.shared_inv) {
+        LAUNCH(K_TABLES, {
+            k_verify_tables_pass0<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
+            launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s);
+            k_verify_tables_pass1<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
+            launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s);
+            k_verify_tables_pass2<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
+            launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s);
+            k_verify_tables_pass3<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
+            launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s);
+            k_verify_tables_pass4<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
+        });
+    } else LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
     // the two fixed-base sums: a wavefront per sum in a small call, 8 lanes per proof, or one from the size at which one lane per proof
@@ -192,7 +218,16 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         case bppp_host::R_G4: LAUNCH(K_ROUND, k_verify_round_g4<<<g4_blocks, BPPP_BLOCK, 0, s>>>(ws, k)); break;
         case bppp_host::R_G2: LAUNCH(K_ROUND, k_verify_round_g2<<<(unsigned)((2 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws, k)); break;
         case bppp_host::R_SMALL: LAUNCH(K_ROUND, k_verify_round_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k)); break;
-        default: LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k)); break;
+        default:
+            if (plan.shared_inv) {
+                // 1 / Z of C_{k-1} for every proof from n / G inversions (round 1: after the halves of C0 are added)
+                LAUNCH(K_ROUND, {
+                    if (k == 1) k_verify_c0_join<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
+                    launch_fe_batch_inv(plan.shared_inv, ws.acc + 20 * n, ws.zinv, n, s);
+                    k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k);
+                });
+            } else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
+            break;
         }
     }
     // the 49 unrolled generator coefficients: sixteen lanes per proof while that still leaves the chip under-filled

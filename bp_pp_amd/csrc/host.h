@@ -138,6 +138,8 @@ struct bppp_ctx {
     int generic_lane_group = 0;                         // BPPP_GENERIC_LANE_GROUP = 2 | 4: that many lanes per instance in the generic verifiers' grouped kernels at any size (tests)
     int next_overlap = -1;   // diagnostic BPPP_NEXT_OVERLAP: the variable-base next commitment on the helper stream always (1) / never (0)
     int tail_beside = -1;     // diagnostic BPPP_TAIL_BESIDE: the last round's sum beside the final fixed-base sum always (1) / never (0)
+    u32* d_zinv = nullptr;    // [10][n] of the current call inside d_ws (carve)
+    int shared_inv = -1;      // diagnostic BPPP_SHARED_INV: proofs per shared field inversion in the one-lane verify kernels (0 = none, 2 4 8 16); unset = by batch size (plan_core.h)
     int tables_beside = -1;   // diagnostic BPPP_TABLES_BESIDE: the one-lane table kernel beside phase 1 always (1) / never (0); unset = where the lane kernels are a lone wavefront per SIMD
     long scal_parts_max = -1;   // diagnostic BPPP_SCAL_PARTS_MAX: largest prove call whose round scalars go out as four workgroups per 64 values
     long lane4_max = -1;   // diagnostic BPPP_LANE4_MAX: largest prove call on the four-lane stage kernels
@@ -194,7 +196,7 @@ static inline void quiesce(bppp_ctx* c) {
     (void)hipGetLastError();
 }
 
-static const size_t WS_WORDS_PER_PROOF = 52 + 80 + 176 + 200 + 208 + 24 + 30 + 30 + 392;
+static const size_t WS_WORDS_PER_PROOF = 52 + 80 + 176 + 200 + 208 + 24 + 30 + 30 + 392 + 10;
 
 static inline int ensure_capacity(bppp_ctx* c, size_t n) {
     if (n <= c->cap) return BPPP_OK;
@@ -286,6 +288,7 @@ static inline void carve(bppp_ctx* c, VerifyWs& ws, size_t n) {
     ws.acc = p; p += 30 * n;
     ws.pfix = p; p += 30 * n;
     ws.fsc = p; p += 392 * n;
+    ws.zinv = nullptr; c->d_zinv = p; p += 10 * n;     // (handed to the kernels as ws.zinv by the calls whose plan shares inversions)
     ws.straus = c->d_straus;
     ws.fb_table = c->d_table;
     ws.fb_w = c->fb_w;

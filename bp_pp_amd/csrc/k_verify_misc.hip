@@ -110,3 +110,18 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_export_states(VerifyWs ws
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N) verify_export_state(ws, t);
 }
+
+// ---- shared inversions of the large-batch verify (plan_core.h: shared_inv): lane i inverts for proofs i, i + L, ... (L = ceil(N / G))
+#define BPPP_FE_BATCH_INV_KERNEL(G)                                                                                     \
+    __global__ __launch_bounds__(BPPP_BLOCK) void k_fe_batch_inv##G(const u32* in, u32* out, size_t N) {                 \
+        const size_t i = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;                                                  \
+        if (i < (N + G - 1) / G) fe_batch_inv_lane<G>(in, out, N, i);                                                    \
+    }
+BPPP_FE_BATCH_INV_KERNEL(2)
+BPPP_FE_BATCH_INV_KERNEL(4)
+BPPP_FE_BATCH_INV_KERNEL(8)
+BPPP_FE_BATCH_INV_KERNEL(16)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_join(VerifyWs ws) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < ws.N) verify_c0_join(ws, t);
+}

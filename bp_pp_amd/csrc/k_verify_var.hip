@@ -8,6 +8,17 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_ta
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N) verify_tables(ws, t);
 }
+// the build as five kernels with the inversions between them shared by G proofs each (plan_core.h: shared_inv; k_fe_batch_inv*)
+#define BPPP_TABLES_PASS_KERNEL(P)                                                                                      \
+    __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables_pass##P(VerifyWs ws) {          \
+        size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;                                                        \
+        if (t < ws.N) verify_tables_pass<P>(ws, t);                                                                      \
+    }
+BPPP_TABLES_PASS_KERNEL(0)
+BPPP_TABLES_PASS_KERNEL(1)
+BPPP_TABLES_PASS_KERNEL(2)
+BPPP_TABLES_PASS_KERNEL(3)
+BPPP_TABLES_PASS_KERNEL(4)
 // beside phase 1 on the helper stream (bppp_u64.hip: tables_beside): decodes the proof's points itself
 __global__ __launch_bounds__(BPPP_C0VAR_SMALL_BLOCK, 2) void k_verify_tables_own(VerifyWs ws) {      // (256 threads: see k_verify_phase1_wg4)
     size_t t = (size_t)blockIdx.x * BPPP_C0VAR_SMALL_BLOCK + threadIdx.x;

@@ -82,6 +82,16 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_g16(bppp::VerifyWs
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed_l1(bppp::VerifyWs ws);      // one lane per proof (full batches)
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_fe_batch_inv2(const bppp::u32* in, bppp::u32* out, size_t N);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_fe_batch_inv4(const bppp::u32* in, bppp::u32* out, size_t N);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_fe_batch_inv8(const bppp::u32* in, bppp::u32* out, size_t N);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_fe_batch_inv16(const bppp::u32* in, bppp::u32* out, size_t N);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_join(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables_pass0(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables_pass1(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables_pass2(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables_pass3(bppp::VerifyWs ws);
+__global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables_pass4(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_head_small(bppp::VerifyWs ws, int k);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_c0_var(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_LANE_MIN_WAVES) void k_verify_round(bppp::VerifyWs ws, int k);

@@ -32,6 +32,7 @@ struct PlanKnobs {
     bool no_small = false, no_lane_groups = false, no_split = false, timing = false;
     int tables_beside = -1, tail_beside = -1, fb_one_lane_mode = -1, next_overlap = -1;      // diagnostics: -1 = by size
     long next_msm_max = -1, lane_forms_max = -1, lane4_max = -1, scal_parts_max = -1;       // diagnostics: -1 = by n_simds
+    int shared_inv = -1;         // diagnostics: proofs per shared inversion (0 none, 2 4 8 16) wherever the one-lane kernels run; -1 = by size
 };
 
 enum PlanTables { TABLES_INLINE = 0, TABLES_ASIDE, TABLES_BESIDE };        // on the main stream | lane-per-point kernel on the helper stream | one-lane kernel beside phase 1
@@ -49,9 +50,12 @@ struct VerifyPlan {
     bool tail_beside = false;    // round 4 as head + tail, final scalars and final sum on the helper stream
     bool final_scalars_g16 = false;
     size_t vtab_sets = 1;        // window-table sets per proof the call needs room for
+    int shared_inv = 0;          // G = 2, 4, 8, 16: the field inversions of the table build and of the rounds are taken once per G proofs by
+                                 // kernels of their own between the passes (verify_core.h: fe_batch_inv_lane); 0: every lane inverts for itself
     uint32_t code() const {
+        const uint32_t lg = shared_inv >= 16 ? 4 : shared_inv >= 8 ? 3 : shared_inv >= 4 ? 2 : shared_inv >= 2 ? 1 : 0;
         return (uint32_t)phase1 | (uint32_t)tables << 4 | (uint32_t)tparts << 8 | (uint32_t)fb << 12 | (uint32_t)c0var << 16 | (uint32_t)round << 20 |
-               (uint32_t)(tail_beside ? 1 : 0) << 24 | (uint32_t)(small ? 1 : 0) << 25 | (uint32_t)(split ? 1 : 0) << 26;
+               (uint32_t)(tail_beside ? 1 : 0) << 24 | (uint32_t)(small ? 1 : 0) << 25 | (uint32_t)(split ? 1 : 0) << 26 | lg << 27;
     }
 };
 
@@ -81,6 +85,15 @@ inline VerifyPlan plan_verify(size_t n, const PlanKnobs& k, bool rlc) {
     const bool one_lane_rounds = !p.split && !grouped && !pairs;
     p.tail_beside = !rlc && !k.timing && one_lane_rounds && (k.tail_beside >= 0 ? k.tail_beside == 1 : (p.small && !k.no_split));
     p.final_scalars_g16 = p.split;
+    // Shared inversions: where the one-lane kernels run with four or more wavefronts per SIMD, a separate launch of n / G lanes that
+    // inverts for G proofs each replaces 8 of the 9 field inversions a proof costs (4 in the table build, 4 in the rounds).  Such a
+    // launch takes what ONE inversion takes (0.15 ms, a lone wavefront per SIMD) however many proofs there are, the inversions it
+    // replaces 0.33 ms per 2^20 proofs: 2^20 proofs 147.6 -> 144.8 ms, 2^19 75.8 -> 74.8, 2^18 38.0 -> 37.6, nothing at 2^17
+    // (profiles/r05/r05_q_ab_shared_inv.txt), so it starts at 256 S.
+    const bool one_lane_all = p.round == R_FULL && p.tables == TABLES_INLINE && p.c0var == C0V_FULL;
+    const int by_size = n >= 1024 * S ? 16 : n >= 256 * S ? 8 : 0;
+    const int want = k.shared_inv >= 0 ? k.shared_inv : by_size;
+    p.shared_inv = !one_lane_all ? 0 : want >= 16 ? 16 : want >= 8 ? 8 : want >= 4 ? 4 : want >= 2 ? 2 : 0;
     return p;
 }
 
@@ -176,9 +189,9 @@ inline int plan_describe(uint32_t code, bool prove, char* buf, size_t cap) {
     static const char* const SC[] = {"one", "parts", "wide"};
     auto pick = [](const char* const* t, size_t nt, uint32_t i) { return i < nt ? t[i] : "?"; };
     if (!prove)
-        return std::snprintf(buf, cap, "phase1=%s tables=%s/%u fb=%s c0var=%s round=%s tail_beside=%u small=%u split=%u", pick(P1, 4, code & 15),
+        return std::snprintf(buf, cap, "phase1=%s tables=%s/%u fb=%s c0var=%s round=%s tail_beside=%u small=%u split=%u shared_inv=%u", pick(P1, 4, code & 15),
                              pick(TB, 3, (code >> 4) & 15), (code >> 8) & 15, pick(FB, 4, (code >> 12) & 15), pick(CV, 5, (code >> 16) & 15),
-                             pick(RD, 6, (code >> 20) & 15), (code >> 24) & 1, (code >> 25) & 1, (code >> 26) & 1);
+                             pick(RD, 6, (code >> 20) & 15), (code >> 24) & 1, (code >> 25) & 1, (code >> 26) & 1, ((code >> 27) & 7) ? 1u << ((code >> 27) & 7) : 0u);
     return std::snprintf(buf, cap, "fb=%s fb4_from_jobs=%u stage=%s fold=%s scalars=%s next_by_msm=%u w2=%u overlap_next=%u next_g4=%u ct=%u",
                          pick(FB, 4, code & 15), (code >> 4) & 15, pick(ST, 6, (code >> 8) & 15), pick(ST, 6, (code >> 12) & 15), pick(SC, 3, (code >> 16) & 15),
                          (code >> 20) & 1, (code >> 21) & 1, (code >> 22) & 1, (code >> 23) & 1, (code >> 24) & 1);

@@ -65,6 +65,10 @@ struct VerifyWs {
     pt_slot* straus;             // [N][5][9]  (generic WNLA / reciprocal paths)
     apt_packed* atab;            // [13][2][8][N] (entry-major, see atab_of) affine multiples 1..8 of the 13 proof points, and of their GLV images (beta x, y)
     u32* tscr;                   // [BPPP_TSCR_FE * 10][N] scratch of verify_tables: running products of the slope denominators
+    u32* zinv;                   // [10][N] or null.  Non-null: the large-batch form with SHARED inversions -- a kernel that needs 1 / v of its
+                                 // proof finds it here, put there by fe_batch_inv_lane (one inversion per G proofs) from the v the kernel before
+                                 // left: the rounds' Z of C_{k-1}, the table build's running products (k_verify_tables_pass).  Null: every
+                                 // lane inverts for itself.
     const apt_packed* fb_table;  // [49][nwin][2^W - 1]
     int fb_w;                    // window bits: 4, 8 or 16
     const apt_packed* fb_table_hi;      // FbTable's second region (0 / null: none)
@@ -927,6 +931,40 @@ HD void ws_ld_fe(fe& a, const u32* base, size_t N, size_t t, int slot, int mag) 
     FE_SETMAG(a, mag);
     (void)mag;
 }
+// out[t] = 1 / in[t] (0 for 0, as fe_inv) for the G elements t = i, i + L, i + 2L, ... (L = ceil(N / G)) that lane i takes: their
+// product is inverted once and unwound (3 multiplications per element), so a batch of N pays N / G inversions instead of N.  in and
+// out are [10][N] limb arrays and may be the same one (a lane reads its G elements before it writes any; lanes share none).
+template <int G>
+HD void fe_batch_inv_lane(const u32* in, u32* out, size_t N, size_t i) {
+    const size_t L = (N + G - 1) / G;
+    fe z[G], pre[G], run, inv, one;
+    bool zero[G];
+    fe_set_u32(one, 1);
+    run = one;
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        const size_t t = i + (size_t)j * L;
+        z[j] = one;
+        zero[j] = true;
+        if (t < N) {
+            ws_ld_fe(z[j], in, N, t, 0, 2);
+            zero[j] = fe_is_zero(z[j]);
+            if (zero[j]) z[j] = one;
+        }
+        pre[j] = run;
+        fe_mul(run, run, z[j]);
+    }
+    fe_inv(inv, run);
+#pragma unroll
+    for (int j = G - 1; j >= 0; j--) {
+        const size_t t = i + (size_t)j * L;
+        fe o;
+        fe_mul(o, inv, pre[j]);
+        fe_mul(inv, inv, z[j]);
+        if (zero[j]) fe_set_u32(o, 0);
+        if (t < N) ws_st_fe(out, N, t, 0, o);
+    }
+}
 HD void glv_beta(fe& b) {
     const u32 BETA_W[8] = {0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u, 0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu};
     fe_from_w8(b, BETA_W);
@@ -1067,12 +1105,16 @@ HD void aff_pop_block(fe di[4], const fe d[4], const u32* tscr, size_t N, size_t
 // pts = the points in packed affine words [NP * 16][N], tscr = BPPP_TSCR_PER_POINT NP running products [.. * 10][N], tab = the
 // instance's table view.
 #define BPPP_TSCR_PER_POINT 5    // level 1: 1 (slots 0 .. NP, re-used by level 3: 1 block) | level 2: 2 | level 4: 2 blocks
-HD void affine_tables_build(const atab_ref tab, u32* tscr, const u32* pts, size_t N, size_t t, const int NP) {
+// The build in five passes with an inversion of `run` between them: the state that crosses a boundary is `run` going in and its inverse
+// coming out (tables, points and running products live in the workspace), so the passes are also kernels of their own with the
+// inversions shared between proofs (k_verify_tables_pass, fe_batch_inv_lane).
+HD void affine_tables_pass_a(const atab_ref tab, u32* tscr, const u32* pts, size_t N, size_t t, const int NP, fe& run) {
     const int L2 = NP, L4 = 3 * NP;          // running products: levels 1 and 3 share slots 0 .. NP, level 2 lives in NP .. 3 NP, level 4 in 3 NP .. 5 NP
-    (void)L4;
-    fe run, inv, beta, one, d, dinv;
+    (void)L2; (void)L4;
+    fe beta, one, d, dinv;
     fe_set_u32(one, 1);
     glv_beta(beta);
+    (void)d; (void)dinv;
     // ---- pass A (up): entry 1 of every table; level-1 denominators 2 y_P
     fe_set_u32(run, 1);
 #pragma nounroll
@@ -1085,7 +1127,14 @@ HD void affine_tables_build(const atab_ref tab, u32* tscr, const u32* pts, size_
         aff_den_dbl(d, a, pid, one);
         aff_push(tscr, N, t, p, run, d);
     }
-    fe_inv(inv, run);
+}
+HD void affine_tables_pass_b(const atab_ref tab, u32* tscr, const u32* pts, size_t N, size_t t, const int NP, fe inv, fe& run) {
+    const int L2 = NP, L4 = 3 * NP;          // running products: levels 1 and 3 share slots 0 .. NP, level 2 lives in NP .. 3 NP, level 4 in 3 NP .. 5 NP
+    (void)L2; (void)L4;
+    fe beta, one, d, dinv;
+    fe_set_u32(one, 1);
+    glv_beta(beta);
+    (void)d; (void)dinv;
     // ---- pass B (down): 2P; level-2 denominators x_2P - x_P (3P = 2P + P), 2 y_2P (4P)
     fe_set_u32(run, 1);
 #pragma nounroll
@@ -1107,7 +1156,14 @@ HD void affine_tables_build(const atab_ref tab, u32* tscr, const u32* pts, size_
         aff_den_dbl(d, a2, pid, one);
         aff_push(tscr, N, t, q + 1, run, d);
     }
-    fe_inv(inv, run);
+}
+HD void affine_tables_pass_c(const atab_ref tab, u32* tscr, const u32* pts, size_t N, size_t t, const int NP, fe inv, fe& run) {
+    const int L2 = NP, L4 = 3 * NP;          // running products: levels 1 and 3 share slots 0 .. NP, level 2 lives in NP .. 3 NP, level 4 in 3 NP .. 5 NP
+    (void)L2; (void)L4;
+    fe beta, one, d, dinv;
+    fe_set_u32(one, 1);
+    glv_beta(beta);
+    (void)d; (void)dinv;
     // ---- pass C (up): 4P, 3P; level-3 denominators x_4P - x_P (5P), 2 y_3P (6P), x_4P - x_3P (7P), 2 y_4P (8P): one block per point
     fe_set_u32(run, 1);
 #pragma nounroll
@@ -1140,11 +1196,16 @@ HD void affine_tables_build(const atab_ref tab, u32* tscr, const u32* pts, size_
         fe_mul(bp, bp, d);
         aff_push_block(tscr, N, t, p, run, bp);
     }
-    fe_inv(inv, run);
+}
+HD void affine_tables_pass_d(const atab_ref tab, u32* tscr, const u32* pts, size_t N, size_t t, const int NP, fe inv, fe& run) {
+    const int L2 = NP, L4 = 3 * NP;          // running products: levels 1 and 3 share slots 0 .. NP, level 2 lives in NP .. 3 NP, level 4 in 3 NP .. 5 NP
+    (void)L2; (void)L4;
+    fe beta, one, d, dinv;
+    fe_set_u32(one, 1);
+    glv_beta(beta);
+    (void)d; (void)dinv;
     // ---- pass D (down): 5P, 6P, 7P, 8P  [5-bit windows: + level-4 denominators for 9P .. 16P, two blocks per point]
-#if BPPP_VWIN == 5
     fe_set_u32(run, 1);
-#endif
 #pragma nounroll
     for (int p = NP - 1; p >= 0; p--) {
         const atab_ref tb = tab + p * 16;
@@ -1197,8 +1258,15 @@ HD void affine_tables_build(const atab_ref tab, u32* tscr, const u32* pts, size_
         aff_push_block(tscr, N, t, L4 + 2 * p + 1, run, be);
 #endif
     }
+}
 #if BPPP_VWIN == 5
-    fe_inv(inv, run);
+HD void affine_tables_pass_e(const atab_ref tab, u32* tscr, const u32* pts, size_t N, size_t t, const int NP, fe inv) {
+    const int L2 = NP, L4 = 3 * NP;          // running products: levels 1 and 3 share slots 0 .. NP, level 2 lives in NP .. 3 NP, level 4 in 3 NP .. 5 NP
+    (void)L2; (void)L4;
+    fe beta, one, d, dinv;
+    fe_set_u32(one, 1);
+    glv_beta(beta);
+    (void)d; (void)dinv;
     // ---- pass E (up): 9P .. 16P; per point the even block (pushed last) unwinds first
 #pragma nounroll
     for (int p = 0; p < NP; p++) {
@@ -1233,7 +1301,37 @@ HD void affine_tables_build(const atab_ref tab, u32* tscr, const u32* pts, size_
         aff_add(R, a8, a5, di[2]);  atab_store(tb, 13, R, beta, pid);
         aff_add(R, a8, a7, di[3]);  atab_store(tb, 15, R, beta, pid);
     }
+}
 #endif
+HD void affine_tables_build(const atab_ref tab, u32* tscr, const u32* pts, size_t N, size_t t, const int NP) {
+    fe run, inv;
+    affine_tables_pass_a(tab, tscr, pts, N, t, NP, run);
+    fe_inv(inv, run);
+    affine_tables_pass_b(tab, tscr, pts, N, t, NP, inv, run);
+    fe_inv(inv, run);
+    affine_tables_pass_c(tab, tscr, pts, N, t, NP, inv, run);
+    fe_inv(inv, run);
+    affine_tables_pass_d(tab, tscr, pts, N, t, NP, inv, run);
+#if BPPP_VWIN == 5
+    fe_inv(inv, run);
+    affine_tables_pass_e(tab, tscr, pts, N, t, NP, inv);
+#endif
+}
+// pass = 0 .. 4 of the u64 verifier's 13 tables with the inversions shared: the running product goes out through ws.zinv, its inverse
+// (fe_batch_inv_lane, in place) comes back through it
+template <int PASS>
+HD void verify_tables_pass(const VerifyWs& ws, size_t t) {
+    const atab_ref tab = atab_of(ws.atab, ws.N, t);
+    fe run, inv;
+    if constexpr (PASS > 0) ws_ld_fe(inv, ws.zinv, ws.N, t, 0, 1);
+    if constexpr (PASS == 0) affine_tables_pass_a(tab, ws.tscr, ws.pts, ws.N, t, BPPP_VPOINTS, run);
+    if constexpr (PASS == 1) affine_tables_pass_b(tab, ws.tscr, ws.pts, ws.N, t, BPPP_VPOINTS, inv, run);
+    if constexpr (PASS == 2) affine_tables_pass_c(tab, ws.tscr, ws.pts, ws.N, t, BPPP_VPOINTS, inv, run);
+    if constexpr (PASS == 3) affine_tables_pass_d(tab, ws.tscr, ws.pts, ws.N, t, BPPP_VPOINTS, inv, run);
+#if BPPP_VWIN == 5
+    if constexpr (PASS == 4) affine_tables_pass_e(tab, ws.tscr, ws.pts, ws.N, t, BPPP_VPOINTS, inv);
+#endif
+    if constexpr (PASS < 4) ws_st_fe(ws.zinv, ws.N, t, 0, run);
 }
 HD void verify_tables(const VerifyWs& ws, size_t t) {
     BPPP_STAMP(t, 16);
@@ -2172,6 +2270,14 @@ HD void verify_c0_var(const VerifyWs& ws, size_t t, int group_lane = -1, int gro
     BPPP_STAMP(t, 21);
     ws_st_pt(ws.acc, N, t, acc);   // the fixed-base part (pfix) is added at the top of round 1
 }
+// C0 = variable-base part + fixed-base part, ahead of round 1 when the rounds find 1 / Z ready (ws.zinv): the shared inversion needs C0's Z
+HD void verify_c0_join(const VerifyWs& ws, size_t t) {
+    pt C, F;
+    ws_ld_pt(C, ws.acc, ws.N, t);
+    ws_ld_pt(F, ws.pfix, ws.N, t);
+    pt_add(C, C, F);
+    ws_st_pt(ws.acc, ws.N, t, C);
+}
 // ---------------------------------------------------------------- phase 3 (k = 1..4): one WNLA round (wnla.rs:84-102)
 // group_lane >= 0: this lane is one of four consecutive lanes that all run the round for proof t (identical work and identical
 // stores, except the sum, which they share: straus_affine_g4) -- the small-batch kernels; -1: one lane per proof
@@ -2191,13 +2297,18 @@ HD void verify_round_on(const VerifyWs& ws, size_t t, int k, TR& tr, int group_l
         if (fe_is_zero(C.Z)) { fe_set_u32(Ca.x, 0); fe_set_u32(Ca.y, 0); }
         ws_ld8(y.v, ws.chal, N, t, 5 + k);
     } else {
-        if (k == 1) {   // C0 = variable-base part (acc) + fixed-base part (pfix); the two kernels run concurrently on two streams
+        if (k == 1 && !ws.zinv) {   // C0 = variable-base part (acc) + fixed-base part (pfix); the two kernels run concurrently on two streams
             pt F;
             ws_ld_pt(F, ws.pfix, N, t);
             pt_add(C, C, F);
         }
         BPPP_STAMP(t, 9);
-        pt_to_affine(Ca, C);
+        if (ws.zinv) {              // shared inversions: C0 was joined by verify_c0_join, 1 / Z is there (pt_to_affine's two products remain)
+            fe zi;
+            ws_ld_fe(zi, ws.zinv, N, t, 0, 1);
+            fe_mul(Ca.x, C.X, zi);
+            fe_mul(Ca.y, C.Y, zi);
+        } else pt_to_affine(Ca, C);
         BPPP_STAMP(t, 10);
         ws_ld_transcript(tr, ws.tstate, N, t);
         app_point(tr, "wnla_com", Ca);                                       // wnla.rs:88-92

@@ -392,6 +392,23 @@ int emul_u64_verify_batch_transcript(const uint8_t* table, int W, size_t n, cons
                                      const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* states_out) {
     return emul_u64_verify_impl(table, W, nullptr, 0, n, V, proofs, accept, status, nullptr, states, n_states, states_out);
 }
+// the large batches' shared inversions (plan_core.h: shared_inv; verify_core.h: fe_batch_inv_lane): G proofs per inversion, lane order
+static int g_shared_inv = 0;
+void emul_set_shared_inv(int g) { g_shared_inv = g; }
+extern "C++" {
+template <int G>
+static void emul_batch_inv_g(const u32* in, u32* out, size_t n) {
+    for (size_t i = 0; i < (n + G - 1) / G; i++) fe_batch_inv_lane<G>(in, out, n, i);
+}
+}
+static void emul_batch_inv(int G, const u32* in, u32* out, size_t n) {
+    switch (G) {
+    case 16: emul_batch_inv_g<16>(in, out, n); break;
+    case 8: emul_batch_inv_g<8>(in, out, n); break;
+    case 4: emul_batch_inv_g<4>(in, out, n); break;
+    default: emul_batch_inv_g<2>(in, out, n); break;
+    }
+}
 static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
                                 const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* trace, const uint8_t* states,
                                 size_t n_states, uint8_t* states_out) {
@@ -434,8 +451,45 @@ static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* labe
         for (size_t t = 0; t < n; t++) verify_tables_own(w2, t);
         if (memcmp(atab.data(), atab2.data(), atab.size() * sizeof(apt_packed)) != 0) return -79;
     }
+    const int G = g_shared_inv;
+    std::vector<u32> zinv(10 * n);
+    if (G) {   // the table build as five passes with the inversions between them shared by G proofs: bit for bit the same tables
+        std::vector<apt_packed> atab3(atab.size());
+        std::vector<u32> tscr3(tscr.size());
+        VerifyWs w3 = ws;
+        w3.atab = atab3.data(); w3.tscr = tscr3.data(); w3.zinv = zinv.data();
+        for (size_t t = 0; t < n; t++) verify_tables_pass<0>(w3, t);
+        emul_batch_inv(G, w3.zinv, w3.zinv, n);
+        for (size_t t = 0; t < n; t++) verify_tables_pass<1>(w3, t);
+        emul_batch_inv(G, w3.zinv, w3.zinv, n);
+        for (size_t t = 0; t < n; t++) verify_tables_pass<2>(w3, t);
+        emul_batch_inv(G, w3.zinv, w3.zinv, n);
+        for (size_t t = 0; t < n; t++) verify_tables_pass<3>(w3, t);
+        emul_batch_inv(G, w3.zinv, w3.zinv, n);
+        for (size_t t = 0; t < n; t++) verify_tables_pass<4>(w3, t);
+        if (memcmp(atab.data(), atab3.data(), atab.size() * sizeof(apt_packed)) != 0) return -80;
+    }
     for (size_t t = 0; t < n; t++) verify_c0_var(ws, t);
     for (size_t t = 0; t < n; t++) verify_c0_fixed(ws, t);
+    if (G) {   // ... and the rounds: C0 joined first, 1 / Z of C_{k-1} from the shared inversions, no head / tail split
+        ws.zinv = zinv.data();
+        for (size_t t = 0; t < n; t++) verify_c0_join(ws, t);
+        for (int k = 1; k <= 4; k++) {
+            emul_batch_inv(G, ws.acc + 20 * n, ws.zinv, n);
+            for (size_t t = 0; t < n; t++) verify_round(ws, t, k);
+        }
+        for (size_t t = 0; t < n; t++) verify_final_scalars(ws, t);
+        for (size_t t = 0; t < n; t++) {
+            FbRanges rg;
+            verify_final_check_ranges(rg);
+            pt rhs;
+            fb_sum_serial(rhs, fb_of(ws), t, ws.fsc, rg);
+            verify_final_check_store(ws, t, rhs);
+        }
+        for (size_t t = 0; t < n; t++) verify_accept(ws, t);
+        for (size_t t = 0; t < n; t++) verify_export_state(ws, t);
+        return 0;
+    }
     for (int k = 1; k <= 3; k++)
         for (size_t t = 0; t < n; t++) verify_round(ws, t, k);
     // the last round as the library runs it at 2^16 proofs: head, then -- beside the tail -- the final scalars and the final sum

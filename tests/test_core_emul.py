@@ -336,8 +336,19 @@ def test_fixed_base_sums_over_a_table_in_two_regions(L, gold, W_hi, W_lo):
             assert out.raw == O.pt_to_xy64(exp), (first, count, nl)
 
 
+# shared: proofs per shared field inversion (plan_core.h: shared_inv -- the table build in five passes and the rounds take 1 / v from
+# fe_batch_inv_lane instead of inverting per proof; the emulator also checks the tables bit for bit against the one-pass build)
+@pytest.mark.parametrize("shared", [0, 2, 4, 8, 16])
 @pytest.mark.parametrize("W", [4, 10])            # 10 = the signed-window scheme (26 windows: pairs dealt round-robin over the lanes)
-def test_full_verify_pipeline_against_golden(L, gold, oracle_c, W):
+def test_full_verify_pipeline_against_golden(L, gold, oracle_c, W, shared):
+    L.emul_set_shared_inv(shared)
+    try:
+        _full_verify_pipeline_against_golden(L, gold, oracle_c, W)
+    finally:
+        L.emul_set_shared_inv(0)
+
+
+def _full_verify_pipeline_against_golden(L, gold, oracle_c, W):
     gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
     ent = L.emul_fb_table_entries(49, W)
     tab = np.zeros(ent * 64, dtype=np.uint8)
@@ -455,7 +466,18 @@ def test_prover_next_commitments_as_fixed_base_sums(L, gold, oracle_c):
     assert (ov == V).all() and (op == proofs).all()
 
 
-def test_identity_and_repeated_points_in_a_proof(L, gold, oracle_c):
+@pytest.mark.parametrize("shared", [0, 16, 4])
+def test_identity_and_repeated_points_in_a_proof(L, gold, oracle_c, shared):
+    """(shared: with the inversions shared by that many proofs -- an identity's Z = 0 inside a group must neither poison the group's
+    product nor come back as anything but 0.)"""
+    L.emul_set_shared_inv(shared)
+    try:
+        _identity_and_repeated_points_in_a_proof(L, gold, oracle_c)
+    finally:
+        L.emul_set_shared_inv(0)
+
+
+def _identity_and_repeated_points_in_a_proof(L, gold, oracle_c):
     """CPU twin of tests/test_gpu_verify.py::test_identity_points_in_proofs_vs_oracle on the device code: each of the 14 points of
     a golden proof replaced by the identity (64 zero bytes: well-formed, hashed as 33 zero bytes, the neutral element of every
     table and sum), all of them at once, and repeated points (P + P inside the window tables): accept, status and the full

@@ -55,10 +55,14 @@ def test_verify_at_every_threshold_vs_oracle(batch, proto, oracle_c, T, d):
     proof, the one a wrong grid size would drop): accept bits, statuses, the reject count, and on a sample that holds every malformed
     proof and its neighbours the whole 704-byte trace of challenges and commitments, equal the oracle's; and the call took the plan
     the size is meant to take."""
-    import torch
-    import workload
     from bp_pp_amd.range_proof import plan_for
     n = T + d
+    _verify_and_check(batch, proto, oracle_c, n, plan_for(n))
+
+
+def _verify_and_check(batch, proto, oracle_c, n, expect_plan):
+    import torch
+    import workload
     V, P = batch["V"][:n].copy(), batch["P"][:n]
     P, expect = workload.corrupt(P, V, every=13)
     P = P.copy()
@@ -69,7 +73,7 @@ def test_verify_at_every_threshold_vs_oracle(batch, proto, oracle_c, T, d):
     P[0, 864:896] = np.frombuffer(workload.N_ORDER.to_bytes(32, "big"), np.uint8)            # a scalar = n
     P[n - 1, 64:96] = np.frombuffer((2**256 - 2**32 - 977).to_bytes(32, "big"), np.uint8)     # a coordinate = p
     acc, st, tr, rej = _device_verify(torch, proto, workload.LABEL, V, P)
-    assert proto.last_plan() == plan_for(n), (n, proto.last_plan())
+    assert proto.last_plan() == expect_plan, (n, proto.last_plan())
     sample = sorted(set(bad + [b + 1 for b in bad if b + 1 < n] + [b - 1 for b in bad if b > 0] + list(range(0, n, max(1, n // 24)))))
     flagged = 0
     for i in sample:
@@ -84,6 +88,25 @@ def test_verify_at_every_threshold_vs_oracle(batch, proto, oracle_c, T, d):
     clean[bad] = False
     assert (acc[clean] == expect[clean]).all() and not st[clean].any()
     assert rej == int((acc == 0).sum())
+
+
+@pytest.mark.parametrize("G,n", [(2, 131073), (4, 70001), (8, 65537), (16, 70001), (16, 131073)])
+def test_shared_inversions_at_the_group_sizes_of_larger_batches(batch, oracle_c, monkeypatch, G, n):
+    """From 2^18 proofs the table build and the rounds take their field inversions from kernels that invert once for G proofs (plan_core.h:
+    shared_inv; G = 8 from 2^18, 16 from 2^20).  BPPP_SHARED_INV forces the groups at sizes this tier can afford, ragged ones included
+    (n not a multiple of G: the last lanes' groups are short).  Same checks as the sweep above."""
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    from bp_pp_amd.range_proof import plan_for
+    monkeypatch.setenv("BPPP_SHARED_INV", str(G))
+    g, gv, hv = workload.split_generators(batch["gens"])
+    p = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=16)
+    try:
+        base = plan_for(n)
+        assert "shared_inv=" in base
+        _verify_and_check(batch, p, oracle_c, n, base[:base.index("shared_inv=")] + "shared_inv=%d" % G)
+    finally:
+        p.close()
 
 
 @pytest.mark.parametrize("T", THRESHOLDS)

@@ -34,6 +34,9 @@ def test_verify_plan_changes_only_at_the_documented_sizes(L):
     assert _changes(L, 0, 1024, 2, 140000) == [1025, 4097, 16385, 32769, 65537, 131072]
     # the thresholds scale with the device
     assert _changes(L, 0, 256, 0, 40000) == [257, 1025, 4097, 8193, 16385, 32768]
+    # beyond 128 S only the number of proofs that share a field inversion changes: 8 from 256 S, 16 from 1,024 S
+    assert _changes(L, 0, 1024, 0, 1100000) == [1025, 4097, 16385, 32769, 65537, 131072, 262144, 1048576]
+    assert _changes(L, 0, 64, 0, 70000) == [65, 257, 1025, 2049, 4097, 8192, 16384, 65536]
 
 
 def test_prove_plan_changes_only_at_the_documented_sizes(L):
@@ -70,12 +73,13 @@ def test_plan_is_total_and_describable(L):
     assert L.bppp_u64_plan(2, 10, 1024, 0) == E and L.bppp_u64_plan(0, 10, 0, 0) == E and L.bppp_u64_plan(0, 10, 1024, 4) == E
     assert L.bppp_plan_describe(-1, 0, buf, len(buf)) == E
     # what the regimes look like (the strings the GPU tier asserts on)
-    assert plan_for(1024) == "phase1=g16 tables=aside/4 fb=l64 c0var=g64 round=g16 tail_beside=0 small=1 split=1"
-    assert plan_for(4096) == "phase1=g16 tables=aside/2 fb=l64 c0var=g32 round=g8 tail_beside=0 small=1 split=1"
-    assert plan_for(16384) == "phase1=small tables=aside/1 fb=l8 c0var=g4 round=g4 tail_beside=0 small=1 split=0"
-    assert plan_for(32768) == "phase1=wg4 tables=beside/1 fb=l8 c0var=small round=g2 tail_beside=0 small=1 split=0"
-    assert plan_for(65536) == "phase1=wg4 tables=beside/1 fb=l8 c0var=small round=small tail_beside=1 small=1 split=0"
-    assert plan_for(65537) == "phase1=full tables=inline/1 fb=l8 c0var=full round=full tail_beside=0 small=0 split=0"
-    assert plan_for(131072) == "phase1=full tables=inline/1 fb=l1 c0var=full round=full tail_beside=0 small=0 split=0"
-    assert plan_for(1 << 20) == plan_for(131072)
+    assert plan_for(1024) == "phase1=g16 tables=aside/4 fb=l64 c0var=g64 round=g16 tail_beside=0 small=1 split=1 shared_inv=0"
+    assert plan_for(4096) == "phase1=g16 tables=aside/2 fb=l64 c0var=g32 round=g8 tail_beside=0 small=1 split=1 shared_inv=0"
+    assert plan_for(16384) == "phase1=small tables=aside/1 fb=l8 c0var=g4 round=g4 tail_beside=0 small=1 split=0 shared_inv=0"
+    assert plan_for(32768) == "phase1=wg4 tables=beside/1 fb=l8 c0var=small round=g2 tail_beside=0 small=1 split=0 shared_inv=0"
+    assert plan_for(65536) == "phase1=wg4 tables=beside/1 fb=l8 c0var=small round=small tail_beside=1 small=1 split=0 shared_inv=0"
+    assert plan_for(65537) == "phase1=full tables=inline/1 fb=l8 c0var=full round=full tail_beside=0 small=0 split=0 shared_inv=0"
+    assert plan_for(131072) == "phase1=full tables=inline/1 fb=l1 c0var=full round=full tail_beside=0 small=0 split=0 shared_inv=0"
+    assert plan_for(1 << 18) == "phase1=full tables=inline/1 fb=l1 c0var=full round=full tail_beside=0 small=0 split=0 shared_inv=8"
+    assert plan_for(1 << 20) == "phase1=full tables=inline/1 fb=l1 c0var=full round=full tail_beside=0 small=0 split=0 shared_inv=16"
     assert plan_for(1 << 14, prove=True) == "fb=l8 fb4_from_jobs=2 stage=g4 fold=g4 scalars=parts next_by_msm=1 w2=0 overlap_next=1 next_g4=1 ct=0"
