@@ -167,19 +167,42 @@ def pmc_traffic(kernel, n_proofs):
     return b * (n_proofs / n_ref)      # the PMC pass of this kernel ran n_ref proofs per launch
 
 
+SHARED_INV = 0      # proofs per shared field inversion in the timed verify calls (the plan's shared_inv; set by main() from last_plan())
+
+
+def shared_inv_of(plan_text):
+    """`shared_inv=G` of a plan description (bppp_plan_describe); 0 when the library predates the field."""
+    for tok in (plan_text or "").split():
+        if tok.startswith("shared_inv="):
+            return int(tok.split("=")[1])
+    return 0
+
+
+def slot_kernels(slot, launches_per_step):
+    """The kernels behind one of the library's timing slots, with their launches per step: one kernel per slot, except where the
+    plan shares field inversions (from 2^18 proofs) -- there the table build is five pass kernels and the inverting launches
+    (+ the join of C0's halves ahead of round 1) have a slot of their own."""
+    if SHARED_INV and slot == "k_verify_tables":
+        return [("k_verify_tables_pass%d" % i, launches_per_step / 5.0) for i in range(5)]
+    if slot == "k_verify_shared_inv":
+        return [("k_verify_shared_inv%d" % SHARED_INV, launches_per_step * 8.0 / 9.0), ("k_verify_c0_join", launches_per_step / 9.0)]
+    return [(slot, launches_per_step)]
+
+
 def pmc_traffic_per_step(kernel_times, steps, n_proofs):
     """Counter bytes of ALL kernels of one step (each kernel's measured bytes per launch x its launches per step), or None when a
     kernel of the step has no counters for this build."""
     total = 0.0
-    for k, v in kernel_times.items():
+    for slot, v in kernel_times.items():
         if not v["launches"]:
             continue
-        b = pmc_traffic(k, n_proofs)
-        if b is None:
-            if k in ("k_verify_accept",):      # (a few bytes per proof; absent from some passes)
-                continue
-            return None
-        total += b * v["launches"] / steps
+        for k, per_step in slot_kernels(slot, v["launches"] / steps):
+            b = pmc_traffic(k, n_proofs)
+            if b is None:
+                if k in ("k_verify_accept",):      # (a few bytes per proof; absent from some passes)
+                    continue
+                return None
+            total += b * per_step
     return total
 
 
@@ -377,6 +400,8 @@ def run_verify(args):
     elapsed = time.perf_counter() - t_start
     kernel_times = proto.timings(reset=True)
     proto.enable_timing(False)
+    global SHARED_INV
+    SHARED_INV = shared_inv_of(proto.last_plan())
 
     # correctness of what was just timed (untimed): accept bits == expectation, global reject count == corrupted proofs
     acc = dA.cpu().numpy()

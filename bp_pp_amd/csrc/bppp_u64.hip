@@ -23,10 +23,10 @@ static void launch_fe_batch_inv(int G, const u32* in, u32* out, size_t n, hipStr
     const size_t lanes = (n + (size_t)G - 1) / (size_t)G;
     const unsigned b = (unsigned)((lanes + BPPP_BLOCK - 1) / BPPP_BLOCK);
     switch (G) {
-    case 16: k_fe_batch_inv16<<<b, BPPP_BLOCK, 0, s>>>(in, out, n); break;
-    case 8: k_fe_batch_inv8<<<b, BPPP_BLOCK, 0, s>>>(in, out, n); break;
-    case 4: k_fe_batch_inv4<<<b, BPPP_BLOCK, 0, s>>>(in, out, n); break;
-    default: k_fe_batch_inv2<<<b, BPPP_BLOCK, 0, s>>>(in, out, n); break;
+    case 16: k_verify_shared_inv16<<<b, BPPP_BLOCK, 0, s>>>(in, out, n); break;
+    case 8: k_verify_shared_inv8<<<b, BPPP_BLOCK, 0, s>>>(in, out, n); break;
+    case 4: k_verify_shared_inv4<<<b, BPPP_BLOCK, 0, s>>>(in, out, n); break;
+    default: k_verify_shared_inv2<<<b, BPPP_BLOCK, 0, s>>>(in, out, n); break;
     }
 }
 
@@ -167,17 +167,16 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     // half's events also cover the other's share of the SIMDs; the overlap itself buys nothing at 2 waves/SIMD: DESIGN.md 4)
     if (tables_aside || tables_beside) HIP_TRY(hipStreamWaitEvent(s, c->ev_tab, 0));
     else if (plan.shared_inv) {
-        LAUNCH(K_TABLES, {
-            k_verify_tables_pass0<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
-            launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s);
-            k_verify_tables_pass1<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
-            launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s);
-            k_verify_tables_pass2<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
-            launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s);
-            k_verify_tables_pass3<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
-            launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s);
-            k_verify_tables_pass4<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
-        });
+        // five passes, the running product of each inverted once per G proofs in between (in place in ws.zinv)
+        LAUNCH(K_TABLES, k_verify_tables_pass0<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+        LAUNCH(K_SHARED_INV, launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s));
+        LAUNCH(K_TABLES, k_verify_tables_pass1<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+        LAUNCH(K_SHARED_INV, launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s));
+        LAUNCH(K_TABLES, k_verify_tables_pass2<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+        LAUNCH(K_SHARED_INV, launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s));
+        LAUNCH(K_TABLES, k_verify_tables_pass3<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
+        LAUNCH(K_SHARED_INV, launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s));
+        LAUNCH(K_TABLES, k_verify_tables_pass4<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     } else LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     HIP_TRY(hipEventRecord(c->ev_fork, s));
     HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
@@ -221,11 +220,11 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         default:
             if (plan.shared_inv) {
                 // 1 / Z of C_{k-1} for every proof from n / G inversions (round 1: after the halves of C0 are added)
-                LAUNCH(K_ROUND, {
+                LAUNCH(K_SHARED_INV, {
                     if (k == 1) k_verify_c0_join<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
                     launch_fe_batch_inv(plan.shared_inv, ws.acc + 20 * n, ws.zinv, n, s);
-                    k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k);
                 });
+                LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
             } else LAUNCH(K_ROUND, k_verify_round<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
             break;
         }

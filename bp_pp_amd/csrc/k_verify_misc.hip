@@ -113,7 +113,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_export_states(VerifyWs ws
 
 // ---- shared inversions of the large-batch verify (plan_core.h: shared_inv): lane i inverts for proofs i, i + L, ... (L = ceil(N / G))
 #define BPPP_FE_BATCH_INV_KERNEL(G)                                                                                     \
-    __global__ __launch_bounds__(BPPP_BLOCK) void k_fe_batch_inv##G(const u32* in, u32* out, size_t N) {                 \
+    __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_shared_inv##G(const u32* in, u32* out, size_t N) {                 \
         const size_t i = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;                                                  \
         if (i < (N + G - 1) / G) fe_batch_inv_lane<G>(in, out, N, i);                                                    \
     }

@@ -8,7 +8,7 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_ta
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < ws.N) verify_tables(ws, t);
 }
-// the build as five kernels with the inversions between them shared by G proofs each (plan_core.h: shared_inv; k_fe_batch_inv*)
+// the build as five kernels with the inversions between them shared by G proofs each (plan_core.h: shared_inv; k_verify_shared_inv*)
 #define BPPP_TABLES_PASS_KERNEL(P)                                                                                      \
     __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables_pass##P(VerifyWs ws) {          \
         size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;                                                        \

@@ -82,10 +82,10 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_phase1_g16(bppp::VerifyWs
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_verify_c0_fixed_l1(bppp::VerifyWs ws);      // one lane per proof (full batches)
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables(bppp::VerifyWs ws);
-__global__ __launch_bounds__(BPPP_BLOCK) void k_fe_batch_inv2(const bppp::u32* in, bppp::u32* out, size_t N);
-__global__ __launch_bounds__(BPPP_BLOCK) void k_fe_batch_inv4(const bppp::u32* in, bppp::u32* out, size_t N);
-__global__ __launch_bounds__(BPPP_BLOCK) void k_fe_batch_inv8(const bppp::u32* in, bppp::u32* out, size_t N);
-__global__ __launch_bounds__(BPPP_BLOCK) void k_fe_batch_inv16(const bppp::u32* in, bppp::u32* out, size_t N);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_shared_inv2(const bppp::u32* in, bppp::u32* out, size_t N);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_shared_inv4(const bppp::u32* in, bppp::u32* out, size_t N);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_shared_inv8(const bppp::u32* in, bppp::u32* out, size_t N);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_verify_shared_inv16(const bppp::u32* in, bppp::u32* out, size_t N);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_join(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables_pass0(bppp::VerifyWs ws);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_verify_tables_pass1(bppp::VerifyWs ws);

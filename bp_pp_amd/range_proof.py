@@ -316,7 +316,7 @@ class U64RangeProofProtocol:
 
     def last_plan(self, prove: bool = False) -> str:
         """Which kernels the context's last u64 verify (or prove) call ran, as text (include/bppp.h: "last_verify_plan" / "last_prove_plan"
-        + bppp_plan_describe) -- e.g. "phase1=wg4 tables=beside/1 fb=l8 c0var=small round=small tail_beside=1 small=1 split=0"."""
+        + bppp_plan_describe) -- e.g. "phase1=wg4 tables=beside/1 fb=l8 c0var=small round=small tail_beside=1 small=1 split=0 shared_inv=0"."""
         return describe_plan(self.get_option("last_prove_plan" if prove else "last_verify_plan"), prove)
 
     def synchronize(self) -> None:

@@ -130,9 +130,10 @@ BPPP_API int bppp_ctx_set_option(bppp_ctx* ctx, const char* name, long value);
 BPPP_API long bppp_ctx_get_option(bppp_ctx* ctx, const char* name);
 /* Which kernels a u64 verify (prove = 0) or prove (prove = 1) call of n proofs runs on a device of n_simds SIMDs (CUs x 4; MI355X: 1024):
  * the size decides among seven (six) launch sequences, from a wavefront per sum for a handful of proofs to one lane per proof from 2^17
- * on (csrc/plan_core.h lists them with their thresholds).  A pure function -- no device, no context; flags: bit 0 = RLC mode (verify) /
+ * on, and from 2^18 proofs how many proofs share one field inversion in the verifier's table build and rounds (shared_inv = 8, 16 from
+ * 2^20; csrc/plan_core.h lists the regimes with their thresholds).  A pure function -- no device, no context; flags: bit 0 = RLC mode (verify) /
  * "ct_prover" (prove), bit 1 = per-kernel timing on.  Returns the plan as a non-negative code whose fields bppp_plan_describe spells out
- * ("phase1=wg4 tables=beside/1 fb=l8 c0var=small round=small tail_beside=1 small=1 split=0"), or BPPP_ERR_INVALID_ARG.  A context's
+ * ("phase1=wg4 tables=beside/1 fb=l8 c0var=small round=small tail_beside=1 small=1 split=0 shared_inv=0"), or BPPP_ERR_INVALID_ARG.  A context's
  * diagnostic environment switches (BPPP_NO_SMALL_KERNELS etc.) are not visible here; "last_verify_plan" reports what really ran. */
 BPPP_API long bppp_u64_plan(int prove, size_t n, int n_simds, int flags);
 /* Text form of a plan code into buf (NUL-terminated, at most cap bytes); returns the length the full text needs, as snprintf does. */
