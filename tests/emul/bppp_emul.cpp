@@ -409,6 +409,24 @@ static void emul_batch_inv(int G, const u32* in, u32* out, size_t n) {
     default: emul_batch_inv_g<2>(in, out, n); break;
     }
 }
+// fe_batch_inv_lane on n field elements (32-byte big-endian each, 0 allowed), G per inversion, out = in allowed: what
+// k_verify_shared_inv<G> computes, lane after lane
+int emul_fe_batch_inv(int G, size_t n, const uint8_t* in, uint8_t* out, int in_place) {
+    std::vector<u32> a(10 * n), b(10 * n);
+    for (size_t t = 0; t < n; t++) {
+        fe x;
+        if (!fe_from_be(x, in + 32 * t)) return -1;
+        ws_st_fe(a.data(), n, t, 0, x);
+    }
+    if (G != 2 && G != 4 && G != 8 && G != 16) return -2;
+    emul_batch_inv(G, a.data(), in_place ? a.data() : b.data(), n);
+    for (size_t t = 0; t < n; t++) {
+        fe x;
+        ws_ld_fe(x, in_place ? a.data() : b.data(), n, t, 0, 1);
+        fe_to_be(out + 32 * t, x);
+    }
+    return 0;
+}
 static int emul_u64_verify_impl(const uint8_t* table, int W, const uint8_t* label, size_t label_len, size_t n, const uint8_t* V,
                                 const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* trace, const uint8_t* states,
                                 size_t n_states, uint8_t* states_out) {

@@ -336,6 +336,28 @@ def test_fixed_base_sums_over_a_table_in_two_regions(L, gold, W_hi, W_lo):
             assert out.raw == O.pt_to_xy64(exp), (first, count, nl)
 
 
+@pytest.mark.parametrize("G", [2, 4, 8, 16])
+def test_shared_inversion_of_a_batch(L, G):
+    """fe_batch_inv_lane (k_verify_shared_inv<G>): 1 / v for every element of a batch from one inversion per G elements -- equal to the
+    inversion of each element alone, zeros (the identity's Z) staying zero without spoiling their group, for batch sizes that leave
+    the last groups short or empty, in place and out of place."""
+    p = 2**256 - 2**32 - 977
+    rng = np.random.default_rng(G)
+    for n in (1, 2, G - 1, G, G + 1, 3 * G + 2, 64, 65, 257):
+        vals = [int.from_bytes(rng.bytes(32), "big") % p for _ in range(n)]
+        for z in {0, n // 2, n - 1}:
+            vals[z] = 0                                   # zeros at the ends and in the middle
+        if n > 5:
+            vals[3], vals[4] = 1, p - 1
+        src = b"".join(v.to_bytes(32, "big") for v in vals)
+        for in_place in (0, 1):
+            out = np.zeros(32 * n, np.uint8)
+            assert L.emul_fe_batch_inv(G, n, src, out.ctypes.data, in_place) == 0
+            for t, v in enumerate(vals):
+                got = int.from_bytes(out[32 * t:32 * t + 32].tobytes(), "big")
+                assert got == (pow(v, p - 2, p) if v else 0), (n, t)
+
+
 # shared: proofs per shared field inversion (plan_core.h: shared_inv -- the table build in five passes and the rounds take 1 / v from
 # fe_batch_inv_lane instead of inverting per proof; the emulator also checks the tables bit for bit against the one-pass build)
 @pytest.mark.parametrize("shared", [0, 2, 4, 8, 16])

@@ -109,6 +109,51 @@ def test_shared_inversions_at_the_group_sizes_of_larger_batches(batch, oracle_c,
         p.close()
 
 
+def test_shared_inversions_at_their_own_size_equal_the_per_proof_form(batch, oracle_c, monkeypatch):
+    """2^18 + 1 proofs (the fixture's batch twice over: the plan's own G = 8, ragged) with tampered and malformed proofs: accept bits,
+    statuses, reject count and ALL 704-byte traces of the call with shared inversions equal those of a context that inverts per proof
+    (BPPP_SHARED_INV=0), byte for byte; a sample also goes to the oracle."""
+    import torch
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    n = (1 << 18) + 1
+    idx = np.arange(n) % NMAX
+    V, P = batch["V"][idx].copy(), batch["P"][idx]
+    P, expect = workload.corrupt(P, V, every=13)
+    P = P.copy()
+    rng = np.random.default_rng(18)
+    bad = sorted(set(int(i) for i in rng.integers(0, n, 64)) | {0, n - 1, n - 2})
+    for i in bad[1:-2]:
+        P[i, int(rng.integers(0, 928))] ^= int(rng.integers(1, 256))
+    P[0, 864:896] = np.frombuffer(workload.N_ORDER.to_bytes(32, "big"), np.uint8)            # a scalar = n
+    P[n - 1, 64:96] = np.frombuffer((2**256 - 2**32 - 977).to_bytes(32, "big"), np.uint8)     # a coordinate = p
+    P[n - 2, :832] = 0                                                                        # every proof point the identity
+    g, gv, hv = workload.split_generators(batch["gens"])
+    res = []
+    for env in (None, "0"):
+        if env is None:
+            monkeypatch.delenv("BPPP_SHARED_INV", raising=False)
+        else:
+            monkeypatch.setenv("BPPP_SHARED_INV", env)
+        p = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=16)
+        try:
+            res.append(_device_verify(torch, p, workload.LABEL, V, P) + (p.last_plan(),))
+        finally:
+            p.close()
+    (a1, s1, t1, r1, plan1), (a0, s0, t0, r0, plan0) = res
+    assert plan1.endswith("shared_inv=8") and plan0.endswith("shared_inv=0") and plan1[:-1] == plan0[:-1]
+    assert (a1 == a0).all() and (s1 == s0).all() and r1 == r0 and (t1 == t0).all()
+    assert r1 == int((a1 == 0).sum()) and s1[0] != 0 and s1[n - 1] != 0 and s1[n - 2] == 0 and a1[n - 2] == 0
+    clean = np.ones(n, bool)
+    clean[bad] = False
+    assert (a1[clean] == expect[clean]).all() and not s1[clean].any()
+    for i in bad + [1, n // 2]:
+        rc, otr = oracle_c.u64_verify(batch["gens"], workload.LABEL, bytes(V[i]), bytes(P[i]), trace=True)
+        assert int(a1[i]) == (1 if rc == 1 else 0) and (int(s1[i]) != 0) == (rc < 0), (i, rc)
+        if rc >= 0:
+            assert bytes(t1[i]) == otr, i
+
+
 @pytest.mark.parametrize("T", THRESHOLDS)
 @pytest.mark.parametrize("d", [-1, 0, 1])
 def test_prove_at_every_threshold_vs_oracle(batch, proto, T, d):
