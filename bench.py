@@ -627,7 +627,7 @@ def run_verify(args):
                             "reject-count all-reduce per step",
                 "total_proofs_per_step": total,
                 "proofs_per_gpu": n,
-                "fb_window_bits": proto.get_option("fb_window_bits"),
+                "fb_window_bits": proto.get_option("fb_window_bits"),            # a window code: 523 = 5 windows of 24 bits + 6 of 23 per scalar (include/bppp.h)
                 "fb_window_bits_hi": proto.get_option("fb_window_bits_hi"),      # > 0: the first fb_hi_bases generators (g, g_vec) in a second, wider table
                 "fb_hi_bases": proto.get_option("fb_hi_bases"),
                 "fb_window_bits_chosen_by": "--fb-window-bits" if args.fb_window_bits else "the library, from the HBM free at context creation",

@@ -30,34 +30,41 @@ static void read_diagnostics(bppp_ctx* c) {
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // projective tables + complete additions
 }
 
-// fb_window_bits = 0: the widest windows whose tables take at most 35 % of the HBM that is FREE when the context is created (and whose
-// build scratch still fits beside them) -- on an otherwise empty MI355X 22 bits for the u64 protocol's 49 generators (79 GB of 288:
-// -2.4 ... -3.1 % per 2^20-proof batch against 20 bits / 21 GB, profiles/r03/r03_e_bench_fbwindow_*), 20 bits when some 60 GB are already
-// taken, 18 bits for the 769 generators of BASELINE configs[4]'s shape (97 GB: 15 additions per scalar instead of the 16 of 16-bit
-// windows over 52 GB, round 5).  Candidates, widest first:
-static const int kDefaultWindows[7] = {22, 20, 19, 18, 16, 8, 4};
-static double table_bytes_for(int nbases, int W) { return (double)nbases * fb_nwin(W) * (double)fb_per_win(W) * sizeof(apt_packed); }
-static size_t build_group_for(int nbases, int W) {          // bases per build pass: scratch (x, y, z, prefix: 160 B per entry) <= ~32 GB
-    const size_t per_base = (size_t)fb_nwin(W) * fb_per_win(W);
-    size_t group = ((size_t)32 << 30) / (per_base * 4 * sizeof(fe));
+// fb_window_bits = 0: the FEWEST windows per scalar whose tables fit the HBM that is FREE when the context is created.  Windows come in
+// two widths sized to the bit (verify_core.h: fb_wb): n windows are floor(258 / n)-bit windows with 258 mod n of them one bit wider, e.g.
+//   11 windows: code  523 (5 x 24 + 6 x 23 bits), 4.29 GB per generator      14 windows: code 618, 168 MB per generator
+//   12 windows: code  621 (6 x 22 + 6 x 21),      1.21 GB                    15 windows: code 317,  75 MB
+//   13 windows: code 1119 (11 x 20 + 2 x 19),     403 MB                     16 windows: code 216,  38 MB   ...  32 windows: code 208, 278 KB
+// (a uniform table of the same count always takes more: 22-bit windows 1.6 GB for 12 additions, 18-bit windows 126 MB for 15).  A table
+// fits when it takes at most 76 % of the free memory, leaves 50 GB of it (or half, if less is free) for workspaces, and its build scratch
+// fits beside it.  On an otherwise empty MI355X: 11 windows for the u64 protocol's 49 generators (210 GB; 726 table additions per proof),
+// 14 windows for the 769 generators of BASELINE configs[4]'s shape (129 GB).
+static int two_width_code_for(int nwin) { const int W = 258 / nwin; return W + 100 * (258 - W * nwin); }
+static double table_bytes_for(int nbases, int W) { return (double)nbases * (double)fb_per_base(W) * sizeof(apt_packed); }
+// bases per build pass: scratch (x, y, z, prefix: 160 B per entry) within `budget` bytes (at most ~32 GB), one base at least
+static size_t build_group_for(int nbases, int W, size_t budget = (size_t)32 << 30) {
+    const size_t per_base = fb_per_base(W);
+    if (budget > ((size_t)32 << 30)) budget = (size_t)32 << 30;
+    size_t group = budget / (per_base * 4 * sizeof(fe));
     if (group < 1) group = 1;
     if (group > (size_t)nbases) group = (size_t)nbases;
     return group;
 }
+static bool tables_fit(double tb, double scratch, size_t free_bytes) {
+    const double fr = (double)free_bytes, room = fr * 0.5 < 50e9 ? fr * 0.5 : 50e9;
+    return tb <= 0.76 * fr && tb + scratch <= 0.92 * fr && fr - tb >= room;
+}
 static bool window_fits(int nbases, int W, size_t free_bytes) {
     const double tb = table_bytes_for(nbases, W);
-    const double scratch = (double)build_group_for(nbases, W) * fb_nwin(W) * (double)fb_per_win(W) * 4 * sizeof(fe);
-    return tb <= 0.35 * (double)free_bytes && tb + scratch <= 0.90 * (double)free_bytes;
+    const double scratch = (double)fb_per_base(W) * 4 * sizeof(fe);          // of a pass over one generator (the build takes more when there is room)
+    return tables_fit(tb, scratch, free_bytes);
 }
 // Build the fixed-base tables of the generators first .. first + nb - 1 of c->d_gens at window width W into a fresh allocation.
 // On failure nothing stays allocated.
 static int build_table_range(bppp_ctx* c, int W, int first, int nb_total, apt_packed** out, size_t* out_bytes) {
     const int nwin = fb_nwin(W);
-    const size_t per_win = fb_per_win(W);
-    const size_t per_base = (size_t)nwin * per_win;
+    const size_t per_base = fb_per_base(W);
     const size_t bytes = (size_t)nb_total * per_base * sizeof(apt_packed);
-    const size_t group = build_group_for(nb_total, W);
-    const size_t gentries = group * per_base;
     apt_packed* d_table = nullptr;
     fe* d_tmp = nullptr;
     auto release = [&]() { if (d_tmp) (void)hipFree(d_tmp); if (d_table) (void)hipFree(d_table); };
@@ -73,6 +80,10 @@ static int build_table_range(bppp_ctx* c, int W, int first, int nb_total, apt_pa
     } while (0)
     if (c->inject_alloc_fault > 0 && --c->inject_alloc_fault == 0) { g_last_error = "injected allocation failure (tables)"; return BPPP_ERR_NOMEM; }
     HIP_TRY_T(hipMalloc(&d_table, bytes));
+    size_t free_now = 0, total_now = 0;           // the build's scratch: up to 32 GB of what is free beside the table
+    if (hipMemGetInfo(&free_now, &total_now) != hipSuccess) { (void)hipGetLastError(); free_now = (size_t)40 << 30; }
+    const size_t group = build_group_for(nb_total, W, (size_t)(0.8 * (double)free_now));
+    const size_t gentries = group * per_base;
     HIP_TRY_T(hipMalloc(&d_tmp, gentries * 4 * sizeof(fe)));
     for (size_t b0 = 0; b0 < (size_t)nb_total; b0 += group) {
         const size_t nb = (size_t)nb_total - b0 < group ? (size_t)nb_total - b0 : group;
@@ -102,15 +113,21 @@ static int build_tables(bppp_ctx* c, int W, bool ct = false) {
     c->fb_w = W;
     return BPPP_OK;
 }
-// Two regions (verify_core.h: FbTable; round 5): the u64 protocol's g and g_vec -- the 17 generators that BOTH fixed-base sums of a verify
-// run over (C0's fixed half and the final check) -- at 24-bit windows, 11 additions per scalar, 100 GB; h_vec at 22 bits, 52 GB.  792 ->
-// 758 table additions per proof.  Taken by fb_window_bits = 0 on the u64 generator shape when the two tables take at most 55 % of the free
-// HBM and leave room for the build scratch and a 2^21-proof workspace; BPPP_NO_MIXED_WINDOWS=1 keeps one table.
-static const int kMixedHiW = 24, kMixedLoW = 22;
+// Two regions (verify_core.h: FbTable; round 5), the u64 shape's second choice when 11 windows for all 49 generators do not fit: the
+// u64 protocol's g and g_vec -- the 17 generators that BOTH fixed-base sums of a verify run over (C0's fixed half and the final check) --
+// at 11 windows (code 523, 73 GB), h_vec at 12 (code 621, 39 GB): 758 table additions per proof against 726 / 792.
+// BPPP_NO_WIDE_TABLES=1 skips the first choice, BPPP_NO_MIXED_WINDOWS=1 both (one table, the general rule).
+static const int kWideCode = 523, kMixedHiW = 523, kMixedLoW = 621;
 static bool mixed_fits(int ng, int nh, size_t free_bytes) {
     const double tb = table_bytes_for(1 + ng, kMixedHiW) + table_bytes_for(nh, kMixedLoW);
-    const double scratch = (double)build_group_for(nh, kMixedLoW) * fb_nwin(kMixedLoW) * (double)fb_per_win(kMixedLoW) * 4 * sizeof(fe);
-    return tb <= 0.55 * (double)free_bytes && tb + scratch <= 0.90 * (double)free_bytes;
+    const double scratch = (double)fb_per_base(kMixedHiW) * 4 * sizeof(fe);
+    return tables_fit(tb, scratch, free_bytes);
+}
+// a window code the library can build: one of the uniform widths, or two widths that tile 258 bits with windows of at most 24 bits
+static bool window_code_valid(int code) {
+    const int W = fb_wb(code), ka = fb_ka(code);
+    if (ka == 0) return W == 4 || W == 8 || W == 16 || W == 10 || W == 18 || W == 19 || W == 20 || W == 22;
+    return code > 0 && code < 3200 && W >= 8 && W <= 23 && ka <= fb_nwin(code) && W * fb_nwin(code) + ka >= 258;
 }
 static int build_tables_mixed(bppp_ctx* c) {
     const int hi = 1 + c->ng;
@@ -162,7 +179,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     *out = nullptr;
     const int NB = 1 + (int)ng + (int)nh;
     const int W0 = fb_window_bits;
-    if (W0 != 0 && W0 != 4 && W0 != 8 && W0 != 16 && W0 != 10 && W0 != 18 && W0 != 19 && W0 != 20 && W0 != 22) return BPPP_ERR_INVALID_ARG;
+    if (W0 != 0 && !window_code_valid(W0)) return BPPP_ERR_INVALID_ARG;
     int rc = check_device(device);
     if (rc != BPPP_OK) return rc;
     HIP_TRY(hipSetDevice(device));
@@ -218,16 +235,29 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
         if (const char* e = std::getenv("BPPP_ASSUME_FREE_GB")) free_b = (size_t)(std::atof(e) * 1e9);      // diagnostic: exercise the choice
         rc = BPPP_ERR_NOMEM;
-        if (ng == 16 && nh == 32 && free_b && !std::getenv("BPPP_NO_MIXED_WINDOWS") && mixed_fits((int)ng, (int)nh, free_b)) {
+        const bool u64_shape = ng == 16 && nh == 32 && free_b && !std::getenv("BPPP_NO_MIXED_WINDOWS");
+        if (u64_shape && !std::getenv("BPPP_NO_WIDE_TABLES") && window_fits(NB, kWideCode, free_b)) {
+            rc = build_tables(c, kWideCode);
+            if (rc != BPPP_OK && rc != BPPP_ERR_NOMEM) return fail(rc);
+        }
+        if (rc != BPPP_OK && u64_shape && mixed_fits((int)ng, (int)nh, free_b)) {
             rc = build_tables_mixed(c);
             if (rc != BPPP_OK && rc != BPPP_ERR_NOMEM) return fail(rc);
         }
+        // the general rule: the fewest windows that fit (and if that allocation fails anyway -- another process took the memory meanwhile
+        // -- the next count); without a reading of the free memory, or below every two-width table, the small uniform ones
+        if (rc != BPPP_OK && free_b)
+            for (int nwin = 11; nwin <= 32; nwin++) {
+                const int code = two_width_code_for(nwin);
+                if (!window_code_valid(code) || !window_fits(NB, code, free_b)) continue;
+                rc = build_tables(c, code);
+                if (rc != BPPP_ERR_NOMEM) break;
+            }
         if (rc != BPPP_OK)
-        for (int W : kDefaultWindows) {
-            if (W > 4 && free_b && !window_fits(NB, W, free_b)) continue;
-            rc = build_tables(c, W);
-            if (rc != BPPP_ERR_NOMEM) break;
-        }
+            for (int W : {8, 4}) {
+                rc = build_tables(c, W);
+                if (rc != BPPP_ERR_NOMEM) break;
+            }
         if (rc != BPPP_OK) return fail(rc);
     }
     *out = c;
@@ -561,8 +591,8 @@ struct TableChecksum {
 int bppp_ctx_save_tables(bppp_ctx* c, const char* path) {
     CtxLock lock_(c);
     if (!c || !path) return BPPP_ERR_INVALID_ARG;
-    if (c->fb_hi_bases) {
-        g_last_error = "this context's tables are in two regions (fb_window_bits = 0 on the u64 shape); create it with an explicit fb_window_bits to save them";
+    if (c->fb_hi_bases || fb_ka(c->fb_w)) {
+        g_last_error = "this context's tables have windows of two widths (fb_window_bits = 0); create it with an explicit fb_window_bits to save them";
         return BPPP_ERR_INVALID_ARG;
     }
     HIP_TRY(hipSetDevice(c->device));
@@ -573,7 +603,7 @@ int bppp_ctx_save_tables(bppp_ctx* c, const char* path) {
     std::memset(&h, 0, sizeof h);
     std::memcpy(h.magic, "BPPPTAB3", 8);
     h.nbases = (uint32_t)c->nbases; h.ng = (uint32_t)c->ng; h.nh = (uint32_t)c->nh; h.window_bits = (uint32_t)c->fb_w;
-    h.nwin = (uint32_t)fb_nwin(c->fb_w); h.per_win = fb_per_win(c->fb_w); h.table_bytes = c->table_bytes;
+    h.nwin = (uint32_t)fb_nwin(c->fb_w); h.per_win = fb_per_narrow(c->fb_w); h.table_bytes = c->table_bytes;
     bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
     std::vector<apt> gens;
     std::vector<uint8_t> buf;
@@ -622,7 +652,7 @@ int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device) {
     bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "BPPPTAB3", 8) == 0;
     const int W = (int)h.window_bits;
     ok = ok && (W == 4 || W == 8 || W == 10 || W == 16 || W == 18 || W == 19 || W == 20 || W == 22) && h.ng <= 4096 && h.nh <= 4096 && h.nbases == 1 + h.ng + h.nh &&
-         h.nwin == (uint32_t)fb_nwin(W) && h.per_win == fb_per_win(W) && h.table_bytes == (uint64_t)h.nbases * h.nwin * h.per_win * sizeof(apt_packed);
+         h.nwin == (uint32_t)fb_nwin(W) && h.per_win == fb_per_narrow(W) && h.table_bytes == (uint64_t)h.nbases * h.nwin * h.per_win * sizeof(apt_packed);
     if (!ok) { std::fclose(f); g_last_error = std::string(path) + " is not a table file of this library"; return BPPP_ERR_INVALID_ARG; }
     if (hipSetDevice(device) != hipSuccess) { std::fclose(f); g_last_error = "hipSetDevice failed"; (void)hipGetLastError(); return BPPP_ERR_HIP; }
     bppp_ctx* c = new (std::nothrow) bppp_ctx();

@@ -266,16 +266,39 @@ void bppp_trace_table_read(const void* table, size_t index);
 #else
 #define FB_TRACE(tab, idx) ((void)0)
 #endif
-HD bool fb_signed(int W) { return W == 20 || W == 10 || W == 22 || W == 18 || W == 19 || W == 24; }
-HD int fb_nwin(int W) { return fb_signed(W) ? (257 + W - 1) / W : 256 / W; }           // signed: ceil(257 / W) windows
-HD size_t fb_per_win(int W) { return fb_signed(W) ? ((size_t)1 << (W - 1)) : (((size_t)1 << W) - 1); }
+// Window code of a table region (FbTable::W, W_hi; the library's "fb_window_bits"): Wb + 100 ka.  A scalar's windows are ka windows of
+// Wb + 1 bits first (the low end), then windows of Wb bits, signed digits throughout; ka = 0 is a uniform table of Wb-bit windows (the
+// only form of the unsigned widths 4, 8, 16).  With two widths the windows can be sized TO THE BIT: a signed recoding needs 258 bits of
+// windows (256 + the carry of the offset + the top digit's sign), so n windows need Wb = floor(258 / n), ka = 258 - n Wb -- e.g. 523 =
+// 5 x 24 + 6 x 23 bits: 11 table additions per scalar from 4.3 GB per generator, where 11 uniform windows (24 bits) take 5.9 GB and the
+// 1.6 GB of 22-bit windows give 12.
+HD int fb_wb(int code) { return code % 100; }
+HD int fb_ka(int code) { return code / 100; }
+HD bool fb_signed(int code) {
+    const int W = fb_wb(code);
+    return fb_ka(code) > 0 || W == 20 || W == 10 || W == 22 || W == 18 || W == 19 || W == 24;
+}
+HD int fb_nwin(int code) {                                       // uniform signed: ceil(257 / W) windows (>= 258 bits for every width in use)
+    const int W = fb_wb(code), ka = fb_ka(code);
+    if (!fb_signed(code)) return 256 / W;
+    return ka ? (258 - ka + W - 1) / W : (257 + W - 1) / W;
+}
+HD size_t fb_per_narrow(int code) { const int W = fb_wb(code); return fb_signed(code) ? ((size_t)1 << (W - 1)) : (((size_t)1 << W) - 1); }   // entries of a Wb-bit window
+HD size_t fb_per_base(int code) { return fb_per_narrow(code) * (size_t)(fb_nwin(code) + fb_ka(code)); }                                       // entries of one generator
+HD int fb_pos(int code, int w) { const int ka = fb_ka(code); return fb_wb(code) * w + (w < ka ? w : ka); }                                    // first bit of window w
+HD size_t fb_per_win_at(int code, int w) { return fb_per_narrow(code) << (w < fb_ka(code) ? 1 : 0); }
+HD size_t fb_win_off(int code, int w) { const int ka = fb_ka(code); return fb_per_narrow(code) * (size_t)(w + (w < ka ? w : ka)); }           // entries of a generator before window w
 HD FbTable fb_of(const VerifyWs& ws) { FbTable f = {ws.fb_table, ws.fb_w, ws.N, ws.fb_table_hi, ws.fb_w_hi, ws.fb_hi_bases}; return f; }
-// windows a scalar below 2^bits can reach (0 = full width).  Signed digits: the recoded value is sum d_i 2^(W i) with d_i in
-// [-2^(W-1), 2^(W-1)), and the top digit absorbs a carry of at most one, so ceil((bits + 1) / W) windows hold everything.
-HD int fb_windows_for(int bits, int W) {
-    const int all = fb_nwin(W);
+// windows a scalar below 2^bits can reach (0 = full width).  Signed digits: the recoded value is sum d_i 2^(pos i) with d_i in
+// [-2^(width_i - 1), 2^(width_i - 1)), and the top digit absorbs a carry of at most one, so the windows up to bit `bits` (inclusive)
+// hold everything: ceil((bits + 1) / W) of a uniform table.
+HD int fb_windows_for(int bits, int code) {
+    const int all = fb_nwin(code);
     if (bits <= 0) return all;
-    const int need = fb_signed(W) ? (bits + 1 + W - 1) / W : (bits + W - 1) / W;
+    const int W = fb_wb(code), ka = fb_ka(code);
+    if (!fb_signed(code)) { const int need = (bits + W - 1) / W; return need < all ? need : all; }
+    int need = (bits + 1 + W) / (W + 1);                    // all of them wide ...
+    if (need > ka) need = (bits + 1 - ka + W - 1) / W;      // ... or the ka wide ones and narrow ones for the rest
     return need < all ? need : all;
 }
 // index (within its run) of the a-th PRESENT term
@@ -288,25 +311,33 @@ HD int fb_term_index(int a, int oddsh) {
 // its first window was reached, and a table address is an increment -- no division, no per-window recoding, no choice by window
 // width (round 4's loop made that choice per step: 12.8 % of its dynamic instructions were scalar-unit bookkeeping).
 struct FbGeom {
-    const apt_packed* table;       // the region's entries: base b, window w at table[((b - base0) nwin + w) per_win ...]
+    const apt_packed* table;       // the region's entries: base b, window w at table[(b - base0) per_base + per_win (w + min(w, ka)) ...]
     int base0;
-    int W, nwin;           // window width; windows of a full-width scalar
-    u32 mask, half;        // 2^W - 1; 2^(W-1) for signed digits (the digit is field - half), 0 for unsigned ones
-    size_t per_win;        // entries per window
-    u32 off[9];            // signed digits: sum_i 2^(W-1 + W i) -- k + off carries digit + 2^(W-1) in every W-bit field
+    int code;              // the region's window code (fb_wb: code = W + 100 ka)
+    int W, ka, nwin;       // width of the narrow windows; wide (W + 1-bit) windows at the low end; windows of a full-width scalar
+    u32 mask, half;        // of a narrow window: 2^W - 1; 2^(W-1) for signed digits (the digit is field - half), 0 for unsigned ones
+    size_t per_win;        // entries of a narrow window (a wide one has twice as many)
+    size_t per_base;       // entries of one generator
+    u32 off[9];            // signed digits: sum_i 2^(top bit of window i) -- k + off carries digit + half in every field
 };
-HD void fb_geom_w(FbGeom& g, int W) {
-    g.W = W;
-    g.nwin = fb_nwin(W);
-    g.per_win = fb_per_win(W);
-    g.mask = (1u << W) - 1u;
-    g.half = fb_signed(W) ? (1u << (W - 1)) : 0u;
+HD bool fb_wide(const FbGeom& g, int w) { return w < g.ka; }
+HD u32 fb_mask_at(const FbGeom& g, int w) { return fb_wide(g, w) ? ((g.mask << 1) | 1u) : g.mask; }
+HD u32 fb_half_at(const FbGeom& g, int w) { return fb_wide(g, w) ? (g.half << 1) : g.half; }
+HD void fb_geom_w(FbGeom& g, int code) {
+    g.code = code;
+    g.W = fb_wb(code);
+    g.ka = fb_ka(code);
+    g.nwin = fb_nwin(code);
+    g.per_win = fb_per_narrow(code);
+    g.per_base = fb_per_base(code);
+    g.mask = (1u << g.W) - 1u;
+    g.half = fb_signed(code) ? (1u << (g.W - 1)) : 0u;
 #pragma unroll
     for (int l = 0; l < 9; l++) g.off[l] = 0;
-    if (fb_signed(W)) {
+    if (fb_signed(code)) {
 #pragma nounroll
         for (int i = 0; i < g.nwin; i++) {
-            const int bit = W - 1 + W * i;
+            const int bit = fb_pos(code, i + 1) - 1;         // the window's top bit
 #pragma unroll
             for (int l = 0; l < 9; l++) g.off[l] |= (l == (bit >> 5)) ? (1u << (bit & 31)) : 0u;
         }
@@ -318,29 +349,31 @@ HD void fb_geom(FbGeom& g, const FbTable& f, bool hi) {
     fb_geom_w(g, hi ? f.W_hi : f.W);
 }
 HD bool fb_in_hi(const FbTable& f, int base) { return base < f.hi_bases; }
-HD const apt_packed* fb_window(const FbGeom& g, int base, int w) { return g.table + ((size_t)(base - g.base0) * g.nwin + w) * g.per_win; }
+HD const apt_packed* fb_window(const FbGeom& g, int base, int w) {
+    return g.table + (size_t)(base - g.base0) * g.per_base + g.per_win * (size_t)(w + (w < g.ka ? w : g.ka));
+}
 HD void fb_recode(u32 kp[9], const u32 k[8], const FbGeom& g) {      // kp = k + off, 9 limbs (< 2^264)
     u32 c = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) kp[i] = addc(k[i], g.off[i], c);
     kp[8] = g.off[8] + c;
 }
-// the W-bit field of window w of the recoded scalar (w differs from lane to lane: selects)
+// the field of window w of the recoded scalar (w differs from lane to lane: selects)
 HD u32 fb_field(const u32 k[8], int w, const FbGeom& g) {
     u32 kp[10];
     fb_recode(kp, k, g);
     kp[9] = 0;
-    const int bit = g.W * w, li = bit >> 5, sh = bit & 31;
+    const int bit = g.W * w + (w < g.ka ? w : g.ka), li = bit >> 5, sh = bit & 31;
     u32 lo = 0, hi = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) { lo = (i == li) ? kp[i] : lo; hi = (i == li) ? kp[i + 1] : hi; }
-    return (u32)((((u64)hi << 32) | lo) >> sh) & g.mask;
+    return (u32)((((u64)hi << 32) | lo) >> sh) & fb_mask_at(g, w);
 }
 // digit of window w: returns the table index (|d| - 1), whether to skip (d == 0) and whether to negate
 HD void fb_digit(const u32 k[8], int W, int w, size_t& idx, bool& skip, bool& neg) {
     FbGeom g;
     fb_geom_w(g, W);
-    const int d = (int)fb_field(k, w, g) - (int)g.half;
+    const int d = (int)fb_field(k, w, g) - (int)fb_half_at(g, w);
     const u32 mag = (u32)(d < 0 ? -d : d);
     idx = mag ? (size_t)(mag - 1) : 0;
     skip = mag == 0;
@@ -349,7 +382,7 @@ HD void fb_digit(const u32 k[8], int W, int w, size_t& idx, bool& skip, bool& ne
 // one table addition with the complete law (the provers' small sums, commit_value, and the re-do of a sum whose fast form met an
 // exceptional addition)
 HD void fb_lookup_add(pt& acc, const FbGeom& g, int base, int w, const u32 k[8]) {
-    const int d = (int)fb_field(k, w, g) - (int)g.half;
+    const int d = (int)fb_field(k, w, g) - (int)fb_half_at(g, w);
     const u32 mag = (u32)(d < 0 ? -d : d);
     const apt_packed* tb = fb_window(g, base, w);
     const size_t idx = mag ? (size_t)(mag - 1) : 0;
@@ -368,7 +401,7 @@ HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, 
     for (int j = 0; j < count; j++) {
         FbGeom g;
         fb_geom(g, fbt, fb_in_hi(fbt, first_base + j));
-        const int nwin = fb_windows_for(bits, g.W);     // bits > 0: the scalars are below 2^bits -- only the windows they can reach
+        const int nwin = fb_windows_for(bits, g.code);  // bits > 0: the scalars are below 2^bits -- only the windows they can reach
         u32 k[8];
         ws_ld8(k, scal, fbt.N, t, first_slot + j);
 #pragma nounroll
@@ -384,7 +417,7 @@ HD void fixed_base_msm(pt& accp, const FbTable& fbt, size_t t, const u32* scal, 
 #define BPPP_FB_LANES 8
 HD void fixed_base_msm_partial(pt& accp, const FbGeom& g, size_t N, size_t t, int lane, const u32* scal, int first_slot, int first_base,
                                int count, int nl = BPPP_FB_LANES, int bits = 0, int oddsh = -1) {
-    const int nwin = fb_windows_for(bits, g.W);
+    const int nwin = fb_windows_for(bits, g.code);
     pt acc;
     pt_set_identity(acc);
     // the (term, window) pairs of the run, window-fastest, dealt round-robin over the lanes (the fast form's dealing: verify_core.h,
@@ -433,8 +466,8 @@ struct FbStep {          // where a step's table entry lives, and how to use it
     const apt_packed* ptr;
     bool skip, neg;
 };
-HD void fb_step_from_field(FbStep& st, const apt_packed* win, u32 field, const FbGeom& g) {
-    const int d = (int)field - (int)g.half;
+HD void fb_step_from_field(FbStep& st, const apt_packed* win, u32 field, u32 half) {
+    const int d = (int)field - (int)half;
     const u32 mag = (u32)(d < 0 ? -d : d);
     st.skip = mag == 0;
     st.neg = d < 0;
@@ -454,7 +487,7 @@ HD void fb_consume_fast(ptz& acc, bool& empty, const apt_packed& pe, bool skip, 
 // here: the window's base address lives in scalar registers and moves by per_win entries per step.
 HD void fb_lane_accumulate_seq(ptz& acc, bool& empty, const FbTable& fbt, const FbGeom& g, size_t t, const u32* scal, int first_slot,
                                int first_base, int count, int bits, int oddsh) {
-    const int nw = fb_windows_for(bits, g.W);          // windows walked per scalar
+    const int nw = fb_windows_for(bits, g.code);       // windows walked per scalar
     const int steps = count * nw;
     if (steps <= 0) return;
     // the producer hands out window pw of term pa next; past the last term it walks the last term again (requested, never consumed)
@@ -473,11 +506,13 @@ HD void fb_lane_accumulate_seq(ptz& acc, bool& empty, const FbTable& fbt, const 
             fb_recode(kp, k, g);
             pw = 0;
         }
-        fb_step_from_field(st, win, kp[0] & g.mask, g);
+        const bool wide = pw < g.ka;                       // (wave-uniform: scalar registers)
+        const int width = g.W + (wide ? 1 : 0);
+        fb_step_from_field(st, win, kp[0] & (wide ? ((g.mask << 1) | 1u) : g.mask), wide ? (g.half << 1) : g.half);
 #pragma unroll
-        for (int i = 0; i < 8; i++) kp[i] = funnel_shr(kp[i + 1], kp[i], g.W);
-        kp[8] >>= g.W;
-        win += g.per_win;
+        for (int i = 0; i < 8; i++) kp[i] = funnel_shr(kp[i + 1], kp[i], width);
+        kp[8] >>= width;
+        win += wide ? 2 * g.per_win : g.per_win;
         pw++;
     };
     FbStep cur_st, nxt_st;
@@ -509,7 +544,7 @@ HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, const
         fb_lane_accumulate_seq(acc, empty, fbt, g, t, scal, first_slot, first_base, count, bits, oddsh);
         return;
     }
-    const int nw = fb_windows_for(bits, g.W);
+    const int nw = fb_windows_for(bits, g.code);
     const int pairs = count * nw;
     if (lane >= pairs) return;
     const int steps = (pairs - lane + nl - 1) / nl;
@@ -524,7 +559,7 @@ HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, const
     };
     auto produce = [&](FbStep& st, const u32 k[8]) {      // k: the scalar of term a
         const int j = fb_term_index(a, oddsh);
-        fb_step_from_field(st, fb_window(g, first_base + j, w), fb_field(k, w, g), g);
+        fb_step_from_field(st, fb_window(g, first_base + j, w), fb_field(k, w, g), fb_half_at(g, w));
     };
     u32 k[8];
     FbStep cur_st, nxt_st;
@@ -2652,40 +2687,42 @@ HD void sec1_compress_lane(uint8_t* commitments33, uint8_t* proofs525, const uin
 #define BPPP_FB_CHUNK 256
 struct FbBuild {
     const apt* gens;        // [nbases]
-    int nbases, W;
-    apt_packed* table;      // [nbases][nwin][2^W - 1], packed canonical affine
+    int nbases, W;          // W: the region's window code (fb_wb)
+    apt_packed* table;      // [nbases][fb_per_base(W)], packed canonical affine
     fe *xtmp, *ytmp, *ztmp; // projective coordinates of the entries of THIS pass (pass 1 -> pass 2)
     fe* ptmp;               // prefix products of Z
     int base0, nb;          // the bases built by this pass: base0 .. base0 + nb - 1 (the scratch holds nb bases' worth of entries)
     int tbase0;             // the generator whose entries open `table` (0, or FbTable::hi_bases for the region that holds the rest)
 };
-HD size_t fb_chunks_per_window(int W) { return (fb_per_win(W) + BPPP_FB_CHUNK - 1) / BPPP_FB_CHUNK; }
+HD size_t fb_chunks_per_window(int code) { return (fb_per_win_at(code, 0) + BPPP_FB_CHUNK - 1) / BPPP_FB_CHUNK; }     // of the widest window (a narrow one uses the first half)
 HD void fb_build_pass1(const FbBuild& fb, size_t tid) {
     const int nwin = fb_nwin(fb.W);
-    const size_t per_win = fb_per_win(fb.W);
     const size_t cpw = fb_chunks_per_window(fb.W);
     size_t c = tid % cpw;
     size_t w = (tid / cpw) % nwin;
     size_t b = tid / (cpw * nwin);
     if (b >= (size_t)fb.nb) return;
+    const size_t per_win = fb_per_win_at(fb.W, (int)w);
+    size_t d0 = c * BPPP_FB_CHUNK;   // entries d0+1 .. min(d0+CH, per_win)
+    if (d0 >= per_win) return;
     apt G = fb.gens[fb.base0 + b];
     pt base;
     pt_from_affine(base, G);
+    const int pos = fb_pos(fb.W, (int)w);
 #pragma nounroll
-    for (size_t i = 0; i < w * (size_t)fb.W; i++) pt_dbl(base, base);
-    // start = (c*CH + 1) * base by double-and-add over the (<= 22-bit) multiplier
+    for (int i = 0; i < pos; i++) pt_dbl(base, base);
+    // start = (c*CH + 1) * base by double-and-add over the (<= 24-bit) multiplier
     u32 m = (u32)(c * BPPP_FB_CHUNK + 1);
     pt cur;
     pt_set_identity(cur);
 #pragma nounroll
-    for (int bit = 22; bit >= 0; bit--) {
+    for (int bit = 24; bit >= 0; bit--) {
         pt_dbl(cur, cur);
         pt s;
         pt_add(s, cur, base);
         pt_cmov(cur, (m >> bit) & 1, s);
     }
-    size_t d0 = c * BPPP_FB_CHUNK;   // entries d0+1 .. min(d0+CH, per_win)
-    size_t off = (b * nwin + w) * per_win;
+    size_t off = b * fb_per_base(fb.W) + fb_win_off(fb.W, (int)w);
 #pragma nounroll
     for (size_t i = 0; i < BPPP_FB_CHUNK && d0 + i < per_win; i++) {
         fb.xtmp[off + d0 + i] = cur.X;
@@ -2696,15 +2733,16 @@ HD void fb_build_pass1(const FbBuild& fb, size_t tid) {
 }
 HD void fb_build_pass2(const FbBuild& fb, size_t tid) {
     const int nwin = fb_nwin(fb.W);
-    const size_t per_win = fb_per_win(fb.W);
     const size_t cpw = fb_chunks_per_window(fb.W);
     size_t c = tid % cpw;
     size_t w = (tid / cpw) % nwin;
     size_t b = tid / (cpw * nwin);
     if (b >= (size_t)fb.nb) return;
+    const size_t per_win = fb_per_win_at(fb.W, (int)w);
     size_t d0 = c * BPPP_FB_CHUNK;
-    size_t off = (b * nwin + w) * per_win + d0;                            // within this pass's scratch
-    const size_t toff = ((size_t)(fb.base0 - fb.tbase0) * nwin) * per_win; // this pass's first table entry
+    if (d0 >= per_win) return;
+    size_t off = b * fb_per_base(fb.W) + fb_win_off(fb.W, (int)w) + d0;    // within this pass's scratch
+    const size_t toff = (size_t)(fb.base0 - fb.tbase0) * fb_per_base(fb.W); // this pass's first table entry
     size_t cnt = per_win - d0 < BPPP_FB_CHUNK ? per_win - d0 : BPPP_FB_CHUNK;
     // identity entries (Z = 0; only when the generator itself is the identity) are skipped in the product
     fe run;

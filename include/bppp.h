@@ -68,21 +68,22 @@ typedef struct bppp_ctx bppp_ctx;
 
 /* U64RangeProofProtocol { g, g_vec[16], h_vec[32] } (u64_proof.rs:19-28) bound to GPU `device`.
  * Builds the fixed-base tables for the 49 generators on the GPU.  fb_window_bits: 0 = the library's choice from the HBM that is FREE on
- * the device when the context is created (hipMemGetInfo).  First choice for this generator shape, when it takes at most 55 % of that
- * memory: a table in TWO regions -- g and g_vec, the 17 generators that both fixed-base sums of a verify run over, at signed 24-bit
- * windows (11 additions per scalar, 100 GB), h_vec at 22 bits (12 additions, 52 GB): 758 instead of 792 table additions per proof,
- * 1 % per 2^20-proof batch and 2 % per 2^17-proof batch over one 22-bit table (bppp_ctx_get_option "fb_window_bits_hi" = 24,
- * "fb_hi_bases" = 17, "fb_window_bits" = 22; such a context cannot be saved with bppp_ctx_save_tables; BPPP_NO_MIXED_WINDOWS=1 in
- * the environment keeps one table).  Otherwise the widest windows among {22, 20, 19, 18, 16, 8, 4}
- * whose tables take at most 35 % of the free HBM and whose build
- * scratch still fits beside them; should that allocation fail anyway, the next narrower width is tried (bppp_ctx_get_option
- * "fb_window_bits" tells which one was taken).  One table for the 49 generators: 22 (signed 22-bit
- * digits: 49 x 12 x 2^21 affine points = 79 GB, 12 table additions per
- * scalar, built in passes with <= 32 GB of temporaries; 2.4-3.1 % faster end to end on a 2^20-proof batch than 20); 20 (signed, 49
- * x 13 x 2^19 points = 21 GB, 13 additions per scalar: the choice when HBM is shared with something else); 16 (unsigned, 3.3 GB,
- * 16 additions); 18, 19 (signed, 15 / 14 additions: for large generator sets with HBM to spare -- 769 generators: 97 / 181 GB);
- * 4, 8, 10 (small tables for tests).  For bppp_wnla_ctx_create the one-table rule over 1 + ng + nh generators (769 generators: 18-bit
- * windows, 97 GB).  bppp_ctx_save_tables / bppp_ctx_create_from_tables keep a built table set as a file. */
+ * the device when the context is created (hipMemGetInfo): the FEWEST windows (= table additions) per scalar whose tables fit.  The
+ * windows of a scalar come in two widths sized to the bit -- a signed recoding needs 258 bits of windows, so n windows are
+ * floor(258 / n)-bit windows with 258 mod n of them one bit wider -- and a layout is named by its WINDOW CODE Wb + 100 ka (ka windows of
+ * Wb + 1 bits at the low end, then windows of Wb bits): 523 = 11 windows (5 x 24 + 6 x 23 bits), 4.3 GB per generator; 621 = 12 windows,
+ * 1.2 GB; 1119 = 13, 403 MB; 618 = 14, 168 MB; 317 = 15, 75 MB; 216 = 16, 38 MB; ... 208 = 32 windows, 278 KB.  A table fits when it
+ * takes at most 76 % of the free memory, leaves 50 GB of it (or half, if less is free) and its build scratch fits beside it; should
+ * the allocation fail anyway, the next count is tried.  On an otherwise empty MI355X the 49 generators get 11 windows (210 GB: 726 table
+ * additions per proof); when that does not fit, this generator shape takes a table in TWO regions -- g and g_vec, the 17 generators that
+ * both fixed-base sums of a verify run over, at 11 windows, h_vec at 12: 112 GB, 758 additions ("fb_window_bits_hi" = 523, "fb_hi_bases"
+ * = 17, "fb_window_bits" = 621) -- and below that the general rule (BPPP_NO_WIDE_TABLES=1 / BPPP_NO_MIXED_WINDOWS=1 in the environment
+ * skip the first / the first two).  bppp_ctx_get_option "fb_window_bits" tells which layout was taken.
+ * An explicit fb_window_bits is a window code as above (any that tiles 258 bits with windows of 8 .. 24 bits) or one of the uniform
+ * widths 22, 20, 19, 18, 10 (signed digits: ceil(257 / W) windows of 2^(W-1) entries), 16, 8, 4 (unsigned digits, 256 / W windows of
+ * 2^W - 1 entries; 4 is the layout of the "ct_prover" tables).  For bppp_wnla_ctx_create the general rule over 1 + ng + nh generators
+ * (769 generators: 14 windows, 129 GB).  bppp_ctx_save_tables / bppp_ctx_create_from_tables keep a built table set of a UNIFORM width
+ * as a file. */
 BPPP_API int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec /* 16 x 64 */,
                     const uint8_t* h_vec /* 32 x 64 */, int device, int fb_window_bits);
 BPPP_API void bppp_ctx_destroy(bppp_ctx* ctx);

@@ -151,13 +151,13 @@ void emul_merlin_kat(const uint8_t* label, size_t label_len, const uint8_t* m1, 
     t_append(t, "some label", m1, (u32)m1_len);
     t_challenge_bytes(t, "challenge", out, (u32)out_len);
 }
-size_t emul_fb_table_entries(int nbases, int W) { return (size_t)nbases * fb_nwin(W) * fb_per_win(W); }
+size_t emul_fb_table_entries(int nbases, int W) { return (size_t)nbases * fb_per_base(W); }
 int emul_fb_build(const uint8_t* gens, int nbases, int W, uint8_t* table_out /* entries x 64 B, LE limbs as device */) {
     std::vector<apt> g(nbases);
     for (int i = 0; i < nbases; i++) if (!apt_from_xy64(g[i], gens + 64 * i)) return -1;
     size_t entries = emul_fb_table_entries(nbases, W);
     // in passes of two bases, as the library does for tables too large to build at once
-    const size_t per_base = (size_t)fb_nwin(W) * fb_per_win(W), group = 2, gentries = group * per_base;
+    const size_t per_base = fb_per_base(W), group = 2, gentries = group * per_base;
     (void)entries;
     std::vector<fe> tmp(gentries * 4);
     for (int b0 = 0; b0 < nbases; b0 += (int)group) {
@@ -169,6 +169,12 @@ int emul_fb_build(const uint8_t* gens, int nbases, int W, uint8_t* table_out /* 
         for (size_t t = 0; t < nthreads; t++) fb_build_pass2(fb, t);
     }
     return 0;
+}
+// geometry of a window code (verify_core.h: fb_wb): out = {windows, first bit of window w, entries of window w, entries of a generator
+// before window w, entries per generator, windows a scalar below 2^bits reaches}
+void emul_fb_shape(int W, int w, int bits, uint64_t out[6]) {
+    out[0] = (uint64_t)fb_nwin(W); out[1] = (uint64_t)fb_pos(W, w); out[2] = fb_per_win_at(W, w); out[3] = fb_win_off(W, w);
+    out[4] = fb_per_base(W); out[5] = (uint64_t)fb_windows_for(bits, W);
 }
 // signed / unsigned window digit of scalar k (fb_digit): magnitude index, skip and negate flags
 int emul_fb_digit(int W, const uint8_t k[32], int w, uint64_t* idx, int* skip, int* neg) {

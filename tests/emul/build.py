@@ -66,6 +66,8 @@ def load():
     L.emul_set_final_scalars_lg.restype = None
     L.emul_set_shared_inv.argtypes = [i32]
     L.emul_set_shared_inv.restype = None
+    L.emul_fb_shape.argtypes = [i32, i32, i32, vp]
+    L.emul_fb_shape.restype = None
     L.emul_fe_batch_inv.argtypes = [i32, sz, cp, vp, i32]
     L.emul_plan_rlc.argtypes = [C.c_uint, i32, i32, C.c_double, vp]
     L.emul_plan_rlc.restype = None

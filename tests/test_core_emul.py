@@ -244,7 +244,52 @@ def test_fixed_base_window_digits_recompose_the_scalar(L, W):
         assert total == k
 
 
-@pytest.mark.parametrize("W", [4, 8, 10])
+# window codes with two widths (verify_core.h: fb_wb): code = Wb + 100 ka -- ka windows of Wb + 1 bits, then windows of Wb bits
+MIXED_CODES = [609, 310, 208, 523, 618, 1119]
+
+
+def _shape(L, code, w=0, bits=0):
+    out = (C.c_uint64 * 6)()
+    L.emul_fb_shape(code, w, bits, out)
+    return dict(nwin=out[0], pos=out[1], per_win=out[2], off=out[3], per_base=out[4], windows_for=out[5])
+
+
+@pytest.mark.parametrize("code", MIXED_CODES)
+def test_two_width_window_geometry_and_digits(L, code):
+    """Tables whose windows are sized to the bit (round 5): the windows tile at least 258 bits without gaps, the entries of a generator
+    are laid out window after window, a scalar below 2^bits reaches exactly the windows up to bit `bits`, and the signed digits
+    recompose every scalar -- the extreme ones included (all digits at either end of their range, carries into the top window)."""
+    Wb, ka = code % 100, code // 100
+    nwin = _shape(L, code)["nwin"]
+    assert nwin == -(-(258 - ka) // Wb) and Wb * nwin + ka >= 258
+    pos = off = 0
+    for w in range(nwin):
+        sh = _shape(L, code, w)
+        width = Wb + (1 if w < ka else 0)
+        assert sh["pos"] == pos and sh["off"] == off and sh["per_win"] == 1 << (width - 1)
+        pos += width
+        off += sh["per_win"]
+    assert _shape(L, code)["per_base"] == off
+    if code == 523:
+        assert nwin == 11 and off == 5 * 2**23 + 6 * 2**22      # 4.3 GB per generator
+    for bits in (1, 4, 8, 63, 64, 65, 127, 128, 200, 255):
+        need = next(n for n in range(1, nwin + 1) if _shape(L, code, n)["pos"] >= bits + 1 or n == nwin)
+        assert _shape(L, code, 0, bits)["windows_for"] == need, bits
+    rnd = random.Random(code)
+    idx, skip, neg = C.c_uint64(), C.c_int(), C.c_int()
+    tops = [_shape(L, code, w + 1)["pos"] - 1 for w in range(nwin)]
+    edge = [sum(1 << t for t in tops if t < 256) % O.N, (sum(1 << t for t in tops if t < 255) - 1) % O.N, O.N - 2**234, O.N - 1 - 2**233]
+    for k in [0, 1, O.N - 1, 2**255, 2**256 % O.N, int("8" * 64, 16) % O.N, int("7" * 64, 16)] + edge + [rnd.getrandbits(256) % O.N for _ in range(40)]:
+        total = 0
+        for w in range(nwin):
+            assert L.emul_fb_digit(code, b32(k), w, C.byref(idx), C.byref(skip), C.byref(neg)) == nwin
+            d = 0 if skip.value else (idx.value + 1)
+            assert d <= _shape(L, code, w)["per_win"]
+            total += (-d if neg.value else d) << _shape(L, code, w)["pos"]
+        assert total == k
+
+
+@pytest.mark.parametrize("W", [4, 8, 10, 609, 310])
 def test_fixed_base_tables(L, gold, W):
     gens = bytes.fromhex(gold["generators"])
     g3 = gens[:128] + bytes(64)                  # two generators + the identity as a (degenerate but legal) generator
@@ -259,7 +304,7 @@ def test_fixed_base_tables(L, gold, W):
         assert out.raw == O.pt_to_xy64(exp)
 
 
-@pytest.mark.parametrize("W", [4, 8, 10])
+@pytest.mark.parametrize("W", [4, 8, 10, 609])
 def test_fixed_base_fast_accumulator_and_its_fallback(L, gold, W):
     """The device's fixed-base lane sums use an incomplete (XYZZ) accumulator with deferred exception detection.  Independent
     generators never trip it.  A REPEATED generator with equal window digits makes a lane add a table entry to itself: the sums that
@@ -292,7 +337,8 @@ def test_fixed_base_fast_accumulator_and_its_fallback(L, gold, W):
     ent = L.emul_fb_table_entries(5, W)
     tab = np.zeros(ent * 64, dtype=np.uint8)
     assert L.emul_fb_build(gd, 5, W, tab.ctypes.data) == 0
-    cases = [[7, 0, 0, 0, 7], [3 << (2 * W), 0, 0, 0, 3 << (2 * W)], [5 << (8 * W), 0, 0, 0, 5 << (8 * W)],
+    Wn = W % 100
+    cases = [[7, 0, 0, 0, 7], [3 << (2 * Wn + 2), 0, 0, 0, 3 << (2 * Wn + 2)], [5 << (8 * Wn + 6), 0, 0, 0, 5 << (8 * Wn + 6)],
              [7, 1, 2, 3, 7], [11, 0, 0, 0, 12], [int("5" * 64, 16) % O.N] * 5]
     for nl in (1, 8, 64):
         hits = 0
@@ -303,13 +349,13 @@ def test_fixed_base_fast_accumulator_and_its_fallback(L, gold, W):
                 exp = O.pt_add(exp, O.pt_mul(Gi, k))
             assert out.raw == O.pt_to_xy64(exp)
             hits += fb.value
-        if nl == 64 and (4 * (256 // W)) % 64 == 0:       # copies 0 and 4 land on one lane when 4 * windows is a multiple of 64 (W = 4, 8)
+        if nl == 64 and W < 100 and (4 * (256 // W)) % 64 == 0:       # copies 0 and 4 land on one lane when 4 * windows is a multiple of 64 (W = 4, 8)
             assert hits >= 3          # the self-additions were detected (and re-done), not silently mis-added
         if nl < 64:
             assert hits == 0          # from the offset point the same sums are ordinary additions
 
 
-@pytest.mark.parametrize("W_hi,W_lo", [(10, 8), (10, 4), (8, 10)])
+@pytest.mark.parametrize("W_hi,W_lo", [(10, 8), (10, 4), (8, 10), (609, 10), (10, 310)])
 def test_fixed_base_sums_over_a_table_in_two_regions(L, gold, W_hi, W_lo):
     """FbTable's second region (round 5: the 17 generators both fixed-base sums of a u64 verify run over get 24-bit windows, the other 32
     keep 22): the first hi_bases generators in one table at one width, the rest in another table at another width, counted from 0.
@@ -361,7 +407,7 @@ def test_shared_inversion_of_a_batch(L, G):
 # shared: proofs per shared field inversion (plan_core.h: shared_inv -- the table build in five passes and the rounds take 1 / v from
 # fe_batch_inv_lane instead of inverting per proof; the emulator also checks the tables bit for bit against the one-pass build)
 @pytest.mark.parametrize("shared", [0, 2, 4, 8, 16])
-@pytest.mark.parametrize("W", [4, 10])            # 10 = the signed-window scheme (26 windows: pairs dealt round-robin over the lanes)
+@pytest.mark.parametrize("W", [4, 10, 609])       # 10 = the signed-window scheme (26 windows: pairs dealt round-robin over the lanes); 609 = windows of two widths (6 x 10 + 22 x 9 bits)
 def test_full_verify_pipeline_against_golden(L, gold, oracle_c, W, shared):
     L.emul_set_shared_inv(shared)
     try:
@@ -394,12 +440,12 @@ def _full_verify_pipeline_against_golden(L, gold, oracle_c, W):
             assert rc == items[k][2] and bytes(tr[k]) == otr
 
 
-def test_full_prove_pipeline_is_byte_identical_to_the_oracle(L, gold, oracle_c):
+@pytest.mark.parametrize("W", [4, 609])           # 609: windows of two widths -- the prover's short scalars (digits, multiplicities, u64 values) stop at the windows they reach
+def test_full_prove_pipeline_is_byte_identical_to_the_oracle(L, gold, oracle_c, W):
     """The device prover code (prove_core.h) on CPU: proofs must equal the reference-shaped prover's bytes for the same
     (x, s, 52 random scalars), on the golden cases and on fresh seeded cases incl. x = 0 and x = 2^64 - 1."""
     import workload
     gens, label = bytes.fromhex(gold["generators"]), bytes.fromhex(gold["label"])
-    W = 4
     ent = L.emul_fb_table_entries(49, W)
     tab = np.zeros(ent * 64, dtype=np.uint8)
     assert L.emul_fb_build(gens, 49, W, tab.ctypes.data) == 0

@@ -118,38 +118,40 @@ def test_generic_host_paths_report_nomem_and_recover():
 
 
 def test_default_window_width_follows_free_memory(monkeypatch):
-    """fb_window_bits = 0: the widest of {22, 20, 19, 18, 16, 8, 4} whose tables take <= 35 % of the FREE HBM (hipMemGetInfo at creation;
-    19 and 18 joined the list in round 5: the 769 generators of BASELINE configs[4]'s shape get 18 bits, 97 GB, instead of 16);
-    BPPP_ASSUME_FREE_GB stands in for a device that is already partly taken.  Verdicts are the same at every width."""
+    """fb_window_bits = 0 takes the FEWEST windows per scalar whose tables fit the free HBM (hipMemGetInfo at creation; BPPP_ASSUME_FREE_GB
+    stands in for a device that is already partly taken), the windows in two widths sized to the bit (code Wb + 100 ka): 11 windows
+    (523: 5 x 24 + 6 x 23 bits, 210 GB for the 49 generators) on an empty MI355X, then 12 (621, 59 GB), 13 (1119, 20 GB), 14 (618,
+    8 GB), 15 (317, 3.7 GB) ... as less is free -- at most 76 % of it, leaving 50 GB or half of it.  In between, for this generator
+    shape, two regions (g and g_vec at 11 windows, h_vec at 12: 112 GB).  Verdicts and commitments are the same in every layout."""
     import workload
     from bp_pp_amd import U64RangeProofProtocol
     g, gv, hv = workload.split_generators(workload.generators())
     _, V, P, _ = workload.make_batch(20, first=10)
     P, expect = workload.corrupt(P, V, every=5)
-    for free_gb, want in ((300, 22), (100, 20), (58, 19), (30, 18), (14, 16), (1.0, 8), (0.001, 4)):
+    x = np.array([0, 7, 2**64 - 1], dtype=np.uint64)
+    sb = np.frombuffer(bytes(range(96)), dtype=np.uint8).reshape(3, 32) & 0x7F
+    ref = {}
+    for free_gb, env, want in ((300, None, (523, 0, 0)), (300, "BPPP_NO_WIDE_TABLES", (621, 523, 17)), (200, None, (621, 523, 17)),
+                               (200, "BPPP_NO_MIXED_WINDOWS", (621, 0, 0)), (100, None, (1119, 0, 0)), (58, None, (1119, 0, 0)),
+                               (30, None, (618, 0, 0)), (14, None, (317, 0, 0)), (1.0, None, (1113, 0, 0)), (0.001, None, (8, 0, 0))):
         monkeypatch.setenv("BPPP_ASSUME_FREE_GB", str(free_gb))
+        if env:
+            monkeypatch.setenv(env, "1")
         p = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=0)
+        if env:
+            monkeypatch.delenv(env)
         try:
-            assert p.get_option("fb_window_bits") == want, (free_gb, p.get_option("fb_window_bits"))
-            # round 5: with 300 GB free the u64 shape gets its table in two regions -- g and g_vec (17 generators) at 24 bits, h_vec at 22
-            assert (p.get_option("fb_window_bits_hi"), p.get_option("fb_hi_bases")) == ((24, 17) if free_gb == 300 else (0, 0))
+            got = (p.get_option("fb_window_bits"), p.get_option("fb_window_bits_hi"), p.get_option("fb_hi_bases"))
+            assert got == want, (free_gb, env, got)
             acc, st = p.verify_batch(V, P, workload.LABEL)
             assert (acc == expect).all() and not st.any()
-            if free_gb == 300:
+            cv = p.commit_value_batch(x, sb)          # g and h_vec[0]: from both regions where there are two
+            if not ref:
+                ref["cv"] = cv
+            assert (cv == ref["cv"]).all()
+            if want[0] == 523 or want[2]:
                 with pytest.raises(Exception):
-                    p.save_tables("/tmp/never_written.bin")          # two regions: not a saveable layout (create with an explicit width)
-                x = np.array([0, 7, 2**64 - 1], dtype=np.uint64)      # commit_value: g from the wide region, h_vec[0] from the other
-                sb = np.frombuffer(bytes(range(96)), dtype=np.uint8).reshape(3, 32) & 0x7F
-                cv_mixed = p.commit_value_batch(x, sb)
-                monkeypatch.setenv("BPPP_NO_MIXED_WINDOWS", "1")
-                q = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=0)
-                monkeypatch.delenv("BPPP_NO_MIXED_WINDOWS")
-                try:
-                    assert (q.get_option("fb_window_bits"), q.get_option("fb_window_bits_hi")) == (22, 0)      # one table of 79 GB
-                    acc2, st2 = q.verify_batch(V, P, workload.LABEL)
-                    assert (acc2 == acc).all() and (st2 == st).all() and (q.commit_value_batch(x, sb) == cv_mixed).all()
-                finally:
-                    q.close()
+                    p.save_tables("/tmp/never_written.bin")          # not a saveable layout (create with an explicit uniform width)
         finally:
             p.close()
     monkeypatch.delenv("BPPP_ASSUME_FREE_GB")
@@ -157,7 +159,7 @@ def test_default_window_width_follows_free_memory(monkeypatch):
     p = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=0)
     try:
         w1 = p.get_option("fb_window_bits")
-        assert w1 in (22, 20, 19, 18, 16)
+        assert w1 in (523, 621, 1119, 618, 317)
         assert p.get_option("n_generators") == 49 and p.get_option("device") == 0
         with pytest.raises(Exception):
             p.get_option("no such option")

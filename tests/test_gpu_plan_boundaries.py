@@ -109,6 +109,30 @@ def test_shared_inversions_at_the_group_sizes_of_larger_batches(batch, oracle_c,
         p.close()
 
 
+@pytest.mark.parametrize("code", [618, 1119])
+def test_tables_with_windows_of_two_widths(batch, oracle_c, code):
+    """Fixed-base tables whose windows are sized to the bit (the library's own choice on an empty MI355X is 523 = 5 x 24 + 6 x 23 bits,
+    210 GB; 618 = 6 x 19 + 8 x 18 bits and 1119 = 11 x 20 + 2 x 19 bits are the same layout at 8 and 20 GB): the verifier on a
+    wavefront per sum, on 8 lanes and on one lane per sum, and the prover, against the oracle as in the sweeps above."""
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    from bp_pp_amd.range_proof import plan_for
+    g, gv, hv = workload.split_generators(batch["gens"])
+    p = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=code)
+    try:
+        assert p.get_option("fb_window_bits") == code
+        for n in (1000, 20000, 131073):
+            _verify_and_check(batch, p, oracle_c, n, plan_for(n))
+        for n in (3, 3000, 20000):
+            proofs, com, st = p.prove_batch(batch["x"][:n], batch["s"][:n], batch["rnd"][:n], workload.LABEL)
+            assert not st.any() and (com == batch["V"][:n]).all() and (proofs == batch["P"][:n]).all()
+    finally:
+        p.close()
+    for bad in (124, 3008, 507):          # a 25-bit window; more wide windows (30) than windows (29); narrow windows below 8 bits
+        with pytest.raises(Exception):
+            U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=bad)
+
+
 def test_shared_inversions_at_their_own_size_equal_the_per_proof_form(batch, oracle_c, monkeypatch):
     """2^18 + 1 proofs (the fixture's batch twice over: the plan's own G = 8, ragged) with tampered and malformed proofs: accept bits,
     statuses, reject count and ALL 704-byte traces of the call with shared inversions equal those of a context that inverts per proof
