@@ -260,6 +260,13 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
             }
         if (rc != BPPP_OK) return fail(rc);
     }
+    {   // max_batch: the largest part of a verify call whose workspace (about 30 KB per proof) takes at most 70 % of what the tables
+        // left free -- still 2^21 proofs beside the 210 GB an empty MI355X gets (288 GiB = 309 GB), fewer on a device that is shared
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            while (c->max_batch > ((size_t)1 << 16) && (double)c->max_batch * 30e3 > 0.70 * (double)free_b) c->max_batch >>= 1;
+        } else (void)hipGetLastError();
+    }
     *out = c;
     return BPPP_OK;
 }

@@ -103,7 +103,9 @@ BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
  * (testing aid): the k-th device allocation this context makes from now on fails, so the call that makes it returns BPPP_ERR_NOMEM and
  * the context stays usable; 0 clears it.  "max_batch": the u64 verify entry
  * points run a batch of more than max_batch proofs as consecutive parts of max_batch on the same stream, which bounds the per-proof
- * workspace (about 30 KB per proof) whatever n is -- a multiple of 64, >= 1024; default 2097152 (63 GB of workspace).
+ * workspace (about 30 KB per proof) whatever n is -- a multiple of 64, >= 1024; default: the largest power of two up to 2097152 (63 GB of
+ * workspace) that takes at most 70 % of the HBM the tables left free at context creation (still 2097152 beside the 210 GB of tables
+ * an empty MI355X gets: 288 GiB are 309 GB).
  * "rlc_chunk" = 8 | 32 | 0 (default): in the RLC modes of the u64 verifier, the proofs per chunk of the stage behind the bucket stage; 0 = per call,
  * from what the previous RLC call on this context rejected -- chunks of 32 while at most one proof in 256 was bad, and the bucket
  * stage's superchunks halved (or the stage skipped) when most of them would hold a bad proof and fail ("rlc_superchunk" set explicitly

@@ -143,6 +143,8 @@ def test_default_window_width_follows_free_memory(monkeypatch):
         try:
             got = (p.get_option("fb_window_bits"), p.get_option("fb_window_bits_hi"), p.get_option("fb_hi_bases"))
             assert got == want, (free_gb, env, got)
+            # the parts of a large call are sized to what the tables left free (at most 70 % of it): still 2^21 proofs beside the 210 GB
+            assert p.get_option("max_batch") == 1 << 21
             acc, st = p.verify_batch(V, P, workload.LABEL)
             assert (acc == expect).all() and not st.any()
             cv = p.commit_value_batch(x, sb)          # g and h_vec[0]: from both regions where there are two
