@@ -17,6 +17,28 @@ def _dominant(kernel_times):
     return name, t, t["total_ms"] / max(1, t["launches"])
 
 
+def two_passes(proto, step, fence, steps):
+    """(seconds for `steps` steps with kernel timing OFF -- the plan a caller gets, the source of `value` --, seconds for the same steps with
+    per-kernel HIP events on, the per-kernel times of that second pass).  See bench.run_verify."""
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    proto.enable_timing(True)
+    proto.timings(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed_timed = time.perf_counter() - t0
+    kt = {k: v for k, v in proto.timings(reset=True).items() if v["launches"]}
+    proto.enable_timing(False)
+    return elapsed, elapsed_timed, kt
+
+
 def measure_prove(args, proto, gens, total, cpu_baseline=True, cpu_sample=4096, world=1, rank=0):
     """BASELINE configs[3] on an existing u64 context: batch-prove ONE fixed batch of `total` u64 values, this rank's contiguous shard
     of it resident in HBM (u64_proof.rs:57-82 -> circuit.rs:260-556 -> wnla.rs:125-190).  Proofs are independent: with world > 1
@@ -44,27 +66,18 @@ def measure_prove(args, proto, gens, total, cpu_baseline=True, cpu_sample=4096, 
 
     for _ in range(args.warmup):
         step()
-    proto.synchronize()
-    proto.enable_timing(True)
-    proto.timings(reset=True)
-    proto.synchronize()
+    def fence():
+        proto.synchronize()
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    elapsed, elapsed_timed, kt = two_passes(proto, step, fence, args.steps)
+    plan = proto.last_plan(prove=True)
     if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    proto.synchronize()
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, elapsed_timed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kt = {k: v for k, v in proto.timings(reset=True).items() if v["launches"]}
-    proto.enable_timing(False)
+        elapsed, elapsed_timed = float(t[0].item()), float(t[1].item())
     # what was timed is correct: no status flag, and the product verifier accepts every proof
     P, V = dP.cpu().numpy(), dV.cpu().numpy()
     acc, vst = proto.verify_batch(V, P, workload.LABEL)
@@ -85,7 +98,9 @@ def measure_prove(args, proto, gens, total, cpu_baseline=True, cpu_sample=4096, 
                                + "; x, s and the 52 prover scalars per proof resident in HBM, device-side transcripts, proofs byte-identical "
                                "to the CPU prover's for the same draws",
                    "total_proofs_per_step": total, "proofs_per_gpu": n, "fb_window_bits": args.fb_window_bits or "library default",
-                   "label": workload.LABEL.decode(), "parallelism": "single" if world == 1 else f"shard{world}"},
+                   "label": workload.LABEL.decode(), "parallelism": "single" if world == 1 else f"shard{world}", "plan": plan,
+                   "kernel_timing_during_value": False},
+        "timing_pass_ms_per_step": elapsed_timed / args.steps * 1e3,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / bench.HBM_PEAK_GBS,
                      "traffic": bench.pmc_traffic(dom, n), "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
                      "algorithmic_bytes_per_launch": bench.ALGO_BYTES_PER_PROVE * n,
@@ -267,17 +282,8 @@ def measure_recip256(args, total, W, cpu_baseline=True, rlc=True, dist_on=False,
 
     for _ in range(args.warmup):
         step()
-    fence()
-    proto.enable_timing(True)
-    proto.timings(reset=True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
-    kt = {k: v for k, v in proto.timings(reset=True).items() if v["launches"]}
-    proto.enable_timing(False)
+    elapsed, elapsed_timed, kt = two_passes(proto, step, fence, args.steps)
+    elapsed, elapsed_timed = max_over_ranks(elapsed), max_over_ranks(elapsed_timed)
     acc, st = dA.cpu().numpy(), dS.cpu().numpy()
     rejects, expected_rejects = int(dR.item()), len(range(0, total, 256))
     ok_t = torch.tensor([1 if ((acc == expect).all() and not st.any()) else 0], dtype=torch.int32, device="cuda")
@@ -296,7 +302,8 @@ def measure_recip256(args, total, W, cpu_baseline=True, rlc=True, dist_on=False,
                                "the generic kernels, inputs resident in HBM, 1/256 proofs corrupted, one 4-byte reject-count all-reduce per step; "
                                "proofs made by the product prover (oracle-checked sample)",
                    "total_proofs_per_step": total, "proofs_per_gpu": n, "fb_window_bits": proto.get_option("fb_window_bits"),
-                   "parallelism": f"shard{world}" if world > 1 else "single"},
+                   "parallelism": f"shard{world}" if world > 1 else "single", "kernel_timing_during_value": False},
+        "timing_pass_ms_per_step": elapsed_timed / args.steps * 1e3,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / bench.HBM_PEAK_GBS,
                      "traffic": bench.pmc_traffic(dom, n), "avg_launch_ms": avg_ms, "launches_per_step": dom_t["launches"] / args.steps,
                      "algorithmic_bytes_per_launch": bench.ALGO_BYTES_PER_RECIP256 * n},
@@ -313,16 +320,9 @@ def measure_recip256(args, total, W, cpu_baseline=True, rlc=True, dist_on=False,
         dS2 = torch.zeros(n, dtype=torch.int32, device="cuda")
         dR2 = torch.zeros(1, dtype=torch.int32, device="cuda")
         step(seed, dA2, dS2, dR2)
-        fence()
-        proto.enable_timing(True)
-        proto.timings(reset=True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step(seed, dA2, dS2, dR2)
-        fence()
-        t_rlc = max_over_ranks(time.perf_counter() - t0) / args.steps
-        kt2 = {k: v["total_ms"] / args.steps for k, v in proto.timings(reset=True).items() if v["launches"]}
-        proto.enable_timing(False)
+        t_rlc, _, kt2 = two_passes(proto, lambda: step(seed, dA2, dS2, dR2), fence, args.steps)
+        t_rlc = max_over_ranks(t_rlc) / args.steps
+        kt2 = {k: v["total_ms"] / args.steps for k, v in kt2.items()}
         result["rlc_mode"] = {"value": total / t_rlc, "unit": "verifies/s", "ms_per_step": t_rlc * 1e3, "kernels_ms_per_step": kt2,
                               "accept_bits_equal_exact_mode": bool((dA2.cpu().numpy() == acc).all() and (dS2.cpu().numpy() == st).all())
                                                               and int(dR2.item()) == rejects,

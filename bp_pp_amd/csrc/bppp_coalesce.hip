@@ -276,6 +276,7 @@ extern "C" {
 int bppp_u64_verify_one_transcript(bppp_ctx* c, uint8_t state[203], const uint8_t commitment[64], const uint8_t proof[928], uint8_t* accept,
                                    int32_t* status) {
     if (!c || !state || !commitment || !proof || !accept) return BPPP_ERR_INVALID_ARG;
+    OneCaller entered_(c);      // before anything else of the context is read (bppp_ctx_destroy waits for the count)
     if (c->ng != 16 || c->nh != 32 || !state_ok(state)) return BPPP_ERR_INVALID_ARG;
     const void* in[4] = {commitment, proof, state, nullptr};
     void* out[4] = {accept, status, state, nullptr};
@@ -284,6 +285,7 @@ int bppp_u64_verify_one_transcript(bppp_ctx* c, uint8_t state[203], const uint8_
 int bppp_u64_verify_one(bppp_ctx* c, const uint8_t* label, size_t label_len, const uint8_t commitment[64], const uint8_t proof[928],
                         uint8_t* accept, int32_t* status) {
     if (!c || !label_ok(label, label_len) || !commitment || !proof || !accept) return BPPP_ERR_INVALID_ARG;
+    OneCaller entered_(c);      // before anything else of the context is read (bppp_ctx_destroy waits for the count)
     if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
     uint8_t st[SB];
     int rc = bppp_transcript_new(label, label_len, st);      // Transcript::new(label) on the host: one Keccak permutation
@@ -295,6 +297,7 @@ int bppp_u64_verify_one(bppp_ctx* c, const uint8_t* label, size_t label_len, con
 int bppp_u64_prove_one_transcript(bppp_ctx* c, uint8_t state[203], uint64_t x, const uint8_t s[32], const uint8_t* rnd, uint8_t proof[928],
                                   uint8_t commitment[64], int32_t* status) {
     if (!c || !state || !s || !rnd || !proof || !commitment) return BPPP_ERR_INVALID_ARG;
+    OneCaller entered_(c);      // before anything else of the context is read (bppp_ctx_destroy waits for the count)
     if (c->ng != 16 || c->nh != 32 || !state_ok(state)) return BPPP_ERR_INVALID_ARG;
     const void* in[4] = {&x, s, rnd, state};
     void* out[4] = {proof, commitment, status, state};
@@ -303,6 +306,7 @@ int bppp_u64_prove_one_transcript(bppp_ctx* c, uint8_t state[203], uint64_t x, c
 int bppp_u64_prove_one(bppp_ctx* c, const uint8_t* label, size_t label_len, uint64_t x, const uint8_t s[32], const uint8_t* rnd,
                        uint8_t proof[928], uint8_t commitment[64], int32_t* status) {
     if (!c || !label_ok(label, label_len) || !s || !rnd || !proof || !commitment) return BPPP_ERR_INVALID_ARG;
+    OneCaller entered_(c);      // before anything else of the context is read (bppp_ctx_destroy waits for the count)
     if (c->ng != 16 || c->nh != 32) return BPPP_ERR_INVALID_ARG;
     uint8_t st[SB];
     int rc = bppp_transcript_new(label, label_len, st);
@@ -315,6 +319,7 @@ int bppp_u64_prove_one(bppp_ctx* c, const uint8_t* label, size_t label_len, uint
 static int recip_one(bppp_ctx* c, uint8_t* state_io, const uint8_t* state_in, size_t dim_nd, size_t dim_np, const uint8_t* commitment,
                      const uint8_t* proof, size_t rounds, size_t nl, size_t nn, uint8_t* accept, int32_t* status) {
     if (!c || !commitment || !proof || !accept) return BPPP_ERR_INVALID_ARG;
+    OneCaller inside(c);        // before anything else of the context is read (bppp_ctx_destroy waits for the count)
     // the shape must be one the context's generators can serve (bppp_generic.hip: recip_verify_check_args) before a front end is made for it
     if (dim_nd == 0 || dim_np == 0 || dim_nd > (size_t)c->ng || dim_nd + 10 > (size_t)c->nh || dim_np > dim_nd + 1 || rounds > 12 || nl > 4096 || nn > 4096)
         return BPPP_ERR_INVALID_ARG;
@@ -322,7 +327,6 @@ static int recip_one(bppp_ctx* c, uint8_t* state_io, const uint8_t* state_in, si
     r.nd = dim_nd; r.np = dim_np; r.rounds = rounds; r.nl = nl; r.nn = nn;
     const void* in[4] = {commitment, proof, state_in, nullptr};
     void* out[4] = {accept, status, state_io, nullptr};
-    OneCaller inside(c);
     for (;;) {
         if (inside.closed()) return BPPP_ERR_CLOSED;
         std::shared_ptr<bppp_front> f;

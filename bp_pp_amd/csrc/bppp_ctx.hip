@@ -3,7 +3,7 @@
 #include "host.h"
 #include "plan_core.h"
 #if defined(BPPP_PHASE_TIMING)
-namespace bppp { __device__ unsigned long long g_bppp_stamps[1024 * 32]; }
+unsigned long long* g_bppp_stamps_dev = nullptr;      // diagnostic builds: the phase-stamp rows (verify_core.h: BPPP_STAMP), allocated at the first verify call
 #endif
 
 thread_local std::string g_last_error;
@@ -25,6 +25,9 @@ static void read_diagnostics(bppp_ctx* c) {
     if (const char* e = std::getenv("BPPP_TAIL_BESIDE")) c->tail_beside = std::atoi(e);
     if (const char* e = std::getenv("BPPP_TABLES_BESIDE")) c->tables_beside = std::atoi(e);
     if (const char* e = std::getenv("BPPP_SHARED_INV")) c->shared_inv = std::atoi(e);
+    if (const char* e = std::getenv("BPPP_GENERIC_PARTS")) c->generic_parts = std::atoi(e);
+    if (const char* e = std::getenv("BPPP_TWIN")) c->twin = std::atoi(e);
+    if (const char* e = std::getenv("BPPP_PACE")) c->pace = std::atoi(e);
     if (const char* e = std::getenv("BPPP_NEXT_MSM_MAX")) c->next_msm_max = std::atol(e);
     c->generic_u64_shape = std::getenv("BPPP_GENERIC_U64_SHAPE") != nullptr;     // reciprocal (16, 16) calls stay on the generic kernels
     c->generic_slow_rounds = std::getenv("BPPP_GENERIC_SLOW_ROUNDS") != nullptr;   // projective tables + complete additions
@@ -175,6 +178,17 @@ int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, c
 
 int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, size_t ng, const uint8_t* h_vec, size_t nh, int device,
                          int fb_window_bits) {
+    return bppp_wnla_ctx_create_budget(out, g, g_vec, ng, h_vec, nh, device, fb_window_bits, 0);
+}
+// the largest part of a verify call whose workspace (about 30 KB per proof) takes at most 70 % of the device memory free NOW
+static void shrink_max_batch_to_free(bppp_ctx* c) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+    while (c->max_batch > ((size_t)1 << 16) && (double)c->max_batch * 30e3 > 0.70 * (double)free_b) c->max_batch >>= 1;
+}
+
+int bppp_wnla_ctx_create_budget(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec, size_t ng, const uint8_t* h_vec, size_t nh, int device,
+                                int fb_window_bits, uint64_t fb_table_budget_bytes) {
     if (!out || !g || (!g_vec && ng) || (!h_vec && nh) || ng > 4096 || nh > 4096) return BPPP_ERR_INVALID_ARG;
     *out = nullptr;
     const int NB = 1 + (int)ng + (int)nh;
@@ -189,6 +203,7 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
     c->n_simds = device_simds(device);
     read_diagnostics(c);
     c->ng = (int)ng; c->nh = (int)nh; c->nbases = NB;
+    c->fb_table_budget = fb_table_budget_bytes;
     uint8_t* d_raw = nullptr;
     auto fail = [&](int code) { if (d_raw) (void)hipFree(d_raw); bppp_ctx_destroy(c); return code; };
 #define HIP_TRY_C(expr)                                                             \
@@ -227,46 +242,58 @@ int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_v
 #undef HIP_TRY_C
     // fixed-base tables: the requested width, or (0) the widest that fits the HBM free right now -- and if even that allocation fails
     // (another process took the memory meanwhile), the next narrower one
+    // a table budget (0 = none) bounds what the tables may take, whichever way their layout is chosen
+    const double budget = fb_table_budget_bytes ? (double)fb_table_budget_bytes : 1e30;
     if (W0 != 0) {
+        if (table_bytes_for(NB, W0) > budget) { g_last_error = "fb_window_bits asks for tables beyond fb_table_budget_bytes"; return fail(BPPP_ERR_INVALID_ARG); }
         rc = build_tables(c, W0);
         if (rc != BPPP_OK) return fail(rc);
     } else {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-        if (const char* e = std::getenv("BPPP_ASSUME_FREE_GB")) free_b = (size_t)(std::atof(e) * 1e9);      // diagnostic: exercise the choice
+        // (re-read after every failed attempt: whoever took the memory meanwhile still has it)
+        auto read_free = [&]() {
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+            if (const char* e = std::getenv("BPPP_ASSUME_FREE_GB")) free_b = (size_t)(std::atof(e) * 1e9);      // diagnostic: exercise the choice
+        };
+        read_free();
         rc = BPPP_ERR_NOMEM;
         const bool u64_shape = ng == 16 && nh == 32 && free_b && !std::getenv("BPPP_NO_MIXED_WINDOWS");
-        if (u64_shape && !std::getenv("BPPP_NO_WIDE_TABLES") && window_fits(NB, kWideCode, free_b)) {
+        if (u64_shape && !std::getenv("BPPP_NO_WIDE_TABLES") && table_bytes_for(NB, kWideCode) <= budget && window_fits(NB, kWideCode, free_b)) {
             rc = build_tables(c, kWideCode);
             if (rc != BPPP_OK && rc != BPPP_ERR_NOMEM) return fail(rc);
+            if (rc != BPPP_OK) read_free();
         }
-        if (rc != BPPP_OK && u64_shape && mixed_fits((int)ng, (int)nh, free_b)) {
+        if (rc != BPPP_OK && u64_shape && table_bytes_for(1 + (int)ng, kMixedHiW) + table_bytes_for((int)nh, kMixedLoW) <= budget && mixed_fits((int)ng, (int)nh, free_b)) {
             rc = build_tables_mixed(c);
             if (rc != BPPP_OK && rc != BPPP_ERR_NOMEM) return fail(rc);
+            if (rc != BPPP_OK) read_free();
         }
         // the general rule: the fewest windows that fit (and if that allocation fails anyway -- another process took the memory meanwhile
         // -- the next count); without a reading of the free memory, or below every two-width table, the small uniform ones
         if (rc != BPPP_OK && free_b)
             for (int nwin = 11; nwin <= 32; nwin++) {
                 const int code = two_width_code_for(nwin);
-                if (!window_code_valid(code) || !window_fits(NB, code, free_b)) continue;
+                if (!window_code_valid(code) || table_bytes_for(NB, code) > budget || !window_fits(NB, code, free_b)) continue;
                 rc = build_tables(c, code);
-                if (rc != BPPP_ERR_NOMEM) break;
+                if (rc == BPPP_OK) break;
+                if (rc != BPPP_ERR_NOMEM) return fail(rc);          // a HIP error is not a reason to try a smaller table: report it
+                read_free();
             }
         if (rc != BPPP_OK)
             for (int W : {8, 4}) {
+                if (table_bytes_for(NB, W) > budget) continue;
                 rc = build_tables(c, W);
                 if (rc != BPPP_ERR_NOMEM) break;
             }
-        if (rc != BPPP_OK) return fail(rc);
+        if (rc != BPPP_OK) {
+            if (rc == BPPP_ERR_NOMEM && fb_table_budget_bytes && table_bytes_for(NB, 4) > budget) g_last_error = "fb_table_budget_bytes is below the smallest table (4-bit windows)";
+            return fail(rc);
+        }
     }
-    {   // max_batch: the largest part of a verify call whose workspace (about 30 KB per proof) takes at most 70 % of what the tables
-        // left free -- still 2^21 proofs beside the 210 GB an empty MI355X gets (288 GiB = 309 GB), fewer on a device that is shared
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            while (c->max_batch > ((size_t)1 << 16) && (double)c->max_batch * 30e3 > 0.70 * (double)free_b) c->max_batch >>= 1;
-        } else (void)hipGetLastError();
-    }
+    // max_batch: the largest part of a verify call whose workspace (about 30 KB per proof) takes at most 70 % of what the tables left
+    // free -- still 2^21 proofs beside the 210 GB an empty MI355X gets (288 GiB = 309 GB), fewer on a device that is shared.  Only a
+    // first guess: memory that disappears later makes the call shrink its parts (bppp_u64.hip: verify_device_impl), not fail.
+    shrink_max_batch_to_free(c);
     *out = c;
     return BPPP_OK;
 }
@@ -305,6 +332,9 @@ void bppp_ctx_destroy(bppp_ctx* c) {
     if (c->ev_rlc_hist) (void)hipEventDestroy(c->ev_rlc_hist);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->twin_stream) { (void)hipStreamSynchronize(c->twin_stream); (void)hipStreamDestroy(c->twin_stream); }
+    if (c->twin_aux) { (void)hipStreamSynchronize(c->twin_aux); (void)hipStreamDestroy(c->twin_aux); }
+    for (hipEvent_t e : {c->ev_twin_fork, c->ev_twin_join, c->ev2_fork, c->ev2_join, c->ev2_tab}) if (e) (void)hipEventDestroy(e);
     if (c->ev_copy) (void)hipEventDestroy(c->ev_copy);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -379,6 +409,12 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
         c->inject_alloc_fault = (int)value;
         return BPPP_OK;
     }
+    // parts of a generic reciprocal verify call on device buffers (bppp_generic.hip: generic_parts_for): 0 = by size, 1 .. 4 = that many
+    if (std::strcmp(name, "generic_parts") == 0) {
+        if (value < 0 || value > 4) return BPPP_ERR_INVALID_ARG;
+        c->generic_parts = (int)value;
+        return BPPP_OK;
+    }
     if (std::strcmp(name, "host_chunk") == 0) {
         if (value != 0 && (value < 1024 || (value & 63))) return BPPP_ERR_INVALID_ARG;
         c->host_chunk = (size_t)value;
@@ -396,6 +432,11 @@ long bppp_ctx_get_option(bppp_ctx* c, const char* name) {
     // "fb_window_bits_hi" bits, the rest at "fb_window_bits"; 0 / 0 = one table
     if (std::strcmp(name, "fb_window_bits_hi") == 0) return c->fb_w_hi;
     if (std::strcmp(name, "fb_hi_bases") == 0) return c->fb_hi_bases;
+    // the same layout in plain numbers: table additions per scalar, and the widest window in bits
+    if (std::strcmp(name, "fb_windows") == 0) return fb_nwin(c->fb_w);
+    if (std::strcmp(name, "fb_window_bits_widest") == 0) return fb_wb(c->fb_w) + (fb_ka(c->fb_w) ? 1 : 0);
+    if (std::strcmp(name, "fb_table_bytes") == 0) return (long)(c->table_bytes + c->table_hi_bytes);      // 0 on a context that borrows its parent's tables
+    if (std::strcmp(name, "fb_table_budget_bytes") == 0) return (long)c->fb_table_budget;
     if (std::strcmp(name, "device") == 0) return c->device;
     if (std::strcmp(name, "n_generators") == 0) return c->nbases;
     if (std::strcmp(name, "rlc_superchunk") == 0) return (long)c->rlc_super_m;
@@ -414,6 +455,7 @@ long bppp_ctx_get_option(bppp_ctx* c, const char* name) {
     }
     if (std::strcmp(name, "max_batch") == 0) return (long)c->max_batch;
     if (std::strcmp(name, "host_chunk") == 0) return (long)c->host_chunk;
+    if (std::strcmp(name, "generic_parts") == 0) return (long)c->generic_parts;
     if (std::strcmp(name, "coalesce_max") == 0) return c->coalesce_max;
     if (std::strcmp(name, "coalesce_us") == 0) return c->coalesce_us;
     if (std::strcmp(name, "coalesce_lanes") == 0) return c->coalesce_lanes;
@@ -428,7 +470,10 @@ long bppp_u64_plan(int prove, size_t n, int n_simds, int flags) {
     bppp_host::PlanKnobs k;
     k.n_simds = n_simds;
     k.timing = (flags & 2) != 0;
-    return prove ? (long)bppp_host::plan_prove(n, k, (flags & 1) != 0).code() : (long)bppp_host::plan_verify(n, k, (flags & 1) != 0).code();
+    if (prove) return (long)bppp_host::plan_prove(n, k, (flags & 1) != 0).code();
+    bppp_host::VerifyPlan p = bppp_host::plan_verify(n, k, (flags & 1) != 0);
+    if (p.twin == 2) p = bppp_host::plan_verify_half(bppp_host::twin_first_half(n), k, p.pace);      // what each of the two chains runs
+    return (long)p.code();
 }
 int bppp_plan_describe(long code, int prove, char* buf, size_t cap) {
     if (code < 0 || code > 0xFFFFFFFFl || (!buf && cap)) return BPPP_ERR_INVALID_ARG;
@@ -505,7 +550,8 @@ int bppp_transcript_challenge_bytes(uint8_t state[203], const uint8_t* label, si
 #if defined(BPPP_PHASE_TIMING)
 // diagnostic builds only (not declared in include/bppp.h): copy the phase stamps out
 BPPP_API int bppp_debug_read_stamps(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bppp::g_bppp_stamps), sizeof(unsigned long long) * 1024 * 32) == hipSuccess ? 0 : -1;
+    if (!g_bppp_stamps_dev) return -1;
+    return hipMemcpy(out, g_bppp_stamps_dev, sizeof(unsigned long long) * BPPP_STAMP_WAVES * 32, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -598,8 +644,10 @@ struct TableChecksum {
 int bppp_ctx_save_tables(bppp_ctx* c, const char* path) {
     CtxLock lock_(c);
     if (!c || !path) return BPPP_ERR_INVALID_ARG;
-    if (c->fb_hi_bases || fb_ka(c->fb_w)) {
-        g_last_error = "this context's tables have windows of two widths (fb_window_bits = 0); create it with an explicit fb_window_bits to save them";
+    if (c->fb_hi_bases || !c->d_table || c->borrows_tables) {
+        g_last_error = c->fb_hi_bases ? "this context's tables are laid out in two regions (the automatic choice when 11 windows for every generator do not fit); "
+                                        "create it with an explicit fb_window_bits (or a table budget that selects one region) to save them"
+                                      : "this context has no tables of its own to save";
         return BPPP_ERR_INVALID_ARG;
     }
     HIP_TRY(hipSetDevice(c->device));
@@ -608,7 +656,7 @@ int bppp_ctx_save_tables(bppp_ctx* c, const char* path) {
     if (!f) { g_last_error = std::string("cannot open ") + path; return BPPP_ERR_INVALID_ARG; }
     TableFileHeader h;
     std::memset(&h, 0, sizeof h);
-    std::memcpy(h.magic, "BPPPTAB3", 8);
+    std::memcpy(h.magic, fb_ka(c->fb_w) ? "BPPPTAB4" : "BPPPTAB3", 8);       // TAB4: window_bits holds a two-width window code (Wb + 100 ka)
     h.nbases = (uint32_t)c->nbases; h.ng = (uint32_t)c->ng; h.nh = (uint32_t)c->nh; h.window_bits = (uint32_t)c->fb_w;
     h.nwin = (uint32_t)fb_nwin(c->fb_w); h.per_win = fb_per_narrow(c->fb_w); h.table_bytes = c->table_bytes;
     bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
@@ -656,10 +704,13 @@ int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device) {
     FILE* f = std::fopen(path, "rb");
     if (!f) { g_last_error = std::string("cannot open ") + path; return BPPP_ERR_INVALID_ARG; }
     TableFileHeader h;
-    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "BPPPTAB3", 8) == 0;
-    const int W = (int)h.window_bits;
-    ok = ok && (W == 4 || W == 8 || W == 10 || W == 16 || W == 18 || W == 19 || W == 20 || W == 22) && h.ng <= 4096 && h.nh <= 4096 && h.nbases == 1 + h.ng + h.nh &&
-         h.nwin == (uint32_t)fb_nwin(W) && h.per_win == fb_per_narrow(W) && h.table_bytes == (uint64_t)h.nbases * h.nwin * h.per_win * sizeof(apt_packed);
+    bool ok = std::fread(&h, sizeof h, 1, f) == 1;
+    const bool tab3 = ok && std::memcmp(h.magic, "BPPPTAB3", 8) == 0, tab4 = ok && std::memcmp(h.magic, "BPPPTAB4", 8) == 0;
+    const int W = ok ? (int)h.window_bits : 0;
+    // TAB3: one of the uniform widths; TAB4: a two-width window code (include/bppp.h) -- in both the geometry fields must be the ones the
+    // code implies, so that a header edited to another layout of the same size is refused before the checksum is even computed
+    ok = ok && (tab3 || tab4) && h.window_bits < 3200 && window_code_valid(W) && (fb_ka(W) > 0) == tab4 && h.ng <= 4096 && h.nh <= 4096 && h.nbases == 1 + h.ng + h.nh &&
+         h.nwin == (uint32_t)fb_nwin(W) && h.per_win == fb_per_narrow(W) && h.table_bytes == (uint64_t)h.nbases * fb_per_base(W) * sizeof(apt_packed);
     if (!ok) { std::fclose(f); g_last_error = std::string(path) + " is not a table file of this library"; return BPPP_ERR_INVALID_ARG; }
     if (hipSetDevice(device) != hipSuccess) { std::fclose(f); g_last_error = "hipSetDevice failed"; (void)hipGetLastError(); return BPPP_ERR_HIP; }
     bppp_ctx* c = new (std::nothrow) bppp_ctx();
@@ -706,6 +757,7 @@ int bppp_ctx_create_from_tables(bppp_ctx** out, const char* path, int device) {
         return fail(BPPP_ERR_INVALID_ARG);
     }
     std::fclose(f);
+    shrink_max_batch_to_free(c);         // like a context built from generators: parts sized to what the tables left free
     *out = c;
     return BPPP_OK;
 }
@@ -736,6 +788,10 @@ int ctx_create_shared_with(bppp_ctx** out, bppp_ctx* parent, const CtShare& ct) 
     c->d_gens = parent->d_gens; c->d_table = parent->d_table; c->table_bytes = 0; c->borrows_tables = true;
     c->d_table_hi = parent->d_table_hi; c->table_hi_bytes = 0; c->fb_w_hi = parent->fb_w_hi; c->fb_hi_bases = parent->fb_hi_bases;
     if (ct.d_table_ct) { c->d_table_ct = ct.d_table_ct; c->borrows_table_ct = true; c->ct_prover = ct.ct_prover; }
+    // the part size the parent settled on (from the memory its tables left, or from a call that ran out of it), shrunk again to what
+    // is free now: the child's workspaces come out of the same device memory
+    c->max_batch = parent->max_batch; c->host_chunk = parent->host_chunk; c->fb_table_budget = parent->fb_table_budget;
+    shrink_max_batch_to_free(c);
     int rc = ctx_alloc_common(c);
     if (rc != BPPP_OK) { bppp_ctx_destroy(c); return rc; }
     *out = c;

@@ -44,19 +44,24 @@ struct TxDev {
 // fast variable-base path of the generic verifiers' rounds: per instance 2 x rounds window tables (16 entries of 64 B per point), the
 // running products of their build (BPPP_TSCR_PER_POINT per point) and the decoded round points -- 1.2 KB + 0.55 KB + 64 B per point, grow-only
 // extra_points: tables of that many more points per instance behind the round points' (the reciprocal verifier's five C0 points)
-static int wnla_fast_setup(bppp_ctx* c, WnlaWs& w, size_t n, size_t rounds, size_t extra_points = 0) {
+static size_t wnla_fast_bytes(size_t n, size_t rounds, size_t extra_points) {
+    const size_t np = 2 * rounds + extra_points;
+    return align16(np * 16 * sizeof(apt_packed) * n) + align16((size_t)BPPP_TSCR_PER_POINT * np * 10 * sizeof(u32) * n) + align16(np * 16 * sizeof(u32) * n);
+}
+// base: where this call's (or this part's) share of the table buffer starts; null = the context's buffer, grown to what the call needs
+static int wnla_fast_setup(bppp_ctx* c, WnlaWs& w, size_t n, size_t rounds, size_t extra_points = 0, uint8_t* base = nullptr) {
     w.atab = nullptr; w.tscr = nullptr; w.rpts = nullptr;
     if (rounds == 0 || c->generic_slow_rounds) return BPPP_OK;
     const size_t np = 2 * rounds + extra_points;
-    const size_t b_tab = align16(np * 16 * sizeof(apt_packed) * n), b_scr = align16((size_t)BPPP_TSCR_PER_POINT * np * 10 * sizeof(u32) * n), b_pts = align16(np * 16 * sizeof(u32) * n);
-    const size_t need = b_tab + b_scr + b_pts;
-    {
-        const int rc_t = ensure_buffer(c, c->d_gtab, c->gtab_bytes, need);
+    const size_t b_tab = align16(np * 16 * sizeof(apt_packed) * n), b_scr = align16((size_t)BPPP_TSCR_PER_POINT * np * 10 * sizeof(u32) * n);
+    if (!base) {
+        const int rc_t = ensure_buffer(c, c->d_gtab, c->gtab_bytes, wnla_fast_bytes(n, rounds, extra_points));
         if (rc_t != BPPP_OK) return rc_t;
+        base = c->d_gtab;
     }
-    w.atab = (apt_packed*)c->d_gtab;
-    w.tscr = (u32*)(c->d_gtab + b_tab);
-    w.rpts = (u32*)(c->d_gtab + b_tab + b_scr);
+    w.atab = (apt_packed*)base;
+    w.tscr = (u32*)(base + b_tab);
+    w.rpts = (u32*)(base + b_tab + b_scr);
     return BPPP_OK;
 }
 // lanes per instance for the generic rounds: 4 or 2 while that still leaves wavefront slots free (and the fast path's tables exist)
@@ -76,8 +81,8 @@ static int wnla_final_scalars_group_lg(const bppp_ctx* c, unsigned rounds, unsig
     while (lg < 3 && ((size_t)blocks << (lg + 1)) <= 4 * (size_t)c->n_simds) lg++;
     return wnla_final_scalars_lg((int)rounds, lg);
 }
-static void launch_wnla_final_scalars(const bppp_ctx* c, const WnlaWs& w, unsigned rounds, size_t n, unsigned blocks, hipStream_t s) {
-    const int lg = wnla_final_scalars_group_lg(c, rounds, blocks);
+static void launch_wnla_final_scalars(const bppp_ctx* c, const WnlaWs& w, unsigned rounds, size_t n, unsigned blocks, hipStream_t s, unsigned call_blocks = 0) {
+    const int lg = wnla_final_scalars_group_lg(c, rounds, call_blocks ? call_blocks : blocks);
     if (lg > 0) {
         k_wnla_final_scalars_grp<<<blocks << lg, BPPP_BLOCK, 0, s>>>(w, lg);
         k_wnla_final_scalars_join<<<blocks, BPPP_BLOCK, 0, s>>>(w, lg);
@@ -220,6 +225,8 @@ int bppp_wnla_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* stat
 
 // ---- generic ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) on a context built by bppp_wnla_ctx_create over
 //      g, g_vec || g_vec_, h_vec || h_vec_
+// one part of a multi-part call (recip_verify_device_entry): its stream and its shares of the context's buffers
+struct GenericPart { hipStream_t s; uint8_t* gtab; pt_slot* straus; unsigned call_blocks; };
 // workspace bytes (beyond the caller's commitments / proofs / accept / status) of one reciprocal verify call
 static size_t recip_verify_ws_bytes(const bppp_ctx* c, size_t n, size_t dim_nd, size_t dim_np, size_t rounds, bool rlc = false) {
     const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh;
@@ -234,7 +241,8 @@ static size_t recip_verify_ws_bytes(const bppp_ctx* c, size_t n, size_t dim_nd, 
 // the launch sequence, every buffer in device memory; d_ws holds recip_verify_ws_bytes()
 static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, size_t dim_nd, size_t dim_np,
                                     const uint8_t* d_com, const uint8_t* d_proofs, size_t rounds, size_t nl, size_t nn, uint8_t* d_acc,
-                                    int32_t* d_st, uint8_t* d_ws, const TranscriptIo* dtio = nullptr, const uint8_t* rlc_seed = nullptr) {
+                                    int32_t* d_st, uint8_t* d_ws, const TranscriptIo* dtio = nullptr, const uint8_t* rlc_seed = nullptr,
+                                    const GenericPart* part = nullptr) {
     const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh;
     const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
     size_t off = 0;
@@ -246,14 +254,15 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     const size_t o_rl = rlc_seed ? take(30 * n * 4) : 0, o_rs = rlc_seed ? take(NB * 8 * n * 4) : 0, o_rf = rlc_seed ? take(nchunks) : 0,
                  o_rli = rlc_seed ? take((nchunks + 4) * 4) : 0;
     uint8_t* d = d_ws;
-    hipStream_t s = c->stream;
+    hipStream_t s = part ? part->s : c->stream;
+    pt_slot* const straus = part ? part->straus : c->d_straus;
     RecipWs r;
     std::memset(&r, 0, sizeof r);
     r.N = n; r.nd = (int)dim_nd; r.np = (int)dim_np; r.rounds = (int)rounds; r.nl = (int)nl; r.nn = (int)nn;
     r.NG = c->ng; r.NH = c->nh; r.proof_bytes = proof_bytes;
     r.commitments = d_com; r.proofs = d_proofs; r.status = d_st; r.tstate = (u32*)(d + o_ts);
     r.sc0 = (u32*)(d + o_sc0); r.pts = (u32*)(d + o_pts); r.acc = (u32*)(d + o_a); r.pfix = (u32*)(d + o_pf); r.inv = (u32*)(d + o_inv);
-    r.straus = c->d_straus;
+    r.straus = straus;
     r.wn_commit = d + o_wc; r.wn_c = d + o_wcv; r.wn_rho = d + o_rho; r.wn_mu = d + o_mu;
     r.fb = fb_table_of(c, n);
     t_new(r.base, label, (u32)label_len);
@@ -270,10 +279,12 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     w.transcript_preloaded = 1;
     w.accept = d_acc; w.status = r.status; w.tstate = r.tstate; w.acc = r.acc; w.pfix = r.pfix;
     w.ys = (u32*)(d + o_ys); w.tab = (u32*)(d + o_tab); w.msc = (u32*)(d + o_msc);
-    w.straus = c->d_straus;
+    w.straus = straus;
     w.fb = r.fb;
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    // (the lane-group choices below go by the wavefronts of the WHOLE call: the parts of a multi-part call share the chip)
+    const unsigned call_blocks = part ? part->call_blocks : blocks;
     int rc;
 #define GLAUNCH(id, ...)                                       \
     do {                                                       \
@@ -288,12 +299,12 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     else GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
     // the WNLA stage's table buffer with room for the five C0 points' tables behind the round points': the variable-base part of C0 on
     // affine window tables too (and on lane groups while one lane per instance leaves wavefront slots free)
-    rc = wnla_fast_setup(c, w, n, rounds, 5);
+    rc = wnla_fast_setup(c, w, n, rounds, 5, part ? part->gtab : nullptr);
     if (rc != BPPP_OK) return rc;
     static_assert(BPPP_ATAB_SOA, "the C0 tables are addressed entry-major behind the round points' tables");
     r.atab = w.atab; r.tscr = w.tscr; r.atab_first = (int)(2 * rounds * 16);
     if (r.atab) {
-        const int grp = wnla_round_group(c, w, blocks);
+        const int grp = wnla_round_group(c, w, call_blocks);
         GLAUNCH(K_RECIP_C0_VAR, {
             k_recip_c0_tables<<<blocks, BPPP_BLOCK, 0, s>>>(r);
             if (grp > 1) k_recip_c0_var_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(r, grp);
@@ -304,13 +315,13 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     GLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     if (w.atab) GLAUNCH(K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     {
-        const int grp = wnla_round_group(c, w, blocks);
+        const int grp = wnla_round_group(c, w, call_blocks);
         for (int k = 1; k <= (int)rounds; k++) {
             if (grp > 1) GLAUNCH(K_WNLA_ROUND, k_wnla_round_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k, grp));
             else GLAUNCH(K_WNLA_ROUND, k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         }
     }
-    GLAUNCH(K_WNLA_FINAL_SCALARS, launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s));
+    GLAUNCH(K_WNLA_FINAL_SCALARS, launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s, call_blocks));
     if (!rlc_seed) {
         if (fb_one_lane) GLAUNCH(K_WNLA_MSM, k_wnla_msm_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(w));
         else GLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
@@ -352,6 +363,13 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     HIP_TRY(hipGetLastError());
     return BPPP_OK;
 }
+// parts of a reciprocal verify call (see recip_verify_device_entry): by how far one lane per instance under-fills the chip; one part
+// with kernel timing on (the per-kernel times must add up), in RLC mode (its stages work on the whole batch) and for small calls
+static int generic_parts_for(const bppp_ctx* c, size_t n, bool rlc) {
+    if (rlc || c->timing || n < 2 * BPPP_BLOCK) return 1;
+    if (c->generic_parts > 0) return c->generic_parts > 4 ? 4 : c->generic_parts;      // forced (A/B runs, tests at small sizes)
+    return 1;
+}
 static int recip_verify_check_args(const bppp_ctx* c, size_t dim_nd, size_t dim_np, size_t rounds, size_t nl, size_t nn) {
     if (dim_nd == 0 || dim_np == 0 || dim_nd > (size_t)c->ng || dim_nd + 10 > (size_t)c->nh || dim_np > dim_nd + 1 || rounds > 12 ||
         nl > 4096 || nn > 4096)
@@ -378,12 +396,57 @@ int recip_verify_device_entry(bppp_ctx* c, const uint8_t* label, size_t label_le
     if (n == 0) return BPPP_OK;
     rc = ensure_straus_capacity(c, n);
     if (rc != BPPP_OK) return rc;
-    // persistent, grow-only workspace (the host-pointer entry point allocates per call instead)
-    const size_t need = recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds, rlc_seed != nullptr);
-    rc = ensure_buffer(c, c->d_gws, c->gws_bytes, need);
-    if (rc != BPPP_OK) return rc;
-    rc = recip_verify_device_impl(c, label, label_len, n, dim_nd, dim_np, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, rounds, nl,
-                                  nn, (uint8_t*)d_accept, (int32_t*)d_status, c->d_gws, nullptr, rlc_seed);
+    // A call that leaves the chip under-filled runs as K PARTS on K streams.  One lane per instance gives 2^15 instances of BASELINE
+    // configs[4]'s shape 512 wavefronts on 1,024 SIMDs for phase 1, the C0 tables and sum, the round tables and the eight rounds -- a
+    // third of the step waiting on lone wavefronts' dependent chains -- while the two fixed-base sums (8 lanes per instance: 769 and 263
+    // bases) fill it.  Instances are independent, so the parts need no ordering among themselves: one part's fixed-base sums run under
+    // another part's one-lane kernels, and the wavefront slots the chains leave idle do the sums' work.
+    const int K = generic_parts_for(c, n, rlc_seed != nullptr);
+    if (K > 1) {
+        rc = bppp_ensure_twin_lanes(c);
+        if (rc != BPPP_OK) return rc;
+        size_t m[4], lo[4], ws_off[4], gt_off[4], ws_total = 0, gt_total = 0;
+        const size_t per = ((n + (size_t)K - 1) / (size_t)K + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+        int parts = 0;
+        for (size_t a = 0; a < n; a += per, parts++) {
+            lo[parts] = a; m[parts] = n - a < per ? n - a : per;
+            ws_off[parts] = ws_total; ws_total += align16(recip_verify_ws_bytes(c, m[parts], dim_nd, dim_np, rounds, false)) + 256;
+            gt_off[parts] = gt_total; gt_total += wnla_fast_bytes(m[parts], rounds, 5) + 256;
+        }
+        rc = ensure_buffer(c, c->d_gws, c->gws_bytes, ws_total);
+        if (rc != BPPP_OK) return rc;
+        const bool fast = rounds != 0 && !c->generic_slow_rounds;
+        if (fast) {
+            rc = ensure_buffer(c, c->d_gtab, c->gtab_bytes, gt_total);
+            if (rc != BPPP_OK) return rc;
+        }
+        hipStream_t streams[4] = {c->stream, c->twin_stream, c->aux_stream, c->twin_aux};
+        hipEvent_t joins[4] = {nullptr, c->ev_twin_join, c->ev2_fork, c->ev2_join};
+        const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
+        const unsigned call_blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
+        HIP_TRY(hipEventRecord(c->ev_twin_fork, c->stream));
+        for (int i = 1; i < parts; i++) HIP_TRY(hipStreamWaitEvent(streams[i], c->ev_twin_fork, 0));
+        int rc_parts = BPPP_OK;
+        for (int i = 0; i < parts && rc_parts == BPPP_OK; i++) {
+            const GenericPart gp = {streams[i], fast ? c->d_gtab + gt_off[i] : nullptr, c->d_straus + lo[i] * 5 * BPPP_STRAUS_ENTRIES, call_blocks};
+            rc_parts = recip_verify_device_impl(c, label, label_len, m[i], dim_nd, dim_np, (const uint8_t*)d_commitments + 64 * lo[i],
+                                                (const uint8_t*)d_proofs + proof_bytes * lo[i], rounds, nl, nn, (uint8_t*)d_accept + lo[i],
+                                                (int32_t*)d_status + lo[i], c->d_gws + ws_off[i], nullptr, nullptr, &gp);
+        }
+        // (joined even after a failed launch: nothing of this call may outlive it on a stream the caller does not know)
+        for (int i = 1; i < parts; i++) {
+            HIP_TRY(hipEventRecord(joins[i], streams[i]));
+            HIP_TRY(hipStreamWaitEvent(c->stream, joins[i], 0));
+        }
+        rc = rc_parts;
+    } else {
+        // persistent, grow-only workspace (the host-pointer entry point allocates per call instead)
+        const size_t need = recip_verify_ws_bytes(c, n, dim_nd, dim_np, rounds, rlc_seed != nullptr);
+        rc = ensure_buffer(c, c->d_gws, c->gws_bytes, need);
+        if (rc != BPPP_OK) return rc;
+        rc = recip_verify_device_impl(c, label, label_len, n, dim_nd, dim_np, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, rounds, nl,
+                                      nn, (uint8_t*)d_accept, (int32_t*)d_status, c->d_gws, nullptr, rlc_seed);
+    }
     if (rc != BPPP_OK || !d_reject_count) return rc;
     k_count_rejects<<<(unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024), 256, 0, c->stream>>>((const uint8_t*)d_accept, n, (int*)d_reject_count);
     HIP_TRY(hipGetLastError());

@@ -6,14 +6,45 @@
 
 // host-buffer verify calls: each pipelined part is this many times the previous one (what crosses PCIe while a part is verified)
 #define BPPP_HOST_PART_GROWTH 7
+#if defined(BPPP_PHASE_TIMING)
+extern unsigned long long* g_bppp_stamps_dev;      // bppp_ctx.hip
+#endif
 static_assert(bppp_host::PLAN_BLOCK == BPPP_BLOCK, "plan_core.h counts workgroups of BPPP_BLOCK lanes");
 // the switches of a context that the plans depend on
+struct VerifyLanes { hipStream_t s, a; hipEvent_t ev_fork, ev_join, ev_tab; hipEvent_t ev_started; };      // a: null = no helper stream; ev_started: recorded after the first kernel (or null)
+// the second stream pair of a twin call (plan_core.h: twin), created at the first such call
+int bppp_ensure_twin_lanes(bppp_ctx* c) {
+    if (c->twin_stream) return BPPP_OK;
+    // The two halves must sit on DIFFERENT hardware queues, or they run one after the other.  The runtime deals streams of one priority
+    // onto its four hardware queues by use count, so with a few contexts alive a third stream of normal priority may well share the queue
+    // of this context's own (measured: the twin form's gain at 2^17 proofs was there with 6 streams in the process and gone with 14).
+    // Streams of another priority come from another set of queues: the second half's pair is created at HIGH priority -- it also gets the
+    // wavefront slots first whenever both halves have a kernel waiting, which costs the first half nothing (the two fit side by side).
+    int prio_least = 0, prio_greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    int kind = 1;                                                                    // 0 normal priority | 1 high priority | 2 a CU mask of all CUs (a queue of its own)
+    if (const char* e = std::getenv("BPPP_TWIN_STREAMS")) kind = std::atoi(e);       // diagnostic
+    if (kind == 2) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+        std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0xFFFFFFFFu);
+        if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+        HIP_TRY(hipExtStreamCreateWithCUMask(&c->twin_stream, (uint32_t)mask.size(), mask.data()));
+        HIP_TRY(hipExtStreamCreateWithCUMask(&c->twin_aux, (uint32_t)mask.size(), mask.data()));
+    } else {
+        const int prio = kind == 1 ? prio_greatest : 0;
+        HIP_TRY(hipStreamCreateWithPriority(&c->twin_stream, hipStreamNonBlocking, prio));
+        HIP_TRY(hipStreamCreateWithPriority(&c->twin_aux, hipStreamNonBlocking, prio));
+    }
+    for (hipEvent_t* e : {&c->ev_twin_fork, &c->ev_twin_join, &c->ev2_fork, &c->ev2_join, &c->ev2_tab}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return BPPP_OK;
+}
 static bppp_host::PlanKnobs knobs_of(const bppp_ctx* c) {
     bppp_host::PlanKnobs k;
     k.n_simds = c->n_simds;
     k.no_small = c->no_small; k.no_lane_groups = c->no_lane_groups; k.no_split = c->no_split; k.timing = c->timing;
     k.tables_beside = c->tables_beside; k.tail_beside = c->tail_beside; k.fb_one_lane_mode = c->fb_one_lane_mode; k.next_overlap = c->next_overlap;
-    k.shared_inv = c->shared_inv;
+    k.shared_inv = c->shared_inv; k.twin = c->twin; k.pace = c->pace;
     k.next_msm_max = c->next_msm_max; k.lane_forms_max = c->lane_forms_max; k.lane4_max = c->lane4_max; k.scal_parts_max = c->scal_parts_max;
     return k;
 }
@@ -42,12 +73,18 @@ int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size
                        void* d_accept, void* d_status, void* d_trace, void* d_reject_count, const uint8_t* rlc_seed,
                        const VerifyTranscripts* tx) {
     if (!c) return BPPP_ERR_INVALID_ARG;
-    const size_t cap = c->max_batch;
-    if (n <= cap || !d_commitments || !d_proofs || !d_accept)
+    if (!d_commitments || !d_proofs || !d_accept)
         return verify_device_part(c, label, label_len, n, d_commitments, d_proofs, d_accept, d_status, d_trace, d_reject_count, rlc_seed, tx, true);
     if (tx && tx->d_states && tx->n_states != 1 && tx->n_states != n) return BPPP_ERR_INVALID_ARG;
     const size_t SB = BPPP_TRANSCRIPT_STATE_BYTES;
-    for (size_t lo = 0; lo < n; lo += cap) {
+    // max_batch is a guess made from the memory that was free when the context was created; another context, another process or the
+    // caller's own allocations may have taken it since.  A part whose workspace cannot be allocated is therefore not the end of the
+    // call: what the failed attempt holds is released, the part size is halved (and stays halved for the calls that follow) and the
+    // part is run again.  Nothing of a part is visible before its last kernel (k_verify_accept*: accept bytes, reject count), and
+    // every allocation of a part precedes that kernel, so a retried part leaves no trace of its first attempt.
+    const size_t min_part = (size_t)1 << 12;
+    for (size_t lo = 0; lo < n || (n == 0 && lo == 0);) {
+        const size_t cap = c->max_batch;
         const size_t m = n - lo < cap ? n - lo : cap;
         VerifyTranscripts part;
         if (tx) {
@@ -59,7 +96,17 @@ int verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t label_len, size
                                     (const uint8_t*)d_proofs + lo * (size_t)BPPP_U64_PROOF_BYTES, (uint8_t*)d_accept + lo,
                                     d_status ? (int32_t*)d_status + lo : nullptr, d_trace ? (uint8_t*)d_trace + lo * (size_t)BPPP_U64_TRACE_BYTES : nullptr,
                                     d_reject_count, rlc_seed, tx ? &part : nullptr, lo == 0);
+        if (rc == BPPP_ERR_NOMEM && m > min_part) {
+            quiesce(c);
+            release_workspaces(c);
+            size_t half = (m / 2 + BPPP_BLOCK - 1) / BPPP_BLOCK * BPPP_BLOCK;
+            if (half < min_part) half = min_part;
+            c->max_batch = half;
+            continue;
+        }
         if (rc != BPPP_OK) return rc;
+        if (n == 0) break;
+        lo += m;
     }
     return BPPP_OK;
 }
@@ -75,8 +122,6 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     // which kernels this size runs: ONE pure function of (n, SIMDs, switches) -- plan_core.h, where the regimes are described
     const bppp_host::VerifyPlan plan = bppp_host::plan_verify(n, knobs_of(c), rlc_seed != nullptr);
     c->last_verify_plan = plan.code();
-    const bool split = plan.split;
-    const int parts = plan.parts;
     rc = ensure_vtab_capacity(c, plan.vtab_sets * n);
     if (rc != BPPP_OK) return rc;
     VerifyWs ws;
@@ -85,6 +130,15 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     ws.atab = c->d_atab;
     ws.tscr = c->d_tscr;
     if (plan.shared_inv) ws.zinv = c->d_zinv;
+#if defined(BPPP_PHASE_TIMING)
+    if (!g_bppp_stamps_dev) {
+        HIP_TRY(hipMalloc(&g_bppp_stamps_dev, sizeof(unsigned long long) * BPPP_STAMP_WAVES * 32));
+        HIP_TRY(hipMemset(g_bppp_stamps_dev, 0, sizeof(unsigned long long) * BPPP_STAMP_WAVES * 32));
+    }
+    ws.stamps = g_bppp_stamps_dev;
+    ws.stamp_stride = (unsigned)(((n + BPPP_BLOCK - 1) / BPPP_BLOCK + BPPP_STAMP_WAVES - 1) / BPPP_STAMP_WAVES);
+    if (ws.stamp_stride == 0) ws.stamp_stride = 1;
+#endif
     RlcWs rl;
     std::memset(&rl, 0, sizeof rl);
     if (rlc_seed) {
@@ -123,35 +177,38 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         ws.states_out = (uint8_t*)tx->d_states_out;
     }
     if (d_reject_count && reset_reject_count) HIP_TRY(hipMemsetAsync(d_reject_count, 0, sizeof(int), c->stream));
+    // the launch sequence of one batch -- or of one half of a twin call -- on one stream pair
+    auto sequence = [&](const VerifyWs& ws, size_t n, const bppp_host::VerifyPlan& plan, const VerifyLanes& L) -> int {
+    int rc = BPPP_OK;
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
-    hipStream_t s = c->stream;
+    hipStream_t s = L.s;
 #define LAUNCH_ON(st, id, ...)                                  \
     do {                                                        \
         rc = timed(c, id, st, [&]() { __VA_ARGS__; });          \
         if (rc != BPPP_OK) return rc;                           \
     } while (0)
 #define LAUNCH(id, ...) LAUNCH_ON(s, id, __VA_ARGS__)
-    hipStream_t a = c->timing ? s : c->aux_stream;
+    hipStream_t a = (c->timing || !L.a) ? s : L.a;
     // (tables: a lane per point on the helper stream while phase 1 runs, or the one-lane kernel beside phase 1 -- both decode their points
     // themselves -- or after phase 1 on the main stream)
     const bool tables_aside = plan.tables == bppp_host::TABLES_ASIDE, tables_beside = plan.tables == bppp_host::TABLES_BESIDE;
     const int tparts = plan.tparts;
     const unsigned wg4_blocks = (unsigned)((n + BPPP_C0VAR_SMALL_BLOCK - 1) / BPPP_C0VAR_SMALL_BLOCK);
     if (tables_beside) {
-        HIP_TRY(hipEventRecord(c->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
+        HIP_TRY(hipEventRecord(L.ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(a, L.ev_fork, 0));
         LAUNCH_ON(a, K_TABLES, k_verify_tables_own<<<wg4_blocks, BPPP_C0VAR_SMALL_BLOCK, 0, a>>>(ws));
-        HIP_TRY(hipEventRecord(c->ev_tab, a));
+        HIP_TRY(hipEventRecord(L.ev_tab, a));
     }
     if (tables_aside) {
         // the table kernel decodes its points itself, so it runs on the helper stream beside phase 1
-        HIP_TRY(hipEventRecord(c->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
+        HIP_TRY(hipEventRecord(L.ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(a, L.ev_fork, 0));
         const unsigned tb = (unsigned)((16 * (size_t)tparts * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
         if (tparts == 4) LAUNCH_ON(a, K_TABLES, k_verify_tables_split4<<<tb, BPPP_BLOCK, 0, a>>>(ws));
         else if (tparts == 2) LAUNCH_ON(a, K_TABLES, k_verify_tables_split2<<<tb, BPPP_BLOCK, 0, a>>>(ws));
         else LAUNCH_ON(a, K_TABLES, k_verify_tables_split1<<<tb, BPPP_BLOCK, 0, a>>>(ws));
-        HIP_TRY(hipEventRecord(c->ev_tab, a));
+        HIP_TRY(hipEventRecord(L.ev_tab, a));
     }
     switch (plan.phase1) {
     case bppp_host::P1_G16: LAUNCH(K_PHASE1, k_verify_phase1_g16<<<(unsigned)((16 * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(ws)); break;
@@ -159,13 +216,14 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     case bppp_host::P1_SMALL: LAUNCH(K_PHASE1, k_verify_phase1_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws)); break;
     default: LAUNCH(K_PHASE1, k_verify_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(ws)); break;
     }
+    if (L.ev_started) HIP_TRY(hipEventRecord(L.ev_started, s));
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     // C0 = variable-base half (window tables of the proof points, then the shared-doubling sum: one lane per proof, 1 wave
     // per SIMD) + fixed-base half (8 lanes per proof): independent, so they run concurrently on two streams and share the
     // SIMDs; round 1 adds the halves.
     // with per-kernel timing on, the two halves run back to back so that the kernel times add up to the step (overlapped, each
     // half's events also cover the other's share of the SIMDs; the overlap itself buys nothing at 2 waves/SIMD: DESIGN.md 4)
-    if (tables_aside || tables_beside) HIP_TRY(hipStreamWaitEvent(s, c->ev_tab, 0));
+    if (tables_aside || tables_beside) HIP_TRY(hipStreamWaitEvent(s, L.ev_tab, 0));
     else if (plan.shared_inv) {
         // five passes, the running product of each inverted once per G proofs in between (in place in ws.zinv)
         LAUNCH(K_TABLES, k_verify_tables_pass0<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
@@ -178,8 +236,8 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         LAUNCH(K_SHARED_INV, launch_fe_batch_inv(plan.shared_inv, ws.zinv, ws.zinv, n, s));
         LAUNCH(K_TABLES, k_verify_tables_pass4<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
     } else LAUNCH(K_TABLES, k_verify_tables<<<blocks, BPPP_BLOCK, 0, s>>>(ws));
-    HIP_TRY(hipEventRecord(c->ev_fork, s));
-    HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
+    HIP_TRY(hipEventRecord(L.ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(a, L.ev_fork, 0));
     // the two fixed-base sums: a wavefront per sum in a small call, 8 lanes per proof, or one from the size at which one lane per proof
     // fills the SIMDs twice over
     const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
@@ -187,7 +245,7 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     if (plan.fb == bppp_host::FB_L64) LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed_l64<<<fb64_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
     else if (plan.fb == bppp_host::FB_L1) LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
     else LAUNCH_ON(a, K_C0_FIXED, k_verify_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, a>>>(ws));
-    HIP_TRY(hipEventRecord(c->ev_join, a));
+    HIP_TRY(hipEventRecord(L.ev_join, a));
     // the variable-base half: 64 / 32 lanes per proof in a small call, lane groups of 4 while the grid leaves the SIMDs under-filled,
     // else one lane per proof (uncapped build: 256-thread workgroups, their four wavefronts land one per SIMD -- see k_verify_var.hip)
     const unsigned g4_blocks = (unsigned)((4 * n + BPPP_BLOCK - 1) / BPPP_BLOCK);
@@ -198,16 +256,18 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     case bppp_host::C0V_SMALL: LAUNCH(K_C0_VAR, k_verify_c0_var_small<<<wg4_blocks, BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws)); break;
     default: LAUNCH(K_C0_VAR, k_verify_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(ws)); break;
     }
-    HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+    HIP_TRY(hipStreamWaitEvent(s, L.ev_join, 0));
     // The last round's two-point sum beside the final fixed-base sum (which needs the challenges, not C_4): for batches whose one-lane
     // kernels are a lone wavefront per SIMD and not on lane groups (2^15 < n <= 2^16), exact mode.  The round then goes out as head and
     // tail (k_verify_var.hip); the final scalars and the final sum follow the head on the helper stream; k_verify_accept waits for both.
     const bool tail_beside = plan.tail_beside;
+    const int parts = plan.parts;
+    (void)parts;
     for (int k = 1; k <= 4; k++) {
         if (k == 4 && tail_beside) {
             LAUNCH(K_ROUND, k_verify_round_head_small<<<blocks, BPPP_BLOCK, 0, s>>>(ws, k));
-            HIP_TRY(hipEventRecord(c->ev_fork, s));
-            HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
+            HIP_TRY(hipEventRecord(L.ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(a, L.ev_fork, 0));
             LAUNCH(K_ROUND, k_verify_round_tail<<<wg4_blocks, BPPP_C0VAR_SMALL_BLOCK, 0, s>>>(ws, k));
             continue;
         }
@@ -237,7 +297,7 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         if (plan.fb == bppp_host::FB_L64) LAUNCH(K_FINAL_CHECK, k_verify_final_check_l64<<<fb64_blocks, BPPP_FB_BLOCK, 0, s>>>(ws));
         else if (plan.fb == bppp_host::FB_L1) LAUNCH_ON(fs, K_FINAL_CHECK, k_verify_final_check_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, fs>>>(ws));
         else LAUNCH_ON(fs, K_FINAL_CHECK, k_verify_final_check<<<fb_blocks, BPPP_FB_BLOCK, 0, fs>>>(ws));
-        if (tail_beside) { HIP_TRY(hipEventRecord(c->ev_join, a)); HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0)); }
+        if (tail_beside) { HIP_TRY(hipEventRecord(L.ev_join, a)); HIP_TRY(hipStreamWaitEvent(s, L.ev_join, 0)); }
         LAUNCH(K_ACCEPT, k_verify_accept<<<blocks, BPPP_BLOCK, 0, s>>>(ws, (int*)d_reject_count));
     } else {
         // How the final checks are grouped -- superchunks of the bucket stage, then chunks of 8 or 32 -- follows what the previous RLC
@@ -281,9 +341,64 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         HIP_TRY(hipEventRecord(c->ev_rlc_hist, s));
         c->rlc_hist_n = n;
     }
-    if (ws.states_out) k_verify_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(ws);
 #undef LAUNCH
 #undef LAUNCH_ON
+    return BPPP_OK;
+    };
+    if (plan.twin == 2) {
+        // two halves, two stream pairs (plan_core.h: twin): the second half starts when the call's inputs are ready on the main stream
+        // and is joined back into it, so callers see one asynchronous call on c->stream as before
+        rc = bppp_ensure_twin_lanes(c);
+        if (rc != BPPP_OK) return rc;
+        const size_t n0 = bppp_host::twin_first_half(n), n1 = n - n0;
+        const bppp_host::VerifyPlan ph0 = bppp_host::plan_verify_half(n0, knobs_of(c), plan.pace), ph1 = bppp_host::plan_verify_half(n1, knobs_of(c), plan.pace);
+        c->last_verify_plan = ph0.code();        // what a half runs (twin=2 says there are two of them)
+        VerifyWs w0 = ws, w1 = ws;
+        u32* z0 = carve_from(c, w0, n0, c->d_ws);
+        u32* z1 = carve_from(c, w1, n1, c->d_ws + WS_WORDS_PER_PROOF * n0);
+        w0.zinv = ph0.shared_inv ? z0 : nullptr;
+        w1.zinv = ph1.shared_inv ? z1 : nullptr;
+        w0.pace = ph0.pace ? 1 : 0; w1.pace = ph1.pace ? 1 : 0;
+        w1.atab = ws.atab + (size_t)BPPP_ATAB_PER_PROOF * n0;
+        w1.tscr = ws.tscr + (size_t)(BPPP_TSCR_FE * 10) * n0;
+        w1.commitments = ws.commitments + 64 * n0;
+        w1.proofs = ws.proofs + (size_t)BPPP_U64_PROOF_BYTES * n0;
+        w1.accept = ws.accept + n0;
+        w1.status = ws.status + n0;
+        if (ws.trace) w1.trace = ws.trace + (size_t)BPPP_U64_TRACE_BYTES * n0;
+        if (ws.states && ws.n_states != 1) { w0.n_states = n0; w1.states = ws.states + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * n0; w1.n_states = n1; }
+        if (ws.states_out) w1.states_out = ws.states_out + (size_t)BPPP_TRANSCRIPT_STATE_BYTES * n0;
+        // Each half is ONE chain of kernels on ONE stream (the fixed-base half of C0 ahead of the variable-base half: no helper streams),
+        // and the second chain starts when the first has finished its first kernel.  Every SIMD then holds an older wavefront of one
+        // chain and a younger one of the other; the arbiter serves the older first, it ends early, its chain's next kernel moves in as
+        // the younger one: the chains leapfrog.  Started TOGETHER the two would mix old and young wavefronts of both chains on the
+        // SIMDs, every kernel would take what the slow role takes, both chains would stay in step for good (measured: the rounds of both
+        // halves starting within 30 us of each other, 1.95 ms each instead of 1.75 with 0.9 ms between them) and the split would buy nothing.
+        const VerifyLanes L0 = {c->stream, nullptr, c->ev_fork, c->ev_join, c->ev_tab, c->ev_twin_fork};
+        const VerifyLanes L1 = {c->twin_stream, nullptr, c->ev2_fork, c->ev2_join, c->ev2_tab, nullptr};
+        rc = sequence(w0, n0, ph0, L0);
+        if (rc == BPPP_OK) {
+            HIP_TRY(hipStreamWaitEvent(c->twin_stream, c->ev_twin_fork, 0));
+            rc = sequence(w1, n1, ph1, L1);
+        }
+        if (rc == BPPP_OK && ws.states_out) {
+            k_verify_export_states<<<(unsigned)((n0 + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, c->stream>>>(w0);
+            k_verify_export_states<<<(unsigned)((n1 + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, c->twin_stream>>>(w1);
+        }
+        // (joined even after a failed launch: nothing of this call may outlive it on a stream the caller does not know)
+        HIP_TRY(hipEventRecord(c->ev_twin_join, c->twin_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_twin_join, 0));
+        if (rc != BPPP_OK) return rc;
+        HIP_TRY(hipGetLastError());
+        return BPPP_OK;
+    }
+    {
+        const VerifyLanes L0 = {c->stream, c->aux_stream, c->ev_fork, c->ev_join, c->ev_tab, nullptr};
+        ws.pace = plan.pace ? 1 : 0;
+        rc = sequence(ws, n, plan, L0);
+        if (rc != BPPP_OK) return rc;
+    }
+    if (ws.states_out) k_verify_export_states<<<(unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, c->stream>>>(ws);
     HIP_TRY(hipGetLastError());
     return BPPP_OK;
 }

@@ -67,6 +67,7 @@ struct bppp_ctx {
     hipStream_t copy_stream = nullptr;  // host-buffer entry points: uploads chunk k + 1 while chunk k is being verified (created on first use)
     hipEvent_t ev_copy = nullptr;
     size_t max_batch = (size_t)1 << 21;    // proofs verified per internal part of one call: bounds the workspace (~63 GB at 2^21)
+    uint64_t fb_table_budget = 0;          // bppp_wnla_ctx_create_budget: what the automatic table layout may take (0 = no cap of the caller's)
     size_t host_chunk = (size_t)1 << 17;   // proofs per pipelined chunk (one full grid at 2 waves/SIMD); 0 = upload the whole batch first
     apt* d_gens = nullptr;       // 49
     apt_packed* d_table = nullptr;
@@ -140,6 +141,10 @@ struct bppp_ctx {
     int next_overlap = -1;   // diagnostic BPPP_NEXT_OVERLAP: the variable-base next commitment on the helper stream always (1) / never (0)
     int tail_beside = -1;     // diagnostic BPPP_TAIL_BESIDE: the last round's sum beside the final fixed-base sum always (1) / never (0)
     u32* d_zinv = nullptr;    // [10][n] of the current call inside d_ws (carve)
+    int generic_parts = 0;    // diagnostic BPPP_GENERIC_PARTS: parts of a generic reciprocal verify call (bppp_generic.hip: generic_parts_for); 0 = by size
+    int twin = -1, pace = -1; // diagnostics BPPP_TWIN / BPPP_PACE (plan_core.h: VerifyPlan::twin, ::pace); unset = by batch size
+    hipStream_t twin_stream = nullptr, twin_aux = nullptr;      // the second half's stream pair of a twin verify call (bppp_u64.hip: ensure_twin_lanes)
+    hipEvent_t ev_twin_fork = nullptr, ev_twin_join = nullptr, ev2_fork = nullptr, ev2_join = nullptr, ev2_tab = nullptr;
     int shared_inv = -1;      // diagnostic BPPP_SHARED_INV: proofs per shared field inversion in the one-lane verify kernels (0 = none, 2 4 8 16); unset = by batch size (plan_core.h)
     int tables_beside = -1;   // diagnostic BPPP_TABLES_BESIDE: the one-lane table kernel beside phase 1 always (1) / never (0); unset = where the lane kernels are a lone wavefront per SIMD
     long scal_parts_max = -1;   // diagnostic BPPP_SCAL_PARTS_MAX: largest prove call whose round scalars go out as four workgroups per 64 values
@@ -194,6 +199,8 @@ static inline void quiesce(bppp_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->twin_stream) (void)hipStreamSynchronize(c->twin_stream);
+    if (c->twin_aux) (void)hipStreamSynchronize(c->twin_aux);
     (void)hipGetLastError();
 }
 
@@ -269,6 +276,23 @@ static inline int ensure_prove_capacity(bppp_ctx* c, size_t n) {
     c->pcap = cap;
     return BPPP_OK;
 }
+// the per-proof workspaces of the u64 verifier given back (a call that ran out of memory retries with smaller parts: bppp_u64.hip)
+static inline void release_workspaces(bppp_ctx* c) {
+    if (c->d_ws) { (void)hipFree(c->d_ws); c->d_ws = nullptr; }
+    c->cap = 0; c->ws_bytes = 0; c->d_zinv = nullptr;
+    if (c->d_atab) { (void)hipFree(c->d_atab); c->d_atab = nullptr; }
+    if (c->d_tscr) { (void)hipFree(c->d_tscr); c->d_tscr = nullptr; }
+    c->vcap = 0; c->vtab_bytes = 0;
+    if (c->d_rlc) { (void)hipFree(c->d_rlc); c->d_rlc = nullptr; }
+    c->rcap = 0; c->rlc_bytes = 0;
+    if (c->d_straus) { (void)hipFree(c->d_straus); c->d_straus = nullptr; }
+    c->scap = 0; c->straus_bytes = 0;
+    if (c->d_bkt) { (void)hipFree(c->d_bkt); c->d_bkt = nullptr; }
+    c->bcap = 0; c->bkt_bytes = 0;
+    if (c->d_pws) { (void)hipFree(c->d_pws); c->d_pws = nullptr; }
+    c->pcap = 0; c->pws_bytes = 0;
+    (void)hipGetLastError();
+}
 static inline int ensure_stage(bppp_ctx* c, size_t bytes) {
     if (bytes <= c->stage_bytes) return BPPP_OK;
     if (c->d_stage) { (void)hipFree(c->d_stage); c->d_stage = nullptr; c->stage_bytes = 0; }
@@ -277,6 +301,21 @@ static inline int ensure_stage(bppp_ctx* c, size_t bytes) {
     return BPPP_OK;
 }
 // workspace carve-up: the SoA stride is the batch size n of THIS call (so lanes stay coalesced for any n <= cap)
+// (carve_from: the same carve-up at any base -- the halves of a twin call sit side by side in d_ws; returns where the half's zinv rows are)
+static inline u32* carve_from(bppp_ctx* c, VerifyWs& ws, size_t n, u32* p) {
+    ws.N = n;
+    ws.tstate = p; p += 52 * n;
+    ws.chal = p; p += 80 * n;
+    ws.sc0 = p; p += 176 * n;
+    ws.cvec = p; p += 200 * n;
+    ws.pts = p; p += 208 * n;
+    ws.lns = p; p += 24 * n;
+    ws.acc = p; p += 30 * n;
+    ws.pfix = p; p += 30 * n;
+    ws.fsc = p; p += 392 * n;
+    (void)c;
+    return p;
+}
 static inline void carve(bppp_ctx* c, VerifyWs& ws, size_t n) {
     u32* p = c->d_ws;
     ws.N = n;
@@ -424,6 +463,8 @@ static inline int check_device(int device) {
     return BPPP_OK;
 }
 
+// bppp_u64.hip: the context's second stream pair (twin verify calls, parts of a generic call) and its events
+int bppp_ensure_twin_lanes(bppp_ctx* c);
 // bppp_ctx.hip: make sure the context has the 4-bit table of the "ct_prover" mode (built once, 3 MB for the u64 generators)
 int ensure_ct_table(bppp_ctx* c);
 // bppp_coalesce.hip: drain and drop the context's single-proof front ends (final: refuse later *_one calls with BPPP_ERR_CLOSED)

@@ -108,7 +108,8 @@ __global__ __launch_bounds__(64) void k_verify_final_check_flagged(VerifyWs ws, 
     const int lane = (int)threadIdx.x;
     const size_t C = rlc_chunk_of(r);
     const size_t items = (size_t)(*r.count) * C;
-    if (items >= BPPP_FLAGGED_L8_FROM) return;   // many: k_verify_final_check_flagged_l8 / _dense do them
+    if (items >= BPPP_FLAGGED_L8_FROM || items * 8 > ws.N) return;   // many: k_verify_final_check_flagged_l8 does them; dense (a small batch with
+                                                                     // many bad chunks): k_verify_final_check_flagged_dense does -- exactly one of the three
 #pragma nounroll
     for (size_t item = blockIdx.x; item < items; item += gridDim.x) {
         const size_t t = (size_t)r.list[item / C] * C + item % C;

@@ -14,7 +14,8 @@
 //           n <= 32 S       (32,768)   rounds on 2 lanes per proof; one-lane table kernel beside phase 1
 //           n <= 64 S       (65,536)   one lane per proof in uncapped builds; tables beside phase 1; last round's sum beside the final sum
 //           n <  128 S      (131,072)  the 256-register builds, 8 lanes per fixed-base sum
-//           n >= 128 S                 one lane per fixed-base sum
+//           n >= 128 S                 one lane per fixed-base sum; up to 288 S (a chip filled once or twice) as TWO half-batch chains of
+//                                      kernels that leapfrog on the SIMDs (twin), and up to 128 S with progress-paced wave priority (pace)
 //   prove   n <= S: a wavefront per sum, wide round scalars | n <= 4 S: 16-lane stages and folds | n <= 16 S: 4-lane stages and folds |
 //           n <= 32 S: next commitment from fixed-base sums | n <= 128 S: round scalars in four parts | n >= 128 S: one lane per sum;
 //           the 256-register builds from more than 64 S values (one wavefront per SIMD) on
@@ -33,6 +34,8 @@ struct PlanKnobs {
     int tables_beside = -1, tail_beside = -1, fb_one_lane_mode = -1, next_overlap = -1;      // diagnostics: -1 = by size
     long next_msm_max = -1, lane_forms_max = -1, lane4_max = -1, scal_parts_max = -1;       // diagnostics: -1 = by n_simds
     int shared_inv = -1;         // diagnostics: proofs per shared inversion (0 none, 2 4 8 16) wherever the one-lane kernels run; -1 = by size
+    int twin = -1;               // diagnostics: 1 = two half-batch sequences wherever the form allows it, 0 = never; -1 = by size
+    int pace = -1;               // diagnostics: 1 = progress-paced wave priority in the one-lane sums always, 0 = never; -1 = by size
 };
 
 enum PlanTables { TABLES_INLINE = 0, TABLES_ASIDE, TABLES_BESIDE };        // on the main stream | lane-per-point kernel on the helper stream | one-lane kernel beside phase 1
@@ -52,10 +55,14 @@ struct VerifyPlan {
     size_t vtab_sets = 1;        // window-table sets per proof the call needs room for
     int shared_inv = 0;          // G = 2, 4, 8, 16: the field inversions of the table build and of the rounds are taken once per G proofs by
                                  // kernels of their own between the passes (verify_core.h: fe_batch_inv_lane); 0: every lane inverts for itself
+    int twin = 1;                // 2: the batch runs as TWO half-batch launch sequences on two stream pairs (each half on the plan plan_verify_half
+                                 // gives it); the other fields then describe a half.  1: one sequence
+    bool pace = false;           // the one-lane sums lower their wave priority as they advance (verify_core.h: straus_pace)
     uint32_t code() const {
         const uint32_t lg = shared_inv >= 16 ? 4 : shared_inv >= 8 ? 3 : shared_inv >= 4 ? 2 : shared_inv >= 2 ? 1 : 0;
         return (uint32_t)phase1 | (uint32_t)tables << 4 | (uint32_t)tparts << 8 | (uint32_t)fb << 12 | (uint32_t)c0var << 16 | (uint32_t)round << 20 |
-               (uint32_t)(tail_beside ? 1 : 0) << 24 | (uint32_t)(small ? 1 : 0) << 25 | (uint32_t)(split ? 1 : 0) << 26 | lg << 27;
+               (uint32_t)(tail_beside ? 1 : 0) << 24 | (uint32_t)(small ? 1 : 0) << 25 | (uint32_t)(split ? 1 : 0) << 26 | lg << 27 |
+               (uint32_t)(twin == 2 ? 1 : 0) << 30 | (uint32_t)(pace ? 1 : 0) << 31;
     }
 };
 
@@ -94,8 +101,36 @@ inline VerifyPlan plan_verify(size_t n, const PlanKnobs& k, bool rlc) {
     const int by_size = n >= 1024 * S ? 16 : n >= 256 * S ? 8 : 0;
     const int want = k.shared_inv >= 0 ? k.shared_inv : by_size;
     p.shared_inv = !one_lane_all ? 0 : want >= 16 ? 16 : want >= 8 ? 8 : want >= 4 ? 4 : want >= 2 ? 2 : 0;
+    // A launch that fills the chip exactly once or twice ends in a long tail: the arbiter serves the older wavefront of a SIMD's pair
+    // first, so one finishes early and its partner runs on alone at a lone wavefront's issue rate -- 41 % of the SIMD-time of the rounds
+    // at 2^17 proofs (profiles/r06/r06_a_wave_timeline.txt), 9 % over the saturated rate for the whole call.  Two remedies, both plan fields:
+    //   twin: the batch as two halves, each a launch sequence of its own on its own stream pair.  A SIMD then holds one wavefront of each
+    //         half, of DIFFERENT kernels; when the older one ends, its sequence's next kernel moves in: the halves leapfrog and no SIMD
+    //         is left with one wavefront except at the very end.  The halves run the 256-register one-lane kernels (plan_verify_half);
+    //   pace: the sums lower their own wave priority as they advance, so that a pair ends together (verify_core.h: straus_pace).
+    //   Where each pays (one box, child contexts timed in turns, profiles/r06/r06_j_twin_sizes.txt; g = wavefronts / wavefront slots):
+    //   twin  g = 1 (2^17 proofs) -1.4 % on top of pace, 1.06 .. 1.25 -3 .. -6 %, 1.75 -11 %, 2 (2^18) -3.5 %, 2.25 -6 %; but +4 % at g = 1.5,
+    //         +2 .. +4 % from 2.5 up (the halves' own part-filled generations collide): so up to g = 2.25, except a last generation that is
+    //         30 .. 70 % full;
+    //   pace  g <= 1 (one generation of pairs): -1.5 .. -2.3 %; +1.5 % beyond (a new wavefront must not outrank a half-done one).
+    const size_t G = 2 * S, rem = blocks % G;
+    const bool fills_once = blocks > S && blocks <= G;            // more than one wavefront per SIMD, at most two: ONE generation of pairs
+    const bool twin_by_size = blocks >= G && 4 * blocks <= 9 * G && !(10 * rem > 3 * G && 10 * rem < 7 * G);
+    const bool twin_ok = !rlc && !k.timing && one_lane_all && fb_one_lane && n >= 2 * PLAN_BLOCK;
+    p.twin = twin_ok && (k.twin >= 0 ? k.twin == 1 : twin_by_size) ? 2 : 1;
+    p.pace = one_lane_all && (k.pace >= 0 ? k.pace == 1 : fills_once);
     return p;
 }
+// the plan of ONE half of a twin call (n_half proofs): the 256-register one-lane kernels and one lane per fixed-base sum whatever the
+// half's size -- a half shares every SIMD with a wavefront of the other half
+inline VerifyPlan plan_verify_half(size_t n_half, const PlanKnobs& k, bool pace) {
+    PlanKnobs h = k;
+    h.no_small = true; h.fb_one_lane_mode = 1; h.tables_beside = 0; h.tail_beside = 0; h.twin = 0; h.pace = pace ? 1 : 0;
+    VerifyPlan p = plan_verify(n_half, h, false);
+    p.twin = 2;
+    return p;
+}
+inline size_t twin_first_half(size_t n) { return (n / 2 + PLAN_BLOCK - 1) / PLAN_BLOCK * PLAN_BLOCK; }
 
 enum PlanStage { ST_FULL = 0, ST_W2, ST_G4, ST_G4_W2, ST_G16, ST_G16_W2 };      // one lane (uncapped | 256 registers), 4 lanes, 16 lanes per value
 enum PlanScalars { SC_ONE = 0, SC_PARTS, SC_WIDE };
@@ -189,9 +224,10 @@ inline int plan_describe(uint32_t code, bool prove, char* buf, size_t cap) {
     static const char* const SC[] = {"one", "parts", "wide"};
     auto pick = [](const char* const* t, size_t nt, uint32_t i) { return i < nt ? t[i] : "?"; };
     if (!prove)
-        return std::snprintf(buf, cap, "phase1=%s tables=%s/%u fb=%s c0var=%s round=%s tail_beside=%u small=%u split=%u shared_inv=%u", pick(P1, 4, code & 15),
+        return std::snprintf(buf, cap, "phase1=%s tables=%s/%u fb=%s c0var=%s round=%s tail_beside=%u small=%u split=%u twin=%u pace=%u shared_inv=%u", pick(P1, 4, code & 15),
                              pick(TB, 3, (code >> 4) & 15), (code >> 8) & 15, pick(FB, 4, (code >> 12) & 15), pick(CV, 5, (code >> 16) & 15),
-                             pick(RD, 6, (code >> 20) & 15), (code >> 24) & 1, (code >> 25) & 1, (code >> 26) & 1, ((code >> 27) & 7) ? 1u << ((code >> 27) & 7) : 0u);
+                             pick(RD, 6, (code >> 20) & 15), (code >> 24) & 1, (code >> 25) & 1, (code >> 26) & 1, ((code >> 30) & 1) + 1u, (code >> 31) & 1,
+                             ((code >> 27) & 7) ? 1u << ((code >> 27) & 7) : 0u);
     return std::snprintf(buf, cap, "fb=%s fb4_from_jobs=%u stage=%s fold=%s scalars=%s next_by_msm=%u w2=%u overlap_next=%u next_g4=%u ct=%u",
                          pick(FB, 4, code & 15), (code >> 4) & 15, pick(ST, 6, (code >> 8) & 15), pick(ST, 6, (code >> 12) & 15), pick(SC, 3, (code >> 16) & 15),
                          (code >> 20) & 1, (code >> 21) & 1, (code >> 22) & 1, (code >> 23) & 1, (code >> 24) & 1);

@@ -22,12 +22,28 @@
 
 namespace bppp {
 
-// Optional phase stamps (diagnostic builds only: -DBPPP_PHASE_TIMING): lane 0 of every wavefront records the constant-rate 100 MHz
+// Optional phase stamps (diagnostic builds only: -DBPPP_PHASE_TIMING): lane 0 of the sampled wavefronts records the constant-rate 100 MHz
 // counter (s_memrealtime: one time base for all eight XCDs, unlike the per-XCD shader-clock counter of clock64()) at marked points of
-// verify_phase1 / verify_round / verify_tables / verify_c0_var into g_bppp_stamps; tools/probes/phase_probe.py and tools/probes/wave_timeline.py read them back.
+// verify_phase1 / verify_round / verify_tables / verify_c0_var into ws.stamps (BPPP_STAMP_WAVES rows of 32 words; every ws.stamp_stride-th
+// wavefront of a launch has a row) and, at the first stamp of each kernel, where it runs (HW_ID | XCC_ID << 32, words 24..28);
+// tools/probes/phase_probe.py and tools/probes/wave_timeline.py read them back through bppp_debug_read_stamps.
+#define BPPP_STAMP_WAVES 4096
 #if defined(BPPP_PHASE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-extern __device__ unsigned long long g_bppp_stamps[1024 * 32];
-#define BPPP_STAMP(t, i) do { if (((t) & 63) == 0 && ((t) >> 6) < 1024) g_bppp_stamps[((t) >> 6) * 32 + (i)] = (unsigned long long)wall_clock64(); } while (0)
+#define BPPP_STAMP(t, i) bppp_stamp(ws.stamps, ws.stamp_stride, (t), (i))
+__device__ __forceinline__ void bppp_stamp(unsigned long long* stamps, unsigned stride, size_t t, int i) {
+    if ((t & 63) != 0 || !stamps) return;
+    const size_t w = t >> 6;
+    if (w % stride != 0 || w / stride >= BPPP_STAMP_WAVES) return;
+    unsigned long long* row = stamps + (w / stride) * 32;
+    row[i] = (unsigned long long)wall_clock64();
+    const int where = i == 0 ? 24 : i == 9 ? 25 : i == 16 ? 26 : i == 20 ? 27 : i == 22 ? 28 : -1;
+    if (where >= 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        row[where] = (unsigned long long)hw | (unsigned long long)xcc << 32;
+    }
+}
 #else
 #define BPPP_STAMP(t, i) ((void)0)
 #endif
@@ -80,6 +96,11 @@ struct VerifyWs {
     const uint8_t* states;
     size_t n_states;
     uint8_t* states_out;
+    int pace;                    // 1: the one-lane sums pace their wave priority by progress (straus_pace; plan_core.h: VerifyPlan::pace)
+#if defined(BPPP_PHASE_TIMING)
+    unsigned long long* stamps;  // diagnostic builds: BPPP_STAMP's rows (null: none)
+    unsigned stamp_stride;
+#endif
 };
 #define BPPP_TRANSCRIPT_STATE_BYTES 203
 HD bool strobe_from_bytes(strobe& s, const uint8_t* b) {
@@ -1564,15 +1585,34 @@ HD void glv_digit_of(const glv_words<M>& g, u64 pk, int r, int& mag, bool& neg) 
     mag = dg < 0 ? -dg : dg;
     neg = (dg < 0) != sneg;
 }
+// Progress-paced wave priority (VerifyWs::pace).  The SIMD's instruction arbiter serves the OLDER of two wavefronts first, so when a launch
+// fills the chip exactly once (2^17 proofs: two wavefronts per SIMD, all started together) one wavefront of each pair runs almost
+// as if alone and its partner mostly waits, then finishes alone at a lone wavefront's poor issue rate: 41 % of the SIMD-time of
+// k_verify_round at 2^17 proofs has ONE wavefront resident (profiles/r06/r06_a_wave_timeline.txt).  With pacing on, a wavefront lowers
+// its own priority (s_setprio 3 .. 0) as it advances through the windows of its sum, in spans that halve towards the end: whichever
+// of the pair is behind is served first, the two reach the end within a few windows of each other, and the lone tail shrinks to that.
+// window: 25 (first) .. 0 (last).  Wave-uniform; a handful of scalar instructions per window.
+HD void straus_pace(bool pace, int window) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!pace) return;
+    if (window >= 13) __builtin_amdgcn_s_setprio(3);
+    else if (window >= 6) __builtin_amdgcn_s_setprio(2);
+    else if (window >= 3) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#else
+    (void)pace; (void)window;
+#endif
+}
 // sum_j k_j P_j over the affine tables; pidx[j] = table (proof point slot) of P_j.  26 windows x (5 doublings + 2M mixed
 // additions); stream 2j is k1 of P_j, stream 2j + 1 its GLV partner (the entry's x times beta: the stream index is uniform over
 // the wavefront, so that multiplication is behind a real branch).  The table entry of the next addition is requested before the
 // current one starts.  Returns false when an exceptional addition was met (re-do with straus_affine_complete).
 template <int M>
-HD bool straus_affine_fast(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g) {
+HD bool straus_affine_fast(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g, bool pace = false) {
     const int total = BPPP_VWINDOWS * 2 * M;
     fe beta;
     glv_beta(beta);
+    straus_pace(pace, BPPP_VWINDOWS - 1);
     ptj acc;
     ptj_init(acc);
     bool empty = true;
@@ -1595,6 +1635,7 @@ HD bool straus_affine_fast(pt& out, atab_ref tab, const int* pidx, const glv_wor
         for (int j = 0; j < M; j++) pn = (j == (rn >> 1)) ? pidx[j] : pn;
         nxt_e = tab[pn * 16 + (nxt_mag ? nxt_mag - 1 : 0)];
         if (r == 0 && s != 0) {
+            straus_pace(pace, i);
 #pragma nounroll
             for (int d = 0; d < 5; d++) ptj_dbl(acc);
         }
@@ -1753,8 +1794,8 @@ HD void straus_affine_complete(pt& out, atab_ref tab, const int* pidx, const glv
 }
 #endif   // BPPP_VWIN
 template <int M>
-HD void straus_affine(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g) {
-    if (!straus_affine_fast<M>(out, tab, pidx, g)) {
+HD void straus_affine(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g, bool pace = false) {
+    if (!straus_affine_fast<M>(out, tab, pidx, g, pace)) {
         // the out-of-line call takes addresses: hand it copies, so the hot loop's scalars and accumulator stay in registers
         glv_words<M> gc = g;
         int pc[M];
@@ -2300,7 +2341,7 @@ HD void verify_c0_var(const VerifyWs& ws, size_t t, int group_lane = -1, int gro
     else if (group_lane >= 0) straus_affine_g4<5>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
     else
 #endif
-        straus_affine<5>(acc, atab_of(ws.atab, ws.N, t), pslot, g);
+        straus_affine<5>(acc, atab_of(ws.atab, ws.N, t), pslot, g, ws.pace != 0);
     (void)group_lane; (void)group_size;
     BPPP_STAMP(t, 21);
     ws_st_pt(ws.acc, N, t, acc);   // the fixed-base part (pfix) is added at the top of round 1
@@ -2398,7 +2439,7 @@ HD void verify_round_on(const VerifyWs& ws, size_t t, int k, TR& tr, int group_l
     else if (group_lane >= 0) straus_affine_g4<2, 2>(acc, atab_of(ws.atab, ws.N, t), pslot, g, group_lane);
     else
 #endif
-        straus_affine<2>(acc, atab_of(ws.atab, ws.N, t), pslot, g);
+        straus_affine<2>(acc, atab_of(ws.atab, ws.N, t), pslot, g, ws.pace != 0);
     (void)group_lane; (void)group_size;
     BPPP_STAMP(t, 13);
     pt_madd(acc, acc, Ca, apt_is_identity(Ca));

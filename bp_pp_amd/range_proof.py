@@ -64,14 +64,21 @@ class U64RangeProofProtocol:
     DIM_ND = 16
     DIM_NP = 16
 
-    def __init__(self, g: bytes, g_vec: Sequence[bytes], h_vec: Sequence[bytes], device: int = 0, fb_window_bits: int = 0):
+    def __init__(self, g: bytes, g_vec: Sequence[bytes], h_vec: Sequence[bytes], device: int = 0, fb_window_bits: int = 0,
+                 fb_table_budget_bytes: int = 0):
+        """fb_window_bits = 0: the library sizes the fixed-base tables to the HBM that is free (include/bppp.h); fb_table_budget_bytes > 0
+        bounds what they may take (bppp_wnla_ctx_create_budget)."""
         if len(g_vec) != G_VEC_FULL_SZ or len(h_vec) != H_VEC_FULL_SZ:
             raise ValueError("g_vec must hold 16 points and h_vec 32 points")
         self.g, self.g_vec, self.h_vec = bytes(g), [bytes(p) for p in g_vec], [bytes(p) for p in h_vec]
         self.device = device
         self._ctx = C.c_void_p()
-        _capi.check(_capi.lib().bppp_ctx_create(C.byref(self._ctx), self.g, b"".join(self.g_vec), b"".join(self.h_vec),
-                                                device, fb_window_bits))
+        if fb_table_budget_bytes:
+            _capi.check(_capi.lib().bppp_wnla_ctx_create_budget(C.byref(self._ctx), self.g, b"".join(self.g_vec), G_VEC_FULL_SZ, b"".join(self.h_vec),
+                                                                H_VEC_FULL_SZ, device, fb_window_bits, int(fb_table_budget_bytes)))
+        else:
+            _capi.check(_capi.lib().bppp_ctx_create(C.byref(self._ctx), self.g, b"".join(self.g_vec), b"".join(self.h_vec),
+                                                    device, fb_window_bits))
 
     @classmethod
     def _wrap(cls, ctx, g=b"", g_vec=(), h_vec=(), device=0, parent=None):

@@ -27,11 +27,12 @@ def _states(transcripts) -> np.ndarray:
 
 
 class WeightNormLinearArgument:
-    def __init__(self, g: bytes, g_vec: Sequence[bytes], h_vec: Sequence[bytes], device: int = 0, fb_window_bits: int = 0):
+    def __init__(self, g: bytes, g_vec: Sequence[bytes], h_vec: Sequence[bytes], device: int = 0, fb_window_bits: int = 0,
+                 fb_table_budget_bytes: int = 0):
         self.ng, self.nh = len(g_vec), len(h_vec)
         self._ctx = C.c_void_p()
-        _capi.check(_capi.lib().bppp_wnla_ctx_create(C.byref(self._ctx), bytes(g), b"".join(g_vec), self.ng, b"".join(h_vec),
-                                                     self.nh, device, fb_window_bits))
+        _capi.check(_capi.lib().bppp_wnla_ctx_create_budget(C.byref(self._ctx), bytes(g), b"".join(g_vec), self.ng, b"".join(h_vec),
+                                                            self.nh, device, fb_window_bits, int(fb_table_budget_bytes)))
 
     @classmethod
     def borrowed(cls, ctx: int, ng: int, nh: int) -> "WeightNormLinearArgument":

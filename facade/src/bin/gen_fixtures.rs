@@ -2,6 +2,13 @@
 //! stdout, everything needed to pin this repository's oracle and HIP path to it:
 //!
 //!   cargo run --release --no-default-features --bin gen_fixtures > ../tests/golden/ref_u64.json
+//!   cargo run --release --no-default-features --bin gen_fixtures -- generic ../tests/golden/statements_generic.json > ../tests/golden/ref_generic.json
+//!
+//! The second form pins the crate's `circuit` and `wnla` modules: it reads STATEMENTS (dimensions, W_m / W_l / a_m / a_l, the partition
+//! as index tables, a witness; WNLA: l and n) written by tests/golden/make_statements_generic.py -- the reference's own `ac_works` and
+//! `wnla_works` (tests.rs:45-171) and the k > 1 / f_m / f_l-and-f_m shapes of tests/circuit_cases.py --, draws generators and blindings
+//! from the seeded RNG, runs the reference's prover and the reference's OWN verifier on its output, and records both: for the f_l-and-f_m
+//! shape this repository's oracle predicts `accept: false` (circuit.rs:559-614); only this run can confirm or refute that.
 //!
 //! (no GPU and no libbppp_hip.so needed).  tests/test_ref_fixtures.py and tests/test_gpu_ref_fixtures.py consume the file when it
 //! exists and skip -- saying so -- when it does not.  UNCOMPILED: written without a Rust toolchain (see lib.rs).
@@ -10,7 +17,9 @@
 //! prover and demand byte-identical proofs, (b) check the model of `Scalar::generate_biased` (64 bytes, big-endian, reduced mod
 //! n), (c) check accept bits, (d) check the transcript state the reference leaves behind (`t: &mut Transcript`), and (e) settle
 //! the serde / hex conventions (`proof_json`, `commitment_json`, `identity_json`).
+use bp_pp::circuit::{ArithmeticCircuit, PartitionType, Witness};
 use bp_pp::range_proof::reciprocal::{Proof, SerializableProof};
+use bp_pp::wnla::WeightNormLinearArgument;
 use bp_pp::range_proof::u64_proof::{U64RangeProofProtocol, G_VEC_FULL_SZ, H_VEC_FULL_SZ};
 use bp_pp_gpu::{conv, tstate};
 use k256::elliptic_curve::group::GroupEncoding;
@@ -76,7 +85,151 @@ fn abi_proof(p: &Proof) -> String {
     hex::encode(v)
 }
 
+fn hex_scalar(v: &serde_json::Value) -> Scalar {
+    let b = hex::decode(v.as_str().expect("a hex string")).expect("hex");
+    conv::get_scalar(&b).expect("a canonical scalar")
+}
+fn hex_scalars(v: &serde_json::Value) -> Vec<Scalar> {
+    v.as_array().expect("an array of hex scalars").iter().map(hex_scalar).collect()
+}
+fn abi_points(ps: &[ProjectivePoint]) -> String {
+    let mut v = Vec::new();
+    ps.iter().for_each(|p| conv::put_point(&mut v, p));
+    hex::encode(v)
+}
+fn abi_scalars(ss: &[Scalar]) -> String {
+    let mut v = Vec::new();
+    ss.iter().for_each(|x| conv::put_scalar(&mut v, x));
+    hex::encode(v)
+}
+/// the scalars a prover drew, by k256's own reduction of the recorded bytes (one `generate_biased` per recorded request)
+fn replay_scalars(bytes: &[u8], calls: &[usize]) -> Vec<Scalar> {
+    let mut rp = Replay(bytes, 0);
+    calls.iter().map(|_| Scalar::generate_biased(&mut rp)).collect()
+}
+fn pow2_at_least(n: usize) -> usize {
+    let mut p = 1;
+    while p < n {
+        p *= 2;
+    }
+    p
+}
+
+/// `generic` mode: circuit.rs and wnla.rs through the reference itself (see the module comment).
+fn generic(statements_path: &str) {
+    let seed = *b"bppp-ref-fixtures-v1-seed-000002";
+    let mut rng = RecordingRng { inner: ChaCha20Rng::from_seed(seed), bytes: vec![], calls: vec![] };
+    let st: serde_json::Value = serde_json::from_str(&std::fs::read_to_string(statements_path).expect("the statements file")).expect("JSON");
+    let mut circuits = vec![];
+    for c in st["circuits"].as_array().expect("circuits") {
+        let usz = |k: &str| c[k].as_u64().expect(k) as usize;
+        let (dim_nm, dim_no, dim_nv, k) = (usz("dim_nm"), usz("dim_no"), usz("dim_nv"), usz("k"));
+        let (dim_nl, dim_nw) = (dim_nv * k, 2 * dim_nm + dim_no);
+        let label: &'static [u8] = Box::leak(hex::decode(c["label"].as_str().unwrap()).unwrap().into_boxed_slice());
+        let rows = |key: &str| -> Vec<Vec<Scalar>> { c[key].as_array().unwrap().iter().map(hex_scalars).collect() };
+        let table = |t: &str| -> Vec<i64> { c["partition"][t].as_array().unwrap().iter().map(|v| v.as_i64().unwrap()).collect() };
+        let (lo, ll, lr, no) = (table("LO"), table("LL"), table("LR"), table("NO"));
+        // generators as the reference's own tests draw them (tests.rs:78-80); padded to the powers of two the WNLA stage needs
+        let (ng, nh) = (pow2_at_least(dim_nm), pow2_at_least(dim_nv + 9));
+        let g = ProjectivePoint::random(&mut rng);
+        let g_all: Vec<ProjectivePoint> = (0..ng).map(|_| ProjectivePoint::random(&mut rng)).collect();
+        let h_all: Vec<ProjectivePoint> = (0..nh).map(|_| ProjectivePoint::random(&mut rng)).collect();
+        rng.take();
+        let partition = move |typ: PartitionType, index: usize| -> Option<usize> {
+            let t = match typ {
+                PartitionType::LO => &lo,
+                PartitionType::LL => &ll,
+                PartitionType::LR => &lr,
+                PartitionType::NO => &no,
+            };
+            t.get(index).and_then(|v| if *v < 0 { None } else { Some(*v as usize) })
+        };
+        let circuit = ArithmeticCircuit {
+            dim_nm, dim_no, k, dim_nl, dim_nv, dim_nw,
+            g,
+            g_vec: g_all[..dim_nm].to_vec(),
+            h_vec: h_all[..9 + dim_nv].to_vec(),
+            W_m: rows("W_m"),
+            W_l: rows("W_l"),
+            a_m: hex_scalars(&c["a_m"]),
+            a_l: hex_scalars(&c["a_l"]),
+            f_l: c["f_l"].as_bool().unwrap(),
+            f_m: c["f_m"].as_bool().unwrap(),
+            g_vec_: g_all[dim_nm..].to_vec(),
+            h_vec_: h_all[9 + dim_nv..].to_vec(),
+            partition,
+        };
+        let v_rows = rows("v");
+        let mut instances = vec![];
+        for _ in 0..c["instances"].as_u64().unwrap_or(1) {
+            let s_v: Vec<Scalar> = (0..k).map(|_| Scalar::generate_biased(&mut rng)).collect();
+            rng.take();
+            let witness = Witness { v: v_rows.clone(), s_v: s_v.clone(), w_l: hex_scalars(&c["w_l"]), w_r: hex_scalars(&c["w_r"]), w_o: hex_scalars(&c["w_o"]) };
+            let v: Vec<ProjectivePoint> = (0..k).map(|i| circuit.commit(&witness.v[i], &witness.s_v[i])).collect();
+            let mut pt = Transcript::new(label);
+            let proof = circuit.prove(&v, witness, &mut pt, &mut rng);
+            let (rng_bytes, rng_calls) = rng.take();
+            let rnd = replay_scalars(&rng_bytes, &rng_calls);
+            let mut vt = Transcript::new(label);
+            let accept = circuit.verify(&v, &mut vt, proof.clone());
+            // the C ABI's layout: c_l, c_r, c_o, c_s | r[rounds] | x[rounds] | l[nl] | n[nn]
+            let mut pb = Vec::new();
+            for q in [&proof.c_l, &proof.c_r, &proof.c_o, &proof.c_s] {
+                conv::put_point(&mut pb, q);
+            }
+            proof.r.iter().chain(proof.x.iter()).for_each(|q| conv::put_point(&mut pb, q));
+            proof.l.iter().chain(proof.n.iter()).for_each(|x| conv::put_scalar(&mut pb, x));
+            instances.push(json!({
+                "s_v": abi_scalars(&s_v), "rng_bytes": hex::encode(&rng_bytes), "rng_calls": rng_calls, "rnd": abi_scalars(&rnd),
+                "commitments": abi_points(&v), "proof": hex::encode(&pb), "rounds": proof.r.len(), "nl": proof.l.len(), "nn": proof.n.len(),
+                "state_after_prove": hex::encode(tstate::to_bytes(&pt)), "state_after_verify": hex::encode(tstate::to_bytes(&vt)),
+                "accept": accept,
+            }));
+        }
+        circuits.push(json!({
+            "name": c["name"], "label": c["label"], "g": abi_points(&[g]), "g_vec": abi_points(&g_all[..dim_nm]), "h_vec": abi_points(&h_all[..9 + dim_nv]),
+            "g_vec_": abi_points(&g_all[dim_nm..]), "h_vec_": abi_points(&h_all[9 + dim_nv..]), "instances": instances,
+        }));
+    }
+    let mut wnlas = vec![];
+    for w in st["wnla"].as_array().expect("wnla") {
+        let (ng, nh) = (w["ng"].as_u64().unwrap() as usize, w["nh"].as_u64().unwrap() as usize);
+        let label: &'static [u8] = Box::leak(hex::decode(w["label"].as_str().unwrap()).unwrap().into_boxed_slice());
+        // tests.rs:141-150: generators, c and rho from the RNG, mu = rho^2
+        let g = ProjectivePoint::random(&mut rng);
+        let g_vec: Vec<ProjectivePoint> = (0..ng).map(|_| ProjectivePoint::random(&mut rng)).collect();
+        let h_vec: Vec<ProjectivePoint> = (0..nh).map(|_| ProjectivePoint::random(&mut rng)).collect();
+        let c: Vec<Scalar> = (0..nh).map(|_| Scalar::generate_biased(&mut rng)).collect();
+        let rho = Scalar::generate_biased(&mut rng);
+        rng.take();
+        let mu = rho * rho;
+        let arg = WeightNormLinearArgument { g, g_vec: g_vec.clone(), h_vec: h_vec.clone(), c: c.clone(), rho, mu };
+        let (l, n) = (hex_scalars(&w["l"]), hex_scalars(&w["n"]));
+        let commit = arg.commit(&l, &n);
+        let mut pt = Transcript::new(label);
+        let proof = arg.prove(&commit, &mut pt, l.clone(), n.clone());
+        let mut vt = Transcript::new(label);
+        let accept = arg.verify(&commit, &mut vt, proof.clone());
+        wnlas.push(json!({
+            "name": w["name"], "label": w["label"], "ng": ng, "nh": nh, "g": abi_points(&[g]), "g_vec": abi_points(&g_vec), "h_vec": abi_points(&h_vec),
+            "c": abi_scalars(&c), "rho": abi_scalars(&[rho]), "mu": abi_scalars(&[mu]), "l": abi_scalars(&l), "n": abi_scalars(&n),
+            "commitment": abi_points(&[commit]), "proof_r": abi_points(&proof.r), "proof_x": abi_points(&proof.x),
+            "proof_l": abi_scalars(&proof.l), "proof_n": abi_scalars(&proof.n),
+            "state_after_prove": hex::encode(tstate::to_bytes(&pt)), "state_after_verify": hex::encode(tstate::to_bytes(&vt)), "accept": accept,
+        }));
+    }
+    let doc = json!({
+        "source": "distributed-lab/bp-pp 0.1.1 (k256 0.13.3, merlin 3.0.0), facade/src/bin/gen_fixtures.rs generic",
+        "seed": hex::encode(seed), "statements": statements_path, "circuits": circuits, "wnla": wnlas,
+    });
+    println!("{}", serde_json::to_string_pretty(&doc).unwrap());
+}
+
 fn main() {
+    let args: Vec<String> = std::env::args().collect();
+    if args.len() >= 3 && args[1] == "generic" {
+        return generic(&args[2]);
+    }
     let seed = *b"bppp-ref-fixtures-v1-seed-000001";
     let mut rng = RecordingRng { inner: ChaCha20Rng::from_seed(seed), bytes: vec![], calls: vec![] };
     let label: &'static [u8] = b"u64 range proof"; // benches/range_proof.rs:32

@@ -51,6 +51,7 @@ extern "C" {
     pub fn bppp_ctx_get_coalesce_stats(ctx: *mut BpppCtx, which: c_int, out: *mut u64) -> c_int;
     pub fn bppp_u64_commit_value_batch(ctx: *mut BpppCtx, n: usize, x: *const u64, s: *const u8, out: *mut u8) -> c_int;
     pub fn bppp_wnla_ctx_create(out: *mut *mut BpppCtx, g: *const u8, g_vec: *const u8, ng: usize, h_vec: *const u8, nh: usize, device: c_int, fb_window_bits: c_int) -> c_int;
+    pub fn bppp_wnla_ctx_create_budget(out: *mut *mut BpppCtx, g: *const u8, g_vec: *const u8, ng: usize, h_vec: *const u8, nh: usize, device: c_int, fb_window_bits: c_int, fb_table_budget_bytes: u64) -> c_int;
     pub fn bppp_wnla_commit_batch(ctx: *mut BpppCtx, n: usize, c: *const u8, mu: *const u8, l: *const u8, nl: usize, nvec: *const u8, nn: usize, out: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_wnla_verify_batch(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, commitments: *const u8, c: *const u8, rho: *const u8, mu: *const u8, rounds: usize, proof_r: *const u8, proof_x: *const u8, proof_l: *const u8, nl: usize, proof_n: *const u8, nn: usize, accept: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_msm_batch(ctx: *mut BpppCtx, n: usize, nterms: usize, base_index: *const i32, scalars: *const u8, out: *mut u8, status: *mut i32) -> c_int;

@@ -48,6 +48,16 @@ impl U64RangeProofProtocolGpu {
         put_point(&mut g, &p.g);
         p.g_vec.iter().for_each(|q| put_point(&mut gv, q));
         p.h_vec.iter().for_each(|q| put_point(&mut hv, q));
+        // The single-proof calls hand `merlin::Transcript` to the library as 203 serialized bytes read through a pointer cast
+        // (tstate.rs): before anything relies on that layout, compare it with a state computed WITHOUT the cast -- the library's own
+        // host-side `Transcript::new(label)` -- and refuse to construct the object if merlin's struct ever stops looking like that.
+        const CHECK_LABEL: &[u8] = b"bp-pp-gpu layout self-check";
+        let mut independent = [0u8; tstate::STATE_BYTES];
+        check(unsafe { bppp_transcript_new(CHECK_LABEL.as_ptr(), CHECK_LABEL.len(), independent.as_mut_ptr()) })?;
+        if !tstate::self_check(CHECK_LABEL, &independent) {
+            return Err(GpuError::Library { code: BPPP_ERR_INVALID_ARG, detail: "merlin::Transcript is not laid out as 200 state bytes + pos, pos_begin, cur_flags: \
+                                                                          the transcript bridge of this facade does not apply to this merlin version".into() });
+        }
         let mut ctx = std::ptr::null_mut();
         check(unsafe { bppp_ctx_create(&mut ctx, g.as_ptr(), gv.as_ptr(), hv.as_ptr(), device, fb_window_bits) })?;
         Ok(Self { ctx, cpu: p.clone() })

@@ -82,10 +82,13 @@ typedef struct bppp_ctx bppp_ctx;
  * An explicit fb_window_bits is a window code as above (any that tiles 258 bits with windows of 8 .. 24 bits) or one of the uniform
  * widths 22, 20, 19, 18, 10 (signed digits: ceil(257 / W) windows of 2^(W-1) entries), 16, 8, 4 (unsigned digits, 256 / W windows of
  * 2^W - 1 entries; 4 is the layout of the "ct_prover" tables).  For bppp_wnla_ctx_create the general rule over 1 + ng + nh generators
- * (769 generators: 14 windows, 129 GB).  bppp_ctx_save_tables / bppp_ctx_create_from_tables keep a built table set of a UNIFORM width
- * as a file. */
+ * (769 generators: 14 windows, 129 GB).  bppp_ctx_save_tables / bppp_ctx_create_from_tables keep a built table set of ONE region (a
+ * uniform width, or a two-width window code) as a file. */
 BPPP_API int bppp_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec /* 16 x 64 */,
                     const uint8_t* h_vec /* 32 x 64 */, int device, int fb_window_bits);
+/* Destroys the context.  Calls that are INSIDE the library when it is called are waited for (the single-proof entry points return
+ * BPPP_ERR_CLOSED to callers that arrive while it runs); once it has RETURNED the handle is dead: starting a new call on it is the
+ * caller's error, as with any freed object -- the caller orders its last call before the destroy. */
 BPPP_API void bppp_ctx_destroy(bppp_ctx* ctx);
 
 /* Run the context's kernels on a caller-owned hipStream_t (passed as void*); NULL restores the context's own stream.  The
@@ -269,6 +272,16 @@ BPPP_API int bppp_u64_commit_value_batch(bppp_ctx* ctx, size_t n, const uint64_t
  * entry points only (the u64 entry points require ng = 16, nh = 32, which bppp_ctx_create builds). */
 BPPP_API int bppp_wnla_ctx_create(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec /* ng x 64 */, size_t ng,
                                   const uint8_t* h_vec /* nh x 64 */, size_t nh, int device, int fb_window_bits);
+/* The same with a TABLE BUDGET: fb_table_budget_bytes > 0 bounds what the fixed-base tables may take, whichever way their layout is
+ * chosen (any generator shape, the u64 one included: ng = 16, nh = 32).  With fb_window_bits = 0 the library takes the fewest windows
+ * whose tables fit both the budget and the free-memory rule above; an explicit fb_window_bits whose tables exceed the budget is
+ * BPPP_ERR_INVALID_ARG.  0 = no budget (bppp_ctx_create / bppp_wnla_ctx_create: on an otherwise empty MI355X the u64 shape then takes
+ * 210 GB for its last 2.7 % of throughput -- INTEGRATION.md 5 has the cost curve).  What a context took and why can be read back:
+ * bppp_ctx_get_option "fb_table_bytes", "fb_table_budget_bytes", "fb_windows" (table additions per scalar), "fb_window_bits_widest".
+ * Contexts from bppp_ctx_create_shared inherit the parent's budget, max_batch and host_chunk. */
+BPPP_API int bppp_wnla_ctx_create_budget(bppp_ctx** out, const uint8_t g[64], const uint8_t* g_vec /* ng x 64 */, size_t ng,
+                                         const uint8_t* h_vec /* nh x 64 */, size_t nh, int device, int fb_window_bits,
+                                         uint64_t fb_table_budget_bytes);
 /* WeightNormLinearArgument::commit (wnla.rs:66-72): out[i] = v*g + <h_vec, l_i> + <g_vec, n_i>, v = <c_i, l_i> + |n_i|^2_mu. */
 BPPP_API int bppp_wnla_commit_batch(bppp_ctx* ctx, size_t n, const uint8_t* c /* n x nh x 32 */, const uint8_t* mu /* n x 32 */,
                                     const uint8_t* l /* n x nl x 32 */, size_t nl, const uint8_t* nvec /* n x nn x 32 */, size_t nn,
@@ -364,7 +377,7 @@ BPPP_API int bppp_derive_generators(const uint8_t* seed, size_t seed_len, size_t
 /* The fixed-base tables of a context as a file, and a context created from such a file instead of from the generators (any of the
  * bppp_ctx_create / bppp_wnla_ctx_create shapes).  NOTE: the tables are BUILT on the GPU in 0.5 s (79 GB, 22-bit) to 3 s -- faster than any
  * disk or PCIe can deliver them -- so the file is for reproducibility and inspection, not for start-up time; what saves memory and
- * time is bppp_ctx_create_shared.  The file (magic "BPPPTAB3") carries a checksum over its header (generator counts, window width), the generators and the table body, and the
+ * time is bppp_ctx_create_shared.  The file (magic "BPPPTAB3" for a uniform width, "BPPPTAB4" for a two-width window code; a table in two regions is not saveable) carries a checksum over its header (generator counts, window width), the generators and the table body, and the
  * stored generators are validated as bppp_ctx_create validates them: a truncated, damaged or foreign file makes
  * bppp_ctx_create_from_tables fail (BPPP_ERR_INVALID_ARG / BPPP_ERR_ENCODING) instead of yielding a verifier over wrong bases.  The
  * checksum is not a MAC: whoever can rewrite the file can rewrite it too -- rebuild the tables when the storage is not trusted. */

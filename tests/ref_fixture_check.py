@@ -126,3 +126,143 @@ def oracle_made_document(n_cases: int = 3):
     return {"source": "THIS repository's oracle (consumer self-test; pins nothing)", "label": label.hex(), "generators": gens.hex(),
             "cases": cases, "negative_cases": negs, "identity_to_bytes": bytes(33).hex(), "identity_json": "00",
             "merlin_kat": {"challenge": "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"}}
+
+
+# ---- the `generic` documents (gen_fixtures.rs generic: the crate's circuit.rs and wnla.rs on the statements of tests/golden/statements_generic.json)
+def load_statements():
+    with open(os.path.join(GOLD, "statements_generic.json")) as f:
+        st = json.load(f)
+    return {c["name"]: c for c in st["circuits"]}, {w["name"]: w for w in st["wnla"]}
+
+
+def _circuit_call_args(st, cdoc):
+    """ctypes arguments of bppp_oracle_circuit_{prove,verify} for statement `st` over the generators recorded in `cdoc`."""
+    import ctypes as C
+    sz = C.c_size_t
+    nm, no, nv, k = st["dim_nm"], st["dim_no"], st["dim_nv"], st["k"]
+    dims = (sz * 6)(nm, no, k, nv * k, nv, 2 * nm + no)
+    hx = lambda rows: b"".join(bytes.fromhex(x) for row in rows for x in row)
+    part = {t: np.array(st["partition"][t], np.int32) for t in ("LO", "LL", "LR", "NO")}
+    gv_, hv_ = bytes.fromhex(cdoc["g_vec_"]), bytes.fromhex(cdoc["h_vec_"])
+    head = (bytes.fromhex(cdoc["g"]), bytes.fromhex(cdoc["g_vec"]), bytes.fromhex(cdoc["h_vec"]), gv_, sz(len(gv_) // 64), hv_, sz(len(hv_) // 64), dims,
+            int(st["f_l"]), int(st["f_m"]), hx(st["W_m"]), hx(st["W_l"]), b"".join(bytes.fromhex(x) for x in st["a_m"]),
+            b"".join(bytes.fromhex(x) for x in st["a_l"]), *(part[t].ctypes.data_as(C.c_void_p) for t in ("LO", "LL", "LR", "NO")))
+    return head, part          # (part is returned to keep the arrays alive)
+
+
+def check_generic_document(doc, oracle_c):
+    """Everything the CPU tier demands of a reference-made generic document: per circuit instance the oracle's prover, fed the recorded
+    generators, blindings and draws, must emit the recorded proof byte for byte, and the oracle's verifier must return the verdict the
+    REFERENCE's verifier returned (`accept`, true or false); the same for the WNLA instances.  Returns the number of instances checked."""
+    import ctypes as C
+    L, sz = oracle_c.lib(), C.c_size_t
+    circuits, wnlas = load_statements()
+    checked = 0
+    for cdoc in doc.get("circuits", []):
+        st = circuits[cdoc["name"]]
+        label = bytes.fromhex(cdoc["label"])
+        head, keep = _circuit_call_args(st, cdoc)
+        hs = lambda xs: b"".join(bytes.fromhex(x) for x in xs)
+        for inst in cdoc["instances"]:
+            rnd = bytes.fromhex(inst["rnd"])
+            assert inst["rng_calls"] == [64] * (len(rnd) // 32)
+            raw = bytes.fromhex(inst["rng_bytes"])
+            assert b"".join(O.sc_to_bytes(O.wide_reduce(raw[64 * i:64 * i + 64])) for i in range(len(rnd) // 32)) == rnd
+            com = C.create_string_buffer(64 * st["k"])
+            pbuf = C.create_string_buffer(64 * (4 + 2 * 16) + 32 * 16)
+            rounds, pl, pn = sz(0), sz(0), sz(0)
+            rc = L.bppp_oracle_circuit_prove(*head, label, sz(len(label)), b"".join(hs(row) for row in st["v"]), bytes.fromhex(inst["s_v"]), hs(st["w_l"]),
+                                             hs(st["w_r"]), hs(st["w_o"]), rnd, sz(len(rnd) // 32), com, pbuf, C.byref(rounds), C.byref(pl), C.byref(pn))
+            assert rc == 0, (cdoc["name"], rc)
+            assert (rounds.value, pl.value, pn.value) == (inst["rounds"], inst["nl"], inst["nn"]), cdoc["name"]
+            nbytes = 64 * (4 + 2 * rounds.value) + 32 * (pl.value + pn.value)
+            assert com.raw == bytes.fromhex(inst["commitments"]), cdoc["name"]
+            assert pbuf.raw[:nbytes] == bytes.fromhex(inst["proof"]), cdoc["name"]
+            v = L.bppp_oracle_circuit_verify(*head, label, sz(len(label)), bytes.fromhex(inst["commitments"]), bytes.fromhex(inst["proof"]),
+                                             sz(inst["rounds"]), sz(inst["nl"]), sz(inst["nn"]))
+            assert (v == 1) == bool(inst["accept"]), (cdoc["name"], v, inst["accept"])
+            checked += 1
+        del keep
+    for w in doc.get("wnla", []):
+        st = wnlas[w["name"]]
+        label = bytes.fromhex(w["label"])
+        ng, nh = w["ng"], w["nh"]
+        b = lambda k: bytes.fromhex(w[k])
+        assert b("l") == b"".join(bytes.fromhex(x) for x in st["l"]) and b("n") == b"".join(bytes.fromhex(x) for x in st["n"])
+        com = C.create_string_buffer(64)
+        assert L.bppp_oracle_wnla_commit(b("g"), b("g_vec"), sz(ng), b("h_vec"), sz(nh), b("c"), sz(nh), b("rho"), b("mu"), b("l"), sz(nh), b("n"), sz(ng), com) == 0
+        assert com.raw == b("commitment"), w["name"]
+        r_out, x_out = C.create_string_buffer(64 * 16), C.create_string_buffer(64 * 16)
+        l_out, n_out = C.create_string_buffer(32 * 8), C.create_string_buffer(32 * 8)
+        nr, nl, nn = sz(0), sz(0), sz(0)
+        assert L.bppp_oracle_wnla_prove(b("g"), b("g_vec"), sz(ng), b("h_vec"), sz(nh), b("c"), sz(nh), b("rho"), b("mu"), label, sz(len(label)), com.raw,
+                                        b("l"), sz(nh), b("n"), sz(ng), r_out, x_out, C.byref(nr), l_out, C.byref(nl), n_out, C.byref(nn)) == 0
+        assert r_out.raw[:64 * nr.value] == b("proof_r") and x_out.raw[:64 * nr.value] == b("proof_x"), w["name"]
+        assert l_out.raw[:32 * nl.value] == b("proof_l") and n_out.raw[:32 * nn.value] == b("proof_n"), w["name"]
+        v = L.bppp_oracle_wnla_verify(b("g"), b("g_vec"), sz(ng), b("h_vec"), sz(nh), b("c"), sz(nh), b("rho"), b("mu"), label, sz(len(label)), b("commitment"),
+                                      b("proof_r"), b("proof_x"), sz(len(b("proof_r")) // 64), b("proof_l"), sz(len(b("proof_l")) // 32), b("proof_n"),
+                                      sz(len(b("proof_n")) // 32))
+        assert (v == 1) == bool(w["accept"]), (w["name"], v)
+        checked += 1
+    return checked
+
+
+def oracle_made_generic_document(oracle_c):
+    """The generic document format written by THIS repository's oracle on the same statements (test of the consumer; pins nothing).
+    `accept` is the oracle's own verdict -- false for the f_l-and-f_m shape, which is exactly the claim a reference-made file settles."""
+    import ctypes as C
+    import hashlib
+    L, sz = oracle_c.lib(), C.c_size_t
+    circuits, wnlas = load_statements()
+    sc = lambda tag, *idx: O.wide_reduce(hashlib.shake_256(b"oracle-made-generic" + tag + b"".join(int(i).to_bytes(4, "little") for i in idx)).digest(64))
+    pt = lambda tag, i: oracle_c.point_mul(None, O.sc_to_bytes(sc(b"gen" + tag, i)))
+    p2 = lambda n: 1 << max(0, (n - 1).bit_length())
+    out_c, out_w = [], []
+    for name, st in circuits.items():
+        nm, nv, k = st["dim_nm"], st["dim_nv"], st["k"]
+        ng, nh = p2(nm), p2(nv + 9)
+        gall, hall = [pt(name.encode() + b"g", i) for i in range(ng)], [pt(name.encode() + b"h", i) for i in range(nh)]
+        cdoc = {"name": name, "label": st["label"], "g": pt(name.encode(), 0).hex(), "g_vec": b"".join(gall[:nm]).hex(), "h_vec": b"".join(hall[:nv + 9]).hex(),
+                "g_vec_": b"".join(gall[nm:]).hex(), "h_vec_": b"".join(hall[nv + 9:]).hex(), "instances": []}
+        head, keep = _circuit_call_args(st, cdoc)
+        label = bytes.fromhex(st["label"])
+        hs = lambda xs: b"".join(bytes.fromhex(x) for x in xs)
+        used = 18 + nv + nm
+        for j in range(st.get("instances", 1)):
+            s_v = b"".join(O.sc_to_bytes(sc(b"sv" + name.encode(), j, i)) for i in range(k))
+            raw = hashlib.shake_256(b"rng" + name.encode() + bytes([j])).digest(64 * used)
+            rnd = b"".join(O.sc_to_bytes(O.wide_reduce(raw[64 * i:64 * i + 64])) for i in range(used))
+            com = C.create_string_buffer(64 * k)
+            pbuf = C.create_string_buffer(64 * (4 + 2 * 16) + 32 * 16)
+            rounds, pl, pn = sz(0), sz(0), sz(0)
+            assert L.bppp_oracle_circuit_prove(*head, label, sz(len(label)), b"".join(hs(row) for row in st["v"]), s_v, hs(st["w_l"]), hs(st["w_r"]),
+                                               hs(st["w_o"]), rnd, sz(used), com, pbuf, C.byref(rounds), C.byref(pl), C.byref(pn)) == 0
+            nbytes = 64 * (4 + 2 * rounds.value) + 32 * (pl.value + pn.value)
+            v = L.bppp_oracle_circuit_verify(*head, label, sz(len(label)), com.raw, pbuf.raw[:nbytes], sz(rounds.value), sz(pl.value), sz(pn.value))
+            cdoc["instances"].append({"s_v": s_v.hex(), "rng_bytes": raw.hex(), "rng_calls": [64] * used, "rnd": rnd.hex(), "commitments": com.raw.hex(),
+                                      "proof": pbuf.raw[:nbytes].hex(), "rounds": rounds.value, "nl": pl.value, "nn": pn.value, "accept": v == 1})
+        out_c.append(cdoc)
+        del keep
+    for name, st in wnlas.items():
+        ng, nh = st["ng"], st["nh"]
+        label = bytes.fromhex(st["label"])
+        g = pt(name.encode(), 0)
+        gv, hv = b"".join(pt(name.encode() + b"g", i) for i in range(ng)), b"".join(pt(name.encode() + b"h", i) for i in range(nh))
+        c = b"".join(O.sc_to_bytes(sc(b"c" + name.encode(), i)) for i in range(nh))
+        rho = sc(b"rho" + name.encode(), 0)
+        rho_b, mu_b = O.sc_to_bytes(rho), O.sc_to_bytes(rho * rho % O.N)
+        lb, nb = b"".join(bytes.fromhex(x) for x in st["l"]), b"".join(bytes.fromhex(x) for x in st["n"])
+        com = C.create_string_buffer(64)
+        assert L.bppp_oracle_wnla_commit(g, gv, sz(ng), hv, sz(nh), c, sz(nh), rho_b, mu_b, lb, sz(nh), nb, sz(ng), com) == 0
+        r_out, x_out = C.create_string_buffer(64 * 16), C.create_string_buffer(64 * 16)
+        l_out, n_out = C.create_string_buffer(32 * 8), C.create_string_buffer(32 * 8)
+        nr, nl, nn = sz(0), sz(0), sz(0)
+        assert L.bppp_oracle_wnla_prove(g, gv, sz(ng), hv, sz(nh), c, sz(nh), rho_b, mu_b, label, sz(len(label)), com.raw, lb, sz(nh), nb, sz(ng), r_out, x_out,
+                                        C.byref(nr), l_out, C.byref(nl), n_out, C.byref(nn)) == 0
+        pr, px, pl_, pn_ = r_out.raw[:64 * nr.value], x_out.raw[:64 * nr.value], l_out.raw[:32 * nl.value], n_out.raw[:32 * nn.value]
+        v = L.bppp_oracle_wnla_verify(g, gv, sz(ng), hv, sz(nh), c, sz(nh), rho_b, mu_b, label, sz(len(label)), com.raw, pr, px, sz(nr.value), pl_, sz(nl.value),
+                                      pn_, sz(nn.value))
+        out_w.append({"name": name, "label": st["label"], "ng": ng, "nh": nh, "g": g.hex(), "g_vec": gv.hex(), "h_vec": hv.hex(), "c": c.hex(), "rho": rho_b.hex(),
+                      "mu": mu_b.hex(), "l": lb.hex(), "n": nb.hex(), "commitment": com.raw.hex(), "proof_r": pr.hex(), "proof_x": px.hex(), "proof_l": pl_.hex(),
+                      "proof_n": pn_.hex(), "accept": v == 1})
+    return {"source": "THIS repository's oracle (consumer self-test; pins nothing)", "circuits": out_c, "wnla": out_w}

@@ -151,9 +151,9 @@ def test_default_window_width_follows_free_memory(monkeypatch):
             if not ref:
                 ref["cv"] = cv
             assert (cv == ref["cv"]).all()
-            if want[0] == 523 or want[2]:
+            if want[2]:
                 with pytest.raises(Exception):
-                    p.save_tables("/tmp/never_written.bin")          # not a saveable layout (create with an explicit uniform width)
+                    p.save_tables("/tmp/never_written.bin")          # a table in two regions is not a saveable layout
         finally:
             p.close()
     monkeypatch.delenv("BPPP_ASSUME_FREE_GB")
@@ -167,6 +167,69 @@ def test_default_window_width_follows_free_memory(monkeypatch):
             p.get_option("no such option")
     finally:
         p.close()
+
+
+def test_table_budget_bounds_the_automatic_layout(monkeypatch, tmp_path):
+    """bppp_wnla_ctx_create_budget: fb_table_budget_bytes caps what the automatic choice may take, on top of the free-memory rule -- the
+    u64 shape on a free MI355X takes 210 GB without one; 120 GB gives the two regions (112 GB), 60 GB 12 windows (59 GB), 25 GB 13,
+    1 GB 18 windows; an explicit width beyond the budget is refused; the context reports what it took ("fb_table_bytes", "fb_windows",
+    "fb_window_bits_widest", "fb_table_budget_bytes"); children inherit budget and part size.  A two-width layout of ONE region saves and
+    loads as a table file (magic BPPPTAB4); verdicts are the same in every layout."""
+    import workload
+    from bp_pp_amd import U64RangeProofProtocol
+    from bp_pp_amd._capi import BpppError
+    g, gv, hv = workload.split_generators(workload.generators())
+    _, V, P, _ = workload.make_batch(20, first=10)
+    P, expect = workload.corrupt(P, V, every=5)
+    monkeypatch.setenv("BPPP_ASSUME_FREE_GB", "300")
+    GB = 10**9
+    for budget, want, windows in ((0, (523, 0, 0), 11), (120 * GB, (621, 523, 17), 12), (60 * GB, (621, 0, 0), 12), (25 * GB, (1119, 0, 0), 13),
+                                  (1 * GB, (614, 0, 0), 18)):
+        if budget == 0:
+            continue                                       # (the 210 GB default is exercised by test_default_window_width_follows_free_memory)
+        p = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=0, fb_table_budget_bytes=budget)
+        try:
+            got = (p.get_option("fb_window_bits"), p.get_option("fb_window_bits_hi"), p.get_option("fb_hi_bases"))
+            assert got == want, (budget, got)
+            assert 0 < p.get_option("fb_table_bytes") <= budget and p.get_option("fb_table_budget_bytes") == budget
+            assert p.get_option("fb_windows") == windows
+            acc, st = p.verify_batch(V, P, workload.LABEL)
+            assert (acc == expect).all() and not st.any()
+            c = p.clone_shared()
+            try:
+                assert c.get_option("fb_table_budget_bytes") == budget and c.get_option("fb_table_bytes") == 0
+                assert c.get_option("max_batch") == p.get_option("max_batch")
+            finally:
+                c.close()
+        finally:
+            p.close()
+    with pytest.raises(BpppError) as ei:                   # an explicit layout beyond the budget: refused, nothing built
+        U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=1119, fb_table_budget_bytes=1 * GB)
+    assert ei.value.code == -2
+    with pytest.raises(BpppError):                         # below the smallest table there is nothing to build
+        U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=0, fb_table_budget_bytes=1000)
+    monkeypatch.delenv("BPPP_ASSUME_FREE_GB")
+    # one region of two widths as an artefact: 24 windows (code 1810: 18 windows of 11 bits, 6 of 10: 67 MB for the 49 generators)
+    a = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=1810)
+    path = str(tmp_path / "two_width.bin")
+    try:
+        assert a.get_option("fb_windows") == 24 and a.get_option("fb_window_bits_widest") == 11
+        a.save_tables(path)
+        assert open(path, "rb").read(8) == b"BPPPTAB4"
+        b = U64RangeProofProtocol.from_tables(path, device=0)
+        try:
+            assert b.get_option("fb_window_bits") == 1810
+            acc, st = b.verify_batch(V, P, workload.LABEL)
+            assert (acc == expect).all() and not st.any()
+        finally:
+            b.close()
+        blob = bytearray(open(path, "rb").read())
+        blob[7] = ord("3")                                 # the same bytes under the uniform-width magic: refused
+        open(path, "wb").write(blob)
+        with pytest.raises(Exception):
+            U64RangeProofProtocol.from_tables(path, device=0)
+    finally:
+        a.close()
 
 
 @pytest.mark.parametrize("off", [1, 4, 8])

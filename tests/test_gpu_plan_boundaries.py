@@ -133,10 +133,11 @@ def test_tables_with_windows_of_two_widths(batch, oracle_c, code):
             U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=bad)
 
 
-def test_shared_inversions_at_their_own_size_equal_the_per_proof_form(batch, oracle_c, monkeypatch):
+def test_shared_inversions_and_the_twin_form_at_their_own_size_equal_the_per_proof_form(batch, oracle_c, monkeypatch):
     """2^18 + 1 proofs (the fixture's batch twice over: the plan's own G = 8, ragged) with tampered and malformed proofs: accept bits,
-    statuses, reject count and ALL 704-byte traces of the call with shared inversions equal those of a context that inverts per proof
-    (BPPP_SHARED_INV=0), byte for byte; a sample also goes to the oracle."""
+    statuses, reject count and ALL 704-byte traces of the call with shared inversions, and of the call as two half-batch chains (the
+    library's own choice at this size), equal those of ONE sequence that inverts per proof (BPPP_TWIN=0 BPPP_SHARED_INV=0), byte for
+    byte; a sample also goes to the oracle."""
     import torch
     import workload
     from bp_pp_amd import U64RangeProofProtocol
@@ -154,19 +155,25 @@ def test_shared_inversions_at_their_own_size_equal_the_per_proof_form(batch, ora
     P[n - 2, :832] = 0                                                                        # every proof point the identity
     g, gv, hv = workload.split_generators(batch["gens"])
     res = []
-    for env in (None, "0"):
-        if env is None:
-            monkeypatch.delenv("BPPP_SHARED_INV", raising=False)
-        else:
-            monkeypatch.setenv("BPPP_SHARED_INV", env)
+    # (1) one sequence, the plan's own shared inversions; (2) one sequence, every lane inverting for itself; (3) what the library does with
+    # this size by itself: two half-batch chains (plan_core.h: twin -- 2^18 + 1 proofs are two ragged halves, 131,104 + 131,041)
+    for twin, env in (("0", None), ("0", "0"), (None, None)):
+        for name, val in (("BPPP_TWIN", twin), ("BPPP_SHARED_INV", env)):
+            if val is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, val)
         p = U64RangeProofProtocol(g, gv, hv, device=0, fb_window_bits=16)
         try:
             res.append(_device_verify(torch, p, workload.LABEL, V, P) + (p.last_plan(),))
         finally:
             p.close()
-    (a1, s1, t1, r1, plan1), (a0, s0, t0, r0, plan0) = res
-    assert plan1.endswith("shared_inv=8") and plan0.endswith("shared_inv=0") and plan1[:-1] == plan0[:-1]
+    monkeypatch.delenv("BPPP_TWIN", raising=False)
+    (a1, s1, t1, r1, plan1), (a0, s0, t0, r0, plan0), (a2, s2, t2, r2, plan2) = res
+    assert plan1.endswith("twin=1 pace=0 shared_inv=8") and plan0.endswith("twin=1 pace=0 shared_inv=0") and plan1[:-1] == plan0[:-1]
+    assert plan2.endswith("twin=2 pace=0 shared_inv=0") and plan2[:plan2.index("twin=")] == plan0[:plan0.index("twin=")]
     assert (a1 == a0).all() and (s1 == s0).all() and r1 == r0 and (t1 == t0).all()
+    assert (a2 == a0).all() and (s2 == s0).all() and r2 == r0 and (t2 == t0).all()
     assert r1 == int((a1 == 0).sum()) and s1[0] != 0 and s1[n - 1] != 0 and s1[n - 2] == 0 and a1[n - 2] == 0
     clean = np.ones(n, bool)
     clean[bad] = False
@@ -198,5 +205,5 @@ def test_every_regime_was_entered():
     change of its plan within the sweep's range."""
     from bp_pp_amd.range_proof import plan_for
     sizes = [T + d for T in THRESHOLDS for d in (-1, 0, 1)]
-    assert len({plan_for(n) for n in sizes}) == 7
+    assert len({plan_for(n) for n in sizes}) == 8          # (the seven regimes; 131,072 and 131,073 differ by the pacing)
     assert len({plan_for(n, prove=True) for n in sizes}) >= 7

@@ -329,3 +329,32 @@ def test_scale_run_kit_dry_run(tmp_path):
     assert abs(b["ranks"]["max_ms"] - b["ms_per_step"]) < 0.5 * b["ms_per_step"] + 1.0
     g = [json.loads(l) for l in open(tmp_path / "group_gpus2.json") if '"value"' in l][0]
     assert g["accept_bits_ok"] and g["rccl_nranks"] == 1 and g["reject_count_on_every_device"] == [8] and g["dry_run_one_device"]
+
+
+@pytest.mark.parametrize("workload,total,rejects", [("verify", 131072, 128), ("recip256", 2048, 8)])
+def test_bench_starts_its_own_ranks(workload, total, rejects):
+    """`python3 bench.py --gpus 2` with NO launcher around it (how the N = 1 line is spelled, with another N): the parent -- which never
+    touches the GPU -- starts the two ranks as child processes under torch.distributed.run, relays rank 0's JSON line and the exit code.
+    On a one-GPU box: gloo ranks on device 0 (BENCH_ONE_DEVICE / BENCH_DIST_BACKEND), control flow only, never a measurement."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_ONE_DEVICE="1", BENCH_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BPPP_FORCE_RCCL"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--total-proofs", str(total), "--steps", "2", "--warmup", "1",
+           "--no-secondary", "--no-cpu-baseline", "--no-session-rates"]
+    if workload != "verify":
+        cmd += ["--workload", workload, "--fb-window-bits", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and '"value"' in l]
+    assert len(lines) == 1, r.stdout[-1500:]
+    b = lines[0]
+    assert b["n_gpus"] == 2 and b["accept_bits_ok"] and b["reject_count_all_reduced"] == rejects and b["config"]["proofs_per_gpu"] == total // 2
+    assert b["config"]["kernel_timing_during_value"] is False
+    if workload == "verify":
+        assert len(b["ranks"]["per_rank_ms"]) == 2 and b["ranks"]["backend"] == "gloo" and b["ranks"]["one_device_dry_run"]
+        assert b["timing_pass"]["ms_per_step"] > 0 and "plan" in b["config"]

@@ -329,23 +329,50 @@ def test_calls_from_several_threads_on_one_context(torch_mod, proto):
     assert not errors and all(results)
 
 
-def test_a_batch_that_cannot_fit_is_refused_cleanly(torch_mod, proto):
-    """BPPP_ERR_NOMEM (include/bppp.h): with the internal partitioning switched off, 2^27 proofs would need ~0.6 TB of workspace.
-    The call fails before anything is launched, names the error, and the context keeps working."""
+def test_a_part_that_cannot_be_allocated_is_halved_not_fatal(torch_mod, proto, oracle_c):
+    """max_batch is a guess from the memory that was free when the context was created.  When the workspace of a part cannot be allocated
+    after all (another context or process took the memory: here the 1st, 2nd, 3rd allocation of the call is made to fail), the call
+    releases what it holds, halves the part size -- which stays halved: "max_batch" -- and runs the part again; verdicts, statuses and the
+    reject count are those of an undisturbed call.  Only a part of at most 4,096 proofs that still cannot be allocated fails the call,
+    with BPPP_ERR_NOMEM and a context that keeps working (include/bppp.h)."""
     import workload
     from bp_pp_amd import _capi
     torch = torch_mod
-    small = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    n = 9000
+    gens, V, P, _ = workload.make_batch(n, first=77000)
+    P, expect = workload.corrupt(P, V, every=500)
+    dV, dP = torch.from_numpy(V).cuda(), torch.from_numpy(P).cuda()
+    dA = torch.zeros(n, dtype=torch.uint8, device="cuda"); dS = torch.zeros(n, dtype=torch.int32, device="cuda"); dR = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for k, want_parts in ((1, 4544), (2, 4544), (3, 4544)):
+        c = proto.clone_shared()                # fresh workspaces: every buffer of the call is still to be allocated
+        try:
+            assert c.get_option("max_batch") == proto.get_option("max_batch")          # children inherit the parent's part size
+            c.set_option("inject_alloc_fault", k)
+            dA.zero_()
+            c.verify_batch_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, dR.data_ptr())
+            c.synchronize()
+            assert (dA.cpu().numpy() == expect).all() and not dS.any().item() and int(dR.item()) == int((expect == 0).sum())
+            assert c.get_option("max_batch") == want_parts, (k, c.get_option("max_batch"))         # 9000 -> ceil(4500 / 64) * 64
+            c.set_option("inject_alloc_fault", 0)
+            dA.zero_()
+            c.verify_batch_device(workload.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, dR.data_ptr())
+            c.synchronize()
+            assert (dA.cpu().numpy() == expect).all() and int(dR.item()) == int((expect == 0).sum())
+        finally:
+            c.close()
+    # at or below the smallest part there is nothing left to halve: the failure is reported, and the context keeps working
+    c = proto.clone_shared()
     try:
-        proto.set_option("max_batch", 1 << 27)
+        c.set_option("inject_alloc_fault", 1)
         with pytest.raises(_capi.BpppError) as ei:
-            proto.verify_batch_device(workload.LABEL, 1 << 27, small.data_ptr(), small.data_ptr(), small.data_ptr(), 0, 0, 0)
+            c.verify_batch_device(workload.LABEL, 4096, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, 0)
         assert ei.value.code == -5 and "memory" in str(ei.value).lower()
+        dA.zero_()
+        c.verify_batch_device(workload.LABEL, 4096, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, 0)
+        c.synchronize()
+        assert (dA[:4096].cpu().numpy() == expect[:4096]).all()
     finally:
-        proto.set_option("max_batch", 1 << 21)
-    gens, V, P, _ = workload.make_batch(70, first=123)
-    acc, st = proto.verify_batch(V, P, workload.LABEL)
-    assert acc.all() and not st.any()
+        c.close()
 
 
 def test_identity_points_in_proofs_vs_oracle(torch_mod, proto, oracle_c):

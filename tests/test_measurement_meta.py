@@ -46,3 +46,41 @@ def test_hostinfo_reads_what_the_box_grants():
     assert q is None or q > 0
     t = hostinfo.throttle_stats()
     assert set(t) == {"nr_periods", "nr_throttled", "throttled_s"} and t["nr_throttled"] >= 0
+
+
+def test_predicted_scaling_is_total_over_the_share_time():
+    """bench.py: `predicted_scaling` = the fixed batch / the time ONE GPU takes for a 1/N share (shard_2pow19 / 18 / 17)."""
+    import bench
+    shares = {17: {"ms_per_step": 18.0}, 18: {"ms_per_step": 36.5}, 19: {"ms_per_step": 72.0}}
+    p = bench.predicted_scaling(1 << 20, 143.0, shares)
+    assert set(p) == {"1", "2", "4", "8", "note"}
+    assert p["1"]["share"] == 1 << 20 and p["8"]["share"] == 1 << 17 and p["2"]["share"] == 1 << 19
+    assert abs(p["8"]["value"] - (1 << 20) / 18.0e-3) < 1.0 and abs(p["8"]["efficiency"] - 143.0 / (8 * 18.0)) < 1e-9
+    assert abs(p["4"]["efficiency"] - 143.0 / (4 * 36.5)) < 1e-9
+    assert set(bench.predicted_scaling(1 << 20, 143.0, {})) == {"1", "note"}          # nothing measured, nothing predicted
+
+
+def test_gpus_n_without_a_launcher_starts_the_ranks_as_children(monkeypatch):
+    """bench.py --gpus N with no WORLD_SIZE around it: the ranks go out as a CHILD torch.distributed.run (127.0.0.1, a free port, the
+    same arguments), never by replacing this process; under rocprofv3 it refuses instead."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    for k in list(os.environ):
+        if k.startswith(("ROCPROF", "ROCP_")) or k == "LD_PRELOAD":
+            monkeypatch.delenv(k)
+    assert bench.launch_ranks(4) == 7                                  # the launcher's exit code is relayed
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("ROCPROFILER_REGISTER_FORCE_LOAD", "1")
+    assert bench.launch_ranks(4) == 2

@@ -13,10 +13,26 @@ def test_consumer_on_an_oracle_made_document(oracle_c):
     assert RC.check_document(RC.oracle_made_document(3), oracle_c) == 3
 
 
+def test_consumer_on_an_oracle_made_generic_document(oracle_c):
+    """The `generic` document (circuit.rs / wnla.rs on tests/golden/statements_generic.json: the reference's ac_works and wnla_works, k > 1,
+    f_m, f_l and f_m) in the oracle-made form: 2 instances of each of the 4 circuits, 3 WNLA shapes.  What the ORACLE says about its own
+    prover's output for the f_l-and-f_m shape is recorded here; a reference-made file is what can confirm it."""
+    doc = RC.oracle_made_generic_document(oracle_c)
+    assert RC.check_generic_document(doc, oracle_c) == 4 * 2 + 3
+    verdicts = {c["name"]: [i["accept"] for i in c["instances"]] for c in doc["circuits"]}
+    assert verdicts["ac_works"] == [True, True] and verdicts["mixed_k2"] == [True, True] and verdicts["fm_nv1"] == [True, True]
+    assert verdicts["fl_fm"] == [False, False]          # tests/circuit_cases.py: circuit.rs:559-582,601-614 -- UNCONFIRMED against the crate
+    assert all(w["accept"] for w in doc["wnla"])
+
+
 def test_oracle_reproduces_the_reference_made_fixtures(oracle_c):
     paths = RC.reference_fixture_paths()
     if not paths:
         pytest.skip("parity UNPINNED: no tests/golden/ref_*.json (run facade/src/bin/gen_fixtures.rs where a Rust toolchain exists)")
     for p in paths:
         with open(p) as f:
-            assert RC.check_document(json.load(f), oracle_c) > 0
+            doc = json.load(f)
+        if "cases" in doc:
+            assert RC.check_document(doc, oracle_c) > 0
+        if "circuits" in doc or "wnla" in doc:          # gen_fixtures.rs generic
+            assert RC.check_generic_document(doc, oracle_c) > 0
