@@ -20,6 +20,8 @@ Other workloads, each printing its own JSON line with `roofline` and `cpu_baseli
   --workload prove     BASELINE configs[3]: batch-prove 2^14 u64 values on one GPU (2262 algorithmic B/prove)
   --workload recip256  BASELINE configs[4]: ONE fixed batch of 2^18 ReciprocalRangeProofProtocol (dim_nd 256, dim_np 16) proofs
                        split over the N GPUs like the headline metric (823 algorithmic B/verify)
+  --workload wnla      the crate's generic `wnla::verify` (wnla.rs:75-121): 2^16 instances of N = 16 / 32, device-resident
+  --workload circuit   the crate's generic `circuit::verify` (circuit.rs:154-256): 2^16 instances of --statement mixed_k2 | ac_works
 The default line carries reduced-size runs of both as the secondary objects `prove_2pow14` and `recip256_2pow15`.
 """
 import argparse
@@ -698,10 +700,12 @@ def run_verify(args):
     ms_ship, ms_timed = elapsed / args.steps * 1e3, elapsed_timed / args.steps * 1e3
     same_plan = plan_shipping == plan_timed
     timing_pass = {"ms_per_step": ms_timed, "plan": plan_timed, "same_plan_as_value": same_plan, "ratio_to_value_pass": ms_timed / ms_ship,
-                   "agrees_within_2pct": (abs(ms_timed / ms_ship - 1.0) <= 0.02) if same_plan else None,
+                   # (checked where the ~25 event pairs of a timed step are noise: steps of 20 ms or more on the same plan)
+                   "agrees_within_2pct": (abs(ms_timed / ms_ship - 1.0) <= 0.02) if (same_plan and ms_ship >= 20.0) else None,
                    "note": "second pass of the same steps with per-kernel HIP events (C0's halves back to back): the source of kernels_ms_per_step, "
                            "roofline and roofline_valu, never of `value`; a plan that differs (below 2^17 proofs per GPU the timed pass has no "
-                           "side-by-side kernels) is not comparable and not checked"}
+                           "side-by-side kernels, at 2^17 .. 2^18 no twin chains) or a step under 20 ms (the events themselves show) is not "
+                           "comparable and not checked"}
     ok_timing = timing_pass["agrees_within_2pct"] is not False
     if rank == 0:
         value = total * args.steps / elapsed
@@ -800,6 +804,18 @@ def run_verify(args):
             r, okr = bench_other.measure_recip256(args, 1 << 15, 0, cpu_baseline=not args.no_cpu_baseline, rlc=True)
             result["recip256_2pow15"] = {k: r[k] for k in keep + ("rlc_mode", "accept_bits_ok", "device_bytes") if k in r}
             ok_extra = ok_extra and okr
+            # the crate's generic `wnla` and `circuit` API at 2^16 instances (their own lines: --workload wnla / circuit)
+            saved_w = args.fb_window_bits
+            args.fb_window_bits = args.fb_window_bits or 16
+            try:
+                rw, okw = bench_other.measure_wnla(args, 1 << 16, cpu_baseline=not args.no_cpu_baseline, cpu_sample=128)
+                rc_, okc = bench_other.measure_circuit(args, 1 << 16, name="mixed_k2", cpu_baseline=not args.no_cpu_baseline, cpu_sample=64)
+            finally:
+                args.fb_window_bits = saved_w
+            gkeep = keep + ("roofline_valu", "accept_bits_ok")
+            result["wnla_16_32_2pow16"] = {k: rw[k] for k in gkeep if k in rw}
+            result["circuit_mixed_k2_2pow16"] = {k: rc_[k] for k in gkeep if k in rc_}
+            ok_extra = ok_extra and okw and okc
         print(json.dumps(result), flush=True)
     if dist_on:
         dist.destroy_process_group()
@@ -814,8 +830,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["verify", "prove", "recip256"], default="verify")
-    ap.add_argument("--total-proofs", type=int, default=0, help="size of the fixed global batch (default: 2^20 verify, 2^14 prove, 2^18 recip256)")
+    ap.add_argument("--workload", choices=["verify", "prove", "recip256", "wnla", "circuit"], default="verify")
+    ap.add_argument("--statement", default="mixed_k2", help="--workload circuit: a statement of tests/golden/statements_generic.json (mixed_k2, ac_works, fm_nv1)")
+    ap.add_argument("--total-proofs", type=int, default=0, help="size of the fixed global batch (default: 2^20 verify, 2^14 prove, 2^18 recip256, 2^16 wnla / circuit)")
     ap.add_argument("--fb-window-bits", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=8192, help="proofs verified by the CPU baseline (rank 0, N=1): ~10-20 s of host work")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -831,6 +848,10 @@ def main():
     if args.workload == "verify":
         args.total_proofs = args.total_proofs or (1 << 20)
         run_verify(args)
+    elif args.workload in ("wnla", "circuit"):
+        import bench_other
+        args.total_proofs = args.total_proofs or (1 << 16)
+        bench_other.run_generic(args)
     else:
         import bench_other
         args.total_proofs = args.total_proofs or ((1 << 14) if args.workload == "prove" else (1 << 18))

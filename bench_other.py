@@ -364,3 +364,239 @@ def run_recip256(args):
         dist.destroy_process_group()
     if not ok:
         sys.exit(1)
+
+
+# ---------------------------------------------------------------- the crate's generic `wnla` and `circuit` API
+GENERIC_SLICE = 1 << 14
+
+
+def _generic_line(metric, unit, total, args, elapsed, elapsed_timed, kt, algo_bytes, workload_text, extra_cfg, fb_bits):
+    import bench
+    dom, dom_t, avg_ms = _dominant(kt)
+    achieved = algo_bytes * total / (avg_ms * 1e-3) / 1e9
+    return {
+        "metric": metric, "value": total * args.steps / elapsed, "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "timing_pass_ms_per_step": elapsed_timed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": dict({"workload": workload_text, "total_proofs_per_step": total, "proofs_per_gpu": total, "fb_window_bits": fb_bits, "parallelism": "single",
+                        "kernel_timing_during_value": False}, **extra_cfg),
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / bench.HBM_PEAK_GBS,
+                     "traffic": bench.pmc_traffic(dom, total), "avg_launch_ms": avg_ms, "launches_per_step": dom_t["launches"] / args.steps,
+                     "algorithmic_bytes_per_launch": algo_bytes * total, "algorithmic_bytes_per_unit": algo_bytes,
+                     "note": "VALU-issue bound like the u64 path (256-bit modular integer code); the HBM fraction is small by construction"},
+        "roofline_valu": bench.valu_roofline(dom, avg_ms, total, 8 if dom in bench.FB_KERNELS else 1),
+        "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in kt.items()},
+    }
+
+
+def measure_wnla(args, total, ng=16, nh=32, cpu_baseline=True, cpu_sample=256):
+    """`WeightNormLinearArgument::verify` (wnla.rs:75-121) for ONE fixed batch of `total` instances over one generator set -- N = 16 / 32 is
+    the u64 protocol's WNLA stage as a stand-alone argument (4 rounds, proof = 8 points + 3 scalars); the reference's own `wnla_works`
+    (tests.rs:139-171, N = 4) is the smoke size.  Instances (c, rho, mu = rho^2, l, n) are seeded draws; commitments and proofs come from
+    the product's own generic prover; everything resident in HBM when the timed region starts (bppp_wnla_verify_batch_device)."""
+    import numpy as np
+    import torch
+    import bench
+    from bp_pp_amd import derive_generators, synth
+    from bp_pp_amd.wnla import WeightNormLinearArgument
+    label = b"wnla test"
+    raw = derive_generators(b"bppp-bench-wnla", 1 + ng + nh)
+    pts = [raw[64 * i:64 * i + 64] for i in range(1 + ng + nh)]
+    t0 = time.time()
+    w = WeightNormLinearArgument(pts[0], pts[1:1 + ng], pts[1 + ng:], device=0, fb_window_bits=args.fb_window_bits)
+    w.synchronize()
+    t_ctx = time.time() - t0
+    bufs = {k: [] for k in ("com", "c", "rho", "mu", "pr", "px", "pl", "pn")}
+    t_prove = 0.0
+    head = None
+    for a in range(0, total, GENERIC_SLICE):
+        m = min(GENERIC_SLICE, total - a)
+        sc = synth._bulk_scalars(b"wnla", a, m, nh + 1 + nh + ng, b"bppp-bench-wnla")
+        sc = sc.reshape(m, -1, 32)
+        c, rho, l, n = sc[:, :nh], sc[:, nh], sc[:, nh + 1:2 * nh + 1], sc[:, 2 * nh + 1:]
+        rho_i = [int.from_bytes(bytes(r), "big") for r in rho]
+        mu = np.frombuffer(b"".join((r * r % synth.N_ORDER).to_bytes(32, "big") for r in rho_i), np.uint8).reshape(m, 32)
+        com, cst = w.commit_batch(c, mu, l, n)
+        t0 = time.perf_counter()
+        pr, px, pl, pn, pst = w.prove_batch(label, com, c, rho, mu, l, n)
+        t_prove += time.perf_counter() - t0
+        assert not cst.any() and not pst.any()
+        if head is None:
+            head = dict(c=c[:cpu_sample].copy(), rho=rho[:cpu_sample].copy(), mu=mu[:cpu_sample].copy())
+        for k, v in (("com", com), ("c", c), ("rho", rho), ("mu", mu), ("pr", pr), ("px", px), ("pl", pl), ("pn", pn)):
+            bufs[k].append(np.ascontiguousarray(v))
+    H = {k: np.concatenate(v) for k, v in bufs.items()}
+    rounds, nl, nn = H["pr"].shape[1], H["pl"].shape[1], H["pn"].shape[1]
+    expect = np.ones(total, np.uint8)
+    bad = np.arange(0, total, 256)
+    H["pn"][bad, 0, 31] ^= 1                      # one instance in 256: the last bit of n[0] flipped, must be rejected
+    expect[bad] = 0
+    D = {k: torch.from_numpy(v).cuda() for k, v in H.items()}
+    dA = torch.zeros(total, dtype=torch.uint8, device="cuda"); dS = torch.zeros(total, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.Stream()
+    _capi_set_stream(w, stream)
+    torch.cuda.synchronize()
+
+    def step():
+        w.verify_batch_device(label, total, D["com"].data_ptr(), D["c"].data_ptr(), D["rho"].data_ptr(), D["mu"].data_ptr(), rounds, D["pr"].data_ptr(),
+                              D["px"].data_ptr(), D["pl"].data_ptr(), nl, D["pn"].data_ptr(), nn, dA.data_ptr(), dS.data_ptr())
+
+    def fence():
+        w.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    elapsed, elapsed_timed, kt = two_passes(w, step, fence, args.steps)
+    acc, st = dA.cpu().numpy(), dS.cpu().numpy()
+    ok = bool((acc == expect).all()) and not st.any()
+    algo = 2 * rounds * 33 + 32 * (nl + nn) + 33 + 32 * nh + 64 + 1
+    r = _generic_line("wnla verifies/sec (batch)", "verifies/s", total, args, elapsed, elapsed_timed, kt, algo,
+                      f"batch verify ONE fixed batch of {total} WeightNormLinearArgument instances (wnla.rs:75-121) with |g_vec| = {ng}, |h_vec| = {nh} "
+                      f"({rounds} rounds; proof = {2 * rounds} points + {nl + nn} scalars) through the generic kernels, inputs resident in HBM, 1/256 corrupted; "
+                      "proofs made by the product prover",
+                      {"ng": ng, "nh": nh, "rounds": rounds, "label": label.decode(), "algorithmic_bytes": f"{algo} = proof in SEC1 form + commitment + c ({nh} scalars) + rho, mu + accept byte"},
+                      w.get_option("fb_window_bits") if hasattr(w, "get_option") else args.fb_window_bits)
+    r["accept_bits_ok"] = ok
+    r["setup_s"] = {"context_tables": t_ctx, "gpu_batch_prove_incl_pcie": t_prove}
+    if cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import ctypes as C
+        import bppp_oracle_c as OC                                   # the oracle, as the timed CPU baseline ONLY
+        L, sz = OC.lib(), C.c_size_t
+        gv, hv = b"".join(pts[1:1 + ng]), b"".join(pts[1 + ng:])
+        m = min(cpu_sample, total)
+        t0 = time.perf_counter()
+        agree = True
+        for i in range(m):
+            v = L.bppp_oracle_wnla_verify(pts[0], gv, sz(ng), hv, sz(nh), bytes(H["c"][i].reshape(-1)), sz(nh), bytes(H["rho"][i]), bytes(H["mu"][i]), label,
+                                          sz(len(label)), bytes(H["com"][i]), bytes(H["pr"][i].reshape(-1)), bytes(H["px"][i].reshape(-1)), sz(rounds),
+                                          bytes(H["pl"][i].reshape(-1)), sz(nl), bytes(H["pn"][i].reshape(-1)), sz(nn))
+            agree &= (v == 1) == bool(acc[i])
+        dt = time.perf_counter() - t0
+        r["cpu_baseline"] = {"value": m / dt, "unit": "verifies/s", "cores": 1, "kind": "port",
+                             "sample": f"first {m} instances of the same batch, reference-shaped C verifier (oracle/bppp_ref.c: wnla.rs:75-121 as written), one thread, {dt:.2f} s",
+                             "agrees_with_gpu": bool(agree)}
+    w.close()
+    return r, ok
+
+
+def _capi_set_stream(w, stream):
+    from bp_pp_amd import _capi
+    _capi.check(_capi.lib().bppp_ctx_set_stream(w._ctx, stream.cuda_stream))
+
+
+def measure_circuit(args, total, name="mixed_k2", cpu_baseline=True, cpu_sample=128):
+    """`ArithmeticCircuit::verify` (circuit.rs:154-256) for ONE fixed batch of `total` instances of ONE circuit: `mixed_k2` (k = 2 committed
+    vectors, w_o spread over all four partition types, dense W_m / W_l: the general path) or the reference's own `ac_works` statement
+    (tests.rs:45-136).  The statement is data (tests/golden/statements_generic.json); generators are derived, blindings and prover draws
+    seeded; commitments and proofs come from the product's own generic prover; everything resident in HBM when the timed region starts
+    (bppp_circuit_verify_batch_device)."""
+    import numpy as np
+    import torch
+    import bench
+    from bp_pp_amd import derive_generators, synth
+    from bp_pp_amd.wnla import ArithmeticCircuit
+    with open(os.path.join(ROOT, "tests", "golden", "statements_generic.json")) as f:
+        st = {c["name"]: c for c in json.load(f)["circuits"]}[name]
+    nm, no, nv, k = st["dim_nm"], st["dim_no"], st["dim_nv"], st["k"]
+    p2 = lambda x: 1 << max(0, (x - 1).bit_length())
+    NG, NH = p2(nm), p2(nv + 9)
+    raw = derive_generators(b"bppp-bench-circuit-" + name.encode(), 1 + NG + NH)
+    pts = [raw[64 * i:64 * i + 64] for i in range(1 + NG + NH)]
+    flat = lambda rows: np.frombuffer(b"".join(bytes.fromhex(x) for row in rows for x in row), np.uint8).reshape(-1, 32)
+    vec = lambda xs: np.frombuffer(b"".join(bytes.fromhex(x) for x in xs), np.uint8).reshape(-1, 32)
+    part = st["partition"]
+    label = bytes.fromhex(st["label"])
+    t0 = time.time()
+    ac = ArithmeticCircuit(nm, no, k, nv, pts[0], pts[1:1 + nm], pts[1 + NG:1 + NG + nv + 9], flat(st["W_m"]), flat(st["W_l"]), vec(st["a_m"]), vec(st["a_l"]),
+                           st["f_l"], st["f_m"], pts[1 + nm:1 + NG], pts[1 + NG + nv + 9:], lambda typ, j: (None if part[typ][j] < 0 else part[typ][j]),
+                           device=0, fb_window_bits=args.fb_window_bits)
+    ac.synchronize()
+    t_ctx = time.time() - t0
+    v_one = np.stack([vec(row) for row in st["v"]])                      # [k, nv, 32]: one witness, fresh blindings and draws per instance
+    used = 18 + nv + nm
+    coms, proofs = [], []
+    t_prove = 0.0
+    shape = None
+    for a in range(0, total, GENERIC_SLICE):
+        m = min(GENERIC_SLICE, total - a)
+        sc = synth._bulk_scalars(b"circ", a, m, k + used, b"bppp-bench-circuit").reshape(m, -1, 32)
+        s_v, rnd = sc[:, :k], sc[:, k:]
+        v = np.broadcast_to(v_one, (m, k, nv, 32)).copy()
+        com = np.stack([ac.commit_batch(v[:, j], s_v[:, j])[0] for j in range(k)], axis=1)      # [m, k, 64]
+        rep = lambda xs: np.broadcast_to(vec(xs), (m,) + vec(xs).shape).copy()
+        t0 = time.perf_counter()
+        pr, pst, shape = ac.prove_batch(label, com, v, s_v, rep(st["w_l"]), rep(st["w_r"]), rep(st["w_o"]), rnd)
+        t_prove += time.perf_counter() - t0
+        assert not pst.any()
+        coms.append(com); proofs.append(pr)
+    Hc, Hp = np.concatenate(coms), np.concatenate(proofs)
+    rounds, nl, nn = shape
+    expect = np.ones(total, np.uint8)
+    bad = np.arange(0, total, 256)
+    Hp[bad, -1] ^= 1                               # one instance in 256: the last bit of the final scalar flipped, must be rejected
+    expect[bad] = 0
+    dC, dP = torch.from_numpy(Hc).cuda(), torch.from_numpy(Hp).cuda()
+    dA = torch.zeros(total, dtype=torch.uint8, device="cuda"); dS = torch.zeros(total, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.Stream()
+    _capi_set_stream(ac._w, stream)
+    torch.cuda.synchronize()
+
+    def step():
+        ac.verify_batch_device(label, total, dC.data_ptr(), dP.data_ptr(), rounds, nl, nn, dA.data_ptr(), dS.data_ptr())
+
+    def fence():
+        ac.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    elapsed, elapsed_timed, kt = two_passes(ac, step, fence, args.steps)
+    acc, stt = dA.cpu().numpy(), dS.cpu().numpy()
+    ok = bool((acc == expect).all()) and not stt.any()
+    algo = (4 + 2 * rounds) * 33 + 32 * (nl + nn) + 33 * k + 1
+    r = _generic_line("arithmetic-circuit verifies/sec (batch)", "verifies/s", total, args, elapsed, elapsed_timed, kt, algo,
+                      f"batch verify ONE fixed batch of {total} ArithmeticCircuit instances (circuit.rs:154-256) of the statement `{name}` (dim_nm {nm}, dim_no {no}, "
+                      f"dim_nv {nv}, k {k}, f_l {st['f_l']}, f_m {st['f_m']}; {1 + NG + NH} generators, {rounds} WNLA rounds) through the generic kernels, inputs "
+                      "resident in HBM, 1/256 corrupted; proofs made by the product prover",
+                      {"statement": name, "rounds": rounds, "label": label.decode(), "algorithmic_bytes": f"{algo} = proof in SEC1 form + {k} commitments + accept byte"},
+                      ac._w.get_option("fb_window_bits") if hasattr(ac._w, "get_option") else args.fb_window_bits)
+    r["accept_bits_ok"] = ok
+    r["setup_s"] = {"context_tables": t_ctx, "gpu_batch_prove_incl_pcie": t_prove}
+    if cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import ctypes as C
+        import bppp_oracle_c as OC                                   # the oracle, as the timed CPU baseline ONLY
+        import ref_fixture_check as RC
+        L, sz = OC.lib(), C.c_size_t
+        cdoc = {"g": pts[0].hex(), "g_vec": b"".join(pts[1:1 + nm]).hex(), "h_vec": b"".join(pts[1 + NG:1 + NG + nv + 9]).hex(),
+                "g_vec_": b"".join(pts[1 + nm:1 + NG]).hex(), "h_vec_": b"".join(pts[1 + NG + nv + 9:]).hex()}
+        head, keep = RC._circuit_call_args(st, cdoc)
+        m = min(cpu_sample, total)
+        t0 = time.perf_counter()
+        agree = True
+        for i in range(m):
+            v = L.bppp_oracle_circuit_verify(*head, label, sz(len(label)), bytes(Hc[i].reshape(-1)), bytes(Hp[i]), sz(rounds), sz(nl), sz(nn))
+            agree &= (v == 1) == bool(acc[i])
+        dt = time.perf_counter() - t0
+        r["cpu_baseline"] = {"value": m / dt, "unit": "verifies/s", "cores": 1, "kind": "port",
+                             "sample": f"first {m} instances of the same batch, reference-shaped C verifier (oracle/bppp_ref.c: circuit.rs:154-256 with dense matrices), one thread, {dt:.2f} s",
+                             "agrees_with_gpu": bool(agree)}
+    ac.close()
+    return r, ok
+
+
+def run_generic(args):
+    """bench.py --workload wnla | circuit: their own JSON lines (one GPU; these paths have no sharded form of their own)."""
+    import torch
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the bp_pp_amd product path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    if args.workload == "wnla":
+        r, ok = measure_wnla(args, args.total_proofs, cpu_baseline=not args.no_cpu_baseline)
+    else:
+        r, ok = measure_circuit(args, args.total_proofs, name=args.statement, cpu_baseline=not args.no_cpu_baseline)
+    print(json.dumps(r), flush=True)
+    if not ok:
+        sys.exit(1)

@@ -14,7 +14,7 @@ POINT_BYTES, SCALAR_BYTES, U64_PROOF_BYTES, U64_TRACE_BYTES = 64, 32, 928, 704
 
 # every symbol include/bppp.h declares (tests/test_capi_symbols.py checks the header against this list and the .so)
 EXPORTS = [
-    "bppp_ctx_create", "bppp_wnla_ctx_create", "bppp_wnla_ctx_create_budget", "bppp_wnla_commit_batch", "bppp_wnla_verify_batch", "bppp_reciprocal_verify_batch", "bppp_reciprocal_verify_batch_device", "bppp_reciprocal_verify_batch_rlc",
+    "bppp_ctx_create", "bppp_wnla_ctx_create", "bppp_wnla_ctx_create_budget", "bppp_wnla_commit_batch", "bppp_wnla_verify_batch", "bppp_wnla_verify_batch_device", "bppp_circuit_verify_batch_device", "bppp_reciprocal_verify_batch", "bppp_reciprocal_verify_batch_device", "bppp_reciprocal_verify_batch_rlc",
     "bppp_reciprocal_verify_batch_rlc_device", "bppp_reciprocal_prove_batch", "bppp_msm_batch", "bppp_wnla_proof_shape", "bppp_wnla_prove_batch", "bppp_circuit_create", "bppp_circuit_destroy", "bppp_circuit_verify_batch", "bppp_circuit_prove_batch", "bppp_ctx_destroy", "bppp_ctx_set_stream", "bppp_ctx_synchronize", "bppp_ctx_set_option", "bppp_u64_verify_batch", "bppp_u64_verify_batch_device", "bppp_u64_verify_batch_rlc_device", "bppp_u64_verify_batch_rlc", "bppp_u64_verify_batch_sec1", "bppp_u64_verify_batch_sec1_device",
     "bppp_u64_commit_value_batch", "bppp_u64_prove_batch", "bppp_u64_prove_batch_device", "bppp_ctx_enable_timing", "bppp_ctx_get_timings", "bppp_ctx_device_bytes",
     "bppp_strerror", "bppp_last_error",
@@ -90,6 +90,9 @@ def lib():
     L.bppp_wnla_commit_batch.argtypes = [vp, sz, vp, vp, vp, sz, vp, sz, vp, vp]
     L.bppp_wnla_verify_batch.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, vp]
     L.bppp_reciprocal_verify_batch.argtypes = [vp, u8p, sz, sz, sz, sz, vp, vp, sz, sz, sz, vp, vp]
+    if "BPPP_LIB" not in os.environ or hasattr(L, "bppp_wnla_verify_batch_device"):
+        L.bppp_wnla_verify_batch_device.argtypes = [vp, u8p, sz, sz, vp, vp, vp, vp, sz, vp, vp, vp, sz, vp, sz, vp, vp]
+        L.bppp_circuit_verify_batch_device.argtypes = [vp, vp, u8p, sz, sz, vp, vp, sz, sz, sz, vp, vp]
     L.bppp_reciprocal_verify_batch_device.argtypes = [vp, u8p, sz, sz, sz, sz, vp, vp, sz, sz, sz, vp, vp]
     L.bppp_reciprocal_verify_batch_rlc_device.argtypes = [vp, u8p, sz, sz, sz, sz, vp, vp, sz, sz, sz, vp, vp, u8p]
     L.bppp_reciprocal_verify_batch_rlc.argtypes = [vp, u8p, sz, sz, sz, sz, vp, vp, sz, sz, sz, vp, vp, u8p]

@@ -107,7 +107,9 @@ struct WnlaBlob {
 static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
                     const uint8_t* cvec, const uint8_t* rho, const uint8_t* mu, size_t rounds, const uint8_t* proof_r,
                     const uint8_t* proof_x, const uint8_t* proof_l, size_t nl, const uint8_t* proof_n, size_t nn, uint8_t* out_points,
-                    uint8_t* accept, int32_t* status, const HostTranscripts* tx = nullptr) {
+                    uint8_t* accept, int32_t* status, const HostTranscripts* tx = nullptr, bool device_io = false) {
+    // device_io (bppp_wnla_verify_batch_device): every pointer above is DEVICE memory, read and written in place; the call is asynchronous
+    // on the context's stream and only the workspace comes out of the context's buffer
     HIP_TRY(hipSetDevice(c->device));
     if (rounds > 12 || nl > 4096 || nn > 4096) return BPPP_ERR_INVALID_ARG;
     int rc = check_host_transcripts(tx, n);
@@ -124,11 +126,12 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
                  o_pf = take(30 * n * 4), o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4),
                  o_msc = take(NB * 8 * n * 4), o_ti = take(tx ? tx->n_states * 203 : 0), o_to = take(tx && tx->states_out ? n * 203 : 0);
     WnlaBlob blob;
-    { const int rc_b = blob.take(c, off + 16); if (rc_b != BPPP_OK) return rc_b; }
-    uint8_t* d = blob.d;
+    if (device_io) { const int rc_b = ensure_blob(c, off + 16); if (rc_b != BPPP_OK) return rc_b; }       // (no sync when the call returns)
+    else { const int rc_b = blob.take(c, off + 16); if (rc_b != BPPP_OK) return rc_b; }
+    uint8_t* d = c->d_blob;
     hipStream_t s = c->stream;
     auto up = [&](size_t o, const uint8_t* src, size_t bytes) -> hipError_t {
-        return (src && bytes) ? hipMemcpyAsync(d + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
+        return (src && bytes && !device_io) ? hipMemcpyAsync(d + o, src, bytes, hipMemcpyHostToDevice, s) : hipSuccess;
     };
     if (tx) HIP_TRY(up(o_ti, tx->states, tx->n_states * 203));
     HIP_TRY(up(o_com, commitments, n * 64));
@@ -139,11 +142,13 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
     HIP_TRY(up(o_x, proof_x, n * rounds * 64));
     HIP_TRY(up(o_l, proof_l, n * nl * 32));
     HIP_TRY(up(o_n, proof_n, n * nn * 32));
+    auto in = [&](size_t o, const uint8_t* p) -> const uint8_t* { return device_io ? p : d + o; };
     WnlaWs w;
     std::memset(&w, 0, sizeof w);
     w.N = n; w.ng = c->ng; w.nh = c->nh; w.rounds = (int)rounds; w.nl = (int)nl; w.nn = (int)nn;
-    w.commitments = d + o_com; w.c = d + o_c; w.rho = d + o_rho; w.mu = d + o_mu; w.proof_r = d + o_r; w.proof_x = d + o_x;
-    w.proof_l = d + o_l; w.proof_n = d + o_n; w.out_points = d + o_out; w.accept = d + o_acc; w.status = (int32_t*)(d + o_st);
+    w.commitments = in(o_com, commitments); w.c = in(o_c, cvec); w.rho = in(o_rho, rho); w.mu = in(o_mu, mu); w.proof_r = in(o_r, proof_r); w.proof_x = in(o_x, proof_x);
+    w.proof_l = in(o_l, proof_l); w.proof_n = in(o_n, proof_n); w.out_points = d + o_out;
+    w.accept = device_io ? accept : d + o_acc; w.status = (device_io && status) ? status : (int32_t*)(d + o_st);
     w.tstate = (u32*)(d + o_ts); w.acc = (u32*)(d + o_a); w.pfix = (u32*)(d + o_pf); w.ys = (u32*)(d + o_ys);
     w.tab = (u32*)(d + o_tab); w.msc = (u32*)(d + o_msc);
     w.stride_r = rounds * 64; w.stride_x = rounds * 64; w.stride_l = nl * 32; w.stride_n = nn * 32;
@@ -166,20 +171,27 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
     } else {
         rc = wnla_fast_setup(c, w, n, rounds);
         if (rc != BPPP_OK) return rc;
-        k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
-        if (w.atab) k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+#define WLAUNCH(id, ...)                                       \
+    do {                                                       \
+        rc = timed(c, id, s, [&]() { __VA_ARGS__; });          \
+        if (rc != BPPP_OK) return rc;                          \
+    } while (0)
+        WLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+        if (w.atab) WLAUNCH(K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w));
         {
             const int grp = wnla_round_group(c, w, blocks);
             for (int k = 1; k <= (int)rounds; k++) {
-                if (grp > 1) k_wnla_round_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k, grp);
-                else k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k);
+                if (grp > 1) WLAUNCH(K_WNLA_ROUND, k_wnla_round_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, k, grp));
+                else WLAUNCH(K_WNLA_ROUND, k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
             }
         }
-        launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s);
-        k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
-        k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+        WLAUNCH(K_WNLA_FINAL_SCALARS, launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s));
+        WLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
+        WLAUNCH(K_WNLA_ACCEPT, k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+#undef WLAUNCH
         if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
         HIP_TRY(hipGetLastError());
+        if (device_io) return BPPP_OK;
         HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
         if (w.tio.states_out) HIP_TRY(hipMemcpyAsync(tx->states_out, d + o_to, n * 203, hipMemcpyDeviceToHost, s));
     }
@@ -207,6 +219,19 @@ int bppp_wnla_verify_batch(bppp_ctx* c, const uint8_t* label, size_t label_len, 
     if (n == 0) return BPPP_OK;
     return wnla_run(c, false, label, label_len, n, commitments, cvec, rho, mu, rounds, proof_r, proof_x, proof_l, nl, proof_n, nn, nullptr,
                     accept, status);
+}
+
+int bppp_wnla_verify_batch_device(bppp_ctx* c, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments, const void* d_c,
+                                  const void* d_rho, const void* d_mu, size_t rounds, const void* d_proof_r, const void* d_proof_x,
+                                  const void* d_proof_l, size_t nl, const void* d_proof_n, size_t nn, void* d_accept, void* d_status) {
+    CtxLock lock_(c);
+    if (!c || !label_ok(label, label_len) || !d_commitments || !d_c || !d_rho || !d_mu || (rounds && (!d_proof_r || !d_proof_x)) || (!d_proof_l && nl) ||
+        (!d_proof_n && nn) || !d_accept)
+        return BPPP_ERR_INVALID_ARG;
+    if (n == 0) return BPPP_OK;
+    return wnla_run(c, false, label, label_len, n, (const uint8_t*)d_commitments, (const uint8_t*)d_c, (const uint8_t*)d_rho, (const uint8_t*)d_mu, rounds,
+                    (const uint8_t*)d_proof_r, (const uint8_t*)d_proof_x, (const uint8_t*)d_proof_l, nl, (const uint8_t*)d_proof_n, nn, nullptr,
+                    (uint8_t*)d_accept, (int32_t*)d_status, nullptr, true);
 }
 
 int bppp_wnla_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* states, size_t n_states, const uint8_t* commitments,
@@ -291,29 +316,54 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
         rc = timed(c, id, s, [&]() { __VA_ARGS__; });          \
         if (rc != BPPP_OK) return rc;                          \
     } while (0)
+    // the WNLA stage's table buffer with room for the five C0 points' tables behind the round points': the variable-base part of C0 on
+    // affine window tables too (and on lane groups while one lane per instance leaves wavefront slots free)
+    rc = wnla_fast_setup(c, w, n, rounds, 5, part ? part->gtab : nullptr);
+    if (rc != BPPP_OK) return rc;
+    r.atab = w.atab; r.tscr = w.tscr; r.atab_first = (int)(2 * rounds * 16);
+    // What needs nothing but the proof bytes -- the round points' window tables -- and what needs only phase 1 -- the C0 points' tables
+    // and C0's variable-base sum, one lane (or a lane group) per instance -- runs on the HELPER stream beside phase 1 and the fixed-base
+    // half of C0 (8 lanes per instance: the kernel that fills the chip); round 6: 2^15 instances of configs[4]'s shape, where the
+    // one-lane kernels are half a wavefront per SIMD, 46.6 -> ms per batch.  With kernel timing on everything stays on one stream so
+    // that the per-kernel times add up; the parts of a multi-part call are chains of their own.
+    const bool beside = w.atab && !c->timing && !part;
+    hipStream_t a = beside ? c->aux_stream : s;
+#define GLAUNCH_ON(st, id, ...)                                 \
+    do {                                                        \
+        rc = timed(c, id, st, [&]() { __VA_ARGS__; });          \
+        if (rc != BPPP_OK) return rc;                           \
+    } while (0)
+    if (beside) {
+        HIP_TRY(hipEventRecord(c->ev_tab, s));               // (the call's inputs are ready on s)
+        HIP_TRY(hipStreamWaitEvent(a, c->ev_tab, 0));
+        GLAUNCH_ON(a, K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, a>>>(w));
+    }
     GLAUNCH(K_RECIP_PHASE1, k_recip_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    if (beside) {
+        HIP_TRY(hipEventRecord(c->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
+    }
     // the two fixed-base sums: 8 lanes per instance, or one from the size at which one lane per instance fills the SIMDs twice over
     const bool fb_one_lane = c->fb_one_lane_mode >= 0 ? c->fb_one_lane_mode == 1 : n >= (size_t)128 * (size_t)c->n_simds;
     const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     if (fb_one_lane) GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
     else GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
-    // the WNLA stage's table buffer with room for the five C0 points' tables behind the round points': the variable-base part of C0 on
-    // affine window tables too (and on lane groups while one lane per instance leaves wavefront slots free)
-    rc = wnla_fast_setup(c, w, n, rounds, 5, part ? part->gtab : nullptr);
-    if (rc != BPPP_OK) return rc;
-    static_assert(BPPP_ATAB_SOA, "the C0 tables are addressed entry-major behind the round points' tables");
-    r.atab = w.atab; r.tscr = w.tscr; r.atab_first = (int)(2 * rounds * 16);
     if (r.atab) {
         const int grp = wnla_round_group(c, w, call_blocks);
-        GLAUNCH(K_RECIP_C0_VAR, {
-            k_recip_c0_tables<<<blocks, BPPP_BLOCK, 0, s>>>(r);
-            if (grp > 1) k_recip_c0_var_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(r, grp);
-            else k_recip_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+        GLAUNCH_ON(a, K_RECIP_C0_VAR, {
+            k_recip_c0_tables<<<blocks, BPPP_BLOCK, 0, a>>>(r);
+            if (grp > 1) k_recip_c0_var_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, a>>>(r, grp);
+            else k_recip_c0_var<<<blocks, BPPP_BLOCK, 0, a>>>(r);
         });
     } else GLAUNCH(K_RECIP_C0_VAR, k_recip_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    if (beside) {
+        HIP_TRY(hipEventRecord(c->ev_join, a));
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+    }
+#undef GLAUNCH_ON
     GLAUNCH(K_RECIP_C0_FINISH, k_recip_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r));
     GLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-    if (w.atab) GLAUNCH(K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (w.atab && !beside) GLAUNCH(K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     {
         const int grp = wnla_round_group(c, w, call_blocks);
         for (int k = 1; k <= (int)rounds; k++) {
@@ -600,7 +650,15 @@ void bppp_circuit_destroy(bppp_circuit* q) {
 }
 static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n,
                                     const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
-                                    int32_t* status, const HostTranscripts* tx);
+                                    int32_t* status, const HostTranscripts* tx, bool device_io = false);
+// ArithmeticCircuit::verify over DEVICE buffers (commitments n x k x 64, proofs, accept n, status n or null), asynchronous on the
+// context's stream: the resident form of bppp_circuit_verify_batch
+int bppp_circuit_verify_batch_device(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
+                                     const void* d_proofs, size_t rounds, size_t nl, size_t nn, void* d_accept, void* d_status) {
+    CtxLock lock_(c);
+    return circuit_verify_host_impl(c, q, label, label_len, n, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, rounds, nl, nn,
+                                    (uint8_t*)d_accept, (int32_t*)d_status, nullptr, true);
+}
 int bppp_circuit_verify_batch(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n, const uint8_t* commitments,
                               const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept, int32_t* status) {
     CtxLock lock_(c);
@@ -616,7 +674,7 @@ int bppp_circuit_verify_batch_transcript(bppp_ctx* c, const bppp_circuit* q, siz
 }
 static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const uint8_t* label, size_t label_len, size_t n,
                                     const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn, uint8_t* accept,
-                                    int32_t* status, const HostTranscripts* tx) {
+                                    int32_t* status, const HostTranscripts* tx, bool device_io) {
     if (!c || !q || !label_ok(label, label_len) || !commitments || !proofs || !accept) return BPPP_ERR_INVALID_ARG;
     const CircuitDev& cd = q->cd;
     if (cd.nm > c->ng || cd.nv + 9 > c->nh || rounds > 12 || nl > 4096 || nn > 4096) return BPPP_ERR_INVALID_ARG;
@@ -637,16 +695,20 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
                  o_ys = take((rounds ? rounds : 1) * 8 * n * 4), o_tab = take(2 * T * 8 * n * 4), o_msc = take(NB * 8 * n * 4),
                  o_ti = take(tx ? tx->n_states * 203 : 0), o_to = take(tx && tx->states_out ? n * 203 : 0);
     WnlaBlob blob;
-    { const int rc_b = blob.take(c, off + 16); if (rc_b != BPPP_OK) return rc_b; }
-    uint8_t* d = blob.d;
+    if (device_io) { const int rc_b = ensure_blob(c, off + 16); if (rc_b != BPPP_OK) return rc_b; }       // (no sync when the call returns)
+    else { const int rc_b = blob.take(c, off + 16); if (rc_b != BPPP_OK) return rc_b; }
+    uint8_t* d = c->d_blob;
     hipStream_t s = c->stream;
     if (tx) HIP_TRY(hipMemcpyAsync(d + o_ti, tx->states, tx->n_states * 203, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * k * 64, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d + o_pr, proofs, n * proof_bytes, hipMemcpyHostToDevice, s));
+    if (!device_io) {
+        HIP_TRY(hipMemcpyAsync(d + o_com, commitments, n * k * 64, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d + o_pr, proofs, n * proof_bytes, hipMemcpyHostToDevice, s));
+    }
     CircuitWs r;
     std::memset(&r, 0, sizeof r);
     r.N = n; r.cd = cd; r.rounds = (int)rounds; r.NG = c->ng; r.NH = c->nh; r.proof_bytes = proof_bytes;
-    r.commitments = d + o_com; r.proofs = d + o_pr; r.status = (int32_t*)(d + o_st); r.tstate = (u32*)(d + o_ts);
+    r.commitments = device_io ? commitments : d + o_com; r.proofs = device_io ? proofs : d + o_pr;
+    r.status = (device_io && status) ? status : (int32_t*)(d + o_st); r.tstate = (u32*)(d + o_ts);
     r.lamv = (u32*)(d + o_lam); r.muv = (u32*)(d + o_muv); r.coef = (u32*)(d + o_coef); r.sc0 = (u32*)(d + o_sc0); r.pts = (u32*)(d + o_pts);
     r.acc = (u32*)(d + o_a); r.pfix = (u32*)(d + o_pf);
     r.straus = c->d_straus;
@@ -663,34 +725,45 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
     w.proof_n = w.proof_l + 32 * nl;
     w.stride_r = w.stride_x = w.stride_l = w.stride_n = proof_bytes;
     w.transcript_preloaded = 1;
-    w.accept = d + o_acc; w.status = r.status; w.tstate = r.tstate; w.acc = r.acc; w.pfix = r.pfix;
+    w.accept = device_io ? accept : d + o_acc; w.status = r.status; w.tstate = r.tstate; w.acc = r.acc; w.pfix = r.pfix;
     w.ys = (u32*)(d + o_ys); w.tab = (u32*)(d + o_tab); w.msc = (u32*)(d + o_msc);
     w.straus = c->d_straus;
     w.fb = r.fb;
     const unsigned blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
     const unsigned fb_blocks = (unsigned)((n * BPPP_FB_LANES + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
-    k_circuit_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r);
-    k_circuit_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r);
-    k_circuit_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r);
-    k_circuit_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r);
-    {
-        int rcf = wnla_fast_setup(c, w, n, rounds);
+#define CLAUNCH(id, ...)                                       \
+    do {                                                       \
+        rc = timed(c, id, s, [&]() { __VA_ARGS__; });          \
+        if (rc != BPPP_OK) return rc;                          \
+    } while (0)
+    {   // the WNLA stage's table buffer with room for the 4 + k points of C0's variable-base part behind the round points' tables
+        int rcf = wnla_fast_setup(c, w, n, rounds, 4 + k);
         if (rcf != BPPP_OK) return rcf;
+        r.atab = w.atab; r.tscr = w.tscr; r.atab_first = (int)(2 * rounds * 16);
     }
-    k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w);
-    if (w.atab) k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    CLAUNCH(K_CIRCUIT_PHASE1, k_circuit_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    CLAUNCH(K_CIRCUIT_C0_FIXED, k_circuit_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
+    CLAUNCH(K_CIRCUIT_C0_VAR, {
+        if (r.atab) k_circuit_c0_tables<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+        k_circuit_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+    });
+    CLAUNCH(K_CIRCUIT_C0_FINISH, k_circuit_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    CLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (w.atab) CLAUNCH(K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     {
         const int grp = wnla_round_group(c, w, blocks);
         for (int kk = 1; kk <= (int)rounds; kk++) {
-            if (grp > 1) k_wnla_round_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, kk, grp);
-            else k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk);
+            if (grp > 1) CLAUNCH(K_WNLA_ROUND, k_wnla_round_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, kk, grp));
+            else CLAUNCH(K_WNLA_ROUND, k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, kk));
         }
     }
-    launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s);
-    k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0);
-    k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w);
+    CLAUNCH(K_WNLA_FINAL_SCALARS, launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s));
+    CLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
+    CLAUNCH(K_WNLA_ACCEPT, k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+#undef CLAUNCH
     if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
     HIP_TRY(hipGetLastError());
+    if (device_io) return BPPP_OK;
     HIP_TRY(hipMemcpyAsync(accept, d + o_acc, n, hipMemcpyDeviceToHost, s));
     if (w.tio.states_out) HIP_TRY(hipMemcpyAsync(tx->states_out, d + o_to, n * 203, hipMemcpyDeviceToHost, s));
     if (status) HIP_TRY(hipMemcpyAsync(status, d + o_st, n * 4, hipMemcpyDeviceToHost, s));

@@ -358,7 +358,7 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         u32* z1 = carve_from(c, w1, n1, c->d_ws + WS_WORDS_PER_PROOF * n0);
         w0.zinv = ph0.shared_inv ? z0 : nullptr;
         w1.zinv = ph1.shared_inv ? z1 : nullptr;
-        w0.pace = ph0.pace ? 1 : 0; w1.pace = ph1.pace ? 1 : 0;
+        w0.pace = ph0.pace; w1.pace = ph1.pace;
         w1.atab = ws.atab + (size_t)BPPP_ATAB_PER_PROOF * n0;
         w1.tscr = ws.tscr + (size_t)(BPPP_TSCR_FE * 10) * n0;
         w1.commitments = ws.commitments + 64 * n0;
@@ -394,7 +394,7 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
     }
     {
         const VerifyLanes L0 = {c->stream, c->aux_stream, c->ev_fork, c->ev_join, c->ev_tab, nullptr};
-        ws.pace = plan.pace ? 1 : 0;
+        ws.pace = plan.pace;
         rc = sequence(ws, n, plan, L0);
         if (rc != BPPP_OK) return rc;
     }

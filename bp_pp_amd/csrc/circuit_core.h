@@ -53,6 +53,11 @@ struct CircuitWs {
     u32* acc;                        // [30][N]
     u32* pfix;                       // [30][N]
     pt_slot* straus;                 // [N][5][9]
+    // fast path of C0's variable-base part (round 6): affine window tables of the 4 + k points behind the WNLA stage's round-point tables
+    // (bppp_generic.hip: wnla_fast_setup with extra_points = 4 + k), built by circuit_c0_tables; null = the projective tables above
+    apt_packed* atab;
+    u32* tscr;
+    int atab_first;
     uint8_t* wn_commit;              // N x 64
     uint8_t* wn_c;                   // N x NH x 32
     uint8_t* wn_rho;                 // N x 32
@@ -367,12 +372,52 @@ HD void circuit_phase1(const CircuitWs& w, size_t t) {
 HD void circuit_c0_fixed_ranges(FbRanges& rg, const CircuitWs& w) { fb_ranges_one(rg, 0, 0, 1 + w.cd.nm); }
 HD void circuit_c0_fixed_store(const CircuitWs& w, size_t t, const pt& total) { ws_st_pt(w.pfix, w.N, t, total); }
 // C0 variable-base half: the 4 + k points in groups of at most 5 per shared-doubling pass
+// the 4 + k points of C0's variable-base part (c_s, c_o, c_l, c_r, v_0 .. v_{k-1}: w.pts) as affine window tables 1P .. 16P, four batched inversions
+HD void circuit_c0_tables(const CircuitWs& w, size_t t) {
+    affine_tables_build(atab_of(w.atab, w.N, t) + w.atab_first, w.tscr, w.pts, w.N, t, 4 + w.cd.k);
+}
+// one chunk of at most five points of the sum on the fast path: signed 5-bit windows over the GLV halves, Jacobian accumulator, mixed additions
+template <int M>
+HD void circuit_c0_chunk(pt& acc, const CircuitWs& w, size_t t, int first) {
+    const size_t N = w.N;
+    int pslot[M];
+    glv_words<M> g;
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        pslot[j] = first + j;
+        sc kk;
+        ws_ld8(kk.v, w.sc0, N, t, 1 + w.cd.nm + first + j);
+        glv_split sp;
+        glv_decompose(sp, kk);
+        glv_words_set<M>(g, j, sp);
+    }
+    straus_affine<M>(acc, atab_of(w.atab, N, t) + w.atab_first, pslot, g);
+}
 HD void circuit_c0_var(const CircuitWs& w, size_t t) {
     const size_t N = w.N;
     const int npts = 4 + w.cd.k;
-    pt_slot* tbl = w.straus + t * (5 * BPPP_STRAUS_ENTRIES);
     pt total;
     pt_set_identity(total);
+    if (w.atab) {
+        // (circuit.rs:230-235: tau^-1 c_s - delta c_o + tau c_l - tau^2 c_r + sum_i 2 tau^3 coef_i v_i, five points at a time)
+#pragma nounroll
+        for (int first = 0; first < npts; first += 5) {
+            const int m = npts - first < 5 ? npts - first : 5;
+            pt acc;
+            switch (m) {
+            case 5: circuit_c0_chunk<5>(acc, w, t, first); break;
+            case 4: circuit_c0_chunk<4>(acc, w, t, first); break;
+            case 3: circuit_c0_chunk<3>(acc, w, t, first); break;
+            case 2: circuit_c0_chunk<2>(acc, w, t, first); break;
+            default: circuit_c0_chunk<1>(acc, w, t, first); break;
+            }
+            if (first == 0) total = acc;
+            else pt_add(total, total, acc);
+        }
+        ws_st_pt(w.acc, N, t, total);
+        return;
+    }
+    pt_slot* tbl = w.straus + t * (5 * BPPP_STRAUS_ENTRIES);
 #pragma nounroll
     for (int first = 0; first < npts; first += 5) {
         const int m = npts - first < 5 ? npts - first : 5;

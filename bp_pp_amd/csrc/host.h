@@ -38,6 +38,7 @@ enum KernelId {
     // generic reciprocal / WNLA verifier
     K_RECIP_PHASE1, K_RECIP_C0_FIXED, K_RECIP_C0_VAR, K_RECIP_C0_FINISH, K_WNLA_BEGIN, K_WNLA_ROUND, K_WNLA_FINAL_SCALARS, K_WNLA_MSM, K_WNLA_ACCEPT,
     K_WNLA_RLC_LHS, K_WNLA_RLC_CHUNK, K_WNLA_RLC_CHECK, K_WNLA_TABLES,
+    K_CIRCUIT_PHASE1, K_CIRCUIT_C0_FIXED, K_CIRCUIT_C0_VAR, K_CIRCUIT_C0_FINISH,      // generic ArithmeticCircuit verifier (then the K_WNLA_* stage)
     K_SHARED_INV,      // u64 verifier from 2^18 proofs: the launches that invert once for 8 / 16 proofs (and the join of C0's halves ahead of round 1)
     K_COUNT
 };
@@ -46,7 +47,8 @@ static const char* const kKernelNames[K_COUNT] = {
     "k_verify_accept", "k_verify_tables", "k_rlc_lhs", "k_rlc_chunk", "k_bkt_prepare", "k_bkt_accumulate", "k_bkt_scalars", "k_bkt_check",
     "k_prove_stage_*", "k_prove_msm", "k_prove_round_scalars", "k_prove_round_fold", "k_prove_round_next",
     "k_recip_phase1", "k_recip_c0_fixed", "k_recip_c0_var", "k_recip_c0_finish", "k_wnla_begin", "k_wnla_round", "k_wnla_final_scalars",
-    "k_wnla_msm", "k_wnla_accept", "k_wnla_rlc_lhs", "k_wnla_rlc_chunk", "k_wnla_rlc_check", "k_wnla_tables", "k_verify_shared_inv"};
+    "k_wnla_msm", "k_wnla_accept", "k_wnla_rlc_lhs", "k_wnla_rlc_chunk", "k_wnla_rlc_check", "k_wnla_tables",
+    "k_circuit_phase1", "k_circuit_c0_fixed", "k_circuit_c0_var", "k_circuit_c0_finish", "k_verify_shared_inv"};
 
 static inline size_t align16(size_t x) { return (x + 15) / 16 * 16; }
 // a transcript label as the ABI takes it: a null pointer only with length 0, and no longer than merlin can frame (its length prefix is a

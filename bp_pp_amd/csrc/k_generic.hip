@@ -262,6 +262,10 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_circuit_c0
     fb_group_sum(part, w.fb, t, lane, w.sc0, rg);
     if (lane == 0) circuit_c0_fixed_store(w, t, part);
 }
+__global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_tables(CircuitWs w) {
+    size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    if (t < w.N) circuit_c0_tables(w, t);
+}
 __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_var(CircuitWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) circuit_c0_var(w, t);

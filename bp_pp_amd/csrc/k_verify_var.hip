@@ -109,7 +109,6 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g2(VerifyWs ws, int
 // proof, so the chains are cut further.  Window tables: a lane per table (13 points x PARTS tables: P and 2^65 P, or P, 2^35 P, 2^70 P,
 // 2^100 P -- 16 PARTS lanes per proof, 13 PARTS active); sums: a lane per part of a GLV stream (verify_core.h: straus_affine_split) --
 // 4 PARTS lanes per proof in a round, 16 PARTS (10 PARTS active) for C0.  Four parts up to one proof per SIMD, two up to four per SIMD.
-#if BPPP_VWIN == 5
 template <int PARTS>
 __device__ __forceinline__ void verify_tables_split(const VerifyWs& ws) {
     const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
@@ -140,4 +139,3 @@ __device__ __forceinline__ void verify_c0_var_group(const VerifyWs& ws) {
 }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g32(VerifyWs ws) { verify_c0_var_group<32>(ws); }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_c0_var_g64(VerifyWs ws) { verify_c0_var_group<64>(ws); }
-#endif

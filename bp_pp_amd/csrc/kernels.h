@@ -212,6 +212,7 @@ __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_msm(bppp::
 __global__ __launch_bounds__(BPPP_BLOCK) void k_msm_store(bppp::MsmWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_phase1(bppp::CircuitWs w);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_circuit_c0_fixed(bppp::CircuitWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_tables(bppp::CircuitWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_var(bppp::CircuitWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_finish(bppp::CircuitWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1(bppp::RecipWs w);

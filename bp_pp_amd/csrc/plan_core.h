@@ -57,12 +57,12 @@ struct VerifyPlan {
                                  // kernels of their own between the passes (verify_core.h: fe_batch_inv_lane); 0: every lane inverts for itself
     int twin = 1;                // 2: the batch runs as TWO half-batch launch sequences on two stream pairs (each half on the plan plan_verify_half
                                  // gives it); the other fields then describe a half.  1: one sequence
-    bool pace = false;           // the one-lane sums lower their wave priority as they advance (verify_core.h: straus_pace)
+    int pace = 0;                // 1: the one-lane variable-base sums lower their wave priority as they advance (straus_core.h: straus_pace); 2: the one-lane fixed-base sums too (fb_core.h: fb_pace)
     uint32_t code() const {
         const uint32_t lg = shared_inv >= 16 ? 4 : shared_inv >= 8 ? 3 : shared_inv >= 4 ? 2 : shared_inv >= 2 ? 1 : 0;
         return (uint32_t)phase1 | (uint32_t)tables << 4 | (uint32_t)tparts << 8 | (uint32_t)fb << 12 | (uint32_t)c0var << 16 | (uint32_t)round << 20 |
                (uint32_t)(tail_beside ? 1 : 0) << 24 | (uint32_t)(small ? 1 : 0) << 25 | (uint32_t)(split ? 1 : 0) << 26 | lg << 27 |
-               (uint32_t)(twin == 2 ? 1 : 0) << 30 | (uint32_t)(pace ? 1 : 0) << 31;
+               (uint32_t)(twin == 2 ? 1 : 0) << 30 | (uint32_t)(pace ? 1 : 0) << 31;        // (pace 2 is a diagnostic: described as pace=1)
     }
 };
 
@@ -118,14 +118,14 @@ inline VerifyPlan plan_verify(size_t n, const PlanKnobs& k, bool rlc) {
     const bool twin_by_size = blocks >= G && 4 * blocks <= 9 * G && !(10 * rem > 3 * G && 10 * rem < 7 * G);
     const bool twin_ok = !rlc && !k.timing && one_lane_all && fb_one_lane && n >= 2 * PLAN_BLOCK;
     p.twin = twin_ok && (k.twin >= 0 ? k.twin == 1 : twin_by_size) ? 2 : 1;
-    p.pace = one_lane_all && (k.pace >= 0 ? k.pace == 1 : fills_once);
+    p.pace = !one_lane_all ? 0 : k.pace >= 0 ? k.pace : fills_once ? 1 : 0;
     return p;
 }
 // the plan of ONE half of a twin call (n_half proofs): the 256-register one-lane kernels and one lane per fixed-base sum whatever the
 // half's size -- a half shares every SIMD with a wavefront of the other half
-inline VerifyPlan plan_verify_half(size_t n_half, const PlanKnobs& k, bool pace) {
+inline VerifyPlan plan_verify_half(size_t n_half, const PlanKnobs& k, int pace) {
     PlanKnobs h = k;
-    h.no_small = true; h.fb_one_lane_mode = 1; h.tables_beside = 0; h.tail_beside = 0; h.twin = 0; h.pace = pace ? 1 : 0;
+    h.no_small = true; h.fb_one_lane_mode = 1; h.tables_beside = 0; h.tail_beside = 0; h.twin = 0; h.pace = pace;
     VerifyPlan p = plan_verify(n_half, h, false);
     p.twin = 2;
     return p;

@@ -804,7 +804,7 @@ HD void prove_round_next(const ProveWs& w, size_t t, int k, int group_lane) {
     glv_decompose(sp, y2m1);
     glv_words_set<2>(g, 1, sp);
     pt acc;
-#if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
+#if defined(__HIP_DEVICE_COMPILE__)
     if (group_lane >= 0) straus_affine_g4<2>(acc, tab, pslot, g, group_lane);
     else
 #endif

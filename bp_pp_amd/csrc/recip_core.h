@@ -213,7 +213,7 @@ HD void recip_c0_var(const RecipWs& w, size_t t, int group_lane = -1, int group_
             glv_words_set<5>(g, j, sp);
         }
         const atab_ref tab = atab_of(w.atab, N, t) + w.atab_first;
-#if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
+#if defined(__HIP_DEVICE_COMPILE__)
         if (group_lane >= 0 && group_size == 4) straus_affine_g4<5, 4>(acc, tab, pslot, g, group_lane);
         else if (group_lane >= 0) straus_affine_g4<5, 2>(acc, tab, pslot, g, group_lane);
         else

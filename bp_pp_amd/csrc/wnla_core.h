@@ -159,7 +159,7 @@ HD void wnla_verify_round(const WnlaWs& w, size_t t, int k, int group_lane = -1,
         glv_words_set<2>(g, 0, sp);
         glv_decompose(sp, y2m1);
         glv_words_set<2>(g, 1, sp);
-#if defined(__HIP_DEVICE_COMPILE__) && BPPP_VWIN == 5
+#if defined(__HIP_DEVICE_COMPILE__)
         if (group_lane >= 0 && group_size == 4) straus_affine_g4<2, 4>(acc, atab_of(w.atab, N, t, 2 * w.rounds * 16), pslot, g, group_lane);
         else if (group_lane >= 0) straus_affine_g4<2, 2>(acc, atab_of(w.atab, N, t, 2 * w.rounds * 16), pslot, g, group_lane);
         else

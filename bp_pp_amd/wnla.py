@@ -105,6 +105,25 @@ class WeightNormLinearArgument:
                                                st.ctypes.data))
         return out, st
 
+    def verify_batch_device(self, label: bytes, n: int, d_commitments: int, d_c: int, d_rho: int, d_mu: int, rounds: int, d_proof_r: int,
+                            d_proof_x: int, d_proof_l: int, nl: int, d_proof_n: int, nn: int, d_accept: int, d_status: int = 0) -> None:
+        """wnla.rs:75-121 over device buffers (raw device pointers, layouts of verify_batch), asynchronous on the context's stream."""
+        _capi.check(_capi.lib().bppp_wnla_verify_batch_device(self._ctx, label, len(label), n, d_commitments, d_c, d_rho, d_mu, rounds, d_proof_r,
+                                                              d_proof_x, d_proof_l, nl, d_proof_n, nn, d_accept, d_status))
+
+    def synchronize(self) -> None:
+        _capi.check(_capi.lib().bppp_ctx_synchronize(self._ctx))
+
+    def get_option(self, name: str) -> int:
+        return int(_capi.check(_capi.lib().bppp_ctx_get_option(self._ctx, name.encode())))
+
+    def enable_timing(self, on: bool = True) -> None:
+        _capi.check(_capi.lib().bppp_ctx_enable_timing(self._ctx, 1 if on else 0))
+
+    def timings(self, reset: bool = True) -> dict:
+        from .range_proof import ctx_timings
+        return ctx_timings(self._ctx, reset)
+
     def verify_batch(self, label: bytes, commitments, c, rho, mu, proof_r, proof_x, proof_l, proof_n, transcripts=None):
         """wnla.rs:75-121 for a batch; proof_r / proof_x: [B, rounds, 64] in the reference's vector order.  -> (accept, status), or
         with `transcripts` (one serialized state or B; `label` ignored) -> (accept, status, advanced states [B, 203])."""
@@ -354,6 +373,21 @@ class ArithmeticCircuit:
         ng = self._w.ng
         idx = [0, 1 + ng] + [1 + ng + 9 + i for i in range(self.dim_nv - 1)]
         return self._w.msm_batch(idx, np.concatenate([v[:, :1, :], s[:, None, :], v[:, 1:, :]], axis=1))
+
+    def verify_batch_device(self, label: bytes, n: int, d_commitments: int, d_proofs: int, rounds: int, nl: int, nn: int, d_accept: int,
+                            d_status: int = 0) -> None:
+        """circuit.rs:154-256 over device buffers (raw device pointers), asynchronous on the context's stream."""
+        _capi.check(_capi.lib().bppp_circuit_verify_batch_device(self._w._ctx, self._circuit, label, len(label), n, d_commitments, d_proofs, rounds,
+                                                                 nl, nn, d_accept, d_status))
+
+    def synchronize(self) -> None:
+        self._w.synchronize()
+
+    def enable_timing(self, on: bool = True) -> None:
+        self._w.enable_timing(on)
+
+    def timings(self, reset: bool = True) -> dict:
+        return self._w.timings(reset)
 
     def verify_batch(self, label: bytes, commitments, proofs, rounds: int, nl: int, nn: int, transcripts=None):
         """circuit.rs:154-256 for a batch: commitments [B, k, 64], proofs [B, 64 (4 + 2 rounds) + 32 (nl + nn)] -> (accept, status),

@@ -54,11 +54,13 @@ extern "C" {
     pub fn bppp_wnla_ctx_create_budget(out: *mut *mut BpppCtx, g: *const u8, g_vec: *const u8, ng: usize, h_vec: *const u8, nh: usize, device: c_int, fb_window_bits: c_int, fb_table_budget_bytes: u64) -> c_int;
     pub fn bppp_wnla_commit_batch(ctx: *mut BpppCtx, n: usize, c: *const u8, mu: *const u8, l: *const u8, nl: usize, nvec: *const u8, nn: usize, out: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_wnla_verify_batch(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, commitments: *const u8, c: *const u8, rho: *const u8, mu: *const u8, rounds: usize, proof_r: *const u8, proof_x: *const u8, proof_l: *const u8, nl: usize, proof_n: *const u8, nn: usize, accept: *mut u8, status: *mut i32) -> c_int;
+    pub fn bppp_wnla_verify_batch_device(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, d_commitments: *const c_void, d_c: *const c_void, d_rho: *const c_void, d_mu: *const c_void, rounds: usize, d_proof_r: *const c_void, d_proof_x: *const c_void, d_proof_l: *const c_void, nl: usize, d_proof_n: *const c_void, nn: usize, d_accept: *mut c_void, d_status: *mut c_void) -> c_int;
     pub fn bppp_msm_batch(ctx: *mut BpppCtx, n: usize, nterms: usize, base_index: *const i32, scalars: *const u8, out: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_reciprocal_prove_batch(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, dim_nd: usize, dim_np: usize, commitments: *const u8, x: *const u8, s: *const u8, digits: *const u8, m: *const u8, rnd: *const u8, proofs: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_circuit_create(ctx: *mut BpppCtx, out: *mut *mut BpppCircuit, dims: *const usize, f_l: c_int, f_m: c_int, W_m: *const u8, W_l: *const u8, a_m: *const u8, a_l: *const u8, part_lo: *const i32, part_ll: *const i32, part_lr: *const i32, part_no: *const i32) -> c_int;
     pub fn bppp_circuit_destroy(circuit: *mut BpppCircuit);
     pub fn bppp_circuit_verify_batch(ctx: *mut BpppCtx, circuit: *const BpppCircuit, label: *const u8, label_len: usize, n: usize, commitments: *const u8, proofs: *const u8, rounds: usize, nl: usize, nn: usize, accept: *mut u8, status: *mut i32) -> c_int;
+    pub fn bppp_circuit_verify_batch_device(ctx: *mut BpppCtx, circuit: *const BpppCircuit, label: *const u8, label_len: usize, n: usize, d_commitments: *const c_void, d_proofs: *const c_void, rounds: usize, nl: usize, nn: usize, d_accept: *mut c_void, d_status: *mut c_void) -> c_int;
     pub fn bppp_circuit_prove_batch(ctx: *mut BpppCtx, circuit: *const BpppCircuit, label: *const u8, label_len: usize, n: usize, v_commitments: *const u8, v: *const u8, s_v: *const u8, w_l: *const u8, w_r: *const u8, w_o: *const u8, rnd: *const u8, proofs: *mut u8, status: *mut i32) -> c_int;
     pub fn bppp_wnla_proof_shape(nl: usize, nn: usize, rounds: *mut usize, nl_out: *mut usize, nn_out: *mut usize);
     pub fn bppp_wnla_prove_batch(ctx: *mut BpppCtx, label: *const u8, label_len: usize, n: usize, commitments: *const u8, c: *const u8, rho: *const u8, mu: *const u8, l: *const u8, nl: usize, n_vec: *const u8, nn: usize, proof_r: *mut u8, proof_x: *mut u8, proof_l: *mut u8, proof_n: *mut u8, status: *mut i32) -> c_int;

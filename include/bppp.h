@@ -295,6 +295,12 @@ BPPP_API int bppp_wnla_verify_batch(bppp_ctx* ctx, const uint8_t* label, size_t 
                                     const uint8_t* proof_r /* n x rounds x 64 */, const uint8_t* proof_x /* n x rounds x 64 */,
                                     const uint8_t* proof_l /* n x nl x 32 */, size_t nl, const uint8_t* proof_n /* n x nn x 32 */,
                                     size_t nn, uint8_t* accept /* n */, int32_t* status /* n or NULL */);
+/* The same over DEVICE buffers (every pointer is device memory of the context's GPU, layouts as above; d_status may be NULL), asynchronous
+ * on the context's stream -- the resident form the throughput of `wnla::verify` is measured on (bench.py --workload wnla). */
+BPPP_API int bppp_wnla_verify_batch_device(bppp_ctx* ctx, const uint8_t* label, size_t label_len, size_t n, const void* d_commitments,
+                                          const void* d_c, const void* d_rho, const void* d_mu, size_t rounds, const void* d_proof_r,
+                                          const void* d_proof_x, const void* d_proof_l, size_t nl, const void* d_proof_n, size_t nn,
+                                          void* d_accept, void* d_status);
 
 /* out[i] = sum_j scalars[i][j] * B[base_index[j]] for n independent rows, B = the context's generators in table order
  * (0 = g, 1 .. NG = g_vec || g_vec_, NG + 1 .. NG + NH = h_vec || h_vec_), base_index strictly increasing.  The crate's commit
@@ -331,6 +337,11 @@ BPPP_API void bppp_circuit_destroy(bppp_circuit* circuit);
 BPPP_API int bppp_circuit_verify_batch(bppp_ctx* ctx, const bppp_circuit* circuit, const uint8_t* label, size_t label_len, size_t n,
                                        const uint8_t* commitments, const uint8_t* proofs, size_t rounds, size_t nl, size_t nn,
                                        uint8_t* accept /* n */, int32_t* status /* n or NULL */);
+/* ... over DEVICE buffers (commitments n x k x 64, proofs, accept n, status n or NULL), asynchronous on the context's stream
+ * (bench.py --workload circuit). */
+BPPP_API int bppp_circuit_verify_batch_device(bppp_ctx* ctx, const bppp_circuit* circuit, const uint8_t* label, size_t label_len, size_t n,
+                                             const void* d_commitments, const void* d_proofs, size_t rounds, size_t nl, size_t nn,
+                                             void* d_accept, void* d_status);
 
 /* ArithmeticCircuit::prove(v, witness, t, rng) (circuit.rs:260-556) for n instances of a shared circuit (bppp_circuit_create).
  * Per instance: v_commitments k x 64 (the reference's `v` argument: circuit.commit of each witness.v[i], e.g. from

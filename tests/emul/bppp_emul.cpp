@@ -981,12 +981,14 @@ int emul_circuit_verify(const uint8_t* table, int W, int NG, int NH, const size_
         fb_sum_serial(a, r.fb, t, r.sc0, rg);
         circuit_c0_fixed_store(r, t, a);
     }
+    FastRounds fastr;
+    fastr.attach(w, n, rounds, 4 + k);                // as circuit_verify_host_impl: the 4 + k C0 points' tables behind the round points'
+    r.atab = w.atab; r.tscr = w.tscr; r.atab_first = 2 * rounds * 16;
+    if (r.atab) for (size_t t = 0; t < n; t++) circuit_c0_tables(r, t);
     for (size_t t = 0; t < n; t++) circuit_c0_var(r, t);
     for (size_t t = 0; t < n; t++) circuit_c0_finish(r, t);
     if (c0_out) memcpy(c0_out, wc.data(), wc.size());
     if (c_out) memcpy(c_out, wcv.data(), wcv.size());
-    FastRounds fastr;
-    fastr.attach(w, n, rounds);
     for (size_t t = 0; t < n; t++) wnla_verify_begin(w, t);
     if (w.atab) for (size_t t = 0; t < n; t++) wnla_verify_tables(w, t);
     for (int kk = 1; kk <= rounds; kk++)

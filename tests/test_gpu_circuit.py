@@ -36,6 +36,16 @@ def test_circuit_verify_vs_oracle(name, B):
         exp2 = [circuit_cases.oracle_verify(case, com[b].tobytes(), P[b].tobytes()) for b in range(B)]
         assert acc.tolist() == exp2 and not st.any()
         assert acc[0] == 0 and acc[1] == 0 and acc[B - 1] == 0
+        # the resident form (bppp_circuit_verify_batch_device): the tampered batch from device buffers, same verdicts; kernel timing on
+        dC, dP = torch.from_numpy(com).cuda(), torch.from_numpy(P).cuda()
+        dA = torch.zeros(B, dtype=torch.uint8, device="cuda"); dS = torch.full((B,), 7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        circ.verify_batch_device(case["label"], B, dC.data_ptr(), dP.data_ptr(), *shape, dA.data_ptr(), dS.data_ptr()); circ.synchronize()
+        assert dA.cpu().numpy().tolist() == exp2 and not dS.any().item()
+        circ.enable_timing(True); dA.zero_()
+        circ.verify_batch_device(case["label"], B, dC.data_ptr(), dP.data_ptr(), *shape, dA.data_ptr(), 0); circ.synchronize()
+        kt = circ.timings(); circ.enable_timing(False)
+        assert dA.cpu().numpy().tolist() == exp2 and kt["k_circuit_phase1"]["launches"] == 1 and kt["k_wnla_msm"]["launches"] == 1
         # malformed: off-curve point -> status flag, never accepted; the rest of the batch is unaffected
         P = case["proofs"].copy()
         P[1, 70] ^= 1

@@ -346,8 +346,8 @@ def test_bench_starts_its_own_ranks(workload, total, rejects):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--total-proofs", str(total), "--steps", "2", "--warmup", "1",
            "--no-secondary", "--no-cpu-baseline", "--no-session-rates"]
-    if workload != "verify":
-        cmd += ["--workload", workload, "--fb-window-bits", "8"]
+    # (explicit small tables: two ranks sizing their tables to "the free HBM" of ONE device at the same moment is not what is under test)
+    cmd += ["--fb-window-bits", "16"] if workload == "verify" else ["--workload", workload, "--fb-window-bits", "8"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{") and '"value"' in l]

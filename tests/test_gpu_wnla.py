@@ -40,6 +40,21 @@ def test_wnla_commit_verify_vs_oracle(ng, nh, B):
             px[0, 0, 63] ^= 1
             acc, st = w.verify_batch(case["label"], **dict(args, proof_x=px))
             assert st[0] == 1 and acc[0] == 0 and acc[1:].all()
+        # the resident form (bppp_wnla_verify_batch_device): the tampered batch from device buffers, same verdicts and statuses, with and
+        # without a status buffer, and with per-kernel timing on
+        d = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in t.items()}
+        dA = torch.zeros(B, dtype=torch.uint8, device="cuda"); dS = torch.full((B,), 7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        dev = lambda st_ptr: w.verify_batch_device(case["label"], B, d["commitments"].data_ptr(), d["c"].data_ptr(), d["rho"].data_ptr(), d["mu"].data_ptr(),
+                                                   case["proof_r"].shape[1], d["proof_r"].data_ptr(), d["proof_x"].data_ptr(), d["proof_l"].data_ptr(),
+                                                   pl.shape[1], d["proof_n"].data_ptr(), pn.shape[1], dA.data_ptr(), st_ptr)
+        dev(dS.data_ptr()); w.synchronize()
+        assert dA.cpu().numpy().tolist() == exp and not dS.any().item()
+        dA.zero_(); dev(0); w.synchronize()
+        assert dA.cpu().numpy().tolist() == exp
+        w.enable_timing(True); dA.zero_(); dev(dS.data_ptr()); w.synchronize()
+        kt = w.timings(); w.enable_timing(False)
+        assert dA.cpu().numpy().tolist() == exp and kt["k_wnla_msm"]["launches"] == 1 and kt["k_wnla_round"]["launches"] == case["proof_r"].shape[1]
         # proof.x.len() != proof.r.len() -> false (wnla.rs:76-78)
         acc, _ = w.verify_batch(case["label"], **dict(args, proof_r=case["proof_r"][:, :-1] if case["proof_r"].shape[1] else np.zeros((B, 1, 64), np.uint8)))
         assert not acc.any()

@@ -23,6 +23,12 @@ for ng, nh in ((4, 4), (16, 32)):
         tv = med(lambda: w.verify_batch(case["label"], **args))
         tp = med(lambda: w.prove_batch(case["label"], case["commitments"], case["c"], case["rho"], case["mu"], case["l"], case["n"]))
         print(f"wnla ng {ng} nh {nh} rounds {case['rounds']}  B {B:3d}  verify {tv:7.3f} ms  prove {tp:7.3f} ms")
+        w.enable_timing(True); w.timings()
+        for _ in range(5):
+            w.verify_batch(case["label"], **args)
+        kt = w.timings(); w.enable_timing(False)
+        print("      verify kernels, ms per call:", {k.replace("k_wnla_", ""): round(v["total_ms"] / 5, 3) for k, v in kt.items() if v["launches"]},
+              "sum", round(sum(v["total_ms"] for v in kt.values()) / 5, 3))
         w.close()
 for B in (1, 64):
     case = recip_cases.make(16, 16, B=B)

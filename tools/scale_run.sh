@@ -10,11 +10,14 @@ set -u
 N=${1:?number of GPUs}; MODE=${2:-real}; REPO="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; OUT=${3:-$REPO/gpurun_out/scale_$N}
 cd "$REPO"; mkdir -p "$OUT"
 TOTAL=${SCALE_TOTAL_PROOFS:-1048576}; STEPS=${SCALE_STEPS:-5}
-if [ "$MODE" = "dry" ]; then export BENCH_ONE_DEVICE=1 BENCH_DIST_BACKEND=gloo; TOTAL=${SCALE_TOTAL_PROOFS:-131072}; fi
+WBITS=""
+# (dry: N ranks share ONE device -- explicit 16-bit tables, 3 GB per rank, instead of each rank sizing its tables to "the free HBM" at the same moment)
+if [ "$MODE" = "dry" ]; then export BENCH_ONE_DEVICE=1 BENCH_DIST_BACKEND=gloo; TOTAL=${SCALE_TOTAL_PROOFS:-131072}; WBITS="--fb-window-bits 16"; fi
 PORT=$((29500 + RANDOM % 400))
 timeout 1800 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus $N \
-  --total-proofs $TOTAL --steps $STEPS --warmup 1 --no-secondary --no-cpu-baseline > $OUT/bench_gpus$N.json 2> $OUT/bench_gpus$N.err
-echo "bench.py --gpus $N rc=$?"
+  --total-proofs $TOTAL --steps $STEPS --warmup 1 --no-secondary --no-cpu-baseline $WBITS > $OUT/bench_gpus$N.json 2> $OUT/bench_gpus$N.err
+RC=$?; echo "bench.py --gpus $N rc=$RC"
+[ $RC -ne 0 ] && { echo "--- tail of bench_gpus$N.err"; grep -v "amdgpu.ids\|hostname of the client socket\|OMP_NUM_THREADS\|^\*\*\*" $OUT/bench_gpus$N.err | tail -25; }
 timeout 1800 python tools/group_run.py --gpus $N --total-proofs $TOTAL --steps $STEPS > $OUT/group_gpus$N.json 2> $OUT/group_gpus$N.err
 echo "group_run.py --gpus $N rc=$?"
 python - $OUT/bench_gpus$N.json $OUT/group_gpus$N.json <<'PY'
