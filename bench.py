@@ -282,6 +282,48 @@ def predicted_scaling(total, ms_one_gpu, shares):
     return out
 
 
+def measure_sec1_device(torch, proto, workload, n, expect, steps, stream, slice_proofs=1 << 16):
+    import numpy as np
+    d33 = torch.empty((n, 33), dtype=torch.uint8, device="cuda")
+    d525 = torch.empty((n, 525), dtype=torch.uint8, device="cuda")
+    dSt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for a in range(0, n, slice_proofs):
+        b = min(n, a + slice_proofs)
+        x = torch.from_numpy(workload.bulk_values(b - a, first=a).view(np.int64)).cuda()
+        s = torch.from_numpy(workload.bulk_blindings(b - a, first=a)).cuda()
+        r = torch.from_numpy(workload.bulk_prover_randomness(b - a, first=a)).cuda()
+        torch.cuda.synchronize()
+        proto.prove_batch_sec1_device(workload.LABEL, b - a, x.data_ptr(), s.data_ptr(), r.data_ptr(), d525[a:b].data_ptr(), d33[a:b].data_ptr(), dSt[a:b].data_ptr())
+        proto.synchronize()
+        del x, s, r
+    # the same proofs as the headline batch, so the same ones are corrupted: one bit of a trailing scalar (the scalars are the last 96 bytes
+    # of both forms: offset in the 928-byte form - 832 + 429)
+    bad = np.nonzero(expect == 0)[0]
+    if len(bad):
+        ti = torch.from_numpy(bad).cuda()
+        to = torch.from_numpy(np.array([workload.corrupt_offset(int(j)) - 832 + 429 for j in bad], dtype=np.int64)).cuda()
+        d525[ti, to] = d525[ti, to] ^ 1
+    dA = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    dS = torch.zeros(n, dtype=torch.int32, device="cuda")
+
+    def step():
+        with torch.cuda.stream(stream):
+            proto.verify_batch_sec1_device(workload.LABEL, n, d33.data_ptr(), d525.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, 0)
+    step(); step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    ok = bool((dA.cpu().numpy() == expect).all()) and not bool(dS.any().item()) and not bool(dSt.any().item())
+    return {"value": n / ms * 1e3, "unit": "verifies/s", "ms_per_step": ms, "proofs": n, "accept_bits_ok": ok,
+            "bytes_per_proof_read": 525 + 33, "algorithmic_bytes_per_proof": ALGO_BYTES_PER_VERIFY,
+            "note": "bppp_u64_verify_batch_sec1_device on the whole batch in the reference's wire form, resident in HBM (what the device reads per "
+                    "proof IS the 559 algorithmic bytes less the accept byte); the same proofs and the same corrupted ones as the headline batch; "
+                    "kernel timing off; never `value`"}
+
+
 def table_sweep(torch, Proto, workload, g, gv, hv, dV, dP, dA, dS, expect, n, steps):
     out = {"unit": "ms per batch of %d proofs, kernel timing off" % n, "points": []}
     for code in (1119, 621, 523):
@@ -585,6 +627,11 @@ def run_verify(args):
             if n >= (1 << lg):
                 shares[lg] = timed_share(1 << lg, f"one GPU's share of BASELINE configs[2]'s {total >> lg}-GPU split: the first {1 << lg} proofs of the same resident batch")
     shard17 = shares.get(17)
+    # the reference's WIRE form resident on the device (reciprocal.rs:37-59: 33-byte SEC1 points -- 525 B per proof + 33 B per commitment):
+    # the same proofs, written in that form by the product's prover, decompressed on the device (14 square roots per proof) and verified
+    sec1_dev = None
+    if world == 1 and not args.no_secondary and not lite:
+        sec1_dev = measure_sec1_device(torch, proto, workload, n, expect, max(3, min(args.steps, 5)), stream)
     callers = None
     if world == 1 and not args.no_secondary and not under_profiler() and not lite:
         m = min(n, 4096)
@@ -774,6 +821,7 @@ def run_verify(args):
             "concurrent_callers": callers,
             "rlc_mode": rlc,
             "host_buffer_path": host_path,
+            "sec1_device": sec1_dev,
             "call_latency": call_latency,
             "prove_2pow14": prove14,
             "recip256_2pow15": recip15,

@@ -233,6 +233,18 @@ class U64RangeProofProtocol:
         _capi.check(_capi.lib().bppp_u64_verify_batch_rlc_device(self._ctx, label, len(label), n, d_commitments, d_proofs, d_accept,
                                                                  d_status or None, d_reject_count or None, seed))
 
+    def verify_batch_sec1_device(self, label: bytes, n: int, d_commitments33: int, d_proofs525: int, d_accept: int, d_status: int = 0,
+                                 d_trace: int = 0, d_reject_count: int = 0) -> None:
+        """The wire form resident on the device (33-byte SEC1 commitments, 525-byte proofs: reciprocal.rs:37-59): decompressed on the device
+        (14 square roots per proof), then the verifier; asynchronous on the context's stream (bppp_u64_verify_batch_sec1_device)."""
+        _capi.check(_capi.lib().bppp_u64_verify_batch_sec1_device(self._ctx, label, len(label), n, d_commitments33, d_proofs525, d_accept, d_status,
+                                                                  d_trace, d_reject_count))
+
+    def prove_batch_sec1_device(self, label: bytes, n: int, d_x: int, d_s: int, d_rnd: int, d_proofs525: int, d_commitments33: int,
+                                d_status: int = 0) -> None:
+        """bppp_u64_prove_batch_sec1_device: the batch prover writing the wire form (525-byte proofs, 33-byte commitments) into device buffers."""
+        _capi.check(_capi.lib().bppp_u64_prove_batch_sec1_device(self._ctx, label, len(label), n, d_x, d_s, d_rnd, d_proofs525, d_commitments33, d_status))
+
     def verify_batch_sec1(self, commitments33, proofs525, label: bytes) -> Tuple[np.ndarray, np.ndarray]:
         """verify over the wire content of SerializableProof: 33-byte SEC1 points, 525-byte proofs (bp_pp_amd/wire.py)."""
         commitments33 = _as_u8(commitments33, (-1, 33))

@@ -108,7 +108,11 @@ BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
  * points run a batch of more than max_batch proofs as consecutive parts of max_batch on the same stream, which bounds the per-proof
  * workspace (about 30 KB per proof) whatever n is -- a multiple of 64, >= 1024; default: the largest power of two up to 2097152 (63 GB of
  * workspace) that takes at most 70 % of the HBM the tables left free at context creation (still 2097152 beside the 210 GB of tables
- * an empty MI355X gets: 288 GiB are 309 GB).
+ * an empty MI355X gets: 288 GiB are 309 GB).  A first guess only: when the workspace of a part cannot be allocated after all (memory
+ * taken since by another context or process), the call releases what it holds, HALVES max_batch -- down to 4096 -- and runs the part
+ * again; BPPP_ERR_NOMEM comes back only when even that does not fit.  Contexts from bppp_ctx_create_shared start from the parent's value.
+ * "generic_parts" = 0 (default: by size -- today always one) | 1 .. 4: bppp_reciprocal_verify_batch_device runs a call as that many
+ * contiguous parts on as many streams (an A/B switch: round 6 measured it and found one part best at every size).
  * "rlc_chunk" = 8 | 32 | 0 (default): in the RLC modes of the u64 verifier, the proofs per chunk of the stage behind the bucket stage; 0 = per call,
  * from what the previous RLC call on this context rejected -- chunks of 32 while at most one proof in 256 was bad, and the bucket
  * stage's superchunks halved (or the stage skipped) when most of them would hold a bad proof and fail ("rlc_superchunk" set explicitly
@@ -136,10 +140,13 @@ BPPP_API int bppp_ctx_set_option(bppp_ctx* ctx, const char* name, long value);
 BPPP_API long bppp_ctx_get_option(bppp_ctx* ctx, const char* name);
 /* Which kernels a u64 verify (prove = 0) or prove (prove = 1) call of n proofs runs on a device of n_simds SIMDs (CUs x 4; MI355X: 1024):
  * the size decides among seven (six) launch sequences, from a wavefront per sum for a handful of proofs to one lane per proof from 2^17
- * on, and from 2^18 proofs how many proofs share one field inversion in the verifier's table build and rounds (shared_inv = 8, 16 from
- * 2^20; csrc/plan_core.h lists the regimes with their thresholds).  A pure function -- no device, no context; flags: bit 0 = RLC mode (verify) /
+ * on; where a call fills the chip's wavefront slots only once or twice (2^17 .. 2.25 x 2^17 proofs on an MI355X, except sizes whose last
+ * generation of wavefronts would be 30 .. 70 % full) it runs as TWO half-batch chains of kernels on two streams (twin=2: the code then
+ * describes what each chain runs), and up to 2^17 proofs the one-lane sums pace their wave priority (pace=1); beyond, how many proofs
+ * share one field inversion in the verifier's table build and rounds (shared_inv = 8, 16 from 2^20; csrc/plan_core.h lists the regimes
+ * with their thresholds and the measurements behind them).  A pure function -- no device, no context; flags: bit 0 = RLC mode (verify) /
  * "ct_prover" (prove), bit 1 = per-kernel timing on.  Returns the plan as a non-negative code whose fields bppp_plan_describe spells out
- * ("phase1=wg4 tables=beside/1 fb=l8 c0var=small round=small tail_beside=1 small=1 split=0 shared_inv=0"), or BPPP_ERR_INVALID_ARG.  A context's
+ * ("phase1=wg4 tables=beside/1 fb=l8 c0var=small round=small tail_beside=1 small=1 split=0 twin=1 pace=0 shared_inv=0"), or BPPP_ERR_INVALID_ARG.  A context's
  * diagnostic environment switches (BPPP_NO_SMALL_KERNELS etc.) are not visible here; "last_verify_plan" reports what really ran. */
 BPPP_API long bppp_u64_plan(int prove, size_t n, int n_simds, int flags);
 /* Text form of a plan code into buf (NUL-terminated, at most cap bytes); returns the length the full text needs, as snprintf does. */

@@ -322,6 +322,8 @@ def test_scale_run_kit_dry_run(tmp_path):
     env = dict(os.environ, SCALE_TOTAL_PROOFS="8192", SCALE_STEPS="2")
     env.pop("BPPP_FORCE_RCCL", None)
     r = subprocess.run(["bash", os.path.join(root, "tools", "scale_run.sh"), "2", "dry", str(tmp_path)], capture_output=True, text=True, timeout=1500, env=env)
+    print(r.stdout)                          # (shown in full by pytest when the assertion below fails)
+    print(r.stderr)
     assert "bench.py --gpus 2 rc=0" in r.stdout and "group_run.py --gpus 2 rc=0" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
     b = [json.loads(l) for l in open(tmp_path / "bench_gpus2.json") if '"value"' in l][0]
     assert b["n_gpus"] == 2 and b["accept_bits_ok"] and b["reject_count_all_reduced"] == 8 and b["config"]["proofs_per_gpu"] == 4096

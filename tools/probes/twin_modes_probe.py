@@ -38,6 +38,11 @@ def main():
         modes.append((f"lib:{kind}", lambda kind=kind: [child(BPPP_TWIN=1, BPPP_TWIN_STREAMS=kind)]))
     modes.append(("ctx2", lambda: [child(BPPP_NO_SMALL_KERNELS=1, BPPP_FB_ONE_LANE=1, BPPP_TWIN=0) for _ in range(2)]))
     modes.append(("one+pace", lambda: [child(BPPP_TWIN=0, BPPP_PACE=1)]))
+    if os.environ.get("SMALL_MODES"):      # 2^16 and below: K contexts on the one-lane 256-register kernels (no lane groups), fixed-base sums on 8 lanes / 1 lane
+        for K in (2, 4):
+            for fb1 in (0, 1):
+                modes.append((f"ctx{K}-fb{'l1' if fb1 else 'l8'}", lambda K=K, fb1=fb1: [child(BPPP_NO_SMALL_KERNELS=1, BPPP_NO_LANE_GROUPS=1, BPPP_FB_ONE_LANE=fb1, BPPP_TWIN=0)
+                                                                                         for _ in range(K)]))
     for rnd in range(2):                      # the whole list twice: drift shows as a difference between the rounds
         for name, make in modes:
             cs = make()

@@ -17,7 +17,7 @@ PORT=$((29500 + RANDOM % 400))
 timeout 1800 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus $N \
   --total-proofs $TOTAL --steps $STEPS --warmup 1 --no-secondary --no-cpu-baseline $WBITS > $OUT/bench_gpus$N.json 2> $OUT/bench_gpus$N.err
 RC=$?; echo "bench.py --gpus $N rc=$RC"
-[ $RC -ne 0 ] && { echo "--- tail of bench_gpus$N.err"; grep -v "amdgpu.ids\|hostname of the client socket\|OMP_NUM_THREADS\|^\*\*\*" $OUT/bench_gpus$N.err | tail -25; }
+[ $RC -ne 0 ] && { echo "--- tail of bench_gpus$N.err"; grep -v "amdgpu.ids\|hostname of the client socket\|OMP_NUM_THREADS\|^\*\*\*" $OUT/bench_gpus$N.err | tail -60; }
 timeout 1800 python tools/group_run.py --gpus $N --total-proofs $TOTAL --steps $STEPS > $OUT/group_gpus$N.json 2> $OUT/group_gpus$N.err
 echo "group_run.py --gpus $N rc=$?"
 python - $OUT/bench_gpus$N.json $OUT/group_gpus$N.json <<'PY'
