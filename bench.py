@@ -747,11 +747,12 @@ def run_verify(args):
     ms_ship, ms_timed = elapsed / args.steps * 1e3, elapsed_timed / args.steps * 1e3
     same_plan = plan_shipping == plan_timed
     timing_pass = {"ms_per_step": ms_timed, "plan": plan_timed, "same_plan_as_value": same_plan, "ratio_to_value_pass": ms_timed / ms_ship,
-                   # (checked where the ~25 event pairs of a timed step are noise: steps of 20 ms or more on the same plan)
-                   "agrees_within_2pct": (abs(ms_timed / ms_ship - 1.0) <= 0.02) if (same_plan and ms_ship >= 20.0) else None,
+                   # (checked where it means something: the same plan, steps of 50 ms or more -- the ~25 event pairs of a timed step are noise
+                   # there --, and every rank on a GPU of its own: the one-device dry run's ranks take turns on one chip)
+                   "agrees_within_2pct": (abs(ms_timed / ms_ship - 1.0) <= 0.02) if (same_plan and ms_ship >= 50.0 and not os.environ.get("BENCH_ONE_DEVICE")) else None,
                    "note": "second pass of the same steps with per-kernel HIP events (C0's halves back to back): the source of kernels_ms_per_step, "
                            "roofline and roofline_valu, never of `value`; a plan that differs (below 2^17 proofs per GPU the timed pass has no "
-                           "side-by-side kernels, at 2^17 .. 2^18 no twin chains) or a step under 20 ms (the events themselves show) is not "
+                           "side-by-side kernels, at 2^17 .. 2^18 no twin chains) or a step under 50 ms (the events themselves show), or ranks sharing one device, is not "
                            "comparable and not checked"}
     ok_timing = timing_pass["agrees_within_2pct"] is not False
     if rank == 0:

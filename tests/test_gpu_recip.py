@@ -272,3 +272,43 @@ def test_c0_points_that_meet_in_the_window_sum(group, monkeypatch):
         assert acc.tolist() == [1] + [0] * 6 + [1] * 63 + [0] and st[70] != 0 and not st[:70].any()
     finally:
         proto.close()
+
+
+@pytest.mark.parametrize("parts", [2, 3, 4])
+def test_device_call_in_parts_equals_one_part(parts):
+    """Option "generic_parts": a device-buffer call as 2 .. 4 contiguous parts on as many streams (bppp_generic.hip: recip_verify_device_entry;
+    an A/B switch -- one part is what the library does by itself).  300 instances of the (32, 16) shape with tampered and malformed ones:
+    accept bits and statuses of the call in parts equal those of the call in one part and the oracle's; ragged last part (300 = 128 + 128 + 44)."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import recip_cases
+    from bp_pp_amd.wnla import ReciprocalRangeProofProtocol
+    B = 300
+    case = recip_cases.make(32, 16, B)
+    proto = ReciprocalRangeProofProtocol(32, 16, case["g"], case["gv"], case["hv"], case["gv_"], case["hv_"], device=0, fb_window_bits=16)
+    try:
+        shape = (case["rounds"], case["nl"], case["nn"])
+        P, com = case["proofs"].copy(), case["commitments"].copy()
+        for b in (0, 127, 128, 129, 255, 256, B - 1):
+            P[b, -1] ^= 1
+        P[130, 256 + 64 * case["rounds"] + 5] ^= 0x40           # a round point off the curve
+        com[131] = case["commitments"][7]
+        dC, dP = torch.from_numpy(com).cuda(), torch.from_numpy(P).cuda()
+        res = {}
+        for k in (1, parts):
+            proto.set_option("generic_parts", k)
+            dA = torch.zeros(B, dtype=torch.uint8, device="cuda"); dS = torch.full((B,), 9, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            proto.verify_batch_device(case["label"], B, dC.data_ptr(), dP.data_ptr(), *shape, dA.data_ptr(), dS.data_ptr())
+            proto.synchronize()
+            res[k] = (dA.cpu().numpy(), dS.cpu().numpy())
+        assert proto.get_option("generic_parts") == parts
+        assert (res[1][0] == res[parts][0]).all() and (res[1][1] == res[parts][1]).all()
+        acc, st = res[parts]
+        for b in (0, 1, 127, 128, 129, 130, 131, 200, 255, 256, B - 2, B - 1):
+            rc = recip_cases.oracle_verify(case, bytes(com[b]), bytes(P[b]))
+            assert int(acc[b]) == (1 if rc == 1 else 0) and int(st[b]) == (1 if rc < 0 else 0), b
+        assert acc.sum() == B - 9
+    finally:
+        proto.close()

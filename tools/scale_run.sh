@@ -13,7 +13,7 @@ TOTAL=${SCALE_TOTAL_PROOFS:-1048576}; STEPS=${SCALE_STEPS:-5}
 WBITS=""
 # (dry: N ranks share ONE device -- explicit 16-bit tables, 3 GB per rank, instead of each rank sizing its tables to "the free HBM" at the same moment)
 if [ "$MODE" = "dry" ]; then export BENCH_ONE_DEVICE=1 BENCH_DIST_BACKEND=gloo; TOTAL=${SCALE_TOTAL_PROOFS:-131072}; WBITS="--fb-window-bits 16"; fi
-PORT=$((29500 + RANDOM % 400))
+PORT=$(python3 -c 'import socket; s = socket.socket(); s.bind(("127.0.0.1", 0)); print(s.getsockname()[1])')      # a port that is free right now
 timeout 1800 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $PORT bench.py --gpus $N \
   --total-proofs $TOTAL --steps $STEPS --warmup 1 --no-secondary --no-cpu-baseline $WBITS > $OUT/bench_gpus$N.json 2> $OUT/bench_gpus$N.err
 RC=$?; echo "bench.py --gpus $N rc=$RC"
