@@ -27,6 +27,7 @@ static void read_diagnostics(bppp_ctx* c) {
     if (const char* e = std::getenv("BPPP_SHARED_INV")) c->shared_inv = std::atoi(e);
     if (const char* e = std::getenv("BPPP_GENERIC_PARTS")) c->generic_parts = std::atoi(e);
     if (const char* e = std::getenv("BPPP_TWIN")) c->twin = std::atoi(e);
+    if (const char* e = std::getenv("BPPP_TWIN_STREAMS")) c->twin_stream_kind = std::atoi(e);
     if (const char* e = std::getenv("BPPP_PACE")) c->pace = std::atoi(e);
     if (const char* e = std::getenv("BPPP_NEXT_MSM_MAX")) c->next_msm_max = std::atol(e);
     c->generic_u64_shape = std::getenv("BPPP_GENERIC_U64_SHAPE") != nullptr;     // reciprocal (16, 16) calls stay on the generic kernels

@@ -44,33 +44,52 @@ struct TxDev {
 // fast variable-base path of the generic verifiers' rounds: per instance 2 x rounds window tables (16 entries of 64 B per point), the
 // running products of their build (BPPP_TSCR_PER_POINT per point) and the decoded round points -- 1.2 KB + 0.55 KB + 64 B per point, grow-only
 // extra_points: tables of that many more points per instance behind the round points' (the reciprocal verifier's five C0 points)
-static size_t wnla_fast_bytes(size_t n, size_t rounds, size_t extra_points) {
-    const size_t np = 2 * rounds + extra_points;
+// Sets of round-point tables a call of n instances builds (WnlaWs::tab_parts): calls that leave the chip EMPTY -- at most four instances
+// per SIMD -- cut every 26-window stream in 2 (4: at most one instance per SIMD) parts over tables of P and 2^65 P (P, 2^35 P, 2^70 P,
+// 2^100 P), a lane per table, and walk a round's sum on 8 (16) lanes: what such a call takes is the length of ONE instance's chain
+// (round 6: one WNLA verify of the u64 size 4.1 -> ms).  The u64 verifier has done the same since round 3 (plan_core.h: split).
+static int wnla_table_parts(const bppp_ctx* c, size_t n, size_t rounds) {
+    if (rounds == 0 || c->generic_slow_rounds || c->no_lane_groups || c->no_split || c->generic_lane_group) return 1;
+    const size_t S = (size_t)(c->n_simds > 0 ? c->n_simds : 1);
+    return n <= S ? 4 : n <= 4 * S ? 2 : 1;
+}
+static size_t wnla_fast_bytes(size_t n, size_t rounds, size_t extra_points, size_t parts = 1) {
+    const size_t np = 2 * rounds * parts + extra_points;
     return align16(np * 16 * sizeof(apt_packed) * n) + align16((size_t)BPPP_TSCR_PER_POINT * np * 10 * sizeof(u32) * n) + align16(np * 16 * sizeof(u32) * n);
 }
 // base: where this call's (or this part's) share of the table buffer starts; null = the context's buffer, grown to what the call needs
-static int wnla_fast_setup(bppp_ctx* c, WnlaWs& w, size_t n, size_t rounds, size_t extra_points = 0, uint8_t* base = nullptr) {
-    w.atab = nullptr; w.tscr = nullptr; w.rpts = nullptr;
+// parts: sets of round-point tables (wnla_table_parts); the extra points' tables follow them, at entry 2 x rounds x 16 x parts
+static int wnla_fast_setup(bppp_ctx* c, WnlaWs& w, size_t n, size_t rounds, size_t extra_points = 0, uint8_t* base = nullptr, size_t parts = 1) {
+    w.atab = nullptr; w.tscr = nullptr; w.rpts = nullptr; w.tab_parts = 1;
     if (rounds == 0 || c->generic_slow_rounds) return BPPP_OK;
-    const size_t np = 2 * rounds + extra_points;
+    const size_t np = 2 * rounds * parts + extra_points;
     const size_t b_tab = align16(np * 16 * sizeof(apt_packed) * n), b_scr = align16((size_t)BPPP_TSCR_PER_POINT * np * 10 * sizeof(u32) * n);
     if (!base) {
-        const int rc_t = ensure_buffer(c, c->d_gtab, c->gtab_bytes, wnla_fast_bytes(n, rounds, extra_points));
+        const int rc_t = ensure_buffer(c, c->d_gtab, c->gtab_bytes, wnla_fast_bytes(n, rounds, extra_points, parts));
         if (rc_t != BPPP_OK) return rc_t;
         base = c->d_gtab;
     }
     w.atab = (apt_packed*)base;
     w.tscr = (u32*)(base + b_tab);
     w.rpts = (u32*)(base + b_tab + b_scr);
+    w.tab_parts = (int)parts;
     return BPPP_OK;
 }
-// lanes per instance for the generic rounds: 4 or 2 while that still leaves wavefront slots free (and the fast path's tables exist)
+// lanes per instance for the generic rounds: 16 / 8 over tables in 4 / 2 parts (calls that leave the chip empty), else 4 or 2 while that
+// still leaves wavefront slots free (and the fast path's tables exist)
 static int wnla_round_group(const bppp_ctx* c, const WnlaWs& w, unsigned blocks) {
     if (!w.atab || c->no_lane_groups) return 1;
+    if (w.tab_parts == 4) return 16;
+    if (w.tab_parts == 2) return 8;
     if (c->generic_lane_group) return c->generic_lane_group;
     if (4 * (size_t)blocks <= (size_t)c->n_simds) return 4;
     if (2 * (size_t)blocks <= (size_t)c->n_simds) return 2;
     return 1;
+}
+// the round points' window tables: a lane per instance, or a lane per (point, part) table in a call that leaves the chip empty
+static void launch_wnla_tables(const WnlaWs& w, size_t n, unsigned blocks, hipStream_t s) {
+    if (w.tab_parts > 1) k_wnla_tables_split<<<(unsigned)(((size_t)32 * w.tab_parts * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, w.tab_parts);
+    else k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w);
 }
 // lanes per instance for the final scalars (k_wnla_final_scalars_grp), as log2: up to 8 while the launch stays within four wavefronts
 // per SIMD.  The work is independent per generator, so unlike the rounds it divides by the full group size.
@@ -169,7 +188,7 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out_points, d + o_out, n * 64, hipMemcpyDeviceToHost, s));
     } else {
-        rc = wnla_fast_setup(c, w, n, rounds);
+        rc = wnla_fast_setup(c, w, n, rounds, 0, nullptr, (size_t)wnla_table_parts(c, n, rounds));
         if (rc != BPPP_OK) return rc;
 #define WLAUNCH(id, ...)                                       \
     do {                                                       \
@@ -177,7 +196,7 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
         if (rc != BPPP_OK) return rc;                          \
     } while (0)
         WLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-        if (w.atab) WLAUNCH(K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+        if (w.atab) WLAUNCH(K_WNLA_TABLES, launch_wnla_tables(w, n, blocks, s));
         {
             const int grp = wnla_round_group(c, w, blocks);
             for (int k = 1; k <= (int)rounds; k++) {
@@ -318,9 +337,9 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     } while (0)
     // the WNLA stage's table buffer with room for the five C0 points' tables behind the round points': the variable-base part of C0 on
     // affine window tables too (and on lane groups while one lane per instance leaves wavefront slots free)
-    rc = wnla_fast_setup(c, w, n, rounds, 5, part ? part->gtab : nullptr);
+    rc = wnla_fast_setup(c, w, n, rounds, 5, part ? part->gtab : nullptr, part ? 1 : (size_t)wnla_table_parts(c, n, rounds));
     if (rc != BPPP_OK) return rc;
-    r.atab = w.atab; r.tscr = w.tscr; r.atab_first = (int)(2 * rounds * 16);
+    r.atab = w.atab; r.tscr = w.tscr; r.atab_first = (int)(2 * rounds * 16 * (size_t)w.tab_parts);
     // What needs nothing but the proof bytes -- the round points' window tables -- and what needs only phase 1 -- the C0 points' tables
     // and C0's variable-base sum, one lane (or a lane group) per instance -- runs on the HELPER stream beside phase 1 and the fixed-base
     // half of C0 (8 lanes per instance: the kernel that fills the chip); round 6: 2^15 instances of configs[4]'s shape, where the
@@ -336,7 +355,7 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     if (beside) {
         HIP_TRY(hipEventRecord(c->ev_tab, s));               // (the call's inputs are ready on s)
         HIP_TRY(hipStreamWaitEvent(a, c->ev_tab, 0));
-        GLAUNCH_ON(a, K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, a>>>(w));
+        GLAUNCH_ON(a, K_WNLA_TABLES, launch_wnla_tables(w, n, blocks, a));
     }
     GLAUNCH(K_RECIP_PHASE1, k_recip_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r));
     if (beside) {
@@ -349,7 +368,7 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     if (fb_one_lane) GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
     else GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
     if (r.atab) {
-        const int grp = wnla_round_group(c, w, call_blocks);
+        const int grp_r = wnla_round_group(c, w, call_blocks), grp = grp_r > 4 ? 4 : grp_r;      // (C0's sum: lane groups of 2 or 4)
         GLAUNCH_ON(a, K_RECIP_C0_VAR, {
             k_recip_c0_tables<<<blocks, BPPP_BLOCK, 0, a>>>(r);
             if (grp > 1) k_recip_c0_var_grp<<<(unsigned)(((size_t)grp * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, a>>>(r, grp);
@@ -363,7 +382,7 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
 #undef GLAUNCH_ON
     GLAUNCH(K_RECIP_C0_FINISH, k_recip_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r));
     GLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-    if (w.atab && !beside) GLAUNCH(K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (w.atab && !beside) GLAUNCH(K_WNLA_TABLES, launch_wnla_tables(w, n, blocks, s));
     {
         const int grp = wnla_round_group(c, w, call_blocks);
         for (int k = 1; k <= (int)rounds; k++) {
@@ -737,9 +756,9 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
         if (rc != BPPP_OK) return rc;                          \
     } while (0)
     {   // the WNLA stage's table buffer with room for the 4 + k points of C0's variable-base part behind the round points' tables
-        int rcf = wnla_fast_setup(c, w, n, rounds, 4 + k);
+        int rcf = wnla_fast_setup(c, w, n, rounds, 4 + k, nullptr, (size_t)wnla_table_parts(c, n, rounds));
         if (rcf != BPPP_OK) return rcf;
-        r.atab = w.atab; r.tscr = w.tscr; r.atab_first = (int)(2 * rounds * 16);
+        r.atab = w.atab; r.tscr = w.tscr; r.atab_first = (int)(2 * rounds * 16 * (size_t)w.tab_parts);
     }
     CLAUNCH(K_CIRCUIT_PHASE1, k_circuit_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r));
     CLAUNCH(K_CIRCUIT_C0_FIXED, k_circuit_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
@@ -749,7 +768,7 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
     });
     CLAUNCH(K_CIRCUIT_C0_FINISH, k_circuit_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r));
     CLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
-    if (w.atab) CLAUNCH(K_WNLA_TABLES, k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w));
+    if (w.atab) CLAUNCH(K_WNLA_TABLES, launch_wnla_tables(w, n, blocks, s));
     {
         const int grp = wnla_round_group(c, w, blocks);
         for (int kk = 1; kk <= (int)rounds; kk++) {

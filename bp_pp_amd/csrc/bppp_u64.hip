@@ -15,15 +15,14 @@ struct VerifyLanes { hipStream_t s, a; hipEvent_t ev_fork, ev_join, ev_tab; hipE
 // the second stream pair of a twin call (plan_core.h: twin), created at the first such call
 int bppp_ensure_twin_lanes(bppp_ctx* c) {
     if (c->twin_stream) return BPPP_OK;
-    // The two halves must sit on DIFFERENT hardware queues, or they run one after the other.  The runtime deals streams of one priority
-    // onto its four hardware queues by use count, so with a few contexts alive a third stream of normal priority may well share the queue
-    // of this context's own (measured: the twin form's gain at 2^17 proofs was there with 6 streams in the process and gone with 14).
-    // Streams of another priority come from another set of queues: the second half's pair is created at HIGH priority -- it also gets the
-    // wavefront slots first whenever both halves have a kernel waiting, which costs the first half nothing (the two fit side by side).
+    // The second chain's streams.  What kind they are made no measurable difference (normal priority, high priority, a CU mask of all
+    // CUs -- i.e. a hardware queue of their own: profiles/r06/r06_e_*, r06_f): the twin form's failures were never queue aliasing but
+    // the two chains falling into step (bppp_u64.hip: verify_device_part).  High priority is kept: such streams come from another set of
+    // hardware queues than the context's own whatever else lives in the process, and the second chain -- started later -- then gets the
+    // wavefront slots first when both have a kernel waiting.
     int prio_least = 0, prio_greatest = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    int kind = 1;                                                                    // 0 normal priority | 1 high priority | 2 a CU mask of all CUs (a queue of its own)
-    if (const char* e = std::getenv("BPPP_TWIN_STREAMS")) kind = std::atoi(e);       // diagnostic
+    const int kind = c->twin_stream_kind;                                            // 0 normal priority | 1 high priority | 2 a CU mask of all CUs (a queue of its own)
     if (kind == 2) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, c->device));
@@ -188,7 +187,10 @@ static int verify_device_part(bppp_ctx* c, const uint8_t* label, size_t label_le
         if (rc != BPPP_OK) return rc;                           \
     } while (0)
 #define LAUNCH(id, ...) LAUNCH_ON(s, id, __VA_ARGS__)
-    hipStream_t a = (c->timing || !L.a) ? s : L.a;
+    // (the helper stream: not with kernel timing on, not for a chain of a twin call, and not where the fixed-base sums run one lane per
+    // proof (fb = l1, from 128 S proofs): there both halves of C0 fill the chip by themselves, and side by side they take LONGER than one
+    // after the other -- round 6: 2^20 proofs 143.3 ms with the halves on two streams against 141.65 back to back, events included)
+    hipStream_t a = (c->timing || !L.a || plan.fb == bppp_host::FB_L1) ? s : L.a;
     // (tables: a lane per point on the helper stream while phase 1 runs, or the one-lane kernel beside phase 1 -- both decode their points
     // themselves -- or after phase 1 on the main stream)
     const bool tables_aside = plan.tables == bppp_host::TABLES_ASIDE, tables_beside = plan.tables == bppp_host::TABLES_BESIDE;

@@ -144,6 +144,7 @@ struct bppp_ctx {
     int tail_beside = -1;     // diagnostic BPPP_TAIL_BESIDE: the last round's sum beside the final fixed-base sum always (1) / never (0)
     u32* d_zinv = nullptr;    // [10][n] of the current call inside d_ws (carve)
     int generic_parts = 0;    // diagnostic BPPP_GENERIC_PARTS: parts of a generic reciprocal verify call (bppp_generic.hip: generic_parts_for); 0 = by size
+    int twin_stream_kind = 1; // diagnostic BPPP_TWIN_STREAMS: the second chain's stream at 0 normal priority | 1 high priority (default) | 2 with a CU mask of all CUs
     int twin = -1, pace = -1; // diagnostics BPPP_TWIN / BPPP_PACE (plan_core.h: VerifyPlan::twin, ::pace); unset = by batch size
     hipStream_t twin_stream = nullptr, twin_aux = nullptr;      // the second half's stream pair of a twin verify call (bppp_u64.hip: ensure_twin_lanes)
     hipEvent_t ev_twin_fork = nullptr, ev_twin_join = nullptr, ev2_fork = nullptr, ev2_join = nullptr, ev2_tab = nullptr;

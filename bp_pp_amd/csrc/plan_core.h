@@ -40,7 +40,7 @@ struct PlanKnobs {
 
 enum PlanTables { TABLES_INLINE = 0, TABLES_ASIDE, TABLES_BESIDE };        // on the main stream | lane-per-point kernel on the helper stream | one-lane kernel beside phase 1
 enum PlanPhase1 { P1_FULL = 0, P1_SMALL, P1_WG4, P1_G16 };                 // 256-register build | uncapped | 256-thread workgroups (beside the tables) | 16 lanes per proof
-enum PlanFb { FB_L8 = 0, FB_L1, FB_L64, FB_L4 };                           // lanes per fixed-base sum
+enum PlanFb { FB_L8 = 0, FB_L1, FB_L64, FB_L4 };                           // lanes per fixed-base sum (FB_L1 also means: C0's two halves one after the other, not side by side)
 enum PlanC0Var { C0V_FULL = 0, C0V_SMALL, C0V_G4, C0V_G32, C0V_G64 };
 enum PlanRound { R_FULL = 0, R_SMALL, R_G2, R_G4, R_G8, R_G16 };
 

@@ -850,8 +850,10 @@ HD void straus_affine(pt& out, atab_ref tab, const int* pidx, const glv_words<M>
 // lane q's share of the split sum (below): part h = q / 2M (windows split_begin(parts, h) .. split_begin(parts, h + 1) - 1) of stream
 // r = q % 2M over the table of 2^(5 split_begin(parts, h)) P (slot pidx + BPPP_VPOINTS h: verify_table_one); q >= 2M parts: nothing.
 // False on an exceptional addition.
+// (stride: table slots between the sets of consecutive parts -- BPPP_VPOINTS for the u64 verifier's 13 points, 2 x rounds for the generic
+// WNLA stage's round points)
 template <int M>
-HD bool straus_split_lane(pt& part, atab_ref tab, const int* pidx, const glv_words<M>& g, int q, int parts) {
+HD bool straus_split_lane(pt& part, atab_ref tab, const int* pidx, const glv_words<M>& g, int q, int parts, int stride = BPPP_VPOINTS) {
     fe beta;
     glv_beta(beta);
     const bool have = q < 2 * M * parts;
@@ -869,7 +871,7 @@ HD bool straus_split_lane(pt& part, atab_ref tab, const int* pidx, const glv_wor
         pn = (st == r) ? pidx[st >> 1] : pn;
     }
     const bool img = (r & 1) != 0;
-    const int base = (pn + BPPP_VPOINTS * h) * 16, w0 = split_begin(parts, h), nw = split_begin(parts, h + 1) - w0;   // 13, or 7 / 6, windows
+    const int base = (pn + stride * h) * 16, w0 = split_begin(parts, h), nw = split_begin(parts, h + 1) - w0;   // 13, or 7 / 6, windows
     auto digit = [&](int i, int& mag, bool& neg) {
         const int b = 5 * i, l = b >> 5, sh = b & 31;
         u32 lo = 0, hi = 0;
@@ -1009,10 +1011,10 @@ __device__ __forceinline__ void straus_affine_g4(pt& out, atab_ref tab, const in
 // the length of the chain is all that counts there.  The other lanes of the group hold no stream and add the identity.  All G lanes of
 // a group must be active and hold the same g / pidx; every lane ends with the total.
 template <int M, int G, int PARTS>
-__device__ __forceinline__ void straus_affine_split(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g, int q) {
+__device__ __forceinline__ void straus_affine_split(pt& out, atab_ref tab, const int* pidx, const glv_words<M>& g, int q, int stride = BPPP_VPOINTS) {
     static_assert(2 * M * PARTS <= G, "a lane per part of a stream");
     pt part;
-    int bad = straus_split_lane<M>(part, tab, pidx, g, q, PARTS) ? 0 : 1;
+    int bad = straus_split_lane<M>(part, tab, pidx, g, q, PARTS, stride) ? 0 : 1;
 #pragma unroll
     for (int m = 1; m < G; m <<= 1) bad |= __shfl_xor(bad, m, 64);
     if (bad) {                      // an exceptional addition somewhere in the group: every lane re-does the whole sum completely

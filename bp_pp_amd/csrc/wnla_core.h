@@ -36,6 +36,8 @@ struct WnlaWs {
     // 2 x rounds round points of every instance, built by one kernel with four batched inversions (verify_core.h:
     // affine_tables_build), then Jacobian accumulators with mixed additions over signed 5-bit windows (straus_affine)
     apt_packed* atab;      // [2 * rounds * 16][N] 64-byte entries: point 2 (k - 1) = X of round k, 2 (k - 1) + 1 = R of round k
+                           // (tab_parts > 1: that many such sets one after the other, set h over 2^(5 split_begin(tab_parts, h)) times the points)
+    int tab_parts;         // 1, or 2 / 4 in calls so small that a round is walked by 8 / 16 lanes per instance (wnla_verify_table_one)
     u32* tscr;             // [BPPP_TSCR_PER_POINT * 2 * rounds * 10][N] running products of the table build
     u32* rpts;             // [2 * rounds * 16][N] the decoded round points (packed affine words)
     FbTable fb;
@@ -125,6 +127,17 @@ HD void wnla_verify_tables(const WnlaWs& w, size_t t) {
 // ---- verify: round k = 1..rounds (wnla.rs:84-102), X = proof.x[rounds - k], R = proof.r[rounds - k]
 // group_lane >= 0: one of group_size (2 or 4) consecutive lanes that all run the round for instance t and share its sum
 // (verify_core.h: straus_affine_g4) -- batches that under-fill the chip with one lane per instance; -1: one lane per instance
+// ... the same for calls that leave the chip EMPTY (a handful of instances: what such a call takes is the length of one instance's chain):
+// a lane per (point, part) -- point p's table for part h of the 26 windows is the table of 2^(5 split_begin(parts, h)) P (straus_core.h:
+// affine_table_one), so that a round's two-point sum can be walked by 4 x parts lanes (straus_affine_split), 13 or 7 windows each
+HD void wnla_verify_table_one(const WnlaWs& w, size_t t, int p, int h, int parts) {
+    const int k = p / 2 + 1;                              // point 2 (k - 1) = X of round k, 2 (k - 1) + 1 = R of round k
+    apt X, R;
+    bool ok = apt_from_xy64(X, w.proof_x + (size_t)t * w.stride_x + (size_t)(w.rounds - k) * 64);
+    ok &= apt_from_xy64(R, w.proof_r + (size_t)t * w.stride_r + (size_t)(w.rounds - k) * 64);
+    if (!ok) { fe_set_u32(X.x, 0); fe_set_u32(X.y, 0); R = X; }
+    affine_table_one(atab_of(w.atab, w.N, t) + (h * 2 * w.rounds + p) * 16, (p & 1) ? R : X, 5 * split_begin(parts, h));
+}
 HD void wnla_verify_round(const WnlaWs& w, size_t t, int k, int group_lane = -1, int group_size = 4) {
     const size_t N = w.N;
     int32_t status = w.status[t];
@@ -160,7 +173,9 @@ HD void wnla_verify_round(const WnlaWs& w, size_t t, int k, int group_lane = -1,
         glv_decompose(sp, y2m1);
         glv_words_set<2>(g, 1, sp);
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (group_lane >= 0 && group_size == 4) straus_affine_g4<2, 4>(acc, atab_of(w.atab, N, t, 2 * w.rounds * 16), pslot, g, group_lane);
+        if (group_lane >= 0 && group_size == 16) straus_affine_split<2, 16, 4>(acc, atab_of(w.atab, N, t), pslot, g, group_lane, 2 * w.rounds);
+        else if (group_lane >= 0 && group_size == 8) straus_affine_split<2, 8, 2>(acc, atab_of(w.atab, N, t), pslot, g, group_lane, 2 * w.rounds);
+        else if (group_lane >= 0 && group_size == 4) straus_affine_g4<2, 4>(acc, atab_of(w.atab, N, t, 2 * w.rounds * 16), pslot, g, group_lane);
         else if (group_lane >= 0) straus_affine_g4<2, 2>(acc, atab_of(w.atab, N, t, 2 * w.rounds * 16), pslot, g, group_lane);
         else
 #endif
