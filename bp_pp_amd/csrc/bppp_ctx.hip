@@ -3,7 +3,7 @@
 #include "host.h"
 #include "plan_core.h"
 #if defined(BPPP_PHASE_TIMING)
-unsigned long long* g_bppp_stamps_dev = nullptr;      // diagnostic builds: the phase-stamp rows (verify_core.h: BPPP_STAMP), allocated at the first verify call
+unsigned long long* g_bppp_stamps_dev = nullptr;      // diagnostic builds: the phase-stamp rows (verify_ws.h: BPPP_STAMP), allocated at the first verify call
 #endif
 
 thread_local std::string g_last_error;
@@ -35,7 +35,7 @@ static void read_diagnostics(bppp_ctx* c) {
 }
 
 // fb_window_bits = 0: the FEWEST windows per scalar whose tables fit the HBM that is FREE when the context is created.  Windows come in
-// two widths sized to the bit (verify_core.h: fb_wb): n windows are floor(258 / n)-bit windows with 258 mod n of them one bit wider, e.g.
+// two widths sized to the bit (fb_core.h: fb_wb): n windows are floor(258 / n)-bit windows with 258 mod n of them one bit wider, e.g.
 //   11 windows: code  523 (5 x 24 + 6 x 23 bits), 4.29 GB per generator      14 windows: code 618, 168 MB per generator
 //   12 windows: code  621 (6 x 22 + 6 x 21),      1.21 GB                    15 windows: code 317,  75 MB
 //   13 windows: code 1119 (11 x 20 + 2 x 19),     403 MB                     16 windows: code 216,  38 MB   ...  32 windows: code 208, 278 KB
@@ -117,7 +117,7 @@ static int build_tables(bppp_ctx* c, int W, bool ct = false) {
     c->fb_w = W;
     return BPPP_OK;
 }
-// Two regions (verify_core.h: FbTable; round 5), the u64 shape's second choice when 11 windows for all 49 generators do not fit: the
+// Two regions (fb_core.h: FbTable; round 5), the u64 shape's second choice when 11 windows for all 49 generators do not fit: the
 // u64 protocol's g and g_vec -- the 17 generators that BOTH fixed-base sums of a verify run over (C0's fixed half and the final check) --
 // at 11 windows (code 523, 73 GB), h_vec at 12 (code 621, 39 GB): 758 table additions per proof against 726 / 792.
 // BPPP_NO_WIDE_TABLES=1 skips the first choice, BPPP_NO_MIXED_WINDOWS=1 both (one table, the general rule).

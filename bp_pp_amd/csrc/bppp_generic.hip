@@ -845,7 +845,7 @@ void bppp_wnla_proof_shape(size_t nl, size_t nn, size_t* rounds, size_t* nl_out,
     if (nn_out) *nn_out = b;
 }
 // "ct_prover" for the generic provers: the 4-bit table over THIS context's generators (built at the first use) for the sums over secret
-// scalars -- every entry of every window read and selected by mask, complete additions (verify_core.h: fb_lookup_add_ct)
+// scalars -- every entry of every window read and selected by mask, complete additions (fb_core.h: fb_lookup_add_ct)
 static int ct_setup(bppp_ctx* c, FbTable& fb_ct, int& ct, size_t n) {
     ct = 0;
     if (!c->ct_prover) return BPPP_OK;

@@ -74,11 +74,11 @@ struct bppp_ctx {
     apt* d_gens = nullptr;       // 49
     apt_packed* d_table = nullptr;
     size_t table_bytes = 0;
-    // second table region (verify_core.h: FbTable): generators 0 .. fb_hi_bases - 1 at fb_w_hi bits; d_table then holds the rest
+    // second table region (fb_core.h: FbTable): generators 0 .. fb_hi_bases - 1 at fb_w_hi bits; d_table then holds the rest
     apt_packed* d_table_hi = nullptr;
     size_t table_hi_bytes = 0;
     int fb_w_hi = 0, fb_hi_bases = 0;
-    // "ct_prover": the 4-bit table the provers' secret-scalar sums scan in full (verify_core.h: fb_lookup_add_ct), built when the option is set
+    // "ct_prover": the 4-bit table the provers' secret-scalar sums scan in full (fb_core.h: fb_lookup_add_ct), built when the option is set
     apt_packed* d_table_ct = nullptr;
     size_t table_ct_bytes = 0;
     bool ct_prover = false, borrows_table_ct = false;

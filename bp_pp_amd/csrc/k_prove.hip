@@ -93,7 +93,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_next(ProveWs w, int 
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) prove_round_next(w, t, k);
 }
-// small batches: four lanes per proof, the sum split into its four GLV streams (verify_core.h: straus_affine_g4)
+// small batches: four lanes per proof, the sum split into its four GLV streams (straus_core.h: straus_affine_g4)
 __global__ __launch_bounds__(BPPP_BLOCK) void k_prove_round_next_g4(ProveWs w, int k) {
     const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     const size_t t = g >> 2;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_rlc_lhs(VerifyWs ws, RlcWs r) {
 }
 
 // small batches (4 n lanes still leave SIMDs empty): four lanes per proof, the round's two-point sum split into its four GLV
-// streams (verify_core.h: straus_affine_g4); everything else is done identically by the four lanes
+// streams (straus_core.h: straus_affine_g4); everything else is done identically by the four lanes
 __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g4(VerifyWs ws, int k) {
     const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     const size_t t = g >> 2;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_verify_round_g2(VerifyWs ws, int
 
 // ---- calls so small that the chip is empty (a few proofs per SIMD at most): what a call takes is the longest dependent chain of one
 // proof, so the chains are cut further.  Window tables: a lane per table (13 points x PARTS tables: P and 2^65 P, or P, 2^35 P, 2^70 P,
-// 2^100 P -- 16 PARTS lanes per proof, 13 PARTS active); sums: a lane per part of a GLV stream (verify_core.h: straus_affine_split) --
+// 2^100 P -- 16 PARTS lanes per proof, 13 PARTS active); sums: a lane per part of a GLV stream (straus_core.h: straus_affine_split) --
 // 4 PARTS lanes per proof in a round, 16 PARTS (10 PARTS active) for C0.  Four parts up to one proof per SIMD, two up to four per SIMD.
 template <int PARTS>
 __device__ __forceinline__ void verify_tables_split(const VerifyWs& ws) {

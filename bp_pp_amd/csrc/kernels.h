@@ -24,7 +24,7 @@
 // fixed-base MSM kernels: BPPP_FB_LANES lanes per proof, 256-thread workgroups; 2 waves/SIMD (212 VGPRs, no spills) -- forcing 3
 // (168 VGPRs, 52 spilled) slows k_verify_final_check from 42.8 to 61.6 ms per 2^20 proofs (same measurement)
 // k_verify_tables: chains of dependent loads and short arithmetic (five passes over a proof's 13 points).  Round 2 ran it at 3 waves per
-// SIMD (168 VGPRs) with one running product per denominator; with one per block of four (verify_core.h: aff_push_block) the unwinding
+// SIMD (168 VGPRs) with one running product per denominator; with one per block of four (straus_core.h: aff_push_block) the unwinding
 // passes hold four denominators and their inverses at once: 229 spilled VGPRs at 168, 7 at 256.  Measured on 2^20 proofs
 // (profiles/r03/r03_c_*): 3 waves 17.2-17.4 ms, 2 waves 14.5-14.6 ms (round 2's form: 14.6-14.75 ms at 3 waves).
 #ifndef BPPP_TABLES_MIN_WAVES

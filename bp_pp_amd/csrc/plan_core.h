@@ -54,7 +54,7 @@ struct VerifyPlan {
     bool final_scalars_g16 = false;
     size_t vtab_sets = 1;        // window-table sets per proof the call needs room for
     int shared_inv = 0;          // G = 2, 4, 8, 16: the field inversions of the table build and of the rounds are taken once per G proofs by
-                                 // kernels of their own between the passes (verify_core.h: fe_batch_inv_lane); 0: every lane inverts for itself
+                                 // kernels of their own between the passes (straus_core.h: fe_batch_inv_lane); 0: every lane inverts for itself
     int twin = 1;                // 2: the batch runs as TWO half-batch launch sequences on two stream pairs (each half on the plan plan_verify_half
                                  // gives it); the other fields then describe a half.  1: one sequence
     int pace = 0;                // 1: the one-lane variable-base sums lower their wave priority as they advance (straus_core.h: straus_pace); 2: the one-lane fixed-base sums too (fb_core.h: fb_pace)
@@ -107,7 +107,7 @@ inline VerifyPlan plan_verify(size_t n, const PlanKnobs& k, bool rlc) {
     //   twin: the batch as two halves, each a launch sequence of its own on its own stream pair.  A SIMD then holds one wavefront of each
     //         half, of DIFFERENT kernels; when the older one ends, its sequence's next kernel moves in: the halves leapfrog and no SIMD
     //         is left with one wavefront except at the very end.  The halves run the 256-register one-lane kernels (plan_verify_half);
-    //   pace: the sums lower their own wave priority as they advance, so that a pair ends together (verify_core.h: straus_pace).
+    //   pace: the sums lower their own wave priority as they advance, so that a pair ends together (straus_core.h: straus_pace).
     //   Where each pays (one box, child contexts timed in turns, profiles/r06/r06_j_twin_sizes.txt; g = wavefronts / wavefront slots):
     //   twin  g = 1 (2^17 proofs) -1.4 % on top of pace, 1.06 .. 1.25 -3 .. -6 %, 1.75 -11 %, 2 (2^18) -3.5 %, 2.25 -6 %; but +4 % at g = 1.5,
     //         +2 .. +4 % from 2.5 up (the halves' own part-filled generations collide): so up to g = 2.25, except a last generation that is

@@ -157,7 +157,7 @@ HD void pt_dbl(pt& r, const pt& p) {
 // The formulas are INCOMPLETE (acc = +-q is not handled), so they are used with deferred detection: an exceptional addition
 // has P = x2 ZZ1 - X1 = 0, which makes ZZ3 = ZZ1 P^2 = 0, and ZZ then stays 0 through every later addition.  A lane therefore
 // tests ZZ once, after its whole sum; if it is 0 although points were added, the proof is re-done with the complete formulas
-// (verify_core.h: fixed_base_msm_partial_fast / the *_slow kernels).  For independent generators this never happens; it does
+// (fb_core.h: fb_lane_finish_fast reports it; k_verify_fixed.hip: the k_verify_final_check_flagged* kernels redo the flagged proofs).  For independent generators this never happens; it does
 // for degenerate generator sets (repeated or related generators), which stay correct through the fallback.
 struct ptz { fe X, Y, ZZ, ZZZ; };
 // true if the flag is set on ANY active lane of the wavefront (a wave-uniform value: branching on it never diverges)

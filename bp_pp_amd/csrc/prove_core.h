@@ -57,12 +57,12 @@ struct ProveWs {
     uint8_t* states_out;
     int next_by_msm;        // 1: prove_round_fold leaves the next commitment's scalars in set 0 for job_e (calls that leave SIMDs idle) instead of handing it to prove_round_next
     // "ct_prover": the sums over the witness and its blindings (V, r_com, c_o, c_l, c_r, c_s) read every entry of every window of this
-    // 4-bit table and select by mask (verify_core.h: fb_lookup_add_ct); the WNLA stage's sums, whose vectors the argument reveals by
+    // 4-bit table and select by mask (fb_core.h: fb_lookup_add_ct); the WNLA stage's sums, whose vectors the argument reveals by
     // design (the circuit layer blinds them: circuit.rs:371-372), keep the fast gathers
     FbTable fb_ct;
     int ct;
 };
-struct MsmJob {             // one fixed-base MSM per proof: sum over runs of bases of scalar set `set` (verify_core.h: FbRanges)
+struct MsmJob {             // one fixed-base MSM per proof: sum over runs of bases of scalar set `set` (fb_core.h: FbRanges)
     int set, out_slot, nranges;
     int first[BPPP_FB_MAX_RUNS], count[BPPP_FB_MAX_RUNS];
     int bits[BPPP_FB_MAX_RUNS];     // > 0: the run's scalars are below 2^bits (hex digits, multiplicities, the u64 value)

@@ -197,7 +197,7 @@ HD void recip_c0_fixed_store(const RecipWs& w, size_t t, const pt& total) { ws_s
 HD void recip_c0_tables(const RecipWs& w, size_t t) {
     affine_tables_build(atab_of(w.atab, w.N, t) + w.atab_first, w.tscr, w.pts, w.N, t, 5);
 }
-// group_lane >= 0: one of group_size (2 or 4) consecutive lanes that all run the sum for instance t (verify_core.h: straus_affine_g4)
+// group_lane >= 0: one of group_size (2 or 4) consecutive lanes that all run the sum for instance t (straus_core.h: straus_affine_g4)
 HD void recip_c0_var(const RecipWs& w, size_t t, int group_lane = -1, int group_size = 4) {
     const size_t N = w.N;
     pt acc;

@@ -126,7 +126,7 @@ HD void wnla_verify_tables(const WnlaWs& w, size_t t) {
 }
 // ---- verify: round k = 1..rounds (wnla.rs:84-102), X = proof.x[rounds - k], R = proof.r[rounds - k]
 // group_lane >= 0: one of group_size (2 or 4) consecutive lanes that all run the round for instance t and share its sum
-// (verify_core.h: straus_affine_g4) -- batches that under-fill the chip with one lane per instance; -1: one lane per instance
+// (straus_core.h: straus_affine_g4) -- batches that under-fill the chip with one lane per instance; -1: one lane per instance
 // ... the same for calls that leave the chip EMPTY (a handful of instances: what such a call takes is the length of one instance's chain):
 // a lane per (point, part) -- point p's table for part h of the 26 windows is the table of 2^(5 split_begin(parts, h)) P (straus_core.h:
 // affine_table_one), so that a round's two-point sum can be walked by 4 x parts lanes (straus_affine_split), 13 or 7 windows each

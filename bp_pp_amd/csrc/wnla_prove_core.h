@@ -34,7 +34,7 @@ struct WnlaProveWs {
     u32* pbuf;        // [3][30][N]    X, R, next commitment (projective)
     pt_slot* straus;  // [N][2 * BPPP_STRAUS_ENTRIES]  window tables of X and R for the next commitment by the verifier's relation
     FbTable fb;
-    FbTable fb_ct;    // "ct_prover": the 4-bit table the X | R sums scan in full (verify_core.h: fb_lookup_add_ct); used when ct != 0
+    FbTable fb_ct;    // "ct_prover": the 4-bit table the X | R sums scan in full (fb_core.h: fb_lookup_add_ct); used when ct != 0
     int ct;           // set by bppp_wnla_prove_batch when the option is on: l and n are the caller's secrets there (wnla.rs:152-160)
     strobe base;
     TranscriptIo tio;                                            // caller's transcripts (wnla.rs:125 `t: &mut Transcript`); input side ignored when transcript_preloaded

@@ -9,7 +9,7 @@
 
 #include "../../bp_pp_amd/csrc/plan_core.h"      // (before the device headers: field.h pulls <stdio.h> in inside its namespace in the host build)
 
-#define BPPP_TRACE_TABLE_READS 1      // verify_core.h: FB_TRACE reports every fixed-base table entry a sum requests (emulator only)
+#define BPPP_TRACE_TABLE_READS 1      // fb_core.h: FB_TRACE reports every fixed-base table entry a sum requests (emulator only)
 #include "../../bp_pp_amd/csrc/prove_core.h"
 #include "../../bp_pp_amd/csrc/circuit_core.h"
 #include "../../bp_pp_amd/csrc/recip_core.h"
@@ -170,7 +170,7 @@ int emul_fb_build(const uint8_t* gens, int nbases, int W, uint8_t* table_out /* 
     }
     return 0;
 }
-// geometry of a window code (verify_core.h: fb_wb): out = {windows, first bit of window w, entries of window w, entries of a generator
+// geometry of a window code (fb_core.h: fb_wb): out = {windows, first bit of window w, entries of window w, entries of a generator
 // before window w, entries per generator, windows a scalar below 2^bits reaches}
 void emul_fb_shape(int W, int w, int bits, uint64_t out[6]) {
     out[0] = (uint64_t)fb_nwin(W); out[1] = (uint64_t)fb_pos(W, w); out[2] = fb_per_win_at(W, w); out[3] = fb_win_off(W, w);
@@ -398,7 +398,7 @@ int emul_u64_verify_batch_transcript(const uint8_t* table, int W, size_t n, cons
                                      const uint8_t* proofs, uint8_t* accept, int32_t* status, uint8_t* states_out) {
     return emul_u64_verify_impl(table, W, nullptr, 0, n, V, proofs, accept, status, nullptr, states, n_states, states_out);
 }
-// the large batches' shared inversions (plan_core.h: shared_inv; verify_core.h: fe_batch_inv_lane): G proofs per inversion, lane order
+// the large batches' shared inversions (plan_core.h: shared_inv; straus_core.h: fe_batch_inv_lane): G proofs per inversion, lane order
 static int g_shared_inv = 0;
 void emul_set_shared_inv(int g) { g_shared_inv = g; }
 extern "C++" {

@@ -169,7 +169,7 @@ def test_affine_tables_and_jacobian_straus(L):
 
 @pytest.mark.parametrize("parts", [2, 4])
 def test_per_lane_tables_and_half_stream_sums(L, parts):
-    """The small-call path of the u64 verifier (verify_core.h: affine_table_one, straus_split_lane): a lane builds ONE window table
+    """The small-call path of the u64 verifier (straus_core.h: affine_table_one, straus_split_lane): a lane builds ONE window table
     -- of P, or of 2^65 P (two parts per stream) / 2^35 P, 2^70 P, 2^100 P (four parts) for the later parts of a stream -- and a
     lane walks ONE part of a GLV stream; the lanes' shares added up must be sum k_j P_j, and every table entry must be the oracle's
     multiple.  Identity points, special scalars, exceptional additions."""
@@ -244,7 +244,7 @@ def test_fixed_base_window_digits_recompose_the_scalar(L, W):
         assert total == k
 
 
-# window codes with two widths (verify_core.h: fb_wb): code = Wb + 100 ka -- ka windows of Wb + 1 bits, then windows of Wb bits
+# window codes with two widths (fb_core.h: fb_wb): code = Wb + 100 ka -- ka windows of Wb + 1 bits, then windows of Wb bits
 MIXED_CODES = [609, 310, 208, 523, 618, 1119]
 
 
@@ -469,7 +469,7 @@ def test_full_prove_pipeline_is_byte_identical_to_the_oracle(L, gold, oracle_c, 
 
 
 def test_secret_scalar_sums_in_the_constant_address_form(L, gold, oracle_c):
-    """ "ct_prover" (verify_core.h: fb_lookup_add_ct): the prover's sums over the witness and its blindings read EVERY entry of every
+    """ "ct_prover" (fb_core.h: fb_lookup_add_ct): the prover's sums over the witness and its blindings read EVERY entry of every
     4-bit window and select by mask.  Same points as the digit-addressed gathers -- window by window, including the zero digit and
     an accumulator that equals the table entry (the doubling case of the complete law) -- and the same proof bytes as the oracle
     prover's, on the golden cases and at the edges of the inputs (x = 0, 2^64 - 1; zero and n - 1 blindings and draws)."""

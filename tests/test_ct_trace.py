@@ -1,6 +1,6 @@
 """The property behind "ct_prover", tested as a property: which fixed-base table entries the provers' sums over SECRET scalars read must
 not depend on the secrets.  The host build of the device code (tests/emul) reports every table entry such a sum requests
-(verify_core.h: FB_TRACE); for two different secrets under the same public inputs the two sequences must be IDENTICAL in the
+(fb_core.h: FB_TRACE); for two different secrets under the same public inputs the two sequences must be IDENTICAL in the
 "ct_prover" forms -- u64 prover, and the generic WNLA / circuit / reciprocal provers -- while in the default forms they differ (the
 digit-addressed gathers: the side channel the mode closes).  Same proof bytes either way, equal to the oracle provers'.
 Reference: k256's constant-time `ProjectivePoint * Scalar` at reciprocal.rs:118, circuit.rs:336-345,469-470, wnla.rs:152-160."""

@@ -65,7 +65,7 @@ def test_wnla_commit_verify_vs_oracle(ng, nh, B):
 @pytest.mark.parametrize("W", [4, 8, 10, 16, 18, 19, 20, 22])
 def test_every_fixed_base_window_width_vs_oracle(W):
     """The same WNLA instances (commit, verify, prove: wnla.rs:66-190) through fixed-base tables of every window width the library
-    accepts -- unsigned 4 / 8 / 16 bits, signed 10 / 18 / 19 / 20 / 22 bits (verify_core.h: fb_digit) -- against the oracle; few
+    accepts -- unsigned 4 / 8 / 16 bits, signed 10 / 18 / 19 / 20 / 22 bits (fb_core.h: fb_digit) -- against the oracle; few
     generators, so that even the 22-bit tables stay small (7 bases x 12 windows x 2^21 entries = 11 GB)."""
     import torch
     if torch.cuda.device_count() == 0:
@@ -94,7 +94,7 @@ def test_every_fixed_base_window_width_vs_oracle(W):
 
 def test_fixed_base_fast_accumulator_fallback_on_device():
     """Repeated generators + a scalar pattern that makes one lane add a table entry to itself: the incomplete (XYZZ) fixed-base
-    accumulator must notice and the lane group must re-do the sum with the complete law (verify_core.h: fb_group_sum)."""
+    accumulator must notice and the lane group must re-do the sum with the complete law (fb_core.h: fb_group_sum)."""
     import ctypes as C
     import torch
     if torch.cuda.device_count() == 0:

@@ -1,4 +1,4 @@
-"""Reads the phase stamps of a -DBPPP_PHASE_TIMING build (see verify_core.h: BPPP_STAMP): shader-clock deltas between the marked
+"""Reads the phase stamps of a -DBPPP_PHASE_TIMING build (see verify_ws.h: BPPP_STAMP): shader-clock deltas between the marked
 points of verify_phase1 and verify_round, averaged over the wavefronts.   BPPP_LIB=.../libbppp_hip_pt.so python tools/phase_probe.py"""
 import ctypes as C, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

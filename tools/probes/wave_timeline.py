@@ -2,7 +2,7 @@
 
 A -DBPPP_PHASE_TIMING build (tools/build_variants.py pt=-DBPPP_PHASE_TIMING) stamps the 100 MHz real-time counter per sampled wavefront
 at marked points of verify_phase1 / verify_tables / verify_c0_var / verify_round, plus HW_ID | XCC_ID at each kernel's first stamp
-(verify_core.h: BPPP_STAMP; up to 4,096 rows: every wavefront up to 2^18 proofs, every 4th at 2^20).
+(verify_ws.h: BPPP_STAMP; up to 4,096 rows: every wavefront up to 2^18 proofs, every 4th at 2^20).
 
     BPPP_LIB=bp_pp_amd/libbppp_hip_pt.so python tools/probes/wave_timeline.py [log2 n ...]      (default 17 20)
 
