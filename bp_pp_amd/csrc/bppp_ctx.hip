@@ -416,6 +416,12 @@ int bppp_ctx_set_option(bppp_ctx* c, const char* name, long value) {
         c->generic_parts = (int)value;
         return BPPP_OK;
     }
+    // how the parts' chains start: 0 together, 1 .. 3 each behind the one before's phase 1 / C0 stage / rounds (host.h: generic_stagger)
+    if (std::strcmp(name, "generic_stagger") == 0) {
+        if (value < 0 || value > 3) return BPPP_ERR_INVALID_ARG;
+        c->generic_stagger = (int)value;
+        return BPPP_OK;
+    }
     if (std::strcmp(name, "host_chunk") == 0) {
         if (value != 0 && (value < 1024 || (value & 63))) return BPPP_ERR_INVALID_ARG;
         c->host_chunk = (size_t)value;
@@ -457,6 +463,7 @@ long bppp_ctx_get_option(bppp_ctx* c, const char* name) {
     if (std::strcmp(name, "max_batch") == 0) return (long)c->max_batch;
     if (std::strcmp(name, "host_chunk") == 0) return (long)c->host_chunk;
     if (std::strcmp(name, "generic_parts") == 0) return (long)c->generic_parts;
+    if (std::strcmp(name, "generic_stagger") == 0) return (long)c->generic_stagger;
     if (std::strcmp(name, "coalesce_max") == 0) return c->coalesce_max;
     if (std::strcmp(name, "coalesce_us") == 0) return c->coalesce_us;
     if (std::strcmp(name, "coalesce_lanes") == 0) return c->coalesce_lanes;

@@ -270,7 +270,9 @@ int bppp_wnla_verify_batch_transcript(bppp_ctx* c, size_t n, const uint8_t* stat
 // ---- generic ReciprocalRangeProofProtocol::verify (reciprocal.rs:98-107) on a context built by bppp_wnla_ctx_create over
 //      g, g_vec || g_vec_, h_vec || h_vec_
 // one part of a multi-part call (recip_verify_device_entry): its stream and its shares of the context's buffers
-struct GenericPart { hipStream_t s; uint8_t* gtab; pt_slot* straus; unsigned call_blocks; };
+// (started / stage: an event recorded behind the part's stage-th milestone -- 1 phase 1, 2 the C0 stage, 3 the rounds -- that the NEXT
+// part's chain waits for, so that the chains run out of step: one part's fixed-base sums under another's one-lane kernels)
+struct GenericPart { hipStream_t s; uint8_t* gtab; pt_slot* straus; unsigned call_blocks; hipEvent_t started; int stage; };
 // workspace bytes (beyond the caller's commitments / proofs / accept / status) of one reciprocal verify call
 static size_t recip_verify_ws_bytes(const bppp_ctx* c, size_t n, size_t dim_nd, size_t dim_np, size_t rounds, bool rlc = false) {
     const size_t NB = (size_t)c->nbases, T = (size_t)1 << rounds, NH = (size_t)c->nh;
@@ -358,6 +360,7 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
         GLAUNCH_ON(a, K_WNLA_TABLES, launch_wnla_tables(w, n, blocks, a));
     }
     GLAUNCH(K_RECIP_PHASE1, k_recip_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    if (part && part->started && part->stage == 1) HIP_TRY(hipEventRecord(part->started, s));
     if (beside) {
         HIP_TRY(hipEventRecord(c->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
@@ -381,6 +384,7 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     }
 #undef GLAUNCH_ON
     GLAUNCH(K_RECIP_C0_FINISH, k_recip_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    if (part && part->started && part->stage == 2) HIP_TRY(hipEventRecord(part->started, s));
     GLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     if (w.atab && !beside) GLAUNCH(K_WNLA_TABLES, launch_wnla_tables(w, n, blocks, s));
     {
@@ -390,6 +394,7 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
             else GLAUNCH(K_WNLA_ROUND, k_wnla_round<<<blocks, BPPP_BLOCK, 0, s>>>(w, k));
         }
     }
+    if (part && part->started && part->stage == 3) HIP_TRY(hipEventRecord(part->started, s));
     GLAUNCH(K_WNLA_FINAL_SCALARS, launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s, call_blocks));
     if (!rlc_seed) {
         if (fb_one_lane) GLAUNCH(K_WNLA_MSM, k_wnla_msm_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(w));
@@ -491,13 +496,17 @@ int recip_verify_device_entry(bppp_ctx* c, const uint8_t* label, size_t label_le
         }
         hipStream_t streams[4] = {c->stream, c->twin_stream, c->aux_stream, c->twin_aux};
         hipEvent_t joins[4] = {nullptr, c->ev_twin_join, c->ev2_fork, c->ev2_join};
+        hipEvent_t started[4] = {c->ev_tab, c->ev_fork, c->ev_join, nullptr};      // (free here: a part's kernels are one chain on one stream)
+        const int stage = c->generic_stagger;
         const size_t proof_bytes = 64 * (5 + 2 * rounds) + 32 * (nl + nn);
         const unsigned call_blocks = (unsigned)((n + BPPP_BLOCK - 1) / BPPP_BLOCK);
         HIP_TRY(hipEventRecord(c->ev_twin_fork, c->stream));
         for (int i = 1; i < parts; i++) HIP_TRY(hipStreamWaitEvent(streams[i], c->ev_twin_fork, 0));
         int rc_parts = BPPP_OK;
         for (int i = 0; i < parts && rc_parts == BPPP_OK; i++) {
-            const GenericPart gp = {streams[i], fast ? c->d_gtab + gt_off[i] : nullptr, c->d_straus + lo[i] * 5 * BPPP_STRAUS_ENTRIES, call_blocks};
+            const GenericPart gp = {streams[i], fast ? c->d_gtab + gt_off[i] : nullptr, c->d_straus + lo[i] * 5 * BPPP_STRAUS_ENTRIES, call_blocks,
+                                    stage && i + 1 < parts ? started[i] : nullptr, stage};
+            if (stage && i > 0) HIP_TRY(hipStreamWaitEvent(streams[i], started[i - 1], 0));
             rc_parts = recip_verify_device_impl(c, label, label_len, m[i], dim_nd, dim_np, (const uint8_t*)d_commitments + 64 * lo[i],
                                                 (const uint8_t*)d_proofs + proof_bytes * lo[i], rounds, nl, nn, (uint8_t*)d_accept + lo[i],
                                                 (int32_t*)d_status + lo[i], c->d_gws + ws_off[i], nullptr, nullptr, &gp);

@@ -143,6 +143,7 @@ struct bppp_ctx {
     int next_overlap = -1;   // diagnostic BPPP_NEXT_OVERLAP: the variable-base next commitment on the helper stream always (1) / never (0)
     int tail_beside = -1;     // diagnostic BPPP_TAIL_BESIDE: the last round's sum beside the final fixed-base sum always (1) / never (0)
     u32* d_zinv = nullptr;    // [10][n] of the current call inside d_ws (carve)
+    int generic_stagger = 1;  // the parts' chains start out of step: part i + 1 behind part i's phase 1 (1), C0 stage (2), rounds (3); 0: together
     int generic_parts = 0;    // diagnostic BPPP_GENERIC_PARTS: parts of a generic reciprocal verify call (bppp_generic.hip: generic_parts_for); 0 = by size
     int twin_stream_kind = 1; // diagnostic BPPP_TWIN_STREAMS: the second chain's stream at 0 normal priority | 1 high priority (default) | 2 with a CU mask of all CUs
     int twin = -1, pace = -1; // diagnostics BPPP_TWIN / BPPP_PACE (plan_core.h: VerifyPlan::twin, ::pace); unset = by batch size
