@@ -112,7 +112,9 @@ BPPP_API int bppp_ctx_set_stream(bppp_ctx* ctx, void* hip_stream);
  * taken since by another context or process), the call releases what it holds, HALVES max_batch -- down to 4096 -- and runs the part
  * again; BPPP_ERR_NOMEM comes back only when even that does not fit.  Contexts from bppp_ctx_create_shared start from the parent's value.
  * "generic_parts" = 0 (default: by size -- today always one) | 1 .. 4: bppp_reciprocal_verify_batch_device runs a call as that many
- * contiguous parts on as many streams (an A/B switch: round 6 measured it and found one part best at every size).
+ * contiguous parts on as many streams (an A/B switch: round 6 measured it and found one part best up to 2^17 instances of configs[4]'s
+ * shape, two parts 2 % ahead at 2^18 -- what two 2^17 calls cost); "generic_stagger" = 0 | 1 (default) | 2 | 3: the parts' chains start
+ * together, or each behind the one before's phase 1 / C0 stage / rounds.
  * "rlc_chunk" = 8 | 32 | 0 (default): in the RLC modes of the u64 verifier, the proofs per chunk of the stage behind the bucket stage; 0 = per call,
  * from what the previous RLC call on this context rejected -- chunks of 32 while at most one proof in 256 was bad, and the bucket
  * stage's superchunks halved (or the stage skipped) when most of them would hold a bad proof and fail ("rlc_superchunk" set explicitly
