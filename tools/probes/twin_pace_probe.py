@@ -12,6 +12,12 @@ from bp_pp_amd import U64RangeProofProtocol, synth
 REPS = int(os.environ.get("REPS", "9"))
 CONFIGS = [("library default", {}), ("twin=0 pace=0", {"BPPP_TWIN": 0, "BPPP_PACE": 0}), ("twin=1", {"BPPP_TWIN": 1, "BPPP_PACE": 0}),
            ("pace=1", {"BPPP_TWIN": 0, "BPPP_PACE": 1}), ("twin=1 pace=1", {"BPPP_TWIN": 1, "BPPP_PACE": 1})]
+if os.environ.get("ONLY_ENV"):           # replaces the list; the FIRST entry is the base of the comparison, e.g. ONLY_ENV="one kernel:BPPP_TABLES_STAGED=0;by stage:BPPP_TABLES_STAGED=1"
+    CONFIGS = []
+    for item in os.environ["ONLY_ENV"].split(";"):
+        name, _, kv = item.partition(":")
+        CONFIGS.append((name, dict(x.split("=") for x in kv.split(",")) if kv else {}))
+BASE = CONFIGS[0][0] if os.environ.get("ONLY_ENV") else "twin=0 pace=0"
 if os.environ.get("EXTRA_ENV"):          # e.g. EXTRA_ENV="twin=1 si=8:BPPP_TWIN=1,BPPP_SHARED_INV=8;..."
     for item in os.environ["EXTRA_ENV"].split(";"):
         name, _, kv = item.partition(":")
@@ -51,7 +57,7 @@ def main():
             c.synchronize()
             oks[name] = bool((dA[:n].cpu().numpy() == expect[:n]).all()) and not bool(dS[:n].any().item()) and int(dR.item()) == int((expect[:n] == 0).sum())
             plans[name] = c.last_plan()
-        inner = max(1, min(8, (1 << 20) // n))
+        inner = max(1, min(16, (1 << 20) // n))
         for _ in range(REPS):
             for name, c in ctxs:
                 torch.cuda.synchronize()
@@ -60,10 +66,10 @@ def main():
                     c.verify_batch_device(synth.LABEL, n, dV.data_ptr(), dP.data_ptr(), dA.data_ptr(), dS.data_ptr(), 0, 0)
                 c.synchronize()
                 times[name].append((time.perf_counter() - t0) * 1e3 / inner)
-        base = float(np.median(times["twin=0 pace=0"]))
+        base = float(np.median(times[BASE]))
         for name, _ in ctxs:
             t = np.array(times[name])
-            print(f"n={n:8d} {name:18s} median {np.median(t):8.3f} ms  min {t.min():8.3f}  {n / np.median(t) / 1e3:6.3f} M/s  vs twin=0 pace=0 {np.median(t) / base - 1:+.2%}  ok={oks[name]}  {plans[name]}", flush=True)
+            print(f"n={n:8d} {name:18s} median {np.median(t):8.3f} ms  min {t.min():8.3f}  {n / np.median(t) / 1e3:6.3f} M/s  vs {BASE} {np.median(t) / base - 1:+.2%}  ok={oks[name]}  {plans[name]}", flush=True)
     for _, c in ctxs:
         c.close()
     proto.close()
