@@ -864,6 +864,10 @@ def run_verify(args):
             gkeep = keep + ("roofline_valu", "accept_bits_ok")
             result["wnla_16_32_2pow16"] = {k: rw[k] for k in gkeep if k in rw}
             result["circuit_mixed_k2_2pow16"] = {k: rc_[k] for k in gkeep if k in rc_}
+            for key, wl in (("wnla_16_32_2pow16", "wnla"), ("circuit_mixed_k2_2pow16", "circuit")):
+                result[key]["note"] = (f"reduced copy of `python bench.py --workload {wl}` on 16-bit fixed-base tables (17 windows per scalar, built in a fraction of a "
+                                       "second, so that the default run stays short; config.fb_window_bits says so); the workload's own line runs on the layout the "
+                                       "library picks on a free device (11 windows) and is about a tenth faster (profiles/r06/r06_zz_cmd_*.txt)")
             ok_extra = ok_extra and okw and okc
         print(json.dumps(result), flush=True)
     if dist_on:
