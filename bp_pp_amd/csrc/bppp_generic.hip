@@ -86,6 +86,16 @@ static int wnla_round_group(const bppp_ctx* c, const WnlaWs& w, unsigned blocks)
     if (2 * (size_t)blocks <= (size_t)c->n_simds) return 2;
     return 1;
 }
+// the fixed-base sums of a generic verify call on a WAVEFRONT per instance instead of 8 lanes: calls of up to eight instances per SIMD, where
+// 8 lanes per instance are at most one wavefront per SIMD and the call waits for one lane's chain of (bases x windows) / 8 dependent
+// table additions -- one instance of configs[4]'s shape: k_wnla_msm 7.6 -> 0.86 ms, k_recip_c0_fixed 2.5 -> 0.32 ms; with phase 1 on lane groups the call
+// 16.7 -> 6.1 ms (round 6, profiles/r06/r06_p4_latency_recip256.txt).  By size, same shape on 16-bit tables: 2,048 instances 14.1 -> 8.4 ms,
+// 4,096 14.9 -> 11.2, 8,192 19.3 -> 18.6, 16,384 28.2 -> 28.7 (profiles/r06/r06_p5_fb_wide_sizes.txt): up to 8 S
+static bool generic_fb_wide(const bppp_ctx* c, size_t n) {
+    if (c->generic_fb_wide_max >= 0) return n <= (size_t)c->generic_fb_wide_max;
+    return !c->no_lane_groups && !c->no_split && n <= 8 * (size_t)c->n_simds;
+}
+static unsigned fb64_blocks_of(size_t n) { return (unsigned)((n * 64 + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK); }
 // the round points' window tables: a lane per instance, or a lane per (point, part) table in a call that leaves the chip empty
 static void launch_wnla_tables(const WnlaWs& w, size_t n, unsigned blocks, hipStream_t s) {
     if (w.tab_parts > 1) k_wnla_tables_split<<<(unsigned)(((size_t)32 * w.tab_parts * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, w.tab_parts);
@@ -205,7 +215,8 @@ static int wnla_run(bppp_ctx* c, bool commit, const uint8_t* label, size_t label
             }
         }
         WLAUNCH(K_WNLA_FINAL_SCALARS, launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s));
-        WLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
+        if (generic_fb_wide(c, n)) WLAUNCH(K_WNLA_MSM, k_wnla_msm_l64<<<fb64_blocks_of(n), BPPP_FB_BLOCK, 0, s>>>(w));
+        else WLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
         WLAUNCH(K_WNLA_ACCEPT, k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w));
 #undef WLAUNCH
         if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);
@@ -359,7 +370,21 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
         HIP_TRY(hipStreamWaitEvent(a, c->ev_tab, 0));
         GLAUNCH_ON(a, K_WNLA_TABLES, launch_wnla_tables(w, n, blocks, a));
     }
-    GLAUNCH(K_RECIP_PHASE1, k_recip_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    {
+        // lanes per instance for phase 1's two loops over the digits: as many (up to 8) as keep the launch within ONE wavefront per SIMD --
+        // the kernel is an uncapped build (one wavefront per SIMD fits), and a group's lanes each repeat the head (transcript, inversions:
+        // a seventh of the one-lane kernel).  Round 6, configs[4]'s shape, the kernel alone: 2^15 instances 3.48 -> 2.10 ms on 2 lanes
+        // (2.65 on 4, 3.8 on 8: two and four generations of wavefronts); the call 45.71 -> 45.30 ms, because the round-point tables
+        // that ran beside the half-empty one-lane kernel now share its SIMDs (profiles/r06/r06_p2_recip_phase1_groups.txt)
+        int G = 1;
+        if (c->recip_p1_group) G = c->recip_p1_group;
+        else if (!c->no_lane_groups) {
+            if (c->generic_lane_group) G = c->generic_lane_group == 2 ? 2 : 8;      // (tests: the smallest and the largest split at any size)
+            else while (G < 8 && 2 * (size_t)G * call_blocks <= (size_t)c->n_simds) G *= 2;
+        }
+        if (G > 1) GLAUNCH(K_RECIP_PHASE1, k_recip_phase1_grp<<<(unsigned)(((size_t)G * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(r, G));
+        else GLAUNCH(K_RECIP_PHASE1, k_recip_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r));
+    }
     if (part && part->started && part->stage == 1) HIP_TRY(hipEventRecord(part->started, s));
     if (beside) {
         HIP_TRY(hipEventRecord(c->ev_fork, s));
@@ -368,7 +393,9 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     // the two fixed-base sums: 8 lanes per instance, or one from the size at which one lane per instance fills the SIMDs twice over
     const bool fb_one_lane = c->fb_one_lane_mode >= 0 ? c->fb_one_lane_mode == 1 : n >= (size_t)128 * (size_t)c->n_simds;
     const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
+    const bool fb_wide = !fb_one_lane && !part && generic_fb_wide(c, n);
     if (fb_one_lane) GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
+    else if (fb_wide) GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed_l64<<<fb64_blocks_of(n), BPPP_FB_BLOCK, 0, s>>>(r));
     else GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
     if (r.atab) {
         const int grp_r = wnla_round_group(c, w, call_blocks), grp = grp_r > 4 ? 4 : grp_r;      // (C0's sum: lane groups of 2 or 4)
@@ -398,6 +425,7 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     GLAUNCH(K_WNLA_FINAL_SCALARS, launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s, call_blocks));
     if (!rlc_seed) {
         if (fb_one_lane) GLAUNCH(K_WNLA_MSM, k_wnla_msm_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(w));
+        else if (fb_wide) GLAUNCH(K_WNLA_MSM, k_wnla_msm_l64<<<fb64_blocks_of(n), BPPP_FB_BLOCK, 0, s>>>(w));
         else GLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
         GLAUNCH(K_WNLA_ACCEPT, k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     } else {
@@ -770,7 +798,8 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
         r.atab = w.atab; r.tscr = w.tscr; r.atab_first = (int)(2 * rounds * 16 * (size_t)w.tab_parts);
     }
     CLAUNCH(K_CIRCUIT_PHASE1, k_circuit_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r));
-    CLAUNCH(K_CIRCUIT_C0_FIXED, k_circuit_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
+    if (generic_fb_wide(c, n)) CLAUNCH(K_CIRCUIT_C0_FIXED, k_circuit_c0_fixed_l64<<<fb64_blocks_of(n), BPPP_FB_BLOCK, 0, s>>>(r));
+    else CLAUNCH(K_CIRCUIT_C0_FIXED, k_circuit_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
     CLAUNCH(K_CIRCUIT_C0_VAR, {
         if (r.atab) k_circuit_c0_tables<<<blocks, BPPP_BLOCK, 0, s>>>(r);
         k_circuit_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r);
@@ -786,7 +815,8 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
         }
     }
     CLAUNCH(K_WNLA_FINAL_SCALARS, launch_wnla_final_scalars(c, w, (unsigned)rounds, n, blocks, s));
-    CLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
+    if (generic_fb_wide(c, n)) CLAUNCH(K_WNLA_MSM, k_wnla_msm_l64<<<fb64_blocks_of(n), BPPP_FB_BLOCK, 0, s>>>(w));
+    else CLAUNCH(K_WNLA_MSM, k_wnla_msm<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(w, 0));
     CLAUNCH(K_WNLA_ACCEPT, k_wnla_accept<<<blocks, BPPP_BLOCK, 0, s>>>(w));
 #undef CLAUNCH
     if (w.tio.states_out) k_generic_export_states<<<blocks, BPPP_BLOCK, 0, s>>>(w);

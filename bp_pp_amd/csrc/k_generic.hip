@@ -80,6 +80,9 @@ __device__ __forceinline__ void wnla_msm_lanes(const WnlaWs& w) {
 }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(WnlaWs w, int commit_mode) { wnla_msm_lanes<BPPP_FB_LANES>(w); (void)commit_mode; }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm_l1(WnlaWs w) { wnla_msm_lanes<1>(w); }
+// a wavefront per instance: calls so small that 8 lanes per instance leave the chip empty and the call waits for one lane's chain of
+// (1 + |g_vec| + |h_vec|) x windows / 8 dependent table additions (bppp_generic.hip: generic_fb_wide)
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm_l64(WnlaWs w) { wnla_msm_lanes<64>(w); }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(WnlaWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) {
@@ -258,17 +261,20 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_phase1(CircuitWs w) {
     const u32 key = preloaded_position_key(w.tio.states, w.tio.n_states, t);
     for_each_position_group(key, [&]() { circuit_phase1(w, t); });
 }
-__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_circuit_c0_fixed(CircuitWs w) {
+template <int NL>
+__device__ __forceinline__ void circuit_c0_fixed_lanes(const CircuitWs& w) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
-    size_t t = g / BPPP_FB_LANES;
-    int lane = (int)(g % BPPP_FB_LANES);
+    size_t t = g / NL;
+    int lane = (int)(g % NL);
     if (t >= w.N) return;
     pt part;
     FbRanges rg;
     circuit_c0_fixed_ranges(rg, w);
-    fb_group_sum(part, w.fb, t, lane, w.sc0, rg);
+    fb_group_sum<NL>(part, w.fb, t, lane, w.sc0, rg);
     if (lane == 0) circuit_c0_fixed_store(w, t, part);
 }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_circuit_c0_fixed(CircuitWs w) { circuit_c0_fixed_lanes<BPPP_FB_LANES>(w); }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_circuit_c0_fixed_l64(CircuitWs w) { circuit_c0_fixed_lanes<64>(w); }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_tables(CircuitWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) circuit_c0_tables(w, t);
@@ -288,6 +294,15 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1(RecipWs w) {
     const u32 key = preloaded_position_key(w.tio.states, w.tio.n_states, t);
     for_each_position_group(key, [&]() { recip_phase1(w, t); });
 }
+// G = 2, 4 or 8 lanes per instance (recip_core.h: recip_phase1): calls whose one-lane kernels leave wavefront slots free
+__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1_grp(RecipWs w, int G) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g / (size_t)G;
+    if (t >= w.N) return;                     // whole groups leave together
+    const int q = (int)(g % (size_t)G);
+    const u32 key = preloaded_position_key(w.tio.states, w.tio.n_states, t);
+    for_each_position_group(key, [&]() { recip_phase1(w, t, q, G); });
+}
 template <int NL>
 __device__ __forceinline__ void recip_c0_fixed_lanes(const RecipWs& w) {
     size_t g = (size_t)blockIdx.x * BPPP_FB_BLOCK + threadIdx.x;
@@ -302,6 +317,7 @@ __device__ __forceinline__ void recip_c0_fixed_lanes(const RecipWs& w) {
 }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed(RecipWs w) { recip_c0_fixed_lanes<BPPP_FB_LANES>(w); }
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed_l1(RecipWs w) { recip_c0_fixed_lanes<1>(w); }
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed_l64(RecipWs w) { recip_c0_fixed_lanes<64>(w); }
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var(RecipWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) recip_c0_var(w, t);

@@ -191,6 +191,10 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_final_scalars_join(bppp::Wn
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm(bppp::WnlaWs w, int commit_mode);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm_l1(bppp::WnlaWs w);               // one lane per instance (full batches)
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed_l1(bppp::RecipWs w);
+// a wavefront per instance (small calls: bppp_generic.hip: generic_fb_wide)
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_msm_l64(bppp::WnlaWs w);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed_l64(bppp::RecipWs w);
+__global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_circuit_c0_fixed_l64(bppp::CircuitWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_commit_store(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_accept(bppp::WnlaWs w);
 __global__ __launch_bounds__(256) void k_count_rejects(const uint8_t* accept, size_t n, int* reject_count);
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_tables(bppp::CircuitW
 __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_var(bppp::CircuitWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_finish(bppp::CircuitWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1(bppp::RecipWs w);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_recip_phase1_grp(bppp::RecipWs w, int G);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_recip_c0_fixed(bppp::RecipWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_recip_c0_var(bppp::RecipWs w);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_recip_c0_tables(bppp::RecipWs w);

@@ -44,7 +44,24 @@ struct RecipWs {
     TranscriptIo tio;                // caller's transcripts (reciprocal.rs:98 `t: &mut Transcript`)
 };
 
-HD void recip_phase1(const RecipWs& w, size_t t) {
+// a^e for a public exponent (square and multiply; e = 0 gives 1)
+HD void sc_pow_u32(sc& r, const sc& a, u32 e) {
+    sc base = a;
+    sc_set_u32(r, 1);
+#pragma nounroll
+    while (e) {
+        if (e & 1u) sc_mul(r, r, base);
+        e >>= 1;
+        if (e) sc_mul(base, base, base);
+    }
+}
+// q, G: lane q of the G (2, 4 or 8) consecutive lanes that run phase 1 for instance t together -- calls whose one-lane kernels leave
+// wavefront slots free (k_recip_phase1_grp).  Decode, transcript, challenges and the np + 2 inversions are done by all lanes alike
+// (identical values, identical stores); the two loops over the dim_nd digits -- 11 dependent multiplications per digit, 97 % of the
+// kernel for configs[4]'s 256 -- are cut into G runs of consecutive digits: a lane starts its run from powers it raises itself
+// (sc_pow_u32), the three sums meet by shuffles, lane 0 stores what belongs to the instance.  Every lane of a group must be active.
+// G = 1: the one-lane form (also the host emulation's).
+HD void recip_phase1(const RecipWs& w, size_t t, int q = 0, int G = 1) {
     const size_t N = w.N;
     const int nd = w.nd, np = w.np;
     int32_t status = ST_OK;
@@ -129,23 +146,37 @@ HD void recip_phase1(const RecipWs& w, size_t t) {
     sc tau2, tau3;
     sc_mul(tau2, tau, tau);
     sc_mul(tau3, tau2, tau);
-    // S = sum_{i=1..nd} lambda^i, musum = sum_{i=1..nd} mu^i
-    sc S = lambda, lp = lambda, mp = mu, musum = mu;
+    // this lane's run of digits: [ja, jb)
+    const int seg = (nd + G - 1) / G, ja = q * seg < nd ? q * seg : nd, jb = ja + seg < nd ? ja + seg : nd;
+    // S = sum_{i=1..nd} lambda^i, musum = sum_{i=1..nd} mu^i  (the run's terms lambda^(ja+1) .. lambda^jb, then the sum over the group)
+    sc S, lp, mp, musum, mip, pw;
+    if (ja == 0) { lp = lambda; mp = mu; }
+    else { sc_pow_u32(lp, lambda, (u32)ja + 1); sc_pow_u32(mp, mu, (u32)ja + 1); }
+    S = lp;
+    musum = mp;
+    if (ja >= jb) { S = zero; musum = zero; }
 #pragma nounroll
-    for (int i = 1; i < nd; i++) { sc_mul(lp, lp, lambda); sc_add(S, S, lp); sc_mul(mp, mp, mu); sc_add(musum, musum, mp); }
-    sc tau_e, two_tau2_S, ps, base_np, pw;
+    for (int i = ja + 1; i < jb; i++) { sc_mul(lp, lp, lambda); sc_add(S, S, lp); sc_mul(mp, mp, mu); sc_add(musum, musum, mp); }
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    if (G > 1) { sc_group_sum16(S, G); sc_group_sum16(musum, G); }
+#endif
+    sc tau_e, two_tau2_S, ps, base_np;
     sc_mul(tau_e, tau, e);
     sc_mul(two_tau2_S, tau2, S);
     sc_add(two_tau2_S, two_tau2_S, two_tau2_S);
     sc_set_u32(ps, 0);
     sc_set_u32(base_np, (u32)np);
-    pw = one;            // np^j
-    sc mip = mu_inv;
-    lp = lambda;
-    mp = mu;
+    // np^j, mu^-(j+1), lambda^(j+1), mu^(j+1) at the run's first digit
+    if (ja == 0) { pw = one; mip = mu_inv; lp = lambda; mp = mu; }
+    else {
+        sc_pow_u32(pw, base_np, (u32)ja);
+        sc_pow_u32(mip, mu_inv, (u32)ja + 1);
+        sc_pow_u32(lp, lambda, (u32)ja + 1);
+        sc_pow_u32(mp, mu, (u32)ja + 1);
+    }
     uint8_t* cw = w.wn_c + (size_t)t * w.NH * 32;
 #pragma nounroll
-    for (int j = 0; j < nd; j++) {
+    for (int j = ja; j < jb; j++) {
         sc pn, cl;
         sc_mul(t1, tau2, pw);
         sc_sub(t2, S, lp);
@@ -165,6 +196,10 @@ HD void recip_phase1(const RecipWs& w, size_t t) {
         sc_mul(mp, mp, mu);
         sc_mul(pw, pw, base_np);
     }
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
+    if (G > 1) sc_group_sum16(ps, G);
+#endif
+    if (q != 0) return;          // (what follows belongs to the instance: lane 0 of the group)
     // (dim_np > dim_nd would leave c_lL entries beyond the lambda powers: dim_np <= dim_nd + 1 is required by the host)
     sc two_tau3;
     sc_add(two_tau3, tau3, tau3);
