@@ -5,6 +5,15 @@
 #pragma once
 #include "verify_ws.h"
 
+// The closures of the hot loops (produce / advance: the software pipeline's state lives in their captures) must be inlined whatever the
+// inliner's budget says: left as calls, their captures -- the recoded scalar, the window pointer, the pipeline registers -- move to
+// scratch memory and EVERY fixed-base kernel slows by 75 % (round 6: an experiment that gave fb_lane_accumulate_seq a second call site
+// was enough, the u64 verifier's sums included: profiles/r06/r06_q_fb_blocks_and_lambda_inlining.txt).
+#if defined(__clang__) || defined(__GNUC__)
+#define BPPP_LAMBDA_INLINE __attribute__((always_inline))
+#else
+#define BPPP_LAMBDA_INLINE
+#endif
 namespace bppp {
 
 // ---------------------------------------------------------------- fixed-base MSM over the batch-shared tables
@@ -278,7 +287,7 @@ HD void fb_lane_accumulate_seq(ptz& acc, bool& empty, const FbTable& fbt, const 
     u32 k[8], kp[9];
     ws_ld8(k, scal, fbt.N, t, first_slot + j);
     fb_recode(kp, k, g);
-    auto produce = [&](FbStep& st) {
+    auto produce = [&](FbStep& st) BPPP_LAMBDA_INLINE {
         if (pw == nw) {          // the scalar words of term jn were requested at the top of this step
             pa = pa + 1 < count ? pa + 1 : count - 1;
             j = jn;
@@ -332,14 +341,14 @@ HD void fb_lane_accumulate_fast(ptz& acc, bool& empty, const FbTable& fbt, const
     const int steps = (pairs - lane + nl - 1) / nl;
     const int da = nl / nw, dw = nl - da * nw;
     int a = lane / nw, w = lane - a * nw;
-    auto advance = [&]() {      // steps past the end re-use the last one (requested, never consumed)
+    auto advance = [&]() BPPP_LAMBDA_INLINE {      // steps past the end re-use the last one (requested, never consumed)
         int na = a + da, nwn = w + dw;
         if (nwn >= nw) { nwn -= nw; na++; }
         const bool in = na < count;
         a = in ? na : a;
         w = in ? nwn : w;
     };
-    auto produce = [&](FbStep& st, const u32 k[8]) {      // k: the scalar of term a
+    auto produce = [&](FbStep& st, const u32 k[8]) BPPP_LAMBDA_INLINE {      // k: the scalar of term a
         const int j = fb_term_index(a, oddsh);
         fb_step_from_field(st, fb_window(g, first_base + j, w), fb_field(k, w, g), fb_half_at(g, w));
     };
@@ -426,7 +435,7 @@ HD void fb_lane_sum_complete(pt& part, const FbTable& fbt, size_t t, int lane, c
     pt_set_identity(acc);
 #pragma nounroll
     for (int r = 0; r < rg.n; r++) {
-        fb_run_regions(fbt, g_lo, g_hi, rg.slot[r], rg.base[r], rg.count[r], rg.oddsh[r], [&](const FbGeom& g, int slot, int base, int count) {
+        fb_run_regions(fbt, g_lo, g_hi, rg.slot[r], rg.base[r], rg.count[r], rg.oddsh[r], [&](const FbGeom& g, int slot, int base, int count) BPPP_LAMBDA_INLINE {
             pt p;
             fixed_base_msm_partial(p, g, fbt.N, t, lane, scal, slot, base, count, nl, rg.bits[r], rg.oddsh[r]);
             pt_add(acc, acc, p);
@@ -454,11 +463,11 @@ HD bool fb_lane_sum_fast(pt& part, const FbTable& fbt, size_t t, int lane, const
 #pragma nounroll
         for (int r = 0; r < rg.n; r++)
             fb_run_regions(fbt, g_lo, g_hi, rg.slot[r], rg.base[r], rg.count[r], rg.oddsh[r],
-                           [&](const FbGeom& g, int, int, int count) { pace_total += count * fb_windows_for(rg.bits[r], g.code); });
+                           [&](const FbGeom& g, int, int, int count) BPPP_LAMBDA_INLINE { pace_total += count * fb_windows_for(rg.bits[r], g.code); });
     }
 #pragma nounroll
     for (int r = 0; r < rg.n; r++) {
-        fb_run_regions(fbt, g_lo, g_hi, rg.slot[r], rg.base[r], rg.count[r], rg.oddsh[r], [&](const FbGeom& g, int slot, int base, int count) {
+        fb_run_regions(fbt, g_lo, g_hi, rg.slot[r], rg.base[r], rg.count[r], rg.oddsh[r], [&](const FbGeom& g, int slot, int base, int count) BPPP_LAMBDA_INLINE {
             fb_lane_accumulate_fast(acc, empty, fbt, g, t, lane, scal, slot, base, count, nl, rg.bits[r], rg.oddsh[r], pace_done, pace_total);
             if (pace_total) pace_done += count * fb_windows_for(rg.bits[r], g.code);
         });
