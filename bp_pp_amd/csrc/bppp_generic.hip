@@ -800,10 +800,21 @@ static int circuit_verify_host_impl(bppp_ctx* c, const bppp_circuit* q, const ui
     CLAUNCH(K_CIRCUIT_PHASE1, k_circuit_phase1<<<blocks, BPPP_BLOCK, 0, s>>>(r));
     if (generic_fb_wide(c, n)) CLAUNCH(K_CIRCUIT_C0_FIXED, k_circuit_c0_fixed_l64<<<fb64_blocks_of(n), BPPP_FB_BLOCK, 0, s>>>(r));
     else CLAUNCH(K_CIRCUIT_C0_FIXED, k_circuit_c0_fixed<<<fb_blocks, BPPP_FB_BLOCK, 0, s>>>(r));
-    CLAUNCH(K_CIRCUIT_C0_VAR, {
-        if (r.atab) k_circuit_c0_tables<<<blocks, BPPP_BLOCK, 0, s>>>(r);
-        k_circuit_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r);
-    });
+    {
+        // C0's variable-base sum: a lane per point (L lanes per instance, tables and sum in one launch) while that stays within two
+        // wavefronts per SIMD, else the one-lane kernels (five points per shared-doubling pass).  Round 6, `mixed_k2` (6 points): one
+        // verify 4.74 -> 2.76 ms (this stage 3.0 -> 0.98), 8,192 instances 1.37 ms where 16,384 on the one-lane kernels take 2.64
+        int L = 8;
+        while (L < 4 + (int)k) L *= 2;
+        const bool per_point = r.atab && !c->no_lane_groups && !c->no_split && L <= 64 && (size_t)L * blocks <= 2 * (size_t)c->n_simds;
+        CLAUNCH(K_CIRCUIT_C0_VAR, {
+            if (per_point) k_circuit_c0_var_pts<<<(unsigned)(((size_t)L * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(r, L);
+            else {
+                if (r.atab) k_circuit_c0_tables<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+                k_circuit_c0_var<<<blocks, BPPP_BLOCK, 0, s>>>(r);
+            }
+        });
+    }
     CLAUNCH(K_CIRCUIT_C0_FINISH, k_circuit_c0_finish<<<blocks, BPPP_BLOCK, 0, s>>>(r));
     CLAUNCH(K_WNLA_BEGIN, k_wnla_begin<<<blocks, BPPP_BLOCK, 0, s>>>(w));
     if (w.atab) CLAUNCH(K_WNLA_TABLES, launch_wnla_tables(w, n, blocks, s));

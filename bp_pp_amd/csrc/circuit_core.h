@@ -437,6 +437,45 @@ HD void circuit_c0_var(const CircuitWs& w, size_t t) {
     }
     ws_st_pt(w.acc, N, t, total);
 }
+#if defined(__HIPCC__)
+// The same sum on L (a power of two >= 4 + k) lanes per instance, for calls that leave the chip empty: lane p builds the window table of
+// point p by itself (a Jacobian chain and ONE inversion: affine_table_one), runs the one-point sum 2 tau^3 coef_p v_p (or c_s, c_o, c_l,
+// c_r with their scalars) over it -- 130 doublings + 52 additions, where the one-lane kernel walks 130 doublings + 52 additions PER POINT
+// in chunks of five -- and the L partial sums meet by shuffles.  More work in all (every lane doubles for itself), a third of the chain:
+// one verify of `mixed_k2` spent 3.0 of its 4.7 ms in the one-lane kernel (round 6).  Every lane of a group must be active.
+__device__ __forceinline__ void circuit_c0_var_points(const CircuitWs& w, size_t t, int p, int L) {
+    const size_t N = w.N;
+    const int npts = 4 + w.cd.k;
+    pt acc;
+    pt_set_identity(acc);
+    if (p < npts) {
+        const atab_ref tab = atab_of(w.atab, N, t) + w.atab_first;
+        apt P;
+        ws_ld_apt(P, w.pts, N, t, p);
+        affine_table_one(tab + p * 16, P, 0);
+        int pslot[1] = {p};
+        glv_words<1> g;
+        sc kk;
+        ws_ld8(kk.v, w.sc0, N, t, 1 + w.cd.nm + p);
+        glv_split sp;
+        glv_decompose(sp, kk);
+        glv_words_set<1>(g, 0, sp);
+        straus_affine<1>(acc, tab, pslot, g);
+    }
+#pragma nounroll
+    for (int m = 1; m < L; m <<= 1) {
+        pt o;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            o.X.v[i] = __shfl_xor(acc.X.v[i], m, 64);
+            o.Y.v[i] = __shfl_xor(acc.Y.v[i], m, 64);
+            o.Z.v[i] = __shfl_xor(acc.Z.v[i], m, 64);
+        }
+        pt_add(acc, acc, o);
+    }
+    if (p == 0) ws_st_pt(w.acc, N, t, acc);
+}
+#endif
 HD void circuit_c0_finish(const CircuitWs& w, size_t t) {
     pt a, f;
     ws_ld_pt(a, w.acc, w.N, t);

@@ -283,6 +283,13 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_var(CircuitWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) circuit_c0_var(w, t);
 }
+// L lanes per instance, a lane per point (circuit_core.h: circuit_c0_var_points): tables and sum in one launch
+__global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_var_pts(CircuitWs w, int L) {
+    const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
+    const size_t t = g / (size_t)L;
+    if (t >= w.N) return;                     // whole groups leave together
+    circuit_c0_var_points(w, t, (int)(g % (size_t)L), L);
+}
 __global__ __launch_bounds__(BPPP_BLOCK) void k_circuit_c0_finish(CircuitWs w) {
     size_t t = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
     if (t < w.N) circuit_c0_finish(w, t);

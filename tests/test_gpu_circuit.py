@@ -55,6 +55,36 @@ def test_circuit_verify_vs_oracle(name, B):
         circ.close()
 
 
+@pytest.mark.parametrize("name,B", [("mixed_k2", 9), ("ac_works", 5)])
+def test_circuit_verify_one_lane_kernels_vs_oracle(name, B, monkeypatch):
+    """Small calls take the per-point form of C0's variable-base sum and the wavefront-per-instance fixed-base sums (bppp_generic.hip:
+    per_point, generic_fb_wide); BPPP_NO_LANE_GROUPS=1 keeps the kernels large batches run -- one lane per instance, five points per
+    shared-doubling pass, 8 lanes per fixed-base sum -- so that they are compared with the oracle at a size the oracle finishes too."""
+    import torch
+    if torch.cuda.device_count() == 0:
+        pytest.fail("needs a GPU")
+    import circuit_cases
+    from bp_pp_amd.wnla import ArithmeticCircuit
+    monkeypatch.setenv("BPPP_NO_LANE_GROUPS", "1")
+    case = circuit_cases.make(name, B)
+    part = lambda typ, j: (None if case["part"][typ][j] < 0 else int(case["part"][typ][j]))
+    arr = lambda b: np.frombuffer(b, np.uint8).reshape(-1, 32)
+    circ = ArithmeticCircuit(case["nm"], case["no"], case["k"], case["nv"], case["g"], case["gv"], case["hv"], arr(case["Wm_bytes"]),
+                             arr(case["Wl_bytes"]), arr(case["am_bytes"]), arr(case["al_bytes"]), case["f_l"], case["f_m"], case["gv_"],
+                             case["hv_"], part, device=0, fb_window_bits=16)
+    try:
+        shape = (case["rounds"], case["pl"], case["pn"])
+        P, com = case["proofs"].copy(), case["commitments"].copy()
+        P[0, -1] ^= 1
+        P[B - 1, 192:256] = P[B - 1, 0:64]
+        com[1, 0] = case["commitments"][2, 0]
+        exp = [circuit_cases.oracle_verify(case, com[b].tobytes(), P[b].tobytes()) for b in range(B)]
+        acc, st = circ.verify_batch(case["label"], com, P, *shape)
+        assert acc.tolist() == exp and not st.any() and sum(exp) == B - 3
+    finally:
+        circ.close()
+
+
 def test_circuit_create_rejects_inconsistent_dimensions():
     import ctypes as C
     import torch

@@ -5,8 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 import numpy as np
-import wnla_cases, recip_cases
-from bp_pp_amd.wnla import WeightNormLinearArgument, ReciprocalRangeProofProtocol
+import wnla_cases, recip_cases, circuit_cases
+from bp_pp_amd.wnla import WeightNormLinearArgument, ReciprocalRangeProofProtocol, ArithmeticCircuit
 
 def med(f, reps=9):
     f(); ts = []
@@ -36,3 +36,23 @@ for B in (1, 64):
     tv = med(lambda: r.verify_batch(case["label"], case["commitments"], case["proofs"], case["rounds"], case["nl"], case["nn"]))
     print(f"reciprocal (16, 16)  B {B:3d}  verify {tv:7.3f} ms")
     r.close()
+
+# one ArithmeticCircuit::verify (circuit.rs:154-256): the reference's own ac_works statement and the k = 2 statement of the bench line
+for name in ("ac_works", "mixed_k2"):
+    for B in (1, 64):
+        case = circuit_cases.make(name, B)
+        part = lambda typ, j: (None if case["part"][typ][j] < 0 else int(case["part"][typ][j]))
+        arr = lambda b: np.frombuffer(b, np.uint8).reshape(-1, 32)
+        circ = ArithmeticCircuit(case["nm"], case["no"], case["k"], case["nv"], case["g"], case["gv"], case["hv"], arr(case["Wm_bytes"]),
+                                 arr(case["Wl_bytes"]), arr(case["am_bytes"]), arr(case["al_bytes"]), case["f_l"], case["f_m"], case["gv_"],
+                                 case["hv_"], part, device=0, fb_window_bits=16)
+        shape = (case["rounds"], case["pl"], case["pn"])
+        tv = med(lambda: circ.verify_batch(case["label"], case["commitments"], case["proofs"], *shape))
+        print(f"circuit {name} rounds {case['rounds']}  B {B:3d}  verify {tv:7.3f} ms")
+        circ.enable_timing(True); circ.timings()
+        for _ in range(5):
+            circ.verify_batch(case["label"], case["commitments"], case["proofs"], *shape)
+        kt = circ.timings(); circ.enable_timing(False)
+        print("      verify kernels, ms per call:", {k.replace("k_", ""): round(v["total_ms"] / 5, 3) for k, v in kt.items() if v["launches"]},
+              "sum", round(sum(v["total_ms"] for v in kt.values()) / 5, 3))
+        circ.close()
