@@ -98,7 +98,11 @@ static bool generic_fb_wide(const bppp_ctx* c, size_t n) {
 static unsigned fb64_blocks_of(size_t n) { return (unsigned)((n * 64 + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK); }
 // the round points' window tables: a lane per instance, or a lane per (point, part) table in a call that leaves the chip empty
 static void launch_wnla_tables(const WnlaWs& w, size_t n, unsigned blocks, hipStream_t s) {
-    if (w.tab_parts > 1) k_wnla_tables_split<<<(unsigned)(((size_t)32 * w.tab_parts * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, w.tab_parts);
+    if (w.tab_parts > 1) {
+        int lp = 2;
+        while (lp < 2 * w.rounds) lp *= 2;
+        k_wnla_tables_split<<<(unsigned)(((size_t)lp * w.tab_parts * n + BPPP_BLOCK - 1) / BPPP_BLOCK), BPPP_BLOCK, 0, s>>>(w, w.tab_parts, lp);
+    }
     else k_wnla_tables<<<blocks, BPPP_BLOCK, 0, s>>>(w);
 }
 // lanes per instance for the final scalars (k_wnla_final_scalars_grp), as log2: up to 8 while the launch stays within four wavefronts

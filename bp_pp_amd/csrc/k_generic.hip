@@ -27,10 +27,12 @@ __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_wnla_tabl
     if (t < w.N) wnla_verify_tables(w, t);
 }
 // calls that leave the chip empty: a lane per (point, part) table (32 x parts lanes per instance, 2 x rounds x parts of them active)
-__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_tables_split(WnlaWs w, int parts) {
+// (lp = lanes per (instance, part): the power of two >= 2 x rounds -- round 6: 32 whatever the rounds left 4 lanes in 32 working for a
+// 2-round argument, and the launch of 8 x the wavefronts took 1.9 ms at 512 instances where the 4-round argument's took 0.55)
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_tables_split(WnlaWs w, int parts, int lp) {
     const size_t g = (size_t)blockIdx.x * BPPP_BLOCK + threadIdx.x;
-    const size_t t = g / (size_t)(32 * parts);
-    const int p = (int)(g & 31), h = (int)((g >> 5) % (size_t)parts);
+    const size_t t = g / ((size_t)lp * (size_t)parts);
+    const int p = (int)(g % (size_t)lp), h = (int)((g / (size_t)lp) % (size_t)parts);
     if (t < w.N && p < 2 * w.rounds) wnla_verify_table_one(w, t, p, h, parts);
 }
 // the round on lane groups (group = 2 or 4 lanes per instance; 8 / 16 over tables in 2 / 4 parts), for batches that under-fill the chip; needs the fast path's tables

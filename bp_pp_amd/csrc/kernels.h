@@ -177,7 +177,7 @@ __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_begin(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round(bppp::WnlaWs w, int k);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_generic_export_states(bppp::WnlaWs w);
 __global__ __launch_bounds__(BPPP_BLOCK, BPPP_TABLES_MIN_WAVES) void k_wnla_tables(bppp::WnlaWs w);
-__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_tables_split(bppp::WnlaWs w, int parts);
+__global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_tables_split(bppp::WnlaWs w, int parts, int lp);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_round_grp(bppp::WnlaWs w, int k, int group);
 __global__ __launch_bounds__(BPPP_BLOCK) void k_wnla_rlc_lhs(bppp::WnlaWs w, bppp::RlcWs r);
 __global__ __launch_bounds__(BPPP_FB_BLOCK, BPPP_FB_MIN_WAVES) void k_wnla_rlc_chunk(bppp::WnlaWs w, bppp::RlcWs r);

@@ -1,12 +1,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-O=gpurun_out/r06_l3; mkdir -p $O
-for wl in circuit wnla; do for n in 512 1024 2048 4096 16384; do for NS in 0 1; do
-  if [ $NS = 1 ]; then export BPPP_NO_SPLIT=1; else unset BPPP_NO_SPLIT; fi
-  timeout 300 python bench.py --workload $wl --total-proofs $n --no-cpu-baseline --steps 10 --fb-window-bits 16 > $O/c.json 2>> $O/err.txt; python - <<P >> $O/sizes.txt
-import json
-d=json.loads(open("$O/c.json").read().strip().splitlines()[-1]); k=d["kernels_ms_per_step"]
-print("$wl n=$n no_split=$NS", round(d["value"]), round(d["ms_per_step"],3), d.get("accept_bits_ok"), {a.replace("k_",""):round(b,3) for a,b in k.items() if b>0.05})
-P
-done; done; done
-unset BPPP_NO_SPLIT
-cat $O/sizes.txt
+O=gpurun_out/r06_t3; mkdir -p $O
+for n in 512 64 4096; do timeout 600 python tools/probes/wnla_shape_probe.py $n >> $O/shapes.txt 2>> $O/err.txt; done; echo "rc=$?" >> $O/log.txt
+timeout 600 python tools/probes/latency_generic.py > $O/latency_generic.txt 2>> $O/err.txt
+timeout 900 python tools/probes/recip_small_latency.py > $O/latency_recip256.txt 2>> $O/err.txt
+timeout 1500 python -m pytest tests/test_gpu_wnla.py tests/test_gpu_circuit.py tests/test_gpu_recip.py tests/test_gpu_ct_generic.py tests/test_gpu_ref_fixtures.py -x -q -m gpu > $O/pytest.txt 2>&1; echo "pytest rc=$?" >> $O/log.txt
+cat $O/log.txt $O/shapes.txt; grep -v "kernels" $O/latency_generic.txt; grep -v kernels $O/latency_recip256.txt; tail -2 $O/pytest.txt
