@@ -1,7 +1,8 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-O=gpurun_out/r06_t3; mkdir -p $O
-for n in 512 64 4096; do timeout 600 python tools/probes/wnla_shape_probe.py $n >> $O/shapes.txt 2>> $O/err.txt; done; echo "rc=$?" >> $O/log.txt
-timeout 600 python tools/probes/latency_generic.py > $O/latency_generic.txt 2>> $O/err.txt
-timeout 900 python tools/probes/recip_small_latency.py > $O/latency_recip256.txt 2>> $O/err.txt
-timeout 1500 python -m pytest tests/test_gpu_wnla.py tests/test_gpu_circuit.py tests/test_gpu_recip.py tests/test_gpu_ct_generic.py tests/test_gpu_ref_fixtures.py -x -q -m gpu > $O/pytest.txt 2>&1; echo "pytest rc=$?" >> $O/log.txt
-cat $O/log.txt $O/shapes.txt; grep -v "kernels" $O/latency_generic.txt; grep -v kernels $O/latency_recip256.txt; tail -2 $O/pytest.txt
+O=gpurun_out/r06_v11; mkdir -p $O
+(rocm-smi --showuniqueid 2>&1 | grep -E "GPU\[0\]" | head -2) > $O/box_id.txt
+F="--no-cpu-baseline --no-secondary --no-session-rates"
+for rep in 1 2; do for lib in libbppp_hip_prev.so libbppp_hip.so; do
+  BPPP_LIB=$PWD/bp_pp_amd/$lib python bench.py --steps 6 --warmup 1 $F 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernels_ms_per_step']; print('$lib 2^20', round(d['value']), round(d['ms_per_step'],2), d['accept_bits_ok'], {a.replace('k_verify_',''):round(b,2) for a,b in k.items()})" >> $O/ab.txt
+done; done
+cat $O/box_id.txt $O/ab.txt
