@@ -1,8 +1,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-O=gpurun_out/r06_v11; mkdir -p $O
-(rocm-smi --showuniqueid 2>&1 | grep -E "GPU\[0\]" | head -2) > $O/box_id.txt
-F="--no-cpu-baseline --no-secondary --no-session-rates"
-for rep in 1 2; do for lib in libbppp_hip_prev.so libbppp_hip.so; do
-  BPPP_LIB=$PWD/bp_pp_amd/$lib python bench.py --steps 6 --warmup 1 $F 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['kernels_ms_per_step']; print('$lib 2^20', round(d['value']), round(d['ms_per_step'],2), d['accept_bits_ok'], {a.replace('k_verify_',''):round(b,2) for a,b in k.items()})" >> $O/ab.txt
-done; done
-cat $O/box_id.txt $O/ab.txt
+O=gpurun_out/r06_s2; mkdir -p $O
+timeout 900 python tests/soak_generic.py > $O/soak_generic.txt 2>&1; echo "soak_generic rc=$?" >> $O/log.txt
+timeout 600 python tests/stress_mixed.py > $O/stress_mixed.txt 2>&1; echo "stress rc=$?" >> $O/log.txt
+timeout 600 python tests/soak_coalesce.py > $O/soak_coalesce.txt 2>&1; echo "soak_coalesce rc=$?" >> $O/log.txt
+for S in "6 17" "3 20" "20 12"; do set -- $S; timeout 900 python tests/soak.py $1 $2 > $O/soak_2pow$2.txt 2>&1; echo "soak$2 rc=$?" >> $O/log.txt; done
+cat $O/log.txt; for f in soak_generic stress_mixed soak_coalesce soak_2pow17 soak_2pow20 soak_2pow12; do tail -n 1 $O/$f.txt | cut -c1-220; done
