@@ -26,6 +26,7 @@ static void read_diagnostics(bppp_ctx* c) {
     if (const char* e = std::getenv("BPPP_TABLES_BESIDE")) c->tables_beside = std::atoi(e);
     if (const char* e = std::getenv("BPPP_SHARED_INV")) c->shared_inv = std::atoi(e);
     if (const char* e = std::getenv("BPPP_GENERIC_PARTS")) c->generic_parts = std::atoi(e);
+    if (const char* e = std::getenv("BPPP_RECIP_BESIDE")) c->recip_beside = std::atoi(e) != 0;
     if (const char* e = std::getenv("BPPP_GENERIC_FB_WIDE_MAX")) c->generic_fb_wide_max = std::atol(e);
     if (const char* e = std::getenv("BPPP_RECIP_P1_GROUP")) { const int g = std::atoi(e); c->recip_p1_group = (g == 1 || g == 2 || g == 4 || g == 8) ? g : 0; }
     if (const char* e = std::getenv("BPPP_TWIN")) c->twin = std::atoi(e);

@@ -360,9 +360,14 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
     // What needs nothing but the proof bytes -- the round points' window tables -- and what needs only phase 1 -- the C0 points' tables
     // and C0's variable-base sum, one lane (or a lane group) per instance -- runs on the HELPER stream beside phase 1 and the fixed-base
     // half of C0 (8 lanes per instance: the kernel that fills the chip); round 6: 2^15 instances of configs[4]'s shape, where the
-    // one-lane kernels are half a wavefront per SIMD, 46.6 -> ms per batch.  With kernel timing on everything stays on one stream so
+    // one-lane kernels are half a wavefront per SIMD, 46.6 -> 45.0 ms per batch.  With kernel timing on everything stays on one stream so
     // that the per-kernel times add up; the parts of a multi-part call are chains of their own.
-    const bool beside = w.atab && !c->timing && !part;
+    // the two fixed-base sums: 8 lanes per instance, or one from the size at which one lane per instance fills the SIMDs twice over
+    const bool fb_one_lane = c->fb_one_lane_mode >= 0 ? c->fb_one_lane_mode == 1 : n >= (size_t)128 * (size_t)c->n_simds;
+    // (only while the one-lane kernels are at most half a wavefront per SIMD: beyond that the kernels fill the chip by themselves and side
+    // by side they take LONGER than one after the other, as in the u64 verifier -- 2^16 instances 79.6 ms on two streams against 79.2 on
+    // one, 2^17 154.2 / 153.0, 2^18 314.3 / 301.4: profiles/r06/r06_b1_recip_beside_sizes.txt)
+    const bool beside = w.atab && !c->timing && !part && (c->recip_beside >= 0 ? c->recip_beside == 1 : 2 * (size_t)call_blocks <= (size_t)c->n_simds);
     hipStream_t a = beside ? c->aux_stream : s;
 #define GLAUNCH_ON(st, id, ...)                                 \
     do {                                                        \
@@ -394,8 +399,6 @@ static int recip_verify_device_impl(bppp_ctx* c, const uint8_t* label, size_t la
         HIP_TRY(hipEventRecord(c->ev_fork, s));
         HIP_TRY(hipStreamWaitEvent(a, c->ev_fork, 0));
     }
-    // the two fixed-base sums: 8 lanes per instance, or one from the size at which one lane per instance fills the SIMDs twice over
-    const bool fb_one_lane = c->fb_one_lane_mode >= 0 ? c->fb_one_lane_mode == 1 : n >= (size_t)128 * (size_t)c->n_simds;
     const unsigned fb1_blocks = (unsigned)((n + BPPP_FB_BLOCK - 1) / BPPP_FB_BLOCK);
     const bool fb_wide = !fb_one_lane && !part && generic_fb_wide(c, n);
     if (fb_one_lane) GLAUNCH(K_RECIP_C0_FIXED, k_recip_c0_fixed_l1<<<fb1_blocks, BPPP_FB_BLOCK, 0, s>>>(r));

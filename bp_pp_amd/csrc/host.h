@@ -139,6 +139,7 @@ struct bppp_ctx {
     bool borrows_tables = false;   // d_gens / d_table belong to another context (bppp_ctx_create_shared)
     bool timing = false;
     bool generic_slow_rounds = false, no_lane_groups = false, no_small = false, no_split = false, generic_u64_shape = false;
+    int recip_beside = -1;                              // diagnostic BPPP_RECIP_BESIDE = 0 | 1: the reciprocal verifier's one-lane kernels beside its fixed-base ones never / always; unset = by size
     long generic_fb_wide_max = -1;                      // diagnostic BPPP_GENERIC_FB_WIDE_MAX: the largest call (instances) whose fixed-base sums run a wavefront per instance; -1 = 8 per SIMD
     int recip_p1_group = 0;                             // diagnostic BPPP_RECIP_P1_GROUP = 1 | 2 | 4 | 8: lanes per instance in the reciprocal verifier's phase 1; 0 = by size
     int generic_lane_group = 0;                         // BPPP_GENERIC_LANE_GROUP = 2 | 4: that many lanes per instance in the generic verifiers' grouped kernels at any size (tests)
